@@ -1,0 +1,65 @@
+/* ggml-mi355x.h -- public C ABI of libggml-mi355x.so, the MI355X (gfx950 / CDNA4) ggml backend.
+ *
+ * The library is a drop-in ggml backend plug-in.  The reference binds it exactly like any other
+ * dynamically loaded backend:
+ *
+ *   loader   : ggml_backend_load(path) / $GGML_BACKEND_PATH        (reference ggml/src/ggml-backend-reg.cpp:603-607)
+ *   symbols  : ggml_backend_init  (required)                       (ggml-backend-reg.cpp:265-285, typedef ggml-backend-impl.h:214)
+ *              ggml_backend_score (optional, 0 = unsupported here) (ggml-backend-reg.cpp:257-263, typedef ggml-backend-impl.h:217)
+ *   objects  : ggml_backend_reg / _device / _buffer_type / _buffer / ggml_backend and their *_i vtables,
+ *              GGML_BACKEND_API_VERSION 2                          (ggml/src/ggml-backend-impl.h:11-210)
+ *
+ * Everything crossing the boundary is a plain C struct of function pointers, plain pointers and sizes.
+ * No C++ or torch types appear in any signature.  The struct layouts are declared (restated, not copied) in
+ * llama.cpp-omni_amd/csrc/ggml_abi.h and verified against the reference headers by tests/test_abi.py.
+ */
+#ifndef GGML_MI355X_H
+#define GGML_MI355X_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GGML_MI355X_API __attribute__((visibility("default")))
+#define GGML_MI355X_NAME "MI355X"          /* registry name; devices are "MI355X0", "MI355X1", ... */
+
+struct ggml_backend_reg;
+struct ggml_backend_buffer;
+struct ggml_backend;
+
+/* replaces: the `ggml_backend_init` entry a backend module exports (GGML_BACKEND_DL_IMPL,
+ * reference ggml/src/ggml-backend-impl.h:220-233).  Returns the statically owned registry object
+ * (api_version == 2); never freed. */
+GGML_MI355X_API struct ggml_backend_reg * ggml_backend_init(void);
+
+/* replaces: `ggml_backend_score` (GGML_BACKEND_DL_SCORE_IMPL, ggml-backend-impl.h:234-251).
+ * 100 when at least one gfx950 device is visible to the HIP runtime, 0 otherwise. */
+GGML_MI355X_API int ggml_backend_score(void);
+
+/* same object as ggml_backend_init(), for hosts that link the library directly
+ * (mirrors ggml_backend_cuda_reg(), reference ggml/include/ggml-cuda.h:40). */
+GGML_MI355X_API struct ggml_backend_reg * ggml_backend_mi355x_reg(void);
+
+/* ---- extensions, also reachable through reg->iface.get_proc_address(reg, "<name>") -------------------- */
+
+/* timing events on a backend's stream (hipEvent with timing enabled; ggml's own events carry no clock). */
+GGML_MI355X_API void * mi355x_timed_event_new(void);
+GGML_MI355X_API void   mi355x_timed_event_record(void * ev, struct ggml_backend * backend);
+GGML_MI355X_API float  mi355x_timed_event_elapsed_ms(void * start, void * stop);      /* synchronises on `stop` */
+GGML_MI355X_API void   mi355x_timed_event_free(void * ev);
+
+/* runtime options: "graphs" (0/1 hipGraph replay of repeated cgraphs), "fusion" (0/1 node fusion),
+ * "profile" (0/1 per-kernel-class event timing, disables graphs).  Returns 0 on success. */
+GGML_MI355X_API int    mi355x_set_option(struct ggml_backend * backend, const char * key, long value);
+/* counters: "graph_replays", "graph_captures", "eager_graphs", "kernels_last_graph",
+ * "prof_mmv_q4k_us", "prof_mmv_q4k_n", "prof_mmv_q4k_bytes", .... Returns -1 if unknown. */
+GGML_MI355X_API double mi355x_get_stat(struct ggml_backend * backend, const char * key);
+
+/* standalone harness only (no libggml-base in the process): what ggml_backend_buffer_free does
+ * (reference ggml/src/ggml-backend.cpp:108-117): iface.free_buffer, then delete the object. */
+GGML_MI355X_API void   mi355x_host_buffer_free(struct ggml_backend_buffer * buffer);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GGML_MI355X_H */

@@ -1,0 +1,357 @@
+// backend.cpp -- the ggml plug-in boundary of the MI355X backend.
+//
+// Implements the five vtable structs of the reference's backend ABI (ggml/src/ggml-backend-impl.h:17-210)
+// and exports `ggml_backend_init` / `ggml_backend_score`, the two symbols the reference's loader binds
+// (ggml/src/ggml-backend-reg.cpp:257-285).  Semantics (ownership, error conventions, async behaviour) follow
+// what the scheduler and allocator expect from a GPU backend; the behavioural template is the reference's
+// own GPU backend host code (ggml-cuda.cu:552-757 buffers, :2541-2633 stream ops, :3271-3760 device/reg) --
+// none of its code is reused: one process drives one or more gfx950 devices through the HIP runtime directly.
+#include "common.hpp"
+#include "ggml_util.hpp"
+#include "kernels.hpp"
+#include "graph.hpp"
+
+#include <mutex>
+#include <string>
+#include <vector>
+#include <stdarg.h>
+
+#include "../../include/ggml-mi355x.h"
+
+// ---------------------------------------------------------------------------------------------- host imports
+// Resolved against the host process' libggml-base when the backend is loaded by the reference; absent
+// (NULL) in the standalone harness, where the fallbacks below are used.
+extern "C" {
+__attribute__((weak)) ggml_backend_buffer_t ggml_backend_buffer_init(ggml_backend_buffer_type_t buft, struct ggml_backend_buffer_i iface, void * context, size_t size);
+__attribute__((weak)) void ggml_log_internal(enum ggml_log_level level, const char * format, ...);
+}
+
+namespace mi {
+
+void log_msg(int level, const char * fmt, ...) {
+    char buf[1024];
+    va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof(buf), fmt, ap); va_end(ap);
+    if (ggml_log_internal) ggml_log_internal((enum ggml_log_level) level, "%s", buf);
+    else if (level >= GGML_LOG_LEVEL_WARN || getenv("MI355X_VERBOSE")) fputs(buf, stderr);
+}
+
+static ggml_backend_buffer_t make_buffer(ggml_backend_buffer_type_t buft, struct ggml_backend_buffer_i iface, void * ctx, size_t size) {
+    if (ggml_backend_buffer_init) return ggml_backend_buffer_init(buft, iface, ctx, size);
+    // standalone: same object the core would `new` (ggml-backend.cpp:85-99); freed by mi355x_host_buffer_free
+    return new ggml_backend_buffer{iface, buft, ctx, size, GGML_BACKEND_BUFFER_USAGE_ANY};
+}
+
+// ---------------------------------------------------------------------------------------------- device table
+struct device_ctx {
+    int         index;
+    std::string name;          // "MI355X<i>"
+    std::string description;   // marketing name from the runtime
+    std::string pci_id;        // dddd:bb:dd.f
+    size_t      total_mem;
+    ggml_backend_buffer_type  buft;
+    ggml_backend_device       dev;
+};
+
+static std::vector<device_ctx *> g_devices;
+static ggml_backend_reg          g_reg;
+static ggml_backend_buffer_type  g_host_buft;
+static std::mutex                g_mutex;
+static bool                      g_init_done = false;
+
+static void set_device(int d) { HIP_CHECK(hipSetDevice(d)); }
+
+// ---------------------------------------------------------------------------------------------- device buffers
+struct buffer_ctx { int device; void * base; size_t size; };
+
+static void buf_free(ggml_backend_buffer_t b) {
+    buffer_ctx * c = (buffer_ctx *) b->context;
+    set_device(c->device);
+    HIP_CHECK(hipFree(c->base));
+    delete c;
+}
+static void * buf_get_base(ggml_backend_buffer_t b) { return ((buffer_ctx *) b->context)->base; }
+
+static enum ggml_status buf_init_tensor(ggml_backend_buffer_t, struct ggml_tensor *) {
+    // no per-tensor extras: kernels never read past the logical end of a row, so no row padding is needed
+    // (the reference's GPU backend pads quantised rows to 512 elements instead, ggml-cuda.cu:604-622)
+    return GGML_STATUS_SUCCESS;
+}
+static void buf_memset_tensor(ggml_backend_buffer_t b, struct ggml_tensor * t, uint8_t v, size_t off, size_t sz) {
+    buffer_ctx * c = (buffer_ctx *) b->context; set_device(c->device);
+    HIP_CHECK(hipMemsetAsync((char *) t->data + off, v, sz, hipStreamPerThread));
+    HIP_CHECK(hipStreamSynchronize(hipStreamPerThread));
+}
+static void buf_set_tensor(ggml_backend_buffer_t b, struct ggml_tensor * t, const void * data, size_t off, size_t sz) {
+    buffer_ctx * c = (buffer_ctx *) b->context; set_device(c->device);
+    HIP_CHECK(hipMemcpyAsync((char *) t->data + off, data, sz, hipMemcpyHostToDevice, hipStreamPerThread));
+    HIP_CHECK(hipStreamSynchronize(hipStreamPerThread));
+}
+static void buf_get_tensor(ggml_backend_buffer_t b, const struct ggml_tensor * t, void * data, size_t off, size_t sz) {
+    buffer_ctx * c = (buffer_ctx *) b->context; set_device(c->device);
+    HIP_CHECK(hipMemcpyAsync(data, (const char *) t->data + off, sz, hipMemcpyDeviceToHost, hipStreamPerThread));
+    HIP_CHECK(hipStreamSynchronize(hipStreamPerThread));
+}
+static bool buffer_is_ours(ggml_backend_buffer_t b);
+static bool buf_cpy_tensor(ggml_backend_buffer_t b, const struct ggml_tensor * src, struct ggml_tensor * dst) {
+    ggml_backend_buffer_t sb = src->view_src ? src->view_src->buffer : src->buffer;
+    if (!sb || !buffer_is_ours(sb)) return false;                    // "not handled": the core falls back to get+set
+    buffer_ctx * sc = (buffer_ctx *) sb->context; buffer_ctx * dc = (buffer_ctx *) b->context;
+    set_device(dc->device);
+    const size_t n = nbytes(src);
+    if (sc->device == dc->device) HIP_CHECK(hipMemcpyAsync(dst->data, src->data, n, hipMemcpyDeviceToDevice, hipStreamPerThread));
+    else                          HIP_CHECK(hipMemcpyPeerAsync(dst->data, dc->device, src->data, sc->device, n, hipStreamPerThread));
+    HIP_CHECK(hipStreamSynchronize(hipStreamPerThread));
+    return true;
+}
+static void buf_clear(ggml_backend_buffer_t b, uint8_t v) {
+    buffer_ctx * c = (buffer_ctx *) b->context; set_device(c->device);
+    HIP_CHECK(hipMemsetAsync(c->base, v, c->size, hipStreamPerThread));
+    HIP_CHECK(hipStreamSynchronize(hipStreamPerThread));
+}
+static const ggml_backend_buffer_i k_buffer_iface = {
+    buf_free, buf_get_base, buf_init_tensor, buf_memset_tensor, buf_set_tensor, buf_get_tensor, buf_cpy_tensor, buf_clear, /*reset*/ nullptr,
+};
+static bool buffer_is_ours(ggml_backend_buffer_t b) { return b->iface.free_buffer == buf_free; }
+
+// ---------------------------------------------------------------------------------------------- buffer type (device)
+static const char * buft_name(ggml_backend_buffer_type_t t) { return ((device_ctx *) t->context)->name.c_str(); }
+static ggml_backend_buffer_t buft_alloc(ggml_backend_buffer_type_t t, size_t size) {
+    device_ctx * d = (device_ctx *) t->context;
+    set_device(d->index);
+    void * p = nullptr;
+    const size_t asz = size < 1 ? 1 : size;
+    hipError_t e = hipMalloc(&p, asz);
+    if (e != hipSuccess) {                                            // OOM is reported, not fatal (caller handles NULL)
+        (void) hipGetLastError();
+        log_msg(GGML_LOG_LEVEL_ERROR, "[mi355x] allocating %.2f MiB on device %d failed: %s\n", size / 1048576.0, d->index, hipGetErrorString(e));
+        return nullptr;
+    }
+    return make_buffer(t, k_buffer_iface, new buffer_ctx{d->index, p, size}, size);
+}
+static size_t buft_alignment(ggml_backend_buffer_type_t) { return 128; }   // one HBM/L2 line; 16-B vector loads need 16
+static bool   buft_is_host(ggml_backend_buffer_type_t) { return false; }
+static const ggml_backend_buffer_type_i k_buft_iface = { buft_name, buft_alloc, buft_alignment, /*max_size*/ nullptr, /*alloc_size*/ nullptr, buft_is_host };
+
+// ---------------------------------------------------------------------------------------------- pinned host buffers
+static void hostbuf_free(ggml_backend_buffer_t b) { HIP_CHECK(hipHostFree(b->context)); }
+static void * hostbuf_base(ggml_backend_buffer_t b) { return b->context; }
+static void hostbuf_memset(ggml_backend_buffer_t, struct ggml_tensor * t, uint8_t v, size_t off, size_t sz) { memset((char *) t->data + off, v, sz); }
+static void hostbuf_set(ggml_backend_buffer_t, struct ggml_tensor * t, const void * d, size_t off, size_t sz) { memcpy((char *) t->data + off, d, sz); }
+static void hostbuf_get(ggml_backend_buffer_t, const struct ggml_tensor * t, void * d, size_t off, size_t sz) { memcpy(d, (const char *) t->data + off, sz); }
+static void hostbuf_clear(ggml_backend_buffer_t b, uint8_t v) { memset(b->context, v, b->size); }
+static const ggml_backend_buffer_i k_hostbuf_iface = { hostbuf_free, hostbuf_base, nullptr, hostbuf_memset, hostbuf_set, hostbuf_get, nullptr, hostbuf_clear, nullptr };
+static const char * hostbuft_name(ggml_backend_buffer_type_t) { return "MI355X_Host"; }
+static ggml_backend_buffer_t hostbuft_alloc(ggml_backend_buffer_type_t t, size_t size) {
+    void * p = nullptr;
+    hipError_t e = hipHostMalloc(&p, size < 1 ? 1 : size, hipHostMallocDefault);
+    if (e != hipSuccess) { (void) hipGetLastError(); return nullptr; }   // core falls back to plain CPU memory
+    return make_buffer(t, k_hostbuf_iface, p, size);
+}
+static size_t hostbuft_alignment(ggml_backend_buffer_type_t) { return 64; }
+static bool   hostbuft_is_host(ggml_backend_buffer_type_t) { return true; }
+static const ggml_backend_buffer_type_i k_hostbuft_iface = { hostbuft_name, hostbuft_alloc, hostbuft_alignment, nullptr, nullptr, hostbuft_is_host };
+
+// ---------------------------------------------------------------------------------------------- backend (stream)
+static ggml_guid g_guid = { 0x4d, 0x49, 0x33, 0x35, 0x35, 0x58, 0x2d, 0x67, 0x66, 0x78, 0x39, 0x35, 0x30, 0x2d, 0x76, 0x31 };
+
+static const char * be_name(ggml_backend_t b) { return ((backend_ctx *) b->context)->name.c_str(); }
+static void be_free(ggml_backend_t b) {
+    backend_ctx * c = (backend_ctx *) b->context;
+    set_device(c->device);
+    HIP_CHECK(hipStreamSynchronize(c->stream));
+    backend_ctx_release(c);
+    delete c;
+    delete b;
+}
+static bool backend_is_ours(ggml_backend_t b);
+static void be_set_async(ggml_backend_t b, struct ggml_tensor * t, const void * data, size_t off, size_t sz) {
+    backend_ctx * c = (backend_ctx *) b->context; set_device(c->device);
+    HIP_CHECK(hipMemcpyAsync((char *) t->data + off, data, sz, hipMemcpyHostToDevice, c->stream));
+}
+static void be_get_async(ggml_backend_t b, const struct ggml_tensor * t, void * data, size_t off, size_t sz) {
+    backend_ctx * c = (backend_ctx *) b->context; set_device(c->device);
+    HIP_CHECK(hipMemcpyAsync(data, (const char *) t->data + off, sz, hipMemcpyDeviceToHost, c->stream));
+}
+static bool be_cpy_async(ggml_backend_t bs, ggml_backend_t bd, const struct ggml_tensor * src, struct ggml_tensor * dst) {
+    if (!backend_is_ours(bs) || !backend_is_ours(bd)) return false;
+    ggml_backend_buffer_t sb = src->view_src ? src->view_src->buffer : src->buffer;
+    ggml_backend_buffer_t db = dst->view_src ? dst->view_src->buffer : dst->buffer;
+    if (!sb || !db || !buffer_is_ours(sb) || !buffer_is_ours(db)) return false;
+    backend_ctx * cs = (backend_ctx *) bs->context; backend_ctx * cd = (backend_ctx *) bd->context;
+    if (((buffer_ctx *) sb->context)->device != cs->device || ((buffer_ctx *) db->context)->device != cd->device) return false;
+    const size_t n = nbytes(dst);
+    set_device(cs->device);
+    if (bs == bd) {
+        HIP_CHECK(hipMemcpyAsync(dst->data, src->data, n, hipMemcpyDeviceToDevice, cs->stream));
+        return true;
+    }
+    // copy on the source stream (over xGMI when the devices differ), then make the destination stream wait for it
+    if (cs->device == cd->device) HIP_CHECK(hipMemcpyAsync(dst->data, src->data, n, hipMemcpyDeviceToDevice, cs->stream));
+    else                          HIP_CHECK(hipMemcpyPeerAsync(dst->data, cd->device, src->data, cs->device, n, cs->stream));
+    if (!cs->copy_event) HIP_CHECK(hipEventCreateWithFlags(&cs->copy_event, hipEventDisableTiming));
+    HIP_CHECK(hipEventRecord(cs->copy_event, cs->stream));
+    set_device(cd->device);
+    HIP_CHECK(hipStreamWaitEvent(cd->stream, cs->copy_event, 0));
+    return true;
+}
+static void be_sync(ggml_backend_t b) {
+    backend_ctx * c = (backend_ctx *) b->context; set_device(c->device);
+    HIP_CHECK(hipStreamSynchronize(c->stream));
+}
+static enum ggml_status be_graph_compute(ggml_backend_t b, struct ggml_cgraph * g) {
+    backend_ctx * c = (backend_ctx *) b->context; set_device(c->device);
+    return graph_compute(c, g);
+}
+static void be_event_record(ggml_backend_t b, ggml_backend_event_t e) {
+    backend_ctx * c = (backend_ctx *) b->context; set_device(c->device);
+    HIP_CHECK(hipEventRecord((hipEvent_t) e->context, c->stream));
+}
+static void be_event_wait(ggml_backend_t b, ggml_backend_event_t e) {
+    backend_ctx * c = (backend_ctx *) b->context; set_device(c->device);
+    HIP_CHECK(hipStreamWaitEvent(c->stream, (hipEvent_t) e->context, 0));
+}
+static const ggml_backend_i k_backend_iface = {
+    be_name, be_free, be_set_async, be_get_async, be_cpy_async, be_sync,
+    /*plan_create*/ nullptr, /*plan_free*/ nullptr, /*plan_update*/ nullptr, /*plan_compute*/ nullptr,
+    be_graph_compute, be_event_record, be_event_wait, /*graph_optimize*/ nullptr,
+};
+static bool backend_is_ours(ggml_backend_t b) { return b && b->iface.graph_compute == be_graph_compute; }
+
+// ---------------------------------------------------------------------------------------------- device
+static const char * dev_name(ggml_backend_dev_t d) { return ((device_ctx *) d->context)->name.c_str(); }
+static const char * dev_desc(ggml_backend_dev_t d) { return ((device_ctx *) d->context)->description.c_str(); }
+static void dev_memory(ggml_backend_dev_t d, size_t * free, size_t * total) {
+    set_device(((device_ctx *) d->context)->index);
+    HIP_CHECK(hipMemGetInfo(free, total));
+}
+static enum ggml_backend_dev_type dev_type(ggml_backend_dev_t) { return GGML_BACKEND_DEVICE_TYPE_GPU; }
+static void dev_props(ggml_backend_dev_t d, struct ggml_backend_dev_props * p) {
+    device_ctx * c = (device_ctx *) d->context;
+    p->name = c->name.c_str(); p->description = c->description.c_str();
+    dev_memory(d, &p->memory_free, &p->memory_total);
+    p->type = GGML_BACKEND_DEVICE_TYPE_GPU;
+    p->device_id = c->pci_id.empty() ? nullptr : c->pci_id.c_str();
+    p->caps = { /*async*/ true, /*host_buffer*/ true, /*buffer_from_host_ptr*/ false, /*events*/ true };
+}
+static ggml_backend_t dev_init_backend(ggml_backend_dev_t d, const char *) {
+    device_ctx * dc = (device_ctx *) d->context;
+    set_device(dc->index);
+    backend_ctx * c = new backend_ctx();
+    c->device = dc->index;
+    c->name   = dc->name;
+    HIP_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    backend_ctx_init(c);
+    return new ggml_backend{ &g_guid, k_backend_iface, d, c };
+}
+static ggml_backend_buffer_type_t dev_buft(ggml_backend_dev_t d) { return &((device_ctx *) d->context)->buft; }
+static ggml_backend_buffer_type_t dev_host_buft(ggml_backend_dev_t) { return &g_host_buft; }
+static bool dev_supports_op(ggml_backend_dev_t, const struct ggml_tensor * op) { return supports_op(op); }
+static bool dev_supports_buft(ggml_backend_dev_t d, ggml_backend_buffer_type_t t) {
+    if (t == &g_host_buft) return false;                              // host memory is not dereferenced by kernels
+    return t->iface.get_name == buft_name && t->context == d->context;
+}
+static bool dev_offload_op(ggml_backend_dev_t, const struct ggml_tensor * op) {
+    // worth shipping CPU-resident weights over PCIe only for real batches (same policy as the reference's GPU backend, ggml-cuda.cu:3701-3705)
+    const int min_batch = 32;
+    return (op->ne[1] >= min_batch && op->op != GGML_OP_GET_ROWS) || (op->ne[2] >= min_batch && op->op == GGML_OP_MUL_MAT_ID);
+}
+static ggml_backend_event_t dev_event_new(ggml_backend_dev_t d) {
+    set_device(((device_ctx *) d->context)->index);
+    hipEvent_t e; HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    return new ggml_backend_event{ d, e };
+}
+static void dev_event_free(ggml_backend_dev_t, ggml_backend_event_t e) { HIP_CHECK(hipEventDestroy((hipEvent_t) e->context)); delete e; }
+static void dev_event_sync(ggml_backend_dev_t, ggml_backend_event_t e) { HIP_CHECK(hipEventSynchronize((hipEvent_t) e->context)); }
+static const ggml_backend_device_i k_device_iface = {
+    dev_name, dev_desc, dev_memory, dev_type, dev_props, dev_init_backend, dev_buft, dev_host_buft, /*from_host_ptr*/ nullptr,
+    dev_supports_op, dev_supports_buft, dev_offload_op, dev_event_new, dev_event_free, dev_event_sync,
+};
+
+// ---------------------------------------------------------------------------------------------- registry
+static const char * reg_name(ggml_backend_reg_t) { return GGML_MI355X_NAME; }
+static size_t reg_dev_count(ggml_backend_reg_t) { return g_devices.size(); }
+static ggml_backend_dev_t reg_get_dev(ggml_backend_reg_t, size_t i) { return i < g_devices.size() ? &g_devices[i]->dev : nullptr; }
+
+struct feature { const char * name; const char * value; };
+static feature g_features[] = { {"ARCH", "gfx950"}, {"WAVE", "64"}, {"ACT_QUANT", "Q8_K/Q8_0 (CPU-parity)"}, {nullptr, nullptr} };
+static feature * get_features(ggml_backend_reg_t) { return g_features; }
+
+} // namespace mi
+
+// extension entry points are reachable through reg->iface.get_proc_address (the reference's mechanism for
+// backend-specific functions, ggml-backend.h:197-212)
+namespace mi {
+static void * reg_proc(ggml_backend_reg_t, const char * name) {
+    if (!strcmp(name, "ggml_backend_get_features")) return (void *) get_features;
+    if (!strcmp(name, "mi355x_timed_event_new"))     return (void *) mi355x_timed_event_new;
+    if (!strcmp(name, "mi355x_timed_event_record"))  return (void *) mi355x_timed_event_record;
+    if (!strcmp(name, "mi355x_timed_event_elapsed_ms")) return (void *) mi355x_timed_event_elapsed_ms;
+    if (!strcmp(name, "mi355x_timed_event_free"))    return (void *) mi355x_timed_event_free;
+    if (!strcmp(name, "mi355x_set_option"))          return (void *) mi355x_set_option;
+    if (!strcmp(name, "mi355x_get_stat"))            return (void *) mi355x_get_stat;
+    return nullptr;
+}
+static const ggml_backend_reg_i k_reg_iface = { reg_name, reg_dev_count, reg_get_dev, reg_proc };
+
+static void init_once() {
+    std::lock_guard<std::mutex> lock(g_mutex);
+    if (g_init_done) return;
+    g_init_done = true;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) { (void) hipGetLastError(); n = 0; }
+    for (int i = 0; i < n; ++i) {
+        hipDeviceProp_t p;
+        if (hipGetDeviceProperties(&p, i) != hipSuccess) continue;
+        const std::string arch = p.gcnArchName;
+        if (arch.rfind("gfx950", 0) != 0 && !getenv("MI355X_ALLOW_ANY_ARCH")) {
+            log_msg(GGML_LOG_LEVEL_WARN, "[mi355x] device %d is %s, not gfx950: skipped\n", i, p.gcnArchName);
+            continue;
+        }
+        device_ctx * d = new device_ctx();
+        d->index = i;
+        d->name = std::string(GGML_MI355X_NAME) + std::to_string(g_devices.size());
+        d->description = p.name;
+        char id[32]; snprintf(id, sizeof(id), "%04x:%02x:%02x.0", p.pciDomainID, p.pciBusID, p.pciDeviceID);
+        d->pci_id = id;
+        d->total_mem = p.totalGlobalMem;
+        d->buft = { k_buft_iface, &d->dev, d };
+        d->dev  = { k_device_iface, &g_reg, d };
+        g_devices.push_back(d);
+    }
+    g_host_buft = { k_hostbuft_iface, g_devices.empty() ? nullptr : &g_devices[0]->dev, nullptr };
+    g_reg = { GGML_BACKEND_API_VERSION, k_reg_iface, nullptr };
+}
+
+} // namespace mi
+
+// ---------------------------------------------------------------------------------------------- exported C ABI
+extern "C" {
+
+ggml_backend_reg_t ggml_backend_mi355x_reg(void) { mi::init_once(); return &mi::g_reg; }
+ggml_backend_reg_t ggml_backend_init(void) { return ggml_backend_mi355x_reg(); }
+int ggml_backend_score(void) {
+    mi::init_once();
+    return mi::g_devices.empty() ? 0 : 100;
+}
+
+// standalone harness only: what the core's ggml_backend_buffer_free does (ggml-backend.cpp:108-117)
+void mi355x_host_buffer_free(ggml_backend_buffer_t b) {
+    if (!b) return;
+    if (b->iface.free_buffer) b->iface.free_buffer(b);
+    delete b;
+}
+
+void * mi355x_timed_event_new(void) { hipEvent_t e; HIP_CHECK(hipEventCreate(&e)); return e; }
+void   mi355x_timed_event_record(void * ev, ggml_backend_t backend) {
+    mi::backend_ctx * c = (mi::backend_ctx *) backend->context;
+    HIP_CHECK(hipSetDevice(c->device));
+    HIP_CHECK(hipEventRecord((hipEvent_t) ev, c->stream));
+}
+float  mi355x_timed_event_elapsed_ms(void * start, void * stop) {
+    HIP_CHECK(hipEventSynchronize((hipEvent_t) stop));
+    float ms = 0; HIP_CHECK(hipEventElapsedTime(&ms, (hipEvent_t) start, (hipEvent_t) stop)); return ms;
+}
+void   mi355x_timed_event_free(void * ev) { HIP_CHECK(hipEventDestroy((hipEvent_t) ev)); }
+
+} // extern "C"

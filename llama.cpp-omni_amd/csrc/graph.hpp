@@ -1,0 +1,57 @@
+// graph.hpp -- per-stream backend state and the graph executor interface.
+#pragma once
+#include "common.hpp"
+#include <map>
+#include <string>
+#include <vector>
+
+namespace mi {
+
+void log_msg(int level, const char * fmt, ...);
+
+struct prof_class { double us = 0; double bytes = 0; long n = 0; };
+
+struct graph_exec {                    // one captured cgraph
+    uint64_t        fingerprint = 0;
+    int             seen = 0;          // times this fingerprint was submitted
+    hipGraph_t      graph = nullptr;
+    hipGraphExec_t  exec = nullptr;
+    int             n_kernels = 0;
+    uint64_t        last_use = 0;
+};
+
+struct backend_ctx {
+    int          device = 0;
+    std::string  name;
+    hipStream_t  stream = nullptr;
+    hipEvent_t   copy_event = nullptr;
+
+    // scratch for quantised / converted activations (grown outside of graph capture only)
+    void *  act_scratch = nullptr;  size_t act_scratch_bytes = 0;
+    // scratch for de-quantised weight tiles / f16 copies on the GEMM path
+    void *  w_scratch = nullptr;    size_t w_scratch_bytes = 0;
+
+    // options
+    bool opt_graphs = true;
+    bool opt_fusion = true;
+    bool opt_profile = false;
+
+    // hipGraph cache
+    std::vector<graph_exec> execs;
+    uint64_t tick = 0;
+
+    // statistics
+    long stat_replays = 0, stat_captures = 0, stat_eager = 0, stat_kernels_last = 0;
+    std::map<std::string, prof_class> prof;
+    struct pending_prof { std::string cls; double bytes; hipEvent_t a, b; };
+    std::vector<pending_prof> prof_pending;
+    std::vector<hipEvent_t>   prof_event_pool;
+};
+
+void backend_ctx_init(backend_ctx * c);
+void backend_ctx_release(backend_ctx * c);
+
+bool             supports_op(const ggml_tensor * op);
+enum ggml_status graph_compute(backend_ctx * c, ggml_cgraph * g);
+
+} // namespace mi

@@ -1,0 +1,85 @@
+// kernels.hpp -- host-callable launchers of the hand-written gfx950 kernels.
+// All pointers are device pointers; every launcher enqueues on `st` and returns immediately.
+#pragma once
+#include "common.hpp"
+
+namespace mi {
+
+// ---- activation quantisers (reference: ggml-cpu.c:1272-1306 `from_float` stage of mul_mat)
+// x: [nrows, K] f32 with row stride xs (bytes). img: nrows images of q8k_image_bytes(K) each.
+void quantize_q8k_image(const float * x, size_t xs, void * img, int64_t K, int64_t nrows, hipStream_t st);
+void quantize_q80_image(const float * x, size_t xs, void * img, int64_t K, int64_t nrows, hipStream_t st);
+// f32 -> f16 (RNE) rows, dst row stride ys bytes
+void convert_f32_f16_rows(const float * x, size_t xs, uint16_t * y, size_t ys, int64_t K, int64_t nrows, hipStream_t st);
+
+// ---- mat-vec on quantised weights: dst[col*ds + row] = dot(W[row, :], act[col, :]), ncols <= MMVQ_MAX_COLS
+#define MI_MMVQ_MAX_COLS 8
+struct mmv_args {
+    const void * W;        // weight rows
+    size_t       w_rs;     // weight row stride in bytes (nb01)
+    const void * act;      // activation images (q8k / q80 / f16 rows), one per column
+    size_t       act_cs;   // activation column stride in bytes
+    float *      dst;      // f32 output
+    size_t       dst_cs;   // output column stride in bytes (nb1)
+    int64_t      K;        // contraction length
+    int64_t      nrows;    // weight rows (= dst ne0)
+    int          ncols;    // activation columns (tokens)
+};
+void mmv_q4_K(const mmv_args & a, hipStream_t st);
+void mmv_q6_K(const mmv_args & a, hipStream_t st);
+void mmv_q8_0(const mmv_args & a, hipStream_t st);
+void mmv_f16 (const mmv_args & a, hipStream_t st);   // act = f16 rows
+void mmv_f32 (const mmv_args & a, hipStream_t st);   // W f32, act = f32 rows
+
+// ---- full dequantisation (GET_ROWS on quantised tables, dequant->GEMM prefill path, CPY q->f32)
+// src row r at src + r*src_rs ; dst row r at dst + r*dst_rs ; K elements per row
+void dequant_rows_f32(int type, const void * src, size_t src_rs, float * dst, size_t dst_rs, int64_t K, int64_t nrows, hipStream_t st);
+void dequant_rows_f16(int type, const void * src, size_t src_rs, uint16_t * dst, size_t dst_rs, int64_t K, int64_t nrows, hipStream_t st);
+
+// ---- tensor descriptor for the strided element-wise kernels
+struct tdesc {
+    void *  p;
+    int64_t ne[4];
+    size_t  nb[4];
+};
+
+// RMS_NORM (ops.cpp:3517-3566), optionally fused with the following MUL by `w` (broadcast over rows) and ADD
+void rms_norm(const tdesc & x, const tdesc & y, float eps, const tdesc * mul_w, hipStream_t st);
+// ROPE f32 (ops.cpp:5534-5720): modes NORMAL / NEOX, optional freq factors, YaRN
+struct rope_params {
+    int   n_dims, mode, n_ctx_orig;
+    float freq_base, freq_scale, ext_factor, attn_factor, beta_fast, beta_slow;
+};
+void rope_f32(const tdesc & x, const int32_t * pos, const float * freq_factors, const tdesc & y, const rope_params & rp, hipStream_t st);
+// SOFT_MAX (ops.cpp:5072-5182): y = softmax(x*scale + slope*mask)
+void soft_max_f32(const tdesc & x, const tdesc * mask, int mask_type, const float * sinks, const tdesc & y, float scale, float max_bias, hipStream_t st);
+// GLU (split or single-tensor forms; ops.cpp:2934-2990 for swiglu)
+void glu_f32(int glu_op, const tdesc & a, const tdesc * b, bool swapped, const tdesc & y, hipStream_t st);
+// unary ops on contiguous f32
+void unary_f32(int uop, const float * x, float * y, int64_t n, hipStream_t st);
+// ADD / SUB / MUL / DIV with ggml broadcast semantics (src1 repeats over src0)
+void bin_bcast_f32(int op, const tdesc & a, const tdesc & b, const tdesc & y, hipStream_t st);
+void scale_f32(const float * x, float * y, int64_t n, float s, float b, hipStream_t st);
+// CPY / CONT / DUP between f32 / f16 with arbitrary strides (same element count)
+void cpy_strided(const tdesc & src, int src_type, const tdesc & dst, int dst_type, hipStream_t st);
+// GET_ROWS (f32 / f16 / quantised tables -> f32), SET_ROWS (f32 -> f32 / f16, i64 or i32 indices)
+void get_rows(const tdesc & src, int src_type, const tdesc & idx, const tdesc & dst, hipStream_t st);
+void set_rows(const tdesc & src, const tdesc & idx, int idx_type, const tdesc & dst, int dst_type, hipStream_t st);
+
+// FLASH_ATTN_EXT (ops.cpp:7912-8148): q f32 [D, nq, nh, ns], k/v f16 [D, nkv, nhkv, ns], mask f16 [nkv, >=nq, 1|nh?, ns]
+struct fattn_args {
+    tdesc q, k, v, dst;
+    const tdesc * mask;      // may be null
+    const float * sinks;     // may be null
+    float scale, max_bias, logit_softcap;
+    void * scratch;          // split-KV partials
+    size_t scratch_bytes;
+};
+size_t fattn_scratch_bytes(const fattn_args & a);
+void   flash_attn_ext_f16(const fattn_args & a, hipStream_t st);
+
+// dense GEMM on the matrix cores: dst[n, m] (f32) = sum_k W[m,k] (f16) * X[n,k] (f16), f32 accumulate
+void gemm_f16_mfma(const uint16_t * W, size_t w_rs, const uint16_t * X, size_t x_rs, float * dst, size_t dst_cs,
+                   int64_t M, int64_t N, int64_t K, hipStream_t st);
+
+} // namespace mi

@@ -1,0 +1,525 @@
+// elementwise.hip -- the non-matmul nodes of the decode / prefill graph (gfx950, wave64).
+// Each kernel restates one `ggml_compute_forward_*` of the reference CPU backend
+// (ggml/src/ggml-cpu/ops.cpp); the line ranges are cited per kernel.
+#include "../kernels.hpp"
+
+namespace mi {
+
+struct td4 { char * p; int64_t ne[4]; int64_t nb[4]; };
+static td4 to_td4(const tdesc & t) {
+    td4 r; r.p = (char *) t.p;
+    for (int i = 0; i < 4; ++i) { r.ne[i] = t.ne[i]; r.nb[i] = (int64_t) t.nb[i]; }
+    return r;
+}
+
+// ================================================================================================
+// de-quantisation of whole rows (reference: dequantize_row_q4_K :1352, _q6_K :1762, _q8_0 :401 in
+// ggml-quants.c).  One thread produces a run of consecutive outputs of one block; float ops are the
+// same single multiply / multiply-subtract as the C source, so results are bit-exact.
+// ================================================================================================
+template <typename T> static __device__ __forceinline__ T cvt_out(float v);
+template <> __device__ __forceinline__ float    cvt_out<float>(float v)    { return v; }
+template <> __device__ __forceinline__ uint16_t cvt_out<uint16_t>(float v) { return f2h(v); }
+
+static __device__ __forceinline__ void q4k_scale_min(int s, const uint8_t * q, int & sc, int & m) {   // get_scale_min_k4, ggml-quants.c:703-710
+    if (s < 4) { sc = q[s] & 63; m = q[s + 4] & 63; }
+    else       { sc = (q[s + 4] & 0xF) | ((q[s - 4] >> 6) << 4); m = (q[s + 4] >> 4) | ((q[s] >> 6) << 4); }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) k_dequant_q4k(const char * __restrict__ src, size_t src_rs, char * __restrict__ dst, size_t dst_rs, int64_t K, int64_t nrows) {
+    // thread -> (row, block, sub-block s of 32, 8 outputs)  : 4 threads per sub-block
+    const int64_t nb = K / 256;
+    const int64_t t  = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t total = nrows * nb * 32;
+    if (t >= total) return;
+    const int     part = (int) (t & 3);           // 8 outputs within the sub-block
+    const int     s    = (int) ((t >> 2) & 7);    // sub-block
+    const int64_t blk  = t >> 5;
+    const int64_t row = blk / nb, ib = blk % nb;
+    const block_q4_K * b = (const block_q4_K *) (src + row * src_rs) + ib;
+    int sc, m; q4k_scale_min(s, b->scales, sc, m);
+    const float d1 = h2f(b->d) * (float) sc;
+    const float m1 = h2f(b->dmin) * (float) m;
+    const uint8_t * q = b->qs + 32 * (s >> 1) + 8 * part;
+    T * out = (T *) (dst + row * dst_rs) + ib * 256 + 32 * s + 8 * part;
+#pragma unroll
+    for (int l = 0; l < 8; ++l) {
+        const int v = (s & 1) ? (q[l] >> 4) : (q[l] & 0xF);
+        out[l] = cvt_out<T>(d1 * (float) v - m1);
+    }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) k_dequant_q6k(const char * __restrict__ src, size_t src_rs, char * __restrict__ dst, size_t dst_rs, int64_t K, int64_t nrows) {
+    // thread -> (row, block, half n, l in 0..31): 4 outputs y[128n + l + {0,32,64,96}]
+    const int64_t nb = K / 256;
+    const int64_t t  = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t total = nrows * nb * 64;
+    if (t >= total) return;
+    const int     l   = (int) (t & 31);
+    const int     n   = (int) ((t >> 5) & 1);
+    const int64_t blk = t >> 6;
+    const int64_t row = blk / nb, ib = blk % nb;
+    const block_q6_K * b = (const block_q6_K *) (src + row * src_rs) + ib;
+    const float d = h2f(b->d);
+    const uint8_t * ql = b->ql + 64 * n;
+    const uint8_t   qh = b->qh[32 * n + l];
+    const int8_t *  sc = b->scales + 8 * n;
+    const int is = l / 16;
+    const int8_t q1 = (int8_t) ((ql[l +  0] & 0xF) | (((qh >> 0) & 3) << 4)) - 32;
+    const int8_t q2 = (int8_t) ((ql[l + 32] & 0xF) | (((qh >> 2) & 3) << 4)) - 32;
+    const int8_t q3 = (int8_t) ((ql[l +  0] >> 4)  | (((qh >> 4) & 3) << 4)) - 32;
+    const int8_t q4 = (int8_t) ((ql[l + 32] >> 4)  | (((qh >> 6) & 3) << 4)) - 32;
+    T * y = (T *) (dst + row * dst_rs) + ib * 256 + 128 * n;
+    y[l +  0] = cvt_out<T>(d * (float) sc[is + 0] * (float) q1);
+    y[l + 32] = cvt_out<T>(d * (float) sc[is + 2] * (float) q2);
+    y[l + 64] = cvt_out<T>(d * (float) sc[is + 4] * (float) q3);
+    y[l + 96] = cvt_out<T>(d * (float) sc[is + 6] * (float) q4);
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) k_dequant_q80(const char * __restrict__ src, size_t src_rs, char * __restrict__ dst, size_t dst_rs, int64_t K, int64_t nrows) {
+    const int64_t nb = K / 32;
+    const int64_t t  = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nrows * K) return;
+    const int64_t row = t / K, e = t % K;
+    const block_q8_0 * b = (const block_q8_0 *) (src + row * src_rs) + e / 32;
+    ((T *) (dst + row * dst_rs))[e] = cvt_out<T>((float) b->qs[e % 32] * h2f(b->d));
+    (void) nb;
+}
+
+template <typename T>
+static void dequant_rows_t(int type, const void * src, size_t src_rs, T * dst, size_t dst_rs, int64_t K, int64_t nrows, hipStream_t st) {
+    if (K == 0 || nrows == 0) return;
+    int64_t nthreads;
+    switch (type) {
+        case GGML_TYPE_Q4_K: nthreads = nrows * (K / 256) * 32;
+            k_dequant_q4k<T><<<dim3((unsigned) ((nthreads + 255) / 256)), dim3(256), 0, st>>>((const char *) src, src_rs, (char *) dst, dst_rs, K, nrows); break;
+        case GGML_TYPE_Q6_K: nthreads = nrows * (K / 256) * 64;
+            k_dequant_q6k<T><<<dim3((unsigned) ((nthreads + 255) / 256)), dim3(256), 0, st>>>((const char *) src, src_rs, (char *) dst, dst_rs, K, nrows); break;
+        case GGML_TYPE_Q8_0: nthreads = nrows * K;
+            k_dequant_q80<T><<<dim3((unsigned) ((nthreads + 255) / 256)), dim3(256), 0, st>>>((const char *) src, src_rs, (char *) dst, dst_rs, K, nrows); break;
+        default: fprintf(stderr, "[mi355x] dequant_rows: unsupported type %d\n", type); abort();
+    }
+}
+void dequant_rows_f32(int type, const void * src, size_t src_rs, float * dst, size_t dst_rs, int64_t K, int64_t nrows, hipStream_t st) {
+    dequant_rows_t<float>(type, src, src_rs, dst, dst_rs, K, nrows, st);
+}
+void dequant_rows_f16(int type, const void * src, size_t src_rs, uint16_t * dst, size_t dst_rs, int64_t K, int64_t nrows, hipStream_t st) {
+    dequant_rows_t<uint16_t>(type, src, src_rs, dst, dst_rs, K, nrows, st);
+}
+
+// ================================================================================================
+// RMS_NORM (+ fused MUL).  reference: ggml_compute_forward_rms_norm_f32, ops.cpp:3517-3566:
+//   sum = sum_i (double)(x_i*x_i);  mean = sum/ne00;  scale = 1/sqrtf(mean+eps);  y = x*scale
+// The sum of squares is accumulated in double exactly like the reference's `ggml_float`, which makes
+// the result independent of the summation order (bit-exact `scale` in practice).  The optional fused
+// weight multiply is the graph's following MUL node (y*w, w broadcast over rows).
+// ================================================================================================
+template <bool HAS_W>
+__global__ void __launch_bounds__(1024) k_rms_norm(td4 x, td4 y, td4 w, float eps) {
+    __shared__ double red[16];
+    const int64_t i1 = blockIdx.x, i2 = blockIdx.y, i3 = blockIdx.z;
+    const float * xr = (const float *) (x.p + i1 * x.nb[1] + i2 * x.nb[2] + i3 * x.nb[3]);
+    float *       yr = (float *) (y.p + i1 * y.nb[1] + i2 * y.nb[2] + i3 * y.nb[3]);
+    const int64_t n = x.ne[0];
+    double s = 0.0;
+    for (int64_t i = threadIdx.x; i < n; i += blockDim.x) { const float v = xr[i]; s += (double) (v * v); }
+    s = block_sum<double>(s, red);
+    const float mean  = (float) (s / (double) n);
+    const float scale = 1.0f / sqrtf(mean + eps);
+    if (HAS_W) {
+        const float * wr = (const float *) (w.p + (i1 % w.ne[1]) * w.nb[1] + (i2 % w.ne[2]) * w.nb[2] + (i3 % w.ne[3]) * w.nb[3]);
+        const int64_t wn = w.ne[0];
+        for (int64_t i = threadIdx.x; i < n; i += blockDim.x) yr[i] = (xr[i] * scale) * wr[wn == n ? i : i % wn];
+    } else {
+        for (int64_t i = threadIdx.x; i < n; i += blockDim.x) yr[i] = xr[i] * scale;
+    }
+}
+
+void rms_norm(const tdesc & x, const tdesc & y, float eps, const tdesc * mul_w, hipStream_t st) {
+    if (x.ne[0] == 0 || x.ne[1] * x.ne[2] * x.ne[3] == 0) return;
+    const int64_t n = x.ne[0];
+    int bs = n <= 128 ? 64 : n < 1024 ? 256 : n < 8192 ? 512 : 1024;
+    dim3 grid((unsigned) x.ne[1], (unsigned) x.ne[2], (unsigned) x.ne[3]);
+    if (mul_w) k_rms_norm<true><<<grid, dim3(bs), 0, st>>>(to_td4(x), to_td4(y), to_td4(*mul_w), eps);
+    else       k_rms_norm<false><<<grid, dim3(bs), 0, st>>>(to_td4(x), to_td4(y), to_td4(x), eps);
+}
+
+// ================================================================================================
+// ROPE f32.  reference: ggml_compute_forward_rope_f32 ops.cpp:5534-5720, rope_yarn :5443-5458,
+// ggml_rope_cache_init :5460-5475, ggml_rope_yarn_corr_dims ggml.c.
+// theta for pair i is produced by the SAME sequential product as the reference's cache init
+// (theta_0 = pos; theta_{i+1} = theta_i * theta_scale) so the angle is bit-identical; only cosf/sinf
+// differ (device libm vs glibc, <= 2 ulp).
+// ================================================================================================
+struct rope_dev {
+    int   n_dims, mode;
+    float theta_scale, freq_scale, ext_factor, attn_factor, corr0, corr1;
+};
+
+__global__ void __launch_bounds__(256) k_rope(td4 x, td4 y, const int32_t * __restrict__ pos, const float * __restrict__ ff, rope_dev rp) {
+    // grid: (ne1 heads, ne2 tokens, ne3); threads over pairs
+    const int64_t i1 = blockIdx.x, i2 = blockIdx.y, i3 = blockIdx.z;
+    const char * xr = x.p + i1 * x.nb[1] + i2 * x.nb[2] + i3 * x.nb[3];
+    char *       yr = y.p + i1 * y.nb[1] + i2 * y.nb[2] + i3 * y.nb[3];
+    const int ne0 = (int) x.ne[0];
+    const bool neox = rp.mode & GGML_ROPE_TYPE_NEOX;
+    const float p = (float) pos[i2];
+    for (int ip = threadIdx.x; ip < ne0 / 2; ip += blockDim.x) {
+        const int i0 = 2 * ip;
+        if (i0 < rp.n_dims) {
+            float theta = p;
+            for (int k = 0; k < ip; ++k) theta *= rp.theta_scale;          // sequential, as ggml_rope_cache_init
+            const float f = ff ? ff[ip] : 1.0f;
+            const float theta_extrap = theta / f;
+            float theta_interp = rp.freq_scale * theta_extrap;
+            float th = theta_interp, mscale = rp.attn_factor;
+            if (rp.ext_factor != 0.0f) {
+                const float yv = ((float) (i0 / 2) - rp.corr0) / fmaxf(0.001f, rp.corr1 - rp.corr0);
+                const float ramp_mix = (1.0f - fminf(1.0f, fmaxf(0.0f, yv))) * rp.ext_factor;
+                th = theta_interp * (1.0f - ramp_mix) + theta_extrap * ramp_mix;
+                mscale *= 1.0f + 0.1f * logf(1.0f / rp.freq_scale);
+            }
+            const float c = cosf(th) * mscale, s = sinf(th) * mscale;
+            if (neox) {
+                const float x0 = *(const float *) (xr + (int64_t) ip * x.nb[0]);
+                const float x1 = *(const float *) (xr + (int64_t) (ip + rp.n_dims / 2) * x.nb[0]);
+                *(float *) (yr + (int64_t) ip * y.nb[0])                   = x0 * c - x1 * s;
+                *(float *) (yr + (int64_t) (ip + rp.n_dims / 2) * y.nb[0]) = x0 * s + x1 * c;
+            } else {
+                const float x0 = *(const float *) (xr + (int64_t) i0 * x.nb[0]);
+                const float x1 = *(const float *) (xr + (int64_t) (i0 + 1) * x.nb[0]);
+                *(float *) (yr + (int64_t) i0 * y.nb[0])       = x0 * c - x1 * s;
+                *(float *) (yr + (int64_t) (i0 + 1) * y.nb[0]) = x0 * s + x1 * c;
+            }
+        } else {                                   // pass-through channels beyond n_dims
+            *(float *) (yr + (int64_t) i0 * y.nb[0])       = *(const float *) (xr + (int64_t) i0 * x.nb[0]);
+            *(float *) (yr + (int64_t) (i0 + 1) * y.nb[0]) = *(const float *) (xr + (int64_t) (i0 + 1) * x.nb[0]);
+        }
+    }
+}
+
+// ggml_rope_yarn_corr_dim / _dims (ggml.c): restated on the host
+static float rope_corr_dim(int n_dims, int n_ctx_orig, float n_rot, float base) {
+    return n_dims * logf(n_ctx_orig / (n_rot * 2 * (float) M_PI)) / (2 * logf(base));
+}
+
+void rope_f32(const tdesc & x, const int32_t * pos, const float * ff, const tdesc & y, const rope_params & rp, hipStream_t st) {
+    if (x.ne[0] * x.ne[1] * x.ne[2] * x.ne[3] == 0) return;
+    rope_dev d;
+    d.n_dims = rp.n_dims; d.mode = rp.mode;
+    d.theta_scale = powf(rp.freq_base, -2.0f / rp.n_dims);
+    d.freq_scale = rp.freq_scale; d.ext_factor = rp.ext_factor; d.attn_factor = rp.attn_factor;
+    const float start = floorf(rope_corr_dim(rp.n_dims, rp.n_ctx_orig, rp.beta_fast, rp.freq_base));
+    const float end   = ceilf (rope_corr_dim(rp.n_dims, rp.n_ctx_orig, rp.beta_slow, rp.freq_base));
+    d.corr0 = fmaxf(0.0f, start); d.corr1 = fminf((float) rp.n_dims - 1, end);
+    dim3 grid((unsigned) x.ne[1], (unsigned) x.ne[2], (unsigned) x.ne[3]);
+    k_rope<<<grid, dim3(64), 0, st>>>(to_td4(x), to_td4(y), pos, ff, d);
+}
+
+// ================================================================================================
+// SOFT_MAX.  reference: ggml_compute_forward_soft_max_f32 ops.cpp:5072-5182:
+//   wp = x*scale + slope*mask ; max ; p = expf(wp-max) ; sum in double ; y = p * (1/sum)
+// mask is f16 or f32, broadcast over heads (i02 % ne12) and batches (i03 % ne13).
+// ================================================================================================
+template <bool MASK_F16>
+__global__ void __launch_bounds__(1024) k_soft_max(td4 x, td4 y, td4 mk, bool has_mask, const float * __restrict__ sinks,
+                                                  float scale, float max_bias, float m0, float m1, uint32_t n_head_log2) {
+    extern __shared__ __attribute__((aligned(16))) char sm_lds[];
+    __shared__ double redd[16];
+    __shared__ float  redf[16];
+    float * buf = (float *) sm_lds;
+    const int64_t i1 = blockIdx.x, i2 = blockIdx.y, i3 = blockIdx.z;
+    const int64_t n = x.ne[0];
+    const float * xr = (const float *) (x.p + i1 * x.nb[1] + i2 * x.nb[2] + i3 * x.nb[3]);
+    float *       yr = (float *) (y.p + i1 * y.nb[1] + i2 * y.nb[2] + i3 * y.nb[3]);
+    const char *  mr = has_mask ? mk.p + i1 * mk.nb[1] + (i2 % mk.ne[2]) * mk.nb[2] + (i3 % mk.ne[3]) * mk.nb[3] : nullptr;
+    const uint32_t h = (uint32_t) i2;
+    const float slope = max_bias > 0.0f ? (h < n_head_log2 ? powf(m0, (float) (h + 1)) : powf(m1, (float) (2 * (h - n_head_log2) + 1))) : 1.0f;
+
+    float mx = -INFINITY;
+    for (int64_t i = threadIdx.x; i < n; i += blockDim.x) {
+        float v = xr[i] * scale;
+        if (mr) v += slope * (MASK_F16 ? h2f(((const uint16_t *) mr)[i]) : ((const float *) mr)[i]);
+        buf[i] = v;
+        mx = fmaxf(mx, v);
+    }
+    mx = block_max(mx, redf);
+    if (sinks) mx = fmaxf(mx, sinks[i2]);
+    double sum = 0.0;
+    for (int64_t i = threadIdx.x; i < n; i += blockDim.x) {
+        const float e = expf(buf[i] - mx);
+        buf[i] = e;
+        sum += (double) e;
+    }
+    sum = block_sum<double>(sum, redd);
+    if (sinks) sum += (double) expf(sinks[i2] - mx);
+    const float inv = (float) (1.0 / sum);
+    for (int64_t i = threadIdx.x; i < n; i += blockDim.x) yr[i] = buf[i] * inv;
+}
+
+void soft_max_f32(const tdesc & x, const tdesc * mask, int mask_type, const float * sinks, const tdesc & y, float scale, float max_bias, hipStream_t st) {
+    if (x.ne[0] * x.ne[1] * x.ne[2] * x.ne[3] == 0) return;
+    const int64_t n = x.ne[0];
+    int bs = n <= 64 ? 64 : n <= 1024 ? 256 : 1024;
+    const uint32_t n_head = (uint32_t) x.ne[2];
+    const uint32_t n_head_log2 = 1u << (uint32_t) floorf(log2f((float) n_head));
+    const float m0 = powf(2.0f, -(max_bias) / n_head_log2);
+    const float m1 = powf(2.0f, -(max_bias / 2.0f) / n_head_log2);
+    dim3 grid((unsigned) x.ne[1], (unsigned) x.ne[2], (unsigned) x.ne[3]);
+    const size_t lds = (size_t) n * 4;
+    td4 mk = mask ? to_td4(*mask) : to_td4(x);
+    if (mask && mask_type == GGML_TYPE_F16) {
+        if (lds > 64 * 1024) HIP_CHECK(hipFuncSetAttribute((const void *) k_soft_max<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
+        k_soft_max<true><<<grid, dim3(bs), lds, st>>>(to_td4(x), to_td4(y), mk, true, sinks, scale, max_bias, m0, m1, n_head_log2);
+    } else {
+        if (lds > 64 * 1024) HIP_CHECK(hipFuncSetAttribute((const void *) k_soft_max<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
+        k_soft_max<false><<<grid, dim3(bs), lds, st>>>(to_td4(x), to_td4(y), mk, mask != nullptr, sinks, scale, max_bias, m0, m1, n_head_log2);
+    }
+}
+
+// ================================================================================================
+// GLU family (ops.cpp:2934-2990 swiglu; reglu/geglu variants alongside) and unary ops (unary-ops.cpp)
+// ================================================================================================
+static __device__ __forceinline__ float op_silu(float x) { return x / (1.0f + expf(-x)); }                 // vec.h:958
+static __device__ __forceinline__ float op_gelu(float x) {                                                 // vec.h ggml_gelu_f32
+    return 0.5f * x * (1.0f + tanhf(0.79788456080286535587989211986876f * x * (1.0f + 0.044715f * x * x)));
+}
+static __device__ __forceinline__ float op_gelu_quick(float x) { return x * (1.0f / (1.0f + expf(-1.702f * x))); }
+static __device__ __forceinline__ float op_gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+
+__global__ void __launch_bounds__(256) k_glu(int op, const char * __restrict__ a, int64_t a_rs, const char * __restrict__ b, int64_t b_rs,
+                                            char * __restrict__ y, int64_t y_rs, int64_t nc, int64_t nr) {
+    const int64_t t = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nc * nr) return;
+    const int64_t r = t / nc, i = t % nc;
+    const float x = ((const float *) (a + r * a_rs))[i];
+    const float g = ((const float *) (b + r * b_rs))[i];
+    float v;
+    switch (op) {
+        case GGML_GLU_OP_REGLU:       v = (x > 0.0f ? x : 0.0f) * g; break;
+        case GGML_GLU_OP_GEGLU:       v = op_gelu(x) * g; break;
+        case GGML_GLU_OP_SWIGLU:      v = op_silu(x) * g; break;
+        case GGML_GLU_OP_GEGLU_ERF:   v = op_gelu_erf(x) * g; break;
+        case GGML_GLU_OP_GEGLU_QUICK: v = op_gelu_quick(x) * g; break;
+        default: v = 0.0f;
+    }
+    ((float *) (y + r * y_rs))[i] = v;
+}
+
+void glu_f32(int glu_op, const tdesc & a, const tdesc * b, bool swapped, const tdesc & y, hipStream_t st) {
+    // rows are contiguous_1 (checked by supports_op): treat as [nc, nr] with a row stride
+    const int64_t nc = y.ne[0];
+    const int64_t nr = y.ne[1] * y.ne[2] * y.ne[3];
+    if (nc * nr == 0) return;
+    const char * ap = (const char *) a.p; const char * bp;
+    int64_t a_rs = (int64_t) a.nb[1], b_rs;
+    if (b) { bp = (const char *) b->p; b_rs = (int64_t) b->nb[1]; }
+    else   { bp = ap + (swapped ? 0 : nc * 4); ap = ap + (swapped ? nc * 4 : 0); b_rs = a_rs; }
+    k_glu<<<dim3((unsigned) ((nc * nr + 255) / 256)), dim3(256), 0, st>>>(glu_op, ap, a_rs, bp, b_rs, (char *) y.p, (int64_t) y.nb[1], nc, nr);
+}
+
+__global__ void __launch_bounds__(256) k_unary(int op, const float * __restrict__ x, float * __restrict__ y, int64_t n) {
+    const int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float v = x[i]; float r;
+    switch (op) {
+        case GGML_UNARY_OP_ABS:        r = fabsf(v); break;
+        case GGML_UNARY_OP_SGN:        r = v > 0.0f ? 1.0f : (v < 0.0f ? -1.0f : 0.0f); break;
+        case GGML_UNARY_OP_NEG:        r = -v; break;
+        case GGML_UNARY_OP_STEP:       r = v > 0.0f ? 1.0f : 0.0f; break;
+        case GGML_UNARY_OP_TANH:       r = tanhf(v); break;
+        case GGML_UNARY_OP_ELU:        r = v > 0.0f ? v : expm1f(v); break;
+        case GGML_UNARY_OP_RELU:       r = v > 0.0f ? v : 0.0f; break;
+        case GGML_UNARY_OP_SIGMOID:    r = 1.0f / (1.0f + expf(-v)); break;
+        case GGML_UNARY_OP_GELU:       r = op_gelu(v); break;
+        case GGML_UNARY_OP_GELU_QUICK: r = op_gelu_quick(v); break;
+        case GGML_UNARY_OP_SILU:       r = op_silu(v); break;
+        case GGML_UNARY_OP_HARDSWISH:  r = v * fminf(1.0f, fmaxf(0.0f, (v + 3.0f) / 6.0f)); break;
+        case GGML_UNARY_OP_HARDSIGMOID:r = fminf(1.0f, fmaxf(0.0f, (v + 3.0f) / 6.0f)); break;
+        case GGML_UNARY_OP_EXP:        r = expf(v); break;
+        case GGML_UNARY_OP_GELU_ERF:   r = op_gelu_erf(v); break;
+        default: r = v;
+    }
+    y[i] = r;
+}
+void unary_f32(int uop, const float * x, float * y, int64_t n, hipStream_t st) {
+    if (n == 0) return;
+    k_unary<<<dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, st>>>(uop, x, y, n);
+}
+
+__global__ void __launch_bounds__(256) k_scale(const float * __restrict__ x, float * __restrict__ y, int64_t n, float s, float b) {
+    const int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) y[i] = x[i] * s + b;
+}
+void scale_f32(const float * x, float * y, int64_t n, float s, float b, hipStream_t st) {
+    if (n == 0) return;
+    k_scale<<<dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, st>>>(x, y, n, s, b);
+}
+
+// ================================================================================================
+// ADD / SUB / MUL / DIV with broadcast (binary-ops.cpp): dst and src0 same shape, src1 repeats.
+// ================================================================================================
+template <int OP>
+__global__ void __launch_bounds__(256) k_bin(td4 a, td4 b, td4 y) {
+    const int64_t n0 = y.ne[0];
+    const int64_t total = y.ne[0] * y.ne[1] * y.ne[2] * y.ne[3];
+    for (int64_t t = (int64_t) blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t) gridDim.x * blockDim.x) {
+        const int64_t i0 = t % n0; int64_t r = t / n0;
+        const int64_t i1 = r % y.ne[1]; r /= y.ne[1];
+        const int64_t i2 = r % y.ne[2]; const int64_t i3 = r / y.ne[2];
+        const float va = *(const float *) (a.p + i0 * a.nb[0] + i1 * a.nb[1] + i2 * a.nb[2] + i3 * a.nb[3]);
+        const float vb = *(const float *) (b.p + (i0 % b.ne[0]) * b.nb[0] + (i1 % b.ne[1]) * b.nb[1] + (i2 % b.ne[2]) * b.nb[2] + (i3 % b.ne[3]) * b.nb[3]);
+        float v;
+        if (OP == GGML_OP_ADD) v = va + vb; else if (OP == GGML_OP_SUB) v = va - vb; else if (OP == GGML_OP_MUL) v = va * vb; else v = va / vb;
+        *(float *) (y.p + i0 * y.nb[0] + i1 * y.nb[1] + i2 * y.nb[2] + i3 * y.nb[3]) = v;
+    }
+}
+void bin_bcast_f32(int op, const tdesc & a, const tdesc & b, const tdesc & y, hipStream_t st) {
+    const int64_t total = y.ne[0] * y.ne[1] * y.ne[2] * y.ne[3];
+    if (total == 0) return;
+    int64_t g = (total + 255) / 256; if (g > 8192) g = 8192;
+    dim3 grid((unsigned) g), blk(256);
+    switch (op) {
+        case GGML_OP_ADD: k_bin<GGML_OP_ADD><<<grid, blk, 0, st>>>(to_td4(a), to_td4(b), to_td4(y)); break;
+        case GGML_OP_SUB: k_bin<GGML_OP_SUB><<<grid, blk, 0, st>>>(to_td4(a), to_td4(b), to_td4(y)); break;
+        case GGML_OP_MUL: k_bin<GGML_OP_MUL><<<grid, blk, 0, st>>>(to_td4(a), to_td4(b), to_td4(y)); break;
+        case GGML_OP_DIV: k_bin<GGML_OP_DIV><<<grid, blk, 0, st>>>(to_td4(a), to_td4(b), to_td4(y)); break;
+        default: abort();
+    }
+}
+
+// ================================================================================================
+// CPY / CONT / DUP: element i (row-major over src->ne) of src -> element i of dst (row-major over dst->ne)
+// (ggml_compute_forward_dup, ops.cpp): types f32 <-> f16, arbitrary strides on both sides.
+// ================================================================================================
+template <typename TS, typename TD> static __device__ __forceinline__ TD cvt_elem(TS v);
+template <> __device__ __forceinline__ float    cvt_elem<float, float>(float v)          { return v; }
+template <> __device__ __forceinline__ uint16_t cvt_elem<float, uint16_t>(float v)       { return f2h(v); }
+template <> __device__ __forceinline__ float    cvt_elem<uint16_t, float>(uint16_t v)    { return h2f(v); }
+template <> __device__ __forceinline__ uint16_t cvt_elem<uint16_t, uint16_t>(uint16_t v) { return v; }
+template <> __device__ __forceinline__ int32_t  cvt_elem<int32_t, int32_t>(int32_t v)    { return v; }
+
+template <typename TS, typename TD>
+__global__ void __launch_bounds__(256) k_cpy(td4 s, td4 d) {
+    const int64_t total = s.ne[0] * s.ne[1] * s.ne[2] * s.ne[3];
+    for (int64_t t = (int64_t) blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t) gridDim.x * blockDim.x) {
+        int64_t r = t;
+        const int64_t s0 = r % s.ne[0]; r /= s.ne[0];
+        const int64_t s1 = r % s.ne[1]; r /= s.ne[1];
+        const int64_t s2 = r % s.ne[2]; const int64_t s3 = r / s.ne[2];
+        r = t;
+        const int64_t d0 = r % d.ne[0]; r /= d.ne[0];
+        const int64_t d1 = r % d.ne[1]; r /= d.ne[1];
+        const int64_t d2 = r % d.ne[2]; const int64_t d3 = r / d.ne[2];
+        const TS v = *(const TS *) (s.p + s0 * s.nb[0] + s1 * s.nb[1] + s2 * s.nb[2] + s3 * s.nb[3]);
+        *(TD *) (d.p + d0 * d.nb[0] + d1 * d.nb[1] + d2 * d.nb[2] + d3 * d.nb[3]) = cvt_elem<TS, TD>(v);
+    }
+}
+void cpy_strided(const tdesc & src, int src_type, const tdesc & dst, int dst_type, hipStream_t st) {
+    const int64_t total = src.ne[0] * src.ne[1] * src.ne[2] * src.ne[3];
+    if (total == 0) return;
+    int64_t g = (total + 255) / 256; if (g > 16384) g = 16384;
+    dim3 grid((unsigned) g), blk(256);
+    const td4 s = to_td4(src), d = to_td4(dst);
+    if      (src_type == GGML_TYPE_F32 && dst_type == GGML_TYPE_F32) k_cpy<float, float><<<grid, blk, 0, st>>>(s, d);
+    else if (src_type == GGML_TYPE_F32 && dst_type == GGML_TYPE_F16) k_cpy<float, uint16_t><<<grid, blk, 0, st>>>(s, d);
+    else if (src_type == GGML_TYPE_F16 && dst_type == GGML_TYPE_F32) k_cpy<uint16_t, float><<<grid, blk, 0, st>>>(s, d);
+    else if (src_type == GGML_TYPE_F16 && dst_type == GGML_TYPE_F16) k_cpy<uint16_t, uint16_t><<<grid, blk, 0, st>>>(s, d);
+    else if (src_type == GGML_TYPE_I32 && dst_type == GGML_TYPE_I32) k_cpy<int32_t, int32_t><<<grid, blk, 0, st>>>(s, d);
+    else { fprintf(stderr, "[mi355x] cpy: unsupported %d -> %d\n", src_type, dst_type); abort(); }
+}
+
+// ================================================================================================
+// GET_ROWS (ops.cpp:4500-4665): dst[:, i10, i11, i12] = to_float(src0[:, idx[i10,i11,i12], i11, i12])
+// ================================================================================================
+template <typename TS>
+__global__ void __launch_bounds__(256) k_get_rows(td4 s, td4 idx, td4 d) {
+    const int64_t i10 = blockIdx.x, i11 = blockIdx.y, i12 = blockIdx.z;
+    const int64_t row = *(const int32_t *) (idx.p + i10 * idx.nb[0] + i11 * idx.nb[1] + i12 * idx.nb[2]);
+    const char * sr = s.p + row * s.nb[1] + i11 * s.nb[2] + i12 * s.nb[3];
+    float *      dr = (float *) (d.p + i10 * d.nb[1] + i11 * d.nb[2] + i12 * d.nb[3]);
+    for (int64_t i = threadIdx.x; i < s.ne[0]; i += blockDim.x) dr[i] = cvt_elem<TS, float>(((const TS *) sr)[i]);
+}
+__global__ void k_get_rows_ptrs(td4 s, td4 idx, td4 d, const char ** src_rows, char ** dst_rows) {
+    const int64_t t = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t n = idx.ne[0] * idx.ne[1] * idx.ne[2];
+    if (t >= n) return;
+    const int64_t i10 = t % idx.ne[0], i11 = (t / idx.ne[0]) % idx.ne[1], i12 = t / (idx.ne[0] * idx.ne[1]);
+    const int64_t row = *(const int32_t *) (idx.p + i10 * idx.nb[0] + i11 * idx.nb[1] + i12 * idx.nb[2]);
+    src_rows[t] = s.p + row * s.nb[1] + i11 * s.nb[2] + i12 * s.nb[3];
+    dst_rows[t] = d.p + i10 * d.nb[1] + i11 * d.nb[2] + i12 * d.nb[3];
+}
+// quantised tables: one workgroup per gathered row, dequantised with the same arithmetic as dequant_rows
+__global__ void __launch_bounds__(256) k_get_rows_q(int type, td4 s, td4 idx, td4 d) {
+    const int64_t i10 = blockIdx.x, i11 = blockIdx.y, i12 = blockIdx.z;
+    const int64_t row = *(const int32_t *) (idx.p + i10 * idx.nb[0] + i11 * idx.nb[1] + i12 * idx.nb[2]);
+    const char * sr = s.p + row * s.nb[1] + i11 * s.nb[2] + i12 * s.nb[3];
+    float *      y  = (float *) (d.p + i10 * d.nb[1] + i11 * d.nb[2] + i12 * d.nb[3]);
+    const int64_t K = s.ne[0];
+    for (int64_t e = threadIdx.x; e < K; e += blockDim.x) {
+        float v;
+        if (type == GGML_TYPE_Q8_0) {
+            const block_q8_0 * b = (const block_q8_0 *) sr + e / 32;
+            v = (float) b->qs[e % 32] * h2f(b->d);
+        } else if (type == GGML_TYPE_Q4_K) {
+            const block_q4_K * b = (const block_q4_K *) sr + e / 256;
+            const int w = (int) (e % 256), sb = w / 32, l = w % 32;
+            int sc, m; q4k_scale_min(sb, b->scales, sc, m);
+            const uint8_t q = b->qs[32 * (sb >> 1) + l];
+            const int qv = (sb & 1) ? (q >> 4) : (q & 0xF);
+            v = (h2f(b->d) * (float) sc) * (float) qv - h2f(b->dmin) * (float) m;
+        } else { // Q6_K
+            const block_q6_K * b = (const block_q6_K *) sr + e / 256;
+            const int w = (int) (e % 256), n = w / 128, r = w % 128, k = r / 32, l = r % 32;
+            const uint8_t qlb = b->ql[64 * n + l + ((k & 1) ? 32 : 0)];
+            const int lo = (k >= 2) ? (qlb >> 4) : (qlb & 0xF);
+            const int hi = (b->qh[32 * n + l] >> (2 * k)) & 3;
+            const int8_t q = (int8_t) (lo | (hi << 4)) - 32;
+            v = h2f(b->d) * (float) b->scales[8 * n + l / 16 + 2 * k] * (float) q;
+        }
+        y[e] = v;
+    }
+}
+void get_rows(const tdesc & src, int src_type, const tdesc & idx, const tdesc & dst, hipStream_t st) {
+    if (idx.ne[0] * idx.ne[1] * idx.ne[2] == 0 || src.ne[0] == 0) return;
+    dim3 grid((unsigned) idx.ne[0], (unsigned) idx.ne[1], (unsigned) idx.ne[2]);
+    const td4 s = to_td4(src), i = to_td4(idx), d = to_td4(dst);
+    switch (src_type) {
+        case GGML_TYPE_F32: k_get_rows<float><<<grid, dim3(256), 0, st>>>(s, i, d); break;
+        case GGML_TYPE_I32: k_get_rows<float><<<grid, dim3(256), 0, st>>>(s, i, d); break;   // bit copy (4-byte elements)
+        case GGML_TYPE_F16: k_get_rows<uint16_t><<<grid, dim3(256), 0, st>>>(s, i, d); break;
+        case GGML_TYPE_Q8_0: case GGML_TYPE_Q4_K: case GGML_TYPE_Q6_K:
+            k_get_rows_q<<<grid, dim3(256), 0, st>>>(src_type, s, i, d); break;
+        default: fprintf(stderr, "[mi355x] get_rows: unsupported type %d\n", src_type); abort();
+    }
+}
+
+// ================================================================================================
+// SET_ROWS (ops.cpp:4739-4787): dst[:, idx[i, i02%ne11, i03%ne12], i02, i03] = from_float(src0[:, i, i02, i03])
+// (KV-cache store: f32 -> f16 RNE, 64-bit indices)
+// ================================================================================================
+template <typename TD, typename TI>
+__global__ void __launch_bounds__(256) k_set_rows(td4 s, td4 idx, td4 d) {
+    const int64_t i = blockIdx.x, i02 = blockIdx.y, i03 = blockIdx.z;
+    const int64_t i1 = (int64_t) *(const TI *) (idx.p + i * idx.nb[0] + (i02 % idx.ne[1]) * idx.nb[1] + (i03 % idx.ne[2]) * idx.nb[2]);
+    const float * sr = (const float *) (s.p + i * s.nb[1] + i02 * s.nb[2] + i03 * s.nb[3]);
+    TD *          dr = (TD *) (d.p + i1 * d.nb[1] + i02 * d.nb[2] + i03 * d.nb[3]);
+    for (int64_t c = threadIdx.x; c < s.ne[0]; c += blockDim.x) dr[c] = cvt_elem<float, TD>(sr[c]);
+}
+void set_rows(const tdesc & src, const tdesc & idx, int idx_type, const tdesc & dst, int dst_type, hipStream_t st) {
+    if (src.ne[0] * src.ne[1] * src.ne[2] * src.ne[3] == 0) return;
+    dim3 grid((unsigned) src.ne[1], (unsigned) src.ne[2], (unsigned) src.ne[3]);
+    const int bs = src.ne[0] <= 64 ? 64 : 256;
+    const td4 s = to_td4(src), i = to_td4(idx), d = to_td4(dst);
+    const bool i64 = idx_type == GGML_TYPE_I64;
+    if (dst_type == GGML_TYPE_F16) {
+        if (i64) k_set_rows<uint16_t, int64_t><<<grid, dim3(bs), 0, st>>>(s, i, d); else k_set_rows<uint16_t, int32_t><<<grid, dim3(bs), 0, st>>>(s, i, d);
+    } else if (dst_type == GGML_TYPE_F32) {
+        if (i64) k_set_rows<float, int64_t><<<grid, dim3(bs), 0, st>>>(s, i, d); else k_set_rows<float, int32_t><<<grid, dim3(bs), 0, st>>>(s, i, d);
+    } else { fprintf(stderr, "[mi355x] set_rows: unsupported dst type %d\n", dst_type); abort(); }
+}
+
+} // namespace mi

@@ -1,0 +1,280 @@
+// fattn.hip -- FLASH_ATTN_EXT for gfx950 (wave64).
+//
+// reference: ggml_compute_forward_flash_attn_ext_f16, ggml-cpu/ops.cpp:7912-8148
+//   per (query row, head):  Q -> f16 ; s_ic = (K_ic . Q) * scale (+softcap) + slope*mask_ic ; online softmax ;
+//   V accumulated with expf(s - M) ; result / S ; written permuted as dst[DV, n_head, n_q, n_seq].
+// Differences allowed by the reference's own tolerance (NMSE 5e-4, tests/test-backend-ops.cpp:5085):
+// the CPU accumulates V in f16 when V is f16 (:8069-8083); this kernel keeps f32 accumulators.
+//
+// "vec" kernel (decode and short query blocks): one workgroup of 4 waves owns R query vectors that share
+// one KV head (GQA group x a few query rows), so K and V are streamed once for the whole group instead of
+// once per head.  Waves split the KV range in 64-row tiles; a tile is staged in LDS (row stride padded by
+// 16 B -> conflict-free ds_read_b128 with lane == kv row), scores are computed lane-per-row, softmax is a
+// wave butterfly, P.V runs lane-per-dim-pair.  Tiles that are fully masked (-inf) are skipped without
+// touching K/V, which is what makes a 256-padded KV cache cheap at small depth.
+#include "../kernels.hpp"
+
+namespace mi {
+
+struct fa_dev {
+    const char * q; const char * k; const char * v; const char * mask; const float * sinks; char * dst;
+    int64_t nq, nh, nhkv, nkv, ns;                      // query rows, heads, kv heads, kv length, sequences
+    int64_t qnb1, qnb2, qnb3, knb1, knb2, knb3, vnb1, vnb2, vnb3;
+    int64_t mnb1, mnb2, mnb3, mne2, mne3;
+    int64_t dnb1, dnb2, dnb3;
+    float scale, max_bias, logit_softcap, m0, m1; uint32_t n_head_log2;
+    int gq;                                             // n_head / n_head_kv
+    int hpw;                                            // heads handled per workgroup (<= R)
+    int qpw;                                            // query rows per workgroup (R / hpw)
+};
+
+extern __shared__ __attribute__((aligned(16))) char fa_lds[];
+
+template <int D, int R>
+__global__ void __launch_bounds__(256) k_fattn_vec(fa_dev a) {
+    constexpr int RS   = D * 2 + 16;          // padded LDS row stride of a K/V tile (bytes)
+    constexpr int DPL  = D / 64;              // output dims per lane
+    constexpr int TILE = 64;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+
+    // ---- which query vectors does this workgroup own
+    const int64_t ngrp_h = (a.gq + a.hpw - 1) / a.hpw;                    // head chunks per kv head
+    const int64_t nqb    = (a.nq + a.qpw - 1) / a.qpw;                    // query blocks
+    int64_t b = blockIdx.x;
+    const int64_t qb  = b % nqb;   b /= nqb;
+    const int64_t hc  = b % ngrp_h; b /= ngrp_h;
+    const int64_t ikv = b % a.nhkv; const int64_t is3 = b / a.nhkv;
+    // r -> (query row, head)
+    int64_t r_q[R], r_h[R]; bool r_ok[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int hq = r % a.hpw, qq = r / a.hpw;
+        r_q[r] = qb * a.qpw + qq;
+        r_h[r] = ikv * a.gq + hc * a.hpw + hq;
+        r_ok[r] = qq < a.qpw && r_q[r] < a.nq && (hc * a.hpw + hq) < a.gq;
+    }
+
+    // ---- LDS carve-up
+    float * qf   = (float *) fa_lds;                                   // [R][D] queries (rounded through f16)
+    char *  tile = fa_lds + R * D * 4 + wave * (TILE * RS);            // per-wave K/V tile
+    float * pl   = (float *) (fa_lds + R * D * 4 + 4 * (TILE * RS)) + wave * (TILE * R);   // per-wave P[kv][R]
+    float * comb = (float *) (fa_lds + R * D * 4 + 4 * (TILE * RS) + 4 * TILE * R * 4);    // [4][R][D+2] merge area
+
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        for (int d = threadIdx.x; d < D; d += 256) {
+            float v = 0.0f;
+            if (r_ok[r]) v = *(const float *) (a.q + d * 4 + r_q[r] * a.qnb1 + r_h[r] * a.qnb2 + is3 * a.qnb3);
+            qf[r * D + d] = h2f(f2h(v));                                // q_to_vec_dot: f32 -> f16 (ops.cpp:8040)
+        }
+    }
+    __syncthreads();
+
+    float slope[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const uint32_t h = (uint32_t) r_h[r];
+        slope[r] = a.max_bias > 0.0f ? (h < a.n_head_log2 ? powf(a.m0, (float) (h + 1)) : powf(a.m1, (float) (2 * (h - a.n_head_log2) + 1))) : 1.0f;
+    }
+
+    float M[R], S[R], acc[R][DPL];
+#pragma unroll
+    for (int r = 0; r < R; ++r) { M[r] = -INFINITY; S[r] = 0.0f;
+#pragma unroll
+        for (int e = 0; e < DPL; ++e) acc[r][e] = 0.0f; }
+
+    const char * kbase = a.k + ikv * a.knb2 + is3 * a.knb3;
+    const char * vbase = a.v + ikv * a.vnb2 + is3 * a.vnb3;
+    const int64_t ntile = (a.nkv + TILE - 1) / TILE;
+
+    for (int64_t t = wave; t < ntile; t += 4) {
+        const int64_t kv    = t * TILE + lane;
+        const bool    kv_ok = kv < a.nkv;
+        // mask values for this lane's kv row, one per distinct query row
+        float mv[R];
+        bool any_live = false;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            float m = 0.0f;
+            if (a.mask && r_ok[r] && kv_ok) {
+                const char * mp = a.mask + r_q[r] * a.mnb1 + (r_h[r] % a.mne2) * a.mnb2 + (is3 % a.mne3) * a.mnb3;
+                m = slope[r] * h2f(((const uint16_t *) mp)[kv]);
+            }
+            if (!kv_ok || !r_ok[r]) m = -INFINITY;
+            mv[r] = m;
+            any_live |= (m != -INFINITY);
+        }
+        if (!__any(any_live)) continue;                               // whole tile masked for every query vector
+
+        // ---- stage K tile: 16-B chunks, 4 rows per wave instruction
+        constexpr int CPR = D * 2 / 16;                               // chunks per row
+#pragma unroll 4
+        for (int c = lane; c < TILE * CPR; c += 64) {
+            const int row = c / CPR, col = c % CPR;
+            int64_t kr = t * TILE + row; kr = kr < a.nkv ? kr : a.nkv - 1;
+            *(u32x4 *) (tile + row * RS + col * 16) = *(const u32x4 *) (kbase + kr * a.knb1 + col * 16);
+        }
+        // the same wave writes and then reads the tile: DS operations of one wave execute in issue order, so
+        // only the compiler has to be told not to move the reads above the writes
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        float s[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) s[r] = 0.0f;
+#pragma unroll 4
+        for (int c = 0; c < CPR; ++c) {
+            const u32x4 kk = *(const u32x4 *) (tile + lane * RS + c * 16);
+            float kf[8];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { kf[2 * e] = h2f((uint16_t) (kk[e] & 0xffff)); kf[2 * e + 1] = h2f((uint16_t) (kk[e] >> 16)); }
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const f32x4 q0 = *(const f32x4 *) (qf + r * D + c * 8);
+                const f32x4 q1 = *(const f32x4 *) (qf + r * D + c * 8 + 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { s[r] = fmaf(kf[e], q0[e], s[r]); s[r] = fmaf(kf[4 + e], q1[e], s[r]); }
+            }
+        }
+        // ---- scale, softcap, mask, online softmax (per query vector, across the 64 lanes of the tile)
+        float ms[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            float v = s[r] * a.scale;
+            if (a.logit_softcap != 0.0f) v = a.logit_softcap * tanhf(v);
+            v += mv[r];
+            if (mv[r] == -INFINITY) v = -INFINITY;
+            const float tmax = wave_max(v);
+            const float Mn   = fmaxf(M[r], tmax);
+            const float p    = (v == -INFINITY) ? 0.0f : expf(v - Mn);
+            ms[r] = (M[r] == -INFINITY) ? 0.0f : expf(M[r] - Mn);
+            if (Mn == -INFINITY) ms[r] = 1.0f;                         // nothing seen yet and nothing live: keep zeros
+            S[r] = S[r] * ms[r] + wave_sum(p);
+            M[r] = Mn;
+            pl[lane * R + r] = p;
+        }
+        // ---- stage V tile over the K tile and accumulate
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll 4
+        for (int c = lane; c < TILE * CPR; c += 64) {
+            const int row = c / CPR, col = c % CPR;
+            int64_t vr = t * TILE + row; vr = vr < a.nkv ? vr : a.nkv - 1;
+            *(u32x4 *) (tile + row * RS + col * 16) = *(const u32x4 *) (vbase + vr * a.vnb1 + col * 16);
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int e = 0; e < DPL; ++e) acc[r][e] *= ms[r];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll 4
+        for (int j = 0; j < TILE; ++j) {
+            float vf[DPL];
+            if (DPL == 2) {
+                const uint32_t w = *(const uint32_t *) (tile + j * RS + lane * 4);
+                vf[0] = h2f((uint16_t) (w & 0xffff)); vf[1] = h2f((uint16_t) (w >> 16));
+            } else {
+#pragma unroll
+                for (int e = 0; e < DPL; ++e) vf[e] = h2f(*(const uint16_t *) (tile + j * RS + (lane * DPL + e) * 2));
+            }
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const float p = pl[j * R + r];
+#pragma unroll
+                for (int e = 0; e < DPL; ++e) acc[r][e] = fmaf(p, vf[e], acc[r][e]);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+
+    // ---- merge the four waves' partial (M, S, acc) and write out
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        float * cw = comb + (wave * R + r) * (D + 2);
+#pragma unroll
+        for (int e = 0; e < DPL; ++e) cw[lane * DPL + e] = acc[r][e];
+        if (lane == 0) { cw[D] = M[r]; cw[D + 1] = S[r]; }
+    }
+    __syncthreads();
+    // wave w finalises query vectors r = w, w+4, ...
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        if ((r & 3) != wave || !r_ok[r]) continue;
+        float Mx = -INFINITY;
+        for (int w = 0; w < 4; ++w) Mx = fmaxf(Mx, comb[(w * R + r) * (D + 2) + D]);
+        float St = 0.0f, o[DPL];
+#pragma unroll
+        for (int e = 0; e < DPL; ++e) o[e] = 0.0f;
+        for (int w = 0; w < 4; ++w) {
+            const float * cw = comb + (w * R + r) * (D + 2);
+            const float Mw = cw[D];
+            const float f  = (Mw == -INFINITY) ? 0.0f : expf(Mw - Mx);
+            St += cw[D + 1] * f;
+#pragma unroll
+            for (int e = 0; e < DPL; ++e) o[e] += cw[lane * DPL + e] * f;
+        }
+        if (a.sinks) {                                                // ops.cpp:8116-8130
+            const float sk = a.sinks[r_h[r]];
+            if (sk > Mx) { const float f = expf(Mx - sk); St = St * f + 1.0f;
+#pragma unroll
+                for (int e = 0; e < DPL; ++e) o[e] *= f; }
+            else St += expf(sk - Mx);
+        }
+        const float inv = St == 0.0f ? 0.0f : 1.0f / St;
+        float * out = (float *) (a.dst + r_h[r] * a.dnb1 + r_q[r] * a.dnb2 + is3 * a.dnb3);
+#pragma unroll
+        for (int e = 0; e < DPL; ++e) out[lane * DPL + e] = o[e] * inv;
+    }
+}
+
+template <int D, int R>
+static size_t fa_lds_bytes() { return (size_t) R * D * 4 + 4 * (64 * (D * 2 + 16)) + 4 * 64 * R * 4 + 4 * R * (D + 2) * 4; }
+
+size_t fattn_scratch_bytes(const fattn_args &) { return 0; }
+
+template <int D>
+static void launch_fa(const fa_dev & a0, hipStream_t st) {
+    fa_dev a = a0;
+    // choose R (query vectors per workgroup): cover the GQA group first, then extra query rows
+    int R;
+    if (a.gq >= 8) R = 8; else if (a.gq >= 4) R = (a.nq > 1 ? 8 : 4); else if (a.gq >= 2) R = (a.nq > 2 ? 8 : (a.nq > 1 ? 4 : 2)); else R = (a.nq >= 8 ? 8 : (a.nq >= 4 ? 4 : (a.nq >= 2 ? 2 : 1)));
+    a.hpw = a.gq < R ? a.gq : R;
+    a.qpw = R / a.hpw; if (a.qpw < 1) a.qpw = 1;
+    const int64_t ngrp_h = (a.gq + a.hpw - 1) / a.hpw;
+    const int64_t nqb    = (a.nq + a.qpw - 1) / a.qpw;
+    const int64_t nblk   = nqb * ngrp_h * a.nhkv * a.ns;
+    dim3 grid((unsigned) nblk), blk(256);
+#define FA_GO(RR)                                                                                                      \
+    do {                                                                                                               \
+        const size_t lds = fa_lds_bytes<D, RR>();                                                                      \
+        if (lds > 64 * 1024) HIP_CHECK(hipFuncSetAttribute((const void *) k_fattn_vec<D, RR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds)); \
+        k_fattn_vec<D, RR><<<grid, blk, lds, st>>>(a);                                                                 \
+    } while (0)
+    switch (R) { case 1: FA_GO(1); break; case 2: FA_GO(2); break; case 4: FA_GO(4); break; default: FA_GO(8); break; }
+#undef FA_GO
+}
+
+void flash_attn_ext_f16(const fattn_args & f, hipStream_t st) {
+    fa_dev a;
+    a.q = (const char *) f.q.p; a.k = (const char *) f.k.p; a.v = (const char *) f.v.p;
+    a.mask = f.mask ? (const char *) f.mask->p : nullptr; a.sinks = f.sinks; a.dst = (char *) f.dst.p;
+    a.nq = f.q.ne[1]; a.nh = f.q.ne[2]; a.ns = f.q.ne[3]; a.nhkv = f.k.ne[2]; a.nkv = f.k.ne[1];
+    if (a.nq * a.nh * a.ns == 0) return;
+    a.qnb1 = f.q.nb[1]; a.qnb2 = f.q.nb[2]; a.qnb3 = f.q.nb[3];
+    a.knb1 = f.k.nb[1]; a.knb2 = f.k.nb[2]; a.knb3 = f.k.nb[3];
+    a.vnb1 = f.v.nb[1]; a.vnb2 = f.v.nb[2]; a.vnb3 = f.v.nb[3];
+    if (f.mask) { a.mnb1 = f.mask->nb[1]; a.mnb2 = f.mask->nb[2]; a.mnb3 = f.mask->nb[3]; a.mne2 = f.mask->ne[2]; a.mne3 = f.mask->ne[3]; }
+    else { a.mnb1 = a.mnb2 = a.mnb3 = 0; a.mne2 = a.mne3 = 1; }
+    a.dnb1 = f.dst.nb[1]; a.dnb2 = f.dst.nb[2]; a.dnb3 = f.dst.nb[3];
+    a.scale = f.scale; a.max_bias = f.max_bias; a.logit_softcap = f.logit_softcap;
+    if (a.logit_softcap != 0.0f) a.scale /= a.logit_softcap;                       // ops.cpp:7985-7987
+    a.n_head_log2 = 1u << (uint32_t) floorf(log2f((float) a.nh));
+    a.m0 = powf(2.0f, -(a.max_bias) / a.n_head_log2);
+    a.m1 = powf(2.0f, -(a.max_bias / 2.0f) / a.n_head_log2);
+    a.gq = (int) (a.nh / a.nhkv);
+    a.hpw = a.qpw = 1;
+    switch ((int) f.q.ne[0]) {
+        case 64:  launch_fa<64>(a, st); break;
+        case 128: launch_fa<128>(a, st); break;
+        default: fprintf(stderr, "[mi355x] flash_attn: unsupported head size %d\n", (int) f.q.ne[0]); abort();
+    }
+}
+
+} // namespace mi

@@ -1,0 +1,131 @@
+// quantize.hip -- on-device activation quantisers for the quantised mat-vec / mat-mul path.
+//
+// The reference CPU backend converts src1 (f32) to the weight type's `vec_dot_type` before every
+// mul_mat (ggml-cpu.c:1272-1306): Q8_K for K-quants, Q8_0 for Q8_0, F16 for F16 weights.  To make the
+// integer stages bit-identical with that oracle the device does the SAME quantisation -- not the
+// per-32 Q8_1 scheme of the CUDA backend.
+#include "../kernels.hpp"
+
+namespace mi {
+
+// ------------------------------------------------------------------------------------------------
+// Q8_K image.  One wave per 256-element block; lane l owns elements 4l..4l+3.
+//   reference: quantize_row_q8_K_ref, ggml-quants.c:2555-2592 (x86 `quantize_row_q8_K` forwards to it,
+//   ggml-cpu/arch/x86/quants.c:493-495):
+//     amax/max  : first element (lowest index) with the largest |x|   (strict '>' scan)
+//     iscale    = -127.f / max
+//     q[j]      = min(127, nearest_int(iscale * x[j]))   -- nearest_int == round-half-even (:444-449)
+//     bsums[g]  = sum of 16 consecutive q
+//     d         = 1 / iscale           (amax == 0 -> d = 0, q = 0)
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_quantize_q8k(const char * __restrict__ x, size_t xs, char * __restrict__ img,
+                                                     int64_t K, int64_t nrows, size_t img_bytes) {
+    const int     lane = threadIdx.x & 63;
+    const int64_t nb   = K / 256;
+    const int64_t blk  = (int64_t) blockIdx.x * 4 + (threadIdx.x >> 6);     // global block id
+    if (blk >= nb * nrows) return;
+    const int64_t row = blk / nb, ib = blk % nb;
+
+    const float * xr = (const float *) (x + row * xs) + ib * 256;
+    char *        im = img + row * img_bytes;
+    int8_t *      qs = (int8_t *) im + ib * 256;
+    int16_t *     bs = (int16_t *) (im + K) + ib * 16;
+    float *       ds = (float *) (im + K + K / 8) + ib;
+
+    const f32x4 v = *(const f32x4 *) (xr + 4 * lane);
+
+    // (|x|, index) arg-max with lowest-index tie-break == the reference's sequential strict-'>' scan
+    float amax = fabsf(v[0]); float mval = v[0]; int idx = 4 * lane;
+#pragma unroll
+    for (int i = 1; i < 4; ++i) {
+        const float a = fabsf(v[i]);
+        if (a > amax) { amax = a; mval = v[i]; idx = 4 * lane + i; }
+    }
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const float a2 = __shfl_xor(amax, o, 64);
+        const float m2 = __shfl_xor(mval, o, 64);
+        const int   i2 = __shfl_xor(idx, o, 64);
+        if (a2 > amax || (a2 == amax && i2 < idx)) { amax = a2; mval = m2; idx = i2; }
+    }
+
+    if (amax == 0.0f) {                  // all-zero block (also catches -0.0f)
+        *(uint32_t *) (qs + 4 * lane) = 0u;
+        if ((lane & 3) == 0) bs[lane >> 2] = 0;
+        if (lane == 0) *ds = 0.0f;
+        return;
+    }
+
+    const float iscale = -127.0f / mval;
+    int q[4]; int s = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float p = iscale * v[i];               // one rounding, like the C source (no FMA with the magic add)
+        int r = (int) __builtin_rintf(p);            // round-half-even == nearest_int()
+        r = r > 127 ? 127 : r;
+        q[i] = r; s += r;
+    }
+    *(uint32_t *) (qs + 4 * lane) = (uint32_t) (q[0] & 0xff) | ((uint32_t) (q[1] & 0xff) << 8) |
+                                    ((uint32_t) (q[2] & 0xff) << 16) | ((uint32_t) (q[3] & 0xff) << 24);
+    s += __shfl_xor(s, 1, 64);
+    s += __shfl_xor(s, 2, 64);
+    if ((lane & 3) == 0) bs[lane >> 2] = (int16_t) s;
+    if (lane == 0) *ds = 1.0f / iscale;
+}
+
+void quantize_q8k_image(const float * x, size_t xs, void * img, int64_t K, int64_t nrows, hipStream_t st) {
+    const int64_t nblk = K / 256 * nrows;
+    if (nblk == 0) return;
+    k_quantize_q8k<<<dim3((unsigned) ((nblk + 3) / 4)), dim3(256), 0, st>>>((const char *) x, xs, (char *) img, K, nrows, q8k_image_bytes(K));
+}
+
+// ------------------------------------------------------------------------------------------------
+// Q8_0 image.  32 lanes per 32-element block (two blocks per wave).
+//   reference (what the x86 CPU backend actually runs): quantize_row_q8_0, ggml-cpu/arch/x86/quants.c:290-345
+//     d  = amax / 127 -> stored as f16        id = amax != 0 ? 127 / amax : 0
+//     q  = round-half-even(x * id)
+//   (the portable quantize_row_q8_0_ref, ggml-quants.c:199-222, uses id = 1/d and roundf; the oracle that
+//   parity is defined against is the compiled x86 backend, so its arithmetic is the one restated here.)
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_quantize_q80(const char * __restrict__ x, size_t xs, char * __restrict__ img,
+                                                     int64_t K, int64_t nrows, size_t img_bytes) {
+    const int64_t nb  = K / 32;
+    const int64_t blk = (int64_t) blockIdx.x * 8 + (threadIdx.x >> 5);
+    if (blk >= nb * nrows) return;
+    const int     l   = threadIdx.x & 31;
+    const int64_t row = blk / nb, ib = blk % nb;
+    const float   v   = ((const float *) (x + row * xs))[ib * 32 + l];
+    float amax = fabsf(v);
+#pragma unroll
+    for (int o = 1; o < 32; o <<= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 64));
+    const float d  = amax / 127.0f;
+    const float id = amax != 0.0f ? 127.0f / amax : 0.0f;
+    const int   q  = (int) __builtin_rintf(v * id);
+    char * im = img + row * img_bytes;
+    ((int8_t *) im)[ib * 32 + l] = (int8_t) q;
+    if (l == 0) ((float *) (im + K))[ib] = h2f(f2h(d));
+}
+
+void quantize_q80_image(const float * x, size_t xs, void * img, int64_t K, int64_t nrows, hipStream_t st) {
+    const int64_t nblk = K / 32 * nrows;
+    if (nblk == 0) return;
+    k_quantize_q80<<<dim3((unsigned) ((nblk + 7) / 8)), dim3(256), 0, st>>>((const char *) x, xs, (char *) img, K, nrows, q80_image_bytes(K));
+}
+
+// ------------------------------------------------------------------------------------------------
+// f32 -> f16 rows (RNE), the F16 weights' vec_dot_type conversion (ggml_cpu_fp32_to_fp16)
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_f32_to_f16_rows(const char * __restrict__ x, size_t xs, char * __restrict__ y, size_t ys, int64_t K, int64_t nrows) {
+    const int64_t row = blockIdx.y;
+    const float * xr = (const float *) (x + row * xs);
+    uint16_t *    yr = (uint16_t *) (y + row * ys);
+    for (int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x; i < K; i += (int64_t) gridDim.x * blockDim.x) yr[i] = f2h(xr[i]);
+}
+
+void convert_f32_f16_rows(const float * x, size_t xs, uint16_t * y, size_t ys, int64_t K, int64_t nrows, hipStream_t st) {
+    if (K == 0 || nrows == 0) return;
+    unsigned gx = (unsigned) ((K + 255) / 256); if (gx > 64) gx = 64;
+    k_f32_to_f16_rows<<<dim3(gx, (unsigned) nrows), dim3(256), 0, st>>>((const char *) x, xs, (char *) y, ys, K, nrows);
+}
+
+} // namespace mi
