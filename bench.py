@@ -1,0 +1,216 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the MI355X ggml backend (contract: see the repo prompt / DESIGN.md).
+
+Metric (BASELINE.json): llama-bench tg128-style decode tokens/s, Qwen3-8B Q4_K_M shapes, batch 1, per GPU
+replica.  A "step" = one decoded token = one `graph_compute` of the llm_build_qwen3 decode graph (36 layers +
+lm head, 4670.5 MB of quantised weights streamed from HBM) submitted through the ggml backend C-ABI of
+libggml-mi355x.so, plus the per-token input upload and logits read-back that llama_decode performs.
+Weights / KV cache are resident in HBM before the timed region.  N > 1: N independent replicas (one
+process per GPU, no data-path collective -- decode of one sequence does not shard).
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import importlib.util
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
+
+
+def load_pkg():
+    name = "llama_cpp_omni_amd"
+    if name in sys.modules:
+        return sys.modules[name]
+    d = os.path.join(ROOT, "llama.cpp-omni_amd")
+    spec = importlib.util.spec_from_file_location(name, os.path.join(d, "__init__.py"), submodule_search_locations=[d])
+    m = importlib.util.module_from_spec(spec)
+    sys.modules[name] = m
+    spec.loader.exec_module(m)
+    return m
+
+
+class Decoder:
+    """llama-bench test_gen analogue: n_gen x { decode(1 token); synchronize } at growing depth."""
+
+    def __init__(self, pkg, be, cfg, types, n_ctx, n_kv, flash_attn=True, seed=1234, share=True, host_copy=False, pinned=True):
+        from llama_cpp_omni_amd import qwen3
+        self.be, self.n_kv = be, n_kv
+        self.model = qwen3.Model(be, cfg, types, n_ctx=n_ctx, seed=seed, share_layer_bytes=share, flash_attn=flash_attn, host_copy=host_copy)
+        self.g, self.I, self.logits = self.model.build(1, n_kv)
+        self.graph = self.g.graph()
+        E, V = cfg["n_embd"], cfg["n_vocab"]
+        self.fa = flash_attn
+        alloc = (lambda n: be.host_array(n)) if pinned else (lambda n: np.empty(n, np.uint8))
+        self.h_embd = alloc(E * 4).view(np.float32)
+        self.h_pos = alloc(4).view(np.int32)
+        self.h_idx = alloc(8).view(np.int64)
+        msz = 2 if flash_attn else 4
+        self.h_mask = alloc(n_kv * msz).view(np.float16 if flash_attn else np.float32)   # row 0 of the padded mask
+        self.h_logits = alloc(V * 4).view(np.float32)
+        rng = np.random.default_rng(seed + 1)
+        self.embd_pool = (rng.standard_normal((64, E)) * 1.0).astype(np.float32)
+        # rows 1..63 of the padded mask stay -inf for the whole run
+        npad = self.I["kq_mask"].ne[1]
+        full = np.full((npad, n_kv), -np.inf, dtype=np.float16 if flash_attn else np.float32)
+        be.tensor_set(self.I["kq_mask"], full)
+
+    def step(self, pos, fetch_logits=True):
+        be, I = self.be, self.I
+        self.h_embd[:] = self.embd_pool[pos % 64]
+        self.h_pos[0] = pos
+        self.h_idx[0] = pos
+        self.h_mask[:] = -np.inf
+        self.h_mask[: pos + 1] = 0.0
+        be.tensor_set_async(I["inp_embd"], self.h_embd)
+        be.tensor_set_async(I["inp_pos"], self.h_pos)
+        be.tensor_set_async(I["k_idxs"], self.h_idx)
+        be.tensor_set_async(I["v_idxs"], self.h_idx)
+        be.tensor_set_async(I["kq_mask"], self.h_mask)
+        be.graph_compute(self.graph)
+        if fetch_logits:
+            be.tensor_get_async(self.logits, self.h_logits)
+        be.synchronize()
+
+
+def cpu_baseline(pkg, cfg, types, n_kv, seconds_budget=20.0):
+    """Reference CPU backend (oracle/_ref, built from /root/reference sources) on the SAME decode graph,
+    timed on this box's host cores for a bounded sample."""
+    try:
+        sys.path.insert(0, ROOT)
+        from oracle.ref_backend import make_ref_cpu_backend, ref_available
+        if not ref_available():
+            return None
+        cores = os.cpu_count() or 1
+        try:  # physical cores: unique (package, core) pairs
+            seen = set()
+            for c in os.listdir("/sys/devices/system/cpu"):
+                p = f"/sys/devices/system/cpu/{c}/topology"
+                if c.startswith("cpu") and c[3:].isdigit() and os.path.exists(p + "/core_id"):
+                    seen.add((open(p + "/physical_package_id").read().strip(), open(p + "/core_id").read().strip()))
+            if seen:
+                cores = len(seen)
+        except Exception:
+            pass
+        threads = min(cores, 64)
+        os.environ.setdefault("OMP_NUM_THREADS", str(threads))
+        be = make_ref_cpu_backend(pkg, threads)
+        dec = Decoder(pkg, be, cfg, types, n_ctx=n_kv, n_kv=n_kv, flash_attn=True, pinned=False)
+        dec.step(0)                                              # warm-up (page-in, thread pool)
+        t0 = time.perf_counter()
+        n = 0
+        while n < 128 and (time.perf_counter() - t0) < seconds_budget:
+            dec.step(1 + n)
+            n += 1
+        dt = time.perf_counter() - t0
+        be.close()
+        return {"value": round(n / dt, 3), "unit": "tok/s", "cores": threads, "kind": "reference",
+                "sample": f"{n} decode steps of the same Qwen3-8B Q4_K_M graph on the reference ggml CPU backend (oracle/_ref, x86-64-v3 build), {threads} OpenMP threads"}
+    except Exception as e:  # the baseline is a reported extra, never a reason to lose the GPU number
+        return {"value": None, "unit": "tok/s", "cores": 0, "kind": "reference", "sample": f"failed: {e!r}"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=128)
+    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--tiny", action="store_true", help="tiny shapes (plumbing check)")
+    ap.add_argument("--no-fa", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    pkg = load_pkg()
+    from llama_cpp_omni_amd import qwen3
+    be = pkg.backend(local_rank if world > 1 else 0)
+    cfg = qwen3.TINY if args.tiny else qwen3.QWEN3_8B
+    types = qwen3.q4_k_m_types(cfg)
+    n_kv = 256                                                     # llama pads the visible KV length to 256 with FA
+    n_ctx = max(512, ((args.steps + args.warmup + 8 + 255) // 256) * 256)
+    n_kv = min(n_ctx, ((args.steps + args.warmup + 8 + 255) // 256) * 256)
+    dec = Decoder(pkg, be, cfg, types, n_ctx=n_ctx, n_kv=n_kv, flash_attn=not args.no_fa)
+    wbytes = dec.model.weight_bytes()
+
+    def barrier():
+        be.synchronize()
+        if dist is not None:
+            import torch
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    pos = 0
+    for _ in range(args.warmup):
+        dec.step(pos); pos += 1
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        dec.step(pos); pos += 1
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        import torch
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    replays = be.get_stat("graph_replays")
+    kernels = be.get_stat("kernels_last_graph")
+
+    # ---- dominant kernel (Q4_K mat-vec) live timing: same decode step, eager, HIP events around every launch
+    roof = None
+    if rank == 0:
+        be.set_option("profile", 1)
+        be.set_option("reset_stats", 1)
+        for _ in range(4):
+            dec.step(pos); pos += 1
+        us, n, by = be.get_stat("prof_mmv_q4k_us"), be.get_stat("prof_mmv_q4k_n"), be.get_stat("prof_mmv_q4k_bytes")
+        us6, n6, by6 = be.get_stat("prof_mmv_q6k_us"), be.get_stat("prof_mmv_q6k_n"), be.get_stat("prof_mmv_q6k_bytes")
+        be.set_option("profile", 0)
+        if n > 0:
+            ach = by / us / 1e3                                      # bytes/us -> GB/s
+            roof = {"bound": "hbm", "kernel": "k_mmv_q4k (Q4_K x Q8_K mat-vec, all decode shapes)", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                    "bytes_per_launch": round(by / n), "avg_launch_us": round(us / n, 3), "launches_per_step": int(n / 4),
+                    "q6k": {"achieved": round(by6 / us6 / 1e3, 1) if us6 else None, "avg_launch_us": round(us6 / n6, 3) if n6 else None,
+                            "bytes_per_launch": round(by6 / n6) if n6 else None}}
+
+    if rank == 0:
+        tok_s = world * args.steps / dt
+        out = {
+            "metric": "llama-bench tg128 tok/s (decode, batch 1), Qwen3-8B Q4_K_M" if not args.tiny else "decode tok/s (tiny plumbing config)",
+            "value": round(tok_s, 2), "unit": "tok/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "q4_K/q6_K weights x q8_K activations (int8 dot, f32 accumulate)", "data": "synthetic",
+            "config": {"workload": "Qwen3-8B Q4_K_M text-only decode, batch=1, 1xMI355X (mul_mat_vec_q path)" if not args.tiny else "tiny",
+                       "n_layer": cfg["n_layer"], "n_embd": cfg["n_embd"], "n_ff": cfg["n_ff"], "n_vocab": cfg["n_vocab"], "n_kv": n_kv,
+                       "flash_attn": not args.no_fa, "weight_bytes_per_token": wbytes, "parallelism": f"replicas x{world} (no collective)",
+                       "graph_replays": replays, "kernels_per_token": kernels},
+            "hbm_frac_whole_step": round(wbytes * (args.steps / dt) / 1e9 / HBM_PEAK_GBS, 4),
+            "roofline": roof,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(pkg, cfg, types, n_kv)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -407,7 +407,7 @@ __global__ void __launch_bounds__(256) k_mmv_f(const char * __restrict__ W, size
                         for (int k = 0; k < 4; ++k) { w[r][2 * k] = h2f((uint16_t) (v[k] & 0xffff)); w[r][2 * k + 1] = h2f((uint16_t) (v[k] >> 16)); }
                     } else {
 #pragma unroll
-                        for (int k = 0; k < 4; ++k) w[r][k] = __builtin_bit_cast(float, v[k]);
+                        for (int k = 0; k < 4; ++k) { const uint32_t bits = v[k]; w[r][k] = __uint_as_float(bits); }   // (bit_cast on a vector element mis-selects element 0)
                     }
                 } else {
 #pragma unroll
@@ -536,7 +536,7 @@ void mmv_q8_0(const mmv_args & a0, hipStream_t st) {
     if (a0.nrows == 0 || a0.ncols == 0) return;
     const size_t ib = q80_image_bytes(a0.K);
     split_cols(a0, ib, [&](const mmv_args & a) {
-        mmv_kernel_t k; int rows = 2;
+        mmv_kernel_t k = nullptr; int rows = 2;
         switch (a.ncols) {
             case 1: k = k_mmv_q80<1, 2>; break;
             case 2: k = k_mmv_q80<2, 2>; break;

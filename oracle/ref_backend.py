@@ -1,0 +1,72 @@
+"""oracle/ref_backend.py -- TEST INFRASTRUCTURE ONLY (never imported by the product package).
+
+Drives the REAL reference CPU backend (oracle/_ref/libggml-ref.so, built from the sources under
+/root/reference by oracle/Makefile.ref) through the same plug-in vtables and the same Python graph mirror
+as the MI355X backend, so a graph can be executed on both and compared node for node -- what the
+reference's tests/test-backend-ops.cpp does with ggml_backend_compare_graph_backend (ggml-backend.cpp:2006).
+
+Used by: tests/ (parity checker) and bench.py's `cpu_baseline` leg ("kind": "reference").
+"""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REF_LIB = os.path.join(HERE, "_ref", "libggml-ref.so")
+
+
+def ref_available():
+    return os.path.exists(REF_LIB)
+
+
+_REF = None
+
+
+def ref_lib():
+    global _REF
+    if _REF is None:
+        if not ref_available():
+            raise RuntimeError(f"{REF_LIB} missing: run `make -f oracle/Makefile.ref` where /root/reference exists")
+        lib = C.CDLL(REF_LIB, mode=C.RTLD_GLOBAL)
+        lib.ggml_backend_cpu_init.restype = C.c_void_p
+        lib.ggml_backend_cpu_buffer_type.restype = C.c_void_p
+        lib.ggml_backend_cpu_set_n_threads.argtypes = [C.c_void_p, C.c_int]
+        lib.ggml_backend_buffer_free.argtypes = [C.c_void_p]
+        lib.ggml_backend_free.argtypes = [C.c_void_p]
+        _REF = lib
+    return _REF
+
+
+def make_ref_cpu_backend(pkg, n_threads=None):
+    """pkg: the loaded llama.cpp-omni_amd package (for its ctypes mirror classes)."""
+    lib = ref_lib()
+
+    class RefCpuBackend(pkg.Backend):
+        def __init__(self):
+            self.lib = None
+            self.ref = lib
+            be = lib.ggml_backend_cpu_init()
+            if n_threads:
+                lib.ggml_backend_cpu_set_n_threads(be, int(n_threads))
+            self._attach(be, lib.ggml_backend_cpu_buffer_type(), None)
+
+        def set_n_threads(self, n):
+            self.ref.ggml_backend_cpu_set_n_threads(self.be, int(n))
+
+        def name(self):
+            return "CPU(reference)"
+
+        def free_buffer(self, b):
+            self._buffers.remove(b)
+            self.ref.ggml_backend_buffer_free(b)
+
+        def set_option(self, key, value):
+            return -1
+
+        def close(self):
+            if self.be:
+                for b in list(self._buffers):
+                    self.free_buffer(b)
+                self.ref.ggml_backend_free(self.be)
+                self.be = None
+
+    return RefCpuBackend()
