@@ -55,6 +55,11 @@ GGML_MI355X_API int    mi355x_set_option(struct ggml_backend * backend, const ch
  * "prof_mmv_q4k_us", "prof_mmv_q4k_n", "prof_mmv_q4k_bytes", .... Returns -1 if unknown. */
 GGML_MI355X_API double mi355x_get_stat(struct ggml_backend * backend, const char * key);
 
+/* test hook: run the on-device activation quantiser the MUL_MAT path uses (kind 0: Q8_K image, 1: Q8_0 image,
+ * layouts in csrc/common.hpp) on `nrows` host rows of K floats and return the images to host memory, so the integer
+ * stage can be compared bit-for-bit with the reference's quantize_row_q8_K / quantize_row_q8_0.  Returns bytes per image. */
+GGML_MI355X_API long   mi355x_debug_quantize(struct ggml_backend * backend, int kind, const float * host_x, long K, long nrows, void * host_images);
+
 /* standalone harness only (no libggml-base in the process): what ggml_backend_buffer_free does
  * (reference ggml/src/ggml-backend.cpp:108-117): iface.free_buffer, then delete the object. */
 GGML_MI355X_API void   mi355x_host_buffer_free(struct ggml_backend_buffer * buffer);

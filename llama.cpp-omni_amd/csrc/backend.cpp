@@ -289,6 +289,7 @@ static void * reg_proc(ggml_backend_reg_t, const char * name) {
     if (!strcmp(name, "mi355x_timed_event_free"))    return (void *) mi355x_timed_event_free;
     if (!strcmp(name, "mi355x_set_option"))          return (void *) mi355x_set_option;
     if (!strcmp(name, "mi355x_get_stat"))            return (void *) mi355x_get_stat;
+    if (!strcmp(name, "mi355x_debug_quantize"))      return (void *) mi355x_debug_quantize;
     return nullptr;
 }
 static const ggml_backend_reg_i k_reg_iface = { reg_name, reg_dev_count, reg_get_dev, reg_proc };
@@ -340,6 +341,23 @@ void mi355x_host_buffer_free(ggml_backend_buffer_t b) {
     if (!b) return;
     if (b->iface.free_buffer) b->iface.free_buffer(b);
     delete b;
+}
+
+long mi355x_debug_quantize(ggml_backend_t backend, int kind, const float * host_x, long K, long nrows, void * host_images) {
+    mi::backend_ctx * c = (mi::backend_ctx *) backend->context;
+    HIP_CHECK(hipSetDevice(c->device));
+    const size_t img = kind == 0 ? q8k_image_bytes(K) : q80_image_bytes(K);
+    float * dx = nullptr; void * di = nullptr;
+    HIP_CHECK(hipMalloc((void **) &dx, (size_t) K * nrows * 4));
+    HIP_CHECK(hipMalloc(&di, img * nrows));
+    HIP_CHECK(hipMemcpyAsync(dx, host_x, (size_t) K * nrows * 4, hipMemcpyHostToDevice, c->stream));
+    HIP_CHECK(hipMemsetAsync(di, 0, img * nrows, c->stream));
+    if (kind == 0) mi::quantize_q8k_image(dx, (size_t) K * 4, di, K, nrows, c->stream);
+    else           mi::quantize_q80_image(dx, (size_t) K * 4, di, K, nrows, c->stream);
+    HIP_CHECK(hipMemcpyAsync(host_images, di, img * nrows, hipMemcpyDeviceToHost, c->stream));
+    HIP_CHECK(hipStreamSynchronize(c->stream));
+    HIP_CHECK(hipFree(dx)); HIP_CHECK(hipFree(di));
+    return (long) img;
 }
 
 void * mi355x_timed_event_new(void) { hipEvent_t e; HIP_CHECK(hipEventCreate(&e)); return e; }

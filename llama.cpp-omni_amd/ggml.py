@@ -176,6 +176,8 @@ def load_library():
         lib.mi355x_set_option.argtypes = [_vp, C.c_char_p, C.c_long]
         lib.mi355x_get_stat.argtypes = [_vp, C.c_char_p]
         lib.mi355x_get_stat.restype = C.c_double
+        lib.mi355x_debug_quantize.argtypes = [_vp, C.c_int, _vp, C.c_long, C.c_long, _vp]
+        lib.mi355x_debug_quantize.restype = C.c_long
         _LIB = lib
     return _LIB
 

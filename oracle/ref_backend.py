@@ -32,6 +32,7 @@ def ref_lib():
         lib.ggml_backend_cpu_set_n_threads.argtypes = [C.c_void_p, C.c_int]
         lib.ggml_backend_buffer_free.argtypes = [C.c_void_p]
         lib.ggml_backend_free.argtypes = [C.c_void_p]
+        lib.ggml_cpu_init()          # fills the f16->f32 lookup table the x86 vec_dot kernels read (ggml-cpu.c:3540-3560)
         _REF = lib
     return _REF
 

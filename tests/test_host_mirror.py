@@ -1,0 +1,95 @@
+"""CPU tests of the host-side mirror (ctypes graph builder + Qwen3 graph): the graphs it emits are executed by the
+REAL reference CPU backend (oracle/_ref) and must reproduce the committed golden vectors -- which validates the
+mirror, the fixtures and the generator script at once.  Plus the world_size-2 gloo test of bench.py's replica logic."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, nmse
+
+
+def tiny_weights(tm):
+    w = {}
+    for k in tm.files:
+        if k.startswith("w_"):
+            _, il, name = k.split("_", 2)
+            w[(int(il), name)] = tm[k]
+    return w
+
+
+def run_tiny(pkg, backend, tm, steps, flash_attn=True):
+    from llama_cpp_omni_amd import qwen3
+    cfg = qwen3.TINY
+    mdl = qwen3.Model(backend, cfg, qwen3.q4_k_m_types(cfg), n_ctx=256, flash_attn=flash_attn, weights=tiny_weights(tm))
+    table = tm["table"].view(np.float16)
+    g, I, logits = mdl.build(1, 256)
+    gr = g.graph()
+    tok, toks, l = 1, [], None
+    for step in range(steps):
+        mdl.set_inputs(I, table[tok].astype(np.float32)[None, :], step, 256)
+        backend.graph_compute(gr)
+        l = backend.tensor_get(logits).copy()
+        tok = int(np.argmax(l))
+        toks.append(tok)
+    g.free()
+    mdl.wctx.free()
+    return toks, l
+
+
+def test_tiny_model_fixture_reproduces_on_reference_cpu(pkg, ref_be, golden):
+    tm = golden["tiny_model"]
+    toks, l = run_tiny(pkg, ref_be, tm, 32)
+    assert toks == list(tm["tokens"])
+    assert nmse(l, tm["final_logits"]) < 1e-10
+
+
+def test_graph_node_sequence_matches_llm_build_qwen3(pkg, ref_be):
+    """Per layer the reference emits: norm,mul, 3 mul_mat, (q) norm,mul,rope, (k) norm,mul,rope, 2 set_rows, fattn, mul_mat, add,
+    norm,mul, 2 mul_mat, glu, mul_mat, add   -- plus views/reshapes/permutes."""
+    from llama_cpp_omni_amd import qwen3
+    OP = pkg.OP
+    cfg = qwen3.TINY
+    mdl = qwen3.Model(ref_be, cfg, qwen3.q4_k_m_types(cfg), n_ctx=256)
+    g, I, logits = mdl.build(1, 256)
+    ops = [n.t.op for n in g.nodes if n.t.op not in (OP.VIEW, OP.RESHAPE, OP.PERMUTE, OP.TRANSPOSE, OP.NONE)]
+    layer = [OP.RMS_NORM, OP.MUL, OP.MUL_MAT, OP.MUL_MAT, OP.MUL_MAT, OP.RMS_NORM, OP.MUL, OP.ROPE, OP.RMS_NORM, OP.MUL, OP.ROPE,
+             OP.SET_ROWS, OP.SET_ROWS, OP.FLASH_ATTN_EXT, OP.MUL_MAT, OP.ADD, OP.RMS_NORM, OP.MUL, OP.MUL_MAT, OP.MUL_MAT, OP.GLU, OP.MUL_MAT, OP.ADD]
+    assert ops == layer * cfg["n_layer"] + [OP.RMS_NORM, OP.MUL, OP.MUL_MAT]
+    assert len(layer) == 23
+    g.free()
+    mdl.wctx.free()
+
+
+def test_q4_k_m_type_map():
+    from conftest import load_pkg
+    load_pkg()
+    from llama_cpp_omni_amd import qwen3
+    t = qwen3.q4_k_m_types(qwen3.QWEN3_8B)
+    hi = [i for i in range(36) if t[i]["ffn_down"] == 14]
+    assert hi == [0, 1, 2, 3, 6, 9, 12, 15, 18, 21, 24, 27, 30, 31, 32, 33, 34, 35]
+    assert all(t[i]["attn_v"] == t[i]["ffn_down"] for i in range(36)) and t["output"] == 14
+
+
+def test_bench_replica_logic_world2_gloo(tmp_path):
+    """bench.py's N>1 path = independent replicas + barrier + MAX-reduce of the elapsed time.  Exercised here with
+    two gloo ranks on CPU (the GPU part is replaced by a sleep of different length per rank)."""
+    script = tmp_path / "w2.py"
+    script.write_text(
+        "import os, time, torch, torch.distributed as dist\n"
+        "dist.init_process_group(backend='gloo')\n"
+        "rank = dist.get_rank(); world = dist.get_world_size()\n"
+        "dist.barrier(); t0 = time.perf_counter(); time.sleep(0.05 * (rank + 1)); dist.barrier(); dt = time.perf_counter() - t0\n"
+        "t = torch.tensor([0.05 * (rank + 1)], dtype=torch.float64); dist.all_reduce(t, op=dist.ReduceOp.MAX)\n"
+        "steps = 10; value = world * steps / float(t.item())\n"
+        "if rank == 0: print('VALUE', value, float(t.item()))\n"
+        "dist.destroy_process_group()\n")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29533", str(script)], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("VALUE")][0].split()
+    assert abs(float(line[2]) - 0.10) < 1e-9                      # MAX over ranks
+    assert abs(float(line[1]) - 2 * 10 / 0.10) < 1e-6             # whole-job aggregate = units of all ranks / max time

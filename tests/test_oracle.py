@@ -1,0 +1,108 @@
+"""CPU tests: the C restatement (oracle/omni_oracle.c) is pinned against golden vectors produced by the REAL
+reference (tests/golden/*.npz, generator oracle/make_golden.py) -- bit-exact for every integer / byte stage,
+tight tolerances for float stages -- and, when oracle/_ref is present, against the live reference library."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from conftest import nmse
+from oracle import oracle_py as orc
+
+TYPES = {"q4_K": orc.Q4_K, "q6_K": orc.Q6_K, "q8_0": orc.Q8_0}
+
+
+@pytest.mark.parametrize("name", list(TYPES))
+def test_dequant_bit_exact_vs_reference(golden, name):
+    g = golden["quant"]
+    got = orc.dequantize(TYPES[name], g[f"{name}_blocks"], 12288)
+    assert np.array_equal(got.view(np.uint32), g[f"{name}_deq"].view(np.uint32))
+
+
+def test_quantize_q8_K_bit_exact_vs_reference(golden):
+    g = golden["quant"]
+    assert np.array_equal(orc.quantize_q8_K(g["y"]), g["y_q8_K"])
+    # edge rows: all-zero block, |x| tie with opposite signs (first one wins), mirrored block, denormal-scale block
+    assert np.array_equal(orc.quantize_q8_K(g["edge"]), g["edge_q8_K"])
+
+
+def test_quantize_q8_0_bit_exact_vs_reference_x86_path(golden):
+    g = golden["quant"]
+    assert np.array_equal(orc.quantize_q8_0(g["y"]), g["y_q8_0"])
+
+
+@pytest.mark.parametrize("name", list(TYPES))
+def test_vec_dot_vs_reference(golden, name):
+    g = golden["quant"]
+    act = g["y_q8_0"] if name == "q8_0" else g["y_q8_K"]
+    for k, want in zip((256, 4096, 12288), g[f"{name}_dots"]):
+        got = orc.vec_dot(TYPES[name], k, g[f"{name}_blocks"], act)
+        # integer sub-sums are exact; only the order of the f32 additions differs (generic C vs AVX2 lanes)
+        assert abs(got - want) <= 2e-6 * max(1.0, abs(want)), (k, got, want)
+
+
+def test_f16_conversion_exhaustive():
+    h = np.arange(65536, dtype=np.uint16)
+    f = h.view(np.float16).astype(np.float32)
+    ok = ~np.isnan(f)
+    back = orc.f32_to_f16(f)
+    assert np.array_equal(back[ok], h[ok])
+    rng = np.random.default_rng(0)
+    x = np.concatenate([rng.standard_normal(200000) * 10.0 ** rng.integers(-9, 6, 200000), [65504, 65519.9, 65520, 1e-8, 6e-8, -0.0]]).astype(np.float32)
+    with np.errstate(over="ignore"):
+        want = x.astype(np.float16).view(np.uint16)
+    assert np.array_equal(orc.f32_to_f16(x), want)
+
+
+def test_ops_vs_reference_cpu_backend(golden):
+    g = golden["ops"]
+    for tag in ("rms4096", "rms128"):
+        got = orc.rms_norm(g[f"{tag}_x"], 1e-6) * g[f"{tag}_w"]
+        assert np.abs(got - g[f"{tag}_y"]).max() <= 2e-6 * np.abs(g[f"{tag}_y"]).max()
+    assert nmse(orc.rope(g["rope_neox_x"], g["rope_neox_pos"], 128, 2, 40960, 1e6), g["rope_neox_y"]) < 1e-10
+    assert nmse(orc.rope(g["rope_norm_x"], g["rope_norm_pos"], 128, 0, 40960, 1e4), g["rope_norm_y"]) < 1e-10
+    m = g["softmax_mask"].astype(np.float32)
+    x = g["softmax_x"]
+    got = np.stack([orc.soft_max(x[b], m[:4], 0.0883883) for b in range(x.shape[0])])
+    assert nmse(got, g["softmax_y"]) < 1e-10
+    assert nmse(orc.swiglu(g["swiglu_a"], g["swiglu_b"]), g["swiglu_y"]) < 1e-10
+    exp = np.zeros((16, 1024), np.uint16)
+    exp[g["setrows_idx"]] = orc.f32_to_f16(g["setrows_src"])
+    assert np.array_equal(exp, g["setrows_tab"])
+    for name, ty in (("q4_K", orc.Q4_K), ("q6_K", orc.Q6_K), ("q8_0", orc.Q8_0), ("f16", orc.F16)):
+        for (M, K, N) in ((16, 256, 1), (64, 1024, 3)):
+            tag = f"mm_{name}_{M}x{K}x{N}"
+            w = g[tag + "_w"]
+            W = w.view(np.uint8).reshape(M, -1)
+            got = orc.mul_mat(ty, W, g[tag + "_x"])
+            assert nmse(got, g[tag + "_y"]) < 1e-9, tag
+
+
+def test_flash_attn_vs_reference_cpu_backend(golden):
+    g = golden["ops"]
+    for nkv in (256, 2048):
+        q, k, v, m, y = (g[f"fa{nkv}_{n}"] for n in ("q", "k", "v", "mask", "y"))
+        for h in range(8):
+            for iq in range(2):
+                got = orc.flash_attn_row(q[h, iq], k[h // 4], v[h // 4], m[iq], 1.0 / np.sqrt(128.0))
+                assert nmse(got, y[iq, h]) < 1e-6, (nkv, h, iq)
+
+
+def test_oracle_vs_live_reference_library(golden):
+    """Where oracle/_ref exists, run the reference's own functions on fresh random data and compare."""
+    from oracle.ref_backend import ref_available, ref_lib
+    if not ref_available():
+        pytest.skip("oracle/_ref not built")
+    ref = ref_lib()
+    rng = np.random.default_rng(99)
+    x = (rng.standard_normal(8192) * rng.choice([0.01, 1.0, 100.0], 8192)).astype(np.float32)
+    x[256:512] = 0
+    out = np.zeros(8192 // 256 * 292, np.uint8)
+    ref.quantize_row_q8_K(x.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p), C.c_int64(8192))
+    mine = orc.quantize_q8_K(x)
+    o, m = out.reshape(-1, 292).copy(), mine.reshape(-1, 292).copy()
+    o[1, 260:] = 0          # zero block: reference leaves bsums stale
+    assert np.array_equal(o, m)
+    out0 = np.zeros(8192 // 32 * 34, np.uint8)
+    ref.quantize_row_q8_0(x.ctypes.data_as(C.c_void_p), out0.ctypes.data_as(C.c_void_p), C.c_int64(8192))
+    assert np.array_equal(out0, orc.quantize_q8_0(x))
