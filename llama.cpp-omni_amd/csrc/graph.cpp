@@ -16,6 +16,7 @@
 #include "ggml_util.hpp"
 #include "kernels.hpp"
 #include "../../include/ggml-mi355x.h"
+#include <unordered_map>
 
 namespace mi {
 
@@ -52,7 +53,12 @@ static size_t act_image_bytes(act_kind k, int64_t K) {
 struct exec_state {
     backend_ctx * c;
     hipStream_t   st;
-    long          n_kernels = 0;
+    ggml_cgraph * g = nullptr;
+    long          n_kernels = 0, n_fused = 0;
+    std::vector<uint8_t> done;                                           // node already covered by a fused item
+    std::unordered_map<const ggml_tensor *, int> index;                  // tensor -> node index
+    std::unordered_map<const ggml_tensor *, std::vector<int>> users;     // tensor -> consumer node indices (ascending)
+    const char * a_range_lo = nullptr; const char * a_range_hi = nullptr;
     // activation cache
     const void *  a_src = nullptr; act_kind a_kind = ACT_NONE; int64_t a_K = 0, a_ne[3] = {0, 0, 0}; size_t a_nb[3] = {0, 0, 0};
     bool          capturing = false;
@@ -201,6 +207,44 @@ static void ensure_scratch(backend_ctx * c, void ** p, size_t * have, size_t nee
 }
 
 // ------------------------------------------------------------------------------------------------ MUL_MAT
+struct byte_range { const char * lo; const char * hi; };
+static byte_range range_of(const ggml_tensor * t) { const char * p = (const char *) t->data; return { p, p + nbytes(t) }; }
+static bool overlap(byte_range a, byte_range b) { return a.lo < b.hi && b.lo < a.hi && a.lo != a.hi && b.lo != b.hi; }
+
+// convert src1 of a MUL_MAT into the activation format of `kind` (or reuse the cached conversion); returns the image stride
+static size_t prepare_act(exec_state & s, const ggml_tensor * x, act_kind kind) {
+    const int64_t K = x->ne[0], N = x->ne[1], ne12 = x->ne[2], ne13 = x->ne[3];
+    const size_t img = act_image_bytes(kind, K);
+    if (kind == ACT_F32) return 0;
+    const bool cached = s.a_src == x->data && s.a_kind == kind && s.a_K == K && s.a_ne[0] == N && s.a_ne[1] == ne12 &&
+                        s.a_ne[2] == ne13 && s.a_nb[0] == x->nb[1] && s.a_nb[1] == x->nb[2] && s.a_nb[2] == x->nb[3];
+    if (cached) return img;
+    auto conv = [&](const float * src, size_t xs, void * out, int64_t rows) {
+        if      (kind == ACT_Q8K) quantize_q8k_image(src, xs, out, K, rows, s.st);
+        else if (kind == ACT_Q80) quantize_q80_image(src, xs, out, K, rows, s.st);
+        else                      convert_f32_f16_rows(src, xs, (uint16_t *) out, img, K, rows, s.st);
+        ++s.n_kernels;
+    };
+    prof_scope ps(s, "act_convert", 0);
+    const bool flat = (ne12 == 1 || x->nb[2] == (size_t) N * x->nb[1]) && (ne13 == 1 || x->nb[3] == (size_t) ne12 * x->nb[2]);
+    if (flat) {
+        conv((const float *) x->data, x->nb[1], s.c->act_scratch, N * ne12 * ne13);
+    } else {
+        for (int64_t i13 = 0; i13 < ne13; ++i13)
+            for (int64_t i12 = 0; i12 < ne12; ++i12)
+                conv((const float *) ((const char *) x->data + i12 * x->nb[2] + i13 * x->nb[3]), x->nb[1],
+                     (char *) s.c->act_scratch + (size_t) ((i13 * ne12 + i12) * N) * img, N);
+    }
+    s.a_src = x->data; s.a_kind = kind; s.a_K = K; s.a_ne[0] = N; s.a_ne[1] = ne12; s.a_ne[2] = ne13;
+    s.a_nb[0] = x->nb[1]; s.a_nb[1] = x->nb[2]; s.a_nb[2] = x->nb[3];
+    s.a_range_lo = (const char *) x->data; s.a_range_hi = (const char *) x->data + nbytes(x);
+    return img;
+}
+
+static const char * mmv_class(int type) {
+    return type == GGML_TYPE_Q4_K ? "mmv_q4k" : type == GGML_TYPE_Q6_K ? "mmv_q6k" : type == GGML_TYPE_Q8_0 ? "mmv_q80" : type == GGML_TYPE_F16 ? "mmv_f16" : "mmv_f32";
+}
+
 static void op_mul_mat(exec_state & s, const ggml_tensor * dst) {
     const ggml_tensor * w = dst->src[0];
     const ggml_tensor * x = dst->src[1];
@@ -208,35 +252,9 @@ static void op_mul_mat(exec_state & s, const ggml_tensor * dst) {
     const int64_t ne12 = x->ne[2], ne13 = x->ne[3];
     const int64_t r2 = ne12 / w->ne[2], r3 = ne13 / w->ne[3];
     const act_kind kind = act_kind_for(w->type);
-    const size_t img = act_image_bytes(kind, K);
+    const size_t img = prepare_act(s, x, kind);
 
-    // ---- activation conversion (skipped when the previous MUL_MAT already converted the very same src1)
-    const bool cached = kind != ACT_F32 && s.a_src == x->data && s.a_kind == kind && s.a_K == K && s.a_ne[0] == N && s.a_ne[1] == ne12 &&
-                        s.a_ne[2] == ne13 && s.a_nb[0] == x->nb[1] && s.a_nb[1] == x->nb[2] && s.a_nb[2] == x->nb[3];
-    if (kind != ACT_F32 && !cached) {
-        auto conv = [&](const float * src, size_t xs, void * out, int64_t rows) {
-            if      (kind == ACT_Q8K) quantize_q8k_image(src, xs, out, K, rows, s.st);
-            else if (kind == ACT_Q80) quantize_q80_image(src, xs, out, K, rows, s.st);
-            else                      convert_f32_f16_rows(src, xs, (uint16_t *) out, img, K, rows, s.st);
-            ++s.n_kernels;
-        };
-        const bool flat = (ne12 == 1 || x->nb[2] == (size_t) N * x->nb[1]) && (ne13 == 1 || x->nb[3] == (size_t) ne12 * x->nb[2]);
-        if (flat) {
-            conv((const float *) x->data, x->nb[1], s.c->act_scratch, N * ne12 * ne13);
-        } else {
-            for (int64_t i13 = 0; i13 < ne13; ++i13)
-                for (int64_t i12 = 0; i12 < ne12; ++i12)
-                    conv((const float *) ((const char *) x->data + i12 * x->nb[2] + i13 * x->nb[3]), x->nb[1],
-                         (char *) s.c->act_scratch + (size_t) ((i13 * ne12 + i12) * N) * img, N);
-        }
-        s.a_src = x->data; s.a_kind = kind; s.a_K = K; s.a_ne[0] = N; s.a_ne[1] = ne12; s.a_ne[2] = ne13;
-        s.a_nb[0] = x->nb[1]; s.a_nb[1] = x->nb[2]; s.a_nb[2] = x->nb[3];
-    }
-
-    // ---- weight streaming
     const double wbytes = (double) M * (double) row_size(w->type, K);
-    const char * cls = w->type == GGML_TYPE_Q4_K ? "mmv_q4k" : w->type == GGML_TYPE_Q6_K ? "mmv_q6k" : w->type == GGML_TYPE_Q8_0 ? "mmv_q80" :
-                       w->type == GGML_TYPE_F16 ? "mmv_f16" : "mmv_f32";
     for (int64_t i13 = 0; i13 < ne13; ++i13) {
         for (int64_t i12 = 0; i12 < ne12; ++i12) {
             const char * wp = (const char *) w->data + (i12 / r2) * w->nb[2] + (i13 / r3) * w->nb[3];
@@ -251,7 +269,7 @@ static void op_mul_mat(exec_state & s, const ggml_tensor * dst) {
                 } else {
                     a.act = (const char *) s.c->act_scratch + (size_t) ((i13 * ne12 + i12) * N + c0) * img; a.act_cs = img;
                 }
-                prof_scope ps(s, cls, wbytes);
+                prof_scope ps(s, mmv_class(w->type), wbytes);
                 switch (w->type) {
                     case GGML_TYPE_Q4_K: mmv_q4_K(a, s.st); break;
                     case GGML_TYPE_Q6_K: mmv_q6_K(a, s.st); break;
@@ -265,60 +283,242 @@ static void op_mul_mat(exec_state & s, const ggml_tensor * dst) {
     }
 }
 
-// ------------------------------------------------------------------------------------------------ node dispatch
-// returns the number of graph nodes consumed (>1 when a fusion fired)
-static int compute_node(exec_state & s, ggml_cgraph * g, int i) {
+// ------------------------------------------------------------------------------------------------ fusion planner
+// Fusions are found on the DATA FLOW, not on adjacency: libllama's node order interleaves the q/k/v chains
+// (ggml_build_forward_expand visits each chain depth-first), so wk's MUL_MAT sits five nodes after wq's.  A node j is
+// executed early, together with node i < j, only when that cannot change any byte another node observes:
+//   * every source of j is a leaf, was computed before i, or is produced inside the fused item, and
+//   * no node strictly between i and j (and outside the item) reads or writes memory overlapping j's output,
+//     nor writes memory overlapping j's inputs (ggml-alloc re-uses the storage of dead tensors).
+static bool is_kquant(int t) { return t == GGML_TYPE_Q4_K || t == GGML_TYPE_Q6_K; }
+
+static bool plain_kq_matvec(const ggml_tensor * n, int max_cols) {      // MUL_MAT(K-quant W [K,M], f32 x [K,N<=max]) with no broadcast
+    if (n->op != GGML_OP_MUL_MAT || is_empty(n)) return false;
+    const ggml_tensor * w = n->src[0], * x = n->src[1];
+    return is_kquant(w->type) && w->ne[2] == 1 && w->ne[3] == 1 && x->ne[2] == 1 && x->ne[3] == 1 && x->ne[1] <= max_cols &&
+           q8k_image_bytes(w->ne[0]) * (size_t) x->ne[1] <= 152 * 1024 && n->nb[0] == 4;
+}
+static bool same_act(const ggml_tensor * a, const ggml_tensor * b) {
+    return a->data == b->data && a->ne[0] == b->ne[0] && a->ne[1] == b->ne[1] && a->ne[2] == b->ne[2] && a->ne[3] == b->ne[3] &&
+           a->nb[1] == b->nb[1] && a->nb[2] == b->nb[2] && a->nb[3] == b->nb[3];
+}
+static int n_users(exec_state & s, const ggml_tensor * t) { auto it = s.users.find(t); return it == s.users.end() ? 0 : (int) it->second.size(); }
+static int sole_user(exec_state & s, const ggml_tensor * t) {           // index of the only consumer node, or -1
+    auto it = s.users.find(t);
+    if (it == s.users.end() || it->second.size() != 1 || (t->flags & GGML_TENSOR_FLAG_OUTPUT)) return -1;
+    return it->second[0];
+}
+static bool ready_before(exec_state & s, const ggml_tensor * src, int i, const int * item, int n_item) {
+    if (!src) return true;
+    const ggml_tensor * t = src;
+    while (t) {                                                          // walk through view chains down to the producing node
+        auto it = s.index.find(t);
+        if (it != s.index.end()) {
+            const int k = it->second;
+            if (!is_noop(s.g->nodes[k])) {
+                if (k < i) return true;
+                for (int q = 0; q < n_item; ++q) if (item[q] == k) return true;
+                return false;
+            }
+            if (k >= i) {                                                // a view node created after i: its base must still be ready
+                bool ok = true;
+                for (int q = 0; q < GGML_MAX_SRC && ok; ++q) if (s.g->nodes[k]->src[q]) ok = ready_before(s, s.g->nodes[k]->src[q], i, item, n_item);
+                return ok;
+            }
+        }
+        t = t->view_src;
+    }
+    return true;                                                         // leaf (weight / graph input)
+}
+static bool can_hoist(exec_state & s, int i, int j, const int * item, int n_item) {
+    const ggml_tensor * nj = s.g->nodes[j];
+    for (int k = 0; k < GGML_MAX_SRC; ++k) if (!ready_before(s, nj->src[k], i, item, n_item)) return false;
+    const byte_range dj = range_of(nj);
+    for (int m = i + 1; m < j; ++m) {
+        const ggml_tensor * nm = s.g->nodes[m];
+        bool in_item = false;
+        for (int q = 0; q < n_item; ++q) in_item |= item[q] == m;
+        if (in_item || s.done[m] || is_noop(nm)) continue;
+        const byte_range dm = range_of(nm);
+        if (overlap(dj, dm)) return false;
+        for (int k = 0; k < GGML_MAX_SRC; ++k) {
+            if (nm->src[k] && overlap(dj, range_of(nm->src[k]))) return false;
+            if (nj->src[k] && overlap(dm, range_of(nj->src[k]))) return false;
+        }
+    }
+    return true;
+}
+static void note_write(exec_state & s, const ggml_tensor * t) {          // a kernel wrote t: drop the activation cache if it aliased
+    if (!s.a_src) return;
+    const byte_range r = range_of(t);
+    if (r.lo < s.a_range_hi && s.a_range_lo < r.hi) s.a_src = nullptr;
+}
+
+// MUL_MAT at node i: try gate/up/SWIGLU, then q/k/v batching, then residual-add epilogue; falls back to the plain path
+static void exec_mul_mat(exec_state & s, int i) {
+    ggml_cgraph * g = s.g;
     ggml_tensor * n = g->nodes[i];
-    if (is_noop(n)) return 1;
-    if (n->op != GGML_OP_MUL_MAT) s.a_src = nullptr;                 // any other writer invalidates the activation cache
+    if (!s.c->opt_fusion || !plain_kq_matvec(n, MI_MMVQ_MAX_COLS)) { op_mul_mat(s, n); note_write(s, n); return; }
+    const ggml_tensor * x = n->src[1];
+    const int64_t K = x->ne[0]; const int N = (int) x->ne[1];
+
+    // ---- (a) ffn_up / ffn_gate + GLU(SWIGLU, split): one launch, intermediates never written
+    if (N <= 4) {
+        const int gi = sole_user(s, n);
+        if (gi > i && g->nodes[gi]->op == GGML_OP_GLU && op_param_i32(g->nodes[gi], 0) == GGML_GLU_OP_SWIGLU && op_param_i32(g->nodes[gi], 1) == 0 &&
+            g->nodes[gi]->src[0] && g->nodes[gi]->src[1]) {
+            ggml_tensor * G = g->nodes[gi];
+            ggml_tensor * other = G->src[0] == n ? G->src[1] : (G->src[1] == n ? G->src[0] : nullptr);
+            auto oit = other ? s.index.find(other) : s.index.end();
+            if (other && oit != s.index.end() && oit->second > i && !s.done[oit->second] && plain_kq_matvec(other, 4) && sole_user(s, other) == gi &&
+                same_act(other->src[1], x) && other->src[0]->type == n->src[0]->type && other->src[0]->ne[1] == n->src[0]->ne[1] &&
+                other->src[0]->nb[1] == n->src[0]->nb[1] && G->nb[0] == 4 && G->ne[0] == n->ne[0] && is_contiguous_1(G)) {
+                const int oi = oit->second;
+                const int item[3] = { i, oi, gi };
+                if (can_hoist(s, i, oi, item, 3) && can_hoist(s, i, gi, item, 3)) {
+                    const size_t img = prepare_act(s, x, ACT_Q8K);
+                    const ggml_tensor * gate = G->src[0], * up = G->src[1];
+                    prof_scope ps(s, n->src[0]->type == GGML_TYPE_Q4_K ? "mmv_q4k" : "mmv_q6k", 2.0 * (double) n->src[0]->ne[1] * (double) row_size(n->src[0]->type, K));
+                    mmv_kquant_pair_swiglu(n->src[0]->type, gate->src[0]->data, up->src[0]->data, n->src[0]->nb[1], s.c->act_scratch, img,
+                                           (float *) G->data, G->nb[1], K, n->src[0]->ne[1], N, s.st);
+                    ++s.n_kernels; s.n_fused += 2;
+                    s.done[oi] = s.done[gi] = 1;
+                    note_write(s, G);
+                    return;
+                }
+            }
+        }
+    }
+
+    // ---- (b) batch MUL_MATs that consume the same activation (wq / wk / wv), each with an optional residual ADD
+    int   mm_idx[3] = { i, -1, -1 }; int nm = 1;
+    for (int j = i + 1; j < g->n_nodes && j < i + 32 && nm < 3; ++j) {
+        ggml_tensor * c = g->nodes[j];
+        if (s.done[j] || !plain_kq_matvec(c, MI_MMVQ_MAX_COLS) || !same_act(c->src[1], x)) continue;
+        // do not steal one half of a gate/up pair (that fusion is worth more)
+        const int cu = sole_user(s, c);
+        if (cu > 0 && g->nodes[cu]->op == GGML_OP_GLU) continue;
+        if (!can_hoist(s, i, j, mm_idx, nm)) continue;
+        mm_idx[nm++] = j;
+    }
+    mmv_multi_args a;
+    a.nmat = nm; a.K = K; a.ncols = N;
+    int add_idx[3] = { -1, -1, -1 };
+    double bytes_q4 = 0, bytes_q6 = 0;
+    for (int q = 0; q < nm; ++q) {
+        ggml_tensor * c = g->nodes[mm_idx[q]];
+        const ggml_tensor * w = c->src[0];
+        a.m[q] = { w->data, w->nb[1], (float *) c->data, c->nb[1], nullptr, 0, w->ne[1], (int) w->type };
+        (w->type == GGML_TYPE_Q4_K ? bytes_q4 : bytes_q6) += (double) w->ne[1] * (double) row_size(w->type, K);
+        // residual: the only consumer is ADD(c, r) / ADD(r, c) with r of the same shape, available now
+        const int ai = sole_user(s, c);
+        if (ai > mm_idx[q] && g->nodes[ai]->op == GGML_OP_ADD && !s.done[ai]) {
+            ggml_tensor * A = g->nodes[ai];
+            const ggml_tensor * r = A->src[0] == c ? A->src[1] : A->src[0];
+            if (((A->src[0] == c) != (A->src[1] == c)) && r && r != c && r->type == GGML_TYPE_F32 && same_shape(r, c) && same_shape(A, c) && r->nb[0] == 4 && A->nb[0] == 4 && A->type == GGML_TYPE_F32) {
+                int item[7]; int ni = 0;
+                for (int t = 0; t < nm; ++t) item[ni++] = mm_idx[t];
+                for (int t = 0; t < q; ++t) if (add_idx[t] >= 0) item[ni++] = add_idx[t];
+                item[ni++] = ai;
+                if (can_hoist(s, i, ai, item, ni)) {
+                    a.m[q].resid = (const float *) r->data; a.m[q].resid_cs = r->nb[1];
+                    a.m[q].dst = (float *) A->data; a.m[q].dst_cs = A->nb[1];
+                    add_idx[q] = ai;
+                }
+            }
+        }
+    }
+    const size_t img = prepare_act(s, x, ACT_Q8K);
+    a.act = s.c->act_scratch; a.act_cs = img;
+    {
+        // profile class: the launch is attributed to the type that carries most of its bytes
+        prof_scope ps(s, bytes_q4 >= bytes_q6 ? "mmv_q4k" : "mmv_q6k", bytes_q4 + bytes_q6);
+        mmv_kquant_multi(a, s.st);
+    }
+    ++s.n_kernels;
+    for (int q = 0; q < nm; ++q) {
+        if (q > 0) { s.done[mm_idx[q]] = 1; ++s.n_fused; }
+        if (add_idx[q] >= 0) { s.done[add_idx[q]] = 1; ++s.n_fused; note_write(s, g->nodes[add_idx[q]]); }
+        else note_write(s, g->nodes[mm_idx[q]]);
+    }
+}
+
+// RMS_NORM at node i: fold the following MUL(w) in, and -- when every consumer is a K-quant MUL_MAT -- also emit the Q8_K image
+static bool exec_rms_norm(exec_state & s, int i) {
+    ggml_cgraph * g = s.g;
+    ggml_tensor * n = g->nodes[i];
+    const float eps = op_param_f32(n, 0);
+    if (!s.c->opt_fusion) return false;
+    const int mi_ = sole_user(s, n);
+    if (mi_ != i + 1 || g->nodes[mi_]->op != GGML_OP_MUL) return false;
+    ggml_tensor * m = g->nodes[mi_];
+    const ggml_tensor * wt = m->src[0] == n ? m->src[1] : m->src[0];
+    if ((m->src[0] == n) == (m->src[1] == n)) return false;
+    if (!wt || wt == n || m->type != GGML_TYPE_F32 || wt->type != GGML_TYPE_F32 || wt->nb[0] != 4 || !same_shape(m, n) || !can_repeat(wt, n) || m->nb[0] != 4) return false;
+    // image variant: row-contiguous 2-D activation, weight a plain [ne0] vector, every consumer a K-quant mat-vec on it
+    bool want_img = n->ne[0] % 256 == 0 && n->ne[2] == 1 && n->ne[3] == 1 && n->ne[1] <= MI_MMVQ_MAX_COLS && wt->ne[0] == n->ne[0] &&
+                    wt->ne[1] * wt->ne[2] * wt->ne[3] == 1 && n->src[0]->nb[0] == 4 && n_users(s, m) > 0;
+    if (want_img) {
+        for (int u : s.users[m]) {
+            const ggml_tensor * c = g->nodes[u];
+            if (!(c->op == GGML_OP_MUL_MAT && c->src[1] == m && is_kquant(c->src[0]->type) && c->src[0]->ne[2] == 1 && c->src[0]->ne[3] == 1)) { want_img = false; break; }
+        }
+    }
+    if (want_img) {
+        prof_scope ps(s, "rms_norm_mul_quant", 0);
+        rms_norm_mul_quant((const float *) n->src[0]->data, n->src[0]->nb[1], (const float *) wt->data, (float *) m->data, m->nb[1], s.c->act_scratch,
+                           n->ne[0], n->ne[1], eps, s.st);
+        ++s.n_kernels; s.n_fused += 1; s.done[mi_] = 1;
+        note_write(s, m);
+        s.a_src = m->data; s.a_kind = ACT_Q8K; s.a_K = m->ne[0]; s.a_ne[0] = m->ne[1]; s.a_ne[1] = 1; s.a_ne[2] = 1;
+        s.a_nb[0] = m->nb[1]; s.a_nb[1] = m->nb[2]; s.a_nb[2] = m->nb[3];
+        s.a_range_lo = (const char *) m->data; s.a_range_hi = (const char *) m->data + nbytes(m);
+        return true;
+    }
+    const tdesc wd = td(wt);
+    prof_scope ps(s, "rms_norm_mul", 0);
+    rms_norm(td(n->src[0]), td(m), eps, &wd, s.st);
+    ++s.n_kernels; s.n_fused += 1; s.done[mi_] = 1;
+    note_write(s, m);
+    return true;
+}
+
+// ------------------------------------------------------------------------------------------------ node dispatch
+static void compute_node(exec_state & s, int i) {
+    ggml_cgraph * g = s.g;
+    ggml_tensor * n = g->nodes[i];
+    if (is_noop(n)) return;
 
     switch (n->op) {
         case GGML_OP_MUL_MAT:
-            op_mul_mat(s, n);
-            return 1;
+            exec_mul_mat(s, i);
+            return;
         case GGML_OP_RMS_NORM: {
-            const float eps = op_param_f32(n, 0);
-            // fusion: RMS_NORM -> MUL(norm, w) where the norm output has no other consumer inside this graph
-            if (s.c->opt_fusion && i + 1 < g->n_nodes) {
-                ggml_tensor * m = g->nodes[i + 1];
-                if (m->op == GGML_OP_MUL && m->type == GGML_TYPE_F32 && (m->src[0] == n || m->src[1] == n)) {
-                    const ggml_tensor * wt = m->src[0] == n ? m->src[1] : m->src[0];
-                    bool only_use = true;
-                    for (int j = i + 2; j < g->n_nodes && only_use; ++j)
-                        for (int k = 0; k < GGML_MAX_SRC; ++k) if (g->nodes[j]->src[k] == n) { only_use = false; break; }
-                    if (only_use && !(n->flags & GGML_TENSOR_FLAG_OUTPUT) && wt->type == GGML_TYPE_F32 && wt->nb[0] == 4 && same_shape(m, n) &&
-                        can_repeat(wt, n) && m->nb[0] == 4 && wt != n) {
-                        const tdesc wd = td(wt);
-                        prof_scope ps(s, "rms_norm_mul", 0);
-                        rms_norm(td(n->src[0]), td(m), eps, &wd, s.st); ++s.n_kernels;
-                        return 2;
-                    }
-                }
-            }
+            if (exec_rms_norm(s, i)) return;
             prof_scope ps(s, "rms_norm", 0);
-            rms_norm(td(n->src[0]), td(n), eps, nullptr, s.st); ++s.n_kernels;
-            return 1;
+            rms_norm(td(n->src[0]), td(n), op_param_f32(n, 0), nullptr, s.st); ++s.n_kernels;
+            break;
         }
         case GGML_OP_ADD: case GGML_OP_SUB: case GGML_OP_MUL: case GGML_OP_DIV: {
             prof_scope ps(s, "bin", 0);
             bin_bcast_f32(n->op, td(n->src[0]), td(n->src[1]), td(n), s.st); ++s.n_kernels;
-            return 1;
+            break;
         }
         case GGML_OP_SCALE: {
             prof_scope ps(s, "scale", 0);
             scale_f32((const float *) n->src[0]->data, (float *) n->data, nelements(n), op_param_f32(n, 0), op_param_f32(n, 1), s.st); ++s.n_kernels;
-            return 1;
+            break;
         }
         case GGML_OP_UNARY: {
             prof_scope ps(s, "unary", 0);
             unary_f32(op_param_i32(n, 0), (const float *) n->src[0]->data, (float *) n->data, nelements(n), s.st); ++s.n_kernels;
-            return 1;
+            break;
         }
         case GGML_OP_GLU: {
             prof_scope ps(s, "glu", 0);
             tdesc b; if (n->src[1]) b = td(n->src[1]);
             glu_f32(op_param_i32(n, 0), td(n->src[0]), n->src[1] ? &b : nullptr, op_param_i32(n, 1) != 0, td(n), s.st); ++s.n_kernels;
-            return 1;
+            break;
         }
         case GGML_OP_ROPE: {
             rope_params rp;
@@ -327,31 +527,31 @@ static int compute_node(exec_state & s, ggml_cgraph * g, int i) {
             rp.attn_factor = op_param_f32(n, 8); rp.beta_fast = op_param_f32(n, 9); rp.beta_slow = op_param_f32(n, 10);
             prof_scope ps(s, "rope", 0);
             rope_f32(td(n->src[0]), (const int32_t *) n->src[1]->data, n->src[2] ? (const float *) n->src[2]->data : nullptr, td(n), rp, s.st); ++s.n_kernels;
-            return 1;
+            break;
         }
         case GGML_OP_SOFT_MAX: {
             tdesc m; if (n->src[1]) m = td(n->src[1]);
             prof_scope ps(s, "soft_max", 0);
             soft_max_f32(td(n->src[0]), n->src[1] ? &m : nullptr, n->src[1] ? n->src[1]->type : 0,
                          n->src[2] ? (const float *) n->src[2]->data : nullptr, td(n), op_param_f32(n, 0), op_param_f32(n, 1), s.st); ++s.n_kernels;
-            return 1;
+            break;
         }
         case GGML_OP_CPY: case GGML_OP_CONT: case GGML_OP_DUP: {
             prof_scope ps(s, "cpy", 0);
             const ggml_tensor * src = n->src[0];
             // CPY writes into src[1]'s storage, which `n` is a view of; n->data is the destination in all three ops
             cpy_strided(td(src), src->type, td(n), n->type, s.st); ++s.n_kernels;
-            return 1;
+            break;
         }
         case GGML_OP_GET_ROWS: {
             prof_scope ps(s, "get_rows", 0);
             get_rows(td(n->src[0]), n->src[0]->type, td(n->src[1]), td(n), s.st); ++s.n_kernels;
-            return 1;
+            break;
         }
         case GGML_OP_SET_ROWS: {
             prof_scope ps(s, "set_rows", 0);
             set_rows(td(n->src[0]), td(n->src[1]), n->src[1]->type, td(n), n->type, s.st); ++s.n_kernels;
-            return 1;
+            break;
         }
         case GGML_OP_FLASH_ATTN_EXT: {
             fattn_args f;
@@ -363,16 +563,36 @@ static int compute_node(exec_state & s, ggml_cgraph * g, int i) {
             f.scratch = nullptr; f.scratch_bytes = 0;
             prof_scope ps(s, "fattn", 0);
             flash_attn_ext_f16(f, s.st); ++s.n_kernels;
-            return 1;
+            break;
         }
         default:
             log_msg(GGML_LOG_LEVEL_ERROR, "[mi355x] graph_compute: op %d (%s) reached the backend but is not implemented -- supports_op bug\n", (int) n->op, n->name);
             abort();
     }
+    note_write(s, n);
 }
 
 static void run_nodes(exec_state & s, ggml_cgraph * g) {
-    for (int i = 0; i < g->n_nodes;) i += compute_node(s, g, i);
+    s.g = g;
+    s.done.assign(g->n_nodes, 0);
+    s.index.clear(); s.users.clear();
+    if (s.c->opt_fusion) {
+        s.index.reserve(g->n_nodes * 2); s.users.reserve(g->n_nodes * 2);
+        for (int i = 0; i < g->n_nodes; ++i) {
+            s.index[g->nodes[i]] = i;
+            if (is_noop(g->nodes[i])) continue;
+            for (int k = 0; k < GGML_MAX_SRC; ++k) {
+                // a consumer of a view counts as a consumer of every tensor on the view chain it reads through
+                const ggml_tensor * t = g->nodes[i]->src[k];
+                while (t) {
+                    auto & v = s.users[t];
+                    if (v.empty() || v.back() != i) v.push_back(i);
+                    t = (t->op == GGML_OP_RESHAPE || t->op == GGML_OP_VIEW || t->op == GGML_OP_PERMUTE || t->op == GGML_OP_TRANSPOSE) ? t->src[0] : nullptr;
+                }
+            }
+        }
+    }
+    for (int i = 0; i < g->n_nodes; ++i) if (!s.done[i]) compute_node(s, i);
 }
 
 // ------------------------------------------------------------------------------------------------ fingerprint

@@ -31,6 +31,28 @@ void mmv_q8_0(const mmv_args & a, hipStream_t st);
 void mmv_f16 (const mmv_args & a, hipStream_t st);   // act = f16 rows
 void mmv_f32 (const mmv_args & a, hipStream_t st);   // W f32, act = f32 rows
 
+// ---- fused K-quant launches (decode): up to 3 matrices sharing one Q8_K activation image set in one launch
+// (wq/wk/wv), Q4_K / Q6_K mixed, optional residual add epilogue (dst = W.x + resid)
+struct mmv_mat {
+    const void * W; size_t w_rs;
+    float * dst;    size_t dst_cs;
+    const float * resid; size_t resid_cs;      // may be null
+    int64_t nrows; int type;
+};
+struct mmv_multi_args {
+    mmv_mat m[3]; int nmat;
+    const void * act; size_t act_cs;           // Q8_K images, one per column
+    int64_t K; int ncols;                      // ncols * q8k_image_bytes(K) must fit LDS (<= 152 KiB)
+};
+void mmv_kquant_multi(const mmv_multi_args & a, hipStream_t st);
+// ffn_gate + ffn_up + SWIGLU: dst[col][r] = silu(Wg[r].x) * (Wu[r].x); both matrices `type`, same shape; ncols <= 4
+void mmv_kquant_pair_swiglu(int type, const void * Wg, const void * Wu, size_t w_rs, const void * act, size_t act_cs, float * dst, size_t dst_cs,
+                            int64_t K, int64_t nrows, int ncols, hipStream_t st);
+
+// RMS_NORM + MUL(w) + Q8_K image of the result in one launch (one workgroup per row); y may be null when only the
+// image is consumed.  Same arithmetic as rms_norm() followed by quantize_q8k_image().
+void rms_norm_mul_quant(const float * x, size_t xs, const float * w, float * y, size_t ys, void * img, int64_t n, int64_t nrows, float eps, hipStream_t st);
+
 // ---- full dequantisation (GET_ROWS on quantised tables, dequant->GEMM prefill path, CPY q->f32)
 // src row r at src + r*src_rs ; dst row r at dst + r*dst_rs ; K elements per row
 void dequant_rows_f32(int type, const void * src, size_t src_rs, float * dst, size_t dst_rs, int64_t K, int64_t nrows, hipStream_t st);

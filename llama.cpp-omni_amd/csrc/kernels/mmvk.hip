@@ -1,0 +1,450 @@
+// mmvk.hip -- K-quant weight-streaming mat-vec kernels (the decode hot loop) for gfx950 / wave64.
+//
+// What is computed (reference: ggml_compute_forward_mul_mat, ggml-cpu/ggml-cpu.c:1210-1402, ne11 <= 8):
+//     dst[col][row] = vec_dot(W[row, :], Q8_K(act[col, :]))
+//     Q4_K x Q8_K : ggml_vec_dot_q4_K_q8_K  (ggml-cpu/quants.c:550-623)
+//     Q6_K x Q8_K : ggml_vec_dot_q6_K_q8_K  (ggml-cpu/quants.c:705-758)
+// Integer sub-block sums are exact and identical to the oracle; only the order of the f32 additions across
+// super-blocks differs (64-lane butterfly instead of an 8-lane SIMD accumulator).
+//
+// Launch shapes
+//   k_mmv_multi : up to 3 matrices that share the activation vector (wq/wk/wv, or a single matrix) in ONE launch;
+//                 waves are split between the matrices in proportion to their bytes; Q4_K and Q6_K may be mixed
+//                 (Q4_K_M stores attn_v / ffn_down as Q6_K on half of the layers).  Optional epilogue:
+//                 dst = W.x + resid (the graph's following residual ADD).
+//   k_mmv_pair  : ffn_gate + ffn_up rows processed together, epilogue silu(gate)*up (the graph's GLU node),
+//                 so neither intermediate vector is written.
+//
+// HBM design (bound: 8 TB/s): every weight byte is read exactly once with non-temporal vector loads straight
+// into VGPRs (no LDS round trip for single-use data); the small activation image is staged once per workgroup in
+// LDS; the next pipeline stage's loads are issued before the current one is consumed; 4-way int8 dot products
+// (v_dot4_i32_i8); no bounds branches around loads (addresses are clamped, contributions of out-of-range lanes
+// are zeroed) so each stage's loads stay in one clause.
+#include "../kernels.hpp"
+
+namespace mi {
+
+extern __shared__ __attribute__((aligned(16))) char mmv_lds[];
+
+static __device__ __forceinline__ void stage_act_k(const char * act, size_t act_cs, int ncols, size_t bytes) {
+    const int n16 = (int) (bytes >> 4);
+    for (int c = 0; c < ncols; ++c) {
+        const u32x4 * s = (const u32x4 *) (act + c * act_cs);
+        u32x4 *       d = (u32x4 *) (mmv_lds + c * bytes);
+        for (int i = threadIdx.x; i < n16; i += blockDim.x) d[i] = s[i];
+    }
+}
+
+static __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + expf(-x)); }    // ggml_silu_f32, vec.h:958
+
+// epilogue shared by all bodies
+struct mmv_out {
+    char *       dst;    size_t dst_cs;      // f32 output, column stride
+    const char * resid;  size_t resid_cs;    // optional residual (added after the dot product), may be null
+};
+
+// =================================================================================================
+// Q4_K : 144-B super-block = 16-B header {d, dmin, 12 B of 6-bit scales/mins} + 128 B of nibbles
+// (ggml-common.h:295-305).  8 lanes per super-block: lane (j = lp>>1, h = lp&1) owns qs[32j+16h .. +16),
+// i.e. 16 low nibbles of sub-block 2j and 16 high nibbles of sub-block 2j+1 (dequantize_row_q4_K,
+// ggml-quants.c:1352-1374).  A wave covers 8 super-blocks (1152 contiguous bytes) per step, U steps per stage.
+// PAIR: the two "rows" of a group are row r of W0 (gate) and row r of W1 (up); epilogue silu(g)*u.
+// =================================================================================================
+template <int NCOLS, int ROWS, int U, bool PAIR>
+static __device__ __forceinline__ void q4k_body(const char * __restrict__ W0, const char * __restrict__ W1, size_t w_rs, const mmv_out o,
+                                                int K, int nrows, int wave, int nwaves) {
+    const int lane = threadIdx.x & 63;
+    const int g = lane >> 3, lp = lane & 7, j = lp >> 1, h = lp & 1;
+    const int nb  = K >> 8;
+    const int nit = (nb + 8 * U - 1) / (8 * U);
+    const size_t img = q8k_image_bytes(K);
+    const int ngrp = PAIR ? nrows : (nrows + ROWS - 1) / ROWS;
+
+    u32x4 hdr[U][ROWS], qs[U][ROWS];
+    auto issue = [&](int grp, int it) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            int ib = (it * U + u) * 8 + g; ib = ib < nb ? ib : nb - 1;
+#pragma unroll
+            for (int r = 0; r < ROWS; ++r) {
+                int row = PAIR ? grp : grp * ROWS + r; row = row < nrows ? row : nrows - 1;
+                const char * bp = ((PAIR && r == 1) ? W1 : W0) + (size_t) row * w_rs + (size_t) ib * 144;
+                hdr[u][r] = ld_nt16(bp);
+                qs[u][r]  = ld_nt16(bp + 16 + lp * 16);
+            }
+        }
+    };
+
+    int grp = wave, it = 0;
+    if (grp >= ngrp) return;
+    issue(grp, 0);
+
+    float acc[ROWS][NCOLS];
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r)
+#pragma unroll
+        for (int c = 0; c < NCOLS; ++c) acc[r][c] = 0.0f;
+
+    const int sh = (j & 1) * 16;
+    while (true) {
+        u32x4 chdr[U][ROWS], cqs[U][ROWS];
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int r = 0; r < ROWS; ++r) { chdr[u][r] = hdr[u][r]; cqs[u][r] = qs[u][r]; }
+        const int cgrp = grp, cit = it;
+        ++it;
+        if (it == nit) { it = 0; grp += nwaves; }
+        const bool more = grp < ngrp;
+        if (more) issue(grp, it);
+
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int  ib    = (cit * U + u) * 8 + g;
+            const bool valid = ib < nb;
+            const int  ibc   = valid ? ib : nb - 1;
+            u32x4 alo[NCOLS], ahi[NCOLS]; int bs0[NCOLS], bs1[NCOLS]; float yd[NCOLS];
+#pragma unroll
+            for (int c = 0; c < NCOLS; ++c) {
+                const char * im = mmv_lds + c * img;
+                alo[c] = *(const u32x4 *) (im + ibc * 256 + 64 * j + 16 * h);
+                ahi[c] = *(const u32x4 *) (im + ibc * 256 + 64 * j + 16 * h + 32);
+                const u32x2 b = *(const u32x2 *) (im + K + (ibc * 16 + 4 * j) * 2);       // bsums[4j .. 4j+3]
+                bs0[c] = (int) (int16_t) (h ? (b[0] >> 16) : b[0]);                       // bsums[4j + h]
+                bs1[c] = (int) (int16_t) (h ? (b[1] >> 16) : b[1]);                       // bsums[4j + 2 + h]
+                yd[c]  = *(const float *) (im + K + (K >> 3) + ibc * 4);
+            }
+#pragma unroll
+            for (int r = 0; r < ROWS; ++r) {
+                const uint32_t u0 = chdr[u][r][1], u1 = chdr[u][r][2], u2 = chdr[u][r][3];
+                // 6-bit scale/min unpack, same bit surgery as ggml-cpu/quants.c:592-597 / get_scale_min_k4
+                const uint32_t s_lo = u0 & 0x3f3f3f3fu;
+                const uint32_t s_hi = (u2 & 0x0f0f0f0fu) | (((u0 >> 6) & 0x03030303u) << 4);
+                const uint32_t m_lo = u1 & 0x3f3f3f3fu;
+                const uint32_t m_hi = ((u2 >> 4) & 0x0f0f0f0fu) | (((u1 >> 6) & 0x03030303u) << 4);
+                const uint32_t sw = (j < 2 ? s_lo : s_hi) >> sh;
+                const uint32_t mw = (j < 2 ? m_lo : m_hi) >> sh;
+                const int sc0 = sw & 0xff, sc1 = (sw >> 8) & 0xff;
+                const int mn0 = mw & 0xff, mn1 = (mw >> 8) & 0xff;
+                const float dx   = h2f((uint16_t) (chdr[u][r][0] & 0xffff));
+                const float dmin = h2f((uint16_t) (chdr[u][r][0] >> 16));
+                uint32_t lo[4], hi[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { lo[k] = cqs[u][r][k] & 0x0f0f0f0fu; hi[k] = (cqs[u][r][k] >> 4) & 0x0f0f0f0fu; }
+                const bool rv = valid && (PAIR ? cgrp : cgrp * ROWS + r) < nrows;
+#pragma unroll
+                for (int c = 0; c < NCOLS; ++c) {
+                    int dl = 0, dh = 0;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) { dl = dot4(lo[k], alo[c][k], dl); dh = dot4(hi[k], ahi[c][k], dh); }
+                    const int isum = sc0 * dl + sc1 * dh;
+                    const int msum = mn0 * bs0[c] + mn1 * bs1[c];
+                    const float t = (dx * yd[c]) * (float) isum - (dmin * yd[c]) * (float) msum;
+                    acc[r][c] += rv ? t : 0.0f;
+                }
+            }
+        }
+
+        if (cit == nit - 1) {             // row group finished: butterfly, epilogue, store
+            if (PAIR) {
+#pragma unroll
+                for (int c = 0; c < NCOLS; ++c) {
+                    const float gsum = wave_sum(acc[0][c]), usum = wave_sum(acc[1][c]);
+                    if (lane == 0) *(float *) (o.dst + c * o.dst_cs + (size_t) cgrp * 4) = silu_f(gsum) * usum;
+                    acc[0][c] = 0.0f; acc[1][c] = 0.0f;
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < ROWS; ++r) {
+                    const int row = cgrp * ROWS + r;
+#pragma unroll
+                    for (int c = 0; c < NCOLS; ++c) {
+                        float s = wave_sum(acc[r][c]);
+                        if (lane == 0 && row < nrows) {
+                            if (o.resid) s += *(const float *) (o.resid + c * o.resid_cs + (size_t) row * 4);
+                            *(float *) (o.dst + c * o.dst_cs + (size_t) row * 4) = s;
+                        }
+                        acc[r][c] = 0.0f;
+                    }
+                }
+            }
+        }
+        if (!more) break;
+    }
+}
+
+// =================================================================================================
+// Q6_K : 210-B super-block {ql[128], qh[64], int8 scales[16], f16 d} (ggml-common.h:330-335): only 2-byte aligned.
+// 8 lanes per super-block: lane (n = lp>>2, tp = lp&3) owns l in [8tp, 8tp+8) of the 128-half n:
+//   ql[64n+l], ql[64n+32+l], qh[32n+l]  ->  4 x 8 six-bit weights at y[128n + {0,32,64,96} + l]
+// (dequantize_row_q6_K, ggml-quants.c:1762-1791).  A wave covers 8 super-blocks (1680 B) per step.
+// Every 8-byte piece is fetched as an ALIGNED 12-byte load and funnel-shifted (v_alignbyte_b32) by the block's
+// 0- or 2-byte phase; the over-read stays inside the same 210-byte block ("Q6_K loads").
+// =================================================================================================
+static __device__ __forceinline__ u32x2 ld_piece8(const char * p) {
+    const uintptr_t a = (uintptr_t) p;
+    const unsigned  s = (unsigned) (a & 3);                              // 0 or 2
+    const uint32_t * q = (const uint32_t *) (a - s);
+    typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
+    const u32x3 v = __builtin_nontemporal_load((const u32x3 *) q);      // global_load_dwordx3, 4-byte aligned
+    u32x2 r;
+    r[0] = __builtin_amdgcn_alignbyte(v[1], v[0], s);
+    r[1] = __builtin_amdgcn_alignbyte(v[2], v[1], s);
+    return r;
+}
+// same, but never touches a byte beyond p+8 (phase 0) / p+10 (phase 2): used for the scales piece, whose 12-byte
+// form would cross the end of the super-block (and, for the last block, of the tensor)
+static __device__ __forceinline__ u32x2 ld_piece8_tail(const char * p) {
+    const uintptr_t a = (uintptr_t) p;
+    const unsigned  s = (unsigned) (a & 3);
+    const uint32_t * q = (const uint32_t *) (a - s);
+    const u32x2    v01 = __builtin_nontemporal_load((const u32x2 *) q);  // q is 4-byte aligned; 8-byte vector at 4-byte alignment
+    const uint32_t v2  = __builtin_nontemporal_load(q + (s ? 2 : 1));
+    u32x2 r;
+    r[0] = __builtin_amdgcn_alignbyte(v01[1], v01[0], s);
+    r[1] = __builtin_amdgcn_alignbyte(v2, v01[1], s);
+    return r;
+}
+// bytes in [0,63] -> signed bytes (w - 32), SWAR without inter-byte borrow
+static __device__ __forceinline__ uint32_t sub32(uint32_t w) { return ((w | 0x80808080u) - 0x20202020u) ^ 0x80808080u; }
+
+template <int NCOLS, int ROWS, int U, bool PAIR>
+static __device__ __forceinline__ void q6k_body(const char * __restrict__ W0, const char * __restrict__ W1, size_t w_rs, const mmv_out o,
+                                                int K, int nrows, int wave, int nwaves) {
+    const int lane = threadIdx.x & 63;
+    const int g = lane >> 3, lp = lane & 7, n = lp >> 2, tp = lp & 3;
+    const int nb  = K >> 8;
+    const int nit = (nb + 8 * U - 1) / (8 * U);
+    const size_t img = q8k_image_bytes(K);
+    const int ngrp = PAIR ? nrows : (nrows + ROWS - 1) / ROWS;
+
+    u32x2 qla[U][ROWS], qlb[U][ROWS], qh[U][ROWS], sc8[U][ROWS]; uint32_t dw[U][ROWS];
+    auto issue2 = [&](int grp, int it) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            int ib = (it * U + u) * 8 + g; ib = ib < nb ? ib : nb - 1;
+#pragma unroll
+            for (int r = 0; r < ROWS; ++r) {
+                int row = PAIR ? grp : grp * ROWS + r; row = row < nrows ? row : nrows - 1;
+                const char * bp = ((PAIR && r == 1) ? W1 : W0) + (size_t) row * w_rs + (size_t) ib * 210;
+                qla[u][r] = ld_piece8(bp + 64 * n + 8 * tp);
+                qlb[u][r] = ld_piece8(bp + 64 * n + 32 + 8 * tp);
+                qh[u][r]  = ld_piece8(bp + 128 + 32 * n + 8 * tp);
+                sc8[u][r] = ld_piece8_tail(bp + 192 + 8 * n);              // scales[8n .. 8n+7]
+                dw[u][r]  = __builtin_nontemporal_load((const uint16_t *) (bp + 208));
+            }
+        }
+    };
+
+    int grp = wave, it = 0;
+    if (grp >= ngrp) return;
+    issue2(grp, 0);
+
+    float acc[ROWS][NCOLS];
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r)
+#pragma unroll
+        for (int c = 0; c < NCOLS; ++c) acc[r][c] = 0.0f;
+
+    const int is = tp >> 1;                 // l/16 for l in [8tp, 8tp+8)
+    while (true) {
+        u32x2 cqla[U][ROWS], cqlb[U][ROWS], cqh[U][ROWS], csc[U][ROWS]; uint32_t cdw[U][ROWS];
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int r = 0; r < ROWS; ++r) { cqla[u][r] = qla[u][r]; cqlb[u][r] = qlb[u][r]; cqh[u][r] = qh[u][r]; csc[u][r] = sc8[u][r]; cdw[u][r] = dw[u][r]; }
+        const int cgrp = grp, cit = it;
+        ++it;
+        if (it == nit) { it = 0; grp += nwaves; }
+        const bool more = grp < ngrp;
+        if (more) issue2(grp, it);
+
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int  ib    = (cit * U + u) * 8 + g;
+            const bool valid = ib < nb;
+            const int  ibc   = valid ? ib : nb - 1;
+            u32x2 a[NCOLS][4]; float yd[NCOLS];
+#pragma unroll
+            for (int c = 0; c < NCOLS; ++c) {
+                const char * im = mmv_lds + c * img;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) a[c][k] = *(const u32x2 *) (im + ibc * 256 + 128 * n + 32 * k + 8 * tp);
+                yd[c] = *(const float *) (im + K + (K >> 3) + ibc * 4);
+            }
+#pragma unroll
+            for (int r = 0; r < ROWS; ++r) {
+                // scales[8n + is + {0,2,4,6}] (signed)
+                const uint32_t s01 = csc[u][r][0] >> (8 * is), s23 = csc[u][r][1] >> (8 * is);
+                const int sc0 = (int8_t) (s01 & 0xff), sc1 = (int8_t) ((s01 >> 16) & 0xff);
+                const int sc2 = (int8_t) (s23 & 0xff), sc3 = (int8_t) ((s23 >> 16) & 0xff);
+                const float dx = h2f((uint16_t) cdw[u][r]);
+                uint32_t w[4][2];
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const uint32_t la = cqla[u][r][e], lb = cqlb[u][r][e], hh = cqh[u][r][e];
+                    w[0][e] = sub32((la & 0x0f0f0f0fu)        | ((hh << 4) & 0x30303030u));
+                    w[1][e] = sub32((lb & 0x0f0f0f0fu)        | ((hh << 2) & 0x30303030u));
+                    w[2][e] = sub32(((la >> 4) & 0x0f0f0f0fu) | (hh & 0x30303030u));
+                    w[3][e] = sub32(((lb >> 4) & 0x0f0f0f0fu) | ((hh >> 2) & 0x30303030u));
+                }
+                const bool rv = valid && (PAIR ? cgrp : cgrp * ROWS + r) < nrows;
+#pragma unroll
+                for (int c = 0; c < NCOLS; ++c) {
+                    const int d0 = dot4(w[0][1], a[c][0][1], dot4(w[0][0], a[c][0][0], 0));
+                    const int d1 = dot4(w[1][1], a[c][1][1], dot4(w[1][0], a[c][1][0], 0));
+                    const int d2 = dot4(w[2][1], a[c][2][1], dot4(w[2][0], a[c][2][0], 0));
+                    const int d3 = dot4(w[3][1], a[c][3][1], dot4(w[3][0], a[c][3][0], 0));
+                    const int isum = sc0 * d0 + sc1 * d1 + sc2 * d2 + sc3 * d3;
+                    const float t = (dx * yd[c]) * (float) isum;
+                    acc[r][c] += rv ? t : 0.0f;
+                }
+            }
+        }
+
+        if (cit == nit - 1) {
+            if (PAIR) {
+#pragma unroll
+                for (int c = 0; c < NCOLS; ++c) {
+                    const float gsum = wave_sum(acc[0][c]), usum = wave_sum(acc[1][c]);
+                    if (lane == 0) *(float *) (o.dst + c * o.dst_cs + (size_t) cgrp * 4) = silu_f(gsum) * usum;
+                    acc[0][c] = 0.0f; acc[1][c] = 0.0f;
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < ROWS; ++r) {
+                    const int row = cgrp * ROWS + r;
+#pragma unroll
+                    for (int c = 0; c < NCOLS; ++c) {
+                        float s = wave_sum(acc[r][c]);
+                        if (lane == 0 && row < nrows) {
+                            if (o.resid) s += *(const float *) (o.resid + c * o.resid_cs + (size_t) row * 4);
+                            *(float *) (o.dst + c * o.dst_cs + (size_t) row * 4) = s;
+                        }
+                        acc[r][c] = 0.0f;
+                    }
+                }
+            }
+        }
+        if (!more) break;
+    }
+}
+
+// =================================================================================================
+// kernels
+// =================================================================================================
+struct mmv_mat_dev { const char * W; size_t w_rs; mmv_out o; int nrows; int type; int wave_end; };   // waves [prev.wave_end, wave_end) work on this matrix
+struct mmv_multi_dev { mmv_mat_dev m[3]; int nmat; const char * act; size_t act_cs; int K; };
+
+// TM: bit0 = Q4_K bodies compiled in, bit1 = Q6_K bodies compiled in
+template <int NCOLS, int ROWS, int U, int TM>
+__global__ void __launch_bounds__(256) k_mmv_multi(const mmv_multi_dev a) {
+    stage_act_k(a.act, a.act_cs, NCOLS, q8k_image_bytes(a.K));
+    __syncthreads();
+    const int wave = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+    int mi_ = 0, w0 = 0;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) if (i + 1 < a.nmat && wave >= a.m[i].wave_end) { mi_ = i + 1; w0 = a.m[i].wave_end; }
+    // (static selection so the descriptor stays in SGPRs)
+    const mmv_mat_dev M = mi_ == 0 ? a.m[0] : (mi_ == 1 ? a.m[1] : a.m[2]);
+    const int lw = wave - w0, nw = M.wave_end - w0;
+    if ((TM & 1) && M.type == GGML_TYPE_Q4_K) q4k_body<NCOLS, ROWS, U, false>(M.W, nullptr, M.w_rs, M.o, a.K, M.nrows, lw, nw);
+    if ((TM & 2) && M.type == GGML_TYPE_Q6_K) q6k_body<NCOLS, ROWS, U, false>(M.W, nullptr, M.w_rs, M.o, a.K, M.nrows, lw, nw);
+}
+
+template <int NCOLS, int U, int TYPE>
+__global__ void __launch_bounds__(256) k_mmv_pair(const char * __restrict__ Wg, const char * __restrict__ Wu, size_t w_rs, const char * __restrict__ act, size_t act_cs,
+                                                 char * __restrict__ dst, size_t dst_cs, int K, int nrows) {
+    stage_act_k(act, act_cs, NCOLS, q8k_image_bytes(K));
+    __syncthreads();
+    const int wave = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
+    const mmv_out o = { dst, dst_cs, nullptr, 0 };
+    if (TYPE == GGML_TYPE_Q4_K) q4k_body<NCOLS, 2, U, true>(Wg, Wu, w_rs, o, K, nrows, wave, nwaves);
+    else                        q6k_body<NCOLS, 2, U, true>(Wg, Wu, w_rs, o, K, nrows, wave, nwaves);
+}
+
+// ------------------------------------------------------------------------------------------------ launch
+static const size_t MMVK_LDS_MAX = 152 * 1024;
+
+template <int NCOLS, int ROWS, int U>
+static void launch_multi_tm(const mmv_multi_dev & d, int tm, int grid, size_t lds, hipStream_t st) {
+    auto go = [&](auto kern) {
+        if (lds > 64 * 1024) HIP_CHECK(hipFuncSetAttribute((const void *) kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
+        kern<<<dim3(grid), dim3(256), lds, st>>>(d);
+    };
+    if (tm == 1) go(k_mmv_multi<NCOLS, ROWS, U, 1>); else if (tm == 2) go(k_mmv_multi<NCOLS, ROWS, U, 2>); else go(k_mmv_multi<NCOLS, ROWS, U, 3>);
+}
+
+void mmv_kquant_multi(const mmv_multi_args & a, hipStream_t st) {
+    if (a.nmat == 0 || a.ncols == 0) return;
+    const size_t img = q8k_image_bytes(a.K);
+    if (img * a.ncols > MMVK_LDS_MAX) { fprintf(stderr, "[mi355x] mmv_kquant_multi: activation images exceed LDS (K=%lld, ncols=%d)\n", (long long) a.K, a.ncols); abort(); }
+    const int rows_pw = a.ncols <= 4 ? 2 : 1;
+    // grid: enough waves that every row group is resident at once when the matrices are small, capped at 8 WG/CU
+    double bytes[3]; double total = 0; int64_t groups = 0;
+    int tm = 0;
+    for (int i = 0; i < a.nmat; ++i) {
+        bytes[i] = (double) a.m[i].nrows * (double) (a.m[i].type == GGML_TYPE_Q4_K ? 144 : 210) * (double) (a.K / 256);
+        total += bytes[i];
+        groups += (a.m[i].nrows + rows_pw - 1) / rows_pw;
+        tm |= a.m[i].type == GGML_TYPE_Q4_K ? 1 : 2;
+    }
+    int64_t grid = (groups + 3) / 4;
+    if (grid > 2048) grid = 2048;
+    if (grid < 1) grid = 1;
+    const int nwaves = (int) grid * 4;
+    mmv_multi_dev d;
+    d.nmat = a.nmat; d.act = (const char *) a.act; d.act_cs = a.act_cs; d.K = (int) a.K;
+    int acc_w = 0; double acc_b = 0;
+    for (int i = 0; i < 3; ++i) {
+        if (i >= a.nmat) { d.m[i] = d.m[0]; d.m[i].wave_end = nwaves; continue; }
+        acc_b += bytes[i];
+        int end = i == a.nmat - 1 ? nwaves : (int) (nwaves * (acc_b / total) + 0.5);
+        if (end <= acc_w) end = acc_w + 1;                                   // every matrix gets at least one wave
+        if (end > nwaves - (a.nmat - 1 - i)) end = nwaves - (a.nmat - 1 - i);
+        d.m[i].W = (const char *) a.m[i].W; d.m[i].w_rs = a.m[i].w_rs; d.m[i].nrows = (int) a.m[i].nrows; d.m[i].type = a.m[i].type;
+        d.m[i].o = { (char *) a.m[i].dst, a.m[i].dst_cs, (const char *) a.m[i].resid, a.m[i].resid_cs };
+        d.m[i].wave_end = end; acc_w = end;
+    }
+    const int nstep = (int) ((a.K / 256 + 7) / 8);
+    const size_t lds = img * a.ncols;
+    const bool u2 = nstep >= 2 && a.ncols == 1;
+#define MM_GO(NC, R, UU) launch_multi_tm<NC, R, UU>(d, tm, (int) grid, lds, st)
+    switch (a.ncols) {
+        case 1: if (u2) MM_GO(1, 2, 2); else MM_GO(1, 2, 1); break;
+        case 2: MM_GO(2, 2, 1); break;
+        case 3: MM_GO(3, 2, 1); break;
+        case 4: MM_GO(4, 2, 1); break;
+        case 5: MM_GO(5, 1, 1); break;
+        case 6: MM_GO(6, 1, 1); break;
+        case 7: MM_GO(7, 1, 1); break;
+        case 8: MM_GO(8, 1, 1); break;
+        default: fprintf(stderr, "[mi355x] mmv_kquant_multi: ncols=%d out of range\n", a.ncols); abort();
+    }
+#undef MM_GO
+}
+
+void mmv_kquant_pair_swiglu(int type, const void * Wg, const void * Wu, size_t w_rs, const void * act, size_t act_cs, float * dst, size_t dst_cs,
+                            int64_t K, int64_t nrows, int ncols, hipStream_t st) {
+    if (nrows == 0 || ncols == 0) return;
+    const size_t lds = q8k_image_bytes(K) * ncols;
+    int64_t grid = (nrows + 3) / 4; if (grid > 2048) grid = 2048;
+    const bool u2 = (K / 256 + 7) / 8 >= 2 && ncols == 1;
+#define MP_GO(NC, UU)                                                                                                  \
+    do {                                                                                                               \
+        if (type == GGML_TYPE_Q4_K) k_mmv_pair<NC, UU, GGML_TYPE_Q4_K><<<dim3((unsigned) grid), dim3(256), lds, st>>>(  \
+            (const char *) Wg, (const char *) Wu, w_rs, (const char *) act, act_cs, (char *) dst, dst_cs, (int) K, (int) nrows);  \
+        else k_mmv_pair<NC, UU, GGML_TYPE_Q6_K><<<dim3((unsigned) grid), dim3(256), lds, st>>>(                         \
+            (const char *) Wg, (const char *) Wu, w_rs, (const char *) act, act_cs, (char *) dst, dst_cs, (int) K, (int) nrows);  \
+    } while (0)
+    switch (ncols) {
+        case 1: if (u2) MP_GO(1, 2); else MP_GO(1, 1); break;
+        case 2: MP_GO(2, 1); break;
+        case 3: MP_GO(3, 1); break;
+        case 4: MP_GO(4, 1); break;
+        default: fprintf(stderr, "[mi355x] mmv_kquant_pair_swiglu: ncols=%d out of range (1..4)\n", ncols); abort();
+    }
+#undef MP_GO
+}
+
+} // namespace mi

@@ -1,4 +1,4 @@
-// mmvq.hip -- weight-streaming mat-vec kernels (decode hot loop) for gfx950 / wave64.
+// mmvq.hip -- weight-streaming mat-vec kernels for Q8_0 / F16 / F32 weights (gfx950, wave64); the K-quants live in mmvk.hip.
 //
 // Computes what the reference CPU backend computes in ggml_compute_forward_mul_mat
 // (ggml-cpu/ggml-cpu.c:1210-1402) for ne11 <= 8: every output is one `vec_dot` of a quantised weight
@@ -29,268 +29,6 @@ static __device__ __forceinline__ void stage_act(const char * act, size_t act_cs
         const u32x4 * s = (const u32x4 *) (act + c * act_cs);
         u32x4 *       d = (u32x4 *) (mmv_lds + c * bytes);
         for (int i = threadIdx.x; i < n16; i += blockDim.x) d[i] = s[i];
-    }
-}
-
-// =================================================================================================
-// Q4_K : 144-B super-block = 16-B header {d, dmin, 12 B of 6-bit scales/mins} + 128 B of nibbles
-// (ggml-common.h:295-305).  8 lanes per super-block: lane (j = lp>>1, h = lp&1) owns qs[32j+16h .. +16),
-// i.e. 16 low nibbles of sub-block 2j and 16 high nibbles of sub-block 2j+1 (dequantize_row_q4_K,
-// ggml-quants.c:1352-1374).  A wave covers 8 super-blocks (1152 contiguous bytes) per step.
-// =================================================================================================
-template <int NCOLS, int ROWS, int U>
-__global__ void __launch_bounds__(256) k_mmv_q4k(const char * __restrict__ W, size_t w_rs, const char * __restrict__ act, size_t act_cs,
-                                                char * __restrict__ dst, size_t dst_cs, int K, int nrows) {
-    const int lane = threadIdx.x & 63;
-    const int g = lane >> 3, lp = lane & 7, j = lp >> 1, h = lp & 1;
-    const int nb  = K >> 8;
-    const int nit = (nb + 8 * U - 1) / (8 * U);          // pipeline stages per row group (U steps of 8 super-blocks each)
-    const size_t img = q8k_image_bytes(K);
-
-    const int wave   = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int nwaves = gridDim.x * 4;
-    const int ngrp   = (nrows + ROWS - 1) / ROWS;
-
-    // ---- software pipeline state: loads for stage (grp, it)
-    u32x4 hdr[U][ROWS], qs[U][ROWS];
-    auto issue = [&](int grp, int it) {
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            int ib = (it * U + u) * 8 + g; ib = ib < nb ? ib : nb - 1;
-#pragma unroll
-            for (int r = 0; r < ROWS; ++r) {
-                int row = grp * ROWS + r; row = row < nrows ? row : nrows - 1;
-                const char * bp = W + (size_t) row * w_rs + (size_t) ib * 144;
-                hdr[u][r] = ld_nt16(bp);
-                qs[u][r]  = ld_nt16(bp + 16 + lp * 16);
-            }
-        }
-    };
-
-    int grp = wave, it = 0;
-    if (grp < ngrp) issue(grp, 0);
-
-    stage_act(act, act_cs, NCOLS, img);
-    __syncthreads();
-    if (grp >= ngrp) return;
-
-    float acc[ROWS][NCOLS];
-#pragma unroll
-    for (int r = 0; r < ROWS; ++r)
-#pragma unroll
-        for (int c = 0; c < NCOLS; ++c) acc[r][c] = 0.0f;
-
-    const int sh = (j & 1) * 16;
-    while (true) {
-        // take ownership of the loaded stage, then immediately issue the next one
-        u32x4 chdr[U][ROWS], cqs[U][ROWS];
-#pragma unroll
-        for (int u = 0; u < U; ++u)
-#pragma unroll
-            for (int r = 0; r < ROWS; ++r) { chdr[u][r] = hdr[u][r]; cqs[u][r] = qs[u][r]; }
-        const int cgrp = grp, cit = it;
-        ++it;
-        if (it == nit) { it = 0; grp += nwaves; }
-        const bool more = grp < ngrp;
-        if (more) issue(grp, it);
-
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int  ib    = (cit * U + u) * 8 + g;
-            const bool valid = ib < nb;
-            const int  ibc   = valid ? ib : nb - 1;
-
-            // activation pieces for this lane (LDS)
-            u32x4 alo[NCOLS], ahi[NCOLS]; int bs0[NCOLS], bs1[NCOLS]; float yd[NCOLS];
-#pragma unroll
-            for (int c = 0; c < NCOLS; ++c) {
-                const char * im = mmv_lds + c * img;
-                alo[c] = *(const u32x4 *) (im + ibc * 256 + 64 * j + 16 * h);
-                ahi[c] = *(const u32x4 *) (im + ibc * 256 + 64 * j + 16 * h + 32);
-                const u32x2 b = *(const u32x2 *) (im + K + (ibc * 16 + 4 * j) * 2);       // bsums[4j .. 4j+3]
-                bs0[c] = (int) (int16_t) (h ? (b[0] >> 16) : b[0]);                       // bsums[4j + h]
-                bs1[c] = (int) (int16_t) (h ? (b[1] >> 16) : b[1]);                       // bsums[4j + 2 + h]
-                yd[c]  = *(const float *) (im + K + (K >> 3) + ibc * 4);
-            }
-
-#pragma unroll
-            for (int r = 0; r < ROWS; ++r) {
-                const uint32_t u0 = chdr[u][r][1], u1 = chdr[u][r][2], u2 = chdr[u][r][3];
-                // 6-bit scale/min unpack, same bit surgery as ggml-cpu/quants.c:592-597 / get_scale_min_k4
-                const uint32_t s_lo = u0 & 0x3f3f3f3fu;
-                const uint32_t s_hi = (u2 & 0x0f0f0f0fu) | (((u0 >> 6) & 0x03030303u) << 4);
-                const uint32_t m_lo = u1 & 0x3f3f3f3fu;
-                const uint32_t m_hi = ((u2 >> 4) & 0x0f0f0f0fu) | (((u1 >> 6) & 0x03030303u) << 4);
-                const uint32_t sw = (j < 2 ? s_lo : s_hi) >> sh;
-                const uint32_t mw = (j < 2 ? m_lo : m_hi) >> sh;
-                const int sc0 = sw & 0xff, sc1 = (sw >> 8) & 0xff;
-                const int mn0 = mw & 0xff, mn1 = (mw >> 8) & 0xff;
-                const float dx   = h2f((uint16_t) (chdr[u][r][0] & 0xffff));
-                const float dmin = h2f((uint16_t) (chdr[u][r][0] >> 16));
-
-                uint32_t lo[4], hi[4];
-#pragma unroll
-                for (int k = 0; k < 4; ++k) { lo[k] = cqs[u][r][k] & 0x0f0f0f0fu; hi[k] = (cqs[u][r][k] >> 4) & 0x0f0f0f0fu; }
-
-                const bool rv = valid && (cgrp * ROWS + r) < nrows;
-#pragma unroll
-                for (int c = 0; c < NCOLS; ++c) {
-                    int dl = 0, dh = 0;
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) { dl = dot4(lo[k], alo[c][k], dl); dh = dot4(hi[k], ahi[c][k], dh); }
-                    const int isum = sc0 * dl + sc1 * dh;
-                    const int msum = mn0 * bs0[c] + mn1 * bs1[c];
-                    const float t = (dx * yd[c]) * (float) isum - (dmin * yd[c]) * (float) msum;
-                    acc[r][c] += rv ? t : 0.0f;
-                }
-            }
-        }
-
-        if (cit == nit - 1) {             // row group finished: butterfly and store
-#pragma unroll
-            for (int r = 0; r < ROWS; ++r) {
-                const int row = cgrp * ROWS + r;
-#pragma unroll
-                for (int c = 0; c < NCOLS; ++c) {
-                    const float s = wave_sum(acc[r][c]);
-                    if (lane == 0 && row < nrows) *(float *) (dst + c * dst_cs + (size_t) row * 4) = s;
-                    acc[r][c] = 0.0f;
-                }
-            }
-        }
-        if (!more) break;
-    }
-}
-
-// =================================================================================================
-// Q6_K : 210-B super-block {ql[128], qh[64], int8 scales[16], f16 d} (ggml-common.h:330-335); only 2-byte
-// aligned, so pieces are fetched with (hardware-)unaligned 8-B loads.  8 lanes per super-block:
-// lane (n = lp>>2, tp = lp&3) owns l in [8tp, 8tp+8) of the 128-half n:
-//   ql[64n+l], ql[64n+32+l], qh[32n+l]  ->  4 x 8 six-bit weights at y[128n + {0,32,64,96} + l]
-// (dequantize_row_q6_K, ggml-quants.c:1762-1791).  A wave covers 8 super-blocks (1680 B) per step.
-// =================================================================================================
-static __device__ __forceinline__ u32x2 ld_u8x8(const char * p) {      // 2-B aligned 8-byte load
-    typedef uint32_t __attribute__((aligned(2))) u32a2;
-    u32x2 v; v[0] = __builtin_nontemporal_load((const u32a2 *) p); v[1] = __builtin_nontemporal_load((const u32a2 *) (p + 4));
-    return v;
-}
-// bytes in [0,63] -> signed bytes (w - 32), SWAR without inter-byte borrow
-static __device__ __forceinline__ uint32_t sub32(uint32_t w) { return ((w | 0x80808080u) - 0x20202020u) ^ 0x80808080u; }
-
-template <int NCOLS, int ROWS, int U>
-__global__ void __launch_bounds__(256) k_mmv_q6k(const char * __restrict__ W, size_t w_rs, const char * __restrict__ act, size_t act_cs,
-                                                char * __restrict__ dst, size_t dst_cs, int K, int nrows) {
-    const int lane = threadIdx.x & 63;
-    const int g = lane >> 3, lp = lane & 7, n = lp >> 2, tp = lp & 3;
-    const int nb  = K >> 8;
-    const int nit = (nb + 8 * U - 1) / (8 * U);
-    const size_t img = q8k_image_bytes(K);
-
-    const int wave   = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int nwaves = gridDim.x * 4;
-    const int ngrp   = (nrows + ROWS - 1) / ROWS;
-
-    u32x2 qla[U][ROWS], qlb[U][ROWS], qh[U][ROWS], scw[U][ROWS]; uint32_t dw[U][ROWS];
-    auto issue = [&](int grp, int it) {
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            int ib = (it * U + u) * 8 + g; ib = ib < nb ? ib : nb - 1;
-#pragma unroll
-            for (int r = 0; r < ROWS; ++r) {
-                int row = grp * ROWS + r; row = row < nrows ? row : nrows - 1;
-                const char * bp = W + (size_t) row * w_rs + (size_t) ib * 210;
-                qla[u][r] = ld_u8x8(bp + 64 * n + 8 * tp);
-                qlb[u][r] = ld_u8x8(bp + 64 * n + 32 + 8 * tp);
-                qh[u][r]  = ld_u8x8(bp + 128 + 32 * n + 8 * tp);
-                scw[u][r] = ld_u8x8(bp + 192 + 8 * n);
-                dw[u][r]  = __builtin_nontemporal_load((const uint16_t *) (bp + 208));
-            }
-        }
-    };
-
-    int grp = wave, it = 0;
-    if (grp < ngrp) issue(grp, 0);
-    stage_act(act, act_cs, NCOLS, img);
-    __syncthreads();
-    if (grp >= ngrp) return;
-
-    float acc[ROWS][NCOLS];
-#pragma unroll
-    for (int r = 0; r < ROWS; ++r)
-#pragma unroll
-        for (int c = 0; c < NCOLS; ++c) acc[r][c] = 0.0f;
-
-    const int is = tp >> 1;                 // l/16 for l in [8tp, 8tp+8)
-    while (true) {
-        u32x2 cqla[U][ROWS], cqlb[U][ROWS], cqh[U][ROWS], cscw[U][ROWS]; uint32_t cdw[U][ROWS];
-#pragma unroll
-        for (int u = 0; u < U; ++u)
-#pragma unroll
-            for (int r = 0; r < ROWS; ++r) { cqla[u][r] = qla[u][r]; cqlb[u][r] = qlb[u][r]; cqh[u][r] = qh[u][r]; cscw[u][r] = scw[u][r]; cdw[u][r] = dw[u][r]; }
-        const int cgrp = grp, cit = it;
-        ++it;
-        if (it == nit) { it = 0; grp += nwaves; }
-        const bool more = grp < ngrp;
-        if (more) issue(grp, it);
-
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int  ib    = (cit * U + u) * 8 + g;
-            const bool valid = ib < nb;
-            const int  ibc   = valid ? ib : nb - 1;
-
-            u32x2 a[NCOLS][4]; float yd[NCOLS];
-#pragma unroll
-            for (int c = 0; c < NCOLS; ++c) {
-                const char * im = mmv_lds + c * img;
-#pragma unroll
-                for (int k = 0; k < 4; ++k) a[c][k] = *(const u32x2 *) (im + ibc * 256 + 128 * n + 32 * k + 8 * tp);
-                yd[c] = *(const float *) (im + K + (K >> 3) + ibc * 4);
-            }
-
-#pragma unroll
-            for (int r = 0; r < ROWS; ++r) {
-                // scales[8n + is + {0,2,4,6}] (signed)
-                const uint32_t s01 = cscw[u][r][0] >> (8 * is), s23 = cscw[u][r][1] >> (8 * is);
-                const int sc0 = (int8_t) (s01 & 0xff), sc1 = (int8_t) ((s01 >> 16) & 0xff);
-                const int sc2 = (int8_t) (s23 & 0xff), sc3 = (int8_t) ((s23 >> 16) & 0xff);
-                const float dx = h2f((uint16_t) cdw[u][r]);
-                uint32_t w[4][2];
-#pragma unroll
-                for (int e = 0; e < 2; ++e) {
-                    const uint32_t la = cqla[u][r][e], lb = cqlb[u][r][e], hh = cqh[u][r][e];
-                    w[0][e] = sub32((la & 0x0f0f0f0fu)        | ((hh << 4) & 0x30303030u));
-                    w[1][e] = sub32((lb & 0x0f0f0f0fu)        | ((hh << 2) & 0x30303030u));
-                    w[2][e] = sub32(((la >> 4) & 0x0f0f0f0fu) | (hh & 0x30303030u));
-                    w[3][e] = sub32(((lb >> 4) & 0x0f0f0f0fu) | ((hh >> 2) & 0x30303030u));
-                }
-                const bool rv = valid && (cgrp * ROWS + r) < nrows;
-#pragma unroll
-                for (int c = 0; c < NCOLS; ++c) {
-                    const int d0 = dot4(w[0][1], a[c][0][1], dot4(w[0][0], a[c][0][0], 0));
-                    const int d1 = dot4(w[1][1], a[c][1][1], dot4(w[1][0], a[c][1][0], 0));
-                    const int d2 = dot4(w[2][1], a[c][2][1], dot4(w[2][0], a[c][2][0], 0));
-                    const int d3 = dot4(w[3][1], a[c][3][1], dot4(w[3][0], a[c][3][0], 0));
-                    const int isum = sc0 * d0 + sc1 * d1 + sc2 * d2 + sc3 * d3;
-                    const float t = (dx * yd[c]) * (float) isum;
-                    acc[r][c] += rv ? t : 0.0f;
-                }
-            }
-        }
-
-        if (cit == nit - 1) {
-#pragma unroll
-            for (int r = 0; r < ROWS; ++r) {
-                const int row = cgrp * ROWS + r;
-#pragma unroll
-                for (int c = 0; c < NCOLS; ++c) {
-                    const float s = wave_sum(acc[r][c]);
-                    if (lane == 0 && row < nrows) *(float *) (dst + c * dst_cs + (size_t) row * 4) = s;
-                    acc[r][c] = 0.0f;
-                }
-            }
-        }
-        if (!more) break;
     }
 }
 
@@ -479,58 +217,17 @@ static void launch_mmv(mmv_kernel_t k, int rows_per_wave, size_t lds, const mmv_
 }
 
 // tuning knob (decode, ncols == 1): MI355X_MMV_CFG = "<rows><u>" e.g. "22" (default), "12", "21", "41"
-static int mmv_cfg() {
-    static int cfg = -1;
-    if (cfg < 0) { const char * e = getenv("MI355X_MMV_CFG"); cfg = e ? atoi(e) : 0; }
-    return cfg;
-}
-
-#define MMV_TABLE(KERNEL)                                                                                              \
-    static mmv_kernel_t KERNEL##_pick(int ncols, int nstep, int * rows) {                                              \
-        if (ncols == 1) {                                                                                              \
-            switch (mmv_cfg()) {                                                                                       \
-                case 12: *rows = 1; return KERNEL<1, 1, 2>;                                                            \
-                case 14: *rows = 1; return KERNEL<1, 1, 4>;                                                            \
-                case 21: *rows = 2; return KERNEL<1, 2, 1>;                                                            \
-                case 41: *rows = 4; return KERNEL<1, 4, 1>;                                                            \
-                case 42: *rows = 4; return KERNEL<1, 4, 2>;                                                            \
-                case 22: *rows = 2; return KERNEL<1, 2, 2>;                                                            \
-                default: break;                                                                                        \
-            }                                                                                                          \
-            *rows = 2;                                                                                                 \
-            return nstep >= 2 ? KERNEL<1, 2, 2> : KERNEL<1, 2, 1>;                                                     \
-        }                                                                                                              \
-        switch (ncols) {                                                                                               \
-            case 2: *rows = 2; return KERNEL<2, 2, 1>;                                                                 \
-            case 3: *rows = 2; return KERNEL<3, 2, 1>;                                                                 \
-            case 4: *rows = 2; return KERNEL<4, 2, 1>;                                                                 \
-            case 5: *rows = 1; return KERNEL<5, 1, 1>;                                                                 \
-            case 6: *rows = 1; return KERNEL<6, 1, 1>;                                                                 \
-            case 7: *rows = 1; return KERNEL<7, 1, 1>;                                                                 \
-            case 8: *rows = 1; return KERNEL<8, 1, 1>;                                                                 \
-            default: fprintf(stderr, "[mi355x] mmv: ncols=%d out of range\n", ncols); abort();                         \
-        }                                                                                                              \
-    }
-MMV_TABLE(k_mmv_q4k)
-MMV_TABLE(k_mmv_q6k)
-
-void mmv_q4_K(const mmv_args & a0, hipStream_t st) {
+static void mmv_kquant_single(int type, const mmv_args & a0, hipStream_t st) {
     if (a0.nrows == 0 || a0.ncols == 0) return;
-    const size_t ib = q8k_image_bytes(a0.K);
-    split_cols(a0, ib, [&](const mmv_args & a) {
-        int rows; mmv_kernel_t k = k_mmv_q4k_pick(a.ncols, (int) ((a.K / 256 + 7) / 8), &rows);
-        launch_mmv(k, rows, ib * a.ncols, a, st);
+    split_cols(a0, q8k_image_bytes(a0.K), [&](const mmv_args & a) {
+        mmv_multi_args m;
+        m.nmat = 1; m.act = a.act; m.act_cs = a.act_cs; m.K = a.K; m.ncols = a.ncols;
+        m.m[0] = { a.W, a.w_rs, a.dst, a.dst_cs, nullptr, 0, a.nrows, type };
+        mmv_kquant_multi(m, st);
     });
 }
-
-void mmv_q6_K(const mmv_args & a0, hipStream_t st) {
-    if (a0.nrows == 0 || a0.ncols == 0) return;
-    const size_t ib = q8k_image_bytes(a0.K);
-    split_cols(a0, ib, [&](const mmv_args & a) {
-        int rows; mmv_kernel_t k = k_mmv_q6k_pick(a.ncols, (int) ((a.K / 256 + 7) / 8), &rows);
-        launch_mmv(k, rows, ib * a.ncols, a, st);
-    });
-}
+void mmv_q4_K(const mmv_args & a, hipStream_t st) { mmv_kquant_single(GGML_TYPE_Q4_K, a, st); }
+void mmv_q6_K(const mmv_args & a, hipStream_t st) { mmv_kquant_single(GGML_TYPE_Q6_K, a, st); }
 
 void mmv_q8_0(const mmv_args & a0, hipStream_t st) {
     if (a0.nrows == 0 || a0.ncols == 0) return;

@@ -9,7 +9,7 @@
 namespace mi {
 
 // ------------------------------------------------------------------------------------------------
-// Q8_K image.  One wave per 256-element block; lane l owns elements 4l..4l+3.
+// One 256-element Q8_K block held by one wave (lane l owns elements 4l..4l+3), written into the image.
 //   reference: quantize_row_q8_K_ref, ggml-quants.c:2555-2592 (x86 `quantize_row_q8_K` forwards to it,
 //   ggml-cpu/arch/x86/quants.c:493-495):
 //     amax/max  : first element (lowest index) with the largest |x|   (strict '>' scan)
@@ -18,22 +18,7 @@ namespace mi {
 //     bsums[g]  = sum of 16 consecutive q
 //     d         = 1 / iscale           (amax == 0 -> d = 0, q = 0)
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_quantize_q8k(const char * __restrict__ x, size_t xs, char * __restrict__ img,
-                                                     int64_t K, int64_t nrows, size_t img_bytes) {
-    const int     lane = threadIdx.x & 63;
-    const int64_t nb   = K / 256;
-    const int64_t blk  = (int64_t) blockIdx.x * 4 + (threadIdx.x >> 6);     // global block id
-    if (blk >= nb * nrows) return;
-    const int64_t row = blk / nb, ib = blk % nb;
-
-    const float * xr = (const float *) (x + row * xs) + ib * 256;
-    char *        im = img + row * img_bytes;
-    int8_t *      qs = (int8_t *) im + ib * 256;
-    int16_t *     bs = (int16_t *) (im + K) + ib * 16;
-    float *       ds = (float *) (im + K + K / 8) + ib;
-
-    const f32x4 v = *(const f32x4 *) (xr + 4 * lane);
-
+static __device__ __forceinline__ void q8k_block_from_regs(const f32x4 v, int lane, int8_t * qs, int16_t * bs, float * ds) {
     // (|x|, index) arg-max with lowest-index tie-break == the reference's sequential strict-'>' scan
     float amax = fabsf(v[0]); float mval = v[0]; int idx = 4 * lane;
 #pragma unroll
@@ -48,14 +33,12 @@ __global__ void __launch_bounds__(256) k_quantize_q8k(const char * __restrict__ 
         const int   i2 = __shfl_xor(idx, o, 64);
         if (a2 > amax || (a2 == amax && i2 < idx)) { amax = a2; mval = m2; idx = i2; }
     }
-
     if (amax == 0.0f) {                  // all-zero block (also catches -0.0f)
         *(uint32_t *) (qs + 4 * lane) = 0u;
         if ((lane & 3) == 0) bs[lane >> 2] = 0;
         if (lane == 0) *ds = 0.0f;
         return;
     }
-
     const float iscale = -127.0f / mval;
     int q[4]; int s = 0;
 #pragma unroll
@@ -73,10 +56,58 @@ __global__ void __launch_bounds__(256) k_quantize_q8k(const char * __restrict__ 
     if (lane == 0) *ds = 1.0f / iscale;
 }
 
+// Q8_K image: one wave per 256-element block
+__global__ void __launch_bounds__(256) k_quantize_q8k(const char * __restrict__ x, size_t xs, char * __restrict__ img,
+                                                     int64_t K, int64_t nrows, size_t img_bytes) {
+    const int     lane = threadIdx.x & 63;
+    const int64_t nb   = K / 256;
+    const int64_t blk  = (int64_t) blockIdx.x * 4 + (threadIdx.x >> 6);     // global block id
+    if (blk >= nb * nrows) return;
+    const int64_t row = blk / nb, ib = blk % nb;
+    const float * xr = (const float *) (x + row * xs) + ib * 256;
+    char *        im = img + row * img_bytes;
+    const f32x4 v = *(const f32x4 *) (xr + 4 * lane);
+    q8k_block_from_regs(v, lane, (int8_t *) im + ib * 256, (int16_t *) (im + K) + ib * 16, (float *) (im + K + K / 8) + ib);
+}
+
 void quantize_q8k_image(const float * x, size_t xs, void * img, int64_t K, int64_t nrows, hipStream_t st) {
     const int64_t nblk = K / 256 * nrows;
     if (nblk == 0) return;
     k_quantize_q8k<<<dim3((unsigned) ((nblk + 3) / 4)), dim3(256), 0, st>>>((const char *) x, xs, (char *) img, K, nrows, q8k_image_bytes(K));
+}
+
+// ------------------------------------------------------------------------------------------------
+// RMS_NORM + MUL(w) + Q8_K image in one launch: one workgroup per row.
+//   y = (x * (1/sqrtf(mean(x^2)+eps))) * w      (ops.cpp:3517-3566 then the graph's MUL node; sum of squares in double)
+//   img = Q8_K(y)                                (what the following MUL_MATs would compute from y)
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(512) k_rms_norm_mul_quant(const char * __restrict__ x, size_t xs, const float * __restrict__ w, char * __restrict__ y, size_t ys,
+                                                           char * __restrict__ img, int64_t n, float eps, size_t img_bytes) {
+    __shared__ double red[16];
+    const int64_t row = blockIdx.x;
+    const float * xr = (const float *) (x + row * xs);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    double s = 0.0;
+    for (int64_t i = threadIdx.x; i < n; i += blockDim.x) { const float v = xr[i]; s += (double) (v * v); }
+    s = block_sum<double>(s, red);
+    const float mean  = (float) (s / (double) n);
+    const float scale = 1.0f / sqrtf(mean + eps);
+    char * im = img + row * img_bytes;
+    for (int64_t ib = wave; ib < n / 256; ib += nw) {
+        const f32x4 xv = *(const f32x4 *) (xr + ib * 256 + 4 * lane);
+        const f32x4 wv = *(const f32x4 *) (w + ib * 256 + 4 * lane);
+        f32x4 v;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = (xv[i] * scale) * wv[i];
+        if (y) *(f32x4 *) ((float *) (y + row * ys) + ib * 256 + 4 * lane) = v;
+        q8k_block_from_regs(v, lane, (int8_t *) im + ib * 256, (int16_t *) (im + n) + ib * 16, (float *) (im + n + n / 8) + ib);
+    }
+}
+
+void rms_norm_mul_quant(const float * x, size_t xs, const float * w, float * y, size_t ys, void * img, int64_t n, int64_t nrows, float eps, hipStream_t st) {
+    if (n == 0 || nrows == 0) return;
+    const int bs = n >= 2048 ? 512 : 256;
+    k_rms_norm_mul_quant<<<dim3((unsigned) nrows), dim3(bs), 0, st>>>((const char *) x, xs, w, (char *) y, ys, (char *) img, n, eps, q8k_image_bytes(n));
 }
 
 // ------------------------------------------------------------------------------------------------
