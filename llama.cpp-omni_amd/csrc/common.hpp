@@ -91,6 +91,54 @@ static __device__ __forceinline__ float block_max(float v, float * scratch) {
     for (int i = 1; i < nw; ++i) r = fmaxf(r, scratch[i]);
     return r;
 }
+// ------------------------------------------------------------------------------------------------
+// One 256-element Q8_K block held by one wave (lane l owns elements 4l..4l+3), written into the image.
+//   reference: quantize_row_q8_K_ref, ggml-quants.c:2555-2592 (x86 `quantize_row_q8_K` forwards to it,
+//   ggml-cpu/arch/x86/quants.c:493-495):
+//     amax/max  : first element (lowest index) with the largest |x|   (strict '>' scan)
+//     iscale    = -127.f / max
+//     q[j]      = min(127, nearest_int(iscale * x[j]))   -- nearest_int == round-half-even (:444-449)
+//     bsums[g]  = sum of 16 consecutive q
+//     d         = 1 / iscale           (amax == 0 -> d = 0, q = 0)
+// ------------------------------------------------------------------------------------------------
+static __device__ __forceinline__ void q8k_block_from_regs(const f32x4 v, int lane, int8_t * qs, int16_t * bs, float * ds) {
+    // (|x|, index) arg-max with lowest-index tie-break == the reference's sequential strict-'>' scan
+    float amax = fabsf(v[0]); float mval = v[0]; int idx = 4 * lane;
+#pragma unroll
+    for (int i = 1; i < 4; ++i) {
+        const float a = fabsf(v[i]);
+        if (a > amax) { amax = a; mval = v[i]; idx = 4 * lane + i; }
+    }
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const float a2 = __shfl_xor(amax, o, 64);
+        const float m2 = __shfl_xor(mval, o, 64);
+        const int   i2 = __shfl_xor(idx, o, 64);
+        if (a2 > amax || (a2 == amax && i2 < idx)) { amax = a2; mval = m2; idx = i2; }
+    }
+    if (amax == 0.0f) {                  // all-zero block (also catches -0.0f)
+        *(uint32_t *) (qs + 4 * lane) = 0u;
+        if ((lane & 3) == 0) bs[lane >> 2] = 0;
+        if (lane == 0) *ds = 0.0f;
+        return;
+    }
+    const float iscale = -127.0f / mval;
+    int q[4]; int s = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float p = iscale * v[i];               // one rounding, like the C source (no FMA with the magic add)
+        int r = (int) __builtin_rintf(p);            // round-half-even == nearest_int()
+        r = r > 127 ? 127 : r;
+        q[i] = r; s += r;
+    }
+    *(uint32_t *) (qs + 4 * lane) = (uint32_t) (q[0] & 0xff) | ((uint32_t) (q[1] & 0xff) << 8) |
+                                    ((uint32_t) (q[2] & 0xff) << 16) | ((uint32_t) (q[3] & 0xff) << 24);
+    s += __shfl_xor(s, 1, 64);
+    s += __shfl_xor(s, 2, 64);
+    if ((lane & 3) == 0) bs[lane >> 2] = (int16_t) s;
+    if (lane == 0) *ds = 1.0f / iscale;
+}
+
 #endif // __HIPCC__
 
 // ---------------------------------------------------------------- activation scratch layout ("q8 image")

@@ -455,8 +455,54 @@ static bool exec_rms_norm(exec_state & s, int i) {
     const ggml_tensor * wt = m->src[0] == n ? m->src[1] : m->src[0];
     if ((m->src[0] == n) == (m->src[1] == n)) return false;
     if (!wt || wt == n || m->type != GGML_TYPE_F32 || wt->type != GGML_TYPE_F32 || wt->nb[0] != 4 || !same_shape(m, n) || !can_repeat(wt, n) || m->nb[0] != 4) return false;
+    // chain variant: RMS_NORM -> MUL(w[D]) -> ROPE [-> SET_ROWS(view as [D*H, T]) into an f16 table]: the q / k chains of a decoder layer
+    {
+        const int ri = sole_user(s, m);
+        const int64_t D = n->ne[0];
+        if (ri > mi_ && g->nodes[ri]->op == GGML_OP_ROPE && g->nodes[ri]->src[0] == m && D % 2 == 0 && D <= 256 && n->ne[3] == 1 &&
+            wt->ne[0] == D && wt->ne[1] * wt->ne[2] * wt->ne[3] == 1 && n->src[0]->nb[0] == 4) {
+            ggml_tensor * r = g->nodes[ri];
+            const int mode = op_param_i32(r, 2);
+            const ggml_tensor * pos = r->src[1], * ff = r->src[2];
+            int item[4] = { i, mi_, ri, -1 };
+            if ((mode == GGML_ROPE_TYPE_NORMAL || mode == GGML_ROPE_TYPE_NEOX) && op_param_i32(r, 1) == D && r->nb[0] == 4 && pos && pos->type == GGML_TYPE_I32 &&
+                pos->nb[0] == 4 && (!ff || (ff->type == GGML_TYPE_F32 && ff->nb[0] == 4)) && can_hoist(s, i, ri, item, 3)) {
+                norm_rope_args a;
+                const ggml_tensor * x = n->src[0];
+                a.x = (const float *) x->data; a.xnb1 = x->nb[1]; a.xnb2 = x->nb[2];
+                a.w = (const float *) wt->data; a.pos = (const int32_t *) pos->data; a.ff = ff ? (const float *) ff->data : nullptr;
+                a.y = (float *) r->data; a.ynb1 = r->nb[1]; a.ynb2 = r->nb[2];
+                a.kv = nullptr; a.kv_rs = 0; a.idx = nullptr; a.idx_is64 = 0; a.idx_nb0 = 0;
+                a.D = (int) D; a.H = (int) n->ne[1]; a.T = (int) n->ne[2]; a.eps = eps;
+                a.rp.n_dims = op_param_i32(r, 1); a.rp.mode = mode; a.rp.n_ctx_orig = op_param_i32(r, 4);
+                a.rp.freq_base = op_param_f32(r, 5); a.rp.freq_scale = op_param_f32(r, 6); a.rp.ext_factor = op_param_f32(r, 7);
+                a.rp.attn_factor = op_param_f32(r, 8); a.rp.beta_fast = op_param_f32(r, 9); a.rp.beta_slow = op_param_f32(r, 10);
+                // optional store of the rotated rows (llama_kv_cache::cpy_k)
+                int si = sole_user(s, r);
+                if (si > ri && g->nodes[si]->op == GGML_OP_SET_ROWS && !s.done[si]) {
+                    ggml_tensor * S = g->nodes[si];
+                    const ggml_tensor * V = S->src[0], * idx = S->src[1];
+                    item[3] = si;
+                    const bool ok = V && idx && V->data == r->data && V->ne[0] == D * n->ne[1] && V->ne[1] == n->ne[2] && V->ne[2] == 1 && V->ne[3] == 1 &&
+                                    V->nb[1] == r->nb[2] && r->nb[1] == (size_t) D * 4 && S->type == GGML_TYPE_F16 && S->nb[0] == 2 &&
+                                    (idx->type == GGML_TYPE_I64 || idx->type == GGML_TYPE_I32) && idx->ne[0] == n->ne[2] && idx->ne[1] == 1 && idx->ne[2] == 1 &&
+                                    can_hoist(s, i, si, item, 4);
+                    if (ok) {
+                        a.kv = S->data; a.kv_rs = S->nb[1]; a.idx = idx->data; a.idx_is64 = idx->type == GGML_TYPE_I64; a.idx_nb0 = idx->nb[0];
+                        a.y = nullptr;                                    // the only consumer was the store
+                    } else si = -1;
+                } else si = -1;
+                prof_scope ps(s, "norm_rope", 0);
+                norm_rope_store(a, s.st);
+                ++s.n_kernels; s.n_fused += si >= 0 ? 3 : 2;
+                s.done[mi_] = s.done[ri] = 1;
+                if (si >= 0) { s.done[si] = 1; note_write(s, g->nodes[si]); } else note_write(s, r);
+                return true;
+            }
+        }
+    }
     // image variant: row-contiguous 2-D activation, weight a plain [ne0] vector, every consumer a K-quant mat-vec on it
-    bool want_img = n->ne[0] % 256 == 0 && n->ne[2] == 1 && n->ne[3] == 1 && n->ne[1] <= MI_MMVQ_MAX_COLS && wt->ne[0] == n->ne[0] &&
+    bool want_img = rms_norm_mul_quant_ok(n->ne[0]) && n->ne[2] == 1 && n->ne[3] == 1 && n->ne[1] <= MI_MMVQ_MAX_COLS && wt->ne[0] == n->ne[0] &&
                     wt->ne[1] * wt->ne[2] * wt->ne[3] == 1 && n->src[0]->nb[0] == 4 && n_users(s, m) > 0;
     if (want_img) {
         for (int u : s.users[m]) {
@@ -561,9 +607,33 @@ static void compute_node(exec_state & s, int i) {
             f.sinks = n->src[4] ? (const float *) n->src[4]->data : nullptr;
             f.scale = op_param_f32(n, 0); f.max_bias = op_param_f32(n, 1); f.logit_softcap = op_param_f32(n, 2);
             f.scratch = nullptr; f.scratch_bytes = 0;
-            prof_scope ps(s, "fattn", 0);
-            flash_attn_ext_f16(f, s.st); ++s.n_kernels;
-            break;
+            // epilogue fusion: when the attention output only feeds K-quant mat-vecs (wo), emit its Q8_K image here
+            const ggml_tensor * xuse = nullptr;
+            if (s.c->opt_fusion && n->ne[3] == 1 && n->ne[2] <= MI_MMVQ_MAX_COLS && n_users(s, n) > 0 && !(n->flags & GGML_TENSOR_FLAG_OUTPUT) &&
+                rms_norm_mul_quant_ok(n->ne[0] * n->ne[1]) && fattn_can_emit_image(f)) {
+                bool ok = true;
+                for (int u : s.users[n]) {
+                    const ggml_tensor * c = g->nodes[u];
+                    const ggml_tensor * x = c->op == GGML_OP_MUL_MAT ? c->src[1] : nullptr;
+                    if (!x || !plain_kq_matvec(c, MI_MMVQ_MAX_COLS) || x->data != n->data || x->ne[0] != n->ne[0] * n->ne[1] || x->ne[1] != n->ne[2] ||
+                        x->nb[1] != (size_t) x->ne[0] * 4 || (xuse && !same_act(xuse, x))) { ok = false; break; }
+                    xuse = x;
+                }
+                if (!ok) xuse = nullptr;
+            }
+            if (xuse) f.img = s.c->act_scratch;
+            {
+                prof_scope ps(s, "fattn", 0);
+                flash_attn_ext_f16(f, s.st); ++s.n_kernels;
+            }
+            note_write(s, n);
+            if (xuse) {
+                s.a_src = xuse->data; s.a_kind = ACT_Q8K; s.a_K = xuse->ne[0]; s.a_ne[0] = xuse->ne[1]; s.a_ne[1] = 1; s.a_ne[2] = 1;
+                s.a_nb[0] = xuse->nb[1]; s.a_nb[1] = xuse->nb[2]; s.a_nb[2] = xuse->nb[3];
+                s.a_range_lo = (const char *) xuse->data; s.a_range_hi = (const char *) xuse->data + nbytes(xuse);
+                ++s.n_fused;
+            }
+            return;
         }
         default:
             log_msg(GGML_LOG_LEVEL_ERROR, "[mi355x] graph_compute: op %d (%s) reached the backend but is not implemented -- supports_op bug\n", (int) n->op, n->name);

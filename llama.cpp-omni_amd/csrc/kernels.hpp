@@ -96,9 +96,23 @@ struct fattn_args {
     float scale, max_bias, logit_softcap;
     void * scratch;          // split-KV partials
     size_t scratch_bytes;
+    void * img = nullptr;    // optional: also emit Q8_K images of the output rows [nh*D] (one per (seq, query row))
 };
 size_t fattn_scratch_bytes(const fattn_args & a);
+bool   fattn_can_emit_image(const fattn_args & a);
 void   flash_attn_ext_f16(const fattn_args & a, hipStream_t st);
+
+// RMS_NORM -> MUL(w) -> ROPE [-> SET_ROWS into an f16 table] on a [D, H, T] f32 activation, one launch
+struct norm_rope_args {
+    const float * x; int64_t xnb1, xnb2;     // head / token byte strides
+    const float * w; const int32_t * pos; const float * ff;
+    float * y; int64_t ynb1, ynb2;           // rope output (null when only the store is consumed)
+    void * kv; int64_t kv_rs;                // f16 table base and row stride (null when there is no store)
+    const void * idx; int idx_is64; int64_t idx_nb0;
+    int D, H, T; float eps; rope_params rp;
+};
+void norm_rope_store(const norm_rope_args & a, hipStream_t st);
+bool rms_norm_mul_quant_ok(int64_t n);
 
 // dense GEMM on the matrix cores: dst[n, m] (f32) = sum_k W[m,k] (f16) * X[n,k] (f16), f32 accumulate
 void gemm_f16_mfma(const uint16_t * W, size_t w_rs, const uint16_t * X, size_t x_rs, float * dst, size_t dst_cs,

@@ -1,4 +1,4 @@
-// fattn.hip -- FLASH_ATTN_EXT for gfx950 (wave64).
+// fattn.hip -- FLASH_ATTN_EXT for gfx950 (wave64), decode / short-query form.
 //
 // reference: ggml_compute_forward_flash_attn_ext_f16, ggml-cpu/ops.cpp:7912-8148
 //   per (query row, head):  Q -> f16 ; s_ic = (K_ic . Q) * scale (+softcap) + slope*mask_ic ; online softmax ;
@@ -6,12 +6,17 @@
 // Differences allowed by the reference's own tolerance (NMSE 5e-4, tests/test-backend-ops.cpp:5085):
 // the CPU accumulates V in f16 when V is f16 (:8069-8083); this kernel keeps f32 accumulators.
 //
-// "vec" kernel (decode and short query blocks): one workgroup of 4 waves owns R query vectors that share
-// one KV head (GQA group x a few query rows), so K and V are streamed once for the whole group instead of
-// once per head.  Waves split the KV range in 64-row tiles; a tile is staged in LDS (row stride padded by
-// 16 B -> conflict-free ds_read_b128 with lane == kv row), scores are computed lane-per-row, softmax is a
-// wave butterfly, P.V runs lane-per-dim-pair.  Tiles that are fully masked (-inf) are skipped without
-// touching K/V, which is what makes a 256-padded KV cache cheap at small depth.
+// One workgroup (4 waves) owns R query vectors that share one KV head (the GQA group x a few query rows), so K and V
+// are streamed once per group, not once per head.  The KV range is cut into 16-row granules dealt round-robin to the
+// waves.  K and V go from HBM/L2 straight into registers -- no LDS staging:
+//   scores : lane (r = lane>>2, dq = lane&3) holds dims [dq*D/4, (dq+1)*D/4) of granule row r (D/32 x 16-B loads, four lanes
+//            cover one contiguous row), dots them with the R queries (f32 in LDS, broadcast reads) and the four partial sums
+//            are folded with two DPP butterflies;
+//   P.V    : lane owns D/64 output dims; the 16 V rows of the granule are fetched by 16 coalesced row loads issued
+//            BEFORE the score arithmetic, so their latency hides under it.
+// Granules whose mask is -inf for every query vector are skipped without touching K/V: a 256-padded KV view costs nothing
+// at small depth.  The four waves' (M, S, acc) partials merge through LDS.  Optional epilogue: emit the Q8_K image of the
+// output row (what the following wo MUL_MAT would otherwise quantise in its own launch).
 #include "../kernels.hpp"
 
 namespace mi {
@@ -26,25 +31,26 @@ struct fa_dev {
     int gq;                                             // n_head / n_head_kv
     int hpw;                                            // heads handled per workgroup (<= R)
     int qpw;                                            // query rows per workgroup (R / hpw)
+    char * img; size_t img_bytes;                       // optional Q8_K image output (one image per (seq, query row)), else null
 };
 
 extern __shared__ __attribute__((aligned(16))) char fa_lds[];
 
 template <int D, int R>
-__global__ void __launch_bounds__(256) k_fattn_vec(fa_dev a) {
-    constexpr int RS   = D * 2 + 16;          // padded LDS row stride of a K/V tile (bytes)
-    constexpr int DPL  = D / 64;              // output dims per lane
-    constexpr int TILE = 64;
+__global__ void __launch_bounds__(256) k_fattn_dec(const fa_dev a) {
+    constexpr int DPL = D / 64;               // output dims per lane
+    constexpr int GR  = 16;                   // KV rows per granule
+    constexpr int KCH = D / 32;               // 16-B K chunks per lane (a quarter row)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r16 = lane >> 2, dq = lane & 3;
 
     // ---- which query vectors does this workgroup own
-    const int64_t ngrp_h = (a.gq + a.hpw - 1) / a.hpw;                    // head chunks per kv head
-    const int64_t nqb    = (a.nq + a.qpw - 1) / a.qpw;                    // query blocks
+    const int64_t ngrp_h = (a.gq + a.hpw - 1) / a.hpw;
+    const int64_t nqb    = (a.nq + a.qpw - 1) / a.qpw;
     int64_t b = blockIdx.x;
-    const int64_t qb  = b % nqb;   b /= nqb;
+    const int64_t qb  = b % nqb;    b /= nqb;
     const int64_t hc  = b % ngrp_h; b /= ngrp_h;
     const int64_t ikv = b % a.nhkv; const int64_t is3 = b / a.nhkv;
-    // r -> (query row, head)
     int64_t r_q[R], r_h[R]; bool r_ok[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
@@ -55,17 +61,16 @@ __global__ void __launch_bounds__(256) k_fattn_vec(fa_dev a) {
     }
 
     // ---- LDS carve-up
-    float * qf   = (float *) fa_lds;                                   // [R][D] queries (rounded through f16)
-    char *  tile = fa_lds + R * D * 4 + wave * (TILE * RS);            // per-wave K/V tile
-    float * pl   = (float *) (fa_lds + R * D * 4 + 4 * (TILE * RS)) + wave * (TILE * R);   // per-wave P[kv][R]
-    float * comb = (float *) (fa_lds + R * D * 4 + 4 * (TILE * RS) + 4 * TILE * R * 4);    // [4][R][D+2] merge area
+    float * qf   = (float *) fa_lds;                                                 // [R][D] queries (rounded through f16)
+    float * pl   = (float *) (fa_lds + R * D * 4) + wave * (GR * R);                 // per-wave P[16][R]
+    float * comb = (float *) (fa_lds + R * D * 4 + 4 * GR * R * 4);                  // [4][R][D+2] merge area, later [R][D] finals
 
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         for (int d = threadIdx.x; d < D; d += 256) {
             float v = 0.0f;
             if (r_ok[r]) v = *(const float *) (a.q + d * 4 + r_q[r] * a.qnb1 + r_h[r] * a.qnb2 + is3 * a.qnb3);
-            qf[r * D + d] = h2f(f2h(v));                                // q_to_vec_dot: f32 -> f16 (ops.cpp:8040)
+            qf[r * D + d] = h2f(f2h(v));                                              // q_to_vec_dot: f32 -> f16 (ops.cpp:8040)
         }
     }
     __syncthreads();
@@ -85,12 +90,11 @@ __global__ void __launch_bounds__(256) k_fattn_vec(fa_dev a) {
 
     const char * kbase = a.k + ikv * a.knb2 + is3 * a.knb3;
     const char * vbase = a.v + ikv * a.vnb2 + is3 * a.vnb3;
-    const int64_t ntile = (a.nkv + TILE - 1) / TILE;
+    const int64_t ngran = (a.nkv + GR - 1) / GR;
 
-    for (int64_t t = wave; t < ntile; t += 4) {
-        const int64_t kv    = t * TILE + lane;
+    for (int64_t gi = wave; gi < ngran; gi += 4) {
+        const int64_t kv    = gi * GR + r16;
         const bool    kv_ok = kv < a.nkv;
-        // mask values for this lane's kv row, one per distinct query row
         float mv[R];
         bool any_live = false;
 #pragma unroll
@@ -104,41 +108,46 @@ __global__ void __launch_bounds__(256) k_fattn_vec(fa_dev a) {
             mv[r] = m;
             any_live |= (m != -INFINITY);
         }
-        if (!__any(any_live)) continue;                               // whole tile masked for every query vector
+        if (!__any(any_live)) continue;                               // whole granule masked for every query vector
 
-        // ---- stage K tile: 16-B chunks, 4 rows per wave instruction
-        constexpr int CPR = D * 2 / 16;                               // chunks per row
-#pragma unroll 4
-        for (int c = lane; c < TILE * CPR; c += 64) {
-            const int row = c / CPR, col = c % CPR;
-            int64_t kr = t * TILE + row; kr = kr < a.nkv ? kr : a.nkv - 1;
-            *(u32x4 *) (tile + row * RS + col * 16) = *(const u32x4 *) (kbase + kr * a.knb1 + col * 16);
+        // ---- issue every load of the granule up front: a quarter K row per lane, then the 16 V rows (D/64 dims per lane)
+        const int64_t kvc = kv_ok ? kv : a.nkv - 1;
+        u32x4 kk[KCH];
+#pragma unroll
+        for (int c = 0; c < KCH; ++c) kk[c] = *(const u32x4 *) (kbase + kvc * a.knb1 + dq * (D / 2) + c * 16);
+        uint32_t vv[GR];
+#pragma unroll
+        for (int j = 0; j < GR; ++j) {
+            int64_t vr = gi * GR + j; vr = vr < a.nkv ? vr : a.nkv - 1;
+            if (DPL == 2) vv[j] = *(const uint32_t *) (vbase + vr * a.vnb1 + lane * 4);
+            else          vv[j] = *(const uint16_t *) (vbase + vr * a.vnb1 + lane * 2);
         }
-        // the same wave writes and then reads the tile: DS operations of one wave execute in issue order, so
-        // only the compiler has to be told not to move the reads above the writes
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+        // ---- scores
         float s[R];
 #pragma unroll
         for (int r = 0; r < R; ++r) s[r] = 0.0f;
-#pragma unroll 4
-        for (int c = 0; c < CPR; ++c) {
-            const u32x4 kk = *(const u32x4 *) (tile + lane * RS + c * 16);
+#pragma unroll
+        for (int c = 0; c < KCH; ++c) {
             float kf[8];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { kf[2 * e] = h2f((uint16_t) (kk[e] & 0xffff)); kf[2 * e + 1] = h2f((uint16_t) (kk[e] >> 16)); }
+            for (int e = 0; e < 4; ++e) { kf[2 * e] = h2f((uint16_t) (kk[c][e] & 0xffff)); kf[2 * e + 1] = h2f((uint16_t) (kk[c][e] >> 16)); }
 #pragma unroll
             for (int r = 0; r < R; ++r) {
-                const f32x4 q0 = *(const f32x4 *) (qf + r * D + c * 8);
-                const f32x4 q1 = *(const f32x4 *) (qf + r * D + c * 8 + 4);
+                const f32x4 q0 = *(const f32x4 *) (qf + r * D + dq * (D / 4) + c * 8);
+                const f32x4 q1 = *(const f32x4 *) (qf + r * D + dq * (D / 4) + c * 8 + 4);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { s[r] = fmaf(kf[e], q0[e], s[r]); s[r] = fmaf(kf[4 + e], q1[e], s[r]); }
             }
         }
-        // ---- scale, softcap, mask, online softmax (per query vector, across the 64 lanes of the tile)
+        // ---- fold the four dim-quarters, scale / softcap / mask, online softmax across the granule
         float ms[R];
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-            float v = s[r] * a.scale;
+            float t = s[r];
+            t += __shfl_xor(t, 1, 64);
+            t += __shfl_xor(t, 2, 64);
+            float v = t * a.scale;
             if (a.logit_softcap != 0.0f) v = a.logit_softcap * tanhf(v);
             v += mv[r];
             if (mv[r] == -INFINITY) v = -INFINITY;
@@ -147,44 +156,34 @@ __global__ void __launch_bounds__(256) k_fattn_vec(fa_dev a) {
             const float p    = (v == -INFINITY) ? 0.0f : expf(v - Mn);
             ms[r] = (M[r] == -INFINITY) ? 0.0f : expf(M[r] - Mn);
             if (Mn == -INFINITY) ms[r] = 1.0f;                         // nothing seen yet and nothing live: keep zeros
-            S[r] = S[r] * ms[r] + wave_sum(p);
+            S[r] = S[r] * ms[r] + wave_sum(dq == 0 ? p : 0.0f);
             M[r] = Mn;
-            pl[lane * R + r] = p;
+            if (dq == 0) pl[r16 * R + r] = p;
         }
-        // ---- stage V tile over the K tile and accumulate
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#pragma unroll 4
-        for (int c = lane; c < TILE * CPR; c += 64) {
-            const int row = c / CPR, col = c % CPR;
-            int64_t vr = t * TILE + row; vr = vr < a.nkv ? vr : a.nkv - 1;
-            *(u32x4 *) (tile + row * RS + col * 16) = *(const u32x4 *) (vbase + vr * a.vnb1 + col * 16);
-        }
+        // ---- P.V
 #pragma unroll
         for (int r = 0; r < R; ++r)
 #pragma unroll
             for (int e = 0; e < DPL; ++e) acc[r][e] *= ms[r];
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#pragma unroll 4
-        for (int j = 0; j < TILE; ++j) {
-            float vf[DPL];
-            if (DPL == 2) {
-                const uint32_t w = *(const uint32_t *) (tile + j * RS + lane * 4);
-                vf[0] = h2f((uint16_t) (w & 0xffff)); vf[1] = h2f((uint16_t) (w >> 16));
-            } else {
 #pragma unroll
-                for (int e = 0; e < DPL; ++e) vf[e] = h2f(*(const uint16_t *) (tile + j * RS + (lane * DPL + e) * 2));
-            }
+        for (int j = 0; j < GR; ++j) {
+            float vf[DPL];
+            if (DPL == 2) { vf[0] = h2f((uint16_t) (vv[j] & 0xffff)); vf[DPL - 1] = h2f((uint16_t) (vv[j] >> 16)); }
+            else          { vf[0] = h2f((uint16_t) vv[j]); }
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 const float p = pl[j * R + r];
+                // masked cells are SKIPPED by the reference (ops.cpp:8047-8050), never multiplied: an uninitialised cache cell
+                // holding inf/NaN must not leak in through 0 * x
 #pragma unroll
-                for (int e = 0; e < DPL; ++e) acc[r][e] = fmaf(p, vf[e], acc[r][e]);
+                for (int e = 0; e < DPL; ++e) acc[r][e] = p != 0.0f ? fmaf(p, vf[e], acc[r][e]) : acc[r][e];
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
 
-    // ---- merge the four waves' partial (M, S, acc) and write out
+    // ---- merge the four waves' partial (M, S, acc)
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         float * cw = comb + (wave * R + r) * (D + 2);
@@ -193,50 +192,85 @@ __global__ void __launch_bounds__(256) k_fattn_vec(fa_dev a) {
         if (lane == 0) { cw[D] = M[r]; cw[D + 1] = S[r]; }
     }
     __syncthreads();
-    // wave w finalises query vectors r = w, w+4, ...
+    float o[R][DPL];                                                   // finals of the query vectors this wave owns (r & 3 == wave)
 #pragma unroll
     for (int r = 0; r < R; ++r) {
+#pragma unroll
+        for (int e = 0; e < DPL; ++e) o[r][e] = 0.0f;
         if ((r & 3) != wave || !r_ok[r]) continue;
         float Mx = -INFINITY;
         for (int w = 0; w < 4; ++w) Mx = fmaxf(Mx, comb[(w * R + r) * (D + 2) + D]);
-        float St = 0.0f, o[DPL];
-#pragma unroll
-        for (int e = 0; e < DPL; ++e) o[e] = 0.0f;
+        float St = 0.0f;
         for (int w = 0; w < 4; ++w) {
             const float * cw = comb + (w * R + r) * (D + 2);
             const float Mw = cw[D];
             const float f  = (Mw == -INFINITY) ? 0.0f : expf(Mw - Mx);
             St += cw[D + 1] * f;
 #pragma unroll
-            for (int e = 0; e < DPL; ++e) o[e] += cw[lane * DPL + e] * f;
+            for (int e = 0; e < DPL; ++e) o[r][e] += cw[lane * DPL + e] * f;
         }
         if (a.sinks) {                                                // ops.cpp:8116-8130
             const float sk = a.sinks[r_h[r]];
             if (sk > Mx) { const float f = expf(Mx - sk); St = St * f + 1.0f;
 #pragma unroll
-                for (int e = 0; e < DPL; ++e) o[e] *= f; }
+                for (int e = 0; e < DPL; ++e) o[r][e] *= f; }
             else St += expf(sk - Mx);
         }
         const float inv = St == 0.0f ? 0.0f : 1.0f / St;
         float * out = (float *) (a.dst + r_h[r] * a.dnb1 + r_q[r] * a.dnb2 + is3 * a.dnb3);
 #pragma unroll
-        for (int e = 0; e < DPL; ++e) out[lane * DPL + e] = o[e] * inv;
+        for (int e = 0; e < DPL; ++e) { o[r][e] *= inv; out[lane * DPL + e] = o[r][e]; }
+    }
+
+    // ---- optional epilogue: Q8_K image of the output row (consumed by the following wo mat-vec)
+    if (a.img) {
+        __syncthreads();                                              // everyone is done reading the merge area
+        float * fin = comb;                                           // [R][D]
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+            if ((r & 3) == wave && r_ok[r])
+#pragma unroll
+                for (int e = 0; e < DPL; ++e) fin[r * D + lane * DPL + e] = o[r][e];
+        __syncthreads();
+        const int nblk = a.qpw * a.hpw * D / 256;                     // launcher guarantees hpw*D % 256 == 0 and full head groups
+        const int64_t Kimg = a.nh * D;
+        for (int bq = wave; bq < nblk; bq += 4) {
+            const int per_q = a.hpw * D / 256;
+            const int qq = bq / per_q, bb = bq % per_q;
+            const int64_t qrow = qb * a.qpw + qq;
+            if (qrow >= a.nq) continue;
+            const f32x4 v = *(const f32x4 *) (fin + (qq * a.hpw) * D + bb * 256 + 4 * lane);
+            char * im = a.img + (is3 * a.nq + qrow) * a.img_bytes;
+            const int64_t ib = ((ikv * a.gq + hc * a.hpw) * D) / 256 + bb;
+            q8k_block_from_regs(v, lane, (int8_t *) im + ib * 256, (int16_t *) (im + Kimg) + ib * 16, (float *) (im + Kimg + Kimg / 8) + ib);
+        }
     }
 }
 
 template <int D, int R>
-static size_t fa_lds_bytes() { return (size_t) R * D * 4 + 4 * (64 * (D * 2 + 16)) + 4 * 64 * R * 4 + 4 * R * (D + 2) * 4; }
+static size_t fa_lds_bytes() { return (size_t) R * D * 4 + 4 * 16 * R * 4 + 4 * R * (D + 2) * 4; }
 
 size_t fattn_scratch_bytes(const fattn_args &) { return 0; }
+
+// choose R (query vectors per workgroup): cover the GQA group first, then extra query rows
+static void fa_split(const fa_dev & a, int & R, int & hpw, int & qpw) {
+    if (a.gq >= 8) R = 8; else if (a.gq >= 4) R = (a.nq > 1 ? 8 : 4); else if (a.gq >= 2) R = (a.nq > 2 ? 8 : (a.nq > 1 ? 4 : 2)); else R = (a.nq >= 8 ? 8 : (a.nq >= 4 ? 4 : (a.nq >= 2 ? 2 : 1)));
+    hpw = a.gq < R ? a.gq : R;
+    qpw = R / hpw; if (qpw < 1) qpw = 1;
+}
+
+bool fattn_can_emit_image(const fattn_args & f) {
+    const int D = (int) f.q.ne[0];
+    if (D != 64 && D != 128) return false;
+    fa_dev a; a.nq = f.q.ne[1]; a.gq = (int) (f.q.ne[2] / f.k.ne[2]);
+    int R, hpw, qpw; fa_split(a, R, hpw, qpw);
+    return (hpw * D) % 256 == 0 && a.gq % hpw == 0 && (f.q.ne[2] * D) % 256 == 0;
+}
 
 template <int D>
 static void launch_fa(const fa_dev & a0, hipStream_t st) {
     fa_dev a = a0;
-    // choose R (query vectors per workgroup): cover the GQA group first, then extra query rows
-    int R;
-    if (a.gq >= 8) R = 8; else if (a.gq >= 4) R = (a.nq > 1 ? 8 : 4); else if (a.gq >= 2) R = (a.nq > 2 ? 8 : (a.nq > 1 ? 4 : 2)); else R = (a.nq >= 8 ? 8 : (a.nq >= 4 ? 4 : (a.nq >= 2 ? 2 : 1)));
-    a.hpw = a.gq < R ? a.gq : R;
-    a.qpw = R / a.hpw; if (a.qpw < 1) a.qpw = 1;
+    int R; fa_split(a, R, a.hpw, a.qpw);
     const int64_t ngrp_h = (a.gq + a.hpw - 1) / a.hpw;
     const int64_t nqb    = (a.nq + a.qpw - 1) / a.qpw;
     const int64_t nblk   = nqb * ngrp_h * a.nhkv * a.ns;
@@ -244,8 +278,8 @@ static void launch_fa(const fa_dev & a0, hipStream_t st) {
 #define FA_GO(RR)                                                                                                      \
     do {                                                                                                               \
         const size_t lds = fa_lds_bytes<D, RR>();                                                                      \
-        if (lds > 64 * 1024) HIP_CHECK(hipFuncSetAttribute((const void *) k_fattn_vec<D, RR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds)); \
-        k_fattn_vec<D, RR><<<grid, blk, lds, st>>>(a);                                                                 \
+        if (lds > 64 * 1024) HIP_CHECK(hipFuncSetAttribute((const void *) k_fattn_dec<D, RR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds)); \
+        k_fattn_dec<D, RR><<<grid, blk, lds, st>>>(a);                                                                 \
     } while (0)
     switch (R) { case 1: FA_GO(1); break; case 2: FA_GO(2); break; case 4: FA_GO(4); break; default: FA_GO(8); break; }
 #undef FA_GO
@@ -270,6 +304,7 @@ void flash_attn_ext_f16(const fattn_args & f, hipStream_t st) {
     a.m1 = powf(2.0f, -(a.max_bias / 2.0f) / a.n_head_log2);
     a.gq = (int) (a.nh / a.nhkv);
     a.hpw = a.qpw = 1;
+    a.img = (char *) f.img; a.img_bytes = f.img ? q8k_image_bytes(a.nh * f.q.ne[0]) : 0;
     switch ((int) f.q.ne[0]) {
         case 64:  launch_fa<64>(a, st); break;
         case 128: launch_fa<128>(a, st); break;

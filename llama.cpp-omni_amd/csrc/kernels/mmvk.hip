@@ -22,9 +22,21 @@
 // are zeroed) so each stage's loads stay in one clause.
 #include "../kernels.hpp"
 
+#ifndef MI_Q4K_NT
+#define MI_Q4K_NT 0        // measured: plain loads beat non-temporal (the 16-B header and the nibbles of a block share 128-B lines across two instructions)
+#endif
+#ifndef MI_Q6K_NT
+#define MI_Q6K_NT 0        // Q6_K pieces of one block are spread over 5 instructions: keep the lines in L1 between them
+#endif
+#ifndef MI_Q6K_X3
+#define MI_Q6K_X3 0        // 1: aligned 12-byte loads + v_alignbyte; 0: hardware-unaligned 8-byte loads
+#endif
+
 namespace mi {
 
 extern __shared__ __attribute__((aligned(16))) char mmv_lds[];
+
+template <typename T> static __device__ __forceinline__ T ld_w(const T * p, bool nt) { return nt ? __builtin_nontemporal_load(p) : *p; }
 
 static __device__ __forceinline__ void stage_act_k(const char * act, size_t act_cs, int ncols, size_t bytes) {
     const int n16 = (int) (bytes >> 4);
@@ -69,8 +81,8 @@ static __device__ __forceinline__ void q4k_body(const char * __restrict__ W0, co
             for (int r = 0; r < ROWS; ++r) {
                 int row = PAIR ? grp : grp * ROWS + r; row = row < nrows ? row : nrows - 1;
                 const char * bp = ((PAIR && r == 1) ? W1 : W0) + (size_t) row * w_rs + (size_t) ib * 144;
-                hdr[u][r] = ld_nt16(bp);
-                qs[u][r]  = ld_nt16(bp + 16 + lp * 16);
+                hdr[u][r] = ld_w((const u32x4 *) bp, MI_Q4K_NT);
+                qs[u][r]  = ld_w((const u32x4 *) (bp + 16 + lp * 16), MI_Q4K_NT);
             }
         }
     };
@@ -182,28 +194,38 @@ static __device__ __forceinline__ void q4k_body(const char * __restrict__ W0, co
 // 0- or 2-byte phase; the over-read stays inside the same 210-byte block ("Q6_K loads").
 // =================================================================================================
 static __device__ __forceinline__ u32x2 ld_piece8(const char * p) {
+#if MI_Q6K_X3
     const uintptr_t a = (uintptr_t) p;
     const unsigned  s = (unsigned) (a & 3);                              // 0 or 2
     const uint32_t * q = (const uint32_t *) (a - s);
     typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
-    const u32x3 v = __builtin_nontemporal_load((const u32x3 *) q);      // global_load_dwordx3, 4-byte aligned
+    const u32x3 v = ld_w((const u32x3 *) q, MI_Q6K_NT);                   // global_load_dwordx3, 4-byte aligned
     u32x2 r;
     r[0] = __builtin_amdgcn_alignbyte(v[1], v[0], s);
     r[1] = __builtin_amdgcn_alignbyte(v[2], v[1], s);
     return r;
+#else
+    typedef uint32_t __attribute__((aligned(2))) u32a2;                  // 2-byte aligned: the hardware handles the phase
+    u32x2 r; r[0] = ld_w((const u32a2 *) p, MI_Q6K_NT); r[1] = ld_w((const u32a2 *) (p + 4), MI_Q6K_NT);
+    return r;
+#endif
 }
 // same, but never touches a byte beyond p+8 (phase 0) / p+10 (phase 2): used for the scales piece, whose 12-byte
 // form would cross the end of the super-block (and, for the last block, of the tensor)
 static __device__ __forceinline__ u32x2 ld_piece8_tail(const char * p) {
+#if MI_Q6K_X3
     const uintptr_t a = (uintptr_t) p;
     const unsigned  s = (unsigned) (a & 3);
     const uint32_t * q = (const uint32_t *) (a - s);
-    const u32x2    v01 = __builtin_nontemporal_load((const u32x2 *) q);  // q is 4-byte aligned; 8-byte vector at 4-byte alignment
-    const uint32_t v2  = __builtin_nontemporal_load(q + (s ? 2 : 1));
+    const u32x2    v01 = ld_w((const u32x2 *) q, MI_Q6K_NT);
+    const uint32_t v2  = ld_w(q + (s ? 2 : 1), MI_Q6K_NT);
     u32x2 r;
     r[0] = __builtin_amdgcn_alignbyte(v01[1], v01[0], s);
     r[1] = __builtin_amdgcn_alignbyte(v2, v01[1], s);
     return r;
+#else
+    return ld_piece8(p);
+#endif
 }
 // bytes in [0,63] -> signed bytes (w - 32), SWAR without inter-byte borrow
 static __device__ __forceinline__ uint32_t sub32(uint32_t w) { return ((w | 0x80808080u) - 0x20202020u) ^ 0x80808080u; }
@@ -231,7 +253,7 @@ static __device__ __forceinline__ void q6k_body(const char * __restrict__ W0, co
                 qlb[u][r] = ld_piece8(bp + 64 * n + 32 + 8 * tp);
                 qh[u][r]  = ld_piece8(bp + 128 + 32 * n + 8 * tp);
                 sc8[u][r] = ld_piece8_tail(bp + 192 + 8 * n);              // scales[8n .. 8n+7]
-                dw[u][r]  = __builtin_nontemporal_load((const uint16_t *) (bp + 208));
+                dw[u][r]  = ld_w((const uint16_t *) (bp + 208), MI_Q6K_NT);
             }
         }
     };

@@ -8,54 +8,6 @@
 
 namespace mi {
 
-// ------------------------------------------------------------------------------------------------
-// One 256-element Q8_K block held by one wave (lane l owns elements 4l..4l+3), written into the image.
-//   reference: quantize_row_q8_K_ref, ggml-quants.c:2555-2592 (x86 `quantize_row_q8_K` forwards to it,
-//   ggml-cpu/arch/x86/quants.c:493-495):
-//     amax/max  : first element (lowest index) with the largest |x|   (strict '>' scan)
-//     iscale    = -127.f / max
-//     q[j]      = min(127, nearest_int(iscale * x[j]))   -- nearest_int == round-half-even (:444-449)
-//     bsums[g]  = sum of 16 consecutive q
-//     d         = 1 / iscale           (amax == 0 -> d = 0, q = 0)
-// ------------------------------------------------------------------------------------------------
-static __device__ __forceinline__ void q8k_block_from_regs(const f32x4 v, int lane, int8_t * qs, int16_t * bs, float * ds) {
-    // (|x|, index) arg-max with lowest-index tie-break == the reference's sequential strict-'>' scan
-    float amax = fabsf(v[0]); float mval = v[0]; int idx = 4 * lane;
-#pragma unroll
-    for (int i = 1; i < 4; ++i) {
-        const float a = fabsf(v[i]);
-        if (a > amax) { amax = a; mval = v[i]; idx = 4 * lane + i; }
-    }
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const float a2 = __shfl_xor(amax, o, 64);
-        const float m2 = __shfl_xor(mval, o, 64);
-        const int   i2 = __shfl_xor(idx, o, 64);
-        if (a2 > amax || (a2 == amax && i2 < idx)) { amax = a2; mval = m2; idx = i2; }
-    }
-    if (amax == 0.0f) {                  // all-zero block (also catches -0.0f)
-        *(uint32_t *) (qs + 4 * lane) = 0u;
-        if ((lane & 3) == 0) bs[lane >> 2] = 0;
-        if (lane == 0) *ds = 0.0f;
-        return;
-    }
-    const float iscale = -127.0f / mval;
-    int q[4]; int s = 0;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const float p = iscale * v[i];               // one rounding, like the C source (no FMA with the magic add)
-        int r = (int) __builtin_rintf(p);            // round-half-even == nearest_int()
-        r = r > 127 ? 127 : r;
-        q[i] = r; s += r;
-    }
-    *(uint32_t *) (qs + 4 * lane) = (uint32_t) (q[0] & 0xff) | ((uint32_t) (q[1] & 0xff) << 8) |
-                                    ((uint32_t) (q[2] & 0xff) << 16) | ((uint32_t) (q[3] & 0xff) << 24);
-    s += __shfl_xor(s, 1, 64);
-    s += __shfl_xor(s, 2, 64);
-    if ((lane & 3) == 0) bs[lane >> 2] = (int16_t) s;
-    if (lane == 0) *ds = 1.0f / iscale;
-}
-
 // Q8_K image: one wave per 256-element block
 __global__ void __launch_bounds__(256) k_quantize_q8k(const char * __restrict__ x, size_t xs, char * __restrict__ img,
                                                      int64_t K, int64_t nrows, size_t img_bytes) {
@@ -81,33 +33,55 @@ void quantize_q8k_image(const float * x, size_t xs, void * img, int64_t K, int64
 //   y = (x * (1/sqrtf(mean(x^2)+eps))) * w      (ops.cpp:3517-3566 then the graph's MUL node; sum of squares in double)
 //   img = Q8_K(y)                                (what the following MUL_MATs would compute from y)
 // ------------------------------------------------------------------------------------------------
+// The row and the weight vector are fetched ONCE, up front, into registers (wave w owns blocks w, w+nw, ...; lane l the
+// elements 4l..4l+3 of each): one memory round trip, then arithmetic only.  MAXB blocks per wave bound the row length.
+template <int MAXB>
 __global__ void __launch_bounds__(512) k_rms_norm_mul_quant(const char * __restrict__ x, size_t xs, const float * __restrict__ w, char * __restrict__ y, size_t ys,
-                                                           char * __restrict__ img, int64_t n, float eps, size_t img_bytes) {
+                                                           char * __restrict__ img, int n, float eps, size_t img_bytes) {
     __shared__ double red[16];
     const int64_t row = blockIdx.x;
     const float * xr = (const float *) (x + row * xs);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6, nb = n >> 8;
+    f32x4 xv[MAXB], wv[MAXB];
+#pragma unroll
+    for (int b = 0; b < MAXB; ++b) {
+        const int ib = wave + b * nw;
+        if (ib < nb) { xv[b] = *(const f32x4 *) (xr + ib * 256 + 4 * lane); wv[b] = *(const f32x4 *) (w + ib * 256 + 4 * lane); }
+        else { xv[b] = f32x4{0, 0, 0, 0}; wv[b] = f32x4{0, 0, 0, 0}; }
+    }
     double s = 0.0;
-    for (int64_t i = threadIdx.x; i < n; i += blockDim.x) { const float v = xr[i]; s += (double) (v * v); }
+#pragma unroll
+    for (int b = 0; b < MAXB; ++b)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) s += (double) (xv[b][i] * xv[b][i]);
     s = block_sum<double>(s, red);
     const float mean  = (float) (s / (double) n);
     const float scale = 1.0f / sqrtf(mean + eps);
     char * im = img + row * img_bytes;
-    for (int64_t ib = wave; ib < n / 256; ib += nw) {
-        const f32x4 xv = *(const f32x4 *) (xr + ib * 256 + 4 * lane);
-        const f32x4 wv = *(const f32x4 *) (w + ib * 256 + 4 * lane);
+#pragma unroll
+    for (int b = 0; b < MAXB; ++b) {
+        const int ib = wave + b * nw;
+        if (ib >= nb) break;
         f32x4 v;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) v[i] = (xv[i] * scale) * wv[i];
+        for (int i = 0; i < 4; ++i) v[i] = (xv[b][i] * scale) * wv[b][i];
         if (y) *(f32x4 *) ((float *) (y + row * ys) + ib * 256 + 4 * lane) = v;
         q8k_block_from_regs(v, lane, (int8_t *) im + ib * 256, (int16_t *) (im + n) + ib * 16, (float *) (im + n + n / 8) + ib);
     }
 }
 
+bool rms_norm_mul_quant_ok(int64_t n) { return n % 256 == 0 && n / 256 <= 8 * 8; }
+
 void rms_norm_mul_quant(const float * x, size_t xs, const float * w, float * y, size_t ys, void * img, int64_t n, int64_t nrows, float eps, hipStream_t st) {
     if (n == 0 || nrows == 0) return;
-    const int bs = n >= 2048 ? 512 : 256;
-    k_rms_norm_mul_quant<<<dim3((unsigned) nrows), dim3(bs), 0, st>>>((const char *) x, xs, w, (char *) y, ys, (char *) img, n, eps, q8k_image_bytes(n));
+    const int nb = (int) (n / 256);
+    const int bs = nb >= 8 ? 512 : (nb >= 4 ? 256 : (nb >= 2 ? 128 : 64));
+    const int per = (nb + bs / 64 - 1) / (bs / 64);
+    const size_t ib = q8k_image_bytes(n);
+    if (per <= 1)      k_rms_norm_mul_quant<1><<<dim3((unsigned) nrows), dim3(bs), 0, st>>>((const char *) x, xs, w, (char *) y, ys, (char *) img, (int) n, eps, ib);
+    else if (per <= 2) k_rms_norm_mul_quant<2><<<dim3((unsigned) nrows), dim3(bs), 0, st>>>((const char *) x, xs, w, (char *) y, ys, (char *) img, (int) n, eps, ib);
+    else if (per <= 4) k_rms_norm_mul_quant<4><<<dim3((unsigned) nrows), dim3(bs), 0, st>>>((const char *) x, xs, w, (char *) y, ys, (char *) img, (int) n, eps, ib);
+    else               k_rms_norm_mul_quant<8><<<dim3((unsigned) nrows), dim3(bs), 0, st>>>((const char *) x, xs, w, (char *) y, ys, (char *) img, (int) n, eps, ib);
 }
 
 // ------------------------------------------------------------------------------------------------

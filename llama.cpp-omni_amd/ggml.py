@@ -150,6 +150,8 @@ class reg_t(C.Structure):
 
 # ------------------------------------------------------------------------------------------------ library
 def lib_path():
+    if os.environ.get("MI355X_LIB"):                  # tuning builds (csrc/Makefile VARIANT=...)
+        return os.environ["MI355X_LIB"]
     return os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libggml-mi355x.so")
 
 
@@ -580,7 +582,39 @@ class Context:
         return self
 
     def graph(self, nodes=None):
+        if nodes is None and getattr(self, "roots", None):
+            return self.graph_expand(self.roots)
         return Graph(list(self.nodes if nodes is None else nodes))
+
+    def graph_expand(self, roots):
+        """Node order of ggml_build_forward_expand() called on `roots` in turn (reference ggml.c ggml_visit_parents: depth-first
+        over src[0..], a node is appended after its sources, visited once) -- the order libllama's graphs reach the backend in."""
+        seen, order = set(), []
+        by_addr = {C.addressof(T.t): T for T in self.tensors}
+
+        def visit(T):
+            key = C.addressof(T.t)
+            if key in seen:
+                return
+            seen.add(key)
+            for i in range(10):
+                p = T.t.src[i]
+                if p:
+                    S = by_addr.get(C.addressof(p.contents))
+                    if S is not None:
+                        visit(S)
+            if T.t.op != OP.NONE:
+                order.append(T)
+
+        import sys
+        lim = sys.getrecursionlimit()
+        sys.setrecursionlimit(max(lim, 20000))
+        try:
+            for r in roots:
+                visit(r)
+        finally:
+            sys.setrecursionlimit(lim)
+        return Graph(order)
 
     def free(self):
         if self.buffer:

@@ -165,6 +165,7 @@ class Model:
         c, be = self.cfg, self.be
         E, H, HK, D = c["n_embd"], c["n_head"], c["n_head_kv"], c["head_dim"]
         g = Context(be)
+        roots = []                                                   # ggml_build_forward_expand() call order of build_attn / llm_build_qwen3
         I = dict(
             inp_embd=g.new_tensor(GGML_TYPE_F32, E, n_tokens), inp_pos=g.new_tensor(GGML_TYPE_I32, n_tokens),
             kq_mask=g.new_tensor(GGML_TYPE_F16 if self.fa else GGML_TYPE_F32, n_kv, (n_tokens + 63) // 64 * 64),
@@ -193,8 +194,9 @@ class Model:
             K = g.rope_ext(K, I["inp_pos"], None, **rope)
             # store into the cache (llama_kv_cache::cpy_k / cpy_v, FA layout)
             kc, vc = self._w(g, L["k_cache"]), self._w(g, L["v_cache"])
-            g.set_rows(kc, g.view_2d(K, HK * D, n_tokens, K.nb[2], 0), I["k_idxs"])
-            g.set_rows(vc, g.view_2d(V, HK * D, n_tokens, V.nb[2], 0), I["v_idxs"])
+            roots += [Q, K, V]
+            roots.append(g.set_rows(kc, g.view_2d(K, HK * D, n_tokens, K.nb[2], 0), I["k_idxs"]))
+            roots.append(g.set_rows(vc, g.view_2d(V, HK * D, n_tokens, V.nb[2], 0), I["v_idxs"]))
             # attention over the first n_kv cells (get_k / get_v views, build_attn_mha)
             k = g.view_4d(kc, D, HK, n_kv, 1, D * f16, HK * D * f16, HK * D * f16 * self.n_ctx, 0)
             v = g.view_4d(vc, D, HK, n_kv, 1, D * f16, HK * D * f16, HK * D * f16 * self.n_ctx, 0)
@@ -223,6 +225,8 @@ class Model:
             inpL = g.add(cur, ffn_inp)
         cur = g.mul(g.rms_norm(inpL, c["rms_eps"]), self._w(g, self.output_norm))
         logits = g.mul_mat(self._w(g, self.output), cur)
+        roots.append(logits)
+        g.roots = roots
         g.alloc()
         return g, I, logits
 

@@ -54,8 +54,10 @@ def test_graph_node_sequence_matches_llm_build_qwen3(pkg, ref_be):
     cfg = qwen3.TINY
     mdl = qwen3.Model(ref_be, cfg, qwen3.q4_k_m_types(cfg), n_ctx=256)
     g, I, logits = mdl.build(1, 256)
-    ops = [n.t.op for n in g.nodes if n.t.op not in (OP.VIEW, OP.RESHAPE, OP.PERMUTE, OP.TRANSPOSE, OP.NONE)]
-    layer = [OP.RMS_NORM, OP.MUL, OP.MUL_MAT, OP.MUL_MAT, OP.MUL_MAT, OP.RMS_NORM, OP.MUL, OP.ROPE, OP.RMS_NORM, OP.MUL, OP.ROPE,
+    # node order = ggml_build_forward_expand() on q_cur, k_cur, v_cur, cpy_k, cpy_v (build_attn, llama-graph.cpp:1559-1575), then the result:
+    # each chain is visited depth-first, so wk's MUL_MAT comes after the whole q chain
+    ops = [n.t.op for n in g.graph().nodes if n.t.op not in (OP.VIEW, OP.RESHAPE, OP.PERMUTE, OP.TRANSPOSE, OP.NONE)]
+    layer = [OP.RMS_NORM, OP.MUL, OP.MUL_MAT, OP.RMS_NORM, OP.MUL, OP.ROPE, OP.MUL_MAT, OP.RMS_NORM, OP.MUL, OP.ROPE, OP.MUL_MAT,
              OP.SET_ROWS, OP.SET_ROWS, OP.FLASH_ATTN_EXT, OP.MUL_MAT, OP.ADD, OP.RMS_NORM, OP.MUL, OP.MUL_MAT, OP.MUL_MAT, OP.GLU, OP.MUL_MAT, OP.ADD]
     assert ops == layer * cfg["n_layer"] + [OP.RMS_NORM, OP.MUL, OP.MUL_MAT]
     assert len(layer) == 23
