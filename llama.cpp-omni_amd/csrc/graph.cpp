@@ -662,6 +662,10 @@ static void run_nodes(exec_state & s, ggml_cgraph * g) {
             }
         }
     }
+    if (s.c->opt_profile && !s.capturing) {
+        // calibration sample: an event pair with nothing in between measures the bracket's own cost, which consumers subtract
+        for (int k = 0; k < 4; ++k) { prof_scope ps(s, "empty", 0); }
+    }
     for (int i = 0; i < g->n_nodes; ++i) if (!s.done[i]) compute_node(s, i);
 }
 

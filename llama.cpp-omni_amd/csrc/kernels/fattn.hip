@@ -23,7 +23,7 @@ namespace mi {
 
 struct fa_dev {
     const char * q; const char * k; const char * v; const char * mask; const float * sinks; char * dst;
-    int64_t nq, nh, nhkv, nkv, ns;                      // query rows, heads, kv heads, kv length, sequences
+    int     nq, nh, nhkv, nkv, ns;                      // query rows, heads, kv heads, kv length, sequences
     int64_t qnb1, qnb2, qnb3, knb1, knb2, knb3, vnb1, vnb2, vnb3;
     int64_t mnb1, mnb2, mnb3, mne2, mne3;
     int64_t dnb1, dnb2, dnb3;
@@ -36,8 +36,8 @@ struct fa_dev {
 
 extern __shared__ __attribute__((aligned(16))) char fa_lds[];
 
-template <int D, int R>
-__global__ void __launch_bounds__(256) k_fattn_dec(const fa_dev a) {
+template <int D, int R, int NW>
+__global__ void __launch_bounds__(64 * NW) k_fattn_dec(const fa_dev a) {
     constexpr int DPL = D / 64;               // output dims per lane
     constexpr int GR  = 16;                   // KV rows per granule
     constexpr int KCH = D / 32;               // 16-B K chunks per lane (a quarter row)
@@ -45,29 +45,30 @@ __global__ void __launch_bounds__(256) k_fattn_dec(const fa_dev a) {
     const int r16 = lane >> 2, dq = lane & 3;
 
     // ---- which query vectors does this workgroup own
-    const int64_t ngrp_h = (a.gq + a.hpw - 1) / a.hpw;
-    const int64_t nqb    = (a.nq + a.qpw - 1) / a.qpw;
-    int64_t b = blockIdx.x;
-    const int64_t qb  = b % nqb;    b /= nqb;
-    const int64_t hc  = b % ngrp_h; b /= ngrp_h;
-    const int64_t ikv = b % a.nhkv; const int64_t is3 = b / a.nhkv;
-    int64_t r_q[R], r_h[R]; bool r_ok[R];
+    const int ngrp_h = (a.gq + a.hpw - 1) / a.hpw;
+    const int nqb    = (a.nq + a.qpw - 1) / a.qpw;
+    int b = (int) blockIdx.x;                                              // 32-bit index math: 64-bit div/mod are ~100-instruction sequences
+    const int qb  = b % nqb;    b /= nqb;
+    const int hc  = b % ngrp_h; b /= ngrp_h;
+    const int ikv = b % a.nhkv; const int is3 = b / a.nhkv;
+    int r_q[R], r_h[R]; bool r_ok[R]; const uint16_t * mrow[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         const int hq = r % a.hpw, qq = r / a.hpw;
         r_q[r] = qb * a.qpw + qq;
         r_h[r] = ikv * a.gq + hc * a.hpw + hq;
         r_ok[r] = qq < a.qpw && r_q[r] < a.nq && (hc * a.hpw + hq) < a.gq;
+        mrow[r] = (a.mask && r_ok[r]) ? (const uint16_t *) (a.mask + r_q[r] * a.mnb1 + (r_h[r] % (int) a.mne2) * a.mnb2 + (is3 % (int) a.mne3) * a.mnb3) : nullptr;
     }
 
     // ---- LDS carve-up
     float * qf   = (float *) fa_lds;                                                 // [R][D] queries (rounded through f16)
     float * pl   = (float *) (fa_lds + R * D * 4) + wave * (GR * R);                 // per-wave P[16][R]
-    float * comb = (float *) (fa_lds + R * D * 4 + 4 * GR * R * 4);                  // [4][R][D+2] merge area, later [R][D] finals
+    float * comb = (float *) (fa_lds + R * D * 4 + NW * GR * R * 4);                 // [NW][R][D+2] merge area, later [R][D] finals
 
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-        for (int d = threadIdx.x; d < D; d += 256) {
+        for (int d = threadIdx.x; d < D; d += 64 * NW) {
             float v = 0.0f;
             if (r_ok[r]) v = *(const float *) (a.q + d * 4 + r_q[r] * a.qnb1 + r_h[r] * a.qnb2 + is3 * a.qnb3);
             qf[r * D + d] = h2f(f2h(v));                                              // q_to_vec_dot: f32 -> f16 (ops.cpp:8040)
@@ -90,20 +91,17 @@ __global__ void __launch_bounds__(256) k_fattn_dec(const fa_dev a) {
 
     const char * kbase = a.k + ikv * a.knb2 + is3 * a.knb3;
     const char * vbase = a.v + ikv * a.vnb2 + is3 * a.vnb3;
-    const int64_t ngran = (a.nkv + GR - 1) / GR;
+    const int ngran = (a.nkv + GR - 1) / GR;
 
-    for (int64_t gi = wave; gi < ngran; gi += 4) {
-        const int64_t kv    = gi * GR + r16;
-        const bool    kv_ok = kv < a.nkv;
+    for (int gi = wave; gi < ngran; gi += NW) {
+        const int  kv    = gi * GR + r16;
+        const bool kv_ok = kv < a.nkv;
         float mv[R];
         bool any_live = false;
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             float m = 0.0f;
-            if (a.mask && r_ok[r] && kv_ok) {
-                const char * mp = a.mask + r_q[r] * a.mnb1 + (r_h[r] % a.mne2) * a.mnb2 + (is3 % a.mne3) * a.mnb3;
-                m = slope[r] * h2f(((const uint16_t *) mp)[kv]);
-            }
+            if (mrow[r] && kv_ok) m = slope[r] * h2f(mrow[r][kv]);
             if (!kv_ok || !r_ok[r]) m = -INFINITY;
             mv[r] = m;
             any_live |= (m != -INFINITY);
@@ -112,13 +110,14 @@ __global__ void __launch_bounds__(256) k_fattn_dec(const fa_dev a) {
 
         // ---- issue every load of the granule up front: a quarter K row per lane, then the 16 V rows (D/64 dims per lane)
         const int64_t kvc = kv_ok ? kv : a.nkv - 1;
+        (void) dq;
         u32x4 kk[KCH];
 #pragma unroll
         for (int c = 0; c < KCH; ++c) kk[c] = *(const u32x4 *) (kbase + kvc * a.knb1 + dq * (D / 2) + c * 16);
         uint32_t vv[GR];
 #pragma unroll
         for (int j = 0; j < GR; ++j) {
-            int64_t vr = gi * GR + j; vr = vr < a.nkv ? vr : a.nkv - 1;
+            int vr = gi * GR + j; vr = vr < a.nkv ? vr : a.nkv - 1;
             if (DPL == 2) vv[j] = *(const uint32_t *) (vbase + vr * a.vnb1 + lane * 4);
             else          vv[j] = *(const uint16_t *) (vbase + vr * a.vnb1 + lane * 2);
         }
@@ -151,12 +150,17 @@ __global__ void __launch_bounds__(256) k_fattn_dec(const fa_dev a) {
             if (a.logit_softcap != 0.0f) v = a.logit_softcap * tanhf(v);
             v += mv[r];
             if (mv[r] == -INFINITY) v = -INFINITY;
-            const float tmax = wave_max(v);
+            float tmax = v;                                             // max over the 16 rows (every row is replicated in its 4 dq lanes)
+#pragma unroll
+            for (int o = 4; o < 64; o <<= 1) tmax = fmaxf(tmax, __shfl_xor(tmax, o, 64));
             const float Mn   = fmaxf(M[r], tmax);
             const float p    = (v == -INFINITY) ? 0.0f : expf(v - Mn);
             ms[r] = (M[r] == -INFINITY) ? 0.0f : expf(M[r] - Mn);
             if (Mn == -INFINITY) ms[r] = 1.0f;                         // nothing seen yet and nothing live: keep zeros
-            S[r] = S[r] * ms[r] + wave_sum(dq == 0 ? p : 0.0f);
+            float psum = p;
+#pragma unroll
+            for (int o = 4; o < 64; o <<= 1) psum += __shfl_xor(psum, o, 64);
+            S[r] = S[r] * ms[r] + psum;
             M[r] = Mn;
             if (dq == 0) pl[r16 * R + r] = p;
         }
@@ -192,16 +196,16 @@ __global__ void __launch_bounds__(256) k_fattn_dec(const fa_dev a) {
         if (lane == 0) { cw[D] = M[r]; cw[D + 1] = S[r]; }
     }
     __syncthreads();
-    float o[R][DPL];                                                   // finals of the query vectors this wave owns (r & 3 == wave)
+    float o[R][DPL];                                                   // finals of the query vectors this wave owns (r % NW == wave)
 #pragma unroll
     for (int r = 0; r < R; ++r) {
 #pragma unroll
         for (int e = 0; e < DPL; ++e) o[r][e] = 0.0f;
-        if ((r & 3) != wave || !r_ok[r]) continue;
+        if ((r % NW) != wave || !r_ok[r]) continue;
         float Mx = -INFINITY;
-        for (int w = 0; w < 4; ++w) Mx = fmaxf(Mx, comb[(w * R + r) * (D + 2) + D]);
+        for (int w = 0; w < NW; ++w) Mx = fmaxf(Mx, comb[(w * R + r) * (D + 2) + D]);
         float St = 0.0f;
-        for (int w = 0; w < 4; ++w) {
+        for (int w = 0; w < NW; ++w) {
             const float * cw = comb + (w * R + r) * (D + 2);
             const float Mw = cw[D];
             const float f  = (Mw == -INFINITY) ? 0.0f : expf(Mw - Mx);
@@ -228,13 +232,13 @@ __global__ void __launch_bounds__(256) k_fattn_dec(const fa_dev a) {
         float * fin = comb;                                           // [R][D]
 #pragma unroll
         for (int r = 0; r < R; ++r)
-            if ((r & 3) == wave && r_ok[r])
+            if ((r % NW) == wave && r_ok[r])
 #pragma unroll
                 for (int e = 0; e < DPL; ++e) fin[r * D + lane * DPL + e] = o[r][e];
         __syncthreads();
         const int nblk = a.qpw * a.hpw * D / 256;                     // launcher guarantees hpw*D % 256 == 0 and full head groups
         const int64_t Kimg = a.nh * D;
-        for (int bq = wave; bq < nblk; bq += 4) {
+        for (int bq = wave; bq < nblk; bq += NW) {
             const int per_q = a.hpw * D / 256;
             const int qq = bq / per_q, bb = bq % per_q;
             const int64_t qrow = qb * a.qpw + qq;
@@ -247,8 +251,8 @@ __global__ void __launch_bounds__(256) k_fattn_dec(const fa_dev a) {
     }
 }
 
-template <int D, int R>
-static size_t fa_lds_bytes() { return (size_t) R * D * 4 + 4 * 16 * R * 4 + 4 * R * (D + 2) * 4; }
+template <int D, int R, int NW>
+static size_t fa_lds_bytes() { return (size_t) R * D * 4 + NW * 16 * R * 4 + NW * R * (D + 2) * 4; }
 
 size_t fattn_scratch_bytes(const fattn_args &) { return 0; }
 
@@ -274,15 +278,19 @@ static void launch_fa(const fa_dev & a0, hipStream_t st) {
     const int64_t ngrp_h = (a.gq + a.hpw - 1) / a.hpw;
     const int64_t nqb    = (a.nq + a.qpw - 1) / a.qpw;
     const int64_t nblk   = nqb * ngrp_h * a.nhkv * a.ns;
-    dim3 grid((unsigned) nblk), blk(256);
-#define FA_GO(RR)                                                                                                      \
+    dim3 grid((unsigned) nblk);
+    // waves per workgroup: one 16-row granule per wave for short contexts (pure latency), 4 waves when there are many workgroups anyway
+    const bool wide = a.nkv > 64 && nblk <= 1024;
+#define FA_GO2(RR, NWW)                                                                                                \
     do {                                                                                                               \
-        const size_t lds = fa_lds_bytes<D, RR>();                                                                      \
-        if (lds > 64 * 1024) HIP_CHECK(hipFuncSetAttribute((const void *) k_fattn_dec<D, RR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds)); \
-        k_fattn_dec<D, RR><<<grid, blk, lds, st>>>(a);                                                                 \
+        const size_t lds = fa_lds_bytes<D, RR, NWW>();                                                                 \
+        if (lds > 64 * 1024) HIP_CHECK(hipFuncSetAttribute((const void *) k_fattn_dec<D, RR, NWW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds)); \
+        k_fattn_dec<D, RR, NWW><<<grid, dim3(64 * NWW), lds, st>>>(a);                                                 \
     } while (0)
+#define FA_GO(RR) do { if (wide) FA_GO2(RR, 8); else FA_GO2(RR, 4); } while (0)     // (16 waves would cap VGPRs at 128 and spill)
     switch (R) { case 1: FA_GO(1); break; case 2: FA_GO(2); break; case 4: FA_GO(4); break; default: FA_GO(8); break; }
 #undef FA_GO
+#undef FA_GO2
 }
 
 void flash_attn_ext_f16(const fattn_args & f, hipStream_t st) {

@@ -29,6 +29,12 @@ def main():
                     be.tensor_set(t, np.zeros(t.nelements(), np.int32 if t.type == GGML_TYPE_I32 else np.int64))
                 elif t.type == GGML_TYPE_F32:
                     be.tensor_set(t, np.ones(t.nelements(), np.float32))
+                elif t.type == GGML_TYPE_F16 and t.ne[1] == 64:          # KQ mask: 72 live cells (tg128 mid-run depth), rest -inf
+                    m = np.full((64, t.ne[0]), -np.inf, np.float16)
+                    m[:, :72] = 0
+                    be.tensor_set(t, m)
+                elif t.type == GGML_TYPE_F16:
+                    be.tensor_set(t, (np.random.default_rng(0).standard_normal(t.nelements()) * 0.5).astype(np.float16))
             g = c.graph()
             for _ in range(3):
                 be.graph_compute(g)
