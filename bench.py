@@ -116,65 +116,46 @@ def cpu_baseline(pkg, cfg, types, n_kv, seconds_budget=20.0):
 
 
 def kernel_roofline(pkg, be, model, reps=5):
-    """Live roofline of the dominant kernel class: one cgraph holding exactly the Q4_K mat-vec launches of one decode step
-    (wq/wk/wv batched, wo, ffn_gate+ffn_up+SWIGLU pair, ffn_down -- the launch shapes the real step uses, on the real layer
-    weights, 3.35 GB > 13x the Infinity Cache) is replayed as a hipGraph and bracketed by two HIP events on the backend's
-    stream.  achieved = algorithmic weight bytes / time.  Launches that involve Q6_K weights are timed the same way and
-    reported next to it."""
+    """Live roofline of the dominant kernel, mi::k_mmv_pair<1,2,Q4_K> (ffn_gate + ffn_up + SWIGLU: 2 x 12288 x 4096 Q4_K rows =
+    56.6 MB per launch, 36 launches and 2.04 of the 4.67 GB of every decoded token).  One cgraph holding the 36 launches of one
+    decode step -- the real layers' weights, 2 GB, 8x the Infinity Cache -- is replayed as a hipGraph and bracketed by two HIP
+    events on the backend's stream; avg launch = elapsed / 36 (so it includes the launch-to-launch boundary, like the
+    per-dispatch duration rocprofv3 --kernel-trace reports; profiles/).  achieved = algorithmic weight bytes / time."""
     from llama_cpp_omni_amd.ggml import GGML_TYPE_F32, GGML_TYPE_Q4_K, Context
     cfg = model.cfg
-    E, F = cfg["n_embd"], cfg["n_ff"]
-
-    def build(pure_q4k):
-        c = Context(be)
-        x = c.new_tensor(GGML_TYPE_F32, E, 1)
-        xf = c.new_tensor(GGML_TYPE_F32, F, 1)
-        nodes_e, nodes_f, nbytes, launches = [], [], 0, 0
-        for L in model.layers:
-            qkv_pure = all(L[k].type == GGML_TYPE_Q4_K for k in ("attn_q", "attn_k", "attn_v"))
-            if qkv_pure == pure_q4k:
-                for k in ("attn_q", "attn_k", "attn_v"):
-                    nodes_e.append(c.mul_mat(model._w(c, L[k]), x)); nbytes += L[k].nbytes()
-                launches += 1
-            if pure_q4k:
-                nodes_e.append(c.mul_mat(model._w(c, L["attn_output"]), x)); nbytes += L["attn_output"].nbytes(); launches += 1
-                up = c.mul_mat(model._w(c, L["ffn_up"]), x)
-                gate = c.mul_mat(model._w(c, L["ffn_gate"]), x)
-                nodes_e += [up, gate, c.swiglu_split(gate, up)]; nbytes += L["ffn_up"].nbytes() + L["ffn_gate"].nbytes(); launches += 1
-            if (L["ffn_down"].type == GGML_TYPE_Q4_K) == pure_q4k:
-                nodes_f.append(c.mul_mat(model._w(c, L["ffn_down"]), xf)); nbytes += L["ffn_down"].nbytes(); launches += 1
-        if not pure_q4k:
-            nodes_e.append(c.mul_mat(model._w(c, model.output), x)); nbytes += model.output.nbytes(); launches += 1
-        c.alloc()
-        rng = np.random.default_rng(0)
-        be.tensor_set(x, rng.standard_normal(E).astype(np.float32))
-        be.tensor_set(xf, rng.standard_normal(F).astype(np.float32))
-        return c, c.graph(nodes_e + nodes_f), nbytes, launches
-
-    out = {}
-    for name, pure in (("q4k", True), ("q6k_mixed", False)):
-        c, g, nbytes, launches = build(pure)
-        for _ in range(3):
-            be.graph_compute(g)                      # eager, capture, first replay
-        be.synchronize()
-        best = 1e30
-        for _ in range(reps):
-            a, b = be.timed_event(), be.timed_event()
-            be.record(a); be.graph_compute(g); be.record(b)
-            best = min(best, be.elapsed_ms(a, b))
-        kern = be.get_stat("kernels_last_graph")
-        out[name] = dict(us=best * 1e3, bytes=nbytes, launches=launches, kernels=int(kern))
-        c.free()
-    q = out["q4k"]
-    n_l = q["kernels"] - 2                             # the graph also holds the two activation quantisers (one per input vector)
-    ach = q["bytes"] / q["us"] / 1e3
-    m = out["q6k_mixed"]
-    return {"bound": "hbm", "kernel": "Q4_K x Q8_K mat-vec launches of one decode step (mi::k_mmv_multi<1,2,2,1>: wq/wk/wv and wo and ffn_down; mi::k_mmv_pair: ffn_gate+ffn_up+SWIGLU)",
+    c = Context(be)
+    x = c.new_tensor(GGML_TYPE_F32, cfg["n_embd"], 1)
+    nbytes, launches = 0, 0
+    for L in model.layers:
+        if L["ffn_up"].type != GGML_TYPE_Q4_K or L["ffn_gate"].type != GGML_TYPE_Q4_K:
+            continue
+        up = c.mul_mat(model._w(c, L["ffn_up"]), x)
+        gate = c.mul_mat(model._w(c, L["ffn_gate"]), x)
+        c.swiglu_split(gate, up)
+        nbytes += L["ffn_up"].nbytes() + L["ffn_gate"].nbytes()
+        launches += 1
+    if launches == 0:
+        return None
+    c.alloc()
+    be.tensor_set(x, np.random.default_rng(0).standard_normal(cfg["n_embd"]).astype(np.float32))
+    g = c.graph()
+    for _ in range(3):
+        be.graph_compute(g)                      # eager, capture, first replay
+    be.synchronize()
+    kern = int(be.get_stat("kernels_last_graph"))
+    assert kern == launches + 1, (kern, launches)   # the pair launches + one activation quantiser
+    best = 1e30
+    for _ in range(reps):
+        a, b = be.timed_event(), be.timed_event()
+        be.record(a); be.graph_compute(g); be.record(b)
+        best = min(best, be.elapsed_ms(a, b))
+    c.free()
+    us = best * 1e3
+    ach = nbytes / us / 1e3
+    return {"bound": "hbm", "kernel": "mi::k_mmv_pair<1,2,12> (Q4_K ffn_gate+ffn_up mat-vec + SWIGLU epilogue)",
             "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
-            "bytes_per_launch": round(q["bytes"] / n_l), "avg_launch_us": round(q["us"] / n_l, 3), "launches": n_l, "bytes_total": q["bytes"],
-            "method": "hipGraph replay of exactly these launches, two HIP events on the backend stream, best of 5",
-            "q6k_mixed": {"achieved": round(m["bytes"] / m["us"] / 1e3, 1), "avg_launch_us": round(m["us"] / max(1, m["kernels"] - 2), 3),
-                          "launches": m["kernels"] - 2, "bytes_total": m["bytes"]}}
+            "bytes_per_launch": nbytes // launches, "avg_launch_us": round(us / launches, 3), "launches": launches,
+            "method": "hipGraph replay of the step's 36 launches of this kernel, two HIP events on the backend stream, best of 5"}
 
 
 def main():
