@@ -59,6 +59,22 @@ static __device__ __forceinline__ T wave_sum(T v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
 }
+// f32 wave64 sum on the DPP network (no LDS round trips): quad butterflies, row mirrors, then the two row broadcasts;
+// the total lands in lane 63 and is returned wave-uniform through v_readlane.  ~8 VALU instructions instead of six
+// dependent ds_bpermute (each ~100+ cycles), which matters at the end of every mat-vec row group.
+template <int CTRL, int ROW_MASK>
+static __device__ __forceinline__ float dpp_f32(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, false));
+}
+static __device__ __forceinline__ float wave_sum_f32(float v) {
+    v += dpp_f32<0xB1, 0xf>(v);        // quad_perm [1,0,3,2]
+    v += dpp_f32<0x4E, 0xf>(v);        // quad_perm [2,3,0,1]
+    v += dpp_f32<0x141, 0xf>(v);       // row_half_mirror
+    v += dpp_f32<0x140, 0xf>(v);       // row_mirror        -> every lane holds its 16-lane row total
+    v += dpp_f32<0x142, 0xa>(v);       // row_bcast:15 into rows 1 and 3
+    v += dpp_f32<0x143, 0xc>(v);       // row_bcast:31 into rows 2 and 3 -> lanes 48..63 hold the wave total
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
 static __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));

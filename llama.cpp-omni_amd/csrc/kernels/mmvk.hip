@@ -64,7 +64,7 @@ struct mmv_out {
 // =================================================================================================
 template <int NCOLS, int ROWS, int U, bool PAIR>
 static __device__ __forceinline__ void q4k_body(const char * __restrict__ W0, const char * __restrict__ W1, size_t w_rs, const mmv_out o,
-                                                int K, int nrows, int wave, int nwaves) {
+                                                const char * __restrict__ act, size_t act_cs, int K, int nrows, int wave, int nwaves) {
     const int lane = threadIdx.x & 63;
     const int g = lane >> 3, lp = lane & 7, j = lp >> 1, h = lp & 1;
     const int nb  = K >> 8;
@@ -88,8 +88,10 @@ static __device__ __forceinline__ void q4k_body(const char * __restrict__ W0, co
     };
 
     int grp = wave, it = 0;
+    if (grp < ngrp) issue(grp, 0);                 // first weight loads are in flight while the activation image is staged
+    stage_act_k(act, act_cs, NCOLS, img);
+    __syncthreads();
     if (grp >= ngrp) return;
-    issue(grp, 0);
 
     float acc[ROWS][NCOLS];
 #pragma unroll
@@ -161,7 +163,7 @@ static __device__ __forceinline__ void q4k_body(const char * __restrict__ W0, co
             if (PAIR) {
 #pragma unroll
                 for (int c = 0; c < NCOLS; ++c) {
-                    const float gsum = wave_sum(acc[0][c]), usum = wave_sum(acc[1][c]);
+                    const float gsum = wave_sum_f32(acc[0][c]), usum = wave_sum_f32(acc[1][c]);
                     if (lane == 0) *(float *) (o.dst + c * o.dst_cs + (size_t) cgrp * 4) = silu_f(gsum) * usum;
                     acc[0][c] = 0.0f; acc[1][c] = 0.0f;
                 }
@@ -171,7 +173,7 @@ static __device__ __forceinline__ void q4k_body(const char * __restrict__ W0, co
                     const int row = cgrp * ROWS + r;
 #pragma unroll
                     for (int c = 0; c < NCOLS; ++c) {
-                        float s = wave_sum(acc[r][c]);
+                        float s = wave_sum_f32(acc[r][c]);
                         if (lane == 0 && row < nrows) {
                             if (o.resid) s += *(const float *) (o.resid + c * o.resid_cs + (size_t) row * 4);
                             *(float *) (o.dst + c * o.dst_cs + (size_t) row * 4) = s;
@@ -232,7 +234,7 @@ static __device__ __forceinline__ uint32_t sub32(uint32_t w) { return ((w | 0x80
 
 template <int NCOLS, int ROWS, int U, bool PAIR>
 static __device__ __forceinline__ void q6k_body(const char * __restrict__ W0, const char * __restrict__ W1, size_t w_rs, const mmv_out o,
-                                                int K, int nrows, int wave, int nwaves) {
+                                                const char * __restrict__ act, size_t act_cs, int K, int nrows, int wave, int nwaves) {
     const int lane = threadIdx.x & 63;
     const int g = lane >> 3, lp = lane & 7, n = lp >> 2, tp = lp & 3;
     const int nb  = K >> 8;
@@ -259,8 +261,10 @@ static __device__ __forceinline__ void q6k_body(const char * __restrict__ W0, co
     };
 
     int grp = wave, it = 0;
+    if (grp < ngrp) issue2(grp, 0);
+    stage_act_k(act, act_cs, NCOLS, img);
+    __syncthreads();
     if (grp >= ngrp) return;
-    issue2(grp, 0);
 
     float acc[ROWS][NCOLS];
 #pragma unroll
@@ -328,7 +332,7 @@ static __device__ __forceinline__ void q6k_body(const char * __restrict__ W0, co
             if (PAIR) {
 #pragma unroll
                 for (int c = 0; c < NCOLS; ++c) {
-                    const float gsum = wave_sum(acc[0][c]), usum = wave_sum(acc[1][c]);
+                    const float gsum = wave_sum_f32(acc[0][c]), usum = wave_sum_f32(acc[1][c]);
                     if (lane == 0) *(float *) (o.dst + c * o.dst_cs + (size_t) cgrp * 4) = silu_f(gsum) * usum;
                     acc[0][c] = 0.0f; acc[1][c] = 0.0f;
                 }
@@ -338,7 +342,7 @@ static __device__ __forceinline__ void q6k_body(const char * __restrict__ W0, co
                     const int row = cgrp * ROWS + r;
 #pragma unroll
                     for (int c = 0; c < NCOLS; ++c) {
-                        float s = wave_sum(acc[r][c]);
+                        float s = wave_sum_f32(acc[r][c]);
                         if (lane == 0 && row < nrows) {
                             if (o.resid) s += *(const float *) (o.resid + c * o.resid_cs + (size_t) row * 4);
                             *(float *) (o.dst + c * o.dst_cs + (size_t) row * 4) = s;
@@ -361,8 +365,8 @@ struct mmv_multi_dev { mmv_mat_dev m[3]; int nmat; const char * act; size_t act_
 // TM: bit0 = Q4_K bodies compiled in, bit1 = Q6_K bodies compiled in
 template <int NCOLS, int ROWS, int U, int TM>
 __global__ void __launch_bounds__(256) k_mmv_multi(const mmv_multi_dev a) {
-    stage_act_k(a.act, a.act_cs, NCOLS, q8k_image_bytes(a.K));
-    __syncthreads();
+    // (each body stages the activation image itself, after issuing its first weight loads; every wave of the workgroup
+    // runs exactly one body, so the single __syncthreads inside is met by all of them)
     const int wave = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
     int mi_ = 0, w0 = 0;
 #pragma unroll
@@ -370,23 +374,31 @@ __global__ void __launch_bounds__(256) k_mmv_multi(const mmv_multi_dev a) {
     // (static selection so the descriptor stays in SGPRs)
     const mmv_mat_dev M = mi_ == 0 ? a.m[0] : (mi_ == 1 ? a.m[1] : a.m[2]);
     const int lw = wave - w0, nw = M.wave_end - w0;
-    if ((TM & 1) && M.type == GGML_TYPE_Q4_K) q4k_body<NCOLS, ROWS, U, false>(M.W, nullptr, M.w_rs, M.o, a.K, M.nrows, lw, nw);
-    if ((TM & 2) && M.type == GGML_TYPE_Q6_K) q6k_body<NCOLS, ROWS, U, false>(M.W, nullptr, M.w_rs, M.o, a.K, M.nrows, lw, nw);
+    if (TM == 1)      q4k_body<NCOLS, ROWS, U, false>(M.W, nullptr, M.w_rs, M.o, a.act, a.act_cs, a.K, M.nrows, lw, nw);
+    else if (TM == 2) q6k_body<NCOLS, ROWS, U, false>(M.W, nullptr, M.w_rs, M.o, a.act, a.act_cs, a.K, M.nrows, lw, nw);
+    else if (M.type == GGML_TYPE_Q4_K) q4k_body<NCOLS, ROWS, U, false>(M.W, nullptr, M.w_rs, M.o, a.act, a.act_cs, a.K, M.nrows, lw, nw);
+    else                               q6k_body<NCOLS, ROWS, U, false>(M.W, nullptr, M.w_rs, M.o, a.act, a.act_cs, a.K, M.nrows, lw, nw);
 }
 
 template <int NCOLS, int U, int TYPE>
 __global__ void __launch_bounds__(256) k_mmv_pair(const char * __restrict__ Wg, const char * __restrict__ Wu, size_t w_rs, const char * __restrict__ act, size_t act_cs,
                                                  char * __restrict__ dst, size_t dst_cs, int K, int nrows) {
-    stage_act_k(act, act_cs, NCOLS, q8k_image_bytes(K));
-    __syncthreads();
     const int wave = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
     const mmv_out o = { dst, dst_cs, nullptr, 0 };
-    if (TYPE == GGML_TYPE_Q4_K) q4k_body<NCOLS, 2, U, true>(Wg, Wu, w_rs, o, K, nrows, wave, nwaves);
-    else                        q6k_body<NCOLS, 2, U, true>(Wg, Wu, w_rs, o, K, nrows, wave, nwaves);
+    if (TYPE == GGML_TYPE_Q4_K) q4k_body<NCOLS, 2, U, true>(Wg, Wu, w_rs, o, act, act_cs, K, nrows, wave, nwaves);
+    else                        q6k_body<NCOLS, 2, U, true>(Wg, Wu, w_rs, o, act, act_cs, K, nrows, wave, nwaves);
 }
 
 // ------------------------------------------------------------------------------------------------ launch
 static const size_t MMVK_LDS_MAX = 152 * 1024;
+
+// workgroups per launch are capped at (resident workgroups per CU) x 256 CUs so that a big matrix is one wave of workgroups
+// that grid-stride over the row groups (no second, partially filled wave); MI355X_MMV_WGS overrides for tuning
+static int mmv_grid_cap() {
+    static int cap = 0;
+    if (!cap) { const char * e = getenv("MI355X_MMV_WGS"); cap = e ? atoi(e) : 2048; if (cap < 1) cap = 2048; }
+    return cap;
+}
 
 template <int NCOLS, int ROWS, int U>
 static void launch_multi_tm(const mmv_multi_dev & d, int tm, int grid, size_t lds, hipStream_t st) {
@@ -412,7 +424,7 @@ void mmv_kquant_multi(const mmv_multi_args & a, hipStream_t st) {
         tm |= a.m[i].type == GGML_TYPE_Q4_K ? 1 : 2;
     }
     int64_t grid = (groups + 3) / 4;
-    if (grid > 2048) grid = 2048;
+    if (grid > mmv_grid_cap()) grid = mmv_grid_cap();
     if (grid < 1) grid = 1;
     const int nwaves = (int) grid * 4;
     mmv_multi_dev d;
@@ -450,7 +462,7 @@ void mmv_kquant_pair_swiglu(int type, const void * Wg, const void * Wu, size_t w
                             int64_t K, int64_t nrows, int ncols, hipStream_t st) {
     if (nrows == 0 || ncols == 0) return;
     const size_t lds = q8k_image_bytes(K) * ncols;
-    int64_t grid = (nrows + 3) / 4; if (grid > 2048) grid = 2048;
+    int64_t grid = (nrows + 3) / 4; if (grid > mmv_grid_cap()) grid = mmv_grid_cap();
     const bool u2 = (K / 256 + 7) / 8 >= 2 && ncols == 1;
 #define MP_GO(NC, UU)                                                                                                  \
     do {                                                                                                               \

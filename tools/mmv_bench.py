@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--ncols", type=int, default=1)
     ap.add_argument("--min-mib", type=int, default=768)
+    ap.add_argument("--pair", action="store_true")
     args = ap.parse_args()
     pkg = load_pkg()
     from llama_cpp_omni_amd import qwen3
@@ -40,7 +41,15 @@ def main():
             c = Context(be)
             x = c.new_tensor(GGML_TYPE_F32, K, args.ncols)
             ws = [c.new_tensor(ty, K, M) for _ in range(n)]
-            ys = [c.mul_mat(w, x) for w in ws]
+            if args.pair:                                            # ffn_gate + ffn_up + SWIGLU launches (k_mmv_pair)
+                n -= n % 2
+                ws = ws[:n]
+                ys = []
+                for i in range(0, n, 2):
+                    up, gate = c.mul_mat(ws[i], x), c.mul_mat(ws[i + 1], x)
+                    ys.append(c.swiglu_split(gate, up))
+            else:
+                ys = [c.mul_mat(w, x) for w in ws]
             c.alloc()
             host = qwen3.random_blocks(rng, ty, min(M, 4096), K)
             reps_rows = (M + host.shape[0] - 1) // host.shape[0]
