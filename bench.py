@@ -158,6 +158,27 @@ def kernel_roofline(pkg, be, model, reps=5):
             "method": "hipGraph replay of the step's 36 launches of this kernel, two HIP events on the backend stream, best of 5"}
 
 
+def prefill_tok_s(pkg, be, model, n_tokens=512, reps=3):
+    """llama-bench pp512 analogue: one ubatch of 512 tokens at depth 0 through the same backend (MFMA GEMM path for the mat-muls)."""
+    g, I, logits = model.build(n_tokens, n_tokens, n_outputs=1)
+    gr = g.graph()
+    rng = np.random.default_rng(5)
+    model.set_inputs(I, rng.standard_normal((n_tokens, model.cfg["n_embd"])).astype(np.float32), 0, n_tokens)
+    be.tensor_set(I["out_ids"], np.array([n_tokens - 1], np.int32))
+    for _ in range(2):
+        be.graph_compute(gr)
+    be.synchronize()
+    best = 1e30
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        be.graph_compute(gr)
+        be.synchronize()
+        best = min(best, time.perf_counter() - t0)
+    ok = bool(np.isfinite(be.tensor_get(logits)).all())
+    g.free()
+    return n_tokens / best, ok
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -247,6 +268,13 @@ def main():
             "hbm_frac_whole_step": round(wbytes * (args.steps / dt) / 1e9 / HBM_PEAK_GBS, 4),
             "roofline": roof,
         }
+        if world == 1 and not os.environ.get("MI355X_BENCH_NO_PP"):
+            try:                                                   # second half of the headline metric: pp512 (reported, not `value`)
+                pp, ok = prefill_tok_s(pkg, be, dec.model)
+                out["pp512_tok_s"] = round(pp, 1) if ok else None
+            except Exception as e:
+                out["pp512_tok_s"] = None
+                out["pp512_error"] = repr(e)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(pkg, cfg, types, n_kv)
         else:

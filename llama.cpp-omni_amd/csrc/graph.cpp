@@ -185,13 +185,35 @@ bool supports_op(const ggml_tensor * op) {
 }
 
 // ------------------------------------------------------------------------------------------------ scratch sizing
+// batches of more than 8 columns go to the MFMA GEMM (activations rounded to f16; quantised weights de-quantised to f16 first)
+static const int64_t GEMM_MIN_COLS = MI_MMVQ_MAX_COLS + 1;
+static bool mm_uses_gemm(const ggml_tensor * n) {
+    const ggml_tensor * w = n->src[0], * x = n->src[1];
+    static const bool no_gemm = getenv("MI355X_NO_GEMM") != nullptr;
+    if (x->ne[1] < GEMM_MIN_COLS || no_gemm) return false;
+    if (w->type != GGML_TYPE_F16 && w->type != GGML_TYPE_Q4_K && w->type != GGML_TYPE_Q6_K && w->type != GGML_TYPE_Q8_0) return false;
+    const int64_t K = w->ne[0];
+    if (K % 32 != 0) return false;
+    if (w->type == GGML_TYPE_F16 && (w->nb[1] % 16 != 0 || w->nb[2] % 16 != 0 || w->nb[3] % 16 != 0 || ((uintptr_t) w->data & 15) != 0)) return false;
+    return true;
+}
 static size_t graph_act_scratch_need(const ggml_cgraph * g) {
     size_t need = 0;
     for (int i = 0; i < g->n_nodes; ++i) {
         const ggml_tensor * n = g->nodes[i];
         if (n->op != GGML_OP_MUL_MAT || is_empty(n)) continue;
-        const act_kind k = act_kind_for(n->src[0]->type);
+        const act_kind k = mm_uses_gemm(n) ? ACT_F16 : act_kind_for(n->src[0]->type);
         const size_t b = act_image_bytes(k, n->src[1]->ne[0]) * (size_t) (n->src[1]->ne[1] * n->src[1]->ne[2] * n->src[1]->ne[3]);
+        if (b > need) need = b;
+    }
+    return need;
+}
+static size_t graph_w_scratch_need(const ggml_cgraph * g) {
+    size_t need = 0;
+    for (int i = 0; i < g->n_nodes; ++i) {
+        const ggml_tensor * n = g->nodes[i];
+        if (n->op != GGML_OP_MUL_MAT || is_empty(n) || !mm_uses_gemm(n) || n->src[0]->type == GGML_TYPE_F16) continue;
+        const size_t b = (size_t) n->src[0]->ne[0] * (size_t) n->src[0]->ne[1] * 2;
         if (b > need) need = b;
     }
     return need;
@@ -251,6 +273,32 @@ static void op_mul_mat(exec_state & s, const ggml_tensor * dst) {
     const int64_t K = w->ne[0], M = w->ne[1], N = x->ne[1];
     const int64_t ne12 = x->ne[2], ne13 = x->ne[3];
     const int64_t r2 = ne12 / w->ne[2], r3 = ne13 / w->ne[3];
+
+    if (mm_uses_gemm(dst)) {
+        // ---- prefill: MFMA GEMM.  X -> f16 rows (what the reference does for F16 weights, ggml-cpu.c:1245-1268); quantised W -> f16
+        const size_t ximg = prepare_act(s, x, ACT_F16);
+        const void * last_w = nullptr;
+        for (int64_t i13 = 0; i13 < ne13; ++i13) {
+            for (int64_t i12 = 0; i12 < ne12; ++i12) {
+                const char * wp = (const char *) w->data + (i12 / r2) * w->nb[2] + (i13 / r3) * w->nb[3];
+                const uint16_t * w16 = (const uint16_t *) wp; size_t w16_rs = w->nb[1];
+                if (w->type != GGML_TYPE_F16) {
+                    if (wp != last_w) {
+                        prof_scope ps(s, "dequant_f16", (double) M * (double) row_size(w->type, K));
+                        dequant_rows_f16(w->type, wp, w->nb[1], (uint16_t *) s.c->w_scratch, (size_t) K * 2, K, M, s.st); ++s.n_kernels;
+                        last_w = wp;
+                    }
+                    w16 = (const uint16_t *) s.c->w_scratch; w16_rs = (size_t) K * 2;
+                }
+                const char * xp = (const char *) s.c->act_scratch + (size_t) ((i13 * ne12 + i12) * N) * ximg;
+                prof_scope ps(s, "gemm_f16", 2.0 * (double) M * (double) N * (double) K);
+                gemm_f16_mfma(w16, w16_rs, (const uint16_t *) xp, ximg, (float *) ((char *) dst->data + i12 * dst->nb[2] + i13 * dst->nb[3]), dst->nb[1], M, N, K, s.st);
+                ++s.n_kernels;
+            }
+        }
+        return;
+    }
+
     const act_kind kind = act_kind_for(w->type);
     const size_t img = prepare_act(s, x, kind);
 
@@ -693,6 +741,7 @@ static uint64_t fingerprint(const ggml_cgraph * g) {
 enum ggml_status graph_compute(backend_ctx * c, ggml_cgraph * g) {
     if (g->n_nodes == 0) return GGML_STATUS_SUCCESS;
     ensure_scratch(c, &c->act_scratch, &c->act_scratch_bytes, graph_act_scratch_need(g));
+    ensure_scratch(c, &c->w_scratch, &c->w_scratch_bytes, graph_w_scratch_need(g));
 
     int n_real = 0;
     for (int i = 0; i < g->n_nodes; ++i) n_real += !is_noop(g->nodes[i]);

@@ -1,0 +1,132 @@
+// gemm.hip -- dense F16 x F16 -> F32 GEMM on the CDNA4 matrix cores (prefill path, batches of more than 8 columns).
+//
+// Replaces what the reference sends to the vendor BLAS: ggml_cuda_op_mul_mat_cublas, ggml-cuda.cu:1211-1355 (F16 weights,
+// activations cast F32 -> F16, FP32 accumulate and FP32 output on CDNA, :1293-1303), and is what the CPU oracle computes in
+// ggml_compute_forward_mul_mat for F16 weights (src1 rounded to the F16 vec_dot_type, f32 accumulation; ggml-cpu.c:1245-1268).
+//     dst[n][m] = sum_k W[m][k] * X[n][k]          W: M x K f16 rows, X: N x K f16 rows (K contiguous in both), dst f32
+// Quantised weights reach this kernel through a de-quantise-to-f16 pass (dequant_rows_f16); fusing that into the LDS staging is
+// the next step.
+//
+// v_mfma_f32_32x32x16_f16: the A fragment of lane l is 8 consecutive k of row l%32 (k-octet l/32), the B fragment likewise --
+// both operands are K-contiguous rows here, so each fragment is ONE 16-byte LDS read.  X supplies the rows (i) and W the columns
+// (j) of every 32x32 C tile so that, per accumulator register, 32 lanes store 32 consecutive m (128 B, coalesced).
+// Workgroup = 4 waves, tile 128 (m) x 128 (n) x 32 (k), each wave 64 x 64 = 2x2 MFMA tiles; LDS rows padded to 80 B
+// (5 x 16 B: conflict-free for ds_read_b128); global -> register -> LDS staging, double-buffered (one barrier per K-step),
+// next tile's global loads issued before the current tile's MFMAs.  blockIdx is remapped so that the workgroups sharing a
+// weight panel run on the same XCD (private L2 per XCD).
+#include "../kernels.hpp"
+
+namespace mi {
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef float    f16v __attribute__((ext_vector_type(16)));
+
+constexpr int G_BM = 128, G_BN = 128, G_BK = 32, G_LD = G_BK + 8;    // LDS row = 40 halfs = 80 bytes
+
+__global__ void __launch_bounds__(256) k_gemm_f16(const char * __restrict__ W, size_t w_rs, const char * __restrict__ X, size_t x_rs,
+                                                  char * __restrict__ dst, size_t dst_cs, int M, int N, int K, int tiles_m, int tiles_n) {
+    __shared__ __attribute__((aligned(16))) _Float16 Ws[2][G_BM * G_LD];
+    __shared__ __attribute__((aligned(16))) _Float16 Xs[2][G_BN * G_LD];
+
+    // XCD-aware tile order: consecutive block ids go round-robin over the 8 XCDs; give each XCD a contiguous run of tiles
+    const int nt  = tiles_m * tiles_n;
+    const int bid = blockIdx.x;
+    const int q = nt / 8, r = nt % 8, xcd = bid % 8, idx = bid / 8;
+    const int tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;      // bijective for any nt
+    const int tm = tile / tiles_n, tn = tile % tiles_n;                                   // n fastest: neighbours share the W panel
+    const int m0 = tm * G_BM, n0 = tn * G_BN;
+
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wm = wave & 1, wn = wave >> 1;
+
+    // staging map: 128 rows x 4 chunks of 16 B per operand tile = 512 chunks, 2 per thread
+    int srow[2], scol[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) { const int c = t + 256 * i; srow[i] = c >> 2; scol[i] = c & 3; }
+    const char * wp[2]; const char * xp[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        int mr = m0 + srow[i]; mr = mr < M ? mr : M - 1;
+        int nr = n0 + srow[i]; nr = nr < N ? nr : N - 1;
+        wp[i] = W + (size_t) mr * w_rs + scol[i] * 16;
+        xp[i] = X + (size_t) nr * x_rs + scol[i] * 16;
+    }
+
+    f16v acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.0f;
+
+    u32x4 wreg[2], xreg[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) { wreg[i] = *(const u32x4 *) wp[i]; xreg[i] = *(const u32x4 *) xp[i]; }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        *(u32x4 *) &Ws[0][srow[i] * G_LD + scol[i] * 8] = wreg[i];
+        *(u32x4 *) &Xs[0][srow[i] * G_LD + scol[i] * 8] = xreg[i];
+    }
+    __syncthreads();
+
+    const int nk = K / G_BK;
+    const int fr = lane & 31, fk = (lane >> 5) * 8;
+    for (int ks = 0; ks < nk; ++ks) {
+        const int cur = ks & 1;
+        if (ks + 1 < nk) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                wreg[i] = *(const u32x4 *) (wp[i] + (size_t) (ks + 1) * (G_BK * 2));
+                xreg[i] = *(const u32x4 *) (xp[i] + (size_t) (ks + 1) * (G_BK * 2));
+            }
+        }
+#pragma unroll
+        for (int kk = 0; kk < G_BK / 16; ++kk) {
+            h8 af[2], bf[2];
+#pragma unroll
+            for (int a = 0; a < 2; ++a) af[a] = *(const h8 *) &Xs[cur][(wn * 64 + a * 32 + fr) * G_LD + kk * 16 + fk];
+#pragma unroll
+            for (int b = 0; b < 2; ++b) bf[b] = *(const h8 *) &Ws[cur][(wm * 64 + b * 32 + fr) * G_LD + kk * 16 + fk];
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[a], bf[b], acc[a][b], 0, 0, 0);
+        }
+        if (ks + 1 < nk) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                *(u32x4 *) &Ws[cur ^ 1][srow[i] * G_LD + scol[i] * 8] = wreg[i];
+                *(u32x4 *) &Xs[cur ^ 1][srow[i] * G_LD + scol[i] * 8] = xreg[i];
+            }
+        }
+        __syncthreads();
+    }
+
+    // C/D layout of the 32x32 tile: col j = lane%32 (-> m), row i = (reg&3) + 8*(reg>>2) + 4*(lane/32) (-> n)
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int m = m0 + wm * 64 + b * 32 + (lane & 31);
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int n = n0 + wn * 64 + a * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+                if (m < M && n < N) *(float *) (dst + (size_t) n * dst_cs + (size_t) m * 4) = acc[a][b][e];
+            }
+        }
+}
+
+bool gemm_f16_ok(const void * W, size_t w_rs, const void * X, size_t x_rs, int64_t K) {
+    return K % G_BK == 0 && K >= G_BK && w_rs % 16 == 0 && x_rs % 16 == 0 && ((uintptr_t) W & 15) == 0 && ((uintptr_t) X & 15) == 0;
+}
+
+void gemm_f16_mfma(const uint16_t * W, size_t w_rs, const uint16_t * X, size_t x_rs, float * dst, size_t dst_cs,
+                   int64_t M, int64_t N, int64_t K, hipStream_t st) {
+    if (M == 0 || N == 0) return;
+    const int tiles_m = (int) ((M + G_BM - 1) / G_BM), tiles_n = (int) ((N + G_BN - 1) / G_BN);
+    k_gemm_f16<<<dim3((unsigned) (tiles_m * tiles_n)), dim3(256), 0, st>>>((const char *) W, w_rs, (const char *) X, x_rs, (char *) dst, dst_cs,
+                                                                          (int) M, (int) N, (int) K, tiles_m, tiles_n);
+}
+
+} // namespace mi

@@ -184,6 +184,27 @@ def test_mul_mat_vs_oracle_shapes(pkg, be, name, M, K, N):
     assert nmse(got, want) < 1e-9, (name, M, K, N)
 
 
+@pytest.mark.parametrize("name", ["q4_K", "q6_K", "q8_0", "f16"])
+@pytest.mark.parametrize("M,K,N", [(64, 256, 9), (130, 1024, 33), (257, 4096, 128), (1000, 2304, 200)])
+def test_mul_mat_gemm_path_vs_oracle(pkg, be, name, M, K, N):
+    """batches > 8 columns run on the MFMA GEMM (f16 operands, f32 accumulate; quantised weights de-quantised to f16).
+    Against the oracle's exact-integer arithmetic the reference's own MUL_MAT bar applies (NMSE 5e-4); for F16 weights the two
+    compute the same products and the error is f32 re-association only."""
+    from llama_cpp_omni_amd import qwen3
+    rng = np.random.default_rng(M + K + N)
+    ty = TYPES[name]
+    wv = qwen3.random_blocks(rng, ty, M, K, std=0.05)
+    xv = rng.standard_normal((N, K)).astype(np.float32)
+    c = pkg.Context(be)
+    w = c.new_tensor(ty, K, M)
+    x = c.new_tensor(pkg.GGML_TYPE_F32, K, N)
+    y = c.mul_mat(w, x)
+    (got,) = run_graph(be, c, [y], [(w, wv), (x, xv)])
+    want = orc.mul_mat(ty, wv.view(np.uint8).reshape(M, -1), xv)
+    err = nmse(got, want)
+    assert err < (1e-9 if name == "f16" else 5e-4), (name, M, K, N, err)
+
+
 def test_mul_mat_zero_and_empty(pkg, be):
     """all-zero activations (Q8_K amax == 0 branch) and a zero-column batch"""
     from llama_cpp_omni_amd import qwen3
