@@ -175,6 +175,19 @@ def prefill_tok_s(pkg, be, model, n_tokens=512, reps=3):
         be.synchronize()
         best = min(best, time.perf_counter() - t0)
     ok = bool(np.isfinite(be.tensor_get(logits)).all())
+    if os.environ.get("MI355X_BENCH_PROFILE"):
+        be.set_option("profile", 1)
+        be.set_option("reset_stats", 1)
+        be.graph_compute(gr)
+        be.synchronize()
+        prof = {}
+        for cls in ("gemm_f16", "dequant_f16", "mmv_q4k", "mmv_q6k", "act_convert", "rms_norm_mul_quant", "rms_norm_mul", "rms_norm", "norm_rope", "rope",
+                    "fattn", "set_rows", "get_rows", "bin", "glu", "cpy", "empty"):
+            u, k = be.get_stat(f"prof_{cls}_us"), be.get_stat(f"prof_{cls}_n")
+            if k > 0:
+                prof[cls] = {"n": int(k), "total_us": round(u, 1), "avg_event_to_event_us": round(u / k, 2)}
+        be.set_option("profile", 0)
+        sys.stderr.write(f"prefill {n_tokens} tokens, eager per-class profile: " + json.dumps(prof) + "\n")
     g.free()
     return n_tokens / best, ok
 

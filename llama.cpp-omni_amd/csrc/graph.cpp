@@ -364,7 +364,7 @@ static bool ready_before(exec_state & s, const ggml_tensor * src, int i, const i
         if (it != s.index.end()) {
             const int k = it->second;
             if (!is_noop(s.g->nodes[k])) {
-                if (k < i) return true;
+                if (k < i || s.done[k]) return true;                     // computed already (in order, or hoisted earlier)
                 for (int q = 0; q < n_item; ++q) if (item[q] == k) return true;
                 return false;
             }
@@ -491,6 +491,61 @@ static void exec_mul_mat(exec_state & s, int i) {
     }
 }
 
+// RMS_NORM(j) -> MUL(w[D]) -> ROPE [-> SET_ROWS of the rotated rows viewed as [D*H, T] into an f16 table]; shape checks only
+struct nr_chain {
+    int norm, mul, rope, store;
+    const ggml_tensor * wt, * pos, * ff;
+    int D, H, T; float eps; rope_params rp;
+};
+static bool match_norm_rope(exec_state & s, int j, nr_chain & c) {
+    ggml_cgraph * g = s.g;
+    ggml_tensor * n = g->nodes[j];
+    const int mi_ = sole_user(s, n);
+    if (mi_ <= j || g->nodes[mi_]->op != GGML_OP_MUL || s.done[mi_]) return false;
+    ggml_tensor * m = g->nodes[mi_];
+    if ((m->src[0] == n) == (m->src[1] == n)) return false;
+    const ggml_tensor * wt = m->src[0] == n ? m->src[1] : m->src[0];
+    const int64_t D = n->ne[0];
+    if (!wt || m->type != GGML_TYPE_F32 || wt->type != GGML_TYPE_F32 || wt->nb[0] != 4 || !same_shape(m, n) || m->nb[0] != 4 ||
+        wt->ne[0] != D || wt->ne[1] * wt->ne[2] * wt->ne[3] != 1 || n->src[0]->nb[0] != 4 || n->src[0]->type != GGML_TYPE_F32) return false;
+    const int ri = sole_user(s, m);
+    if (!(ri > mi_ && g->nodes[ri]->op == GGML_OP_ROPE && g->nodes[ri]->src[0] == m && !s.done[ri] && D % 2 == 0 && D <= 256 && n->ne[3] == 1)) return false;
+    ggml_tensor * r = g->nodes[ri];
+    const int mode = op_param_i32(r, 2);
+    const ggml_tensor * pos = r->src[1], * ff = r->src[2];
+    if (!((mode == GGML_ROPE_TYPE_NORMAL || mode == GGML_ROPE_TYPE_NEOX) && op_param_i32(r, 1) == D && r->nb[0] == 4 && pos && pos->type == GGML_TYPE_I32 &&
+          pos->nb[0] == 4 && (!ff || (ff->type == GGML_TYPE_F32 && ff->nb[0] == 4)))) return false;
+    c.norm = j; c.mul = mi_; c.rope = ri; c.store = -1; c.wt = wt; c.pos = pos; c.ff = ff;
+    c.D = (int) D; c.H = (int) n->ne[1]; c.T = (int) n->ne[2]; c.eps = op_param_f32(n, 0);
+    memset(&c.rp, 0, sizeof(c.rp));
+    c.rp.n_dims = op_param_i32(r, 1); c.rp.mode = mode; c.rp.n_ctx_orig = op_param_i32(r, 4);
+    c.rp.freq_base = op_param_f32(r, 5); c.rp.freq_scale = op_param_f32(r, 6); c.rp.ext_factor = op_param_f32(r, 7);
+    c.rp.attn_factor = op_param_f32(r, 8); c.rp.beta_fast = op_param_f32(r, 9); c.rp.beta_slow = op_param_f32(r, 10);
+    // optional store of the rotated rows (llama_kv_cache::cpy_k): the rope output's only consumer
+    const int si = sole_user(s, r);
+    if (si > ri && g->nodes[si]->op == GGML_OP_SET_ROWS && !s.done[si]) {
+        const ggml_tensor * S = g->nodes[si], * V = S->src[0], * idx = S->src[1];
+        if (V && idx && V->data == r->data && V->ne[0] == D * n->ne[1] && V->ne[1] == n->ne[2] && V->ne[2] == 1 && V->ne[3] == 1 &&
+            V->nb[1] == r->nb[2] && r->nb[1] == (size_t) D * 4 && S->type == GGML_TYPE_F16 && S->nb[0] == 2 &&
+            (idx->type == GGML_TYPE_I64 || idx->type == GGML_TYPE_I32) && idx->ne[0] == n->ne[2] && idx->ne[1] == 1 && idx->ne[2] == 1) c.store = si;
+    }
+    return true;
+}
+static norm_rope_job chain_job(exec_state & s, const nr_chain & c) {
+    ggml_cgraph * g = s.g;
+    const ggml_tensor * x = g->nodes[c.norm]->src[0]; ggml_tensor * r = g->nodes[c.rope];
+    norm_rope_job j;
+    j.x = (const float *) x->data; j.xnb1 = x->nb[1]; j.xnb2 = x->nb[2]; j.w = (const float *) c.wt->data;
+    j.y = (float *) r->data; j.ynb1 = r->nb[1]; j.ynb2 = r->nb[2];
+    j.kv = nullptr; j.kv_rs = 0; j.idx = nullptr; j.idx_is64 = 0; j.idx_nb0 = 0; j.H = c.H;
+    if (c.store >= 0) {
+        const ggml_tensor * S = g->nodes[c.store], * idx = S->src[1];
+        j.kv = S->data; j.kv_rs = S->nb[1]; j.idx = idx->data; j.idx_is64 = idx->type == GGML_TYPE_I64; j.idx_nb0 = idx->nb[0];
+        j.y = nullptr;                                                    // the only consumer was the store
+    }
+    return j;
+}
+
 // RMS_NORM at node i: fold the following MUL(w) in, and -- when every consumer is a K-quant MUL_MAT -- also emit the Q8_K image
 static bool exec_rms_norm(exec_state & s, int i) {
     ggml_cgraph * g = s.g;
@@ -503,48 +558,70 @@ static bool exec_rms_norm(exec_state & s, int i) {
     const ggml_tensor * wt = m->src[0] == n ? m->src[1] : m->src[0];
     if ((m->src[0] == n) == (m->src[1] == n)) return false;
     if (!wt || wt == n || m->type != GGML_TYPE_F32 || wt->type != GGML_TYPE_F32 || wt->nb[0] != 4 || !same_shape(m, n) || !can_repeat(wt, n) || m->nb[0] != 4) return false;
-    // chain variant: RMS_NORM -> MUL(w[D]) -> ROPE [-> SET_ROWS(view as [D*H, T]) into an f16 table]: the q / k chains of a decoder layer
+    // chain variant: RMS_NORM -> MUL(w[D]) -> ROPE [-> SET_ROWS(view as [D*H, T]) into an f16 table]: the q / k chains of a decoder
+    // layer; a second chain with the same rope parameters and one plain f32 -> f16 SET_ROWS (the v store) join the launch
     {
-        const int ri = sole_user(s, m);
-        const int64_t D = n->ne[0];
-        if (ri > mi_ && g->nodes[ri]->op == GGML_OP_ROPE && g->nodes[ri]->src[0] == m && D % 2 == 0 && D <= 256 && n->ne[3] == 1 &&
-            wt->ne[0] == D && wt->ne[1] * wt->ne[2] * wt->ne[3] == 1 && n->src[0]->nb[0] == 4) {
-            ggml_tensor * r = g->nodes[ri];
-            const int mode = op_param_i32(r, 2);
-            const ggml_tensor * pos = r->src[1], * ff = r->src[2];
-            int item[4] = { i, mi_, ri, -1 };
-            if ((mode == GGML_ROPE_TYPE_NORMAL || mode == GGML_ROPE_TYPE_NEOX) && op_param_i32(r, 1) == D && r->nb[0] == 4 && pos && pos->type == GGML_TYPE_I32 &&
-                pos->nb[0] == 4 && (!ff || (ff->type == GGML_TYPE_F32 && ff->nb[0] == 4)) && can_hoist(s, i, ri, item, 3)) {
-                norm_rope_args a;
-                const ggml_tensor * x = n->src[0];
-                a.x = (const float *) x->data; a.xnb1 = x->nb[1]; a.xnb2 = x->nb[2];
-                a.w = (const float *) wt->data; a.pos = (const int32_t *) pos->data; a.ff = ff ? (const float *) ff->data : nullptr;
-                a.y = (float *) r->data; a.ynb1 = r->nb[1]; a.ynb2 = r->nb[2];
-                a.kv = nullptr; a.kv_rs = 0; a.idx = nullptr; a.idx_is64 = 0; a.idx_nb0 = 0;
-                a.D = (int) D; a.H = (int) n->ne[1]; a.T = (int) n->ne[2]; a.eps = eps;
-                a.rp.n_dims = op_param_i32(r, 1); a.rp.mode = mode; a.rp.n_ctx_orig = op_param_i32(r, 4);
-                a.rp.freq_base = op_param_f32(r, 5); a.rp.freq_scale = op_param_f32(r, 6); a.rp.ext_factor = op_param_f32(r, 7);
-                a.rp.attn_factor = op_param_f32(r, 8); a.rp.beta_fast = op_param_f32(r, 9); a.rp.beta_slow = op_param_f32(r, 10);
-                // optional store of the rotated rows (llama_kv_cache::cpy_k)
-                int si = sole_user(s, r);
-                if (si > ri && g->nodes[si]->op == GGML_OP_SET_ROWS && !s.done[si]) {
-                    ggml_tensor * S = g->nodes[si];
+        nr_chain A;
+        if (match_norm_rope(s, i, A)) {
+            nr_chain B; int bj = -1, vj = -1; norm_rope_job vjob;
+            int item[12]; int ni = 0;
+            item[ni++] = A.norm; item[ni++] = A.mul; item[ni++] = A.rope;
+            bool okA = can_hoist(s, i, A.rope, item, ni);
+            if (okA && A.store >= 0) {
+                item[ni++] = A.store;
+                if (!can_hoist(s, i, A.store, item, ni)) { --ni; A.store = -1; }
+            }
+            if (okA) {
+                // second chain
+                for (int j = i + 1; j < g->n_nodes && j < i + 24; ++j) {
+                    if (s.done[j] || g->nodes[j]->op != GGML_OP_RMS_NORM) continue;
+                    if (!match_norm_rope(s, j, B) || B.D != A.D || B.T != A.T || B.eps != A.eps || B.pos != A.pos || B.ff != A.ff ||
+                        memcmp(&B.rp, &A.rp, sizeof(rope_params)) != 0) break;
+                    int it2[12]; int n2 = ni;
+                    memcpy(it2, item, sizeof(int) * ni);
+                    it2[n2++] = B.norm; it2[n2++] = B.mul; it2[n2++] = B.rope;
+                    bool ok = can_hoist(s, i, B.norm, it2, n2) && can_hoist(s, i, B.mul, it2, n2) && can_hoist(s, i, B.rope, it2, n2);
+                    if (ok && B.store >= 0) {
+                        it2[n2++] = B.store;
+                        if (!can_hoist(s, i, B.store, it2, n2)) { --n2; B.store = -1; }
+                    }
+                    if (ok) { bj = j; memcpy(item, it2, sizeof(int) * n2); ni = n2; }
+                    break;
+                }
+                // plain store of rows of D-element groups (v_cur -> v cache)
+                for (int j = i + 1; j < g->n_nodes && j < i + 32; ++j) {
+                    ggml_tensor * S = g->nodes[j];
+                    if (s.done[j] || S->op != GGML_OP_SET_ROWS) continue;
+                    bool mine = false;
+                    for (int q = 0; q < ni; ++q) mine |= item[q] == j;
+                    if (mine) continue;
                     const ggml_tensor * V = S->src[0], * idx = S->src[1];
-                    item[3] = si;
-                    const bool ok = V && idx && V->data == r->data && V->ne[0] == D * n->ne[1] && V->ne[1] == n->ne[2] && V->ne[2] == 1 && V->ne[3] == 1 &&
-                                    V->nb[1] == r->nb[2] && r->nb[1] == (size_t) D * 4 && S->type == GGML_TYPE_F16 && S->nb[0] == 2 &&
-                                    (idx->type == GGML_TYPE_I64 || idx->type == GGML_TYPE_I32) && idx->ne[0] == n->ne[2] && idx->ne[1] == 1 && idx->ne[2] == 1 &&
-                                    can_hoist(s, i, si, item, 4);
-                    if (ok) {
-                        a.kv = S->data; a.kv_rs = S->nb[1]; a.idx = idx->data; a.idx_is64 = idx->type == GGML_TYPE_I64; a.idx_nb0 = idx->nb[0];
-                        a.y = nullptr;                                    // the only consumer was the store
-                    } else si = -1;
-                } else si = -1;
-                prof_scope ps(s, "norm_rope", 0);
-                norm_rope_store(a, s.st);
-                ++s.n_kernels; s.n_fused += si >= 0 ? 3 : 2;
-                s.done[mi_] = s.done[ri] = 1;
-                if (si >= 0) { s.done[si] = 1; note_write(s, g->nodes[si]); } else note_write(s, r);
+                    if (!(V && idx && V->type == GGML_TYPE_F32 && S->type == GGML_TYPE_F16 && S->nb[0] == 2 && V->nb[0] == 4 && V->ne[0] % A.D == 0 &&
+                          V->ne[1] == A.T && V->ne[2] == 1 && V->ne[3] == 1 && (idx->type == GGML_TYPE_I64 || idx->type == GGML_TYPE_I32) &&
+                          idx->ne[0] == A.T && idx->ne[1] == 1 && idx->ne[2] == 1)) continue;
+                    item[ni++] = j;
+                    if (can_hoist(s, i, j, item, ni)) {
+                        vj = j;
+                        vjob = { (const float *) V->data, (int64_t) A.D * 4, (int64_t) V->nb[1], nullptr, nullptr, 0, 0,
+                                 S->data, (int64_t) S->nb[1], idx->data, idx->type == GGML_TYPE_I64, (int64_t) idx->nb[0], (int) (V->ne[0] / A.D) };
+                    } else --ni;
+                    break;
+                }
+                norm_rope_args a;
+                a.njobs = 0; a.pos = (const int32_t *) A.pos->data; a.ff = A.ff ? (const float *) A.ff->data : nullptr;
+                a.D = A.D; a.T = A.T; a.eps = A.eps; a.rp = A.rp;
+                a.j[a.njobs++] = chain_job(s, A);
+                if (bj >= 0) a.j[a.njobs++] = chain_job(s, B);
+                if (vj >= 0) a.j[a.njobs++] = vjob;
+                {
+                    prof_scope ps(s, "norm_rope", 0);
+                    norm_rope_store(a, s.st);
+                }
+                ++s.n_kernels;
+                for (int q = 1; q < ni; ++q) { s.done[item[q]] = 1; ++s.n_fused; }
+                note_write(s, g->nodes[A.store >= 0 ? A.store : A.rope]);
+                if (bj >= 0) note_write(s, g->nodes[B.store >= 0 ? B.store : B.rope]);
+                if (vj >= 0) note_write(s, g->nodes[vj]);
                 return true;
             }
         }

@@ -103,13 +103,19 @@ bool   fattn_can_emit_image(const fattn_args & a);
 void   flash_attn_ext_f16(const fattn_args & a, hipStream_t st);
 
 // RMS_NORM -> MUL(w) -> ROPE [-> SET_ROWS into an f16 table] on a [D, H, T] f32 activation, one launch
-struct norm_rope_args {
+// up to three such jobs share a launch (q chain, k chain + store, plain f32 -> f16 v store: w == null)
+struct norm_rope_job {
     const float * x; int64_t xnb1, xnb2;     // head / token byte strides
-    const float * w; const int32_t * pos; const float * ff;
+    const float * w;                         // norm weight [D]; null = plain store job
     float * y; int64_t ynb1, ynb2;           // rope output (null when only the store is consumed)
     void * kv; int64_t kv_rs;                // f16 table base and row stride (null when there is no store)
     const void * idx; int idx_is64; int64_t idx_nb0;
-    int D, H, T; float eps; rope_params rp;
+    int H;
+};
+struct norm_rope_args {
+    norm_rope_job j[3]; int njobs;
+    const int32_t * pos; const float * ff;
+    int D, T; float eps; rope_params rp;
 };
 void norm_rope_store(const norm_rope_args & a, hipStream_t st);
 bool rms_norm_mul_quant_ok(int64_t n);

@@ -181,7 +181,9 @@ def test_mul_mat_vs_oracle_shapes(pkg, be, name, M, K, N):
     y = c.mul_mat(w, x)
     (got,) = run_graph(be, c, [y], [(w, wv), (x, xv)])
     want = orc.mul_mat(ty, wv.view(np.uint8).reshape(M, -1), xv)
-    assert nmse(got, want) < 1e-9, (name, M, K, N)
+    # <= 8 columns: mat-vec path, the oracle's own integer arithmetic; more: MFMA GEMM on f16 operands (reference MUL_MAT bar)
+    bar = 1e-9 if (N <= 8 or name in ("f16", "f32")) else 5e-4
+    assert nmse(got, want) < bar, (name, M, K, N)
 
 
 @pytest.mark.parametrize("name", ["q4_K", "q6_K", "q8_0", "f16"])
