@@ -18,21 +18,9 @@
 // at small depth.  The four waves' (M, S, acc) partials merge through LDS.  Optional epilogue: emit the Q8_K image of the
 // output row (what the following wo MUL_MAT would otherwise quantise in its own launch).
 #include "../kernels.hpp"
+#include "fattn_dev.hpp"
 
 namespace mi {
-
-struct fa_dev {
-    const char * q; const char * k; const char * v; const char * mask; const float * sinks; char * dst;
-    int     nq, nh, nhkv, nkv, ns;                      // query rows, heads, kv heads, kv length, sequences
-    int64_t qnb1, qnb2, qnb3, knb1, knb2, knb3, vnb1, vnb2, vnb3;
-    int64_t mnb1, mnb2, mnb3, mne2, mne3;
-    int64_t dnb1, dnb2, dnb3;
-    float scale, max_bias, logit_softcap, m0, m1; uint32_t n_head_log2;
-    int gq;                                             // n_head / n_head_kv
-    int hpw;                                            // heads handled per workgroup (<= R)
-    int qpw;                                            // query rows per workgroup (R / hpw)
-    char * img; size_t img_bytes;                       // optional Q8_K image output (one image per (seq, query row)), else null
-};
 
 extern __shared__ __attribute__((aligned(16))) char fa_lds[];
 
@@ -313,6 +301,8 @@ void flash_attn_ext_f16(const fattn_args & f, hipStream_t st) {
     a.gq = (int) (a.nh / a.nhkv);
     a.hpw = a.qpw = 1;
     a.img = (char *) f.img; a.img_bytes = f.img ? q8k_image_bytes(a.nh * f.q.ne[0]) : 0;
+    // batches of query rows go to the matrix-core kernel (fattn_mma.hip); single / few rows stay on the streaming decode kernel
+    if (a.nq > 8 && !a.img && (f.q.ne[0] == 64 || f.q.ne[0] == 128)) { flash_attn_ext_mma(a, (int) f.q.ne[0], st); return; }
     switch ((int) f.q.ne[0]) {
         case 64:  launch_fa<64>(a, st); break;
         case 128: launch_fa<128>(a, st); break;

@@ -1,0 +1,23 @@
+// fattn_dev.hpp -- device-side argument block shared by the two FLASH_ATTN_EXT kernels (fattn.hip: decode, fattn_mma.hip: prefill)
+#pragma once
+#include "../kernels.hpp"
+
+namespace mi {
+
+struct fa_dev {
+    const char * q; const char * k; const char * v; const char * mask; const float * sinks; char * dst;
+    int     nq, nh, nhkv, nkv, ns;                      // query rows, heads, kv heads, kv length, sequences
+    int64_t qnb1, qnb2, qnb3, knb1, knb2, knb3, vnb1, vnb2, vnb3;
+    int64_t mnb1, mnb2, mnb3, mne2, mne3;
+    int64_t dnb1, dnb2, dnb3;
+    float scale, max_bias, logit_softcap, m0, m1; uint32_t n_head_log2;
+    int gq;                                             // n_head / n_head_kv
+    int hpw;                                            // heads handled per workgroup (<= R)
+    int qpw;                                            // query rows per workgroup (R / hpw)
+    char * img; size_t img_bytes;                       // optional Q8_K image output (one image per (seq, query row)), else null
+};
+
+// prefill kernel (fattn_mma.hip): MFMA tiles, 32 query rows per wave
+void flash_attn_ext_mma(const fa_dev & a, int D, hipStream_t st);
+
+} // namespace mi

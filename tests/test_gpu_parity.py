@@ -153,6 +153,69 @@ def test_flash_attn_golden(pkg, be, golden, nkv):
     assert nmse(got, g[f"fa{nkv}_y"]) < 5e-4
 
 
+def _attn_f64(q, k, v, mask, scale, softcap=0.0, sinks=None):
+    """ggml_compute_forward_flash_attn_ext_f16 restated in float64 (ops.cpp:7912-8148): q [ns, nh, nq, D] (rounded to f16),
+    k/v [ns, nhkv, nkv, D], mask [nq_pad, nkv] f16 or None -> [ns, nq, nh, D]"""
+    ns, nh, nq, D = q.shape
+    gq = nh // k.shape[1]
+    out = np.zeros((ns, nq, nh, D))
+    qh = q.astype(np.float16).astype(np.float64)
+    for s in range(ns):
+        for h in range(nh):
+            kk = k[s, h // gq].astype(np.float64); vv = v[s, h // gq].astype(np.float64)
+            sc = qh[s, h] @ kk.T * (scale / softcap if softcap else scale)
+            if softcap:
+                sc = softcap * np.tanh(sc)
+            if mask is not None:
+                sc = sc + mask[:nq].astype(np.float64)
+            mx = sc.max(axis=1, keepdims=True)
+            if sinks is not None:
+                mx = np.maximum(mx, sinks[h])
+            mx = np.where(np.isfinite(mx), mx, 0.0)
+            p = np.exp(sc - mx)
+            den = p.sum(axis=1, keepdims=True) + (np.exp(sinks[h] - mx) if sinks is not None else 0.0)
+            out[s, :, h, :] = (p @ vv) / np.where(den == 0, 1.0, den)
+    return out
+
+
+@pytest.mark.parametrize("D,nq,nh,nhkv,nkv,ns,kind", [
+    (128, 35, 4, 2, 113, 1, "causal"), (128, 128, 8, 2, 512, 2, "causal"), (64, 70, 4, 4, 96, 1, "none"),
+    (128, 512, 8, 2, 512, 1, "causal"), (128, 33, 4, 1, 256, 1, "padded"), (64, 32, 2, 2, 64, 3, "sinks"), (128, 40, 4, 4, 160, 1, "softcap")])
+def test_flash_attn_prefill_mfma(pkg, be, D, nq, nh, nhkv, nkv, ns, kind):
+    """batches of query rows take the matrix-core kernel (fattn_mma.hip); bar = the reference's FLASH_ATTN_EXT NMSE 5e-4"""
+    rng = np.random.default_rng(D + nq + nkv)
+    qv = rng.standard_normal((ns, nh, nq, D)).astype(np.float32)
+    kv = rng.standard_normal((ns, nhkv, nkv, D)).astype(np.float16)
+    vv = rng.standard_normal((ns, nhkv, nkv, D)).astype(np.float16)
+    nq_pad = (nq + 63) // 64 * 64
+    mask = None
+    if kind != "none":
+        mask = np.zeros((nq_pad, nkv), np.float16)
+        off = nkv - nq if kind != "padded" else nkv // 2 - nq        # "padded": the second half of the KV view is unused cells
+        for i in range(nq_pad):
+            mask[i, max(0, min(nkv, off + min(i, nq - 1) + 1)):] = -np.inf
+    sinks = rng.standard_normal(nh).astype(np.float32) if kind == "sinks" else None
+    softcap = 7.0 if kind == "softcap" else 0.0
+    c = pkg.Context(be)
+    q = c.new_tensor(pkg.GGML_TYPE_F32, D, nq, nh, ns)
+    k = c.new_tensor(pkg.GGML_TYPE_F16, D, nkv, nhkv, ns)
+    v = c.new_tensor(pkg.GGML_TYPE_F16, D, nkv, nhkv, ns)
+    feeds = [(q, qv), (k, kv), (v, vv)]
+    m = sk = None
+    if mask is not None:
+        m = c.new_tensor(pkg.GGML_TYPE_F16, nkv, nq_pad)
+        feeds.append((m, mask))
+    if sinks is not None:
+        sk = c.new_tensor(pkg.GGML_TYPE_F32, nh)
+        feeds.append((sk, sinks))
+    scale = 1.0 / np.sqrt(D)
+    y = c.flash_attn_ext(q, k, v, m, scale, 0.0, softcap, sk)
+    (got,) = run_graph(be, c, [y], feeds)
+    want = _attn_f64(qv, kv, vv, mask, scale, softcap, sinks)
+    assert np.isfinite(got).all()
+    assert nmse(got.reshape(want.shape), want) < 5e-4
+
+
 @pytest.mark.parametrize("name", ["q4_K", "q6_K", "q8_0", "f16"])
 def test_mul_mat_golden(pkg, be, golden, name):
     g = golden["ops"]
