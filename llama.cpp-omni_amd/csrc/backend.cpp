@@ -10,6 +10,7 @@
 #include "ggml_util.hpp"
 #include "kernels.hpp"
 #include "graph.hpp"
+#include "shadow.hpp"
 
 #include <mutex>
 #include <string>
@@ -66,6 +67,7 @@ struct buffer_ctx { int device; void * base; size_t size; };
 static void buf_free(ggml_backend_buffer_t b) {
     buffer_ctx * c = (buffer_ctx *) b->context;
     set_device(c->device);
+    shadow_invalidate(c->device, c->base, c->size);
     HIP_CHECK(hipFree(c->base));
     delete c;
 }
@@ -78,11 +80,13 @@ static enum ggml_status buf_init_tensor(ggml_backend_buffer_t, struct ggml_tenso
 }
 static void buf_memset_tensor(ggml_backend_buffer_t b, struct ggml_tensor * t, uint8_t v, size_t off, size_t sz) {
     buffer_ctx * c = (buffer_ctx *) b->context; set_device(c->device);
+    shadow_invalidate(c->device, (char *) t->data + off, sz);
     HIP_CHECK(hipMemsetAsync((char *) t->data + off, v, sz, hipStreamPerThread));
     HIP_CHECK(hipStreamSynchronize(hipStreamPerThread));
 }
 static void buf_set_tensor(ggml_backend_buffer_t b, struct ggml_tensor * t, const void * data, size_t off, size_t sz) {
     buffer_ctx * c = (buffer_ctx *) b->context; set_device(c->device);
+    shadow_invalidate(c->device, (char *) t->data + off, sz);
     HIP_CHECK(hipMemcpyAsync((char *) t->data + off, data, sz, hipMemcpyHostToDevice, hipStreamPerThread));
     HIP_CHECK(hipStreamSynchronize(hipStreamPerThread));
 }
@@ -98,6 +102,7 @@ static bool buf_cpy_tensor(ggml_backend_buffer_t b, const struct ggml_tensor * s
     buffer_ctx * sc = (buffer_ctx *) sb->context; buffer_ctx * dc = (buffer_ctx *) b->context;
     set_device(dc->device);
     const size_t n = nbytes(src);
+    shadow_invalidate(dc->device, dst->data, n);
     if (sc->device == dc->device) HIP_CHECK(hipMemcpyAsync(dst->data, src->data, n, hipMemcpyDeviceToDevice, hipStreamPerThread));
     else                          HIP_CHECK(hipMemcpyPeerAsync(dst->data, dc->device, src->data, sc->device, n, hipStreamPerThread));
     HIP_CHECK(hipStreamSynchronize(hipStreamPerThread));
@@ -105,6 +110,7 @@ static bool buf_cpy_tensor(ggml_backend_buffer_t b, const struct ggml_tensor * s
 }
 static void buf_clear(ggml_backend_buffer_t b, uint8_t v) {
     buffer_ctx * c = (buffer_ctx *) b->context; set_device(c->device);
+    shadow_invalidate(c->device, c->base, c->size);
     HIP_CHECK(hipMemsetAsync(c->base, v, c->size, hipStreamPerThread));
     HIP_CHECK(hipStreamSynchronize(hipStreamPerThread));
 }
@@ -166,6 +172,7 @@ static void be_free(ggml_backend_t b) {
 static bool backend_is_ours(ggml_backend_t b);
 static void be_set_async(ggml_backend_t b, struct ggml_tensor * t, const void * data, size_t off, size_t sz) {
     backend_ctx * c = (backend_ctx *) b->context; set_device(c->device);
+    shadow_invalidate(c->device, (char *) t->data + off, sz);
     HIP_CHECK(hipMemcpyAsync((char *) t->data + off, data, sz, hipMemcpyHostToDevice, c->stream));
 }
 static void be_get_async(ggml_backend_t b, const struct ggml_tensor * t, void * data, size_t off, size_t sz) {
@@ -180,6 +187,7 @@ static bool be_cpy_async(ggml_backend_t bs, ggml_backend_t bd, const struct ggml
     backend_ctx * cs = (backend_ctx *) bs->context; backend_ctx * cd = (backend_ctx *) bd->context;
     if (((buffer_ctx *) sb->context)->device != cs->device || ((buffer_ctx *) db->context)->device != cd->device) return false;
     const size_t n = nbytes(dst);
+    shadow_invalidate(cd->device, dst->data, n);
     set_device(cs->device);
     if (bs == bd) {
         HIP_CHECK(hipMemcpyAsync(dst->data, src->data, n, hipMemcpyDeviceToDevice, cs->stream));

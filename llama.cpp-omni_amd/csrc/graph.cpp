@@ -15,6 +15,7 @@
 #include "graph.hpp"
 #include "ggml_util.hpp"
 #include "kernels.hpp"
+#include "shadow.hpp"
 #include "../../include/ggml-mi355x.h"
 #include <unordered_map>
 
@@ -267,6 +268,21 @@ static const char * mmv_class(int type) {
     return type == GGML_TYPE_Q4_K ? "mmv_q4k" : type == GGML_TYPE_Q6_K ? "mmv_q6k" : type == GGML_TYPE_Q8_0 ? "mmv_q80" : type == GGML_TYPE_F16 ? "mmv_f16" : "mmv_f32";
 }
 
+// resident F16 image of a quantised weight matrix (shadow.hpp): built on first use outside of graph capture, only for tensors
+// that live in a buffer marked GGML_BACKEND_BUFFER_USAGE_WEIGHTS
+static const uint16_t * weight_shadow(exec_state & s, const ggml_tensor * w, const char * wp, int64_t K, int64_t M) {
+    const ggml_tensor * root = w;
+    while (root->view_src) root = root->view_src;
+    if (root->op != GGML_OP_NONE || !root->buffer || root->buffer->usage != GGML_BACKEND_BUFFER_USAGE_WEIGHTS) return nullptr;
+    const uint16_t * sh = shadow_find(s.c->device, wp, w->type, K, M, w->nb[1]);
+    if (sh || s.capturing) return sh;
+    uint16_t * p = shadow_create(s.c->device, wp, (size_t) (M - 1) * w->nb[1] + row_size(w->type, K), w->type, K, M, w->nb[1]);
+    if (!p) return nullptr;
+    prof_scope ps(s, "dequant_f16", (double) M * (double) row_size(w->type, K));
+    dequant_rows_f16(w->type, wp, w->nb[1], p, (size_t) K * 2, K, M, s.st); ++s.n_kernels;
+    return p;
+}
+
 static void op_mul_mat(exec_state & s, const ggml_tensor * dst) {
     const ggml_tensor * w = dst->src[0];
     const ggml_tensor * x = dst->src[1];
@@ -282,7 +298,9 @@ static void op_mul_mat(exec_state & s, const ggml_tensor * dst) {
             for (int64_t i12 = 0; i12 < ne12; ++i12) {
                 const char * wp = (const char *) w->data + (i12 / r2) * w->nb[2] + (i13 / r3) * w->nb[3];
                 const uint16_t * w16 = (const uint16_t *) wp; size_t w16_rs = w->nb[1];
-                if (w->type != GGML_TYPE_F16) {
+                const uint16_t * sh = w->type != GGML_TYPE_F16 ? weight_shadow(s, w, wp, K, M) : nullptr;
+                if (sh) { w16 = sh; w16_rs = (size_t) K * 2; }
+                else if (w->type != GGML_TYPE_F16) {
                     if (wp != last_w) {
                         prof_scope ps(s, "dequant_f16", (double) M * (double) row_size(w->type, K));
                         dequant_rows_f16(w->type, wp, w->nb[1], (uint16_t *) s.c->w_scratch, (size_t) K * 2, K, M, s.st); ++s.n_kernels;
@@ -842,6 +860,10 @@ enum ggml_status graph_compute(backend_ctx * c, ggml_cgraph * g) {
         }
         ge->last_use = ++c->tick;
         ge->seen++;
+        if (ge->exec && ge->shadow_gen != shadow_generation()) {    // a weight image baked into this capture was dropped
+            HIP_CHECK(hipGraphExecDestroy(ge->exec)); HIP_CHECK(hipGraphDestroy(ge->graph));
+            ge->exec = nullptr; ge->graph = nullptr; ge->seen = 1;  // run eagerly once (rebuilds the images), capture next time
+        }
         if (ge->exec) {
             HIP_CHECK(hipGraphLaunch(ge->exec, c->stream));
             c->stat_replays++; c->stat_kernels_last = ge->n_kernels;
@@ -859,7 +881,7 @@ enum ggml_status graph_compute(backend_ctx * c, ggml_cgraph * g) {
                 hipGraphExec_t ex = nullptr;
                 e = hipGraphInstantiate(&ex, graph, nullptr, nullptr, 0);
                 if (e == hipSuccess) {
-                    ge->graph = graph; ge->exec = ex; ge->n_kernels = (int) s.n_kernels;
+                    ge->graph = graph; ge->exec = ex; ge->n_kernels = (int) s.n_kernels; ge->shadow_gen = shadow_generation();
                     HIP_CHECK(hipGraphLaunch(ex, c->stream));
                     c->stat_captures++; c->stat_kernels_last = s.n_kernels;
                     return GGML_STATUS_SUCCESS;
@@ -903,6 +925,7 @@ int mi355x_set_option(struct ggml_backend * backend, const char * key, long valu
     if (!strcmp(key, "graphs"))  { c->opt_graphs = value != 0; return 0; }
     if (!strcmp(key, "fusion"))  { c->opt_fusion = value != 0; c->execs.clear(); return 0; }
     if (!strcmp(key, "profile")) { c->opt_profile = value != 0; return 0; }
+    if (!strcmp(key, "f16_shadow")) { mi::shadow_set_enabled(value != 0); c->execs.clear(); return 0; }
     if (!strcmp(key, "reset_stats")) { c->prof.clear(); c->stat_replays = c->stat_captures = c->stat_eager = 0; return 0; }
     return -1;
 }
@@ -912,6 +935,7 @@ double mi355x_get_stat(struct ggml_backend * backend, const char * key) {
     if (!strcmp(key, "graph_captures"))     return (double) c->stat_captures;
     if (!strcmp(key, "eager_graphs"))       return (double) c->stat_eager;
     if (!strcmp(key, "kernels_last_graph")) return (double) c->stat_kernels_last;
+    if (!strncmp(key, "shadow_", 7))        return mi::shadow_stat(key);
     if (!strncmp(key, "prof_", 5)) {
         std::string k(key + 5);
         const size_t us = k.rfind("_us"), nn = k.rfind("_n"), by = k.rfind("_bytes");

@@ -18,6 +18,7 @@ struct graph_exec {                    // one captured cgraph
     hipGraphExec_t  exec = nullptr;
     int             n_kernels = 0;
     uint64_t        last_use = 0;
+    uint64_t        shadow_gen = 0;    // shadow_generation() at capture time
 };
 
 struct backend_ctx {

@@ -117,6 +117,94 @@ __global__ void __launch_bounds__(256) k_gemm_f16(const char * __restrict__ W, s
         }
 }
 
+// ---- K % 64 == 0: direct global -> LDS staging (global_load_lds_dwordx4), BK = 64, one barrier per K-step.
+// An LDS-DMA instruction writes lane l's 16 bytes at (wave-uniform base) + 16*l, so a wave fills 8 consecutive unpadded 128-byte
+// rows per instruction; bank conflicts are avoided on the SOURCE side instead of by padding: LDS chunk c of row r holds global
+// chunk c ^ ((r >> 1) & 7), and the fragment reads apply the same XOR (a ds_read_b128 is served in groups of 16 lanes over 64 banks:
+// two 128-byte rows, so the row's parity picks the bank half and (r >> 1) & 7 spreads the 8 chunk slots -- conflict-free).  Tile t+1's DMA is issued right after the barrier that publishes
+// tile t, so it runs under tile t's 16 MFMAs per wave.
+typedef __attribute__((address_space(3))) void * lds_ptr_t;
+typedef const __attribute__((address_space(1))) void * gbl_ptr_t;
+constexpr int H_BK = 64, H_ROWB = H_BK * 2, H_TILEB = 128 * H_ROWB;          // 16 KB per operand tile
+
+__global__ void __launch_bounds__(256) k_gemm_f16_glds(const char * __restrict__ W, size_t w_rs, const char * __restrict__ X, size_t x_rs,
+                                                       char * __restrict__ dst, size_t dst_cs, int M, int N, int K, int tiles_m, int tiles_n) {
+    __shared__ __attribute__((aligned(16))) char lds[2][2][H_TILEB];          // [buffer][W | X]
+
+    const int nt  = tiles_m * tiles_n;
+    const int bid = blockIdx.x;
+    const int q = nt / 8, r = nt % 8, xcd = bid % 8, idx = bid / 8;
+    const int tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    const int tm = tile / tiles_n, tn = tile % tiles_n;
+    const int m0 = tm * G_BM, n0 = tn * G_BN;
+
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wm = wave & 1, wn = wave >> 1;
+
+    // staging: wave w fills rows [32w, 32w+32) of both operand tiles, 8 rows per instruction
+    const int r8 = lane >> 3;
+    const char * wp[4]; const char * xp[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int gc = (lane & 7) ^ (((j * 8 + r8) >> 1) & 7);       // source chunk that lands in LDS chunk (lane & 7) of row 32w+8j+r8
+        int mr = m0 + wave * 32 + j * 8 + r8; mr = mr < M ? mr : M - 1;
+        int nr = n0 + wave * 32 + j * 8 + r8; nr = nr < N ? nr : N - 1;
+        wp[j] = W + (size_t) mr * w_rs + gc * 16;
+        xp[j] = X + (size_t) nr * x_rs + gc * 16;
+    }
+    auto stage = [&](int buf, int ks) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            __builtin_amdgcn_global_load_lds((gbl_ptr_t) (wp[j] + (size_t) ks * H_ROWB), (lds_ptr_t) (&lds[buf][0][(wave * 32 + j * 8) * H_ROWB]), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gbl_ptr_t) (xp[j] + (size_t) ks * H_ROWB), (lds_ptr_t) (&lds[buf][1][(wave * 32 + j * 8) * H_ROWB]), 16, 0, 0);
+        }
+    };
+
+    f16v acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.0f;
+
+    const int nk = K / H_BK;
+    const int fr = lane & 31, hb = lane >> 5, sw = (fr >> 1) & 7;
+    stage(0, 0);
+    for (int ks = 0; ks < nk; ++ks) {
+        const int cur = ks & 1;
+        __syncthreads();                                   // tile ks has landed (the fence drains the DMA), buffer cur^1 is free
+        if (ks + 1 < nk) stage(cur ^ 1, ks + 1);
+        const char * wb = &lds[cur][0][0]; const char * xb = &lds[cur][1][0];
+#pragma unroll
+        for (int kk = 0; kk < H_BK / 16; ++kk) {
+            const int co = ((kk * 2 + hb) ^ sw) << 4;
+            h8 af[2], bf[2];
+#pragma unroll
+            for (int a = 0; a < 2; ++a) af[a] = *(const h8 *) (xb + (wn * 64 + a * 32 + fr) * H_ROWB + co);
+#pragma unroll
+            for (int b = 0; b < 2; ++b) bf[b] = *(const h8 *) (wb + (wm * 64 + b * 32 + fr) * H_ROWB + co);
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[a], bf[b], acc[a][b], 0, 0, 0);
+        }
+    }
+
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int m = m0 + wm * 64 + b * 32 + (lane & 31);
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int n = n0 + wn * 64 + a * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+                if (m < M && n < N) *(float *) (dst + (size_t) n * dst_cs + (size_t) m * 4) = acc[a][b][e];
+            }
+        }
+}
+
 bool gemm_f16_ok(const void * W, size_t w_rs, const void * X, size_t x_rs, int64_t K) {
     return K % G_BK == 0 && K >= G_BK && w_rs % 16 == 0 && x_rs % 16 == 0 && ((uintptr_t) W & 15) == 0 && ((uintptr_t) X & 15) == 0;
 }
@@ -125,8 +213,12 @@ void gemm_f16_mfma(const uint16_t * W, size_t w_rs, const uint16_t * X, size_t x
                    int64_t M, int64_t N, int64_t K, hipStream_t st) {
     if (M == 0 || N == 0) return;
     const int tiles_m = (int) ((M + G_BM - 1) / G_BM), tiles_n = (int) ((N + G_BN - 1) / G_BN);
-    k_gemm_f16<<<dim3((unsigned) (tiles_m * tiles_n)), dim3(256), 0, st>>>((const char *) W, w_rs, (const char *) X, x_rs, (char *) dst, dst_cs,
-                                                                          (int) M, (int) N, (int) K, tiles_m, tiles_n);
+    if (K % H_BK == 0)
+        k_gemm_f16_glds<<<dim3((unsigned) (tiles_m * tiles_n)), dim3(256), 0, st>>>((const char *) W, w_rs, (const char *) X, x_rs, (char *) dst, dst_cs,
+                                                                                   (int) M, (int) N, (int) K, tiles_m, tiles_n);
+    else
+        k_gemm_f16<<<dim3((unsigned) (tiles_m * tiles_n)), dim3(256), 0, st>>>((const char *) W, w_rs, (const char *) X, x_rs, (char *) dst, dst_cs,
+                                                                              (int) M, (int) N, (int) K, tiles_m, tiles_n);
 }
 
 } // namespace mi

@@ -1,0 +1,26 @@
+// shadow.hpp -- resident F16 images of quantised WEIGHT tensors for the prefill GEMM.
+//
+// MI355X has 288 GB of HBM per GPU: a Q4_K_M Qwen3-8B is 4.7 GB and its F16 image 15 GB, so both stay resident.  Decode
+// (bandwidth-bound) streams the quantised blocks; prefill (compute-bound) feeds the matrix cores from the F16 image instead of
+// de-quantising every weight on every ubatch (what the reference does per call: ggml-cuda.cu:1250-1268, to_fp16_cuda into a pool
+// buffer).  An image is built the first time a weight is used by a GEMM, only for tensors whose buffer carries
+// GGML_BACKEND_BUFFER_USAGE_WEIGHTS (what libllama sets on model buffers, src/llama-model.cpp), and is dropped when the
+// tensor's bytes are rewritten through the buffer interface (set_tensor / memset / cpy / clear / free).
+#pragma once
+#include "common.hpp"
+
+namespace mi {
+
+// the image of rows [M x K] at `src` (row stride src_rs), or null when none exists
+const uint16_t * shadow_find(int device, const void * src, int type, int64_t K, int64_t M, size_t src_rs);
+// allocate an (uninitialised) image and register it; null when shadows are disabled or memory is short.  The caller fills it.
+uint16_t *       shadow_create(int device, const void * src, size_t src_bytes, int type, int64_t K, int64_t M, size_t src_rs);
+// bytes [p, p+n) of device memory are about to change: drop the overlapping images
+void             shadow_invalidate(int device, const void * p, size_t n);
+// bumped whenever an image is dropped: captured hipGraphs that baked an image pointer in are stale after that
+uint64_t         shadow_generation();
+void             shadow_set_enabled(bool on);
+bool             shadow_enabled();
+double           shadow_stat(const char * name);      // "shadow_bytes", "shadow_tensors"
+
+} // namespace mi

@@ -12,7 +12,7 @@ import numpy as np
 __all__ = [
     "lib_path", "load_library", "Backend", "backend", "Context", "Tensor",
     "GGML_TYPE_F32", "GGML_TYPE_F16", "GGML_TYPE_Q8_0", "GGML_TYPE_Q4_K", "GGML_TYPE_Q6_K", "GGML_TYPE_I32", "GGML_TYPE_I64",
-    "GGML_ROPE_TYPE_NORMAL", "GGML_ROPE_TYPE_NEOX", "type_traits", "row_size", "OP", "GLU", "UNARY", "ggml_tensor", "ggml_cgraph",
+    "GGML_BACKEND_BUFFER_USAGE_ANY", "GGML_BACKEND_BUFFER_USAGE_WEIGHTS", "GGML_BACKEND_BUFFER_USAGE_COMPUTE", "GGML_ROPE_TYPE_NORMAL", "GGML_ROPE_TYPE_NEOX", "type_traits", "row_size", "OP", "GLU", "UNARY", "ggml_tensor", "ggml_cgraph",
 ]
 
 # ------------------------------------------------------------------------------------------------ constants
@@ -21,6 +21,7 @@ GGML_TYPE_Q4_K, GGML_TYPE_Q6_K, GGML_TYPE_Q8_K = 12, 14, 15
 GGML_TYPE_I32, GGML_TYPE_I64 = 26, 27
 GGML_ROPE_TYPE_NORMAL, GGML_ROPE_TYPE_NEOX = 0, 2
 GGML_PREC_F32 = 10
+GGML_BACKEND_BUFFER_USAGE_ANY, GGML_BACKEND_BUFFER_USAGE_WEIGHTS, GGML_BACKEND_BUFFER_USAGE_COMPUTE = 0, 1, 2   # ggml-backend.h:49-53
 
 
 class OP:
@@ -554,7 +555,9 @@ class Context:
         return T
 
     # ---- allocation: every non-view tensor gets its own aligned slot in one device buffer
-    def alloc(self):
+    def alloc(self, usage=GGML_BACKEND_BUFFER_USAGE_ANY):
+        """usage: ggml_backend_buffer_set_usage() of the reference (ggml-backend.cpp:178-186); libllama marks its model buffers
+        GGML_BACKEND_BUFFER_USAGE_WEIGHTS (src/llama-model.cpp), which is what lets the backend keep F16 images of them"""
         al = self.be.alignment
         off = 0
         slots = []
@@ -566,6 +569,7 @@ class Context:
             off += max(T.nbytes(), 1)
         self.buffer = self.be.alloc_buffer(max(off, 1))
         buf = C.cast(self.buffer, C.POINTER(buffer_t)).contents
+        buf.usage = usage
         base = buf.iface.get_base(self.buffer)
         for T, o in slots:
             T.t.buffer = self.buffer

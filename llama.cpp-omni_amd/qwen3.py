@@ -10,7 +10,7 @@ import math
 
 import numpy as np
 
-from .ggml import (GGML_ROPE_TYPE_NEOX, GGML_TYPE_F16, GGML_TYPE_F32, GGML_TYPE_I32, GGML_TYPE_I64, GGML_TYPE_Q4_K, GGML_TYPE_Q6_K,
+from .ggml import (GGML_BACKEND_BUFFER_USAGE_WEIGHTS, GGML_ROPE_TYPE_NEOX, GGML_TYPE_F16, GGML_TYPE_F32, GGML_TYPE_I32, GGML_TYPE_I64, GGML_TYPE_Q4_K, GGML_TYPE_Q6_K,
                    GGML_TYPE_Q8_0, Context, row_size)
 
 QWEN3_8B = dict(n_embd=4096, n_layer=36, n_head=32, n_head_kv=8, head_dim=128, n_ff=12288, n_vocab=151936,
@@ -109,7 +109,7 @@ class Model:
             self.layers.append(L)
         self.output_norm = w.new_tensor(GGML_TYPE_F32, E)
         self.output = w.new_tensor(types["output"], E, V)
-        w.alloc()
+        w.alloc(usage=GGML_BACKEND_BUFFER_USAGE_WEIGHTS)
         self.host = {} if host_copy else None
         rng = np.random.default_rng(seed)
         cache = {}

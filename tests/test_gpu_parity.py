@@ -270,6 +270,45 @@ def test_mul_mat_gemm_path_vs_oracle(pkg, be, name, M, K, N):
     assert err < (1e-9 if name == "f16" else 5e-4), (name, M, K, N, err)
 
 
+@pytest.mark.parametrize("name", ["q4_K", "q6_K", "q8_0"])
+def test_resident_f16_weight_image(pkg, be, name):
+    """Quantised tensors in a WEIGHTS buffer get a resident F16 image on their first GEMM (shadow.hpp); rewriting the tensor
+    through the buffer interface drops the image, so the next run sees the new weights -- also through hipGraph replays."""
+    from llama_cpp_omni_amd import qwen3
+    rng = np.random.default_rng(99)
+    ty, M, K, N = TYPES[name], 192, 1024, 64
+    w1 = qwen3.random_blocks(rng, ty, M, K, std=0.05)
+    w2 = qwen3.random_blocks(rng, ty, M, K, std=0.05)
+    xv = rng.standard_normal((N, K)).astype(np.float32)
+    wctx = pkg.Context(be)
+    w = wctx.new_tensor(ty, K, M)
+    wctx.alloc(usage=pkg.GGML_BACKEND_BUFFER_USAGE_WEIGHTS)
+    c = pkg.Context(be)
+    wl = c._new(w.type, w.ne, view_src=w, view_offs=0)
+    for i in range(4):
+        wl.t.nb[i] = w.t.nb[i]
+    x = c.new_tensor(pkg.GGML_TYPE_F32, K, N)
+    # a chain long enough (>= 8 real nodes) to be captured into a hipGraph on its second submission
+    y = c.mul_mat(wl, x)
+    z = y
+    for _ in range(8):
+        z = c.scale(z, 1.0)
+    c.alloc()
+    gr = c.graph()
+    be.tensor_set(x, xv)
+    n0 = be.get_stat("shadow_tensors")
+    for wv in (w1, w2):
+        be.tensor_set(w, wv)
+        want = orc.mul_mat(ty, wv.view(np.uint8).reshape(M, -1), xv)
+        for rep in range(3):                                       # eager, capture, replay
+            be.graph_compute(gr)
+            assert nmse(be.tensor_get(z), want) < 5e-4, (name, rep)
+        assert be.get_stat("shadow_tensors") == n0 + 1
+    c.free()
+    wctx.free()
+    assert be.get_stat("shadow_tensors") == n0                     # freeing the weight buffer drops its images
+
+
 def test_mul_mat_zero_and_empty(pkg, be):
     """all-zero activations (Q8_K amax == 0 branch) and a zero-column batch"""
     from llama_cpp_omni_amd import qwen3
