@@ -63,6 +63,8 @@ struct exec_state {
     // activation cache
     const void *  a_src = nullptr; act_kind a_kind = ACT_NONE; int64_t a_K = 0, a_ne[3] = {0, 0, 0}; size_t a_nb[3] = {0, 0, 0};
     bool          capturing = false;
+    // mask whose tile map currently sits in fa_scratch
+    const void *  fa_mask = nullptr; int64_t fa_dims[4] = {0, 0, 0, 0}; size_t fa_mnb1 = 0;
 };
 
 // ------------------------------------------------------------------------------------------------ profiling
@@ -215,6 +217,25 @@ static size_t graph_w_scratch_need(const ggml_cgraph * g) {
         const ggml_tensor * n = g->nodes[i];
         if (n->op != GGML_OP_MUL_MAT || is_empty(n) || !mm_uses_gemm(n) || n->src[0]->type == GGML_TYPE_F16) continue;
         const size_t b = (size_t) n->src[0]->ne[0] * (size_t) n->src[0]->ne[1] * 2;
+        if (b > need) need = b;
+    }
+    return need;
+}
+static void fill_fattn_args(const ggml_tensor * n, fattn_args & f, tdesc & m) {
+    f.q = td(n->src[0]); f.k = td(n->src[1]); f.v = td(n->src[2]); f.dst = td(n);
+    if (n->src[3]) m = td(n->src[3]);
+    f.mask = n->src[3] ? &m : nullptr;
+    f.sinks = n->src[4] ? (const float *) n->src[4]->data : nullptr;
+    f.scale = op_param_f32(n, 0); f.max_bias = op_param_f32(n, 1); f.logit_softcap = op_param_f32(n, 2);
+    f.scratch = nullptr; f.scratch_bytes = 0;
+}
+static size_t graph_fa_scratch_need(const ggml_cgraph * g) {
+    size_t need = 0;
+    for (int i = 0; i < g->n_nodes; ++i) {
+        const ggml_tensor * n = g->nodes[i];
+        if (n->op != GGML_OP_FLASH_ATTN_EXT || is_empty(n)) continue;
+        fattn_args f; tdesc m; fill_fattn_args(n, f, m);
+        const size_t b = fattn_scratch_bytes(f);
         if (b > need) need = b;
     }
     return need;
@@ -415,6 +436,7 @@ static bool can_hoist(exec_state & s, int i, int j, const int * item, int n_item
     return true;
 }
 static void note_write(exec_state & s, const ggml_tensor * t) {          // a kernel wrote t: drop the activation cache if it aliased
+    if (s.fa_mask) { const char * p = (const char *) t->data; if ((const char *) s.fa_mask >= p && (const char *) s.fa_mask < p + nbytes(t)) s.fa_mask = nullptr; }
     if (!s.a_src) return;
     const byte_range r = range_of(t);
     if (r.lo < s.a_range_hi && s.a_range_lo < r.hi) s.a_src = nullptr;
@@ -743,13 +765,8 @@ static void compute_node(exec_state & s, int i) {
             break;
         }
         case GGML_OP_FLASH_ATTN_EXT: {
-            fattn_args f;
-            f.q = td(n->src[0]); f.k = td(n->src[1]); f.v = td(n->src[2]); f.dst = td(n);
-            tdesc m; if (n->src[3]) m = td(n->src[3]);
-            f.mask = n->src[3] ? &m : nullptr;
-            f.sinks = n->src[4] ? (const float *) n->src[4]->data : nullptr;
-            f.scale = op_param_f32(n, 0); f.max_bias = op_param_f32(n, 1); f.logit_softcap = op_param_f32(n, 2);
-            f.scratch = nullptr; f.scratch_bytes = 0;
+            fattn_args f; tdesc m;
+            fill_fattn_args(n, f, m);
             // epilogue fusion: when the attention output only feeds K-quant mat-vecs (wo), emit its Q8_K image here
             const ggml_tensor * xuse = nullptr;
             if (s.c->opt_fusion && n->ne[3] == 1 && n->ne[2] <= MI_MMVQ_MAX_COLS && n_users(s, n) > 0 && !(n->flags & GGML_TENSOR_FLAG_OUTPUT) &&
@@ -765,6 +782,17 @@ static void compute_node(exec_state & s, int i) {
                 if (!ok) xuse = nullptr;
             }
             if (xuse) f.img = s.c->act_scratch;
+            if (fattn_scratch_bytes(f) > 0) {
+                // the mask tile map is computed once per mask tensor and graph run (every layer shares the mask)
+                const ggml_tensor * mk = n->src[3];
+                f.scratch = s.c->fa_scratch; f.scratch_bytes = s.c->fa_scratch_bytes;
+                f.map_valid = s.fa_mask == mk->data && s.fa_dims[0] == mk->ne[0] && s.fa_dims[1] == n->src[0]->ne[1] && s.fa_dims[2] == mk->ne[2] &&
+                              s.fa_dims[3] == mk->ne[3] && s.fa_mnb1 == mk->nb[1];
+                if (!f.map_valid) {
+                    s.fa_mask = mk->data; s.fa_dims[0] = mk->ne[0]; s.fa_dims[1] = n->src[0]->ne[1]; s.fa_dims[2] = mk->ne[2]; s.fa_dims[3] = mk->ne[3];
+                    s.fa_mnb1 = mk->nb[1]; ++s.n_kernels;
+                }
+            }
             {
                 prof_scope ps(s, "fattn", 0);
                 flash_attn_ext_f16(f, s.st); ++s.n_kernels;
@@ -837,6 +865,7 @@ enum ggml_status graph_compute(backend_ctx * c, ggml_cgraph * g) {
     if (g->n_nodes == 0) return GGML_STATUS_SUCCESS;
     ensure_scratch(c, &c->act_scratch, &c->act_scratch_bytes, graph_act_scratch_need(g));
     ensure_scratch(c, &c->w_scratch, &c->w_scratch_bytes, graph_w_scratch_need(g));
+    ensure_scratch(c, &c->fa_scratch, &c->fa_scratch_bytes, graph_fa_scratch_need(g));
 
     int n_real = 0;
     for (int i = 0; i < g->n_nodes; ++i) n_real += !is_noop(g->nodes[i]);
@@ -913,6 +942,7 @@ void backend_ctx_release(backend_ctx * c) {
     for (auto ev : c->prof_event_pool) (void) hipEventDestroy(ev);
     if (c->act_scratch) (void) hipFree(c->act_scratch);
     if (c->w_scratch) (void) hipFree(c->w_scratch);
+    if (c->fa_scratch) (void) hipFree(c->fa_scratch);
     if (c->copy_event) (void) hipEventDestroy(c->copy_event);
     if (c->stream) (void) hipStreamDestroy(c->stream);
 }

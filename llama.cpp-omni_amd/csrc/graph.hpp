@@ -31,6 +31,8 @@ struct backend_ctx {
     void *  act_scratch = nullptr;  size_t act_scratch_bytes = 0;
     // scratch for de-quantised weight tiles / f16 copies on the GEMM path
     void *  w_scratch = nullptr;    size_t w_scratch_bytes = 0;
+    // mask tile map of the prefill flash-attention kernel
+    void *  fa_scratch = nullptr;   size_t fa_scratch_bytes = 0;
 
     // options
     bool opt_graphs = true;

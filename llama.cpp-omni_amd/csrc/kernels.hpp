@@ -94,8 +94,9 @@ struct fattn_args {
     const tdesc * mask;      // may be null
     const float * sinks;     // may be null
     float scale, max_bias, logit_softcap;
-    void * scratch;          // split-KV partials
+    void * scratch;          // mask tile map of the prefill kernel (fattn_scratch_bytes(); unused by the decode kernel)
     size_t scratch_bytes;
+    bool   map_valid = false; // scratch already holds the tile map of THIS mask (same tensor used by an earlier node of the graph)
     void * img = nullptr;    // optional: also emit Q8_K images of the output rows [nh*D] (one per (seq, query row))
 };
 size_t fattn_scratch_bytes(const fattn_args & a);

@@ -242,7 +242,14 @@ __global__ void __launch_bounds__(64 * NW) k_fattn_dec(const fa_dev a) {
 template <int D, int R, int NW>
 static size_t fa_lds_bytes() { return (size_t) R * D * 4 + NW * 16 * R * 4 + NW * R * (D + 2) * 4; }
 
-size_t fattn_scratch_bytes(const fattn_args &) { return 0; }
+static bool fa_use_mma(const fattn_args & f) {
+    return f.q.ne[1] > 8 && !f.img && (f.q.ne[0] == 64 || f.q.ne[0] == 128) && fattn_mma_ok(f.k.ne[1]);
+}
+size_t fattn_map_bytes(int64_t nq, int64_t nkv, int64_t mne2, int64_t mne3);
+size_t fattn_scratch_bytes(const fattn_args & f) {
+    if (!fa_use_mma(f) || !f.mask) return 0;
+    return fattn_map_bytes(f.q.ne[1], f.k.ne[1], f.mask->ne[2], f.mask->ne[3]);
+}
 
 // choose R (query vectors per workgroup): cover the GQA group first, then extra query rows
 static void fa_split(const fa_dev & a, int & R, int & hpw, int & qpw) {
@@ -302,7 +309,16 @@ void flash_attn_ext_f16(const fattn_args & f, hipStream_t st) {
     a.hpw = a.qpw = 1;
     a.img = (char *) f.img; a.img_bytes = f.img ? q8k_image_bytes(a.nh * f.q.ne[0]) : 0;
     // batches of query rows go to the matrix-core kernel (fattn_mma.hip); single / few rows stay on the streaming decode kernel
-    if (a.nq > 8 && !a.img && (f.q.ne[0] == 64 || f.q.ne[0] == 128)) { flash_attn_ext_mma(a, (int) f.q.ne[0], st); return; }
+    if (fa_use_mma(f)) {
+        a.tile_map = nullptr; a.map_nqb = (a.nq + 31) / 32;
+        if (f.mask) {
+            if (!f.scratch || f.scratch_bytes < fattn_scratch_bytes(f)) { fprintf(stderr, "[mi355x] flash_attn: mask tile map scratch missing\n"); abort(); }
+            if (!f.map_valid) fattn_mask_map(a, (uint8_t *) f.scratch, st);
+            a.tile_map = (const uint8_t *) f.scratch;
+        }
+        flash_attn_ext_mma(a, (int) f.q.ne[0], st);
+        return;
+    }
     switch ((int) f.q.ne[0]) {
         case 64:  launch_fa<64>(a, st); break;
         case 128: launch_fa<128>(a, st); break;

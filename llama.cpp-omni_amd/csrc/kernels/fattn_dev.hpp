@@ -14,10 +14,13 @@ struct fa_dev {
     int gq;                                             // n_head / n_head_kv
     int hpw;                                            // heads handled per workgroup (<= R)
     int qpw;                                            // query rows per workgroup (R / hpw)
+    const uint8_t * tile_map; int map_nqb;              // mask tile classes [mne3][mne2][map_nqb][ntile] (prefill kernel), or null = no mask
     char * img; size_t img_bytes;                       // optional Q8_K image output (one image per (seq, query row)), else null
 };
 
 // prefill kernel (fattn_mma.hip): MFMA tiles, 32 query rows per wave
 void flash_attn_ext_mma(const fa_dev & a, int D, hipStream_t st);
+void fattn_mask_map(const fa_dev & a, uint8_t * map, hipStream_t st);     // classify the mask's 32 x 32 tiles
+bool fattn_mma_ok(int64_t nkv);
 
 } // namespace mi

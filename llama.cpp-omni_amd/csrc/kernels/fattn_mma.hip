@@ -4,7 +4,7 @@
 // [softcap] + slope * mask, online softmax, V weighted sum, / S, sinks, output permuted to [DV, n_head, n_q, n_seq]); what the
 // reference's GPU backend does for the same node is fattn-mma-f16.cuh -- this kernel shares the maths, not the tiling.
 // Accuracy bar: the reference's own NMSE 5e-4 for this op (tests/test-backend-ops.cpp:5085): P is rounded to f16 for the second
-// matrix product and exp is the hardware v_exp_f32 -- both far inside that bar (measured ~1e-7).
+// matrix product and the exponentials are v_exp_f32 in the base-2 domain -- both far inside that bar (measured ~1e-7).
 //
 // Tiling: a wave owns 32 query rows of one head; a workgroup is NW waves on consecutive 32-row blocks of the same head, so one
 // staged K / V tile (32 KV rows) feeds NW*32 queries.  Everything is computed TRANSPOSED so that a lane owns one query column:
@@ -16,29 +16,43 @@
 // only a label, so K-slot (lane/32, e) of MFMA step s is declared to be kv = (e&3) + 4*(lane/32) + 8*(e>>2) + 16*s -- exactly
 // the kv a lane already holds in registers 8s..8s+7 -- and the V^T fragment is gathered to match (two 8-byte LDS reads per step).
 // V is transposed while it is staged (pairs of KV rows packed into one 32-bit LDS word).
-// KV tiles whose mask is -inf for every query of the workgroup are skipped before any K/V traffic (causal prefill touches half
-// of the tiles; a cache view padded past the used cells costs nothing).
+//
+// Mask tile map: the mask is shared by every head (and every layer of a graph), so a tiny pre-pass (k_fattn_mask_map) classifies
+// each 32 x 32 mask tile once -- 0: -inf everywhere, 1: zero everywhere, 2: mixed -- and the attention kernel never touches the
+// mask itself except on mixed (diagonal) tiles.  Dead tiles are skipped without K/V traffic or barriers (causal prefill touches
+// half of the tiles; a cache view padded past the used cells costs nothing), all-zero tiles skip the mask arithmetic.
+// Pipeline (one barrier per live KV tile): the next live tile's K/V rows are fetched into registers BEFORE the current tile's
+// matrix work and written to the other LDS buffer after it.
 #include "fattn_dev.hpp"
 
 namespace mi {
 
 typedef _Float16 h8v  __attribute__((ext_vector_type(8)));
+typedef _Float16 h2v  __attribute__((ext_vector_type(2)));
 typedef float    f16a __attribute__((ext_vector_type(16)));
+typedef float    f32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int FM_KT = 32;                       // KV rows per tile
+constexpr int FM_MAXT = 4096;                   // live-tile bitmap capacity: nkv <= 131072
+constexpr float FM_LOG2E = 1.4426950408889634f;
 
 template <int D> struct fm_cfg {
     static constexpr int KLD = D + 8;           // K tile row pitch in halfs (16-byte aligned rows, conflict-free b128 reads)
     static constexpr int VLD = FM_KT + 2;       // V^T row pitch in halfs (17 words: odd, spreads the transposing writes)
+    static constexpr int KB  = FM_KT * KLD * 2; // bytes of one K buffer
+    static constexpr int VB  = D * VLD * 2;     // bytes of one V^T buffer
 };
 
 template <int D, int NW>
-__global__ void __launch_bounds__(64 * NW) k_fattn_mma(const fa_dev a, const int nqt) {
+__global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2))) k_fattn_mma(const fa_dev a, const int nqt) {
     constexpr int KLD = fm_cfg<D>::KLD, VLD = fm_cfg<D>::VLD;
     constexpr int NKS = D / 16;                 // MFMA k-steps of the score product
     constexpr int NDB = D / 32;                 // 32-row blocks of O^T
-    __shared__ __attribute__((aligned(16))) _Float16 Ks[FM_KT * KLD];
-    __shared__ __attribute__((aligned(16))) uint32_t Vt[D * VLD / 2];
+    constexpr int NT  = 64 * NW;
+    constexpr int KCH = (FM_KT * (D / 8) + NT - 1) / NT;            // 16-byte K chunks per thread per tile
+    constexpr int VIT = ((FM_KT / 2) * (D / 8) + NT - 1) / NT;      // V row-pair items per thread per tile
+    __shared__ __attribute__((aligned(16))) _Float16 Ks[2][FM_KT * KLD];
+    __shared__ __attribute__((aligned(16))) uint32_t Vt[2][D * VLD / 2];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lq = lane & 31, hb = lane >> 5;
@@ -49,7 +63,7 @@ __global__ void __launch_bounds__(64 * NW) k_fattn_mma(const fa_dev a, const int
     const int q0  = (qt * NW + wave) * 32;                // this wave's first query row
     const int q   = q0 + lq;
     const int qc  = q < a.nq ? q : a.nq - 1;
-    const bool wave_has_rows = q0 < a.nq;
+    const bool row_ok = q < a.nq;
 
     // ---- Q fragments: 8 consecutive d of row q per k-step, f32 -> f16 (q_to_vec_dot, ops.cpp:8040)
     h8v qf[NKS];
@@ -65,6 +79,8 @@ __global__ void __launch_bounds__(64 * NW) k_fattn_mma(const fa_dev a, const int
     }
     const uint32_t hu = (uint32_t) h;
     const float slope = a.max_bias > 0.0f ? (hu < a.n_head_log2 ? powf(a.m0, (float) (hu + 1)) : powf(a.m1, (float) (2 * (hu - a.n_head_log2) + 1))) : 1.0f;
+    const float slope2 = slope * FM_LOG2E;
+    const float c2 = a.logit_softcap != 0.0f ? a.scale : a.scale * FM_LOG2E;    // scores live in the base-2 domain (softcap: after tanh)
     const uint16_t * mrow = a.mask ? (const uint16_t *) (a.mask + qc * a.mnb1 + (h % (int) a.mne2) * a.mnb2 + (is3 % (int) a.mne3) * a.mnb3) : nullptr;
     const bool mask_vec = a.mask && (a.mnb1 % 8 == 0) && (((uintptr_t) mrow) % 8 == 0);
 
@@ -73,124 +89,190 @@ __global__ void __launch_bounds__(64 * NW) k_fattn_mma(const fa_dev a, const int
     for (int db = 0; db < NDB; ++db)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc_o[db][e] = 0.0f;
-    float M = -INFINITY, S = 0.0f;
+    float M = -INFINITY, S = 0.0f;                        // running max (base-2 domain) and this lane's partial sum
 
     const char * kbase = a.k + ikv * a.knb2 + is3 * a.knb3;
     const char * vbase = a.v + ikv * a.vnb2 + is3 * a.vnb3;
     const int ntile = (a.nkv + FM_KT - 1) / FM_KT;
 
-    for (int t = 0; t < ntile; ++t) {
+    // ---- which tiles does any query of this workgroup see?  one bit per tile, built from the mask tile map
+    __shared__ uint64_t live_bits[FM_MAXT / 64];
+    const int qb0 = qt * NW;                                        // first 32-row query block of the workgroup
+    const uint8_t * maprow = a.tile_map ? a.tile_map + (((int64_t) (is3 % (int) a.mne3) * a.mne2 + (h % (int) a.mne2)) * a.map_nqb) * ntile : nullptr;
+    for (int c = wave; c * 64 < ntile; c += NW) {
+        const int tt = c * 64 + lane;
+        bool lv = false;
+        if (tt < ntile) {
+            if (!maprow) lv = true;
+            else
+#pragma unroll
+                for (int w = 0; w < NW; ++w) if (qb0 + w < a.map_nqb) lv |= maprow[(int64_t) (qb0 + w) * ntile + tt] != 0;
+        }
+        const uint64_t bits = __ballot(lv);
+        if (lane == 0) live_bits[c] = bits;
+    }
+    __syncthreads();
+    auto next_live = [&](int u) {                                    // smallest live tile >= u, or ntile (wave-uniform)
+        while (u < ntile) {
+            const uint64_t w = live_bits[u >> 6] >> (u & 63);
+            if (w) { u += __builtin_ctzll(w); break; }
+            u = (u | 63) + 1;
+        }
+        return __builtin_amdgcn_readfirstlane(u < ntile ? u : ntile);
+    };
+    const uint8_t * myrow = (maprow && qb0 + wave < a.map_nqb) ? maprow + (int64_t) (qb0 + wave) * ntile : nullptr;
+    auto tile_class = [&](int t) -> int {                            // this wave's 32 queries x tile t
+        if (q0 >= a.nq) return 0;
+        if (!maprow) return (t + 1) * FM_KT <= a.nkv ? 1 : 2;
+        return myrow ? (int) myrow[t] : 0;
+    };
+
+    // mask words of this lane's query for tile t: word pair g (0..3) = halfs kv0 + 4*hb + 8*g + {0..3}; cells past nkv read as -inf
+    auto load_mask = [&](int t, u32x2 (&w)[4]) {
         const int kv0 = t * FM_KT;
-        // ---- mask values of this lane's query: kv = kv0 + 4*hb + 8*g + {0..3}, g = 0..3  (register e = 4*g + i)
-        float mv[16];
-        bool live = false;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const int kvb = kv0 + 4 * hb + 8 * g;
-            if (mrow && mask_vec && kvb + 3 < a.nkv) {
-                const u32x2 w = *(const u32x2 *) (mrow + kvb);
-                mv[4 * g + 0] = h2f((uint16_t) (w[0] & 0xffff)); mv[4 * g + 1] = h2f((uint16_t) (w[0] >> 16));
-                mv[4 * g + 2] = h2f((uint16_t) (w[1] & 0xffff)); mv[4 * g + 3] = h2f((uint16_t) (w[1] >> 16));
+            if (kvb + 3 < a.nkv && (!mrow || mask_vec)) {
+                if (mrow) w[g] = *(const u32x2 *) (mrow + kvb); else { w[g][0] = 0u; w[g][1] = 0u; }
             } else {
+                uint32_t hv[4];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int kv = kvb + i;
-                    mv[4 * g + i] = kv < a.nkv ? (mrow ? h2f(mrow[kv]) : 0.0f) : -INFINITY;
+                for (int i = 0; i < 4; ++i) hv[i] = kvb + i < a.nkv ? (mrow ? (uint32_t) mrow[kvb + i] : 0u) : 0xfc00u;
+                w[g][0] = hv[0] | (hv[1] << 16); w[g][1] = hv[2] | (hv[3] << 16);
+            }
+        }
+    };
+    // K / V rows of tile t into registers (rows past nkv are zero)
+    u32x4 kreg[KCH], vreg[VIT][2];
+    auto load_kv = [&](int t) {
+        const int kv0 = t * FM_KT;
+#pragma unroll
+        for (int i = 0; i < KCH; ++i) {
+            const int c = tid + i * NT;
+            const int row = c / (D / 8), col = c % (D / 8);
+            kreg[i] = u32x4{ 0u, 0u, 0u, 0u };
+            if (c < FM_KT * (D / 8) && kv0 + row < a.nkv) kreg[i] = *(const u32x4 *) (kbase + (int64_t) (kv0 + row) * a.knb1 + col * 16);
+        }
+#pragma unroll
+        for (int i = 0; i < VIT; ++i) {
+            const int c = tid + i * NT;
+            const int o = c % (D / 8), p = c / (D / 8);
+            vreg[i][0] = vreg[i][1] = u32x4{ 0u, 0u, 0u, 0u };
+            if (c < (FM_KT / 2) * (D / 8)) {
+                if (kv0 + 2 * p     < a.nkv) vreg[i][0] = *(const u32x4 *) (vbase + (int64_t) (kv0 + 2 * p)     * a.vnb1 + o * 16);
+                if (kv0 + 2 * p + 1 < a.nkv) vreg[i][1] = *(const u32x4 *) (vbase + (int64_t) (kv0 + 2 * p + 1) * a.vnb1 + o * 16);
+            }
+        }
+    };
+    auto store_kv = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < KCH; ++i) {
+            const int c = tid + i * NT;
+            const int row = c / (D / 8), col = c % (D / 8);
+            if (c < FM_KT * (D / 8)) *(u32x4 *) &Ks[buf][row * KLD + col * 8] = kreg[i];
+        }
+#pragma unroll
+        for (int i = 0; i < VIT; ++i) {
+            const int c = tid + i * NT;
+            const int o = c % (D / 8), p = c / (D / 8);
+            if (c < (FM_KT / 2) * (D / 8)) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    Vt[buf][(8 * o + 2 * e)     * (VLD / 2) + p] = (vreg[i][0][e] & 0xffffu) | (vreg[i][1][e] << 16);
+                    Vt[buf][(8 * o + 2 * e + 1) * (VLD / 2) + p] = (vreg[i][0][e] >> 16)     | (vreg[i][1][e] & 0xffff0000u);
                 }
             }
         }
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            mv[e] = mv[e] == -INFINITY ? -INFINITY : slope * mv[e];
-            live |= mv[e] != -INFINITY;
-        }
-        live = live && q < a.nq;
-        const bool wave_live = __any(live) && wave_has_rows;
-        if (!__syncthreads_or(wave_live ? 1 : 0)) continue;      // also: every wave is done with the previous tile's LDS
+    };
 
-        // ---- stage K (row-major) and V (transposed, kv pairs packed) ; rows past nkv are zero
-        for (int c = tid; c < FM_KT * (D / 8); c += 64 * NW) {
-            const int row = c / (D / 8), col = c % (D / 8);
-            u32x4 w = { 0u, 0u, 0u, 0u };
-            if (kv0 + row < a.nkv) w = *(const u32x4 *) (kbase + (int64_t) (kv0 + row) * a.knb1 + col * 16);
-            *(u32x4 *) &Ks[row * KLD + col * 8] = w;
-        }
-        for (int c = tid; c < (FM_KT / 2) * (D / 8); c += 64 * NW) {
-            const int o = c % (D / 8), p = c / (D / 8);
-            u32x4 w0 = { 0u, 0u, 0u, 0u }, w1 = { 0u, 0u, 0u, 0u };
-            if (kv0 + 2 * p     < a.nkv) w0 = *(const u32x4 *) (vbase + (int64_t) (kv0 + 2 * p)     * a.vnb1 + o * 16);
-            if (kv0 + 2 * p + 1 < a.nkv) w1 = *(const u32x4 *) (vbase + (int64_t) (kv0 + 2 * p + 1) * a.vnb1 + o * 16);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                Vt[(8 * o + 2 * i)     * (VLD / 2) + p] = (w0[i] & 0xffffu) | (w1[i] << 16);
-                Vt[(8 * o + 2 * i + 1) * (VLD / 2) + p] = (w0[i] >> 16)     | (w1[i] & 0xffff0000u);
-            }
-        }
+    int t = next_live(0), nlive = 0;
+    if (t < ntile) load_kv(t);
+    int cls = t < ntile ? tile_class(t) : 0;
+    while (t < ntile) {
+        const int buf = nlive & 1;
+        u32x2 mw[4] = {};
+        if (cls == 2) load_mask(t, mw);                              // mixed tile: this lane's mask words (latency under the stores)
+        store_kv(buf);
+        // barrier: tile t is visible; everybody is past the previous live tile's matrix work, so the other buffer may be refilled
         __syncthreads();
-        if (!wave_live) continue;
+        const int tn = next_live(t + 1);
+        if (tn < ntile) load_kv(tn);                                 // in flight under this tile's MFMAs
+        const int cls_n = tn < ntile ? tile_class(tn) : 0;
 
-        // ---- S^T = K . Q^T
-        f16a sc;
+        if (cls != 0) {
+            // ---- S^T = K . Q^T
+            f16a sc;
 #pragma unroll
-        for (int e = 0; e < 16; ++e) sc[e] = 0.0f;
+            for (int e = 0; e < 16; ++e) sc[e] = 0.0f;
 #pragma unroll
-        for (int ks = 0; ks < NKS; ++ks) {
-            const h8v kf = *(const h8v *) &Ks[lq * KLD + ks * 16 + hb * 8];
-            sc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], sc, 0, 0, 0);
-        }
-        // ---- scale / softcap / mask, online softmax down this lane's query column
-        float tmax = -INFINITY;
+            for (int ks = 0; ks < NKS; ++ks) {
+                const h8v kf = *(const h8v *) &Ks[buf][lq * KLD + ks * 16 + hb * 8];
+                sc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], sc, 0, 0, 0);
+            }
+            // ---- scale / softcap / mask (all-zero mask tiles skip the mask arithmetic), base-2 online softmax
+            float tmax = -INFINITY;
+            if (cls == 1 && a.logit_softcap == 0.0f && slope == 1.0f) {
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            float v = sc[e] * a.scale;
-            if (a.logit_softcap != 0.0f) v = a.logit_softcap * tanhf(v);
-            v = mv[e] == -INFINITY ? -INFINITY : v + mv[e];
-            sc[e] = v;
-            tmax = fmaxf(tmax, v);
-        }
-        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-        const float Mn = fmaxf(M, tmax);
-        const float Mu = Mn == -INFINITY ? 0.0f : Mn;
-        const float alpha = __expf(M - Mu);                           // M == -inf -> 0
-        float psum = 0.0f;
-        h8v pf[2];
+                for (int e = 0; e < 16; ++e) { sc[e] *= c2; tmax = fmaxf(tmax, sc[e]); }
+            } else {
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const float p = __expf(sc[e] - Mu);                       // masked -> 0
-            psum += p;
-            pf[e >> 3][e & 7] = (_Float16) p;
-        }
-        S = S * alpha + psum;
-        M = Mn;
-        if (!__all(alpha == 1.0f)) {
+                for (int e = 0; e < 16; ++e) {
+                    const uint32_t w = mw[e >> 2][(e >> 1) & 1];
+                    const uint16_t hbits = (uint16_t) ((e & 1) ? (w >> 16) : (w & 0xffffu));
+                    float v = sc[e] * c2;
+                    if (a.logit_softcap != 0.0f) v = a.logit_softcap * FM_LOG2E * tanhf(v);
+                    v = (hbits == 0xfc00u || !row_ok) ? -INFINITY : v + slope2 * h2f(hbits);
+                    sc[e] = v;
+                    tmax = fmaxf(tmax, v);
+                }
+            }
+            tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+            const float Mn = fmaxf(M, tmax);
+            const float Mu = Mn == -INFINITY ? 0.0f : Mn;
+            const float alpha = __builtin_amdgcn_exp2f(M - Mu);           // M == -inf -> 0
+            float psum = 0.0f;
+            union { h2v h2[4]; h8v v; } pf[2];
 #pragma unroll
-            for (int db = 0; db < NDB; ++db)
+            for (int e = 0; e < 16; e += 2) {
+                const float p0 = __builtin_amdgcn_exp2f(sc[e] - Mu), p1 = __builtin_amdgcn_exp2f(sc[e + 1] - Mu);   // masked -> 0
+                psum += p0 + p1;
+                const f32x2 pp = { p0, p1 };
+                pf[e >> 3].h2[(e & 7) >> 1] = __builtin_convertvector(pp, h2v);          // v_cvt_pk_f16_f32 (round-to-nearest-even)
+            }
+            S = S * alpha + psum;
+            M = Mn;
+            if (!__all(alpha == 1.0f)) {
 #pragma unroll
-                for (int e = 0; e < 16; ++e) acc_o[db][e] *= alpha;
-        }
-        // ---- O^T += V^T . P^T
+                for (int db = 0; db < NDB; ++db)
 #pragma unroll
-        for (int db = 0; db < NDB; ++db) {
+                    for (int e = 0; e < 16; ++e) acc_o[db][e] *= alpha;
+            }
+            // ---- O^T += V^T . P^T
 #pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2) {
-                const uint32_t * vr = &Vt[(db * 32 + lq) * (VLD / 2) + 8 * s2 + 2 * hb];
-                union { uint32_t u[4]; h8v v; } vf;
-                vf.u[0] = vr[0]; vf.u[1] = vr[1]; vf.u[2] = vr[4]; vf.u[3] = vr[5];
-                acc_o[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf.v, pf[s2], acc_o[db], 0, 0, 0);
+            for (int db = 0; db < NDB; ++db) {
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    const uint32_t * vr = &Vt[buf][(db * 32 + lq) * (VLD / 2) + 8 * s2 + 2 * hb];
+                    union { uint32_t u[4]; h8v v; } vf;
+                    vf.u[0] = vr[0]; vf.u[1] = vr[1]; vf.u[2] = vr[4]; vf.u[3] = vr[5];
+                    acc_o[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf.v, pf[s2].v, acc_o[db], 0, 0, 0);
+                }
             }
         }
+        t = tn; cls = cls_n; ++nlive;
     }
 
     // ---- finish: fold the two lane halves' partial sums, sinks (ops.cpp:8116-8130), normalise, store permuted
     S += __shfl_xor(S, 32, 64);
     float osc = 1.0f;
     if (a.sinks) {
-        const float sk = a.sinks[h];
-        if (sk > M) { const float f = __expf(M - sk); S = S * f + 1.0f; osc = f; }
-        else S += __expf(sk - M);
+        const float sk = a.sinks[h] * FM_LOG2E;
+        if (sk > M) { const float f = __builtin_amdgcn_exp2f(M - sk); S = S * f + 1.0f; osc = f; }
+        else S += __builtin_amdgcn_exp2f(sk - M);
     }
     const float inv = S == 0.0f ? 0.0f : osc / S;
-    if (q < a.nq) {
+    if (row_ok) {
         char * out = a.dst + h * a.dnb1 + q * a.dnb2 + is3 * a.dnb3;
 #pragma unroll
         for (int db = 0; db < NDB; ++db)
@@ -204,12 +286,55 @@ __global__ void __launch_bounds__(64 * NW) k_fattn_mma(const fa_dev a, const int
     }
 }
 
+// ---- mask tile map: class of every 32 (q) x 32 (kv) tile of the f16 mask; one wave per tile
+__global__ void __launch_bounds__(256) k_fattn_mask_map(const char * __restrict__ mask, int64_t mnb1, int64_t mnb2, int64_t mnb3, int mne2, int mne3,
+                                                        int nq, int nkv, int nqb, int ntile, uint8_t * __restrict__ map) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wid = (int64_t) blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (wid >= (int64_t) mne3 * mne2 * nqb * ntile) return;
+    int64_t r = wid;
+    const int t  = (int) (r % ntile); r /= ntile;
+    const int qb = (int) (r % nqb);   r /= nqb;
+    const int i2 = (int) (r % mne2);  const int i3 = (int) (r / mne2);
+    const int q = qb * 32 + (lane >> 1), kv0 = t * FM_KT + (lane & 1) * 16;
+    bool live = false, nz = false;
+    if (q < nq) {
+        const uint16_t * row = (const uint16_t *) (mask + q * mnb1 + i2 * mnb2 + i3 * mnb3);
+        if (kv0 + 15 < nkv && (((uintptr_t) (row + kv0)) & 15) == 0) {
+            const u32x4 w0 = *(const u32x4 *) (row + kv0), w1 = *(const u32x4 *) (row + kv0 + 8);
+            uint32_t d = 0, o = 0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { d |= (w0[i] ^ 0xfc00fc00u) | (w1[i] ^ 0xfc00fc00u); o |= w0[i] | w1[i]; }
+            live = d != 0; nz = o != 0;
+        } else {
+            for (int i = 0; i < 16; ++i) {
+                const uint32_t hv = kv0 + i < nkv ? (uint32_t) row[kv0 + i] : 0xfc00u;
+                live |= hv != 0xfc00u; nz |= hv != 0;
+            }
+        }
+    }
+    const bool any_live = __any(live), any_nz = __any(nz);
+    if (lane == 0) map[wid] = any_live ? (any_nz ? 2 : 1) : 0;
+}
+
+size_t fattn_map_bytes(int64_t nq, int64_t nkv, int64_t mne2, int64_t mne3) {
+    return (size_t) (mne3 * mne2 * ((nq + 31) / 32) * ((nkv + FM_KT - 1) / FM_KT));
+}
+bool fattn_mma_ok(int64_t nkv) { return (nkv + FM_KT - 1) / FM_KT <= FM_MAXT; }
+
+void fattn_mask_map(const fa_dev & a, uint8_t * map, hipStream_t st) {
+    const int nqb = (a.nq + 31) / 32, ntile = (a.nkv + FM_KT - 1) / FM_KT;
+    const int64_t nw = (int64_t) a.mne3 * a.mne2 * nqb * ntile;
+    k_fattn_mask_map<<<dim3((unsigned) ((nw + 3) / 4)), dim3(256), 0, st>>>(a.mask, a.mnb1, a.mnb2, a.mnb3, (int) a.mne2, (int) a.mne3, a.nq, a.nkv, nqb, ntile, map);
+}
+
 template <int D>
 static void launch_fm(const fa_dev & a, hipStream_t st) {
     const int nqt4 = (a.nq + 127) / 128;
-    if ((int64_t) nqt4 * a.nh * a.ns >= 256 || a.nq <= 32) {
-        if (a.nq <= 32) { const int nqt = 1;  k_fattn_mma<D, 1><<<dim3((unsigned) (nqt * a.nh * a.ns)), dim3(64), 0, st>>>(a, nqt); }
-        else            { k_fattn_mma<D, 4><<<dim3((unsigned) (nqt4 * a.nh * a.ns)), dim3(256), 0, st>>>(a, nqt4); }
+    if (a.nq <= 32) {
+        k_fattn_mma<D, 1><<<dim3((unsigned) (a.nh * a.ns)), dim3(64), 0, st>>>(a, 1);
+    } else if ((int64_t) nqt4 * a.nh * a.ns >= 512) {
+        k_fattn_mma<D, 4><<<dim3((unsigned) (nqt4 * a.nh * a.ns)), dim3(256), 0, st>>>(a, nqt4);
     } else {
         const int nqt = (a.nq + 63) / 64;
         k_fattn_mma<D, 2><<<dim3((unsigned) (nqt * a.nh * a.ns)), dim3(128), 0, st>>>(a, nqt);
