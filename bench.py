@@ -20,6 +20,7 @@ import time
 import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
+MFMA_F16_PEAK_TFLOPS = 2500.0    # dense F16/BF16 MFMA peak (MI355X_MICROARCH.md: ~2.5 PF dense; 2:1-sparsity figures are not used)
 HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
 
 
@@ -192,6 +193,46 @@ def prefill_tok_s(pkg, be, model, n_tokens=512, reps=3):
     return n_tokens / best, ok
 
 
+def c3_prefill(pkg, be, n_seq=8, n_prompt=2048, n_ubatch=512, tiny=False):
+    """BASELINE.json configs[2]: Qwen3-8B F16 prefill, 8 sequences x 2048 tokens (MFMA GEMM + flash-attn), llama-bench style:
+    each prompt is fed as n_prompt / n_ubatch ubatches at growing KV depth; inputs are resident before the timed region."""
+    from llama_cpp_omni_amd import qwen3
+    cfg = qwen3.TINY if tiny else qwen3.QWEN3_8B
+    if tiny:
+        n_prompt, n_ubatch = 256, 64
+    model = qwen3.Model(be, cfg, qwen3.uniform_types(cfg, pkg.GGML_TYPE_F16), n_ctx=n_prompt, seed=77, share_layer_bytes=True, flash_attn=True)
+    rng = np.random.default_rng(6)
+    chunks = []
+    for c in range(n_prompt // n_ubatch):
+        n_kv = (c + 1) * n_ubatch
+        g, I, logits = model.build(n_ubatch, n_kv, n_outputs=1)
+        model.set_inputs(I, rng.standard_normal((n_ubatch, cfg["n_embd"])).astype(np.float32), c * n_ubatch, n_kv)
+        be.tensor_set(I["out_ids"], np.array([n_ubatch - 1], np.int32))
+        chunks.append((g, g.graph(), logits))
+    for _ in range(2):                                             # eager pass, then the hipGraph-capturing pass
+        for _, gr, _ in chunks:
+            be.graph_compute(gr)
+    be.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n_seq):
+        for _, gr, _ in chunks:
+            be.graph_compute(gr)
+    be.synchronize()
+    dt = time.perf_counter() - t0
+    ok = bool(np.isfinite(be.tensor_get(chunks[-1][2])).all())
+    n_tok = n_seq * n_prompt
+    # FLOPs as BASELINE.md row C3: 2 x layer weights per token + causal attention 4 * D * n_head * (n^2 / 2) per layer and sequence
+    E, F, L = cfg["n_embd"], cfg["n_ff"], cfg["n_layer"]
+    hd, nh, nkvh = cfg["head_dim"], cfg["n_head"], cfg["n_head_kv"]
+    w_layer = E * hd * nh + 2 * E * hd * nkvh + hd * nh * E + 3 * E * F
+    flops = n_tok * 2.0 * L * w_layer + n_seq * L * 4.0 * hd * nh * (n_prompt * (n_prompt + 1) / 2)
+    for g, _, _ in chunks:
+        g.free()
+    model.wctx.free()
+    return {"tok_s": round(n_tok / dt, 1) if ok else None, "ms_total": round(dt * 1e3, 2), "tflops": round(flops / dt / 1e12, 1),
+            "frac_of_dense_f16_peak": round(flops / dt / 1e12 / MFMA_F16_PEAK_TFLOPS, 4), "n_seq": n_seq, "n_prompt": n_prompt, "n_ubatch": n_ubatch}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -200,6 +241,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--tiny", action="store_true", help="tiny shapes (plumbing check)")
     ap.add_argument("--no-fa", action="store_true")
+    ap.add_argument("--c3", action="store_true", help="also run BASELINE configs[2]: Qwen3-8B F16 prefill 8 x 2048 tokens (adds the `c3_f16_prefill` object)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -288,6 +330,11 @@ def main():
             except Exception as e:
                 out["pp512_tok_s"] = None
                 out["pp512_error"] = repr(e)
+        if args.c3 and world == 1:
+            try:
+                out["c3_f16_prefill"] = {"ub512": c3_prefill(pkg, be, n_ubatch=512, tiny=args.tiny), "ub2048": c3_prefill(pkg, be, n_ubatch=2048, tiny=args.tiny)}
+            except Exception as e:
+                out["c3_f16_prefill"] = {"error": repr(e)}
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(pkg, cfg, types, n_kv)
         else:

@@ -240,6 +240,16 @@ static size_t graph_fa_scratch_need(const ggml_cgraph * g) {
     }
     return need;
 }
+static size_t graph_gemm_partial_need(const ggml_cgraph * g) {
+    size_t need = 0;
+    for (int i = 0; i < g->n_nodes; ++i) {
+        const ggml_tensor * n = g->nodes[i];
+        if (n->op != GGML_OP_MUL_MAT || is_empty(n) || !mm_uses_gemm(n) || n->src[1]->ne[2] != 1 || n->src[1]->ne[3] != 1) continue;
+        const size_t b = gemm_split_scratch_bytes(n->src[0]->ne[1], n->src[1]->ne[1], n->src[0]->ne[0]);
+        if (b > need) need = b;
+    }
+    return need;
+}
 static void ensure_scratch(backend_ctx * c, void ** p, size_t * have, size_t need) {
     if (need <= *have) return;
     HIP_CHECK(hipStreamSynchronize(c->stream));             // nothing in flight may still read the old block
@@ -442,10 +452,90 @@ static void note_write(exec_state & s, const ggml_tensor * t) {          // a ke
     if (r.lo < s.a_range_hi && s.a_range_lo < r.hi) s.a_src = nullptr;
 }
 
+// prefill: MUL_MAT at node i goes to the MFMA GEMM together with the other MUL_MATs that consume the same activation (wq / wk / wv,
+// ffn_gate / ffn_up: one launch fills the chip where wk alone is 32 tiles), with the residual ADD folded into the epilogue; a lone
+// under-filled matrix (wo, ffn_down at ubatch 512) is split along K instead.  Returns false when the plain path must run.
+static bool gemm_operand(exec_state & s, const ggml_tensor * w, const uint16_t ** w16, size_t * rs) {
+    if (w->ne[2] != 1 || w->ne[3] != 1) return false;
+    if (w->type == GGML_TYPE_F16) { *w16 = (const uint16_t *) w->data; *rs = w->nb[1]; return true; }
+    const uint16_t * sh = weight_shadow(s, w, (const char *) w->data, w->ne[0], w->ne[1]);
+    if (!sh) return false;
+    *w16 = sh; *rs = (size_t) w->ne[0] * 2;
+    return true;
+}
+static bool gemm_groupable(const ggml_tensor * c) {
+    if (c->op != GGML_OP_MUL_MAT || is_empty(c) || !mm_uses_gemm(c)) return false;
+    const ggml_tensor * x = c->src[1];
+    return x->ne[2] == 1 && x->ne[3] == 1 && c->src[0]->ne[0] % 64 == 0 && c->nb[0] == 4 && c->type == GGML_TYPE_F32;
+}
+static bool exec_gemm_group(exec_state & s, int i) {
+    ggml_cgraph * g = s.g;
+    ggml_tensor * n = g->nodes[i];
+    if (!gemm_groupable(n)) return false;
+    const ggml_tensor * x = n->src[1];
+    const int64_t K = x->ne[0], N = x->ne[1];
+    gemm_multi_args a;
+    a.nmat = 0; a.N = N; a.K = K; a.partial = nullptr;
+    int mm_idx[3] = { i, -1, -1 };
+    {
+        const uint16_t * w16; size_t rs;
+        if (!gemm_operand(s, n->src[0], &w16, &rs)) return false;
+        a.m[a.nmat++] = { w16, rs, (float *) n->data, n->nb[1], n->src[0]->ne[1], nullptr, 0 };
+    }
+    for (int j = i + 1; j < g->n_nodes && j < i + 32 && a.nmat < 3; ++j) {
+        ggml_tensor * c = g->nodes[j];
+        if (s.done[j] || !gemm_groupable(c) || !same_act(c->src[1], x)) continue;
+        if (!can_hoist(s, i, j, mm_idx, a.nmat)) continue;
+        const uint16_t * w16; size_t rs;
+        if (!gemm_operand(s, c->src[0], &w16, &rs)) continue;
+        mm_idx[a.nmat] = j;
+        a.m[a.nmat++] = { w16, rs, (float *) c->data, c->nb[1], c->src[0]->ne[1], nullptr, 0 };
+    }
+    // residual: the only consumer is ADD(c, r) / ADD(r, c) with r of the same shape, available now
+    int add_idx[3] = { -1, -1, -1 };
+    for (int q = 0; q < a.nmat; ++q) {
+        ggml_tensor * c = g->nodes[mm_idx[q]];
+        const int ai = sole_user(s, c);
+        if (ai > mm_idx[q] && g->nodes[ai]->op == GGML_OP_ADD && !s.done[ai]) {
+            ggml_tensor * A = g->nodes[ai];
+            const ggml_tensor * r = A->src[0] == c ? A->src[1] : A->src[0];
+            if (((A->src[0] == c) != (A->src[1] == c)) && r && r != c && r->type == GGML_TYPE_F32 && same_shape(r, c) && same_shape(A, c) && r->nb[0] == 4 && A->nb[0] == 4 &&
+                A->type == GGML_TYPE_F32 && r->nb[1] % 16 == 0 && A->nb[1] % 16 == 0) {
+                int item[7]; int ni = 0;
+                for (int t = 0; t < a.nmat; ++t) item[ni++] = mm_idx[t];
+                for (int t = 0; t < q; ++t) if (add_idx[t] >= 0) item[ni++] = add_idx[t];
+                item[ni++] = ai;
+                if (can_hoist(s, i, ai, item, ni)) {
+                    a.m[q].resid = (const float *) r->data; a.m[q].resid_cs = r->nb[1];
+                    a.m[q].dst = (float *) A->data; a.m[q].dst_cs = A->nb[1];
+                    add_idx[q] = ai;
+                }
+            }
+        }
+    }
+    const size_t ximg = prepare_act(s, x, ACT_F16);
+    a.X = (const uint16_t *) s.c->act_scratch; a.x_rs = ximg;
+    if (a.nmat == 1 && a.m[0].dst_cs % 16 == 0 && gemm_split_scratch_bytes(a.m[0].M, N, K) <= s.c->gemm_partial_bytes) a.partial = (float *) s.c->gemm_partial;
+    double flops = 0;
+    for (int q = 0; q < a.nmat; ++q) flops += 2.0 * (double) a.m[q].M * (double) N * (double) K;
+    {
+        prof_scope ps(s, "gemm_f16", flops);
+        gemm_f16_multi(a, s.st);
+    }
+    ++s.n_kernels;
+    for (int q = 0; q < a.nmat; ++q) {
+        if (q > 0) { s.done[mm_idx[q]] = 1; ++s.n_fused; }
+        if (add_idx[q] >= 0) { s.done[add_idx[q]] = 1; ++s.n_fused; note_write(s, g->nodes[add_idx[q]]); }
+        else note_write(s, g->nodes[mm_idx[q]]);
+    }
+    return true;
+}
+
 // MUL_MAT at node i: try gate/up/SWIGLU, then q/k/v batching, then residual-add epilogue; falls back to the plain path
 static void exec_mul_mat(exec_state & s, int i) {
     ggml_cgraph * g = s.g;
     ggml_tensor * n = g->nodes[i];
+    if (s.c->opt_fusion && exec_gemm_group(s, i)) return;
     if (!s.c->opt_fusion || !plain_kq_matvec(n, MI_MMVQ_MAX_COLS)) { op_mul_mat(s, n); note_write(s, n); return; }
     const ggml_tensor * x = n->src[1];
     const int64_t K = x->ne[0]; const int N = (int) x->ne[1];
@@ -866,6 +956,7 @@ enum ggml_status graph_compute(backend_ctx * c, ggml_cgraph * g) {
     ensure_scratch(c, &c->act_scratch, &c->act_scratch_bytes, graph_act_scratch_need(g));
     ensure_scratch(c, &c->w_scratch, &c->w_scratch_bytes, graph_w_scratch_need(g));
     ensure_scratch(c, &c->fa_scratch, &c->fa_scratch_bytes, graph_fa_scratch_need(g));
+    ensure_scratch(c, &c->gemm_partial, &c->gemm_partial_bytes, graph_gemm_partial_need(g));
 
     int n_real = 0;
     for (int i = 0; i < g->n_nodes; ++i) n_real += !is_noop(g->nodes[i]);
@@ -943,6 +1034,7 @@ void backend_ctx_release(backend_ctx * c) {
     if (c->act_scratch) (void) hipFree(c->act_scratch);
     if (c->w_scratch) (void) hipFree(c->w_scratch);
     if (c->fa_scratch) (void) hipFree(c->fa_scratch);
+    if (c->gemm_partial) (void) hipFree(c->gemm_partial);
     if (c->copy_event) (void) hipEventDestroy(c->copy_event);
     if (c->stream) (void) hipStreamDestroy(c->stream);
 }

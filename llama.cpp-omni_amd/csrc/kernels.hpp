@@ -125,4 +125,11 @@ bool rms_norm_mul_quant_ok(int64_t n);
 void gemm_f16_mfma(const uint16_t * W, size_t w_rs, const uint16_t * X, size_t x_rs, float * dst, size_t dst_cs,
                    int64_t M, int64_t N, int64_t K, hipStream_t st);
 
+// grouped form: up to three matrices sharing X in one launch, optional residual epilogue (dst = W.x + resid), and -- for a lone
+// under-filled matrix when `partial` scratch (gemm_split_scratch_bytes) is supplied -- deterministic split-K
+struct gemm_mat { const uint16_t * W; size_t w_rs; float * dst; size_t dst_cs; int64_t M; const float * resid; size_t resid_cs; };
+struct gemm_multi_args { gemm_mat m[3]; int nmat; const uint16_t * X; size_t x_rs; int64_t N, K; float * partial; };
+void   gemm_f16_multi(const gemm_multi_args & a, hipStream_t st);
+size_t gemm_split_scratch_bytes(int64_t M, int64_t N, int64_t K);
+
 } // namespace mi

@@ -127,15 +127,31 @@ typedef __attribute__((address_space(3))) void * lds_ptr_t;
 typedef const __attribute__((address_space(1))) void * gbl_ptr_t;
 constexpr int H_BK = 64, H_ROWB = H_BK * 2, H_TILEB = 128 * H_ROWB;          // 16 KB per operand tile
 
-__global__ void __launch_bounds__(256) k_gemm_f16_glds(const char * __restrict__ W, size_t w_rs, const char * __restrict__ X, size_t x_rs,
-                                                       char * __restrict__ dst, size_t dst_cs, int M, int N, int K, int tiles_m, int tiles_n) {
+// One launch serves up to three matrices that share the activation X (wq / wk / wv, ffn_gate / ffn_up): their M tiles are simply
+// concatenated, which is what fills the 256 CUs at ubatch 512 (wk alone is 32 tiles).  Optional epilogue: dst = acc + resid (the
+// residual ADD that follows wo / ffn_down).  Split-K: blockIdx / n_tiles selects a K range and the partial sums go to a dense
+// scratch slab per split (k_gemm_reduce adds the slabs -- and the residual -- in a fixed order: deterministic, no atomics).
+struct gemm_dev {
+    const char * W[3]; size_t w_rs[3]; char * dst[3]; size_t dst_cs[3]; const char * resid[3]; size_t resid_cs[3]; int M[3]; int tm_end[3];
+    int nmat; const char * X; size_t x_rs; int N, K, tiles_m, tiles_n, ksteps_per_split; size_t split_stride;
+};
+
+__global__ void __launch_bounds__(256) k_gemm_f16_glds(const gemm_dev g) {
     __shared__ __attribute__((aligned(16))) char lds[2][2][H_TILEB];          // [buffer][W | X]
 
-    const int nt  = tiles_m * tiles_n;
-    const int bid = blockIdx.x;
+    const int nt    = g.tiles_m * g.tiles_n;
+    const int split = blockIdx.x / nt;
+    const int bid   = blockIdx.x % nt;
     const int q = nt / 8, r = nt % 8, xcd = bid % 8, idx = bid / 8;
     const int tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    const int tm = tile / tiles_n, tn = tile % tiles_n;
+    int tm = tile / g.tiles_n; const int tn = tile % g.tiles_n;
+    int mi = 0;
+    if (g.nmat > 1 && tm >= g.tm_end[0]) { mi = 1; if (g.nmat > 2 && tm >= g.tm_end[1]) mi = 2; }
+    tm -= mi == 0 ? 0 : g.tm_end[mi - 1];
+    const char * W = mi == 0 ? g.W[0] : (mi == 1 ? g.W[1] : g.W[2]);
+    const size_t w_rs = mi == 0 ? g.w_rs[0] : (mi == 1 ? g.w_rs[1] : g.w_rs[2]);
+    const int M = mi == 0 ? g.M[0] : (mi == 1 ? g.M[1] : g.M[2]);
+    const int N = g.N;
     const int m0 = tm * G_BM, n0 = tn * G_BN;
 
     const int t = threadIdx.x, lane = t & 63;
@@ -151,7 +167,7 @@ __global__ void __launch_bounds__(256) k_gemm_f16_glds(const char * __restrict__
         int mr = m0 + wave * 32 + j * 8 + r8; mr = mr < M ? mr : M - 1;
         int nr = n0 + wave * 32 + j * 8 + r8; nr = nr < N ? nr : N - 1;
         wp[j] = W + (size_t) mr * w_rs + gc * 16;
-        xp[j] = X + (size_t) nr * x_rs + gc * 16;
+        xp[j] = g.X + (size_t) nr * g.x_rs + gc * 16;
     }
     auto stage = [&](int buf, int ks) {
 #pragma unroll
@@ -169,13 +185,15 @@ __global__ void __launch_bounds__(256) k_gemm_f16_glds(const char * __restrict__
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.0f;
 
-    const int nk = K / H_BK;
+    const int nk_all = g.K / H_BK;
+    const int k_lo = split * g.ksteps_per_split;
+    const int k_hi = k_lo + g.ksteps_per_split < nk_all ? k_lo + g.ksteps_per_split : nk_all;
     const int fr = lane & 31, hb = lane >> 5, sw = (fr >> 1) & 7;
-    stage(0, 0);
-    for (int ks = 0; ks < nk; ++ks) {
-        const int cur = ks & 1;
+    stage(0, k_lo);
+    for (int ks = k_lo; ks < k_hi; ++ks) {
+        const int cur = (ks - k_lo) & 1;
         __syncthreads();                                   // tile ks has landed (the fence drains the DMA), buffer cur^1 is free
-        if (ks + 1 < nk) stage(cur ^ 1, ks + 1);
+        if (ks + 1 < k_hi) stage(cur ^ 1, ks + 1);
         const char * wb = &lds[cur][0][0]; const char * xb = &lds[cur][1][0];
 #pragma unroll
         for (int kk = 0; kk < H_BK / 16; ++kk) {
@@ -192,6 +210,10 @@ __global__ void __launch_bounds__(256) k_gemm_f16_glds(const char * __restrict__
         }
     }
 
+    char * dst = (mi == 0 ? g.dst[0] : (mi == 1 ? g.dst[1] : g.dst[2])) + (size_t) split * g.split_stride;
+    const size_t dst_cs = mi == 0 ? g.dst_cs[0] : (mi == 1 ? g.dst_cs[1] : g.dst_cs[2]);
+    const char * resid = mi == 0 ? g.resid[0] : (mi == 1 ? g.resid[1] : g.resid[2]);
+    const size_t resid_cs = mi == 0 ? g.resid_cs[0] : (mi == 1 ? g.resid_cs[1] : g.resid_cs[2]);
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -200,25 +222,93 @@ __global__ void __launch_bounds__(256) k_gemm_f16_glds(const char * __restrict__
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int n = n0 + wn * 64 + a * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
-                if (m < M && n < N) *(float *) (dst + (size_t) n * dst_cs + (size_t) m * 4) = acc[a][b][e];
+                if (m < M && n < N) {
+                    float v = acc[a][b][e];
+                    if (resid) v += *(const float *) (resid + (size_t) n * resid_cs + (size_t) m * 4);
+                    *(float *) (dst + (size_t) n * dst_cs + (size_t) m * 4) = v;
+                }
             }
         }
+}
+
+// dst[n][m] = sum_s part[s][n][m] (+ resid[n][m]), fixed summation order
+__global__ void __launch_bounds__(256) k_gemm_reduce(const float * __restrict__ part, int nsplit, size_t split_elems, const char * __restrict__ resid, size_t resid_cs,
+                                                     char * __restrict__ dst, size_t dst_cs, int M, int N) {
+    const int64_t i = ((int64_t) blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i >= (int64_t) M * N) return;
+    const int n = (int) (i / M), m = (int) (i % M);                       // M % 4 == 0 (checked by the launcher)
+    f32x4 v = *(const f32x4 *) (part + i);
+    for (int s = 1; s < nsplit; ++s) { const f32x4 w = *(const f32x4 *) (part + s * split_elems + i); v += w; }
+    if (resid) { const f32x4 w = *(const f32x4 *) (resid + (size_t) n * resid_cs + (size_t) m * 4); v += w; }
+    *(f32x4 *) (dst + (size_t) n * dst_cs + (size_t) m * 4) = v;
 }
 
 bool gemm_f16_ok(const void * W, size_t w_rs, const void * X, size_t x_rs, int64_t K) {
     return K % G_BK == 0 && K >= G_BK && w_rs % 16 == 0 && x_rs % 16 == 0 && ((uintptr_t) W & 15) == 0 && ((uintptr_t) X & 15) == 0;
 }
 
+// choose a K split that brings a lone, under-filled launch up to about two workgroups per CU
+static int pick_ksplit(int64_t tiles, int64_t nk) {
+    if (tiles >= 256 || nk < 32) return 1;
+    int s = (int) (512 / tiles);
+    if (s > 4) s = 4;
+    while (s > 1 && nk / s < 16) --s;
+    return s < 1 ? 1 : s;
+}
+size_t gemm_split_scratch_bytes(int64_t M, int64_t N, int64_t K) {
+    if (K % H_BK != 0 || M % 4 != 0) return 0;
+    const int64_t tiles = ((M + G_BM - 1) / G_BM) * ((N + G_BN - 1) / G_BN);
+    const int s = pick_ksplit(tiles, K / H_BK);
+    return s > 1 ? (size_t) s * (size_t) M * (size_t) N * 4 : 0;
+}
+
+void gemm_f16_multi(const gemm_multi_args & a, hipStream_t st) {
+    if (a.N == 0 || a.nmat == 0) return;
+    const int tiles_n = (int) ((a.N + G_BN - 1) / G_BN);
+    if (a.K % H_BK != 0) {                                    // padded register-staged kernel, one matrix at a time
+        for (int i = 0; i < a.nmat; ++i) {
+            const gemm_mat & m = a.m[i];
+            if (m.M == 0) continue;
+            if (m.resid) { fprintf(stderr, "[mi355x] gemm: residual epilogue needs K %% 64 == 0\n"); abort(); }
+            const int tiles_m = (int) ((m.M + G_BM - 1) / G_BM);
+            k_gemm_f16<<<dim3((unsigned) (tiles_m * tiles_n)), dim3(256), 0, st>>>((const char *) m.W, m.w_rs, (const char *) a.X, a.x_rs, (char *) m.dst, m.dst_cs,
+                                                                                  (int) m.M, (int) a.N, (int) a.K, tiles_m, tiles_n);
+        }
+        return;
+    }
+    gemm_dev g;
+    int tm = 0;
+    for (int i = 0; i < 3; ++i) {
+        const gemm_mat & m = a.m[i < a.nmat ? i : 0];
+        g.W[i] = (const char *) m.W; g.w_rs[i] = m.w_rs; g.dst[i] = (char *) m.dst; g.dst_cs[i] = m.dst_cs;
+        g.resid[i] = (const char *) m.resid; g.resid_cs[i] = m.resid_cs; g.M[i] = (int) m.M;
+        if (i < a.nmat) tm += (int) ((m.M + G_BM - 1) / G_BM);
+        g.tm_end[i] = tm;
+    }
+    g.nmat = a.nmat; g.X = (const char *) a.X; g.x_rs = a.x_rs; g.N = (int) a.N; g.K = (int) a.K; g.tiles_m = tm; g.tiles_n = tiles_n;
+    const int nk = (int) (a.K / H_BK);
+    int ksplit = 1;
+    if (a.nmat == 1 && a.partial && a.m[0].M % 4 == 0) ksplit = pick_ksplit((int64_t) tm * tiles_n, nk);
+    g.ksteps_per_split = (nk + ksplit - 1) / ksplit; g.split_stride = 0;
+    if (tm == 0) return;
+    if (ksplit > 1) {
+        const gemm_mat & m = a.m[0];
+        g.dst[0] = (char *) a.partial; g.dst_cs[0] = (size_t) m.M * 4; g.resid[0] = nullptr; g.split_stride = (size_t) m.M * (size_t) a.N * 4;
+        k_gemm_f16_glds<<<dim3((unsigned) (tm * tiles_n * ksplit)), dim3(256), 0, st>>>(g);
+        const int64_t quads = m.M * a.N / 4;
+        k_gemm_reduce<<<dim3((unsigned) ((quads + 255) / 256)), dim3(256), 0, st>>>(a.partial, ksplit, (size_t) m.M * (size_t) a.N, (const char *) m.resid, m.resid_cs,
+                                                                                  (char *) m.dst, m.dst_cs, (int) m.M, (int) a.N);
+        return;
+    }
+    k_gemm_f16_glds<<<dim3((unsigned) (tm * tiles_n)), dim3(256), 0, st>>>(g);
+}
+
 void gemm_f16_mfma(const uint16_t * W, size_t w_rs, const uint16_t * X, size_t x_rs, float * dst, size_t dst_cs,
                    int64_t M, int64_t N, int64_t K, hipStream_t st) {
-    if (M == 0 || N == 0) return;
-    const int tiles_m = (int) ((M + G_BM - 1) / G_BM), tiles_n = (int) ((N + G_BN - 1) / G_BN);
-    if (K % H_BK == 0)
-        k_gemm_f16_glds<<<dim3((unsigned) (tiles_m * tiles_n)), dim3(256), 0, st>>>((const char *) W, w_rs, (const char *) X, x_rs, (char *) dst, dst_cs,
-                                                                                   (int) M, (int) N, (int) K, tiles_m, tiles_n);
-    else
-        k_gemm_f16<<<dim3((unsigned) (tiles_m * tiles_n)), dim3(256), 0, st>>>((const char *) W, w_rs, (const char *) X, x_rs, (char *) dst, dst_cs,
-                                                                              (int) M, (int) N, (int) K, tiles_m, tiles_n);
+    gemm_multi_args a;
+    a.nmat = 1; a.m[0] = { W, w_rs, dst, dst_cs, M, nullptr, 0 };
+    a.X = X; a.x_rs = x_rs; a.N = N; a.K = K; a.partial = nullptr;
+    gemm_f16_multi(a, st);
 }
 
 } // namespace mi
