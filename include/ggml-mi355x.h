@@ -49,10 +49,13 @@ GGML_MI355X_API float  mi355x_timed_event_elapsed_ms(void * start, void * stop);
 GGML_MI355X_API void   mi355x_timed_event_free(void * ev);
 
 /* runtime options: "graphs" (0/1 hipGraph replay of repeated cgraphs), "fusion" (0/1 node fusion),
- * "profile" (0/1 per-kernel-class event timing, disables graphs).  Returns 0 on success. */
+ * "profile" (0/1 per-kernel-class event timing, disables graphs), "f16_shadow" (0/1 resident F16 images of quantised weights for
+ * the prefill GEMM, process-wide), "norm_in_kernel" (0/1 RMS_NORM+MUL built inside the consuming decode mat-vec launches; default 0),
+ * "reset_stats".  Returns 0 on success, -1 for an unknown key. */
 GGML_MI355X_API int    mi355x_set_option(struct ggml_backend * backend, const char * key, long value);
 /* counters: "graph_replays", "graph_captures", "eager_graphs", "kernels_last_graph",
- * "prof_mmv_q4k_us", "prof_mmv_q4k_n", "prof_mmv_q4k_bytes", .... Returns -1 if unknown. */
+ * "shadow_bytes", "shadow_tensors", "prof_mmv_q4k_us", "prof_mmv_q4k_n", "prof_mmv_q4k_bytes", ....
+ * Returns -1 if unknown. */
 GGML_MI355X_API double mi355x_get_stat(struct ggml_backend * backend, const char * key);
 
 /* test hook: run the on-device activation quantiser the MUL_MAT path uses (kind 0: Q8_K image, 1: Q8_0 image,

@@ -63,6 +63,8 @@ struct exec_state {
     // activation cache
     const void *  a_src = nullptr; act_kind a_kind = ACT_NONE; int64_t a_K = 0, a_ne[3] = {0, 0, 0}; size_t a_nb[3] = {0, 0, 0};
     bool          capturing = false;
+    // deferred RMS_NORM -> MUL(w): not computed yet; its K-quant mat-vec consumers build the Q8_K image in-kernel (mmvk.hip act_norm)
+    struct { const ggml_tensor * m = nullptr; const ggml_tensor * x = nullptr; const ggml_tensor * wt = nullptr; float eps = 0; int left = 0; } pn;
     // mask whose tile map currently sits in fa_scratch
     const void *  fa_mask = nullptr; int64_t fa_dims[4] = {0, 0, 0, 0}; size_t fa_mnb1 = 0;
 };
@@ -266,9 +268,11 @@ static byte_range range_of(const ggml_tensor * t) { const char * p = (const char
 static bool overlap(byte_range a, byte_range b) { return a.lo < b.hi && b.lo < a.hi && a.lo != a.hi && b.lo != b.hi; }
 
 // convert src1 of a MUL_MAT into the activation format of `kind` (or reuse the cached conversion); returns the image stride
+static void materialise_norm(exec_state & s);
 static size_t prepare_act(exec_state & s, const ggml_tensor * x, act_kind kind) {
     const int64_t K = x->ne[0], N = x->ne[1], ne12 = x->ne[2], ne13 = x->ne[3];
     const size_t img = act_image_bytes(kind, K);
+    if (s.pn.m && x == s.pn.m) materialise_norm(s);                      // a consumer outside the in-kernel-norm launches
     if (kind == ACT_F32) return 0;
     const bool cached = s.a_src == x->data && s.a_kind == kind && s.a_K == K && s.a_ne[0] == N && s.a_ne[1] == ne12 &&
                         s.a_ne[2] == ne13 && s.a_nb[0] == x->nb[1] && s.a_nb[1] == x->nb[2] && s.a_nb[2] == x->nb[3];
@@ -452,6 +456,30 @@ static void note_write(exec_state & s, const ggml_tensor * t) {          // a ke
     if (r.lo < s.a_range_hi && s.a_range_lo < r.hi) s.a_src = nullptr;
 }
 
+// ---- deferred norm (see exec_state::pn)
+static void materialise_norm(exec_state & s) {                           // run the stand-alone kernel now: f32 result + Q8_K image, seeds the cache
+    const ggml_tensor * m = s.pn.m, * x = s.pn.x, * wt = s.pn.wt;
+    s.pn.m = nullptr;
+    {
+        prof_scope ps(s, "rms_norm_mul_quant", 0);
+        rms_norm_mul_quant((const float *) x->data, x->nb[1], (const float *) wt->data, (float *) m->data, m->nb[1], s.c->act_scratch, m->ne[0], m->ne[1], s.pn.eps, s.st);
+    }
+    ++s.n_kernels;
+    s.a_src = m->data; s.a_kind = ACT_Q8K; s.a_K = m->ne[0]; s.a_ne[0] = m->ne[1]; s.a_ne[1] = 1; s.a_ne[2] = 1;
+    s.a_nb[0] = m->nb[1]; s.a_nb[1] = m->nb[2]; s.a_nb[2] = m->nb[3];
+    s.a_range_lo = (const char *) m->data; s.a_range_hi = (const char *) m->data + nbytes(m);
+}
+// may the launch that writes `outs` take its activation from the pending norm of x?  (it reads the norm's INPUT while it runs)
+static bool norm_in_kernel(exec_state & s, const ggml_tensor * x, const ggml_tensor * const * outs, int n_outs, int n_consumers, mmv_norm & nr) {
+    if (!s.pn.m || x != s.pn.m) return false;                             // identity of the tensor, not of its address (ggml-alloc re-uses memory)
+    const byte_range rx = range_of(s.pn.x);
+    for (int i = 0; i < n_outs; ++i) if (outs[i] && overlap(range_of(outs[i]), rx)) { materialise_norm(s); return false; }
+    nr.x = (const float *) s.pn.x->data; nr.x_cs = s.pn.x->nb[1]; nr.w = (const float *) s.pn.wt->data; nr.eps = s.pn.eps;
+    s.pn.left -= n_consumers;
+    if (s.pn.left <= 0) s.pn.m = nullptr;                                 // every consumer served: m's memory is nobody's business any more
+    return true;
+}
+
 // prefill: MUL_MAT at node i goes to the MFMA GEMM together with the other MUL_MATs that consume the same activation (wq / wk / wv,
 // ffn_gate / ffn_up: one launch fills the chip where wk alone is 32 tiles), with the residual ADD folded into the epilogue; a lone
 // under-filled matrix (wo, ffn_down at ubatch 512) is split along K instead.  Returns false when the plain path must run.
@@ -554,11 +582,13 @@ static void exec_mul_mat(exec_state & s, int i) {
                 const int oi = oit->second;
                 const int item[3] = { i, oi, gi };
                 if (can_hoist(s, i, oi, item, 3) && can_hoist(s, i, gi, item, 3)) {
-                    const size_t img = prepare_act(s, x, ACT_Q8K);
+                    mmv_norm nrm;
+                    const ggml_tensor * outs[1] = { G };
+                    const size_t img = norm_in_kernel(s, x, outs, 1, 2, nrm) ? q8k_image_bytes(K) : prepare_act(s, x, ACT_Q8K);
                     const ggml_tensor * gate = G->src[0], * up = G->src[1];
                     prof_scope ps(s, n->src[0]->type == GGML_TYPE_Q4_K ? "mmv_q4k" : "mmv_q6k", 2.0 * (double) n->src[0]->ne[1] * (double) row_size(n->src[0]->type, K));
                     mmv_kquant_pair_swiglu(n->src[0]->type, gate->src[0]->data, up->src[0]->data, n->src[0]->nb[1], s.c->act_scratch, img,
-                                           (float *) G->data, G->nb[1], K, n->src[0]->ne[1], N, s.st);
+                                           (float *) G->data, G->nb[1], K, n->src[0]->ne[1], N, s.st, &nrm);
                     ++s.n_kernels; s.n_fused += 2;
                     s.done[oi] = s.done[gi] = 1;
                     note_write(s, G);
@@ -606,7 +636,9 @@ static void exec_mul_mat(exec_state & s, int i) {
             }
         }
     }
-    const size_t img = prepare_act(s, x, ACT_Q8K);
+    const ggml_tensor * outs[3] = { nullptr, nullptr, nullptr };
+    for (int q = 0; q < nm; ++q) outs[q] = add_idx[q] >= 0 ? g->nodes[add_idx[q]] : g->nodes[mm_idx[q]];
+    const size_t img = norm_in_kernel(s, x, outs, nm, nm, a.norm) ? q8k_image_bytes(K) : prepare_act(s, x, ACT_Q8K);
     a.act = s.c->act_scratch; a.act_cs = img;
     {
         // profile class: the launch is attributed to the type that carries most of its bytes
@@ -766,14 +798,29 @@ static bool exec_rms_norm(exec_state & s, int i) {
         }
     }
     if (want_img) {
-        prof_scope ps(s, "rms_norm_mul_quant", 0);
-        rms_norm_mul_quant((const float *) n->src[0]->data, n->src[0]->nb[1], (const float *) wt->data, (float *) m->data, m->nb[1], s.c->act_scratch,
-                           n->ne[0], n->ne[1], eps, s.st);
-        ++s.n_kernels; s.n_fused += 1; s.done[mi_] = 1;
-        note_write(s, m);
-        s.a_src = m->data; s.a_kind = ACT_Q8K; s.a_K = m->ne[0]; s.a_ne[0] = m->ne[1]; s.a_ne[1] = 1; s.a_ne[2] = 1;
-        s.a_nb[0] = m->nb[1]; s.a_nb[1] = m->nb[2]; s.a_nb[2] = m->nb[3];
-        s.a_range_lo = (const char *) m->data; s.a_range_hi = (const char *) m->data + nbytes(m);
+        if (s.pn.m) materialise_norm(s);                              // (an earlier deferred norm that was never consumed in-kernel)
+        // defer: the consumers build the image themselves.  Needs: every consumer a fused K-quant mat-vec, 16-byte aligned rows,
+        // and nothing that runs before the last consumer may write over the norm's input
+        const ggml_tensor * xs = n->src[0];
+        // (measured on MI355X, decode of Qwen3-8B: the in-kernel norm removes 73 launches per token and costs the consumers exactly
+        //  what it saves -- 378 tok/s either way, DESIGN.md section 7 -- so it is opt-in: option "norm_in_kernel" / MI355X_NORM_IN_KERNEL=1)
+        bool defer = s.c->opt_norm_in_kernel && mmv_norm_ok(n->ne[0], (int) n->ne[1]) && !(m->flags & GGML_TENSOR_FLAG_OUTPUT) && ((uintptr_t) xs->data & 15) == 0 && xs->nb[1] % 16 == 0 && ((uintptr_t) wt->data & 15) == 0;
+        int last_user = mi_;
+        for (int u : s.users[m]) { defer = defer && plain_kq_matvec(g->nodes[u], MI_MMVQ_MAX_COLS); if (u > last_user) last_user = u; }
+        if (defer) {
+            const byte_range rx = range_of(xs);
+            for (int k = mi_ + 1; k < last_user && defer; ++k) {
+                const ggml_tensor * nk = g->nodes[k];
+                if (is_noop(nk) || s.done[k]) continue;
+                bool is_user = false;
+                for (int u : s.users[m]) is_user |= u == k;
+                if (!is_user && overlap(range_of(nk), rx)) defer = false;
+            }
+        }
+        s.done[mi_] = 1; s.n_fused += 1;
+        s.pn.m = m; s.pn.x = xs; s.pn.wt = wt; s.pn.eps = eps; s.pn.left = n_users(s, m);
+        if (!defer) { note_write(s, m); materialise_norm(s); }
+        else { ++s.n_fused; if (s.a_src == m->data) s.a_src = nullptr; }
         return true;
     }
     const tdesc wd = td(wt);
@@ -1026,6 +1073,7 @@ void backend_ctx_init(backend_ctx * c) {
     if ((e = getenv("MI355X_GRAPHS")))  c->opt_graphs  = atoi(e) != 0;
     if ((e = getenv("MI355X_FUSION")))  c->opt_fusion  = atoi(e) != 0;
     if ((e = getenv("MI355X_PROFILE"))) c->opt_profile = atoi(e) != 0;
+    if ((e = getenv("MI355X_NORM_IN_KERNEL"))) c->opt_norm_in_kernel = atoi(e) != 0;
 }
 void backend_ctx_release(backend_ctx * c) {
     for (auto & e : c->execs) { if (e.exec) (void) hipGraphExecDestroy(e.exec); if (e.graph) (void) hipGraphDestroy(e.graph); }
@@ -1047,6 +1095,7 @@ int mi355x_set_option(struct ggml_backend * backend, const char * key, long valu
     if (!strcmp(key, "graphs"))  { c->opt_graphs = value != 0; return 0; }
     if (!strcmp(key, "fusion"))  { c->opt_fusion = value != 0; c->execs.clear(); return 0; }
     if (!strcmp(key, "profile")) { c->opt_profile = value != 0; return 0; }
+    if (!strcmp(key, "norm_in_kernel")) { c->opt_norm_in_kernel = value != 0; c->execs.clear(); return 0; }
     if (!strcmp(key, "f16_shadow")) { mi::shadow_set_enabled(value != 0); c->execs.clear(); return 0; }
     if (!strcmp(key, "reset_stats")) { c->prof.clear(); c->stat_replays = c->stat_captures = c->stat_eager = 0; return 0; }
     return -1;

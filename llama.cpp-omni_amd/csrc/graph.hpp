@@ -40,6 +40,7 @@ struct backend_ctx {
     bool opt_graphs = true;
     bool opt_fusion = true;
     bool opt_profile = false;
+    bool opt_norm_in_kernel = false;   // RMS_NORM+MUL computed inside the consuming mat-vec launches (mmvk.hip act_norm)
 
     // hipGraph cache
     std::vector<graph_exec> execs;

@@ -39,7 +39,12 @@ struct mmv_mat {
     const float * resid; size_t resid_cs;      // may be null
     int64_t nrows; int type;
 };
+// norm.x != null: the activation is rms_norm(x) * w of these f32 rows (column stride x_cs); every workgroup builds the Q8_K image
+// itself (mmvk.hip), `act` is ignored
+bool mmv_norm_ok(int64_t K, int ncols);        // shapes the in-kernel norm supports (one column, K <= 4096)
+struct mmv_norm { const float * x = nullptr; size_t x_cs = 0; const float * w = nullptr; float eps = 0.0f; };
 struct mmv_multi_args {
+    mmv_norm norm;
     mmv_mat m[3]; int nmat;
     const void * act; size_t act_cs;           // Q8_K images, one per column
     int64_t K; int ncols;                      // ncols * q8k_image_bytes(K) must fit LDS (<= 152 KiB)
@@ -47,7 +52,7 @@ struct mmv_multi_args {
 void mmv_kquant_multi(const mmv_multi_args & a, hipStream_t st);
 // ffn_gate + ffn_up + SWIGLU: dst[col][r] = silu(Wg[r].x) * (Wu[r].x); both matrices `type`, same shape; ncols <= 4
 void mmv_kquant_pair_swiglu(int type, const void * Wg, const void * Wu, size_t w_rs, const void * act, size_t act_cs, float * dst, size_t dst_cs,
-                            int64_t K, int64_t nrows, int ncols, hipStream_t st);
+                            int64_t K, int64_t nrows, int ncols, hipStream_t st, const mmv_norm * norm = nullptr);
 
 // RMS_NORM + MUL(w) + Q8_K image of the result in one launch (one workgroup per row); y may be null when only the
 // image is consumed.  Same arithmetic as rms_norm() followed by quantize_q8k_image().

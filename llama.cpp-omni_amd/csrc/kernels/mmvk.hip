@@ -47,6 +47,50 @@ static __device__ __forceinline__ void stage_act_k(const char * act, size_t act_
     }
 }
 
+// Activation source of a launch: ready-made Q8_K images, or (NORM kernels, one column, K <= 4096) the f32 row they are to be
+// made from -- then EVERY workgroup builds the image of rms_norm(x) * w itself, in LDS.  That replaces a whole dependent launch
+// (k_rms_norm_mul_quant, ~5 us of pure latency per use) by 32 KB of L2 reads per workgroup.  Ordering matters: the row and the
+// norm weights are requested FIRST (memory returns in order), then the first stage of weight blocks; the reduction and the
+// quantisation then run while those weight loads are in flight.  The arithmetic is the stand-alone kernel's (sum of squares in
+// double, (x*scale)*w, q8k_block_from_regs); every workgroup produces the same bits (the order depends on the thread layout only).
+struct act_norm { const char * x; size_t x_cs; const float * w; float eps; };
+constexpr int NORM_MAXB = 4;                                       // 256-element blocks per wave: K <= 4 waves * 4 * 256
+struct norm_regs { f32x4 x[NORM_MAXB], w[NORM_MAXB]; };
+
+static __device__ __forceinline__ void norm_prefetch(const act_norm nr, int K, norm_regs & r) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nb = K >> 8;
+    const float * xr = (const float *) nr.x;
+#pragma unroll
+    for (int b = 0; b < NORM_MAXB; ++b) {
+        const int ib = wave + 4 * b;
+        if (ib < nb) { r.x[b] = *(const f32x4 *) (xr + ib * 256 + 4 * lane); r.w[b] = *(const f32x4 *) (nr.w + ib * 256 + 4 * lane); }
+        else { r.x[b] = f32x4{0, 0, 0, 0}; r.w[b] = f32x4{0, 0, 0, 0}; }
+    }
+}
+static __device__ __forceinline__ void norm_finish(const act_norm nr, int K, const norm_regs & r) {
+    __shared__ double nred[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nb = K >> 8;
+    double ss = 0.0;
+#pragma unroll
+    for (int b = 0; b < NORM_MAXB; ++b)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ss += (double) (r.x[b][i] * r.x[b][i]);
+    ss = block_sum<double>(ss, nred);
+    const float mean  = (float) (ss / (double) K);
+    const float scale = 1.0f / sqrtf(mean + nr.eps);
+    char * im = mmv_lds;
+#pragma unroll
+    for (int b = 0; b < NORM_MAXB; ++b) {
+        const int ib = wave + 4 * b;
+        if (ib >= nb) break;
+        f32x4 y;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) y[i] = (r.x[b][i] * scale) * r.w[b][i];
+        q8k_block_from_regs(y, lane, (int8_t *) im + ib * 256, (int16_t *) (im + K) + ib * 16, (float *) (im + K + (K >> 3)) + ib);
+    }
+}
+bool mmv_norm_ok(int64_t K, int ncols) { return ncols == 1 && K % 256 == 0 && K / 256 <= 4 * NORM_MAXB; }
+
 static __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + expf(-x)); }    // ggml_silu_f32, vec.h:958
 
 // epilogue shared by all bodies
@@ -62,9 +106,9 @@ struct mmv_out {
 // ggml-quants.c:1352-1374).  A wave covers 8 super-blocks (1152 contiguous bytes) per step, U steps per stage.
 // PAIR: the two "rows" of a group are row r of W0 (gate) and row r of W1 (up); epilogue silu(g)*u.
 // =================================================================================================
-template <int NCOLS, int ROWS, int U, bool PAIR>
+template <int NCOLS, int ROWS, int U, bool PAIR, bool NORM>
 static __device__ __forceinline__ void q4k_body(const char * __restrict__ W0, const char * __restrict__ W1, size_t w_rs, const mmv_out o,
-                                                const char * __restrict__ act, size_t act_cs, int K, int nrows, int wave, int nwaves) {
+                                                const char * __restrict__ act, size_t act_cs, int K, int nrows, int wave, int nwaves, const act_norm nr) {
     const int lane = threadIdx.x & 63;
     const int g = lane >> 3, lp = lane & 7, j = lp >> 1, h = lp & 1;
     const int nb  = K >> 8;
@@ -88,8 +132,10 @@ static __device__ __forceinline__ void q4k_body(const char * __restrict__ W0, co
     };
 
     int grp = wave, it = 0;
-    if (grp < ngrp) issue(grp, 0);                 // first weight loads are in flight while the activation image is staged
-    stage_act_k(act, act_cs, NCOLS, img);
+    norm_regs nrg;
+    if (NORM) norm_prefetch(nr, K, nrg);           // the row to normalise is requested before anything else
+    if (grp < ngrp) issue(grp, 0);                 // first weight loads are in flight while the activation image is staged / built
+    if (NORM) norm_finish(nr, K, nrg); else stage_act_k(act, act_cs, NCOLS, img);
     __syncthreads();
     if (grp >= ngrp) return;
 
@@ -232,9 +278,9 @@ static __device__ __forceinline__ u32x2 ld_piece8_tail(const char * p) {
 // bytes in [0,63] -> signed bytes (w - 32), SWAR without inter-byte borrow
 static __device__ __forceinline__ uint32_t sub32(uint32_t w) { return ((w | 0x80808080u) - 0x20202020u) ^ 0x80808080u; }
 
-template <int NCOLS, int ROWS, int U, bool PAIR>
+template <int NCOLS, int ROWS, int U, bool PAIR, bool NORM>
 static __device__ __forceinline__ void q6k_body(const char * __restrict__ W0, const char * __restrict__ W1, size_t w_rs, const mmv_out o,
-                                                const char * __restrict__ act, size_t act_cs, int K, int nrows, int wave, int nwaves) {
+                                                const char * __restrict__ act, size_t act_cs, int K, int nrows, int wave, int nwaves, const act_norm nr) {
     const int lane = threadIdx.x & 63;
     const int g = lane >> 3, lp = lane & 7, n = lp >> 2, tp = lp & 3;
     const int nb  = K >> 8;
@@ -261,8 +307,10 @@ static __device__ __forceinline__ void q6k_body(const char * __restrict__ W0, co
     };
 
     int grp = wave, it = 0;
+    norm_regs nrg;
+    if (NORM) norm_prefetch(nr, K, nrg);
     if (grp < ngrp) issue2(grp, 0);
-    stage_act_k(act, act_cs, NCOLS, img);
+    if (NORM) norm_finish(nr, K, nrg); else stage_act_k(act, act_cs, NCOLS, img);
     __syncthreads();
     if (grp >= ngrp) return;
 
@@ -360,10 +408,10 @@ static __device__ __forceinline__ void q6k_body(const char * __restrict__ W0, co
 // kernels
 // =================================================================================================
 struct mmv_mat_dev { const char * W; size_t w_rs; mmv_out o; int nrows; int type; int wave_end; };   // waves [prev.wave_end, wave_end) work on this matrix
-struct mmv_multi_dev { mmv_mat_dev m[3]; int nmat; const char * act; size_t act_cs; int K; };
+struct mmv_multi_dev { mmv_mat_dev m[3]; int nmat; const char * act; size_t act_cs; int K; act_norm nr; };
 
 // TM: bit0 = Q4_K bodies compiled in, bit1 = Q6_K bodies compiled in
-template <int NCOLS, int ROWS, int U, int TM>
+template <int NCOLS, int ROWS, int U, int TM, bool NORM>
 __global__ void __launch_bounds__(256) k_mmv_multi(const mmv_multi_dev a) {
     // (each body stages the activation image itself, after issuing its first weight loads; every wave of the workgroup
     // runs exactly one body, so the single __syncthreads inside is met by all of them)
@@ -374,19 +422,19 @@ __global__ void __launch_bounds__(256) k_mmv_multi(const mmv_multi_dev a) {
     // (static selection so the descriptor stays in SGPRs)
     const mmv_mat_dev M = mi_ == 0 ? a.m[0] : (mi_ == 1 ? a.m[1] : a.m[2]);
     const int lw = wave - w0, nw = M.wave_end - w0;
-    if (TM == 1)      q4k_body<NCOLS, ROWS, U, false>(M.W, nullptr, M.w_rs, M.o, a.act, a.act_cs, a.K, M.nrows, lw, nw);
-    else if (TM == 2) q6k_body<NCOLS, ROWS, U, false>(M.W, nullptr, M.w_rs, M.o, a.act, a.act_cs, a.K, M.nrows, lw, nw);
-    else if (M.type == GGML_TYPE_Q4_K) q4k_body<NCOLS, ROWS, U, false>(M.W, nullptr, M.w_rs, M.o, a.act, a.act_cs, a.K, M.nrows, lw, nw);
-    else                               q6k_body<NCOLS, ROWS, U, false>(M.W, nullptr, M.w_rs, M.o, a.act, a.act_cs, a.K, M.nrows, lw, nw);
+    if (TM == 1)      q4k_body<NCOLS, ROWS, U, false, NORM>(M.W, nullptr, M.w_rs, M.o, a.act, a.act_cs, a.K, M.nrows, lw, nw, a.nr);
+    else if (TM == 2) q6k_body<NCOLS, ROWS, U, false, NORM>(M.W, nullptr, M.w_rs, M.o, a.act, a.act_cs, a.K, M.nrows, lw, nw, a.nr);
+    else if (M.type == GGML_TYPE_Q4_K) q4k_body<NCOLS, ROWS, U, false, NORM>(M.W, nullptr, M.w_rs, M.o, a.act, a.act_cs, a.K, M.nrows, lw, nw, a.nr);
+    else                               q6k_body<NCOLS, ROWS, U, false, NORM>(M.W, nullptr, M.w_rs, M.o, a.act, a.act_cs, a.K, M.nrows, lw, nw, a.nr);
 }
 
-template <int NCOLS, int U, int TYPE>
+template <int NCOLS, int U, int TYPE, bool NORM>
 __global__ void __launch_bounds__(256) k_mmv_pair(const char * __restrict__ Wg, const char * __restrict__ Wu, size_t w_rs, const char * __restrict__ act, size_t act_cs,
-                                                 char * __restrict__ dst, size_t dst_cs, int K, int nrows) {
+                                                 char * __restrict__ dst, size_t dst_cs, int K, int nrows, const act_norm nr) {
     const int wave = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
     const mmv_out o = { dst, dst_cs, nullptr, 0 };
-    if (TYPE == GGML_TYPE_Q4_K) q4k_body<NCOLS, 2, U, true>(Wg, Wu, w_rs, o, act, act_cs, K, nrows, wave, nwaves);
-    else                        q6k_body<NCOLS, 2, U, true>(Wg, Wu, w_rs, o, act, act_cs, K, nrows, wave, nwaves);
+    if (TYPE == GGML_TYPE_Q4_K) q4k_body<NCOLS, 2, U, true, NORM>(Wg, Wu, w_rs, o, act, act_cs, K, nrows, wave, nwaves, nr);
+    else                        q6k_body<NCOLS, 2, U, true, NORM>(Wg, Wu, w_rs, o, act, act_cs, K, nrows, wave, nwaves, nr);
 }
 
 // ------------------------------------------------------------------------------------------------ launch
@@ -400,17 +448,18 @@ static int mmv_grid_cap() {
     return cap;
 }
 
-template <int NCOLS, int ROWS, int U>
+template <int NCOLS, int ROWS, int U, bool NORM = false>
 static void launch_multi_tm(const mmv_multi_dev & d, int tm, int grid, size_t lds, hipStream_t st) {
     auto go = [&](auto kern) {
         if (lds > 64 * 1024) HIP_CHECK(hipFuncSetAttribute((const void *) kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
         kern<<<dim3(grid), dim3(256), lds, st>>>(d);
     };
-    if (tm == 1) go(k_mmv_multi<NCOLS, ROWS, U, 1>); else if (tm == 2) go(k_mmv_multi<NCOLS, ROWS, U, 2>); else go(k_mmv_multi<NCOLS, ROWS, U, 3>);
+    if (tm == 1) go(k_mmv_multi<NCOLS, ROWS, U, 1, NORM>); else if (tm == 2) go(k_mmv_multi<NCOLS, ROWS, U, 2, NORM>); else go(k_mmv_multi<NCOLS, ROWS, U, 3, NORM>);
 }
 
 void mmv_kquant_multi(const mmv_multi_args & a, hipStream_t st) {
     if (a.nmat == 0 || a.ncols == 0) return;
+    if (a.norm.x && a.ncols != 1) { fprintf(stderr, "[mi355x] mmv_kquant_multi: in-kernel norm is a one-column path\n"); abort(); }
     const size_t img = q8k_image_bytes(a.K);
     if (img * a.ncols > MMVK_LDS_MAX) { fprintf(stderr, "[mi355x] mmv_kquant_multi: activation images exceed LDS (K=%lld, ncols=%d)\n", (long long) a.K, a.ncols); abort(); }
     const int rows_pw = a.ncols <= 4 ? 2 : 1;
@@ -424,11 +473,13 @@ void mmv_kquant_multi(const mmv_multi_args & a, hipStream_t st) {
         tm |= a.m[i].type == GGML_TYPE_Q4_K ? 1 : 2;
     }
     int64_t grid = (groups + 3) / 4;
-    if (grid > mmv_grid_cap()) grid = mmv_grid_cap();
+    const int cap = a.norm.x ? (mmv_grid_cap() < 1024 ? mmv_grid_cap() : 1024) : mmv_grid_cap();   // in-kernel norm: fewer, longer workgroups
+    if (grid > cap) grid = cap;
     if (grid < 1) grid = 1;
     const int nwaves = (int) grid * 4;
     mmv_multi_dev d;
     d.nmat = a.nmat; d.act = (const char *) a.act; d.act_cs = a.act_cs; d.K = (int) a.K;
+    d.nr = { (const char *) a.norm.x, a.norm.x_cs, a.norm.w, a.norm.eps };
     int acc_w = 0; double acc_b = 0;
     for (int i = 0; i < 3; ++i) {
         if (i >= a.nmat) { d.m[i] = d.m[0]; d.m[i].wave_end = nwaves; continue; }
@@ -445,7 +496,12 @@ void mmv_kquant_multi(const mmv_multi_args & a, hipStream_t st) {
     const bool u2 = nstep >= 2 && a.ncols == 1;
 #define MM_GO(NC, R, UU) launch_multi_tm<NC, R, UU>(d, tm, (int) grid, lds, st)
     switch (a.ncols) {
-        case 1: if (u2) MM_GO(1, 2, 2); else MM_GO(1, 2, 1); break;
+        case 1:
+            if (a.norm.x) {
+                if (!mmv_norm_ok(a.K, 1)) { fprintf(stderr, "[mi355x] mmv_kquant_multi: in-kernel norm needs one column and K <= %d\n", 4 * NORM_MAXB * 256); abort(); }
+                if (u2) launch_multi_tm<1, 2, 2, true>(d, tm, (int) grid, lds, st); else launch_multi_tm<1, 2, 1, true>(d, tm, (int) grid, lds, st);
+            } else if (u2) MM_GO(1, 2, 2); else MM_GO(1, 2, 1);
+            break;
         case 2: MM_GO(2, 2, 1); break;
         case 3: MM_GO(3, 2, 1); break;
         case 4: MM_GO(4, 2, 1); break;
@@ -459,26 +515,36 @@ void mmv_kquant_multi(const mmv_multi_args & a, hipStream_t st) {
 }
 
 void mmv_kquant_pair_swiglu(int type, const void * Wg, const void * Wu, size_t w_rs, const void * act, size_t act_cs, float * dst, size_t dst_cs,
-                            int64_t K, int64_t nrows, int ncols, hipStream_t st) {
+                            int64_t K, int64_t nrows, int ncols, hipStream_t st, const mmv_norm * norm) {
     if (nrows == 0 || ncols == 0) return;
     const size_t lds = q8k_image_bytes(K) * ncols;
-    int64_t grid = (nrows + 3) / 4; if (grid > mmv_grid_cap()) grid = mmv_grid_cap();
+    if (norm && norm->x && ncols != 1) { fprintf(stderr, "[mi355x] mmv_kquant_pair_swiglu: in-kernel norm is a one-column path\n"); abort(); }
+    const act_norm nr = norm && norm->x ? act_norm{ (const char *) norm->x, norm->x_cs, norm->w, norm->eps } : act_norm{ nullptr, 0, nullptr, 0.0f };
+    const int cap = nr.x ? (mmv_grid_cap() < 1024 ? mmv_grid_cap() : 1024) : mmv_grid_cap();
+    int64_t grid = (nrows + 3) / 4; if (grid > cap) grid = cap;
     const bool u2 = (K / 256 + 7) / 8 >= 2 && ncols == 1;
-#define MP_GO(NC, UU)                                                                                                  \
+#define MP_GO(NC, UU) MP_GO2(NC, UU, false)
+#define MP_GO2(NC, UU, NRM)                                                                                            \
     do {                                                                                                               \
-        if (type == GGML_TYPE_Q4_K) k_mmv_pair<NC, UU, GGML_TYPE_Q4_K><<<dim3((unsigned) grid), dim3(256), lds, st>>>(  \
-            (const char *) Wg, (const char *) Wu, w_rs, (const char *) act, act_cs, (char *) dst, dst_cs, (int) K, (int) nrows);  \
-        else k_mmv_pair<NC, UU, GGML_TYPE_Q6_K><<<dim3((unsigned) grid), dim3(256), lds, st>>>(                         \
-            (const char *) Wg, (const char *) Wu, w_rs, (const char *) act, act_cs, (char *) dst, dst_cs, (int) K, (int) nrows);  \
+        if (type == GGML_TYPE_Q4_K) k_mmv_pair<NC, UU, GGML_TYPE_Q4_K, NRM><<<dim3((unsigned) grid), dim3(256), lds, st>>>(  \
+            (const char *) Wg, (const char *) Wu, w_rs, (const char *) act, act_cs, (char *) dst, dst_cs, (int) K, (int) nrows, nr);  \
+        else k_mmv_pair<NC, UU, GGML_TYPE_Q6_K, NRM><<<dim3((unsigned) grid), dim3(256), lds, st>>>(                    \
+            (const char *) Wg, (const char *) Wu, w_rs, (const char *) act, act_cs, (char *) dst, dst_cs, (int) K, (int) nrows, nr);  \
     } while (0)
     switch (ncols) {
-        case 1: if (u2) MP_GO(1, 2); else MP_GO(1, 1); break;
+        case 1:
+            if (nr.x) {
+                if (!mmv_norm_ok(K, 1)) { fprintf(stderr, "[mi355x] mmv_kquant_pair_swiglu: in-kernel norm needs one column and K <= %d\n", 4 * NORM_MAXB * 256); abort(); }
+                if (u2) MP_GO2(1, 2, true); else MP_GO2(1, 1, true);
+            } else if (u2) MP_GO(1, 2); else MP_GO(1, 1);
+            break;
         case 2: MP_GO(2, 1); break;
         case 3: MP_GO(3, 1); break;
         case 4: MP_GO(4, 1); break;
         default: fprintf(stderr, "[mi355x] mmv_kquant_pair_swiglu: ncols=%d out of range (1..4)\n", ncols); abort();
     }
 #undef MP_GO
+#undef MP_GO2
 }
 
 } // namespace mi

@@ -424,6 +424,24 @@ def test_f16_model_logits_within_1e3(pkg, be, ref_be):
     assert np.array_equal(outs[0].argmax(1), outs[1].argmax(1))
 
 
+def test_norm_in_kernel_option(pkg, be, golden):
+    """opt-in variant: RMS_NORM + MUL computed inside the consuming mat-vec launches (no stand-alone norm kernel) -- same tokens,
+    fewer launches"""
+    from test_host_mirror import run_tiny
+    tm = golden["tiny_model"]
+    t0, l0 = run_tiny(pkg, be, tm, 16)
+    k0 = be.get_stat("kernels_last_graph")
+    be.set_option("norm_in_kernel", 1)
+    try:
+        t1, l1 = run_tiny(pkg, be, tm, 16)
+        k1 = be.get_stat("kernels_last_graph")
+    finally:
+        be.set_option("norm_in_kernel", 0)
+    assert t0 == t1 == list(tm["tokens"])[:16]
+    assert nmse(l1, l0) < 1e-9
+    assert k1 < k0
+
+
 def test_graph_replay_is_bit_identical(pkg, be, golden):
     """hipGraph replay of a repeated cgraph gives the same bits as the eager run."""
     from test_host_mirror import run_tiny
