@@ -165,6 +165,12 @@ static void be_free(ggml_backend_t b) {
     backend_ctx * c = (backend_ctx *) b->context;
     set_device(c->device);
     HIP_CHECK(hipStreamSynchronize(c->stream));
+    if (getenv("MI355X_LOG_STATS"))
+        log_msg(GGML_LOG_LEVEL_INFO, "[mi355x] %s: graphs eager=%ld captured=%ld replayed=%ld, kernels in last graph=%ld\n", c->name.c_str(),
+                c->stat_eager, c->stat_captures, c->stat_replays, c->stat_kernels_last);
+    if (getenv("MI355X_LOG_STATS"))
+        for (auto & kv : c->prof)                                         // per-class event timing (only filled in "profile" mode)
+            log_msg(GGML_LOG_LEVEL_INFO, "[mi355x]   %-22s n=%8ld  total %10.1f us  avg %8.2f us\n", kv.first.c_str(), kv.second.n, kv.second.us, kv.second.n ? kv.second.us / kv.second.n : 0.0);
     backend_ctx_release(c);
     delete c;
     delete b;
@@ -210,6 +216,7 @@ static enum ggml_status be_graph_compute(ggml_backend_t b, struct ggml_cgraph * 
     backend_ctx * c = (backend_ctx *) b->context; set_device(c->device);
     return graph_compute(c, g);
 }
+static void be_graph_optimize(ggml_backend_t b, struct ggml_cgraph * g) { graph_optimize((backend_ctx *) b->context, g); }
 static void be_event_record(ggml_backend_t b, ggml_backend_event_t e) {
     backend_ctx * c = (backend_ctx *) b->context; set_device(c->device);
     HIP_CHECK(hipEventRecord((hipEvent_t) e->context, c->stream));
@@ -221,7 +228,7 @@ static void be_event_wait(ggml_backend_t b, ggml_backend_event_t e) {
 static const ggml_backend_i k_backend_iface = {
     be_name, be_free, be_set_async, be_get_async, be_cpy_async, be_sync,
     /*plan_create*/ nullptr, /*plan_free*/ nullptr, /*plan_update*/ nullptr, /*plan_compute*/ nullptr,
-    be_graph_compute, be_event_record, be_event_wait, /*graph_optimize*/ nullptr,
+    be_graph_compute, be_event_record, be_event_wait, be_graph_optimize,
 };
 static bool backend_is_ours(ggml_backend_t b) { return b && b->iface.graph_compute == be_graph_compute; }
 
@@ -320,7 +327,7 @@ static void init_once() {
         device_ctx * d = new device_ctx();
         d->index = i;
         d->name = std::string(GGML_MI355X_NAME) + std::to_string(g_devices.size());
-        d->description = p.name;
+        d->description = p.name[0] ? std::string(p.name) : std::string("AMD Instinct MI355X (") + p.gcnArchName + ")";   // some containers report no marketing name
         char id[32]; snprintf(id, sizeof(id), "%04x:%02x:%02x.0", p.pciDomainID, p.pciBusID, p.pciDeviceID);
         d->pci_id = id;
         d->total_mem = p.totalGlobalMem;

@@ -356,6 +356,25 @@ static void op_mul_mat(exec_state & s, const ggml_tensor * dst) {
     const size_t img = prepare_act(s, x, kind);
 
     const double wbytes = (double) M * (double) row_size(w->type, K);
+    // attention without FLASH_ATTN_EXT: K / V^T per KV head against one activation per query head -- every head in ONE launch
+    if ((w->type == GGML_TYPE_F16 || w->type == GGML_TYPE_F32) && ne12 * ne13 > 1 && N <= MI_MMVQ_MAX_COLS && ne12 * ne13 <= 65535) {
+        mmv_args a;
+        a.W = w->data; a.w_rs = w->nb[1]; a.K = K; a.nrows = M; a.ncols = (int) N;
+        a.dst = (float *) dst->data; a.dst_cs = dst->nb[1];
+        a.nbatch = (int) (ne12 * ne13); a.ne12 = (int) ne12; a.r2 = (int) r2; a.r3 = (int) r3;
+        a.w_nb2 = w->nb[2]; a.w_nb3 = w->nb[3]; a.dst_nb2 = dst->nb[2]; a.dst_nb3 = dst->nb[3];
+        bool ok = true;
+        if (kind == ACT_F32) {
+            a.act = x->data; a.act_cs = x->nb[1]; a.act_bs = x->nb[2];
+            ok = ne13 == 1 || x->nb[3] == (size_t) ne12 * x->nb[2];
+        } else { a.act = s.c->act_scratch; a.act_cs = img; a.act_bs = (size_t) N * img; }
+        if (ok) {
+            prof_scope ps(s, mmv_class(w->type), wbytes * (double) (ne12 * ne13) / (double) (r2 * r3));
+            if (w->type == GGML_TYPE_F16) mmv_f16(a, s.st); else mmv_f32(a, s.st);
+            ++s.n_kernels;
+            return;
+        }
+    }
     for (int64_t i13 = 0; i13 < ne13; ++i13) {
         for (int64_t i12 = 0; i12 < ne12; ++i12) {
             const char * wp = (const char *) w->data + (i12 / r2) * w->nb[2] + (i13 / r3) * w->nb[3];
@@ -1066,6 +1085,36 @@ enum ggml_status graph_compute(backend_ctx * c, ggml_cgraph * g) {
     c->stat_eager++; c->stat_kernels_last = s.n_kernels;
     if (c->opt_profile) prof_drain(c);
     return GGML_STATUS_SUCCESS;
+}
+
+// ggml_backend_i.graph_optimize: called by ggml_backend_sched on each split BEFORE ggml-alloc assigns addresses
+// (ggml-backend.cpp:1304-1310), so a re-ordering here also shapes the tensor lifetimes the allocator sees.
+// libllama emits the q / k / v projections interleaved with the q and k chains (wq, reshape, norm, mul, rope, wk, ...): by the
+// time wk runs, ggml-alloc has already recycled the q chain's dead buffers for it, and an executor-side hoist of wk next to wq
+// must be refused (its output aliases memory the q chain still writes).  Moving the sibling mat-muls -- same activation, weight
+// operands -- directly behind the first one BEFORE allocation removes the aliasing and lets exec_mul_mat batch them, and leaves
+// the q chain, k chain and v store adjacent for the single norm_rope launch.  A moved node depends only on a weight and on the
+// shared activation, produces a fresh (non-view) tensor, and nothing between its old and new position can consume it, so every
+// topological and memory dependency is preserved.
+void graph_optimize(backend_ctx *, ggml_cgraph * g) {
+    static const bool off = getenv("MI355X_NO_GRAPH_OPTIMIZE") != nullptr;
+    if (off || !g || g->n_nodes < 3) return;
+    auto is_weight = [](const ggml_tensor * t) { return t && t->op == GGML_OP_NONE && t->view_src == nullptr && t->buffer != nullptr; };
+    for (int i = 0; i < g->n_nodes; ++i) {
+        ggml_tensor * a = g->nodes[i];
+        if (a->op != GGML_OP_MUL_MAT || a->view_src || !is_weight(a->src[0])) continue;
+        int at = i + 1;                                                  // next free slot behind the group
+        for (int j = i + 1; j < g->n_nodes && j < i + 64; ++j) {
+            ggml_tensor * c = g->nodes[j];
+            if (c->op != GGML_OP_MUL_MAT || c->view_src || c->src[1] != a->src[1] || !is_weight(c->src[0])) continue;
+            if (j != at) {                                               // rotate nodes[at .. j] right by one
+                for (int k = j; k > at; --k) g->nodes[k] = g->nodes[k - 1];
+                g->nodes[at] = c;
+            }
+            ++at;
+        }
+        i = at - 1;
+    }
 }
 
 void backend_ctx_init(backend_ctx * c) {

@@ -59,5 +59,6 @@ void backend_ctx_release(backend_ctx * c);
 
 bool             supports_op(const ggml_tensor * op);
 enum ggml_status graph_compute(backend_ctx * c, ggml_cgraph * g);
+void             graph_optimize(backend_ctx * c, ggml_cgraph * g);   // node re-ordering before allocation (ggml_backend_i.graph_optimize)
 
 } // namespace mi

@@ -24,6 +24,10 @@ struct mmv_args {
     int64_t      K;        // contraction length
     int64_t      nrows;    // weight rows (= dst ne0)
     int          ncols;    // activation columns (tokens)
+    // broadcast batch (mmv_f16 / mmv_f32 only): nbatch = ne12 * ne13 matrices in one launch, batch b = i13 * ne12 + i12 reads
+    // W + (i12 / r2) * w_nb2 + (i13 / r3) * w_nb3, act + b * act_bs, writes dst + i12 * dst_nb2 + i13 * dst_nb3
+    int          nbatch = 1, ne12 = 1, r2 = 1, r3 = 1;
+    size_t       w_nb2 = 0, w_nb3 = 0, act_bs = 0, dst_nb2 = 0, dst_nb3 = 0;
 };
 void mmv_q4_K(const mmv_args & a, hipStream_t st);
 void mmv_q6_K(const mmv_args & a, hipStream_t st);

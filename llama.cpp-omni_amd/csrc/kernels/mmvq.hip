@@ -101,9 +101,19 @@ __global__ void __launch_bounds__(256) k_mmv_q80(const char * __restrict__ W, si
 // F16 / F32 weights: each lane consumes 16 B (8 halfs / 4 floats) per step; activations (f16 rows for F16
 // weights, as the reference rounds src1 to the F16 vec_dot_type; f32 rows for F32 weights) live in LDS.
 // =================================================================================================
+// blockIdx.y walks the broadcast batch (attention without FLASH_ATTN_EXT: one K / V^T matrix per KV head, one activation per query
+// head): batch b = i13 * ne12 + i12 reads W + (i12 / r2) * w_nb2 + (i13 / r3) * w_nb3 -- one launch instead of one per head.
+struct mmv_batch { int ne12, r2, r3; size_t w_nb2, w_nb3, act_bs, dst_nb2, dst_nb3; };
+
 template <int NCOLS, int ROWS, bool WF16>
 __global__ void __launch_bounds__(256) k_mmv_f(const char * __restrict__ W, size_t w_rs, const char * __restrict__ act, size_t act_cs,
-                                              char * __restrict__ dst, size_t dst_cs, int K, int nrows) {
+                                              char * __restrict__ dst, size_t dst_cs, int K, int nrows, const mmv_batch bt) {
+    {
+        const int b = blockIdx.y, i12 = b % bt.ne12, i13 = b / bt.ne12;
+        W   += (size_t) (i12 / bt.r2) * bt.w_nb2 + (size_t) (i13 / bt.r3) * bt.w_nb3;
+        act += (size_t) b * bt.act_bs;
+        dst += (size_t) i12 * bt.dst_nb2 + (size_t) i13 * bt.dst_nb3;
+    }
     constexpr int EPL = WF16 ? 8 : 4;                 // elements per lane per step
     const int lane = threadIdx.x & 63;
     const int nstep = (K + 64 * EPL - 1) / (64 * EPL);
@@ -253,14 +263,15 @@ void mmv_q8_0(const mmv_args & a0, hipStream_t st) {
     do {                                                                                                               \
         const size_t ldsb = arow * (NC);                                                                               \
         if (ldsb > 64 * 1024) HIP_CHECK(hipFuncSetAttribute((const void *) k_mmv_f<NC, ROWS, WF16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) ldsb));                              \
-        k_mmv_f<NC, ROWS, WF16><<<dim3(grid_for(a.nrows, ROWS)), dim3(256), ldsb, st>>>(                               \
-            (const char *) a.W, a.w_rs, (const char *) a.act, a.act_cs, (char *) a.dst, a.dst_cs, (int) a.K, (int) a.nrows); \
+        k_mmv_f<NC, ROWS, WF16><<<dim3(grid_for(a.nrows, ROWS), (unsigned) a.nbatch), dim3(256), ldsb, st>>>(          \
+            (const char *) a.W, a.w_rs, (const char *) a.act, a.act_cs, (char *) a.dst, a.dst_cs, (int) a.K, (int) a.nrows, bt); \
     } while (0)
 
 template <bool WF16>
 static void mmv_float(const mmv_args & a0, hipStream_t st) {
     if (a0.nrows == 0 || a0.ncols == 0) return;
     const size_t arow = ((size_t) a0.K * (WF16 ? 2 : 4) + 15) & ~(size_t) 15;
+    const mmv_batch bt = { a0.nbatch > 1 ? a0.ne12 : 1, a0.nbatch > 1 ? a0.r2 : 1, a0.nbatch > 1 ? a0.r3 : 1, a0.w_nb2, a0.w_nb3, a0.act_bs, a0.dst_nb2, a0.dst_nb3 };
     split_cols(a0, arow, [&](const mmv_args & a) {
         switch (a.ncols) {
             case 1: MMVF_LAUNCH(1, 2, WF16); break;

@@ -1,0 +1,128 @@
+#!/usr/bin/env python3
+"""tools/make_synth_gguf.py -- write a synthetic Qwen3-shaped GGUF v3 file (C2 = Q4_K_M map, C3 = all F16).
+
+Own implementation of the on-disk format the reference reads (ggml/src/gguf.cpp: header, KV section, tensor infos, 32-byte
+aligned data; gguf-py/gguf/gguf_writer.py is the reference's writer).  Weights are random *valid* blocks written directly in
+their quantised layout (llama_cpp_omni_amd.qwen3.random_blocks), norms are 1.0, the tokenizer is "no_vocab"
+(accepted by the reference loader, src/llama-vocab.cpp:1679-1699).  One layer's bytes are generated once and reused for every
+layer (the file is for timing and cross-device parity, not for language).
+
+    python tools/make_synth_gguf.py --config 8b --types q4_k_m -o /tmp/qwen3-8b-q4km-synth.gguf
+    python tools/make_synth_gguf.py --config tiny --types q4_k_m -o /tmp/tiny.gguf --distinct-layers
+"""
+import argparse
+import os
+import struct
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bench import load_pkg  # noqa: E402
+
+GGUF_MAGIC, GGUF_VERSION, ALIGN = 0x46554747, 3, 32
+T_U32, T_F32, T_STR = 4, 6, 8
+
+
+def _s(b):
+    b = b.encode() if isinstance(b, str) else b
+    return struct.pack("<Q", len(b)) + b
+
+
+def kv_u32(k, v):
+    return _s(k) + struct.pack("<II", T_U32, v)
+
+
+def kv_f32(k, v):
+    return _s(k) + struct.pack("<If", T_F32, v)
+
+
+def kv_str(k, v):
+    return _s(k) + struct.pack("<I", T_STR) + _s(v)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--config", choices=["8b", "tiny"], default="8b")
+    ap.add_argument("--types", choices=["q4_k_m", "f16", "q8_0"], default="q4_k_m")
+    ap.add_argument("-o", "--out", required=True)
+    ap.add_argument("--seed", type=int, default=1234)
+    ap.add_argument("--distinct-layers", action="store_true", help="fresh random bytes per layer (small configs)")
+    ap.add_argument("--n-ctx", type=int, default=40960)
+    args = ap.parse_args()
+
+    load_pkg()
+    from llama_cpp_omni_amd import qwen3
+    from llama_cpp_omni_amd.ggml import GGML_TYPE_F16, GGML_TYPE_F32, GGML_TYPE_Q4_K, GGML_TYPE_Q8_0, row_size
+    cfg = qwen3.QWEN3_8B if args.config == "8b" else qwen3.TINY
+    if args.types == "q4_k_m":
+        types, embd_ty, ftype = qwen3.q4_k_m_types(cfg), GGML_TYPE_Q4_K, 15        # LLAMA_FTYPE_MOSTLY_Q4_K_M
+    elif args.types == "f16":
+        types, embd_ty, ftype = qwen3.uniform_types(cfg, GGML_TYPE_F16), GGML_TYPE_F16, 1
+    else:
+        types, embd_ty, ftype = qwen3.uniform_types(cfg, GGML_TYPE_Q8_0), GGML_TYPE_Q8_0, 7
+    E, H, HK, D, F, V, L = cfg["n_embd"], cfg["n_head"], cfg["n_head_kv"], cfg["head_dim"], cfg["n_ff"], cfg["n_vocab"], cfg["n_layer"]
+
+    # ---- tensor list in file order: (name, type, ne) with ne[0] the contiguous dimension
+    tensors = [("token_embd.weight", embd_ty, (E, V)), ("output_norm.weight", GGML_TYPE_F32, (E,)), ("output.weight", types["output"], (E, V))]
+    for il in range(L):
+        t = types[il]
+        tensors += [(f"blk.{il}.attn_norm.weight", GGML_TYPE_F32, (E,)), (f"blk.{il}.attn_q.weight", t["attn_q"], (E, H * D)),
+                    (f"blk.{il}.attn_k.weight", t["attn_k"], (E, HK * D)), (f"blk.{il}.attn_v.weight", t["attn_v"], (E, HK * D)),
+                    (f"blk.{il}.attn_output.weight", t["attn_output"], (H * D, E)), (f"blk.{il}.attn_q_norm.weight", GGML_TYPE_F32, (D,)),
+                    (f"blk.{il}.attn_k_norm.weight", GGML_TYPE_F32, (D,)), (f"blk.{il}.ffn_norm.weight", GGML_TYPE_F32, (E,)),
+                    (f"blk.{il}.ffn_gate.weight", t["ffn_gate"], (E, F)), (f"blk.{il}.ffn_up.weight", t["ffn_up"], (E, F)),
+                    (f"blk.{il}.ffn_down.weight", t["ffn_down"], (F, E))]
+
+    def nbytes(ty, ne):
+        rows = int(np.prod(ne[1:])) if len(ne) > 1 else 1
+        return row_size(ty, ne[0]) * rows
+
+    arch = "qwen3"
+    kvs = [kv_str("general.architecture", arch), kv_str("general.name", f"qwen3-{args.config}-{args.types}-synthetic"), kv_u32("general.file_type", ftype),
+           kv_u32("general.quantization_version", 2), kv_u32("general.alignment", ALIGN),
+           kv_u32(f"{arch}.block_count", L), kv_u32(f"{arch}.context_length", args.n_ctx), kv_u32(f"{arch}.embedding_length", E),
+           kv_u32(f"{arch}.feed_forward_length", F), kv_u32(f"{arch}.attention.head_count", H), kv_u32(f"{arch}.attention.head_count_kv", HK),
+           kv_u32(f"{arch}.attention.key_length", D), kv_u32(f"{arch}.attention.value_length", D),
+           kv_f32(f"{arch}.attention.layer_norm_rms_epsilon", cfg["rms_eps"]), kv_f32(f"{arch}.rope.freq_base", cfg["rope_base"]),
+           kv_u32(f"{arch}.vocab_size", V), kv_str("tokenizer.ggml.model", "no_vocab")]
+
+    offs, off = [], 0
+    for _, ty, ne in tensors:
+        offs.append(off)
+        off = (off + nbytes(ty, ne) + ALIGN - 1) // ALIGN * ALIGN
+    head = struct.pack("<IIQQ", GGUF_MAGIC, GGUF_VERSION, len(tensors), len(kvs)) + b"".join(kvs)
+    for (name, ty, ne), o in zip(tensors, offs):
+        head += _s(name) + struct.pack("<I", len(ne)) + b"".join(struct.pack("<Q", d) for d in ne) + struct.pack("<IQ", ty, o)
+    head += b"\0" * ((-len(head)) % ALIGN)
+
+    rng = np.random.default_rng(args.seed)
+    cache = {}
+
+    def data_for(name, ty, ne):
+        if ty == GGML_TYPE_F32 and len(ne) == 1:
+            return np.ones(ne[0], np.float32).view(np.uint8)
+        base = name.split(".", 2)[2] if name.startswith("blk.") else name
+        key = name if args.distinct_layers else (base, ty, ne)
+        if key not in cache:
+            if not args.distinct_layers and len(cache) > 16:
+                cache.clear()
+            cache[key] = qwen3.random_blocks(rng, ty, ne[1], ne[0]).reshape(-1)
+        return cache[key]
+
+    with open(args.out, "wb") as f:
+        f.write(head)
+        base = f.tell()
+        for (name, ty, ne), o in zip(tensors, offs):
+            pad = base + o - f.tell()
+            assert pad >= 0
+            f.write(b"\0" * pad)
+            d = data_for(name, ty, ne)
+            assert d.nbytes == nbytes(ty, ne), (name, d.nbytes, nbytes(ty, ne))
+            f.write(d.tobytes() if d.nbytes < (1 << 26) else memoryview(np.ascontiguousarray(d)))
+        f.write(b"\0" * ((-f.tell()) % ALIGN))
+    print(f"wrote {args.out}: {len(tensors)} tensors, {os.path.getsize(args.out) / 1e6:.1f} MB")
+
+
+if __name__ == "__main__":
+    main()
