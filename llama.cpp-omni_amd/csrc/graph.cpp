@@ -287,6 +287,9 @@ static size_t prepare_act(exec_state & s, const ggml_tensor * x, act_kind kind) 
     const bool flat = (ne12 == 1 || x->nb[2] == (size_t) N * x->nb[1]) && (ne13 == 1 || x->nb[3] == (size_t) ne12 * x->nb[2]);
     if (flat) {
         conv((const float *) x->data, x->nb[1], s.c->act_scratch, N * ne12 * ne13);
+    } else if (kind == ACT_F16 && N * ne12 * ne13 <= 65535) {            // permuted rows (q seen per head): one strided launch
+        convert_f32_f16_rows3((const float *) x->data, x->nb[1], x->nb[2], x->nb[3], N, ne12, ne13, (uint16_t *) s.c->act_scratch, img, K, s.st);
+        ++s.n_kernels;
     } else {
         for (int64_t i13 = 0; i13 < ne13; ++i13)
             for (int64_t i12 = 0; i12 < ne12; ++i12)
@@ -328,6 +331,19 @@ static void op_mul_mat(exec_state & s, const ggml_tensor * dst) {
     if (mm_uses_gemm(dst)) {
         // ---- prefill: MFMA GEMM.  X -> f16 rows (what the reference does for F16 weights, ggml-cpu.c:1245-1268); quantised W -> f16
         const size_t ximg = prepare_act(s, x, ACT_F16);
+        // attention without FLASH_ATTN_EXT at prefill: every head's K.Q^T (or V^T.P) product in one launch
+        if (w->type == GGML_TYPE_F16 && ne12 * ne13 > 1 && ne12 * ne13 <= 65535 && K % 64 == 0 && w->nb[1] % 16 == 0 && w->nb[2] % 16 == 0 && w->nb[3] % 16 == 0 &&
+            ((uintptr_t) w->data & 15) == 0 && dst->nb[0] == 4) {
+            gemm_multi_args a;
+            a.nmat = 1; a.m[0] = { (const uint16_t *) w->data, w->nb[1], (float *) dst->data, dst->nb[1], M, nullptr, 0 };
+            a.X = (const uint16_t *) s.c->act_scratch; a.x_rs = ximg; a.N = N; a.K = K; a.partial = nullptr;
+            a.nbatch = (int) (ne12 * ne13); a.ne12 = (int) ne12; a.r2 = (int) r2; a.r3 = (int) r3;
+            a.w_nb2 = w->nb[2]; a.w_nb3 = w->nb[3]; a.x_bs = (size_t) N * ximg; a.dst_nb2 = dst->nb[2]; a.dst_nb3 = dst->nb[3];
+            prof_scope ps(s, "gemm_f16", 2.0 * (double) M * (double) N * (double) K * (double) (ne12 * ne13));
+            gemm_f16_multi(a, s.st);
+            ++s.n_kernels;
+            return;
+        }
         const void * last_w = nullptr;
         for (int64_t i13 = 0; i13 < ne13; ++i13) {
             for (int64_t i12 = 0; i12 < ne12; ++i12) {

@@ -11,6 +11,7 @@ void quantize_q8k_image(const float * x, size_t xs, void * img, int64_t K, int64
 void quantize_q80_image(const float * x, size_t xs, void * img, int64_t K, int64_t nrows, hipStream_t st);
 // f32 -> f16 (RNE) rows, dst row stride ys bytes
 void convert_f32_f16_rows(const float * x, size_t xs, uint16_t * y, size_t ys, int64_t K, int64_t nrows, hipStream_t st);
+void convert_f32_f16_rows3(const float * x, size_t nb1, size_t nb2, size_t nb3, int64_t n1, int64_t n2, int64_t n3, uint16_t * y, size_t ys, int64_t K, hipStream_t st);
 
 // ---- mat-vec on quantised weights: dst[col*ds + row] = dot(W[row, :], act[col, :]), ncols <= MMVQ_MAX_COLS
 #define MI_MMVQ_MAX_COLS 8
@@ -137,7 +138,12 @@ void gemm_f16_mfma(const uint16_t * W, size_t w_rs, const uint16_t * X, size_t x
 // grouped form: up to three matrices sharing X in one launch, optional residual epilogue (dst = W.x + resid), and -- for a lone
 // under-filled matrix when `partial` scratch (gemm_split_scratch_bytes) is supplied -- deterministic split-K
 struct gemm_mat { const uint16_t * W; size_t w_rs; float * dst; size_t dst_cs; int64_t M; const float * resid; size_t resid_cs; };
-struct gemm_multi_args { gemm_mat m[3]; int nmat; const uint16_t * X; size_t x_rs; int64_t N, K; float * partial; };
+struct gemm_multi_args {
+    gemm_mat m[3]; int nmat; const uint16_t * X; size_t x_rs; int64_t N, K; float * partial;
+    // broadcast batch (nmat == 1, K % 64 == 0): nbatch = ne12 * ne13 products in one launch; batch b = i13 * ne12 + i12 reads
+    // W + (i12 / r2) * w_nb2 + (i13 / r3) * w_nb3 and X + b * x_bs, writes dst + i12 * dst_nb2 + i13 * dst_nb3
+    int nbatch = 1, ne12 = 1, r2 = 1, r3 = 1; size_t w_nb2 = 0, w_nb3 = 0, x_bs = 0, dst_nb2 = 0, dst_nb3 = 0;
+};
 void   gemm_f16_multi(const gemm_multi_args & a, hipStream_t st);
 size_t gemm_split_scratch_bytes(int64_t M, int64_t N, int64_t K);
 

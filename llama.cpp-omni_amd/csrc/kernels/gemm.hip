@@ -134,6 +134,9 @@ constexpr int H_BK = 64, H_ROWB = H_BK * 2, H_TILEB = 128 * H_ROWB;          // 
 struct gemm_dev {
     const char * W[3]; size_t w_rs[3]; char * dst[3]; size_t dst_cs[3]; const char * resid[3]; size_t resid_cs[3]; int M[3]; int tm_end[3];
     int nmat; const char * X; size_t x_rs; int N, K, tiles_m, tiles_n, ksteps_per_split; size_t split_stride;
+    // broadcast batch over blockIdx.y (attention without FLASH_ATTN_EXT: one K / V^T matrix per KV head, one activation block per query
+    // head): batch b = i13 * ne12 + i12 uses W + (i12 / r2) * w_nb2 + (i13 / r3) * w_nb3, X + b * x_bs, dst + i12 * dst_nb2 + i13 * dst_nb3
+    int ne12, r2, r3; size_t w_nb2, w_nb3, x_bs, dst_nb2, dst_nb3;
 };
 
 __global__ void __launch_bounds__(256) k_gemm_f16_glds(const gemm_dev g) {
@@ -148,7 +151,8 @@ __global__ void __launch_bounds__(256) k_gemm_f16_glds(const gemm_dev g) {
     int mi = 0;
     if (g.nmat > 1 && tm >= g.tm_end[0]) { mi = 1; if (g.nmat > 2 && tm >= g.tm_end[1]) mi = 2; }
     tm -= mi == 0 ? 0 : g.tm_end[mi - 1];
-    const char * W = mi == 0 ? g.W[0] : (mi == 1 ? g.W[1] : g.W[2]);
+    const int bi12 = blockIdx.y % g.ne12, bi13 = blockIdx.y / g.ne12;
+    const char * W = (mi == 0 ? g.W[0] : (mi == 1 ? g.W[1] : g.W[2])) + (size_t) (bi12 / g.r2) * g.w_nb2 + (size_t) (bi13 / g.r3) * g.w_nb3;
     const size_t w_rs = mi == 0 ? g.w_rs[0] : (mi == 1 ? g.w_rs[1] : g.w_rs[2]);
     const int M = mi == 0 ? g.M[0] : (mi == 1 ? g.M[1] : g.M[2]);
     const int N = g.N;
@@ -167,7 +171,7 @@ __global__ void __launch_bounds__(256) k_gemm_f16_glds(const gemm_dev g) {
         int mr = m0 + wave * 32 + j * 8 + r8; mr = mr < M ? mr : M - 1;
         int nr = n0 + wave * 32 + j * 8 + r8; nr = nr < N ? nr : N - 1;
         wp[j] = W + (size_t) mr * w_rs + gc * 16;
-        xp[j] = g.X + (size_t) nr * g.x_rs + gc * 16;
+        xp[j] = g.X + (size_t) blockIdx.y * g.x_bs + (size_t) nr * g.x_rs + gc * 16;
     }
     auto stage = [&](int buf, int ks) {
 #pragma unroll
@@ -210,7 +214,7 @@ __global__ void __launch_bounds__(256) k_gemm_f16_glds(const gemm_dev g) {
         }
     }
 
-    char * dst = (mi == 0 ? g.dst[0] : (mi == 1 ? g.dst[1] : g.dst[2])) + (size_t) split * g.split_stride;
+    char * dst = (mi == 0 ? g.dst[0] : (mi == 1 ? g.dst[1] : g.dst[2])) + (size_t) split * g.split_stride + (size_t) bi12 * g.dst_nb2 + (size_t) bi13 * g.dst_nb3;
     const size_t dst_cs = mi == 0 ? g.dst_cs[0] : (mi == 1 ? g.dst_cs[1] : g.dst_cs[2]);
     const char * resid = mi == 0 ? g.resid[0] : (mi == 1 ? g.resid[1] : g.resid[2]);
     const size_t resid_cs = mi == 0 ? g.resid_cs[0] : (mi == 1 ? g.resid_cs[1] : g.resid_cs[2]);
@@ -266,6 +270,7 @@ void gemm_f16_multi(const gemm_multi_args & a, hipStream_t st) {
     if (a.N == 0 || a.nmat == 0) return;
     const int tiles_n = (int) ((a.N + G_BN - 1) / G_BN);
     if (a.K % H_BK != 0) {                                    // padded register-staged kernel, one matrix at a time
+        if (a.nbatch > 1) { fprintf(stderr, "[mi355x] gemm: batched launch needs K %% 64 == 0\n"); abort(); }
         for (int i = 0; i < a.nmat; ++i) {
             const gemm_mat & m = a.m[i];
             if (m.M == 0) continue;
@@ -286,9 +291,12 @@ void gemm_f16_multi(const gemm_multi_args & a, hipStream_t st) {
         g.tm_end[i] = tm;
     }
     g.nmat = a.nmat; g.X = (const char *) a.X; g.x_rs = a.x_rs; g.N = (int) a.N; g.K = (int) a.K; g.tiles_m = tm; g.tiles_n = tiles_n;
+    const int nbatch = a.nbatch > 1 ? a.nbatch : 1;
+    g.ne12 = nbatch > 1 ? a.ne12 : 1; g.r2 = nbatch > 1 ? a.r2 : 1; g.r3 = nbatch > 1 ? a.r3 : 1;
+    g.w_nb2 = a.w_nb2; g.w_nb3 = a.w_nb3; g.x_bs = a.x_bs; g.dst_nb2 = a.dst_nb2; g.dst_nb3 = a.dst_nb3;
     const int nk = (int) (a.K / H_BK);
     int ksplit = 1;
-    if (a.nmat == 1 && a.partial && a.m[0].M % 4 == 0) ksplit = pick_ksplit((int64_t) tm * tiles_n, nk);
+    if (a.nmat == 1 && nbatch == 1 && a.partial && a.m[0].M % 4 == 0) ksplit = pick_ksplit((int64_t) tm * tiles_n, nk);
     g.ksteps_per_split = (nk + ksplit - 1) / ksplit; g.split_stride = 0;
     if (tm == 0) return;
     if (ksplit > 1) {
@@ -300,7 +308,7 @@ void gemm_f16_multi(const gemm_multi_args & a, hipStream_t st) {
                                                                                   (char *) m.dst, m.dst_cs, (int) m.M, (int) a.N);
         return;
     }
-    k_gemm_f16_glds<<<dim3((unsigned) (tm * tiles_n)), dim3(256), 0, st>>>(g);
+    k_gemm_f16_glds<<<dim3((unsigned) (tm * tiles_n), (unsigned) nbatch), dim3(256), 0, st>>>(g);
 }
 
 void gemm_f16_mfma(const uint16_t * W, size_t w_rs, const uint16_t * X, size_t x_rs, float * dst, size_t dst_cs,

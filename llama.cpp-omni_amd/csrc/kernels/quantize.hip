@@ -127,6 +127,23 @@ __global__ void __launch_bounds__(256) k_f32_to_f16_rows(const char * __restrict
     for (int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x; i < K; i += (int64_t) gridDim.x * blockDim.x) yr[i] = f2h(xr[i]);
 }
 
+// same, rows enumerated over three strided dimensions (a permuted activation, e.g. q [D, n_tokens, n_head] seen per head):
+// row r = (i1, i2, i3) with i1 fastest, source offset i1*nb1 + i2*nb2 + i3*nb3, destination rows dense in r
+__global__ void __launch_bounds__(256) k_f32_to_f16_rows3(const char * __restrict__ x, size_t nb1, size_t nb2, size_t nb3, int n1, int n2,
+                                                         char * __restrict__ y, size_t ys, int64_t K) {
+    const int64_t row = blockIdx.y;
+    const int i1 = (int) (row % n1), i2 = (int) ((row / n1) % n2), i3 = (int) (row / ((int64_t) n1 * n2));
+    const float * xr = (const float *) (x + i1 * nb1 + i2 * nb2 + i3 * nb3);
+    uint16_t *    yr = (uint16_t *) (y + row * ys);
+    for (int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x; i < K; i += (int64_t) gridDim.x * blockDim.x) yr[i] = f2h(xr[i]);
+}
+void convert_f32_f16_rows3(const float * x, size_t nb1, size_t nb2, size_t nb3, int64_t n1, int64_t n2, int64_t n3, uint16_t * y, size_t ys, int64_t K, hipStream_t st) {
+    const int64_t nrows = n1 * n2 * n3;
+    if (K == 0 || nrows == 0) return;
+    unsigned gx = (unsigned) ((K + 255) / 256); if (gx > 64) gx = 64;
+    k_f32_to_f16_rows3<<<dim3(gx, (unsigned) nrows), dim3(256), 0, st>>>((const char *) x, nb1, nb2, nb3, (int) n1, (int) n2, (char *) y, ys, K);
+}
+
 void convert_f32_f16_rows(const float * x, size_t xs, uint16_t * y, size_t ys, int64_t K, int64_t nrows, hipStream_t st) {
     if (K == 0 || nrows == 0) return;
     unsigned gx = (unsigned) ((K + 255) / 256); if (gx > 64) gx = 64;
