@@ -153,8 +153,19 @@ def kernel_roofline(pkg, be, model, reps=5):
     c.free()
     us = best * 1e3
     ach = nbytes / us / 1e3
+    # HBM traffic per launch: PMC counters cannot be read from inside this process; the figure is the committed rocprofv3
+    # --pmc FETCH_SIZE pass of this same command (tools/profile_round.sh -> profiles/r01_pmc_fetch_size.json, corrected x2 per
+    # MI355X_MICROARCH.md), null when that file is absent
+    traffic = None
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_fetch_size.json")))
+        for k, v in pmc["kernels"].items():
+            if "k_mmv_pair<1, 2, 12" in k:
+                traffic = v["hbm_bytes_per_dispatch_corrected"]
+    except Exception:
+        pass
     return {"bound": "hbm", "kernel": "mi::k_mmv_pair<1,2,12> (Q4_K ffn_gate+ffn_up mat-vec + SWIGLU epilogue)",
-            "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+            "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
             "bytes_per_launch": nbytes // launches, "avg_launch_us": round(us / launches, 3), "launches": launches,
             "method": "hipGraph replay of the step's 36 launches of this kernel, two HIP events on the backend stream, best of 5"}
 
