@@ -65,6 +65,8 @@ struct exec_state {
     bool          capturing = false;
     // deferred RMS_NORM -> MUL(w): not computed yet; its K-quant mat-vec consumers build the Q8_K image in-kernel (mmvk.hip act_norm)
     struct { const ggml_tensor * m = nullptr; const ggml_tensor * x = nullptr; const ggml_tensor * wt = nullptr; float eps = 0; int left = 0; } pn;
+    // deferred q chain + k chain/store + v store of a decode layer: executed by the FLASH_ATTN_EXT node `fa` itself (fattn_pre)
+    struct { int fa = -1; fattn_pre pre; int kst = -1, vst = -1; } pq;
     // mask whose tile map currently sits in fa_scratch
     const void *  fa_mask = nullptr; int64_t fa_dims[4] = {0, 0, 0, 0}; size_t fa_mnb1 = 0;
 };
@@ -743,6 +745,59 @@ static norm_rope_job chain_job(exec_state & s, const nr_chain & c) {
     return j;
 }
 
+// Decode (one token, one sequence): can the layer's q chain, k chain + store and v store run INSIDE the attention kernel?  Needs the
+// rope(q) output to be consumed by exactly one FLASH_ATTN_EXT node (through views), that node to read the very cache rows the two
+// stores write, and nothing but views between the chains and the attention node.  On success the chains are not launched; the
+// attention node picks the work up (compute_node).
+static bool try_defer_qkv_to_attention(exec_state & s, const nr_chain & A, const nr_chain * B, int vj, const int * item, int ni) {
+    static const bool off = getenv("MI355X_NO_QKV_IN_ATTN") != nullptr;
+    ggml_cgraph * g = s.g;
+    if (off || A.T != 1 || !B || B->store < 0 || vj < 0 || A.store >= 0 || A.D > 128) return false;
+    const ggml_tensor * rq = g->nodes[A.rope];
+    // follow the single-consumer view chain from rope(q) to the attention node
+    const ggml_tensor * t = rq; int fi = -1;
+    for (int hop = 0; hop < 4; ++hop) {
+        const int u = sole_user(s, t);
+        if (u < 0) return false;
+        const ggml_tensor * c = g->nodes[u];
+        if (c->op == GGML_OP_FLASH_ATTN_EXT) {                          // (the consumer map attributes users of a view to its root too)
+            const ggml_tensor * w = c->src[0];
+            while (w && w != t) w = w->view_src;
+            if (!w) return false;
+            fi = u; break;
+        }
+        if (!is_noop(c)) return false;
+        t = c;
+    }
+    if (fi < 0 || s.done[fi]) return false;
+    const ggml_tensor * f = g->nodes[fi];
+    const ggml_tensor * fq = f->src[0], * fk = f->src[1], * fv = f->src[2];
+    const ggml_tensor * Sk = g->nodes[B->store], * Sv = g->nodes[vj];
+    const int64_t D = A.D;
+    if (fq->data != rq->data || fq->ne[0] != D || fq->ne[1] != 1 || fq->ne[2] != A.H || fq->ne[3] != 1 || fq->nb[2] != rq->nb[1] || rq->nb[0] != 4) return false;
+    if (fk->type != GGML_TYPE_F16 || fv->type != GGML_TYPE_F16 || fk->data != Sk->data || fv->data != Sv->data || fk->nb[1] != Sk->nb[1] || fv->nb[1] != Sv->nb[1] ||
+        fk->nb[2] != (size_t) D * 2 || fv->nb[2] != (size_t) D * 2 || fk->ne[2] != B->H || fv->ne[2] != B->H || fk->ne[3] != 1 || fv->ne[0] != D) return false;
+    int last = 0;
+    for (int q = 0; q < ni; ++q) if (item[q] > last) last = item[q];
+    for (int k = A.norm + 1; k < fi; ++k) {
+        bool mine = false;
+        for (int q = 0; q < ni; ++q) mine |= item[q] == k;
+        if (!mine && !s.done[k] && !is_noop(g->nodes[k])) return false;             // something else runs in between: keep the separate launch
+    }
+    fattn_args fa; tdesc m; fill_fattn_args(f, fa, m);
+    if (!fattn_pre_ok(fa)) return false;
+    const ggml_tensor * xq = g->nodes[A.norm]->src[0], * xk = g->nodes[B->norm]->src[0], * xv = Sv->src[0], * kidx = Sk->src[1], * vidx = Sv->src[1];
+    if (kidx->type != vidx->type) return false;
+    fattn_pre & p = s.pq.pre;
+    p.qraw = (const float *) xq->data; p.q_hs = xq->nb[1]; p.kraw = (const float *) xk->data; p.k_hs = xk->nb[1];
+    p.vraw = (const float *) xv->data; p.v_hs = (int64_t) D * 4;
+    p.qw = (const float *) A.wt->data; p.kw = (const float *) B->wt->data; p.pos = (const int32_t *) A.pos->data; p.ff = A.ff ? (const float *) A.ff->data : nullptr;
+    p.eps = A.eps; p.rp = A.rp;
+    p.kcache = Sk->data; p.kc_rs = Sk->nb[1]; p.vcache = Sv->data; p.vc_rs = Sv->nb[1]; p.kidx = kidx->data; p.vidx = vidx->data; p.idx_is64 = kidx->type == GGML_TYPE_I64;
+    s.pq.fa = fi; s.pq.kst = B->store; s.pq.vst = vj;
+    return true;
+}
+
 // RMS_NORM at node i: fold the following MUL(w) in, and -- when every consumer is a K-quant MUL_MAT -- also emit the Q8_K image
 static bool exec_rms_norm(exec_state & s, int i) {
     ggml_cgraph * g = s.g;
@@ -803,6 +858,11 @@ static bool exec_rms_norm(exec_state & s, int i) {
                                  S->data, (int64_t) S->nb[1], idx->data, idx->type == GGML_TYPE_I64, (int64_t) idx->nb[0], (int) (V->ne[0] / A.D) };
                     } else --ni;
                     break;
+                }
+                if (try_defer_qkv_to_attention(s, A, bj >= 0 ? &B : nullptr, vj, item, ni)) {
+                    for (int q = 1; q < ni; ++q) { s.done[item[q]] = 1; ++s.n_fused; }
+                    ++s.n_fused;
+                    return true;
                 }
                 norm_rope_args a;
                 a.njobs = 0; a.pos = (const int32_t *) A.pos->data; a.ff = A.ff ? (const float *) A.ff->data : nullptr;
@@ -954,6 +1014,8 @@ static void compute_node(exec_state & s, int i) {
                 if (!ok) xuse = nullptr;
             }
             if (xuse) f.img = s.c->act_scratch;
+            const bool with_pre = s.pq.fa == i;
+            if (with_pre) f.pre = &s.pq.pre;
             if (fattn_scratch_bytes(f) > 0) {
                 // the mask tile map is computed once per mask tensor and graph run (every layer shares the mask)
                 const ggml_tensor * mk = n->src[3];
@@ -970,6 +1032,7 @@ static void compute_node(exec_state & s, int i) {
                 flash_attn_ext_f16(f, s.st); ++s.n_kernels;
             }
             note_write(s, n);
+            if (with_pre) { note_write(s, g->nodes[s.pq.kst]); note_write(s, g->nodes[s.pq.vst]); s.pq.fa = -1; }
             if (xuse) {
                 s.a_src = xuse->data; s.a_kind = ACT_Q8K; s.a_K = xuse->ne[0]; s.a_ne[0] = xuse->ne[1]; s.a_ne[1] = 1; s.a_ne[2] = 1;
                 s.a_nb[0] = xuse->nb[1]; s.a_nb[1] = xuse->nb[2]; s.a_nb[2] = xuse->nb[3];

@@ -98,6 +98,13 @@ void cpy_strided(const tdesc & src, int src_type, const tdesc & dst, int dst_typ
 void get_rows(const tdesc & src, int src_type, const tdesc & idx, const tdesc & dst, hipStream_t st);
 void set_rows(const tdesc & src, const tdesc & idx, int idx_type, const tdesc & dst, int dst_type, hipStream_t st);
 
+// decode pre-stage of FLASH_ATTN_EXT: the layer's q chain, k chain + store and v store (what norm_rope_store() does in its own launch)
+// executed by the attention kernel itself; one token, one sequence (fattn_pre_ok)
+struct fattn_pre {
+    const float * qraw; int64_t q_hs; const float * kraw; int64_t k_hs; const float * vraw; int64_t v_hs;   // f32 heads, head stride in bytes
+    const float * qw; const float * kw; const int32_t * pos; const float * ff; float eps; rope_params rp;
+    void * kcache; int64_t kc_rs; void * vcache; int64_t vc_rs; const void * kidx; const void * vidx; int idx_is64;
+};
 // FLASH_ATTN_EXT (ops.cpp:7912-8148): q f32 [D, nq, nh, ns], k/v f16 [D, nkv, nhkv, ns], mask f16 [nkv, >=nq, 1|nh?, ns]
 struct fattn_args {
     tdesc q, k, v, dst;
@@ -108,9 +115,11 @@ struct fattn_args {
     size_t scratch_bytes;
     bool   map_valid = false; // scratch already holds the tile map of THIS mask (same tensor used by an earlier node of the graph)
     void * img = nullptr;    // optional: also emit Q8_K images of the output rows [nh*D] (one per (seq, query row))
+    const fattn_pre * pre = nullptr;   // optional q/k/v pre-stage (decode)
 };
 size_t fattn_scratch_bytes(const fattn_args & a);
 bool   fattn_can_emit_image(const fattn_args & a);
+bool   fattn_pre_ok(const fattn_args & a);
 void   flash_attn_ext_f16(const fattn_args & a, hipStream_t st);
 
 // RMS_NORM -> MUL(w) -> ROPE [-> SET_ROWS into an f16 table] on a [D, H, T] f32 activation, one launch

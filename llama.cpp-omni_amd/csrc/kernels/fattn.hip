@@ -24,7 +24,7 @@ namespace mi {
 
 extern __shared__ __attribute__((aligned(16))) char fa_lds[];
 
-template <int D, int R, int NW>
+template <int D, int R, int NW, bool PRE>
 __global__ void __launch_bounds__(64 * NW) k_fattn_dec(const fa_dev a) {
     constexpr int DPL = D / 64;               // output dims per lane
     constexpr int GR  = 16;                   // KV rows per granule
@@ -54,15 +54,46 @@ __global__ void __launch_bounds__(64 * NW) k_fattn_dec(const fa_dev a) {
     float * pl   = (float *) (fa_lds + R * D * 4) + wave * (GR * R);                 // per-wave P[16][R]
     float * comb = (float *) (fa_lds + R * D * 4 + NW * GR * R * 4);                 // [NW][R][D+2] merge area, later [R][D] finals
 
+    if (PRE) {
+        // one token, one sequence, the whole GQA group in this workgroup (launcher-checked): tasks 0 = k head (norm, rope, store),
+        // 1 = v head (store), 2 + r = q head r (norm, rope, into LDS); one wave per task
+        const fa_pre & P = a.pre;
+        const float posf = (float) P.pos[0];
+        for (int task = wave; task < R + 2; task += NW) {
+            if (task == 1) {
+                const int64_t row = P.idx_is64 ? *(const int64_t *) P.vidx : (int64_t) *(const int32_t *) P.vidx;
+                uint16_t * vr = (uint16_t *) (P.vcache + row * P.vc_rs) + ikv * D;
+                const float * xv = (const float *) (P.vraw + ikv * P.v_hs);
+                for (int e = lane; e < D; e += 64) vr[e] = f2h(xv[e]);
+            } else {
+                const bool isk = task == 0;
+                const int  r   = task - 2;
+                const int  hq  = ikv * a.gq + hc * a.hpw + (isk ? 0 : r);
+                const char * xr = isk ? P.kraw + ikv * P.k_hs : P.qraw + hq * P.q_hs;
+                float r0[1], r1[1]; int e0[1], e1[1]; bool act[1];
+                norm_rope_wave<1>(xr, isk ? P.kw : P.qw, D, P.eps, posf, P.ff, P.rd, lane, r0, r1, e0, e1, act);
+                if (act[0]) {
+                    if (isk) {
+                        const int64_t row = P.idx_is64 ? *(const int64_t *) P.kidx : (int64_t) *(const int32_t *) P.kidx;
+                        uint16_t * kr = (uint16_t *) (P.kcache + row * P.kc_rs) + ikv * D;
+                        kr[e0[0]] = f2h(r0[0]); kr[e1[0]] = f2h(r1[0]);
+                    } else {
+                        qf[r * D + e0[0]] = h2f(f2h(r0[0])); qf[r * D + e1[0]] = h2f(f2h(r1[0]));   // q_to_vec_dot rounding (ops.cpp:8040)
+                    }
+                }
+            }
+        }
+    } else {
 #pragma unroll
-    for (int r = 0; r < R; ++r) {
-        for (int d = threadIdx.x; d < D; d += 64 * NW) {
-            float v = 0.0f;
-            if (r_ok[r]) v = *(const float *) (a.q + d * 4 + r_q[r] * a.qnb1 + r_h[r] * a.qnb2 + is3 * a.qnb3);
-            qf[r * D + d] = h2f(f2h(v));                                              // q_to_vec_dot: f32 -> f16 (ops.cpp:8040)
+        for (int r = 0; r < R; ++r) {
+            for (int d = threadIdx.x; d < D; d += 64 * NW) {
+                float v = 0.0f;
+                if (r_ok[r]) v = *(const float *) (a.q + d * 4 + r_q[r] * a.qnb1 + r_h[r] * a.qnb2 + is3 * a.qnb3);
+                qf[r * D + d] = h2f(f2h(v));                                          // q_to_vec_dot: f32 -> f16 (ops.cpp:8040)
+            }
         }
     }
-    __syncthreads();
+    __syncthreads();                                       // (drains the k / v cache stores of the pre-stage before any wave reads the cache)
 
     float slope[R];
 #pragma unroll
@@ -258,6 +289,16 @@ static void fa_split(const fa_dev & a, int & R, int & hpw, int & qpw) {
     qpw = R / hpw; if (qpw < 1) qpw = 1;
 }
 
+// the q/k/v pre-stage needs: the streaming decode kernel, one token of one sequence, the whole GQA group of a KV head in ONE
+// workgroup (a second workgroup would read the cache row the first one is still writing), head size <= 128
+bool fattn_pre_ok(const fattn_args & f) {
+    const int D = (int) f.q.ne[0];
+    if ((D != 64 && D != 128) || f.q.ne[1] != 1 || f.q.ne[3] != 1 || f.k.ne[3] != 1) return false;
+    fa_dev a; a.nq = 1; a.gq = (int) (f.q.ne[2] / f.k.ne[2]);
+    int R, hpw, qpw; fa_split(a, R, hpw, qpw);
+    return hpw == a.gq && qpw == 1 && R == hpw;
+}
+
 bool fattn_can_emit_image(const fattn_args & f) {
     const int D = (int) f.q.ne[0];
     if (D != 64 && D != 128) return false;
@@ -276,16 +317,18 @@ static void launch_fa(const fa_dev & a0, hipStream_t st) {
     dim3 grid((unsigned) nblk);
     // waves per workgroup: one 16-row granule per wave for short contexts (pure latency), 4 waves when there are many workgroups anyway
     const bool wide = a.nkv > 64 && nblk <= 1024;
-#define FA_GO2(RR, NWW)                                                                                                \
+#define FA_GO3(RR, NWW, PP)                                                                                            \
     do {                                                                                                               \
         const size_t lds = fa_lds_bytes<D, RR, NWW>();                                                                 \
-        if (lds > 64 * 1024) HIP_CHECK(hipFuncSetAttribute((const void *) k_fattn_dec<D, RR, NWW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds)); \
-        k_fattn_dec<D, RR, NWW><<<grid, dim3(64 * NWW), lds, st>>>(a);                                                 \
+        if (lds > 64 * 1024) HIP_CHECK(hipFuncSetAttribute((const void *) k_fattn_dec<D, RR, NWW, PP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds)); \
+        k_fattn_dec<D, RR, NWW, PP><<<grid, dim3(64 * NWW), lds, st>>>(a);                                             \
     } while (0)
+#define FA_GO2(RR, NWW) do { if (a.pre.qraw) FA_GO3(RR, NWW, true); else FA_GO3(RR, NWW, false); } while (0)
 #define FA_GO(RR) do { if (wide) FA_GO2(RR, 8); else FA_GO2(RR, 4); } while (0)     // (16 waves would cap VGPRs at 128 and spill)
     switch (R) { case 1: FA_GO(1); break; case 2: FA_GO(2); break; case 4: FA_GO(4); break; default: FA_GO(8); break; }
 #undef FA_GO
 #undef FA_GO2
+#undef FA_GO3
 }
 
 void flash_attn_ext_f16(const fattn_args & f, hipStream_t st) {
@@ -308,6 +351,13 @@ void flash_attn_ext_f16(const fattn_args & f, hipStream_t st) {
     a.gq = (int) (a.nh / a.nhkv);
     a.hpw = a.qpw = 1;
     a.img = (char *) f.img; a.img_bytes = f.img ? q8k_image_bytes(a.nh * f.q.ne[0]) : 0;
+    a.pre.qraw = nullptr;
+    if (f.pre) {
+        if (!fattn_pre_ok(f)) { fprintf(stderr, "[mi355x] flash_attn: q/k/v pre-stage requested for an unsupported shape\n"); abort(); }
+        const fattn_pre & p = *f.pre;
+        a.pre = { (const char *) p.qraw, p.q_hs, (const char *) p.kraw, p.k_hs, (const char *) p.vraw, p.v_hs, p.qw, p.kw, p.pos, p.ff, p.eps, make_rope_dev(p.rp),
+                  (char *) p.kcache, p.kc_rs, (char *) p.vcache, p.vc_rs, (const char *) p.kidx, (const char *) p.vidx, p.idx_is64 };
+    }
     // batches of query rows go to the matrix-core kernel (fattn_mma.hip); single / few rows stay on the streaming decode kernel
     if (fa_use_mma(f)) {
         a.tile_map = nullptr; a.map_nqb = (a.nq + 31) / 32;

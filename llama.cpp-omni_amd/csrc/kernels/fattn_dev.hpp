@@ -1,8 +1,18 @@
 // fattn_dev.hpp -- device-side argument block shared by the two FLASH_ATTN_EXT kernels (fattn.hip: decode, fattn_mma.hip: prefill)
 #pragma once
 #include "../kernels.hpp"
+#include "norm_rope_dev.hpp"
 
 namespace mi {
+
+// decode pre-stage (qraw == null: none): the layer's q / k chains (RMS_NORM -> MUL -> ROPE) and the k / v cache stores are done by
+// the attention workgroup of each KV head itself, so the separate k_norm_rope launch (and its ~5 us of dependency latency)
+// disappears; arithmetic is norm_rope_wave's, shared with that kernel
+struct fa_pre {
+    const char * qraw; int64_t q_hs; const char * kraw; int64_t k_hs; const char * vraw; int64_t v_hs;   // f32 [D] per head, head strides in bytes
+    const float * qw; const float * kw; const int32_t * pos; const float * ff; float eps; rope_dev rd;
+    char * kcache; int64_t kc_rs; char * vcache; int64_t vc_rs; const char * kidx; const char * vidx; int idx_is64;
+};
 
 struct fa_dev {
     const char * q; const char * k; const char * v; const char * mask; const float * sinks; char * dst;
@@ -15,6 +25,7 @@ struct fa_dev {
     int hpw;                                            // heads handled per workgroup (<= R)
     int qpw;                                            // query rows per workgroup (R / hpw)
     const uint8_t * tile_map; int map_nqb;              // mask tile classes [mne3][mne2][map_nqb][ntile] (prefill kernel), or null = no mask
+    fa_pre pre;
     char * img; size_t img_bytes;                       // optional Q8_K image output (one image per (seq, query row)), else null
 };
 
