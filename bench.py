@@ -259,15 +259,22 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
+    # test hooks (1-GPU box smoke of the multi-process path): MI355X_BENCH_DIST_BACKEND=gloo + MI355X_BENCH_SHARE_GPU=1 run every rank on
+    # device 0 with a CPU rendezvous; the driver's real N > 1 runs use neither (one rank per GPU, RCCL)
+    dist_backend = os.environ.get("MI355X_BENCH_DIST_BACKEND", "nccl")
+    dev_index = 0 if os.environ.get("MI355X_BENCH_SHARE_GPU") else local_rank
     if world > 1:
         import torch
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if dist_backend == "nccl":
+            torch.cuda.set_device(dev_index)
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(backend=dist_backend)
 
     pkg = load_pkg()
     from llama_cpp_omni_amd import qwen3
-    be = pkg.backend(local_rank if world > 1 else 0)
+    be = pkg.backend(dev_index if world > 1 else 0)
     cfg = qwen3.TINY if args.tiny else qwen3.QWEN3_8B
     types = qwen3.q4_k_m_types(cfg)
     n_kv = 256                                                     # llama pads the visible KV length to 256 with FA
@@ -281,7 +288,8 @@ def main():
         if dist is not None:
             import torch
             dist.barrier()
-            torch.cuda.synchronize()
+            if dist_backend == "nccl":
+                torch.cuda.synchronize()
 
     pos = 0
     for _ in range(args.warmup):
@@ -294,7 +302,7 @@ def main():
     dt = time.perf_counter() - t0
     if dist is not None:
         import torch
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda" if dist_backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     replays = be.get_stat("graph_replays")
@@ -327,7 +335,7 @@ def main():
             "value": round(tok_s, 2), "unit": "tok/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "q4_K/q6_K weights x q8_K activations (int8 dot, f32 accumulate)", "data": "synthetic",
-            "config": {"workload": "Qwen3-8B Q4_K_M text-only decode, batch=1, 1xMI355X (mul_mat_vec_q path)" if not args.tiny else "tiny",
+            "config": {"workload": f"Qwen3-8B Q4_K_M text-only decode, batch=1 per GPU, {world}xMI355X (mul_mat_vec_q path)" if not args.tiny else "tiny",
                        "n_layer": cfg["n_layer"], "n_embd": cfg["n_embd"], "n_ff": cfg["n_ff"], "n_vocab": cfg["n_vocab"], "n_kv": n_kv,
                        "flash_attn": not args.no_fa, "weight_bytes_per_token": wbytes, "parallelism": f"replicas x{world} (no collective)",
                        "graph_replays": replays, "kernels_per_token": kernels},
