@@ -745,6 +745,33 @@ static norm_rope_job chain_job(exec_state & s, const nr_chain & c) {
     return j;
 }
 
+// Prefill: does every consumer of t read all of it as the [K, N] activation of a MUL_MAT that goes to the MFMA GEMM (directly or through
+// a reshape of the same bytes)?  Then the producer can emit the f16 rows the GEMM wants and the separate conversion launch disappears.
+static bool gemm_only_consumers(exec_state & s, const ggml_tensor * t, int64_t K, int64_t N, const ggml_tensor ** x_out) {
+    static const bool off = getenv("MI355X_NO_F16_EMIT") != nullptr;
+    if (off || !s.c->opt_fusion || (t->flags & GGML_TENSOR_FLAG_OUTPUT) || N <= MI_MMVQ_MAX_COLS) return false;
+    auto it = s.users.find(t);
+    if (it == s.users.end() || it->second.empty()) return false;
+    if (act_image_bytes(ACT_F16, K) * (size_t) N > s.c->act_scratch_bytes) return false;
+    const ggml_tensor * x0 = nullptr;
+    for (int u : it->second) {
+        const ggml_tensor * c = s.g->nodes[u];
+        if (c->op != GGML_OP_MUL_MAT || is_empty(c) || !mm_uses_gemm(c)) return false;
+        const ggml_tensor * x = c->src[1];
+        if (x->type != GGML_TYPE_F32 || x->data != t->data || x->ne[0] != K || x->ne[1] != N || x->ne[2] != 1 || x->ne[3] != 1 || x->nb[1] != (size_t) K * 4 ||
+            c->src[0]->data == t->data) return false;
+        if (x0 && !same_act(x0, x)) return false;
+        x0 = x;
+    }
+    *x_out = x0;
+    return true;
+}
+static void seed_act_f16(exec_state & s, const ggml_tensor * x) {              // the f16 image of x now sits in act_scratch
+    s.a_src = x->data; s.a_kind = ACT_F16; s.a_K = x->ne[0]; s.a_ne[0] = x->ne[1]; s.a_ne[1] = 1; s.a_ne[2] = 1;
+    s.a_nb[0] = x->nb[1]; s.a_nb[1] = x->nb[2]; s.a_nb[2] = x->nb[3];
+    s.a_range_lo = (const char *) x->data; s.a_range_hi = (const char *) x->data + nbytes(x);
+}
+
 // Decode (one token, one sequence): can the layer's q chain, k chain + store and v store run INSIDE the attention kernel?  Needs the
 // rope(q) output to be consumed by exactly one FLASH_ATTN_EXT node (through views), that node to read the very cache rows the two
 // stores write, and nothing but views between the chains and the attention node.  On success the chains are not launched; the
@@ -919,10 +946,16 @@ static bool exec_rms_norm(exec_state & s, int i) {
         return true;
     }
     const tdesc wd = td(wt);
-    prof_scope ps(s, "rms_norm_mul", 0);
-    rms_norm(td(n->src[0]), td(m), eps, &wd, s.st);
+    const ggml_tensor * xg = nullptr;
+    const bool emit16 = n->ne[2] == 1 && n->ne[3] == 1 && m->nb[1] == (size_t) m->ne[0] * 4 && gemm_only_consumers(s, m, m->ne[0], m->ne[1], &xg);
+    {
+        prof_scope ps(s, "rms_norm_mul", 0);
+        if (emit16) rms_norm(td(n->src[0]), td(m), eps, &wd, s.st, (uint16_t *) s.c->act_scratch, act_image_bytes(ACT_F16, m->ne[0]), n_users(s, m) > 1);
+        else        rms_norm(td(n->src[0]), td(m), eps, &wd, s.st);
+    }
     ++s.n_kernels; s.n_fused += 1; s.done[mi_] = 1;
     note_write(s, m);
+    if (emit16) { seed_act_f16(s, xg); ++s.n_fused; }
     return true;
 }
 
@@ -958,10 +991,19 @@ static void compute_node(exec_state & s, int i) {
             break;
         }
         case GGML_OP_GLU: {
-            prof_scope ps(s, "glu", 0);
             tdesc b; if (n->src[1]) b = td(n->src[1]);
-            glu_f32(op_param_i32(n, 0), td(n->src[0]), n->src[1] ? &b : nullptr, op_param_i32(n, 1) != 0, td(n), s.st); ++s.n_kernels;
-            break;
+            const ggml_tensor * xg = nullptr;
+            const bool emit16 = n->ne[2] == 1 && n->ne[3] == 1 && n->nb[1] == (size_t) n->ne[0] * 4 && gemm_only_consumers(s, n, n->ne[0], n->ne[1], &xg);
+            {
+                prof_scope ps(s, "glu", 0);
+                if (emit16) glu_f32(op_param_i32(n, 0), td(n->src[0]), n->src[1] ? &b : nullptr, op_param_i32(n, 1) != 0, td(n), s.st,
+                                    (uint16_t *) s.c->act_scratch, act_image_bytes(ACT_F16, n->ne[0]), n_users(s, n) > 1);
+                else        glu_f32(op_param_i32(n, 0), td(n->src[0]), n->src[1] ? &b : nullptr, op_param_i32(n, 1) != 0, td(n), s.st);
+            }
+            ++s.n_kernels;
+            note_write(s, n);
+            if (emit16) { seed_act_f16(s, xg); ++s.n_fused; }
+            return;
         }
         case GGML_OP_ROPE: {
             rope_params rp;
@@ -1016,6 +1058,12 @@ static void compute_node(exec_state & s, int i) {
             if (xuse) f.img = s.c->act_scratch;
             const bool with_pre = s.pq.fa == i;
             if (with_pre) f.pre = &s.pq.pre;
+            // prefill: the attention output [D, H, nq, ns] read as [H*D, nq*ns] rows by wo's GEMM -> emit those rows in f16 from the kernel
+            const ggml_tensor * xg16 = nullptr;
+            if (!xuse && fattn_uses_mma(f) && n->nb[1] == (size_t) n->ne[0] * 4 && n->nb[2] == (size_t) n->ne[0] * n->ne[1] * 4 &&
+                n->nb[3] == n->nb[2] * (size_t) n->ne[2] && gemm_only_consumers(s, n, n->ne[0] * n->ne[1], n->ne[2] * n->ne[3], &xg16)) {
+                f.out16 = (uint16_t *) s.c->act_scratch; f.out16_rs = act_image_bytes(ACT_F16, n->ne[0] * n->ne[1]); f.write_f32 = n_users(s, n) > 1;
+            }
             if (fattn_scratch_bytes(f) > 0) {
                 // the mask tile map is computed once per mask tensor and graph run (every layer shares the mask)
                 const ggml_tensor * mk = n->src[3];
@@ -1033,6 +1081,7 @@ static void compute_node(exec_state & s, int i) {
             }
             note_write(s, n);
             if (with_pre) { note_write(s, g->nodes[s.pq.kst]); note_write(s, g->nodes[s.pq.vst]); s.pq.fa = -1; }
+            if (xg16) { seed_act_f16(s, xg16); ++s.n_fused; }
             if (xuse) {
                 s.a_src = xuse->data; s.a_kind = ACT_Q8K; s.a_K = xuse->ne[0]; s.a_ne[0] = xuse->ne[1]; s.a_ne[1] = 1; s.a_ne[2] = 1;
                 s.a_nb[0] = xuse->nb[1]; s.a_nb[1] = xuse->nb[2]; s.a_nb[2] = xuse->nb[3];

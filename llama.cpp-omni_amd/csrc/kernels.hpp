@@ -76,7 +76,8 @@ struct tdesc {
 };
 
 // RMS_NORM (ops.cpp:3517-3566), optionally fused with the following MUL by `w` (broadcast over rows) and ADD
-void rms_norm(const tdesc & x, const tdesc & y, float eps, const tdesc * mul_w, hipStream_t st);
+// y16 != null (2-D, with mul_w): also emit f16-rounded rows (row stride y16_rs) for the prefill GEMM; write_f32 = false skips y
+void rms_norm(const tdesc & x, const tdesc & y, float eps, const tdesc * mul_w, hipStream_t st, uint16_t * y16 = nullptr, size_t y16_rs = 0, bool write_f32 = true);
 // ROPE f32 (ops.cpp:5534-5720): modes NORMAL / NEOX, optional freq factors, YaRN
 struct rope_params {
     int   n_dims, mode, n_ctx_orig;
@@ -86,7 +87,7 @@ void rope_f32(const tdesc & x, const int32_t * pos, const float * freq_factors, 
 // SOFT_MAX (ops.cpp:5072-5182): y = softmax(x*scale + slope*mask)
 void soft_max_f32(const tdesc & x, const tdesc * mask, int mask_type, const float * sinks, const tdesc & y, float scale, float max_bias, hipStream_t st);
 // GLU (split or single-tensor forms; ops.cpp:2934-2990 for swiglu)
-void glu_f32(int glu_op, const tdesc & a, const tdesc * b, bool swapped, const tdesc & y, hipStream_t st);
+void glu_f32(int glu_op, const tdesc & a, const tdesc * b, bool swapped, const tdesc & y, hipStream_t st, uint16_t * y16 = nullptr, size_t y16_rs = 0, bool write_f32 = true);
 // unary ops on contiguous f32
 void unary_f32(int uop, const float * x, float * y, int64_t n, hipStream_t st);
 // ADD / SUB / MUL / DIV with ggml broadcast semantics (src1 repeats over src0)
@@ -116,10 +117,12 @@ struct fattn_args {
     bool   map_valid = false; // scratch already holds the tile map of THIS mask (same tensor used by an earlier node of the graph)
     void * img = nullptr;    // optional: also emit Q8_K images of the output rows [nh*D] (one per (seq, query row))
     const fattn_pre * pre = nullptr;   // optional q/k/v pre-stage (decode)
+    uint16_t * out16 = nullptr; size_t out16_rs = 0; bool write_f32 = true;   // prefill kernel: also / only emit f16 rows [nh*D] per (seq, query)
 };
 size_t fattn_scratch_bytes(const fattn_args & a);
 bool   fattn_can_emit_image(const fattn_args & a);
 bool   fattn_pre_ok(const fattn_args & a);
+bool   fattn_uses_mma(const fattn_args & a);      // the matrix-core (prefill) kernel will run: out16 is honoured
 void   flash_attn_ext_f16(const fattn_args & a, hipStream_t st);
 
 // RMS_NORM -> MUL(w) -> ROPE [-> SET_ROWS into an f16 table] on a [D, H, T] f32 activation, one launch

@@ -117,8 +117,10 @@ void dequant_rows_f16(int type, const void * src, size_t src_rs, uint16_t * dst,
 // the result independent of the summation order (bit-exact `scale` in practice).  The optional fused
 // weight multiply is the graph's following MUL node (y*w, w broadcast over rows).
 // ================================================================================================
+// y16 != null: also (or, with y.p == null, only) emit the f16-rounded row -- the activation format of the prefill GEMM -- so the
+// separate f32 -> f16 conversion launch and, when no one else reads it, the f32 write disappear (2-D inputs only)
 template <bool HAS_W>
-__global__ void __launch_bounds__(1024) k_rms_norm(td4 x, td4 y, td4 w, float eps) {
+__global__ void __launch_bounds__(1024) k_rms_norm(td4 x, td4 y, td4 w, float eps, char * __restrict__ y16, int64_t y16_rs) {
     __shared__ double red[16];
     const int64_t i1 = blockIdx.x, i2 = blockIdx.y, i3 = blockIdx.z;
     const float * xr = (const float *) (x.p + i1 * x.nb[1] + i2 * x.nb[2] + i3 * x.nb[3]);
@@ -132,19 +134,27 @@ __global__ void __launch_bounds__(1024) k_rms_norm(td4 x, td4 y, td4 w, float ep
     if (HAS_W) {
         const float * wr = (const float *) (w.p + (i1 % w.ne[1]) * w.nb[1] + (i2 % w.ne[2]) * w.nb[2] + (i3 % w.ne[3]) * w.nb[3]);
         const int64_t wn = w.ne[0];
-        for (int64_t i = threadIdx.x; i < n; i += blockDim.x) yr[i] = (xr[i] * scale) * wr[wn == n ? i : i % wn];
+        uint16_t * hr = y16 ? (uint16_t *) (y16 + i1 * y16_rs) : nullptr;
+        for (int64_t i = threadIdx.x; i < n; i += blockDim.x) {
+            const float v = (xr[i] * scale) * wr[wn == n ? i : i % wn];
+            if (y.p) yr[i] = v;
+            if (hr)  hr[i] = f2h(v);
+        }
     } else {
         for (int64_t i = threadIdx.x; i < n; i += blockDim.x) yr[i] = xr[i] * scale;
     }
 }
 
-void rms_norm(const tdesc & x, const tdesc & y, float eps, const tdesc * mul_w, hipStream_t st) {
+void rms_norm(const tdesc & x, const tdesc & y, float eps, const tdesc * mul_w, hipStream_t st, uint16_t * y16, size_t y16_rs, bool write_f32) {
     if (x.ne[0] == 0 || x.ne[1] * x.ne[2] * x.ne[3] == 0) return;
     const int64_t n = x.ne[0];
     int bs = n <= 128 ? 64 : n < 1024 ? 256 : n < 8192 ? 512 : 1024;
     dim3 grid((unsigned) x.ne[1], (unsigned) x.ne[2], (unsigned) x.ne[3]);
-    if (mul_w) k_rms_norm<true><<<grid, dim3(bs), 0, st>>>(to_td4(x), to_td4(y), to_td4(*mul_w), eps);
-    else       k_rms_norm<false><<<grid, dim3(bs), 0, st>>>(to_td4(x), to_td4(y), to_td4(x), eps);
+    if (y16 && (!mul_w || x.ne[2] * x.ne[3] != 1)) { fprintf(stderr, "[mi355x] rms_norm: f16 emission needs the fused weight and a 2-D input\n"); abort(); }
+    td4 yd = to_td4(y);
+    if (!write_f32) yd.p = nullptr;
+    if (mul_w) k_rms_norm<true><<<grid, dim3(bs), 0, st>>>(to_td4(x), yd, to_td4(*mul_w), eps, (char *) y16, (int64_t) y16_rs);
+    else       k_rms_norm<false><<<grid, dim3(bs), 0, st>>>(to_td4(x), yd, to_td4(x), eps, nullptr, 0);
 }
 
 // ================================================================================================
@@ -154,12 +164,12 @@ void rms_norm(const tdesc & x, const tdesc & y, float eps, const tdesc * mul_w, 
 // (theta_0 = pos; theta_{i+1} = theta_i * theta_scale) so the angle is bit-identical; only cosf/sinf
 // differ (device libm vs glibc, <= 2 ulp).
 // ================================================================================================
-struct rope_dev {
+struct rope_dev_e {
     int   n_dims, mode;
     float theta_scale, freq_scale, ext_factor, attn_factor, corr0, corr1;
 };
 
-__global__ void __launch_bounds__(256) k_rope(td4 x, td4 y, const int32_t * __restrict__ pos, const float * __restrict__ ff, rope_dev rp) {
+__global__ void __launch_bounds__(256) k_rope(td4 x, td4 y, const int32_t * __restrict__ pos, const float * __restrict__ ff, rope_dev_e rp) {
     // grid: (ne1 heads, ne2 tokens, ne3); threads over pairs
     const int64_t i1 = blockIdx.x, i2 = blockIdx.y, i3 = blockIdx.z;
     const char * xr = x.p + i1 * x.nb[1] + i2 * x.nb[2] + i3 * x.nb[3];
@@ -208,7 +218,7 @@ static float rope_corr_dim(int n_dims, int n_ctx_orig, float n_rot, float base) 
 
 void rope_f32(const tdesc & x, const int32_t * pos, const float * ff, const tdesc & y, const rope_params & rp, hipStream_t st) {
     if (x.ne[0] * x.ne[1] * x.ne[2] * x.ne[3] == 0) return;
-    rope_dev d;
+    rope_dev_e d;
     d.n_dims = rp.n_dims; d.mode = rp.mode;
     d.theta_scale = powf(rp.freq_base, -2.0f / rp.n_dims);
     d.freq_scale = rp.freq_scale; d.ext_factor = rp.ext_factor; d.attn_factor = rp.attn_factor;
@@ -291,7 +301,7 @@ static __device__ __forceinline__ float op_gelu_quick(float x) { return x * (1.0
 static __device__ __forceinline__ float op_gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 
 __global__ void __launch_bounds__(256) k_glu(int op, const char * __restrict__ a, int64_t a_rs, const char * __restrict__ b, int64_t b_rs,
-                                            char * __restrict__ y, int64_t y_rs, int64_t nc, int64_t nr) {
+                                            char * __restrict__ y, int64_t y_rs, int64_t nc, int64_t nr, char * __restrict__ y16, int64_t y16_rs) {
     const int64_t t = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= nc * nr) return;
     const int64_t r = t / nc, i = t % nc;
@@ -306,10 +316,11 @@ __global__ void __launch_bounds__(256) k_glu(int op, const char * __restrict__ a
         case GGML_GLU_OP_GEGLU_QUICK: v = op_gelu_quick(x) * g; break;
         default: v = 0.0f;
     }
-    ((float *) (y + r * y_rs))[i] = v;
+    if (y)   ((float *) (y + r * y_rs))[i] = v;
+    if (y16) ((uint16_t *) (y16 + r * y16_rs))[i] = f2h(v);           // activation image of the following GEMM
 }
 
-void glu_f32(int glu_op, const tdesc & a, const tdesc * b, bool swapped, const tdesc & y, hipStream_t st) {
+void glu_f32(int glu_op, const tdesc & a, const tdesc * b, bool swapped, const tdesc & y, hipStream_t st, uint16_t * y16, size_t y16_rs, bool write_f32) {
     // rows are contiguous_1 (checked by supports_op): treat as [nc, nr] with a row stride
     const int64_t nc = y.ne[0];
     const int64_t nr = y.ne[1] * y.ne[2] * y.ne[3];
@@ -318,7 +329,7 @@ void glu_f32(int glu_op, const tdesc & a, const tdesc * b, bool swapped, const t
     int64_t a_rs = (int64_t) a.nb[1], b_rs;
     if (b) { bp = (const char *) b->p; b_rs = (int64_t) b->nb[1]; }
     else   { bp = ap + (swapped ? 0 : nc * 4); ap = ap + (swapped ? nc * 4 : 0); b_rs = a_rs; }
-    k_glu<<<dim3((unsigned) ((nc * nr + 255) / 256)), dim3(256), 0, st>>>(glu_op, ap, a_rs, bp, b_rs, (char *) y.p, (int64_t) y.nb[1], nc, nr);
+    k_glu<<<dim3((unsigned) ((nc * nr + 255) / 256)), dim3(256), 0, st>>>(glu_op, ap, a_rs, bp, b_rs, write_f32 ? (char *) y.p : nullptr, (int64_t) y.nb[1], nc, nr, (char *) y16, (int64_t) y16_rs);
 }
 
 __global__ void __launch_bounds__(256) k_unary(int op, const float * __restrict__ x, float * __restrict__ y, int64_t n) {

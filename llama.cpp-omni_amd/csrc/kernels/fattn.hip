@@ -276,6 +276,7 @@ static size_t fa_lds_bytes() { return (size_t) R * D * 4 + NW * 16 * R * 4 + NW 
 static bool fa_use_mma(const fattn_args & f) {
     return f.q.ne[1] > 8 && !f.img && (f.q.ne[0] == 64 || f.q.ne[0] == 128) && fattn_mma_ok(f.k.ne[1]);
 }
+bool fattn_uses_mma(const fattn_args & f) { return fa_use_mma(f); }
 size_t fattn_map_bytes(int64_t nq, int64_t nkv, int64_t mne2, int64_t mne3);
 size_t fattn_scratch_bytes(const fattn_args & f) {
     if (!fa_use_mma(f) || !f.mask) return 0;
@@ -352,6 +353,7 @@ void flash_attn_ext_f16(const fattn_args & f, hipStream_t st) {
     a.hpw = a.qpw = 1;
     a.img = (char *) f.img; a.img_bytes = f.img ? q8k_image_bytes(a.nh * f.q.ne[0]) : 0;
     a.pre.qraw = nullptr;
+    a.out16 = (char *) f.out16; a.out16_rs = (int64_t) f.out16_rs; a.write_f32 = f.write_f32 ? 1 : 0;
     if (f.pre) {
         if (!fattn_pre_ok(f)) { fprintf(stderr, "[mi355x] flash_attn: q/k/v pre-stage requested for an unsupported shape\n"); abort(); }
         const fattn_pre & p = *f.pre;

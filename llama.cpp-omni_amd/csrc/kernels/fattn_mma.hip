@@ -281,7 +281,12 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2)
                 f32x4 o4;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) o4[i] = acc_o[db][4 * g + i] * inv;
-                *(f32x4 *) (out + (db * 32 + 8 * g + 4 * hb) * 4) = o4;
+                if (a.write_f32) *(f32x4 *) (out + (db * 32 + 8 * g + 4 * hb) * 4) = o4;
+                if (a.out16) {
+                    u32x2 hw;
+                    hw[0] = (uint32_t) f2h(o4[0]) | ((uint32_t) f2h(o4[1]) << 16); hw[1] = (uint32_t) f2h(o4[2]) | ((uint32_t) f2h(o4[3]) << 16);
+                    *(u32x2 *) (a.out16 + ((int64_t) is3 * a.nq + q) * a.out16_rs + ((int64_t) h * D + db * 32 + 8 * g + 4 * hb) * 2) = hw;
+                }
             }
     }
 }
