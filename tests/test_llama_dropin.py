@@ -27,12 +27,14 @@ def _greedy(gguf, ngl, fa, dump, env_extra=None):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("fa", [1, 0])
-def test_reference_libllama_drives_the_plugin(tmp_path, fa):
+@pytest.mark.parametrize("config,types,fa", [("tiny", "q4_k_m", 1), ("tiny", "q4_k_m", 0),
+                                             # the omni TTS decoder's family: arch llama (RoPE NORM, no q/k-norm), Q8_0 / F16 weights
+                                             ("tts-tiny", "q8_0", 1), ("tts-tiny", "f16", 1), ("tts-tiny", "q8_0", 0)])
+def test_reference_libllama_drives_the_plugin(tmp_path, config, types, fa):
     if not os.path.exists(BIN):
         pytest.skip("oracle/_ref/llama-bench-min not built (make -f oracle/Makefile.ref llama)")
     gguf = str(tmp_path / "tiny.gguf")
-    subprocess.run([sys.executable, os.path.join(ROOT, "tools", "make_synth_gguf.py"), "--config", "tiny", "--types", "q4_k_m", "-o", gguf,
+    subprocess.run([sys.executable, os.path.join(ROOT, "tools", "make_synth_gguf.py"), "--config", config, "--types", types, "-o", gguf,
                     "--distinct-layers"], check=True, timeout=300)
     ids_cpu, l_cpu, _ = _greedy(gguf, 0, fa, str(tmp_path / "cpu.bin"))
     ids_gpu, l_gpu, err = _greedy(gguf, 99, fa, str(tmp_path / "gpu.bin"), {"GGML_BACKEND_PATH": LIB})

@@ -43,7 +43,8 @@ def kv_str(k, v):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--config", choices=["8b", "tiny"], default="8b")
+    ap.add_argument("--config", choices=["8b", "tiny", "tts", "tts-tiny"], default="8b",
+                    help="8b / tiny: qwen3 arch; tts / tts-tiny: the omni TTS decoder's shape (arch llama, RoPE NORM, no q/k-norm; SURVEY.md 8(f) rank 2)")
     ap.add_argument("--types", choices=["q4_k_m", "f16", "q8_0"], default="q4_k_m")
     ap.add_argument("-o", "--out", required=True)
     ap.add_argument("--seed", type=int, default=1234)
@@ -54,7 +55,10 @@ def main():
     load_pkg()
     from llama_cpp_omni_amd import qwen3
     from llama_cpp_omni_amd.ggml import GGML_TYPE_F16, GGML_TYPE_F32, GGML_TYPE_Q4_K, GGML_TYPE_Q8_0, row_size
-    cfg = qwen3.QWEN3_8B if args.config == "8b" else qwen3.TINY
+    TTS = dict(n_embd=768, n_layer=20, n_head=12, n_head_kv=12, head_dim=64, n_ff=3072, n_vocab=32000, rms_eps=1e-6, rope_base=1e4, n_ctx_orig=4096)
+    TTS_TINY = dict(n_embd=256, n_layer=2, n_head=4, n_head_kv=4, head_dim=64, n_ff=512, n_vocab=512, rms_eps=1e-6, rope_base=1e4, n_ctx_orig=4096)
+    is_llama = args.config.startswith("tts")
+    cfg = {"8b": qwen3.QWEN3_8B, "tiny": qwen3.TINY, "tts": TTS, "tts-tiny": TTS_TINY}[args.config]
     if args.types == "q4_k_m":
         types, embd_ty, ftype = qwen3.q4_k_m_types(cfg), GGML_TYPE_Q4_K, 15        # LLAMA_FTYPE_MOSTLY_Q4_K_M
     elif args.types == "f16":
@@ -69,8 +73,10 @@ def main():
         t = types[il]
         tensors += [(f"blk.{il}.attn_norm.weight", GGML_TYPE_F32, (E,)), (f"blk.{il}.attn_q.weight", t["attn_q"], (E, H * D)),
                     (f"blk.{il}.attn_k.weight", t["attn_k"], (E, HK * D)), (f"blk.{il}.attn_v.weight", t["attn_v"], (E, HK * D)),
-                    (f"blk.{il}.attn_output.weight", t["attn_output"], (H * D, E)), (f"blk.{il}.attn_q_norm.weight", GGML_TYPE_F32, (D,)),
-                    (f"blk.{il}.attn_k_norm.weight", GGML_TYPE_F32, (D,)), (f"blk.{il}.ffn_norm.weight", GGML_TYPE_F32, (E,)),
+                    (f"blk.{il}.attn_output.weight", t["attn_output"], (H * D, E))]
+        if not is_llama:
+            tensors += [(f"blk.{il}.attn_q_norm.weight", GGML_TYPE_F32, (D,)), (f"blk.{il}.attn_k_norm.weight", GGML_TYPE_F32, (D,))]
+        tensors += [(f"blk.{il}.ffn_norm.weight", GGML_TYPE_F32, (E,)),
                     (f"blk.{il}.ffn_gate.weight", t["ffn_gate"], (E, F)), (f"blk.{il}.ffn_up.weight", t["ffn_up"], (E, F)),
                     (f"blk.{il}.ffn_down.weight", t["ffn_down"], (F, E))]
 
@@ -78,7 +84,7 @@ def main():
         rows = int(np.prod(ne[1:])) if len(ne) > 1 else 1
         return row_size(ty, ne[0]) * rows
 
-    arch = "qwen3"
+    arch = "llama" if is_llama else "qwen3"
     kvs = [kv_str("general.architecture", arch), kv_str("general.name", f"qwen3-{args.config}-{args.types}-synthetic"), kv_u32("general.file_type", ftype),
            kv_u32("general.quantization_version", 2), kv_u32("general.alignment", ALIGN),
            kv_u32(f"{arch}.block_count", L), kv_u32(f"{arch}.context_length", args.n_ctx), kv_u32(f"{arch}.embedding_length", E),
@@ -86,6 +92,8 @@ def main():
            kv_u32(f"{arch}.attention.key_length", D), kv_u32(f"{arch}.attention.value_length", D),
            kv_f32(f"{arch}.attention.layer_norm_rms_epsilon", cfg["rms_eps"]), kv_f32(f"{arch}.rope.freq_base", cfg["rope_base"]),
            kv_u32(f"{arch}.vocab_size", V), kv_str("tokenizer.ggml.model", "no_vocab")]
+    if is_llama:
+        kvs.append(kv_u32(f"{arch}.rope.dimension_count", D))
 
     offs, off = [], 0
     for _, ty, ne in tensors:
