@@ -440,11 +440,13 @@ __global__ void __launch_bounds__(256) k_mmv_pair(const char * __restrict__ Wg, 
 // ------------------------------------------------------------------------------------------------ launch
 static const size_t MMVK_LDS_MAX = 152 * 1024;
 
-// workgroups per launch are capped at (resident workgroups per CU) x 256 CUs so that a big matrix is one wave of workgroups
-// that grid-stride over the row groups (no second, partially filled wave); MI355X_MMV_WGS overrides for tuning
+// workgroups per launch are capped at (resident workgroups per CU) x 256 CUs = 1024 (occupancy 4 waves/SIMD), so that a big matrix
+// is ONE resident wave of workgroups that grid-stride over the row groups: 12288 gate/up rows = exactly 3 per wave.  Measured on
+// the ffn_gate+ffn_up launch: 1024 -> 13.4 us, 2048 -> 14.2 us (1.5 rows per wave: uneven tail), 3072 -> 15.2 us.
+// MI355X_MMV_WGS overrides for tuning
 static int mmv_grid_cap() {
     static int cap = 0;
-    if (!cap) { const char * e = getenv("MI355X_MMV_WGS"); cap = e ? atoi(e) : 2048; if (cap < 1) cap = 2048; }
+    if (!cap) { const char * e = getenv("MI355X_MMV_WGS"); cap = e ? atoi(e) : 1024; if (cap < 1) cap = 1024; }
     return cap;
 }
 
