@@ -1155,7 +1155,13 @@ enum ggml_status graph_compute(backend_ctx * c, ggml_cgraph * g) {
     int n_real = 0;
     for (int i = 0; i < g->n_nodes; ++i) n_real += !is_noop(g->nodes[i]);
 
-    const bool try_graph = c->opt_graphs && !c->opt_profile && n_real >= 8;
+    // hipGraph replay pays for launch-bound graphs (decode: hundreds of ~5 us kernels).  A prefill ubatch runs 50-100 us kernels, the
+    // host stays far ahead of the device when it simply enqueues them, and capture + instantiation would cost a submission several ms
+    int64_t max_cols = 0;
+    for (int i = 0; i < g->n_nodes; ++i)
+        if (g->nodes[i]->op == GGML_OP_MUL_MAT && g->nodes[i]->src[1]->ne[1] > max_cols) max_cols = g->nodes[i]->src[1]->ne[1];
+    static const int64_t graph_max_cols = getenv("MI355X_GRAPH_MAX_COLS") ? atoll(getenv("MI355X_GRAPH_MAX_COLS")) : 32;
+    const bool try_graph = c->opt_graphs && !c->opt_profile && n_real >= 8 && max_cols <= graph_max_cols;
     if (try_graph) {
         const uint64_t fp = fingerprint(g);
         graph_exec * ge = nullptr;
