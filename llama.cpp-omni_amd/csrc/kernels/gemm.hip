@@ -139,8 +139,14 @@ struct gemm_dev {
     int ne12, r2, r3; size_t w_nb2, w_nb3, x_bs, dst_nb2, dst_nb3;
 };
 
+// MB = 32-row MFMA tiles per wave along m: the workgroup tile is (64*MB) x 128.  MB = 2 is the default; MB = 3 (192 x 128) is chosen
+// by the launcher when it removes a partially filled round of workgroups (ffn_gate+ffn_up at ubatch 512: 768 tiles of 128 rows are
+// 1.5 rounds of the 512 resident workgroups, 512 tiles of 192 rows are exactly one).
+extern __shared__ __attribute__((aligned(16))) char gemm_lds[];
+template <int MB>
 __global__ void __launch_bounds__(256) k_gemm_f16_glds(const gemm_dev g) {
-    __shared__ __attribute__((aligned(16))) char lds[2][2][H_TILEB];          // [buffer][W | X]
+    constexpr int BM = 64 * MB, WTILEB = BM * H_ROWB, BUFB = WTILEB + H_TILEB;  // per buffer: W tile then X tile
+    char * const lds = gemm_lds;
 
     const int nt    = g.tiles_m * g.tiles_n;
     const int split = blockIdx.x / nt;
@@ -156,36 +162,42 @@ __global__ void __launch_bounds__(256) k_gemm_f16_glds(const gemm_dev g) {
     const size_t w_rs = mi == 0 ? g.w_rs[0] : (mi == 1 ? g.w_rs[1] : g.w_rs[2]);
     const int M = mi == 0 ? g.M[0] : (mi == 1 ? g.M[1] : g.M[2]);
     const int N = g.N;
-    const int m0 = tm * G_BM, n0 = tn * G_BN;
+    const int m0 = tm * BM, n0 = tn * G_BN;
 
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int wm = wave & 1, wn = wave >> 1;
 
-    // staging: wave w fills rows [32w, 32w+32) of both operand tiles, 8 rows per instruction
+    // staging: wave w fills rows [16*MB*w, +16*MB) of the W tile and [32w, 32w+32) of the X tile, 8 rows per instruction
+    // (16*MB*w and 32w are multiples of 16, so the swizzle term (row >> 1) & 7 only depends on j and r8)
     const int r8 = lane >> 3;
-    const char * wp[4]; const char * xp[4];
+    const char * wp[2 * MB]; const char * xp[4];
+#pragma unroll
+    for (int j = 0; j < 2 * MB; ++j) {
+        const int gc = (lane & 7) ^ (((j * 8 + r8) >> 1) & 7);       // source chunk that lands in LDS chunk (lane & 7) of that row
+        int mr = m0 + wave * 16 * MB + j * 8 + r8; mr = mr < M ? mr : M - 1;
+        wp[j] = W + (size_t) mr * w_rs + gc * 16;
+    }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        const int gc = (lane & 7) ^ (((j * 8 + r8) >> 1) & 7);       // source chunk that lands in LDS chunk (lane & 7) of row 32w+8j+r8
-        int mr = m0 + wave * 32 + j * 8 + r8; mr = mr < M ? mr : M - 1;
+        const int gc = (lane & 7) ^ (((j * 8 + r8) >> 1) & 7);
         int nr = n0 + wave * 32 + j * 8 + r8; nr = nr < N ? nr : N - 1;
-        wp[j] = W + (size_t) mr * w_rs + gc * 16;
         xp[j] = g.X + (size_t) blockIdx.y * g.x_bs + (size_t) nr * g.x_rs + gc * 16;
     }
     auto stage = [&](int buf, int ks) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            __builtin_amdgcn_global_load_lds((gbl_ptr_t) (wp[j] + (size_t) ks * H_ROWB), (lds_ptr_t) (&lds[buf][0][(wave * 32 + j * 8) * H_ROWB]), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((gbl_ptr_t) (xp[j] + (size_t) ks * H_ROWB), (lds_ptr_t) (&lds[buf][1][(wave * 32 + j * 8) * H_ROWB]), 16, 0, 0);
-        }
+        for (int j = 0; j < 2 * MB; ++j)
+            __builtin_amdgcn_global_load_lds((gbl_ptr_t) (wp[j] + (size_t) ks * H_ROWB), (lds_ptr_t) (lds + buf * BUFB + (wave * 16 * MB + j * 8) * H_ROWB), 16, 0, 0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            __builtin_amdgcn_global_load_lds((gbl_ptr_t) (xp[j] + (size_t) ks * H_ROWB), (lds_ptr_t) (lds + buf * BUFB + WTILEB + (wave * 32 + j * 8) * H_ROWB), 16, 0, 0);
     };
 
-    f16v acc[2][2];
+    f16v acc[2][MB];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
+        for (int b = 0; b < MB; ++b)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.0f;
 
@@ -198,19 +210,19 @@ __global__ void __launch_bounds__(256) k_gemm_f16_glds(const gemm_dev g) {
         const int cur = (ks - k_lo) & 1;
         __syncthreads();                                   // tile ks has landed (the fence drains the DMA), buffer cur^1 is free
         if (ks + 1 < k_hi) stage(cur ^ 1, ks + 1);
-        const char * wb = &lds[cur][0][0]; const char * xb = &lds[cur][1][0];
+        const char * wb = lds + cur * BUFB; const char * xb = wb + WTILEB;
 #pragma unroll
         for (int kk = 0; kk < H_BK / 16; ++kk) {
             const int co = ((kk * 2 + hb) ^ sw) << 4;
-            h8 af[2], bf[2];
+            h8 af[2], bf[MB];
 #pragma unroll
             for (int a = 0; a < 2; ++a) af[a] = *(const h8 *) (xb + (wn * 64 + a * 32 + fr) * H_ROWB + co);
 #pragma unroll
-            for (int b = 0; b < 2; ++b) bf[b] = *(const h8 *) (wb + (wm * 64 + b * 32 + fr) * H_ROWB + co);
+            for (int b = 0; b < MB; ++b) bf[b] = *(const h8 *) (wb + (wm * 32 * MB + b * 32 + fr) * H_ROWB + co);
 #pragma unroll
             for (int a = 0; a < 2; ++a)
 #pragma unroll
-                for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[a], bf[b], acc[a][b], 0, 0, 0);
+                for (int b = 0; b < MB; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[a], bf[b], acc[a][b], 0, 0, 0);
         }
     }
 
@@ -221,8 +233,8 @@ __global__ void __launch_bounds__(256) k_gemm_f16_glds(const gemm_dev g) {
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int b = 0; b < 2; ++b) {
-            const int m = m0 + wm * 64 + b * 32 + (lane & 31);
+        for (int b = 0; b < MB; ++b) {
+            const int m = m0 + wm * 32 * MB + b * 32 + (lane & 31);
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int n = n0 + wn * 64 + a * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
@@ -282,12 +294,21 @@ void gemm_f16_multi(const gemm_multi_args & a, hipStream_t st) {
         return;
     }
     gemm_dev g;
+    // workgroup tile height: 192 rows when that removes a partially filled round of the 512 resident workgroups
+    auto count_tm = [&](int bm) { int t = 0; for (int i = 0; i < a.nmat; ++i) t += (int) ((a.m[i].M + bm - 1) / bm); return t; };
+    int BM = G_BM;
+    {
+        static const bool no192 = getenv("MI355X_GEMM_NO_192") != nullptr;
+        const int64_t t128 = (int64_t) count_tm(128) * tiles_n, t192 = (int64_t) count_tm(192) * tiles_n;
+        const int64_t c128 = ((t128 + 511) / 512) * 128, c192 = ((t192 + 511) / 512) * 192;
+        if (!no192 && a.nbatch <= 1 && t128 > 512 && c192 < c128) BM = 192;
+    }
     int tm = 0;
     for (int i = 0; i < 3; ++i) {
         const gemm_mat & m = a.m[i < a.nmat ? i : 0];
         g.W[i] = (const char *) m.W; g.w_rs[i] = m.w_rs; g.dst[i] = (char *) m.dst; g.dst_cs[i] = m.dst_cs;
         g.resid[i] = (const char *) m.resid; g.resid_cs[i] = m.resid_cs; g.M[i] = (int) m.M;
-        if (i < a.nmat) tm += (int) ((m.M + G_BM - 1) / G_BM);
+        if (i < a.nmat) tm += (int) ((m.M + BM - 1) / BM);
         g.tm_end[i] = tm;
     }
     g.nmat = a.nmat; g.X = (const char *) a.X; g.x_rs = a.x_rs; g.N = (int) a.N; g.K = (int) a.K; g.tiles_m = tm; g.tiles_n = tiles_n;
@@ -296,19 +317,26 @@ void gemm_f16_multi(const gemm_multi_args & a, hipStream_t st) {
     g.w_nb2 = a.w_nb2; g.w_nb3 = a.w_nb3; g.x_bs = a.x_bs; g.dst_nb2 = a.dst_nb2; g.dst_nb3 = a.dst_nb3;
     const int nk = (int) (a.K / H_BK);
     int ksplit = 1;
-    if (a.nmat == 1 && nbatch == 1 && a.partial && a.m[0].M % 4 == 0) ksplit = pick_ksplit((int64_t) tm * tiles_n, nk);
+    if (BM == G_BM && a.nmat == 1 && nbatch == 1 && a.partial && a.m[0].M % 4 == 0) ksplit = pick_ksplit((int64_t) tm * tiles_n, nk);
     g.ksteps_per_split = (nk + ksplit - 1) / ksplit; g.split_stride = 0;
     if (tm == 0) return;
     if (ksplit > 1) {
         const gemm_mat & m = a.m[0];
         g.dst[0] = (char *) a.partial; g.dst_cs[0] = (size_t) m.M * 4; g.resid[0] = nullptr; g.split_stride = (size_t) m.M * (size_t) a.N * 4;
-        k_gemm_f16_glds<<<dim3((unsigned) (tm * tiles_n * ksplit)), dim3(256), 0, st>>>(g);
+        k_gemm_f16_glds<2><<<dim3((unsigned) (tm * tiles_n * ksplit)), dim3(256), 2 * (128 * H_ROWB + H_TILEB), st>>>(g);
         const int64_t quads = m.M * a.N / 4;
         k_gemm_reduce<<<dim3((unsigned) ((quads + 255) / 256)), dim3(256), 0, st>>>(a.partial, ksplit, (size_t) m.M * (size_t) a.N, (const char *) m.resid, m.resid_cs,
                                                                                   (char *) m.dst, m.dst_cs, (int) m.M, (int) a.N);
         return;
     }
-    k_gemm_f16_glds<<<dim3((unsigned) (tm * tiles_n), (unsigned) nbatch), dim3(256), 0, st>>>(g);
+    if (BM == 192) {
+        constexpr int lds192 = 2 * (192 * H_ROWB + H_TILEB);        // 80 KB: two workgroups per CU
+        static bool attr_set = false;
+        if (!attr_set) { HIP_CHECK(hipFuncSetAttribute((const void *) k_gemm_f16_glds<3>, hipFuncAttributeMaxDynamicSharedMemorySize, lds192)); attr_set = true; }
+        k_gemm_f16_glds<3><<<dim3((unsigned) (tm * tiles_n), (unsigned) nbatch), dim3(256), lds192, st>>>(g);
+    } else {
+        k_gemm_f16_glds<2><<<dim3((unsigned) (tm * tiles_n), (unsigned) nbatch), dim3(256), 2 * (128 * H_ROWB + H_TILEB), st>>>(g);
+    }
 }
 
 void gemm_f16_mfma(const uint16_t * W, size_t w_rs, const uint16_t * X, size_t x_rs, float * dst, size_t dst_cs,
