@@ -302,6 +302,8 @@ void gemm_f16_multi(const gemm_multi_args & a, hipStream_t st) {
         const int64_t t128 = (int64_t) count_tm(128) * tiles_n, t192 = (int64_t) count_tm(192) * tiles_n;
         const int64_t c128 = ((t128 + 511) / 512) * 128, c192 = ((t192 + 511) / 512) * 192;
         if (!no192 && a.nbatch <= 1 && t128 > 512 && c192 < c128) BM = 192;
+        // (64-row tiles for launches with fewer 128-row tiles than CUs -- qkv at ubatch 512 is 192 -- measured neutral; tuning override:)
+        if (const char * e = getenv("MI355X_GEMM_BM")) { const int f = atoi(e); if (f == 64 || f == 128 || f == 192) BM = f; }
     }
     int tm = 0;
     for (int i = 0; i < 3; ++i) {
@@ -329,7 +331,9 @@ void gemm_f16_multi(const gemm_multi_args & a, hipStream_t st) {
                                                                                   (char *) m.dst, m.dst_cs, (int) m.M, (int) a.N);
         return;
     }
-    if (BM == 192) {
+    if (BM == 64) {
+        k_gemm_f16_glds<1><<<dim3((unsigned) (tm * tiles_n), (unsigned) nbatch), dim3(256), 2 * (64 * H_ROWB + H_TILEB), st>>>(g);
+    } else if (BM == 192) {
         constexpr int lds192 = 2 * (192 * H_ROWB + H_TILEB);        // 80 KB: two workgroups per CU
         static bool attr_set = false;
         if (!attr_set) { HIP_CHECK(hipFuncSetAttribute((const void *) k_gemm_f16_glds<3>, hipFuncAttributeMaxDynamicSharedMemorySize, lds192)); attr_set = true; }
