@@ -67,6 +67,9 @@ struct exec_state {
     struct { const ggml_tensor * m = nullptr; const ggml_tensor * x = nullptr; const ggml_tensor * wt = nullptr; float eps = 0; int left = 0; } pn;
     // deferred q chain + k chain/store + v store of a decode layer: executed by the FLASH_ATTN_EXT node `fa` itself (fattn_pre)
     struct { int fa = -1; fattn_pre pre; int kst = -1, vst = -1; } pq;
+    // deferred split-K reduction: `A` (the mat-mul + residual result) still lies as `nsplit` slabs in gemm_partial; the RMS_NORM that
+    // reads it next folds the reduction in (gemm_reduce_rms_norm), anything else materialises it first
+    struct { const ggml_tensor * A = nullptr; int nsplit = 0; const float * resid = nullptr; size_t resid_cs = 0; } pr;
     // mask whose tile map currently sits in fa_scratch
     const void *  fa_mask = nullptr; int64_t fa_dims[4] = {0, 0, 0, 0}; size_t fa_mnb1 = 0;
 };
@@ -520,6 +523,13 @@ static bool norm_in_kernel(exec_state & s, const ggml_tensor * x, const ggml_ten
 // prefill: MUL_MAT at node i goes to the MFMA GEMM together with the other MUL_MATs that consume the same activation (wq / wk / wv,
 // ffn_gate / ffn_up: one launch fills the chip where wk alone is 32 tiles), with the residual ADD folded into the epilogue; a lone
 // under-filled matrix (wo, ffn_down at ubatch 512) is split along K instead.  Returns false when the plain path must run.
+static void materialise_reduce(exec_state & s) {
+    const ggml_tensor * A = s.pr.A;
+    s.pr.A = nullptr;
+    prof_scope ps(s, "gemm_reduce", 0);
+    gemm_reduce((const float *) s.c->gemm_partial, s.pr.nsplit, s.pr.resid, s.pr.resid_cs, (float *) A->data, A->nb[1], A->ne[0], A->ne[1], s.st);
+    ++s.n_kernels;
+}
 static bool gemm_operand(exec_state & s, const ggml_tensor * w, const uint16_t ** w16, size_t * rs) {
     if (w->ne[2] != 1 || w->ne[3] != 1) return false;
     if (w->type == GGML_TYPE_F16) { *w16 = (const uint16_t *) w->data; *rs = w->nb[1]; return true; }
@@ -583,11 +593,22 @@ static bool exec_gemm_group(exec_state & s, int i) {
     if (a.nmat == 1 && a.m[0].dst_cs % 16 == 0 && gemm_split_scratch_bytes(a.m[0].M, N, K) <= s.c->gemm_partial_bytes) a.partial = (float *) s.c->gemm_partial;
     double flops = 0;
     for (int q = 0; q < a.nmat; ++q) flops += 2.0 * (double) a.m[q].M * (double) N * (double) K;
+    // a split-K result whose next reader is RMS_NORM (wo / ffn_down + residual -> the next norm): leave the slabs, the norm reduces them
+    int nsplit = 0;
+    const ggml_tensor * Aout = a.nmat == 1 ? g->nodes[add_idx[0] >= 0 ? add_idx[0] : i] : nullptr;
+    static const bool no_defer_reduce = getenv("MI355X_NO_REDUCE_IN_NORM") != nullptr;
+    if (!no_defer_reduce && a.partial && Aout && Aout->ne[2] == 1 && Aout->ne[3] == 1 && gemm_reduce_rms_norm_ok(Aout->ne[0]) && Aout->nb[1] % 16 == 0 &&
+        (!a.m[0].resid || a.m[0].resid_cs % 16 == 0)) {
+        int nx = (add_idx[0] >= 0 ? add_idx[0] : i) + 1;
+        while (nx < g->n_nodes && (s.done[nx] || is_noop(g->nodes[nx]) || nx == add_idx[0])) ++nx;
+        if (nx < g->n_nodes && g->nodes[nx]->op == GGML_OP_RMS_NORM && g->nodes[nx]->src[0] == Aout) a.deferred_split = &nsplit;
+    }
     {
         prof_scope ps(s, "gemm_f16", flops);
         gemm_f16_multi(a, s.st);
     }
     ++s.n_kernels;
+    if (nsplit > 1) { s.pr.A = Aout; s.pr.nsplit = nsplit; s.pr.resid = a.m[0].resid; s.pr.resid_cs = a.m[0].resid_cs; }
     for (int q = 0; q < a.nmat; ++q) {
         if (q > 0) { s.done[mm_idx[q]] = 1; ++s.n_fused; }
         if (add_idx[q] >= 0) { s.done[add_idx[q]] = 1; ++s.n_fused; note_write(s, g->nodes[add_idx[q]]); }
@@ -830,6 +851,8 @@ static bool exec_rms_norm(exec_state & s, int i) {
     ggml_cgraph * g = s.g;
     ggml_tensor * n = g->nodes[i];
     const float eps = op_param_f32(n, 0);
+    // (a pending split-K result is folded in only by the plain 2-D norm + mul path at the end; every other path reads it from memory)
+    if (s.pr.A && s.pr.A == n->src[0] && !(n->ne[2] == 1 && n->ne[3] == 1 && n->ne[1] > MI_MMVQ_MAX_COLS && n->ne[0] > 256)) materialise_reduce(s);
     if (!s.c->opt_fusion) return false;
     const int mi_ = sole_user(s, n);
     if (mi_ != i + 1 || g->nodes[mi_]->op != GGML_OP_MUL) return false;
@@ -948,7 +971,19 @@ static bool exec_rms_norm(exec_state & s, int i) {
     const tdesc wd = td(wt);
     const ggml_tensor * xg = nullptr;
     const bool emit16 = n->ne[2] == 1 && n->ne[3] == 1 && m->nb[1] == (size_t) m->ne[0] * 4 && gemm_only_consumers(s, m, m->ne[0], m->ne[1], &xg);
-    {
+    const bool from_split = s.pr.A && s.pr.A == n->src[0];
+    if (from_split && !(n->ne[2] == 1 && n->ne[3] == 1 && wt->ne[0] == n->ne[0] && wt->ne[1] * wt->ne[2] * wt->ne[3] == 1 && m->nb[1] % 16 == 0 && ((uintptr_t) wt->data & 15) == 0))
+        materialise_reduce(s);
+    if (s.pr.A && s.pr.A == n->src[0]) {
+        // the norm's input still lies as split-K slabs: reduce, add the residual, write it, and normalise in one pass
+        const ggml_tensor * A = s.pr.A;
+        const bool w32 = !emit16 || n_users(s, m) > 1;
+        prof_scope ps(s, "rms_norm_mul", 0);
+        gemm_reduce_rms_norm((const float *) s.c->gemm_partial, s.pr.nsplit, s.pr.resid, s.pr.resid_cs, (float *) A->data, A->nb[1], (const float *) wt->data, eps,
+                             w32 ? (float *) m->data : nullptr, m->nb[1], emit16 ? (uint16_t *) s.c->act_scratch : nullptr, act_image_bytes(ACT_F16, m->ne[0]),
+                             A->ne[0], A->ne[1], s.st);
+        s.pr.A = nullptr; ++s.n_fused;
+    } else {
         prof_scope ps(s, "rms_norm_mul", 0);
         if (emit16) rms_norm(td(n->src[0]), td(m), eps, &wd, s.st, (uint16_t *) s.c->act_scratch, act_image_bytes(ACT_F16, m->ne[0]), n_users(s, m) > 1);
         else        rms_norm(td(n->src[0]), td(m), eps, &wd, s.st);
@@ -964,6 +999,7 @@ static void compute_node(exec_state & s, int i) {
     ggml_cgraph * g = s.g;
     ggml_tensor * n = g->nodes[i];
     if (is_noop(n)) return;
+    if (s.pr.A && !(n->op == GGML_OP_RMS_NORM && n->src[0] == s.pr.A)) materialise_reduce(s);      // somebody else reads the split-K result first
 
     switch (n->op) {
         case GGML_OP_MUL_MAT:
@@ -971,6 +1007,7 @@ static void compute_node(exec_state & s, int i) {
             return;
         case GGML_OP_RMS_NORM: {
             if (exec_rms_norm(s, i)) return;
+            if (s.pr.A) materialise_reduce(s);
             prof_scope ps(s, "rms_norm", 0);
             rms_norm(td(n->src[0]), td(n), op_param_f32(n, 0), nullptr, s.st); ++s.n_kernels;
             break;

@@ -155,7 +155,15 @@ struct gemm_multi_args {
     // broadcast batch (nmat == 1, K % 64 == 0): nbatch = ne12 * ne13 products in one launch; batch b = i13 * ne12 + i12 reads
     // W + (i12 / r2) * w_nb2 + (i13 / r3) * w_nb3 and X + b * x_bs, writes dst + i12 * dst_nb2 + i13 * dst_nb3
     int nbatch = 1, ne12 = 1, r2 = 1, r3 = 1; size_t w_nb2 = 0, w_nb3 = 0, x_bs = 0, dst_nb2 = 0, dst_nb3 = 0;
+    // non-null: when a split-K is chosen the reduction is NOT run; *deferred_split = number of [N][M] slabs left in `partial` (0: none,
+    // dst is complete) and the caller owes gemm_reduce() or gemm_reduce_rms_norm()
+    int * deferred_split = nullptr;
 };
+void   gemm_reduce(const float * partial, int nsplit, const float * resid, size_t resid_cs, float * dst, size_t dst_cs, int64_t M, int64_t N, hipStream_t st);
+// the same reduction fused with the RMS_NORM -> MUL(w) of the result: dst = sum + resid (f32); y = rms_norm(dst) * w -> y32 / f16 rows y16
+bool   gemm_reduce_rms_norm_ok(int64_t M);
+void   gemm_reduce_rms_norm(const float * partial, int nsplit, const float * resid, size_t resid_cs, float * dst, size_t dst_cs, const float * w, float eps,
+                            float * y32, size_t y32_cs, uint16_t * y16, size_t y16_rs, int64_t M, int64_t N, hipStream_t st);
 void   gemm_f16_multi(const gemm_multi_args & a, hipStream_t st);
 size_t gemm_split_scratch_bytes(int64_t M, int64_t N, int64_t K);
 

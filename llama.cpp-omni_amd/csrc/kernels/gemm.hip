@@ -263,6 +263,64 @@ bool gemm_f16_ok(const void * W, size_t w_rs, const void * X, size_t x_rs, int64
     return K % G_BK == 0 && K >= G_BK && w_rs % 16 == 0 && x_rs % 16 == 0 && ((uintptr_t) W & 15) == 0 && ((uintptr_t) X & 15) == 0;
 }
 
+// split-K reduction fused with the RMS_NORM -> MUL(w) that follows the residual ADD (ops.cpp:3517-3566 arithmetic: sum of squares in
+// double): x = sum_s part[s] + resid -> dst (f32, the next residual); y = (x * scale) * w -> y32 (optional) and / or f16 rows y16
+// (the activation image of the next GEMM).  One workgroup per row, the row stays in registers (M <= 16384, M % 4 == 0).
+__global__ void __launch_bounds__(256) k_gemm_reduce_rms_norm(const float * __restrict__ part, int nsplit, size_t split_elems, const char * __restrict__ resid, size_t resid_cs,
+                                                              char * __restrict__ dst, size_t dst_cs, const float * __restrict__ w, float eps,
+                                                              char * __restrict__ y32, size_t y32_cs, char * __restrict__ y16, size_t y16_rs, int M) {
+    __shared__ double red[4];
+    const int n = blockIdx.x;
+    constexpr int MAXV = 16;
+    f32x4 v[MAXV];
+    double ss = 0.0;
+#pragma unroll
+    for (int k = 0; k < MAXV; ++k) {
+        const int i = (threadIdx.x + k * 256) * 4;
+        v[k] = f32x4{0, 0, 0, 0};
+        if (i < M) {
+            f32x4 a = *(const f32x4 *) (part + (size_t) n * M + i);
+            for (int s = 1; s < nsplit; ++s) { const f32x4 b = *(const f32x4 *) (part + s * split_elems + (size_t) n * M + i); a += b; }
+            if (resid) { const f32x4 b = *(const f32x4 *) (resid + (size_t) n * resid_cs + (size_t) i * 4); a += b; }
+            *(f32x4 *) (dst + (size_t) n * dst_cs + (size_t) i * 4) = a;
+            v[k] = a;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) ss += (double) (a[e] * a[e]);
+        }
+    }
+    ss = block_sum<double>(ss, red);
+    const float mean  = (float) (ss / (double) M);
+    const float scale = 1.0f / sqrtf(mean + eps);
+#pragma unroll
+    for (int k = 0; k < MAXV; ++k) {
+        const int i = (threadIdx.x + k * 256) * 4;
+        if (i >= M) break;
+        const f32x4 ww = *(const f32x4 *) (w + i);
+        f32x4 y;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) y[e] = (v[k][e] * scale) * ww[e];
+        if (y32) *(f32x4 *) (y32 + (size_t) n * y32_cs + (size_t) i * 4) = y;
+        if (y16) {
+            u32x2 h;
+            h[0] = (uint32_t) f2h(y[0]) | ((uint32_t) f2h(y[1]) << 16); h[1] = (uint32_t) f2h(y[2]) | ((uint32_t) f2h(y[3]) << 16);
+            *(u32x2 *) (y16 + (size_t) n * y16_rs + (size_t) i * 2) = h;
+        }
+    }
+}
+
+void gemm_reduce(const float * partial, int nsplit, const float * resid, size_t resid_cs, float * dst, size_t dst_cs, int64_t M, int64_t N, hipStream_t st) {
+    const int64_t quads = M * N / 4;
+    if (quads == 0) return;
+    k_gemm_reduce<<<dim3((unsigned) ((quads + 255) / 256)), dim3(256), 0, st>>>(partial, nsplit, (size_t) M * (size_t) N, (const char *) resid, resid_cs, (char *) dst, dst_cs, (int) M, (int) N);
+}
+bool gemm_reduce_rms_norm_ok(int64_t M) { return M % 4 == 0 && M <= 16384; }
+void gemm_reduce_rms_norm(const float * partial, int nsplit, const float * resid, size_t resid_cs, float * dst, size_t dst_cs, const float * w, float eps,
+                          float * y32, size_t y32_cs, uint16_t * y16, size_t y16_rs, int64_t M, int64_t N, hipStream_t st) {
+    if (M == 0 || N == 0) return;
+    k_gemm_reduce_rms_norm<<<dim3((unsigned) N), dim3(256), 0, st>>>(partial, nsplit, (size_t) M * (size_t) N, (const char *) resid, resid_cs, (char *) dst, dst_cs, w, eps,
+                                                                    (char *) y32, y32_cs, (char *) y16, y16_rs, (int) M);
+}
+
 // choose a K split that brings a lone, under-filled launch up to about two workgroups per CU
 static int pick_ksplit(int64_t tiles, int64_t nk) {
     if (tiles >= 256 || nk < 32) return 1;
@@ -293,6 +351,7 @@ void gemm_f16_multi(const gemm_multi_args & a, hipStream_t st) {
         }
         return;
     }
+    if (a.deferred_split) *a.deferred_split = 0;
     gemm_dev g;
     // workgroup tile height: 192 rows when that removes a partially filled round of the 512 resident workgroups
     auto count_tm = [&](int bm) { int t = 0; for (int i = 0; i < a.nmat; ++i) t += (int) ((a.m[i].M + bm - 1) / bm); return t; };
@@ -326,9 +385,8 @@ void gemm_f16_multi(const gemm_multi_args & a, hipStream_t st) {
         const gemm_mat & m = a.m[0];
         g.dst[0] = (char *) a.partial; g.dst_cs[0] = (size_t) m.M * 4; g.resid[0] = nullptr; g.split_stride = (size_t) m.M * (size_t) a.N * 4;
         k_gemm_f16_glds<2><<<dim3((unsigned) (tm * tiles_n * ksplit)), dim3(256), 2 * (128 * H_ROWB + H_TILEB), st>>>(g);
-        const int64_t quads = m.M * a.N / 4;
-        k_gemm_reduce<<<dim3((unsigned) ((quads + 255) / 256)), dim3(256), 0, st>>>(a.partial, ksplit, (size_t) m.M * (size_t) a.N, (const char *) m.resid, m.resid_cs,
-                                                                                  (char *) m.dst, m.dst_cs, (int) m.M, (int) a.N);
+        if (a.deferred_split) { *a.deferred_split = ksplit; return; }          // the caller fuses the reduction into its next kernel
+        gemm_reduce(a.partial, ksplit, m.resid, m.resid_cs, m.dst, m.dst_cs, m.M, a.N, st);
         return;
     }
     if (BM == 64) {
