@@ -110,9 +110,10 @@ bool supports_op(const ggml_tensor * op) {
         case GGML_OP_MUL_MAT: {
             if (!s0 || !s1) return false;
             const act_kind k = act_kind_for(s0->type);
-            if (k == ACT_NONE || s1->type != GGML_TYPE_F32 || op->type != GGML_TYPE_F32) return false;
+            if (k == ACT_NONE || op->type != GGML_TYPE_F32) return false;
+            if (s1->type != GGML_TYPE_F32 && !(s1->type == GGML_TYPE_F16 && k == ACT_F16)) return false;      // F16 x F16: the convolutions' mat-mul
             if (s0->ne[0] % blck_size(s0->type) != 0) return false;
-            if (s0->nb[0] != type_size(s0->type) || s1->nb[0] != sizeof(float) || op->nb[0] != sizeof(float)) return false;
+            if (s0->nb[0] != type_size(s0->type) || s1->nb[0] != type_size(s1->type) || op->nb[0] != sizeof(float)) return false;
             if (s0->nb[1] < row_size(s0->type, s0->ne[0])) return false;          // transposed weights: not handled
             if (s0->ne[2] == 0 || s0->ne[3] == 0 || s1->ne[2] % s0->ne[2] != 0 || s1->ne[3] % s0->ne[3] != 0) return false;
             if (k == ACT_Q8K || k == ACT_Q80) {
@@ -125,7 +126,12 @@ bool supports_op(const ggml_tensor * op) {
             return s0 && s1 && s0->type == GGML_TYPE_F32 && s1->type == GGML_TYPE_F32 && op->type == GGML_TYPE_F32 &&
                    same_shape(s0, op) && can_repeat(s1, s0);
         case GGML_OP_RMS_NORM:
+        case GGML_OP_NORM:
             return s0 && s0->type == GGML_TYPE_F32 && op->type == GGML_TYPE_F32 && s0->nb[0] == 4 && op->nb[0] == 4;
+        case GGML_OP_IM2COL:
+            // src0 = kernel (shape only), src1 = f32 image with dense [IH, IW] planes, dst dense f16 / f32
+            return s0 && s1 && s1->type == GGML_TYPE_F32 && (op->type == GGML_TYPE_F16 || op->type == GGML_TYPE_F32) && is_contiguous(op) && s1->nb[0] == 4 &&
+                   (op_param_i32(op, 6) != 1 || s1->nb[1] == (size_t) s1->ne[0] * 4) && nelements(op) < ((int64_t) 1 << 40);
         case GGML_OP_SCALE:
             return s0 && s0->type == GGML_TYPE_F32 && op->type == GGML_TYPE_F32 && is_contiguous(s0) && is_contiguous(op);
         case GGML_OP_UNARY: {
@@ -290,7 +296,14 @@ static size_t prepare_act(exec_state & s, const ggml_tensor * x, act_kind kind) 
     };
     prof_scope ps(s, "act_convert", 0);
     const bool flat = (ne12 == 1 || x->nb[2] == (size_t) N * x->nb[1]) && (ne13 == 1 || x->nb[3] == (size_t) ne12 * x->nb[2]);
-    if (flat) {
+    if (x->type == GGML_TYPE_F16) {
+        // F16 x F16 (the MUL_MAT of ggml_conv_1d / ggml_conv_2d: im2col columns against an f16 kernel): the activation rows are already
+        // in the GEMM's format; gather them into the dense image (supports_op admits F16 src1 only next to F16 src0)
+        tdesc d; d.p = s.c->act_scratch; d.ne[0] = K; d.ne[1] = N; d.ne[2] = ne12; d.ne[3] = ne13;
+        d.nb[0] = 2; d.nb[1] = img; d.nb[2] = img * (size_t) N; d.nb[3] = img * (size_t) (N * ne12);
+        cpy_strided(td(x), GGML_TYPE_F16, d, GGML_TYPE_F16, s.st);
+        ++s.n_kernels;
+    } else if (flat) {
         conv((const float *) x->data, x->nb[1], s.c->act_scratch, N * ne12 * ne13);
     } else if (kind == ACT_F16 && N * ne12 * ne13 <= 65535) {            // permuted rows (q seen per head): one strided launch
         convert_f32_f16_rows3((const float *) x->data, x->nb[1], x->nb[2], x->nb[3], N, ne12, ne13, (uint16_t *) s.c->act_scratch, img, K, s.st);
@@ -1005,6 +1018,16 @@ static void compute_node(exec_state & s, int i) {
         case GGML_OP_MUL_MAT:
             exec_mul_mat(s, i);
             return;
+        case GGML_OP_IM2COL: {
+            prof_scope ps(s, "im2col", 0);
+            im2col_f32(td(n->src[0]), td(n->src[1]), td(n), n->type, n->op_params, s.st); ++s.n_kernels;
+            break;
+        }
+        case GGML_OP_NORM: {
+            prof_scope ps(s, "norm", 0);
+            norm_f32(td(n->src[0]), td(n), op_param_f32(n, 0), s.st); ++s.n_kernels;
+            break;
+        }
         case GGML_OP_RMS_NORM: {
             if (exec_rms_norm(s, i)) return;
             if (s.pr.A) materialise_reduce(s);

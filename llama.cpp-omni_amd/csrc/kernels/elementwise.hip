@@ -158,6 +158,73 @@ void rms_norm(const tdesc & x, const tdesc & y, float eps, const tdesc * mul_w, 
 }
 
 // ================================================================================================
+// IM2COL (the data movement half of ggml_conv_1d / ggml_conv_2d; the contraction is a MUL_MAT).
+// reference: ggml_compute_forward_im2col_f16 / _f32, ops.cpp:6150-6301:  [N, IC, IH, IW] -> [N, OH, OW, IC*KH*KW],
+// dst[.., iic*KH*KW + ikh*KW + ikw] = src[iih][iiw] with iiw = iow*s0 + ikw*d0 - p0, iih = ioh*s1 + ikh*d1 - p1, zero outside.
+// ================================================================================================
+struct im2col_dev { int N, IC, IH, IW, KH, KW, OH, OW, s0, s1, p0, p1, d0, d1; int64_t ofs0, ofs1; };
+
+template <typename T>
+__global__ void __launch_bounds__(256) k_im2col(const char * __restrict__ src, T * __restrict__ dst, const im2col_dev a, int64_t total) {
+    const int64_t gid = (int64_t) blockIdx.x * 256 + threadIdx.x;
+    if (gid >= total) return;
+    const int ckk = a.IC * a.KH * a.KW;
+    const int64_t pix = gid / ckk;                      // (in, ioh, iow) flattened
+    const int e = (int) (gid - pix * ckk);
+    const int iic = e / (a.KH * a.KW), k = e - iic * (a.KH * a.KW), ikh = k / a.KW, ikw = k - ikh * a.KW;
+    const int iow = (int) (pix % a.OW); const int64_t t = pix / a.OW;
+    const int ioh = (int) (t % a.OH), in = (int) (t / a.OH);
+    const int iiw = iow * a.s0 + ikw * a.d0 - a.p0, iih = ioh * a.s1 + ikh * a.d1 - a.p1;
+    float v = 0.0f;
+    if (iih >= 0 && iih < a.IH && iiw >= 0 && iiw < a.IW) v = ((const float *) (src + in * a.ofs0 + iic * a.ofs1))[(int64_t) iih * a.IW + iiw];
+    if (sizeof(T) == 2) ((uint16_t *) dst)[gid] = f2h(v); else ((float *) dst)[gid] = v;
+}
+void im2col_f32(const tdesc & kernel, const tdesc & x, const tdesc & y, int y_type, const int32_t * p, hipStream_t st) {
+    const bool is_2D = p[6] == 1;
+    im2col_dev a;
+    a.s0 = p[0]; a.s1 = p[1]; a.p0 = p[2]; a.p1 = p[3]; a.d0 = p[4]; a.d1 = p[5];
+    a.N  = (int) (is_2D ? x.ne[3] : x.ne[2]); a.IC = (int) (is_2D ? x.ne[2] : x.ne[1]); a.IH = (int) (is_2D ? x.ne[1] : 1); a.IW = (int) x.ne[0];
+    a.KH = (int) (is_2D ? kernel.ne[1] : 1);  a.KW = (int) kernel.ne[0];
+    a.OH = (int) (is_2D ? y.ne[2] : 1);       a.OW = (int) y.ne[1];
+    a.ofs0 = (int64_t) (is_2D ? x.nb[3] : x.nb[2]); a.ofs1 = (int64_t) (is_2D ? x.nb[2] : x.nb[1]);
+    const int64_t total = (int64_t) a.N * a.OH * a.OW * a.IC * a.KH * a.KW;
+    if (total == 0) return;
+    const unsigned grid = (unsigned) ((total + 255) / 256);
+    if (y_type == GGML_TYPE_F16) k_im2col<uint16_t><<<dim3(grid), dim3(256), 0, st>>>((const char *) x.p, (uint16_t *) y.p, a, total);
+    else                         k_im2col<float><<<dim3(grid), dim3(256), 0, st>>>((const char *) x.p, (float *) y.p, a, total);
+}
+
+// ================================================================================================
+// NORM (LayerNorm without affine part).  reference: ggml_compute_forward_norm_f32, ops.cpp:3450-3495: mean = sum(x)/n,
+// variance = sum((x-mean)^2)/n (both sums in double, ggml_vec_sum_f32 / ggml_vec_cvar_f32), y = (x-mean) / sqrt(variance + eps).
+// The omni audio / vision encoders normalise with it (tools/omni/audition.cpp, vision.cpp).
+// ================================================================================================
+__global__ void __launch_bounds__(1024) k_norm(td4 x, td4 y, float eps) {
+    __shared__ double red[16];
+    const int64_t i1 = blockIdx.x, i2 = blockIdx.y, i3 = blockIdx.z;
+    const float * xr = (const float *) (x.p + i1 * x.nb[1] + i2 * x.nb[2] + i3 * x.nb[3]);
+    float *       yr = (float *) (y.p + i1 * y.nb[1] + i2 * y.nb[2] + i3 * y.nb[3]);
+    const int64_t n = x.ne[0];
+    double s = 0.0;
+    for (int64_t i = threadIdx.x; i < n; i += blockDim.x) s += (double) xr[i];
+    s = block_sum<double>(s, red);
+    const float mean = (float) s / (float) n;
+    double v = 0.0;
+    for (int64_t i = threadIdx.x; i < n; i += blockDim.x) { const float d = xr[i] - mean; v += (double) (d * d); }
+    __syncthreads();
+    v = block_sum<double>(v, red);
+    const float variance = (float) (v / (double) n);
+    const float scale = 1.0f / sqrtf(variance + eps);
+    for (int64_t i = threadIdx.x; i < n; i += blockDim.x) yr[i] = (xr[i] - mean) * scale;
+}
+void norm_f32(const tdesc & x, const tdesc & y, float eps, hipStream_t st) {
+    if (x.ne[0] == 0 || x.ne[1] * x.ne[2] * x.ne[3] == 0) return;
+    const int64_t n = x.ne[0];
+    const int bs = n <= 128 ? 64 : n < 1024 ? 256 : n < 8192 ? 512 : 1024;
+    k_norm<<<dim3((unsigned) x.ne[1], (unsigned) x.ne[2], (unsigned) x.ne[3]), dim3(bs), 0, st>>>(to_td4(x), to_td4(y), eps);
+}
+
+// ================================================================================================
 // ROPE f32.  reference: ggml_compute_forward_rope_f32 ops.cpp:5534-5720, rope_yarn :5443-5458,
 // ggml_rope_cache_init :5460-5475, ggml_rope_yarn_corr_dims ggml.c.
 // theta for pair i is produced by the SAME sequential product as the reference's cache init
