@@ -247,6 +247,102 @@ __global__ void __launch_bounds__(256) k_gemm_f16_glds(const gemm_dev g) {
         }
 }
 
+// ---- 256 x 256 tile, 8 waves (2 along m x 4 along n, 128 x 64 per wave = 4 x 2 MFMA tiles, 128 accumulator registers), same staging
+// scheme: 64 KB of LDS per K-step buffer, one workgroup per CU.  Twice the operand reuse of the 128 x 128 kernel (0.75 LDS reads and
+// half the global bytes per MFMA); chosen by the launcher only where 256-square tiles fill the chip in whole rounds.
+__global__ void __launch_bounds__(512) k_gemm_f16_glds256(const gemm_dev g) {
+    constexpr int WTILEB = 256 * H_ROWB, BUFB = 2 * WTILEB;
+    char * const lds = gemm_lds;
+
+    const int nt  = g.tiles_m * g.tiles_n;
+    const int bid = blockIdx.x;
+    const int q = nt / 8, r = nt % 8, xcd = bid % 8, idx = bid / 8;
+    const int tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    int tm = tile / g.tiles_n; const int tn = tile % g.tiles_n;
+    int mi = 0;
+    if (g.nmat > 1 && tm >= g.tm_end[0]) { mi = 1; if (g.nmat > 2 && tm >= g.tm_end[1]) mi = 2; }
+    tm -= mi == 0 ? 0 : g.tm_end[mi - 1];
+    const char * W = mi == 0 ? g.W[0] : (mi == 1 ? g.W[1] : g.W[2]);
+    const size_t w_rs = mi == 0 ? g.w_rs[0] : (mi == 1 ? g.w_rs[1] : g.w_rs[2]);
+    const int M = mi == 0 ? g.M[0] : (mi == 1 ? g.M[1] : g.M[2]);
+    const int N = g.N;
+    const int m0 = tm * 256, n0 = tn * 256;
+
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wm = wave & 1, wn = wave >> 1;
+
+    // staging: wave w fills rows [32w, 32w+32) of both 256-row operand tiles, 8 rows per instruction
+    const int r8 = lane >> 3;
+    const char * wp[4]; const char * xp[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int gc = (lane & 7) ^ (((j * 8 + r8) >> 1) & 7);
+        int mr = m0 + wave * 32 + j * 8 + r8; mr = mr < M ? mr : M - 1;
+        int nr = n0 + wave * 32 + j * 8 + r8; nr = nr < N ? nr : N - 1;
+        wp[j] = W + (size_t) mr * w_rs + gc * 16;
+        xp[j] = g.X + (size_t) nr * g.x_rs + gc * 16;
+    }
+    auto stage = [&](int buf, int ks) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            __builtin_amdgcn_global_load_lds((gbl_ptr_t) (wp[j] + (size_t) ks * H_ROWB), (lds_ptr_t) (lds + buf * BUFB + (wave * 32 + j * 8) * H_ROWB), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gbl_ptr_t) (xp[j] + (size_t) ks * H_ROWB), (lds_ptr_t) (lds + buf * BUFB + WTILEB + (wave * 32 + j * 8) * H_ROWB), 16, 0, 0);
+        }
+    };
+
+    f16v acc[2][4];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.0f;
+
+    const int nk = g.K / H_BK;
+    const int fr = lane & 31, hb = lane >> 5, sw = (fr >> 1) & 7;
+    stage(0, 0);
+    for (int ks = 0; ks < nk; ++ks) {
+        const int cur = ks & 1;
+        __syncthreads();                                   // tile ks has landed (the fence drains the DMA), buffer cur^1 is free
+        if (ks + 1 < nk) stage(cur ^ 1, ks + 1);
+        const char * wb = lds + cur * BUFB; const char * xb = wb + WTILEB;
+#pragma unroll
+        for (int kk = 0; kk < H_BK / 16; ++kk) {
+            const int co = ((kk * 2 + hb) ^ sw) << 4;
+            h8 af[2], bf[4];
+#pragma unroll
+            for (int a = 0; a < 2; ++a) af[a] = *(const h8 *) (xb + (wn * 64 + a * 32 + fr) * H_ROWB + co);
+#pragma unroll
+            for (int b = 0; b < 4; ++b) bf[b] = *(const h8 *) (wb + (wm * 128 + b * 32 + fr) * H_ROWB + co);
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[a], bf[b], acc[a][b], 0, 0, 0);
+        }
+    }
+
+    char * dst = mi == 0 ? g.dst[0] : (mi == 1 ? g.dst[1] : g.dst[2]);
+    const size_t dst_cs = mi == 0 ? g.dst_cs[0] : (mi == 1 ? g.dst_cs[1] : g.dst_cs[2]);
+    const char * resid = mi == 0 ? g.resid[0] : (mi == 1 ? g.resid[1] : g.resid[2]);
+    const size_t resid_cs = mi == 0 ? g.resid_cs[0] : (mi == 1 ? g.resid_cs[1] : g.resid_cs[2]);
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int m = m0 + wm * 128 + b * 32 + (lane & 31);
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int n = n0 + wn * 64 + a * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+                if (m < M && n < N) {
+                    float v = acc[a][b][e];
+                    if (resid) v += *(const float *) (resid + (size_t) n * resid_cs + (size_t) m * 4);
+                    *(float *) (dst + (size_t) n * dst_cs + (size_t) m * 4) = v;
+                }
+            }
+        }
+}
+
 // dst[n][m] = sum_s part[s][n][m] (+ resid[n][m]), fixed summation order
 __global__ void __launch_bounds__(256) k_gemm_reduce(const float * __restrict__ part, int nsplit, size_t split_elems, const char * __restrict__ resid, size_t resid_cs,
                                                      char * __restrict__ dst, size_t dst_cs, int M, int N) {
@@ -364,6 +460,19 @@ void gemm_f16_multi(const gemm_multi_args & a, hipStream_t st) {
         // (64-row tiles for launches with fewer 128-row tiles than CUs -- qkv at ubatch 512 is 192 -- measured neutral; tuning override:)
         if (const char * e = getenv("MI355X_GEMM_BM")) { const int f = atoi(e); if (f == 64 || f == 128 || f == 192) BM = f; }
     }
+    // 256 x 256 workgroup tiles (one workgroup per CU, ~1.2x the per-CU rate of the 128-row kernels: 1015 vs 851 TFLOP/s at 8192^3) when they come in
+    // whole rounds of the 256 CUs: time ~ rounds * tile area / rate, 128-row kernels run two workgroups per CU at half rate each
+    bool big = false;
+    {
+        static const int force = getenv("MI355X_GEMM_256") ? atoi(getenv("MI355X_GEMM_256")) : -1;      // 1 force on, 0 off (tuning)
+        const int tiles_n256 = (int) ((a.N + 255) / 256);
+        const int64_t t256 = (int64_t) count_tm(256) * tiles_n256, tsel = (int64_t) count_tm(BM) * tiles_n;
+        const double c256 = (double) ((t256 + 255) / 256) * 65536.0 / 1.2, csel = (double) ((tsel + 511) / 512) * 2.0 * 128.0 * BM;
+        big = a.nbatch <= 1 && a.N >= 256 && t256 >= 256 && c256 < csel;
+        if (force == 0) big = false;
+        if (force == 1 && a.nbatch <= 1) big = true;
+    }
+    if (big) BM = 256;
     int tm = 0;
     for (int i = 0; i < 3; ++i) {
         const gemm_mat & m = a.m[i < a.nmat ? i : 0];
@@ -371,6 +480,18 @@ void gemm_f16_multi(const gemm_multi_args & a, hipStream_t st) {
         g.resid[i] = (const char *) m.resid; g.resid_cs[i] = m.resid_cs; g.M[i] = (int) m.M;
         if (i < a.nmat) tm += (int) ((m.M + BM - 1) / BM);
         g.tm_end[i] = tm;
+    }
+    if (big) {
+        if (tm == 0) return;
+        const int tiles_n256 = (int) ((a.N + 255) / 256);
+        g.nmat = a.nmat; g.X = (const char *) a.X; g.x_rs = a.x_rs; g.N = (int) a.N; g.K = (int) a.K; g.tiles_m = tm; g.tiles_n = tiles_n256;
+        g.ksteps_per_split = (int) (a.K / H_BK); g.split_stride = 0;
+        g.ne12 = g.r2 = g.r3 = 1; g.w_nb2 = g.w_nb3 = g.x_bs = g.dst_nb2 = g.dst_nb3 = 0;
+        constexpr int lds256 = 2 * 2 * 256 * H_ROWB;               // 128 KB
+        static bool attr256 = false;
+        if (!attr256) { HIP_CHECK(hipFuncSetAttribute((const void *) k_gemm_f16_glds256, hipFuncAttributeMaxDynamicSharedMemorySize, lds256)); attr256 = true; }
+        k_gemm_f16_glds256<<<dim3((unsigned) (tm * tiles_n256)), dim3(512), lds256, st>>>(g);
+        return;
     }
     g.nmat = a.nmat; g.X = (const char *) a.X; g.x_rs = a.x_rs; g.N = (int) a.N; g.K = (int) a.K; g.tiles_m = tm; g.tiles_n = tiles_n;
     const int nbatch = a.nbatch > 1 ? a.nbatch : 1;
