@@ -184,13 +184,22 @@ __global__ void __launch_bounds__(256) k_gemm_f16_glds(const gemm_dev g) {
         int nr = n0 + wave * 32 + j * 8 + r8; nr = nr < N ? nr : N - 1;
         xp[j] = g.X + (size_t) blockIdx.y * g.x_bs + (size_t) nr * g.x_rs + gc * 16;
     }
+    auto stage_w = [&](int buf, int ks, int j) {
+        __builtin_amdgcn_global_load_lds((gbl_ptr_t) (wp[j] + (size_t) ks * H_ROWB), (lds_ptr_t) (lds + buf * BUFB + (wave * 16 * MB + j * 8) * H_ROWB), 16, 0, 0);
+    };
+    auto stage_x = [&](int buf, int ks, int j) {
+        __builtin_amdgcn_global_load_lds((gbl_ptr_t) (xp[j] + (size_t) ks * H_ROWB), (lds_ptr_t) (lds + buf * BUFB + WTILEB + (wave * 32 + j * 8) * H_ROWB), 16, 0, 0);
+    };
+    // quarter q (0..3) of the next tile's DMA: issued between the k-sub-steps so that the LDS reads and MFMAs of the current tile start
+    // right after the barrier instead of behind all of the wave's DMA issues
+    auto stage_part = [&](int buf, int ks, int q) {
+        stage_x(buf, ks, q);
+        if (q < 2 * MB) stage_w(buf, ks, q);
+        if (4 + q < 2 * MB) stage_w(buf, ks, 4 + q);
+    };
     auto stage = [&](int buf, int ks) {
 #pragma unroll
-        for (int j = 0; j < 2 * MB; ++j)
-            __builtin_amdgcn_global_load_lds((gbl_ptr_t) (wp[j] + (size_t) ks * H_ROWB), (lds_ptr_t) (lds + buf * BUFB + (wave * 16 * MB + j * 8) * H_ROWB), 16, 0, 0);
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-            __builtin_amdgcn_global_load_lds((gbl_ptr_t) (xp[j] + (size_t) ks * H_ROWB), (lds_ptr_t) (lds + buf * BUFB + WTILEB + (wave * 32 + j * 8) * H_ROWB), 16, 0, 0);
+        for (int q = 0; q < 4; ++q) stage_part(buf, ks, q);
     };
 
     f16v acc[2][MB];
@@ -209,7 +218,7 @@ __global__ void __launch_bounds__(256) k_gemm_f16_glds(const gemm_dev g) {
     for (int ks = k_lo; ks < k_hi; ++ks) {
         const int cur = (ks - k_lo) & 1;
         __syncthreads();                                   // tile ks has landed (the fence drains the DMA), buffer cur^1 is free
-        if (ks + 1 < k_hi) stage(cur ^ 1, ks + 1);
+        if (ks + 1 < k_hi) stage(cur ^ 1, ks + 1);          // (interleaving the DMA issues with the k-sub-steps pays on the 256-square kernel only: two workgroups per CU already overlap here)
         const char * wb = lds + cur * BUFB; const char * xb = wb + WTILEB;
 #pragma unroll
         for (int kk = 0; kk < H_BK / 16; ++kk) {
@@ -283,12 +292,15 @@ __global__ void __launch_bounds__(512) k_gemm_f16_glds256(const gemm_dev g) {
         wp[j] = W + (size_t) mr * w_rs + gc * 16;
         xp[j] = g.X + (size_t) nr * g.x_rs + gc * 16;
     }
+    // one quarter of the next tile's DMA (2 of the wave's 8 instructions): issued between the k-sub-steps so that the LDS reads and
+    // MFMAs of the current tile start right after the barrier instead of behind eight DMA issues
+    auto stage_part = [&](int buf, int ks, int j) {
+        __builtin_amdgcn_global_load_lds((gbl_ptr_t) (wp[j] + (size_t) ks * H_ROWB), (lds_ptr_t) (lds + buf * BUFB + (wave * 32 + j * 8) * H_ROWB), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gbl_ptr_t) (xp[j] + (size_t) ks * H_ROWB), (lds_ptr_t) (lds + buf * BUFB + WTILEB + (wave * 32 + j * 8) * H_ROWB), 16, 0, 0);
+    };
     auto stage = [&](int buf, int ks) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            __builtin_amdgcn_global_load_lds((gbl_ptr_t) (wp[j] + (size_t) ks * H_ROWB), (lds_ptr_t) (lds + buf * BUFB + (wave * 32 + j * 8) * H_ROWB), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((gbl_ptr_t) (xp[j] + (size_t) ks * H_ROWB), (lds_ptr_t) (lds + buf * BUFB + WTILEB + (wave * 32 + j * 8) * H_ROWB), 16, 0, 0);
-        }
+        for (int j = 0; j < 4; ++j) stage_part(buf, ks, j);
     };
 
     f16v acc[2][4];
@@ -305,7 +317,6 @@ __global__ void __launch_bounds__(512) k_gemm_f16_glds256(const gemm_dev g) {
     for (int ks = 0; ks < nk; ++ks) {
         const int cur = ks & 1;
         __syncthreads();                                   // tile ks has landed (the fence drains the DMA), buffer cur^1 is free
-        if (ks + 1 < nk) stage(cur ^ 1, ks + 1);
         const char * wb = lds + cur * BUFB; const char * xb = wb + WTILEB;
 #pragma unroll
         for (int kk = 0; kk < H_BK / 16; ++kk) {
@@ -315,6 +326,7 @@ __global__ void __launch_bounds__(512) k_gemm_f16_glds256(const gemm_dev g) {
             for (int a = 0; a < 2; ++a) af[a] = *(const h8 *) (xb + (wn * 64 + a * 32 + fr) * H_ROWB + co);
 #pragma unroll
             for (int b = 0; b < 4; ++b) bf[b] = *(const h8 *) (wb + (wm * 128 + b * 32 + fr) * H_ROWB + co);
+            if (ks + 1 < nk) stage_part(cur ^ 1, ks + 1, kk);
 #pragma unroll
             for (int a = 0; a < 2; ++a)
 #pragma unroll
