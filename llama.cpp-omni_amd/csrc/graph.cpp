@@ -70,6 +70,8 @@ struct exec_state {
     // deferred split-K reduction: `A` (the mat-mul + residual result) still lies as `nsplit` slabs in gemm_partial; the RMS_NORM that
     // reads it next folds the reduction in (gemm_reduce_rms_norm), anything else materialises it first
     struct { const ggml_tensor * A = nullptr; int nsplit = 0; const float * resid = nullptr; size_t resid_cs = 0; } pr;
+    // (pos, rope parameters) whose (cos, sin) table currently sits in rope_scratch (prefill: shared by every layer of the graph)
+    struct { const void * pos = nullptr; const void * ff = nullptr; int T = 0, D = 0; rope_params rp; } rt;
     // mask whose tile map currently sits in fa_scratch
     const void *  fa_mask = nullptr; int64_t fa_dims[4] = {0, 0, 0, 0}; size_t fa_mnb1 = 0;
 };
@@ -249,6 +251,17 @@ static size_t graph_fa_scratch_need(const ggml_cgraph * g) {
         if (n->op != GGML_OP_FLASH_ATTN_EXT || is_empty(n)) continue;
         fattn_args f; tdesc m; fill_fattn_args(n, f, m);
         const size_t b = fattn_scratch_bytes(f);
+        if (b > need) need = b;
+    }
+    return need;
+}
+static const int64_t ROPE_TABLE_MIN_TOKENS = 32;
+static size_t graph_rope_scratch_need(const ggml_cgraph * g) {
+    size_t need = 0;
+    for (int i = 0; i < g->n_nodes; ++i) {
+        const ggml_tensor * n = g->nodes[i];
+        if (n->op != GGML_OP_ROPE || n->ne[2] < ROPE_TABLE_MIN_TOKENS) continue;
+        const size_t b = (size_t) n->ne[2] * (size_t) n->ne[0] * 4;
         if (b > need) need = b;
     }
     return need;
@@ -933,6 +946,13 @@ static bool exec_rms_norm(exec_state & s, int i) {
                 a.j[a.njobs++] = chain_job(s, A);
                 if (bj >= 0) a.j[a.njobs++] = chain_job(s, B);
                 if (vj >= 0) a.j[a.njobs++] = vjob;
+                if (A.T >= ROPE_TABLE_MIN_TOKENS && (size_t) A.T * A.D * 4 <= s.c->rope_scratch_bytes) {
+                    // prefill: the angles depend on (position, pair) only -- one table per graph instead of sincos per head, layer and chain
+                    a.rope_tab = (float *) s.c->rope_scratch;
+                    a.rope_tab_valid = s.rt.pos == A.pos->data && s.rt.ff == (A.ff ? A.ff->data : nullptr) && s.rt.T == A.T && s.rt.D == A.D &&
+                                       memcmp(&s.rt.rp, &A.rp, sizeof(rope_params)) == 0;
+                    if (!a.rope_tab_valid) { s.rt.pos = A.pos->data; s.rt.ff = A.ff ? A.ff->data : nullptr; s.rt.T = A.T; s.rt.D = A.D; s.rt.rp = A.rp; ++s.n_kernels; }
+                }
                 {
                     prof_scope ps(s, "norm_rope", 0);
                     norm_rope_store(a, s.st);
@@ -1210,6 +1230,7 @@ enum ggml_status graph_compute(backend_ctx * c, ggml_cgraph * g) {
     ensure_scratch(c, &c->act_scratch, &c->act_scratch_bytes, graph_act_scratch_need(g));
     ensure_scratch(c, &c->w_scratch, &c->w_scratch_bytes, graph_w_scratch_need(g));
     ensure_scratch(c, &c->fa_scratch, &c->fa_scratch_bytes, graph_fa_scratch_need(g));
+    ensure_scratch(c, &c->rope_scratch, &c->rope_scratch_bytes, graph_rope_scratch_need(g));
     ensure_scratch(c, &c->gemm_partial, &c->gemm_partial_bytes, graph_gemm_partial_need(g));
 
     int n_real = 0;
@@ -1325,6 +1346,7 @@ void backend_ctx_release(backend_ctx * c) {
     if (c->act_scratch) (void) hipFree(c->act_scratch);
     if (c->w_scratch) (void) hipFree(c->w_scratch);
     if (c->fa_scratch) (void) hipFree(c->fa_scratch);
+    if (c->rope_scratch) (void) hipFree(c->rope_scratch);
     if (c->gemm_partial) (void) hipFree(c->gemm_partial);
     if (c->copy_event) (void) hipEventDestroy(c->copy_event);
     if (c->stream) (void) hipStreamDestroy(c->stream);

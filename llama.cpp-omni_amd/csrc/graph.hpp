@@ -33,6 +33,8 @@ struct backend_ctx {
     void *  w_scratch = nullptr;    size_t w_scratch_bytes = 0;
     // mask tile map of the prefill flash-attention kernel
     void *  fa_scratch = nullptr;   size_t fa_scratch_bytes = 0;
+    // (cos, sin) table of a prefill ubatch's rotary positions (fused.hip k_rope_table)
+    void *  rope_scratch = nullptr; size_t rope_scratch_bytes = 0;
     // split-K partial sums of the prefill GEMM
     void *  gemm_partial = nullptr; size_t gemm_partial_bytes = 0;
 

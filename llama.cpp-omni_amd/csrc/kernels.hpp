@@ -143,6 +143,8 @@ struct norm_rope_args {
     norm_rope_job j[3]; int njobs;
     const int32_t * pos; const float * ff;
     int D, T; float eps; rope_params rp;
+    // optional scratch for the ubatch's (cos, sin) table, T * D/2 float pairs; rope_tab_valid: it already holds THIS (pos, rope params)
+    float * rope_tab = nullptr; bool rope_tab_valid = false;
 };
 void norm_rope_store(const norm_rope_args & a, hipStream_t st);
 bool rms_norm_mul_quant_ok(int64_t n);

@@ -23,7 +23,18 @@ struct nr_dev {
     nr_job j[3]; int njobs;
     const int32_t * pos; const float * ff;
     int D, T; float eps; rope_dev rd;
+    const float * tab;                                // optional [T][D/2] (cos, sin) table of this ubatch (k_rope_table), else null
 };
+
+// (cos, sin) of every (token, rotation pair) of a ubatch, once per graph: 36 layers x (q heads + k heads) re-use them
+__global__ void __launch_bounds__(256) k_rope_table(const int32_t * __restrict__ pos, const float * __restrict__ ff, const rope_dev rd, int T, int half, float * __restrict__ tab) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= T * half) return;
+    const int t = i / half, ip = i - t * half;
+    float c, s;
+    rope_angle((float) pos[t], ip, ff, rd, c, s);
+    tab[2 * i] = c; tab[2 * i + 1] = s;
+}
 
 template <int PPL>   // rotation pairs per lane: 1 for D <= 128, 2 for D <= 256
 __global__ void __launch_bounds__(256) k_norm_rope(const nr_dev a) {
@@ -47,7 +58,7 @@ __global__ void __launch_bounds__(256) k_norm_rope(const nr_dev a) {
     }
 
     float r0[PPL], r1[PPL]; int e0[PPL], e1[PPL]; bool act[PPL];
-    norm_rope_wave<PPL>(xr, J.w, a.D, a.eps, (float) a.pos[t], a.ff, a.rd, lane, r0, r1, e0, e1, act);
+    norm_rope_wave<PPL>(xr, J.w, a.D, a.eps, (float) a.pos[t], a.ff, a.rd, lane, r0, r1, e0, e1, act, a.tab ? a.tab + (size_t) t * a.D : nullptr);
 #pragma unroll
     for (int q = 0; q < PPL; ++q) {
         if (!act[q]) continue;
@@ -66,6 +77,11 @@ void norm_rope_store(const norm_rope_args & f, hipStream_t st) {
     if (f.D == 0 || f.T == 0 || f.njobs == 0) return;
     nr_dev a;
     a.njobs = f.njobs; a.pos = f.pos; a.ff = f.ff; a.D = f.D; a.T = f.T; a.eps = f.eps; a.rd = make_rope_dev(f.rp);
+    a.tab = f.rope_tab;
+    if (f.rope_tab && !f.rope_tab_valid) {
+        const int n = f.T * (f.D / 2);
+        k_rope_table<<<dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, st>>>(f.pos, f.ff, a.rd, f.T, f.D / 2, f.rope_tab);
+    }
     int acc = 0;
     for (int i = 0; i < 3; ++i) {
         const norm_rope_job & s = f.j[i < f.njobs ? i : 0];

@@ -23,11 +23,30 @@ static inline rope_dev make_rope_dev(const rope_params & rp) {
     return r;
 }
 
+// (cos, sin) * mscale of rotation pair ip at position pos -- the reference's rope_yarn on the sequentially multiplied theta
+static __device__ __forceinline__ void rope_angle(float pos, int ip, const float * ff, const rope_dev rd, float & c, float & s) {
+    float theta = pos;
+    for (int k = 0; k < ip; ++k) theta *= rd.theta_scale;                        // sequential, as ggml_rope_cache_init
+    const float f = ff ? ff[ip] : 1.0f;
+    const float theta_extrap = theta / f;
+    const float theta_interp = rd.freq_scale * theta_extrap;
+    float th = theta_interp, mscale = rd.attn_factor;
+    if (rd.ext_factor != 0.0f) {
+        const float yv = ((float) ip - rd.corr0) / fmaxf(0.001f, rd.corr1 - rd.corr0);
+        const float ramp_mix = (1.0f - fminf(1.0f, fmaxf(0.0f, yv))) * rd.ext_factor;
+        th = theta_interp * (1.0f - ramp_mix) + theta_extrap * ramp_mix;
+        mscale *= 1.0f + 0.1f * logf(1.0f / rd.freq_scale);
+    }
+    c = cosf(th) * mscale; s = sinf(th) * mscale;
+}
+
 // one wave, one head of D elements at xr (f32, contiguous): lane l owns rotation pairs l + 64*p, p < PPL.
-// out: rotated values r0/r1 at element indices e0/e1 (valid where act[p])
+// out: rotated values r0/r1 at element indices e0/e1 (valid where act[p]).  tab != null: (cos, sin) pairs of this token, [D/2] float2,
+// produced by rope_angle (the per-graph table of a prefill ubatch: every layer and head re-uses the same angles)
 template <int PPL>
 static __device__ __forceinline__ void norm_rope_wave(const char * xr, const float * w, int D, float eps, float pos, const float * ff, const rope_dev rd,
-                                                      int lane, float (&r0)[PPL], float (&r1)[PPL], int (&e0)[PPL], int (&e1)[PPL], bool (&act)[PPL]) {
+                                                      int lane, float (&r0)[PPL], float (&r1)[PPL], int (&e0)[PPL], int (&e1)[PPL], bool (&act)[PPL],
+                                                      const float * tab = nullptr) {
     const int  half = D / 2;
     const bool neox = rd.mode & GGML_ROPE_TYPE_NEOX;
     float x0[PPL], x1[PPL], w0v[PPL], w1v[PPL];
@@ -53,19 +72,9 @@ static __device__ __forceinline__ void norm_rope_wave(const char * xr, const flo
         if (!act[q]) continue;
         const int ip = lane + 64 * q;
         const float v0 = (x0[q] * scale) * w0v[q], v1 = (x1[q] * scale) * w1v[q];
-        float theta = pos;
-        for (int k = 0; k < ip; ++k) theta *= rd.theta_scale;                    // sequential, as ggml_rope_cache_init
-        const float f = ff ? ff[ip] : 1.0f;
-        const float theta_extrap = theta / f;
-        const float theta_interp = rd.freq_scale * theta_extrap;
-        float th = theta_interp, mscale = rd.attn_factor;
-        if (rd.ext_factor != 0.0f) {
-            const float yv = ((float) ip - rd.corr0) / fmaxf(0.001f, rd.corr1 - rd.corr0);
-            const float ramp_mix = (1.0f - fminf(1.0f, fmaxf(0.0f, yv))) * rd.ext_factor;
-            th = theta_interp * (1.0f - ramp_mix) + theta_extrap * ramp_mix;
-            mscale *= 1.0f + 0.1f * logf(1.0f / rd.freq_scale);
-        }
-        const float c = cosf(th) * mscale, s = sinf(th) * mscale;
+        float c, s;
+        if (tab) { c = tab[2 * ip]; s = tab[2 * ip + 1]; }
+        else     rope_angle(pos, ip, ff, rd, c, s);
         r0[q] = v0 * c - v1 * s; r1[q] = v0 * s + v1 * c;
     }
 }
