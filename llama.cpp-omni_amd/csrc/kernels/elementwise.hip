@@ -387,6 +387,25 @@ __global__ void __launch_bounds__(256) k_glu(int op, const char * __restrict__ a
     if (y16) ((uint16_t *) (y16 + r * y16_rs))[i] = f2h(v);           // activation image of the following GEMM
 }
 
+// SWIGLU on 16-byte aligned rows: four elements per lane, one row per blockIdx.y (no 64-bit index arithmetic) -- the prefill shape
+__global__ void __launch_bounds__(256) k_swiglu_v4(const char * __restrict__ a, int64_t a_rs, const char * __restrict__ b, int64_t b_rs,
+                                                  char * __restrict__ y, int64_t y_rs, int nc4, char * __restrict__ y16, int64_t y16_rs) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= nc4) return;
+    const int64_t r = blockIdx.y;
+    const f32x4 x = ((const f32x4 *) (a + r * a_rs))[i];
+    const f32x4 g = ((const f32x4 *) (b + r * b_rs))[i];
+    f32x4 v;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = op_silu(x[e]) * g[e];
+    if (y) ((f32x4 *) (y + r * y_rs))[i] = v;
+    if (y16) {
+        u32x2 h;
+        h[0] = (uint32_t) f2h(v[0]) | ((uint32_t) f2h(v[1]) << 16); h[1] = (uint32_t) f2h(v[2]) | ((uint32_t) f2h(v[3]) << 16);
+        ((u32x2 *) (y16 + r * y16_rs))[i] = h;
+    }
+}
+
 void glu_f32(int glu_op, const tdesc & a, const tdesc * b, bool swapped, const tdesc & y, hipStream_t st, uint16_t * y16, size_t y16_rs, bool write_f32) {
     // rows are contiguous_1 (checked by supports_op): treat as [nc, nr] with a row stride
     const int64_t nc = y.ne[0];
@@ -396,6 +415,12 @@ void glu_f32(int glu_op, const tdesc & a, const tdesc * b, bool swapped, const t
     int64_t a_rs = (int64_t) a.nb[1], b_rs;
     if (b) { bp = (const char *) b->p; b_rs = (int64_t) b->nb[1]; }
     else   { bp = ap + (swapped ? 0 : nc * 4); ap = ap + (swapped ? nc * 4 : 0); b_rs = a_rs; }
+    if (glu_op == GGML_GLU_OP_SWIGLU && nc % 4 == 0 && nr <= 65535 && ((uintptr_t) ap & 15) == 0 && ((uintptr_t) bp & 15) == 0 && a_rs % 16 == 0 && b_rs % 16 == 0 &&
+        ((uintptr_t) y.p & 15) == 0 && y.nb[1] % 16 == 0 && ((uintptr_t) y16 & 7) == 0 && y16_rs % 8 == 0) {
+        k_swiglu_v4<<<dim3((unsigned) ((nc / 4 + 255) / 256), (unsigned) nr), dim3(256), 0, st>>>(ap, a_rs, bp, b_rs, write_f32 ? (char *) y.p : nullptr, (int64_t) y.nb[1],
+                                                                                              (int) (nc / 4), (char *) y16, (int64_t) y16_rs);
+        return;
+    }
     k_glu<<<dim3((unsigned) ((nc * nr + 255) / 256)), dim3(256), 0, st>>>(glu_op, ap, a_rs, bp, b_rs, write_f32 ? (char *) y.p : nullptr, (int64_t) y.nb[1], nc, nr, (char *) y16, (int64_t) y16_rs);
 }
 
