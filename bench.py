@@ -231,6 +231,20 @@ def c3_prefill(pkg, be, n_seq=8, n_prompt=2048, n_ubatch=512, tiny=False):
     be.synchronize()
     dt = time.perf_counter() - t0
     ok = bool(np.isfinite(be.tensor_get(chunks[-1][2])).all())
+    if os.environ.get("MI355X_BENCH_PROFILE"):
+        be.set_option("profile", 1)
+        be.set_option("reset_stats", 1)
+        for _, gr, _ in chunks:
+            be.graph_compute(gr)
+        be.synchronize()
+        prof = {}
+        for cls in ("gemm_f16", "gemm_reduce", "act_convert", "rms_norm_mul", "rms_norm", "norm_rope", "rope", "fattn", "set_rows", "get_rows", "bin", "glu", "cpy",
+                    "mmv_f16", "empty"):
+            u, k = be.get_stat(f"prof_{cls}_us"), be.get_stat(f"prof_{cls}_n")
+            if k > 0:
+                prof[cls] = {"n": int(k), "total_us": round(u, 1), "avg_event_to_event_us": round(u / k, 2)}
+        be.set_option("profile", 0)
+        sys.stderr.write(f"C3 one sequence ({n_prompt} tokens, ubatch {n_ubatch}), eager per-class profile: " + json.dumps(prof) + "\n")
     n_tok = n_seq * n_prompt
     # FLOPs as BASELINE.md row C3: 2 x layer weights per token + causal attention 4 * D * n_head * (n^2 / 2) per layer and sequence
     E, F, L = cfg["n_embd"], cfg["n_ff"], cfg["n_layer"]

@@ -43,18 +43,23 @@ template <int D> struct fm_cfg {
     static constexpr int VB  = D * VLD * 2;     // bytes of one V^T buffer
 };
 
-template <int D, int NW>
-__global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2))) k_fattn_mma(const fa_dev a, const int nqt) {
+// KS = KV split inside the workgroup: NW*KS waves; wave (qb, ks) owns query block qb and the ks-th 32-row tile of every staged group of
+// KS tiles, with its own running (M, S, O); the KS partial states of a query block are merged through LDS at the end.  Used when a
+// single wave per 32 queries would leave half of the chip's SIMDs without a wave (one 512-token ubatch of one sequence: 512 blocks).
+template <int D, int NW, int KS>
+__global__ void __launch_bounds__(64 * NW * KS) __attribute__((amdgpu_waves_per_eu(2))) k_fattn_mma(const fa_dev a, const int nqt) {
     constexpr int KLD = fm_cfg<D>::KLD, VLD = fm_cfg<D>::VLD;
     constexpr int NKS = D / 16;                 // MFMA k-steps of the score product
     constexpr int NDB = D / 32;                 // 32-row blocks of O^T
-    constexpr int NT  = 64 * NW;
-    constexpr int KCH = (FM_KT * (D / 8) + NT - 1) / NT;            // 16-byte K chunks per thread per tile
-    constexpr int VIT = ((FM_KT / 2) * (D / 8) + NT - 1) / NT;      // V row-pair items per thread per tile
-    __shared__ __attribute__((aligned(16))) _Float16 Ks[2][FM_KT * KLD];
-    __shared__ __attribute__((aligned(16))) uint32_t Vt[2][D * VLD / 2];
+    constexpr int NT  = 64 * NW * KS;
+    constexpr int GT  = FM_KT * KS;             // KV rows staged per iteration (a group of KS tiles)
+    constexpr int KCH = (GT * (D / 8) + NT - 1) / NT;               // 16-byte K chunks per thread per group
+    constexpr int VIT = ((GT / 2) * (D / 8) + NT - 1) / NT;         // V row-pair items per thread per group
+    __shared__ __attribute__((aligned(16))) _Float16 Ks[2][KS][FM_KT * KLD];
+    __shared__ __attribute__((aligned(16))) uint32_t Vt[2][KS][D * VLD / 2];
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave_all = tid >> 6;
+    const int wave = wave_all % NW, kvs = wave_all / NW;    // query block within the workgroup, KV split
     const int lq = lane & 31, hb = lane >> 5;
     int b = (int) blockIdx.x;
     const int qt  = nqt - 1 - b % nqt; b /= nqt;          // longest (latest, for causal masks) query tiles first
@@ -93,20 +98,24 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2)
 
     const char * kbase = a.k + ikv * a.knb2 + is3 * a.knb3;
     const char * vbase = a.v + ikv * a.vnb2 + is3 * a.vnb3;
-    const int ntile = (a.nkv + FM_KT - 1) / FM_KT;
+    const int ntile32 = (a.nkv + FM_KT - 1) / FM_KT;              // 32-row mask / compute tiles
+    const int ntile = (ntile32 + KS - 1) / KS;                    // staged groups of KS tiles
 
     // ---- which tiles does any query of this workgroup see?  one bit per tile, built from the mask tile map
     __shared__ uint64_t live_bits[FM_MAXT / 64];
     const int qb0 = qt * NW;                                        // first 32-row query block of the workgroup
-    const uint8_t * maprow = a.tile_map ? a.tile_map + (((int64_t) (is3 % (int) a.mne3) * a.mne2 + (h % (int) a.mne2)) * a.map_nqb) * ntile : nullptr;
-    for (int c = wave; c * 64 < ntile; c += NW) {
+    const uint8_t * maprow = a.tile_map ? a.tile_map + (((int64_t) (is3 % (int) a.mne3) * a.mne2 + (h % (int) a.mne2)) * a.map_nqb) * ntile32 : nullptr;
+    for (int c = wave_all; c * 64 < ntile; c += NW * KS) {
         const int tt = c * 64 + lane;
         bool lv = false;
         if (tt < ntile) {
             if (!maprow) lv = true;
             else
 #pragma unroll
-                for (int w = 0; w < NW; ++w) if (qb0 + w < a.map_nqb) lv |= maprow[(int64_t) (qb0 + w) * ntile + tt] != 0;
+                for (int w = 0; w < NW; ++w)
+#pragma unroll
+                    for (int k = 0; k < KS; ++k)
+                        if (qb0 + w < a.map_nqb && tt * KS + k < ntile32) lv |= maprow[(int64_t) (qb0 + w) * ntile32 + tt * KS + k] != 0;
         }
         const uint64_t bits = __ballot(lv);
         if (lane == 0) live_bits[c] = bits;
@@ -120,9 +129,10 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2)
         }
         return __builtin_amdgcn_readfirstlane(u < ntile ? u : ntile);
     };
-    const uint8_t * myrow = (maprow && qb0 + wave < a.map_nqb) ? maprow + (int64_t) (qb0 + wave) * ntile : nullptr;
-    auto tile_class = [&](int t) -> int {                            // this wave's 32 queries x tile t
-        if (q0 >= a.nq) return 0;
+    const uint8_t * myrow = (maprow && qb0 + wave < a.map_nqb) ? maprow + (int64_t) (qb0 + wave) * ntile32 : nullptr;
+    auto tile_class = [&](int g) -> int {                            // this wave's 32 queries x its tile of group g
+        const int t = g * KS + kvs;
+        if (q0 >= a.nq || t >= ntile32) return 0;
         if (!maprow) return (t + 1) * FM_KT <= a.nkv ? 1 : 2;
         return myrow ? (int) myrow[t] : 0;
     };
@@ -146,20 +156,20 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2)
     // K / V rows of tile t into registers (rows past nkv are zero)
     u32x4 kreg[KCH], vreg[VIT][2];
     auto load_kv = [&](int t) {
-        const int kv0 = t * FM_KT;
+        const int kv0 = t * GT;
 #pragma unroll
         for (int i = 0; i < KCH; ++i) {
             const int c = tid + i * NT;
             const int row = c / (D / 8), col = c % (D / 8);
             kreg[i] = u32x4{ 0u, 0u, 0u, 0u };
-            if (c < FM_KT * (D / 8) && kv0 + row < a.nkv) kreg[i] = *(const u32x4 *) (kbase + (int64_t) (kv0 + row) * a.knb1 + col * 16);
+            if (c < GT * (D / 8) && kv0 + row < a.nkv) kreg[i] = *(const u32x4 *) (kbase + (int64_t) (kv0 + row) * a.knb1 + col * 16);
         }
 #pragma unroll
         for (int i = 0; i < VIT; ++i) {
             const int c = tid + i * NT;
             const int o = c % (D / 8), p = c / (D / 8);
             vreg[i][0] = vreg[i][1] = u32x4{ 0u, 0u, 0u, 0u };
-            if (c < (FM_KT / 2) * (D / 8)) {
+            if (c < (GT / 2) * (D / 8)) {
                 if (kv0 + 2 * p     < a.nkv) vreg[i][0] = *(const u32x4 *) (vbase + (int64_t) (kv0 + 2 * p)     * a.vnb1 + o * 16);
                 if (kv0 + 2 * p + 1 < a.nkv) vreg[i][1] = *(const u32x4 *) (vbase + (int64_t) (kv0 + 2 * p + 1) * a.vnb1 + o * 16);
             }
@@ -170,17 +180,18 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2)
         for (int i = 0; i < KCH; ++i) {
             const int c = tid + i * NT;
             const int row = c / (D / 8), col = c % (D / 8);
-            if (c < FM_KT * (D / 8)) *(u32x4 *) &Ks[buf][row * KLD + col * 8] = kreg[i];
+            if (c < GT * (D / 8)) *(u32x4 *) &Ks[buf][row / FM_KT][(row % FM_KT) * KLD + col * 8] = kreg[i];
         }
 #pragma unroll
         for (int i = 0; i < VIT; ++i) {
             const int c = tid + i * NT;
             const int o = c % (D / 8), p = c / (D / 8);
-            if (c < (FM_KT / 2) * (D / 8)) {
+            if (c < (GT / 2) * (D / 8)) {
+                const int sub = p / (FM_KT / 2), pp = p % (FM_KT / 2);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    Vt[buf][(8 * o + 2 * e)     * (VLD / 2) + p] = (vreg[i][0][e] & 0xffffu) | (vreg[i][1][e] << 16);
-                    Vt[buf][(8 * o + 2 * e + 1) * (VLD / 2) + p] = (vreg[i][0][e] >> 16)     | (vreg[i][1][e] & 0xffff0000u);
+                    Vt[buf][sub][(8 * o + 2 * e)     * (VLD / 2) + pp] = (vreg[i][0][e] & 0xffffu) | (vreg[i][1][e] << 16);
+                    Vt[buf][sub][(8 * o + 2 * e + 1) * (VLD / 2) + pp] = (vreg[i][0][e] >> 16)     | (vreg[i][1][e] & 0xffff0000u);
                 }
             }
         }
@@ -192,7 +203,7 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2)
     while (t < ntile) {
         const int buf = nlive & 1;
         u32x2 mw[4] = {};
-        if (cls == 2) load_mask(t, mw);                              // mixed tile: this lane's mask words (latency under the stores)
+        if (cls == 2) load_mask(t * KS + kvs, mw);                              // mixed tile: this lane's mask words (latency under the stores)
         store_kv(buf);
         // barrier: tile t is visible; everybody is past the previous live tile's matrix work, so the other buffer may be refilled
         __syncthreads();
@@ -207,7 +218,7 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2)
             for (int e = 0; e < 16; ++e) sc[e] = 0.0f;
 #pragma unroll
             for (int ks = 0; ks < NKS; ++ks) {
-                const h8v kf = *(const h8v *) &Ks[buf][lq * KLD + ks * 16 + hb * 8];
+                const h8v kf = *(const h8v *) &Ks[buf][kvs][lq * KLD + ks * 16 + hb * 8];
                 sc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], sc, 0, 0, 0);
             }
             // ---- scale / softcap / mask (all-zero mask tiles skip the mask arithmetic), base-2 online softmax
@@ -253,7 +264,7 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2)
             for (int db = 0; db < NDB; ++db) {
 #pragma unroll
                 for (int s2 = 0; s2 < 2; ++s2) {
-                    const uint32_t * vr = &Vt[buf][(db * 32 + lq) * (VLD / 2) + 8 * s2 + 2 * hb];
+                    const uint32_t * vr = &Vt[buf][kvs][(db * 32 + lq) * (VLD / 2) + 8 * s2 + 2 * hb];
                     union { uint32_t u[4]; h8v v; } vf;
                     vf.u[0] = vr[0]; vf.u[1] = vr[1]; vf.u[2] = vr[4]; vf.u[3] = vr[5];
                     acc_o[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf.v, pf[s2].v, acc_o[db], 0, 0, 0);
@@ -263,6 +274,34 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2)
         t = tn; cls = cls_n; ++nlive;
     }
 
+    // ---- merge the KS partial states of each query block (same lane layout in every wave of a block): the ks > 0 waves park
+    // (M, S, O^T) in LDS, the ks == 0 wave folds them in and finishes
+    if (KS > 1) {
+        __shared__ float mrg[KS > 1 ? (KS - 1) * NW * 64 * (NDB * 16 + 2) : 1];
+        float * mine = mrg + ((size_t) ((kvs > 0 ? kvs - 1 : 0) * NW + wave) * 64 + lane) * (NDB * 16 + 2);
+        if (kvs > 0) {
+            mine[0] = M; mine[1] = S;
+#pragma unroll
+            for (int db = 0; db < NDB; ++db)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) mine[2 + db * 16 + e] = acc_o[db][e];
+        }
+        __syncthreads();
+        if (kvs > 0) return;
+#pragma unroll
+        for (int k = 1; k < KS; ++k) {
+            const float * oth = mrg + ((size_t) ((k - 1) * NW + wave) * 64 + lane) * (NDB * 16 + 2);
+            const float Mo = oth[0], So = oth[1];
+            const float Mn = fmaxf(M, Mo);
+            const float Mu = Mn == -INFINITY ? 0.0f : Mn;
+            const float f0 = __builtin_amdgcn_exp2f(M - Mu), f1 = __builtin_amdgcn_exp2f(Mo - Mu);
+            S = S * f0 + So * f1; M = Mn;
+#pragma unroll
+            for (int db = 0; db < NDB; ++db)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc_o[db][e] = acc_o[db][e] * f0 + oth[2 + db * 16 + e] * f1;
+        }
+    }
     // ---- finish: fold the two lane halves' partial sums, sinks (ops.cpp:8116-8130), normalise, store permuted
     S += __shfl_xor(S, 32, 64);
     float osc = 1.0f;
@@ -336,13 +375,16 @@ void fattn_mask_map(const fa_dev & a, uint8_t * map, hipStream_t st) {
 template <int D>
 static void launch_fm(const fa_dev & a, hipStream_t st) {
     const int nqt4 = (a.nq + 127) / 128;
+    static const bool no_split = getenv("MI355X_FA_NO_KVSPLIT") != nullptr;
+    const int64_t blocks32 = (int64_t) ((a.nq + 31) / 32) * a.nh * a.ns;          // one wave each without a KV split
     if (a.nq <= 32) {
-        k_fattn_mma<D, 1><<<dim3((unsigned) (a.nh * a.ns)), dim3(64), 0, st>>>(a, 1);
+        k_fattn_mma<D, 1, 1><<<dim3((unsigned) (a.nh * a.ns)), dim3(64), 0, st>>>(a, 1);
     } else if ((int64_t) nqt4 * a.nh * a.ns >= 512) {
-        k_fattn_mma<D, 4><<<dim3((unsigned) (nqt4 * a.nh * a.ns)), dim3(256), 0, st>>>(a, nqt4);
+        k_fattn_mma<D, 4, 1><<<dim3((unsigned) (nqt4 * a.nh * a.ns)), dim3(256), 0, st>>>(a, nqt4);
     } else {
         const int nqt = (a.nq + 63) / 64;
-        k_fattn_mma<D, 2><<<dim3((unsigned) (nqt * a.nh * a.ns)), dim3(128), 0, st>>>(a, nqt);
+        if (!no_split && blocks32 <= 768 && a.nkv >= 128) k_fattn_mma<D, 2, 2><<<dim3((unsigned) (nqt * a.nh * a.ns)), dim3(256), 0, st>>>(a, nqt);   // fewer waves than SIMDs
+        else                                             k_fattn_mma<D, 2, 1><<<dim3((unsigned) (nqt * a.nh * a.ns)), dim3(128), 0, st>>>(a, nqt);
     }
 }
 
