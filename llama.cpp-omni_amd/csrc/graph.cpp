@@ -1315,6 +1315,7 @@ void graph_optimize(backend_ctx *, ggml_cgraph * g) {
     static const bool off = getenv("MI355X_NO_GRAPH_OPTIMIZE") != nullptr;
     if (off || !g || g->n_nodes < 3) return;
     auto is_weight = [](const ggml_tensor * t) { return t && t->op == GGML_OP_NONE && t->view_src == nullptr && t->buffer != nullptr; };
+    auto root_of = [](const ggml_tensor * t) { while (t->view_src) t = t->view_src; return t; };
     for (int i = 0; i < g->n_nodes; ++i) {
         ggml_tensor * a = g->nodes[i];
         if (a->op != GGML_OP_MUL_MAT || a->view_src || !is_weight(a->src[0])) continue;
@@ -1322,6 +1323,14 @@ void graph_optimize(backend_ctx *, ggml_cgraph * g) {
         for (int j = i + 1; j < g->n_nodes && j < i + 64; ++j) {
             ggml_tensor * c = g->nodes[j];
             if (c->op != GGML_OP_MUL_MAT || c->view_src || c->src[1] != a->src[1] || !is_weight(c->src[0])) continue;
+            // (an in-place op on the shared activation between the two would make the later mat-mul see different data: leave it)
+            bool inplace_between = false;
+            for (int k = at; k < j && !inplace_between; ++k) {
+                const ggml_tensor * mnode = g->nodes[k];
+                if (is_noop(mnode)) continue;
+                for (const ggml_tensor * r = mnode->view_src; r; r = r->view_src) if (r == root_of(a->src[1])) { inplace_between = true; break; }
+            }
+            if (inplace_between) break;
             if (j != at) {                                               // rotate nodes[at .. j] right by one
                 for (int k = j; k > at; --k) g->nodes[k] = g->nodes[k - 1];
                 g->nodes[at] = c;
