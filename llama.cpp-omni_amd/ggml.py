@@ -26,7 +26,8 @@ GGML_BACKEND_BUFFER_USAGE_ANY, GGML_BACKEND_BUFFER_USAGE_WEIGHTS, GGML_BACKEND_B
 
 class OP:
     NONE, DUP, ADD, SUB, MUL, DIV = 0, 1, 2, 6, 7, 8
-    RMS_NORM, MUL_MAT, SCALE, CPY, CONT, RESHAPE, VIEW, PERMUTE, TRANSPOSE = 24, 28, 31, 33, 34, 35, 36, 37, 38
+    NORM, RMS_NORM, MUL_MAT, SCALE, CPY, CONT, RESHAPE, VIEW, PERMUTE, TRANSPOSE = 23, 24, 28, 31, 33, 34, 35, 36, 37, 38
+    IM2COL = 51
     GET_ROWS, SET_ROWS, SOFT_MAX, ROPE, FLASH_ATTN_EXT, UNARY, GLU = 39, 41, 45, 47, 69, 80, 89
 
 
@@ -509,6 +510,30 @@ class Context:
     def rms_norm(self, a, eps):
         T = self._new(a.type, a.ne)
         return self._op(T, OP.RMS_NORM, [a], (_f32_bits(eps),))
+
+    def norm(self, a, eps):
+        """ggml_norm (LayerNorm without the affine part), ggml.c"""
+        T = self._new(a.type, a.ne)
+        return self._op(T, OP.NORM, [a], (_f32_bits(eps),))
+
+    def im2col(self, kernel, x, s0, s1, p0, p1, d0, d1, is_2d, dst_type):
+        """ggml_im2col (ggml.c): kernel [KW, KH, IC, OC] (2-D) / [K, IC, OC] (1-D) gives only the window shape"""
+        def out_size(ins, ks, s, p, d):
+            return (ins + 2 * p - d * (ks - 1) - 1) // s + 1
+        if is_2d:
+            OH, OW = out_size(x.ne[1], kernel.ne[1], s1, p1, d1), out_size(x.ne[0], kernel.ne[0], s0, p0, d0)
+            ne = (kernel.ne[2] * kernel.ne[1] * kernel.ne[0], OW, OH, x.ne[3])
+        else:
+            OW = out_size(x.ne[0], kernel.ne[0], s0, p0, d0)
+            ne = (kernel.ne[1] * kernel.ne[0], OW, x.ne[2], 1)
+        T = self._new(dst_type, ne)
+        return self._op(T, OP.IM2COL, [kernel, x], (s0, s1, p0, p1, d0, d1, 1 if is_2d else 0))
+
+    def conv_1d(self, kernel, x, s0, p0, d0):
+        """ggml_conv_1d (ggml.c): im2col in f16, then one MUL_MAT against the flattened f16 kernel -> [OL, OC, N]"""
+        col = self.im2col(kernel, x, s0, 0, p0, 0, d0, 0, False, GGML_TYPE_F16)
+        r = self.mul_mat(self.reshape(col, col.ne[0], col.ne[2] * col.ne[1]), self.reshape(kernel, kernel.ne[0] * kernel.ne[1], kernel.ne[2]))
+        return self.reshape(r, col.ne[1], kernel.ne[2], col.ne[2])
 
     def mul_mat(self, a, b):
         assert a.ne[0] == b.ne[0] and b.ne[2] % a.ne[2] == 0 and b.ne[3] % a.ne[3] == 0

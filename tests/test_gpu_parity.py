@@ -439,6 +439,37 @@ def test_prefill_ubatch_vs_reference_backend(pkg, be, ref_be, wtype):
     assert agree > (0.99 if wtype == "f16" else 0.9), agree           # (random weights: near-ties may flip between f16 GEMM and integer dot)
 
 
+def test_encoder_block_vs_reference_backend(pkg, be, ref_be):
+    """First ops of the omni audio encoder (tools/omni/audition.cpp: conv1d -> GELU -> LayerNorm * w + b -> F16 linear), i.e. IM2COL,
+    the F16 x F16 MUL_MAT of ggml_conv_1d, UNARY(GELU), CONT(transpose), NORM, MUL, ADD, MUL_MAT -- against the reference CPU backend."""
+    rng = np.random.default_rng(31)
+    L, IC, OC, K, F = 96, 16, 32, 3, 64
+    xv = rng.standard_normal((1, IC, L)).astype(np.float32)
+    kv = (rng.standard_normal((OC, IC, K)) * 0.2).astype(np.float16)
+    wv = rng.standard_normal(OC).astype(np.float32); bv = rng.standard_normal(OC).astype(np.float32)
+    lv = (rng.standard_normal((F, OC)) * 0.2).astype(np.float16)
+    outs = []
+    for backend in (be, ref_be):
+        c = pkg.Context(backend)
+        x = c.new_tensor(pkg.GGML_TYPE_F32, L, IC, 1)
+        kern = c.new_tensor(pkg.GGML_TYPE_F16, K, IC, OC)
+        w = c.new_tensor(pkg.GGML_TYPE_F32, OC); b = c.new_tensor(pkg.GGML_TYPE_F32, OC)
+        lin = c.new_tensor(pkg.GGML_TYPE_F16, OC, F)
+        h = c.conv_1d(kern, x, 1, 1, 1)                                # [OL, OC, 1]
+        h = c.unary(h, pkg.UNARY.GELU)
+        h = c.cont(c.transpose(c.reshape(h, h.ne[0], h.ne[1])))        # [OC, OL]: features contiguous per frame
+        h = c.add(c.mul(c.norm(h, 1e-5), w), b)
+        y = c.mul_mat(lin, h)                                          # [F, OL]
+        c.alloc()
+        for t, v in ((x, xv), (kern, kv), (w, wv), (b, bv), (lin, lv)):
+            backend.tensor_set(t, v)
+        backend.graph_compute(c.graph())
+        outs.append(backend.tensor_get(y).copy())
+        c.free()
+    assert np.isfinite(outs[0]).all()
+    assert nmse(outs[0], outs[1]) < 1e-6
+
+
 def test_f16_model_logits_within_1e3(pkg, be, ref_be):
     """north star: F16 logits within 1e-3 of the reference CPU backend (F16 weights, f16-rounded activations, f32 accumulate)."""
     from llama_cpp_omni_amd import qwen3
