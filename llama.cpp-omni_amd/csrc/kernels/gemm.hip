@@ -429,6 +429,17 @@ void gemm_reduce_rms_norm(const float * partial, int nsplit, const float * resid
                                                                     (char *) y32, y32_cs, (char *) y16, y16_rs, (int) M);
 }
 
+// dynamic LDS above 64 KB needs a function attribute, once per (kernel, device): a process may drive several GPUs
+static void allow_big_lds(const void * kernel, int bytes, int slot) {
+    static bool done[2][64] = {};
+    int dev = 0;
+    HIP_CHECK(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 64 || !done[slot][dev]) {
+        HIP_CHECK(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+        if (dev >= 0 && dev < 64) done[slot][dev] = true;
+    }
+}
+
 // choose a K split that brings a lone, under-filled launch up to about two workgroups per CU
 static int pick_ksplit(int64_t tiles, int64_t nk) {
     if (tiles >= 256 || nk < 32) return 1;
@@ -500,8 +511,7 @@ void gemm_f16_multi(const gemm_multi_args & a, hipStream_t st) {
         g.ksteps_per_split = (int) (a.K / H_BK); g.split_stride = 0;
         g.ne12 = g.r2 = g.r3 = 1; g.w_nb2 = g.w_nb3 = g.x_bs = g.dst_nb2 = g.dst_nb3 = 0;
         constexpr int lds256 = 2 * 2 * 256 * H_ROWB;               // 128 KB
-        static bool attr256 = false;
-        if (!attr256) { HIP_CHECK(hipFuncSetAttribute((const void *) k_gemm_f16_glds256, hipFuncAttributeMaxDynamicSharedMemorySize, lds256)); attr256 = true; }
+        allow_big_lds((const void *) k_gemm_f16_glds256, lds256, 0);
         k_gemm_f16_glds256<<<dim3((unsigned) (tm * tiles_n256)), dim3(512), lds256, st>>>(g);
         return;
     }
@@ -526,8 +536,7 @@ void gemm_f16_multi(const gemm_multi_args & a, hipStream_t st) {
         k_gemm_f16_glds<1><<<dim3((unsigned) (tm * tiles_n), (unsigned) nbatch), dim3(256), 2 * (64 * H_ROWB + H_TILEB), st>>>(g);
     } else if (BM == 192) {
         constexpr int lds192 = 2 * (192 * H_ROWB + H_TILEB);        // 80 KB: two workgroups per CU
-        static bool attr_set = false;
-        if (!attr_set) { HIP_CHECK(hipFuncSetAttribute((const void *) k_gemm_f16_glds<3>, hipFuncAttributeMaxDynamicSharedMemorySize, lds192)); attr_set = true; }
+        allow_big_lds((const void *) k_gemm_f16_glds<3>, lds192, 1);
         k_gemm_f16_glds<3><<<dim3((unsigned) (tm * tiles_n), (unsigned) nbatch), dim3(256), lds192, st>>>(g);
     } else {
         k_gemm_f16_glds<2><<<dim3((unsigned) (tm * tiles_n), (unsigned) nbatch), dim3(256), 2 * (128 * H_ROWB + H_TILEB), st>>>(g);
