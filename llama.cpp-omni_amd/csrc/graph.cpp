@@ -1144,7 +1144,11 @@ static void compute_node(exec_state & s, int i) {
                 n->nb[3] == n->nb[2] * (size_t) n->ne[2] && gemm_only_consumers(s, n, n->ne[0] * n->ne[1], n->ne[2] * n->ne[3], &xg16)) {
                 f.out16 = (uint16_t *) s.c->act_scratch; f.out16_rs = act_image_bytes(ACT_F16, n->ne[0] * n->ne[1]); f.write_f32 = n_users(s, n) > 1;
             }
-            if (fattn_scratch_bytes(f) > 0) {
+            if (fattn_scratch_bytes(f) > 0 && !fattn_uses_mma(f)) {       // decode kernel at long context: workspace of its KV split
+                f.scratch = s.c->fa_scratch; f.scratch_bytes = s.c->fa_scratch_bytes;
+                s.fa_mask = nullptr;                                      // (the scratch no longer holds a mask tile map)
+                ++s.n_kernels;
+            } else if (fattn_scratch_bytes(f) > 0) {
                 // the mask tile map is computed once per mask tensor and graph run (every layer shares the mask)
                 const ggml_tensor * mk = n->src[3];
                 f.scratch = s.c->fa_scratch; f.scratch_bytes = s.c->fa_scratch_bytes;

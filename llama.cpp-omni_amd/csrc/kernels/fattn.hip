@@ -36,6 +36,7 @@ __global__ void __launch_bounds__(64 * NW) k_fattn_dec(const fa_dev a) {
     const int ngrp_h = (a.gq + a.hpw - 1) / a.hpw;
     const int nqb    = (a.nq + a.qpw - 1) / a.qpw;
     int b = (int) blockIdx.x;                                              // 32-bit index math: 64-bit div/mod are ~100-instruction sequences
+    const int sp  = b % a.nsplit; b /= a.nsplit;                           // which slice of the KV range (long contexts, see launch_fa)
     const int qb  = b % nqb;    b /= nqb;
     const int hc  = b % ngrp_h; b /= ngrp_h;
     const int ikv = b % a.nhkv; const int is3 = b / a.nhkv;
@@ -112,7 +113,8 @@ __global__ void __launch_bounds__(64 * NW) k_fattn_dec(const fa_dev a) {
     const char * vbase = a.v + ikv * a.vnb2 + is3 * a.vnb3;
     const int ngran = (a.nkv + GR - 1) / GR;
 
-    for (int gi = wave; gi < ngran; gi += NW) {
+    const int gps = (ngran + a.nsplit - 1) / a.nsplit, g_lo = sp * gps, g_hi = g_lo + gps < ngran ? g_lo + gps : ngran;
+    for (int gi = g_lo + wave; gi < g_hi; gi += NW) {
         const int  kv    = gi * GR + r16;
         const bool kv_ok = kv < a.nkv;
         float mv[R];
@@ -232,6 +234,13 @@ __global__ void __launch_bounds__(64 * NW) k_fattn_dec(const fa_dev a) {
 #pragma unroll
             for (int e = 0; e < DPL; ++e) o[r][e] += cw[lane * DPL + e] * f;
         }
+        if (a.nsplit > 1) {                                           // partial state of this KV slice; k_fattn_merge finishes the row
+            float * pr = a.part + ((((int64_t) is3 * a.nq + r_q[r]) * a.nh + r_h[r]) * a.nsplit + sp) * (D + 2);
+#pragma unroll
+            for (int e = 0; e < DPL; ++e) pr[lane * DPL + e] = o[r][e];
+            if (lane == 0) { pr[D] = Mx; pr[D + 1] = St; }
+            continue;
+        }
         if (a.sinks) {                                                // ops.cpp:8116-8130
             const float sk = a.sinks[r_h[r]];
             if (sk > Mx) { const float f = expf(Mx - sk); St = St * f + 1.0f;
@@ -270,6 +279,59 @@ __global__ void __launch_bounds__(64 * NW) k_fattn_dec(const fa_dev a) {
     }
 }
 
+// second pass of the split decode (flash-decoding): one wave per (sequence, query row, 256-element block of the output row) folds the
+// nsplit partial states of its heads, applies the sinks, normalises, stores -- and emits the Q8_K block of the row's image for wo
+template <int D>
+__global__ void __launch_bounds__(64) k_fattn_merge(const float * __restrict__ part, int nsplit, int nq, int nh, int nblk, const float * __restrict__ sinks,
+                                                   char * __restrict__ dst, int64_t dnb1, int64_t dnb2, int64_t dnb3, char * __restrict__ img, size_t img_bytes) {
+    const int lane = threadIdx.x;
+    int b = blockIdx.x;
+    const int ib = b % nblk; b /= nblk;
+    const int qrow = b % nq, is3 = b / nq;
+    const int n = nh * D;
+    const int e0 = ib * 256 + 4 * lane;
+    f32x4 v = { 0.0f, 0.0f, 0.0f, 0.0f };
+    if (e0 < n) {
+        const int head = e0 / D, d = e0 % D;
+        const float * base = part + (((int64_t) is3 * nq + qrow) * nh + head) * nsplit * (D + 2);
+        float Mx = -INFINITY;
+#pragma unroll 8
+        for (int s = 0; s < nsplit; ++s) Mx = fmaxf(Mx, base[s * (D + 2) + D]);
+        float St = 0.0f;
+#pragma unroll 8
+        for (int s = 0; s < nsplit; ++s) {
+            const float Ms = base[s * (D + 2) + D];
+            const float f  = Ms == -INFINITY ? 0.0f : expf(Ms - Mx);
+            St += base[s * (D + 2) + D + 1] * f;
+            const f32x4 p = *(const f32x4 *) (base + s * (D + 2) + d);
+            v += p * f;
+        }
+        if (sinks) {                                                  // ops.cpp:8116-8130
+            const float sk = sinks[head];
+            if (sk > Mx) { const float f = expf(Mx - sk); St = St * f + 1.0f; v *= f; }
+            else St += expf(sk - Mx);
+        }
+        v *= St == 0.0f ? 0.0f : 1.0f / St;
+        *(f32x4 *) (dst + head * dnb1 + qrow * dnb2 + is3 * dnb3 + d * 4) = v;
+    }
+    if (img) {                                                        // (launcher: n % 256 == 0)
+        char * im = img + ((int64_t) is3 * nq + qrow) * img_bytes;
+        q8k_block_from_regs(v, lane, (int8_t *) im + ib * 256, (int16_t *) (im + n) + ib * 16, (float *) (im + n + n / 8) + ib);
+    }
+}
+
+// long contexts: the streaming decode kernel has one workgroup per KV-head group, which at depth 32k is 8 workgroups reading 4 GB per
+// token; cut the KV range into slices of >= 256 rows so that a few hundred workgroups share it (flash-decoding) and merge afterwards
+static int fa_decode_nsplit(const fattn_args & f) {
+    static const bool off = getenv("MI355X_FA_NO_DECODE_SPLIT") != nullptr;
+    const int64_t nkv = f.k.ne[1];
+    if (off || nkv < 1024 || f.pre) return 1;
+    int64_t s = nkv / 256;
+    const int64_t groups = f.k.ne[2] * f.q.ne[3] * f.q.ne[1];        // workgroups without a split (at least)
+    while (s > 1 && s * groups > 1024) s /= 2;
+    return (int) (s < 1 ? 1 : (s > 64 ? 64 : s));
+}
+
 template <int D, int R, int NW>
 static size_t fa_lds_bytes() { return (size_t) R * D * 4 + NW * 16 * R * 4 + NW * R * (D + 2) * 4; }
 
@@ -279,7 +341,12 @@ static bool fa_use_mma(const fattn_args & f) {
 bool fattn_uses_mma(const fattn_args & f) { return fa_use_mma(f); }
 size_t fattn_map_bytes(int64_t nq, int64_t nkv, int64_t mne2, int64_t mne3);
 size_t fattn_scratch_bytes(const fattn_args & f) {
-    if (!fa_use_mma(f) || !f.mask) return 0;
+    if (!fa_use_mma(f)) {                                             // decode kernel: partial rows of the KV split
+        fattn_args g = f; g.pre = nullptr;
+        const int ns = fa_decode_nsplit(g);
+        return ns > 1 ? (size_t) (f.q.ne[1] * f.q.ne[3] * f.q.ne[2]) * (size_t) ns * (size_t) (f.q.ne[0] + 2) * 4 : 0;
+    }
+    if (!f.mask) return 0;
     return fattn_map_bytes(f.q.ne[1], f.k.ne[1], f.mask->ne[2], f.mask->ne[3]);
 }
 
@@ -297,6 +364,8 @@ bool fattn_pre_ok(const fattn_args & f) {
     if ((D != 64 && D != 128) || f.q.ne[1] != 1 || f.q.ne[3] != 1 || f.k.ne[3] != 1) return false;
     fa_dev a; a.nq = 1; a.gq = (int) (f.q.ne[2] / f.k.ne[2]);
     int R, hpw, qpw; fa_split(a, R, hpw, qpw);
+    fattn_args g = f; g.pre = nullptr;
+    if (fa_decode_nsplit(g) > 1) return false;                        // another workgroup would read the cache row this one is still writing
     return hpw == a.gq && qpw == 1 && R == hpw;
 }
 
@@ -314,7 +383,7 @@ static void launch_fa(const fa_dev & a0, hipStream_t st) {
     int R; fa_split(a, R, a.hpw, a.qpw);
     const int64_t ngrp_h = (a.gq + a.hpw - 1) / a.hpw;
     const int64_t nqb    = (a.nq + a.qpw - 1) / a.qpw;
-    const int64_t nblk   = nqb * ngrp_h * a.nhkv * a.ns;
+    const int64_t nblk   = nqb * ngrp_h * a.nhkv * a.ns * a.nsplit;
     dim3 grid((unsigned) nblk);
     // waves per workgroup: one 16-row granule per wave for short contexts (pure latency), 4 waves when there are many workgroups anyway
     const bool wide = a.nkv > 64 && nblk <= 1024;
@@ -371,10 +440,23 @@ void flash_attn_ext_f16(const fattn_args & f, hipStream_t st) {
         flash_attn_ext_mma(a, (int) f.q.ne[0], st);
         return;
     }
+    a.nsplit = 1; a.part = nullptr;
+    const int nsplit = fa_decode_nsplit(f);
+    char * img_final = nullptr;
+    if (nsplit > 1 && f.scratch && f.scratch_bytes >= fattn_scratch_bytes(f) && (!a.img || (a.nh * f.q.ne[0]) % 256 == 0)) {
+        a.nsplit = nsplit; a.part = (float *) f.scratch;
+        img_final = a.img; a.img = nullptr;                           // the image is emitted by the merge pass
+    }
     switch ((int) f.q.ne[0]) {
         case 64:  launch_fa<64>(a, st); break;
         case 128: launch_fa<128>(a, st); break;
         default: fprintf(stderr, "[mi355x] flash_attn: unsupported head size %d\n", (int) f.q.ne[0]); abort();
+    }
+    if (a.nsplit > 1) {
+        const int nblk = (int) ((a.nh * f.q.ne[0] + 255) / 256);
+        const dim3 grid((unsigned) (a.nq * a.ns * nblk));
+        if (f.q.ne[0] == 64) k_fattn_merge<64><<<grid, dim3(64), 0, st>>>(a.part, a.nsplit, a.nq, a.nh, nblk, a.sinks, a.dst, a.dnb1, a.dnb2, a.dnb3, img_final, a.img_bytes);
+        else                 k_fattn_merge<128><<<grid, dim3(64), 0, st>>>(a.part, a.nsplit, a.nq, a.nh, nblk, a.sinks, a.dst, a.dnb1, a.dnb2, a.dnb3, img_final, a.img_bytes);
     }
 }
 
