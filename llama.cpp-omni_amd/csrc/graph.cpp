@@ -653,14 +653,14 @@ static void exec_mul_mat(exec_state & s, int i) {
     const int64_t K = x->ne[0]; const int N = (int) x->ne[1];
 
     // ---- (a) ffn_up / ffn_gate + GLU(SWIGLU, split): one launch, intermediates never written
-    if (N <= 4) {
+    if (N <= MI_MMVQ_MAX_COLS) {
         const int gi = sole_user(s, n);
         if (gi > i && g->nodes[gi]->op == GGML_OP_GLU && op_param_i32(g->nodes[gi], 0) == GGML_GLU_OP_SWIGLU && op_param_i32(g->nodes[gi], 1) == 0 &&
             g->nodes[gi]->src[0] && g->nodes[gi]->src[1]) {
             ggml_tensor * G = g->nodes[gi];
             ggml_tensor * other = G->src[0] == n ? G->src[1] : (G->src[1] == n ? G->src[0] : nullptr);
             auto oit = other ? s.index.find(other) : s.index.end();
-            if (other && oit != s.index.end() && oit->second > i && !s.done[oit->second] && plain_kq_matvec(other, 4) && sole_user(s, other) == gi &&
+            if (other && oit != s.index.end() && oit->second > i && !s.done[oit->second] && plain_kq_matvec(other, MI_MMVQ_MAX_COLS) && sole_user(s, other) == gi &&
                 same_act(other->src[1], x) && other->src[0]->type == n->src[0]->type && other->src[0]->ne[1] == n->src[0]->ne[1] &&
                 other->src[0]->nb[1] == n->src[0]->nb[1] && G->nb[0] == 4 && G->ne[0] == n->ne[0] && is_contiguous_1(G)) {
                 const int oi = oit->second;

@@ -55,7 +55,7 @@ struct mmv_multi_args {
     int64_t K; int ncols;                      // ncols * q8k_image_bytes(K) must fit LDS (<= 152 KiB)
 };
 void mmv_kquant_multi(const mmv_multi_args & a, hipStream_t st);
-// ffn_gate + ffn_up + SWIGLU: dst[col][r] = silu(Wg[r].x) * (Wu[r].x); both matrices `type`, same shape; ncols <= 4
+// ffn_gate + ffn_up + SWIGLU: dst[col][r] = silu(Wg[r].x) * (Wu[r].x); both matrices `type`, same shape; ncols <= 8
 void mmv_kquant_pair_swiglu(int type, const void * Wg, const void * Wu, size_t w_rs, const void * act, size_t act_cs, float * dst, size_t dst_cs,
                             int64_t K, int64_t nrows, int ncols, hipStream_t st, const mmv_norm * norm = nullptr);
 

@@ -464,7 +464,7 @@ void mmv_kquant_multi(const mmv_multi_args & a, hipStream_t st) {
     if (a.norm.x && a.ncols != 1) { fprintf(stderr, "[mi355x] mmv_kquant_multi: in-kernel norm is a one-column path\n"); abort(); }
     const size_t img = q8k_image_bytes(a.K);
     if (img * a.ncols > MMVK_LDS_MAX) { fprintf(stderr, "[mi355x] mmv_kquant_multi: activation images exceed LDS (K=%lld, ncols=%d)\n", (long long) a.K, a.ncols); abort(); }
-    const int rows_pw = a.ncols <= 4 ? 2 : 1;
+    const int rows_pw = 2;
     // grid: enough waves that every row group is resident at once when the matrices are small, capped at 8 WG/CU
     double bytes[3]; double total = 0; int64_t groups = 0;
     int tm = 0;
@@ -507,10 +507,10 @@ void mmv_kquant_multi(const mmv_multi_args & a, hipStream_t st) {
         case 2: MM_GO(2, 2, 1); break;
         case 3: MM_GO(3, 2, 1); break;
         case 4: MM_GO(4, 2, 1); break;
-        case 5: MM_GO(5, 1, 1); break;
-        case 6: MM_GO(6, 1, 1); break;
-        case 7: MM_GO(7, 1, 1); break;
-        case 8: MM_GO(8, 1, 1); break;
+        case 5: MM_GO(5, 2, 1); break;
+        case 6: MM_GO(6, 2, 1); break;
+        case 7: MM_GO(7, 2, 1); break;
+        case 8: MM_GO(8, 2, 1); break;
         default: fprintf(stderr, "[mi355x] mmv_kquant_multi: ncols=%d out of range\n", a.ncols); abort();
     }
 #undef MM_GO
@@ -543,7 +543,11 @@ void mmv_kquant_pair_swiglu(int type, const void * Wg, const void * Wu, size_t w
         case 2: MP_GO(2, 1); break;
         case 3: MP_GO(3, 1); break;
         case 4: MP_GO(4, 1); break;
-        default: fprintf(stderr, "[mi355x] mmv_kquant_pair_swiglu: ncols=%d out of range (1..4)\n", ncols); abort();
+        case 5: MP_GO(5, 1); break;
+        case 6: MP_GO(6, 1); break;
+        case 7: MP_GO(7, 1); break;
+        case 8: MP_GO(8, 1); break;
+        default: fprintf(stderr, "[mi355x] mmv_kquant_pair_swiglu: ncols=%d out of range (1..8)\n", ncols); abort();
     }
 #undef MP_GO
 #undef MP_GO2
