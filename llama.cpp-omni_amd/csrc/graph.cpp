@@ -1374,6 +1374,7 @@ int mi355x_set_option(struct ggml_backend * backend, const char * key, long valu
     if (!strcmp(key, "fusion"))  { c->opt_fusion = value != 0; c->execs.clear(); return 0; }
     if (!strcmp(key, "profile")) { c->opt_profile = value != 0; return 0; }
     if (!strcmp(key, "norm_in_kernel")) { c->opt_norm_in_kernel = value != 0; c->execs.clear(); return 0; }
+    if (!strcmp(key, "fattn_gqa")) { mi::fattn_set_gqa(value != 0); c->execs.clear(); return 0; }
     if (!strcmp(key, "f16_shadow")) { mi::shadow_set_enabled(value != 0); c->execs.clear(); return 0; }
     if (!strcmp(key, "reset_stats")) { c->prof.clear(); c->stat_replays = c->stat_captures = c->stat_eager = 0; return 0; }
     return -1;

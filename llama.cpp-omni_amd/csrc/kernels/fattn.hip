@@ -114,35 +114,36 @@ __global__ void __launch_bounds__(64 * NW) k_fattn_dec(const fa_dev a) {
     const int ngran = (a.nkv + GR - 1) / GR;
 
     const int gps = (ngran + a.nsplit - 1) / a.nsplit, g_lo = sp * gps, g_hi = g_lo + gps < ngran ? g_lo + gps : ngran;
-    for (int gi = g_lo + wave; gi < g_hi; gi += NW) {
+    // Two granules in flight per wave: the mask row and the K / V rows of granule g + NW are requested before granule g is reduced, so a
+    // wave with several granules (long contexts, KV split) pays the memory latency once instead of once per granule.
+    struct granule { float mv[R]; u32x4 kk[KCH]; uint32_t vv[GR]; bool live; };
+    auto fetch = [&](const int gi, granule & G) {
         const int  kv    = gi * GR + r16;
         const bool kv_ok = kv < a.nkv;
-        float mv[R];
         bool any_live = false;
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             float m = 0.0f;
             if (mrow[r] && kv_ok) m = slope[r] * h2f(mrow[r][kv]);
             if (!kv_ok || !r_ok[r]) m = -INFINITY;
-            mv[r] = m;
+            G.mv[r] = m;
             any_live |= (m != -INFINITY);
         }
-        if (!__any(any_live)) continue;                               // whole granule masked for every query vector
+        G.live = __any(any_live);
+        if (!G.live) return;                                          // whole granule masked for every query vector
 
         // ---- issue every load of the granule up front: a quarter K row per lane, then the 16 V rows (D/64 dims per lane)
         const int64_t kvc = kv_ok ? kv : a.nkv - 1;
-        (void) dq;
-        u32x4 kk[KCH];
 #pragma unroll
-        for (int c = 0; c < KCH; ++c) kk[c] = *(const u32x4 *) (kbase + kvc * a.knb1 + dq * (D / 2) + c * 16);
-        uint32_t vv[GR];
+        for (int c = 0; c < KCH; ++c) G.kk[c] = *(const u32x4 *) (kbase + kvc * a.knb1 + dq * (D / 2) + c * 16);
 #pragma unroll
         for (int j = 0; j < GR; ++j) {
             int vr = gi * GR + j; vr = vr < a.nkv ? vr : a.nkv - 1;
-            if (DPL == 2) vv[j] = *(const uint32_t *) (vbase + vr * a.vnb1 + lane * 4);
-            else          vv[j] = *(const uint16_t *) (vbase + vr * a.vnb1 + lane * 2);
+            if (DPL == 2) G.vv[j] = *(const uint32_t *) (vbase + vr * a.vnb1 + lane * 4);
+            else          G.vv[j] = *(const uint16_t *) (vbase + vr * a.vnb1 + lane * 2);
         }
-
+    };
+    auto reduce = [&](const granule & G) {
         // ---- scores
         float s[R];
 #pragma unroll
@@ -151,7 +152,7 @@ __global__ void __launch_bounds__(64 * NW) k_fattn_dec(const fa_dev a) {
         for (int c = 0; c < KCH; ++c) {
             float kf[8];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { kf[2 * e] = h2f((uint16_t) (kk[c][e] & 0xffff)); kf[2 * e + 1] = h2f((uint16_t) (kk[c][e] >> 16)); }
+            for (int e = 0; e < 4; ++e) { kf[2 * e] = h2f((uint16_t) (G.kk[c][e] & 0xffff)); kf[2 * e + 1] = h2f((uint16_t) (G.kk[c][e] >> 16)); }
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 const f32x4 q0 = *(const f32x4 *) (qf + r * D + dq * (D / 4) + c * 8);
@@ -169,8 +170,8 @@ __global__ void __launch_bounds__(64 * NW) k_fattn_dec(const fa_dev a) {
             t += __shfl_xor(t, 2, 64);
             float v = t * a.scale;
             if (a.logit_softcap != 0.0f) v = a.logit_softcap * tanhf(v);
-            v += mv[r];
-            if (mv[r] == -INFINITY) v = -INFINITY;
+            v += G.mv[r];
+            if (G.mv[r] == -INFINITY) v = -INFINITY;
             float tmax = v;                                             // max over the 16 rows (every row is replicated in its 4 dq lanes)
 #pragma unroll
             for (int o = 4; o < 64; o <<= 1) tmax = fmaxf(tmax, __shfl_xor(tmax, o, 64));
@@ -194,8 +195,8 @@ __global__ void __launch_bounds__(64 * NW) k_fattn_dec(const fa_dev a) {
 #pragma unroll
         for (int j = 0; j < GR; ++j) {
             float vf[DPL];
-            if (DPL == 2) { vf[0] = h2f((uint16_t) (vv[j] & 0xffff)); vf[DPL - 1] = h2f((uint16_t) (vv[j] >> 16)); }
-            else          { vf[0] = h2f((uint16_t) vv[j]); }
+            if (DPL == 2) { vf[0] = h2f((uint16_t) (G.vv[j] & 0xffff)); vf[DPL - 1] = h2f((uint16_t) (G.vv[j] >> 16)); }
+            else          { vf[0] = h2f((uint16_t) G.vv[j]); }
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 const float p = pl[j * R + r];
@@ -206,6 +207,33 @@ __global__ void __launch_bounds__(64 * NW) k_fattn_dec(const fa_dev a) {
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
+    constexpr bool PIPE = R * DPL <= 8;                  // the second granule's registers fit (<= 256 VGPRs, no scratch)
+    if (PIPE) {
+        granule A, B;
+        int gi = g_lo + wave;
+        if (gi < g_hi) {
+            fetch(gi, A);
+            for (;;) {
+                int gn = gi + NW;
+                const bool has_b = gn < g_hi;
+                if (has_b) fetch(gn, B);
+                if (A.live) reduce(A);
+                if (!has_b) break;
+                gi = gn; gn = gi + NW;
+                const bool has_a = gn < g_hi;
+                if (has_a) fetch(gn, A);
+                if (B.live) reduce(B);
+                if (!has_a) break;
+                gi = gn;
+            }
+        }
+    } else {
+        for (int gi = g_lo + wave; gi < g_hi; gi += NW) {
+            granule A;
+            fetch(gi, A);
+            if (A.live) reduce(A);
+        }
     }
 
     // ---- merge the four waves' partial (M, S, acc)
@@ -279,32 +307,62 @@ __global__ void __launch_bounds__(64 * NW) k_fattn_dec(const fa_dev a) {
     }
 }
 
-// second pass of the split decode (flash-decoding): one wave per (sequence, query row, 256-element block of the output row) folds the
-// nsplit partial states of its heads, applies the sinks, normalises, stores -- and emits the Q8_K block of the row's image for wo
+// second pass of the split decode (flash-decoding): one workgroup per (sequence, query row, 256-element block of the output row).  Its
+// four waves each fold every fourth partial state of their heads (all loads of a wave independent: two round trips, not nsplit),
+// park the result in LDS, and wave 0 folds those four, applies the sinks, normalises, stores -- and emits the Q8_K block of the row's
+// image for wo
 template <int D>
-__global__ void __launch_bounds__(64) k_fattn_merge(const float * __restrict__ part, int nsplit, int nq, int nh, int nblk, const float * __restrict__ sinks,
-                                                   char * __restrict__ dst, int64_t dnb1, int64_t dnb2, int64_t dnb3, char * __restrict__ img, size_t img_bytes) {
-    const int lane = threadIdx.x;
+__global__ void __launch_bounds__(256) k_fattn_merge(const float * __restrict__ part, int nsplit, int nq, int nh, int nblk, const float * __restrict__ sinks,
+                                                    char * __restrict__ dst, int64_t dnb1, int64_t dnb2, int64_t dnb3, char * __restrict__ img, size_t img_bytes) {
+    __shared__ __attribute__((aligned(16))) float park[4][64][6];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     int b = blockIdx.x;
     const int ib = b % nblk; b /= nblk;
     const int qrow = b % nq, is3 = b / nq;
     const int n = nh * D;
     const int e0 = ib * 256 + 4 * lane;
+    const int head = e0 / D, d = e0 % D;
     f32x4 v = { 0.0f, 0.0f, 0.0f, 0.0f };
+    float Mx = -INFINITY, St = 0.0f;
     if (e0 < n) {
-        const int head = e0 / D, d = e0 % D;
         const float * base = part + (((int64_t) is3 * nq + qrow) * nh + head) * nsplit * (D + 2);
-        float Mx = -INFINITY;
-#pragma unroll 8
-        for (int s = 0; s < nsplit; ++s) Mx = fmaxf(Mx, base[s * (D + 2) + D]);
-        float St = 0.0f;
-#pragma unroll 8
-        for (int s = 0; s < nsplit; ++s) {
-            const float Ms = base[s * (D + 2) + D];
-            const float f  = Ms == -INFINITY ? 0.0f : expf(Ms - Mx);
-            St += base[s * (D + 2) + D + 1] * f;
-            const f32x4 p = *(const f32x4 *) (base + s * (D + 2) + d);
-            v += p * f;
+        constexpr int B = 16;                                         // partial states in flight per wave: clamped indices, no branches
+        for (int s0 = wave; s0 < nsplit; s0 += 4 * B) {
+            float Ms[B], Ss[B]; f32x4 p[B];
+#pragma unroll
+            for (int i = 0; i < B; ++i) {
+                const int s = s0 + 4 * i, sc = s < nsplit ? s : s0;
+                Ms[i] = base[sc * (D + 2) + D]; Ss[i] = base[sc * (D + 2) + D + 1];
+                p[i]  = *(const f32x4 *) (base + sc * (D + 2) + d);
+                if (s >= nsplit) Ms[i] = -INFINITY;
+            }
+            float Mn = Mx;
+#pragma unroll
+            for (int i = 0; i < B; ++i) Mn = fmaxf(Mn, Ms[i]);
+            const float f0 = Mx == -INFINITY ? 0.0f : expf(Mx - Mn);
+            St *= f0; v *= f0; Mx = Mn;
+#pragma unroll
+            for (int i = 0; i < B; ++i) {
+                const float f = Ms[i] == -INFINITY ? 0.0f : expf(Ms[i] - Mx);
+                St += Ss[i] * f;
+                v += p[i] * f;
+            }
+        }
+    }
+    float * pk = &park[wave][lane][0];
+    *(f32x4 *) pk = v; pk[4] = Mx; pk[5] = St;
+    __syncthreads();
+    if (wave != 0) return;
+    if (e0 < n) {
+        float Mw[4];
+#pragma unroll
+        for (int w = 0; w < 4; ++w) { Mw[w] = park[w][lane][4]; Mx = fmaxf(Mx, Mw[w]); }
+        v = f32x4{ 0.0f, 0.0f, 0.0f, 0.0f }; St = 0.0f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const float f = Mw[w] == -INFINITY ? 0.0f : expf(Mw[w] - Mx);
+            St += park[w][lane][5] * f;
+            v += *(const f32x4 *) &park[w][lane][0] * f;
         }
         if (sinks) {                                                  // ops.cpp:8116-8130
             const float sk = sinks[head];
@@ -332,6 +390,39 @@ static int fa_decode_nsplit(const fattn_args & f) {
     return (int) (s < 1 ? 1 : (s > 64 ? 64 : s));
 }
 
+// A few query tokens whose (token, head) pairs fit 32-column tiles go through the matrix cores (k_fattn_gqa, fattn_mma.hip): one token,
+// one token of each of a few sequences, a short draft.  The streaming kernel above remains for the shapes that do not fit (more than
+// 32 heads per KV head, per-head masks) and as the cross-check ("fattn_gqa" option off).
+static bool g_gqa_enabled = true;
+void fattn_set_gqa(bool on) { g_gqa_enabled = on; }
+struct gqa_plan { bool ok; int qpw, nsplit, nw; };
+static gqa_plan fa_gqa_plan(const fattn_args & f) {
+    static const bool off = getenv("MI355X_FA_NO_DECODE_MMA") != nullptr;
+    static const int  direct_tiles = getenv("MI355X_FA_GQA_DIRECT_TILES") ? atoi(getenv("MI355X_FA_GQA_DIRECT_TILES")) : 8;
+    gqa_plan p = { false, 1, 1, 4 };
+    const int64_t D = f.q.ne[0], nq = f.q.ne[1], nkv = f.k.ne[1], gq = f.k.ne[2] > 0 ? f.q.ne[2] / f.k.ne[2] : 0;
+    if (off || !g_gqa_enabled || (D != 64 && D != 128) || f.v.ne[0] != D || nq < 1 || nq > 8 || gq < 1 || gq > 32 || nkv < 1) return p;
+    if (f.q.ne[2] != gq * f.k.ne[2]) return p;
+    if (f.mask && f.mask->ne[2] != 1) return p;                       // (a per-head mask would need per-lane mask rows)
+    // one token over a shallow cache stays on the streaming kernel: it skips the dead granules of a padded cache view before touching
+    // K / V and measures ~3 us per layer faster there (tg128: 398 vs 381 tok/s); everything else is faster here
+    static const int stream_tiles = getenv("MI355X_FA_STREAM_TILES") ? atoi(getenv("MI355X_FA_STREAM_TILES")) : 8;
+    if (nq == 1 && (nkv + 31) / 32 <= stream_tiles) return p;
+    p.ok  = true;
+    p.qpw = (int) (nq < 32 / gq ? nq : 32 / gq);
+    const int64_t groups = f.k.ne[2] * f.q.ne[3] * ((nq + p.qpw - 1) / p.qpw);
+    const int64_t ntile  = (nkv + 31) / 32;
+    if (ntile <= direct_tiles) {                                      // shallow: one workgroup per group finishes the rows itself
+        static const int force_nw = getenv("MI355X_FA_GQA_NW") ? atoi(getenv("MI355X_FA_GQA_NW")) : 0;
+        p.nsplit = 1; p.nw = force_nw ? force_nw : (f.pre ? 8 : 4);   // pre-stage: gq + 2 wave tasks in one round
+    } else {                                                          // deep: slices of >= 4 tiles, two workgroups per CU, merge pass
+        int64_t s = 512 / groups;
+        if (s > (ntile + 3) / 4) s = (ntile + 3) / 4;
+        p.nsplit = (int) (s < 2 ? 2 : s); p.nw = 4;
+    }
+    return p;
+}
+
 template <int D, int R, int NW>
 static size_t fa_lds_bytes() { return (size_t) R * D * 4 + NW * 16 * R * 4 + NW * R * (D + 2) * 4; }
 
@@ -341,9 +432,10 @@ static bool fa_use_mma(const fattn_args & f) {
 bool fattn_uses_mma(const fattn_args & f) { return fa_use_mma(f); }
 size_t fattn_map_bytes(int64_t nq, int64_t nkv, int64_t mne2, int64_t mne3);
 size_t fattn_scratch_bytes(const fattn_args & f) {
-    if (!fa_use_mma(f)) {                                             // decode kernel: partial rows of the KV split
+    if (!fa_use_mma(f)) {                                             // decode kernels: partial rows of the KV split
         fattn_args g = f; g.pre = nullptr;
-        const int ns = fa_decode_nsplit(g);
+        const gqa_plan gp = fa_gqa_plan(g);
+        const int ns = gp.ok ? gp.nsplit : fa_decode_nsplit(g);
         return ns > 1 ? (size_t) (f.q.ne[1] * f.q.ne[3] * f.q.ne[2]) * (size_t) ns * (size_t) (f.q.ne[0] + 2) * 4 : 0;
     }
     if (!f.mask) return 0;
@@ -362,6 +454,7 @@ static void fa_split(const fa_dev & a, int & R, int & hpw, int & qpw) {
 bool fattn_pre_ok(const fattn_args & f) {
     const int D = (int) f.q.ne[0];
     if ((D != 64 && D != 128) || f.q.ne[1] != 1 || f.q.ne[3] != 1 || f.k.ne[3] != 1) return false;
+    if (fa_gqa_plan(f).ok) return true;                               // (with a KV split only the slice that owns the new cache row stores it)
     fa_dev a; a.nq = 1; a.gq = (int) (f.q.ne[2] / f.k.ne[2]);
     int R, hpw, qpw; fa_split(a, R, hpw, qpw);
     fattn_args g = f; g.pre = nullptr;
@@ -373,6 +466,8 @@ bool fattn_can_emit_image(const fattn_args & f) {
     const int D = (int) f.q.ne[0];
     if (D != 64 && D != 128) return false;
     fa_dev a; a.nq = f.q.ne[1]; a.gq = (int) (f.q.ne[2] / f.k.ne[2]);
+    const gqa_plan gp = fa_gqa_plan(f);                               // finishing workgroup: whole 256-element blocks of the row; else the merge pass
+    if (gp.ok) return (f.q.ne[2] * D) % 256 == 0 && (gp.nsplit > 1 || (a.gq * D) % 256 == 0);
     int R, hpw, qpw; fa_split(a, R, hpw, qpw);
     return (hpw * D) % 256 == 0 && a.gq % hpw == 0 && (f.q.ne[2] * D) % 256 == 0;
 }
@@ -440,14 +535,19 @@ void flash_attn_ext_f16(const fattn_args & f, hipStream_t st) {
         flash_attn_ext_mma(a, (int) f.q.ne[0], st);
         return;
     }
-    a.nsplit = 1; a.part = nullptr;
-    const int nsplit = fa_decode_nsplit(f);
+    a.nsplit = 1; a.part = nullptr; a.tile_map = nullptr; a.map_nqb = 0;
+    const gqa_plan gp = fa_gqa_plan(f);
+    const int nsplit = gp.ok ? gp.nsplit : fa_decode_nsplit(f);
     char * img_final = nullptr;
     if (nsplit > 1 && f.scratch && f.scratch_bytes >= fattn_scratch_bytes(f) && (!a.img || (a.nh * f.q.ne[0]) % 256 == 0)) {
         a.nsplit = nsplit; a.part = (float *) f.scratch;
         img_final = a.img; a.img = nullptr;                           // the image is emitted by the merge pass
     }
-    switch ((int) f.q.ne[0]) {
+    if (gp.ok) {
+        if (a.nsplit == 1 && a.img && (a.gq * f.q.ne[0]) % 256 != 0) { fprintf(stderr, "[mi355x] flash_attn: image epilogue needs the KV split workspace for this shape\n"); abort(); }
+        a.qpw = gp.qpw;
+        flash_attn_ext_gqa(a, (int) f.q.ne[0], gp.nw, st);
+    } else switch ((int) f.q.ne[0]) {
         case 64:  launch_fa<64>(a, st); break;
         case 128: launch_fa<128>(a, st); break;
         default: fprintf(stderr, "[mi355x] flash_attn: unsupported head size %d\n", (int) f.q.ne[0]); abort();
@@ -455,8 +555,8 @@ void flash_attn_ext_f16(const fattn_args & f, hipStream_t st) {
     if (a.nsplit > 1) {
         const int nblk = (int) ((a.nh * f.q.ne[0] + 255) / 256);
         const dim3 grid((unsigned) (a.nq * a.ns * nblk));
-        if (f.q.ne[0] == 64) k_fattn_merge<64><<<grid, dim3(64), 0, st>>>(a.part, a.nsplit, a.nq, a.nh, nblk, a.sinks, a.dst, a.dnb1, a.dnb2, a.dnb3, img_final, a.img_bytes);
-        else                 k_fattn_merge<128><<<grid, dim3(64), 0, st>>>(a.part, a.nsplit, a.nq, a.nh, nblk, a.sinks, a.dst, a.dnb1, a.dnb2, a.dnb3, img_final, a.img_bytes);
+        if (f.q.ne[0] == 64) k_fattn_merge<64><<<grid, dim3(256), 0, st>>>(a.part, a.nsplit, a.nq, a.nh, nblk, a.sinks, a.dst, a.dnb1, a.dnb2, a.dnb3, img_final, a.img_bytes);
+        else                 k_fattn_merge<128><<<grid, dim3(256), 0, st>>>(a.part, a.nsplit, a.nq, a.nh, nblk, a.sinks, a.dst, a.dnb1, a.dnb2, a.dnb3, img_final, a.img_bytes);
     }
 }
 

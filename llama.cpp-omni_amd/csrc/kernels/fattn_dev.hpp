@@ -35,5 +35,8 @@ struct fa_dev {
 void flash_attn_ext_mma(const fa_dev & a, int D, hipStream_t st);
 void fattn_mask_map(const fa_dev & a, uint8_t * map, hipStream_t st);     // classify the mask's 32 x 32 tiles
 bool fattn_mma_ok(int64_t nkv);
+// decode shape on the matrix cores (k_fattn_gqa): a.qpw tokens x gq heads of a KV head (<= 32 pairs) as one query tile, nw = 4 or 8 waves,
+// KV range in a.nsplit slices (-> a.part when > 1), optional a.pre / a.img
+void flash_attn_ext_gqa(const fa_dev & a, int D, int nw, hipStream_t st);
 
 } // namespace mi

@@ -330,6 +330,320 @@ __global__ void __launch_bounds__(64 * NW * KS) __attribute__((amdgpu_waves_per_
     }
 }
 
+// ---- decode shape on the matrix cores (a few query tokens; fattn.hip routes them here): the 32 query columns of a wave tile are up to
+// qpw * gq <= 32 (token, head) pairs that share ONE KV head -- column j = token j / gq, head ikv*gq + j % gq -- so a GQA group reads its
+// K / V rows once.  Every wave works alone on its own 32-row KV tiles (tile t of the slice goes to wave t % NW): no workgroup barrier
+// in the loop.
+//   K : straight from memory into the A-operand registers.  The contraction index is only a label, so K-slot (ks, hb, e) is declared to be
+//       d = hb*D/2 + 8*ks + e: a lane reads D/2 CONTIGUOUS halfs of its row (Q is loaded with the same labelling).
+//   V : the wave's 32 rows, transposed through its private LDS region exactly as the prefill kernel does.
+//   next tile's K / V / mask words are requested right after the score product freed the registers, and land under softmax + P.V.
+// The KV range is cut into a.nsplit slices (grid = slices x token chunks x KV heads x sequences); the NW waves of a workgroup fold their
+// states through LDS.  nsplit == 1: the workgroup finishes the rows itself (sinks, 1/S, store, optional Q8_K image of the output row for
+// the wo mat-vec); nsplit > 1: ONE partial (O, M, S) row per (token, head) goes to a.part for k_fattn_merge (fattn.hip), natural-log
+// convention.  PRE: the layer's q / k chains (RMS_NORM -> MUL -> ROPE) and the k / v cache stores of the one new token run first, in
+// this launch (fa_pre, fattn_dev.hpp); with a KV split only the slice that owns the new cache row stores it -- the other slices never
+// read that row.
+template <int D, int NW, bool PRE>
+__global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2))) k_fattn_gqa(const fa_dev a) {
+    constexpr int VLD = fm_cfg<D>::VLD;
+    constexpr int NKS = D / 16, NDB = D / 32;
+    constexpr int VW  = D * VLD / 2;                      // 32-bit words of one V^T tile
+    constexpr int MS  = NDB * 16 + 4;                     // floats of one lane's parked state: M, S, 2 pad, O (16-byte vectors)
+    constexpr int MW  = 64 * MS;                          // floats of one parked wave state
+    constexpr int LW  = NW * VW > (NW / 2) * MW ? NW * VW : (NW / 2) * MW;       // the merge area and the final rows re-use the V tiles
+    static_assert((NW & (NW - 1)) == 0 && NW >= 2, "NW is a power of two");
+    static_assert(LW >= 32 * D, "final rows fit");
+    __shared__ __attribute__((aligned(16))) uint32_t Vt[LW];
+    __shared__ __attribute__((aligned(16))) _Float16 qs[PRE ? 32 * D : 8];     // pre-stage: the GQA group's q heads after norm + rope
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lq = lane & 31, hb = lane >> 5;
+    int b = (int) blockIdx.x;
+    const int nqc = (a.nq + a.qpw - 1) / a.qpw;
+    const int sp  = b % a.nsplit; b /= a.nsplit;
+    const int qc  = b % nqc;      b /= nqc;
+    const int ikv = b % a.nhkv;   const int is3 = b / a.nhkv;
+    const int tok = qc * a.qpw + lq / a.gq;
+    const bool row_ok = lq < a.qpw * a.gq && tok < a.nq;
+    const int q = row_ok ? tok : 0;
+    const int h = ikv * a.gq + (row_ok ? lq % a.gq : 0);
+
+    const int ntile = (a.nkv + FM_KT - 1) / FM_KT;
+    const int tps = (ntile + a.nsplit - 1) / a.nsplit;
+    const int t_hi = (sp + 1) * tps < ntile ? (sp + 1) * tps : ntile;
+
+    const uint32_t hu = (uint32_t) h;
+    const float slope = a.max_bias > 0.0f ? (hu < a.n_head_log2 ? powf(a.m0, (float) (hu + 1)) : powf(a.m1, (float) (2 * (hu - a.n_head_log2) + 1))) : 1.0f;
+    const float slope2 = slope * FM_LOG2E;
+    const float c2 = a.logit_softcap != 0.0f ? a.scale : a.scale * FM_LOG2E;
+    const uint16_t * mrow = a.mask ? (const uint16_t *) (a.mask + q * a.mnb1 + (is3 % (int) a.mne3) * a.mnb3) : nullptr;   // (launcher: mask ne2 == 1)
+    const bool mask_vec = a.mask && (a.mnb1 % 8 == 0) && (((uintptr_t) mrow) % 8 == 0);
+
+    f16a acc_o[NDB];
+#pragma unroll
+    for (int db = 0; db < NDB; ++db)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc_o[db][e] = 0.0f;
+    float M = -INFINITY, S = 0.0f;
+
+    const char * kbase = a.k + ikv * a.knb2 + is3 * a.knb3;
+    const char * vbase = a.v + ikv * a.vnb2 + is3 * a.vnb3;
+    uint32_t * vt = Vt + wave * VW;
+
+    u32x4 kreg[NKS], vreg[NDB][2]; u32x2 mwn[4];
+    auto load_tile = [&](int t) {
+        const int kv0 = t * FM_KT;
+        const bool kok = kv0 + lq < a.nkv;
+        const char * kr = kbase + (int64_t) (kok ? kv0 + lq : 0) * a.knb1 + hb * D;        // hb * (D/2) halfs
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) { kreg[ks] = *(const u32x4 *) (kr + ks * 16); if (!kok) kreg[ks] = u32x4{ 0u, 0u, 0u, 0u }; }
+#pragma unroll
+        for (int i = 0; i < NDB; ++i) {
+            const int c = lane + i * 64;
+            const int o = c % (D / 8), p = c / (D / 8);
+            vreg[i][0] = vreg[i][1] = u32x4{ 0u, 0u, 0u, 0u };
+            if (kv0 + 2 * p     < a.nkv) vreg[i][0] = *(const u32x4 *) (vbase + (int64_t) (kv0 + 2 * p)     * a.vnb1 + o * 16);
+            if (kv0 + 2 * p + 1 < a.nkv) vreg[i][1] = *(const u32x4 *) (vbase + (int64_t) (kv0 + 2 * p + 1) * a.vnb1 + o * 16);
+        }
+        // mask words of this lane's (token) row: word pair g = halfs kv0 + 4*hb + 8*g + {0..3}; cells past nkv read as -inf
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int kvb = kv0 + 4 * hb + 8 * g;
+            if (kvb + 3 < a.nkv && (!mrow || mask_vec)) {
+                if (mrow) mwn[g] = *(const u32x2 *) (mrow + kvb); else { mwn[g][0] = 0u; mwn[g][1] = 0u; }
+            } else {
+                uint32_t hv[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) hv[i] = kvb + i < a.nkv ? (mrow ? (uint32_t) mrow[kvb + i] : 0u) : 0xfc00u;
+                mwn[g][0] = hv[0] | (hv[1] << 16); mwn[g][1] = hv[2] | (hv[3] << 16);
+            }
+        }
+    };
+
+    // the first tile's K / V / mask words are requested before anything else: their latency hides the pre-stage / the Q loads
+    int t = sp * tps + wave;
+    if (t < t_hi) load_tile(t);
+
+    h8v qf[NKS];
+    if (PRE) {
+        // one token, one sequence (launcher-checked): tasks 0 = k head (norm, rope, store), 1 = v head (store), 2 + r = q head r
+        const fa_pre & P = a.pre;
+        const float posf = (float) P.pos[0];
+        const int64_t krow = P.idx_is64 ? *(const int64_t *) P.kidx : (int64_t) *(const int32_t *) P.kidx;
+        const int64_t vrow = P.idx_is64 ? *(const int64_t *) P.vidx : (int64_t) *(const int32_t *) P.vidx;
+        const bool own_k = (int) (krow / FM_KT) / tps == sp, own_v = (int) (vrow / FM_KT) / tps == sp;
+        for (int task = wave; task < a.gq + 2; task += NW) {
+            if (task == 1) {
+                if (!own_v) continue;
+                uint16_t * vr = (uint16_t *) (P.vcache + vrow * P.vc_rs) + ikv * D;
+                const float * xv = (const float *) (P.vraw + ikv * P.v_hs);
+                for (int e = lane; e < D; e += 64) vr[e] = f2h(xv[e]);
+            } else {
+                const bool isk = task == 0;
+                if (isk && !own_k) continue;
+                const int  r   = task - 2;
+                const char * xr = isk ? P.kraw + ikv * P.k_hs : P.qraw + (ikv * a.gq + r) * P.q_hs;
+                float r0[1], r1[1]; int e0[1], e1[1]; bool act[1];
+                norm_rope_wave<1>(xr, isk ? P.kw : P.qw, D, P.eps, posf, P.ff, P.rd, lane, r0, r1, e0, e1, act);
+                if (act[0]) {
+                    if (isk) {
+                        uint16_t * kr = (uint16_t *) (P.kcache + krow * P.kc_rs) + ikv * D;
+                        kr[e0[0]] = f2h(r0[0]); kr[e1[0]] = f2h(r1[0]);
+                    } else {
+                        qs[r * D + e0[0]] = (_Float16) r0[0]; qs[r * D + e1[0]] = (_Float16) r1[0];    // q_to_vec_dot rounding (ops.cpp:8040)
+                    }
+                }
+            }
+        }
+        __syncthreads();                                  // (also drains the k / v cache stores before any wave reads the cache)
+        if (t < t_hi && (t == (int) (krow / FM_KT) || t == (int) (vrow / FM_KT))) load_tile(t);     // the tile with the row just stored: again
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) qf[ks] = *(const h8v *) &qs[(row_ok ? lq : 0) * D + hb * (D / 2) + ks * 8];
+    } else {
+        const char * qr = a.q + q * a.qnb1 + h * a.qnb2 + is3 * a.qnb3;
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+            const f32x4 v0 = *(const f32x4 *) (qr + (hb * (D / 2) + ks * 8) * 4);
+            const f32x4 v1 = *(const f32x4 *) (qr + (hb * (D / 2) + ks * 8 + 4) * 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { qf[ks][e] = (_Float16) v0[e]; qf[ks][4 + e] = (_Float16) v1[e]; }   // q_to_vec_dot: f32 -> f16 (ops.cpp:8040)
+        }
+    }
+    while (t < t_hi) {
+        // ---- S^T = K . Q^T (frees kreg)
+        f16a sc;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) sc[e] = 0.0f;
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+            union { u32x4 u; h8v v; } kf; kf.u = kreg[ks];
+            sc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf.v, qf[ks], sc, 0, 0, 0);
+        }
+        u32x2 mw[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) mw[g] = mwn[g];
+        // ---- V rows -> transposed tile in this wave's LDS region (frees vreg); wave-private, so only a wave-level ordering point
+#pragma unroll
+        for (int i = 0; i < NDB; ++i) {
+            const int c = lane + i * 64;
+            const int o = c % (D / 8), p = c / (D / 8);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                vt[(8 * o + 2 * e)     * (VLD / 2) + p] = (vreg[i][0][e] & 0xffffu) | (vreg[i][1][e] << 16);
+                vt[(8 * o + 2 * e + 1) * (VLD / 2) + p] = (vreg[i][0][e] >> 16)     | (vreg[i][1][e] & 0xffff0000u);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const int tn = t + NW;
+        if (tn < t_hi) load_tile(tn);                                  // in flight under the softmax and P.V below
+
+        // ---- scale / softcap / mask, base-2 online softmax (as k_fattn_mma)
+        float tmax = -INFINITY;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const uint32_t w = mw[e >> 2][(e >> 1) & 1];
+            const uint16_t hbits = (uint16_t) ((e & 1) ? (w >> 16) : (w & 0xffffu));
+            float v = sc[e] * c2;
+            if (a.logit_softcap != 0.0f) v = a.logit_softcap * FM_LOG2E * tanhf(v);
+            v = (hbits == 0xfc00u || !row_ok) ? -INFINITY : v + slope2 * h2f(hbits);
+            sc[e] = v;
+            tmax = fmaxf(tmax, v);
+        }
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+        const float Mn = fmaxf(M, tmax);
+        const float Mu = Mn == -INFINITY ? 0.0f : Mn;
+        const float alpha = __builtin_amdgcn_exp2f(M - Mu);
+        float psum = 0.0f;
+        union { h2v h2[4]; h8v v; } pf[2];
+#pragma unroll
+        for (int e = 0; e < 16; e += 2) {
+            const float p0 = __builtin_amdgcn_exp2f(sc[e] - Mu), p1 = __builtin_amdgcn_exp2f(sc[e + 1] - Mu);
+            psum += p0 + p1;
+            const f32x2 pp = { p0, p1 };
+            pf[e >> 3].h2[(e & 7) >> 1] = __builtin_convertvector(pp, h2v);
+        }
+        S = S * alpha + psum;
+        M = Mn;
+        if (!__all(alpha == 1.0f)) {
+#pragma unroll
+            for (int db = 0; db < NDB; ++db)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc_o[db][e] *= alpha;
+        }
+        // ---- O^T += V^T . P^T
+#pragma unroll
+        for (int db = 0; db < NDB; ++db) {
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const uint32_t * vr = &vt[(db * 32 + lq) * (VLD / 2) + 8 * s2 + 2 * hb];
+                union { uint32_t u[4]; h8v v; } vf;
+                vf.u[0] = vr[0]; vf.u[1] = vr[1]; vf.u[2] = vr[4]; vf.u[3] = vr[5];
+                acc_o[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf.v, pf[s2].v, acc_o[db], 0, 0, 0);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        t = tn;
+    }
+
+    // ---- fold the NW wave states pairwise through LDS (the V tiles are dead): waves [s, 2s) park, waves [0, s) fold, s = NW/2 .. 1
+    float * mrg = (float *) Vt;
+    __syncthreads();
+#pragma unroll
+    for (int s = NW / 2; s >= 1; s >>= 1) {
+        if (wave >= s && wave < 2 * s && row_ok) {              // (dead columns carry nothing)
+            float * mine = mrg + (size_t) (wave - s) * MW + lane * MS;
+            *(f32x2 *) mine = f32x2{ M, S };
+#pragma unroll
+            for (int db = 0; db < NDB; ++db)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) *(f32x4 *) (mine + 4 + db * 16 + 4 * g) = f32x4{ acc_o[db][4 * g], acc_o[db][4 * g + 1], acc_o[db][4 * g + 2], acc_o[db][4 * g + 3] };
+        }
+        __syncthreads();
+        if (wave < s && row_ok) {
+            const float * oth = mrg + (size_t) wave * MW + lane * MS;
+            const f32x2 ms = *(const f32x2 *) oth;
+            const float Mo = ms[0], So = ms[1];
+            const float Mn = fmaxf(M, Mo);
+            const float Mu = Mn == -INFINITY ? 0.0f : Mn;
+            const float f0 = __builtin_amdgcn_exp2f(M - Mu), f1 = __builtin_amdgcn_exp2f(Mo - Mu);
+            S = S * f0 + So * f1; M = Mn;
+#pragma unroll
+            for (int db = 0; db < NDB; ++db)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 o4 = *(const f32x4 *) (oth + 4 + db * 16 + 4 * g);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) acc_o[db][4 * g + i] = acc_o[db][4 * g + i] * f0 + o4[i] * f1;
+                }
+        }
+        __syncthreads();
+    }
+    if (a.nsplit > 1) {
+        if (wave != 0 || !row_ok) return;
+        S += __shfl_xor(S, 32, 64);                                    // (row_ok is the same in both lane halves)
+        float * pr = a.part + ((((int64_t) is3 * a.nq + q) * a.nh + h) * a.nsplit + sp) * (D + 2);
+#pragma unroll
+        for (int db = 0; db < NDB; ++db)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4 o4;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) o4[i] = acc_o[db][4 * g + i];
+                *(f32x4 *) (pr + db * 32 + 8 * g + 4 * hb) = o4;
+            }
+        if (hb == 0) { pr[D] = M * 0.6931471805599453f; pr[D + 1] = S; }
+        return;
+    }
+    // ---- single slice: finish here -- sinks (ops.cpp:8116-8130), normalise, store permuted, optional Q8_K image of the rows
+    float * fin = mrg;                                                 // [32 columns][D] finals (image epilogue)
+    if (wave == 0) {
+        S += __shfl_xor(S, 32, 64);
+        float osc = 1.0f;
+        if (a.sinks) {
+            const float sk = a.sinks[h] * FM_LOG2E;
+            if (sk > M) { const float f = __builtin_amdgcn_exp2f(M - sk); S = S * f + 1.0f; osc = f; }
+            else S += __builtin_amdgcn_exp2f(sk - M);
+        }
+        const float inv = S == 0.0f ? 0.0f : osc / S;
+        char * out = a.dst + h * a.dnb1 + q * a.dnb2 + is3 * a.dnb3;
+#pragma unroll
+        for (int db = 0; db < NDB; ++db)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4 o4;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) o4[i] = acc_o[db][4 * g + i] * inv;
+                if (row_ok) *(f32x4 *) (out + (db * 32 + 8 * g + 4 * hb) * 4) = o4;
+                if (a.img) *(f32x4 *) (fin + lq * D + db * 32 + 8 * g + 4 * hb) = row_ok ? o4 : f32x4{ 0.0f, 0.0f, 0.0f, 0.0f };
+            }
+    }
+    if (a.img) {                                                       // (launcher: gq * D % 256 == 0; column lq = token lq / gq, head lq % gq)
+        __syncthreads();
+        const int per_q = a.gq * D / 256, nblk = a.qpw * per_q;
+        const int64_t Kimg = (int64_t) a.nh * D;
+        for (int bq = wave; bq < nblk; bq += NW) {
+            const int qq = bq / per_q, bb = bq % per_q;
+            const int64_t qrow = qc * a.qpw + qq;
+            if (qrow >= a.nq) continue;
+            const f32x4 v = *(const f32x4 *) (fin + (qq * a.gq) * D + bb * 256 + 4 * lane);
+            char * im = a.img + (is3 * a.nq + qrow) * a.img_bytes;
+            const int64_t ib = ((int64_t) ikv * a.gq * D) / 256 + bb;
+            q8k_block_from_regs(v, lane, (int8_t *) im + ib * 256, (int16_t *) (im + Kimg) + ib * 16, (float *) (im + Kimg + Kimg / 8) + ib);
+        }
+    }
+}
+
+void flash_attn_ext_gqa(const fa_dev & a, int D, int nw, hipStream_t st) {
+    const int nqc = (a.nq + a.qpw - 1) / a.qpw;
+    const dim3 grid((unsigned) (a.nsplit * nqc * a.nhkv * a.ns));
+    const bool pre = a.pre.qraw != nullptr;
+#define GQA_GO(DD, NWW) do { if (pre) k_fattn_gqa<DD, NWW, true><<<grid, dim3(64 * NWW), 0, st>>>(a); else k_fattn_gqa<DD, NWW, false><<<grid, dim3(64 * NWW), 0, st>>>(a); } while (0)
+    if (D == 64) { if (nw == 8) GQA_GO(64, 8); else GQA_GO(64, 4); }
+    else         { if (nw == 8) GQA_GO(128, 8); else GQA_GO(128, 4); }
+#undef GQA_GO
+}
+
 // ---- mask tile map: class of every 32 (q) x 32 (kv) tile of the f16 mask; one wave per tile
 __global__ void __launch_bounds__(256) k_fattn_mask_map(const char * __restrict__ mask, int64_t mnb1, int64_t mnb2, int64_t mnb3, int mne2, int mne3,
                                                         int nq, int nkv, int nqb, int ntile, uint8_t * __restrict__ map) {

@@ -153,7 +153,7 @@ def test_flash_attn_golden(pkg, be, golden, nkv):
     assert nmse(got, g[f"fa{nkv}_y"]) < 5e-4
 
 
-def _attn_f64(q, k, v, mask, scale, softcap=0.0, sinks=None):
+def _attn_f64(q, k, v, mask, scale, softcap=0.0, sinks=None, max_bias=0.0):
     """ggml_compute_forward_flash_attn_ext_f16 restated in float64 (ops.cpp:7912-8148): q [ns, nh, nq, D] (rounded to f16),
     k/v [ns, nhkv, nkv, D], mask [nq_pad, nkv] f16 or None -> [ns, nq, nh, D]"""
     ns, nh, nq, D = q.shape
@@ -167,7 +167,12 @@ def _attn_f64(q, k, v, mask, scale, softcap=0.0, sinks=None):
             if softcap:
                 sc = softcap * np.tanh(sc)
             if mask is not None:
-                sc = sc + mask[:nq].astype(np.float64)
+                slope = 1.0
+                if max_bias > 0:                             # ALiBi head slopes (ops.cpp:7990-7996, 8008)
+                    n2 = 2 ** int(np.floor(np.log2(nh)))
+                    m0, m1 = 2.0 ** (-max_bias / n2), 2.0 ** (-(max_bias / 2.0) / n2)
+                    slope = m0 ** (h + 1) if h < n2 else m1 ** (2 * (h - n2) + 1)
+                sc = sc + slope * mask[:nq].astype(np.float64)
             mx = sc.max(axis=1, keepdims=True)
             if sinks is not None:
                 mx = np.maximum(mx, sinks[h])
@@ -212,6 +217,64 @@ def test_flash_attn_prefill_mfma(pkg, be, D, nq, nh, nhkv, nkv, ns, kind):
     y = c.flash_attn_ext(q, k, v, m, scale, 0.0, softcap, sk)
     (got,) = run_graph(be, c, [y], feeds)
     want = _attn_f64(qv, kv, vv, mask, scale, softcap, sinks)
+    assert np.isfinite(got).all()
+    assert nmse(got.reshape(want.shape), want) < 5e-4
+
+
+@pytest.mark.parametrize("gqa", [1, 0])
+@pytest.mark.parametrize("D,nq,nh,nhkv,nkv,ns,kind", [
+    (128, 1, 32, 8, 4096, 1, "depth"), (128, 8, 32, 8, 3000, 1, "seqs"), (64, 4, 8, 1, 1500, 2, "none"), (128, 1, 4, 4, 1024, 1, "sinks"),
+    (128, 2, 16, 4, 5000, 1, "softcap"), (128, 3, 8, 1, 2048, 1, "depth"), (64, 1, 12, 2, 33000, 1, "depth"),
+    (128, 1, 32, 8, 256, 1, "depth"), (128, 1, 32, 8, 77, 1, "depth"), (64, 8, 64, 8, 512, 1, "seqs"), (128, 3, 32, 2, 300, 2, "none"),
+    (64, 5, 5, 5, 40, 1, "sinks"), (128, 7, 4, 4, 1, 1, "none"), (128, 2, 8, 2, 640, 1, "alibi")])
+def test_flash_attn_decode_mfma(pkg, be, D, nq, nh, nhkv, nkv, ns, kind, gqa):
+    """a few query tokens: the (token, head) pairs of a KV head form 32-column matrix-core tiles (k_fattn_gqa); shallow caches are
+    finished by the workgroup itself, deep ones are cut into KV slices merged by a second pass (k_fattn_merge).  gqa=0 sends the same
+    shapes through the streaming kernel (option fattn_gqa).  bar = the reference's FLASH_ATTN_EXT NMSE 5e-4"""
+    be.set_option("fattn_gqa", gqa)
+    try:
+        _decode_attn_case(pkg, be, D, nq, nh, nhkv, nkv, ns, kind)
+    finally:
+        be.set_option("fattn_gqa", 1)
+
+
+def _decode_attn_case(pkg, be, D, nq, nh, nhkv, nkv, ns, kind):
+    rng = np.random.default_rng(D + nq + nkv)
+    qv = rng.standard_normal((ns, nh, nq, D)).astype(np.float32)
+    kv = rng.standard_normal((ns, nhkv, nkv, D)).astype(np.float16)
+    vv = rng.standard_normal((ns, nhkv, nkv, D)).astype(np.float16)
+    mask = None
+    if kind != "none":
+        mask = np.zeros((64, nkv), np.float16)
+        if kind == "seqs":                                   # unified KV cache: token t only sees the cells of its own sequence
+            mask[:] = -np.inf
+            for t in range(nq):
+                mask[t, t::nq] = 0
+                mask[t, max(nq, nkv - 200):] = -np.inf
+        else:
+            for t in range(64):
+                mask[t, max(1, nkv - 137) + min(t, nq - 1):] = -np.inf
+    sinks = rng.standard_normal(nh).astype(np.float32) if kind == "sinks" else None
+    softcap = 7.0 if kind == "softcap" else 0.0
+    max_bias = 8.0 if kind == "alibi" else 0.0
+    if kind == "alibi":                                       # finite position biases on the live cells
+        mask = np.where(np.isinf(mask), mask, -np.abs(np.arange(nkv)[None, :] - (nkv - 137)).astype(np.float16) / 16).astype(np.float16)
+    c = pkg.Context(be)
+    q = c.new_tensor(pkg.GGML_TYPE_F32, D, nq, nh, ns)
+    k = c.new_tensor(pkg.GGML_TYPE_F16, D, nkv, nhkv, ns)
+    v = c.new_tensor(pkg.GGML_TYPE_F16, D, nkv, nhkv, ns)
+    feeds = [(q, qv), (k, kv), (v, vv)]
+    m = sk = None
+    if mask is not None:
+        m = c.new_tensor(pkg.GGML_TYPE_F16, nkv, 64)
+        feeds.append((m, mask))
+    if sinks is not None:
+        sk = c.new_tensor(pkg.GGML_TYPE_F32, nh)
+        feeds.append((sk, sinks))
+    scale = 1.0 / np.sqrt(D)
+    y = c.flash_attn_ext(q, k, v, m, scale, max_bias, softcap, sk)
+    (got,) = run_graph(be, c, [y], feeds)
+    want = _attn_f64(qv, kv, vv, mask, scale, softcap, sinks, max_bias)
     assert np.isfinite(got).all()
     assert nmse(got.reshape(want.shape), want) < 5e-4
 
