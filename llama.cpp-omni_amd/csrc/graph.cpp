@@ -205,10 +205,23 @@ bool supports_op(const ggml_tensor * op) {
 // ------------------------------------------------------------------------------------------------ scratch sizing
 // batches of more than 8 columns go to the MFMA GEMM (activations rounded to f16; quantised weights de-quantised to f16 first)
 static const int64_t GEMM_MIN_COLS = MI_MMVQ_MAX_COLS + 1;
+// ... except K-quant weights against up to MMQ_MAX_COLS columns (several sequences decoded together, drafts, small ubatches): those
+// read the quantised blocks themselves on the int8 matrix cores (mmq.hip) -- 0.56 / 0.82 bytes per weight instead of the 2 of an f16 image
+static int64_t mmq_max_cols() {
+    static const int64_t v = getenv("MI355X_MMQ_MAX_COLS") ? atoll(getenv("MI355X_MMQ_MAX_COLS")) : 64;
+    return v;
+}
+static bool mm_uses_mmq(const ggml_tensor * n) {
+    const ggml_tensor * w = n->src[0], * x = n->src[1];
+    return (w->type == GGML_TYPE_Q4_K || w->type == GGML_TYPE_Q6_K) && x->type == GGML_TYPE_F32 && x->ne[1] > MI_MMVQ_MAX_COLS && x->ne[1] <= mmq_max_cols() &&
+           mmq_ok(w->type, w->ne[0], w->data, w->nb[1]) && (w->ne[2] == 1 || mmq_ok(w->type, w->ne[0], (const char *) w->data + w->nb[2], w->nb[1])) &&
+           (w->ne[3] == 1 || mmq_ok(w->type, w->ne[0], (const char *) w->data + w->nb[3], w->nb[1]));
+}
 static bool mm_uses_gemm(const ggml_tensor * n) {
     const ggml_tensor * w = n->src[0], * x = n->src[1];
     static const bool no_gemm = getenv("MI355X_NO_GEMM") != nullptr;
     if (x->ne[1] < GEMM_MIN_COLS || no_gemm) return false;
+    if (mm_uses_mmq(n)) return false;
     if (w->type != GGML_TYPE_F16 && w->type != GGML_TYPE_Q4_K && w->type != GGML_TYPE_Q6_K && w->type != GGML_TYPE_Q8_0) return false;
     const int64_t K = w->ne[0];
     if (K % 32 != 0) return false;
@@ -426,6 +439,17 @@ static void op_mul_mat(exec_state & s, const ggml_tensor * dst) {
         for (int64_t i12 = 0; i12 < ne12; ++i12) {
             const char * wp = (const char *) w->data + (i12 / r2) * w->nb[2] + (i13 / r3) * w->nb[3];
             char *       dp = (char *) dst->data + i12 * dst->nb[2] + i13 * dst->nb[3];
+            if (mm_uses_mmq(dst)) {                                   // 9 .. 64 columns of a K-quant matrix: int8 MFMA, 32 columns per launch
+                for (int64_t c0 = 0; c0 < N; c0 += 32) {
+                    mmq_args q;
+                    q.nmat = 1; q.m[0] = { wp, w->nb[1], (float *) (dp + c0 * dst->nb[1]), dst->nb[1], M, (int) w->type };
+                    q.act = (const char *) s.c->act_scratch + (size_t) ((i13 * ne12 + i12) * N + c0) * img; q.act_cs = img;
+                    q.K = K; q.ncols = (int) (N - c0 < 32 ? N - c0 : 32);
+                    prof_scope ps(s, w->type == GGML_TYPE_Q4_K ? "mmq_q4k" : "mmq_q6k", wbytes);
+                    mmq_kquant(q, s.st); ++s.n_kernels;
+                }
+                continue;
+            }
             for (int64_t c0 = 0; c0 < N; c0 += MI_MMVQ_MAX_COLS) {
                 mmv_args a;
                 a.W = wp; a.w_rs = w->nb[1]; a.K = K; a.nrows = M;
@@ -464,6 +488,13 @@ static bool plain_kq_matvec(const ggml_tensor * n, int max_cols) {      // MUL_M
     const ggml_tensor * w = n->src[0], * x = n->src[1];
     return is_kquant(w->type) && w->ne[2] == 1 && w->ne[3] == 1 && x->ne[2] == 1 && x->ne[3] == 1 && x->ne[1] <= max_cols &&
            q8k_image_bytes(w->ne[0]) * (size_t) x->ne[1] <= 152 * 1024 && n->nb[0] == 4;
+}
+// ... or against 9 .. 64 columns on the int8 matrix cores (mmq.hip): the same fusions (sibling batching, residual epilogue, norm image)
+static bool kq_mm_ok(const ggml_tensor * n) {
+    if (plain_kq_matvec(n, MI_MMVQ_MAX_COLS)) return true;
+    if (n->op != GGML_OP_MUL_MAT || is_empty(n) || !mm_uses_mmq(n)) return false;
+    const ggml_tensor * w = n->src[0], * x = n->src[1];
+    return w->ne[2] == 1 && w->ne[3] == 1 && x->ne[2] == 1 && x->ne[3] == 1 && n->nb[0] == 4 && x->nb[0] == 4;
 }
 static bool same_act(const ggml_tensor * a, const ggml_tensor * b) {
     return a->data == b->data && a->ne[0] == b->ne[0] && a->ne[1] == b->ne[1] && a->ne[2] == b->ne[2] && a->ne[3] == b->ne[3] &&
@@ -648,7 +679,7 @@ static void exec_mul_mat(exec_state & s, int i) {
     ggml_cgraph * g = s.g;
     ggml_tensor * n = g->nodes[i];
     if (s.c->opt_fusion && exec_gemm_group(s, i)) return;
-    if (!s.c->opt_fusion || !plain_kq_matvec(n, MI_MMVQ_MAX_COLS)) { op_mul_mat(s, n); note_write(s, n); return; }
+    if (!s.c->opt_fusion || !kq_mm_ok(n)) { op_mul_mat(s, n); note_write(s, n); return; }
     const ggml_tensor * x = n->src[1];
     const int64_t K = x->ne[0]; const int N = (int) x->ne[1];
 
@@ -686,10 +717,10 @@ static void exec_mul_mat(exec_state & s, int i) {
     int   mm_idx[3] = { i, -1, -1 }; int nm = 1;
     for (int j = i + 1; j < g->n_nodes && j < i + 32 && nm < 3; ++j) {
         ggml_tensor * c = g->nodes[j];
-        if (s.done[j] || !plain_kq_matvec(c, MI_MMVQ_MAX_COLS) || !same_act(c->src[1], x)) continue;
-        // do not steal one half of a gate/up pair (that fusion is worth more)
+        if (s.done[j] || !kq_mm_ok(c) || !same_act(c->src[1], x)) continue;
+        // do not steal one half of a gate/up pair (that fusion is worth more; it exists for the mat-vec widths only)
         const int cu = sole_user(s, c);
-        if (cu > 0 && g->nodes[cu]->op == GGML_OP_GLU) continue;
+        if (N <= MI_MMVQ_MAX_COLS && cu > 0 && g->nodes[cu]->op == GGML_OP_GLU) continue;
         if (!can_hoist(s, i, j, mm_idx, nm)) continue;
         mm_idx[nm++] = j;
     }
@@ -724,12 +755,25 @@ static void exec_mul_mat(exec_state & s, int i) {
     for (int q = 0; q < nm; ++q) outs[q] = add_idx[q] >= 0 ? g->nodes[add_idx[q]] : g->nodes[mm_idx[q]];
     const size_t img = norm_in_kernel(s, x, outs, nm, nm, a.norm) ? q8k_image_bytes(K) : prepare_act(s, x, ACT_Q8K);
     a.act = s.c->act_scratch; a.act_cs = img;
-    {
+    if (N > MI_MMVQ_MAX_COLS) {                                       // int8 matrix cores, 32 columns per launch
+        for (int c0 = 0; c0 < N; c0 += 32) {
+            mmq_args q;
+            q.nmat = nm; q.act = (const char *) s.c->act_scratch + (size_t) c0 * img; q.act_cs = img; q.K = K; q.ncols = N - c0 < 32 ? N - c0 : 32;
+            for (int t = 0; t < nm; ++t) {
+                const mmv_mat & m = a.m[t];
+                q.m[t].W = m.W; q.m[t].w_rs = m.w_rs; q.m[t].dst = (float *) ((char *) m.dst + (size_t) c0 * m.dst_cs); q.m[t].dst_cs = m.dst_cs;
+                q.m[t].nrows = m.nrows; q.m[t].type = m.type;
+                q.m[t].resid = m.resid ? (const float *) ((const char *) m.resid + (size_t) c0 * m.resid_cs) : nullptr; q.m[t].resid_cs = m.resid_cs;
+            }
+            prof_scope ps(s, bytes_q4 >= bytes_q6 ? "mmq_q4k" : "mmq_q6k", bytes_q4 + bytes_q6);
+            mmq_kquant(q, s.st); ++s.n_kernels;
+        }
+    } else {
         // profile class: the launch is attributed to the type that carries most of its bytes
         prof_scope ps(s, bytes_q4 >= bytes_q6 ? "mmv_q4k" : "mmv_q6k", bytes_q4 + bytes_q6);
         mmv_kquant_multi(a, s.st);
+        ++s.n_kernels;
     }
-    ++s.n_kernels;
     for (int q = 0; q < nm; ++q) {
         if (q > 0) { s.done[mm_idx[q]] = 1; ++s.n_fused; }
         if (add_idx[q] >= 0) { s.done[add_idx[q]] = 1; ++s.n_fused; note_write(s, g->nodes[add_idx[q]]); }
@@ -967,12 +1011,13 @@ static bool exec_rms_norm(exec_state & s, int i) {
         }
     }
     // image variant: row-contiguous 2-D activation, weight a plain [ne0] vector, every consumer a K-quant mat-vec on it
-    bool want_img = rms_norm_mul_quant_ok(n->ne[0]) && n->ne[2] == 1 && n->ne[3] == 1 && n->ne[1] <= MI_MMVQ_MAX_COLS && wt->ne[0] == n->ne[0] &&
+    bool want_img = rms_norm_mul_quant_ok(n->ne[0]) && n->ne[2] == 1 && n->ne[3] == 1 && n->ne[1] <= mmq_max_cols() && wt->ne[0] == n->ne[0] &&
                     wt->ne[1] * wt->ne[2] * wt->ne[3] == 1 && n->src[0]->nb[0] == 4 && n_users(s, m) > 0;
     if (want_img) {
         for (int u : s.users[m]) {
             const ggml_tensor * c = g->nodes[u];
-            if (!(c->op == GGML_OP_MUL_MAT && c->src[1] == m && is_kquant(c->src[0]->type) && c->src[0]->ne[2] == 1 && c->src[0]->ne[3] == 1)) { want_img = false; break; }
+            if (!(c->op == GGML_OP_MUL_MAT && c->src[1] == m && is_kquant(c->src[0]->type) && c->src[0]->ne[2] == 1 && c->src[0]->ne[3] == 1 &&
+                  (n->ne[1] <= MI_MMVQ_MAX_COLS || mm_uses_mmq(c)))) { want_img = false; break; }
         }
     }
     if (want_img) {
@@ -1245,7 +1290,7 @@ enum ggml_status graph_compute(backend_ctx * c, ggml_cgraph * g) {
     int64_t max_cols = 0;
     for (int i = 0; i < g->n_nodes; ++i)
         if (g->nodes[i]->op == GGML_OP_MUL_MAT && g->nodes[i]->src[1]->ne[1] > max_cols) max_cols = g->nodes[i]->src[1]->ne[1];
-    static const int64_t graph_max_cols = getenv("MI355X_GRAPH_MAX_COLS") ? atoll(getenv("MI355X_GRAPH_MAX_COLS")) : 32;
+    static const int64_t graph_max_cols = getenv("MI355X_GRAPH_MAX_COLS") ? atoll(getenv("MI355X_GRAPH_MAX_COLS")) : (mmq_max_cols() > 32 ? mmq_max_cols() : 32);
     const bool try_graph = c->opt_graphs && !c->opt_profile && n_real >= 8 && max_cols <= graph_max_cols;
     if (try_graph) {
         const uint64_t fp = fingerprint(g);

@@ -59,6 +59,13 @@ void mmv_kquant_multi(const mmv_multi_args & a, hipStream_t st);
 void mmv_kquant_pair_swiglu(int type, const void * Wg, const void * Wu, size_t w_rs, const void * act, size_t act_cs, float * dst, size_t dst_cs,
                             int64_t K, int64_t nrows, int ncols, hipStream_t st, const mmv_norm * norm = nullptr);
 
+// ---- K-quant weights against 2 .. 32 activation columns on the int8 matrix cores (mmq.hip): up to 3 matrices (Q4_K / Q6_K mixed)
+// sharing one set of Q8_K activation images; dst[col*dst_cs + row], optional residual add epilogue
+struct mmq_mat { const void * W; size_t w_rs; float * dst; size_t dst_cs; int64_t nrows; int type; const float * resid = nullptr; size_t resid_cs = 0; };   // resid: optional dst = W.x + resid
+struct mmq_args { mmq_mat m[3]; int nmat; const void * act; size_t act_cs; int64_t K; int ncols; };
+bool mmq_ok(int type, int64_t K, const void * W, size_t w_rs);
+void mmq_kquant(const mmq_args & a, hipStream_t st);
+
 // RMS_NORM + MUL(w) + Q8_K image of the result in one launch (one workgroup per row); y may be null when only the
 // image is consumed.  Same arithmetic as rms_norm() followed by quantize_q8k_image().
 void rms_norm_mul_quant(const float * x, size_t xs, const float * w, float * y, size_t ys, void * img, int64_t n, int64_t nrows, float eps, hipStream_t st);

@@ -416,9 +416,11 @@ static gqa_plan fa_gqa_plan(const fattn_args & f) {
         static const int force_nw = getenv("MI355X_FA_GQA_NW") ? atoi(getenv("MI355X_FA_GQA_NW")) : 0;
         p.nsplit = 1; p.nw = force_nw ? force_nw : (f.pre ? 8 : 4);   // pre-stage: gq + 2 wave tasks in one round
     } else {                                                          // deep: slices of >= 4 tiles, two workgroups per CU, merge pass
-        int64_t s = 512 / groups;
-        if (s > (ntile + 3) / 4) s = (ntile + 3) / 4;
-        p.nsplit = (int) (s < 2 ? 2 : s); p.nw = 4;
+        static const int deep_nw  = getenv("MI355X_FA_GQA_DEEP_NW") ? atoi(getenv("MI355X_FA_GQA_DEEP_NW")) : 4;
+        static const int deep_wgs = getenv("MI355X_FA_GQA_WGS") ? atoi(getenv("MI355X_FA_GQA_WGS")) : 512;
+        int64_t s = deep_wgs / groups;
+        if (s > (ntile + deep_nw - 1) / deep_nw) s = (ntile + deep_nw - 1) / deep_nw;
+        p.nsplit = (int) (s < 2 ? 2 : s); p.nw = deep_nw;
     }
     return p;
 }

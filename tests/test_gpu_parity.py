@@ -308,8 +308,28 @@ def test_mul_mat_vs_oracle_shapes(pkg, be, name, M, K, N):
     (got,) = run_graph(be, c, [y], [(w, wv), (x, xv)])
     want = orc.mul_mat(ty, wv.view(np.uint8).reshape(M, -1), xv)
     # <= 8 columns: mat-vec path, the oracle's own integer arithmetic; more: MFMA GEMM on f16 operands (reference MUL_MAT bar)
-    bar = 1e-9 if (N <= 8 or name in ("f16", "f32")) else 5e-4
+    bar = 1e-9 if (N <= 8 or name in ("f16", "f32", "q4_K", "q6_K")) else 5e-4       # (K-quants at 9..64 columns: mmq.hip, integer sums)
     assert nmse(got, want) < bar, (name, M, K, N)
+
+
+@pytest.mark.parametrize("name", ["q4_K", "q6_K"])
+@pytest.mark.parametrize("M,K,N", [(64, 256, 9), (257, 768, 16), (130, 1024, 33), (33, 2304, 31), (4096, 4096, 12), (1024, 12288, 64), (96, 512, 40)])
+def test_mul_mat_mmq_vs_oracle(pkg, be, name, M, K, N):
+    """9 .. 64 columns against K-quant weights: the int8 matrix-core kernel (mmq.hip) on Q8_K activation images -- the oracle's own
+    integer sums (ggml_vec_dot_q4_K_q8_K / _q6_K_q8_K), f32 re-association across blocks only, so the mat-vec bar applies"""
+    from llama_cpp_omni_amd import qwen3
+    rng = np.random.default_rng(M * 17 + K + N)
+    ty = TYPES[name]
+    wv = qwen3.random_blocks(rng, ty, M, K, std=0.05)
+    xv = (rng.standard_normal((N, K)) * rng.choice([0.1, 1.0, 10.0])).astype(np.float32)
+    xv[N // 2, : K // 2] = 0.0                                 # (a zero half row: an all-zero Q8_K block, d = 0)
+    c = pkg.Context(be)
+    w = c.new_tensor(ty, K, M)
+    x = c.new_tensor(pkg.GGML_TYPE_F32, K, N)
+    y = c.mul_mat(w, x)
+    (got,) = run_graph(be, c, [y], [(w, wv), (x, xv)])
+    want = orc.mul_mat(ty, wv.view(np.uint8).reshape(M, -1), xv)
+    assert nmse(got, want) < 1e-9, (name, M, K, N)
 
 
 @pytest.mark.parametrize("name", ["q4_K", "q6_K", "q8_0", "f16"])
@@ -339,7 +359,7 @@ def test_resident_f16_weight_image(pkg, be, name):
     through the buffer interface drops the image, so the next run sees the new weights -- also through hipGraph replays."""
     from llama_cpp_omni_amd import qwen3
     rng = np.random.default_rng(99)
-    ty, M, K, N = TYPES[name], 192, 1024, 64
+    ty, M, K, N = TYPES[name], 192, 1024, 96          # (more columns than the int8 mmq path takes: the F16 GEMM)
     w1 = qwen3.random_blocks(rng, ty, M, K, std=0.05)
     w2 = qwen3.random_blocks(rng, ty, M, K, std=0.05)
     xv = rng.standard_normal((N, K)).astype(np.float32)
