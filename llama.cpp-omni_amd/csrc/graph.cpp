@@ -211,9 +211,14 @@ static int64_t mmq_max_cols() {
     static const int64_t v = getenv("MI355X_MMQ_MAX_COLS") ? atoll(getenv("MI355X_MMQ_MAX_COLS")) : 64;
     return v;
 }
+static int64_t mmq_min_cols() {       // narrower batches stay on the dot4 mat-vec kernels (one column: 4.3 TB/s; the MFMA tile would be 1/32 full).
+    // measured crossover (12288 x 4096 Q4_K: dot4 8.0 / 11.2 / 19.0 us at 2 / 4 / 8 columns, mmq 13.3 us flat): 6 columns
+    static const int64_t v = getenv("MI355X_MMQ_MIN_COLS") ? atoll(getenv("MI355X_MMQ_MIN_COLS")) : 6;
+    return v;
+}
 static bool mm_uses_mmq(const ggml_tensor * n) {
     const ggml_tensor * w = n->src[0], * x = n->src[1];
-    return (w->type == GGML_TYPE_Q4_K || w->type == GGML_TYPE_Q6_K) && x->type == GGML_TYPE_F32 && x->ne[1] > MI_MMVQ_MAX_COLS && x->ne[1] <= mmq_max_cols() &&
+    return (w->type == GGML_TYPE_Q4_K || w->type == GGML_TYPE_Q6_K) && x->type == GGML_TYPE_F32 && x->ne[1] >= mmq_min_cols() && x->ne[1] <= mmq_max_cols() &&
            mmq_ok(w->type, w->ne[0], w->data, w->nb[1]) && (w->ne[2] == 1 || mmq_ok(w->type, w->ne[0], (const char *) w->data + w->nb[2], w->nb[1])) &&
            (w->ne[3] == 1 || mmq_ok(w->type, w->ne[0], (const char *) w->data + w->nb[3], w->nb[1]));
 }
@@ -491,8 +496,8 @@ static bool plain_kq_matvec(const ggml_tensor * n, int max_cols) {      // MUL_M
 }
 // ... or against 9 .. 64 columns on the int8 matrix cores (mmq.hip): the same fusions (sibling batching, residual epilogue, norm image)
 static bool kq_mm_ok(const ggml_tensor * n) {
-    if (plain_kq_matvec(n, MI_MMVQ_MAX_COLS)) return true;
-    if (n->op != GGML_OP_MUL_MAT || is_empty(n) || !mm_uses_mmq(n)) return false;
+    if (n->op != GGML_OP_MUL_MAT || is_empty(n)) return false;
+    if (!mm_uses_mmq(n)) return plain_kq_matvec(n, MI_MMVQ_MAX_COLS);
     const ggml_tensor * w = n->src[0], * x = n->src[1];
     return w->ne[2] == 1 && w->ne[3] == 1 && x->ne[2] == 1 && x->ne[3] == 1 && n->nb[0] == 4 && x->nb[0] == 4;
 }
@@ -684,7 +689,8 @@ static void exec_mul_mat(exec_state & s, int i) {
     const int64_t K = x->ne[0]; const int N = (int) x->ne[1];
 
     // ---- (a) ffn_up / ffn_gate + GLU(SWIGLU, split): one launch, intermediates never written
-    if (N <= MI_MMVQ_MAX_COLS) {
+    const bool use_mmq = mm_uses_mmq(n);
+    if (!use_mmq) {
         const int gi = sole_user(s, n);
         if (gi > i && g->nodes[gi]->op == GGML_OP_GLU && op_param_i32(g->nodes[gi], 0) == GGML_GLU_OP_SWIGLU && op_param_i32(g->nodes[gi], 1) == 0 &&
             g->nodes[gi]->src[0] && g->nodes[gi]->src[1]) {
@@ -720,7 +726,7 @@ static void exec_mul_mat(exec_state & s, int i) {
         if (s.done[j] || !kq_mm_ok(c) || !same_act(c->src[1], x)) continue;
         // do not steal one half of a gate/up pair (that fusion is worth more; it exists for the mat-vec widths only)
         const int cu = sole_user(s, c);
-        if (N <= MI_MMVQ_MAX_COLS && cu > 0 && g->nodes[cu]->op == GGML_OP_GLU) continue;
+        if (!use_mmq && cu > 0 && g->nodes[cu]->op == GGML_OP_GLU) continue;
         if (!can_hoist(s, i, j, mm_idx, nm)) continue;
         mm_idx[nm++] = j;
     }
@@ -755,7 +761,7 @@ static void exec_mul_mat(exec_state & s, int i) {
     for (int q = 0; q < nm; ++q) outs[q] = add_idx[q] >= 0 ? g->nodes[add_idx[q]] : g->nodes[mm_idx[q]];
     const size_t img = norm_in_kernel(s, x, outs, nm, nm, a.norm) ? q8k_image_bytes(K) : prepare_act(s, x, ACT_Q8K);
     a.act = s.c->act_scratch; a.act_cs = img;
-    if (N > MI_MMVQ_MAX_COLS) {                                       // int8 matrix cores, 32 columns per launch
+    if (use_mmq) {                                                    // int8 matrix cores, 32 columns per launch
         for (int c0 = 0; c0 < N; c0 += 32) {
             mmq_args q;
             q.nmat = nm; q.act = (const char *) s.c->act_scratch + (size_t) c0 * img; q.act_cs = img; q.K = K; q.ncols = N - c0 < 32 ? N - c0 : 32;

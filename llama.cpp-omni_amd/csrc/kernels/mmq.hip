@@ -70,17 +70,20 @@ __global__ void __launch_bounds__(64 * KS) __attribute__((amdgpu_waves_per_eu(2)
     for (int i = 0; i < NT * 4; ++i) out[i] = 0.0f;
 
     if (M.type == GGML_TYPE_Q4_K) {
-        struct wblk { u32x4 hdr, qs[4], av[8]; };                      // one block of the 32 rows + the tokens' int8 for it
+        struct wblk { u32x4 hdr, qs[4]; };                             // one block of this lane's row (its half of the nibbles)
+        struct ablk { u32x4 av[8]; };                                  // the token's int8 of one block (this lane's 16 of every 32)
         auto fetch = [&](int b, wblk & G) {
             const char * p = wrow + (size_t) b * 144;
             G.hdr = *(const u32x4 *) p;
 #pragma unroll
             for (int q = 0; q < 4; ++q) G.qs[q] = *(const u32x4 *) (p + 16 + q * 32 + 16 * hb);
+        };
+        auto fetch_a = [&](int b, ablk & G) {
             const char * ab = arow + (size_t) b * 256;
 #pragma unroll
             for (int j = 0; j < 8; ++j) G.av[j] = *(const u32x4 *) (ab + j * 32);
         };
-        auto reduce = [&](int b, const wblk & G) {
+        auto reduce = [&](int b, const wblk & G, const ablk & GA) {
             // scales / mins of the 8 sub-blocks (get_scale_min_k4, ggml-quants.c:703-710)
             const uint32_t s0 = G.hdr[1], s1 = G.hdr[2], s2 = G.hdr[3];          // scales[0..3], [4..7], [8..11]
             int sc[8], mn[8];
@@ -95,7 +98,7 @@ __global__ void __launch_bounds__(64 * KS) __attribute__((amdgpu_waves_per_eu(2)
             for (int e = 0; e < 16; ++e) { acc[e] = 0; mins[e] = 0; }
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                u32x4 av = G.av[j];
+                u32x4 av = GA.av[j];
                 if (!tok_ok) av = u32x4{ 0u, 0u, 0u, 0u };
                 const u32x4 wq = G.qs[j >> 1];
                 i32x4 wv, mv, aa;
@@ -121,27 +124,28 @@ __global__ void __launch_bounds__(64 * KS) __attribute__((amdgpu_waves_per_eu(2)
                 for (int i = 0; i < 4; ++i) out[4 * g + i] += y4[i] * (d * (float) acc[4 * g + i] - dmin * (float) mins[4 * g + i]);
             }
         };
-        wblk A, B;
-        int b = wave;
-        if (b < nblk) fetch(b, A);
+        // weights ring: RD - 1 blocks of this lane's row in flight ahead of the one being reduced (HBM latency ~2 us, a block's
+        // arithmetic well under 1 us); the tokens' int8 come from L2 at use
+        constexpr int RD = 4;
+        wblk R[RD]; ablk GA;
+        const int nb_w = wave < nblk ? (nblk - wave + KS - 1) / KS : 0;         // this wave's blocks: wave, wave + KS, ...
+#pragma unroll
+        for (int u = 0; u < RD - 1; ++u) if (u < nb_w) fetch(wave + u * KS, R[u]);
         stage_scales();
-        if (b < nblk) {
-            for (;;) {
-                int bn = b + KS;
-                const bool has_b = bn < nblk;
-                if (has_b) fetch(bn, B);
-                reduce(b, A);
-                if (!has_b) break;
-                b = bn; bn = b + KS;
-                const bool has_a = bn < nblk;
-                if (has_a) fetch(bn, A);
-                reduce(b, B);
-                if (!has_a) break;
-                b = bn;
+        for (int i0 = 0; i0 < nb_w; i0 += RD) {
+#pragma unroll
+            for (int u = 0; u < RD; ++u) {
+                const int i = i0 + u;
+                if (i < nb_w) {
+                    if (i + RD - 1 < nb_w) fetch(wave + (i + RD - 1) * KS, R[(u + RD - 1) % RD]);
+                    fetch_a(wave + i * KS, GA);
+                    reduce(wave + i * KS, R[u], GA);
+                }
             }
         }
     } else {                                                             // GGML_TYPE_Q6_K
-        struct wblk { u32x2 ql[8], qh[4]; u32x4 sc; uint32_t d; u32x2 av[16]; };
+        struct wblk { u32x2 ql[8], qh[4]; u32x4 sc; uint32_t d; };
+        struct ablk { u32x2 av[16]; };
         auto fetch = [&](int b, wblk & G) {
             const char * p = wrow + (size_t) b * 210;
             // ql chunk c = n*4 + par*2 + is -> bytes n*64 + par*32 + is*16 + 8*hb ; qh chunk c = n*2 + is -> bytes 128 + n*32 + is*16 + 8*hb
@@ -151,11 +155,13 @@ __global__ void __launch_bounds__(64 * KS) __attribute__((amdgpu_waves_per_eu(2)
             for (int c = 0; c < 4; ++c) G.qh[c] = ld8u(p + 128 + (c >> 1) * 32 + (c & 1) * 16 + 8 * hb);
             G.sc = ld16u(p + 192);
             G.d  = (uint32_t) *(const uint16_t *) (p + 208);
+        };
+        auto fetch_a = [&](int b, ablk & G) {
             const char * ab = a.act + (size_t) (tok_ok ? lq : 0) * a.act_cs + (size_t) b * 256 + 8 * hb;
 #pragma unroll
             for (int t = 0; t < 16; ++t) G.av[t] = *(const u32x2 *) (ab + t * 16);
         };
-        auto reduce = [&](int b, const wblk & G) {
+        auto reduce = [&](int b, const wblk & G, const ablk & GA) {
             i32x16 acc, corr;
 #pragma unroll
             for (int e = 0; e < 16; ++e) { acc[e] = 0; corr[e] = 0; }
@@ -163,7 +169,7 @@ __global__ void __launch_bounds__(64 * KS) __attribute__((amdgpu_waves_per_eu(2)
             for (int s = 0; s < 16; ++s) {
                 // sub-block s: half n = s/8, value group q = (s%8)/2 (ql nibble / qh bit pair), is = s%2  (dequantize_row_q6_K, ggml-quants.c:1762-1791)
                 const int n = s >> 3, q = (s & 7) >> 1, is = s & 1;
-                u32x2 av = G.av[s];
+                u32x2 av = GA.av[s];
                 if (!tok_ok) av = u32x2{ 0u, 0u };
                 const u32x2 l = G.ql[n * 4 + (q & 1) * 2 + is], h = G.qh[n * 2 + is];
                 const int scs = (int) (int8_t) ((G.sc[s >> 2] >> (8 * (s & 3))) & 0xff);
@@ -190,23 +196,23 @@ __global__ void __launch_bounds__(64 * KS) __attribute__((amdgpu_waves_per_eu(2)
                 for (int i = 0; i < 4; ++i) out[4 * g + i] += y4[i] * (d * (float) (acc[4 * g + i] - 32 * corr[4 * g + i]));
             }
         };
-        wblk A, B;
-        int b = wave;
-        if (b < nblk) fetch(b, A);
+        // weights ring: RD - 1 blocks of this lane's row in flight ahead of the one being reduced (HBM latency ~2 us, a block's
+        // arithmetic well under 1 us); the tokens' int8 come from L2 at use
+        constexpr int RD = 3;
+        wblk R[RD]; ablk GA;
+        const int nb_w = wave < nblk ? (nblk - wave + KS - 1) / KS : 0;         // this wave's blocks: wave, wave + KS, ...
+#pragma unroll
+        for (int u = 0; u < RD - 1; ++u) if (u < nb_w) fetch(wave + u * KS, R[u]);
         stage_scales();
-        if (b < nblk) {
-            for (;;) {
-                int bn = b + KS;
-                const bool has_b = bn < nblk;
-                if (has_b) fetch(bn, B);
-                reduce(b, A);
-                if (!has_b) break;
-                b = bn; bn = b + KS;
-                const bool has_a = bn < nblk;
-                if (has_a) fetch(bn, A);
-                reduce(b, B);
-                if (!has_a) break;
-                b = bn;
+        for (int i0 = 0; i0 < nb_w; i0 += RD) {
+#pragma unroll
+            for (int u = 0; u < RD; ++u) {
+                const int i = i0 + u;
+                if (i < nb_w) {
+                    if (i + RD - 1 < nb_w) fetch(wave + (i + RD - 1) * KS, R[(u + RD - 1) % RD]);
+                    fetch_a(wave + i * KS, GA);
+                    reduce(wave + i * KS, R[u], GA);
+                }
             }
         }
     }
