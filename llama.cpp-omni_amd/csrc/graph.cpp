@@ -1174,13 +1174,13 @@ static void compute_node(exec_state & s, int i) {
             fill_fattn_args(n, f, m);
             // epilogue fusion: when the attention output only feeds K-quant mat-vecs (wo), emit its Q8_K image here
             const ggml_tensor * xuse = nullptr;
-            if (s.c->opt_fusion && n->ne[3] == 1 && n->ne[2] <= MI_MMVQ_MAX_COLS && n_users(s, n) > 0 && !(n->flags & GGML_TENSOR_FLAG_OUTPUT) &&
+            if (s.c->opt_fusion && n->ne[3] == 1 && n->ne[2] <= 32 && n_users(s, n) > 0 && !(n->flags & GGML_TENSOR_FLAG_OUTPUT) &&
                 rms_norm_mul_quant_ok(n->ne[0] * n->ne[1]) && fattn_can_emit_image(f)) {
                 bool ok = true;
                 for (int u : s.users[n]) {
                     const ggml_tensor * c = g->nodes[u];
                     const ggml_tensor * x = c->op == GGML_OP_MUL_MAT ? c->src[1] : nullptr;
-                    if (!x || !plain_kq_matvec(c, MI_MMVQ_MAX_COLS) || x->data != n->data || x->ne[0] != n->ne[0] * n->ne[1] || x->ne[1] != n->ne[2] ||
+                    if (!x || !kq_mm_ok(c) || x->data != n->data || x->ne[0] != n->ne[0] * n->ne[1] || x->ne[1] != n->ne[2] ||
                         x->nb[1] != (size_t) x->ne[0] * 4 || (xuse && !same_act(xuse, x))) { ok = false; break; }
                     xuse = x;
                 }

@@ -401,7 +401,9 @@ static gqa_plan fa_gqa_plan(const fattn_args & f) {
     static const int  direct_tiles = getenv("MI355X_FA_GQA_DIRECT_TILES") ? atoi(getenv("MI355X_FA_GQA_DIRECT_TILES")) : 8;
     gqa_plan p = { false, 1, 1, 4 };
     const int64_t D = f.q.ne[0], nq = f.q.ne[1], nkv = f.k.ne[1], gq = f.k.ne[2] > 0 ? f.q.ne[2] / f.k.ne[2] : 0;
-    if (off || !g_gqa_enabled || (D != 64 && D != 128) || f.v.ne[0] != D || nq < 1 || nq > 8 || gq < 1 || gq > 32 || nkv < 1) return p;
+    static const int64_t max_nq = getenv("MI355X_FA_GQA_MAX_NQ") ? atoll(getenv("MI355X_FA_GQA_MAX_NQ")) : 32;   // more tokens: the prefill kernel
+    if (off || !g_gqa_enabled || (D != 64 && D != 128) || f.v.ne[0] != D || nq < 1 || nq > max_nq || gq < 1 || gq > 32 || nkv < 1) return p;
+    if (nq > 8 && (f.out16 || !fattn_mma_ok(nkv))) return p;
     if (f.q.ne[2] != gq * f.k.ne[2]) return p;
     if (f.mask && f.mask->ne[2] != 1) return p;                       // (a per-head mask would need per-lane mask rows)
     // one token over a shallow cache stays on the streaming kernel: it skips the dead granules of a padded cache view before touching
@@ -429,7 +431,9 @@ template <int D, int R, int NW>
 static size_t fa_lds_bytes() { return (size_t) R * D * 4 + NW * 16 * R * 4 + NW * R * (D + 2) * 4; }
 
 static bool fa_use_mma(const fattn_args & f) {
-    return f.q.ne[1] > 8 && !f.img && (f.q.ne[0] == 64 || f.q.ne[0] == 128) && fattn_mma_ok(f.k.ne[1]);
+    if (!(f.q.ne[1] > 8 && !f.img && (f.q.ne[0] == 64 || f.q.ne[0] == 128) && fattn_mma_ok(f.k.ne[1]))) return false;
+    fattn_args g = f; g.pre = nullptr; g.out16 = nullptr;
+    return f.out16 != nullptr || !fa_gqa_plan(g).ok;              // 9 .. 32 tokens: the decode-shape kernel, unless the f16 rows of a GEMM consumer are wanted
 }
 bool fattn_uses_mma(const fattn_args & f) { return fa_use_mma(f); }
 size_t fattn_map_bytes(int64_t nq, int64_t nkv, int64_t mne2, int64_t mne3);

@@ -226,7 +226,8 @@ def test_flash_attn_prefill_mfma(pkg, be, D, nq, nh, nhkv, nkv, ns, kind):
     (128, 1, 32, 8, 4096, 1, "depth"), (128, 8, 32, 8, 3000, 1, "seqs"), (64, 4, 8, 1, 1500, 2, "none"), (128, 1, 4, 4, 1024, 1, "sinks"),
     (128, 2, 16, 4, 5000, 1, "softcap"), (128, 3, 8, 1, 2048, 1, "depth"), (64, 1, 12, 2, 33000, 1, "depth"),
     (128, 1, 32, 8, 256, 1, "depth"), (128, 1, 32, 8, 77, 1, "depth"), (64, 8, 64, 8, 512, 1, "seqs"), (128, 3, 32, 2, 300, 2, "none"),
-    (64, 5, 5, 5, 40, 1, "sinks"), (128, 7, 4, 4, 1, 1, "none"), (128, 2, 8, 2, 640, 1, "alibi")])
+    (64, 5, 5, 5, 40, 1, "sinks"), (128, 7, 4, 4, 1, 1, "none"), (128, 2, 8, 2, 640, 1, "alibi"),
+    (128, 16, 32, 8, 1100, 1, "seqs"), (128, 32, 8, 2, 700, 1, "seqs"), (64, 20, 8, 8, 96, 2, "depth")])
 def test_flash_attn_decode_mfma(pkg, be, D, nq, nh, nhkv, nkv, ns, kind, gqa):
     """a few query tokens: the (token, head) pairs of a KV head form 32-column matrix-core tiles (k_fattn_gqa); shallow caches are
     finished by the workgroup itself, deep ones are cut into KV slices merged by a second pass (k_fattn_merge).  gqa=0 sends the same
