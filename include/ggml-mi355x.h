@@ -51,6 +51,7 @@ GGML_MI355X_API void   mi355x_timed_event_free(void * ev);
 /* runtime options: "graphs" (0/1 hipGraph replay of repeated cgraphs), "fusion" (0/1 node fusion),
  * "profile" (0/1 per-kernel-class event timing, disables graphs), "f16_shadow" (0/1 resident F16 images of quantised weights for
  * the prefill GEMM, process-wide), "norm_in_kernel" (0/1 RMS_NORM+MUL built inside the consuming decode mat-vec launches; default 0),
+ * "fattn_gqa" (0/1 matrix-core kernel for few-token FLASH_ATTN_EXT; 0 = streaming kernel for every such shape; default 1, process-wide),
  * "reset_stats".  Returns 0 on success, -1 for an unknown key. */
 GGML_MI355X_API int    mi355x_set_option(struct ggml_backend * backend, const char * key, long value);
 /* counters: "graph_replays", "graph_captures", "eager_graphs", "kernels_last_graph",
