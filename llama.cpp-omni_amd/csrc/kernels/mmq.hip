@@ -98,8 +98,7 @@ __global__ void __launch_bounds__(64 * KS) __attribute__((amdgpu_waves_per_eu(2)
             for (int e = 0; e < 16; ++e) { acc[e] = 0; mins[e] = 0; }
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                u32x4 av = GA.av[j];
-                if (!tok_ok) av = u32x4{ 0u, 0u, 0u, 0u };
+                const u32x4 av = GA.av[j];                          // (lanes past ncols carry token 0's bytes: their outputs are never stored)
                 const u32x4 wq = G.qs[j >> 1];
                 i32x4 wv, mv, aa;
 #pragma unroll
@@ -169,8 +168,7 @@ __global__ void __launch_bounds__(64 * KS) __attribute__((amdgpu_waves_per_eu(2)
             for (int s = 0; s < 16; ++s) {
                 // sub-block s: half n = s/8, value group q = (s%8)/2 (ql nibble / qh bit pair), is = s%2  (dequantize_row_q6_K, ggml-quants.c:1762-1791)
                 const int n = s >> 3, q = (s & 7) >> 1, is = s & 1;
-                u32x2 av = GA.av[s];
-                if (!tok_ok) av = u32x2{ 0u, 0u };
+                const u32x2 av = GA.av[s];
                 const u32x2 l = G.ql[n * 4 + (q & 1) * 2 + is], h = G.qh[n * 2 + is];
                 const int scs = (int) (int8_t) ((G.sc[s >> 2] >> (8 * (s & 3))) & 0xff);
                 union { u32x2 u; long l; } wv, sv, aa;
