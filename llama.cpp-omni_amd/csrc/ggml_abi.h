@@ -66,6 +66,7 @@ enum ggml_op {                          // ggml.h:459-566
     GGML_OP_GLU = 89,
     GGML_OP_COUNT = 90,
 };
+enum ggml_op_pool { GGML_OP_POOL_MAX = 0, GGML_OP_POOL_AVG = 1, GGML_OP_POOL_COUNT = 2 };      /* ggml.h:2024-2028 */
 
 enum ggml_unary_op {                    // ggml.h:568-587
     GGML_UNARY_OP_ABS = 0, GGML_UNARY_OP_SGN = 1, GGML_UNARY_OP_NEG = 2, GGML_UNARY_OP_STEP = 3,

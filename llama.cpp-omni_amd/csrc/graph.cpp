@@ -134,6 +134,14 @@ bool supports_op(const ggml_tensor * op) {
             // src0 = kernel (shape only), src1 = f32 image with dense [IH, IW] planes, dst dense f16 / f32
             return s0 && s1 && s1->type == GGML_TYPE_F32 && (op->type == GGML_TYPE_F16 || op->type == GGML_TYPE_F32) && is_contiguous(op) && s1->nb[0] == 4 &&
                    (op_param_i32(op, 6) != 1 || s1->nb[1] == (size_t) s1->ne[0] * 4) && nelements(op) < ((int64_t) 1 << 40);
+        case GGML_OP_POOL_2D:
+            return s0 && (s0->type == GGML_TYPE_F32 || s0->type == GGML_TYPE_F16) && op->type == GGML_TYPE_F32 && is_contiguous(op) &&
+                   s0->nb[0] == (s0->type == GGML_TYPE_F32 ? 4u : 2u) && (s0->ne[3] == 1 || s0->nb[3] == (size_t) s0->ne[2] * s0->nb[2]) &&
+                   (op_param_i32(op, 0) == GGML_OP_POOL_AVG || op_param_i32(op, 0) == GGML_OP_POOL_MAX);
+        case GGML_OP_POOL_1D:                                 // the reference implements k == s, p == 0 only (ops.cpp:7270-7276)
+            return s0 && (s0->type == GGML_TYPE_F32 || s0->type == GGML_TYPE_F16) && op->type == GGML_TYPE_F32 && is_contiguous(op) && is_contiguous(s0) &&
+                   op_param_i32(op, 1) == op_param_i32(op, 2) && op_param_i32(op, 3) == 0 &&
+                   (op_param_i32(op, 0) == GGML_OP_POOL_AVG || op_param_i32(op, 0) == GGML_OP_POOL_MAX);
         case GGML_OP_SCALE:
             return s0 && s0->type == GGML_TYPE_F32 && op->type == GGML_TYPE_F32 && is_contiguous(s0) && is_contiguous(op);
         case GGML_OP_UNARY: {
@@ -1092,6 +1100,11 @@ static void compute_node(exec_state & s, int i) {
         case GGML_OP_IM2COL: {
             prof_scope ps(s, "im2col", 0);
             im2col_f32(td(n->src[0]), td(n->src[1]), td(n), n->type, n->op_params, s.st); ++s.n_kernels;
+            break;
+        }
+        case GGML_OP_POOL_1D: case GGML_OP_POOL_2D: {
+            prof_scope ps(s, "pool", 0);
+            pool_f32(td(n->src[0]), n->src[0]->type, td(n), n->op_params, n->op == GGML_OP_POOL_2D, s.st); ++s.n_kernels;
             break;
         }
         case GGML_OP_NORM: {

@@ -87,6 +87,8 @@ struct tdesc {
 void rms_norm(const tdesc & x, const tdesc & y, float eps, const tdesc * mul_w, hipStream_t st, uint16_t * y16 = nullptr, size_t y16_rs = 0, bool write_f32 = true);
 // IM2COL (ops.cpp:6150-6301): x f32 [IW, IH, IC, N] (2-D) or [IW, IC, N] (1-D) -> y f16 / f32 [IC*KH*KW, OW, OH, N]; p = op_params (s0,s1,p0,p1,d0,d1,is_2D)
 void im2col_f32(const tdesc & kernel, const tdesc & x, const tdesc & y, int y_type, const int32_t * p, hipStream_t st);
+// POOL_2D (ops.cpp:7281-7355) / POOL_1D with k == s, p == 0 (ops.cpp:7212-7260): avg / max windows of f32 / f16 planes -> f32; p = op_params
+void pool_f32(const tdesc & x, int x_type, const tdesc & y, const int32_t * p, bool is_2d, hipStream_t st);
 // NORM (ops.cpp:3450-3495): y = (x - mean) / sqrt(var + eps) per row
 void norm_f32(const tdesc & x, const tdesc & y, float eps, hipStream_t st);
 // ROPE f32 (ops.cpp:5534-5720): modes NORMAL / NEOX, optional freq factors, YaRN

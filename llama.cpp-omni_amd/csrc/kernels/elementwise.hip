@@ -2,6 +2,7 @@
 // Each kernel restates one `ggml_compute_forward_*` of the reference CPU backend
 // (ggml/src/ggml-cpu/ops.cpp); the line ranges are cited per kernel.
 #include "../kernels.hpp"
+#include <float.h>
 
 namespace mi {
 
@@ -192,6 +193,50 @@ void im2col_f32(const tdesc & kernel, const tdesc & x, const tdesc & y, int y_ty
     const unsigned grid = (unsigned) ((total + 255) / 256);
     if (y_type == GGML_TYPE_F16) k_im2col<uint16_t><<<dim3(grid), dim3(256), 0, st>>>((const char *) x.p, (uint16_t *) y.p, a, total);
     else                         k_im2col<float><<<dim3(grid), dim3(256), 0, st>>>((const char *) x.p, (float *) y.p, a, total);
+}
+
+// ================================================================================================
+// POOL_2D / POOL_1D (avg, max).  reference: ggml_compute_forward_pool_2d, ops.cpp:7281-7355 (window clipped at the borders, the
+// average still divides by k0*k1) and ggml_compute_forward_pool_1d_sk_p0, ops.cpp:7212-7260 (k == s, no padding: a 2-D pool with a
+// 1-row window).  One thread per output cell, the window summed in the reference's order (ky outer, kx inner), `/ ka` a division.
+struct pool_dev { int op, k0, k1, s0, s1, p0, p1; int IW, IH, OW, OH; int64_t nb1, nb2; int f16; };
+__global__ void __launch_bounds__(256) k_pool2d(const char * __restrict__ x, float * __restrict__ y, const pool_dev a, int64_t total) {
+    const int64_t i = (int64_t) blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int ox = (int) (i % a.OW); const int64_t r = i / a.OW;
+    const int oy = (int) (r % a.OH); const int64_t pl = r / a.OH;
+    const char * plane = x + pl * a.nb2;
+    float out = a.op == GGML_OP_POOL_AVG ? 0.0f : -FLT_MAX;
+    const int ix = -a.p0 + ox * a.s0, iy = -a.p1 + oy * a.s1;
+    for (int ky = 0; ky < a.k1; ++ky) {
+        if (iy + ky < 0 || iy + ky >= a.IH) continue;
+        const char * row = plane + (int64_t) (iy + ky) * a.nb1;
+        for (int kx = 0; kx < a.k0; ++kx) {
+            const int j = ix + kx;
+            if (j < 0 || j >= a.IW) continue;
+            const float v = a.f16 ? h2f(((const uint16_t *) row)[j]) : ((const float *) row)[j];
+            if (a.op == GGML_OP_POOL_AVG) out += v; else if (v > out) out = v;
+        }
+    }
+    if (a.op == GGML_OP_POOL_AVG) out /= (float) (a.k0 * a.k1);
+    y[i] = out;
+}
+void pool_f32(const tdesc & x, int x_type, const tdesc & y, const int32_t * p, bool is_2d, hipStream_t st) {
+    pool_dev a;
+    a.op = p[0]; a.f16 = x_type == GGML_TYPE_F16;
+    int64_t planes;
+    if (is_2d) {
+        a.k0 = p[1]; a.k1 = p[2]; a.s0 = p[3]; a.s1 = p[4]; a.p0 = p[5]; a.p1 = p[6];
+        a.IW = (int) x.ne[0]; a.IH = (int) x.ne[1]; a.OW = (int) y.ne[0]; a.OH = (int) y.ne[1];
+        a.nb1 = (int64_t) x.nb[1]; a.nb2 = (int64_t) x.nb[2]; planes = x.ne[2] * x.ne[3];
+    } else {                                                  // [k0, s0, p0] with k0 == s0, p0 == 0 (supports_op): every row of the tensor is one "plane row"
+        a.k0 = p[1]; a.k1 = 1; a.s0 = p[2]; a.s1 = 1; a.p0 = 0; a.p1 = 0;
+        a.IW = (int) x.ne[0]; a.IH = (int) (x.ne[1] * x.ne[2] * x.ne[3]); a.OW = (int) y.ne[0]; a.OH = a.IH;
+        a.nb1 = (int64_t) x.nb[1]; a.nb2 = 0; planes = 1;
+    }
+    const int64_t total = (int64_t) a.OW * a.OH * planes;
+    if (total == 0) return;
+    k_pool2d<<<dim3((unsigned) ((total + 255) / 256)), dim3(256), 0, st>>>((const char *) x.p, (float *) y.p, a, total);
 }
 
 // ================================================================================================

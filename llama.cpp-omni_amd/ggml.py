@@ -28,6 +28,8 @@ class OP:
     NONE, DUP, ADD, SUB, MUL, DIV = 0, 1, 2, 6, 7, 8
     NORM, RMS_NORM, MUL_MAT, SCALE, CPY, CONT, RESHAPE, VIEW, PERMUTE, TRANSPOSE = 23, 24, 28, 31, 33, 34, 35, 36, 37, 38
     IM2COL = 51
+    POOL_1D = 58
+    POOL_2D = 59
     GET_ROWS, SET_ROWS, SOFT_MAX, ROPE, FLASH_ATTN_EXT, UNARY, GLU = 39, 41, 45, 47, 69, 80, 89
 
 
@@ -528,6 +530,18 @@ class Context:
             ne = (kernel.ne[1] * kernel.ne[0], OW, x.ne[2], 1)
         T = self._new(dst_type, ne)
         return self._op(T, OP.IM2COL, [kernel, x], (s0, s1, p0, p1, d0, d1, 1 if is_2d else 0))
+
+    def pool_2d(self, x, op, k0, k1, s0, s1, p0, p1):
+        """ggml_pool_2d (ggml.c): op 0 = max, 1 = avg; x [IW, IH, C, N] -> f32 [OW, OH, C, N]"""
+        ne = ((x.ne[0] + 2 * p0 - k0) // s0 + 1, (x.ne[1] + 2 * p1 - k1) // s1 + 1, x.ne[2], x.ne[3])
+        T = self._new(GGML_TYPE_F32, ne)
+        return self._op(T, OP.POOL_2D, [x], (op, k0, k1, s0, s1, p0, p1))
+
+    def pool_1d(self, x, op, k0, s0, p0):
+        """ggml_pool_1d (ggml.c): windows along ne[0]"""
+        ne = ((x.ne[0] + 2 * p0 - k0) // s0 + 1, x.ne[1], x.ne[2], x.ne[3])
+        T = self._new(GGML_TYPE_F32, ne)
+        return self._op(T, OP.POOL_1D, [x], (op, k0, s0, p0))
 
     def conv_1d(self, kernel, x, s0, p0, d0):
         """ggml_conv_1d (ggml.c): im2col in f16, then one MUL_MAT against the flattened f16 kernel -> [OL, OC, N]"""

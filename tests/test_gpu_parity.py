@@ -555,6 +555,34 @@ def test_encoder_block_vs_reference_backend(pkg, be, ref_be):
     assert nmse(outs[0], outs[1]) < 1e-6
 
 
+@pytest.mark.parametrize("case", ["2d_avg", "2d_max_pad", "2d_f16", "1d_avg5", "1d_max2"])
+def test_pool_vs_reference_backend(pkg, be, ref_be, case):
+    """POOL_2D / POOL_1D (the omni encoders' pooling: audition.cpp:697 avg k = s = 5 along the token axis; vision.cpp) -- same window
+    order and the same division as ggml_compute_forward_pool_2d / _pool_1d_sk_p0, so the bits must match the reference CPU backend."""
+    rng = np.random.default_rng(5)
+    outs = []
+    for backend in (be, ref_be):
+        c = pkg.Context(backend)
+        if case.startswith("2d"):
+            ty = pkg.GGML_TYPE_F16 if case == "2d_f16" else pkg.GGML_TYPE_F32
+            xv = rng.standard_normal((2, 3, 11, 13)).astype(np.float16 if case == "2d_f16" else np.float32)
+            x = c.new_tensor(ty, 13, 11, 3, 2)
+            y = c.pool_2d(x, 0 if case == "2d_max_pad" else 1, 3, 2, 2, 1, 1 if case == "2d_max_pad" else 0, 1 if case == "2d_max_pad" else 0)
+        else:
+            xv = rng.standard_normal((1, 2, 24, 40)).astype(np.float32)
+            x = c.new_tensor(pkg.GGML_TYPE_F32, 40, 24, 2, 1)
+            k = 5 if case == "1d_avg5" else 2
+            y = c.pool_1d(x, 1 if case == "1d_avg5" else 0, k, k, 0)
+        c.alloc()
+        backend.tensor_set(x, xv)
+        backend.graph_compute(c.graph())
+        outs.append(backend.tensor_get(y).copy())
+        c.free()
+        rng = np.random.default_rng(5)
+    assert outs[0].shape == outs[1].shape and np.isfinite(outs[0]).all()
+    assert np.array_equal(outs[0], outs[1])
+
+
 def test_f16_model_logits_within_1e3(pkg, be, ref_be):
     """north star: F16 logits within 1e-3 of the reference CPU backend (F16 weights, f16-rounded activations, f32 accumulate)."""
     from llama_cpp_omni_amd import qwen3
