@@ -1138,6 +1138,31 @@ static void compute_node(exec_state & s, int i) {
             tdesc b; if (n->src[1]) b = td(n->src[1]);
             const ggml_tensor * xg = nullptr;
             const bool emit16 = n->ne[2] == 1 && n->ne[3] == 1 && n->nb[1] == (size_t) n->ne[0] * 4 && gemm_only_consumers(s, n, n->ne[0], n->ne[1], &xg);
+            // every consumer a K-quant mat-mul on the whole result (ffn_down at several columns): emit the Q8_K images here
+            const ggml_tensor * xq = nullptr;
+            if (s.c->opt_fusion && !emit16 && n->src[1] && op_param_i32(n, 0) == GGML_GLU_OP_SWIGLU && op_param_i32(n, 1) == 0 && n_users(s, n) > 0 &&
+                !(n->flags & GGML_TENSOR_FLAG_OUTPUT) && n->nb[1] == (size_t) n->ne[0] * 4 && swiglu_q8k_ok(td(n->src[0]), b, td(n))) {
+                bool ok = true;
+                for (int u : s.users[n]) {
+                    const ggml_tensor * c = g->nodes[u];
+                    const ggml_tensor * x = c->op == GGML_OP_MUL_MAT ? c->src[1] : nullptr;
+                    if (!x || !kq_mm_ok(c) || x->data != n->data || x->ne[0] != n->ne[0] || x->ne[1] != n->ne[1] || x->nb[1] != n->nb[1] || (xq && !same_act(xq, x))) { ok = false; break; }
+                    xq = x;
+                }
+                if (!ok) xq = nullptr;
+            }
+            if (xq) {
+                {
+                    prof_scope ps(s, "glu", 0);
+                    swiglu_q8k(td(n->src[0]), b, td(n), true, s.c->act_scratch, s.st);      // (f32 too: the image cache may be dropped before the consumer runs)
+                }
+                ++s.n_kernels; ++s.n_fused;
+                note_write(s, n);
+                s.a_src = xq->data; s.a_kind = ACT_Q8K; s.a_K = xq->ne[0]; s.a_ne[0] = xq->ne[1]; s.a_ne[1] = 1; s.a_ne[2] = 1;
+                s.a_nb[0] = xq->nb[1]; s.a_nb[1] = xq->nb[2]; s.a_nb[2] = xq->nb[3];
+                s.a_range_lo = (const char *) xq->data; s.a_range_hi = (const char *) xq->data + nbytes(xq);
+                return;
+            }
             {
                 prof_scope ps(s, "glu", 0);
                 if (emit16) glu_f32(op_param_i32(n, 0), td(n->src[0]), n->src[1] ? &b : nullptr, op_param_i32(n, 1) != 0, td(n), s.st,

@@ -101,6 +101,10 @@ void rope_f32(const tdesc & x, const int32_t * pos, const float * freq_factors, 
 void soft_max_f32(const tdesc & x, const tdesc * mask, int mask_type, const float * sinks, const tdesc & y, float scale, float max_bias, hipStream_t st);
 // GLU (split or single-tensor forms; ops.cpp:2934-2990 for swiglu)
 void glu_f32(int glu_op, const tdesc & a, const tdesc * b, bool swapped, const tdesc & y, hipStream_t st, uint16_t * y16 = nullptr, size_t y16_rs = 0, bool write_f32 = true);
+// SWIGLU (split form) straight into the Q8_K activation images of its rows (+ optionally the f32 result): the GLU of an FFN whose
+// down projection is a K-quant mat-mul at several columns
+bool swiglu_q8k_ok(const tdesc & a, const tdesc & b, const tdesc & y);
+void swiglu_q8k(const tdesc & a, const tdesc & b, const tdesc & y, bool write_f32, void * img, hipStream_t st);
 // unary ops on contiguous f32
 void unary_f32(int uop, const float * x, float * y, int64_t n, hipStream_t st);
 // ADD / SUB / MUL / DIV with ggml broadcast semantics (src1 repeats over src0)

@@ -451,6 +451,37 @@ __global__ void __launch_bounds__(256) k_swiglu_v4(const char * __restrict__ a, 
     }
 }
 
+// SWIGLU whose only consumers are K-quant mat-muls (ffn_down at several columns): one wave per (row, 256-element block) computes
+// silu(a) * b and writes the Q8_K block of the row's activation image directly (quantize_row_q8_K arithmetic, common.hpp) --
+// the separate quantiser launch disappears; y (the f32 result) is optional
+__global__ void __launch_bounds__(256) k_swiglu_q8k(const char * __restrict__ a, int64_t a_rs, const char * __restrict__ b, int64_t b_rs,
+                                                   char * __restrict__ y, int64_t y_rs, char * __restrict__ img, size_t img_bytes, int nblk, int64_t total) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wid = (int64_t) blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (wid >= total) return;
+    const int64_t r = wid / nblk; const int ib = (int) (wid - r * nblk);
+    const f32x4 x = *(const f32x4 *) (a + r * a_rs + (int64_t) ib * 1024 + lane * 16);
+    const f32x4 g = *(const f32x4 *) (b + r * b_rs + (int64_t) ib * 1024 + lane * 16);
+    f32x4 v;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = op_silu(x[e]) * g[e];
+    if (y) *(f32x4 *) (y + r * y_rs + (int64_t) ib * 1024 + lane * 16) = v;
+    char * im = img + r * img_bytes;
+    const int64_t K = (int64_t) nblk * 256;
+    q8k_block_from_regs(v, lane, (int8_t *) im + ib * 256, (int16_t *) (im + K) + ib * 16, (float *) (im + K + K / 8) + ib);
+}
+bool swiglu_q8k_ok(const tdesc & a, const tdesc & b, const tdesc & y) {
+    return y.ne[0] % 256 == 0 && y.ne[2] == 1 && y.ne[3] == 1 && ((uintptr_t) a.p & 15) == 0 && ((uintptr_t) b.p & 15) == 0 && a.nb[1] % 16 == 0 && b.nb[1] % 16 == 0 &&
+           ((uintptr_t) y.p & 15) == 0 && y.nb[1] % 16 == 0;
+}
+void swiglu_q8k(const tdesc & a, const tdesc & b, const tdesc & y, bool write_f32, void * img, hipStream_t st) {
+    const int nblk = (int) (y.ne[0] / 256);
+    const int64_t total = (int64_t) nblk * y.ne[1];
+    if (total == 0) return;
+    k_swiglu_q8k<<<dim3((unsigned) ((total + 3) / 4)), dim3(256), 0, st>>>((const char *) a.p, (int64_t) a.nb[1], (const char *) b.p, (int64_t) b.nb[1],
+                                                                         write_f32 ? (char *) y.p : nullptr, (int64_t) y.nb[1], (char *) img, q8k_image_bytes(y.ne[0]), nblk, total);
+}
+
 void glu_f32(int glu_op, const tdesc & a, const tdesc * b, bool swapped, const tdesc & y, hipStream_t st, uint16_t * y16, size_t y16_rs, bool write_f32) {
     // rows are contiguous_1 (checked by supports_op): treat as [nc, nr] with a row stride
     const int64_t nc = y.ne[0];
