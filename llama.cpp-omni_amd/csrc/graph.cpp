@@ -33,7 +33,13 @@ static bool is_noop(const ggml_tensor * t) {
 }
 
 enum act_kind { ACT_NONE = 0, ACT_Q8K, ACT_Q80, ACT_F16, ACT_F32 };
+// block formats without integer-dot kernels of their own: every MUL_MAT runs on the F16 image of the weights (resident for model
+// tensors, shadow.hpp; else de-quantised into scratch per call) with f16-rounded activations -- the arithmetic of the prefill GEMM
+static bool is_image_quant(int t) {
+    return t == GGML_TYPE_Q4_0 || t == GGML_TYPE_Q4_1 || t == GGML_TYPE_Q5_0 || t == GGML_TYPE_Q5_1 || t == GGML_TYPE_Q2_K || t == GGML_TYPE_Q3_K || t == GGML_TYPE_Q5_K;
+}
 static act_kind act_kind_for(int wtype) {
+    if (is_image_quant(wtype)) return ACT_F16;
     switch (wtype) {
         case GGML_TYPE_Q4_K: case GGML_TYPE_Q6_K: return ACT_Q8K;
         case GGML_TYPE_Q8_0: return ACT_Q80;
@@ -185,6 +191,7 @@ bool supports_op(const ggml_tensor * op) {
             if (!s0 || !s1 || s1->type != GGML_TYPE_I32 || op->type != GGML_TYPE_F32 || op->nb[0] != 4) return false;
             switch (s0->type) {
                 case GGML_TYPE_F32: case GGML_TYPE_F16: case GGML_TYPE_Q8_0: case GGML_TYPE_Q4_K: case GGML_TYPE_Q6_K:
+                case GGML_TYPE_Q4_0: case GGML_TYPE_Q4_1: case GGML_TYPE_Q5_0: case GGML_TYPE_Q5_1: case GGML_TYPE_Q2_K: case GGML_TYPE_Q3_K: case GGML_TYPE_Q5_K:
                     return s0->nb[0] == type_size(s0->type);
                 default: return false;
             }
@@ -235,7 +242,7 @@ static bool mm_uses_gemm(const ggml_tensor * n) {
     static const bool no_gemm = getenv("MI355X_NO_GEMM") != nullptr;
     if (x->ne[1] < GEMM_MIN_COLS || no_gemm) return false;
     if (mm_uses_mmq(n)) return false;
-    if (w->type != GGML_TYPE_F16 && w->type != GGML_TYPE_Q4_K && w->type != GGML_TYPE_Q6_K && w->type != GGML_TYPE_Q8_0) return false;
+    if (w->type != GGML_TYPE_F16 && w->type != GGML_TYPE_Q4_K && w->type != GGML_TYPE_Q6_K && w->type != GGML_TYPE_Q8_0 && !is_image_quant(w->type)) return false;
     const int64_t K = w->ne[0];
     if (K % 32 != 0) return false;
     if (w->type == GGML_TYPE_F16 && (w->nb[1] % 16 != 0 || w->nb[2] % 16 != 0 || w->nb[3] % 16 != 0 || ((uintptr_t) w->data & 15) != 0)) return false;
@@ -256,7 +263,7 @@ static size_t graph_w_scratch_need(const ggml_cgraph * g) {
     size_t need = 0;
     for (int i = 0; i < g->n_nodes; ++i) {
         const ggml_tensor * n = g->nodes[i];
-        if (n->op != GGML_OP_MUL_MAT || is_empty(n) || !mm_uses_gemm(n) || n->src[0]->type == GGML_TYPE_F16) continue;
+        if (n->op != GGML_OP_MUL_MAT || is_empty(n) || n->src[0]->type == GGML_TYPE_F16 || !(mm_uses_gemm(n) || is_image_quant(n->src[0]->type))) continue;
         const size_t b = (size_t) n->src[0]->ne[0] * (size_t) n->src[0]->ne[1] * 2;
         if (b > need) need = b;
     }
@@ -463,9 +470,19 @@ static void op_mul_mat(exec_state & s, const ggml_tensor * dst) {
                 }
                 continue;
             }
+            const void * wv = wp; size_t wv_rs = w->nb[1]; int wv_type = w->type;
+            if (is_image_quant(w->type)) {                            // mat-vec on the F16 image of the block format
+                const uint16_t * sh = weight_shadow(s, w, wp, K, M);
+                if (!sh) {
+                    prof_scope ps(s, "dequant_f16", wbytes);
+                    dequant_rows_f16(w->type, wp, w->nb[1], (uint16_t *) s.c->w_scratch, (size_t) K * 2, K, M, s.st); ++s.n_kernels;
+                    sh = (const uint16_t *) s.c->w_scratch;
+                }
+                wv = sh; wv_rs = (size_t) K * 2; wv_type = GGML_TYPE_F16;
+            }
             for (int64_t c0 = 0; c0 < N; c0 += MI_MMVQ_MAX_COLS) {
                 mmv_args a;
-                a.W = wp; a.w_rs = w->nb[1]; a.K = K; a.nrows = M;
+                a.W = wv; a.w_rs = wv_rs; a.K = K; a.nrows = M;
                 a.ncols = (int) (N - c0 < MI_MMVQ_MAX_COLS ? N - c0 : MI_MMVQ_MAX_COLS);
                 a.dst = (float *) (dp + c0 * dst->nb[1]); a.dst_cs = dst->nb[1];
                 if (kind == ACT_F32) {
@@ -473,8 +490,8 @@ static void op_mul_mat(exec_state & s, const ggml_tensor * dst) {
                 } else {
                     a.act = (const char *) s.c->act_scratch + (size_t) ((i13 * ne12 + i12) * N + c0) * img; a.act_cs = img;
                 }
-                prof_scope ps(s, mmv_class(w->type), wbytes);
-                switch (w->type) {
+                prof_scope ps(s, mmv_class(wv_type), wbytes);
+                switch (wv_type) {
                     case GGML_TYPE_Q4_K: mmv_q4_K(a, s.st); break;
                     case GGML_TYPE_Q6_K: mmv_q6_K(a, s.st); break;
                     case GGML_TYPE_Q8_0: mmv_q8_0(a, s.st); break;

@@ -90,6 +90,75 @@ __global__ void __launch_bounds__(256) k_dequant_q80(const char * __restrict__ s
     (void) nb;
 }
 
+// ---- the other block formats (Q4_0 / Q4_1 / Q5_0 / Q5_1 / Q2_K / Q3_K / Q5_K): one element at a time, the float operations of
+// dequantize_row_q4_0 :307, _q4_1 :327, _q5_0 :348, _q5_1 :374, _q2_K :784, _q3_K :1128, _q5_K :1554 (ggml-quants.c) in the same order.
+// These types have no integer-dot kernels here: MUL_MAT runs on their (resident) F16 image, GET_ROWS gathers through this function.
+static __device__ __forceinline__ float h2f_at(const uint8_t * p) { return h2f((uint16_t) (p[0] | (p[1] << 8))); }
+static __device__ float dq_elem_other(int type, const char * row, int64_t e) {
+    switch (type) {
+        case GGML_TYPE_Q4_0: case GGML_TYPE_Q4_1: {
+            const int bs = type == GGML_TYPE_Q4_0 ? 18 : 20;
+            const uint8_t * b = (const uint8_t *) row + (e / 32) * bs;
+            const int w = (int) (e % 32), j = w & 15;
+            const uint8_t q = b[(bs - 16) + j];
+            const int x = w < 16 ? (q & 0x0F) : (q >> 4);
+            const float d = h2f_at(b);
+            if (type == GGML_TYPE_Q4_0) return (float) (x - 8) * d;
+            return (float) x * d + h2f_at(b + 2);
+        }
+        case GGML_TYPE_Q5_0: case GGML_TYPE_Q5_1: {
+            const int bs = type == GGML_TYPE_Q5_0 ? 22 : 24, hoff = bs - 20;
+            const uint8_t * b = (const uint8_t *) row + (e / 32) * bs;
+            const int w = (int) (e % 32), j = w & 15;
+            const uint32_t qh = (uint32_t) b[hoff] | ((uint32_t) b[hoff + 1] << 8) | ((uint32_t) b[hoff + 2] << 16) | ((uint32_t) b[hoff + 3] << 24);
+            const uint8_t q = b[hoff + 4 + j];
+            const int x = w < 16 ? ((q & 0x0F) | (((qh >> j) << 4) & 0x10)) : ((q >> 4) | ((qh >> (j + 12)) & 0x10));
+            const float d = h2f_at(b);
+            if (type == GGML_TYPE_Q5_0) return (float) (x - 16) * d;
+            return (float) x * d + h2f_at(b + 2);
+        }
+        case GGML_TYPE_Q2_K: {                                        // scales[16] qs[64] d dmin
+            const uint8_t * b = (const uint8_t *) row + (e / 256) * 84;
+            const int w = (int) (e % 256), n = w >> 7, r = w & 127, j = r >> 5, sub = (r >> 4) & 1, l = r & 15;
+            const uint8_t sc = b[n * 8 + j * 2 + sub];
+            const float dl = h2f_at(b + 80) * (float) (sc & 0xF), ml = h2f_at(b + 82) * (float) (sc >> 4);
+            const uint8_t q = b[16 + n * 32 + sub * 16 + l];
+            return dl * (float) (int8_t) ((q >> (2 * j)) & 3) - ml;
+        }
+        case GGML_TYPE_Q3_K: {                                        // hmask[32] qs[64] scales[12] d
+            const uint8_t * b = (const uint8_t *) row + (e / 256) * 110;
+            const int w = (int) (e % 256), n = w >> 7, r = w & 127, j = r >> 5, sub = (r >> 4) & 1, l = r & 15;
+            const int k = n * 8 + j * 2 + sub, grp = k >> 2, i = k & 3;
+            const uint8_t * sp = b + 96;
+            const int lo = grp == 0 ? (sp[i] & 0xF) : grp == 1 ? (sp[4 + i] & 0xF) : grp == 2 ? (sp[i] >> 4) : (sp[4 + i] >> 4);
+            const int hi = (sp[8 + i] >> (2 * grp)) & 3;
+            const float dl = h2f_at(b + 108) * (float) ((int) (int8_t) (lo | (hi << 4)) - 32);
+            const uint8_t q = b[32 + n * 32 + sub * 16 + l];
+            const uint8_t hm = b[sub * 16 + l];
+            const int m = 1 << (n * 4 + j);
+            return dl * (float) ((int) (int8_t) ((q >> (2 * j)) & 3) - ((hm & m) ? 0 : 4));
+        }
+        case GGML_TYPE_Q5_K: {                                        // d dmin scales[12] qh[32] qs[128]
+            const uint8_t * b = (const uint8_t *) row + (e / 256) * 176;
+            const int w = (int) (e % 256), p = w >> 6, hi = (w >> 5) & 1, l = w & 31;
+            int sc, m; q4k_scale_min(2 * p + hi, b + 4, sc, m);
+            const float d1 = h2f_at(b) * (float) sc, m1 = h2f_at(b + 2) * (float) m;
+            const uint8_t ql = b[48 + 32 * p + l];
+            const int nib = hi ? (ql >> 4) : (ql & 0xF);
+            const int hb = (b[16 + l] & ((hi ? 2 : 1) << (2 * p))) ? 16 : 0;
+            return d1 * (float) (nib + hb) - m1;
+        }
+        default: return 0.0f;
+    }
+}
+template <typename T>
+__global__ void __launch_bounds__(256) k_dequant_other(int type, const char * __restrict__ src, size_t src_rs, char * __restrict__ dst, size_t dst_rs, int64_t K, int64_t nrows) {
+    const int64_t t = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nrows * K) return;
+    const int64_t row = t / K, e = t % K;
+    ((T *) (dst + row * dst_rs))[e] = cvt_out<T>(dq_elem_other(type, src + row * src_rs, e));
+}
+
 template <typename T>
 static void dequant_rows_t(int type, const void * src, size_t src_rs, T * dst, size_t dst_rs, int64_t K, int64_t nrows, hipStream_t st) {
     if (K == 0 || nrows == 0) return;
@@ -101,6 +170,9 @@ static void dequant_rows_t(int type, const void * src, size_t src_rs, T * dst, s
             k_dequant_q6k<T><<<dim3((unsigned) ((nthreads + 255) / 256)), dim3(256), 0, st>>>((const char *) src, src_rs, (char *) dst, dst_rs, K, nrows); break;
         case GGML_TYPE_Q8_0: nthreads = nrows * K;
             k_dequant_q80<T><<<dim3((unsigned) ((nthreads + 255) / 256)), dim3(256), 0, st>>>((const char *) src, src_rs, (char *) dst, dst_rs, K, nrows); break;
+        case GGML_TYPE_Q4_0: case GGML_TYPE_Q4_1: case GGML_TYPE_Q5_0: case GGML_TYPE_Q5_1: case GGML_TYPE_Q2_K: case GGML_TYPE_Q3_K: case GGML_TYPE_Q5_K:
+            nthreads = nrows * K;
+            k_dequant_other<T><<<dim3((unsigned) ((nthreads + 255) / 256)), dim3(256), 0, st>>>(type, (const char *) src, src_rs, (char *) dst, dst_rs, K, nrows); break;
         default: fprintf(stderr, "[mi355x] dequant_rows: unsupported type %d\n", type); abort();
     }
 }
@@ -650,6 +722,8 @@ __global__ void __launch_bounds__(256) k_get_rows_q(int type, td4 s, td4 idx, td
             const uint8_t q = b->qs[32 * (sb >> 1) + l];
             const int qv = (sb & 1) ? (q >> 4) : (q & 0xF);
             v = (h2f(b->d) * (float) sc) * (float) qv - h2f(b->dmin) * (float) m;
+        } else if (type != GGML_TYPE_Q6_K) {
+            v = dq_elem_other(type, sr, e);
         } else { // Q6_K
             const block_q6_K * b = (const block_q6_K *) sr + e / 256;
             const int w = (int) (e % 256), n = w / 128, r = w % 128, k = r / 32, l = r % 32;
@@ -671,6 +745,7 @@ void get_rows(const tdesc & src, int src_type, const tdesc & idx, const tdesc & 
         case GGML_TYPE_I32: k_get_rows<float><<<grid, dim3(256), 0, st>>>(s, i, d); break;   // bit copy (4-byte elements)
         case GGML_TYPE_F16: k_get_rows<uint16_t><<<grid, dim3(256), 0, st>>>(s, i, d); break;
         case GGML_TYPE_Q8_0: case GGML_TYPE_Q4_K: case GGML_TYPE_Q6_K:
+        case GGML_TYPE_Q4_0: case GGML_TYPE_Q4_1: case GGML_TYPE_Q5_0: case GGML_TYPE_Q5_1: case GGML_TYPE_Q2_K: case GGML_TYPE_Q3_K: case GGML_TYPE_Q5_K:
             k_get_rows_q<<<grid, dim3(256), 0, st>>>(src_type, s, i, d); break;
         default: fprintf(stderr, "[mi355x] get_rows: unsupported type %d\n", src_type); abort();
     }

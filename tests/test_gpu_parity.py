@@ -555,6 +555,50 @@ def test_encoder_block_vs_reference_backend(pkg, be, ref_be):
     assert nmse(outs[0], outs[1]) < 1e-6
 
 
+# (type id, block bytes, offsets of the fp16 fields inside a block) of the block formats served through their F16 image
+IMAGE_QUANTS = {"q4_0": (2, 18, (0,)), "q4_1": (3, 20, (0, 2)), "q5_0": (6, 22, (0,)), "q5_1": (7, 24, (0, 2)),
+                "q2_K": (10, 84, (80, 82)), "q3_K": (11, 110, (108,)), "q5_K": (13, 176, (0, 2))}
+
+
+def _random_image_quant_rows(rng, name, M, K):
+    """valid random blocks: every quant / scale byte uniform, the fp16 super-scales small positive numbers"""
+    _, bs, hoffs = IMAGE_QUANTS[name]
+    nb = K // (32 if bs < 30 else 256)
+    raw = rng.integers(0, 256, (M, nb, bs), dtype=np.uint8)
+    for o in hoffs:
+        raw[:, :, o:o + 2] = rng.uniform(0.002, 0.02, (M, nb, 1)).astype(np.float16).view(np.uint8).reshape(M, nb, 2)
+    return raw.reshape(M, -1)
+
+
+@pytest.mark.parametrize("name", sorted(IMAGE_QUANTS))
+@pytest.mark.parametrize("M,K,N", [(48, 512, 1), (130, 1024, 5), (96, 768, 24)])
+def test_mul_mat_image_quants_vs_reference_backend(pkg, be, ref_be, name, M, K, N):
+    """Q4_0 / Q4_1 / Q5_0 / Q5_1 / Q2_K / Q3_K / Q5_K weights: MUL_MAT on the F16 image of the de-quantised blocks (mat-vec and GEMM
+    widths) and GET_ROWS, against the reference CPU backend; bar = the reference's MUL_MAT NMSE 5e-4, GET_ROWS bit-exact."""
+    rng = np.random.default_rng(M + K + N)
+    ty = IMAGE_QUANTS[name][0]
+    wv = _random_image_quant_rows(rng, name, M, K)
+    xv = rng.standard_normal((N, K)).astype(np.float32)
+    iv = rng.integers(0, M, 7).astype(np.int32)
+    outs = []
+    for backend in (be, ref_be):
+        c = pkg.Context(backend)
+        w = c.new_tensor(ty, K, M)
+        x = c.new_tensor(pkg.GGML_TYPE_F32, K, N)
+        idx = c.new_tensor(pkg.GGML_TYPE_I32, 7)
+        y = c.mul_mat(w, x)
+        r = c.get_rows(w, idx)
+        c.alloc()
+        backend.tensor_set(w, wv); backend.tensor_set(x, xv); backend.tensor_set(idx, iv)
+        gr = c.graph()
+        backend.graph_compute(gr)
+        outs.append((backend.tensor_get(y).copy(), backend.tensor_get(r).copy()))
+        c.free()
+    assert np.isfinite(outs[0][0]).all()
+    assert nmse(outs[0][0], outs[1][0]) < 5e-4, name
+    assert np.array_equal(outs[0][1], outs[1][1]), name
+
+
 @pytest.mark.parametrize("case", ["2d_avg", "2d_max_pad", "2d_f16", "1d_avg5", "1d_max2"])
 def test_pool_vs_reference_backend(pkg, be, ref_be, case):
     """POOL_2D / POOL_1D (the omni encoders' pooling: audition.cpp:697 avg k = s = 5 along the token axis; vision.cpp) -- same window
