@@ -83,6 +83,21 @@ def random_blocks(rng, ty, nrows, K, std=0.02):
         blk[..., 0:2] = _f16_bits(d)[..., None].view(np.uint8).reshape(nrows, nb, 2)
         blk[..., 2:] = rng.integers(0, 256, size=(nrows, nb, 32), dtype=np.uint8)
         return blk.reshape(nrows, nb * 34)
+    if ty == 2:                                              # Q4_0: value = (q - 8) * d, q in [0, 15]: std ~ 4.6 d
+        nb = K // 32
+        blk = np.empty((nrows, nb, 18), dtype=np.uint8)
+        d = (std / 4.6) * rng.uniform(0.5, 1.5, size=(nrows, nb)).astype(np.float32)
+        blk[..., 0:2] = _f16_bits(d)[..., None].view(np.uint8).reshape(nrows, nb, 2)
+        blk[..., 2:] = rng.integers(0, 256, size=(nrows, nb, 16), dtype=np.uint8)
+        return blk.reshape(nrows, nb * 18)
+    if ty == 13:                                             # Q5_K: value = d*sc*q - dmin*m, q in [0, 31]: E[sc*q] = 488, std ~ 420
+        nb = K // 256
+        blk = np.empty((nrows, nb, 176), dtype=np.uint8)
+        d = (std / 420.0) * rng.uniform(0.5, 1.5, size=(nrows, nb)).astype(np.float32)
+        blk[..., 0:2] = _f16_bits(d)[..., None].view(np.uint8).reshape(nrows, nb, 2)
+        blk[..., 2:4] = _f16_bits(d * 15.5)[..., None].view(np.uint8).reshape(nrows, nb, 2)
+        blk[..., 4:] = rng.integers(0, 256, size=(nrows, nb, 172), dtype=np.uint8)
+        return blk.reshape(nrows, nb * 176)
     raise ValueError(ty)
 
 

@@ -45,7 +45,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--config", choices=["8b", "tiny", "tts", "tts-tiny"], default="8b",
                     help="8b / tiny: qwen3 arch; tts / tts-tiny: the omni TTS decoder's shape (arch llama, RoPE NORM, no q/k-norm; SURVEY.md 8(f) rank 2)")
-    ap.add_argument("--types", choices=["q4_k_m", "f16", "q8_0"], default="q4_k_m")
+    ap.add_argument("--types", choices=["q4_k_m", "f16", "q8_0", "q4_0", "q5_k"], default="q4_k_m")
     ap.add_argument("-o", "--out", required=True)
     ap.add_argument("--seed", type=int, default=1234)
     ap.add_argument("--distinct-layers", action="store_true", help="fresh random bytes per layer (small configs)")
@@ -63,6 +63,10 @@ def main():
         types, embd_ty, ftype = qwen3.q4_k_m_types(cfg), GGML_TYPE_Q4_K, 15        # LLAMA_FTYPE_MOSTLY_Q4_K_M
     elif args.types == "f16":
         types, embd_ty, ftype = qwen3.uniform_types(cfg, GGML_TYPE_F16), GGML_TYPE_F16, 1
+    elif args.types == "q4_0":
+        types, embd_ty, ftype = qwen3.uniform_types(cfg, 2), 2, 2                   # GGML_TYPE_Q4_0, LLAMA_FTYPE_MOSTLY_Q4_0
+    elif args.types == "q5_k":
+        types, embd_ty, ftype = qwen3.uniform_types(cfg, 13), 13, 16                # GGML_TYPE_Q5_K, LLAMA_FTYPE_MOSTLY_Q5_K_S
     else:
         types, embd_ty, ftype = qwen3.uniform_types(cfg, GGML_TYPE_Q8_0), GGML_TYPE_Q8_0, 7
     E, H, HK, D, F, V, L = cfg["n_embd"], cfg["n_head"], cfg["n_head_kv"], cfg["head_dim"], cfg["n_ff"], cfg["n_vocab"], cfg["n_layer"]
