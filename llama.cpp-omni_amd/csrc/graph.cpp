@@ -36,12 +36,12 @@ enum act_kind { ACT_NONE = 0, ACT_Q8K, ACT_Q80, ACT_F16, ACT_F32 };
 // block formats without integer-dot kernels of their own: every MUL_MAT runs on the F16 image of the weights (resident for model
 // tensors, shadow.hpp; else de-quantised into scratch per call) with f16-rounded activations -- the arithmetic of the prefill GEMM
 static bool is_image_quant(int t) {
-    return t == GGML_TYPE_Q4_0 || t == GGML_TYPE_Q4_1 || t == GGML_TYPE_Q5_0 || t == GGML_TYPE_Q5_1 || t == GGML_TYPE_Q2_K || t == GGML_TYPE_Q3_K || t == GGML_TYPE_Q5_K;
+    return t == GGML_TYPE_Q4_0 || t == GGML_TYPE_Q4_1 || t == GGML_TYPE_Q5_0 || t == GGML_TYPE_Q5_1 || t == GGML_TYPE_Q2_K || t == GGML_TYPE_Q3_K;
 }
 static act_kind act_kind_for(int wtype) {
     if (is_image_quant(wtype)) return ACT_F16;
     switch (wtype) {
-        case GGML_TYPE_Q4_K: case GGML_TYPE_Q6_K: return ACT_Q8K;
+        case GGML_TYPE_Q4_K: case GGML_TYPE_Q5_K: case GGML_TYPE_Q6_K: return ACT_Q8K;
         case GGML_TYPE_Q8_0: return ACT_Q80;
         case GGML_TYPE_F16:  return ACT_F16;
         case GGML_TYPE_F32:  return ACT_F32;
@@ -126,7 +126,7 @@ bool supports_op(const ggml_tensor * op) {
             if (s0->ne[2] == 0 || s0->ne[3] == 0 || s1->ne[2] % s0->ne[2] != 0 || s1->ne[3] % s0->ne[3] != 0) return false;
             if (k == ACT_Q8K || k == ACT_Q80) {
                 // 16-B / 2-B vector paths assume block-aligned rows (always true for ggml-allocated tensors)
-                if (s0->nb[1] % (s0->type == GGML_TYPE_Q4_K ? 16 : 2) != 0) return false;
+                if (s0->nb[1] % ((s0->type == GGML_TYPE_Q4_K || s0->type == GGML_TYPE_Q5_K) ? 16 : 2) != 0) return false;
             }
             return true;
         }
@@ -233,7 +233,7 @@ static int64_t mmq_min_cols() {       // narrower batches stay on the dot4 mat-v
 }
 static bool mm_uses_mmq(const ggml_tensor * n) {
     const ggml_tensor * w = n->src[0], * x = n->src[1];
-    return (w->type == GGML_TYPE_Q4_K || w->type == GGML_TYPE_Q6_K) && x->type == GGML_TYPE_F32 && x->ne[1] >= mmq_min_cols() && x->ne[1] <= mmq_max_cols() &&
+    return (w->type == GGML_TYPE_Q4_K || w->type == GGML_TYPE_Q5_K || w->type == GGML_TYPE_Q6_K) && x->type == GGML_TYPE_F32 && x->ne[1] >= mmq_min_cols() && x->ne[1] <= mmq_max_cols() &&
            mmq_ok(w->type, w->ne[0], w->data, w->nb[1]) && (w->ne[2] == 1 || mmq_ok(w->type, w->ne[0], (const char *) w->data + w->nb[2], w->nb[1])) &&
            (w->ne[3] == 1 || mmq_ok(w->type, w->ne[0], (const char *) w->data + w->nb[3], w->nb[1]));
 }
@@ -242,7 +242,7 @@ static bool mm_uses_gemm(const ggml_tensor * n) {
     static const bool no_gemm = getenv("MI355X_NO_GEMM") != nullptr;
     if (x->ne[1] < GEMM_MIN_COLS || no_gemm) return false;
     if (mm_uses_mmq(n)) return false;
-    if (w->type != GGML_TYPE_F16 && w->type != GGML_TYPE_Q4_K && w->type != GGML_TYPE_Q6_K && w->type != GGML_TYPE_Q8_0 && !is_image_quant(w->type)) return false;
+    if (w->type != GGML_TYPE_F16 && w->type != GGML_TYPE_Q4_K && w->type != GGML_TYPE_Q5_K && w->type != GGML_TYPE_Q6_K && w->type != GGML_TYPE_Q8_0 && !is_image_quant(w->type)) return false;
     const int64_t K = w->ne[0];
     if (K % 32 != 0) return false;
     if (w->type == GGML_TYPE_F16 && (w->nb[1] % 16 != 0 || w->nb[2] % 16 != 0 || w->nb[3] % 16 != 0 || ((uintptr_t) w->data & 15) != 0)) return false;
@@ -493,6 +493,7 @@ static void op_mul_mat(exec_state & s, const ggml_tensor * dst) {
                 prof_scope ps(s, mmv_class(wv_type), wbytes);
                 switch (wv_type) {
                     case GGML_TYPE_Q4_K: mmv_q4_K(a, s.st); break;
+                    case GGML_TYPE_Q5_K: mmv_q5_K(a, s.st); break;
                     case GGML_TYPE_Q6_K: mmv_q6_K(a, s.st); break;
                     case GGML_TYPE_Q8_0: mmv_q8_0(a, s.st); break;
                     case GGML_TYPE_F16:  mmv_f16(a, s.st); break;
@@ -511,7 +512,7 @@ static void op_mul_mat(exec_state & s, const ggml_tensor * dst) {
 //   * every source of j is a leaf, was computed before i, or is produced inside the fused item, and
 //   * no node strictly between i and j (and outside the item) reads or writes memory overlapping j's output,
 //     nor writes memory overlapping j's inputs (ggml-alloc re-uses the storage of dead tensors).
-static bool is_kquant(int t) { return t == GGML_TYPE_Q4_K || t == GGML_TYPE_Q6_K; }
+static bool is_kquant(int t) { return t == GGML_TYPE_Q4_K || t == GGML_TYPE_Q5_K || t == GGML_TYPE_Q6_K; }   // the formats with integer-dot kernels on Q8_K activations
 
 static bool plain_kq_matvec(const ggml_tensor * n, int max_cols) {      // MUL_MAT(K-quant W [K,M], f32 x [K,N<=max]) with no broadcast
     if (n->op != GGML_OP_MUL_MAT || is_empty(n)) return false;

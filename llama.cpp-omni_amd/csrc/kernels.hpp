@@ -32,6 +32,7 @@ struct mmv_args {
 };
 void mmv_q4_K(const mmv_args & a, hipStream_t st);
 void mmv_q6_K(const mmv_args & a, hipStream_t st);
+void mmv_q5_K(const mmv_args & a, hipStream_t st);
 void mmv_q8_0(const mmv_args & a, hipStream_t st);
 void mmv_f16 (const mmv_args & a, hipStream_t st);   // act = f16 rows
 void mmv_f32 (const mmv_args & a, hipStream_t st);   // W f32, act = f32 rows

@@ -69,14 +69,19 @@ __global__ void __launch_bounds__(64 * KS) __attribute__((amdgpu_waves_per_eu(2)
 #pragma unroll
     for (int i = 0; i < NT * 4; ++i) out[i] = 0.0f;
 
-    if (M.type == GGML_TYPE_Q4_K) {
-        struct wblk { u32x4 hdr, qs[4]; };                             // one block of this lane's row (its half of the nibbles)
+    if (M.type == GGML_TYPE_Q4_K || M.type == GGML_TYPE_Q5_K) {
+        // Q5_K (176-byte blocks: d, dmin, scales[12], qh[32], qs[128]): the same sub-block structure, bit j of qh[l] is the fifth bit of
+        // sub-block j's weight l -- OR-ed into the unpacked nibbles, everything else as Q4_K
+        const bool q5 = M.type == GGML_TYPE_Q5_K;
+        const int bs = q5 ? 176 : 144, qoff = q5 ? 48 : 16;
+        struct wblk { u32x4 hdr, qs[4], qh; };                         // one block of this lane's row (its half of the nibbles)
         struct ablk { u32x4 av[8]; };                                  // the token's int8 of one block (this lane's 16 of every 32)
         auto fetch = [&](int b, wblk & G) {
-            const char * p = wrow + (size_t) b * 144;
+            const char * p = wrow + (size_t) b * bs;
             G.hdr = *(const u32x4 *) p;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) G.qs[q] = *(const u32x4 *) (p + 16 + q * 32 + 16 * hb);
+            for (int q = 0; q < 4; ++q) G.qs[q] = *(const u32x4 *) (p + qoff + q * 32 + 16 * hb);
+            if (q5) G.qh = *(const u32x4 *) (p + 16 + 16 * hb);
         };
         auto fetch_a = [&](int b, ablk & G) {
             const char * ab = arow + (size_t) b * 256;
@@ -103,7 +108,9 @@ __global__ void __launch_bounds__(64 * KS) __attribute__((amdgpu_waves_per_eu(2)
                 i32x4 wv, mv, aa;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    wv[e] = (int) ((wq[e] >> (4 * (j & 1))) & 0x0f0f0f0fu);
+                    uint32_t w5 = (wq[e] >> (4 * (j & 1))) & 0x0f0f0f0fu;
+                    if (q5) w5 |= ((G.qh[e] >> j) & 0x01010101u) << 4;
+                    wv[e] = (int) w5;
                     mv[e] = mn[j] * 0x01010101;
                     aa[e] = (int) av[e];
                 }
@@ -249,7 +256,7 @@ __global__ void __launch_bounds__(64 * KS) __attribute__((amdgpu_waves_per_eu(2)
 }
 
 bool mmq_ok(int type, int64_t K, const void * W, size_t w_rs) {
-    if (type == GGML_TYPE_Q4_K) return K % 256 == 0 && w_rs % 16 == 0 && ((uintptr_t) W & 15) == 0;
+    if (type == GGML_TYPE_Q4_K || type == GGML_TYPE_Q5_K) return K % 256 == 0 && w_rs % 16 == 0 && ((uintptr_t) W & 15) == 0;
     if (type == GGML_TYPE_Q6_K) return K % 256 == 0 && w_rs % 2 == 0 && ((uintptr_t) W & 1) == 0;
     return false;
 }

@@ -106,7 +106,10 @@ struct mmv_out {
 // ggml-quants.c:1352-1374).  A wave covers 8 super-blocks (1152 contiguous bytes) per step, U steps per stage.
 // PAIR: the two "rows" of a group are row r of W0 (gate) and row r of W1 (up); epilogue silu(g)*u.
 // =================================================================================================
-template <int NCOLS, int ROWS, int U, bool PAIR, bool NORM>
+// Q5: the block is a block_q5_K (ggml-common.h:313-323: d, dmin, scales[12], qh[32], qs[128] = 176 B) -- the same 6-bit scales / mins and
+// nibble layout as Q4_K plus one high bit per weight (bit 2j of qh[l] for sub-block 2j, bit 2j+1 for 2j+1: dequantize_row_q5_K,
+// ggml-quants.c:1554-1580; ggml_vec_dot_q5_K_q8_K, ggml-cpu/quants.c): the 5-bit values go through the same dot4 against the Q8_K bytes
+template <int NCOLS, int ROWS, int U, bool PAIR, bool NORM, bool Q5 = false>
 static __device__ __forceinline__ void q4k_body(const char * __restrict__ W0, const char * __restrict__ W1, size_t w_rs, const mmv_out o,
                                                 const char * __restrict__ act, size_t act_cs, int K, int nrows, int wave, int nwaves, const act_norm nr) {
     const int lane = threadIdx.x & 63;
@@ -116,7 +119,8 @@ static __device__ __forceinline__ void q4k_body(const char * __restrict__ W0, co
     const size_t img = q8k_image_bytes(K);
     const int ngrp = PAIR ? nrows : (nrows + ROWS - 1) / ROWS;
 
-    u32x4 hdr[U][ROWS], qs[U][ROWS];
+    constexpr int BS = Q5 ? 176 : 144, QOFF = Q5 ? 48 : 16;
+    u32x4 hdr[U][ROWS], qs[U][ROWS], qhb[Q5 ? U : 1][Q5 ? ROWS : 1];
     auto issue = [&](int grp, int it) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -124,9 +128,10 @@ static __device__ __forceinline__ void q4k_body(const char * __restrict__ W0, co
 #pragma unroll
             for (int r = 0; r < ROWS; ++r) {
                 int row = PAIR ? grp : grp * ROWS + r; row = row < nrows ? row : nrows - 1;
-                const char * bp = ((PAIR && r == 1) ? W1 : W0) + (size_t) row * w_rs + (size_t) ib * 144;
+                const char * bp = ((PAIR && r == 1) ? W1 : W0) + (size_t) row * w_rs + (size_t) ib * BS;
                 hdr[u][r] = ld_w((const u32x4 *) bp, MI_Q4K_NT);
-                qs[u][r]  = ld_w((const u32x4 *) (bp + 16 + lp * 16), MI_Q4K_NT);
+                qs[u][r]  = ld_w((const u32x4 *) (bp + QOFF + lp * 16), MI_Q4K_NT);
+                if (Q5) qhb[u][r] = ld_w((const u32x4 *) (bp + 16 + (lp & 1) * 16), MI_Q4K_NT);      // qh[16h .. 16h+15]
             }
         }
     };
@@ -147,11 +152,11 @@ static __device__ __forceinline__ void q4k_body(const char * __restrict__ W0, co
 
     const int sh = (j & 1) * 16;
     while (true) {
-        u32x4 chdr[U][ROWS], cqs[U][ROWS];
+        u32x4 chdr[U][ROWS], cqs[U][ROWS], cqh[Q5 ? U : 1][Q5 ? ROWS : 1];
 #pragma unroll
         for (int u = 0; u < U; ++u)
 #pragma unroll
-            for (int r = 0; r < ROWS; ++r) { chdr[u][r] = hdr[u][r]; cqs[u][r] = qs[u][r]; }
+            for (int r = 0; r < ROWS; ++r) { chdr[u][r] = hdr[u][r]; cqs[u][r] = qs[u][r]; if (Q5) cqh[u][r] = qhb[u][r]; }
         const int cgrp = grp, cit = it;
         ++it;
         if (it == nit) { it = 0; grp += nwaves; }
@@ -190,7 +195,10 @@ static __device__ __forceinline__ void q4k_body(const char * __restrict__ W0, co
                 const float dmin = h2f((uint16_t) (chdr[u][r][0] >> 16));
                 uint32_t lo[4], hi[4];
 #pragma unroll
-                for (int k = 0; k < 4; ++k) { lo[k] = cqs[u][r][k] & 0x0f0f0f0fu; hi[k] = (cqs[u][r][k] >> 4) & 0x0f0f0f0fu; }
+                for (int k = 0; k < 4; ++k) {
+                    lo[k] = cqs[u][r][k] & 0x0f0f0f0fu; hi[k] = (cqs[u][r][k] >> 4) & 0x0f0f0f0fu;
+                    if (Q5) { lo[k] |= ((cqh[u][r][k] >> (2 * j)) & 0x01010101u) << 4; hi[k] |= ((cqh[u][r][k] >> (2 * j + 1)) & 0x01010101u) << 4; }
+                }
                 const bool rv = valid && (PAIR ? cgrp : cgrp * ROWS + r) < nrows;
 #pragma unroll
                 for (int c = 0; c < NCOLS; ++c) {
@@ -410,7 +418,7 @@ static __device__ __forceinline__ void q6k_body(const char * __restrict__ W0, co
 struct mmv_mat_dev { const char * W; size_t w_rs; mmv_out o; int nrows; int type; int wave_end; };   // waves [prev.wave_end, wave_end) work on this matrix
 struct mmv_multi_dev { mmv_mat_dev m[3]; int nmat; const char * act; size_t act_cs; int K; act_norm nr; };
 
-// TM: bit0 = Q4_K bodies compiled in, bit1 = Q6_K bodies compiled in
+// TM: bit0 = Q4_K bodies compiled in, bit1 = Q6_K, bit2 = Q5_K
 template <int NCOLS, int ROWS, int U, int TM, bool NORM>
 __global__ void __launch_bounds__(256) k_mmv_multi(const mmv_multi_dev a) {
     // (each body stages the activation image itself, after issuing its first weight loads; every wave of the workgroup
@@ -424,8 +432,10 @@ __global__ void __launch_bounds__(256) k_mmv_multi(const mmv_multi_dev a) {
     const int lw = wave - w0, nw = M.wave_end - w0;
     if (TM == 1)      q4k_body<NCOLS, ROWS, U, false, NORM>(M.W, nullptr, M.w_rs, M.o, a.act, a.act_cs, a.K, M.nrows, lw, nw, a.nr);
     else if (TM == 2) q6k_body<NCOLS, ROWS, U, false, NORM>(M.W, nullptr, M.w_rs, M.o, a.act, a.act_cs, a.K, M.nrows, lw, nw, a.nr);
-    else if (M.type == GGML_TYPE_Q4_K) q4k_body<NCOLS, ROWS, U, false, NORM>(M.W, nullptr, M.w_rs, M.o, a.act, a.act_cs, a.K, M.nrows, lw, nw, a.nr);
-    else                               q6k_body<NCOLS, ROWS, U, false, NORM>(M.W, nullptr, M.w_rs, M.o, a.act, a.act_cs, a.K, M.nrows, lw, nw, a.nr);
+    else if (TM == 4) q4k_body<NCOLS, ROWS, U, false, NORM, true>(M.W, nullptr, M.w_rs, M.o, a.act, a.act_cs, a.K, M.nrows, lw, nw, a.nr);
+    else if ((TM & 1) && M.type == GGML_TYPE_Q4_K) q4k_body<NCOLS, ROWS, U, false, NORM>(M.W, nullptr, M.w_rs, M.o, a.act, a.act_cs, a.K, M.nrows, lw, nw, a.nr);
+    else if ((TM & 4) && M.type == GGML_TYPE_Q5_K) q4k_body<NCOLS, ROWS, U, false, NORM, true>(M.W, nullptr, M.w_rs, M.o, a.act, a.act_cs, a.K, M.nrows, lw, nw, a.nr);
+    else                                           q6k_body<NCOLS, ROWS, U, false, NORM>(M.W, nullptr, M.w_rs, M.o, a.act, a.act_cs, a.K, M.nrows, lw, nw, a.nr);
 }
 
 template <int NCOLS, int U, int TYPE, bool NORM>
@@ -433,8 +443,9 @@ __global__ void __launch_bounds__(256) k_mmv_pair(const char * __restrict__ Wg, 
                                                  char * __restrict__ dst, size_t dst_cs, int K, int nrows, const act_norm nr) {
     const int wave = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
     const mmv_out o = { dst, dst_cs, nullptr, 0 };
-    if (TYPE == GGML_TYPE_Q4_K) q4k_body<NCOLS, 2, U, true, NORM>(Wg, Wu, w_rs, o, act, act_cs, K, nrows, wave, nwaves, nr);
-    else                        q6k_body<NCOLS, 2, U, true, NORM>(Wg, Wu, w_rs, o, act, act_cs, K, nrows, wave, nwaves, nr);
+    if (TYPE == GGML_TYPE_Q4_K)      q4k_body<NCOLS, 2, U, true, NORM>(Wg, Wu, w_rs, o, act, act_cs, K, nrows, wave, nwaves, nr);
+    else if (TYPE == GGML_TYPE_Q5_K) q4k_body<NCOLS, 2, U, true, NORM, true>(Wg, Wu, w_rs, o, act, act_cs, K, nrows, wave, nwaves, nr);
+    else                             q6k_body<NCOLS, 2, U, true, NORM>(Wg, Wu, w_rs, o, act, act_cs, K, nrows, wave, nwaves, nr);
 }
 
 // ------------------------------------------------------------------------------------------------ launch
@@ -456,7 +467,8 @@ static void launch_multi_tm(const mmv_multi_dev & d, int tm, int grid, size_t ld
         if (lds > 64 * 1024) HIP_CHECK(hipFuncSetAttribute((const void *) kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
         kern<<<dim3(grid), dim3(256), lds, st>>>(d);
     };
-    if (tm == 1) go(k_mmv_multi<NCOLS, ROWS, U, 1, NORM>); else if (tm == 2) go(k_mmv_multi<NCOLS, ROWS, U, 2, NORM>); else go(k_mmv_multi<NCOLS, ROWS, U, 3, NORM>);
+    if (tm == 1) go(k_mmv_multi<NCOLS, ROWS, U, 1, NORM>); else if (tm == 2) go(k_mmv_multi<NCOLS, ROWS, U, 2, NORM>); else if (tm == 3) go(k_mmv_multi<NCOLS, ROWS, U, 3, NORM>);
+    else if (tm == 4) go(k_mmv_multi<NCOLS, ROWS, U, 4, NORM>); else if (tm == 6) go(k_mmv_multi<NCOLS, ROWS, U, 6, NORM>); else go(k_mmv_multi<NCOLS, ROWS, U, 7, NORM>);
 }
 
 void mmv_kquant_multi(const mmv_multi_args & a, hipStream_t st) {
@@ -469,10 +481,10 @@ void mmv_kquant_multi(const mmv_multi_args & a, hipStream_t st) {
     double bytes[3]; double total = 0; int64_t groups = 0;
     int tm = 0;
     for (int i = 0; i < a.nmat; ++i) {
-        bytes[i] = (double) a.m[i].nrows * (double) (a.m[i].type == GGML_TYPE_Q4_K ? 144 : 210) * (double) (a.K / 256);
+        bytes[i] = (double) a.m[i].nrows * (double) (a.m[i].type == GGML_TYPE_Q4_K ? 144 : a.m[i].type == GGML_TYPE_Q5_K ? 176 : 210) * (double) (a.K / 256);
         total += bytes[i];
         groups += (a.m[i].nrows + rows_pw - 1) / rows_pw;
-        tm |= a.m[i].type == GGML_TYPE_Q4_K ? 1 : 2;
+        tm |= a.m[i].type == GGML_TYPE_Q4_K ? 1 : a.m[i].type == GGML_TYPE_Q5_K ? 4 : 2;
     }
     int64_t grid = (groups + 3) / 4;
     const int cap = a.norm.x ? (mmv_grid_cap() < 1024 ? mmv_grid_cap() : 1024) : mmv_grid_cap();   // in-kernel norm: fewer, longer workgroups
@@ -529,6 +541,8 @@ void mmv_kquant_pair_swiglu(int type, const void * Wg, const void * Wu, size_t w
 #define MP_GO2(NC, UU, NRM)                                                                                            \
     do {                                                                                                               \
         if (type == GGML_TYPE_Q4_K) k_mmv_pair<NC, UU, GGML_TYPE_Q4_K, NRM><<<dim3((unsigned) grid), dim3(256), lds, st>>>(  \
+            (const char *) Wg, (const char *) Wu, w_rs, (const char *) act, act_cs, (char *) dst, dst_cs, (int) K, (int) nrows, nr);  \
+        else if (type == GGML_TYPE_Q5_K) k_mmv_pair<NC, UU, GGML_TYPE_Q5_K, NRM><<<dim3((unsigned) grid), dim3(256), lds, st>>>(  \
             (const char *) Wg, (const char *) Wu, w_rs, (const char *) act, act_cs, (char *) dst, dst_cs, (int) K, (int) nrows, nr);  \
         else k_mmv_pair<NC, UU, GGML_TYPE_Q6_K, NRM><<<dim3((unsigned) grid), dim3(256), lds, st>>>(                    \
             (const char *) Wg, (const char *) Wu, w_rs, (const char *) act, act_cs, (char *) dst, dst_cs, (int) K, (int) nrows, nr);  \

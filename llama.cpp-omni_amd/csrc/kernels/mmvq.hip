@@ -238,6 +238,7 @@ static void mmv_kquant_single(int type, const mmv_args & a0, hipStream_t st) {
 }
 void mmv_q4_K(const mmv_args & a, hipStream_t st) { mmv_kquant_single(GGML_TYPE_Q4_K, a, st); }
 void mmv_q6_K(const mmv_args & a, hipStream_t st) { mmv_kquant_single(GGML_TYPE_Q6_K, a, st); }
+void mmv_q5_K(const mmv_args & a, hipStream_t st) { mmv_kquant_single(GGML_TYPE_Q5_K, a, st); }
 
 void mmv_q8_0(const mmv_args & a0, hipStream_t st) {
     if (a0.nrows == 0 || a0.ncols == 0) return;

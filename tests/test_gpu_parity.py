@@ -557,12 +557,13 @@ def test_encoder_block_vs_reference_backend(pkg, be, ref_be):
 
 # (type id, block bytes, offsets of the fp16 fields inside a block) of the block formats served through their F16 image
 IMAGE_QUANTS = {"q4_0": (2, 18, (0,)), "q4_1": (3, 20, (0, 2)), "q5_0": (6, 22, (0,)), "q5_1": (7, 24, (0, 2)),
-                "q2_K": (10, 84, (80, 82)), "q3_K": (11, 110, (108,)), "q5_K": (13, 176, (0, 2))}
+                "q2_K": (10, 84, (80, 82)), "q3_K": (11, 110, (108,))}
+Q5_K_DESC = (13, 176, (0, 2))
 
 
 def _random_image_quant_rows(rng, name, M, K):
     """valid random blocks: every quant / scale byte uniform, the fp16 super-scales small positive numbers"""
-    _, bs, hoffs = IMAGE_QUANTS[name]
+    _, bs, hoffs = Q5_K_DESC if name == "q5_K" else IMAGE_QUANTS[name]
     nb = K // (32 if bs < 30 else 256)
     raw = rng.integers(0, 256, (M, nb, bs), dtype=np.uint8)
     for o in hoffs:
@@ -573,7 +574,7 @@ def _random_image_quant_rows(rng, name, M, K):
 @pytest.mark.parametrize("name", sorted(IMAGE_QUANTS))
 @pytest.mark.parametrize("M,K,N", [(48, 512, 1), (130, 1024, 5), (96, 768, 24)])
 def test_mul_mat_image_quants_vs_reference_backend(pkg, be, ref_be, name, M, K, N):
-    """Q4_0 / Q4_1 / Q5_0 / Q5_1 / Q2_K / Q3_K / Q5_K weights: MUL_MAT on the F16 image of the de-quantised blocks (mat-vec and GEMM
+    """Q4_0 / Q4_1 / Q5_0 / Q5_1 / Q2_K / Q3_K weights: MUL_MAT on the F16 image of the de-quantised blocks (mat-vec and GEMM
     widths) and GET_ROWS, against the reference CPU backend; bar = the reference's MUL_MAT NMSE 5e-4, GET_ROWS bit-exact."""
     rng = np.random.default_rng(M + K + N)
     ty = IMAGE_QUANTS[name][0]
@@ -597,6 +598,28 @@ def test_mul_mat_image_quants_vs_reference_backend(pkg, be, ref_be, name, M, K, 
     assert np.isfinite(outs[0][0]).all()
     assert nmse(outs[0][0], outs[1][0]) < 5e-4, name
     assert np.array_equal(outs[0][1], outs[1][1]), name
+
+
+@pytest.mark.parametrize("M,K,N", [(48, 512, 1), (130, 1024, 5), (257, 768, 8), (96, 768, 6), (4096, 4096, 1), (64, 2304, 24), (1000, 1024, 40)])
+def test_mul_mat_q5_K_vs_reference_backend(pkg, be, ref_be, M, K, N):
+    """Q5_K weights take the Q4_K kernels with the fifth bit OR-ed in (dot4 mat-vec up to 5 columns, int8 MFMA from 6): the integer sums
+    of ggml_vec_dot_q5_K_q8_K on the same Q8_K activations -- f32 re-association only against the reference CPU backend"""
+    rng = np.random.default_rng(M + K + N)
+    wv = _random_image_quant_rows(rng, "q5_K", M, K)
+    xv = (rng.standard_normal((N, K)) * rng.choice([0.1, 1.0, 10.0])).astype(np.float32)
+    outs = []
+    for backend in (be, ref_be):
+        c = pkg.Context(backend)
+        w = c.new_tensor(13, K, M)
+        x = c.new_tensor(pkg.GGML_TYPE_F32, K, N)
+        y = c.mul_mat(w, x)
+        c.alloc()
+        backend.tensor_set(w, wv); backend.tensor_set(x, xv)
+        backend.graph_compute(c.graph())
+        outs.append(backend.tensor_get(y).copy())
+        c.free()
+    assert np.isfinite(outs[0]).all()
+    assert nmse(outs[0], outs[1]) < 1e-9
 
 
 @pytest.mark.parametrize("case", ["2d_avg", "2d_max_pad", "2d_f16", "1d_avg5", "1d_max2"])

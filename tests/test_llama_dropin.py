@@ -27,7 +27,7 @@ def _greedy(gguf, ngl, fa, dump, env_extra=None):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("config,types,fa", [("tiny", "q4_k_m", 1), ("tiny", "q4_k_m", 0),
+@pytest.mark.parametrize("config,types,fa", [("tiny", "q4_k_m", 1), ("tiny", "q4_k_m", 0), ("tiny", "q5_k", 1),
                                              # the omni TTS decoder's family: arch llama (RoPE NORM, no q/k-norm), Q8_0 / F16 weights
                                              ("tts-tiny", "q8_0", 1), ("tts-tiny", "f16", 1), ("tts-tiny", "q8_0", 0)])
 def test_reference_libllama_drives_the_plugin(tmp_path, config, types, fa):
@@ -45,9 +45,9 @@ def test_reference_libllama_drives_the_plugin(tmp_path, config, types, fa):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("types", ["q4_0", "q5_k"])
+@pytest.mark.parametrize("types", ["q4_0"])
 def test_image_quant_models_stay_on_the_gpu(tmp_path, types):
-    """Q4_0 / Q5_K models (no integer-dot kernels here: MUL_MAT on the resident F16 image of the blocks, GET_ROWS de-quantising): every
+    """Q4_0 models (no integer-dot kernels here: MUL_MAT on the resident F16 image of the blocks, GET_ROWS de-quantising): every
     layer offloaded, logits inside the reference's bar against the CPU backend's integer arithmetic; greedy ids may flip on a near-tie
     of this random-weight toy model (f16-rounded activations vs Q8 activations), so 90 % agreement is asked for"""
     if not os.path.exists(BIN):
