@@ -36,13 +36,15 @@ enum act_kind { ACT_NONE = 0, ACT_Q8K, ACT_Q80, ACT_F16, ACT_F32 };
 // block formats without integer-dot kernels of their own: every MUL_MAT runs on the F16 image of the weights (resident for model
 // tensors, shadow.hpp; else de-quantised into scratch per call) with f16-rounded activations -- the arithmetic of the prefill GEMM
 static bool is_image_quant(int t) {
-    return t == GGML_TYPE_Q4_0 || t == GGML_TYPE_Q4_1 || t == GGML_TYPE_Q5_0 || t == GGML_TYPE_Q5_1 || t == GGML_TYPE_Q2_K || t == GGML_TYPE_Q3_K;
+    return t == GGML_TYPE_Q4_1 || t == GGML_TYPE_Q5_1 || t == GGML_TYPE_Q2_K || t == GGML_TYPE_Q3_K;
 }
+// Q4_0 / Q5_0: integer mat-vec kernels on Q8_0 activations up to 8 columns (mmvq.hip), the F16 image from 9 columns on
+static bool is_q40_like(int t) { return t == GGML_TYPE_Q4_0 || t == GGML_TYPE_Q5_0; }
 static act_kind act_kind_for(int wtype) {
     if (is_image_quant(wtype)) return ACT_F16;
     switch (wtype) {
         case GGML_TYPE_Q4_K: case GGML_TYPE_Q5_K: case GGML_TYPE_Q6_K: return ACT_Q8K;
-        case GGML_TYPE_Q8_0: return ACT_Q80;
+        case GGML_TYPE_Q8_0: case GGML_TYPE_Q4_0: case GGML_TYPE_Q5_0: return ACT_Q80;
         case GGML_TYPE_F16:  return ACT_F16;
         case GGML_TYPE_F32:  return ACT_F32;
         default: return ACT_NONE;
@@ -242,7 +244,7 @@ static bool mm_uses_gemm(const ggml_tensor * n) {
     static const bool no_gemm = getenv("MI355X_NO_GEMM") != nullptr;
     if (x->ne[1] < GEMM_MIN_COLS || no_gemm) return false;
     if (mm_uses_mmq(n)) return false;
-    if (w->type != GGML_TYPE_F16 && w->type != GGML_TYPE_Q4_K && w->type != GGML_TYPE_Q5_K && w->type != GGML_TYPE_Q6_K && w->type != GGML_TYPE_Q8_0 && !is_image_quant(w->type)) return false;
+    if (w->type != GGML_TYPE_F16 && w->type != GGML_TYPE_Q4_K && w->type != GGML_TYPE_Q5_K && w->type != GGML_TYPE_Q6_K && w->type != GGML_TYPE_Q8_0 && !is_image_quant(w->type) && !is_q40_like(w->type)) return false;
     const int64_t K = w->ne[0];
     if (K % 32 != 0) return false;
     if (w->type == GGML_TYPE_F16 && (w->nb[1] % 16 != 0 || w->nb[2] % 16 != 0 || w->nb[3] % 16 != 0 || ((uintptr_t) w->data & 15) != 0)) return false;
@@ -496,6 +498,8 @@ static void op_mul_mat(exec_state & s, const ggml_tensor * dst) {
                     case GGML_TYPE_Q5_K: mmv_q5_K(a, s.st); break;
                     case GGML_TYPE_Q6_K: mmv_q6_K(a, s.st); break;
                     case GGML_TYPE_Q8_0: mmv_q8_0(a, s.st); break;
+                    case GGML_TYPE_Q4_0: mmv_q4_0(a, s.st); break;
+                    case GGML_TYPE_Q5_0: mmv_q5_0(a, s.st); break;
                     case GGML_TYPE_F16:  mmv_f16(a, s.st); break;
                     default:             mmv_f32(a, s.st); break;
                 }

@@ -34,6 +34,8 @@ void mmv_q4_K(const mmv_args & a, hipStream_t st);
 void mmv_q6_K(const mmv_args & a, hipStream_t st);
 void mmv_q5_K(const mmv_args & a, hipStream_t st);
 void mmv_q8_0(const mmv_args & a, hipStream_t st);
+void mmv_q4_0(const mmv_args & a, hipStream_t st);   // Q4_0 / Q5_0 weights x Q8_0 activation images (the reference's vec_dot_q4_0_q8_0 / _q5_0_q8_0 integers)
+void mmv_q5_0(const mmv_args & a, hipStream_t st);
 void mmv_f16 (const mmv_args & a, hipStream_t st);   // act = f16 rows
 void mmv_f32 (const mmv_args & a, hipStream_t st);   // W f32, act = f32 rows
 

@@ -98,6 +98,84 @@ __global__ void __launch_bounds__(256) k_mmv_q80(const char * __restrict__ W, si
 }
 
 // =================================================================================================
+// Q4_0 / Q5_0 weights x Q8_0 activations.  reference: ggml_vec_dot_q4_0_q8_0 / _q5_0_q8_0 (ggml-cpu/quants.c:115-149, 219-262):
+//   sumi = sum_j ((x.qs[j] & 0xF) [| fifth bit] - OFF) * y.qs[j] + ((x.qs[j] >> 4) [| fifth bit] - OFF) * y.qs[j + 16],  OFF = 8 / 16
+//   sumf += sumi * d_x * d_y
+// Four lanes per 32-weight block (4 bytes of nibbles = weights 4l..4l+3 and 16+4l..19+4l each), 16 blocks per wave step; the offset is
+// taken out of the dot products (sum q*y - OFF * sum y), all in exact integers.
+// =================================================================================================
+template <int NCOLS, int ROWS, bool Q5>
+__global__ void __launch_bounds__(256) k_mmv_q40(const char * __restrict__ W, size_t w_rs, const char * __restrict__ act, size_t act_cs,
+                                                char * __restrict__ dst, size_t dst_cs, int K, int nrows) {
+    typedef uint32_t __attribute__((aligned(2))) u32a2;
+    constexpr int BS = Q5 ? 22 : 18, QOFF = Q5 ? 6 : 2, OFF = Q5 ? 16 : 8;
+    const int lane = threadIdx.x & 63;
+    const int g = lane >> 2, lp = lane & 3;
+    const int nb  = K >> 5;
+    const int nit = (nb + 15) >> 4;
+    const size_t img = q80_image_bytes(K);
+    const int wave   = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int nwaves = gridDim.x * 4;
+    const int ngrp   = (nrows + ROWS - 1) / ROWS;
+
+    stage_act(act, act_cs, NCOLS, img);
+    __syncthreads();
+
+    for (int grp = wave; grp < ngrp; grp += nwaves) {
+        float acc[ROWS][NCOLS];
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r)
+#pragma unroll
+            for (int c = 0; c < NCOLS; ++c) acc[r][c] = 0.0f;
+#pragma unroll 4
+        for (int it = 0; it < nit; ++it) {
+            const int  ib    = it * 16 + g;
+            const bool valid = ib < nb;
+            const int  ibc   = valid ? ib : nb - 1;
+            uint32_t lo[ROWS], hi[ROWS]; float dx[ROWS];
+#pragma unroll
+            for (int r = 0; r < ROWS; ++r) {
+                int row = grp * ROWS + r; row = row < nrows ? row : nrows - 1;
+                const char * bp = W + (size_t) row * w_rs + (size_t) ibc * BS;
+                dx[r] = h2f(*(const uint16_t *) bp);
+                const uint32_t q = *(const u32a2 *) (bp + QOFF + 4 * lp);
+                lo[r] = q & 0x0f0f0f0fu; hi[r] = (q >> 4) & 0x0f0f0f0fu;
+                if (Q5) {
+                    const uint32_t qh = *(const u32a2 *) (bp + 2);
+                    const uint32_t bl = (qh >> (4 * lp)) & 0xfu, bh = (qh >> (16 + 4 * lp)) & 0xfu;
+                    lo[r] |= ((bl & 1u) | ((bl & 2u) << 7) | ((bl & 4u) << 14) | ((bl & 8u) << 21)) << 4;
+                    hi[r] |= ((bh & 1u) | ((bh & 2u) << 7) | ((bh & 4u) << 14) | ((bh & 8u) << 21)) << 4;
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < NCOLS; ++c) {
+                const char * im = mmv_lds + c * img;
+                const uint32_t a0 = *(const uint32_t *) (im + ibc * 32 + 4 * lp);
+                const uint32_t a1 = *(const uint32_t *) (im + ibc * 32 + 16 + 4 * lp);
+                const float    yd = *(const float *) (im + K + ibc * 4);
+                const int ysum = dot4(0x01010101u, a0, dot4(0x01010101u, a1, 0));
+#pragma unroll
+                for (int r = 0; r < ROWS; ++r) {
+                    const bool rv = valid && (grp * ROWS + r) < nrows;
+                    const int isum = dot4(lo[r], a0, dot4(hi[r], a1, 0)) - OFF * ysum;
+                    const float t = (float) isum * (dx[r] * yd);
+                    acc[r][c] += rv ? t : 0.0f;
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) {
+            const int row = grp * ROWS + r;
+#pragma unroll
+            for (int c = 0; c < NCOLS; ++c) {
+                const float s = wave_sum(acc[r][c]);
+                if (lane == 0 && row < nrows) *(float *) (dst + c * dst_cs + (size_t) row * 4) = s;
+            }
+        }
+    }
+}
+
+// =================================================================================================
 // F16 / F32 weights: each lane consumes 16 B (8 halfs / 4 floats) per step; activations (f16 rows for F16
 // weights, as the reference rounds src1 to the F16 vec_dot_type; f32 rows for F32 weights) live in LDS.
 // =================================================================================================
@@ -259,6 +337,29 @@ void mmv_q8_0(const mmv_args & a0, hipStream_t st) {
         launch_mmv(k, rows, ib * a.ncols, a, st);
     });
 }
+
+template <bool Q5>
+static void mmv_q40_t(const mmv_args & a0, hipStream_t st) {
+    if (a0.nrows == 0 || a0.ncols == 0) return;
+    const size_t ib = q80_image_bytes(a0.K);
+    split_cols(a0, ib, [&](const mmv_args & a) {
+        mmv_kernel_t k = nullptr; int rows = 2;
+        switch (a.ncols) {
+            case 1: k = k_mmv_q40<1, 2, Q5>; break;
+            case 2: k = k_mmv_q40<2, 2, Q5>; break;
+            case 3: k = k_mmv_q40<3, 2, Q5>; break;
+            case 4: k = k_mmv_q40<4, 2, Q5>; break;
+            case 5: k = k_mmv_q40<5, 1, Q5>; rows = 1; break;
+            case 6: k = k_mmv_q40<6, 1, Q5>; rows = 1; break;
+            case 7: k = k_mmv_q40<7, 1, Q5>; rows = 1; break;
+            case 8: k = k_mmv_q40<8, 1, Q5>; rows = 1; break;
+            default: abort();
+        }
+        launch_mmv(k, rows, ib * a.ncols, a, st);
+    });
+}
+void mmv_q4_0(const mmv_args & a, hipStream_t st) { mmv_q40_t<false>(a, st); }
+void mmv_q5_0(const mmv_args & a, hipStream_t st) { mmv_q40_t<true>(a, st); }
 
 #define MMVF_LAUNCH(NC, ROWS, WF16)                                                                                    \
     do {                                                                                                               \

@@ -600,6 +600,29 @@ def test_mul_mat_image_quants_vs_reference_backend(pkg, be, ref_be, name, M, K, 
     assert np.array_equal(outs[0][1], outs[1][1]), name
 
 
+@pytest.mark.parametrize("name", ["q4_0", "q5_0"])
+@pytest.mark.parametrize("M,K,N", [(48, 512, 1), (130, 1024, 5), (257, 96, 8), (33, 4096, 3), (4096, 4096, 1)])
+def test_mul_mat_q4_0_q5_0_integer_path(pkg, be, ref_be, name, M, K, N):
+    """Q4_0 / Q5_0 weights up to 8 columns: integer mat-vec on Q8_0 activation images (k_mmv_q40) -- the integers of
+    ggml_vec_dot_q4_0_q8_0 / _q5_0_q8_0, f32 re-association only against the reference CPU backend"""
+    rng = np.random.default_rng(M + K + N)
+    wv = _random_image_quant_rows(rng, name, M, K)
+    xv = (rng.standard_normal((N, K)) * rng.choice([0.1, 1.0, 10.0])).astype(np.float32)
+    outs = []
+    for backend in (be, ref_be):
+        c = pkg.Context(backend)
+        w = c.new_tensor(IMAGE_QUANTS[name][0], K, M)
+        x = c.new_tensor(pkg.GGML_TYPE_F32, K, N)
+        y = c.mul_mat(w, x)
+        c.alloc()
+        backend.tensor_set(w, wv); backend.tensor_set(x, xv)
+        backend.graph_compute(c.graph())
+        outs.append(backend.tensor_get(y).copy())
+        c.free()
+    assert np.isfinite(outs[0]).all()
+    assert nmse(outs[0], outs[1]) < 1e-8, name
+
+
 @pytest.mark.parametrize("M,K,N", [(48, 512, 1), (130, 1024, 5), (257, 768, 8), (96, 768, 6), (4096, 4096, 1), (64, 2304, 24), (1000, 1024, 40)])
 def test_mul_mat_q5_K_vs_reference_backend(pkg, be, ref_be, M, K, N):
     """Q5_K weights take the Q4_K kernels with the fifth bit OR-ed in (dot4 mat-vec up to 5 columns, int8 MFMA from 6): the integer sums
