@@ -15,7 +15,7 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from bench import load_pkg  # noqa: E402
 
-TYPES = {"q4_K": 12, "q6_K": 14, "q8_0": 8, "f16": 1}
+TYPES = {"q4_K": 12, "q6_K": 14, "q8_0": 8, "f16": 1, "q4_0": 2, "q5_K": 13}
 
 
 def main():
