@@ -653,33 +653,52 @@ template <> __device__ __forceinline__ float    cvt_elem<uint16_t, float>(uint16
 template <> __device__ __forceinline__ uint16_t cvt_elem<uint16_t, uint16_t>(uint16_t v) { return v; }
 template <> __device__ __forceinline__ int32_t  cvt_elem<int32_t, int32_t>(int32_t v)    { return v; }
 
-template <typename TS, typename TD>
+// IX: index type of the element counter -- 32-bit whenever the tensor has fewer than 2^31 elements (a 64-bit div/mod is a ~100-instruction
+// sequence and there are eight per element: the KQ-mask cast of every libllama decode graph took 63 us with them, 2.4 % of the step)
+template <typename TS, typename TD, typename IX>
 __global__ void __launch_bounds__(256) k_cpy(td4 s, td4 d) {
-    const int64_t total = s.ne[0] * s.ne[1] * s.ne[2] * s.ne[3];
-    for (int64_t t = (int64_t) blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t) gridDim.x * blockDim.x) {
-        int64_t r = t;
-        const int64_t s0 = r % s.ne[0]; r /= s.ne[0];
-        const int64_t s1 = r % s.ne[1]; r /= s.ne[1];
-        const int64_t s2 = r % s.ne[2]; const int64_t s3 = r / s.ne[2];
+    const IX total = (IX) (s.ne[0] * s.ne[1] * s.ne[2] * s.ne[3]);
+    const IX sn0 = (IX) s.ne[0], sn1 = (IX) s.ne[1], sn2 = (IX) s.ne[2], dn0 = (IX) d.ne[0], dn1 = (IX) d.ne[1], dn2 = (IX) d.ne[2];
+    for (IX t = (IX) blockIdx.x * (IX) blockDim.x + (IX) threadIdx.x; t < total; t += (IX) gridDim.x * (IX) blockDim.x) {
+        IX r = t;
+        const int64_t s0 = r % sn0; r /= sn0;
+        const int64_t s1 = r % sn1; r /= sn1;
+        const int64_t s2 = r % sn2; const int64_t s3 = r / sn2;
         r = t;
-        const int64_t d0 = r % d.ne[0]; r /= d.ne[0];
-        const int64_t d1 = r % d.ne[1]; r /= d.ne[1];
-        const int64_t d2 = r % d.ne[2]; const int64_t d3 = r / d.ne[2];
+        const int64_t d0 = r % dn0; r /= dn0;
+        const int64_t d1 = r % dn1; r /= dn1;
+        const int64_t d2 = r % dn2; const int64_t d3 = r / dn2;
         const TS v = *(const TS *) (s.p + s0 * s.nb[0] + s1 * s.nb[1] + s2 * s.nb[2] + s3 * s.nb[3]);
         *(TD *) (d.p + d0 * d.nb[0] + d1 * d.nb[1] + d2 * d.nb[2] + d3 * d.nb[3]) = cvt_elem<TS, TD>(v);
     }
 }
+// both sides dense in the same element order: a linear convert (the f32 -> f16 KQ-mask cast, CONT of dense tensors)
+template <typename TS, typename TD>
+__global__ void __launch_bounds__(256) k_cpy_lin(const TS * __restrict__ s, TD * __restrict__ d, int64_t total) {
+    for (int64_t t = (int64_t) blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t) gridDim.x * 256) d[t] = cvt_elem<TS, TD>(s[t]);
+}
+static bool dense_rowmajor(const tdesc & t, size_t es) {
+    size_t nb = es;
+    for (int i = 0; i < 4; ++i) { if (t.ne[i] != 1 && t.nb[i] != nb) return false; nb *= (size_t) t.ne[i]; }
+    return true;
+}
+template <typename TS, typename TD>
+static void cpy_go(const tdesc & src, const tdesc & dst, int64_t total, hipStream_t st) {
+    int64_t g = (total + 255) / 256; if (g > 16384) g = 16384;
+    const dim3 grid((unsigned) g), blk(256);
+    if (dense_rowmajor(src, sizeof(TS)) && dense_rowmajor(dst, sizeof(TD))) { k_cpy_lin<TS, TD><<<grid, blk, 0, st>>>((const TS *) src.p, (TD *) dst.p, total); return; }
+    const td4 s = to_td4(src), d = to_td4(dst);
+    if (total < ((int64_t) 1 << 31)) k_cpy<TS, TD, uint32_t><<<grid, blk, 0, st>>>(s, d);
+    else                             k_cpy<TS, TD, int64_t><<<grid, blk, 0, st>>>(s, d);
+}
 void cpy_strided(const tdesc & src, int src_type, const tdesc & dst, int dst_type, hipStream_t st) {
     const int64_t total = src.ne[0] * src.ne[1] * src.ne[2] * src.ne[3];
     if (total == 0) return;
-    int64_t g = (total + 255) / 256; if (g > 16384) g = 16384;
-    dim3 grid((unsigned) g), blk(256);
-    const td4 s = to_td4(src), d = to_td4(dst);
-    if      (src_type == GGML_TYPE_F32 && dst_type == GGML_TYPE_F32) k_cpy<float, float><<<grid, blk, 0, st>>>(s, d);
-    else if (src_type == GGML_TYPE_F32 && dst_type == GGML_TYPE_F16) k_cpy<float, uint16_t><<<grid, blk, 0, st>>>(s, d);
-    else if (src_type == GGML_TYPE_F16 && dst_type == GGML_TYPE_F32) k_cpy<uint16_t, float><<<grid, blk, 0, st>>>(s, d);
-    else if (src_type == GGML_TYPE_F16 && dst_type == GGML_TYPE_F16) k_cpy<uint16_t, uint16_t><<<grid, blk, 0, st>>>(s, d);
-    else if (src_type == GGML_TYPE_I32 && dst_type == GGML_TYPE_I32) k_cpy<int32_t, int32_t><<<grid, blk, 0, st>>>(s, d);
+    if      (src_type == GGML_TYPE_F32 && dst_type == GGML_TYPE_F32) cpy_go<float, float>(src, dst, total, st);
+    else if (src_type == GGML_TYPE_F32 && dst_type == GGML_TYPE_F16) cpy_go<float, uint16_t>(src, dst, total, st);
+    else if (src_type == GGML_TYPE_F16 && dst_type == GGML_TYPE_F32) cpy_go<uint16_t, float>(src, dst, total, st);
+    else if (src_type == GGML_TYPE_F16 && dst_type == GGML_TYPE_F16) cpy_go<uint16_t, uint16_t>(src, dst, total, st);
+    else if (src_type == GGML_TYPE_I32 && dst_type == GGML_TYPE_I32) cpy_go<int32_t, int32_t>(src, dst, total, st);
     else { fprintf(stderr, "[mi355x] cpy: unsupported %d -> %d\n", src_type, dst_type); abort(); }
 }
 
