@@ -524,6 +524,42 @@ def test_prefill_ubatch_vs_reference_backend(pkg, be, ref_be, wtype):
     assert agree > (0.99 if wtype == "f16" else 0.9), agree           # (random weights: near-ties may flip between f16 GEMM and integer dot)
 
 
+@pytest.mark.parametrize("n_kv,T,steps", [(768, 300, 3), (2048, 1500, 2)])
+def test_decode_on_a_deep_cache_vs_reference_backend(pkg, be, ref_be, n_kv, T, steps):
+    """Decode steps on top of a cache of several hundred / thousand rows: the attention node takes the matrix-core kernel with KV slices
+    (k_fattn_gqa + k_fattn_merge), its q/k/v pre-stage runs inside the sliced launch (only the slice that owns the new cache row stores
+    it) and the merge pass emits the Q8_K image for wo -- logits against the reference CPU backend on the same graphs."""
+    from llama_cpp_omni_amd import qwen3
+    cfg = dict(n_embd=1024, n_layer=2, n_head=8, n_head_kv=2, head_dim=128, n_ff=2048, n_vocab=512, rms_eps=1e-6, rope_base=1e6, n_ctx_orig=4096)
+    types = qwen3.q4_k_m_types(cfg)
+    rng = np.random.default_rng(n_kv)
+    embd = rng.standard_normal((T + steps, cfg["n_embd"])).astype(np.float32)
+    outs = []
+    for backend in (be, ref_be):
+        mdl = qwen3.Model(backend, cfg, types, n_ctx=n_kv, seed=4, flash_attn=True)
+        done = 0
+        while done < T:                                                # prefill in ubatches of 512 at growing depth
+            n = min(512, T - done)
+            g, I, logits = mdl.build(n, n_kv)
+            mdl.set_inputs(I, embd[done:done + n], done, n_kv)
+            backend.graph_compute(g.graph())
+            backend.synchronize()
+            g.free()
+            done += n
+        g1, I1, logits1 = mdl.build(1, n_kv)
+        gr = g1.graph()
+        ls = []
+        for k in range(steps):                                         # (second submission onwards: hipGraph replay on the device backend)
+            mdl.set_inputs(I1, embd[T + k:T + k + 1], T + k, n_kv)
+            backend.graph_compute(gr)
+            ls.append(backend.tensor_get(logits1).copy())
+        outs.append(np.stack(ls))
+        g1.free(); mdl.wctx.free()
+    assert np.isfinite(outs[0]).all()
+    assert nmse(outs[0], outs[1]) < 2e-3                               # (prefill on f16 operands vs the CPU's Q8_K activations, as test_prefill_ubatch)
+    assert np.array_equal(outs[0].argmax(-1), outs[1].argmax(-1))
+
+
 def test_encoder_block_vs_reference_backend(pkg, be, ref_be):
     """First ops of the omni audio encoder (tools/omni/audition.cpp: conv1d -> GELU -> LayerNorm * w + b -> F16 linear), i.e. IM2COL,
     the F16 x F16 MUL_MAT of ggml_conv_1d, UNARY(GELU), CONT(transpose), NORM, MUL, ADD, MUL_MAT -- against the reference CPU backend."""
