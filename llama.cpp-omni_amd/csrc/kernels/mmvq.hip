@@ -40,60 +40,88 @@ static __device__ __forceinline__ void stage_act(const char * act, size_t act_cs
 template <int NCOLS, int ROWS>
 __global__ void __launch_bounds__(256) k_mmv_q80(const char * __restrict__ W, size_t w_rs, const char * __restrict__ act, size_t act_cs,
                                                 char * __restrict__ dst, size_t dst_cs, int K, int nrows) {
-    typedef uint32_t __attribute__((aligned(2))) u32a2;
+    // four lanes per 34-byte block (8 quants = one hardware-unaligned 8-byte load each; blocks are only 2-byte aligned), 16 blocks per
+    // wave step, U steps per stage; the loads of the next stage are issued before the current one is consumed, the first ones before
+    // the activation images are staged
+    typedef u32x2 __attribute__((aligned(2))) u32x2a2;
+    constexpr int U = NCOLS <= 2 ? 4 : 2;
     const int lane = threadIdx.x & 63;
-    const int g = lane >> 3, lp = lane & 7;
+    const int g = lane >> 2, lp = lane & 3;
     const int nb  = K >> 5;
-    const int nit = (nb + 7) >> 3;
+    const int nit = (nb + 16 * U - 1) / (16 * U);
     const size_t img = q80_image_bytes(K);
     const int wave   = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int nwaves = gridDim.x * 4;
     const int ngrp   = (nrows + ROWS - 1) / ROWS;
 
-    stage_act(act, act_cs, NCOLS, img);
-    __syncthreads();
-
-    for (int grp = wave; grp < ngrp; grp += nwaves) {
-        float acc[ROWS][NCOLS];
+    u32x2 q[U][ROWS]; uint32_t dw[U][ROWS];
+    auto issue = [&](int grp, int it) {
 #pragma unroll
-        for (int r = 0; r < ROWS; ++r)
-#pragma unroll
-            for (int c = 0; c < NCOLS; ++c) acc[r][c] = 0.0f;
-#pragma unroll 4
-        for (int it = 0; it < nit; ++it) {
-            const int  ib    = it * 8 + g;
-            const bool valid = ib < nb;
-            const int  ibc   = valid ? ib : nb - 1;
-            uint32_t q[ROWS]; uint32_t dw[ROWS];
+        for (int u = 0; u < U; ++u) {
+            int ib = (it * U + u) * 16 + g; ib = ib < nb ? ib : nb - 1;
 #pragma unroll
             for (int r = 0; r < ROWS; ++r) {
                 int row = grp * ROWS + r; row = row < nrows ? row : nrows - 1;
-                const char * bp = W + (size_t) row * w_rs + (size_t) ibc * 34;
-                dw[r] = *(const uint16_t *) bp;
-                q[r]  = __builtin_nontemporal_load((const u32a2 *) (bp + 2 + 4 * lp));
+                const char * bp = W + (size_t) row * w_rs + (size_t) ib * 34;
+                dw[u][r] = *(const uint16_t *) bp;
+                q[u][r]  = *(const u32x2a2 *) (bp + 2 + 8 * lp);
             }
+        }
+    };
+    int grp = wave, it = 0;
+    if (grp < ngrp) issue(grp, 0);
+    stage_act(act, act_cs, NCOLS, img);
+    __syncthreads();
+    if (grp >= ngrp) return;
+
+    float acc[ROWS][NCOLS];
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r)
+#pragma unroll
+        for (int c = 0; c < NCOLS; ++c) acc[r][c] = 0.0f;
+    while (true) {
+        u32x2 cq[U][ROWS]; uint32_t cd[U][ROWS];
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int r = 0; r < ROWS; ++r) { cq[u][r] = q[u][r]; cd[u][r] = dw[u][r]; }
+        const int cgrp = grp, cit = it;
+        ++it;
+        if (it == nit) { it = 0; grp += nwaves; }
+        const bool more = grp < ngrp;
+        if (more) issue(grp, it);
+
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int  ib    = (cit * U + u) * 16 + g;
+            const bool valid = ib < nb;
+            const int  ibc   = valid ? ib : nb - 1;
 #pragma unroll
             for (int c = 0; c < NCOLS; ++c) {
                 const char * im = mmv_lds + c * img;
-                const uint32_t a  = *(const uint32_t *) (im + ibc * 32 + 4 * lp);
-                const float    yd = *(const float *) (im + K + ibc * 4);
+                const u32x2 a  = *(const u32x2 *) (im + ibc * 32 + 8 * lp);
+                const float yd = *(const float *) (im + K + ibc * 4);
 #pragma unroll
                 for (int r = 0; r < ROWS; ++r) {
-                    const bool rv = valid && (grp * ROWS + r) < nrows;
-                    const float t = (float) dot4(q[r], a, 0) * (h2f((uint16_t) dw[r]) * yd);
+                    const bool rv = valid && (cgrp * ROWS + r) < nrows;
+                    const float t = (float) dot4(cq[u][r][0], a[0], dot4(cq[u][r][1], a[1], 0)) * (h2f((uint16_t) cd[u][r]) * yd);
                     acc[r][c] += rv ? t : 0.0f;
                 }
             }
         }
+        if (cit == nit - 1) {
 #pragma unroll
-        for (int r = 0; r < ROWS; ++r) {
-            const int row = grp * ROWS + r;
+            for (int r = 0; r < ROWS; ++r) {
+                const int row = cgrp * ROWS + r;
 #pragma unroll
-            for (int c = 0; c < NCOLS; ++c) {
-                const float s = wave_sum(acc[r][c]);
-                if (lane == 0 && row < nrows) *(float *) (dst + c * dst_cs + (size_t) row * 4) = s;
+                for (int c = 0; c < NCOLS; ++c) {
+                    const float s = wave_sum(acc[r][c]);
+                    if (lane == 0 && row < nrows) *(float *) (dst + c * dst_cs + (size_t) row * 4) = s;
+                    acc[r][c] = 0.0f;
+                }
             }
         }
+        if (!more) break;
     }
 }
 
