@@ -135,71 +135,105 @@ __global__ void __launch_bounds__(256) k_mmv_q80(const char * __restrict__ W, si
 template <int NCOLS, int ROWS, bool Q5>
 __global__ void __launch_bounds__(256) k_mmv_q40(const char * __restrict__ W, size_t w_rs, const char * __restrict__ act, size_t act_cs,
                                                 char * __restrict__ dst, size_t dst_cs, int K, int nrows) {
+    // two lanes per block: lane half hf owns nibble bytes 8hf .. 8hf+7 = weights 8hf..8hf+7 (low nibbles) and 16+8hf..23+8hf (high);
+    // 32 blocks per wave step, U steps per stage, next stage requested before the current one is consumed
+    typedef u32x2 __attribute__((aligned(2))) u32x2a2;
     typedef uint32_t __attribute__((aligned(2))) u32a2;
     constexpr int BS = Q5 ? 22 : 18, QOFF = Q5 ? 6 : 2, OFF = Q5 ? 16 : 8;
+    constexpr int U = NCOLS <= 2 ? 2 : 1;
     const int lane = threadIdx.x & 63;
-    const int g = lane >> 2, lp = lane & 3;
+    const int g = lane >> 1, hf = lane & 1;
     const int nb  = K >> 5;
-    const int nit = (nb + 15) >> 4;
+    const int nit = (nb + 32 * U - 1) / (32 * U);
     const size_t img = q80_image_bytes(K);
     const int wave   = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int nwaves = gridDim.x * 4;
     const int ngrp   = (nrows + ROWS - 1) / ROWS;
 
-    stage_act(act, act_cs, NCOLS, img);
-    __syncthreads();
-
-    for (int grp = wave; grp < ngrp; grp += nwaves) {
-        float acc[ROWS][NCOLS];
+    u32x2 q[U][ROWS]; uint32_t dw[U][ROWS], qh[Q5 ? U : 1][Q5 ? ROWS : 1];
+    auto issue = [&](int grp, int it) {
 #pragma unroll
-        for (int r = 0; r < ROWS; ++r)
-#pragma unroll
-            for (int c = 0; c < NCOLS; ++c) acc[r][c] = 0.0f;
-#pragma unroll 4
-        for (int it = 0; it < nit; ++it) {
-            const int  ib    = it * 16 + g;
-            const bool valid = ib < nb;
-            const int  ibc   = valid ? ib : nb - 1;
-            uint32_t lo[ROWS], hi[ROWS]; float dx[ROWS];
+        for (int u = 0; u < U; ++u) {
+            int ib = (it * U + u) * 32 + g; ib = ib < nb ? ib : nb - 1;
 #pragma unroll
             for (int r = 0; r < ROWS; ++r) {
                 int row = grp * ROWS + r; row = row < nrows ? row : nrows - 1;
-                const char * bp = W + (size_t) row * w_rs + (size_t) ibc * BS;
-                dx[r] = h2f(*(const uint16_t *) bp);
-                const uint32_t q = *(const u32a2 *) (bp + QOFF + 4 * lp);
-                lo[r] = q & 0x0f0f0f0fu; hi[r] = (q >> 4) & 0x0f0f0f0fu;
-                if (Q5) {
-                    const uint32_t qh = *(const u32a2 *) (bp + 2);
-                    const uint32_t bl = (qh >> (4 * lp)) & 0xfu, bh = (qh >> (16 + 4 * lp)) & 0xfu;
-                    lo[r] |= ((bl & 1u) | ((bl & 2u) << 7) | ((bl & 4u) << 14) | ((bl & 8u) << 21)) << 4;
-                    hi[r] |= ((bh & 1u) | ((bh & 2u) << 7) | ((bh & 4u) << 14) | ((bh & 8u) << 21)) << 4;
+                const char * bp = W + (size_t) row * w_rs + (size_t) ib * BS;
+                dw[u][r] = *(const uint16_t *) bp;
+                q[u][r]  = *(const u32x2a2 *) (bp + QOFF + 8 * hf);
+                if (Q5) qh[u][r] = *(const u32a2 *) (bp + 2);
+            }
+        }
+    };
+    // fifth bits of 4 consecutive weights (bits b .. b+3 of qh) spread into bit 4 of the four bytes of a word
+    auto spread = [](uint32_t bits) { return ((bits & 1u) | ((bits & 2u) << 7) | ((bits & 4u) << 14) | ((bits & 8u) << 21)) << 4; };
+    int grp = wave, it = 0;
+    if (grp < ngrp) issue(grp, 0);
+    stage_act(act, act_cs, NCOLS, img);
+    __syncthreads();
+    if (grp >= ngrp) return;
+
+    float acc[ROWS][NCOLS];
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r)
+#pragma unroll
+        for (int c = 0; c < NCOLS; ++c) acc[r][c] = 0.0f;
+    while (true) {
+        u32x2 cq[U][ROWS]; uint32_t cd[U][ROWS], ch[Q5 ? U : 1][Q5 ? ROWS : 1];
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int r = 0; r < ROWS; ++r) { cq[u][r] = q[u][r]; cd[u][r] = dw[u][r]; if (Q5) ch[u][r] = qh[u][r]; }
+        const int cgrp = grp, cit = it;
+        ++it;
+        if (it == nit) { it = 0; grp += nwaves; }
+        const bool more = grp < ngrp;
+        if (more) issue(grp, it);
+
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int  ib    = (cit * U + u) * 32 + g;
+            const bool valid = ib < nb;
+            const int  ibc   = valid ? ib : nb - 1;
+            uint32_t lo[ROWS][2], hi[ROWS][2]; float dx[ROWS];
+#pragma unroll
+            for (int r = 0; r < ROWS; ++r) {
+                dx[r] = h2f((uint16_t) cd[u][r]);
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    lo[r][k] = cq[u][r][k] & 0x0f0f0f0fu; hi[r][k] = (cq[u][r][k] >> 4) & 0x0f0f0f0fu;
+                    if (Q5) { lo[r][k] |= spread((ch[u][r] >> (8 * hf + 4 * k)) & 0xfu); hi[r][k] |= spread((ch[u][r] >> (16 + 8 * hf + 4 * k)) & 0xfu); }
                 }
             }
 #pragma unroll
             for (int c = 0; c < NCOLS; ++c) {
                 const char * im = mmv_lds + c * img;
-                const uint32_t a0 = *(const uint32_t *) (im + ibc * 32 + 4 * lp);
-                const uint32_t a1 = *(const uint32_t *) (im + ibc * 32 + 16 + 4 * lp);
-                const float    yd = *(const float *) (im + K + ibc * 4);
-                const int ysum = dot4(0x01010101u, a0, dot4(0x01010101u, a1, 0));
+                const u32x2 a0 = *(const u32x2 *) (im + ibc * 32 + 8 * hf);
+                const u32x2 a1 = *(const u32x2 *) (im + ibc * 32 + 16 + 8 * hf);
+                const float yd = *(const float *) (im + K + ibc * 4);
+                const int ysum = dot4(0x01010101u, a0[0], dot4(0x01010101u, a0[1], dot4(0x01010101u, a1[0], dot4(0x01010101u, a1[1], 0))));
 #pragma unroll
                 for (int r = 0; r < ROWS; ++r) {
-                    const bool rv = valid && (grp * ROWS + r) < nrows;
-                    const int isum = dot4(lo[r], a0, dot4(hi[r], a1, 0)) - OFF * ysum;
+                    const bool rv = valid && (cgrp * ROWS + r) < nrows;
+                    const int isum = dot4(lo[r][0], a0[0], dot4(lo[r][1], a0[1], dot4(hi[r][0], a1[0], dot4(hi[r][1], a1[1], 0)))) - OFF * ysum;
                     const float t = (float) isum * (dx[r] * yd);
                     acc[r][c] += rv ? t : 0.0f;
                 }
             }
         }
+        if (cit == nit - 1) {
 #pragma unroll
-        for (int r = 0; r < ROWS; ++r) {
-            const int row = grp * ROWS + r;
+            for (int r = 0; r < ROWS; ++r) {
+                const int row = cgrp * ROWS + r;
 #pragma unroll
-            for (int c = 0; c < NCOLS; ++c) {
-                const float s = wave_sum(acc[r][c]);
-                if (lane == 0 && row < nrows) *(float *) (dst + c * dst_cs + (size_t) row * 4) = s;
+                for (int c = 0; c < NCOLS; ++c) {
+                    const float s = wave_sum(acc[r][c]);
+                    if (lane == 0 && row < nrows) *(float *) (dst + c * dst_cs + (size_t) row * 4) = s;
+                    acc[r][c] = 0.0f;
+                }
             }
         }
+        if (!more) break;
     }
 }
 
