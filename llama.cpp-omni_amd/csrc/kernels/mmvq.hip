@@ -275,6 +275,90 @@ __global__ void __launch_bounds__(256) k_mmv_f(const char * __restrict__ W, size
     __syncthreads();
 
     const bool vec_ok = (K % EPL == 0) && (w_rs % 16 == 0) && (((uintptr_t) W & 15) == 0);
+    if (vec_ok && K % (64 * EPL) == 0) {
+        // whole 16-byte steps only (every model matrix): U steps per stage, the next stage's loads issued before the current one is
+        // multiplied, activations read from LDS as one 16-byte vector per step.  Same multiply-add order as the general loop below.
+        constexpr int U = NCOLS <= 2 ? 4 : 2;
+        const int nstage = (nstep + U - 1) / U;
+        u32x4 v[U][ROWS];
+        auto issue = [&](int grp, int st) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                int sidx = st * U + u; sidx = sidx < nstep ? sidx : nstep - 1;
+#pragma unroll
+                for (int r = 0; r < ROWS; ++r) {
+                    int row = grp * ROWS + r; row = row < nrows ? row : nrows - 1;
+                    v[u][r] = ld_nt16(W + (size_t) row * w_rs + ((size_t) sidx * 64 + lane) * 16);
+                }
+            }
+        };
+        int grp = wave, st = 0;
+        if (grp >= ngrp) return;
+        issue(grp, 0);
+        float acc[ROWS][NCOLS];
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r)
+#pragma unroll
+            for (int c = 0; c < NCOLS; ++c) acc[r][c] = 0.0f;
+        while (true) {
+            u32x4 cv[U][ROWS];
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int r = 0; r < ROWS; ++r) cv[u][r] = v[u][r];
+            const int cgrp = grp, cst = st;
+            ++st;
+            if (st == nstage) { st = 0; grp += nwaves; }
+            const bool more = grp < ngrp;
+            if (more) issue(grp, st);
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int sidx = cst * U + u;
+                if (sidx >= nstep) continue;
+                float w[ROWS][EPL];
+#pragma unroll
+                for (int r = 0; r < ROWS; ++r) {
+                    if (WF16) {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) { w[r][2 * k] = h2f((uint16_t) (cv[u][r][k] & 0xffff)); w[r][2 * k + 1] = h2f((uint16_t) (cv[u][r][k] >> 16)); }
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) { const uint32_t bits = cv[u][r][k]; w[r][k] = __uint_as_float(bits); }
+                    }
+                }
+#pragma unroll
+                for (int c = 0; c < NCOLS; ++c) {
+                    const u32x4 xv = *(const u32x4 *) (mmv_lds + c * arow + ((size_t) sidx * 64 + lane) * 16);
+                    float x[EPL];
+                    if (WF16) {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) { x[2 * k] = h2f((uint16_t) (xv[k] & 0xffff)); x[2 * k + 1] = h2f((uint16_t) (xv[k] >> 16)); }
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) { const uint32_t bits = xv[k]; x[k] = __uint_as_float(bits); }
+                    }
+#pragma unroll
+                    for (int r = 0; r < ROWS; ++r)
+#pragma unroll
+                        for (int k = 0; k < EPL; ++k) acc[r][c] = fmaf(w[r][k], x[k], acc[r][c]);
+                }
+            }
+            if (cst == nstage - 1) {
+#pragma unroll
+                for (int r = 0; r < ROWS; ++r) {
+                    const int row = cgrp * ROWS + r;
+#pragma unroll
+                    for (int c = 0; c < NCOLS; ++c) {
+                        const float sum = wave_sum(acc[r][c]);
+                        if (lane == 0 && row < nrows) *(float *) (dst + c * dst_cs + (size_t) row * 4) = sum;
+                        acc[r][c] = 0.0f;
+                    }
+                }
+            }
+            if (!more) break;
+        }
+        return;
+    }
     for (int grp = wave; grp < ngrp; grp += nwaves) {
         float acc[ROWS][NCOLS];
 #pragma unroll
