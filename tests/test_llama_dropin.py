@@ -116,12 +116,13 @@ def test_graph_optimize_hook_under_the_scheduler(tmp_path):
     assert res["opt"][1] < res["noopt"][1]
 
 
-def test_synthetic_gguf_loads_on_reference_cpu(tmp_path):
+@pytest.mark.parametrize("types", ["q4_k_m", "q4_0", "q5_k", "q8_0"])
+def test_synthetic_gguf_loads_on_reference_cpu(tmp_path, types):
     """CPU-only: the file format written by tools/make_synth_gguf.py is accepted by the reference loader and decodes."""
     if not os.path.exists(BIN):
         pytest.skip("oracle/_ref/llama-bench-min not built")
     gguf = str(tmp_path / "tiny.gguf")
-    subprocess.run([sys.executable, os.path.join(ROOT, "tools", "make_synth_gguf.py"), "--config", "tiny", "--types", "q4_k_m", "-o", gguf,
+    subprocess.run([sys.executable, os.path.join(ROOT, "tools", "make_synth_gguf.py"), "--config", "tiny", "--types", types, "-o", gguf,
                     "--distinct-layers"], check=True, timeout=300)
     ids, logits, _ = _greedy(gguf, 0, 1, str(tmp_path / "cpu.bin"))
     assert len(ids) == 24 and np.isfinite(logits).all() and logits.size == 512
