@@ -144,7 +144,7 @@ def kernel_roofline(pkg, be, model, reps=5):
         be.graph_compute(g)                      # eager, capture, first replay
     be.synchronize()
     kern = int(be.get_stat("kernels_last_graph"))
-    assert kern == launches + 1, (kern, launches)   # the pair launches + one activation quantiser
+    assert kern in (launches, launches + 1), (kern, launches)   # the pair launches (+ one activation quantiser when the batch-1 kernels are off)
     best = 1e30
     for _ in range(reps):
         a, b = be.timed_event(), be.timed_event()

@@ -531,6 +531,37 @@ static bool kq_mm_ok(const ggml_tensor * n) {
     const ggml_tensor * w = n->src[0], * x = n->src[1];
     return w->ne[2] == 1 && w->ne[3] == 1 && x->ne[2] == 1 && x->ne[3] == 1 && n->nb[0] == 4 && x->nb[0] == 4;
 }
+// batch-1 decode form (mmv1.hip): one column, Q4_K / Q6_K, K a multiple of 4096 up to 12288, aligned rows
+static bool mv1_node_ok(exec_state & s, const ggml_tensor * n) {
+    if (!s.c->opt_mv1 || !plain_kq_matvec(n, 1)) return false;
+    const ggml_tensor * w = n->src[0], * x = n->src[1];
+    if (x->ne[1] != 1 || x->type != GGML_TYPE_F32 || (w->type != GGML_TYPE_Q4_K && w->type != GGML_TYPE_Q6_K)) return false;
+    mv1_args v; v.nmat = 1; v.K = w->ne[0];
+    v.m[0] = { w->data, w->nb[1], (float *) n->data, 0, nullptr, 0, w->ne[1], (int) w->type };
+    v.img = (const void *) 16;                                             // (source checked separately)
+    return mmv1_ok(v);
+}
+// activation source of an mmv1 launch on x: the pending norm (computed inside the launch), the cached Q8_K image, the f32 row itself
+// (quantised inside the launch), or -- when an output would overwrite x while the launch reads it -- a quantise launch first
+static size_t prepare_act(exec_state & s, const ggml_tensor * x, act_kind kind);
+static bool norm_in_kernel(exec_state & s, const ggml_tensor * x, const ggml_tensor * const * outs, int n_outs, int n_consumers, mmv_norm & nr);
+static void mv1_source(exec_state & s, const ggml_tensor * x, const ggml_tensor * const * outs, int n_outs, int n_consumers, mv1_args & v) {
+    mmv_norm nr;
+    if (s.pn.m && x == s.pn.m && ((uintptr_t) s.pn.x->data & 15) == 0 && ((uintptr_t) s.pn.wt->data & 15) == 0 && norm_in_kernel(s, x, outs, n_outs, n_consumers, nr)) {
+        v.x = nr.x; v.norm_w = nr.w; v.eps = nr.eps;
+        return;
+    }
+    const int64_t K = x->ne[0];
+    const bool cached = s.a_src == x->data && s.a_kind == ACT_Q8K && s.a_K == K && s.a_ne[0] == 1 && s.a_ne[1] == x->ne[2] && s.a_ne[2] == x->ne[3];
+    bool plain = !cached && !(s.pn.m && x == s.pn.m) && ((uintptr_t) x->data & 15) == 0;
+    if (plain) {
+        const byte_range rx = range_of(x);
+        for (int i = 0; i < n_outs; ++i) if (outs[i] && overlap(range_of(outs[i]), rx)) plain = false;
+    }
+    if (plain) { v.x = (const float *) x->data; v.norm_w = nullptr; return; }
+    prepare_act(s, x, ACT_Q8K);
+    v.img = s.c->act_scratch;
+}
 static bool same_act(const ggml_tensor * a, const ggml_tensor * b) {
     return a->data == b->data && a->ne[0] == b->ne[0] && a->ne[1] == b->ne[1] && a->ne[2] == b->ne[2] && a->ne[3] == b->ne[3] &&
            a->nb[1] == b->nb[1] && a->nb[2] == b->nb[2] && a->nb[3] == b->nb[3];
@@ -735,6 +766,19 @@ static void exec_mul_mat(exec_state & s, int i) {
                 if (can_hoist(s, i, oi, item, 3) && can_hoist(s, i, gi, item, 3)) {
                     mmv_norm nrm;
                     const ggml_tensor * outs[1] = { G };
+                    const ggml_tensor * gate_n = G->src[0], * up_n = G->src[1];
+                    if (N == 1 && mv1_node_ok(s, gate_n) && mv1_node_ok(s, up_n) && ((uintptr_t) G->data & 3) == 0) {
+                        mv1_args v; v.nmat = 1; v.K = K;
+                        v.m[0] = { gate_n->src[0]->data, gate_n->src[0]->nb[1], (float *) G->data, 0, nullptr, 0, gate_n->src[0]->ne[1], (int) gate_n->src[0]->type };
+                        v.W_up = up_n->src[0]->data;
+                        mv1_source(s, x, outs, 1, 2, v);
+                        prof_scope ps(s, n->src[0]->type == GGML_TYPE_Q4_K ? "mmv_q4k" : "mmv_q6k", 2.0 * (double) n->src[0]->ne[1] * (double) row_size(n->src[0]->type, K));
+                        mmv1(v, s.st);
+                        ++s.n_kernels; s.n_fused += 2;
+                        s.done[oi] = s.done[gi] = 1;
+                        note_write(s, G);
+                        return;
+                    }
                     const size_t img = norm_in_kernel(s, x, outs, 1, 2, nrm) ? q8k_image_bytes(K) : prepare_act(s, x, ACT_Q8K);
                     const ggml_tensor * gate = G->src[0], * up = G->src[1];
                     prof_scope ps(s, n->src[0]->type == GGML_TYPE_Q4_K ? "mmv_q4k" : "mmv_q6k", 2.0 * (double) n->src[0]->ne[1] * (double) row_size(n->src[0]->type, K));
@@ -789,6 +833,24 @@ static void exec_mul_mat(exec_state & s, int i) {
     }
     const ggml_tensor * outs[3] = { nullptr, nullptr, nullptr };
     for (int q = 0; q < nm; ++q) outs[q] = add_idx[q] >= 0 ? g->nodes[add_idx[q]] : g->nodes[mm_idx[q]];
+    bool all_mv1 = N == 1 && !use_mmq;
+    for (int q = 0; q < nm && all_mv1; ++q) all_mv1 = mv1_node_ok(s, g->nodes[mm_idx[q]]) && ((uintptr_t) a.m[q].dst & 3) == 0 && ((uintptr_t) a.m[q].resid & 3) == 0;
+    if (all_mv1) {
+        mv1_args v; v.nmat = nm; v.K = K;
+        for (int q = 0; q < nm; ++q) v.m[q] = a.m[q];
+        mv1_source(s, x, outs, nm, nm, v);
+        {
+            prof_scope ps(s, bytes_q4 >= bytes_q6 ? "mmv_q4k" : "mmv_q6k", bytes_q4 + bytes_q6);
+            mmv1(v, s.st);
+        }
+        ++s.n_kernels;
+        for (int q = 0; q < nm; ++q) {
+            if (q > 0) { s.done[mm_idx[q]] = 1; ++s.n_fused; }
+            if (add_idx[q] >= 0) { s.done[add_idx[q]] = 1; ++s.n_fused; note_write(s, g->nodes[add_idx[q]]); }
+            else note_write(s, g->nodes[mm_idx[q]]);
+        }
+        return;
+    }
     const size_t img = norm_in_kernel(s, x, outs, nm, nm, a.norm) ? q8k_image_bytes(K) : prepare_act(s, x, ACT_Q8K);
     a.act = s.c->act_scratch; a.act_cs = img;
     if (use_mmq) {                                                    // int8 matrix cores, 32 columns per launch
@@ -1063,7 +1125,10 @@ static bool exec_rms_norm(exec_state & s, int i) {
         const ggml_tensor * xs = n->src[0];
         // (measured on MI355X, decode of Qwen3-8B: the in-kernel norm removes 73 launches per token and costs the consumers exactly
         //  what it saves -- 378 tok/s either way, DESIGN.md section 7 -- so it is opt-in: option "norm_in_kernel" / MI355X_NORM_IN_KERNEL=1)
-        bool defer = s.c->opt_norm_in_kernel && mmv_norm_ok(n->ne[0], (int) n->ne[1]) && !(m->flags & GGML_TENSOR_FLAG_OUTPUT) && ((uintptr_t) xs->data & 15) == 0 && xs->nb[1] % 16 == 0 && ((uintptr_t) wt->data & 15) == 0;
+        // the batch-1 decode launches (mmv1.hip) always take the norm in: their prologue builds the image from x and the norm weights
+        bool all_mv1 = n->ne[1] == 1;
+        for (int u : s.users[m]) all_mv1 = all_mv1 && mv1_node_ok(s, g->nodes[u]);
+        bool defer = (all_mv1 || (s.c->opt_norm_in_kernel && mmv_norm_ok(n->ne[0], (int) n->ne[1]))) && !(m->flags & GGML_TENSOR_FLAG_OUTPUT) && ((uintptr_t) xs->data & 15) == 0 && xs->nb[1] % 16 == 0 && ((uintptr_t) wt->data & 15) == 0;
         int last_user = mi_;
         for (int u : s.users[m]) { defer = defer && plain_kq_matvec(g->nodes[u], MI_MMVQ_MAX_COLS); if (u > last_user) last_user = u; }
         if (defer) {
@@ -1462,6 +1527,7 @@ void backend_ctx_init(backend_ctx * c) {
     if ((e = getenv("MI355X_FUSION")))  c->opt_fusion  = atoi(e) != 0;
     if ((e = getenv("MI355X_PROFILE"))) c->opt_profile = atoi(e) != 0;
     if ((e = getenv("MI355X_NORM_IN_KERNEL"))) c->opt_norm_in_kernel = atoi(e) != 0;
+    if ((e = getenv("MI355X_MV1")))     c->opt_mv1     = atoi(e) != 0;
 }
 void backend_ctx_release(backend_ctx * c) {
     for (auto & e : c->execs) { if (e.exec) (void) hipGraphExecDestroy(e.exec); if (e.graph) (void) hipGraphDestroy(e.graph); }
@@ -1485,6 +1551,7 @@ int mi355x_set_option(struct ggml_backend * backend, const char * key, long valu
     if (!strcmp(key, "fusion"))  { c->opt_fusion = value != 0; c->execs.clear(); return 0; }
     if (!strcmp(key, "profile")) { c->opt_profile = value != 0; return 0; }
     if (!strcmp(key, "norm_in_kernel")) { c->opt_norm_in_kernel = value != 0; c->execs.clear(); return 0; }
+    if (!strcmp(key, "mv1")) { c->opt_mv1 = value != 0; c->execs.clear(); return 0; }
     if (!strcmp(key, "fattn_gqa")) { mi::fattn_set_gqa(value != 0); c->execs.clear(); return 0; }
     if (!strcmp(key, "f16_shadow")) { mi::shadow_set_enabled(value != 0); c->execs.clear(); return 0; }
     if (!strcmp(key, "reset_stats")) { c->prof.clear(); c->stat_replays = c->stat_captures = c->stat_eager = 0; return 0; }

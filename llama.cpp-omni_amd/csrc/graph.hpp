@@ -43,6 +43,7 @@ struct backend_ctx {
     bool opt_fusion = true;
     bool opt_profile = false;
     bool opt_norm_in_kernel = false;   // RMS_NORM+MUL computed inside the consuming mat-vec launches (mmvk.hip act_norm)
+    bool opt_mv1 = true;               // batch-1 decode mat-vecs on mmv1.hip (f32 activation in, image built in the prologue)
 
     // hipGraph cache
     std::vector<graph_exec> execs;

@@ -62,6 +62,18 @@ void mmv_kquant_multi(const mmv_multi_args & a, hipStream_t st);
 void mmv_kquant_pair_swiglu(int type, const void * Wg, const void * Wu, size_t w_rs, const void * act, size_t act_cs, float * dst, size_t dst_cs,
                             int64_t K, int64_t nrows, int ncols, hipStream_t st, const mmv_norm * norm = nullptr);
 
+// ---- batch-1 decode form (mmv1.hip): ONE activation column, Q4_K / Q6_K, K a multiple of 4096 up to 12288.  The launch takes the f32
+// activation row itself -- x, or rms_norm(x) * norm_w (the RMS_NORM + MUL nodes in front of src1) -- and every workgroup builds the Q8_K
+// image in its prologue, so no norm / quantise launch precedes it; img != null hands over a ready image (q8k_image_bytes layout) instead.
+// W_up != null: m[0] is ffn_gate, W_up ffn_up (same type / shape / stride), dst = silu(gate.x) * (up.x).  dst / resid strides unused.
+struct mv1_args {
+    mmv_mat m[3]; int nmat = 0; const void * W_up = nullptr;
+    const float * x = nullptr; const float * norm_w = nullptr; float eps = 0.0f; const void * img = nullptr;
+    int64_t K = 0;
+};
+bool mmv1_ok(const mv1_args & a);
+void mmv1(const mv1_args & a, hipStream_t st);
+
 // ---- K-quant weights against 2 .. 32 activation columns on the int8 matrix cores (mmq.hip): up to 3 matrices (Q4_K / Q6_K mixed)
 // sharing one set of Q8_K activation images; dst[col*dst_cs + row], optional residual add epilogue
 struct mmq_mat { const void * W; size_t w_rs; float * dst; size_t dst_cs; int64_t nrows; int type; const float * resid = nullptr; size_t resid_cs = 0; };   // resid: optional dst = W.x + resid

@@ -1,0 +1,546 @@
+// mmv1.hip -- the batch-1 decode mat-vec of K-quant weights (Q4_K / Q6_K x one activation column), gfx950 / wave64.
+//
+// What is computed (reference: ggml_compute_forward_mul_mat, ggml-cpu/ggml-cpu.c:1210-1402, ne11 == 1):
+//     dst[row] = vec_dot(W[row, :], Q8_K(act))         act = x                        (src1 as the graph hands it over)
+//                                                       or  rms_norm(x) * w            (the RMS_NORM + MUL nodes in front of src1)
+//     Q8_K(.)  : quantize_row_q8_K_ref, ggml-quants.c:2555-2592
+//     rms_norm : ggml_compute_forward_rms_norm_f32, ggml-cpu/ops.cpp:3517-3566 (sum of squares in double)
+//     vec_dot  : ggml_vec_dot_q4_K_q8_K / _q6_K_q8_K, ggml-cpu/quants.c:550-623 / 705-758 (integer sub-block sums exact)
+// Epilogues: + resid (the graph's residual ADD), or silu(gate) * up for the ffn_gate / ffn_up pair (the graph's GLU node).
+//
+// Why a second family next to mmvk.hip: a decode step is ~180 dependent launches, and what a launch costs is its serial latency chain,
+// not its bytes (tools/launch_bench.hip: a 9.4 MB stream behind a dependent 16 KB read is 4.0 us, 56.6 MB 10.4 us -- 2.7 us + bytes /
+// 7.4 TB/s).  So this kernel
+//   * takes the f32 activation row itself: no stand-alone norm / quantise launch in front of it (3 of the 8 launches of a layer).  Every
+//     workgroup builds the Q8_K image in LDS with DPP-network reductions (no ds_bpermute chains: ~80 VALU per 256-block) while its
+//     first weight loads are already in flight;
+//   * keeps DEPTH stages of weight loads in flight per wave (VGPRs are the largest prefetch buffer of a CU: 512 KB);
+//   * hands contiguous row ranges to waves.
+#include "../kernels.hpp"
+
+namespace mi {
+
+extern __shared__ __attribute__((aligned(16))) char mv1_lds[];
+
+// ------------------------------------------------------------------------------------------------ DPP-network wave reductions
+template <int CTRL, int ROW_MASK>
+static __device__ __forceinline__ int dpp_i32(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, ROW_MASK, 0xf, false); }
+
+// max of non-negative values (lanes outside a row_bcast's row mask contribute the identity 0)
+// (non-negative IEEE floats order like their bit patterns, and an unsigned max with identity 0 folds into one v_max_u32_dpp per step)
+template <int CTRL, int ROW_MASK>
+static __device__ __forceinline__ uint32_t dpp_u32(uint32_t v) { return (uint32_t) __builtin_amdgcn_update_dpp(0, (int) v, CTRL, ROW_MASK, 0xf, false); }
+static __device__ __forceinline__ uint32_t umax32(uint32_t a, uint32_t b) { return a > b ? a : b; }
+template <int CTRL> static __device__ __forceinline__ uint32_t dpp_u32q(uint32_t v) { return (uint32_t) __builtin_amdgcn_update_dpp(0, (int) v, CTRL, 0xf, 0xf, true); }
+static __device__ __forceinline__ float wave_max_pos(float f) {
+    uint32_t v = (uint32_t) __float_as_int(f);
+    v = umax32(v, dpp_u32<0xB1, 0xf>(v));
+    v = umax32(v, dpp_u32<0x4E, 0xf>(v));
+    v = umax32(v, dpp_u32<0x141, 0xf>(v));
+    v = umax32(v, dpp_u32<0x140, 0xf>(v));
+    v = umax32(v, dpp_u32<0x142, 0xa>(v));
+    v = umax32(v, dpp_u32<0x143, 0xc>(v));
+    return __int_as_float(__builtin_amdgcn_readlane((int) v, 63));
+}
+template <int CTRL, int ROW_MASK>
+static __device__ __forceinline__ double dpp_f64(double v) {
+    const int lo = dpp_i32<CTRL, ROW_MASK>(__double2loint(v)), hi = dpp_i32<CTRL, ROW_MASK>(__double2hiint(v));
+    return __hiloint2double(hi, lo);
+}
+static __device__ __forceinline__ double wave_sum_f64(double v) {
+    v += dpp_f64<0xB1, 0xf>(v);
+    v += dpp_f64<0x4E, 0xf>(v);
+    v += dpp_f64<0x141, 0xf>(v);
+    v += dpp_f64<0x140, 0xf>(v);
+    v += dpp_f64<0x142, 0xa>(v);
+    v += dpp_f64<0x143, 0xc>(v);
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 63), __builtin_amdgcn_readlane(__double2loint(v), 63));
+}
+
+// LDS image of the activation row (private to this file; nb = K / 256 blocks):
+//   [ qs : nb x 272 B ]  int8 quants of block b at b * 272 (16 B of padding per block: the four lanes of a weight block read 64-B pieces of
+//                        one activation block, sixteen weight blocks per wave -- a 256-B stride would put them all on the same banks)
+//   [ bs : nb x 16 B  ]  int16 sums of the 8 sub-blocks of 32 (= bsums[2s] + bsums[2s+1] of block_q8_K): the Q4_K body's `mins` term
+//   [ b16: nb x 32 B  ]  the 16 bsums of block_q8_K, permuted so that a Q6_K lane reads its four as one 8-byte piece:
+//                        position 8n + 4hf + m holds bsums[8n + 2m + hf] (mv1_b16_pos)
+//   [ d  : nb x 4 B   ]  f32 scale
+static __device__ __forceinline__ int mv1_img_bs(int nb)  { return nb * 272; }
+static __device__ __forceinline__ int mv1_img_b16(int nb) { return nb * 288; }
+static __device__ __forceinline__ int mv1_img_d(int nb)   { return nb * 320; }
+static __device__ __forceinline__ int mv1_b16_pos(int s)  { return (s & 8) | ((s & 1) << 2) | ((s >> 1) & 3); }
+static inline size_t mv1_image_bytes(int64_t K) { return (size_t) (K / 256) * 324 + 16; }
+
+// One 256-element Q8_K block held by one wave (lane l owns elements 4l..4l+3) -> image parts.  Same results as q8k_block_from_regs
+// (common.hpp; reference quantize_row_q8_K_ref): the first element with the largest |x| is found with a DPP max, a ballot and a
+// v_readlane instead of an 18-step shuffle tournament.
+static __device__ __forceinline__ void q8k_block_fast(const f32x4 v, int lane, int8_t * qs, int16_t * bs32, int16_t * b16, float * ds) {
+    const float a0 = fabsf(v[0]), a1 = fabsf(v[1]), a2 = fabsf(v[2]), a3 = fabsf(v[3]);
+    const float a  = fmaxf(fmaxf(a0, a1), fmaxf(a2, a3));
+    const float amax = wave_max_pos(a);
+    if (amax == 0.0f) {                                                  // all-zero block (wave-uniform branch)
+        *(uint32_t *) (qs + 4 * lane) = 0u;
+        if ((lane & 7) == 0) bs32[lane >> 3] = 0;
+        if ((lane & 3) == 0) b16[lane >> 2] = 0;
+        if (lane == 0) *ds = 0.0f;
+        return;
+    }
+    const float mc = a0 == a ? v[0] : (a1 == a ? v[1] : (a2 == a ? v[2] : v[3]));       // first element of this lane with the lane's largest |x|
+    const unsigned long long bal = __ballot(a == amax);
+    const int first = __builtin_ctzll(bal);                              // lowest lane holding the block's largest |x|
+    const float mval = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mc), first));
+    const float iscale = -127.0f / mval;
+    int q[4]; int s = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float p = iscale * v[i];
+        int r = (int) __builtin_rintf(p);                                // round-half-even == nearest_int()
+        r = r > 127 ? 127 : r;
+        q[i] = r; s += r;
+    }
+    *(uint32_t *) (qs + 4 * lane) = (uint32_t) (q[0] & 0xff) | ((uint32_t) (q[1] & 0xff) << 8) | ((uint32_t) (q[2] & 0xff) << 16) | ((uint32_t) (q[3] & 0xff) << 24);
+    s += dpp_i32<0xB1, 0xf>(s);
+    s += dpp_i32<0x4E, 0xf>(s);                                          // sum of 16 (the reference's bsums entry) in every lane of the quad
+    if ((lane & 3) == 0) b16[mv1_b16_pos(lane >> 2)] = (int16_t) s;
+    s += dpp_i32<0x141, 0xf>(s);                                         // row_half_mirror: + the neighbouring quad -> sum of 32
+    if ((lane & 7) == 0) bs32[lane >> 3] = (int16_t) s;
+    if (lane == 0) *ds = 1.0f / iscale;
+}
+
+// ------------------------------------------------------------------------------------------------ activation prologue
+// Build the Q8_K image of the activation row in LDS (layout: common.hpp q8k_image_bytes).  NW waves; wave w owns blocks w, w + NW, ...
+//   img != null : copy a ready-made image
+//   nw  != null : y = (x * (1 / sqrtf(mean(x^2) + eps))) * nw, image of y          (RMS_NORM + MUL + from_float)
+//   else        : image of x                                                      (from_float only)
+// Two halves, because a wave's memory operations return IN ORDER (s_waitcnt vmcnt counts oldest-first): mv1_act_issue requests the
+// wave's share of the row (and of the norm weights) BEFORE the first weight stage is requested, so the row arrives after one memory
+// latency instead of behind the wave's own 8 KB of weight loads; mv1_act_finish reduces / quantises while the weights are in flight.
+// XB = blocks per wave held in registers: the launcher guarantees K / 256 <= XB * NW.
+struct mv1_src { const float * x; const float * nw; float eps; const char * img; };
+template <int XB> struct mv1_act_regs { f32x4 x[XB], w[XB]; };
+
+template <int NW, int XB>
+static __device__ __forceinline__ void mv1_act_issue(const mv1_src s, int K, mv1_act_regs<XB> & r) {
+    if (s.img) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nb = K >> 8;
+#pragma unroll
+    for (int c = 0; c < XB; ++c) {
+        const int ib = wave + c * NW;
+        r.x[c] = ib < nb ? *(const f32x4 *) (s.x + ib * 256 + 4 * lane) : f32x4{0, 0, 0, 0};
+    }
+    if (s.nw) {
+#pragma unroll
+        for (int c = 0; c < XB; ++c) {
+            const int ib = wave + c * NW;
+            r.w[c] = ib < nb ? *(const f32x4 *) (s.nw + ib * 256 + 4 * lane) : f32x4{0, 0, 0, 0};
+        }
+    }
+}
+// called by every wave of the workgroup; contains workgroup barriers; the image is complete when it returns
+template <int NW, int XB>
+static __device__ __forceinline__ void mv1_act_finish(const mv1_src s, int K, const mv1_act_regs<XB> & r, char * im, double * red) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nb = K >> 8;
+    if (s.img) {                                        // common.hpp layout [qs : K][bsums : K/16 int16][d : K/256 f32] -> this file's layout
+        for (int i = threadIdx.x; i < nb * 16; i += 64 * NW) *(u32x4 *) (im + (i >> 4) * 272 + (i & 15) * 16) = ((const u32x4 *) s.img)[i];
+        for (int i = threadIdx.x; i < nb * 8; i += 64 * NW) {
+            const uint32_t p = *(const uint32_t *) (s.img + K + i * 4);
+            *(int16_t *) (im + mv1_img_bs(nb) + i * 2) = (int16_t) ((int) (int16_t) (p & 0xffff) + (int) (int16_t) (p >> 16));
+            const int b = i >> 3, s0 = (i & 7) * 2;
+            *(int16_t *) (im + mv1_img_b16(nb) + b * 32 + mv1_b16_pos(s0) * 2)     = (int16_t) (p & 0xffff);
+            *(int16_t *) (im + mv1_img_b16(nb) + b * 32 + mv1_b16_pos(s0 + 1) * 2) = (int16_t) (p >> 16);
+        }
+        for (int i = threadIdx.x; i < nb; i += 64 * NW) *(float *) (im + mv1_img_d(nb) + i * 4) = *(const float *) (s.img + K + (K >> 3) + i * 4);
+        __syncthreads();
+        return;
+    }
+    float scale = 1.0f;
+    if (s.nw) {
+        double ss = 0.0;
+#pragma unroll
+        for (int c = 0; c < XB; ++c)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) ss += (double) (r.x[c][i] * r.x[c][i]);
+        ss = wave_sum_f64(ss);
+        if (lane == 0) red[wave] = ss;
+        __syncthreads();
+        double tot = 0.0;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) tot += red[w];
+        const float mean = (float) (tot / (double) K);
+        scale = 1.0f / sqrtf(mean + s.eps);
+    }
+#pragma unroll
+    for (int c = 0; c < XB; ++c) {
+        const int ib = wave + c * NW;
+        if (ib < nb) {
+            f32x4 y = r.x[c];
+            if (s.nw) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) y[i] = (r.x[c][i] * scale) * r.w[c][i];
+            }
+            q8k_block_fast(y, lane, (int8_t *) im + ib * 272, (int16_t *) (im + mv1_img_bs(nb)) + ib * 8, (int16_t *) (im + mv1_img_b16(nb)) + ib * 16, (float *) (im + mv1_img_d(nb)) + ib);
+        }
+    }
+    __syncthreads();
+}
+
+// 24-bit integer multiply / multiply-add: with both operands visibly sign-extended from 24 bits hipcc selects v_mul_i32_i24 / v_mad_i32_i24
+// (full rate; v_mul_lo_u32 / v_mad_u64_u32 are quarter rate) and drops the extension itself.  Operands must fit 24 bits signed.
+static __device__ __forceinline__ int sx24(int a) { return (a << 8) >> 8; }
+static __device__ __forceinline__ int mul24(int a, int b) { return sx24(a) * sx24(b); }
+static __device__ __forceinline__ int mad24(int a, int b, int c) { return sx24(a) * sx24(b) + c; }
+
+static __device__ __forceinline__ float mv1_silu(float x) { return x / (1.0f + expf(-x)); }    // ggml_silu_f32, vec.h:958
+
+// ------------------------------------------------------------------------------------------------ matrices of a launch
+struct mv1_mat { const char * W; size_t w_rs; char * dst; const char * resid; int nrows; int type; int wave_end; };   // waves [prev.wave_end, wave_end)
+struct mv1_dev { mv1_mat m[3]; int nmat; const char * W1; mv1_src src; int K; };
+
+// buffer descriptor of a whole matrix (raw buffer, byte-addressed, bounds = the matrix; built from wave-uniform values only)
+typedef __amdgpu_buffer_rsrc_t mv1_rsrc;
+static __device__ __forceinline__ mv1_rsrc mv1_make_rsrc(const char * p, size_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc((void *) p, (short) 0, (int) (bytes > 0xfffffffful ? 0xffffffffu : (uint32_t) bytes), 0x00020000);
+}
+
+// row groups [g0, g1) of one matrix for wave lw of nw: contiguous ranges (a wave streams one contiguous piece of the matrix)
+static __device__ __forceinline__ void mv1_range(int ngrp, int lw, int nw, int & g0, int & g1) {
+    const int q = ngrp / nw, r = ngrp % nw;
+    g0 = lw * q + (lw < r ? lw : r);
+    g1 = g0 + q + (lw < r ? 1 : 0);
+}
+
+// ================================================================================================= Q4_K
+// 144-B super-block = 16-B header {d, dmin, 12 B of 6-bit scales/mins} + 128 B of nibbles (ggml-common.h:295-305).  FOUR lanes per
+// super-block: lane q owns qs[32q .. 32q+32) = all 32 low nibbles of sub-block 2q and all 32 high nibbles of sub-block 2q+1
+// (dequantize_row_q4_K, ggml-quants.c:1352-1374), so one decode of (scale, min) x 2 serves 64 weights.  A wave covers 16 super-blocks
+// (2304 contiguous bytes = one row of K = 4096) per step; R rows per task (rows R*t .. R*t+R-1 of W, or -- PAIR -- row t of the gate and
+// of the up matrix); DEPTH stages of loads in flight.  The kernel is VALU-issue-bound before it is HBM-bound (rocprofv3 SQ_INSTS_VALU),
+// so everything per-lane that can be a kernel-lifetime constant is one: global loads are `scalar base + lane offset`, LDS reads are
+// `lane base + immediate`, the 6-bit fields are picked with v_perm_b32 under a lane-constant selector, 24-bit multiplies.
+// Requires K % 4096 == 0, 16-byte aligned rows; R == 2 without PAIR requires an even row count (launcher-checked).
+template <int R, int DEPTH, bool PAIR, bool NT, typename PRO>
+static __device__ __forceinline__ void mv1_q4k(const char * __restrict__ W0, const char * __restrict__ W1, size_t w_rs, char * __restrict__ dst, const char * __restrict__ resid,
+                                               int K, int nrows, int lw, int nw, PRO & pro) {
+    constexpr int NBUF = DEPTH + 1;
+    const int lane = threadIdx.x & 63;
+    const int blk = lane >> 2, q = lane & 3;
+    const int nb  = K >> 8;
+    const int nit = nb >> 4;                              // steps per row
+    const int ntask = PAIR ? nrows : nrows / R;
+    int g0, g1; mv1_range(ntask, lw, nw, g0, g1);
+
+    // in-flight bytes per VGPR decide the HBM rate (Little: ~3.5 us loaded latency x 20 GB/s per CU = 70 KB per CU just to break even), so the
+    // 16-byte header is fetched ONCE per block -- lane q takes dword q -- and broadcast inside the quad on the DPP network when it is used
+    const uint32_t voff_h = (uint32_t) blk * 144u + 4u * (uint32_t) q, voff_q = (uint32_t) blk * 144u + 16u + 32u * (uint32_t) q;
+    uint32_t hq[NBUF][R]; u32x4 qa[NBUF][R], qb[NBUF][R];
+    // buffer loads: 128-bit descriptor of the whole matrix + wave-uniform byte offset (SGPR) + lane-constant offset (one VGPR) + immediate --
+    // no per-load address arithmetic, no 64-bit pointer pairs in VGPRs
+    const mv1_rsrc rs0 = mv1_make_rsrc(W0, (size_t) nrows * w_rs), rs1 = mv1_make_rsrc(PAIR ? W1 : W0, (size_t) nrows * w_rs);
+    const uint32_t rs32 = (uint32_t) w_rs;
+    auto issue = [&](int task, int it, int bf) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int row = PAIR ? task : task * R + r;
+            const uint32_t so = (uint32_t) row * rs32 + (uint32_t) it * 2304u;                           // wave-uniform
+            const mv1_rsrc rs = (PAIR && r == 1) ? rs1 : rs0;
+            hq[bf][r] = __builtin_amdgcn_raw_buffer_load_b32(rs, voff_h, so, NT ? 2 : 0);
+            qa[bf][r] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff_q, so, NT ? 2 : 0);
+            qb[bf][r] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff_q + 16u, so, NT ? 2 : 0);
+        }
+    };
+#ifndef MV1_KO
+#define MV1_KO 0
+#endif
+    if (!(MV1_KO & 1)) pro.issue();                     // the activation row is requested before the first weight stage
+    int ig = g0, iit = 0;
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d)
+        if (ig < g1) { issue(ig, iit, d); if (++iit == nit) { iit = 0; ++ig; } }
+
+    if (!(MV1_KO & 1)) pro.finish();                    // builds the activation image in LDS, ends with a workgroup barrier
+    if (g0 >= g1) return;
+
+    // lane-constant LDS addresses of step 0; a step advances them by 16 blocks
+    const char * im = mv1_lds;
+    const char * la = im + blk * 272 + 64 * q;
+    const char * lb = im + mv1_img_bs(nb) + blk * 16 + 4 * q;
+    const char * ld = im + mv1_img_d(nb) + blk * 4;
+    // byte selector for v_perm_b32(hi, lo, sel): bytes (2(q&1), 2(q&1)+1) of `lo` (sub-blocks 0..3) or of `hi` (4..7), upper half zero
+    const uint32_t sel = 0x0c0c0000u | (uint32_t) ((q < 2 ? 0 : 4) + 2 * (q & 1)) | ((uint32_t) ((q < 2 ? 0 : 4) + 2 * (q & 1) + 1) << 8);
+    float acc[R], accm[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) { acc[r] = 0.0f; accm[r] = 0.0f; }
+    int cg = g0, cit = 0;
+    for (;;) {
+#pragma unroll
+        for (int ph = 0; ph < NBUF; ++ph) {
+            if (ig < g1) { issue(ig, iit, (ph + DEPTH) % NBUF); if (++iit == nit) { iit = 0; ++ig; } }
+            if (MV1_KO & 2) {
+#pragma unroll
+                for (int r = 0; r < R; ++r) { const u32x4 Q = qa[ph][r], P = qb[ph][r]; acc[r] += __int_as_float((hq[ph][r] ^ Q[0] ^ Q[1] ^ Q[2] ^ Q[3] ^ P[0] ^ P[1] ^ P[2] ^ P[3]) & 0x3fffffff); }
+            } else {
+                const int so = cit * 16;                                             // first block of this step (wave-uniform)
+                const u32x4 a0 = *(const u32x4 *) (la + so * 272), a1 = *(const u32x4 *) (la + so * 272 + 16);      // activations of sub-block 2q
+                const u32x4 a2 = *(const u32x4 *) (la + so * 272 + 32), a3 = *(const u32x4 *) (la + so * 272 + 48); // ... of sub-block 2q+1
+                const uint32_t bsw = *(const uint32_t *) (lb + so * 16);                                           // their two sums of 32
+                const int bs0 = (int) (int16_t) (bsw & 0xffff), bs1 = (int) (int16_t) (bsw >> 16);
+                const float yd = *(const float *) (ld + so * 4);
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const u32x4 Q = qa[ph][r], P = qb[ph][r];
+                    const uint32_t hw = hq[ph][r];
+                    const uint32_t H[4] = { dpp_u32q<0x00>(hw), dpp_u32q<0x55>(hw), dpp_u32q<0xAA>(hw), dpp_u32q<0xFF>(hw) };       // quad_perm broadcasts
+                    // 6-bit scale / min unpack for all eight sub-blocks at once (get_scale_min_k4, ggml-quants.c:703-710), then this lane's pair
+                    const uint32_t s_lo = H[1] & 0x3f3f3f3fu, s_hi = (H[3] & 0x0f0f0f0fu) | ((H[1] >> 2) & 0x30303030u);
+                    const uint32_t m_lo = H[2] & 0x3f3f3f3fu, m_hi = ((H[3] >> 4) & 0x0f0f0f0fu) | ((H[2] >> 2) & 0x30303030u);
+                    const uint32_t sw = __builtin_amdgcn_perm(s_hi, s_lo, sel), mw = __builtin_amdgcn_perm(m_hi, m_lo, sel);
+                    const int sc0 = sw & 0xff, sc1 = sw >> 8;
+                    const int mn0 = mw & 0xff, mn1 = mw >> 8;
+                    const float dx   = h2f((uint16_t) (H[0] & 0xffff));
+                    const float dmin = h2f((uint16_t) (H[0] >> 16));
+                    int dl = 0, dh = 0;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        dl = dot4(Q[k] & 0x0f0f0f0fu, a0[k], dl); dh = dot4((Q[k] >> 4) & 0x0f0f0f0fu, a2[k], dh);
+                        dl = dot4(P[k] & 0x0f0f0f0fu, a1[k], dl); dh = dot4((P[k] >> 4) & 0x0f0f0f0fu, a3[k], dh);
+                    }
+                    // |dl|, |dh| <= 32 * 15 * 128 and the scales are 6-bit: the products fit 24-bit multiplies
+                    const int isum = mad24(sc0, dl, mul24(sc1, dh));
+                    const int msum = mad24(mn0, bs0, mul24(mn1, bs1));
+                    acc[r]  = fmaf(dx * yd, (float) isum, acc[r]);
+                    accm[r] = fmaf(dmin * yd, (float) msum, accm[r]);
+                }
+            }
+            if (cit == nit - 1) {                          // task finished: butterfly, epilogue, store
+                if (PAIR) {
+                    const float gsum = wave_sum_f32(acc[0] - accm[0]), usum = wave_sum_f32(acc[R - 1] - accm[R - 1]);
+                    if (lane == 0) *(float *) (dst + (size_t) cg * 4) = mv1_silu(gsum) * usum;
+                } else {
+#pragma unroll
+                    for (int r = 0; r < R; ++r) {
+                        const int row = cg * R + r;
+                        float s = wave_sum_f32(acc[r] - accm[r]);
+                        if (lane == 0) {
+                            if (resid) s += *(const float *) (resid + (size_t) row * 4);
+                            *(float *) (dst + (size_t) row * 4) = s;
+                        }
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < R; ++r) { acc[r] = 0.0f; accm[r] = 0.0f; }
+            }
+            if (++cit == nit) { cit = 0; ++cg; }
+            if (cg >= g1) return;
+        }
+    }
+}
+
+// ================================================================================================= Q6_K
+// 210-B super-block {ql[128], qh[64], int8 scales[16], f16 d} (ggml-common.h:330-335): only 2-byte aligned.  FOUR lanes per super-block:
+// lane (n, hf) owns l in [16hf, 16hf+16) of the 128-half n: ql[64n+l], ql[64n+32+l], qh[32n+l] -> 4 x 16 six-bit weights at
+// y[128n + 32m + l], m = 0..3, all with scale index 8n + hf + 2m (dequantize_row_q6_K, ggml-quants.c:1762-1791).  A wave covers 16
+// super-blocks (3360 contiguous bytes = one row of K = 4096) per step.  The pieces are hardware-unaligned 16-byte loads.  The -32 offset of
+// the 6-bit values is not applied per weight (3 VALU per dword) but per sub-block of 16 through the activation's bsums:
+// sum((q - 32) * a) = sum(q * a) - 32 * bsum -- the same integers.
+typedef u32x4 __attribute__((aligned(2))) u32x4_a2;
+typedef uint32_t __attribute__((aligned(2))) u32_a2;
+
+template <int R, int DEPTH, bool PAIR, typename PRO>
+static __device__ __forceinline__ void mv1_q6k(const char * __restrict__ W0, const char * __restrict__ W1, size_t w_rs, char * __restrict__ dst, const char * __restrict__ resid,
+                                               int K, int nrows, int lw, int nw, PRO & pro) {
+    constexpr int NBUF = DEPTH + 1;
+    const int lane = threadIdx.x & 63;
+    const int blk = lane >> 2, n = (lane >> 1) & 1, hf = lane & 1;
+    const int nb  = K >> 8;
+    const int nit = nb >> 4;
+    const int ntask = PAIR ? nrows : nrows / R;
+    int g0, g1; mv1_range(ntask, lw, nw, g0, g1);
+
+    const uint32_t vb = (uint32_t) blk * 210u;
+    const uint32_t voff_l = vb + 64u * n + 16u * hf, voff_h = vb + 128u + 32u * n + 16u * hf;
+    u32x4 qla[NBUF][R], qlb[NBUF][R], qh[NBUF][R]; uint32_t sc[NBUF][R], dw[NBUF][R];     // sc: lane (n, hf) fetches scale dword 2n + hf
+    const mv1_rsrc rs0 = mv1_make_rsrc(W0, (size_t) nrows * w_rs), rs1 = mv1_make_rsrc(PAIR ? W1 : W0, (size_t) nrows * w_rs);
+    const uint32_t rs32 = (uint32_t) w_rs;
+    const uint32_t voff_s = vb + 192u + 4u * (uint32_t) (lane & 3);
+    auto issue = [&](int task, int it, int bf) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int row = PAIR ? task : task * R + r;
+            const uint32_t so = (uint32_t) row * rs32 + (uint32_t) it * 3360u;                           // wave-uniform
+            const mv1_rsrc rs = (PAIR && r == 1) ? rs1 : rs0;
+            qla[bf][r] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff_l, so, 0);
+            qlb[bf][r] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff_l + 32u, so, 0);
+            qh[bf][r]  = __builtin_amdgcn_raw_buffer_load_b128(rs, voff_h, so, 0);
+            sc[bf][r]  = __builtin_amdgcn_raw_buffer_load_b32(rs, voff_s, so, 0);
+            dw[bf][r]  = __builtin_amdgcn_raw_buffer_load_b16(rs, vb + 208u, so, 0);
+        }
+    };
+    if (!(MV1_KO & 1)) pro.issue();
+    int ig = g0, iit = 0;
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d)
+        if (ig < g1) { issue(ig, iit, d); if (++iit == nit) { iit = 0; ++ig; } }
+
+    if (!(MV1_KO & 1)) pro.finish();
+    if (g0 >= g1) return;
+
+    const char * im = mv1_lds;
+    const char * la = im + blk * 272 + 128 * n + 16 * hf;
+    const char * lb = im + mv1_img_b16(nb) + blk * 32 + (8 * n + 4 * hf) * 2;
+    const char * ld = im + mv1_img_d(nb) + blk * 4;
+    // scales[8n + hf + 2m], m = 0..3: bytes (hf, hf+2) of scale dwords 2n and 2n+1
+    const uint32_t sel = (uint32_t) hf | ((uint32_t) (hf + 2) << 8) | ((uint32_t) (4 + hf) << 16) | ((uint32_t) (6 + hf) << 24);
+    float acc[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) acc[r] = 0.0f;
+    int cg = g0, cit = 0;
+    for (;;) {
+#pragma unroll
+        for (int ph = 0; ph < NBUF; ++ph) {
+            if (ig < g1) { issue(ig, iit, (ph + DEPTH) % NBUF); if (++iit == nit) { iit = 0; ++ig; } }
+            {
+                const int so = cit * 16;
+                u32x4 a[4];
+#pragma unroll
+                for (int m = 0; m < 4; ++m) a[m] = *(const u32x4 *) (la + so * 272 + 32 * m);
+                const u32x2 bq = *(const u32x2 *) (lb + so * 32);
+                const int bs[4] = { (int) (int16_t) (bq[0] & 0xffff), (int) (int16_t) (bq[0] >> 16), (int) (int16_t) (bq[1] & 0xffff), (int) (int16_t) (bq[1] >> 16) };
+                const float yd = *(const float *) (ld + so * 4);
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const uint32_t sq = sc[ph][r];                                  // quad_perm [0,0,2,2] / [1,1,3,3]: scale dwords 2n and 2n+1
+                    const uint32_t scw = __builtin_amdgcn_perm(dpp_u32q<0xF5>(sq), dpp_u32q<0xA0>(sq), sel);
+                    const float dx = h2f((uint16_t) dw[ph][r]);
+                    int d[4] = { 0, 0, 0, 0 };
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const uint32_t A = qla[ph][r][k], B = qlb[ph][r][k], H = qh[ph][r][k];
+                        d[0] = dot4((A & 0x0f0f0f0fu)        | ((H << 4) & 0x30303030u), a[0][k], d[0]);
+                        d[1] = dot4((B & 0x0f0f0f0fu)        | ((H << 2) & 0x30303030u), a[1][k], d[1]);
+                        d[2] = dot4(((A >> 4) & 0x0f0f0f0fu) | (H & 0x30303030u),        a[2][k], d[2]);
+                        d[3] = dot4(((B >> 4) & 0x0f0f0f0fu) | ((H >> 2) & 0x30303030u), a[3][k], d[3]);
+                    }
+                    int isum = 0;
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) {
+                        const int scm = (int) (int8_t) ((scw >> (8 * m)) & 0xff);
+                        // |d - 32 bs| <= 16 * 63 * 128 + 32 * 2048: 24-bit multiplies
+                        isum = mad24(scm, mad24(bs[m], -32, d[m]), isum);
+                    }
+                    acc[r] = fmaf(dx * yd, (float) isum, acc[r]);
+                }
+            }
+            if (cit == nit - 1) {
+                if (PAIR) {
+                    const float gsum = wave_sum_f32(acc[0]), usum = wave_sum_f32(acc[R - 1]);
+                    if (lane == 0) *(float *) (dst + (size_t) cg * 4) = mv1_silu(gsum) * usum;
+                } else {
+#pragma unroll
+                    for (int r = 0; r < R; ++r) {
+                        const int row = cg * R + r;
+                        float s = wave_sum_f32(acc[r]);
+                        if (lane == 0) {
+                            if (resid) s += *(const float *) (resid + (size_t) row * 4);
+                            *(float *) (dst + (size_t) row * 4) = s;
+                        }
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < R; ++r) acc[r] = 0.0f;
+            }
+            if (++cit == nit) { cit = 0; ++cg; }
+            if (cg >= g1) return;
+        }
+    }
+}
+
+// ================================================================================================= kernel
+// TM: bit0 = Q4_K body compiled in, bit1 = Q6_K.  PAIR: m[0] = gate, W1 = up (same type / shape), epilogue silu(g) * u.
+template <int NW, int XB> struct mv1_pro {
+    const mv1_src s; int K; double * red; mv1_act_regs<XB> r;
+    __device__ __forceinline__ void issue()  { mv1_act_issue<NW, XB>(s, K, r); }
+    __device__ __forceinline__ void finish() { mv1_act_finish<NW, XB>(s, K, r, mv1_lds, red); }
+};
+
+template <int NW, int XB, int R, int DEPTH, int TM, bool PAIR, bool NT>
+__global__ void __launch_bounds__(64 * NW) k_mv1(const mv1_dev a) {
+    __shared__ double red[NW];
+    const int wave = __builtin_amdgcn_readfirstlane(blockIdx.x * NW + (threadIdx.x >> 6));
+    int mi_ = 0, w0 = 0;
+    if (!PAIR) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) if (i + 1 < a.nmat && wave >= a.m[i].wave_end) { mi_ = i + 1; w0 = a.m[i].wave_end; }
+    }
+    const mv1_mat M = mi_ == 0 ? a.m[0] : (mi_ == 1 ? a.m[1] : a.m[2]);
+    const int lw = wave - w0, nw = M.wave_end - w0;
+    mv1_pro<NW, XB> pro = { a.src, a.K, red, {} };
+    if (TM == 1 || ((TM & 1) && M.type == GGML_TYPE_Q4_K)) mv1_q4k<R, DEPTH, PAIR, NT>(M.W, a.W1, M.w_rs, M.dst, M.resid, a.K, M.nrows, lw, nw, pro);
+    else                                                    mv1_q6k<R, DEPTH, PAIR>(M.W, a.W1, M.w_rs, M.dst, M.resid, a.K, M.nrows, lw, nw, pro);
+}
+
+} // namespace mi
+
+// ------------------------------------------------------------------------------------------------ host side
+namespace mi {
+
+// measured on MI355X (tools/mmv_lab.hip, replayed hipGraph, rotating weights): 4096 waves, one stage of loads in flight per wave; the
+// gate / up pair as 512 workgroups of 8 waves with two rows per task, everything else as 256 workgroups of 16 waves (ONE image build per CU)
+// with one row per task
+static const int MV1_WAVES = 4096;
+
+bool mmv1_ok(const mv1_args & a) {
+    if (a.nmat < 1 || a.nmat > 3 || a.K <= 0 || a.K % 4096 != 0 || a.K > 12288) return false;
+    if (a.W_up && a.nmat != 1) return false;
+    for (int i = 0; i < a.nmat; ++i) {
+        const mmv_mat & m = a.m[i];
+        if (m.type != GGML_TYPE_Q4_K && m.type != GGML_TYPE_Q6_K) return false;
+        if (m.nrows <= 0 || (uint64_t) m.nrows * m.w_rs > 0xffffffffull) return false;
+        if (m.type == GGML_TYPE_Q4_K && (m.w_rs % 16 != 0 || ((uintptr_t) m.W & 15) != 0)) return false;
+        if (m.type == GGML_TYPE_Q6_K && (m.w_rs % 2 != 0 || ((uintptr_t) m.W & 1) != 0)) return false;
+        if (((uintptr_t) m.dst & 3) != 0 || ((uintptr_t) m.resid & 3) != 0) return false;
+    }
+    if (a.W_up && (((uintptr_t) a.W_up & 15) != 0 || a.m[0].resid)) return false;
+    if (a.img) return ((uintptr_t) a.img & 15) == 0;
+    return a.x && ((uintptr_t) a.x & 15) == 0 && ((uintptr_t) a.norm_w & 15) == 0;
+}
+
+template <int NW, int XB, int R, bool PAIR>
+static void mv1_go(const mv1_dev & d, int tm, int grid, hipStream_t st) {
+    const size_t lds = mv1_image_bytes(d.K);
+    if (tm == 1)      k_mv1<NW, XB, R, 1, 1, PAIR, false><<<dim3(grid), dim3(64 * NW), lds, st>>>(d);
+    else if (tm == 2) k_mv1<NW, XB, R, 1, 2, PAIR, false><<<dim3(grid), dim3(64 * NW), lds, st>>>(d);
+    else if (!PAIR)   k_mv1<NW, XB, R, 1, 3, false, false><<<dim3(grid), dim3(64 * NW), lds, st>>>(d);
+    else { fprintf(stderr, "[mi355x] mmv1: a gate / up pair of mixed types\n"); abort(); }
+}
+
+void mmv1(const mv1_args & a, hipStream_t st) {
+    if (!mmv1_ok(a)) { fprintf(stderr, "[mi355x] mmv1: unsupported arguments (K=%lld)\n", (long long) a.K); abort(); }
+    const bool pair = a.W_up != nullptr;
+    const int nw_wg = pair ? 8 : 16;
+    double bytes[3], total = 0; int64_t tasks = 0; int tm = 0;
+    for (int i = 0; i < a.nmat; ++i) {
+        bytes[i] = (double) a.m[i].nrows * (double) (a.m[i].type == GGML_TYPE_Q4_K ? 144 : 210) * (double) (a.K / 256);
+        total += bytes[i]; tasks += a.m[i].nrows;
+        tm |= a.m[i].type == GGML_TYPE_Q4_K ? 1 : 2;
+    }
+    int64_t grid = (tasks + nw_wg - 1) / nw_wg;
+    if (grid > MV1_WAVES / nw_wg) grid = MV1_WAVES / nw_wg;
+    const int nwaves = (int) grid * nw_wg;
+    mv1_dev d;
+    d.nmat = a.nmat; d.K = (int) a.K; d.W1 = (const char *) a.W_up;
+    d.src = { a.img ? nullptr : a.x, a.img ? nullptr : a.norm_w, a.eps, (const char *) a.img };
+    int acc_w = 0; double acc_b = 0;
+    for (int i = 0; i < 3; ++i) {
+        if (i >= a.nmat) { d.m[i] = d.m[0]; d.m[i].wave_end = nwaves; continue; }
+        acc_b += bytes[i];
+        int end = i == a.nmat - 1 ? nwaves : (int) (nwaves * (acc_b / total) + 0.5);
+        if (end <= acc_w) end = acc_w + 1;                                   // every matrix gets at least one wave
+        if (end > nwaves - (a.nmat - 1 - i)) end = nwaves - (a.nmat - 1 - i);
+        d.m[i] = { (const char *) a.m[i].W, a.m[i].w_rs, (char *) a.m[i].dst, (const char *) a.m[i].resid, (int) a.m[i].nrows, a.m[i].type, end };
+        acc_w = end;
+    }
+    const int nb = (int) (a.K / 256);
+    if (pair) { if (nb <= 16) mv1_go<8, 2, 2, true>(d, tm, (int) grid, st); else mv1_go<8, 6, 2, true>(d, tm, (int) grid, st); }
+    else      { if (nb <= 16) mv1_go<16, 1, 1, false>(d, tm, (int) grid, st); else mv1_go<16, 3, 1, false>(d, tm, (int) grid, st); }
+}
+
+} // namespace mi

@@ -437,8 +437,16 @@ def test_full_size_properties(pkg, be, name, M, K):
     rows = rng.choice(M, 64, replace=False)
     want = orc.mul_mat(ty, wv[rows], xv)
     assert nmse(y2[:, rows], want) < 1e-9
-    y0, y1 = run(wv, xv[:1]), run(wv, xv[1:])
-    assert np.array_equal(y2[0], y0[0]) and np.array_equal(y2[1], y1[0])
+    # one column runs on the batch-1 decode kernels (mmv1.hip), two on the multi-column family (mmvk.hip): the integer sub-block sums are
+    # the same, the order of the f32 additions across super-blocks is not -- bit-equality holds inside a family
+    be.set_option("mv1", 0)
+    try:
+        y0, y1 = run(wv, xv[:1]), run(wv, xv[1:])
+        assert np.array_equal(y2[0], y0[0]) and np.array_equal(y2[1], y1[0])
+    finally:
+        be.set_option("mv1", 1)
+    y0 = run(wv, xv[:1])
+    assert nmse(y0[:, rows], want[:1]) < 1e-9 and nmse(y0[0], y2[0]) < 1e-11
     yp = run(wv[perm], xv[:1])
     assert np.array_equal(yp[0], y0[0][perm])
     assert np.array_equal(y0[0][:1024], y0[0][1024:2048])      # identical weight rows give identical outputs wherever they sit
