@@ -295,7 +295,7 @@ static size_t graph_rope_scratch_need(const ggml_cgraph * g) {
     size_t need = 0;
     for (int i = 0; i < g->n_nodes; ++i) {
         const ggml_tensor * n = g->nodes[i];
-        if (n->op != GGML_OP_ROPE || n->ne[2] < ROPE_TABLE_MIN_TOKENS) continue;
+        if (n->op != GGML_OP_ROPE || (n->ne[2] < ROPE_TABLE_MIN_TOKENS && n->ne[2] != 1)) continue;     // (one token: the table of fattn_one.hip)
         const size_t b = (size_t) n->ne[2] * (size_t) n->ne[0] * 4;
         if (b > need) need = b;
     }
@@ -1297,9 +1297,26 @@ static void compute_node(exec_state & s, int i) {
         case GGML_OP_FLASH_ATTN_EXT: {
             fattn_args f; tdesc m;
             fill_fattn_args(n, f, m);
+            const bool with_pre = s.pq.fa == i;
+            if (with_pre) f.pre = &s.pq.pre;
+            // one token over a shallow cache: the latency-optimised kernel (fattn_one.hip) takes the token's (cos, sin) from a table that is
+            // computed once per graph, and leaves the Q8_K image to wo's own prologue
+            bool one = false;
+            if (with_pre && fattn_one_ok(f) && s.c->rope_scratch_bytes >= (size_t) n->src[0]->ne[0] * 4) {
+                const fattn_pre & P = s.pq.pre;
+                const int D = (int) n->src[0]->ne[0];
+                const bool valid = s.rt.pos == (const void *) P.pos && s.rt.ff == (const void *) P.ff && s.rt.T == 1 && s.rt.D == D && memcmp(&s.rt.rp, &P.rp, sizeof(rope_params)) == 0;
+                if (!valid) {
+                    prof_scope ps(s, "rope", 0);
+                    rope_table(P.pos, P.ff, P.rp, 1, D, (float *) s.c->rope_scratch, s.st); ++s.n_kernels;
+                    s.rt.pos = P.pos; s.rt.ff = P.ff; s.rt.T = 1; s.rt.D = D; s.rt.rp = P.rp;
+                }
+                f.rope_tab = (const float *) s.c->rope_scratch;
+                one = true;
+            }
             // epilogue fusion: when the attention output only feeds K-quant mat-vecs (wo), emit its Q8_K image here
             const ggml_tensor * xuse = nullptr;
-            if (s.c->opt_fusion && n->ne[3] == 1 && n->ne[2] <= 32 && n_users(s, n) > 0 && !(n->flags & GGML_TENSOR_FLAG_OUTPUT) &&
+            if (!one && s.c->opt_fusion && n->ne[3] == 1 && n->ne[2] <= 32 && n_users(s, n) > 0 && !(n->flags & GGML_TENSOR_FLAG_OUTPUT) &&
                 rms_norm_mul_quant_ok(n->ne[0] * n->ne[1]) && fattn_can_emit_image(f)) {
                 bool ok = true;
                 for (int u : s.users[n]) {
@@ -1312,8 +1329,6 @@ static void compute_node(exec_state & s, int i) {
                 if (!ok) xuse = nullptr;
             }
             if (xuse) f.img = s.c->act_scratch;
-            const bool with_pre = s.pq.fa == i;
-            if (with_pre) f.pre = &s.pq.pre;
             // prefill: the attention output [D, H, nq, ns] read as [H*D, nq*ns] rows by wo's GEMM -> emit those rows in f16 from the kernel
             const ggml_tensor * xg16 = nullptr;
             if (!xuse && fattn_uses_mma(f) && n->nb[1] == (size_t) n->ne[0] * 4 && n->nb[2] == (size_t) n->ne[0] * n->ne[1] * 4 &&

@@ -150,7 +150,11 @@ struct fattn_args {
     void * img = nullptr;    // optional: also emit Q8_K images of the output rows [nh*D] (one per (seq, query row))
     const fattn_pre * pre = nullptr;   // optional q/k/v pre-stage (decode)
     uint16_t * out16 = nullptr; size_t out16_rs = 0; bool write_f32 = true;   // prefill kernel: also / only emit f16 rows [nh*D] per (seq, query)
+    const float * rope_tab = nullptr;  // (cos, sin) pairs [D/2] of the token (rope_table), required by the one-token kernel (fattn_one_ok)
 };
+bool   fattn_one_ok(const fattn_args & a);       // one token, one sequence, pre-stage, <= 256 cache rows: the latency-optimised kernel (fattn_one.hip) runs
+// (cos, sin) * mscale of every (token, rotation pair): tab[T][D/2][2], what ggml_rope_cache_init / rope_yarn give for these positions
+void   rope_table(const int32_t * pos, const float * ff, const rope_params & rp, int T, int D, float * tab, hipStream_t st);
 size_t fattn_scratch_bytes(const fattn_args & a);
 bool   fattn_can_emit_image(const fattn_args & a);
 bool   fattn_pre_ok(const fattn_args & a);

@@ -530,6 +530,11 @@ void flash_attn_ext_f16(const fattn_args & f, hipStream_t st) {
         a.pre = { (const char *) p.qraw, p.q_hs, (const char *) p.kraw, p.k_hs, (const char *) p.vraw, p.v_hs, p.qw, p.kw, p.pos, p.ff, p.eps, make_rope_dev(p.rp),
                   (char *) p.kcache, p.kc_rs, (char *) p.vcache, p.vc_rs, (const char *) p.kidx, (const char *) p.vidx, p.idx_is64 };
     }
+    if (f.pre && f.rope_tab && fattn_one_ok(f)) {                    // tg at shallow depth: the latency-optimised one-token kernel
+        a.nsplit = 1; a.part = nullptr; a.tile_map = nullptr; a.map_nqb = 0;
+        flash_attn_one(a, (int) f.q.ne[0], f.rope_tab, st);
+        return;
+    }
     // batches of query rows go to the matrix-core kernel (fattn_mma.hip); single / few rows stay on the streaming decode kernel
     if (fa_use_mma(f)) {
         a.tile_map = nullptr; a.map_nqb = (a.nq + 31) / 32;

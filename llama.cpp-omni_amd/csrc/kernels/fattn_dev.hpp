@@ -38,5 +38,7 @@ bool fattn_mma_ok(int64_t nkv);
 // decode shape on the matrix cores (k_fattn_gqa): a.qpw tokens x gq heads of a KV head (<= 32 pairs) as one query tile, nw = 4 or 8 waves,
 // KV range in a.nsplit slices (-> a.part when > 1), optional a.pre / a.img
 void flash_attn_ext_gqa(const fa_dev & a, int D, int nw, hipStream_t st);
+// one token of one sequence over <= 256 cache rows with the pre-stage (fattn_one.hip); rope_tab: the token's (cos, sin) table
+void flash_attn_one(const fa_dev & a, int D, const float * rope_tab, hipStream_t st);
 
 } // namespace mi

@@ -73,6 +73,12 @@ __global__ void __launch_bounds__(256) k_norm_rope(const nr_dev a) {
     }
 }
 
+void rope_table(const int32_t * pos, const float * ff, const rope_params & rp, int T, int D, float * tab, hipStream_t st) {
+    const int n = T * (D / 2);
+    if (n <= 0) return;
+    k_rope_table<<<dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, st>>>(pos, ff, make_rope_dev(rp), T, D / 2, tab);
+}
+
 void norm_rope_store(const norm_rope_args & f, hipStream_t st) {
     if (f.D == 0 || f.T == 0 || f.njobs == 0) return;
     nr_dev a;
