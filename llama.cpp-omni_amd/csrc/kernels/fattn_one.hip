@@ -47,8 +47,22 @@ static __device__ __forceinline__ double wave_sum_f64o(double v) {
 
 constexpr int FA1_NKV = 256;                      // cache rows a workgroup holds in registers
 
+// compact argument block (one scalar-load burst): the general fa_dev is ~450 bytes and reading it piecemeal costs round trips
+struct fa1_dev {
+    const char * qraw, * kraw, * vraw; const float * qw, * kw, * tab;        // pre-stage inputs
+    char * kcache, * vcache; const char * kidx, * vidx;                      // cache tables + row index of the new token (i64 or i32)
+    const char * k, * v, * mask; const float * sinks; char * dst;
+    int q_hs, k_hs, v_hs, kc_rs, vc_rs, knb1, knb2, vnb1, vnb2, mnb2, mne2, dnb1;
+    int nkv, gq, neox, n_head_log2;
+    float eps, scale, max_bias, logit_softcap, m0, m1;
+};
+
+static __device__ __forceinline__ __amdgpu_buffer_rsrc_t fa1_rsrc(const void * p, int bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc((void *) p, (short) 0, bytes, 0x00020000);
+}
+
 template <int D>
-__global__ void __launch_bounds__(256) k_fattn_one(const fa_dev a, const float * __restrict__ tab) {
+__global__ void __launch_bounds__(256) k_fattn_one(const fa1_dev a) {
     constexpr int KCH = D / 32;                   // 16-B K chunks per lane (a quarter row)
     constexpr int NG  = FA1_NKV / 16 / 4;         // 16-row granules per wave
     constexpr int DPW = D / 4;                    // output dims per wave
@@ -60,58 +74,54 @@ __global__ void __launch_bounds__(256) k_fattn_one(const fa_dev a, const float *
 
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int h = blockIdx.x, ikv = h / a.gq;
-    const fa_pre & P = a.pre;
     const int nkv = a.nkv < FA1_NKV ? a.nkv : FA1_NKV;
 
-    // ---------------------------------------------------------------- 1. request everything
-    const int64_t krow = P.idx_is64 ? *(const int64_t *) P.kidx : (int64_t) *(const int32_t *) P.kidx;     // cache rows of the new token (scalar loads)
-    const int64_t vrow = P.idx_is64 ? *(const int64_t *) P.vidx : (int64_t) *(const int32_t *) P.vidx;
-    // q head (wave 0) / k head (wave 1): rotation pair ip = lane
-    const bool neox = P.rd.mode & GGML_ROPE_TYPE_NEOX;
-    const bool act  = lane < HALF;
-    const int  e0 = neox ? lane : 2 * lane, e1 = neox ? lane + HALF : 2 * lane + 1;
-    float x0 = 0, x1 = 0, w0 = 0, w1 = 0, tc = 1, ts = 0, xv[D / 64];
-    if (wave < 2 && act) {
-        const char * xr = wave == 0 ? P.qraw + h * P.q_hs : P.kraw + ikv * P.k_hs;
-        const float * w = wave == 0 ? P.qw : P.kw;
-        x0 = *(const float *) (xr + e0 * 4); x1 = *(const float *) (xr + e1 * 4);
-        w0 = w[e0]; w1 = w[e1];
-        tc = tab[2 * lane]; ts = tab[2 * lane + 1];
-    }
-    if (wave == 2) {
-#pragma unroll
-        for (int i = 0; i < D / 64; ++i) xv[i] = *(const float *) (P.vraw + ikv * P.v_hs + (lane + 64 * i) * 4);
-    }
+    // ---------------------------------------------------------------- 1. request everything: one burst of vector loads, no wait in between
+    // (buffer loads with exact bounds instead of branches or clamps: an out-of-range element reads as zero.  The row indices are fetched
+    //  as VECTOR loads too: a scalar load of them would sit in front of every later kernarg read -- one more serial round trip.)
+    const bool act = lane < HALF;
+    const int  e0 = a.neox ? lane : 2 * lane, e1 = a.neox ? lane + HALF : 2 * lane + 1;
+    const __amdgpu_buffer_rsrc_t xrs = fa1_rsrc(wave == 0 ? a.qraw + h * a.q_hs : (wave == 1 ? a.kraw + ikv * a.k_hs : a.vraw + ikv * a.v_hs), wave < 3 ? D * 4 : 0);
+    const __amdgpu_buffer_rsrc_t wrs = fa1_rsrc(wave == 0 ? a.qw : a.kw, wave < 2 ? D * 4 : 0);
+    const __amdgpu_buffer_rsrc_t trs = fa1_rsrc(a.tab, wave < 2 ? D * 4 : 0);
+    // waves 0 / 1: rotation pair `lane` of the q / k head (elements e0, e1); wave 2: elements lane, lane + 64 of the v head
+    const uint32_t xo0 = wave < 2 ? (act ? e0 * 4 : D * 4) : lane * 4, xo1 = wave < 2 ? (act ? e1 * 4 : D * 4) : (lane + 64) * 4;
+    const float x0 = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(xrs, xo0, 0, 0)), x1 = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(xrs, xo1, 0, 0));
+    const float w0 = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(wrs, xo0, 0, 0)), w1 = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(wrs, xo1, 0, 0));
+    const u32x2 tcs = __builtin_amdgcn_raw_buffer_load_b64(trs, act ? lane * 8 : D * 4, 0, 0);
     // mask row of this head: lane owns rows lane + 64 i
-    const uint16_t * mrow = a.mask ? (const uint16_t *) (a.mask + (h % (int) a.mne2) * a.mnb2) : nullptr;
+    const __amdgpu_buffer_rsrc_t mrs = fa1_rsrc(a.mask ? a.mask + (h % a.mne2) * a.mnb2 : a.mask, a.mask ? nkv * 2 : 0);
     uint16_t mraw[FA1_NKV / 64];
 #pragma unroll
-    for (int i = 0; i < FA1_NKV / 64; ++i) { const int kv = lane + 64 * i; mraw[i] = (mrow && kv < nkv) ? mrow[kv] : (uint16_t) 0; }
+    for (int i = 0; i < FA1_NKV / 64; ++i) mraw[i] = __builtin_amdgcn_raw_buffer_load_b16(mrs, (lane + 64 * i) * 2, 0, 0);
+    const int krow = (int) __builtin_amdgcn_raw_buffer_load_b32(fa1_rsrc(a.kidx, 4), 0, 0, 0);     // (little-endian low half of an i64 index)
+    const int vrow = (int) __builtin_amdgcn_raw_buffer_load_b32(fa1_rsrc(a.vidx, 4), 0, 0, 0);
     // K: granule g = wave + 4 i, row g * 16 + (lane >> 2), lane quarter dq = lane & 3
     const int r16 = lane >> 2, dq = lane & 3;
-    const char * kbase = a.k + ikv * a.knb2, * vbase = a.v + ikv * a.vnb2;
+    const __amdgpu_buffer_rsrc_t krs = fa1_rsrc(a.k + ikv * a.knb2, (nkv - 1) * a.knb1 + D * 2);
+    const __amdgpu_buffer_rsrc_t vrs = fa1_rsrc(a.v + ikv * a.vnb2, (nkv - 1) * a.vnb1 + D * 2);
+    const uint32_t kvo = (uint32_t) r16 * (uint32_t) a.knb1 + (uint32_t) dq * (D / 2);
     u32x4 kk[NG][KCH];
 #pragma unroll
     for (int i = 0; i < NG; ++i) {
-        int row = (wave + 4 * i) * 16 + r16; row = row < nkv ? row : nkv - 1;
+        const uint32_t so = (uint32_t) ((wave + 4 * i) * 16) * (uint32_t) a.knb1;                      // wave-uniform
 #pragma unroll
-        for (int c = 0; c < KCH; ++c) kk[i][c] = *(const u32x4 *) (kbase + (int64_t) row * a.knb1 + dq * (D / 2) + c * 16);
+        for (int c = 0; c < KCH; ++c) kk[i][c] = __builtin_amdgcn_raw_buffer_load_b128(krs, kvo + 16u * c, so, 0);
     }
     // V: this wave's DPW output dims of every row; lane (rs, dp): row j * RPI + rs, dims wave * DPW + 2 dp, +1
     const int rs = lane / LPR, dp = lane % LPR;
+    const uint32_t vvo = (uint32_t) rs * (uint32_t) a.vnb1 + (uint32_t) (wave * DPW + 2 * dp) * 2u;
     uint32_t vv[NJ];
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-        int row = j * RPI + rs; row = row < nkv ? row : nkv - 1;
-        vv[j] = *(const uint32_t *) (vbase + (int64_t) row * a.vnb1 + (wave * DPW + 2 * dp) * 2);
-    }
+    for (int j = 0; j < NJ; ++j) vv[j] = __builtin_amdgcn_raw_buffer_load_b32(vrs, vvo, (uint32_t) (j * RPI) * (uint32_t) a.vnb1, 0);
 
     // ---------------------------------------------------------------- 2. q chain, k chain + store, v store (norm_rope_dev.hpp arithmetic)
     if (wave < 2) {
+        const float tc = __uint_as_float(tcs[0]), ts = __uint_as_float(tcs[1]);
         double ss = (double) (x0 * x0) + (double) (x1 * x1);
         ss = wave_sum_f64o(ss);
-        const float mean  = (float) (ss / (double) D);
-        const float scale = 1.0f / sqrtf(mean + P.eps);
+        const float mean  = (float) (ss * (1.0 / D));                                // D is a power of two: the same double as ss / D
+        const float scale = 1.0f / sqrtf(mean + a.eps);
         const float v0 = (x0 * scale) * w0, v1 = (x1 * scale) * w1;
         const float r0 = v0 * tc - v1 * ts, r1 = v0 * ts + v1 * tc;
         if (act) {
@@ -119,24 +129,26 @@ __global__ void __launch_bounds__(256) k_fattn_one(const fa_dev a, const float *
             if (wave == 0) { qf[e0] = h2f(h0); qf[e1] = h2f(h1); }                 // q_to_vec_dot rounding (ops.cpp:8040)
             else {
                 kc[e0] = h2f(h0); kc[e1] = h2f(h1);
-                if (h % a.gq == 0) { uint16_t * kr = (uint16_t *) (P.kcache + krow * P.kc_rs) + ikv * D; kr[e0] = h0; kr[e1] = h1; }
+                if (h % a.gq == 0) { uint16_t * kr = (uint16_t *) (a.kcache + (int64_t) krow * a.kc_rs) + ikv * D; kr[e0] = h0; kr[e1] = h1; }
             }
         }
     } else if (wave == 2) {
-#pragma unroll
-        for (int i = 0; i < D / 64; ++i) {
-            const uint16_t hv = f2h(xv[i]);
-            vc[lane + 64 * i] = h2f(hv);
-            if (h % a.gq == 0) ((uint16_t *) (P.vcache + vrow * P.vc_rs) + ikv * D)[lane + 64 * i] = hv;
+        const uint16_t hv0 = f2h(x0), hv1 = f2h(x1);
+        vc[lane] = h2f(hv0);
+        if (D > 64) vc[lane + 64] = h2f(hv1);
+        if (h % a.gq == 0) {
+            uint16_t * vr = (uint16_t *) (a.vcache + (int64_t) vrow * a.vc_rs) + ikv * D;
+            vr[lane] = hv0;
+            if (D > 64) vr[lane + 64] = hv1;
         }
     }
     // mask values + liveness (every wave computes the same)
-    const float slope = a.max_bias > 0.0f ? ((uint32_t) h < a.n_head_log2 ? powf(a.m0, (float) (h + 1)) : powf(a.m1, (float) (2 * (h - (int) a.n_head_log2) + 1))) : 1.0f;
+    const float slope = a.max_bias > 0.0f ? (h < a.n_head_log2 ? powf(a.m0, (float) (h + 1)) : powf(a.m1, (float) (2 * (h - a.n_head_log2) + 1))) : 1.0f;
     float mv[FA1_NKV / 64]; int n_live = 0;
 #pragma unroll
     for (int i = 0; i < FA1_NKV / 64; ++i) {
         const int kv = lane + 64 * i;
-        float m = mrow ? slope * h2f(mraw[i]) : 0.0f;
+        float m = a.mask ? slope * h2f(mraw[i]) : 0.0f;
         if (kv >= nkv) m = -INFINITY;
         mv[i] = m;
         const unsigned long long live = __ballot(m != -INFINITY);
@@ -146,9 +158,13 @@ __global__ void __launch_bounds__(256) k_fattn_one(const fa_dev a, const float *
 
     // ---------------------------------------------------------------- 3. scores
     {
-        float qr[D / 4];
+        // q is already rounded to f16 (q_to_vec_dot): keep this lane's quarter as packed halves and use v_dot2_f32_f16 (f32 accumulate)
+        f16x2 qh[D / 8];
 #pragma unroll
-        for (int c = 0; c < D / 16; ++c) { const f32x4 t = *(const f32x4 *) (qf + dq * (D / 4) + 4 * c); qr[4 * c] = t[0]; qr[4 * c + 1] = t[1]; qr[4 * c + 2] = t[2]; qr[4 * c + 3] = t[3]; }
+        for (int c = 0; c < D / 16; ++c) {
+            const f32x4 t = *(const f32x4 *) (qf + dq * (D / 4) + 4 * c);
+            qh[2 * c] = f16x2{ (_Float16) t[0], (_Float16) t[1] }; qh[2 * c + 1] = f16x2{ (_Float16) t[2], (_Float16) t[3] };
+        }
 #pragma unroll
         for (int i = 0; i < NG; ++i) {
             const int g = wave + 4 * i;
@@ -158,13 +174,13 @@ __global__ void __launch_bounds__(256) k_fattn_one(const fa_dev a, const float *
             for (int c = 0; c < KCH; ++c)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    s = fmaf(h2f((uint16_t) (kk[i][c][e] & 0xffff)), qr[c * 8 + 2 * e], s);
-                    s = fmaf(h2f((uint16_t) (kk[i][c][e] >> 16)), qr[c * 8 + 2 * e + 1], s);
+                    f16x2 kh; const uint32_t kw = kk[i][c][e]; __builtin_memcpy(&kh, &kw, 4);
+                    s = __builtin_amdgcn_fdot2(kh, qh[c * 4 + e], s, false);
                 }
             s += dppf_old<0xB1, 0xf>(0.0f, s);                                       // fold the four dim-quarters (quad butterflies)
             s += dppf_old<0x4E, 0xf>(0.0f, s);
             const int row = g * 16 + r16;
-            if (dq == 0 && row < nkv && row != (int) krow) sc[row] = s;              // (the new token's row is not in the cache yet: below)
+            if (dq == 0 && row < nkv && row != krow) sc[row] = s;              // (the new token's row is not in the cache yet: below)
         }
         if (wave == 3) {                                                             // score of the new token itself, from the k head in LDS
             float s = 0.0f;
@@ -203,9 +219,9 @@ __global__ void __launch_bounds__(256) k_fattn_one(const fa_dev a, const float *
     // the new token's V row is in LDS, not in the registers: take its weight out of the table
     float pcur = 0.0f;
     const bool vin = vrow >= 0 && vrow < nkv;
-    if (vin) { pcur = pl[wave][((int) vrow % RPI) * NJ + (int) vrow / RPI]; }
+    if (vin) { pcur = pl[wave][(vrow % RPI) * NJ + vrow / RPI]; }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    if (vin && lane == 0) pl[wave][((int) vrow % RPI) * NJ + (int) vrow / RPI] = 0.0f;
+    if (vin && lane == 0) pl[wave][(vrow % RPI) * NJ + vrow / RPI] = 0.0f;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
     // ---------------------------------------------------------------- 5. P.V for this wave's dims
@@ -247,15 +263,25 @@ bool fattn_one_ok(const fattn_args & f) {
     if (f.k.ne[1] < 1 || f.k.ne[1] > FA1_NKV || f.k.ne[2] < 1 || f.q.ne[2] % f.k.ne[2] != 0) return false;
     if (f.k.nb[1] % 16 != 0 || f.v.nb[1] % 4 != 0 || ((uintptr_t) f.k.p & 15) != 0 || ((uintptr_t) f.v.p & 3) != 0 || f.k.nb[2] % 16 != 0 || f.v.nb[2] % 4 != 0) return false;
     if (f.dst.nb[0] != 4 || f.dst.nb[1] % 8 != 0 || ((uintptr_t) f.dst.p & 7) != 0) return false;
+    if (f.k.nb[1] * FA1_NKV > 0x7fffffff || f.v.nb[1] * FA1_NKV > 0x7fffffff || f.k.nb[2] > 0x7fffffff || f.v.nb[2] > 0x7fffffff) return false;
     if (f.img || f.out16) return false;
     return true;
 }
 
-void flash_attn_one(const fa_dev & a, int D, const float * rope_tab, hipStream_t st) {
+void flash_attn_one(const fa_dev & f, int D, const float * rope_tab, hipStream_t st) {
     if (!rope_tab) { fprintf(stderr, "[mi355x] flash_attn_one: the (cos, sin) table of the token is missing\n"); abort(); }
-    const dim3 grid((unsigned) a.nh);
-    if (D == 64) k_fattn_one<64><<<grid, dim3(256), 0, st>>>(a, rope_tab);
-    else         k_fattn_one<128><<<grid, dim3(256), 0, st>>>(a, rope_tab);
+    const fa_pre & P = f.pre;
+    fa1_dev a;
+    a.qraw = P.qraw; a.kraw = P.kraw; a.vraw = P.vraw; a.qw = P.qw; a.kw = P.kw; a.tab = rope_tab;
+    a.kcache = P.kcache; a.vcache = P.vcache; a.kidx = P.kidx; a.vidx = P.vidx;
+    a.k = f.k; a.v = f.v; a.mask = f.mask; a.sinks = f.sinks; a.dst = f.dst;
+    a.q_hs = (int) P.q_hs; a.k_hs = (int) P.k_hs; a.v_hs = (int) P.v_hs; a.kc_rs = (int) P.kc_rs; a.vc_rs = (int) P.vc_rs;
+    a.knb1 = (int) f.knb1; a.knb2 = (int) f.knb2; a.vnb1 = (int) f.vnb1; a.vnb2 = (int) f.vnb2; a.mnb2 = (int) f.mnb2; a.mne2 = (int) f.mne2; a.dnb1 = (int) f.dnb1;
+    a.nkv = f.nkv; a.gq = f.gq; a.neox = (P.rd.mode & GGML_ROPE_TYPE_NEOX) ? 1 : 0; a.n_head_log2 = (int) f.n_head_log2;
+    a.eps = P.eps; a.scale = f.scale; a.max_bias = f.max_bias; a.logit_softcap = f.logit_softcap; a.m0 = f.m0; a.m1 = f.m1;
+    const dim3 grid((unsigned) f.nh);
+    if (D == 64) k_fattn_one<64><<<grid, dim3(256), 0, st>>>(a);
+    else         k_fattn_one<128><<<grid, dim3(256), 0, st>>>(a);
 }
 
 } // namespace mi
