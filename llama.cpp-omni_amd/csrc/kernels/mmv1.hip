@@ -121,18 +121,20 @@ template <int XB> struct mv1_act_regs { f32x4 x[XB], w[XB]; };
 template <int NW, int XB>
 static __device__ __forceinline__ void mv1_act_issue(const mv1_src s, int K, mv1_act_regs<XB> & r) {
     if (s.img) return;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nb = K >> 8;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // exact-bounds buffer descriptors instead of `block < nb ? load : 0`: a conditional load costs a branch AND a full s_waitcnt before the
+    // next request, i.e. one serial memory round trip per condition in front of the weight stream; out-of-range elements read as zero
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void *) s.x, (short) 0, K * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void *) s.nw, (short) 0, s.nw ? K * 4 : 0, 0x00020000);
 #pragma unroll
     for (int c = 0; c < XB; ++c) {
-        const int ib = wave + c * NW;
-        r.x[c] = ib < nb ? *(const f32x4 *) (s.x + ib * 256 + 4 * lane) : f32x4{0, 0, 0, 0};
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(xr, (uint32_t) ((wave + c * NW) * 1024 + 16 * lane), 0, 0);
+        r.x[c] = f32x4{ __uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]) };
     }
-    if (s.nw) {
 #pragma unroll
-        for (int c = 0; c < XB; ++c) {
-            const int ib = wave + c * NW;
-            r.w[c] = ib < nb ? *(const f32x4 *) (s.nw + ib * 256 + 4 * lane) : f32x4{0, 0, 0, 0};
-        }
+    for (int c = 0; c < XB; ++c) {
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(wr, (uint32_t) ((wave + c * NW) * 1024 + 16 * lane), 0, 0);
+        r.w[c] = f32x4{ __uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]) };
     }
 }
 // called by every wave of the workgroup; contains workgroup barriers; the image is complete when it returns
@@ -230,7 +232,13 @@ static __device__ __forceinline__ void mv1_q4k(const char * __restrict__ W0, con
 
     // in-flight bytes per VGPR decide the HBM rate (Little: ~3.5 us loaded latency x 20 GB/s per CU = 70 KB per CU just to break even), so the
     // 16-byte header is fetched ONCE per block -- lane q takes dword q -- and broadcast inside the quad on the DPP network when it is used
+#ifdef MV1_DENSE_LOADS      // measurement only (wrong results): every cache line requested by exactly one instruction
+    const uint32_t voff_h = 2048u + 4u * (uint32_t) lane, voff_q = 16u * (uint32_t) lane;
+#define MV1_QB_OFF 1024u
+#else
     const uint32_t voff_h = (uint32_t) blk * 144u + 4u * (uint32_t) q, voff_q = (uint32_t) blk * 144u + 16u + 32u * (uint32_t) q;
+#define MV1_QB_OFF 16u
+#endif
     uint32_t hq[NBUF][R]; u32x4 qa[NBUF][R], qb[NBUF][R];
     // buffer loads: 128-bit descriptor of the whole matrix + wave-uniform byte offset (SGPR) + lane-constant offset (one VGPR) + immediate --
     // no per-load address arithmetic, no 64-bit pointer pairs in VGPRs
@@ -244,7 +252,7 @@ static __device__ __forceinline__ void mv1_q4k(const char * __restrict__ W0, con
             const mv1_rsrc rs = (PAIR && r == 1) ? rs1 : rs0;
             hq[bf][r] = __builtin_amdgcn_raw_buffer_load_b32(rs, voff_h, so, NT ? 2 : 0);
             qa[bf][r] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff_q, so, NT ? 2 : 0);
-            qb[bf][r] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff_q + 16u, so, NT ? 2 : 0);
+            qb[bf][r] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff_q + MV1_QB_OFF, so, NT ? 2 : 0);
         }
     };
 #ifndef MV1_KO

@@ -178,7 +178,12 @@ int main(int argc, char ** argv) {
         const bool big = ntot > 20000;
 #if defined(LAB_ONE)
         VAR(8, 2, 1, 0, 4096);
+        VAR(8, 2, 1, 1, 4096);
+        VAR(8, 2, 2, 1, 4096);
+        VAR(8, 2, 3, 1, 4096);
         VAR(16, 1, 1, 0, 4096);
+        VAR(16, 1, 1, 1, 4096);
+        VAR(16, 1, 3, 1, 4096);
 #else
         VAR(8, 2, 1, 0, 4096);
         VAR(8, 2, 2, 0, 4096);
