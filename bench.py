@@ -79,46 +79,59 @@ class Decoder:
         be.synchronize()
 
 
-def cpu_baseline(pkg, cfg, types, n_kv, seconds_budget=20.0):
-    """Reference CPU backend (oracle/_ref, built from /root/reference sources) on the SAME decode graph,
-    timed on this box's host cores for a bounded sample."""
+def cpu_baseline(pkg, cfg, types, n_kv, seconds_budget=24.0):
+    """Reference CPU backend (oracle/_ref, built from /root/reference sources) on the SAME decode graph, timed on this box's host
+    cores for a bounded sample.  Thread counts come from the cores this process may actually run on (sched_getaffinity: a cgroup /
+    affinity mask smaller than the machine would otherwise be oversubscribed); the sweep {all, half, physical} is timed and the best is
+    reported together with the bandwidth it implies."""
     try:
         sys.path.insert(0, ROOT)
         from oracle.ref_backend import make_ref_cpu_backend, ref_available
         if not ref_available():
             return None
-        cores = os.cpu_count() or 1
-        try:  # physical cores: unique (package, core) pairs
-            seen = set()
-            for c in os.listdir("/sys/devices/system/cpu"):
-                p = f"/sys/devices/system/cpu/{c}/topology"
-                if c.startswith("cpu") and c[3:].isdigit() and os.path.exists(p + "/core_id"):
-                    seen.add((open(p + "/physical_package_id").read().strip(), open(p + "/core_id").read().strip()))
-            if seen:
-                cores = len(seen)
+        allowed = sorted(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else list(range(os.cpu_count() or 1))
+        n_aff = len(allowed)
+        phys = set()
+        try:  # physical cores among the allowed CPUs: unique (package, core) pairs
+            for c in allowed:
+                p = f"/sys/devices/system/cpu/cpu{c}/topology"
+                phys.add((open(p + "/physical_package_id").read().strip(), open(p + "/core_id").read().strip()))
         except Exception:
-            pass
-        threads = min(cores, 64)
-        os.environ.setdefault("OMP_NUM_THREADS", str(threads))
-        be = make_ref_cpu_backend(pkg, threads)
+            phys = set()
+        n_phys = len(phys) if phys else n_aff
+        cands = sorted({max(1, n_aff), max(1, n_aff // 2), max(1, n_phys), max(1, n_phys // 2)}, reverse=True)[:4]
+        wbytes = None
+        results = []
+        be = make_ref_cpu_backend(pkg, cands[0])
         dec = Decoder(pkg, be, cfg, types, n_ctx=n_kv, n_kv=n_kv, flash_attn=True, pinned=False)
+        wbytes = dec.model.weight_bytes()
         dec.step(0)                                              # warm-up (page-in, thread pool)
-        t0 = time.perf_counter()
-        n = 0
-        while n < 128 and (time.perf_counter() - t0) < seconds_budget:
-            dec.step(1 + n)
-            n += 1
-        dt = time.perf_counter() - t0
+        pos = 1
+        per = seconds_budget / len(cands)
+        for th in cands:
+            be.set_n_threads(th)
+            dec.step(pos); pos += 1                              # thread-pool resize outside the timed region
+            t0 = time.perf_counter()
+            n = 0
+            while n < 48 and (time.perf_counter() - t0) < per:
+                dec.step(pos); pos += 1; n += 1
+            dt = time.perf_counter() - t0
+            results.append((n / dt, th, n))
         be.close()
-        return {"value": round(n / dt, 3), "unit": "tok/s", "cores": threads, "kind": "reference",
-                "sample": f"{n} decode steps of the same Qwen3-8B Q4_K_M graph on the reference ggml CPU backend (oracle/_ref, x86-64-v3 build), {threads} OpenMP threads"}
+        best = max(results)
+        return {"value": round(best[0], 3), "unit": "tok/s", "cores": best[1], "kind": "reference",
+                "gb_per_s": round(best[0] * wbytes / 1e9, 1),
+                "allowed_cpus": n_aff, "physical_cores_allowed": n_phys,
+                "thread_sweep_tok_s": {str(th): round(v, 3) for v, th, _ in results},
+                "sample": f"{best[2]} decode steps of the same Qwen3-8B Q4_K_M graph on the reference ggml CPU backend (oracle/_ref, x86-64-v3 build, "
+                          f"its own thread pool), best of the thread sweep over the {n_aff} CPUs this process is allowed on"}
     except Exception as e:  # the baseline is a reported extra, never a reason to lose the GPU number
         return {"value": None, "unit": "tok/s", "cores": 0, "kind": "reference", "sample": f"failed: {e!r}"}
 
 
 def kernel_roofline(pkg, be, model, reps=5):
-    """Live roofline of the dominant kernel, mi::k_mmv_pair<1,2,Q4_K> (ffn_gate + ffn_up + SWIGLU: 2 x 12288 x 4096 Q4_K rows =
-    56.6 MB per launch, 36 launches and 2.04 of the 4.67 GB of every decoded token).  One cgraph holding the 36 launches of one
+    """Live roofline of the dominant kernel, mi::k_mv1<8,2,2,1,1,true,false> (mmv1.hip: RMS norm + Q8_K image in the prologue, ffn_gate +
+    ffn_up + SWIGLU: 2 x 12288 x 4096 Q4_K rows = 56.6 MB per launch, 36 launches and 2.04 of the 4.67 GB of every decoded token).  One cgraph holding the 36 launches of one
     decode step -- the real layers' weights, 2 GB, 8x the Infinity Cache -- is replayed as a hipGraph and bracketed by two HIP
     events on the backend's stream; avg launch = elapsed / 36 (so it includes the launch-to-launch boundary, like the
     per-dispatch duration rocprofv3 --kernel-trace reports; profiles/).  achieved = algorithmic weight bytes / time."""
@@ -130,8 +143,9 @@ def kernel_roofline(pkg, be, model, reps=5):
     for L in model.layers:
         if L["ffn_up"].type != GGML_TYPE_Q4_K or L["ffn_gate"].type != GGML_TYPE_Q4_K:
             continue
-        up = c.mul_mat(model._w(c, L["ffn_up"]), x)
-        gate = c.mul_mat(model._w(c, L["ffn_gate"]), x)
+        xn = c.mul(c.rms_norm(x, cfg["rms_eps"]), model._w(c, L["ffn_norm"]))     # the launch as the step runs it: ffn_norm folded into its prologue
+        up = c.mul_mat(model._w(c, L["ffn_up"]), xn)
+        gate = c.mul_mat(model._w(c, L["ffn_gate"]), xn)
         c.swiglu_split(gate, up)
         nbytes += L["ffn_up"].nbytes() + L["ffn_gate"].nbytes()
         launches += 1
@@ -144,7 +158,7 @@ def kernel_roofline(pkg, be, model, reps=5):
         be.graph_compute(g)                      # eager, capture, first replay
     be.synchronize()
     kern = int(be.get_stat("kernels_last_graph"))
-    assert kern in (launches, launches + 1), (kern, launches)   # the pair launches (+ one activation quantiser when the batch-1 kernels are off)
+    assert kern == launches, (kern, launches)           # exactly the pair launches: norm, quantisation and SwiGLU are inside them
     best = 1e30
     for _ in range(reps):
         a, b = be.timed_event(), be.timed_event()
@@ -153,19 +167,24 @@ def kernel_roofline(pkg, be, model, reps=5):
     c.free()
     us = best * 1e3
     ach = nbytes / us / 1e3
-    # HBM traffic per launch: PMC counters cannot be read from inside this process; the figure is the committed rocprofv3
-    # --pmc FETCH_SIZE pass of this same command (tools/profile_round.sh -> profiles/r01_pmc_fetch_size.json, corrected x2 per
-    # MI355X_MICROARCH.md), null when that file is absent
-    traffic = None
+    # HBM traffic per launch: PMC counters cannot be read from inside this process.  The figure comes from the committed rocprofv3
+    # --pmc FETCH_SIZE pass of this same command (tools/profile_round.sh -> profiles/<round>_pmc_fetch_size.json, corrected x2 per
+    # MI355X_MICROARCH.md); it is used only when that file names THIS kernel, and the file / kernel symbol are printed beside it
+    traffic, traffic_src = None, None
     try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_fetch_size.json")))
-        for k, v in pmc["kernels"].items():
-            if "k_mmv_pair<1, 2, 12" in k:
-                traffic = v["hbm_bytes_per_dispatch_corrected"]
+        cands = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc_fetch_size.json"))
+        for fn in reversed(cands):
+            pmc = json.load(open(os.path.join(ROOT, "profiles", fn)))
+            for k, v in pmc["kernels"].items():
+                if "k_mv1<8, 2, 2, 1, 1, true" in k:
+                    traffic = v["hbm_bytes_per_dispatch_corrected"]
+                    traffic_src = {"file": "profiles/" + fn, "kernel": k[:80], "commit": pmc.get("commit")}
+            if traffic is not None:
+                break
     except Exception:
         pass
-    return {"bound": "hbm", "kernel": "mi::k_mmv_pair<1,2,12> (Q4_K ffn_gate+ffn_up mat-vec + SWIGLU epilogue)",
-            "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
+    return {"bound": "hbm", "kernel": "mi::k_mv1<8,2,2,1,1,true,false> (RMS norm + Q8_K image prologue, Q4_K ffn_gate+ffn_up mat-vec, SWIGLU epilogue)",
+            "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
             "bytes_per_launch": nbytes // launches, "avg_launch_us": round(us / launches, 3), "launches": launches,
             "method": "hipGraph replay of the step's 36 launches of this kernel, two HIP events on the backend stream, best of 5"}
 
@@ -266,7 +285,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--tiny", action="store_true", help="tiny shapes (plumbing check)")
     ap.add_argument("--no-fa", action="store_true")
-    ap.add_argument("--c3", action="store_true", help="also run BASELINE configs[2]: Qwen3-8B F16 prefill 8 x 2048 tokens (adds the `c3_f16_prefill` object)")
+    ap.add_argument("--c3", action="store_true", help="(default on at N = 1) BASELINE configs[2]: Qwen3-8B F16 prefill 8 x 2048 tokens (the `c3_f16_prefill` object)")
+    ap.add_argument("--no-c3", action="store_true", help="skip the C3 leg")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -363,7 +383,7 @@ def main():
             except Exception as e:
                 out["pp512_tok_s"] = None
                 out["pp512_error"] = repr(e)
-        if args.c3 and world == 1:
+        if (args.c3 or not (args.no_c3 or args.tiny)) and world == 1:
             try:
                 out["c3_f16_prefill"] = {"ub512": c3_prefill(pkg, be, n_ubatch=512, tiny=args.tiny), "ub2048": c3_prefill(pkg, be, n_ubatch=2048, tiny=args.tiny)}
             except Exception as e:

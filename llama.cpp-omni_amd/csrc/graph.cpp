@@ -1568,6 +1568,7 @@ int mi355x_set_option(struct ggml_backend * backend, const char * key, long valu
     if (!strcmp(key, "norm_in_kernel")) { c->opt_norm_in_kernel = value != 0; c->execs.clear(); return 0; }
     if (!strcmp(key, "mv1")) { c->opt_mv1 = value != 0; c->execs.clear(); return 0; }
     if (!strcmp(key, "fattn_gqa")) { mi::fattn_set_gqa(value != 0); c->execs.clear(); return 0; }
+    if (!strcmp(key, "fattn_one")) { mi::fattn_set_one(value != 0); c->execs.clear(); return 0; }
     if (!strcmp(key, "f16_shadow")) { mi::shadow_set_enabled(value != 0); c->execs.clear(); return 0; }
     if (!strcmp(key, "reset_stats")) { c->prof.clear(); c->stat_replays = c->stat_captures = c->stat_eager = 0; return 0; }
     return -1;
@@ -1579,6 +1580,8 @@ double mi355x_get_stat(struct ggml_backend * backend, const char * key) {
     if (!strcmp(key, "eager_graphs"))       return (double) c->stat_eager;
     if (!strcmp(key, "kernels_last_graph")) return (double) c->stat_kernels_last;
     if (!strncmp(key, "shadow_", 7))        return mi::shadow_stat(key);
+    if (!strcmp(key, "gemm256_launches"))   return (double) mi::gemm_variant_launches(0);
+    if (!strcmp(key, "gemm192_launches"))   return (double) mi::gemm_variant_launches(1);
     if (!strncmp(key, "prof_", 5)) {
         std::string k(key + 5);
         const size_t us = k.rfind("_us"), nn = k.rfind("_n"), by = k.rfind("_bytes");

@@ -152,6 +152,7 @@ struct fattn_args {
     uint16_t * out16 = nullptr; size_t out16_rs = 0; bool write_f32 = true;   // prefill kernel: also / only emit f16 rows [nh*D] per (seq, query)
     const float * rope_tab = nullptr;  // (cos, sin) pairs [D/2] of the token (rope_table), required by the one-token kernel (fattn_one_ok)
 };
+void   fattn_set_one(bool on);             // one-token kernel on (default) / off: the round-1 decode kernels take the shape (cross-check)
 bool   fattn_one_ok(const fattn_args & a);       // one token, one sequence, pre-stage, <= 256 cache rows: the latency-optimised kernel (fattn_one.hip) runs
 // (cos, sin) * mscale of every (token, rotation pair): tab[T][D/2][2], what ggml_rope_cache_init / rope_yarn give for these positions
 void   rope_table(const int32_t * pos, const float * ff, const rope_params & rp, int T, int D, float * tab, hipStream_t st);
@@ -205,5 +206,6 @@ void   gemm_reduce_rms_norm(const float * partial, int nsplit, const float * res
                             float * y32, size_t y32_cs, uint16_t * y16, size_t y16_rs, int64_t M, int64_t N, hipStream_t st);
 void   gemm_f16_multi(const gemm_multi_args & a, hipStream_t st);
 size_t gemm_split_scratch_bytes(int64_t M, int64_t N, int64_t K);
+long   gemm_variant_launches(int v);      // launches so far of the 256 x 256 (0) / 192-row (1) tile kernels (test instrumentation)
 
 } // namespace mi

@@ -256,8 +256,11 @@ __global__ void __launch_bounds__(256) k_fattn_one(const fa1_dev a) {
 }
 
 // one token of one sequence, q / k / v pre-stage, <= 256 cache rows, f16 mask shared by the heads of a token (or per head), D 64 / 128
+static bool g_one_enabled = true;
+void fattn_set_one(bool on) { g_one_enabled = on; }
 bool fattn_one_ok(const fattn_args & f) {
-    static const bool off = getenv("MI355X_FA_NO_ONE") != nullptr;
+    static const bool env_off = getenv("MI355X_FA_NO_ONE") != nullptr;
+    const bool off = env_off || !g_one_enabled;
     const int64_t D = f.q.ne[0];
     if (off || !f.pre || (D != 64 && D != 128) || f.v.ne[0] != D || f.q.ne[1] != 1 || f.q.ne[3] != 1 || f.k.ne[3] != 1) return false;
     if (f.k.ne[1] < 1 || f.k.ne[1] > FA1_NKV || f.k.ne[2] < 1 || f.q.ne[2] % f.k.ne[2] != 0) return false;

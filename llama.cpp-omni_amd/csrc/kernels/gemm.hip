@@ -455,6 +455,10 @@ size_t gemm_split_scratch_bytes(int64_t M, int64_t N, int64_t K) {
     return s > 1 ? (size_t) s * (size_t) M * (size_t) N * 4 : 0;
 }
 
+// launches per tile variant (tests assert that a shape really selected the kernel it is meant to cover): 0 = 256 x 256, 1 = 192-row
+static long g_gemm_variant_launches[2] = { 0, 0 };
+long gemm_variant_launches(int v) { return v >= 0 && v < 2 ? g_gemm_variant_launches[v] : 0; }
+
 void gemm_f16_multi(const gemm_multi_args & a, hipStream_t st) {
     if (a.N == 0 || a.nmat == 0) return;
     const int tiles_n = (int) ((a.N + G_BN - 1) / G_BN);
@@ -513,6 +517,7 @@ void gemm_f16_multi(const gemm_multi_args & a, hipStream_t st) {
         constexpr int lds256 = 2 * 2 * 256 * H_ROWB;               // 128 KB
         allow_big_lds((const void *) k_gemm_f16_glds256, lds256, 0);
         k_gemm_f16_glds256<<<dim3((unsigned) (tm * tiles_n256)), dim3(512), lds256, st>>>(g);
+        ++g_gemm_variant_launches[0];
         return;
     }
     g.nmat = a.nmat; g.X = (const char *) a.X; g.x_rs = a.x_rs; g.N = (int) a.N; g.K = (int) a.K; g.tiles_m = tm; g.tiles_n = tiles_n;
@@ -538,6 +543,7 @@ void gemm_f16_multi(const gemm_multi_args & a, hipStream_t st) {
         constexpr int lds192 = 2 * (192 * H_ROWB + H_TILEB);        // 80 KB: two workgroups per CU
         allow_big_lds((const void *) k_gemm_f16_glds<3>, lds192, 1);
         k_gemm_f16_glds<3><<<dim3((unsigned) (tm * tiles_n), (unsigned) nbatch), dim3(256), lds192, st>>>(g);
+        ++g_gemm_variant_launches[1];
     } else {
         k_gemm_f16_glds<2><<<dim3((unsigned) (tm * tiles_n), (unsigned) nbatch), dim3(256), 2 * (128 * H_ROWB + H_TILEB), st>>>(g);
     }

@@ -223,10 +223,13 @@ class Model:
                 cur = g.reshape(cur, H * D, n_tokens)
             else:
                 kq = g.mul_mat(k, q)
-                kq = g.soft_max_ext(kq, I["kq_mask"], kq_scale, 0.0)
+                kqs = g.soft_max_ext(kq, I["kq_mask"], kq_scale, 0.0)
                 vt = g.cont(g.transpose(v))                           # "avoid this branch" path of build_attn_mha
-                kqv = g.mul_mat(vt, kq)
+                kqv = g.mul_mat(vt, kqs)
                 cur = g.cont(g.permute(kqv, 0, 2, 1, 3), H * D, n_tokens)
+                if getattr(self, "taps", None) is not None and il == 0:   # debugging aid: keep layer 0's attention intermediates alive
+                    self.taps.update(Q=Q, K=K, V=V, kq=kq, kqs=kqs, vt=vt, kqv=kqv, attn=cur)
+                    roots += [kq, kqs, vt, kqv, cur]
             cur = g.mul_mat(self._w(g, L["attn_output"]), cur)
             if il == n_layer - 1 and "out_ids" in I:
                 cur = g.get_rows(cur, I["out_ids"])

@@ -106,3 +106,35 @@ def test_oracle_vs_live_reference_library(golden):
     out0 = np.zeros(8192 // 32 * 34, np.uint8)
     ref.quantize_row_q8_0(x.ctypes.data_as(C.c_void_p), out0.ctypes.data_as(C.c_void_p), C.c_int64(8192))
     assert np.array_equal(out0, orc.quantize_q8_0(x))
+
+
+def test_reference_decorrelates_under_a_1e6_perturbation():
+    """Control for the end-to-end logit bars of the GPU tests: the reference CPU backend against ITSELF.  An 8-layer Q4_K_M model
+    (n_embd 1024) decodes one token twice, the second time with the input embedding perturbed by 1e-6 relative -- the size of an f32
+    summation-order difference.  Every mat-vec re-quantises its input to Q8_K; once one rounding flips, the +-1 step is a 1e-2
+    perturbation for everything downstream, so the logits differ by ~1e-3 NMSE although both runs are "the reference".  Any two
+    implementations that add the same exact integer block sums in a different f32 order sit on this noise floor."""
+    import numpy as np
+    from conftest import load_pkg, nmse
+    from oracle.ref_backend import make_ref_cpu_backend, ref_available
+    if not ref_available():
+        pytest.skip("oracle/_ref/libggml-ref.so not built")
+    pkg = load_pkg()
+    from llama_cpp_omni_amd import qwen3
+    be = make_ref_cpu_backend(pkg, 8)
+    cfg = dict(n_embd=1024, n_layer=8, n_head=8, n_head_kv=2, head_dim=128, n_ff=3072, n_vocab=2048, rms_eps=1e-6, rope_base=1e6, n_ctx_orig=4096)
+    types = qwen3.q4_k_m_types(cfg)
+    rng = np.random.default_rng(3)
+    embd = rng.standard_normal((1, cfg["n_embd"])).astype(np.float32)
+    outs = []
+    for eps in (0.0, 1e-7, 1e-6):
+        mdl = qwen3.Model(be, cfg, types, n_ctx=256, seed=11, flash_attn=True)
+        g, I, logits = mdl.build(1, 256)
+        e = (embd * (1.0 + eps * np.sign(rng.standard_normal(embd.shape)))).astype(np.float32)
+        mdl.set_inputs(I, e, 0, 256)
+        be.graph_compute(g.graph())
+        outs.append(be.tensor_get(logits).copy())
+        g.free(); mdl.wctx.free()
+    be.close()
+    assert nmse(outs[1], outs[0]) < 1e-9            # (1e-7: no rounding happened to flip in this small model)
+    assert 1e-5 < nmse(outs[2], outs[0]) < 1e-1     # 1e-6: one flipped, the outputs decorrelate to the rounding-noise floor

@@ -1,0 +1,214 @@
+"""Round-2 GPU parity tests (through the C-ABI, `-m gpu`): the batch-1 decode kernels at Qwen3-8B width (mmv1.hip, fattn_one.hip) against
+the reference CPU backend, the GEMM tile variants and the flash-attention shape that BASELINE configs[2] (C3) actually runs, and greedy
+token ids at 8B shape through the reference's own libllama.  Nothing here reads /root/reference."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import nmse
+from oracle import oracle_py as orc
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIN = os.path.join(ROOT, "oracle", "_ref", "llama-bench-min")
+LIB = os.path.join(ROOT, "llama.cpp-omni_amd", "lib", "libggml-mi355x.so")
+
+# two decoder layers at the real Qwen3-8B widths (every decode mat-vec is the 8B launch shape: K = 4096 / 12288, GQA 4, head 128);
+# with two layers the Q4_K_M map makes layer 0 all-Q4_K and gives layer 1 Q6_K attn_v / ffn_down: both kernel bodies and the mixed launch
+W8 = dict(n_embd=4096, n_layer=2, n_head=32, n_head_kv=8, head_dim=128, n_ff=12288, n_vocab=4096, rms_eps=1e-6, rope_base=1e6, n_ctx_orig=4096)
+
+
+def _decode_run(pkg, backend, cfg, types, embd, steps, n_kv, fa, opts=None):
+    from llama_cpp_omni_amd import qwen3
+    for k, v in (opts or {}).items():
+        backend.set_option(k, v)
+    mdl = qwen3.Model(backend, cfg, types, n_ctx=n_kv, seed=11, flash_attn=fa)
+    g, I, logits = mdl.build(1, n_kv)
+    gr = g.graph()
+    outs = []
+    for t in range(steps):                                    # (third submission onwards: hipGraph replay on the device backend)
+        mdl.set_inputs(I, embd[t:t + 1], t, n_kv)
+        backend.graph_compute(gr)
+        outs.append(backend.tensor_get(logits).copy())
+    kern = backend.get_stat("kernels_last_graph") if getattr(backend, "lib", None) is not None else None
+    g.free(); mdl.wctx.free()
+    for k in (opts or {}):
+        backend.set_option(k, 1)
+    return np.stack(outs), kern
+
+
+@pytest.mark.parametrize("fa", [True])      # (llama-bench's default, flash-attention off, is covered at 8B shape through the reference libllama below)
+def test_decode_steps_at_8b_width_vs_reference_backend(pkg, be, ref_be, fa):
+    """12 decode steps from an empty cache: RMS norm + Q8_K image inside the mat-vec launches (mmv1.hip), the one-token attention kernel with
+    its q / k / v pre-stage (fattn_one.hip; fa=False: the soft-max path), residual and SwiGLU epilogues -- logits and arg-max against the
+    reference CPU backend on the same graphs; the same with the round-2 kernels switched off (the round-1 path) as a cross-check."""
+    from llama_cpp_omni_amd import qwen3
+    types = qwen3.q4_k_m_types(W8)
+    rng = np.random.default_rng(3)
+    steps = 12
+    embd = rng.standard_normal((steps, W8["n_embd"])).astype(np.float32)
+    n_kv = 256 if fa else 32
+    ref, _ = _decode_run(pkg, ref_be, W8, types, embd, steps, n_kv, fa)
+    got, kern = _decode_run(pkg, be, W8, types, embd, steps, n_kv, fa)
+    old, kern_old = _decode_run(pkg, be, W8, types, embd, steps, n_kv, fa, {"mv1": 0})
+    assert np.isfinite(got).all()
+    if fa:
+        assert kern <= 5 * W8["n_layer"] + 3, kern             # 5 launches per layer + rope table + output norm/lm-head launch
+    assert kern < kern_old
+    for t in range(steps):
+        # Without flash-attention both sides do the same arithmetic up to f32 summation order.  With it the CPU accumulates V in f16
+        # (ops.cpp:8069-8083; op-level NMSE 5e-8 .. 2e-6 against float64 where this backend is at 1e-14, tools/dbg_fa2.py) and that
+        # perturbation is re-quantised to Q8_K in front of every following mat-vec: roundings flip, and two layers + lm head later the
+        # logits differ by ~5e-4 .. 8e-4 NMSE on these random weights -- the round-1 and round-2 kernels agree with each other to 1e-14
+        # on the first steps (tools/dbg_fa.py), so the bar below measures the reference's own f16 accumulation, not this backend
+        assert nmse(got[t], ref[t]) < (2e-3 if fa else 1e-6), (t, nmse(got[t], ref[t]))
+        assert nmse(old[t], ref[t]) < (2e-3 if fa else 1e-6), t
+        if not fa:
+            assert int(np.argmax(got[t])) == int(np.argmax(ref[t])), t
+        else:   # the winning id may only change between near-ties of the reference itself (random weights: logits are not well separated)
+            err = float(np.sqrt(np.mean((got[t] - ref[t]) ** 2)))
+            assert ref[t][int(np.argmax(got[t]))] >= ref[t].max() - 4.0 * err, t
+
+
+def test_mmv1_activation_sources_vs_oracle(pkg, be):
+    """The three activation sources of the batch-1 kernels on one 4096-wide row: plain f32 (quantised in the prologue), RMS_NORM + MUL folded
+    in, and the residual epilogue -- each against the C oracle (integer dot of the reference's Q8_K image), Q4_K and Q6_K."""
+    from llama_cpp_omni_amd import qwen3
+    rng = np.random.default_rng(17)
+    K, M = 4096, 512
+    x = (rng.standard_normal((1, K)) * 2.0).astype(np.float32)
+    x[0, 256:512] = 0.0                                       # an all-zero Q8_K block
+    x[0, 700] = -x[0, 701]                                    # a +/- tie candidate
+    nw = rng.standard_normal(K).astype(np.float32)
+    r = rng.standard_normal((1, M)).astype(np.float32)
+    for name in ("q4_K", "q6_K"):
+        ty = {"q4_K": pkg.GGML_TYPE_Q4_K, "q6_K": pkg.GGML_TYPE_Q6_K}[name]
+        wv = qwen3.random_blocks(rng, ty, M, K, std=0.05)
+        wb = wv.view(np.uint8).reshape(M, -1)
+        c = pkg.Context(be)
+        w = c.new_tensor(ty, K, M); xt = c.new_tensor(pkg.GGML_TYPE_F32, K, 1); nt = c.new_tensor(pkg.GGML_TYPE_F32, K); rt = c.new_tensor(pkg.GGML_TYPE_F32, M, 1)
+        y_plain = c.mul_mat(w, xt)
+        xn = c.mul(c.rms_norm(xt, 1e-6), nt)
+        y_norm = c.add(c.mul_mat(w, xn), rt)
+        from test_gpu_parity import run_graph
+        got_plain, got_norm = run_graph(be, c, [y_plain, y_norm], [(w, wv), (xt, x), (nt, nw), (rt, r)])
+        want_plain = orc.mul_mat(ty, wb, x)
+        xn_ref = orc.rms_norm(x, 1e-6) * nw
+        want_norm = orc.mul_mat(ty, wb, xn_ref.astype(np.float32)) + r
+        assert nmse(got_plain, want_plain) < 1e-9, name
+        assert nmse(got_norm, want_norm) < 1e-9, name
+
+
+# ------------------------------------------------------------------------------------------------ C3: the kernels configs[2] selects
+@pytest.mark.parametrize("variant,M,nmat,N,K", [("gemm256", 4096, 1, 4096, 512), ("gemm256", 4096, 2, 2048, 256), ("gemm192", 12288, 2, 512, 256)])
+def test_gemm_tile_variants_vs_oracle(pkg, be, variant, M, nmat, N, K):
+    """k_gemm_f16_glds256 (256 x 256 tiles, whole rounds of the 256 CUs: ffn_gate/up at ubatch 2048) and the 192-row k_gemm_f16_glds<3>
+    (ffn_gate/up at ubatch 512) are only chosen from >= 256 / > 512 tiles; these shapes force them (launch counters confirm) and sampled
+    output rows / columns are compared with the oracle's F16 mul_mat (f16-rounded activations, f32 accumulate)."""
+    from test_gpu_parity import run_graph
+    rng = np.random.default_rng(M + N + K)
+    ty = pkg.GGML_TYPE_F16
+    ws = [(rng.standard_normal((M, K)) * 0.05).astype(np.float16) for _ in range(nmat)]
+    xv = rng.standard_normal((N, K)).astype(np.float32)
+    c = pkg.Context(be)
+    x = c.new_tensor(pkg.GGML_TYPE_F32, K, N)
+    wts = [c.new_tensor(ty, K, M) for _ in range(nmat)]
+    ys = [c.mul_mat(w, x) for w in wts]
+    before = be.get_stat(variant + "_launches")
+    got = run_graph(be, c, ys, [(x, xv)] + list(zip(wts, ws)))
+    assert be.get_stat(variant + "_launches") > before, "the shape did not select " + variant
+    rows = rng.choice(M, 48, replace=False); cols = rng.choice(N, 48, replace=False)
+    for g, wv in zip(got, ws):
+        g = g.reshape(N, M)
+        want = orc.mul_mat(ty, wv[rows].view(np.uint8).reshape(len(rows), -1), xv[cols])
+        assert nmse(g[np.ix_(cols, rows)], want) < 1e-9
+        assert np.isfinite(g).all()
+
+
+def test_flash_attn_prefill_2048_vs_oracle(pkg, be):
+    """FLASH_ATTN_EXT at the C3 ubatch: 2048 query rows x 2048 KV rows, causal mask, GQA 4, head 128 -- sampled (query, head) rows against
+    the pinned C oracle's flash_attn_row (the reference's arithmetic incl. f16 V accumulation; bar = the reference's NMSE 5e-4)."""
+    from test_gpu_parity import run_graph
+    rng = np.random.default_rng(2048)
+    D, nq, nh, nhkv, nkv = 128, 2048, 8, 2, 2048
+    qv = rng.standard_normal((nh, nq, D)).astype(np.float32)
+    kv = rng.standard_normal((nhkv, nkv, D)).astype(np.float16)
+    vv = rng.standard_normal((nhkv, nkv, D)).astype(np.float16)
+    mask = np.zeros((nq, nkv), np.float16)
+    mask[np.triu_indices(nq, 1)] = -np.inf
+    c = pkg.Context(be)
+    q = c.new_tensor(pkg.GGML_TYPE_F32, D, nq, nh); k = c.new_tensor(pkg.GGML_TYPE_F16, D, nkv, nhkv); v = c.new_tensor(pkg.GGML_TYPE_F16, D, nkv, nhkv)
+    m = c.new_tensor(pkg.GGML_TYPE_F16, nkv, nq)
+    scale = 1.0 / np.sqrt(D)
+    y = c.flash_attn_ext(q, k, v, m, scale)
+    (got,) = run_graph(be, c, [y], [(q, qv), (k, kv), (v, vv), (m, mask)])
+    got = got.reshape(nq, nh, D)
+    assert np.isfinite(got).all()
+    num = den = 0.0
+    for iq in [0, 1, 31, 32, 33, 511, 1000, 1024, 2047] + list(rng.choice(nq, 12, replace=False)):
+        for h in (0, 3, 5, 7):
+            want = orc.flash_attn_row(qv[h, iq], kv[h // (nh // nhkv)].view(np.uint16), vv[h // (nh // nhkv)].view(np.uint16), mask[iq].view(np.uint16), scale)
+            d = got[iq, h].astype(np.float64) - want
+            num += float((d * d).sum()); den += float((want.astype(np.float64) ** 2).sum())
+    assert num / den < 5e-4, num / den
+
+
+# ------------------------------------------------------------------------------------------------ 8B shape through the reference libllama
+def _greedy_all(gguf, ngl, fa, dump, n, threads, env_extra=None, forced=None):
+    env = dict(os.environ)
+    env.pop("GGML_BACKEND_PATH", None)
+    if env_extra:
+        env.update(env_extra)
+    cmd = [BIN, "-m", gguf, "-ngl", str(ngl), "-fa", str(fa), "--greedy", str(n), "-t", str(threads), "--dump-all-logits", dump]
+    if forced:
+        cmd += ["--force-ids", ",".join(str(i) for i in forced)]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1500)
+    assert out.returncode == 0, out.stderr[-2000:]
+    ids = json.loads(out.stdout.strip().splitlines()[-1])["greedy_ids"]
+    return ids, np.fromfile(dump, np.float32).reshape(n, -1), out.stderr
+
+
+@pytest.mark.parametrize("fa", [0, 1])
+def test_8b_shape_greedy_ids_through_reference_libllama(tmp_path, fa):
+    """The synthetic Qwen3-8B Q4_K_M GGUF (36 layers, 5 GB, tools/make_synth_gguf.py) decoded by the reference's libllama + scheduler: `-ngl 0`
+    (reference CPU backend) against `-ngl 99` with this plug-in, flash-attention off (llama-bench's default) and on.  32 greedy steps at a
+    151936-entry vocabulary (no short cycle: the CPU ids are pairwise distinct).  The plug-in is teacher-forced along the CPU's ids so that
+    every step compares logits on identical inputs.  What can be asked of the logits: the integer block sums are identical on both sides,
+    but the f32 additions across super-blocks run in a different order (64-lane butterfly vs 8-lane SIMD), a 1e-7 difference -- and every
+    mat-vec re-quantises its input to Q8_K, where a 1e-7 perturbation flips roundings whose +-1 steps are a 1e-2 perturbation for the next
+    layer: within three or four layers any two summation orders decorrelate to the rounding-noise floor of the format, ~1e-3 NMSE at the
+    logits of a 36-layer model (measured 1e-3 .. 1e-2 per step, 1.2e-3 at the very first token where attention is trivial;
+    tests/test_oracle.py::test_reference_decorrelates_under_a_1e6_perturbation shows the reference CPU backend doing the same to ITSELF).
+    So: per-step NMSE < 3e-2, and the plug-in's own arg-max equals the CPU's id except where the REFERENCE's top logits are closer than
+    that noise (random weights: such near-ties exist)."""
+    if not os.path.exists(BIN):
+        pytest.skip("oracle/_ref/llama-bench-min not built (make -f oracle/Makefile.ref llama)")
+    import shutil
+    if shutil.disk_usage(str(tmp_path)).free < 7e9:
+        pytest.skip("needs 5 GB of scratch disk for the synthetic 8B GGUF")
+    gguf = str(tmp_path / "q8b.gguf")
+    subprocess.run([sys.executable, os.path.join(ROOT, "tools", "make_synth_gguf.py"), "--config", "8b", "--types", "q4_k_m", "-o", gguf, "--n-ctx", "4096"],
+                   check=True, timeout=900)
+    threads = max(4, min(48, len(os.sched_getaffinity(0)) // 2))
+    n = 32
+    ids_cpu, l_cpu, _ = _greedy_all(gguf, 0, fa, str(tmp_path / "c.bin"), n, threads)
+    ids_gpu, l_gpu, err = _greedy_all(gguf, 99, fa, str(tmp_path / "g.bin"), n, threads, {"GGML_BACKEND_PATH": LIB}, forced=ids_cpu)
+    os.remove(gguf)
+    assert "MI355X0" in err and "offloaded 37/37 layers to GPU" in err
+    assert len(set(ids_cpu)) >= 24, ids_cpu                    # a fixture that does not fall into a short cycle
+    exact = 0
+    print("per-step NMSE", ["%.1e" % float(((l_gpu[t] - l_cpu[t]) ** 2).sum() / (l_cpu[t] ** 2).sum()) for t in range(n)])
+    for t in range(n):
+        e = float(((l_gpu[t] - l_cpu[t]) ** 2).sum() / (l_cpu[t] ** 2).sum())
+        assert e < 3e-2, (t, e)
+        if ids_gpu[t] == ids_cpu[t]:
+            exact += 1
+        else:                                                  # only a near-tie of the reference's own logits may flip
+            rms = float(np.sqrt(np.mean((l_gpu[t] - l_cpu[t]) ** 2)))
+            assert l_cpu[t][ids_gpu[t]] >= l_cpu[t].max() - 4.0 * rms, (t, ids_gpu[t], ids_cpu[t])
+    assert exact >= int(0.6 * n), (exact, ids_gpu, ids_cpu)    # (fa=0: 29 of 32, fa=1: 21 of 32 on this fixture; every mismatch passed the near-tie rule)
+    print(f"fa={fa}: {exact}/{n} ids identical, worst step NMSE {max(float(((l_gpu[t] - l_cpu[t]) ** 2).sum() / (l_cpu[t] ** 2).sum()) for t in range(n)):.2e}")
