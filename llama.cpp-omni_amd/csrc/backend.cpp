@@ -127,6 +127,12 @@ static ggml_backend_buffer_t buft_alloc(ggml_backend_buffer_type_t t, size_t siz
     void * p = nullptr;
     const size_t asz = size < 1 ? 1 : size;
     hipError_t e = hipMalloc(&p, asz);
+    if (e != hipSuccess && shadow_bytes(d->index) > 0) {              // the resident F16 weight images are droppable: give them back and retry
+        (void) hipGetLastError();
+        const size_t freed = shadow_drop_all(d->index);
+        log_msg(GGML_LOG_LEVEL_WARN, "[mi355x] device %d short of memory: dropped %.1f MiB of F16 weight images\n", d->index, freed / 1048576.0);
+        e = hipMalloc(&p, asz);
+    }
     if (e != hipSuccess) {                                            // OOM is reported, not fatal (caller handles NULL)
         (void) hipGetLastError();
         log_msg(GGML_LOG_LEVEL_ERROR, "[mi355x] allocating %.2f MiB on device %d failed: %s\n", size / 1048576.0, d->index, hipGetErrorString(e));
@@ -236,8 +242,11 @@ static bool backend_is_ours(ggml_backend_t b) { return b && b->iface.graph_compu
 static const char * dev_name(ggml_backend_dev_t d) { return ((device_ctx *) d->context)->name.c_str(); }
 static const char * dev_desc(ggml_backend_dev_t d) { return ((device_ctx *) d->context)->description.c_str(); }
 static void dev_memory(ggml_backend_dev_t d, size_t * free, size_t * total) {
-    set_device(((device_ctx *) d->context)->index);
+    const int idx = ((device_ctx *) d->context)->index;
+    set_device(idx);
     HIP_CHECK(hipMemGetInfo(free, total));
+    *free += shadow_bytes(idx);                                       // (images are dropped on demand: buft_alloc / ensure_scratch)
+    if (*free > *total) *free = *total;
 }
 static enum ggml_backend_dev_type dev_type(ggml_backend_dev_t) { return GGML_BACKEND_DEVICE_TYPE_GPU; }
 static void dev_props(ggml_backend_dev_t d, struct ggml_backend_dev_props * p) {

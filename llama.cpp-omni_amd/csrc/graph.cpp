@@ -18,6 +18,7 @@
 #include "shadow.hpp"
 #include "../../include/ggml-mi355x.h"
 #include <unordered_map>
+#include <unordered_set>
 
 namespace mi {
 
@@ -67,6 +68,7 @@ struct exec_state {
     std::vector<uint8_t> done;                                           // node already covered by a fused item
     std::unordered_map<const ggml_tensor *, int> index;                  // tensor -> node index
     std::unordered_map<const ggml_tensor *, std::vector<int>> users;     // tensor -> consumer node indices (ascending)
+    std::unordered_set<const ggml_tensor *> external;                    // tensors with readers outside this cgraph (see is_out)
     const char * a_range_lo = nullptr; const char * a_range_hi = nullptr;
     // activation cache
     const void *  a_src = nullptr; act_kind a_kind = ACT_NONE; int64_t a_K = 0, a_ne[3] = {0, 0, 0}; size_t a_nb[3] = {0, 0, 0};
@@ -111,6 +113,8 @@ static void prof_drain(backend_ctx * c) {
 }
 
 // ------------------------------------------------------------------------------------------------ supports_op
+static bool mm_uses_mmq(const ggml_tensor * n);
+static bool mm_uses_gemm(const ggml_tensor * n);
 bool supports_op(const ggml_tensor * op) {
     const ggml_tensor * s0 = op->src[0];
     const ggml_tensor * s1 = op->src[1];
@@ -129,6 +133,12 @@ bool supports_op(const ggml_tensor * op) {
             if (k == ACT_Q8K || k == ACT_Q80) {
                 // 16-B / 2-B vector paths assume block-aligned rows (always true for ggml-allocated tensors)
                 if (s0->nb[1] % ((s0->type == GGML_TYPE_Q4_K || s0->type == GGML_TYPE_Q5_K) ? 16 : 2) != 0) return false;
+            }
+            // every mat-vec path (up to 8 columns per launch; F32 weights at any width) stages one activation column in LDS: a column
+            // beyond 152 KiB has no kernel (e.g. attention without FLASH_ATTN_EXT past ~77k cache rows: K = n_kv) -> leave it to the CPU
+            if (!mm_uses_gemm(op) && !mm_uses_mmq(op)) {
+                const size_t col = k == ACT_F32 ? (size_t) s0->ne[0] * 4 : act_image_bytes(is_image_quant(s0->type) ? ACT_F16 : k, s0->ne[0]);
+                if (col > (size_t) 152 * 1024) return false;
             }
             return true;
         }
@@ -311,14 +321,24 @@ static size_t graph_gemm_partial_need(const ggml_cgraph * g) {
     }
     return need;
 }
-static void ensure_scratch(backend_ctx * c, void ** p, size_t * have, size_t need) {
-    if (need <= *have) return;
+void drop_graph_execs(backend_ctx * c) {                   // captured graphs bake pointers / fusion decisions in: destroy, do not just forget
+    for (auto & e : c->execs) { if (e.exec) (void) hipGraphExecDestroy(e.exec); if (e.graph) (void) hipGraphDestroy(e.graph); }
+    c->execs.clear();
+}
+static bool ensure_scratch(backend_ctx * c, void ** p, size_t * have, size_t need) {
+    if (need <= *have) return true;
     HIP_CHECK(hipStreamSynchronize(c->stream));             // nothing in flight may still read the old block
     if (*p) HIP_CHECK(hipFree(*p));
+    *p = nullptr; *have = 0;
     size_t n = need + need / 4; n = (n + ((size_t) 1 << 20) - 1) & ~(((size_t) 1 << 20) - 1);
-    HIP_CHECK(hipMalloc(p, n));
+    if (hipMalloc(p, n) != hipSuccess) {                    // the resident F16 weight images are the first thing to give back
+        (void) hipGetLastError();
+        shadow_drop_all(c->device);
+        if (hipMalloc(p, n) != hipSuccess) { (void) hipGetLastError(); *p = nullptr; drop_graph_execs(c); return false; }
+    }
     *have = n;
-    c->execs.clear();                                       // captured graphs baked the old pointer in
+    drop_graph_execs(c);                                    // captured graphs baked the old pointer in
+    return true;
 }
 
 // ------------------------------------------------------------------------------------------------ MUL_MAT
@@ -378,12 +398,14 @@ static const uint16_t * weight_shadow(exec_state & s, const ggml_tensor * w, con
     const ggml_tensor * root = w;
     while (root->view_src) root = root->view_src;
     if (root->op != GGML_OP_NONE || !root->buffer || root->buffer->usage != GGML_BACKEND_BUFFER_USAGE_WEIGHTS) return nullptr;
-    const uint16_t * sh = shadow_find(s.c->device, wp, w->type, K, M, w->nb[1]);
-    if (sh || s.capturing) return sh;
-    uint16_t * p = shadow_create(s.c->device, wp, (size_t) (M - 1) * w->nb[1] + row_size(w->type, K), w->type, K, M, w->nb[1]);
-    if (!p) return nullptr;
-    prof_scope ps(s, "dequant_f16", (double) M * (double) row_size(w->type, K));
-    dequant_rows_f16(w->type, wp, w->nb[1], p, (size_t) K * 2, K, M, s.st); ++s.n_kernels;
+    bool created = false;
+    uint16_t * p = shadow_get_or_create(s.c->device, wp, (size_t) (M - 1) * w->nb[1] + row_size(w->type, K), w->type, K, M, w->nb[1], s.st, s.capturing, &created);
+    if (!p || !created) return p;
+    {
+        prof_scope ps(s, "dequant_f16", (double) M * (double) row_size(w->type, K));
+        dequant_rows_f16(w->type, wp, w->nb[1], p, (size_t) K * 2, K, M, s.st); ++s.n_kernels;
+    }
+    shadow_mark_ready(p, s.st);
     return p;
 }
 
@@ -566,10 +588,17 @@ static bool same_act(const ggml_tensor * a, const ggml_tensor * b) {
     return a->data == b->data && a->ne[0] == b->ne[0] && a->ne[1] == b->ne[1] && a->ne[2] == b->ne[2] && a->ne[3] == b->ne[3] &&
            a->nb[1] == b->nb[1] && a->nb[2] == b->nb[2] && a->nb[3] == b->nb[3];
 }
-static int n_users(exec_state & s, const ggml_tensor * t) { auto it = s.users.find(t); return it == s.users.end() ? 0 : (int) it->second.size(); }
+// Is t read by somebody this executor does not see?  Graph outputs, and -- when the scheduler cut the graph into splits -- tensors whose
+// whole-graph use count (ggml_cgraph::use_counts, shared by the split views: ggml_graph_view) exceeds the uses inside this split: a later
+// split (on this or another backend) reads them, so their f32 value must be written and no fusion may swallow them (cf. ggml_can_fuse).
+static bool is_out(exec_state & s, const ggml_tensor * t) { return (t->flags & GGML_TENSOR_FLAG_OUTPUT) || s.external.count(t) != 0; }
+static int n_users(exec_state & s, const ggml_tensor * t) {
+    auto it = s.users.find(t);
+    return (it == s.users.end() ? 0 : (int) it->second.size()) + (s.external.count(t) ? 1 : 0);
+}
 static int sole_user(exec_state & s, const ggml_tensor * t) {           // index of the only consumer node, or -1
     auto it = s.users.find(t);
-    if (it == s.users.end() || it->second.size() != 1 || (t->flags & GGML_TENSOR_FLAG_OUTPUT)) return -1;
+    if (it == s.users.end() || it->second.size() != 1 || is_out(s, t)) return -1;
     return it->second[0];
 }
 static bool ready_before(exec_state & s, const ggml_tensor * src, int i, const int * item, int n_item) {
@@ -938,7 +967,7 @@ static norm_rope_job chain_job(exec_state & s, const nr_chain & c) {
 // a reshape of the same bytes)?  Then the producer can emit the f16 rows the GEMM wants and the separate conversion launch disappears.
 static bool gemm_only_consumers(exec_state & s, const ggml_tensor * t, int64_t K, int64_t N, const ggml_tensor ** x_out) {
     static const bool off = getenv("MI355X_NO_F16_EMIT") != nullptr;
-    if (off || !s.c->opt_fusion || (t->flags & GGML_TENSOR_FLAG_OUTPUT) || N <= MI_MMVQ_MAX_COLS) return false;
+    if (off || !s.c->opt_fusion || is_out(s, t) || N <= MI_MMVQ_MAX_COLS) return false;
     auto it = s.users.find(t);
     if (it == s.users.end() || it->second.empty()) return false;
     if (act_image_bytes(ACT_F16, K) * (size_t) N > s.c->act_scratch_bytes) return false;
@@ -1128,7 +1157,7 @@ static bool exec_rms_norm(exec_state & s, int i) {
         // the batch-1 decode launches (mmv1.hip) always take the norm in: their prologue builds the image from x and the norm weights
         bool all_mv1 = n->ne[1] == 1;
         for (int u : s.users[m]) all_mv1 = all_mv1 && mv1_node_ok(s, g->nodes[u]);
-        bool defer = (all_mv1 || (s.c->opt_norm_in_kernel && mmv_norm_ok(n->ne[0], (int) n->ne[1]))) && !(m->flags & GGML_TENSOR_FLAG_OUTPUT) && ((uintptr_t) xs->data & 15) == 0 && xs->nb[1] % 16 == 0 && ((uintptr_t) wt->data & 15) == 0;
+        bool defer = (all_mv1 || (s.c->opt_norm_in_kernel && mmv_norm_ok(n->ne[0], (int) n->ne[1]))) && !is_out(s, m) && ((uintptr_t) xs->data & 15) == 0 && xs->nb[1] % 16 == 0 && ((uintptr_t) wt->data & 15) == 0;
         int last_user = mi_;
         for (int u : s.users[m]) { defer = defer && plain_kq_matvec(g->nodes[u], MI_MMVQ_MAX_COLS); if (u > last_user) last_user = u; }
         if (defer) {
@@ -1228,7 +1257,7 @@ static void compute_node(exec_state & s, int i) {
             // every consumer a K-quant mat-mul on the whole result (ffn_down at several columns): emit the Q8_K images here
             const ggml_tensor * xq = nullptr;
             if (s.c->opt_fusion && !emit16 && n->src[1] && op_param_i32(n, 0) == GGML_GLU_OP_SWIGLU && op_param_i32(n, 1) == 0 && n_users(s, n) > 0 &&
-                !(n->flags & GGML_TENSOR_FLAG_OUTPUT) && n->nb[1] == (size_t) n->ne[0] * 4 && swiglu_q8k_ok(td(n->src[0]), b, td(n))) {
+                !is_out(s, n) && n->nb[1] == (size_t) n->ne[0] * 4 && swiglu_q8k_ok(td(n->src[0]), b, td(n))) {
                 bool ok = true;
                 for (int u : s.users[n]) {
                     const ggml_tensor * c = g->nodes[u];
@@ -1316,7 +1345,7 @@ static void compute_node(exec_state & s, int i) {
             }
             // epilogue fusion: when the attention output only feeds K-quant mat-vecs (wo), emit its Q8_K image here
             const ggml_tensor * xuse = nullptr;
-            if (!one && s.c->opt_fusion && n->ne[3] == 1 && n->ne[2] <= 32 && n_users(s, n) > 0 && !(n->flags & GGML_TENSOR_FLAG_OUTPUT) &&
+            if (!one && s.c->opt_fusion && n->ne[3] == 1 && n->ne[2] <= 32 && n_users(s, n) > 0 && !is_out(s, n) &&
                 rms_norm_mul_quant_ok(n->ne[0] * n->ne[1]) && fattn_can_emit_image(f)) {
                 bool ok = true;
                 for (int u : s.users[n]) {
@@ -1392,6 +1421,32 @@ static void run_nodes(exec_state & s, ggml_cgraph * g) {
             }
         }
     }
+    s.external.clear();
+    if (s.c->opt_fusion && g->use_counts && g->visited_hash_set.size > 0 && g->visited_hash_set.keys && g->visited_hash_set.used) {
+        // direct uses inside this cgraph, counted like ggml_build_forward counts them (every src of every node, view nodes included)
+        std::unordered_map<const ggml_tensor *, int> direct;
+        direct.reserve(g->n_nodes * 2);
+        for (int i = 0; i < g->n_nodes; ++i)
+            for (int k = 0; k < GGML_MAX_SRC; ++k) if (g->nodes[i]->src[k]) ++direct[g->nodes[i]->src[k]];
+        const ggml_hash_set & hs = g->visited_hash_set;
+        auto whole = [&](const ggml_tensor * t) -> int {                 // ggml_hash_find (ggml-impl.h:257-270): pointer >> 4, linear probing
+            const size_t h = ((size_t) (uintptr_t) t >> 4) % hs.size;
+            size_t i = h;
+            while ((hs.used[i >> 5] >> (i & 31)) & 1u) {
+                if (hs.keys[i] == t) return g->use_counts[i];
+                i = (i + 1) % hs.size;
+                if (i == h) break;
+            }
+            return -1;
+        };
+        for (int i = 0; i < g->n_nodes; ++i) {
+            const ggml_tensor * t = g->nodes[i];
+            const int w = whole(t);
+            auto it = direct.find(t);
+            if (w > (it == direct.end() ? 0 : it->second))
+                for (const ggml_tensor * r = t; r; r = r->view_src) s.external.insert(r);     // a view read elsewhere keeps its base's bytes alive too
+        }
+    }
     if (s.c->opt_profile && !s.capturing) {
         // calibration sample: an event pair with nothing in between measures the bracket's own cost, which consumers subtract
         for (int k = 0; k < 4; ++k) { prof_scope ps(s, "empty", 0); }
@@ -1406,7 +1461,7 @@ static uint64_t fingerprint(const ggml_cgraph * g) {
     h = mix(h, (uint64_t) g->n_nodes);
     for (int i = 0; i < g->n_nodes; ++i) {
         const ggml_tensor * n = g->nodes[i];
-        h = mix(h, (uint64_t) n->op); h = mix(h, (uint64_t) n->type); h = mix(h, (uint64_t) (uintptr_t) n->data);
+        h = mix(h, (uint64_t) n->op); h = mix(h, (uint64_t) n->type); h = mix(h, (uint64_t) (uintptr_t) n->data); h = mix(h, (uint64_t) (uint32_t) n->flags);
         for (int d = 0; d < 4; ++d) { h = mix(h, (uint64_t) n->ne[d]); h = mix(h, (uint64_t) n->nb[d]); }
         for (int p = 0; p < GGML_MAX_OP_PARAMS / 4; ++p) h = mix(h, (uint64_t) (uint32_t) n->op_params[p]);
         for (int k = 0; k < GGML_MAX_SRC; ++k) {
@@ -1422,11 +1477,14 @@ static uint64_t fingerprint(const ggml_cgraph * g) {
 // ------------------------------------------------------------------------------------------------ graph_compute
 enum ggml_status graph_compute(backend_ctx * c, ggml_cgraph * g) {
     if (g->n_nodes == 0) return GGML_STATUS_SUCCESS;
-    ensure_scratch(c, &c->act_scratch, &c->act_scratch_bytes, graph_act_scratch_need(g));
-    ensure_scratch(c, &c->w_scratch, &c->w_scratch_bytes, graph_w_scratch_need(g));
-    ensure_scratch(c, &c->fa_scratch, &c->fa_scratch_bytes, graph_fa_scratch_need(g));
-    ensure_scratch(c, &c->rope_scratch, &c->rope_scratch_bytes, graph_rope_scratch_need(g));
-    ensure_scratch(c, &c->gemm_partial, &c->gemm_partial_bytes, graph_gemm_partial_need(g));
+    if (!ensure_scratch(c, &c->act_scratch, &c->act_scratch_bytes, graph_act_scratch_need(g)) ||
+        !ensure_scratch(c, &c->w_scratch, &c->w_scratch_bytes, graph_w_scratch_need(g)) ||
+        !ensure_scratch(c, &c->fa_scratch, &c->fa_scratch_bytes, graph_fa_scratch_need(g)) ||
+        !ensure_scratch(c, &c->rope_scratch, &c->rope_scratch_bytes, graph_rope_scratch_need(g)) ||
+        !ensure_scratch(c, &c->gemm_partial, &c->gemm_partial_bytes, graph_gemm_partial_need(g))) {
+        log_msg(GGML_LOG_LEVEL_ERROR, "[mi355x] graph_compute: out of device memory for scratch buffers\n");
+        return GGML_STATUS_ALLOC_FAILED;
+    }
 
     int n_real = 0;
     for (int i = 0; i < g->n_nodes; ++i) n_real += !is_noop(g->nodes[i]);
@@ -1545,8 +1603,7 @@ void backend_ctx_init(backend_ctx * c) {
     if ((e = getenv("MI355X_MV1")))     c->opt_mv1     = atoi(e) != 0;
 }
 void backend_ctx_release(backend_ctx * c) {
-    for (auto & e : c->execs) { if (e.exec) (void) hipGraphExecDestroy(e.exec); if (e.graph) (void) hipGraphDestroy(e.graph); }
-    c->execs.clear();
+    drop_graph_execs(c);
     for (auto ev : c->prof_event_pool) (void) hipEventDestroy(ev);
     if (c->act_scratch) (void) hipFree(c->act_scratch);
     if (c->w_scratch) (void) hipFree(c->w_scratch);
@@ -1565,11 +1622,11 @@ int mi355x_set_option(struct ggml_backend * backend, const char * key, long valu
     if (!strcmp(key, "graphs"))  { c->opt_graphs = value != 0; return 0; }
     if (!strcmp(key, "fusion"))  { c->opt_fusion = value != 0; c->execs.clear(); return 0; }
     if (!strcmp(key, "profile")) { c->opt_profile = value != 0; return 0; }
-    if (!strcmp(key, "norm_in_kernel")) { c->opt_norm_in_kernel = value != 0; c->execs.clear(); return 0; }
-    if (!strcmp(key, "mv1")) { c->opt_mv1 = value != 0; c->execs.clear(); return 0; }
-    if (!strcmp(key, "fattn_gqa")) { mi::fattn_set_gqa(value != 0); c->execs.clear(); return 0; }
-    if (!strcmp(key, "fattn_one")) { mi::fattn_set_one(value != 0); c->execs.clear(); return 0; }
-    if (!strcmp(key, "f16_shadow")) { mi::shadow_set_enabled(value != 0); c->execs.clear(); return 0; }
+    if (!strcmp(key, "norm_in_kernel")) { c->opt_norm_in_kernel = value != 0; mi::drop_graph_execs(c); return 0; }
+    if (!strcmp(key, "mv1")) { c->opt_mv1 = value != 0; mi::drop_graph_execs(c); return 0; }
+    if (!strcmp(key, "fattn_gqa")) { mi::fattn_set_gqa(value != 0); mi::drop_graph_execs(c); return 0; }
+    if (!strcmp(key, "fattn_one")) { mi::fattn_set_one(value != 0); mi::drop_graph_execs(c); return 0; }
+    if (!strcmp(key, "f16_shadow")) { mi::shadow_set_enabled(value != 0); mi::drop_graph_execs(c); return 0; }
     if (!strcmp(key, "reset_stats")) { c->prof.clear(); c->stat_replays = c->stat_captures = c->stat_eager = 0; return 0; }
     return -1;
 }

@@ -59,6 +59,7 @@ struct backend_ctx {
 
 void backend_ctx_init(backend_ctx * c);
 void backend_ctx_release(backend_ctx * c);
+void drop_graph_execs(backend_ctx * c);      // destroy every captured hipGraph of the context (option changes, scratch re-allocation)
 
 bool             supports_op(const ggml_tensor * op);
 enum ggml_status graph_compute(backend_ctx * c, ggml_cgraph * g);

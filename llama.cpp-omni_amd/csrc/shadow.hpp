@@ -11,10 +11,18 @@
 
 namespace mi {
 
-// the image of rows [M x K] at `src` (row stride src_rs), or null when none exists
-const uint16_t * shadow_find(int device, const void * src, int type, int64_t K, int64_t M, size_t src_rs);
-// allocate an (uninitialised) image and register it; null when shadows are disabled or memory is short.  The caller fills it.
-uint16_t *       shadow_create(int device, const void * src, size_t src_bytes, int type, int64_t K, int64_t M, size_t src_rs);
+// The image of rows [M x K] at `src` (row stride src_rs) for use on stream `st`, or null when there is none (yet).  An image is filled by a
+// kernel on its creator's stream: until that kernel is known to have finished, other streams are made to wait on the image's event
+// (hipStreamWaitEvent) -- or, while `capturing` (no cross-stream waits inside a stream capture), get null and take the per-call path.
+const uint16_t * shadow_find(int device, const void * src, int type, int64_t K, int64_t M, size_t src_rs, hipStream_t st, bool capturing);
+// Find-or-create under ONE lock (two contexts sharing a model never register the same image twice).  Returns null when shadows are
+// disabled, memory is short or another thread is still filling this image; *created tells the caller to launch the fill kernel on `st`
+// and then call shadow_mark_ready(image, st).
+uint16_t *       shadow_get_or_create(int device, const void * src, size_t src_bytes, int type, int64_t K, int64_t M, size_t src_rs, hipStream_t st, bool capturing, bool * created);
+void             shadow_mark_ready(const void * image, hipStream_t st);
+// drop every image of the device (an allocation failed: the images are the first thing to give back); returns the bytes freed
+size_t           shadow_drop_all(int device);
+size_t           shadow_bytes(int device);
 // bytes [p, p+n) of device memory are about to change: drop the overlapping images
 void             shadow_invalidate(int device, const void * p, size_t n);
 // bumped whenever an image is dropped: captured hipGraphs that baked an image pointer in are stale after that
