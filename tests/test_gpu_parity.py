@@ -524,12 +524,25 @@ def test_prefill_ubatch_vs_reference_backend(pkg, be, ref_be, wtype):
     # activations to Q8_K (int8 per 256) before its integer dot, the GEMM path keeps them in f16 (what the reference's GPU backends
     # do too) -- per op that difference is ~1e-5 NMSE (test_mul_mat_gemm_path_vs_oracle, bar 5e-4), end to end over two layers and
     # the lm-head it compounds to ~5e-4, almost all of it the CPU's own activation-quantisation noise
+    # Per op the quantised path is proven at the pp512 shapes in test_round2_gpu.py::test_prefill_512_tokens_per_op_vs_oracle_and_exact (NMSE
+    # vs the oracle < 5e-5, and closer to the exact product than the oracle is).  End to end the bar cannot be the per-op bar: every
+    # following mat-mul re-quantises its input to Q8_K on the CPU side, and test_oracle.py::test_reference_decorrelates_under_a_1e6_
+    # perturbation shows the reference itself moving by ~1e-3 NMSE under a 1e-6 input perturbation.
     bar = 1e-5 if wtype == "f16" else 2e-3
     for a, b in zip(outs[0], outs[1]):
         assert np.isfinite(a).all()
         assert nmse(a, b) < bar, (wtype, nmse(a, b))
-    agree = np.mean(np.argmax(outs[0][0].reshape(T, -1), 1) == np.argmax(outs[1][0].reshape(T, -1), 1))
-    assert agree > (0.99 if wtype == "f16" else 0.9), agree           # (random weights: near-ties may flip between f16 GEMM and integer dot)
+    # arg-max: identical wherever the reference's own top logits are separated by more than the noise between the two runs
+    lg, lr = outs[0][0].reshape(T, -1), outs[1][0].reshape(T, -1)
+    same = 0
+    for t in range(T):
+        ig, ir = int(np.argmax(lg[t])), int(np.argmax(lr[t]))
+        if ig == ir:
+            same += 1
+        else:
+            rms = float(np.sqrt(np.mean((lg[t] - lr[t]) ** 2)))
+            assert lr[t][ig] >= lr[t].max() - 4.0 * rms, (wtype, t)
+    assert same >= (0.99 if wtype == "f16" else 0.9) * T, same
 
 
 @pytest.mark.parametrize("n_kv,T,steps", [(768, 300, 3), (2048, 1500, 2)])

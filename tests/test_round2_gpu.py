@@ -157,6 +157,38 @@ def test_flash_attn_prefill_2048_vs_oracle(pkg, be):
     assert num / den < 5e-4, num / den
 
 
+# ------------------------------------------------------------------------------------------------ C2 pp512: the F16-image GEMM path, per op
+@pytest.mark.parametrize("name,M,K", [("q4_K", 4096, 4096), ("q4_K", 12288, 4096), ("q6_K", 4096, 12288), ("q6_K", 1024, 4096)])
+def test_prefill_512_tokens_per_op_vs_oracle_and_exact(pkg, be, name, M, K):
+    """A 512-token ubatch of a Q4_K_M model multiplies f16-rounded activations with the resident F16 image of the de-quantised weights (what
+    the reference's GPU backends do, ggml-cuda.cu:1211-1355) where the CPU oracle quantises the activations to Q8_K first.  At the real
+    pp512 shapes (n_embd 4096 / n_ff 12288, 512 columns, sampled weight rows): (a) against the oracle the reference's MUL_MAT bar, NMSE
+    5e-4, holds with two orders of magnitude to spare; (b) against the exact product (bit-exact de-quantised weights x f32 activations
+    in float64) this path is CLOSER than the oracle's own integer arithmetic -- the difference between the two is the oracle's
+    activation-quantisation noise, not an error of this backend."""
+    from llama_cpp_omni_amd import qwen3
+    from test_gpu_parity import run_graph
+    ty = {"q4_K": pkg.GGML_TYPE_Q4_K, "q6_K": pkg.GGML_TYPE_Q6_K}[name]
+    rng = np.random.default_rng(M + K)
+    N, R = 512, 192
+    wv = qwen3.random_blocks(rng, ty, M, K, std=0.05)
+    wb = wv.view(np.uint8).reshape(M, -1)
+    xv = (rng.standard_normal((N, K)) * np.exp(rng.standard_normal((N, 1)))).astype(np.float32)     # token rows of different scale
+    c = pkg.Context(be)
+    w = c.new_tensor(ty, K, M); x = c.new_tensor(pkg.GGML_TYPE_F32, K, N)
+    y = c.mul_mat(w, x)
+    (got,) = run_graph(be, c, [y], [(w, wv), (x, xv)])
+    got = got.reshape(N, M)
+    rows = rng.choice(M, R, replace=False)
+    want = orc.mul_mat(ty, wb[rows], xv)                                  # [N, R]: Q8_K activations, integer dots
+    wd = np.stack([orc.dequantize(ty, wb[r], K) for r in rows]).astype(np.float64)   # bit-exact de-quantisation (pinned to the reference's golden blocks)
+    exact = xv.astype(np.float64) @ wd.T
+    e_oracle, e_gpu_exact, e_orc_exact = nmse(got[:, rows], want), nmse(got[:, rows], exact), nmse(want, exact)
+    assert np.isfinite(got).all()
+    assert e_oracle < 5e-5, (name, M, K, e_oracle)                        # (the reference's own bar is 5e-4)
+    assert e_gpu_exact < 1e-6 and e_gpu_exact < e_orc_exact, (e_gpu_exact, e_orc_exact)
+
+
 # ------------------------------------------------------------------------------------------------ 8B shape through the reference libllama
 def _greedy_all(gguf, ngl, fa, dump, n, threads, env_extra=None, forced=None):
     env = dict(os.environ)
