@@ -1451,7 +1451,18 @@ static void run_nodes(exec_state & s, ggml_cgraph * g) {
         // calibration sample: an event pair with nothing in between measures the bracket's own cost, which consumers subtract
         for (int k = 0; k < 4; ++k) { prof_scope ps(s, "empty", 0); }
     }
-    for (int i = 0; i < g->n_nodes; ++i) if (!s.done[i]) compute_node(s, i);
+    for (int i = 0; i < g->n_nodes; ++i) {
+        if (s.done[i]) continue;
+        compute_node(s, i);
+        if (!s.capturing) {                                  // a launch with an invalid configuration fails silently otherwise (and poisons a later capture)
+            const hipError_t e = hipGetLastError();
+            if (e != hipSuccess) {
+                log_msg(GGML_LOG_LEVEL_ERROR, "[mi355x] graph_compute: node %d (%s, op %d, ne = [%lld, %lld, %lld, %lld]) failed to launch: %s\n", i, g->nodes[i]->name, (int) g->nodes[i]->op,
+                        (long long) g->nodes[i]->ne[0], (long long) g->nodes[i]->ne[1], (long long) g->nodes[i]->ne[2], (long long) g->nodes[i]->ne[3], hipGetErrorString(e));
+                abort();
+            }
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ fingerprint

@@ -39,10 +39,10 @@ static size_t max_total_bytes() {
 static bool entry_usable(shadow_entry & e, hipStream_t st, bool capturing) {
     if (e.complete) return true;
     if (!e.recorded) return false;                                   // its creator has not even launched the fill yet
+    if (capturing) return st == e.owner;                             // (no event query / cross-stream wait inside a stream capture: both invalidate it)
     if (hipEventQuery(e.ready) == hipSuccess) { e.complete = true; return true; }
     (void) hipGetLastError();
     if (st == e.owner) return true;                                  // same stream: ordered behind the fill
-    if (capturing) return false;
     HIP_CHECK(hipStreamWaitEvent(st, e.ready, 0));
     return true;
 }

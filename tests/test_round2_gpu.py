@@ -244,3 +244,48 @@ def test_8b_shape_greedy_ids_through_reference_libllama(tmp_path, fa):
             assert l_cpu[t][ids_gpu[t]] >= l_cpu[t].max() - 4.0 * rms, (t, ids_gpu[t], ids_cpu[t])
     assert exact >= int(0.6 * n), (exact, ids_gpu, ids_cpu)    # (fa=0: 29 of 32, fa=1: 21 of 32 on this fixture; every mismatch passed the near-tie rule)
     print(f"fa={fa}: {exact}/{n} ids identical, worst step NMSE {max(float(((l_gpu[t] - l_cpu[t]) ** 2).sum() / (l_cpu[t] ** 2).sum()) for t in range(n)):.2e}")
+
+
+# ------------------------------------------------------------------------------------------------ the omni TTS decoder at its real shape
+@pytest.mark.parametrize("types", ["q8_0", "f16"])
+def test_tts_real_shape_embd_input_through_libllama(tmp_path, types):
+    """the omni TTS decoder (arch llama, 20 layers, n_embd 768, 12 heads x 64, n_ff 3072, vocab 32000, RoPE NORM, no
+    q/k-norm; reference tools/omni/convert/tts.txt) as a synthetic GGUF, driven by the reference's libllama through the `llama_batch::embd`
+    input path -- what prefill_with_emb_tts uses (reference tools/omni/omni.cpp:2081): a 26-row embedding prefill (one LLM chunk,
+    max_new_speak_tokens_per_chunk) and 24 single-embedding decode steps.  The inputs do not depend on the outputs, so every step compares
+    logits on identical inputs: `-ngl 99` with this plug-in against `-ngl 0`."""
+    if not os.path.exists(BIN):
+        pytest.skip("oracle/_ref/llama-bench-min not built (make -f oracle/Makefile.ref llama)")
+    gguf = str(tmp_path / "tts.gguf")
+    subprocess.run([sys.executable, os.path.join(ROOT, "tools", "make_synth_gguf.py"), "--config", "tts", "--types", types, "-o", gguf, "--n-ctx", "4096",
+                    "--distinct-layers"], check=True, timeout=900)
+    n, threads = 24, max(4, min(32, len(os.sched_getaffinity(0)) // 2))
+
+    def run(ngl, extra):
+        env = dict(os.environ)
+        env.pop("GGML_BACKEND_PATH", None)
+        env.update(extra)
+        dump = str(tmp_path / f"l{ngl}.bin")
+        out = subprocess.run([BIN, "-m", gguf, "-ngl", str(ngl), "-fa", "1", "--greedy", str(n), "-t", str(threads), "--embd", "--dump-all-logits", dump],
+                             env=env, capture_output=True, text=True, timeout=900)
+        assert out.returncode == 0, out.stderr[-2000:]
+        return json.loads(out.stdout.strip().splitlines()[-1])["greedy_ids"], np.fromfile(dump, np.float32).reshape(n, -1), out.stderr
+
+    ids_c, l_c, _ = run(0, {})
+    ids_g, l_g, err = run(99, {"GGML_BACKEND_PATH": LIB})
+    assert "MI355X0" in err and "offloaded 21/21 layers to GPU" in err
+    same = 0
+    for t in range(n):
+        e = float(((l_g[t] - l_c[t]) ** 2).sum() / (l_c[t] ** 2).sum())
+        assert e < (1e-3 if types == "f16" else 3e-2), (t, e)       # (quantised: the Q8_0 re-quantisation noise floor, cf. the 8B test)
+        if ids_g[t] == ids_c[t]:
+            same += 1
+        else:
+            rms = float(np.sqrt(np.mean((l_g[t] - l_c[t]) ** 2)))
+            assert l_c[t][ids_g[t]] >= l_c[t].max() - 4.0 * rms, t
+    assert same >= int(0.75 * n), (same, ids_g, ids_c)
+    # and the llama-bench loops on the same input path (numbers are printed for profiles/)
+    out = subprocess.run([BIN, "-m", gguf, "-ngl", "99", "-fa", "1", "-p", "26", "-n", "128", "-r", "3", "-t", "8", "--embd"],
+                         env=dict(os.environ, GGML_BACKEND_PATH=LIB), capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-1500:]
+    print(f"TTS {types}:", out.stdout.strip().replace("\n", " | "))
