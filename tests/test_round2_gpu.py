@@ -289,3 +289,65 @@ def test_tts_real_shape_embd_input_through_libllama(tmp_path, types):
                          env=dict(os.environ, GGML_BACKEND_PATH=LIB), capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-1500:]
     print(f"TTS {types}:", out.stdout.strip().replace("\n", " | "))
+
+
+# ------------------------------------------------------------------------------------------------ omni encoders at their real shapes
+def _fill(backend, rng, tensors, scales):
+    for t, sc in zip(tensors, scales):
+        n = t.nelements()
+        v = (rng.standard_normal(n) * float(sc)).astype(np.float32)
+        backend.tensor_set(t, v.astype(np.float16) if t.type == 1 else v)
+
+
+def _flat_weights(W):
+    out = [v for k, v in W.items() if k != "layers"]
+    for L in W["layers"]:
+        out += list(L.values())
+    return out
+
+
+@pytest.mark.parametrize("which", ["whisper", "siglip2"])
+def test_omni_encoder_layer_at_real_shape_vs_reference_backend(pkg, be, ref_be, which):
+    """SURVEY.md 8(f) rank 3 at the real widths, built node for node as the reference emits them (llama.cpp-omni_amd/encoders.py):
+    whisper  -- APM front end + ONE encoder layer + tail: 3000 mel frames -> conv1d_ph x2 -> 1500 tokens, n_state 1024, 16 heads x 64,
+                F16 K / V, 1500 x 1500 soft-max, MLP 4096, final LN, two projections, avg-pool(5)     (audition.cpp:341-715)
+    siglip2  -- VPM: ggml_conv_2d patch embedding of a 448 x 448 image (1024 patches), ONE ViT layer at n_embd 1152, 16 heads x 72 (f32
+                K.Q^T with K = 72), FFN 4304 with GELU, post LN                                        (vision.cpp:394-705)
+    Every node must be accepted by supports_op (a declined node would silently run on the CPU under the scheduler) and the output must match
+    the reference CPU backend on the same graph."""
+    from llama_cpp_omni_amd import encoders as E
+    outs = []
+    for backend in (be, ref_be):
+        rng, rng0 = np.random.default_rng(7), np.random.default_rng(8)
+        c = pkg.Context(backend)
+        if which == "whisper":
+            W = E.whisper_weights(c, E.WHISPER, 1)
+            inp, out = E.whisper(c, E.WHISPER, W, 3000)
+        else:
+            W = E.siglip2_weights(c, E.SIGLIP2, 1)
+            inp, out = E.siglip2(c, E.SIGLIP2, W)
+        if backend is be:
+            bad = E.declined_nodes(backend, c)
+            assert not bad, f"supports_op declined: {bad}"
+        c.alloc()
+        ws = _flat_weights(W)
+        # matrices ~ 1/sqrt(fan_in), norm gains ~ 1, biases small: activations stay O(1) through the layer
+        sc = []
+        for t in ws:
+            if t.type == 1 or t.ne[1] > 1 and t.ne[0] > 8:
+                fan = t.ne[0] * (t.ne[1] if len([d for d in t.ne if d > 1]) > 2 else 1)
+                sc.append(1.0 / np.sqrt(fan))
+            else:
+                sc.append(0.1)
+        _fill(backend, rng, ws, sc)
+        for key in ("ln_w", "post_ln_w"):
+            if key in W:
+                backend.tensor_set(W[key], (1.0 + 0.1 * rng0.standard_normal(W[key].nelements())).astype(np.float32))
+        backend.tensor_set(inp, rng.standard_normal(inp.nelements()).astype(np.float32))
+        backend.graph_compute(c.graph())
+        outs.append(backend.tensor_get(out).copy())
+        c.free()
+    assert np.isfinite(outs[0]).all()
+    e = nmse(outs[0], outs[1])
+    print(which, "NMSE vs the reference CPU backend:", e)
+    assert e < 5e-4, e
