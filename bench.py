@@ -82,7 +82,7 @@ class Decoder:
 def cpu_baseline(pkg, cfg, types, n_kv, seconds_budget=24.0):
     """Reference CPU backend (oracle/_ref, built from /root/reference sources) on the SAME decode graph, timed on this box's host
     cores for a bounded sample.  Thread counts come from the cores this process may actually run on (sched_getaffinity: a cgroup /
-    affinity mask smaller than the machine would otherwise be oversubscribed); the sweep {all, half, physical} is timed and the best is
+    affinity mask smaller than the machine would otherwise be oversubscribed); an ascending sweep up to that count is timed and the best is
     reported together with the bandwidth it implies."""
     try:
         sys.path.insert(0, ROOT)
@@ -99,7 +99,10 @@ def cpu_baseline(pkg, cfg, types, n_kv, seconds_budget=24.0):
         except Exception:
             phys = set()
         n_phys = len(phys) if phys else n_aff
-        cands = sorted({max(1, n_aff), max(1, n_aff // 2), max(1, n_phys), max(1, n_phys // 2)}, reverse=True)[:4]
+        # ascending sweep, stopped at the first thread count that is slower than the one before (an oversubscribed pool of spinning
+        # ggml workers can be 100x slower: one step at 256 threads took 90 s on a 256-CPU box whose best was 64) -- the pilot step of
+        # each count is what bounds the time, a slow one ends the sweep
+        cands = sorted({c for c in (8, 16, 32, 64, max(1, n_phys // 2), n_phys, n_aff) if 1 <= c <= n_aff})
         wbytes = None
         results = []
         be = make_ref_cpu_backend(pkg, cands[0])
@@ -107,16 +110,23 @@ def cpu_baseline(pkg, cfg, types, n_kv, seconds_budget=24.0):
         wbytes = dec.model.weight_bytes()
         dec.step(0)                                              # warm-up (page-in, thread pool)
         pos = 1
-        per = seconds_budget / len(cands)
+        per = seconds_budget / 4
         for th in cands:
             be.set_n_threads(th)
-            dec.step(pos); pos += 1                              # thread-pool resize outside the timed region
+            t0 = time.perf_counter()
+            dec.step(pos); pos += 1                              # pilot: thread-pool resize outside the timed region
+            pilot = time.perf_counter() - t0
+            if results and pilot > 3.0 / max(results)[0]:        # 3x slower than the best so far: past the knee
+                results.append((1.0 / pilot, th, 1))
+                break
             t0 = time.perf_counter()
             n = 0
             while n < 48 and (time.perf_counter() - t0) < per:
                 dec.step(pos); pos += 1; n += 1
             dt = time.perf_counter() - t0
             results.append((n / dt, th, n))
+            if len(results) >= 2 and results[-1][0] < 0.8 * results[-2][0]:
+                break
         be.close()
         best = max(results)
         return {"value": round(best[0], 3), "unit": "tok/s", "cores": best[1], "kind": "reference",
@@ -277,6 +287,65 @@ def c3_prefill(pkg, be, n_seq=8, n_prompt=2048, n_ubatch=512, tiny=False):
             "frac_of_dense_f16_peak": round(flops / dt / 1e12 / MFMA_F16_PEAK_TFLOPS, 4), "n_seq": n_seq, "n_prompt": n_prompt, "n_ubatch": n_ubatch}
 
 
+class Replicas:
+    """N > 1: one process per GPU (torch.distributed.run), each a whole-model replica; no data-path collective (decode of one sequence does
+    not shard).  The only communication is the contract's: barrier + synchronize on both sides of the timed region and the
+    MAX over ranks of the elapsed time; `value` = units of all ranks / that time.
+    Test hooks (1-GPU box / CPU smoke of this very code): MI355X_BENCH_DIST_BACKEND=gloo -> CPU rendezvous instead of RCCL;
+    MI355X_BENCH_SHARE_GPU=1 -> every rank on device 0.  The driver's real N > 1 runs use neither."""
+
+    def __init__(self):
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.backend = os.environ.get("MI355X_BENCH_DIST_BACKEND", "nccl")
+        self.dev_index = 0 if os.environ.get("MI355X_BENCH_SHARE_GPU") else self.local_rank
+        self.dist = None
+        if self.world > 1:
+            import torch
+            import torch.distributed as dist
+            if self.backend == "nccl":
+                torch.cuda.set_device(self.dev_index)
+                dist.init_process_group(backend="nccl", device_id=torch.device("cuda", self.dev_index))
+            else:
+                dist.init_process_group(backend=self.backend)
+            self.dist = dist
+
+    def barrier(self, device_sync):
+        device_sync()
+        if self.dist is not None:
+            self.dist.barrier()
+            if self.backend == "nccl":
+                import torch
+                torch.cuda.synchronize()
+
+    def timed(self, step, steps, warmup, device_sync):
+        """W untimed warm-up steps, then EXACTLY `steps` steps bracketed by barrier + synchronize; returns the MAX over ranks of the seconds"""
+        pos = 0
+        for _ in range(warmup):
+            step(pos); pos += 1
+        self.barrier(device_sync)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step(pos); pos += 1
+        self.barrier(device_sync)
+        dt = time.perf_counter() - t0
+        if self.dist is not None:
+            import torch
+            t = torch.tensor([dt], dtype=torch.float64, device="cuda" if self.backend == "nccl" else "cpu")
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt, pos
+
+    def aggregate(self, steps, dt):
+        return self.world * steps / dt                               # whole-job units per second (weak scaling: per-rank work is fixed)
+
+    def finish(self):
+        if self.dist is not None:
+            self.dist.barrier()
+            self.dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -289,26 +358,11 @@ def main():
     ap.add_argument("--no-c3", action="store_true", help="skip the C3 leg")
     args = ap.parse_args()
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    dist = None
-    # test hooks (1-GPU box smoke of the multi-process path): MI355X_BENCH_DIST_BACKEND=gloo + MI355X_BENCH_SHARE_GPU=1 run every rank on
-    # device 0 with a CPU rendezvous; the driver's real N > 1 runs use neither (one rank per GPU, RCCL)
-    dist_backend = os.environ.get("MI355X_BENCH_DIST_BACKEND", "nccl")
-    dev_index = 0 if os.environ.get("MI355X_BENCH_SHARE_GPU") else local_rank
-    if world > 1:
-        import torch
-        import torch.distributed as dist
-        if dist_backend == "nccl":
-            torch.cuda.set_device(dev_index)
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", dev_index))
-        else:
-            dist.init_process_group(backend=dist_backend)
-
+    rep = Replicas()
+    world, rank = rep.world, rep.rank
     pkg = load_pkg()
     from llama_cpp_omni_amd import qwen3
-    be = pkg.backend(dev_index if world > 1 else 0)
+    be = pkg.backend(rep.dev_index if world > 1 else 0)
     cfg = qwen3.TINY if args.tiny else qwen3.QWEN3_8B
     types = qwen3.q4_k_m_types(cfg)
     n_kv = 256                                                     # llama pads the visible KV length to 256 with FA
@@ -317,34 +371,13 @@ def main():
     dec = Decoder(pkg, be, cfg, types, n_ctx=n_ctx, n_kv=n_kv, flash_attn=not args.no_fa)
     wbytes = dec.model.weight_bytes()
 
-    def barrier():
-        be.synchronize()
-        if dist is not None:
-            import torch
-            dist.barrier()
-            if dist_backend == "nccl":
-                torch.cuda.synchronize()
-
-    pos = 0
-    for _ in range(args.warmup):
-        dec.step(pos); pos += 1
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        dec.step(pos); pos += 1
-    barrier()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        import torch
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda" if dist_backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt, pos = rep.timed(dec.step, args.steps, args.warmup, be.synchronize)
     replays = be.get_stat("graph_replays")
     kernels = be.get_stat("kernels_last_graph")
 
     # ---- dominant kernel, measured live: replay of exactly the step's Q4_K mat-vec launches with HIP events at both ends
     roof = None
-    if rank == 0:
+    if rank == 0 and not args.tiny:                               # (the tiny plumbing config is below the batch-1 kernels' shapes: no roofline)
         roof = kernel_roofline(pkg, be, dec.model)
         if os.environ.get("MI355X_BENCH_PROFILE"):
             be.set_option("profile", 1)
@@ -363,7 +396,7 @@ def main():
             sys.stderr.write("eager per-class profile (HIP events around every launch): " + json.dumps(prof) + "\n")
 
     if rank == 0:
-        tok_s = world * args.steps / dt
+        tok_s = rep.aggregate(args.steps, dt)
         out = {
             "metric": "llama-bench tg128 tok/s (decode, batch 1), Qwen3-8B Q4_K_M" if not args.tiny else "decode tok/s (tiny plumbing config)",
             "value": round(tok_s, 2), "unit": "tok/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -393,9 +426,7 @@ def main():
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    rep.finish()
 
 
 if __name__ == "__main__":

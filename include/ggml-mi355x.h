@@ -23,9 +23,12 @@ extern "C" {
 #define GGML_MI355X_API __attribute__((visibility("default")))
 #define GGML_MI355X_NAME "MI355X"          /* registry name; devices are "MI355X0", "MI355X1", ... */
 
+#include <stddef.h>
+
 struct ggml_backend_reg;
 struct ggml_backend_buffer;
 struct ggml_backend;
+struct ggml_tensor;
 
 /* replaces: the `ggml_backend_init` entry a backend module exports (GGML_BACKEND_DL_IMPL,
  * reference ggml/src/ggml-backend-impl.h:220-233).  Returns the statically owned registry object
@@ -63,6 +66,23 @@ GGML_MI355X_API double mi355x_get_stat(struct ggml_backend * backend, const char
  * layouts in csrc/common.hpp) on `nrows` host rows of K floats and return the images to host memory, so the integer
  * stage can be compared bit-for-bit with the reference's quantize_row_q8_K / quantize_row_q8_0.  Returns bytes per image. */
 GGML_MI355X_API long   mi355x_debug_quantize(struct ggml_backend * backend, int kind, const float * host_x, long K, long nrows, void * host_images);
+
+/* ---- omni pipeline: module pinning and the LLM -> TTS hidden-state hand-off (BASELINE configs[3], [4]) ----------------
+ *
+ * replaces: the host round trip of `LLMOut::hidden_states` (std::vector<float> filled from llama_get_embeddings, reference
+ * tools/omni/omni.cpp:256-270; consumed by prefill_with_emb_tts :2081 and the projector graph :1187-1258).  With the LLM and the TTS
+ * decoder on different MI355X the rows go GPU to GPU: RCCL ncclSend / ncclRecv over one xGMI link, stream-ordered behind the LLM graph on
+ * `src_backend` and in front of whatever `dst_backend` runs next; no host synchronisation.  `src` / `dst` are device pointers inside
+ * buffers of the respective backend (e.g. tensor->data).  Returns 1 (RCCL), 2 (peer-copy fallback: librccl absent or
+ * MI355X_HANDOFF=peer), 0 (nbytes == 0), < 0 on error.  mi355x_handoff_tensor moves a dense f32 / f16 tensor into one of equal size. */
+GGML_MI355X_API int    mi355x_handoff_init(void);                      /* optional: build the communicators now; returns ranks (0 = fallback) */
+GGML_MI355X_API int    mi355x_handoff(struct ggml_backend * src_backend, const void * src, struct ggml_backend * dst_backend, void * dst, size_t nbytes);
+GGML_MI355X_API int    mi355x_handoff_tensor(struct ggml_backend * src_backend, const struct ggml_tensor * src, struct ggml_backend * dst_backend, struct ggml_tensor * dst);
+GGML_MI355X_API long   mi355x_handoff_count(int kind);                 /* hand-offs done so far through RCCL (1) / peer copies (2) */
+GGML_MI355X_API void   mi355x_handoff_shutdown(void);
+/* replaces: nothing in the reference (it loads every module on the default device); the device ordinal ("MI355X<i>") a module of the
+ * omni pipeline is pinned to: "vpm", "apm", "llm", "tts", "t2w", "vocoder" -> 0..5 modulo the visible devices, or MI355X_MODULE_MAP. */
+GGML_MI355X_API int    mi355x_module_device(const char * module);
 
 /* standalone harness only (no libggml-base in the process): what ggml_backend_buffer_free does
  * (reference ggml/src/ggml-backend.cpp:108-117): iface.free_buffer, then delete the object. */

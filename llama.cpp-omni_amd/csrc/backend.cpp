@@ -314,6 +314,12 @@ static void * reg_proc(ggml_backend_reg_t, const char * name) {
     if (!strcmp(name, "mi355x_set_option"))          return (void *) mi355x_set_option;
     if (!strcmp(name, "mi355x_get_stat"))            return (void *) mi355x_get_stat;
     if (!strcmp(name, "mi355x_debug_quantize"))      return (void *) mi355x_debug_quantize;
+    if (!strcmp(name, "mi355x_handoff_init"))        return (void *) mi355x_handoff_init;
+    if (!strcmp(name, "mi355x_handoff"))             return (void *) mi355x_handoff;
+    if (!strcmp(name, "mi355x_handoff_tensor"))      return (void *) mi355x_handoff_tensor;
+    if (!strcmp(name, "mi355x_handoff_count"))       return (void *) mi355x_handoff_count;
+    if (!strcmp(name, "mi355x_handoff_shutdown"))    return (void *) mi355x_handoff_shutdown;
+    if (!strcmp(name, "mi355x_module_device"))       return (void *) mi355x_module_device;
     return nullptr;
 }
 static const ggml_backend_reg_i k_reg_iface = { reg_name, reg_dev_count, reg_get_dev, reg_proc };

@@ -186,6 +186,11 @@ def load_library():
         lib.mi355x_get_stat.restype = C.c_double
         lib.mi355x_debug_quantize.argtypes = [_vp, C.c_int, _vp, C.c_long, C.c_long, _vp]
         lib.mi355x_debug_quantize.restype = C.c_long
+        lib.mi355x_handoff.argtypes = [_vp, _vp, _vp, _vp, C.c_size_t]
+        lib.mi355x_handoff_tensor.argtypes = [_vp, _vp, _vp, _vp]
+        lib.mi355x_handoff_count.argtypes = [C.c_int]
+        lib.mi355x_handoff_count.restype = C.c_long
+        lib.mi355x_module_device.argtypes = [C.c_char_p]
         _LIB = lib
     return _LIB
 
@@ -338,6 +343,10 @@ class Backend:
 
     def get_stat(self, key):
         return self.lib.mi355x_get_stat(self.be, key.encode())
+
+    def handoff_tensor(self, src, dst_backend, dst):
+        """device-to-device hand-off of a dense tensor to a tensor of another backend (RCCL send / recv; include/ggml-mi355x.h)"""
+        return self.lib.mi355x_handoff_tensor(self.be, src.ptr, dst_backend.be, dst.ptr)
 
     def timed_event(self):
         return self.lib.mi355x_timed_event_new()

@@ -76,22 +76,28 @@ def test_q4_k_m_type_map():
 
 
 def test_bench_replica_logic_world2_gloo(tmp_path):
-    """bench.py's N>1 path = independent replicas + barrier + MAX-reduce of the elapsed time.  Exercised here with
-    two gloo ranks on CPU (the GPU part is replaced by a sleep of different length per rank)."""
+    """bench.py's N > 1 path is its `Replicas` class: rank / device from the launcher's env, barrier + synchronize on both sides of exactly K
+    timed steps, MAX over ranks of the elapsed time, value = units of all ranks / that time.  Two gloo ranks on CPU run THAT code (imported
+    from bench.py) around a stand-in step of different length per rank; the GPU form of the same launch is
+    tests/test_round2_gpu.py::test_bench_runs_as_two_ranks_through_its_gloo_hooks."""
     script = tmp_path / "w2.py"
     script.write_text(
-        "import os, time, torch, torch.distributed as dist\n"
-        "dist.init_process_group(backend='gloo')\n"
-        "rank = dist.get_rank(); world = dist.get_world_size()\n"
-        "dist.barrier(); t0 = time.perf_counter(); time.sleep(0.05 * (rank + 1)); dist.barrier(); dt = time.perf_counter() - t0\n"
-        "t = torch.tensor([0.05 * (rank + 1)], dtype=torch.float64); dist.all_reduce(t, op=dist.ReduceOp.MAX)\n"
-        "steps = 10; value = world * steps / float(t.item())\n"
-        "if rank == 0: print('VALUE', value, float(t.item()))\n"
-        "dist.destroy_process_group()\n")
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533")
+        "import os, sys, time\n"
+        f"sys.path.insert(0, {ROOT!r})\n"
+        "import bench\n"
+        "rep = bench.Replicas()\n"
+        "assert rep.world == 2 and rep.backend == 'gloo' and rep.dev_index == 0\n"
+        "calls, syncs = [], []\n"
+        "def step(pos): calls.append(pos); time.sleep(0.02 * (rep.rank + 1))\n"
+        "dt, pos = rep.timed(step, 5, 2, lambda: syncs.append(1))\n"
+        "assert calls == list(range(7)) and pos == 7 and len(syncs) == 2\n"
+        "if rep.rank == 0: print('VALUE', rep.aggregate(5, dt), dt)\n"
+        "rep.finish()\n")
+    env = dict(os.environ, MI355X_BENCH_DIST_BACKEND="gloo", MI355X_BENCH_SHARE_GPU="1")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                         "--master-port", "29533", str(script)], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]
     line = [l for l in r.stdout.splitlines() if l.startswith("VALUE")][0].split()
-    assert abs(float(line[2]) - 0.10) < 1e-9                      # MAX over ranks
-    assert abs(float(line[1]) - 2 * 10 / 0.10) < 1e-6             # whole-job aggregate = units of all ranks / max time
+    dt = float(line[2])
+    assert 0.2 <= dt < 0.5                                        # MAX over ranks: the slow rank's 5 x 0.04 s, not rank 0's 5 x 0.02 s
+    assert abs(float(line[1]) - 2 * 5 / dt) < 1e-6                # whole-job aggregate = units of all ranks / max time

@@ -351,3 +351,92 @@ def test_omni_encoder_layer_at_real_shape_vs_reference_backend(pkg, be, ref_be, 
     e = nmse(outs[0], outs[1])
     print(which, "NMSE vs the reference CPU backend:", e)
     assert e < 5e-4, e
+
+
+# ------------------------------------------------------------------------------------------------ (e) hand-off, module pinning, N > 1 bench path
+def _n_devices(pkg, be):
+    return int(be.reg.contents.iface.get_device_count(be.reg))
+
+
+def test_llm_to_tts_handoff_on_device(pkg, be):
+    """The LLM -> TTS hidden-state hand-off (include/ggml-mi355x.h mi355x_handoff*, csrc/handoff.cpp): a [26 x 4096] f32 chunk produced by a graph
+    on one backend is moved on the device and consumed by a graph on another backend, with no host synchronisation in between.
+    On this 1-GPU box: (a) inside one backend the exchange goes through RCCL (self send / recv: communicator, group, stream plumbing);
+    (b) between two backends (two streams) of device 0 it is the device-copy path with an event; both must deliver the producer's values to
+    the consumer graph.  The cross-device form (RCCL over xGMI) is test_handoff_between_two_devices (needs >= 2 GPUs)."""
+    from test_gpu_parity import run_graph
+    rng = np.random.default_rng(26)
+    hv = rng.standard_normal((26, 4096)).astype(np.float32)
+    be2 = pkg.Backend(0)                                               # a second backend (own stream) on the same device: the "TTS" side
+    try:
+        for dst_be, want_path in ((be, 1), (be2, 2)):
+            cs = pkg.Context(be)                                       # producer ("LLM"): h = x * 2
+            x = cs.new_tensor(pkg.GGML_TYPE_F32, 4096, 26)
+            h = cs.scale(x, 2.0)
+            cs.alloc()
+            cd = pkg.Context(dst_be)                                   # consumer ("TTS"): y = e + 1
+            e = cd.new_tensor(pkg.GGML_TYPE_F32, 4096, 26)
+            y = cd.scale(e, 1.0, 1.0)
+            cd.alloc()
+            dst_be.tensor_set(e, np.zeros((26, 4096), np.float32))
+            be.tensor_set(x, hv)
+            be.graph_compute(cs.graph())                               # asynchronous on the producer's stream
+            rc = be.handoff_tensor(h, dst_be, e)                       # queued behind it; the consumer's stream waits for the data
+            assert rc == want_path, rc
+            dst_be.graph_compute(cd.graph())
+            got = dst_be.tensor_get(y)
+            assert np.array_equal(got.reshape(26, 4096), hv * 2.0 + 1.0)
+            cs.free(); cd.free()
+        assert be.lib.mi355x_handoff_count(1) >= 1 and be.lib.mi355x_handoff_count(2) >= 1
+    finally:
+        be2.close()
+
+
+def test_handoff_between_two_devices(pkg, be):
+    """LLM on MI355X<a>, TTS on MI355X<b> (mi355x_module_device): RCCL ncclSend / ncclRecv over xGMI; also ggml's own cpy_tensor_async
+    (hipMemcpyPeerAsync) between the two devices' buffers."""
+    if _n_devices(pkg, be) < 2:
+        pytest.skip("needs two MI355X in one box (the driver's multi-GPU node); the 1-GPU forms run in test_llm_to_tts_handoff_on_device")
+    a, b = be.lib.mi355x_module_device(b"llm"), be.lib.mi355x_module_device(b"tts")
+    assert a != b
+    bs, bd = pkg.Backend(a), pkg.Backend(b)
+    rng = np.random.default_rng(1)
+    hv = rng.standard_normal((26, 4096)).astype(np.float32)
+    cs, cd = pkg.Context(bs), pkg.Context(bd)
+    x = cs.new_tensor(pkg.GGML_TYPE_F32, 4096, 26); h = cs.scale(x, 2.0); cs.alloc()
+    e = cd.new_tensor(pkg.GGML_TYPE_F32, 4096, 26); y = cd.scale(e, 1.0, 1.0); cd.alloc()
+    bs.tensor_set(x, hv)
+    bs.graph_compute(cs.graph())
+    assert bs.handoff_tensor(h, bd, e) == 1
+    bd.graph_compute(cd.graph())
+    assert np.array_equal(bd.tensor_get(y).reshape(26, 4096), hv * 2.0 + 1.0)
+    # ggml_backend_tensor_copy_async's hook of the ABI (ggml-backend-impl.h:101): src on device a -> dst on device b
+    ok = bs.be_s.iface.cpy_tensor_async(bs.be, bd.be, h.ptr, e.ptr)
+    assert ok
+    bd.graph_compute(cd.graph())
+    assert np.array_equal(bd.tensor_get(y).reshape(26, 4096), hv * 2.0 + 1.0)
+    cs.free(); cd.free(); bs.close(); bd.close()
+
+
+def test_module_pinning_map(pkg, be):
+    n = _n_devices(pkg, be)
+    names = [b"vpm", b"apm", b"llm", b"tts", b"t2w", b"vocoder"]
+    got = [be.lib.mi355x_module_device(m) for m in names]
+    assert got == [i % n for i in range(6)]
+    assert be.lib.mi355x_module_device(b"nonsense") == -1
+
+
+def test_bench_runs_as_two_ranks_through_its_gloo_hooks(tmp_path):
+    """The N > 1 path of bench.py itself (one process per rank, barrier + max-over-ranks timing, aggregate tok/s), launched exactly as the driver
+    does (python -m torch.distributed.run --nproc-per-node 2 bench.py --gpus 2 ...), with its test hooks so that it runs on a 1-GPU box:
+    CPU rendezvous (gloo) and both ranks on device 0."""
+    env = dict(os.environ, MI355X_BENCH_DIST_BACKEND="gloo", MI355X_BENCH_SHARE_GPU="1", MI355X_BENCH_NO_PP="1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29571",
+                          os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "8", "--warmup", "2", "--tiny", "--no-cpu-baseline"],
+                         env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout                                 # rank 0 prints the ONE line
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["steps"] == 8 and j["scaling"] == "weak" and j["value"] > 0
+    assert abs(j["value"] - 2 * 8 / (j["ms_per_step"] * 8 / 1e3)) / j["value"] < 1e-3       # aggregate = ranks x steps / max-over-ranks time
