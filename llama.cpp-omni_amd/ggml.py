@@ -476,6 +476,8 @@ class Context:
 
     def transpose(self, a):
         T = self._new(a.type, a.ne, view_src=a)
+        for i in range(4):                                            # (ggml_transpose: every stride is the source's, dims 0 / 1 swapped)
+            T.t.nb[i] = a.t.nb[i]
         T.t.ne[0], T.t.ne[1] = a.t.ne[1], a.t.ne[0]
         T.t.nb[0], T.t.nb[1] = a.t.nb[1], a.t.nb[0]
         return self._op(T, OP.TRANSPOSE, [a])

@@ -41,7 +41,7 @@ def _decode_run(pkg, backend, cfg, types, embd, steps, n_kv, fa, opts=None):
     return np.stack(outs), kern
 
 
-@pytest.mark.parametrize("fa", [True])      # (llama-bench's default, flash-attention off, is covered at 8B shape through the reference libllama below)
+@pytest.mark.parametrize("fa", [True, False])
 def test_decode_steps_at_8b_width_vs_reference_backend(pkg, be, ref_be, fa):
     """12 decode steps from an empty cache: RMS norm + Q8_K image inside the mat-vec launches (mmv1.hip), the one-token attention kernel with
     its q / k / v pre-stage (fattn_one.hip; fa=False: the soft-max path), residual and SwiGLU epilogues -- logits and arg-max against the
@@ -60,18 +60,17 @@ def test_decode_steps_at_8b_width_vs_reference_backend(pkg, be, ref_be, fa):
         assert kern <= 5 * W8["n_layer"] + 3, kern             # 5 launches per layer + rope table + output norm/lm-head launch
     assert kern < kern_old
     for t in range(steps):
-        # Without flash-attention both sides do the same arithmetic up to f32 summation order.  With it the CPU accumulates V in f16
-        # (ops.cpp:8069-8083; op-level NMSE 5e-8 .. 2e-6 against float64 where this backend is at 1e-14, tools/dbg_fa2.py) and that
+        # With flash-attention the CPU accumulates V in f16 (ops.cpp:8069-8083; op-level NMSE 5e-8 .. 2e-6 against float64 where this
+        # backend is at 1e-14, tools/dbg_fa2.py); without it both sides do the same arithmetic up to f32 summation order (1e-7).  Either
         # perturbation is re-quantised to Q8_K in front of every following mat-vec: roundings flip, and two layers + lm head later the
-        # logits differ by ~5e-4 .. 8e-4 NMSE on these random weights -- the round-1 and round-2 kernels agree with each other to 1e-14
-        # on the first steps (tools/dbg_fa.py), so the bar below measures the reference's own f16 accumulation, not this backend
-        assert nmse(got[t], ref[t]) < (2e-3 if fa else 1e-6), (t, nmse(got[t], ref[t]))
-        assert nmse(old[t], ref[t]) < (2e-3 if fa else 1e-6), t
-        if not fa:
-            assert int(np.argmax(got[t])) == int(np.argmax(ref[t])), t
-        else:   # the winning id may only change between near-ties of the reference itself (random weights: logits are not well separated)
-            err = float(np.sqrt(np.mean((got[t] - ref[t]) ** 2)))
-            assert ref[t][int(np.argmax(got[t]))] >= ref[t].max() - 4.0 * err, t
+        # logits differ by 1e-4 .. 8e-4 NMSE on these random weights (the reference decorrelates from ITSELF the same way under a 1e-6
+        # input perturbation, tests/test_oracle.py::test_reference_decorrelates_under_a_1e6_perturbation) -- the round-1 and round-2
+        # kernels agree with each other to 1e-14 on the first steps (tools/dbg_fa.py).  Per-op parity is pinned at 1e-9 elsewhere; the
+        # bar here is the end-to-end noise floor plus the near-tie rule for the winning id.
+        assert nmse(got[t], ref[t]) < 2e-3, (t, nmse(got[t], ref[t]))
+        assert nmse(old[t], ref[t]) < 2e-3, t
+        err = float(np.sqrt(np.mean((got[t] - ref[t]) ** 2)))
+        assert ref[t][int(np.argmax(got[t]))] >= ref[t].max() - 4.0 * err, t
 
 
 def test_mmv1_activation_sources_vs_oracle(pkg, be):

@@ -100,7 +100,8 @@ int main(int argc, char ** argv) {
         if (S.pair) total *= 2;
         // rotation: slices of the arenas, stride = the launch's bytes rounded up to 1 MB; at least 600 MB before anything repeats
         const size_t stride = ((total + (1 << 20) - 1) >> 20) << 20;
-        const int nrot = (int) std::max<size_t>(1, std::min<size_t>(ARENA / stride, 64));
+        int nrot = (int) std::max<size_t>(1, std::min<size_t>(ARENA / stride, 64));
+        if (getenv("LAB_NROT")) nrot = std::min(nrot, atoi(getenv("LAB_NROT")));     // few sets: the weights stay in the 256 MB Infinity Cache
         const int N = total > (100u << 20) ? 8 : 48;
         printf("\n== %s : %.1f MB per launch, %d rotating weight sets\n", S.name, total / 1e6, nrot);
         auto wptr = [&](int s, int i, bool second) -> const char * {
