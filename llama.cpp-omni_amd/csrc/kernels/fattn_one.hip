@@ -73,7 +73,10 @@ __global__ void __launch_bounds__(256) k_fattn_one(const fa1_dev a) {
     __shared__ __attribute__((aligned(16))) float qf[D], kc[D], vc[D], sc[FA1_NKV], pl[4][FA1_NKV];
 
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int h = blockIdx.x, ikv = h / a.gq;
+    // XCD-aware head order: workgroups go round-robin over the 8 XCDs (each with its own L2), so the gq heads that share one K / V head are
+    // given workgroup ids that are congruent modulo the number of KV heads -- with 8 KV heads one XCD fetches each K / V head once
+    // (rocprofv3 FETCH_SIZE: 4.4 MB -> ~1.1 MB per launch at n_kv 256)
+    const int nkvh = (int) gridDim.x / a.gq, ikv = (int) blockIdx.x % nkvh, h = ikv * a.gq + (int) blockIdx.x / nkvh;
     const int nkv = a.nkv < FA1_NKV ? a.nkv : FA1_NKV;
 
     // ---------------------------------------------------------------- 1. request everything: one burst of vector loads, no wait in between
