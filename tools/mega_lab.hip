@@ -1,0 +1,308 @@
+// tools/mega_lab.hip -- measurement (not part of the product): the FFN half of a decode step, [ffn_norm -> gate/up + SwiGLU -> down + residual]
+// x n_layer, as (a) the hipGraph of k_mv1 launches the backend runs today (2 dependent launches per layer) and (b) ONE persistent launch in
+// which the same workgroups walk the phases and hand the activation row over through memory with a flag array (tools/sync_bench.hip,
+// variant c), the NEXT phase's weights already sitting in their registers while they wait.  Same arithmetic in the same order: the final
+// rows must be bit-identical.
+//   build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off tools/mega_lab.hip -o build/mega_lab      run: build/mega_lab [n_layer]
+#include "../llama.cpp-omni_amd/csrc/kernels/mmv1.hip"
+#include <vector>
+#include <cmath>
+#include <cstring>
+
+using namespace mi;
+
+__global__ void k_fill(uint32_t * p, size_t n32, uint32_t seed) {
+    for (size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x; i < n32; i += (size_t) gridDim.x * blockDim.x) {
+        uint32_t h = (uint32_t) i * 2654435761u ^ seed; h ^= h >> 15; h *= 2246822519u; h ^= h >> 13; h *= 3266489917u; h ^= h >> 16;
+        p[i] = h;
+    }
+}
+__global__ void k_fix_scales(char * p, size_t nblk, int bs, int off, int nf16) {
+    for (size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x; i < nblk; i += (size_t) gridDim.x * blockDim.x) {
+        uint16_t * d = (uint16_t *) (p + i * bs + off);
+        for (int k = 0; k < nf16; ++k) d[k] = (uint16_t) (0x1c00 + ((i * 7 + k * 13) & 0x3ff));     // ~ 2^-8 .. 2^-7
+    }
+}
+__global__ void k_fill_f32(float * p, size_t n, uint32_t seed, float amp) {
+    for (size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t) gridDim.x * blockDim.x) {
+        uint32_t h = (uint32_t) i * 2654435761u ^ seed; h ^= h >> 15; h *= 2246822519u; h ^= h >> 13; h *= 3266489917u; h ^= h >> 16;
+        p[i] = amp * ((float) (h & 0xffffff) / 8388608.0f - 1.0f);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ the persistent kernel
+#define AUX_AGENT 16                                    // buffer aux bit 4 = sc1: agent scope (write-through store / L2-bypassing load)
+struct mega_args {
+    const char * Wg, * Wu, * Wd; size_t sg, sd;         // gate / up / down of layer 0 and the byte strides to the next layer
+    const float * nw;                                   // [L][E] ffn_norm weights
+    float * x;                                          // [L + 1][E]: x[0] = input row, x[l + 1] = x[l] + down(silu(gate) * up)
+    float * h;                                          // [L][F]
+    unsigned * flags; unsigned epoch0; unsigned * err;
+    int L; float eps;
+    unsigned long long * ts;                            // optional [L][2][5] wall-clock stamps of workgroup `ts_wg` (100 MHz)
+    int ts_wg;
+};
+constexpr int ME = 4096, MF = 12288, MNW = 16, MWG = 256;       // Qwen3-8B FFN; 256 workgroups x 16 waves = 4096 waves, one per CU
+
+static __device__ __forceinline__ void mega_wait(const __amdgpu_buffer_rsrc_t rf, unsigned want, unsigned * err) {
+    if (threadIdx.x < 64) {
+        long spins = 0; bool ok;
+        do {
+            asm volatile("" ::: "memory");                            // (the poll must be re-issued: without this LICM hoists the load)
+            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rf, threadIdx.x * 16, 0, AUX_AGENT);
+            ok = (int) (v[0] - want) >= 0 && (int) (v[1] - want) >= 0 && (int) (v[2] - want) >= 0 && (int) (v[3] - want) >= 0;
+            ok = __builtin_amdgcn_ballot_w64(!ok) == 0;
+        } while (!ok && ++spins < 300000L);
+        if (!ok && threadIdx.x == 0) *err = want;
+    }
+    __syncthreads();
+}
+static __device__ __forceinline__ void mega_signal(const __amdgpu_buffer_rsrc_t rf, unsigned val) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's write-through stores have reached the coherence point
+    __syncthreads();
+    if (threadIdx.x == 0) __builtin_amdgcn_raw_buffer_store_b32(val, rf, blockIdx.x * 4, 0, AUX_AGENT);
+}
+
+struct q4k_act { u32x4 a0, a1, a2, a3; int bs0, bs1; float yd; };
+static __device__ __forceinline__ q4k_act q4k_act_load(const char * la, const char * lb, const char * ld, int so) {
+    q4k_act A;
+    A.a0 = *(const u32x4 *) (la + so * 272); A.a1 = *(const u32x4 *) (la + so * 272 + 16);
+    A.a2 = *(const u32x4 *) (la + so * 272 + 32); A.a3 = *(const u32x4 *) (la + so * 272 + 48);
+    const uint32_t bsw = *(const uint32_t *) (lb + so * 16);
+    A.bs0 = (int) (int16_t) (bsw & 0xffff); A.bs1 = (int) (int16_t) (bsw >> 16);
+    A.yd = *(const float *) (ld + so * 4);
+    return A;
+}
+// one step (16 super-blocks of one row) of mv1_q4k's arithmetic
+static __device__ __forceinline__ void q4k_step(const uint32_t hw, const u32x4 Q, const u32x4 P, const q4k_act & A, const uint32_t sel, float & acc, float & accm) {
+    const uint32_t H[4] = { dpp_u32q<0x00>(hw), dpp_u32q<0x55>(hw), dpp_u32q<0xAA>(hw), dpp_u32q<0xFF>(hw) };
+    const uint32_t s_lo = H[1] & 0x3f3f3f3fu, s_hi = (H[3] & 0x0f0f0f0fu) | ((H[1] >> 2) & 0x30303030u);
+    const uint32_t m_lo = H[2] & 0x3f3f3f3fu, m_hi = ((H[3] >> 4) & 0x0f0f0f0fu) | ((H[2] >> 2) & 0x30303030u);
+    const uint32_t sw = __builtin_amdgcn_perm(s_hi, s_lo, sel), mw = __builtin_amdgcn_perm(m_hi, m_lo, sel);
+    const int sc0 = sw & 0xff, sc1 = sw >> 8, mn0 = mw & 0xff, mn1 = mw >> 8;
+    const float dx = h2f((uint16_t) (H[0] & 0xffff)), dmin = h2f((uint16_t) (H[0] >> 16));
+    int dl = 0, dh = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        dl = dot4(Q[k] & 0x0f0f0f0fu, A.a0[k], dl); dh = dot4((Q[k] >> 4) & 0x0f0f0f0fu, A.a2[k], dh);
+        dl = dot4(P[k] & 0x0f0f0f0fu, A.a1[k], dl); dh = dot4((P[k] >> 4) & 0x0f0f0f0fu, A.a3[k], dh);
+    }
+    const int isum = mad24(sc0, dl, mul24(sc1, dh));
+    const int msum = mad24(mn0, A.bs0, mul24(mn1, A.bs1));
+    acc  = fmaf(dx * A.yd, (float) isum, acc);
+    accm = fmaf(dmin * A.yd, (float) msum, accm);
+}
+
+// image of a row handed over by other workgroups (sc1 loads), built like mv1_act_issue / mv1_act_finish
+template <int XB>
+static __device__ __forceinline__ void mega_image(const float * x, const float * nw, float eps, int K, char * im, double * red) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nb = K >> 8;
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void *) x, (short) 0, K * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void *) nw, (short) 0, nw ? K * 4 : 0, 0x00020000);
+    f32x4 xv[XB], wv[XB];
+#pragma unroll
+    for (int c = 0; c < XB; ++c) {
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(xr, (uint32_t) ((wave + c * MNW) * 1024 + 16 * lane), 0, AUX_AGENT);
+        xv[c] = f32x4{ __uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]) };
+    }
+#pragma unroll
+    for (int c = 0; c < XB; ++c) {
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(wr, (uint32_t) ((wave + c * MNW) * 1024 + 16 * lane), 0, 0);
+        wv[c] = f32x4{ __uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]) };
+    }
+    float scale = 1.0f;
+    if (nw) {
+        double ss = 0.0;
+#pragma unroll
+        for (int c = 0; c < XB; ++c)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) ss += (double) (xv[c][i] * xv[c][i]);
+        ss = wave_sum_f64(ss);
+        if (lane == 0) red[wave] = ss;
+        __syncthreads();
+        double tot = 0.0;
+#pragma unroll
+        for (int w = 0; w < MNW; ++w) tot += red[w];
+        scale = 1.0f / sqrtf((float) (tot / (double) K) + eps);
+    }
+#pragma unroll
+    for (int c = 0; c < XB; ++c) {
+        const int ib = wave + c * MNW;
+        if (ib < nb) {
+            f32x4 y = xv[c];
+            if (nw) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) y[i] = (xv[c][i] * scale) * wv[c][i];
+            }
+            q8k_block_fast(y, lane, (int8_t *) im + ib * 272, (int16_t *) (im + mv1_img_bs(nb)) + ib * 8, (int16_t *) (im + mv1_img_b16(nb)) + ib * 16, (float *) (im + mv1_img_d(nb)) + ib);
+        }
+    }
+    __syncthreads();
+}
+
+__global__ void __launch_bounds__(64 * MNW) k_mega_ffn(const mega_args a) {
+    __shared__ double red[MNW];
+    const int lane = threadIdx.x & 63;
+    const int gw = __builtin_amdgcn_readfirstlane((int) (blockIdx.x * MNW + (threadIdx.x >> 6)));     // 0 .. 4095
+    const int blk = lane >> 2, q = lane & 3;
+    const uint32_t voff_h = (uint32_t) blk * 144u + 4u * (uint32_t) q, voff_q = (uint32_t) blk * 144u + 16u + 32u * (uint32_t) q;
+    const uint32_t sel = 0x0c0c0000u | (uint32_t) ((q < 2 ? 0 : 4) + 2 * (q & 1)) | ((uint32_t) ((q < 2 ? 0 : 4) + 2 * (q & 1) + 1) << 8);
+    const __amdgpu_buffer_rsrc_t rf = __builtin_amdgcn_make_buffer_rsrc((void *) a.flags, (short) 0, MWG * 4, 0x00020000);
+    char * im = mv1_lds;
+
+    // pair phase registers: 3 tasks x {gate, up} x (header dword + 2 x 16 B) = 54 VGPRs; down phase: 3 steps x 9 = 27
+    uint32_t ph[3][2]; u32x4 pa[3][2], pb[3][2];
+    uint32_t dh_[3]; u32x4 da[3], db[3];
+    auto issue_pair = [&](int l) {
+        const mv1_rsrc rg = mv1_make_rsrc(a.Wg + (size_t) l * a.sg, (size_t) MF * 2304), ru = mv1_make_rsrc(a.Wu + (size_t) l * a.sg, (size_t) MF * 2304);
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            const uint32_t so = (uint32_t) (gw * 3 + t) * 2304u;
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const mv1_rsrc rs = r ? ru : rg;
+                ph[t][r] = __builtin_amdgcn_raw_buffer_load_b32(rs, voff_h, so, 0);
+                pa[t][r] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff_q, so, 0);
+                pb[t][r] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff_q + 16u, so, 0);
+            }
+        }
+    };
+    auto issue_down = [&](int l) {
+        const mv1_rsrc rd = mv1_make_rsrc(a.Wd + (size_t) l * a.sd, (size_t) ME * 6912);
+#pragma unroll
+        for (int it = 0; it < 3; ++it) {
+            const uint32_t so = (uint32_t) gw * 6912u + (uint32_t) it * 2304u;
+            dh_[it] = __builtin_amdgcn_raw_buffer_load_b32(rd, voff_h, so, 0);
+            da[it]  = __builtin_amdgcn_raw_buffer_load_b128(rd, voff_q, so, 0);
+            db[it]  = __builtin_amdgcn_raw_buffer_load_b128(rd, voff_q + 16u, so, 0);
+        }
+    };
+
+    issue_pair(0);
+    unsigned phase = 0;
+    const bool stamp = a.ts && (int) blockIdx.x == a.ts_wg && threadIdx.x == 0;
+#define STAMP(l, p, i) do { if (stamp) a.ts[((l) * 2 + (p)) * 5 + (i)] = wall_clock64(); } while (0)
+    for (int l = 0; l < a.L; ++l) {
+        // ---------------- gate / up + SwiGLU on x[l] (with ffn_norm)
+        STAMP(l, 0, 0);
+        if (l > 0) mega_wait(rf, a.epoch0 + phase, a.err);
+        STAMP(l, 0, 1);
+        {
+            const int nb = ME >> 8;
+            mega_image<1>(a.x + (size_t) l * ME, a.nw + (size_t) l * ME, a.eps, ME, im, red);
+            STAMP(l, 0, 2);
+            const char * la = im + blk * 272 + 64 * q, * lb = im + mv1_img_bs(nb) + blk * 16 + 4 * q, * ld = im + mv1_img_d(nb) + blk * 4;
+            const q4k_act A = q4k_act_load(la, lb, ld, 0);
+            const __amdgpu_buffer_rsrc_t rh = __builtin_amdgcn_make_buffer_rsrc((void *) (a.h + (size_t) l * MF), (short) 0, MF * 4, 0x00020000);
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                float ag = 0.0f, agm = 0.0f, au = 0.0f, aum = 0.0f;
+                q4k_step(ph[t][0], pa[t][0], pb[t][0], A, sel, ag, agm);
+                q4k_step(ph[t][1], pa[t][1], pb[t][1], A, sel, au, aum);
+                const float gsum = wave_sum_f32(ag - agm), usum = wave_sum_f32(au - aum);
+                if (lane == 0) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(mv1_silu(gsum) * usum), rh, (uint32_t) (gw * 3 + t) * 4u, 0, AUX_AGENT);
+            }
+        }
+        STAMP(l, 0, 3);
+        mega_signal(rf, a.epoch0 + ++phase);
+        STAMP(l, 0, 4);
+        issue_down(l);                                                  // streams while the other workgroups finish and the flags travel
+        // ---------------- down + residual on h[l]
+        STAMP(l, 1, 0);
+        mega_wait(rf, a.epoch0 + phase, a.err);
+        STAMP(l, 1, 1);
+        {
+            const int nb = MF >> 8;
+            mega_image<3>(a.h + (size_t) l * MF, nullptr, a.eps, MF, im, red);
+            STAMP(l, 1, 2);
+            const char * la = im + blk * 272 + 64 * q, * lb = im + mv1_img_bs(nb) + blk * 16 + 4 * q, * ld = im + mv1_img_d(nb) + blk * 4;
+            float acc = 0.0f, accm = 0.0f;
+#pragma unroll
+            for (int it = 0; it < 3; ++it) {
+                const q4k_act A = q4k_act_load(la, lb, ld, it * 16);
+                q4k_step(dh_[it], da[it], db[it], A, sel, acc, accm);
+            }
+            float s = wave_sum_f32(acc - accm);
+            if (lane == 0) {
+                const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void *) (a.x + (size_t) l * ME), (short) 0, 2 * ME * 4, 0x00020000);
+                s += __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rx, (uint32_t) gw * 4u, 0, AUX_AGENT));
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(s), rx, (uint32_t) (ME + gw) * 4u, 0, AUX_AGENT);
+            }
+        }
+        STAMP(l, 1, 3);
+        mega_signal(rf, a.epoch0 + ++phase);
+        STAMP(l, 1, 4);
+        if (l + 1 < a.L) issue_pair(l + 1);
+    }
+}
+
+int main(int argc, char ** argv) {
+    setvbuf(stdout, nullptr, _IONBF, 0);
+    const int L = argc > 1 ? atoi(argv[1]) : 36;
+    hipStream_t st; HIP_CHECK(hipStreamCreate(&st));
+    hipEvent_t e0, e1; HIP_CHECK(hipEventCreate(&e0)); HIP_CHECK(hipEventCreate(&e1));
+    const size_t sg = (size_t) MF * 2304, sd = (size_t) ME * 6912;
+    char * Wg, * Wu, * Wd; float * nw, * xa, * xb, * ha, * hb; unsigned * flags, * err;
+    HIP_CHECK(hipMalloc(&Wg, sg * L)); HIP_CHECK(hipMalloc(&Wu, sg * L)); HIP_CHECK(hipMalloc(&Wd, sd * L));
+    HIP_CHECK(hipMalloc(&nw, (size_t) L * ME * 4)); HIP_CHECK(hipMalloc(&xa, (size_t) (L + 1) * ME * 4)); HIP_CHECK(hipMalloc(&xb, (size_t) (L + 1) * ME * 4));
+    HIP_CHECK(hipMalloc(&ha, (size_t) L * MF * 4)); HIP_CHECK(hipMalloc(&hb, (size_t) L * MF * 4)); HIP_CHECK(hipMalloc(&flags, MWG * 4)); HIP_CHECK(hipMalloc(&err, 4));
+    k_fill<<<4096, 256, 0, st>>>((uint32_t *) Wg, sg * L / 4, 1u); k_fill<<<4096, 256, 0, st>>>((uint32_t *) Wu, sg * L / 4, 2u); k_fill<<<4096, 256, 0, st>>>((uint32_t *) Wd, sd * L / 4, 3u);
+    k_fix_scales<<<4096, 256, 0, st>>>(Wg, sg * L / 144, 144, 0, 2); k_fix_scales<<<4096, 256, 0, st>>>(Wu, sg * L / 144, 144, 0, 2); k_fix_scales<<<4096, 256, 0, st>>>(Wd, sd * L / 144, 144, 0, 2);
+    k_fill_f32<<<64, 256, 0, st>>>(nw, (size_t) L * ME, 12u, 1.0f);
+    HIP_CHECK(hipMemsetAsync(xa, 0, (size_t) (L + 1) * ME * 4, st)); HIP_CHECK(hipMemsetAsync(xb, 0, (size_t) (L + 1) * ME * 4, st));
+    k_fill_f32<<<64, 256, 0, st>>>(xa, ME, 11u, 1.0f); k_fill_f32<<<64, 256, 0, st>>>(xb, ME, 11u, 1.0f);
+    HIP_CHECK(hipMemsetAsync(flags, 0, MWG * 4, st)); HIP_CHECK(hipMemsetAsync(err, 0, 4, st));
+    HIP_CHECK(hipStreamSynchronize(st));
+
+    // (a) today's launches: 2 per layer
+    auto chain = [&]() {
+        for (int l = 0; l < L; ++l) {
+            mv1_dev p; p.nmat = 1; p.K = ME; p.W1 = Wu + l * sg; p.src = { xa + (size_t) l * ME, nw + (size_t) l * ME, 1e-6f, nullptr };
+            p.m[0] = { Wg + l * sg, 2304, (char *) (ha + (size_t) l * MF), nullptr, MF, GGML_TYPE_Q4_K, 4096 }; p.m[1] = p.m[0]; p.m[2] = p.m[0];
+            k_mv1<8, 2, 2, 1, 1, true, false><<<dim3(512), dim3(512), mv1_image_bytes(ME), st>>>(p);
+            mv1_dev d; d.nmat = 1; d.K = MF; d.W1 = nullptr; d.src = { ha + (size_t) l * MF, nullptr, 1e-6f, nullptr };
+            d.m[0] = { Wd + l * sd, 6912, (char *) (xa + (size_t) (l + 1) * ME), (const char *) (xa + (size_t) l * ME), ME, GGML_TYPE_Q4_K, 4096 }; d.m[1] = d.m[0]; d.m[2] = d.m[0];
+            k_mv1<16, 3, 1, 1, 1, false, false><<<dim3(256), dim3(1024), mv1_image_bytes(MF), st>>>(d);
+        }
+        HIP_CHECK(hipGetLastError());
+    };
+    chain(); HIP_CHECK(hipStreamSynchronize(st));
+    hipGraph_t graph; hipGraphExec_t exec;
+    HIP_CHECK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal)); chain(); HIP_CHECK(hipStreamEndCapture(st, &graph));
+    HIP_CHECK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+    float best_a = 1e30f, best_b = 1e30f;
+    for (int r = 0; r < 5; ++r) {
+        HIP_CHECK(hipEventRecord(e0, st)); HIP_CHECK(hipGraphLaunch(exec, st)); HIP_CHECK(hipEventRecord(e1, st)); HIP_CHECK(hipEventSynchronize(e1));
+        float ms; HIP_CHECK(hipEventElapsedTime(&ms, e0, e1)); if (ms < best_a) best_a = ms;
+    }
+    // (b) one persistent launch
+    unsigned long long * ts; HIP_CHECK(hipMalloc(&ts, (size_t) L * 10 * 8)); HIP_CHECK(hipMemset(ts, 0, (size_t) L * 10 * 8));
+    mega_args m = { Wg, Wu, Wd, sg, sd, nw, xb, hb, flags, 0u, err, L, 1e-6f, nullptr, 0 };
+    unsigned epoch = 0;
+    for (int r = 0; r < 6; ++r) {
+        m.epoch0 = epoch; epoch += 2 * L + 1;
+        HIP_CHECK(hipEventRecord(e0, st));
+        k_mega_ffn<<<dim3(MWG), dim3(64 * MNW), mv1_image_bytes(MF), st>>>(m);
+        HIP_CHECK(hipGetLastError());
+        HIP_CHECK(hipEventRecord(e1, st)); HIP_CHECK(hipEventSynchronize(e1));
+        float ms; HIP_CHECK(hipEventElapsedTime(&ms, e0, e1)); if (r > 0 && ms < best_b) best_b = ms;
+    }
+    std::vector<float> va(ME), vb(ME); unsigned herr = 0;
+    HIP_CHECK(hipMemcpy(va.data(), xa + (size_t) L * ME, ME * 4, hipMemcpyDeviceToHost)); HIP_CHECK(hipMemcpy(vb.data(), xb + (size_t) L * ME, ME * 4, hipMemcpyDeviceToHost));
+    HIP_CHECK(hipMemcpy(&herr, err, 4, hipMemcpyDeviceToHost));
+    int bad = 0, nonfinite = 0; for (int i = 0; i < ME; ++i) { if (memcmp(&va[i], &vb[i], 4)) ++bad; if (!std::isfinite(va[i])) ++nonfinite; }
+    const double mb = (2.0 * sg + sd) / 1e6;
+    printf("FFN chain, %d layers (%.1f MB per layer): hipGraph of k_mv1 launches %.2f us per layer (%.2f TB/s) | one persistent launch %.2f us per layer (%.2f TB/s) | rows differing %d, non-finite %d, wait time-outs %u (x[L][0] = %g)\n",
+           L, mb, best_a * 1e3 / L, mb / (best_a * 1e3 / L) , best_b * 1e3 / L, mb / (best_b * 1e3 / L), bad, nonfinite, herr, va[0]);
+    for (int wg : { 0, 100, 255 }) {
+        m.ts = ts; m.ts_wg = wg; m.epoch0 = epoch; epoch += 2 * L + 1;
+        k_mega_ffn<<<dim3(MWG), dim3(64 * MNW), mv1_image_bytes(MF), st>>>(m);
+        HIP_CHECK(hipStreamSynchronize(st));
+        std::vector<unsigned long long> t((size_t) L * 10); HIP_CHECK(hipMemcpy(t.data(), ts, t.size() * 8, hipMemcpyDeviceToHost));
+        double d[2][4] = {};
+        for (int l = 1; l < L; ++l) for (int p = 0; p < 2; ++p) for (int i = 0; i < 4; ++i) d[p][i] += (double) (t[(l * 2 + p) * 5 + i + 1] - t[(l * 2 + p) * 5 + i]) * 0.01 / (L - 1);
+        printf("  workgroup %3d, us per phase [wait | image | dot + store | signal]: gate/up %.2f %.2f %.2f %.2f   down %.2f %.2f %.2f %.2f   (whole layer %.2f)\n", wg,
+               d[0][0], d[0][1], d[0][2], d[0][3], d[1][0], d[1][1], d[1][2], d[1][3], (double) (t[(size_t) (L - 1) * 10] - t[10]) * 0.01 / (L - 2));
+    }
+    return 0;
+}
