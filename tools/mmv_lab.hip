@@ -177,7 +177,14 @@ int main(int argc, char ** argv) {
         } while (0)
 
         const bool big = ntot > 20000;
-#if defined(LAB_ONE)
+#if defined(LAB_DEPTH)     // prefetch depth with the default cache policy
+        VAR(8, 2, 1, 0, 4096);
+        VAR(8, 2, 2, 0, 4096);
+        VAR(8, 2, 3, 0, 4096);
+        VAR(16, 1, 1, 0, 4096);
+        VAR(16, 1, 2, 0, 4096);
+        VAR(16, 1, 3, 0, 4096);
+#elif defined(LAB_ONE)
         VAR(8, 2, 1, 0, 4096);
         VAR(8, 2, 1, 1, 4096);
         VAR(8, 2, 2, 1, 4096);
