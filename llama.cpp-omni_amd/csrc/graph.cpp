@@ -162,6 +162,32 @@ bool supports_op(const ggml_tensor * op) {
                    (op_param_i32(op, 0) == GGML_OP_POOL_AVG || op_param_i32(op, 0) == GGML_OP_POOL_MAX);
         case GGML_OP_SCALE:
             return s0 && s0->type == GGML_TYPE_F32 && op->type == GGML_TYPE_F32 && is_contiguous(s0) && is_contiguous(op);
+        // ---- the Token2Wav graphs' extra ops (kernels/t2w_ops.hip)
+        case GGML_OP_SQR: case GGML_OP_SQRT: case GGML_OP_LOG: case GGML_OP_SIN: case GGML_OP_COS: case GGML_OP_CLAMP: case GGML_OP_LEAKY_RELU:
+            return s0 && s0->type == GGML_TYPE_F32 && op->type == GGML_TYPE_F32 && is_contiguous(s0) && is_contiguous(op);
+        case GGML_OP_CONCAT: {
+            if (!s0 || !s1 || s0->type != op->type || s1->type != op->type) return false;
+            const int t = op->type;
+            return t == GGML_TYPE_F32 || t == GGML_TYPE_I32 || t == GGML_TYPE_F16;
+        }
+        case GGML_OP_REPEAT: {
+            if (!s0 || s0->type != op->type || !can_repeat(s0, op)) return false;
+            const int t = op->type;
+            return t == GGML_TYPE_F32 || t == GGML_TYPE_I32 || t == GGML_TYPE_F16;
+        }
+        case GGML_OP_PAD:
+            return s0 && s0->type == GGML_TYPE_F32 && op->type == GGML_TYPE_F32 && s0->nb[0] == 4 && is_contiguous(op);
+        case GGML_OP_PAD_REFLECT_1D:
+            return s0 && s0->type == GGML_TYPE_F32 && op->type == GGML_TYPE_F32 && op_param_i32(op, 0) < s0->ne[0] && op_param_i32(op, 1) < s0->ne[0];
+        case GGML_OP_ARANGE:
+            return op->type == GGML_TYPE_F32 && is_contiguous(op);
+        case GGML_OP_TIMESTEP_EMBEDDING:
+            return s0 && s0->type == GGML_TYPE_F32 && op->type == GGML_TYPE_F32 && s0->nb[0] == 4 && op->nb[0] == 4;
+        case GGML_OP_SUM_ROWS:
+            return s0 && s0->type == GGML_TYPE_F32 && op->type == GGML_TYPE_F32 && s0->nb[0] == 4;
+        case GGML_OP_CONV_TRANSPOSE_1D:          // (ggml_conv_transpose_1d asserts p0 == 0, d0 == 1 and a 2-D src1)
+            return s0 && s1 && (s0->type == GGML_TYPE_F16 || s0->type == GGML_TYPE_F32) && s1->type == GGML_TYPE_F32 && op->type == GGML_TYPE_F32 &&
+                   s0->nb[0] == (s0->type == GGML_TYPE_F16 ? 2u : 4u) && s1->nb[0] == 4 && op->nb[0] == 4 && s1->ne[2] == 1 && s1->ne[3] == 1 && s0->ne[3] == 1;
         case GGML_OP_UNARY: {
             if (!s0 || s0->type != GGML_TYPE_F32 || op->type != GGML_TYPE_F32 || !is_contiguous(s0) || !is_contiguous(op)) return false;
             switch (op_param_i32(op, 0)) {
@@ -197,7 +223,8 @@ bool supports_op(const ggml_tensor * op) {
             if (!s0) return false;
             const int a = s0->type, b = op->type;
             const bool fl = (a == GGML_TYPE_F32 || a == GGML_TYPE_F16) && (b == GGML_TYPE_F32 || b == GGML_TYPE_F16);
-            return (fl || (a == GGML_TYPE_I32 && b == GGML_TYPE_I32)) && nelements(s0) == nelements(op);
+            const bool fi = (a == GGML_TYPE_F32 && b == GGML_TYPE_I32) || (a == GGML_TYPE_I32 && b == GGML_TYPE_F32);      // ggml_cast to / from i32 (Token2Wav masks)
+            return (fl || fi || (a == GGML_TYPE_I32 && b == GGML_TYPE_I32)) && nelements(s0) == nelements(op);
         }
         case GGML_OP_GET_ROWS: {
             if (!s0 || !s1 || s1->type != GGML_TYPE_I32 || op->type != GGML_TYPE_F32 || op->nb[0] != 4) return false;
@@ -1245,6 +1272,51 @@ static void compute_node(exec_state & s, int i) {
             scale_f32((const float *) n->src[0]->data, (float *) n->data, nelements(n), op_param_f32(n, 0), op_param_f32(n, 1), s.st); ++s.n_kernels;
             break;
         }
+        case GGML_OP_SQR: case GGML_OP_SQRT: case GGML_OP_LOG: case GGML_OP_SIN: case GGML_OP_COS: case GGML_OP_CLAMP: case GGML_OP_LEAKY_RELU: {
+            prof_scope ps(s, "math", 0);
+            math_f32(n->op, (const float *) n->src[0]->data, (float *) n->data, nelements(n), op_param_f32(n, 0), op_param_f32(n, 1), s.st); ++s.n_kernels;
+            break;
+        }
+        case GGML_OP_CONCAT: {
+            prof_scope ps(s, "concat", 0);
+            concat(td(n->src[0]), td(n->src[1]), td(n), op_param_i32(n, 0), n->type == GGML_TYPE_F16 ? 2 : 4, s.st); ++s.n_kernels;
+            break;
+        }
+        case GGML_OP_REPEAT: {
+            prof_scope ps(s, "repeat", 0);
+            repeat(td(n->src[0]), td(n), n->type == GGML_TYPE_F16 ? 2 : 4, s.st); ++s.n_kernels;
+            break;
+        }
+        case GGML_OP_PAD: {
+            prof_scope ps(s, "pad", 0);
+            pad_f32(td(n->src[0]), td(n), n->op_params, s.st); ++s.n_kernels;
+            break;
+        }
+        case GGML_OP_PAD_REFLECT_1D: {
+            prof_scope ps(s, "pad_reflect", 0);
+            pad_reflect_1d_f32(td(n->src[0]), td(n), op_param_i32(n, 0), op_param_i32(n, 1), s.st); ++s.n_kernels;
+            break;
+        }
+        case GGML_OP_ARANGE: {
+            prof_scope ps(s, "arange", 0);
+            arange_f32((float *) n->data, nelements(n), op_param_f32(n, 0), op_param_f32(n, 2), s.st); ++s.n_kernels;
+            break;
+        }
+        case GGML_OP_TIMESTEP_EMBEDDING: {
+            prof_scope ps(s, "timestep_embedding", 0);
+            timestep_embedding_f32((const float *) n->src[0]->data, td(n), n->src[0]->ne[0], op_param_i32(n, 0), op_param_i32(n, 1), s.st); ++s.n_kernels;
+            break;
+        }
+        case GGML_OP_SUM_ROWS: {
+            prof_scope ps(s, "sum_rows", 0);
+            sum_rows_f32(td(n->src[0]), td(n), s.st); ++s.n_kernels;
+            break;
+        }
+        case GGML_OP_CONV_TRANSPOSE_1D: {
+            prof_scope ps(s, "conv_transpose_1d", 0);
+            conv_transpose_1d_f32(td(n->src[0]), n->src[0]->type, td(n->src[1]), td(n), op_param_i32(n, 0), s.st); ++s.n_kernels;
+            break;
+        }
         case GGML_OP_UNARY: {
             prof_scope ps(s, "unary", 0);
             unary_f32(op_param_i32(n, 0), (const float *) n->src[0]->data, (float *) n->data, nelements(n), s.st); ++s.n_kernels;
@@ -1310,7 +1382,9 @@ static void compute_node(exec_state & s, int i) {
             prof_scope ps(s, "cpy", 0);
             const ggml_tensor * src = n->src[0];
             // CPY writes into src[1]'s storage, which `n` is a view of; n->data is the destination in all three ops
-            cpy_strided(td(src), src->type, td(n), n->type, s.st); ++s.n_kernels;
+            if ((src->type == GGML_TYPE_F32) != (n->type == GGML_TYPE_F32) && (src->type == GGML_TYPE_I32 || n->type == GGML_TYPE_I32)) cast_f32_i32(td(src), src->type == GGML_TYPE_F32, td(n), s.st);
+            else cpy_strided(td(src), src->type, td(n), n->type, s.st);
+            ++s.n_kernels;
             break;
         }
         case GGML_OP_GET_ROWS: {

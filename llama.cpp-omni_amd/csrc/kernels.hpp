@@ -125,6 +125,18 @@ void unary_f32(int uop, const float * x, float * y, int64_t n, hipStream_t st);
 // ADD / SUB / MUL / DIV with ggml broadcast semantics (src1 repeats over src0)
 void bin_bcast_f32(int op, const tdesc & a, const tdesc & b, const tdesc & y, hipStream_t st);
 void scale_f32(const float * x, float * y, int64_t n, float s, float b, hipStream_t st);
+// ---- ops of the Token2Wav graphs (kernels/t2w_ops.hip; reference tools/omni/token2wav/token2wav-impl.cpp)
+// SQR / SQRT / LOG / SIN / COS / CLAMP(p0 = min, p1 = max) / LEAKY_RELU(p0 = slope) on dense f32
+void math_f32(int op, const float * x, float * y, int64_t n, float p0, float p1, hipStream_t st);
+void concat(const tdesc & a, const tdesc & b, const tdesc & y, int dim, int elem_size, hipStream_t st);            // ops.cpp:1968-2009
+void repeat(const tdesc & x, const tdesc & y, int elem_size, hipStream_t st);                                      // ops.cpp:1637-1679
+void pad_f32(const tdesc & x, const tdesc & y, const int32_t * p, hipStream_t st);                                 // ops.cpp:7592-7638; p = {lp0, rp0, ..., lp3, rp3}
+void pad_reflect_1d_f32(const tdesc & x, const tdesc & y, int p0, int p1, hipStream_t st);                         // ops.cpp:7660-7691
+void arange_f32(float * y, int64_t n, float start, float step, hipStream_t st);                                    // ops.cpp:7762-7783
+void timestep_embedding_f32(const float * ts, const tdesc & y, int64_t n, int dim, int max_period, hipStream_t st);  // ops.cpp:7800-7831
+void sum_rows_f32(const tdesc & x, const tdesc & y, hipStream_t st);                                               // ops.cpp:1399-1430
+void conv_transpose_1d_f32(const tdesc & w, int w_type, const tdesc & x, const tdesc & y, int s0, hipStream_t st); // ops.cpp:5952-6122
+void cast_f32_i32(const tdesc & src, bool src_is_f32, const tdesc & dst, hipStream_t st);                          // ops.cpp:555, 558-561
 // CPY / CONT / DUP between f32 / f16 with arbitrary strides (same element count)
 void cpy_strided(const tdesc & src, int src_type, const tdesc & dst, int dst_type, hipStream_t st);
 // GET_ROWS (f32 / f16 / quantised tables -> f32), SET_ROWS (f32 -> f32 / f16, i64 or i32 indices)

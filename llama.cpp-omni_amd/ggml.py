@@ -26,6 +26,8 @@ GGML_BACKEND_BUFFER_USAGE_ANY, GGML_BACKEND_BUFFER_USAGE_WEIGHTS, GGML_BACKEND_B
 
 class OP:
     NONE, DUP, ADD, SUB, MUL, DIV = 0, 1, 2, 6, 7, 8
+    SQR, SQRT, LOG, SIN, COS, SUM_ROWS, REPEAT, CONCAT = 9, 10, 11, 12, 13, 15, 19, 21
+    CLAMP, CONV_TRANSPOSE_1D, PAD, PAD_REFLECT_1D, ARANGE, TIMESTEP_EMBEDDING, LEAKY_RELU = 49, 50, 62, 63, 65, 66, 68
     NORM, RMS_NORM, MUL_MAT, SCALE, CPY, CONT, RESHAPE, VIEW, PERMUTE, TRANSPOSE = 23, 24, 28, 31, 33, 34, 35, 36, 37, 38
     IM2COL = 51
     POOL_1D = 58
@@ -517,6 +519,75 @@ class Context:
     def scale(self, a, s, b=0.0):
         T = self._new(a.type, a.ne)
         return self._op(T, OP.SCALE, [a], (_f32_bits(s), _f32_bits(b)))
+
+    # ---- ops of the Token2Wav graphs (constructors as in ggml.c: result shapes and op_params)
+    def _math(self, op, a, params=()):
+        T = self._new(a.type, a.ne)
+        return self._op(T, op, [a], params)
+
+    def sqr(self, a):
+        return self._math(OP.SQR, a)
+
+    def sqrt(self, a):
+        return self._math(OP.SQRT, a)
+
+    def log(self, a):
+        return self._math(OP.LOG, a)
+
+    def sin(self, a):
+        return self._math(OP.SIN, a)
+
+    def cos(self, a):
+        return self._math(OP.COS, a)
+
+    def clamp(self, a, lo, hi):
+        """ggml_clamp is always in place: the result is a view of `a`"""
+        T = self._new(a.type, a.ne, view_src=a)
+        for i in range(4):
+            T.t.nb[i] = a.t.nb[i]
+        return self._op(T, OP.CLAMP, [a], (_f32_bits(lo), _f32_bits(hi)))
+
+    def leaky_relu(self, a, slope):
+        return self._math(OP.LEAKY_RELU, a, (_f32_bits(slope),))
+
+    def sum_rows(self, a):
+        T = self._new(a.type, (1, a.ne[1], a.ne[2], a.ne[3]))
+        return self._op(T, OP.SUM_ROWS, [a])
+
+    def repeat_4d(self, a, ne0, ne1, ne2, ne3):
+        T = self._new(a.type, (ne0, ne1, ne2, ne3))
+        return self._op(T, OP.REPEAT, [a])
+
+    def repeat(self, a, b):
+        return self.repeat_4d(a, *b.ne)
+
+    def concat(self, a, b, dim):
+        ne = list(a.ne)
+        ne[dim] += b.ne[dim]
+        T = self._new(a.type, ne)
+        return self._op(T, OP.CONCAT, [a, b], (dim,))
+
+    def pad_ext(self, a, lp0, rp0, lp1, rp1, lp2, rp2, lp3, rp3):
+        T = self._new(a.type, (a.ne[0] + lp0 + rp0, a.ne[1] + lp1 + rp1, a.ne[2] + lp2 + rp2, a.ne[3] + lp3 + rp3))
+        return self._op(T, OP.PAD, [a], (lp0, rp0, lp1, rp1, lp2, rp2, lp3, rp3))
+
+    def pad_reflect_1d(self, a, p0, p1):
+        T = self._new(a.type, (a.ne[0] + p0 + p1, a.ne[1], a.ne[2], a.ne[3]))
+        return self._op(T, OP.PAD_REFLECT_1D, [a], (p0, p1))
+
+    def arange(self, start, stop, step):
+        import math
+        T = self._new(GGML_TYPE_F32, (int(math.ceil((stop - start) / step)),))
+        return self._op(T, OP.ARANGE, [], (_f32_bits(start), _f32_bits(stop), _f32_bits(step)))
+
+    def timestep_embedding(self, ts, dim, max_period):
+        T = self._new(GGML_TYPE_F32, (dim + (dim & 1), ts.ne[0]))
+        return self._op(T, OP.TIMESTEP_EMBEDDING, [ts], (dim, max_period))
+
+    def conv_transpose_1d(self, kernel, x, s0):
+        """ggml_conv_transpose_1d(a, b, s0, p0 = 0, d0 = 1): kernel [K, Cout, Cin], x [L, Cin] -> [(L - 1) * s0 + K, Cout]"""
+        T = self._new(GGML_TYPE_F32, ((x.ne[0] - 1) * s0 + kernel.ne[0], kernel.ne[1], 1, 1))
+        return self._op(T, OP.CONV_TRANSPOSE_1D, [kernel, x], (s0, 0, 1))
 
     def unary(self, a, uop):
         T = self._new(a.type, a.ne)
