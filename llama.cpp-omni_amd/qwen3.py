@@ -242,6 +242,10 @@ class Model:
             cur = g.mul_mat(self._w(g, L["ffn_down"]), cur)
             inpL = g.add(cur, ffn_inp)
         cur = g.mul(g.rms_norm(inpL, c["rms_eps"]), self._w(g, self.output_norm))
+        self.hidden_out = None
+        if getattr(self, "tap_hidden", False):                         # result_norm as llama_get_embeddings exposes it to the TTS module (omni.cpp:256-270):
+            self.hidden_out = g.scale(cur, 1.0)                          # a second reader keeps the rows materialised next to the fused lm-head launch
+            roots.append(self.hidden_out)
         logits = g.mul_mat(self._w(g, self.output), cur)
         roots.append(logits)
         g.roots = roots

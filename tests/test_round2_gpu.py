@@ -417,6 +417,87 @@ def test_handoff_between_two_devices(pkg, be):
     cs.free(); cd.free(); bs.close(); bd.close()
 
 
+def test_omni_chunk_through_pinned_modules(pkg, be, ref_be):
+    """One chunk of the duplex pipeline (BASELINE configs[4], shapes of configs[3]) with every module on the backend mi355x_module_device
+    pins it to (all device 0 on this box, one stream each): APM (Whisper front end + layer, 500 mel frames -> 50 audio embeddings of 4096)
+    -> device hand-off -> LLM prefill of the 50 embedding rows (n_embd 4096, Q4_K_M: the 6..64-column integer path + MFMA attention)
+    -> result_norm rows handed off on the device -> TTS side (projector 4096 -> 768 in F16, then a 768-wide Q8_0 decoder over the rows).
+    No host copy or host synchronisation between the modules: ordering is by the hand-offs' stream events.  The same graphs, chained through
+    host arrays on the reference CPU backend, give the expected logits."""
+    from llama_cpp_omni_amd import encoders as E, qwen3
+    from test_round2_gpu import _flat_weights, _fill
+    F32, F16 = pkg.GGML_TYPE_F32, pkg.GGML_TYPE_F16
+    TTS = dict(n_embd=768, n_layer=2, n_head=12, n_head_kv=12, head_dim=64, n_ff=2048, n_vocab=1024, rms_eps=1e-6, rope_base=1e4, n_ctx_orig=4096)
+    n_frames, n_tok = 500, 50
+    mods = {m: be.lib.mi355x_module_device(m.encode()) for m in ("apm", "llm", "tts")}
+    assert all(v == 0 for v in mods.values()) or _n_devices(pkg, be) > 1
+
+    def run(backends, device_handoff):
+        b_apm, b_llm, b_tts = backends
+        # --- APM
+        ca = pkg.Context(b_apm)
+        Wa = E.whisper_weights(ca, E.WHISPER, 1)
+        mel, aud = E.whisper(ca, E.WHISPER, Wa, n_frames)               # [4096, 50]
+        aud_out = ca.scale(aud, 1.0)
+        ca.alloc()
+        rng = np.random.default_rng(41)
+        ws = _flat_weights(Wa)
+        _fill(b_apm, rng, ws, [1.0 / np.sqrt(t.ne[0] * (t.ne[1] if len([d for d in t.ne if d > 1]) > 2 else 1)) if (t.type == 1 or (t.ne[1] > 1 and t.ne[0] > 8)) else 0.1 for t in ws])
+        b_apm.tensor_set(Wa["ln_w"], np.ones(Wa["ln_w"].nelements(), np.float32))
+        b_apm.tensor_set(mel, rng.standard_normal(mel.nelements()).astype(np.float32))
+        # --- LLM
+        llm = qwen3.Model(b_llm, W8, qwen3.q4_k_m_types(W8), n_ctx=256, seed=5, flash_attn=True)
+        llm.tap_hidden = True
+        gl, Il, _ = llm.build(n_tok, 256)
+        hid_out = llm.hidden_out                                        # [4096, 50] result_norm rows
+        llm.set_inputs(Il, np.zeros((n_tok, W8["n_embd"]), np.float32), 0, 256)
+        # --- TTS
+        tts = qwen3.Model(b_tts, TTS, qwen3.uniform_types(TTS, pkg.GGML_TYPE_Q8_0), n_ctx=256, seed=9, flash_attn=True)
+        cp = pkg.Context(b_tts)
+        hin = cp.new_tensor(F32, W8["n_embd"], n_tok)
+        pw = cp.new_tensor(F16, W8["n_embd"], TTS["n_embd"])
+        proj = cp.mul_mat(pw, hin)                                      # [768, 50]
+        cp.alloc()
+        b_tts.tensor_set(pw, (np.random.default_rng(3).standard_normal(pw.nelements()) / 64.0).astype(np.float16))
+        gt, It, logits = tts.build(n_tok, 256)
+        tts.set_inputs(It, np.zeros((n_tok, TTS["n_embd"]), np.float32), 0, 256)
+        # --- the chunk
+        b_apm.graph_compute(ca.graph())
+        if device_handoff:
+            assert b_apm.handoff_tensor(aud_out, b_llm, Il["inp_embd"]) in (1, 2)
+        else:
+            b_llm.tensor_set(Il["inp_embd"], b_apm.tensor_get(aud_out))
+        b_llm.graph_compute(gl.graph())
+        if device_handoff:
+            assert b_llm.handoff_tensor(hid_out, b_tts, hin) in (1, 2)
+        else:
+            b_tts.tensor_set(hin, b_llm.tensor_get(hid_out))
+        b_tts.graph_compute(cp.graph())
+        if device_handoff:
+            assert b_tts.handoff_tensor(proj, b_tts, It["inp_embd"]) in (1, 2)
+        else:
+            b_tts.tensor_set(It["inp_embd"], b_tts.tensor_get(proj))
+        b_tts.graph_compute(gt.graph())
+        out = b_tts.tensor_get(logits).copy()
+        hid = b_llm.tensor_get(hid_out).copy()
+        for x in (ca, gl, cp, gt):
+            x.free()
+        llm.wctx.free(); tts.wctx.free()
+        return hid, out
+
+    trio = [pkg.Backend(mods[m]) for m in ("apm", "llm", "tts")]
+    try:
+        hid, got = run(trio, True)
+    finally:
+        for b in trio:
+            b.close()
+    hid_ref, want = run([ref_be, ref_be, ref_be], False)
+    assert np.isfinite(got).all() and np.isfinite(hid).all()
+    e_h, e_o = nmse(hid, hid_ref), nmse(got, want)
+    print("omni chunk: LLM result_norm NMSE", e_h, "TTS logits NMSE", e_o)
+    assert e_h < 2e-3 and e_o < 5e-3, (e_h, e_o)
+
+
 def test_module_pinning_map(pkg, be):
     n = _n_devices(pkg, be)
     names = [b"vpm", b"apm", b"llm", b"tts", b"t2w", b"vocoder"]
