@@ -51,6 +51,10 @@ class Decoder:
         self.h_embd = alloc(E * 4).view(np.float32)
         self.h_pos = alloc(4).view(np.int32)
         self.h_idx = alloc(8).view(np.int64)
+        self.nv = cfg["n_head_kv"] * cfg["head_dim"] if self.model.v_trans else 0       # flash-attention off: the v store scatters single elements
+        self.n_ctx = n_ctx
+        self.h_vidx = alloc(8 * max(self.nv, 1)).view(np.int64)
+        self.v_base = np.arange(max(self.nv, 1), dtype=np.int64) * n_ctx
         msz = 2 if flash_attn else 4
         self.h_mask = alloc(n_kv * msz).view(np.float16 if flash_attn else np.float32)   # row 0 of the padded mask
         self.h_logits = alloc(V * 4).view(np.float32)
@@ -71,7 +75,11 @@ class Decoder:
         be.tensor_set_async(I["inp_embd"], self.h_embd)
         be.tensor_set_async(I["inp_pos"], self.h_pos)
         be.tensor_set_async(I["k_idxs"], self.h_idx)
-        be.tensor_set_async(I["v_idxs"], self.h_idx)
+        if self.nv:
+            self.h_vidx[:] = self.v_base + pos
+            be.tensor_set_async(I["v_idxs"], self.h_vidx)
+        else:
+            be.tensor_set_async(I["v_idxs"], self.h_idx)
         be.tensor_set_async(I["kq_mask"], self.h_mask)
         be.graph_compute(self.graph)
         if fetch_logits:

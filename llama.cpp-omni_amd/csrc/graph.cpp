@@ -76,7 +76,8 @@ struct exec_state {
     // deferred RMS_NORM -> MUL(w): not computed yet; its K-quant mat-vec consumers build the Q8_K image in-kernel (mmvk.hip act_norm)
     struct { const ggml_tensor * m = nullptr; const ggml_tensor * x = nullptr; const ggml_tensor * wt = nullptr; float eps = 0; int left = 0; } pn;
     // deferred q chain + k chain/store + v store of a decode layer: executed by the FLASH_ATTN_EXT node `fa` itself (fattn_pre)
-    struct { int fa = -1; fattn_pre pre; int kst = -1, vst = -1; } pq;
+    struct { int fa = -1; fattn_pre pre; int kst = -1, vst = -1;
+             bool sm = false; int sm_soft = -1, sm_mm2 = -1, sm_cont = -1; attn_sm_args sma; } pq;   // sm: the flash-attention-off form, `fa` = its first MUL_MAT
     // deferred split-K reduction: `A` (the mat-mul + residual result) still lies as `nsplit` slabs in gemm_partial; the RMS_NORM that
     // reads it next folds the reduction in (gemm_reduce_rms_norm), anything else materialises it first
     struct { const ggml_tensor * A = nullptr; int nsplit = 0; const float * resid = nullptr; size_t resid_cs = 0; } pr;
@@ -1070,6 +1071,91 @@ static bool try_defer_qkv_to_attention(exec_state & s, const nr_chain & A, const
     return true;
 }
 
+// The same for the flash-attention-OFF graph (src/llama-graph.cpp:1362-1420): rope(q) feeds MUL_MAT(k, q) -> SOFT_MAX_EXT(mask f32, scale) ->
+// MUL_MAT(v^T, p) -> PERMUTE -> CONT, the k chain stores a cache row, the v store is the single-element scatter into the TRANSPOSED cache
+// (llama-kv-cache.cpp:1091-1109).  On success the first MUL_MAT node runs the whole step as one launch (attn_one_sm, fattn_one.hip).
+static bool try_defer_qkv_to_softmax_attention(exec_state & s, const nr_chain & A, const nr_chain * B, int vsj, const int * item, int ni) {
+    static const bool off = getenv("MI355X_NO_QKV_IN_ATTN") != nullptr || getenv("MI355X_NO_ATTN_SM") != nullptr;
+    ggml_cgraph * g = s.g;
+    if (off || A.T != 1 || !B || B->store < 0 || vsj < 0 || A.store >= 0 || (A.D != 64 && A.D != 128)) return false;
+    const ggml_tensor * rq = g->nodes[A.rope];
+    auto views_back_to = [](const ggml_tensor * w, const ggml_tensor * t) { while (w && w != t) w = w->view_src; return w != nullptr; };
+    // rope(q) -> [views] -> MUL_MAT(k, q)
+    const ggml_tensor * t = rq; int m1 = -1;
+    for (int hop = 0; hop < 4; ++hop) {
+        const int u = sole_user(s, t);
+        if (u < 0) return false;
+        const ggml_tensor * c = g->nodes[u];
+        if (c->op == GGML_OP_MUL_MAT) { if (!views_back_to(c->src[1], t)) return false; m1 = u; break; }
+        if (!is_noop(c)) return false;
+        t = c;
+    }
+    if (m1 < 0 || s.done[m1]) return false;
+    const ggml_tensor * M1 = g->nodes[m1], * fk = M1->src[0], * fq = M1->src[1];
+    const ggml_tensor * Sk = g->nodes[B->store], * Sv = g->nodes[vsj];
+    const int64_t D = A.D, H = A.H, HK = B->H;
+    if (fq->data != rq->data || fq->type != GGML_TYPE_F32 || fq->ne[0] != D || fq->ne[1] != 1 || fq->ne[2] != H || fq->ne[3] != 1 || fq->nb[2] != rq->nb[1] || rq->nb[0] != 4) return false;
+    if (fk->type != GGML_TYPE_F16 || fk->data != Sk->data || fk->ne[0] != D || fk->ne[2] != HK || fk->ne[3] != 1 || fk->nb[0] != 2 || fk->nb[1] != Sk->nb[1] || fk->nb[2] != (size_t) D * 2) return false;
+    const int64_t nkv = fk->ne[1];
+    if (M1->type != GGML_TYPE_F32 || M1->ne[0] != nkv || M1->ne[1] != 1 || M1->ne[2] != H || M1->ne[3] != 1) return false;
+    // -> SOFT_MAX_EXT
+    const int smi = sole_user(s, M1);
+    if (smi < 0 || s.done[smi]) return false;
+    const ggml_tensor * SM = g->nodes[smi];
+    if (SM->op != GGML_OP_SOFT_MAX || SM->src[0] != M1 || SM->src[2] || op_param_f32(SM, 1) != 0.0f || !same_shape(SM, M1)) return false;
+    const ggml_tensor * mk = SM->src[1];
+    if (mk && (mk->type != GGML_TYPE_F32 || mk->ne[0] != nkv || mk->nb[0] != 4 || mk->ne[2] != 1 || mk->ne[3] != 1)) return false;
+    // -> MUL_MAT(v^T, p)
+    const int m2 = sole_user(s, SM);
+    if (m2 < 0 || s.done[m2]) return false;
+    const ggml_tensor * M2 = g->nodes[m2];
+    if (M2->op != GGML_OP_MUL_MAT || M2->src[1] != SM) return false;
+    const ggml_tensor * fv = M2->src[0];
+    if (fv->type != GGML_TYPE_F16 || fv->data != Sv->data || fv->ne[0] != nkv || fv->ne[1] != D || fv->ne[2] != HK || fv->ne[3] != 1 || fv->nb[0] != 2 ||
+        fv->nb[2] != (size_t) D * fv->nb[1]) return false;
+    if (M2->type != GGML_TYPE_F32 || M2->ne[0] != D || M2->ne[1] != 1 || M2->ne[2] != H || M2->ne[3] != 1 || M2->nb[0] != 4) return false;
+    // -> PERMUTE -> CONT [D * H]
+    t = M2; int ci = -1;
+    for (int hop = 0; hop < 4; ++hop) {
+        const int u = sole_user(s, t);
+        if (u < 0) return false;
+        const ggml_tensor * c = g->nodes[u];
+        if (c->op == GGML_OP_CONT) { if (!views_back_to(c->src[0], t)) return false; ci = u; break; }
+        if (!is_noop(c)) return false;
+        t = c;
+    }
+    if (ci < 0 || s.done[ci]) return false;
+    const ggml_tensor * C = g->nodes[ci], * cs = C->src[0];
+    if (C->type != GGML_TYPE_F32 || !is_contiguous(C) || nelements(C) != D * H || cs->data != M2->data || cs->ne[0] != D || cs->ne[1] != H || cs->ne[2] != 1 || cs->ne[3] != 1 ||
+        cs->nb[0] != 4 || cs->nb[1] != M2->nb[2]) return false;
+    // the v scatter: one f16 element per index into the same transposed cache
+    const ggml_tensor * xv = Sv->src[0], * vidx = Sv->src[1], * kidx = Sk->src[1];
+    if (Sv->type != GGML_TYPE_F16 || Sv->ne[0] != 1 || Sv->nb[1] != 2 || xv->type != GGML_TYPE_F32 || xv->ne[0] != 1 || xv->ne[1] != D * HK || xv->nb[1] != 4 ||
+        nelements(xv) != D * HK || vidx->ne[0] != D * HK || kidx->type != vidx->type || (vidx->type != GGML_TYPE_I64 && vidx->type != GGML_TYPE_I32) ||
+        vidx->nb[0] != (vidx->type == GGML_TYPE_I64 ? 8u : 4u)) return false;
+    for (int k = A.norm + 1; k < ci; ++k) {
+        bool mine = k == m1 || k == smi || k == m2;
+        for (int q = 0; q < ni; ++q) mine |= item[q] == k;
+        if (!mine && !s.done[k] && !is_noop(g->nodes[k])) return false;             // something else runs in between: keep the separate launches
+    }
+    const ggml_tensor * xq = g->nodes[A.norm]->src[0], * xk = g->nodes[B->norm]->src[0];
+    fattn_pre & p = s.pq.pre;
+    p.qraw = (const float *) xq->data; p.q_hs = xq->nb[1]; p.kraw = (const float *) xk->data; p.k_hs = xk->nb[1];
+    p.vraw = (const float *) xv->data; p.v_hs = (int64_t) D * 4;
+    p.qw = (const float *) A.wt->data; p.kw = (const float *) B->wt->data; p.pos = (const int32_t *) A.pos->data; p.ff = A.ff ? (const float *) A.ff->data : nullptr;
+    p.eps = A.eps; p.rp = A.rp;
+    p.kcache = Sk->data; p.kc_rs = Sk->nb[1]; p.vcache = Sv->data; p.vc_rs = 2; p.kidx = kidx->data; p.vidx = vidx->data; p.idx_is64 = kidx->type == GGML_TYPE_I64;
+    attn_sm_args & a = s.pq.sma;
+    a = attn_sm_args();
+    a.pre = &s.pq.pre; a.k = fk->data; a.knb1 = fk->nb[1]; a.knb2 = fk->nb[2]; a.v = fv->data; a.vnb1 = fv->nb[1]; a.vnb2 = fv->nb[2];
+    a.mask = mk ? mk->data : nullptr; a.mnb2 = 0; a.mne2 = 1; a.dst = C->data; a.dnb1 = (int64_t) D * 4; a.vidx_n = vidx->ne[0];
+    a.D = (int) D; a.nkv = (int) nkv; a.n_head = (int) H; a.n_head_kv = (int) HK; a.scale = op_param_f32(SM, 0);
+    a.rope_tab = (const float *) s.c->rope_scratch;                                  // filled when the launch happens
+    if (s.c->rope_scratch_bytes < (size_t) D * 4 || !attn_one_sm_ok(a)) return false;
+    s.pq.fa = m1; s.pq.sm = true; s.pq.kst = B->store; s.pq.vst = vsj; s.pq.sm_soft = smi; s.pq.sm_mm2 = m2; s.pq.sm_cont = ci;
+    return true;
+}
+
 // RMS_NORM at node i: fold the following MUL(w) in, and -- when every consumer is a K-quant MUL_MAT -- also emit the Q8_K image
 static bool exec_rms_norm(exec_state & s, int i) {
     ggml_cgraph * g = s.g;
@@ -1132,6 +1218,26 @@ static bool exec_rms_norm(exec_state & s, int i) {
                                  S->data, (int64_t) S->nb[1], idx->data, idx->type == GGML_TYPE_I64, (int64_t) idx->nb[0], (int) (V->ne[0] / A.D) };
                     } else --ni;
                     break;
+                }
+                // flash-attention off, one token: the v store is a scatter of single elements into the transposed cache
+                if (vj < 0 && A.T == 1 && bj >= 0) {
+                    for (int j = i + 1; j < g->n_nodes && j < i + 32; ++j) {
+                        ggml_tensor * S = g->nodes[j];
+                        if (s.done[j] || S->op != GGML_OP_SET_ROWS) continue;
+                        bool mine = false;
+                        for (int q = 0; q < ni; ++q) mine |= item[q] == j;
+                        if (mine) continue;
+                        const ggml_tensor * V = S->src[0];
+                        if (!(V && V->type == GGML_TYPE_F32 && S->type == GGML_TYPE_F16 && V->ne[0] == 1 && S->ne[0] == 1 && V->ne[1] == (int64_t) A.D * B.H)) continue;
+                        item[ni++] = j;
+                        if (can_hoist(s, i, j, item, ni) && try_defer_qkv_to_softmax_attention(s, A, &B, j, item, ni)) {
+                            for (int q = 1; q < ni; ++q) { s.done[item[q]] = 1; ++s.n_fused; }
+                            ++s.n_fused;
+                            return true;
+                        }
+                        --ni;
+                        break;
+                    }
                 }
                 if (try_defer_qkv_to_attention(s, A, bj >= 0 ? &B : nullptr, vj, item, ni)) {
                     for (int q = 1; q < ni; ++q) { s.done[item[q]] = 1; ++s.n_fused; }
@@ -1238,6 +1344,25 @@ static void compute_node(exec_state & s, int i) {
 
     switch (n->op) {
         case GGML_OP_MUL_MAT:
+            if (s.pq.sm && s.pq.fa == i) {                                // flash-attention off, one token: K.q, soft-max, V^T.p, permute + cont and the q / k / v pre-stage in one launch
+                const fattn_pre & P = s.pq.pre;
+                attn_sm_args & a = s.pq.sma;
+                const bool valid = s.rt.pos == (const void *) P.pos && s.rt.ff == (const void *) P.ff && s.rt.T == 1 && s.rt.D == a.D && memcmp(&s.rt.rp, &P.rp, sizeof(rope_params)) == 0;
+                if (!valid) {
+                    prof_scope ps(s, "rope", 0);
+                    rope_table(P.pos, P.ff, P.rp, 1, a.D, (float *) s.c->rope_scratch, s.st); ++s.n_kernels;
+                    s.rt.pos = P.pos; s.rt.ff = P.ff; s.rt.T = 1; s.rt.D = a.D; s.rt.rp = P.rp;
+                }
+                a.rope_tab = (const float *) s.c->rope_scratch;
+                {
+                    prof_scope ps(s, "fattn", 0);
+                    attn_one_sm(a, s.st); ++s.n_kernels;
+                }
+                s.done[s.pq.sm_soft] = 1; s.done[s.pq.sm_mm2] = 1; s.done[s.pq.sm_cont] = 1; s.n_fused += 3;
+                note_write(s, g->nodes[s.pq.sm_cont]); note_write(s, g->nodes[s.pq.kst]); note_write(s, g->nodes[s.pq.vst]);
+                s.pq.fa = -1; s.pq.sm = false;
+                return;
+            }
             exec_mul_mat(s, i);
             return;
         case GGML_OP_IM2COL: {

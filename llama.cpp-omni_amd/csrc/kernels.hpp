@@ -164,6 +164,20 @@ struct fattn_args {
     uint16_t * out16 = nullptr; size_t out16_rs = 0; bool write_f32 = true;   // prefill kernel: also / only emit f16 rows [nh*D] per (seq, query)
     const float * rope_tab = nullptr;  // (cos, sin) pairs [D/2] of the token (rope_table), required by the one-token kernel (fattn_one_ok)
 };
+// One decode token through the reference's flash-attention-OFF attention (MUL_MAT(k, q) -> SOFT_MAX_EXT -> MUL_MAT(v^T, p) -> PERMUTE -> CONT on
+// the TRANSPOSED v cache) with the q / k / v pre-stage, as ONE launch (fattn_one.hip: k_attn_one_sm)
+struct attn_sm_args {
+    const fattn_pre * pre = nullptr;       // q chain, k chain + row store, v: vcache = base of the transposed cache, vidx = the scatter indices
+    const float * rope_tab = nullptr;
+    const void * k = nullptr; int64_t knb1 = 0, knb2 = 0;      // f16 K view [D, n_kv, HK]: cell stride, kv-head stride (bytes)
+    const void * v = nullptr; int64_t vnb1 = 0, vnb2 = 0;      // f16 V^T view [n_kv, D, HK]: dim stride, kv-head stride (bytes); cells contiguous
+    const void * mask = nullptr; int64_t mnb2 = 0, mne2 = 1;   // f32 mask row(s) [n_kv]
+    void * dst = nullptr; int64_t dnb1 = 0;                    // f32 [D, H]: head stride (bytes)
+    int64_t vidx_n = 0;
+    int D = 0, nkv = 0, n_head = 0, n_head_kv = 0; float scale = 1.0f;
+};
+bool   attn_one_sm_ok(const attn_sm_args & a);
+void   attn_one_sm(const attn_sm_args & a, hipStream_t st);
 void   fattn_set_one(bool on);             // one-token kernel on (default) / off: the round-1 decode kernels take the shape (cross-check)
 bool   fattn_one_ok(const fattn_args & a);       // one token, one sequence, pre-stage, <= 256 cache rows: the latency-optimised kernel (fattn_one.hip) runs
 // (cos, sin) * mscale of every (token, rotation pair): tab[T][D/2][2], what ggml_rope_cache_init / rope_yarn give for these positions

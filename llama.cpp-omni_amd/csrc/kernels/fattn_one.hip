@@ -54,6 +54,7 @@ struct fa1_dev {
     const char * k, * v, * mask; const float * sinks; char * dst;
     int q_hs, k_hs, v_hs, kc_rs, vc_rs, knb1, knb2, vnb1, vnb2, mnb2, mne2, dnb1;
     int nkv, gq, neox, n_head_log2;
+    int vidx_st, vidx_n;                                                     // soft-max path: bytes per v scatter index, number of indices
     float eps, scale, max_bias, logit_softcap, m0, m1;
 };
 
@@ -258,6 +259,191 @@ __global__ void __launch_bounds__(256) k_fattn_one(const fa1_dev a) {
     }
 }
 
+// ================================================================================================= flash-attention OFF (llama-bench's default)
+// The same one-token step as the reference's soft-max path emits it (src/llama-graph.cpp:1362-1420, build_attn_mha without flash_attn):
+//     kq  = MUL_MAT(k f16 [D, n_kv, HK], q f32)          q rounded to f16 (vec_dot_type of f16), f32 accumulation
+//     p   = SOFT_MAX_EXT(kq, mask f32, scale)            ops.cpp:5072-5182
+//     kqv = MUL_MAT(v^T f16 [n_kv, D, HK], p)            p rounded to f16 AFTER normalisation, f32 accumulation
+//     out = CONT(PERMUTE(kqv))                           [D * H]
+// with the V cache TRANSPOSED ([n_ctx cells contiguous, D * HK], llama-kv-cache.cpp:1091-1109: the v store is a SET_ROWS scatter of single
+// elements, index d_global * n_ctx + cell) and the same q / k / v pre-stage as k_fattn_one.  As separate launches this is 8 kernels per layer
+// (norm_rope, scatter, f32->f16 x2, batched mat-vec x2, soft-max, cont: 436 launches and 356 tok/s per decode step against 181 / 509 with
+// flash-attention on); here it is one.
+template <int D>
+__global__ void __launch_bounds__(256) k_attn_one_sm(const fa1_dev a) {
+    constexpr int KCH = D / 32, NG = FA1_NKV / 16 / 4, DPW = D / 4, HALF = D / 2;
+    constexpr int LPD = 64 / DPW;                 // lanes per output dim (2 at D = 128, 4 at D = 64): each takes FA1_NKV / LPD consecutive cells
+    constexpr int CPL = FA1_NKV / LPD;            // cells per lane
+    constexpr int NV  = CPL / 8;                  // 16-B V loads per lane
+    __shared__ __attribute__((aligned(16))) float qf[D], kc[D], vc[D], sc[FA1_NKV], pl[4][FA1_NKV];
+
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nkvh = (int) gridDim.x / a.gq, ikv = (int) blockIdx.x % nkvh, h = ikv * a.gq + (int) blockIdx.x / nkvh;     // XCD-aware head order (k_fattn_one)
+    const int nkv = a.nkv < FA1_NKV ? a.nkv : FA1_NKV;
+
+    // ---------------------------------------------------------------- 1. request everything
+    const bool act = lane < HALF;
+    const int  e0 = a.neox ? lane : 2 * lane, e1 = a.neox ? lane + HALF : 2 * lane + 1;
+    const __amdgpu_buffer_rsrc_t xrs = fa1_rsrc(wave == 0 ? a.qraw + h * a.q_hs : (wave == 1 ? a.kraw + ikv * a.k_hs : a.vraw + ikv * a.v_hs), wave < 3 ? D * 4 : 0);
+    const __amdgpu_buffer_rsrc_t wrs = fa1_rsrc(wave == 0 ? a.qw : a.kw, wave < 2 ? D * 4 : 0);
+    const __amdgpu_buffer_rsrc_t trs = fa1_rsrc(a.tab, wave < 2 ? D * 4 : 0);
+    const uint32_t xo0 = wave < 2 ? (act ? e0 * 4 : D * 4) : lane * 4, xo1 = wave < 2 ? (act ? e1 * 4 : D * 4) : (lane + 64) * 4;
+    const float x0 = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(xrs, xo0, 0, 0)), x1 = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(xrs, xo1, 0, 0));
+    const float w0 = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(wrs, xo0, 0, 0)), w1 = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(wrs, xo1, 0, 0));
+    const u32x2 tcs = __builtin_amdgcn_raw_buffer_load_b64(trs, act ? lane * 8 : D * 4, 0, 0);
+    const __amdgpu_buffer_rsrc_t mrs = fa1_rsrc(a.mask ? a.mask + (h % a.mne2) * a.mnb2 : a.mask, a.mask ? nkv * 4 : 0);          // f32 mask row
+    uint32_t mraw[FA1_NKV / 64];
+#pragma unroll
+    for (int i = 0; i < FA1_NKV / 64; ++i) mraw[i] = __builtin_amdgcn_raw_buffer_load_b32(mrs, (lane + 64 * i) * 4, 0, 0);
+    const int krow = (int) __builtin_amdgcn_raw_buffer_load_b32(fa1_rsrc(a.kidx, 4), 0, 0, 0);
+    // v scatter indices: element e of the v row goes to vcache[vidx[e]] (e = ikv * D + d); element 0's index is the cell itself
+    const __amdgpu_buffer_rsrc_t irs = fa1_rsrc(a.vidx, a.vidx_n * a.vidx_st);
+    const int vrow = (int) __builtin_amdgcn_raw_buffer_load_b32(irs, 0, 0, 0);
+    const int vi0 = (int) __builtin_amdgcn_raw_buffer_load_b32(irs, (uint32_t) (ikv * D + lane) * (uint32_t) a.vidx_st, 0, 0);
+    const int vi1 = (int) __builtin_amdgcn_raw_buffer_load_b32(irs, (uint32_t) (ikv * D + lane + 64) * (uint32_t) a.vidx_st, 0, 0);
+    const int r16 = lane >> 2, dq = lane & 3;
+    const __amdgpu_buffer_rsrc_t krs = fa1_rsrc(a.k + ikv * a.knb2, (nkv - 1) * a.knb1 + D * 2);
+    const uint32_t kvo = (uint32_t) r16 * (uint32_t) a.knb1 + (uint32_t) dq * (D / 2);
+    u32x4 kk[NG][KCH];
+#pragma unroll
+    for (int i = 0; i < NG; ++i) {
+        const uint32_t so = (uint32_t) ((wave + 4 * i) * 16) * (uint32_t) a.knb1;
+#pragma unroll
+        for (int c = 0; c < KCH; ++c) kk[i][c] = __builtin_amdgcn_raw_buffer_load_b128(krs, kvo + 16u * c, so, 0);
+    }
+    // V^T: lane (dl, part): output dim wave * DPW + dl, cells [part * CPL, part * CPL + CPL) -- contiguous along the cells
+    const int dl = lane / LPD, part = lane % LPD, dmine = wave * DPW + dl;
+    const __amdgpu_buffer_rsrc_t vrs = fa1_rsrc(a.v + ikv * a.vnb2, (D - 1) * a.vnb1 + nkv * 2);
+    u32x4 vv[NV];
+#pragma unroll
+    for (int j = 0; j < NV; ++j) vv[j] = __builtin_amdgcn_raw_buffer_load_b128(vrs, (uint32_t) dmine * (uint32_t) a.vnb1 + (uint32_t) (part * CPL + 8 * j) * 2u, 0, 0);
+
+    // ---------------------------------------------------------------- 2. q chain, k chain + store, v scatter
+    if (wave < 2) {
+        const float tc = __uint_as_float(tcs[0]), ts = __uint_as_float(tcs[1]);
+        double ss = (double) (x0 * x0) + (double) (x1 * x1);
+        ss = wave_sum_f64o(ss);
+        const float mean  = (float) (ss * (1.0 / D));
+        const float scale = 1.0f / sqrtf(mean + a.eps);
+        const float v0 = (x0 * scale) * w0, v1 = (x1 * scale) * w1;
+        const float r0 = v0 * tc - v1 * ts, r1 = v0 * ts + v1 * tc;
+        if (act) {
+            const uint16_t h0 = f2h(r0), h1 = f2h(r1);
+            if (wave == 0) { qf[e0] = h2f(h0); qf[e1] = h2f(h1); }                 // MUL_MAT(k f16, q): q rounded to f16
+            else {
+                kc[e0] = h2f(h0); kc[e1] = h2f(h1);
+                if (h % a.gq == 0) { uint16_t * kr = (uint16_t *) (a.kcache + (int64_t) krow * a.kc_rs) + ikv * D; kr[e0] = h0; kr[e1] = h1; }
+            }
+        }
+    } else if (wave == 2) {
+        const uint16_t hv0 = f2h(x0), hv1 = f2h(x1);
+        vc[lane] = h2f(hv0);
+        if (D > 64) vc[lane + 64] = h2f(hv1);
+        if (h % a.gq == 0) {
+            *(uint16_t *) (a.vcache + (int64_t) vi0 * 2) = hv0;
+            if (D > 64) *(uint16_t *) (a.vcache + (int64_t) vi1 * 2) = hv1;
+        }
+    }
+    float mv[FA1_NKV / 64]; int n_live = 0;
+#pragma unroll
+    for (int i = 0; i < FA1_NKV / 64; ++i) {
+        const int kv = lane + 64 * i;
+        float m = a.mask ? __uint_as_float(mraw[i]) : 0.0f;
+        if (kv >= nkv) m = -INFINITY;
+        mv[i] = m;
+        const unsigned long long live = __ballot(m != -INFINITY);
+        if (live) n_live = 64 * i + 64 - __builtin_clzll(live);
+    }
+    __syncthreads();
+
+    // ---------------------------------------------------------------- 3. scores
+    {
+        f16x2 qh[D / 8];
+#pragma unroll
+        for (int c = 0; c < D / 16; ++c) {
+            const f32x4 t = *(const f32x4 *) (qf + dq * (D / 4) + 4 * c);
+            qh[2 * c] = f16x2{ (_Float16) t[0], (_Float16) t[1] }; qh[2 * c + 1] = f16x2{ (_Float16) t[2], (_Float16) t[3] };
+        }
+#pragma unroll
+        for (int i = 0; i < NG; ++i) {
+            const int g = wave + 4 * i;
+            if (g * 16 >= n_live) continue;
+            float s = 0.0f;
+#pragma unroll
+            for (int c = 0; c < KCH; ++c)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    f16x2 kh; const uint32_t kw = kk[i][c][e]; __builtin_memcpy(&kh, &kw, 4);
+                    s = __builtin_amdgcn_fdot2(kh, qh[c * 4 + e], s, false);
+                }
+            s += dppf_old<0xB1, 0xf>(0.0f, s);
+            s += dppf_old<0x4E, 0xf>(0.0f, s);
+            const int row = g * 16 + r16;
+            if (dq == 0 && row < nkv && row != krow) sc[row] = s;
+        }
+        if (wave == 3) {
+            float s = 0.0f;
+#pragma unroll
+            for (int i = 0; i < D / 64; ++i) s = fmaf(kc[lane + 64 * i], qf[lane + 64 * i], s);
+            s = wave_sum_f32(s);
+            if (lane == 0 && krow >= 0 && krow < nkv) sc[krow] = s;
+        }
+    }
+    __syncthreads();
+
+    // ---------------------------------------------------------------- 4. soft-max (ops.cpp:5072-5182): p = exp(s * scale + mask - max) / sum, then f16 (the KQV product's vec_dot_type)
+    {
+        float sv[FA1_NKV / 64], pe[FA1_NKV / 64];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int i = 0; i < FA1_NKV / 64; ++i) {
+            const int kv = lane + 64 * i;
+            float v = kv < n_live ? sc[kv] * a.scale : 0.0f;
+            v += mv[i];
+            if (mv[i] == -INFINITY) v = -INFINITY;
+            sv[i] = v; mx = fmaxf(mx, v);
+        }
+        const float M = wave_max_f32(mx);
+        float S = 0.0f;
+#pragma unroll
+        for (int i = 0; i < FA1_NKV / 64; ++i) { pe[i] = sv[i] == -INFINITY ? 0.0f : expf(sv[i] - M); S += pe[i]; }
+        S = wave_sum_f32(S);
+        const float inv = S == 0.0f ? 0.0f : 1.0f / S;
+#pragma unroll
+        for (int i = 0; i < FA1_NKV / 64; ++i) pl[wave][lane + 64 * i] = h2f(f2h(pe[i] * inv));
+    }
+    float pcur = 0.0f;
+    const bool vin = vrow >= 0 && vrow < nkv;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (vin) pcur = pl[wave][vrow];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (vin && lane == 0) pl[wave][vrow] = 0.0f;                       // the new token's V values come from LDS (they are not in the cache view yet)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+    // ---------------------------------------------------------------- 5. P . V^T for this lane's dim and cell range
+    float acc = 0.0f;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const int c0 = part * CPL + 8 * j;
+        if (c0 >= n_live) continue;                                      // (everything past the last visible cell has p == 0)
+        const f32x4 pa = *(const f32x4 *) (&pl[wave][c0]), pb = *(const f32x4 *) (&pl[wave][c0 + 4]);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const uint32_t w = vv[j][t];
+            const float p0 = t < 2 ? pa[2 * t] : pb[2 * t - 4], p1 = t < 2 ? pa[2 * t + 1] : pb[2 * t - 3];
+            // masked cells are never multiplied (an uninitialised cell may hold inf / NaN): p == 0 -> skip
+            acc = fmaf(p0, p0 != 0.0f ? h2f((uint16_t) (w & 0xffff)) : 0.0f, acc);
+            acc = fmaf(p1, p1 != 0.0f ? h2f((uint16_t) (w >> 16)) : 0.0f, acc);
+        }
+    }
+#pragma unroll
+    for (int o = 1; o < LPD; o <<= 1) acc += __shfl_xor(acc, o, 64);
+    if (part == 0) {
+        acc = fmaf(pcur, vc[dmine], acc);
+        *((float *) (a.dst + h * a.dnb1) + dmine) = acc;
+    }
+}
+
 // one token of one sequence, q / k / v pre-stage, <= 256 cache rows, f16 mask shared by the heads of a token (or per head), D 64 / 128
 static bool g_one_enabled = true;
 void fattn_set_one(bool on) { g_one_enabled = on; }
@@ -288,6 +474,35 @@ void flash_attn_one(const fa_dev & f, int D, const float * rope_tab, hipStream_t
     const dim3 grid((unsigned) f.nh);
     if (D == 64) k_fattn_one<64><<<grid, dim3(256), 0, st>>>(a);
     else         k_fattn_one<128><<<grid, dim3(256), 0, st>>>(a);
+}
+
+
+// ---- host side of the soft-max path
+bool attn_one_sm_ok(const attn_sm_args & f) {
+    static const bool env_off = getenv("MI355X_NO_ATTN_SM") != nullptr;
+    if (env_off || !g_one_enabled) return false;
+    if ((f.D != 64 && f.D != 128) || f.nkv < 1 || f.nkv > FA1_NKV || f.nkv % 8 != 0 || f.n_head < 1 || f.n_head_kv < 1 || f.n_head % f.n_head_kv != 0) return false;
+    if (f.knb1 % 16 != 0 || f.knb2 % 16 != 0 || ((uintptr_t) f.k & 15) != 0 || f.vnb1 % 16 != 0 || f.vnb2 % 16 != 0 || ((uintptr_t) f.v & 15) != 0) return false;
+    if (f.knb1 * FA1_NKV > 0x7fffffff || f.vnb1 * f.D > 0x7fffffff || f.knb2 > 0x7fffffff || f.vnb2 > 0x7fffffff) return false;
+    if (f.dnb1 % 4 != 0 || ((uintptr_t) f.dst & 3) != 0 || !f.pre || !f.rope_tab) return false;
+    if (f.vidx_n < (int64_t) f.n_head_kv * f.D) return false;
+    return true;
+}
+void attn_one_sm(const attn_sm_args & f, hipStream_t st) {
+    if (!attn_one_sm_ok(f)) { fprintf(stderr, "[mi355x] attn_one_sm: unsupported arguments\n"); abort(); }
+    const fattn_pre & P = *f.pre;
+    fa1_dev a;
+    a.qraw = (const char *) P.qraw; a.kraw = (const char *) P.kraw; a.vraw = (const char *) P.vraw; a.qw = P.qw; a.kw = P.kw; a.tab = f.rope_tab;
+    a.kcache = (char *) P.kcache; a.vcache = (char *) P.vcache; a.kidx = (const char *) P.kidx; a.vidx = (const char *) P.vidx;
+    a.k = (const char *) f.k; a.v = (const char *) f.v; a.mask = (const char *) f.mask; a.sinks = nullptr; a.dst = (char *) f.dst;
+    a.q_hs = (int) P.q_hs; a.k_hs = (int) P.k_hs; a.v_hs = (int) P.v_hs; a.kc_rs = (int) P.kc_rs; a.vc_rs = 2;
+    a.knb1 = (int) f.knb1; a.knb2 = (int) f.knb2; a.vnb1 = (int) f.vnb1; a.vnb2 = (int) f.vnb2; a.mnb2 = (int) f.mnb2; a.mne2 = (int) (f.mne2 > 0 ? f.mne2 : 1); a.dnb1 = (int) f.dnb1;
+    a.nkv = f.nkv; a.gq = f.n_head / f.n_head_kv; a.neox = (P.rp.mode & GGML_ROPE_TYPE_NEOX) ? 1 : 0; a.n_head_log2 = 0;
+    a.vidx_st = P.idx_is64 ? 8 : 4; a.vidx_n = (int) f.vidx_n;
+    a.eps = P.eps; a.scale = f.scale; a.max_bias = 0.0f; a.logit_softcap = 0.0f; a.m0 = 1.0f; a.m1 = 1.0f;
+    const dim3 grid((unsigned) f.n_head);
+    if (f.D == 64) k_attn_one_sm<64><<<grid, dim3(256), 0, st>>>(a);
+    else           k_attn_one_sm<128><<<grid, dim3(256), 0, st>>>(a);
 }
 
 } // namespace mi

@@ -104,8 +104,11 @@ def random_blocks(rng, ty, nrows, K, std=0.02):
 class Model:
     """Weights + KV cache resident in HBM, and graph builders for one ubatch."""
 
-    def __init__(self, be, cfg, types, n_ctx=512, seed=1234, share_layer_bytes=False, flash_attn=True, host_copy=False, weights=None):
+    def __init__(self, be, cfg, types, n_ctx=512, seed=1234, share_layer_bytes=False, flash_attn=True, host_copy=False, weights=None, v_trans=None):
         self.be, self.cfg, self.types, self.n_ctx, self.fa = be, cfg, types, n_ctx, flash_attn
+        # llama_kv_cache: the V cache is TRANSPOSED whenever flash-attention is off (llama-kv-cache.cpp: v_trans = !cparams.flash_attn);
+        # v_trans=False with flash_attn=False builds build_attn_mha's "avoid this branch" form (row cache + CONT(TRANSPOSE(v))) instead
+        self.v_trans = (not flash_attn) if v_trans is None else bool(v_trans)
         c = cfg
         self.wctx = Context(be)
         w = self.wctx
@@ -184,7 +187,7 @@ class Model:
         I = dict(
             inp_embd=g.new_tensor(GGML_TYPE_F32, E, n_tokens), inp_pos=g.new_tensor(GGML_TYPE_I32, n_tokens),
             kq_mask=g.new_tensor(GGML_TYPE_F16 if self.fa else GGML_TYPE_F32, n_kv, (n_tokens + 63) // 64 * 64),
-            k_idxs=g.new_tensor(GGML_TYPE_I64, n_tokens), v_idxs=g.new_tensor(GGML_TYPE_I64, n_tokens),
+            k_idxs=g.new_tensor(GGML_TYPE_I64, n_tokens), v_idxs=g.new_tensor(GGML_TYPE_I64, n_tokens * (HK * D if self.v_trans else 1)),
         )
         if n_outputs is not None and n_outputs != n_tokens:
             I["out_ids"] = g.new_tensor(GGML_TYPE_I32, n_outputs)
@@ -211,10 +214,16 @@ class Model:
             kc, vc = self._w(g, L["k_cache"]), self._w(g, L["v_cache"])
             roots += [Q, K, V]
             roots.append(g.set_rows(kc, g.view_2d(K, HK * D, n_tokens, K.nb[2], 0), I["k_idxs"]))
-            roots.append(g.set_rows(vc, g.view_2d(V, HK * D, n_tokens, V.nb[2], 0), I["v_idxs"]))
+            if self.v_trans:                                            # cpy_v, transposed cache: one element per row index (llama-kv-cache.cpp:1091-1109)
+                roots.append(g.set_rows(g.reshape(vc, 1, HK * D * self.n_ctx), g.reshape(g.reshape(V, HK * D, n_tokens), 1, HK * D * n_tokens), I["v_idxs"]))
+            else:
+                roots.append(g.set_rows(vc, g.view_2d(V, HK * D, n_tokens, V.nb[2], 0), I["v_idxs"]))
             # attention over the first n_kv cells (get_k / get_v views, build_attn_mha)
             k = g.view_4d(kc, D, HK, n_kv, 1, D * f16, HK * D * f16, HK * D * f16 * self.n_ctx, 0)
-            v = g.view_4d(vc, D, HK, n_kv, 1, D * f16, HK * D * f16, HK * D * f16 * self.n_ctx, 0)
+            if self.v_trans:                                            # get_v: [n_kv, HK, D] over the [kv_size, n_embd_v_gqa] cache (llama-kv-cache.cpp:1012-1018)
+                v = g.view_4d(vc, n_kv, HK, D, 1, self.n_ctx * D * f16, self.n_ctx * f16, self.n_ctx * HK * D * f16, 0)
+            else:
+                v = g.view_4d(vc, D, HK, n_kv, 1, D * f16, HK * D * f16, HK * D * f16 * self.n_ctx, 0)
             q = g.permute(Q, 0, 2, 1, 3)
             k = g.permute(k, 0, 2, 1, 3)
             v = g.permute(v, 0, 2, 1, 3)
@@ -224,7 +233,7 @@ class Model:
             else:
                 kq = g.mul_mat(k, q)
                 kqs = g.soft_max_ext(kq, I["kq_mask"], kq_scale, 0.0)
-                vt = g.cont(g.transpose(v))                           # "avoid this branch" path of build_attn_mha
+                vt = v if self.v_trans else g.cont(g.transpose(v))    # (row cache: the "avoid this branch" path of build_attn_mha)
                 kqv = g.mul_mat(vt, kqs)
                 cur = g.cont(g.permute(kqv, 0, 2, 1, 3), H * D, n_tokens)
                 if getattr(self, "taps", None) is not None and il == 0:   # debugging aid: keep layer 0's attention intermediates alive
@@ -269,7 +278,11 @@ class Model:
         pos = np.arange(pos0, pos0 + n, dtype=np.int32)
         be.tensor_set(I["inp_pos"], pos)
         be.tensor_set(I["k_idxs"], pos.astype(np.int64))
-        be.tensor_set(I["v_idxs"], pos.astype(np.int64))
+        if self.v_trans:                                                # set_input_v_idxs: j * kv_size + cell for every element j of the row (llama-kv-cache.cpp:1169-1183)
+            nv = self.cfg["n_head_kv"] * self.cfg["head_dim"]
+            be.tensor_set(I["v_idxs"], (np.arange(nv, dtype=np.int64)[None, :] * self.n_ctx + pos.astype(np.int64)[:, None]).ravel())
+        else:
+            be.tensor_set(I["v_idxs"], pos.astype(np.int64))
         npad = I["kq_mask"].ne[1]
         m = np.full((npad, n_kv), -np.inf, dtype=np.float32)
         for i in range(n):
