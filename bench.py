@@ -58,6 +58,7 @@ class Decoder:
         msz = 2 if flash_attn else 4
         self.h_mask = alloc(n_kv * msz).view(np.float16 if flash_attn else np.float32)   # row 0 of the padded mask
         self.h_logits = alloc(V * 4).view(np.float32)
+        self.mask_upto = -1
         rng = np.random.default_rng(seed + 1)
         self.embd_pool = (rng.standard_normal((64, E)) * 1.0).astype(np.float32)
         # rows 1..63 of the padded mask stay -inf for the whole run
@@ -70,8 +71,12 @@ class Decoder:
         self.h_embd[:] = self.embd_pool[pos % 64]
         self.h_pos[0] = pos
         self.h_idx[0] = pos
-        self.h_mask[:] = -np.inf
-        self.h_mask[: pos + 1] = 0.0
+        if pos == self.mask_upto:                                # causal mask row of the new token: one more visible cell than the last step's
+            self.h_mask[pos] = 0.0
+        else:
+            self.h_mask[:] = -np.inf
+            self.h_mask[: pos + 1] = 0.0
+        self.mask_upto = pos + 1
         be.tensor_set_async(I["inp_embd"], self.h_embd)
         be.tensor_set_async(I["inp_pos"], self.h_pos)
         be.tensor_set_async(I["k_idxs"], self.h_idx)

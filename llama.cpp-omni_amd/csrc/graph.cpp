@@ -581,8 +581,19 @@ static bool kq_mm_ok(const ggml_tensor * n) {
     const ggml_tensor * w = n->src[0], * x = n->src[1];
     return w->ne[2] == 1 && w->ne[3] == 1 && x->ne[2] == 1 && x->ne[3] == 1 && n->nb[0] == 4 && x->nb[0] == 4;
 }
-// batch-1 decode form (mmv1.hip): one column, Q4_K / Q6_K, K a multiple of 4096 up to 12288, aligned rows
+// the Q8_0 twin (mmv1q.hip): MUL_MAT(Q8_0 W [K, M], f32 x [K, 1]), no broadcast -- the TTS / Token2Wav modules' decode mat-vecs
+static bool q80_mv1_node(exec_state & s, const ggml_tensor * n) {
+    if (!s.c->opt_mv1 || n->op != GGML_OP_MUL_MAT || is_empty(n)) return false;
+    const ggml_tensor * w = n->src[0], * x = n->src[1];
+    if (w->type != GGML_TYPE_Q8_0 || x->type != GGML_TYPE_F32 || w->ne[2] != 1 || w->ne[3] != 1 || x->ne[1] != 1 || x->ne[2] != 1 || x->ne[3] != 1 || n->nb[0] != 4 || x->nb[0] != 4) return false;
+    mv1_args v; v.nmat = 1; v.K = w->ne[0];
+    v.m[0] = { w->data, w->nb[1], (float *) n->data, 0, nullptr, 0, w->ne[1], (int) w->type };
+    v.img = (const void *) 16;
+    return mmv1_ok(v);
+}
+// batch-1 decode form (mmv1.hip): one column, Q4_K / Q6_K, K a multiple of 4096 up to 12288, aligned rows; or the Q8_0 twin
 static bool mv1_node_ok(exec_state & s, const ggml_tensor * n) {
+    if (q80_mv1_node(s, n)) return true;
     if (!s.c->opt_mv1 || !plain_kq_matvec(n, 1)) return false;
     const ggml_tensor * w = n->src[0], * x = n->src[1];
     if (x->ne[1] != 1 || x->type != GGML_TYPE_F32 || (w->type != GGML_TYPE_Q4_K && w->type != GGML_TYPE_Q6_K)) return false;
@@ -602,14 +613,15 @@ static void mv1_source(exec_state & s, const ggml_tensor * x, const ggml_tensor 
         return;
     }
     const int64_t K = x->ne[0];
-    const bool cached = s.a_src == x->data && s.a_kind == ACT_Q8K && s.a_K == K && s.a_ne[0] == 1 && s.a_ne[1] == x->ne[2] && s.a_ne[2] == x->ne[3];
+    const act_kind kind = v.m[0].type == GGML_TYPE_Q8_0 ? ACT_Q80 : ACT_Q8K;       // (v.m[] is filled before the source is chosen)
+    const bool cached = s.a_src == x->data && s.a_kind == kind && s.a_K == K && s.a_ne[0] == 1 && s.a_ne[1] == x->ne[2] && s.a_ne[2] == x->ne[3];
     bool plain = !cached && !(s.pn.m && x == s.pn.m) && ((uintptr_t) x->data & 15) == 0;
     if (plain) {
         const byte_range rx = range_of(x);
         for (int i = 0; i < n_outs; ++i) if (outs[i] && overlap(range_of(outs[i]), rx)) plain = false;
     }
     if (plain) { v.x = (const float *) x->data; v.norm_w = nullptr; return; }
-    prepare_act(s, x, ACT_Q8K);
+    prepare_act(s, x, kind);
     v.img = s.c->act_scratch;
 }
 static bool same_act(const ggml_tensor * a, const ggml_tensor * b) {
@@ -802,7 +814,8 @@ static void exec_mul_mat(exec_state & s, int i) {
     ggml_cgraph * g = s.g;
     ggml_tensor * n = g->nodes[i];
     if (s.c->opt_fusion && exec_gemm_group(s, i)) return;
-    if (!s.c->opt_fusion || !kq_mm_ok(n)) { op_mul_mat(s, n); note_write(s, n); return; }
+    const bool q80 = s.c->opt_fusion && q80_mv1_node(s, n);                  // Q8_0, one column: the same fusions on mmv1q.hip
+    if (!s.c->opt_fusion || (!kq_mm_ok(n) && !q80)) { op_mul_mat(s, n); note_write(s, n); return; }
     const ggml_tensor * x = n->src[1];
     const int64_t K = x->ne[0]; const int N = (int) x->ne[1];
 
@@ -815,7 +828,7 @@ static void exec_mul_mat(exec_state & s, int i) {
             ggml_tensor * G = g->nodes[gi];
             ggml_tensor * other = G->src[0] == n ? G->src[1] : (G->src[1] == n ? G->src[0] : nullptr);
             auto oit = other ? s.index.find(other) : s.index.end();
-            if (other && oit != s.index.end() && oit->second > i && !s.done[oit->second] && plain_kq_matvec(other, MI_MMVQ_MAX_COLS) && sole_user(s, other) == gi &&
+            if (other && oit != s.index.end() && oit->second > i && !s.done[oit->second] && (q80 ? q80_mv1_node(s, other) : plain_kq_matvec(other, MI_MMVQ_MAX_COLS)) && sole_user(s, other) == gi &&
                 same_act(other->src[1], x) && other->src[0]->type == n->src[0]->type && other->src[0]->ne[1] == n->src[0]->ne[1] &&
                 other->src[0]->nb[1] == n->src[0]->nb[1] && G->nb[0] == 4 && G->ne[0] == n->ne[0] && is_contiguous_1(G)) {
                 const int oi = oit->second;
@@ -829,13 +842,14 @@ static void exec_mul_mat(exec_state & s, int i) {
                         v.m[0] = { gate_n->src[0]->data, gate_n->src[0]->nb[1], (float *) G->data, 0, nullptr, 0, gate_n->src[0]->ne[1], (int) gate_n->src[0]->type };
                         v.W_up = up_n->src[0]->data;
                         mv1_source(s, x, outs, 1, 2, v);
-                        prof_scope ps(s, n->src[0]->type == GGML_TYPE_Q4_K ? "mmv_q4k" : "mmv_q6k", 2.0 * (double) n->src[0]->ne[1] * (double) row_size(n->src[0]->type, K));
+                        prof_scope ps(s, q80 ? "mmv_q80" : (n->src[0]->type == GGML_TYPE_Q4_K ? "mmv_q4k" : "mmv_q6k"), 2.0 * (double) n->src[0]->ne[1] * (double) row_size(n->src[0]->type, K));
                         mmv1(v, s.st);
                         ++s.n_kernels; s.n_fused += 2;
                         s.done[oi] = s.done[gi] = 1;
                         note_write(s, G);
                         return;
                     }
+                    if (q80) { fprintf(stderr, "[mi355x] exec_mul_mat: a Q8_0 gate / up pair that mmv1q refuses\n"); abort(); }   // (q80_mv1_node accepted both halves)
                     const size_t img = norm_in_kernel(s, x, outs, 1, 2, nrm) ? q8k_image_bytes(K) : prepare_act(s, x, ACT_Q8K);
                     const ggml_tensor * gate = G->src[0], * up = G->src[1];
                     prof_scope ps(s, n->src[0]->type == GGML_TYPE_Q4_K ? "mmv_q4k" : "mmv_q6k", 2.0 * (double) n->src[0]->ne[1] * (double) row_size(n->src[0]->type, K));
@@ -854,7 +868,7 @@ static void exec_mul_mat(exec_state & s, int i) {
     int   mm_idx[3] = { i, -1, -1 }; int nm = 1;
     for (int j = i + 1; j < g->n_nodes && j < i + 32 && nm < 3; ++j) {
         ggml_tensor * c = g->nodes[j];
-        if (s.done[j] || !kq_mm_ok(c) || !same_act(c->src[1], x)) continue;
+        if (s.done[j] || !(q80 ? q80_mv1_node(s, c) : kq_mm_ok(c)) || !same_act(c->src[1], x)) continue;
         // do not steal one half of a gate/up pair (that fusion is worth more; it exists for the mat-vec widths only)
         const int cu = sole_user(s, c);
         if (!use_mmq && cu > 0 && g->nodes[cu]->op == GGML_OP_GLU) continue;
@@ -897,7 +911,7 @@ static void exec_mul_mat(exec_state & s, int i) {
         for (int q = 0; q < nm; ++q) v.m[q] = a.m[q];
         mv1_source(s, x, outs, nm, nm, v);
         {
-            prof_scope ps(s, bytes_q4 >= bytes_q6 ? "mmv_q4k" : "mmv_q6k", bytes_q4 + bytes_q6);
+            prof_scope ps(s, q80 ? "mmv_q80" : (bytes_q4 >= bytes_q6 ? "mmv_q4k" : "mmv_q6k"), bytes_q4 + bytes_q6);
             mmv1(v, s.st);
         }
         ++s.n_kernels;
@@ -908,6 +922,7 @@ static void exec_mul_mat(exec_state & s, int i) {
         }
         return;
     }
+    if (q80) { fprintf(stderr, "[mi355x] exec_mul_mat: a Q8_0 batch that mmv1q refuses\n"); abort(); }                 // (every member passed q80_mv1_node)
     const size_t img = norm_in_kernel(s, x, outs, nm, nm, a.norm) ? q8k_image_bytes(K) : prepare_act(s, x, ACT_Q8K);
     a.act = s.c->act_scratch; a.act_cs = img;
     if (use_mmq) {                                                    // int8 matrix cores, 32 columns per launch
@@ -938,8 +953,9 @@ static void exec_mul_mat(exec_state & s, int i) {
 
 // RMS_NORM(j) -> MUL(w[D]) -> ROPE [-> SET_ROWS of the rotated rows viewed as [D*H, T] into an f16 table]; shape checks only
 struct nr_chain {
-    int norm, mul, rope, store;
-    const ggml_tensor * wt, * pos, * ff;
+    int norm, mul, rope, store;                    // norm / mul = -1: a ROPE-only chain (llama architecture: no q / k norm)
+    const ggml_tensor * wt, * pos, * ff;           // wt = null: no norm
+    const ggml_tensor * xin; int first;            // the f32 heads the chain starts from, and the chain's first node
     int D, H, T; float eps; rope_params rp;
 };
 static bool match_norm_rope(exec_state & s, int j, nr_chain & c) {
@@ -960,7 +976,7 @@ static bool match_norm_rope(exec_state & s, int j, nr_chain & c) {
     const ggml_tensor * pos = r->src[1], * ff = r->src[2];
     if (!((mode == GGML_ROPE_TYPE_NORMAL || mode == GGML_ROPE_TYPE_NEOX) && op_param_i32(r, 1) == D && r->nb[0] == 4 && pos && pos->type == GGML_TYPE_I32 &&
           pos->nb[0] == 4 && (!ff || (ff->type == GGML_TYPE_F32 && ff->nb[0] == 4)))) return false;
-    c.norm = j; c.mul = mi_; c.rope = ri; c.store = -1; c.wt = wt; c.pos = pos; c.ff = ff;
+    c.norm = j; c.mul = mi_; c.rope = ri; c.store = -1; c.wt = wt; c.pos = pos; c.ff = ff; c.xin = n->src[0]; c.first = j;
     c.D = (int) D; c.H = (int) n->ne[1]; c.T = (int) n->ne[2]; c.eps = op_param_f32(n, 0);
     memset(&c.rp, 0, sizeof(c.rp));
     c.rp.n_dims = op_param_i32(r, 1); c.rp.mode = mode; c.rp.n_ctx_orig = op_param_i32(r, 4);
@@ -978,9 +994,9 @@ static bool match_norm_rope(exec_state & s, int j, nr_chain & c) {
 }
 static norm_rope_job chain_job(exec_state & s, const nr_chain & c) {
     ggml_cgraph * g = s.g;
-    const ggml_tensor * x = g->nodes[c.norm]->src[0]; ggml_tensor * r = g->nodes[c.rope];
+    const ggml_tensor * x = c.xin; ggml_tensor * r = g->nodes[c.rope];
     norm_rope_job j;
-    j.x = (const float *) x->data; j.xnb1 = x->nb[1]; j.xnb2 = x->nb[2]; j.w = (const float *) c.wt->data;
+    j.x = (const float *) x->data; j.xnb1 = x->nb[1]; j.xnb2 = x->nb[2]; j.w = c.wt ? (const float *) c.wt->data : nullptr; j.rope_only = c.wt ? 0 : 1;
     j.y = (float *) r->data; j.ynb1 = r->nb[1]; j.ynb2 = r->nb[2];
     j.kv = nullptr; j.kv_rs = 0; j.idx = nullptr; j.idx_is64 = 0; j.idx_nb0 = 0; j.H = c.H;
     if (c.store >= 0) {
@@ -1052,19 +1068,19 @@ static bool try_defer_qkv_to_attention(exec_state & s, const nr_chain & A, const
         fk->nb[2] != (size_t) D * 2 || fv->nb[2] != (size_t) D * 2 || fk->ne[2] != B->H || fv->ne[2] != B->H || fk->ne[3] != 1 || fv->ne[0] != D) return false;
     int last = 0;
     for (int q = 0; q < ni; ++q) if (item[q] > last) last = item[q];
-    for (int k = A.norm + 1; k < fi; ++k) {
+    for (int k = A.first + 1; k < fi; ++k) {
         bool mine = false;
         for (int q = 0; q < ni; ++q) mine |= item[q] == k;
         if (!mine && !s.done[k] && !is_noop(g->nodes[k])) return false;             // something else runs in between: keep the separate launch
     }
     fattn_args fa; tdesc m; fill_fattn_args(f, fa, m);
-    if (!fattn_pre_ok(fa)) return false;
-    const ggml_tensor * xq = g->nodes[A.norm]->src[0], * xk = g->nodes[B->norm]->src[0], * xv = Sv->src[0], * kidx = Sk->src[1], * vidx = Sv->src[1];
+    if (!fattn_pre_ok(fa) || (A.wt == nullptr) != (B->wt == nullptr)) return false;
+    const ggml_tensor * xq = A.xin, * xk = B->xin, * xv = Sv->src[0], * kidx = Sk->src[1], * vidx = Sv->src[1];
     if (kidx->type != vidx->type) return false;
     fattn_pre & p = s.pq.pre;
     p.qraw = (const float *) xq->data; p.q_hs = xq->nb[1]; p.kraw = (const float *) xk->data; p.k_hs = xk->nb[1];
     p.vraw = (const float *) xv->data; p.v_hs = (int64_t) D * 4;
-    p.qw = (const float *) A.wt->data; p.kw = (const float *) B->wt->data; p.pos = (const int32_t *) A.pos->data; p.ff = A.ff ? (const float *) A.ff->data : nullptr;
+    p.qw = A.wt ? (const float *) A.wt->data : nullptr; p.kw = B->wt ? (const float *) B->wt->data : nullptr; p.pos = (const int32_t *) A.pos->data; p.ff = A.ff ? (const float *) A.ff->data : nullptr;
     p.eps = A.eps; p.rp = A.rp;
     p.kcache = Sk->data; p.kc_rs = Sk->nb[1]; p.vcache = Sv->data; p.vc_rs = Sv->nb[1]; p.kidx = kidx->data; p.vidx = vidx->data; p.idx_is64 = kidx->type == GGML_TYPE_I64;
     s.pq.fa = fi; s.pq.kst = B->store; s.pq.vst = vj;
@@ -1133,16 +1149,17 @@ static bool try_defer_qkv_to_softmax_attention(exec_state & s, const nr_chain & 
     if (Sv->type != GGML_TYPE_F16 || Sv->ne[0] != 1 || Sv->nb[1] != 2 || xv->type != GGML_TYPE_F32 || xv->ne[0] != 1 || xv->ne[1] != D * HK || xv->nb[1] != 4 ||
         nelements(xv) != D * HK || vidx->ne[0] != D * HK || kidx->type != vidx->type || (vidx->type != GGML_TYPE_I64 && vidx->type != GGML_TYPE_I32) ||
         vidx->nb[0] != (vidx->type == GGML_TYPE_I64 ? 8u : 4u)) return false;
-    for (int k = A.norm + 1; k < ci; ++k) {
+    if ((A.wt == nullptr) != (B->wt == nullptr)) return false;
+    for (int k = A.first + 1; k < ci; ++k) {
         bool mine = k == m1 || k == smi || k == m2;
         for (int q = 0; q < ni; ++q) mine |= item[q] == k;
         if (!mine && !s.done[k] && !is_noop(g->nodes[k])) return false;             // something else runs in between: keep the separate launches
     }
-    const ggml_tensor * xq = g->nodes[A.norm]->src[0], * xk = g->nodes[B->norm]->src[0];
+    const ggml_tensor * xq = A.xin, * xk = B->xin;
     fattn_pre & p = s.pq.pre;
     p.qraw = (const float *) xq->data; p.q_hs = xq->nb[1]; p.kraw = (const float *) xk->data; p.k_hs = xk->nb[1];
     p.vraw = (const float *) xv->data; p.v_hs = (int64_t) D * 4;
-    p.qw = (const float *) A.wt->data; p.kw = (const float *) B->wt->data; p.pos = (const int32_t *) A.pos->data; p.ff = A.ff ? (const float *) A.ff->data : nullptr;
+    p.qw = A.wt ? (const float *) A.wt->data : nullptr; p.kw = B->wt ? (const float *) B->wt->data : nullptr; p.pos = (const int32_t *) A.pos->data; p.ff = A.ff ? (const float *) A.ff->data : nullptr;
     p.eps = A.eps; p.rp = A.rp;
     p.kcache = Sk->data; p.kc_rs = Sk->nb[1]; p.vcache = Sv->data; p.vc_rs = 2; p.kidx = kidx->data; p.vidx = vidx->data; p.idx_is64 = kidx->type == GGML_TYPE_I64;
     attn_sm_args & a = s.pq.sma;
@@ -1153,6 +1170,110 @@ static bool try_defer_qkv_to_softmax_attention(exec_state & s, const nr_chain & 
     a.rope_tab = (const float *) s.c->rope_scratch;                                  // filled when the launch happens
     if (s.c->rope_scratch_bytes < (size_t) D * 4 || !attn_one_sm_ok(a)) return false;
     s.pq.fa = m1; s.pq.sm = true; s.pq.kst = B->store; s.pq.vst = vsj; s.pq.sm_soft = smi; s.pq.sm_mm2 = m2; s.pq.sm_cont = ci;
+    return true;
+}
+
+// ROPE at node i without a norm in front (llama architecture: the omni TTS decoder, src/llama-model.cpp llm_build_llama): the q chain is
+// ROPE alone, the k chain ROPE -> SET_ROWS, v a plain (or, flash-attention off, scattered) store.  Same three outcomes as the Qwen3 chains:
+// everything inside the one-token attention launch, or one norm_rope launch for both chains + the v store, or (no match) the plain op.
+static bool match_rope_only(exec_state & s, int j, nr_chain & c) {
+    ggml_cgraph * g = s.g;
+    ggml_tensor * r = g->nodes[j];
+    if (r->op != GGML_OP_ROPE || s.done[j]) return false;
+    const ggml_tensor * x = r->src[0], * pos = r->src[1], * ff = r->src[2];
+    const int64_t D = r->ne[0];
+    const int mode = op_param_i32(r, 2);
+    if (!x || x->type != GGML_TYPE_F32 || r->type != GGML_TYPE_F32 || x->nb[0] != 4 || r->nb[0] != 4 || D % 2 != 0 || D > 256 || r->ne[3] != 1 || !same_shape(x, r)) return false;
+    if (!((mode == GGML_ROPE_TYPE_NORMAL || mode == GGML_ROPE_TYPE_NEOX) && op_param_i32(r, 1) == D && pos && pos->type == GGML_TYPE_I32 && pos->nb[0] == 4 &&
+          (!ff || (ff->type == GGML_TYPE_F32 && ff->nb[0] == 4)))) return false;
+    c.norm = -1; c.mul = -1; c.rope = j; c.store = -1; c.wt = nullptr; c.pos = pos; c.ff = ff; c.xin = x; c.first = j;
+    c.D = (int) D; c.H = (int) r->ne[1]; c.T = (int) r->ne[2]; c.eps = 0.0f;
+    memset(&c.rp, 0, sizeof(c.rp));
+    c.rp.n_dims = op_param_i32(r, 1); c.rp.mode = mode; c.rp.n_ctx_orig = op_param_i32(r, 4);
+    c.rp.freq_base = op_param_f32(r, 5); c.rp.freq_scale = op_param_f32(r, 6); c.rp.ext_factor = op_param_f32(r, 7);
+    c.rp.attn_factor = op_param_f32(r, 8); c.rp.beta_fast = op_param_f32(r, 9); c.rp.beta_slow = op_param_f32(r, 10);
+    const int si = sole_user(s, r);
+    if (si > j && g->nodes[si]->op == GGML_OP_SET_ROWS && !s.done[si]) {
+        const ggml_tensor * S = g->nodes[si], * V = S->src[0], * idx = S->src[1];
+        if (V && idx && V->data == r->data && V->ne[0] == D * r->ne[1] && V->ne[1] == r->ne[2] && V->ne[2] == 1 && V->ne[3] == 1 &&
+            V->nb[1] == r->nb[2] && r->nb[1] == (size_t) D * 4 && S->type == GGML_TYPE_F16 && S->nb[0] == 2 &&
+            (idx->type == GGML_TYPE_I64 || idx->type == GGML_TYPE_I32) && idx->ne[0] == r->ne[2] && idx->ne[1] == 1 && idx->ne[2] == 1) c.store = si;
+    }
+    return true;
+}
+static bool try_defer_qkv_to_attention(exec_state & s, const nr_chain & A, const nr_chain * B, int vj, const int * item, int ni);
+static bool try_defer_qkv_to_softmax_attention(exec_state & s, const nr_chain & A, const nr_chain * B, int vsj, const int * item, int ni);
+static bool exec_rope_chain(exec_state & s, int i) {
+    static const bool off = getenv("MI355X_NO_ROPE_CHAIN") != nullptr;
+    ggml_cgraph * g = s.g;
+    nr_chain A;
+    if (off || !match_rope_only(s, i, A) || A.store >= 0) return false;             // (starts at the q chain: the first ROPE of a layer in llm_build_llama)
+    int item[8]; int ni = 0;
+    item[ni++] = A.rope;
+    nr_chain B; int bj = -1;
+    for (int j = i + 1; j < g->n_nodes && j < i + 24; ++j) {
+        if (s.done[j] || g->nodes[j]->op != GGML_OP_ROPE || !match_rope_only(s, j, B)) continue;
+        if (B.D != A.D || B.T != A.T || B.pos != A.pos || B.ff != A.ff || memcmp(&B.rp, &A.rp, sizeof(rope_params)) != 0 || B.store < 0) continue;
+        int it2[8]; int n2 = ni;
+        memcpy(it2, item, sizeof(int) * ni);
+        it2[n2++] = B.rope;
+        if (!can_hoist(s, i, B.rope, it2, n2)) break;
+        it2[n2++] = B.store;
+        if (!can_hoist(s, i, B.store, it2, n2)) break;
+        bj = j; memcpy(item, it2, sizeof(int) * n2); ni = n2;
+        break;
+    }
+    if (bj < 0) return false;
+    // v store: plain rows, or (flash-attention off, one token) the single-element scatter
+    int vj = -1; norm_rope_job vjob;
+    for (int j = i + 1; j < g->n_nodes && j < i + 32; ++j) {
+        ggml_tensor * S = g->nodes[j];
+        if (s.done[j] || S->op != GGML_OP_SET_ROWS) continue;
+        bool mine = false;
+        for (int q = 0; q < ni; ++q) mine |= item[q] == j;
+        if (mine) continue;
+        const ggml_tensor * V = S->src[0], * idx = S->src[1];
+        if (V && V->type == GGML_TYPE_F32 && S->type == GGML_TYPE_F16 && V->ne[0] == 1 && S->ne[0] == 1 && A.T == 1 && V->ne[1] == (int64_t) A.D * B.H) {
+            item[ni++] = j;
+            if (can_hoist(s, i, j, item, ni) && try_defer_qkv_to_softmax_attention(s, A, &B, j, item, ni)) {
+                for (int q = 1; q < ni; ++q) { s.done[item[q]] = 1; ++s.n_fused; }
+                ++s.n_fused;
+                return true;
+            }
+            --ni;
+            break;
+        }
+        if (!(V && idx && V->type == GGML_TYPE_F32 && S->type == GGML_TYPE_F16 && S->nb[0] == 2 && V->nb[0] == 4 && V->ne[0] % A.D == 0 &&
+              V->ne[1] == A.T && V->ne[2] == 1 && V->ne[3] == 1 && (idx->type == GGML_TYPE_I64 || idx->type == GGML_TYPE_I32) &&
+              idx->ne[0] == A.T && idx->ne[1] == 1 && idx->ne[2] == 1)) continue;
+        item[ni++] = j;
+        if (can_hoist(s, i, j, item, ni)) {
+            vj = j;
+            vjob = { (const float *) V->data, (int64_t) A.D * 4, (int64_t) V->nb[1], nullptr, nullptr, 0, 0,
+                     S->data, (int64_t) S->nb[1], idx->data, idx->type == GGML_TYPE_I64, (int64_t) idx->nb[0], (int) (V->ne[0] / A.D) };
+        } else --ni;
+        break;
+    }
+    if (try_defer_qkv_to_attention(s, A, &B, vj, item, ni)) {
+        for (int q = 1; q < ni; ++q) { s.done[item[q]] = 1; ++s.n_fused; }
+        ++s.n_fused;
+        return true;
+    }
+    norm_rope_args a;
+    a.njobs = 0; a.pos = (const int32_t *) A.pos->data; a.ff = A.ff ? (const float *) A.ff->data : nullptr;
+    a.D = A.D; a.T = A.T; a.eps = 0.0f; a.rp = A.rp;
+    a.j[a.njobs++] = chain_job(s, A);
+    a.j[a.njobs++] = chain_job(s, B);
+    if (vj >= 0) a.j[a.njobs++] = vjob;
+    {
+        prof_scope ps(s, "norm_rope", 0);
+        norm_rope_store(a, s.st);
+    }
+    ++s.n_kernels;
+    for (int q = 1; q < ni; ++q) { s.done[item[q]] = 1; ++s.n_fused; }
+    note_write(s, g->nodes[A.rope]);
+    note_write(s, g->nodes[B.store]);
+    if (vj >= 0) note_write(s, g->nodes[vj]);
     return true;
 }
 
@@ -1266,6 +1387,30 @@ static bool exec_rms_norm(exec_state & s, int i) {
                 note_write(s, g->nodes[A.store >= 0 ? A.store : A.rope]);
                 if (bj >= 0) note_write(s, g->nodes[B.store >= 0 ? B.store : B.rope]);
                 if (vj >= 0) note_write(s, g->nodes[vj]);
+                return true;
+            }
+        }
+    }
+    // every consumer a Q8_0 batch-1 mat-vec (mmv1q.hip: the TTS / Token2Wav decoders): the norm is computed inside their launches
+    if (s.c->opt_mv1 && n->ne[1] == 1 && n->ne[2] == 1 && n->ne[3] == 1 && rms_norm_mul_quant_ok(n->ne[0]) && wt->ne[0] == n->ne[0] && wt->ne[1] * wt->ne[2] * wt->ne[3] == 1 &&
+        n->src[0]->nb[0] == 4 && n_users(s, m) > 0 && !is_out(s, m) && ((uintptr_t) n->src[0]->data & 15) == 0 && ((uintptr_t) wt->data & 15) == 0) {
+        bool all_q80 = true; int last_user = mi_;
+        for (int u : s.users[m]) { const ggml_tensor * c = g->nodes[u]; all_q80 = all_q80 && c->src[1] == m && q80_mv1_node(s, c); if (u > last_user) last_user = u; }
+        if (all_q80) {
+            const ggml_tensor * xs = n->src[0];
+            const byte_range rx = range_of(xs);
+            for (int k = mi_ + 1; k < last_user && all_q80; ++k) {           // nothing that runs before the last consumer may write over the norm's input
+                const ggml_tensor * nk = g->nodes[k];
+                if (is_noop(nk) || s.done[k]) continue;
+                bool is_user = false;
+                for (int u : s.users[m]) is_user |= u == k;
+                if (!is_user && overlap(range_of(nk), rx)) all_q80 = false;
+            }
+            if (all_q80) {
+                if (s.pn.m) materialise_norm(s);
+                s.done[mi_] = 1; s.n_fused += 2;
+                s.pn.m = m; s.pn.x = xs; s.pn.wt = wt; s.pn.eps = eps; s.pn.left = n_users(s, m);
+                if (s.a_src == m->data) s.a_src = nullptr;
                 return true;
             }
         }
@@ -1488,6 +1633,7 @@ static void compute_node(exec_state & s, int i) {
             return;
         }
         case GGML_OP_ROPE: {
+            if (s.c->opt_fusion && exec_rope_chain(s, i)) return;
             rope_params rp;
             rp.n_dims = op_param_i32(n, 1); rp.mode = op_param_i32(n, 2); rp.n_ctx_orig = op_param_i32(n, 4);
             rp.freq_base = op_param_f32(n, 5); rp.freq_scale = op_param_f32(n, 6); rp.ext_factor = op_param_f32(n, 7);
@@ -1506,6 +1652,9 @@ static void compute_node(exec_state & s, int i) {
         case GGML_OP_CPY: case GGML_OP_CONT: case GGML_OP_DUP: {
             prof_scope ps(s, "cpy", 0);
             const ggml_tensor * src = n->src[0];
+            static const bool dbg_cpy = getenv("MI355X_DEBUG_CPY") != nullptr;
+            if (dbg_cpy) fprintf(stderr, "[mi355x] cpy node %s: %s [%lld, %lld, %lld, %lld] type %d nb [%zu, %zu, %zu] -> type %d\n", n->name, src->name, (long long) src->ne[0], (long long) src->ne[1],
+                                 (long long) src->ne[2], (long long) src->ne[3], (int) src->type, src->nb[1], src->nb[2], src->nb[3], (int) n->type);
             // CPY writes into src[1]'s storage, which `n` is a view of; n->data is the destination in all three ops
             if ((src->type == GGML_TYPE_F32) != (n->type == GGML_TYPE_F32) && (src->type == GGML_TYPE_I32 || n->type == GGML_TYPE_I32)) cast_f32_i32(td(src), src->type == GGML_TYPE_F32, td(n), s.st);
             else cpy_strided(td(src), src->type, td(n), n->type, s.st);

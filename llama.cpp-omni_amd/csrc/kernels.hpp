@@ -71,8 +71,10 @@ struct mv1_args {
     const float * x = nullptr; const float * norm_w = nullptr; float eps = 0.0f; const void * img = nullptr;
     int64_t K = 0;
 };
-bool mmv1_ok(const mv1_args & a);
+bool mmv1_ok(const mv1_args & a);                 // Q4_K / Q6_K (mmv1.hip) or Q8_0 (mmv1q.hip: K % 32 == 0, K <= 4096; img = Q8_0 image)
 void mmv1(const mv1_args & a, hipStream_t st);
+bool mmv1q_ok(const mv1_args & a);
+void mmv1q(const mv1_args & a, hipStream_t st);
 
 // ---- K-quant weights against 2 .. 32 activation columns on the int8 matrix cores (mmq.hip): up to 3 matrices (Q4_K / Q6_K mixed)
 // sharing one set of Q8_K activation images; dst[col*dst_cs + row], optional residual add epilogue
@@ -193,11 +195,12 @@ void   flash_attn_ext_f16(const fattn_args & a, hipStream_t st);
 // up to three such jobs share a launch (q chain, k chain + store, plain f32 -> f16 v store: w == null)
 struct norm_rope_job {
     const float * x; int64_t xnb1, xnb2;     // head / token byte strides
-    const float * w;                         // norm weight [D]; null = plain store job
+    const float * w;                         // norm weight [D]; null = plain store job, or (rope_only) a ROPE chain without norm
     float * y; int64_t ynb1, ynb2;           // rope output (null when only the store is consumed)
     void * kv; int64_t kv_rs;                // f16 table base and row stride (null when there is no store)
     const void * idx; int idx_is64; int64_t idx_nb0;
     int H;
+    int rope_only = 0;                       // w == null and the job still rotates (llama-architecture q / k chains)
 };
 struct norm_rope_args {
     norm_rope_job j[3]; int njobs;

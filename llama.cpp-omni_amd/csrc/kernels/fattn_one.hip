@@ -55,6 +55,7 @@ struct fa1_dev {
     int q_hs, k_hs, v_hs, kc_rs, vc_rs, knb1, knb2, vnb1, vnb2, mnb2, mne2, dnb1;
     int nkv, gq, neox, n_head_log2;
     int vidx_st, vidx_n;                                                     // soft-max path: bytes per v scatter index, number of indices
+    int has_norm;                                                            // q / k chains start with RMS_NORM * w (Qwen3) or are ROPE only (llama architecture)
     float eps, scale, max_bias, logit_softcap, m0, m1;
 };
 
@@ -86,7 +87,7 @@ __global__ void __launch_bounds__(256) k_fattn_one(const fa1_dev a) {
     const bool act = lane < HALF;
     const int  e0 = a.neox ? lane : 2 * lane, e1 = a.neox ? lane + HALF : 2 * lane + 1;
     const __amdgpu_buffer_rsrc_t xrs = fa1_rsrc(wave == 0 ? a.qraw + h * a.q_hs : (wave == 1 ? a.kraw + ikv * a.k_hs : a.vraw + ikv * a.v_hs), wave < 3 ? D * 4 : 0);
-    const __amdgpu_buffer_rsrc_t wrs = fa1_rsrc(wave == 0 ? a.qw : a.kw, wave < 2 ? D * 4 : 0);
+    const __amdgpu_buffer_rsrc_t wrs = fa1_rsrc(wave == 0 ? a.qw : a.kw, (wave < 2 && a.has_norm) ? D * 4 : 0);
     const __amdgpu_buffer_rsrc_t trs = fa1_rsrc(a.tab, wave < 2 ? D * 4 : 0);
     // waves 0 / 1: rotation pair `lane` of the q / k head (elements e0, e1); wave 2: elements lane, lane + 64 of the v head
     const uint32_t xo0 = wave < 2 ? (act ? e0 * 4 : D * 4) : lane * 4, xo1 = wave < 2 ? (act ? e1 * 4 : D * 4) : (lane + 64) * 4;
@@ -126,7 +127,7 @@ __global__ void __launch_bounds__(256) k_fattn_one(const fa1_dev a) {
         ss = wave_sum_f64o(ss);
         const float mean  = (float) (ss * (1.0 / D));                                // D is a power of two: the same double as ss / D
         const float scale = 1.0f / sqrtf(mean + a.eps);
-        const float v0 = (x0 * scale) * w0, v1 = (x1 * scale) * w1;
+        const float v0 = a.has_norm ? (x0 * scale) * w0 : x0, v1 = a.has_norm ? (x1 * scale) * w1 : x1;      // (llama-architecture chains: ROPE only)
         const float r0 = v0 * tc - v1 * ts, r1 = v0 * ts + v1 * tc;
         if (act) {
             const uint16_t h0 = f2h(r0), h1 = f2h(r1);
@@ -285,7 +286,7 @@ __global__ void __launch_bounds__(256) k_attn_one_sm(const fa1_dev a) {
     const bool act = lane < HALF;
     const int  e0 = a.neox ? lane : 2 * lane, e1 = a.neox ? lane + HALF : 2 * lane + 1;
     const __amdgpu_buffer_rsrc_t xrs = fa1_rsrc(wave == 0 ? a.qraw + h * a.q_hs : (wave == 1 ? a.kraw + ikv * a.k_hs : a.vraw + ikv * a.v_hs), wave < 3 ? D * 4 : 0);
-    const __amdgpu_buffer_rsrc_t wrs = fa1_rsrc(wave == 0 ? a.qw : a.kw, wave < 2 ? D * 4 : 0);
+    const __amdgpu_buffer_rsrc_t wrs = fa1_rsrc(wave == 0 ? a.qw : a.kw, (wave < 2 && a.has_norm) ? D * 4 : 0);
     const __amdgpu_buffer_rsrc_t trs = fa1_rsrc(a.tab, wave < 2 ? D * 4 : 0);
     const uint32_t xo0 = wave < 2 ? (act ? e0 * 4 : D * 4) : lane * 4, xo1 = wave < 2 ? (act ? e1 * 4 : D * 4) : (lane + 64) * 4;
     const float x0 = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(xrs, xo0, 0, 0)), x1 = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(xrs, xo1, 0, 0));
@@ -325,7 +326,7 @@ __global__ void __launch_bounds__(256) k_attn_one_sm(const fa1_dev a) {
         ss = wave_sum_f64o(ss);
         const float mean  = (float) (ss * (1.0 / D));
         const float scale = 1.0f / sqrtf(mean + a.eps);
-        const float v0 = (x0 * scale) * w0, v1 = (x1 * scale) * w1;
+        const float v0 = a.has_norm ? (x0 * scale) * w0 : x0, v1 = a.has_norm ? (x1 * scale) * w1 : x1;      // (llama-architecture chains: ROPE only)
         const float r0 = v0 * tc - v1 * ts, r1 = v0 * ts + v1 * tc;
         if (act) {
             const uint16_t h0 = f2h(r0), h1 = f2h(r1);
@@ -470,6 +471,7 @@ void flash_attn_one(const fa_dev & f, int D, const float * rope_tab, hipStream_t
     a.q_hs = (int) P.q_hs; a.k_hs = (int) P.k_hs; a.v_hs = (int) P.v_hs; a.kc_rs = (int) P.kc_rs; a.vc_rs = (int) P.vc_rs;
     a.knb1 = (int) f.knb1; a.knb2 = (int) f.knb2; a.vnb1 = (int) f.vnb1; a.vnb2 = (int) f.vnb2; a.mnb2 = (int) f.mnb2; a.mne2 = (int) f.mne2; a.dnb1 = (int) f.dnb1;
     a.nkv = f.nkv; a.gq = f.gq; a.neox = (P.rd.mode & GGML_ROPE_TYPE_NEOX) ? 1 : 0; a.n_head_log2 = (int) f.n_head_log2;
+    a.has_norm = P.qw != nullptr; a.vidx_st = 0; a.vidx_n = 0;
     a.eps = P.eps; a.scale = f.scale; a.max_bias = f.max_bias; a.logit_softcap = f.logit_softcap; a.m0 = f.m0; a.m1 = f.m1;
     const dim3 grid((unsigned) f.nh);
     if (D == 64) k_fattn_one<64><<<grid, dim3(256), 0, st>>>(a);
@@ -498,7 +500,7 @@ void attn_one_sm(const attn_sm_args & f, hipStream_t st) {
     a.q_hs = (int) P.q_hs; a.k_hs = (int) P.k_hs; a.v_hs = (int) P.v_hs; a.kc_rs = (int) P.kc_rs; a.vc_rs = 2;
     a.knb1 = (int) f.knb1; a.knb2 = (int) f.knb2; a.vnb1 = (int) f.vnb1; a.vnb2 = (int) f.vnb2; a.mnb2 = (int) f.mnb2; a.mne2 = (int) (f.mne2 > 0 ? f.mne2 : 1); a.dnb1 = (int) f.dnb1;
     a.nkv = f.nkv; a.gq = f.n_head / f.n_head_kv; a.neox = (P.rp.mode & GGML_ROPE_TYPE_NEOX) ? 1 : 0; a.n_head_log2 = 0;
-    a.vidx_st = P.idx_is64 ? 8 : 4; a.vidx_n = (int) f.vidx_n;
+    a.vidx_st = P.idx_is64 ? 8 : 4; a.vidx_n = (int) f.vidx_n; a.has_norm = P.qw != nullptr;
     a.eps = P.eps; a.scale = f.scale; a.max_bias = 0.0f; a.logit_softcap = 0.0f; a.m0 = 1.0f; a.m1 = 1.0f;
     const dim3 grid((unsigned) f.n_head);
     if (f.D == 64) k_attn_one_sm<64><<<grid, dim3(256), 0, st>>>(a);

@@ -13,7 +13,8 @@ namespace mi {
 
 struct nr_job {
     const char * x; int64_t xnb1, xnb2;               // [D, H, T] f32 input (head / token byte strides)
-    const float * w;                                  // [D] norm weight; null = no norm / rope (plain store job)
+    const float * w;                                  // [D] norm weight; null = no norm
+    int plain;                                        // plain f32 -> f16 store job (no norm, no rope)
     char * y; int64_t ynb1, ynb2;                     // f32 rope output (may be null)
     char * kv; int64_t kv_rs;                         // f16 table base + row stride (may be null)
     const char * idx; int idx_is64; int64_t idx_nb0;  // row index per token
@@ -51,7 +52,7 @@ __global__ void __launch_bounds__(256) k_norm_rope(const nr_dev a) {
     int64_t row = 0;
     if (J.kv) row = J.idx_is64 ? *(const int64_t *) (J.idx + t * J.idx_nb0) : (int64_t) *(const int32_t *) (J.idx + t * J.idx_nb0);
 
-    if (!J.w) {                                       // plain store job: f32 -> f16 rows (k_set_rows' arithmetic)
+    if (J.plain) {                                    // plain store job: f32 -> f16 rows (k_set_rows' arithmetic)
         uint16_t * kr = (uint16_t *) (J.kv + row * J.kv_rs) + (int64_t) h * a.D;
         for (int e = lane; e < a.D; e += 64) kr[e] = f2h(*(const float *) (xr + e * 4));
         return;
@@ -92,7 +93,7 @@ void norm_rope_store(const norm_rope_args & f, hipStream_t st) {
     for (int i = 0; i < 3; ++i) {
         const norm_rope_job & s = f.j[i < f.njobs ? i : 0];
         nr_job & d = a.j[i];
-        d.x = (const char *) s.x; d.xnb1 = s.xnb1; d.xnb2 = s.xnb2; d.w = s.w;
+        d.x = (const char *) s.x; d.xnb1 = s.xnb1; d.xnb2 = s.xnb2; d.w = s.w; d.plain = (!s.w && !s.rope_only) ? 1 : 0;
         d.y = (char *) s.y; d.ynb1 = s.ynb1; d.ynb2 = s.ynb2;
         d.kv = (char *) s.kv; d.kv_rs = s.kv_rs; d.idx = (const char *) s.idx; d.idx_is64 = s.idx_is64; d.idx_nb0 = s.idx_nb0;
         d.H = s.H;

@@ -42,7 +42,8 @@ static __device__ __forceinline__ void rope_angle(float pos, int ip, const float
 
 // one wave, one head of D elements at xr (f32, contiguous): lane l owns rotation pairs l + 64*p, p < PPL.
 // out: rotated values r0/r1 at element indices e0/e1 (valid where act[p]).  tab != null: (cos, sin) pairs of this token, [D/2] float2,
-// produced by rope_angle (the per-graph table of a prefill ubatch: every layer and head re-uses the same angles)
+// produced by rope_angle (the per-graph table of a prefill ubatch: every layer and head re-uses the same angles).
+// w == null: no norm (the llama-architecture chains -- the TTS decoder -- are ROPE only): the raw values are rotated
 template <int PPL>
 static __device__ __forceinline__ void norm_rope_wave(const char * xr, const float * w, int D, float eps, float pos, const float * ff, const rope_dev rd,
                                                       int lane, float (&r0)[PPL], float (&r1)[PPL], int (&e0)[PPL], int (&e1)[PPL], bool (&act)[PPL],
@@ -59,7 +60,7 @@ static __device__ __forceinline__ void norm_rope_wave(const char * xr, const flo
         e1[p] = neox ? ip + half : 2 * ip + 1;
         if (act[p]) {
             x0[p] = *(const float *) (xr + e0[p] * 4); x1[p] = *(const float *) (xr + e1[p] * 4);
-            w0v[p] = w[e0[p]]; w1v[p] = w[e1[p]];
+            w0v[p] = w ? w[e0[p]] : 1.0f; w1v[p] = w ? w[e1[p]] : 1.0f;
             ss += (double) (x0[p] * x0[p]); ss += (double) (x1[p] * x1[p]);
         } else { x0[p] = x1[p] = w0v[p] = w1v[p] = 0.0f; }
     }
@@ -71,7 +72,7 @@ static __device__ __forceinline__ void norm_rope_wave(const char * xr, const flo
         r0[q] = r1[q] = 0.0f;
         if (!act[q]) continue;
         const int ip = lane + 64 * q;
-        const float v0 = (x0[q] * scale) * w0v[q], v1 = (x1[q] * scale) * w1v[q];
+        const float v0 = w ? (x0[q] * scale) * w0v[q] : x0[q], v1 = w ? (x1[q] * scale) * w1v[q] : x1[q];
         float c, s;
         if (tab) { c = tab[2 * ip]; s = tab[2 * ip + 1]; }
         else     rope_angle(pos, ip, ff, rd, c, s);
