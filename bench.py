@@ -300,6 +300,35 @@ def c3_prefill(pkg, be, n_seq=8, n_prompt=2048, n_ubatch=512, tiny=False):
             "frac_of_dense_f16_peak": round(flops / dt / 1e12 / MFMA_F16_PEAK_TFLOPS, 4), "n_seq": n_seq, "n_prompt": n_prompt, "n_ubatch": n_ubatch}
 
 
+def extra_legs(pkg, be, headline_no_fa):
+    """Measured beside the headline (same timing loop, 64 steps each; not part of `value`): the decode step with flash-attention OFF --
+    llama-bench's default, libllama's transposed-V-cache graph -- and the omni TTS decoder at its real shape (Q8_0,
+    llama architecture: 8(f) rank 2), both through the same C-ABI."""
+    from llama_cpp_omni_amd import qwen3
+    res = {}
+    try:
+        legs = [("tts_q8_0_decode", qwen3.TTS, qwen3.uniform_types(qwen3.TTS, pkg.GGML_TYPE_Q8_0), True)]
+        if not headline_no_fa:
+            legs.insert(0, ("qwen3_8b_q4_k_m_decode_no_fa", qwen3.QWEN3_8B, qwen3.q4_k_m_types(qwen3.QWEN3_8B), False))
+        for name, cfg, types, fa in legs:
+            dec = Decoder(pkg, be, cfg, types, n_ctx=256, n_kv=256, flash_attn=fa, seed=4321)
+            for p in range(8):
+                dec.step(p)
+            be.synchronize()
+            t0 = time.perf_counter()
+            for p in range(8, 72):
+                dec.step(p)
+            be.synchronize()
+            dt = time.perf_counter() - t0
+            ok = bool(np.isfinite(dec.h_logits).all())
+            res[name] = {"tok_s": round(64 / dt, 1) if ok else None, "ms_per_step": round(dt / 64 * 1e3, 4), "kernels_per_token": be.get_stat("kernels_last_graph"),
+                         "n_layer": cfg["n_layer"], "n_embd": cfg["n_embd"]}
+            dec.g.free(); dec.model.wctx.free()
+    except Exception as e:  # extras never cost the headline
+        res["error"] = repr(e)
+    return res
+
+
 class Replicas:
     """N > 1: one process per GPU (torch.distributed.run), each a whole-model replica; no data-path collective (decode of one sequence does
     not shard).  The only communication is the contract's: barrier + synchronize on both sides of the timed region and the
@@ -434,6 +463,8 @@ def main():
                 out["c3_f16_prefill"] = {"ub512": c3_prefill(pkg, be, n_ubatch=512, tiny=args.tiny), "ub2048": c3_prefill(pkg, be, n_ubatch=2048, tiny=args.tiny)}
             except Exception as e:
                 out["c3_f16_prefill"] = {"error": repr(e)}
+        if world == 1 and not args.tiny and not os.environ.get("MI355X_BENCH_NO_EXTRAS"):
+            out["extras"] = extra_legs(pkg, be, args.no_fa)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(pkg, cfg, types, n_kv)
         else:

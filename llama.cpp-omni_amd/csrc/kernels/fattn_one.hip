@@ -312,12 +312,13 @@ __global__ void __launch_bounds__(256) k_attn_one_sm(const fa1_dev a) {
 #pragma unroll
         for (int c = 0; c < KCH; ++c) kk[i][c] = __builtin_amdgcn_raw_buffer_load_b128(krs, kvo + 16u * c, so, 0);
     }
-    // V^T: lane (dl, part): output dim wave * DPW + dl, cells [part * CPL, part * CPL + CPL) -- contiguous along the cells
+    // V^T: lane (dl, part): output dim wave * DPW + dl, cells 8 (LPD j + part) .. + 7 for j < NV: the LPD lanes of a dim read adjacent 16-byte
+    // pieces, so an instruction takes LPD x 16 contiguous bytes per dim row and four consecutive instructions use up each 128-byte line
     const int dl = lane / LPD, part = lane % LPD, dmine = wave * DPW + dl;
     const __amdgpu_buffer_rsrc_t vrs = fa1_rsrc(a.v + ikv * a.vnb2, (D - 1) * a.vnb1 + nkv * 2);
     u32x4 vv[NV];
 #pragma unroll
-    for (int j = 0; j < NV; ++j) vv[j] = __builtin_amdgcn_raw_buffer_load_b128(vrs, (uint32_t) dmine * (uint32_t) a.vnb1 + (uint32_t) (part * CPL + 8 * j) * 2u, 0, 0);
+    for (int j = 0; j < NV; ++j) vv[j] = __builtin_amdgcn_raw_buffer_load_b128(vrs, (uint32_t) dmine * (uint32_t) a.vnb1 + (uint32_t) (LPD * j + part) * 16u, 0, 0);
 
     // ---------------------------------------------------------------- 2. q chain, k chain + store, v scatter
     if (wave < 2) {
@@ -425,7 +426,7 @@ __global__ void __launch_bounds__(256) k_attn_one_sm(const fa1_dev a) {
     float acc = 0.0f;
 #pragma unroll
     for (int j = 0; j < NV; ++j) {
-        const int c0 = part * CPL + 8 * j;
+        const int c0 = (LPD * j + part) * 8;
         if (c0 >= n_live) continue;                                      // (everything past the last visible cell has p == 0)
         const f32x4 pa = *(const f32x4 *) (&pl[wave][c0]), pb = *(const f32x4 *) (&pl[wave][c0 + 4]);
 #pragma unroll

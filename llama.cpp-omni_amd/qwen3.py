@@ -15,6 +15,8 @@ from .ggml import (GGML_BACKEND_BUFFER_USAGE_WEIGHTS, GGML_ROPE_TYPE_NEOX, GGML_
 
 QWEN3_8B = dict(n_embd=4096, n_layer=36, n_head=32, n_head_kv=8, head_dim=128, n_ff=12288, n_vocab=151936,
                 rms_eps=1e-6, rope_base=1e6, n_ctx_orig=40960)
+TTS = dict(arch="llama", n_embd=768, n_layer=20, n_head=12, n_head_kv=12, head_dim=64, n_ff=3072, n_vocab=32000,
+           rms_eps=1e-5, rope_base=1e4, n_ctx_orig=4096)           # the omni TTS decoder (reference tools/omni/convert/tts.txt; tools/make_synth_gguf.py --config tts)
 TINY = dict(n_embd=256, n_layer=2, n_head=4, n_head_kv=2, head_dim=64, n_ff=512, n_vocab=512,
             rms_eps=1e-6, rope_base=1e6, n_ctx_orig=4096)
 
@@ -192,7 +194,8 @@ class Model:
         if n_outputs is not None and n_outputs != n_tokens:
             I["out_ids"] = g.new_tensor(GGML_TYPE_I32, n_outputs)
         kq_scale = 1.0 / math.sqrt(D)
-        rope = dict(n_dims=D, mode=GGML_ROPE_TYPE_NEOX, n_ctx_orig=c["n_ctx_orig"], freq_base=c["rope_base"], freq_scale=1.0,
+        llama_arch = c.get("arch") == "llama"                          # llm_build_llama (the omni TTS decoder): no q / k norm, RoPE NORM
+        rope = dict(n_dims=D, mode=0 if llama_arch else GGML_ROPE_TYPE_NEOX, n_ctx_orig=c["n_ctx_orig"], freq_base=c["rope_base"], freq_scale=1.0,
                     ext_factor=0.0, attn_factor=1.0, beta_fast=32.0, beta_slow=1.0)
         f16 = 2
         inpL = I["inp_embd"]
@@ -206,9 +209,11 @@ class Model:
             Q = g.reshape(Q, D, H, n_tokens)
             K = g.reshape(K, D, HK, n_tokens)
             V = g.reshape(V, D, HK, n_tokens)
-            Q = g.mul(g.rms_norm(Q, c["rms_eps"]), self._w(g, L["attn_q_norm"]))
+            if not llama_arch:
+                Q = g.mul(g.rms_norm(Q, c["rms_eps"]), self._w(g, L["attn_q_norm"]))
             Q = g.rope_ext(Q, I["inp_pos"], None, **rope)
-            K = g.mul(g.rms_norm(K, c["rms_eps"]), self._w(g, L["attn_k_norm"]))
+            if not llama_arch:
+                K = g.mul(g.rms_norm(K, c["rms_eps"]), self._w(g, L["attn_k_norm"]))
             K = g.rope_ext(K, I["inp_pos"], None, **rope)
             # store into the cache (llama_kv_cache::cpy_k / cpy_v, FA layout)
             kc, vc = self._w(g, L["k_cache"]), self._w(g, L["v_cache"])
