@@ -5,6 +5,7 @@
 // rows must be bit-identical.
 //   build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off tools/mega_lab.hip -o build/mega_lab      run: build/mega_lab [n_layer]
 #include "../llama.cpp-omni_amd/csrc/kernels/mmv1.hip"
+#include "../llama.cpp-omni_amd/csrc/kernels/mmv1q.hip"
 #include <vector>
 #include <cmath>
 #include <cstring>

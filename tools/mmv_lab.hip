@@ -5,6 +5,7 @@
 #include "../llama.cpp-omni_amd/csrc/kernels/quantize.hip"
 #include "../llama.cpp-omni_amd/csrc/kernels/mmvk.hip"
 #include "../llama.cpp-omni_amd/csrc/kernels/mmv1.hip"
+#include "../llama.cpp-omni_amd/csrc/kernels/mmv1q.hip"
 #include <vector>
 #include <string>
 #include <functional>
@@ -177,7 +178,19 @@ int main(int argc, char ** argv) {
         } while (0)
 
         const bool big = ntot > 20000;
-#if defined(LAB_DEPTH)     // prefetch depth with the default cache policy
+#if defined(LAB_FEW)       // fewer resident waves, deeper register prefetch (one workgroup per CU keeps 256 VGPRs per lane)
+        VAR(8, 2, 1, 0, 4096);
+        VAR(8, 2, 2, 0, 2048);
+        VAR(8, 2, 3, 0, 2048);
+        VAR(8, 2, 4, 0, 2048);
+        VAR(8, 2, 5, 0, 2048);
+        VAR(16, 1, 1, 0, 4096);
+        VAR(16, 1, 2, 0, 2048);
+        VAR(16, 1, 4, 0, 2048);
+        VAR(16, 1, 6, 0, 2048);
+        VAR(8, 1, 4, 0, 2048);
+        VAR(8, 1, 6, 0, 1024);
+#elif defined(LAB_DEPTH)     // prefetch depth with the default cache policy
         VAR(8, 2, 1, 0, 4096);
         VAR(8, 2, 2, 0, 4096);
         VAR(8, 2, 3, 0, 4096);
