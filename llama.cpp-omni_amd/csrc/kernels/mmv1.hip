@@ -259,6 +259,8 @@ static __device__ __forceinline__ void mv1_q4k(const char * __restrict__ W0, con
 #define MV1_KO 0
 #endif
     if (!(MV1_KO & 1)) pro.issue();                     // the activation row is requested before the first weight stage
+    if (MV1_KO & 16) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // measurement: the row has ARRIVED before the first weight request
+    if (MV1_KO & 32) __builtin_amdgcn_s_barrier();                         // measurement: every wave's row request is out before the first weight request
     int ig = g0, iit = 0;
 #pragma unroll
     for (int d = 0; d < DEPTH; ++d)
