@@ -585,7 +585,7 @@ static bool kq_mm_ok(const ggml_tensor * n) {
 static bool q80_mv1_node(exec_state & s, const ggml_tensor * n) {
     if (!s.c->opt_mv1 || n->op != GGML_OP_MUL_MAT || is_empty(n)) return false;
     const ggml_tensor * w = n->src[0], * x = n->src[1];
-    if (w->type != GGML_TYPE_Q8_0 || x->type != GGML_TYPE_F32 || w->ne[2] != 1 || w->ne[3] != 1 || x->ne[1] != 1 || x->ne[2] != 1 || x->ne[3] != 1 || n->nb[0] != 4 || x->nb[0] != 4) return false;
+    if ((w->type != GGML_TYPE_Q8_0 && w->type != GGML_TYPE_F16) || x->type != GGML_TYPE_F32 || w->ne[2] != 1 || w->ne[3] != 1 || x->ne[1] != 1 || x->ne[2] != 1 || x->ne[3] != 1 || n->nb[0] != 4 || x->nb[0] != 4) return false;
     mv1_args v; v.nmat = 1; v.K = w->ne[0];
     v.m[0] = { w->data, w->nb[1], (float *) n->data, 0, nullptr, 0, w->ne[1], (int) w->type };
     v.img = (const void *) 16;
@@ -613,7 +613,7 @@ static void mv1_source(exec_state & s, const ggml_tensor * x, const ggml_tensor 
         return;
     }
     const int64_t K = x->ne[0];
-    const act_kind kind = v.m[0].type == GGML_TYPE_Q8_0 ? ACT_Q80 : ACT_Q8K;       // (v.m[] is filled before the source is chosen)
+    const act_kind kind = v.m[0].type == GGML_TYPE_Q8_0 ? ACT_Q80 : (v.m[0].type == GGML_TYPE_F16 ? ACT_F16 : ACT_Q8K);       // (v.m[] is filled before the source is chosen)
     const bool cached = s.a_src == x->data && s.a_kind == kind && s.a_K == K && s.a_ne[0] == 1 && s.a_ne[1] == x->ne[2] && s.a_ne[2] == x->ne[3];
     bool plain = !cached && !(s.pn.m && x == s.pn.m) && ((uintptr_t) x->data & 15) == 0;
     if (plain) {
@@ -842,7 +842,7 @@ static void exec_mul_mat(exec_state & s, int i) {
                         v.m[0] = { gate_n->src[0]->data, gate_n->src[0]->nb[1], (float *) G->data, 0, nullptr, 0, gate_n->src[0]->ne[1], (int) gate_n->src[0]->type };
                         v.W_up = up_n->src[0]->data;
                         mv1_source(s, x, outs, 1, 2, v);
-                        prof_scope ps(s, q80 ? "mmv_q80" : (n->src[0]->type == GGML_TYPE_Q4_K ? "mmv_q4k" : "mmv_q6k"), 2.0 * (double) n->src[0]->ne[1] * (double) row_size(n->src[0]->type, K));
+                        prof_scope ps(s, q80 ? (n->src[0]->type == GGML_TYPE_F16 ? "mmv_f16" : "mmv_q80") : (n->src[0]->type == GGML_TYPE_Q4_K ? "mmv_q4k" : "mmv_q6k"), 2.0 * (double) n->src[0]->ne[1] * (double) row_size(n->src[0]->type, K));
                         mmv1(v, s.st);
                         ++s.n_kernels; s.n_fused += 2;
                         s.done[oi] = s.done[gi] = 1;
@@ -868,7 +868,7 @@ static void exec_mul_mat(exec_state & s, int i) {
     int   mm_idx[3] = { i, -1, -1 }; int nm = 1;
     for (int j = i + 1; j < g->n_nodes && j < i + 32 && nm < 3; ++j) {
         ggml_tensor * c = g->nodes[j];
-        if (s.done[j] || !(q80 ? q80_mv1_node(s, c) : kq_mm_ok(c)) || !same_act(c->src[1], x)) continue;
+        if (s.done[j] || !(q80 ? (q80_mv1_node(s, c) && c->src[0]->type == n->src[0]->type) : kq_mm_ok(c)) || !same_act(c->src[1], x)) continue;
         // do not steal one half of a gate/up pair (that fusion is worth more; it exists for the mat-vec widths only)
         const int cu = sole_user(s, c);
         if (!use_mmq && cu > 0 && g->nodes[cu]->op == GGML_OP_GLU) continue;
@@ -911,7 +911,7 @@ static void exec_mul_mat(exec_state & s, int i) {
         for (int q = 0; q < nm; ++q) v.m[q] = a.m[q];
         mv1_source(s, x, outs, nm, nm, v);
         {
-            prof_scope ps(s, q80 ? "mmv_q80" : (bytes_q4 >= bytes_q6 ? "mmv_q4k" : "mmv_q6k"), bytes_q4 + bytes_q6);
+            prof_scope ps(s, q80 ? (n->src[0]->type == GGML_TYPE_F16 ? "mmv_f16" : "mmv_q80") : (bytes_q4 >= bytes_q6 ? "mmv_q4k" : "mmv_q6k"), bytes_q4 + bytes_q6);
             mmv1(v, s.st);
         }
         ++s.n_kernels;

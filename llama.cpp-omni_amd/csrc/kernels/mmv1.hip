@@ -498,7 +498,7 @@ namespace mi {
 static const int MV1_WAVES = 4096;
 
 bool mmv1_ok(const mv1_args & a) {
-    if (a.nmat >= 1 && a.m[0].type == GGML_TYPE_Q8_0) return mmv1q_ok(a);          // the Q8_0 twin (mmv1q.hip)
+    if (a.nmat >= 1 && (a.m[0].type == GGML_TYPE_Q8_0 || a.m[0].type == GGML_TYPE_F16)) return mmv1q_ok(a);          // the Q8_0 / F16 twins (mmv1q.hip)
     if (a.nmat < 1 || a.nmat > 3 || a.K <= 0 || a.K % 4096 != 0 || a.K > 12288) return false;
     if (a.W_up && a.nmat != 1) return false;
     for (int i = 0; i < a.nmat; ++i) {
@@ -524,7 +524,7 @@ static void mv1_go(const mv1_dev & d, int tm, int grid, hipStream_t st) {
 }
 
 void mmv1(const mv1_args & a, hipStream_t st) {
-    if (a.nmat >= 1 && a.m[0].type == GGML_TYPE_Q8_0) { mmv1q(a, st); return; }
+    if (a.nmat >= 1 && (a.m[0].type == GGML_TYPE_Q8_0 || a.m[0].type == GGML_TYPE_F16)) { mmv1q(a, st); return; }
     if (!mmv1_ok(a)) { fprintf(stderr, "[mi355x] mmv1: unsupported arguments (K=%lld)\n", (long long) a.K); abort(); }
     const bool pair = a.W_up != nullptr;
     const int nw_wg = pair ? 8 : 16;
