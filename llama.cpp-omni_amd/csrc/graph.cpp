@@ -1714,6 +1714,11 @@ static void compute_node(exec_state & s, int i) {
             }
             if (fattn_scratch_bytes(f) > 0 && !fattn_uses_mma(f)) {       // decode kernel at long context: workspace of its KV split
                 f.scratch = s.c->fa_scratch; f.scratch_bytes = s.c->fa_scratch_bytes;
+                if (!s.c->fa_counters && !s.capturing) {                  // (first use is always an eager submission: captures come from the second on)
+                    if (hipMalloc((void **) &s.c->fa_counters, 1024 * sizeof(unsigned)) == hipSuccess) HIP_CHECK(hipMemsetAsync(s.c->fa_counters, 0, 1024 * sizeof(unsigned), s.st));
+                    else { (void) hipGetLastError(); s.c->fa_counters = nullptr; }
+                }
+                f.counters = s.c->fa_counters;
                 s.fa_mask = nullptr;                                      // (the scratch no longer holds a mask tile map)
                 ++s.n_kernels;
             } else if (fattn_scratch_bytes(f) > 0) {
@@ -1986,6 +1991,7 @@ void backend_ctx_release(backend_ctx * c) {
     if (c->act_scratch) (void) hipFree(c->act_scratch);
     if (c->w_scratch) (void) hipFree(c->w_scratch);
     if (c->fa_scratch) (void) hipFree(c->fa_scratch);
+    if (c->fa_counters) (void) hipFree(c->fa_counters);
     if (c->rope_scratch) (void) hipFree(c->rope_scratch);
     if (c->gemm_partial) (void) hipFree(c->gemm_partial);
     if (c->copy_event) (void) hipEventDestroy(c->copy_event);

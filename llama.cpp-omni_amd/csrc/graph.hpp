@@ -33,6 +33,7 @@ struct backend_ctx {
     void *  w_scratch = nullptr;    size_t w_scratch_bytes = 0;
     // mask tile map of the prefill flash-attention kernel
     void *  fa_scratch = nullptr;   size_t fa_scratch_bytes = 0;
+    unsigned * fa_counters = nullptr;   // [1024] arrival counters of the sliced one-token attention (zero between launches: the last arriver resets its own)
     // (cos, sin) table of a prefill ubatch's rotary positions (fused.hip k_rope_table)
     void *  rope_scratch = nullptr; size_t rope_scratch_bytes = 0;
     // split-K partial sums of the prefill GEMM

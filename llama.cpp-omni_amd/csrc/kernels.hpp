@@ -159,6 +159,7 @@ struct fattn_args {
     const float * sinks;     // may be null
     float scale, max_bias, logit_softcap;
     void * scratch;          // mask tile map of the prefill kernel (fattn_scratch_bytes(); unused by the decode kernel)
+    unsigned * counters = nullptr;   // >= n_head zeroed arrival counters: the sliced one-token kernel merges its slices itself (else: k_fattn_merge)
     size_t scratch_bytes;
     bool   map_valid = false; // scratch already holds the tile map of THIS mask (same tensor used by an earlier node of the graph)
     void * img = nullptr;    // optional: also emit Q8_K images of the output rows [nh*D] (one per (seq, query row))
@@ -181,6 +182,7 @@ struct attn_sm_args {
 bool   attn_one_sm_ok(const attn_sm_args & a);
 void   attn_one_sm(const attn_sm_args & a, hipStream_t st);
 void   fattn_set_one(bool on);             // one-token kernel on (default) / off: the round-1 decode kernels take the shape (cross-check)
+int    fattn_one_nsplit(const fattn_args & a);   // 256-row KV slices of the one-token kernel (> 1: partial rows + k_fattn_merge, needs the scratch)
 bool   fattn_one_ok(const fattn_args & a);       // one token, one sequence, pre-stage, <= 256 cache rows: the latency-optimised kernel (fattn_one.hip) runs
 // (cos, sin) * mscale of every (token, rotation pair): tab[T][D/2][2], what ggml_rope_cache_init / rope_yarn give for these positions
 void   rope_table(const int32_t * pos, const float * ff, const rope_params & rp, int T, int D, float * tab, hipStream_t st);

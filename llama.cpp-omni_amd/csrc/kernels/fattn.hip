@@ -441,7 +441,8 @@ size_t fattn_scratch_bytes(const fattn_args & f) {
     if (!fa_use_mma(f)) {                                             // decode kernels: partial rows of the KV split
         fattn_args g = f; g.pre = nullptr;
         const gqa_plan gp = fa_gqa_plan(g);
-        const int ns = gp.ok ? gp.nsplit : fa_decode_nsplit(g);
+        int ns = gp.ok ? gp.nsplit : fa_decode_nsplit(g);
+        if (f.q.ne[1] == 1 && f.q.ne[3] == 1 && f.k.ne[1] > 256 && f.k.ne[1] <= 8192) { const int n1 = fattn_one_nsplit(f); if (n1 > ns) ns = n1; }   // (the one-token kernel's slices)
         return ns > 1 ? (size_t) (f.q.ne[1] * f.q.ne[3] * f.q.ne[2]) * (size_t) ns * (size_t) (f.q.ne[0] + 2) * 4 : 0;
     }
     if (!f.mask) return 0;
@@ -530,10 +531,21 @@ void flash_attn_ext_f16(const fattn_args & f, hipStream_t st) {
         a.pre = { (const char *) p.qraw, p.q_hs, (const char *) p.kraw, p.k_hs, (const char *) p.vraw, p.v_hs, p.qw, p.kw, p.pos, p.ff, p.eps, make_rope_dev(p.rp),
                   (char *) p.kcache, p.kc_rs, (char *) p.vcache, p.vc_rs, (const char *) p.kidx, (const char *) p.vidx, p.idx_is64 };
     }
-    if (f.pre && f.rope_tab && fattn_one_ok(f)) {                    // tg at shallow depth: the latency-optimised one-token kernel
-        a.nsplit = 1; a.part = nullptr; a.tile_map = nullptr; a.map_nqb = 0;
-        flash_attn_one(a, (int) f.q.ne[0], f.rope_tab, st);
-        return;
+    if (f.pre && f.rope_tab && fattn_one_ok(f)) {                    // one token, up to 4096 cache rows: the latency-optimised one-token kernel
+        const int ns1 = fattn_one_nsplit(f);
+        const size_t need = (size_t) a.nh * (size_t) ns1 * (size_t) (f.q.ne[0] + 2) * 4;
+        if (ns1 == 1 || (f.scratch && f.scratch_bytes >= need)) {
+            static const bool no_inl = getenv("MI355X_FA_ONE_MERGE_LAUNCH") != nullptr;
+            a.nsplit = ns1; a.part = ns1 > 1 ? (float *) f.scratch : nullptr; a.tile_map = nullptr; a.map_nqb = 0;
+            a.cnt = (ns1 > 1 && !no_inl && a.nh <= 1024) ? f.counters : nullptr;
+            flash_attn_one(a, (int) f.q.ne[0], f.rope_tab, st);
+            if (ns1 > 1 && !a.cnt) {                                 // fold the slices' partial rows, apply the sinks, normalise
+                const int nblk = (int) ((a.nh * f.q.ne[0] + 255) / 256);
+                if (f.q.ne[0] == 64) k_fattn_merge<64><<<dim3((unsigned) nblk), dim3(256), 0, st>>>(a.part, ns1, 1, a.nh, nblk, a.sinks, a.dst, a.dnb1, a.dnb2, a.dnb3, nullptr, 0);
+                else                 k_fattn_merge<128><<<dim3((unsigned) nblk), dim3(256), 0, st>>>(a.part, ns1, 1, a.nh, nblk, a.sinks, a.dst, a.dnb1, a.dnb2, a.dnb3, nullptr, 0);
+            }
+            return;
+        }
     }
     // batches of query rows go to the matrix-core kernel (fattn_mma.hip); single / few rows stay on the streaming decode kernel
     if (fa_use_mma(f)) {

@@ -26,6 +26,7 @@ struct fa_dev {
     int qpw;                                            // query rows per workgroup (R / hpw)
     const uint8_t * tile_map; int map_nqb;              // mask tile classes [mne3][mne2][map_nqb][ntile] (prefill kernel), or null = no mask
     int nsplit; float * part;                           // decode kernel: KV range cut into nsplit workgroups per head group, partial (O, M, S) rows in `part`
+    unsigned * cnt = nullptr;                           // one-token kernel with slices: per-head arrival counters (merge inside the launch)
     fa_pre pre;
     char * out16; int64_t out16_rs; int write_f32;      // prefill kernel: f16 copy of the output rows (activation image of wo's GEMM)
     char * img; size_t img_bytes;                       // optional Q8_K image output (one image per (seq, query row)), else null

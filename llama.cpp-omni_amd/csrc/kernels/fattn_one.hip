@@ -18,6 +18,7 @@
 // The output is the plain f32 row; the following wo mat-vec quantises it in its own prologue (mmv1.hip).
 #include "../kernels.hpp"
 #include "fattn_dev.hpp"
+#include <type_traits>
 
 namespace mi {
 
@@ -46,6 +47,7 @@ static __device__ __forceinline__ double wave_sum_f64o(double v) {
 }
 
 constexpr int FA1_NKV = 256;                      // cache rows a workgroup holds in registers
+constexpr int FA1_MAX_SPLIT = 32;                 // 256-row slices per head handled by this kernel + k_fattn_merge (deeper: k_fattn_gqa's MFMA tiles)
 
 // compact argument block (one scalar-load burst): the general fa_dev is ~450 bytes and reading it piecemeal costs round trips
 struct fa1_dev {
@@ -56,6 +58,8 @@ struct fa1_dev {
     int nkv, gq, neox, n_head_log2;
     int vidx_st, vidx_n;                                                     // soft-max path: bytes per v scatter index, number of indices
     int has_norm;                                                            // q / k chains start with RMS_NORM * w (Qwen3) or are ROPE only (llama architecture)
+    int nsplit; float * part;                                                // KV range cut into 256-row slices, one workgroup per (head, slice): partial (O, M, S) rows
+    unsigned * cnt;                                                          // per-head arrival counters (zero between launches); null: k_fattn_merge folds the slices
     float eps, scale, max_bias, logit_softcap, m0, m1;
 };
 
@@ -78,8 +82,11 @@ __global__ void __launch_bounds__(256) k_fattn_one(const fa1_dev a) {
     // XCD-aware head order: workgroups go round-robin over the 8 XCDs (each with its own L2), so the gq heads that share one K / V head are
     // given workgroup ids that are congruent modulo the number of KV heads -- with 8 KV heads one XCD fetches each K / V head once
     // (rocprofv3 FETCH_SIZE: 4.4 MB -> ~1.1 MB per launch at n_kv 256)
-    const int nkvh = (int) gridDim.x / a.gq, ikv = (int) blockIdx.x % nkvh, h = ikv * a.gq + (int) blockIdx.x / nkvh;
-    const int nkv = a.nkv < FA1_NKV ? a.nkv : FA1_NKV;
+    // deeper caches (257 .. 4096 rows): grid = heads x slices, slice sp takes rows [256 sp, 256 sp + 256) and leaves the partial state of its rows
+    // (unnormalised O, running max M, sum S) for k_fattn_merge -- flash-decoding with this kernel's latency chain instead of the MFMA kernel's
+    const int n_head = (int) gridDim.x / a.nsplit, bh = (int) blockIdx.x % n_head, sp = (int) blockIdx.x / n_head, row0 = sp * FA1_NKV;
+    const int nkvh = n_head / a.gq, ikv = bh % nkvh, h = ikv * a.gq + bh / nkvh;
+    const int nkv = a.nkv - row0 < FA1_NKV ? a.nkv - row0 : FA1_NKV;              // rows of this slice
 
     // ---------------------------------------------------------------- 1. request everything: one burst of vector loads, no wait in between
     // (buffer loads with exact bounds instead of branches or clamps: an out-of-range element reads as zero.  The row indices are fetched
@@ -95,16 +102,18 @@ __global__ void __launch_bounds__(256) k_fattn_one(const fa1_dev a) {
     const float w0 = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(wrs, xo0, 0, 0)), w1 = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(wrs, xo1, 0, 0));
     const u32x2 tcs = __builtin_amdgcn_raw_buffer_load_b64(trs, act ? lane * 8 : D * 4, 0, 0);
     // mask row of this head: lane owns rows lane + 64 i
-    const __amdgpu_buffer_rsrc_t mrs = fa1_rsrc(a.mask ? a.mask + (h % a.mne2) * a.mnb2 : a.mask, a.mask ? nkv * 2 : 0);
+    const __amdgpu_buffer_rsrc_t mrs = fa1_rsrc(a.mask ? a.mask + (h % a.mne2) * a.mnb2 + row0 * 2 : a.mask, a.mask ? nkv * 2 : 0);
     uint16_t mraw[FA1_NKV / 64];
 #pragma unroll
     for (int i = 0; i < FA1_NKV / 64; ++i) mraw[i] = __builtin_amdgcn_raw_buffer_load_b16(mrs, (lane + 64 * i) * 2, 0, 0);
-    const int krow = (int) __builtin_amdgcn_raw_buffer_load_b32(fa1_rsrc(a.kidx, 4), 0, 0, 0);     // (little-endian low half of an i64 index)
-    const int vrow = (int) __builtin_amdgcn_raw_buffer_load_b32(fa1_rsrc(a.vidx, 4), 0, 0, 0);
+    const int krow_g = (int) __builtin_amdgcn_raw_buffer_load_b32(fa1_rsrc(a.kidx, 4), 0, 0, 0);   // (little-endian low half of an i64 index)
+    const int vrow_g = (int) __builtin_amdgcn_raw_buffer_load_b32(fa1_rsrc(a.vidx, 4), 0, 0, 0);
+    const int krow = krow_g - row0, vrow = vrow_g - row0;                                          // the new token's row relative to this slice
+    const bool owner = a.nsplit == 1 || (krow_g >= row0 && krow_g < row0 + FA1_NKV) || (sp == 0 && (krow_g < 0 || krow_g >= a.nkv));   // the slice that stores the new cache rows
     // K: granule g = wave + 4 i, row g * 16 + (lane >> 2), lane quarter dq = lane & 3
     const int r16 = lane >> 2, dq = lane & 3;
-    const __amdgpu_buffer_rsrc_t krs = fa1_rsrc(a.k + ikv * a.knb2, (nkv - 1) * a.knb1 + D * 2);
-    const __amdgpu_buffer_rsrc_t vrs = fa1_rsrc(a.v + ikv * a.vnb2, (nkv - 1) * a.vnb1 + D * 2);
+    const __amdgpu_buffer_rsrc_t krs = fa1_rsrc(a.k + ikv * a.knb2 + (int64_t) row0 * a.knb1, (nkv - 1) * a.knb1 + D * 2);
+    const __amdgpu_buffer_rsrc_t vrs = fa1_rsrc(a.v + ikv * a.vnb2 + (int64_t) row0 * a.vnb1, (nkv - 1) * a.vnb1 + D * 2);
     const uint32_t kvo = (uint32_t) r16 * (uint32_t) a.knb1 + (uint32_t) dq * (D / 2);
     u32x4 kk[NG][KCH];
 #pragma unroll
@@ -134,15 +143,15 @@ __global__ void __launch_bounds__(256) k_fattn_one(const fa1_dev a) {
             if (wave == 0) { qf[e0] = h2f(h0); qf[e1] = h2f(h1); }                 // q_to_vec_dot rounding (ops.cpp:8040)
             else {
                 kc[e0] = h2f(h0); kc[e1] = h2f(h1);
-                if (h % a.gq == 0) { uint16_t * kr = (uint16_t *) (a.kcache + (int64_t) krow * a.kc_rs) + ikv * D; kr[e0] = h0; kr[e1] = h1; }
+                if (h % a.gq == 0 && owner) { uint16_t * kr = (uint16_t *) (a.kcache + (int64_t) krow_g * a.kc_rs) + ikv * D; kr[e0] = h0; kr[e1] = h1; }
             }
         }
     } else if (wave == 2) {
         const uint16_t hv0 = f2h(x0), hv1 = f2h(x1);
         vc[lane] = h2f(hv0);
         if (D > 64) vc[lane + 64] = h2f(hv1);
-        if (h % a.gq == 0) {
-            uint16_t * vr = (uint16_t *) (a.vcache + (int64_t) vrow * a.vc_rs) + ikv * D;
+        if (h % a.gq == 0 && owner) {
+            uint16_t * vr = (uint16_t *) (a.vcache + (int64_t) vrow_g * a.vc_rs) + ikv * D;
             vr[lane] = hv0;
             if (D > 64) vr[lane + 64] = hv1;
         }
@@ -248,10 +257,64 @@ __global__ void __launch_bounds__(256) k_fattn_one(const fa1_dev a) {
     if (rs == 0) { acc0 = fmaf(pcur, vc[wave * DPW + 2 * dp], acc0); acc1 = fmaf(pcur, vc[wave * DPW + 2 * dp + 1], acc1); }
 #pragma unroll
     for (int o = LPR; o < 64; o <<= 1) { acc0 += __shfl_xor(acc0, o, 64); acc1 += __shfl_xor(acc1, o, 64); }
-    if (a.sinks) {                                                                   // ops.cpp:8116-8130
+    if (a.sinks && a.nsplit == 1) {                                                  // ops.cpp:8116-8130 (with a KV split: in the merge pass)
         const float sk = a.sinks[h];
         if (sk > M) { const float f = expf(M - sk); S = S * f + 1.0f; acc0 *= f; acc1 *= f; }
         else S += expf(sk - M);
+    }
+    if (a.nsplit > 1) {                                                              // partial state of this slice
+        // written through to the coherence point (sc1): the slices of a head sit on one XCD by construction (same workgroup id modulo 8), but
+        // that is placement, not a guarantee -- the merge below must be right wherever the last arriver runs
+        const __amdgpu_buffer_rsrc_t prs = fa1_rsrc(a.part + (int64_t) h * a.nsplit * (D + 2), a.nsplit * (D + 2) * 4);
+        const uint32_t po = (uint32_t) sp * (D + 2) * 4u;
+        if (rs == 0) {
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc0), prs, po + (uint32_t) (wave * DPW + 2 * dp) * 4u, 0, 16);
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc1), prs, po + (uint32_t) (wave * DPW + 2 * dp + 1) * 4u, 0, 16);
+        }
+        if (threadIdx.x == 0) {
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(M), prs, po + (uint32_t) D * 4u, 0, 16);
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(S), prs, po + (uint32_t) (D + 1) * 4u, 0, 16);
+        }
+        if (!a.cnt) return;                                                          // k_fattn_merge finishes the rows
+        // last arriver folds the head's slices (flash-decoding without the second launch): every wave drains its stores, one lane takes a ticket
+        __shared__ unsigned last;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0) last = __hip_atomic_fetch_add(a.cnt + h, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned) (a.nsplit - 1) ? 1u : 0u;
+        __syncthreads();
+        if (!last) return;
+        if (threadIdx.x < D) {                                                       // thread d: output dim d of head h
+            const int d = threadIdx.x;
+            float Mx = -INFINITY, St = 0.0f, o = 0.0f;
+            // every slice's state requested at once (clamped indices, no branches); 16-wide for the common depths, 32-wide beyond
+            auto fold = [&](auto WIDTH) {
+                constexpr int W = decltype(WIDTH)::value;
+                float Ms[W], Ss[W], os[W];
+#pragma unroll
+                for (int i = 0; i < W; ++i) {
+                    const uint32_t so = (uint32_t) ((i < a.nsplit ? i : 0) * (D + 2)) * 4u;
+                    Ms[i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(prs, so + (uint32_t) D * 4u, 0, 16));
+                    Ss[i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(prs, so + (uint32_t) (D + 1) * 4u, 0, 16));
+                    os[i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(prs, so + (uint32_t) d * 4u, 0, 16));
+                }
+#pragma unroll
+                for (int i = 0; i < W; ++i) { if (i >= a.nsplit) Ms[i] = -INFINITY; Mx = fmaxf(Mx, Ms[i]); }
+#pragma unroll
+                for (int i = 0; i < W; ++i) {
+                    const float f = Ms[i] == -INFINITY ? 0.0f : expf(Ms[i] - Mx);
+                    St += Ss[i] * f; o += os[i] * f;
+                }
+            };
+            if (a.nsplit <= 16) fold(std::integral_constant<int, 16>()); else fold(std::integral_constant<int, FA1_MAX_SPLIT>());
+            if (a.sinks) {                                                           // ops.cpp:8116-8130
+                const float sk = a.sinks[h];
+                if (sk > Mx) { const float f = expf(Mx - sk); St = St * f + 1.0f; o *= f; }
+                else St += expf(sk - Mx);
+            }
+            ((float *) (a.dst + h * a.dnb1))[d] = St == 0.0f ? 0.0f : o * (1.0f / St);
+        }
+        if (threadIdx.x == 0) __hip_atomic_store(a.cnt + h, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // ready for the next launch
+        return;
     }
     const float inv = S == 0.0f ? 0.0f : 1.0f / S;
     if (rs == 0) {
@@ -454,7 +517,7 @@ bool fattn_one_ok(const fattn_args & f) {
     const bool off = env_off || !g_one_enabled;
     const int64_t D = f.q.ne[0];
     if (off || !f.pre || (D != 64 && D != 128) || f.v.ne[0] != D || f.q.ne[1] != 1 || f.q.ne[3] != 1 || f.k.ne[3] != 1) return false;
-    if (f.k.ne[1] < 1 || f.k.ne[1] > FA1_NKV || f.k.ne[2] < 1 || f.q.ne[2] % f.k.ne[2] != 0) return false;
+    if (f.k.ne[1] < 1 || f.k.ne[1] > FA1_NKV * FA1_MAX_SPLIT || f.k.ne[2] < 1 || f.q.ne[2] % f.k.ne[2] != 0) return false;
     if (f.k.nb[1] % 16 != 0 || f.v.nb[1] % 4 != 0 || ((uintptr_t) f.k.p & 15) != 0 || ((uintptr_t) f.v.p & 3) != 0 || f.k.nb[2] % 16 != 0 || f.v.nb[2] % 4 != 0) return false;
     if (f.dst.nb[0] != 4 || f.dst.nb[1] % 8 != 0 || ((uintptr_t) f.dst.p & 7) != 0) return false;
     if (f.k.nb[1] * FA1_NKV > 0x7fffffff || f.v.nb[1] * FA1_NKV > 0x7fffffff || f.k.nb[2] > 0x7fffffff || f.v.nb[2] > 0x7fffffff) return false;
@@ -462,6 +525,7 @@ bool fattn_one_ok(const fattn_args & f) {
     return true;
 }
 
+int fattn_one_nsplit(const fattn_args & f) { return (int) ((f.k.ne[1] + FA1_NKV - 1) / FA1_NKV); }
 void flash_attn_one(const fa_dev & f, int D, const float * rope_tab, hipStream_t st) {
     if (!rope_tab) { fprintf(stderr, "[mi355x] flash_attn_one: the (cos, sin) table of the token is missing\n"); abort(); }
     const fa_pre & P = f.pre;
@@ -473,8 +537,9 @@ void flash_attn_one(const fa_dev & f, int D, const float * rope_tab, hipStream_t
     a.knb1 = (int) f.knb1; a.knb2 = (int) f.knb2; a.vnb1 = (int) f.vnb1; a.vnb2 = (int) f.vnb2; a.mnb2 = (int) f.mnb2; a.mne2 = (int) f.mne2; a.dnb1 = (int) f.dnb1;
     a.nkv = f.nkv; a.gq = f.gq; a.neox = (P.rd.mode & GGML_ROPE_TYPE_NEOX) ? 1 : 0; a.n_head_log2 = (int) f.n_head_log2;
     a.has_norm = P.qw != nullptr; a.vidx_st = 0; a.vidx_n = 0;
+    a.nsplit = f.nsplit > 1 ? f.nsplit : 1; a.part = f.part; a.cnt = f.nsplit > 1 ? f.cnt : nullptr;
     a.eps = P.eps; a.scale = f.scale; a.max_bias = f.max_bias; a.logit_softcap = f.logit_softcap; a.m0 = f.m0; a.m1 = f.m1;
-    const dim3 grid((unsigned) f.nh);
+    const dim3 grid((unsigned) (f.nh * a.nsplit));
     if (D == 64) k_fattn_one<64><<<grid, dim3(256), 0, st>>>(a);
     else         k_fattn_one<128><<<grid, dim3(256), 0, st>>>(a);
 }
@@ -501,7 +566,7 @@ void attn_one_sm(const attn_sm_args & f, hipStream_t st) {
     a.q_hs = (int) P.q_hs; a.k_hs = (int) P.k_hs; a.v_hs = (int) P.v_hs; a.kc_rs = (int) P.kc_rs; a.vc_rs = 2;
     a.knb1 = (int) f.knb1; a.knb2 = (int) f.knb2; a.vnb1 = (int) f.vnb1; a.vnb2 = (int) f.vnb2; a.mnb2 = (int) f.mnb2; a.mne2 = (int) (f.mne2 > 0 ? f.mne2 : 1); a.dnb1 = (int) f.dnb1;
     a.nkv = f.nkv; a.gq = f.n_head / f.n_head_kv; a.neox = (P.rp.mode & GGML_ROPE_TYPE_NEOX) ? 1 : 0; a.n_head_log2 = 0;
-    a.vidx_st = P.idx_is64 ? 8 : 4; a.vidx_n = (int) f.vidx_n; a.has_norm = P.qw != nullptr;
+    a.vidx_st = P.idx_is64 ? 8 : 4; a.vidx_n = (int) f.vidx_n; a.has_norm = P.qw != nullptr; a.nsplit = 1; a.part = nullptr; a.cnt = nullptr;
     a.eps = P.eps; a.scale = f.scale; a.max_bias = 0.0f; a.logit_softcap = 0.0f; a.m0 = 1.0f; a.m1 = 1.0f;
     const dim3 grid((unsigned) f.n_head);
     if (f.D == 64) k_attn_one_sm<64><<<grid, dim3(256), 0, st>>>(a);
