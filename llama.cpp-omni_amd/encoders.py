@@ -4,6 +4,7 @@
                   conv1d_ph + bias + GELU (x2, the second with stride 2), learned positions, per layer LayerNorm -> q/k/v (+bias) ->
                   K / V cast to F16 -> KQ -> soft_max_ext (no mask) -> KQV -> out proj (+bias) -> residual -> LayerNorm -> MLP(GELU) ->
                   residual; final LayerNorm, two projections with ReLU, avg-pool(5) over the tokens.
+  resampler(...): VPM projector, the second half of `build_minicpmv` (vision.cpp:292-377): 64 learned queries cross-attend over the patches
   siglip2(...)  : VPM, `build_inp` + `build_vit` (reference tools/omni/vision.cpp:394-705): ggml_conv_2d patch embedding (+bias), learned
                   positions, per layer LayerNorm -> q/k/v (+bias) -> f32 KQ -> soft_max_ext -> KQV -> out proj (+bias) -> residual ->
                   LayerNorm -> FFN(GELU, biases) -> residual; post LayerNorm.
@@ -17,6 +18,7 @@ from .ggml import GGML_TYPE_F16, GGML_TYPE_F32, UNARY
 
 WHISPER = dict(n_mels=80, n_state=1024, n_head=16, n_ctx=1500, eps=1e-5, d_proj=4096)      # MiniCPM-o APM: Whisper-medium encoder widths
 SIGLIP2 = dict(image=448, patch=14, n_embd=1152, n_head=16, n_ff=4304, eps=1e-6)           # VPM: SigLip2-so400m widths (head_dim 72)
+RESAMPLER = dict(n_embd=1152, n_out=4096, n_query=64, d_head=128, eps=1e-6)               # MiniCPM-V resampler projector: 64 queries x 4096 over the patches
 
 
 def conv_1d_ph(c, kernel, x, s, d):
@@ -137,6 +139,38 @@ def siglip2(c, hp, W):
         cur = c.add(c.mul_mat(L["down_w"], cur), L["down_b"])
         inpL = c.add(inpL, cur)
     return inp, layer_norm(c, inpL, W["post_ln_w"], W["post_ln_b"], hp["eps"])
+
+
+def resampler_weights(c, rp, wtype=GGML_TYPE_F16):
+    E, O, NQ = rp["n_embd"], rp["n_out"], rp["n_query"]
+    f32 = GGML_TYPE_F32
+    t = c.new_tensor
+    return dict(query=t(f32, O, NQ), kv_proj_w=t(wtype, E, O), ln_q_w=t(f32, O), ln_q_b=t(f32, O), ln_kv_w=t(f32, O), ln_kv_b=t(f32, O),
+                q_w=t(wtype, O, O), q_b=t(f32, O), k_w=t(wtype, O, O), k_b=t(f32, O), v_w=t(wtype, O, O), v_b=t(f32, O), o_w=t(wtype, O, O), o_b=t(f32, O),
+                ln_post_w=t(f32, O), ln_post_b=t(f32, O), proj_w=t(wtype, O, O))
+
+
+def resampler(c, rp, W, embeddings, n_pos):
+    """the projector half of build_minicpmv (reference tools/omni/vision.cpp:292-377): kv projection of the ViT output, LayerNorms, k = v +
+    pos_embed, cross-attention of the learned queries over the patches through build_attn (:648-703: permutes, CONT of V^T, K.Q^T,
+    soft_max_ext, V product, CONT), post LayerNorm, output projection.  returns (pos_embed input [n_out, n_pos], out [n_out, n_query])"""
+    O, NQ, D = rp["n_out"], rp["n_query"], rp["d_head"]
+    H = O // D
+    pos_embed = c.new_tensor(GGML_TYPE_F32, O, n_pos)
+    q = layer_norm(c, W["query"], W["ln_q_w"], W["ln_q_b"], rp["eps"])
+    v = layer_norm(c, c.mul_mat(W["kv_proj_w"], embeddings), W["ln_kv_w"], W["ln_kv_b"], rp["eps"])
+    k = c.add(v, pos_embed)
+    Q = c.reshape(c.add(c.mul_mat(W["q_w"], q), W["q_b"]), D, H, NQ)
+    K = c.reshape(c.add(c.mul_mat(W["k_w"], k), W["k_b"]), D, H, n_pos)
+    V = c.reshape(c.add(c.mul_mat(W["v_w"], v), W["v_b"]), D, H, n_pos)
+    qp, kp = c.permute(Q, 0, 2, 1, 3), c.permute(K, 0, 2, 1, 3)
+    vt = c.cont(c.permute(V, 1, 2, 0, 3))
+    kq = c.soft_max_ext(c.mul_mat(kp, qp), None, 1.0 / np.sqrt(float(D)), 0.0)
+    kqv = c.mul_mat(vt, kq)
+    cur = c.cont(c.permute(kqv, 0, 2, 1, 3), D * H, NQ)
+    cur = c.add(c.mul_mat(W["o_w"], cur), W["o_b"])
+    cur = layer_norm(c, cur, W["ln_post_w"], W["ln_post_b"], rp["eps"])
+    return pos_embed, c.mul_mat(W["proj_w"], cur)
 
 
 def declined_nodes(backend, graph_ctx):

@@ -311,7 +311,8 @@ def test_omni_encoder_layer_at_real_shape_vs_reference_backend(pkg, be, ref_be, 
     whisper  -- APM front end + ONE encoder layer + tail: 3000 mel frames -> conv1d_ph x2 -> 1500 tokens, n_state 1024, 16 heads x 64,
                 F16 K / V, 1500 x 1500 soft-max, MLP 4096, final LN, two projections, avg-pool(5)     (audition.cpp:341-715)
     siglip2  -- VPM: ggml_conv_2d patch embedding of a 448 x 448 image (1024 patches), ONE ViT layer at n_embd 1152, 16 heads x 72 (f32
-                K.Q^T with K = 72), FFN 4304 with GELU, post LN                                        (vision.cpp:394-705)
+                K.Q^T with K = 72), FFN 4304 with GELU, post LN (vision.cpp:394-705), then the resampler projector of build_minicpmv
+                (:292-377): kv projection to 4096, 64 learned queries x 32 heads x 128 cross-attending over the patches, post LN, projection
     Every node must be accepted by supports_op (a declined node would silently run on the CPU under the scheduler) and the output must match
     the reference CPU backend on the same graph."""
     from llama_cpp_omni_amd import encoders as E
@@ -324,7 +325,10 @@ def test_omni_encoder_layer_at_real_shape_vs_reference_backend(pkg, be, ref_be, 
             inp, out = E.whisper(c, E.WHISPER, W, 3000)
         else:
             W = E.siglip2_weights(c, E.SIGLIP2, 1)
-            inp, out = E.siglip2(c, E.SIGLIP2, W)
+            inp, vit = E.siglip2(c, E.SIGLIP2, W)
+            Wr = E.resampler_weights(c, E.RESAMPLER)                      # + the resampler projector: the whole build_minicpmv graph
+            pos_embed, out = E.resampler(c, E.RESAMPLER, Wr, vit, (E.SIGLIP2["image"] // E.SIGLIP2["patch"]) ** 2)
+            W = dict(W, **{"rs_" + k: v for k, v in Wr.items()}, rs_pos_embed=pos_embed)
         if backend is be:
             bad = E.declined_nodes(backend, c)
             assert not bad, f"supports_op declined: {bad}"
