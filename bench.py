@@ -246,17 +246,30 @@ def prefill_tok_s(pkg, be, model, n_tokens=512, reps=3):
     return n_tokens / best, ok
 
 
-def c3_prefill(pkg, be, n_seq=8, n_prompt=2048, n_ubatch=512, tiny=False):
+def c3_prefill(pkg, be, n_seq=8, n_prompt=2048, n_ubatch=512, tiny=False, one_ubatch=False):
     """BASELINE.json configs[2]: Qwen3-8B F16 prefill, 8 sequences x 2048 tokens (MFMA GEMM + flash-attn), llama-bench style:
     each prompt is fed as n_prompt / n_ubatch ubatches at growing KV depth; inputs are resident before the timed region."""
     from llama_cpp_omni_amd import qwen3
     cfg = qwen3.TINY if tiny else qwen3.QWEN3_8B
     if tiny:
         n_prompt, n_ubatch = 256, 64
-    model = qwen3.Model(be, cfg, qwen3.uniform_types(cfg, pkg.GGML_TYPE_F16), n_ctx=n_prompt, seed=77, share_layer_bytes=True, flash_attn=True)
+    if one_ubatch:
+        n_ubatch = n_seq * n_prompt
+    model = qwen3.Model(be, cfg, qwen3.uniform_types(cfg, pkg.GGML_TYPE_F16), n_ctx=n_ubatch if one_ubatch else n_prompt, seed=77, share_layer_bytes=True, flash_attn=True)
     rng = np.random.default_rng(6)
     chunks = []
-    for c in range(n_prompt // n_ubatch):
+    if one_ubatch:
+        # all sequences in ONE ubatch (llama-batched-bench -npp 2048 -npl 8 -ub 16384, unified KV cache): cells s * n_prompt + i, positions i,
+        # block-diagonal causal mask -- the GEMMs see 16384 columns, the attention only the live blocks
+        n_tok = n_seq * n_prompt
+        g, I, logits = model.build(n_tok, n_tok, n_outputs=n_seq)
+        model.set_inputs(I, rng.standard_normal((n_tok, cfg["n_embd"])).astype(np.float32), 0, n_tok, n_seq=n_seq)
+        be.tensor_set(I["out_ids"], (np.arange(n_seq, dtype=np.int32) + 1) * n_prompt - 1)
+        chunks.append((g, g.graph(), logits))
+        reps = 1
+    else:
+        reps = n_seq
+    for c in range(n_prompt // n_ubatch if reps == n_seq else 0):
         n_kv = (c + 1) * n_ubatch
         g, I, logits = model.build(n_ubatch, n_kv, n_outputs=1)
         model.set_inputs(I, rng.standard_normal((n_ubatch, cfg["n_embd"])).astype(np.float32), c * n_ubatch, n_kv)
@@ -267,7 +280,7 @@ def c3_prefill(pkg, be, n_seq=8, n_prompt=2048, n_ubatch=512, tiny=False):
             be.graph_compute(gr)
     be.synchronize()
     t0 = time.perf_counter()
-    for _ in range(n_seq):
+    for _ in range(reps):
         for _, gr, _ in chunks:
             be.graph_compute(gr)
     be.synchronize()
@@ -462,7 +475,8 @@ def main():
                 out["pp512_error"] = repr(e)
         if (args.c3 or not (args.no_c3 or args.tiny)) and world == 1:
             try:
-                out["c3_f16_prefill"] = {"ub512": c3_prefill(pkg, be, n_ubatch=512, tiny=args.tiny), "ub2048": c3_prefill(pkg, be, n_ubatch=2048, tiny=args.tiny)}
+                out["c3_f16_prefill"] = {"ub512": c3_prefill(pkg, be, n_ubatch=512, tiny=args.tiny), "ub2048": c3_prefill(pkg, be, n_ubatch=2048, tiny=args.tiny),
+                                        "ub16384": c3_prefill(pkg, be, tiny=args.tiny, one_ubatch=True)}
             except Exception as e:
                 out["c3_f16_prefill"] = {"error": repr(e)}
         if not args.no_cpu_baseline and world == 1:

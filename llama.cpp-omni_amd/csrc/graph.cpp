@@ -735,6 +735,8 @@ static bool gemm_groupable(const ggml_tensor * c) {
     const ggml_tensor * x = c->src[1];
     return x->ne[2] == 1 && x->ne[3] == 1 && c->src[0]->ne[0] % 64 == 0 && c->nb[0] == 4 && c->type == GGML_TYPE_F32;
 }
+static bool gemm_only_consumers(exec_state & s, const ggml_tensor * t, int64_t K, int64_t N, const ggml_tensor ** x_out);
+static void seed_act_f16(exec_state & s, const ggml_tensor * x);
 static bool exec_gemm_group(exec_state & s, int i) {
     ggml_cgraph * g = s.g;
     ggml_tensor * n = g->nodes[i];
@@ -780,8 +782,39 @@ static bool exec_gemm_group(exec_state & s, int i) {
             }
         }
     }
+    // ffn_gate / ffn_up whose only reader is one GLU(SWIGLU, split) that only feeds GEMMs: SWIGLU runs in the epilogue and the launch writes
+    // the f16 activation image of ffn_down (into the alternate scratch: this launch still reads its own input image from act_scratch)
+    int glu_idx = -1; const ggml_tensor * glu_x = nullptr;
+    if (a.nmat == 2 && add_idx[0] < 0 && add_idx[1] < 0 && s.c->act_scratch_alt) {
+        const int g0 = sole_user(s, g->nodes[mm_idx[0]]), g1 = sole_user(s, g->nodes[mm_idx[1]]);
+        if (g0 >= 0 && g0 == g1 && g0 > mm_idx[1] && !s.done[g0]) {
+            const ggml_tensor * G = g->nodes[g0];
+            const ggml_tensor * m0 = g->nodes[mm_idx[0]], * m1 = g->nodes[mm_idx[1]];
+            int item[3] = { mm_idx[0], mm_idx[1], g0 };
+            if (G->op == GGML_OP_GLU && op_param_i32(G, 0) == GGML_GLU_OP_SWIGLU && op_param_i32(G, 1) == 0 && G->src[0] && G->src[1] &&
+                ((G->src[0] == m0 && G->src[1] == m1) || (G->src[0] == m1 && G->src[1] == m0)) && G->type == GGML_TYPE_F32 && G->ne[2] == 1 && G->ne[3] == 1 &&
+                G->ne[0] == m0->ne[0] && G->ne[1] == N && G->nb[1] == (size_t) G->ne[0] * 4 && !is_out(s, m0) && !is_out(s, m1) &&
+                act_image_bytes(ACT_F16, G->ne[0]) * (size_t) N <= s.c->act_scratch_alt_bytes && gemm_only_consumers(s, G, G->ne[0], G->ne[1], &glu_x) && gemm_glu_ok(a) &&
+                can_hoist(s, i, g0, item, 3)) {
+                glu_idx = g0;
+                a.glu_out16 = (uint16_t *) s.c->act_scratch_alt; a.glu_out16_rs = act_image_bytes(ACT_F16, G->ne[0]); a.glu_gate = G->src[0] == m0 ? 0 : 1;
+            }
+        }
+    }
     const size_t ximg = prepare_act(s, x, ACT_F16);
     a.X = (const uint16_t *) s.c->act_scratch; a.x_rs = ximg;
+    if (glu_idx >= 0) {
+        double flops = 2.0 * 2.0 * (double) a.m[0].M * (double) N * (double) K;
+        {
+            prof_scope ps(s, "gemm_f16", flops);
+            gemm_f16_multi(a, s.st);
+        }
+        ++s.n_kernels; s.n_fused += 2;
+        s.done[mm_idx[1]] = 1; s.done[glu_idx] = 1;
+        std::swap(s.c->act_scratch, s.c->act_scratch_alt); std::swap(s.c->act_scratch_bytes, s.c->act_scratch_alt_bytes);
+        seed_act_f16(s, glu_x);
+        return true;
+    }
     if (a.nmat == 1 && a.m[0].dst_cs % 16 == 0 && gemm_split_scratch_bytes(a.m[0].M, N, K) <= s.c->gemm_partial_bytes) a.partial = (float *) s.c->gemm_partial;
     double flops = 0;
     for (int q = 0; q < a.nmat; ++q) flops += 2.0 * (double) a.m[q].M * (double) N * (double) K;
@@ -1860,7 +1893,10 @@ enum ggml_status graph_compute(backend_ctx * c, ggml_cgraph * g) {
                 return GGML_STATUS_SUCCESS;
             }
     }
+    bool any_gemm_cols = false;                                   // a prefill graph: the GEMM that fuses SWIGLU writes its f16 result image next to its input image
+    for (int i = 0; i < g->n_nodes && !any_gemm_cols; ++i) any_gemm_cols = g->nodes[i]->op == GGML_OP_GLU && g->nodes[i]->ne[1] > MI_MMVQ_MAX_COLS;
     if (!ensure_scratch(c, &c->act_scratch, &c->act_scratch_bytes, graph_act_scratch_need(g)) ||
+        !ensure_scratch(c, &c->act_scratch_alt, &c->act_scratch_alt_bytes, any_gemm_cols ? graph_act_scratch_need(g) : 0) ||
         !ensure_scratch(c, &c->w_scratch, &c->w_scratch_bytes, graph_w_scratch_need(g)) ||
         !ensure_scratch(c, &c->fa_scratch, &c->fa_scratch_bytes, graph_fa_scratch_need(g)) ||
         !ensure_scratch(c, &c->rope_scratch, &c->rope_scratch_bytes, graph_rope_scratch_need(g)) ||
@@ -1989,6 +2025,7 @@ void backend_ctx_release(backend_ctx * c) {
     drop_graph_execs(c);
     for (auto ev : c->prof_event_pool) (void) hipEventDestroy(ev);
     if (c->act_scratch) (void) hipFree(c->act_scratch);
+    if (c->act_scratch_alt) (void) hipFree(c->act_scratch_alt);
     if (c->w_scratch) (void) hipFree(c->w_scratch);
     if (c->fa_scratch) (void) hipFree(c->fa_scratch);
     if (c->fa_counters) (void) hipFree(c->fa_counters);
@@ -2023,6 +2060,7 @@ double mi355x_get_stat(struct ggml_backend * backend, const char * key) {
     if (!strncmp(key, "shadow_", 7))        return mi::shadow_stat(key);
     if (!strcmp(key, "gemm256_launches"))   return (double) mi::gemm_variant_launches(0);
     if (!strcmp(key, "gemm192_launches"))   return (double) mi::gemm_variant_launches(1);
+    if (!strcmp(key, "gemm_glu_launches"))  return (double) mi::gemm_variant_launches(2);
     if (!strncmp(key, "prof_", 5)) {
         std::string k(key + 5);
         const size_t us = k.rfind("_us"), nn = k.rfind("_n"), by = k.rfind("_bytes");

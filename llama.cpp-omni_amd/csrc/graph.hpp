@@ -29,6 +29,7 @@ struct backend_ctx {
 
     // scratch for quantised / converted activations (grown outside of graph capture only)
     void *  act_scratch = nullptr;  size_t act_scratch_bytes = 0;
+    void *  act_scratch_alt = nullptr;  size_t act_scratch_alt_bytes = 0;      // second image buffer: a GEMM that emits the next GEMM's f16 activation image (SWIGLU epilogue) swaps the two
     // scratch for de-quantised weight tiles / f16 copies on the GEMM path
     void *  w_scratch = nullptr;    size_t w_scratch_bytes = 0;
     // mask tile map of the prefill flash-attention kernel

@@ -229,6 +229,8 @@ struct gemm_multi_args {
     // non-null: when a split-K is chosen the reduction is NOT run; *deferred_split = number of [N][M] slabs left in `partial` (0: none,
     // dst is complete) and the caller owes gemm_reduce() or gemm_reduce_rms_norm()
     int * deferred_split = nullptr;
+    // gate / up + SWIGLU (gemm_glu_ok): no f32 outputs; f16 rows of silu(W[glu_gate].x) * (W[1 - glu_gate].x) go to glu_out16
+    uint16_t * glu_out16 = nullptr; size_t glu_out16_rs = 0; int glu_gate = 0;
 };
 void   gemm_reduce(const float * partial, int nsplit, const float * resid, size_t resid_cs, float * dst, size_t dst_cs, int64_t M, int64_t N, hipStream_t st);
 // the same reduction fused with the RMS_NORM -> MUL(w) of the result: dst = sum + resid (f32); y = rms_norm(dst) * w -> y32 / f16 rows y16
@@ -237,6 +239,7 @@ void   gemm_reduce_rms_norm(const float * partial, int nsplit, const float * res
                             float * y32, size_t y32_cs, uint16_t * y16, size_t y16_rs, int64_t M, int64_t N, hipStream_t st);
 void   gemm_f16_multi(const gemm_multi_args & a, hipStream_t st);
 size_t gemm_split_scratch_bytes(int64_t M, int64_t N, int64_t K);
-long   gemm_variant_launches(int v);      // launches so far of the 256 x 256 (0) / 192-row (1) tile kernels (test instrumentation)
+long   gemm_variant_launches(int v);      // launches so far of the 256 x 256 (0) / 192-row (1) / gate-up-SWIGLU (2) tile kernels (test instrumentation)
+bool   gemm_glu_ok(const gemm_multi_args & a);
 
 } // namespace mi

@@ -218,9 +218,68 @@ __global__ void __launch_bounds__(1024) k_rms_norm(td4 x, td4 y, td4 w, float ep
     }
 }
 
+// Many rows (prefill ubatches): one WAVE per row, the row held in registers (MAXV 16-byte pieces per lane), sum of squares in double per lane and
+// folded across the wave -- one read of x, no LDS, no barrier (k_rms_norm re-reads the row and issues 4-byte accesses: 1.8 TB/s on 16384 x 4096).
+template <int MAXV>
+__global__ void __launch_bounds__(256) k_rms_norm_rows(td4 x, td4 y, const float * __restrict__ w, float eps, char * __restrict__ y16, int64_t y16_rs, int64_t nrows) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t) blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= nrows) return;
+    const int64_t i1 = row % x.ne[1], i2 = (row / x.ne[1]) % x.ne[2], i3 = row / (x.ne[1] * x.ne[2]);
+    const char * xr = x.p + i1 * x.nb[1] + i2 * x.nb[2] + i3 * x.nb[3];
+    const int n = (int) x.ne[0];
+    f32x4 v[MAXV];
+    double ss = 0.0;
+#pragma unroll
+    for (int k = 0; k < MAXV; ++k) {
+        const int i = (lane + 64 * k) * 4;
+        v[k] = f32x4{ 0.0f, 0.0f, 0.0f, 0.0f };
+        if (i < n) v[k] = *(const f32x4 *) (xr + (size_t) i * 4);
+    }
+#pragma unroll
+    for (int k = 0; k < MAXV; ++k)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) ss += (double) (v[k][e] * v[k][e]);
+    ss = wave_sum<double>(ss);
+    const float mean  = (float) (ss / (double) n);
+    const float scale = 1.0f / sqrtf(mean + eps);
+    char * yr = y.p ? y.p + i1 * y.nb[1] + i2 * y.nb[2] + i3 * y.nb[3] : nullptr;
+    char * hr = y16 ? y16 + row * y16_rs : nullptr;
+#pragma unroll
+    for (int k = 0; k < MAXV; ++k) {
+        const int i = (lane + 64 * k) * 4;
+        if (i >= n) break;
+        f32x4 o;
+        if (w) { const f32x4 ww = *(const f32x4 *) (w + i);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = (v[k][e] * scale) * ww[e];
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = v[k][e] * scale;
+        }
+        if (yr) *(f32x4 *) (yr + (size_t) i * 4) = o;
+        if (hr) { u32x2 h; h[0] = (uint32_t) f2h(o[0]) | ((uint32_t) f2h(o[1]) << 16); h[1] = (uint32_t) f2h(o[2]) | ((uint32_t) f2h(o[3]) << 16); *(u32x2 *) (hr + (size_t) i * 2) = h; }
+    }
+}
+
 void rms_norm(const tdesc & x, const tdesc & y, float eps, const tdesc * mul_w, hipStream_t st, uint16_t * y16, size_t y16_rs, bool write_f32) {
     if (x.ne[0] == 0 || x.ne[1] * x.ne[2] * x.ne[3] == 0) return;
     const int64_t n = x.ne[0];
+    {
+        const int64_t nrows = x.ne[1] * x.ne[2] * x.ne[3];
+        auto al16 = [](const tdesc & t) { return ((uintptr_t) t.p & 15) == 0 && t.nb[0] == 4 && t.nb[1] % 16 == 0 && t.nb[2] % 16 == 0 && t.nb[3] % 16 == 0; };
+        const bool w_ok = !mul_w || (mul_w->ne[0] == n && mul_w->ne[1] * mul_w->ne[2] * mul_w->ne[3] == 1 && mul_w->nb[0] == 4 && ((uintptr_t) mul_w->p & 15) == 0);
+        if (nrows >= 64 && n % 4 == 0 && n <= 8192 && al16(x) && al16(y) && w_ok && (!y16 || (y16_rs % 8 == 0 && ((uintptr_t) y16 & 7) == 0)) && (mul_w || !y16)) {
+            td4 yd = to_td4(y);
+            if (!write_f32) yd.p = nullptr;
+            const dim3 grid((unsigned) ((nrows + 3) / 4));
+            const float * wp = mul_w ? (const float *) mul_w->p : nullptr;
+            if (n <= 2048)      k_rms_norm_rows<8><<<grid, dim3(256), 0, st>>>(to_td4(x), yd, wp, eps, (char *) y16, (int64_t) y16_rs, nrows);
+            else if (n <= 4096) k_rms_norm_rows<16><<<grid, dim3(256), 0, st>>>(to_td4(x), yd, wp, eps, (char *) y16, (int64_t) y16_rs, nrows);
+            else                k_rms_norm_rows<32><<<grid, dim3(256), 0, st>>>(to_td4(x), yd, wp, eps, (char *) y16, (int64_t) y16_rs, nrows);
+            return;
+        }
+    }
     int bs = n <= 128 ? 64 : n < 1024 ? 256 : n < 8192 ? 512 : 1024;
     dim3 grid((unsigned) x.ne[1], (unsigned) x.ne[2], (unsigned) x.ne[3]);
     if (y16 && (!mul_w || x.ne[2] * x.ne[3] != 1)) { fprintf(stderr, "[mi355x] rms_norm: f16 emission needs the fused weight and a 2-D input\n"); abort(); }

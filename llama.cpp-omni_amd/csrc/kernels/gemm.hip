@@ -137,6 +137,8 @@ struct gemm_dev {
     // broadcast batch over blockIdx.y (attention without FLASH_ATTN_EXT: one K / V^T matrix per KV head, one activation block per query
     // head): batch b = i13 * ne12 + i12 uses W + (i12 / r2) * w_nb2 + (i13 / r3) * w_nb3, X + b * x_bs, dst + i12 * dst_nb2 + i13 * dst_nb3
     int ne12, r2, r3; size_t w_nb2, w_nb3, x_bs, dst_nb2, dst_nb3;
+    unsigned long long * dbg;
+    char * out16; size_t out16_rs; int glu_gate;      // k_gemm_f16_ph8<.., true>: f16 rows of silu(W[glu_gate].x) * (W[1 - glu_gate].x)
 };
 
 // MB = 32-row MFMA tiles per wave along m: the workgroup tile is (64*MB) x 128.  MB = 2 is the default; MB = 3 (192 x 128) is chosen
@@ -355,6 +357,197 @@ __global__ void __launch_bounds__(512) k_gemm_f16_glds256(const gemm_dev g) {
         }
 }
 
+// ---- 256 x 256 tile, 8 waves, EIGHT-PHASE schedule: the kernel above drains every LDS-DMA at its one barrier per K-step, so a tile's
+// operands have at most one K-step (~0.4 us of MFMA work) to arrive -- less than an HBM round trip under load.  Here the DMA never drains
+// inside the loop:
+//   * a K-step's operands are four 16-KB "items", in the order they are needed: X-h0, W-h0, X-h1, W-h1.  Wave (wm, wn) owns rows
+//     wm*128 + [0,128) x columns wn*64 + [0,64); W-h0 / W-h1 hold the first / second 64 rows of BOTH wm, X-h0 / X-h1 the first / second 32
+//     columns of all four wn, so every wave walks its C quadrants (64 x 32, 8 MFMAs) in the same item order, one per phase:
+//         phase 0: reads W-h0 (8 x ds_read_b128), acc[0][0..1] (X-h0 is in registers already)     phase 1: reads X-h1 (4), acc[1][0..1]
+//         phase 2: reads W-h1 (8), acc[1][2..3]              phase 3: reads X-h0 of the NEXT K-step (4, into the registers X-h1 left), acc[0][2..3]
+//   * the 8 DMA instructions per thread and K-step are issued 1 / 3 / 1 / 3 per phase -- most where the fewest LDS reads are -- five to six
+//     phases before the phase that reads them, each into the slot the same item of two K-steps earlier occupied; every phase ends its
+//     issue part with a counted s_waitcnt vmcnt(9 or 10): what the NEXT phase reads has landed, more than a K-step stays in flight across
+//     the barrier
+//   * waves 0-3 (wm = 0) and 4-7 (wm = 1) run half a phase apart (one extra barrier up front for the second group): wave w and w + 4 share
+//     a SIMD, so while one issues LDS reads and DMA the other runs its 8 MFMAs (ping-pong); two raw s_barrier per phase keep the lock step
+//   RAW: an item is read one phase after the vmcnt wait + barrier that retire it.  WAR: an item overwrites the slot of the same item two
+//   K-steps back, whose last ds_read was retired by an lgkmcnt(0) at least three barriers before the issue (lead <= 6 phases).
+// GLU = true (ffn_gate / ffn_up -> SWIGLU -> ffn_down's activation): the tile is 128 rows of BOTH matrices -- W-h0 comes from the gate matrix,
+// W-h1 from the same rows of the up matrix -- so a lane's acc[a][0..1] and acc[a][2..3] are gate and up of the same output element:
+// silu(gate) * up (vec.h:958 arithmetic, f32) is rounded to f16 straight into the activation image of the next GEMM; the two f32
+// [n_ff x n_tokens] intermediates and the GLU launch never exist.
+// MI355X_GEMM_ABL (measurement only): 1 no DMA inside the loop (stale operands), 8 cycle stamps per phase part.
+template <int ABL, bool GLU>
+__global__ void __launch_bounds__(512) k_gemm_f16_ph8(const gemm_dev g) {
+    constexpr int HALFB = 128 * H_ROWB, BUFB = 4 * HALFB;          // 16 KB per item, 64 KB per buffer: slots W-h0, W-h1, X-h0, X-h1
+    constexpr int S_W0 = 0, S_W1 = 1, S_X0 = 2, S_X1 = 3;
+    char * const lds = gemm_lds;
+
+    const int nt  = g.tiles_m * g.tiles_n;
+    const int bid = blockIdx.x;
+    const int q = nt / 8, r = nt % 8, xcd = bid % 8, idx = bid / 8;
+    const int tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    // an XCD's 32 resident workgroups are consecutive tiles: walk the tile grid in bands of 8 tile rows, column-major inside a band, so that
+    // they form an 8 x 4 block (8 W panels + 4 X panels through that XCD's L2) instead of a 1 x 32 strip (1 + 32 panels)
+    const int band = tile / (8 * g.tiles_n), inb = tile % (8 * g.tiles_n), bh = g.tiles_m - band * 8 < 8 ? g.tiles_m - band * 8 : 8;
+    int tm = band * 8 + inb % bh; const int tn = inb / bh;
+    int mi = 0;
+    if (!GLU && g.nmat > 1 && tm >= g.tm_end[0]) { mi = 1; if (g.nmat > 2 && tm >= g.tm_end[1]) mi = 2; }
+    tm -= mi == 0 ? 0 : g.tm_end[mi - 1];
+    const char * W = mi == 0 ? g.W[0] : (mi == 1 ? g.W[1] : g.W[2]);
+    const size_t w_rs = mi == 0 ? g.w_rs[0] : (mi == 1 ? g.w_rs[1] : g.w_rs[2]);
+    const int M = mi == 0 ? g.M[0] : (mi == 1 ? g.M[1] : g.M[2]);
+    const int N = g.N;
+    const int m0 = tm * (GLU ? 128 : 256), n0 = tn * 256;
+
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wm = wave >> 2, wn = wave & 3;                       // waves w and w + 4 (one SIMD) are in different phase groups
+
+    // staging: an item is 128 LDS rows; instruction i of wave w fills local rows i*64 + w*8 + [0,8), lane l the 16-B chunk l & 7 of row l >> 3
+    // from source chunk (l & 7) ^ ((row >> 1) & 7) (the bank swizzle of the kernels above, applied on the source side)
+    const int r8 = lane >> 3;
+    const char * src[4][2];                                        // [slot][instruction]
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int lr = i * 64 + wave * 8 + r8;
+        const int gc = (lane & 7) ^ ((lr >> 1) & 7);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            int mr = GLU ? m0 + lr : m0 + (lr >> 6) * 128 + h * 64 + (lr & 63); mr = mr < M ? mr : M - 1;
+            int nr = n0 + (lr >> 5) * 64 + h * 32 + (lr & 31);  nr = nr < N ? nr : N - 1;
+            const int wi = GLU ? (h == 0 ? g.glu_gate : 1 - g.glu_gate) : 0;                         // (GLU: M and the row stride are checked equal)
+            src[S_W0 + h][i] = (GLU ? g.W[wi] : W) + (size_t) mr * w_rs + gc * 16;
+            src[S_X0 + h][i] = g.X + (size_t) nr * g.x_rs + gc * 16;
+        }
+    }
+    const int nk = g.K / H_BK;
+    bool in_loop = false;
+    auto dma = [&](int buf, int slot, int i, int kt) {             // one DMA instruction: half i of an item
+        if ((ABL & 1) && in_loop) return;
+        const size_t ko = (size_t) (kt < nk ? kt : nk - 1) * H_ROWB; // past the end: the last K-step again, into a slot nobody reads any more
+        __builtin_amdgcn_global_load_lds((gbl_ptr_t) (src[slot][i] + ko), (lds_ptr_t) (lds + buf * BUFB + slot * HALFB + (i * 64 + wave * 8) * H_ROWB), 16, 0, 0);
+    };
+
+    f16v acc[2][4];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.0f;
+
+    const int fr = lane & 31, hb = lane >> 5, sw = (fr >> 1) & 7;
+    int co[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) co[kk] = ((kk * 2 + hb) ^ sw) << 4;
+    const char * const wrow = lds + (wm * 64 + fr) * H_ROWB;        // + buffer, slot, (second 32-row fragment) 32 * H_ROWB
+    const char * const xrow = lds + (wn * 32 + fr) * H_ROWB;
+    h8 wr[2][4], x0[4], x1[4];
+    auto read_w = [&](int buf, int slot) {
+#pragma unroll
+        for (int bb = 0; bb < 2; ++bb)
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) wr[bb][kk] = *(const h8 *) (wrow + buf * BUFB + slot * HALFB + bb * 32 * H_ROWB + co[kk]);
+    };
+    auto read_x = [&](int buf, int slot, h8 (&x)[4]) {
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) x[kk] = *(const h8 *) (xrow + buf * BUFB + slot * HALFB + co[kk]);
+    };
+    auto mma = [&](int a, int bh, const h8 (&x)[4]) {
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+            for (int bb = 0; bb < 2; ++bb) acc[a][2 * bh + bb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(x[kk], wr[bb][kk], acc[a][2 * bh + bb], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+    };
+#define PH8_BAR()     asm volatile("s_barrier" ::: "memory")
+#define PH8_ISSUED(n) asm volatile("s_waitcnt vmcnt(" #n ")\n\ts_barrier" ::: "memory")
+#define PH8_READ()    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+    unsigned long long st[12] = {}, tc = 0;
+#define PH8_T(i) do { if (ABL & 8) { const unsigned long long n = __builtin_readcyclecounter(); st[i] += n - tc; tc = n; } } while (0)
+
+    // prologue: K-step 0 whole, X-h0 / W-h0 / X-h1 of K-step 1 (14 instructions, the state the loop's phase 3 leaves), X-h0 of K-step 0 into x0
+#pragma unroll
+    for (int i = 0; i < 2; ++i) dma(0, S_X0, i, 0);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) dma(0, S_W0, i, 0);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) dma(0, S_X1, i, 0);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) dma(0, S_W1, i, 0);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) dma(1, S_X0, i, 1);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) dma(1, S_W0, i, 1);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) dma(1, S_X1, i, 1);
+    PH8_ISSUED(12);
+    read_x(0, S_X0, x0);
+    PH8_ISSUED(10);
+    PH8_READ();
+    if (wm == 1) PH8_BAR();
+    in_loop = true;
+    if (ABL & 8) tc = __builtin_readcyclecounter();
+    auto kstep = [&](auto PARc, int kt) {
+        constexpr int P = decltype(PARc)::value;
+        h8 (&xa)[4] = P ? x1 : x0; h8 (&xb)[4] = P ? x0 : x1;      // X-h0 of this K-step sits where the previous K-step's X-h1 was
+        read_w(P, S_W0);       dma(P ^ 1, S_W1, 0, kt + 1);                                                                        PH8_T(0); PH8_ISSUED(9);  PH8_T(1);  PH8_READ(); mma(0, 0, xa); PH8_BAR(); PH8_T(2);
+        read_x(P, S_X1, xb);   dma(P ^ 1, S_W1, 1, kt + 1); dma(P, S_X0, 0, kt + 2); dma(P, S_X0, 1, kt + 2);                      PH8_T(3); PH8_ISSUED(10); PH8_T(4);  PH8_READ(); mma(1, 0, xb); PH8_BAR(); PH8_T(5);
+        read_w(P, S_W1);       dma(P, S_W0, 0, kt + 2);                                                                            PH8_T(6); PH8_ISSUED(9);  PH8_T(7);  PH8_READ(); mma(1, 1, xb); PH8_BAR(); PH8_T(8);
+        read_x(P ^ 1, S_X0, xb); dma(P, S_W0, 1, kt + 2); dma(P, S_X1, 0, kt + 2); dma(P, S_X1, 1, kt + 2);                        PH8_T(9); PH8_ISSUED(10); PH8_T(10); PH8_READ(); mma(0, 1, xa); PH8_BAR(); PH8_T(11);
+    };
+    int kt = 0;
+    for (; kt + 1 < nk; kt += 2) { kstep(std::integral_constant<int, 0>(), kt); kstep(std::integral_constant<int, 1>(), kt + 1); }
+    if (kt < nk) kstep(std::integral_constant<int, 0>(), kt);
+    if (wm == 0) PH8_BAR();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if ((ABL & 8) && g.dbg && blockIdx.x == 300 && lane == 0 && (wave & 3) == 0)
+        for (int i = 0; i < 12; ++i) g.dbg[wm * 12 + i] = st[i];
+#undef PH8_BAR
+#undef PH8_ISSUED
+#undef PH8_READ
+#undef PH8_T
+
+    if (GLU) {
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int bb = 0; bb < 2; ++bb) {
+                const int m = m0 + wm * 64 + bb * 32 + (lane & 31);
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int n = n0 + wn * 64 + a * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+                    const float x = acc[a][bb][e], u = acc[a][2 + bb][e];
+                    const float v = (x / (1.0f + expf(-x))) * u;
+                    if (m < M && n < N) *(uint16_t *) (g.out16 + (size_t) n * g.out16_rs + (size_t) m * 2) = f2h(v);
+                }
+            }
+        return;
+    }
+    char * dst = mi == 0 ? g.dst[0] : (mi == 1 ? g.dst[1] : g.dst[2]);
+    const size_t dst_cs = mi == 0 ? g.dst_cs[0] : (mi == 1 ? g.dst_cs[1] : g.dst_cs[2]);
+    const char * resid = mi == 0 ? g.resid[0] : (mi == 1 ? g.resid[1] : g.resid[2]);
+    const size_t resid_cs = mi == 0 ? g.resid_cs[0] : (mi == 1 ? g.resid_cs[1] : g.resid_cs[2]);
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int m = m0 + wm * 128 + b * 32 + (lane & 31);
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int n = n0 + wn * 64 + a * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+                if (m < M && n < N) {
+                    float v = acc[a][b][e];
+                    if (resid) v += *(const float *) (resid + (size_t) n * resid_cs + (size_t) m * 4);
+                    *(float *) (dst + (size_t) n * dst_cs + (size_t) m * 4) = v;
+                }
+            }
+        }
+}
+
 // dst[n][m] = sum_s part[s][n][m] (+ resid[n][m]), fixed summation order
 __global__ void __launch_bounds__(256) k_gemm_reduce(const float * __restrict__ part, int nsplit, size_t split_elems, const char * __restrict__ resid, size_t resid_cs,
                                                      char * __restrict__ dst, size_t dst_cs, int M, int N) {
@@ -431,7 +624,7 @@ void gemm_reduce_rms_norm(const float * partial, int nsplit, const float * resid
 
 // dynamic LDS above 64 KB needs a function attribute, once per (kernel, device): a process may drive several GPUs
 static void allow_big_lds(const void * kernel, int bytes, int slot) {
-    static bool done[2][64] = {};
+    static bool done[3][64] = {};
     int dev = 0;
     HIP_CHECK(hipGetDevice(&dev));
     if (dev < 0 || dev >= 64 || !done[slot][dev]) {
@@ -456,8 +649,14 @@ size_t gemm_split_scratch_bytes(int64_t M, int64_t N, int64_t K) {
 }
 
 // launches per tile variant (tests assert that a shape really selected the kernel it is meant to cover): 0 = 256 x 256, 1 = 192-row
-static long g_gemm_variant_launches[2] = { 0, 0 };
-long gemm_variant_launches(int v) { return v >= 0 && v < 2 ? g_gemm_variant_launches[v] : 0; }
+static long g_gemm_variant_launches[3] = { 0, 0, 0 };
+long gemm_variant_launches(int v) { return v >= 0 && v < 3 ? g_gemm_variant_launches[v] : 0; }
+// gate / up + SWIGLU in one launch: equal shapes and row strides, whole 128-row blocks, enough tiles to occupy the chip
+bool gemm_glu_ok(const gemm_multi_args & a) {
+    static const bool off = getenv("MI355X_NO_GEMM_GLU") != nullptr;
+    if (off || a.nmat != 2 || a.nbatch > 1 || a.K % H_BK != 0 || a.m[0].M != a.m[1].M || a.m[0].w_rs != a.m[1].w_rs || a.m[0].M % 128 != 0 || a.m[0].resid || a.m[1].resid) return false;
+    return (a.m[0].M / 128) * ((a.N + 255) / 256) >= 128;
+}
 
 void gemm_f16_multi(const gemm_multi_args & a, hipStream_t st) {
     if (a.N == 0 || a.nmat == 0) return;
@@ -476,6 +675,22 @@ void gemm_f16_multi(const gemm_multi_args & a, hipStream_t st) {
     }
     if (a.deferred_split) *a.deferred_split = 0;
     gemm_dev g;
+    if (a.glu_out16) {                                        // ffn_gate / ffn_up + SWIGLU in one launch (gemm_glu_ok() said yes)
+        const int tiles_n256 = (int) ((a.N + 255) / 256), tm128 = (int) (a.m[0].M / 128);
+        for (int i = 0; i < 3; ++i) {
+            const gemm_mat & m = a.m[i < 2 ? i : 0];
+            g.W[i] = (const char *) m.W; g.w_rs[i] = m.w_rs; g.dst[i] = nullptr; g.dst_cs[i] = 0; g.resid[i] = nullptr; g.resid_cs[i] = 0; g.M[i] = (int) m.M; g.tm_end[i] = tm128;
+        }
+        g.nmat = 1; g.X = (const char *) a.X; g.x_rs = a.x_rs; g.N = (int) a.N; g.K = (int) a.K; g.tiles_m = tm128; g.tiles_n = tiles_n256;
+        g.ksteps_per_split = (int) (a.K / H_BK); g.split_stride = 0;
+        g.ne12 = g.r2 = g.r3 = 1; g.w_nb2 = g.w_nb3 = g.x_bs = g.dst_nb2 = g.dst_nb3 = 0;
+        g.dbg = nullptr; g.out16 = (char *) a.glu_out16; g.out16_rs = a.glu_out16_rs; g.glu_gate = a.glu_gate;
+        constexpr int lds256 = 2 * 2 * 256 * H_ROWB;
+        allow_big_lds((const void *) k_gemm_f16_ph8<0, true>, lds256, 2);
+        k_gemm_f16_ph8<0, true><<<dim3((unsigned) (tm128 * tiles_n256)), dim3(512), lds256, st>>>(g);
+        ++g_gemm_variant_launches[2];
+        return;
+    }
     // workgroup tile height: 192 rows when that removes a partially filled round of the 512 resident workgroups
     auto count_tm = [&](int bm) { int t = 0; for (int i = 0; i < a.nmat; ++i) t += (int) ((a.m[i].M + bm - 1) / bm); return t; };
     int BM = G_BM;
@@ -515,8 +730,27 @@ void gemm_f16_multi(const gemm_multi_args & a, hipStream_t st) {
         g.ksteps_per_split = (int) (a.K / H_BK); g.split_stride = 0;
         g.ne12 = g.r2 = g.r3 = 1; g.w_nb2 = g.w_nb3 = g.x_bs = g.dst_nb2 = g.dst_nb3 = 0;
         constexpr int lds256 = 2 * 2 * 256 * H_ROWB;               // 128 KB
-        allow_big_lds((const void *) k_gemm_f16_glds256, lds256, 0);
-        k_gemm_f16_glds256<<<dim3((unsigned) (tm * tiles_n256)), dim3(512), lds256, st>>>(g);
+        static const bool one_barrier = getenv("MI355X_GEMM_PH8") && atoi(getenv("MI355X_GEMM_PH8")) == 0;      // (A/B: the one-barrier-per-K-step kernel)
+        g.dbg = nullptr; g.out16 = nullptr; g.out16_rs = 0; g.glu_gate = 0;
+        if (one_barrier) {
+            allow_big_lds((const void *) k_gemm_f16_glds256, lds256, 0);
+            k_gemm_f16_glds256<<<dim3((unsigned) (tm * tiles_n256)), dim3(512), lds256, st>>>(g);
+        } else {
+            static const int abl = getenv("MI355X_GEMM_ABL") ? atoi(getenv("MI355X_GEMM_ABL")) : 0;
+            auto go = [&](auto kern) { HIP_CHECK(hipFuncSetAttribute((const void *) kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds256)); kern<<<dim3((unsigned) (tm * tiles_n256)), dim3(512), lds256, st>>>(g); };
+            if (abl == 8) {
+                static unsigned long long * dbg = nullptr; static int shown = 0;
+                if (!dbg) HIP_CHECK(hipMalloc(&dbg, 24 * 8));
+                g.dbg = dbg;
+                go(k_gemm_f16_ph8<8, false>);
+                if (shown++ < 2) {
+                    unsigned long long h[24]; HIP_CHECK(hipStreamSynchronize(st)); HIP_CHECK(hipMemcpy(h, dbg, sizeof(h), hipMemcpyDeviceToHost));
+                    for (int w = 0; w < 2; ++w) { fprintf(stderr, "[ph8 stamps] group %d, cycles per K-step:", w); for (int i = 0; i < 12; ++i) fprintf(stderr, " %s%.0f", i % 3 == 0 ? "| " : "", (double) h[w * 12 + i] / (a.K / 64)); fprintf(stderr, "\n"); }
+                }
+                return;
+            }
+            if (abl == 1) go(k_gemm_f16_ph8<1, false>); else go(k_gemm_f16_ph8<0, false>);
+        }
         ++g_gemm_variant_launches[0];
         return;
     }

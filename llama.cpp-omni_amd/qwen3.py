@@ -275,11 +275,26 @@ class Model:
         return T
 
     # ---------------------------------------------------------------------------------- inputs
-    def set_inputs(self, I, embd, pos0, n_kv):
-        """Causal decode/prefill inputs for tokens at positions pos0 .. pos0+n-1 written to cache cells of the same index."""
+    def set_inputs(self, I, embd, pos0, n_kv, n_seq=1):
+        """Causal decode/prefill inputs for tokens at positions pos0 .. pos0+n-1 written to cache cells of the same index.
+        n_seq > 1: the ubatch holds n_seq equal-length sequences back to back (unified KV cache, llama_kv_cache::set_input_kq_mask with
+        several seq_ids): token i of sequence s sits at position i in cell s * len + i and sees only its own sequence's earlier cells."""
         be = self.be
         n = embd.shape[0]
         be.tensor_set(I["inp_embd"], embd.astype(np.float32))
+        if n_seq > 1:
+            assert pos0 == 0 and n % n_seq == 0 and not self.v_trans
+            ln = n // n_seq
+            be.tensor_set(I["inp_pos"], np.tile(np.arange(ln, dtype=np.int32), n_seq))
+            cells = np.arange(n, dtype=np.int64)
+            be.tensor_set(I["k_idxs"], cells); be.tensor_set(I["v_idxs"], cells)
+            npad = I["kq_mask"].ne[1]
+            m = np.full((npad, n_kv), -np.inf, dtype=np.float16 if self.fa else np.float32)
+            blk = np.where(np.tril(np.ones((ln, ln), bool)), 0.0, -np.inf).astype(m.dtype)
+            for s in range(n_seq):
+                m[s * ln:(s + 1) * ln, s * ln:(s + 1) * ln] = blk
+            be.tensor_set(I["kq_mask"], m)
+            return
         pos = np.arange(pos0, pos0 + n, dtype=np.int32)
         be.tensor_set(I["inp_pos"], pos)
         be.tensor_set(I["k_idxs"], pos.astype(np.int64))

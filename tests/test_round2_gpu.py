@@ -524,3 +524,38 @@ def test_bench_runs_as_two_ranks_through_its_gloo_hooks(tmp_path):
     j = json.loads(lines[0])
     assert j["n_gpus"] == 2 and j["steps"] == 8 and j["scaling"] == "weak" and j["value"] > 0
     assert abs(j["value"] - 2 * 8 / (j["ms_per_step"] * 8 / 1e3)) / j["value"] < 1e-3       # aggregate = ranks x steps / max-over-ranks time
+
+
+def test_gate_up_swiglu_in_the_gemm_epilogue_vs_oracle(pkg, be):
+    """ffn_up / ffn_gate -> SWIGLU -> ffn_down at a prefill shape: the two mat-muls and the GLU become ONE launch of k_gemm_f16_ph8<GLU> (W-h0 from
+    the gate matrix, W-h1 from the up matrix, silu(gate) * up rounded to f16 in the epilogue -- the activation image of ffn_down); the
+    launch counter confirms the path, the ffn_down output is compared with the oracle's chain (F16 mul_mat with f16-rounded activations,
+    f32 SWIGLU, F16 mul_mat), and the same graph with the fusion's shape precondition broken (a second reader of the GLU result) must agree."""
+    from test_gpu_parity import run_graph
+    rng = np.random.default_rng(77)
+    E, F, N = 512, 2048, 4096                                     # 16 row blocks x 16 column tiles = 256 workgroups
+    ty = pkg.GGML_TYPE_F16
+    wg = (rng.standard_normal((F, E)) * 0.05).astype(np.float16); wu = (rng.standard_normal((F, E)) * 0.05).astype(np.float16)
+    wd = (rng.standard_normal((E, F)) * 0.05).astype(np.float16)
+    xv = rng.standard_normal((N, E)).astype(np.float32)
+    outs = []
+    for second_reader in (False, True):
+        c = pkg.Context(be)
+        x = c.new_tensor(pkg.GGML_TYPE_F32, E, N)
+        tg, tu, td_ = c.new_tensor(ty, E, F), c.new_tensor(ty, E, F), c.new_tensor(ty, F, E)
+        up = c.mul_mat(tu, x); gate = c.mul_mat(tg, x)
+        act = c.swiglu_split(gate, up)
+        y = c.mul_mat(td_, act)
+        roots = [y] + ([c.scale(act, 1.0)] if second_reader else [])
+        before = be.get_stat("gemm_glu_launches")
+        got = run_graph(be, c, roots, [(x, xv), (tg, wg), (tu, wu), (td_, wd)])
+        fused = be.get_stat("gemm_glu_launches") - before
+        assert (fused == 0) if second_reader else (fused == 1), fused
+        outs.append(got[0].reshape(N, E))
+    cols = rng.choice(N, 64, replace=False)
+    g_ = orc.mul_mat(ty, wg.view(np.uint8).reshape(F, -1), xv[cols]); u_ = orc.mul_mat(ty, wu.view(np.uint8).reshape(F, -1), xv[cols])
+    a_ = (g_ / (1.0 + np.exp(-g_.astype(np.float64)))).astype(np.float32) * u_
+    want = orc.mul_mat(ty, wd.view(np.uint8).reshape(E, -1), a_.astype(np.float32))
+    assert np.isfinite(outs[0]).all()
+    assert nmse(outs[0][cols], want) < 1e-6, nmse(outs[0][cols], want)
+    assert nmse(outs[0], outs[1]) < 1e-9, nmse(outs[0], outs[1])       # fused vs three launches: same arithmetic up to expf / summation details
