@@ -74,6 +74,59 @@ __global__ void __launch_bounds__(256) k_norm_rope(const nr_dev a) {
     }
 }
 
+// Prefill ubatches (D = 128, NEOX pairs (i, i + 64), angles from the per-graph table): 16 lanes per (head, token) row instead of a wave --
+// lane j owns elements 4j .. 4j+3 and 64+4j .. 64+4j+3 (its four rotation pairs), so every access is 16 bytes (f32) / 8 bytes (f16 cache
+// row) and a wave covers four heads; everything a row needs (x, w, angles, cache row index) is requested before the first use.
+// k_norm_rope's arithmetic: sum of squares in double, (x * scale) * w, v0 c - v1 s / v0 s + v1 c, f16 round-to-nearest-even.
+__global__ void __launch_bounds__(256) k_norm_rope_v4(const nr_dev a) {
+    constexpr int D = 128;
+    const int lane = threadIdx.x & 63, sub = lane >> 4, j = lane & 15;
+    const int wid = __builtin_amdgcn_readfirstlane((int) (blockIdx.x * 4 + (threadIdx.x >> 6)));
+    if (wid * 4 >= a.j[a.njobs - 1].wave_end) return;
+    int ji = 0, w0 = 0;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) if (i + 1 < a.njobs && wid * 4 >= a.j[i].wave_end) { ji = i + 1; w0 = a.j[i].wave_end; }   // (every H is a multiple of 4: a wave never straddles jobs)
+    const nr_job J = ji == 0 ? a.j[0] : (ji == 1 ? a.j[1] : a.j[2]);
+    const int lw = wid * 4 + sub - w0;
+    const int h = lw % J.H, t = lw / J.H;
+    const char * xr = J.x + h * J.xnb1 + t * J.xnb2;
+    const f32x4 lo = *(const f32x4 *) (xr + j * 16), hi = *(const f32x4 *) (xr + 256 + j * 16);
+    int64_t row = 0;
+    if (J.kv) row = J.idx_is64 ? *(const int64_t *) (J.idx + t * J.idx_nb0) : (int64_t) *(const int32_t *) (J.idx + t * J.idx_nb0);
+    auto pack = [](const f32x4 v) { u32x2 h; h[0] = (uint32_t) f2h(v[0]) | ((uint32_t) f2h(v[1]) << 16); h[1] = (uint32_t) f2h(v[2]) | ((uint32_t) f2h(v[3]) << 16); return h; };
+    if (J.plain) {                                    // plain store job: f32 -> f16 rows
+        char * kr = J.kv + row * J.kv_rs + (int64_t) h * D * 2;
+        *(u32x2 *) (kr + j * 8) = pack(lo); *(u32x2 *) (kr + 128 + j * 8) = pack(hi);
+        return;
+    }
+    f32x4 wl = { 1.0f, 1.0f, 1.0f, 1.0f }, wh = wl;
+    if (J.w) { wl = *(const f32x4 *) (J.w + 4 * j); wh = *(const f32x4 *) (J.w + 64 + 4 * j); }
+    const float * tb = a.tab + (size_t) t * D + 8 * j;                     // (cos, sin) of pairs 4j .. 4j+3
+    const f32x4 cs0 = *(const f32x4 *) tb, cs1 = *(const f32x4 *) (tb + 4);
+    double ss = 0.0;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { ss += (double) (lo[e] * lo[e]); ss += (double) (hi[e] * hi[e]); }
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);           // the 16 lanes of this row
+    const float mean  = (float) (ss / (double) D);
+    const float scale = 1.0f / sqrtf(mean + a.eps);
+    f32x4 r0, r1;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float v0 = J.w ? (lo[e] * scale) * wl[e] : lo[e], v1 = J.w ? (hi[e] * scale) * wh[e] : hi[e];
+        const float c = e < 2 ? cs0[2 * e] : cs1[2 * e - 4], sn = e < 2 ? cs0[2 * e + 1] : cs1[2 * e - 3];
+        r0[e] = v0 * c - v1 * sn; r1[e] = v0 * sn + v1 * c;
+    }
+    if (J.y) {
+        char * yr = J.y + h * J.ynb1 + t * J.ynb2;
+        *(f32x4 *) (yr + j * 16) = r0; *(f32x4 *) (yr + 256 + j * 16) = r1;
+    }
+    if (J.kv) {
+        char * kr = J.kv + row * J.kv_rs + (int64_t) h * D * 2;
+        *(u32x2 *) (kr + j * 8) = pack(r0); *(u32x2 *) (kr + 128 + j * 8) = pack(r1);
+    }
+}
+
 void rope_table(const int32_t * pos, const float * ff, const rope_params & rp, int T, int D, float * tab, hipStream_t st) {
     const int n = T * (D / 2);
     if (n <= 0) return;
@@ -99,6 +152,16 @@ void norm_rope_store(const norm_rope_args & f, hipStream_t st) {
         d.H = s.H;
         if (i < f.njobs) acc += s.H * f.T;
         d.wave_end = acc;
+    }
+    {   // many tokens, D = 128, NEOX, table angles, 16-byte aligned rows, heads in fours: the 16-lanes-per-row kernel
+        static const bool off = getenv("MI355X_NO_NORM_ROPE_V4") != nullptr;
+        bool v4 = !off && f.D == 128 && f.T >= 16 && (a.rd.mode & GGML_ROPE_TYPE_NEOX) && a.tab != nullptr;
+        for (int i = 0; i < f.njobs && v4; ++i) {
+            const nr_job & d = a.j[i];
+            v4 = d.H % 4 == 0 && ((uintptr_t) d.x & 15) == 0 && d.xnb1 % 16 == 0 && d.xnb2 % 16 == 0 && (!d.w || ((uintptr_t) d.w & 15) == 0) &&
+                 (!d.y || (((uintptr_t) d.y & 15) == 0 && d.ynb1 % 16 == 0 && d.ynb2 % 16 == 0)) && (!d.kv || (((uintptr_t) d.kv & 7) == 0 && d.kv_rs % 8 == 0)) && (!d.plain || d.kv);
+        }
+        if (v4) { k_norm_rope_v4<<<dim3((unsigned) ((acc / 4 + 3) / 4)), dim3(256), 0, st>>>(a); return; }
     }
     dim3 grid((unsigned) ((acc + 3) / 4));
     if (f.D <= 128) k_norm_rope<1><<<grid, dim3(256), 0, st>>>(a);
