@@ -236,7 +236,7 @@ def prefill_tok_s(pkg, be, model, n_tokens=512, reps=3):
         be.synchronize()
         prof = {}
         for cls in ("gemm_f16", "dequant_f16", "mmv_q4k", "mmv_q6k", "act_convert", "rms_norm_mul_quant", "rms_norm_mul", "rms_norm", "norm_rope", "rope",
-                    "fattn", "set_rows", "get_rows", "bin", "glu", "cpy", "empty"):
+                    "fattn", "set_rows", "get_rows", "bin", "glu", "cpy", "soft_max", "dequant_f16", "empty"):
             u, k = be.get_stat(f"prof_{cls}_us"), be.get_stat(f"prof_{cls}_n")
             if k > 0:
                 prof[cls] = {"n": int(k), "total_us": round(u, 1), "avg_event_to_event_us": round(u / k, 2)}
@@ -293,7 +293,7 @@ def c3_prefill(pkg, be, n_seq=8, n_prompt=2048, n_ubatch=512, tiny=False, one_ub
             be.graph_compute(gr)
         be.synchronize()
         prof = {}
-        for cls in ("gemm_f16", "gemm_reduce", "act_convert", "rms_norm_mul", "rms_norm", "norm_rope", "rope", "fattn", "set_rows", "get_rows", "bin", "glu", "cpy",
+        for cls in ("gemm_f16", "gemm_reduce", "act_convert", "rms_norm_mul", "rms_norm", "norm_rope", "rope", "fattn", "set_rows", "get_rows", "bin", "glu", "cpy", "soft_max", "dequant_f16",
                     "mmv_f16", "empty"):
             u, k = be.get_stat(f"prof_{cls}_us"), be.get_stat(f"prof_{cls}_n")
             if k > 0:
@@ -470,6 +470,7 @@ def main():
             try:                                                   # second half of the headline metric: pp512 (reported, not `value`)
                 pp, ok = prefill_tok_s(pkg, be, dec.model)
                 out["pp512_tok_s"] = round(pp, 1) if ok else None
+                out["ttft_ms_pp512"] = round(512.0 / pp * 1e3, 2) if ok else None      # time to first token of a 512-token prompt: one ubatch through the same graphs
             except Exception as e:
                 out["pp512_tok_s"] = None
                 out["pp512_error"] = repr(e)

@@ -1404,6 +1404,21 @@ static bool exec_rms_norm(exec_state & s, int i) {
                 a.j[a.njobs++] = chain_job(s, A);
                 if (bj >= 0) a.j[a.njobs++] = chain_job(s, B);
                 if (vj >= 0) a.j[a.njobs++] = vjob;
+                // flash-attention off, prefill: rope(q) is read (through views) by exactly one per-head MUL_MAT on the MFMA GEMM (K . q): write
+                // its f16 activation image here instead of the f32 rows + a conversion launch
+                const ggml_tensor * q16 = nullptr;
+                if (A.store < 0 && A.T > MI_MMVQ_MAX_COLS && !getenv("MI355X_NO_F16_EMIT")) {
+                    const ggml_tensor * rq = g->nodes[A.rope];
+                    const int u = sole_user(s, rq);                      // (consumers are counted through view chains)
+                    const ggml_tensor * c = u >= 0 ? g->nodes[u] : nullptr;
+                    const ggml_tensor * t = c && c->op == GGML_OP_MUL_MAT ? c->src[1] : nullptr;
+                    const ggml_tensor * base = t;
+                    while (base && base != rq && (base->op == GGML_OP_RESHAPE || base->op == GGML_OP_VIEW || base->op == GGML_OP_PERMUTE || base->op == GGML_OP_TRANSPOSE)) base = base->src[0];
+                    if (t && base == rq && c->src[0] != t && mm_uses_gemm(c) && t->data == rq->data && t->type == GGML_TYPE_F32 && !is_out(s, t) &&
+                        t->ne[0] == A.D && t->ne[1] == A.T && t->ne[2] == A.H && t->ne[3] == 1 && t->nb[0] == 4 && t->nb[1] == (size_t) rq->nb[2] &&
+                        t->nb[2] == (size_t) rq->nb[1] && act_image_bytes(ACT_F16, A.D) * (size_t) (A.T * A.H) <= s.c->act_scratch_bytes) q16 = t;
+                }
+                if (q16) { a.j[0].y = nullptr; a.j[0].y16 = s.c->act_scratch; a.j[0].y16_rs = (int64_t) act_image_bytes(ACT_F16, A.D); }
                 if (A.T >= ROPE_TABLE_MIN_TOKENS && (size_t) A.T * A.D * 4 <= s.c->rope_scratch_bytes) {
                     // prefill: the angles depend on (position, pair) only -- one table per graph instead of sincos per head, layer and chain
                     a.rope_tab = (float *) s.c->rope_scratch;
@@ -1420,6 +1435,12 @@ static bool exec_rms_norm(exec_state & s, int i) {
                 note_write(s, g->nodes[A.store >= 0 ? A.store : A.rope]);
                 if (bj >= 0) note_write(s, g->nodes[B.store >= 0 ? B.store : B.rope]);
                 if (vj >= 0) note_write(s, g->nodes[vj]);
+                if (q16) {                                              // the image of the permuted view [D, T, H] now sits in act_scratch (rows h * T + t)
+                    s.a_src = q16->data; s.a_kind = ACT_F16; s.a_K = q16->ne[0]; s.a_ne[0] = q16->ne[1]; s.a_ne[1] = q16->ne[2]; s.a_ne[2] = q16->ne[3];
+                    s.a_nb[0] = q16->nb[1]; s.a_nb[1] = q16->nb[2]; s.a_nb[2] = q16->nb[3];
+                    s.a_range_lo = (const char *) q16->data; s.a_range_hi = (const char *) q16->data + nbytes(q16);
+                    ++s.n_fused;
+                }
                 return true;
             }
         }
@@ -1677,9 +1698,30 @@ static void compute_node(exec_state & s, int i) {
         }
         case GGML_OP_SOFT_MAX: {
             tdesc m; if (n->src[1]) m = td(n->src[1]);
+            // the probabilities of a prefill ubatch without FLASH_ATTN_EXT feed exactly one MUL_MAT (V^T . P, one product per head) on the MFMA GEMM:
+            // emit its f16 activation image here -- the f32 block is neither written nor converted
+            const ggml_tensor * xg = nullptr;
+            {
+                const int u = s.c->opt_fusion && !is_out(s, n) ? sole_user(s, n) : -1;
+                const ggml_tensor * c = u > i ? g->nodes[u] : nullptr;
+                static const bool off = getenv("MI355X_NO_F16_EMIT") != nullptr;
+                if (!off && c && c->op == GGML_OP_MUL_MAT && c->src[1] == n && c->src[0] != n && mm_uses_gemm(c) && is_contiguous(n) && n->ne[1] > MI_MMVQ_MAX_COLS &&
+                    act_image_bytes(ACT_F16, n->ne[0]) * (size_t) (n->ne[1] * n->ne[2] * n->ne[3]) <= s.c->act_scratch_bytes &&
+                    soft_max_rows_ok(td(n->src[0]), n->src[1] ? &m : nullptr, n->src[1] ? n->src[1]->type : 0, n->src[2] ? (const float *) n->src[2]->data : nullptr, td(n)))
+                    xg = n;
+            }
             prof_scope ps(s, "soft_max", 0);
             soft_max_f32(td(n->src[0]), n->src[1] ? &m : nullptr, n->src[1] ? n->src[1]->type : 0,
-                         n->src[2] ? (const float *) n->src[2]->data : nullptr, td(n), op_param_f32(n, 0), op_param_f32(n, 1), s.st); ++s.n_kernels;
+                         n->src[2] ? (const float *) n->src[2]->data : nullptr, td(n), op_param_f32(n, 0), op_param_f32(n, 1), s.st,
+                         xg ? (uint16_t *) s.c->act_scratch : nullptr, xg ? act_image_bytes(ACT_F16, n->ne[0]) : 0, xg == nullptr);
+            ++s.n_kernels;
+            if (xg) {
+                s.a_src = xg->data; s.a_kind = ACT_F16; s.a_K = xg->ne[0]; s.a_ne[0] = xg->ne[1]; s.a_ne[1] = xg->ne[2]; s.a_ne[2] = xg->ne[3];
+                s.a_nb[0] = xg->nb[1]; s.a_nb[1] = xg->nb[2]; s.a_nb[2] = xg->nb[3];
+                s.a_range_lo = (const char *) xg->data; s.a_range_hi = (const char *) xg->data + nbytes(xg);
+                ++s.n_fused;
+                return;                                             // (no note_write: the f32 block was not written)
+            }
             break;
         }
         case GGML_OP_CPY: case GGML_OP_CONT: case GGML_OP_DUP: {
@@ -1690,7 +1732,21 @@ static void compute_node(exec_state & s, int i) {
                                  (long long) src->ne[2], (long long) src->ne[3], (int) src->type, src->nb[1], src->nb[2], src->nb[3], (int) n->type);
             // CPY writes into src[1]'s storage, which `n` is a view of; n->data is the destination in all three ops
             if ((src->type == GGML_TYPE_F32) != (n->type == GGML_TYPE_F32) && (src->type == GGML_TYPE_I32 || n->type == GGML_TYPE_I32)) cast_f32_i32(td(src), src->type == GGML_TYPE_F32, td(n), s.st);
-            else cpy_strided(td(src), src->type, td(n), n->type, s.st);
+            else {
+                // CONT(PERMUTE(kqv)) of a prefill ubatch whose only readers are MFMA GEMMs (wo): gather straight into the f16 activation image
+                const ggml_tensor * xg = nullptr;
+                if (n->op == GGML_OP_CONT && src->type == GGML_TYPE_F32 && n->type == GGML_TYPE_F32 && n->ne[2] == 1 && n->ne[3] == 1 && n->nb[1] == (size_t) n->ne[0] * 4 &&
+                    n_users(s, n) == 1 && gemm_only_consumers(s, n, n->ne[0], n->ne[1], &xg)) {
+                    tdesc d; d.p = s.c->act_scratch; d.ne[0] = n->ne[0]; d.ne[1] = n->ne[1]; d.ne[2] = 1; d.ne[3] = 1;
+                    const size_t img = act_image_bytes(ACT_F16, n->ne[0]);
+                    d.nb[0] = 2; d.nb[1] = img; d.nb[2] = img * (size_t) n->ne[1]; d.nb[3] = d.nb[2];
+                    cpy_strided(td(src), GGML_TYPE_F32, d, GGML_TYPE_F16, s.st);
+                    ++s.n_kernels; ++s.n_fused;
+                    seed_act_f16(s, xg);
+                    return;                                         // (the f32 copy was not written)
+                }
+                cpy_strided(td(src), src->type, td(n), n->type, s.st);
+            }
             ++s.n_kernels;
             break;
         }
@@ -1701,7 +1757,10 @@ static void compute_node(exec_state & s, int i) {
         }
         case GGML_OP_SET_ROWS: {
             prof_scope ps(s, "set_rows", 0);
-            set_rows(td(n->src[0]), td(n->src[1]), n->src[1]->type, td(n), n->type, s.st); ++s.n_kernels;
+            int64_t period = 0;                                    // single-element rows: the row length of the block the reshape chain started from
+            if (n->src[0]->ne[0] == 1)
+                for (const ggml_tensor * v = n->src[0]->view_src; v; v = v->view_src) if (v->ne[0] > 1) { period = v->ne[0]; break; }
+            set_rows(td(n->src[0]), td(n->src[1]), n->src[1]->type, td(n), n->type, s.st, period); ++s.n_kernels;
             break;
         }
         case GGML_OP_FLASH_ATTN_EXT: {

@@ -115,7 +115,9 @@ struct rope_params {
 };
 void rope_f32(const tdesc & x, const int32_t * pos, const float * freq_factors, const tdesc & y, const rope_params & rp, hipStream_t st);
 // SOFT_MAX (ops.cpp:5072-5182): y = softmax(x*scale + slope*mask)
-void soft_max_f32(const tdesc & x, const tdesc * mask, int mask_type, const float * sinks, const tdesc & y, float scale, float max_bias, hipStream_t st);
+void soft_max_f32(const tdesc & x, const tdesc * mask, int mask_type, const float * sinks, const tdesc & y, float scale, float max_bias, hipStream_t st,
+                  uint16_t * y16 = nullptr, size_t y16_rs = 0, bool write_f32 = true);      // y16: also / only the f16 rows (the next MUL_MAT's activation image); needs soft_max_rows_ok
+bool soft_max_rows_ok(const tdesc & x, const tdesc * mask, int mask_type, const float * sinks, const tdesc & y);
 // GLU (split or single-tensor forms; ops.cpp:2934-2990 for swiglu)
 void glu_f32(int glu_op, const tdesc & a, const tdesc * b, bool swapped, const tdesc & y, hipStream_t st, uint16_t * y16 = nullptr, size_t y16_rs = 0, bool write_f32 = true);
 // SWIGLU (split form) straight into the Q8_K activation images of its rows (+ optionally the f32 result): the GLU of an FFN whose
@@ -143,7 +145,7 @@ void cast_f32_i32(const tdesc & src, bool src_is_f32, const tdesc & dst, hipStre
 void cpy_strided(const tdesc & src, int src_type, const tdesc & dst, int dst_type, hipStream_t st);
 // GET_ROWS (f32 / f16 / quantised tables -> f32), SET_ROWS (f32 -> f32 / f16, i64 or i32 indices)
 void get_rows(const tdesc & src, int src_type, const tdesc & idx, const tdesc & dst, hipStream_t st);
-void set_rows(const tdesc & src, const tdesc & idx, int idx_type, const tdesc & dst, int dst_type, hipStream_t st);
+void set_rows(const tdesc & src, const tdesc & idx, int idx_type, const tdesc & dst, int dst_type, hipStream_t st, int64_t period = 0);   // period: rows r = t * period + j of single-element rows (a work-order hint)
 
 // decode pre-stage of FLASH_ATTN_EXT: the layer's q chain, k chain + store and v store (what norm_rope_store() does in its own launch)
 // executed by the attention kernel itself; one token, one sequence (fattn_pre_ok)
@@ -203,6 +205,8 @@ struct norm_rope_job {
     const void * idx; int idx_is64; int64_t idx_nb0;
     int H;
     int rope_only = 0;                       // w == null and the job still rotates (llama-architecture q / k chains)
+    // optional f16 copy of the rope output as the activation image of a per-head MUL_MAT (flash-attention off: K . q): row h * T + t, y16_rs bytes apart
+    void * y16 = nullptr; int64_t y16_rs = 0;
 };
 struct norm_rope_args {
     norm_rope_job j[3]; int njobs;

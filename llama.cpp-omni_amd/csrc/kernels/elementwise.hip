@@ -513,9 +513,92 @@ __global__ void __launch_bounds__(1024) k_soft_max(td4 x, td4 y, td4 mk, bool ha
     for (int64_t i = threadIdx.x; i < n; i += blockDim.x) yr[i] = buf[i] * inv;
 }
 
-void soft_max_f32(const tdesc & x, const tdesc * mask, int mask_type, const float * sinks, const tdesc & y, float scale, float max_bias, hipStream_t st) {
+// Many short rows (the [n_kv, n_tokens, n_head] score block of a prefill ubatch without FLASH_ATTN_EXT): one WAVE per row, the row in
+// registers, 16-byte accesses, no LDS and no barrier; optionally the f16 rows the following MUL_MAT (V^T . P) wants as its activation image
+// (y16; y.p == null then skips the f32 result).  Same arithmetic as k_soft_max: x * scale + slope * mask, max, expf, sum in double, * (1 / sum).
+template <int MAXV, bool MASK_F16>
+__global__ void __launch_bounds__(256) k_soft_max_rows(td4 x, td4 y, td4 mk, bool has_mask, float scale, float max_bias, float m0, float m1, uint32_t n_head_log2,
+                                                       char * __restrict__ y16, int64_t y16_rs, int64_t nrows) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t) blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= nrows) return;
+    const int64_t i1 = row % x.ne[1], i2 = (row / x.ne[1]) % x.ne[2], i3 = row / (x.ne[1] * x.ne[2]);
+    const int n = (int) x.ne[0];
+    const char * xr = x.p + i1 * x.nb[1] + i2 * x.nb[2] + i3 * x.nb[3];
+    const char * mr = has_mask ? mk.p + i1 * mk.nb[1] + (i2 % mk.ne[2]) * mk.nb[2] + (i3 % mk.ne[3]) * mk.nb[3] : nullptr;
+    const uint32_t h = (uint32_t) i2;
+    const float slope = max_bias > 0.0f ? (h < n_head_log2 ? powf(m0, (float) (h + 1)) : powf(m1, (float) (2 * (h - n_head_log2) + 1))) : 1.0f;
+    f32x4 v[MAXV];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < MAXV; ++k) {
+        const int i = (lane + 64 * k) * 4;
+        v[k] = f32x4{ -INFINITY, -INFINITY, -INFINITY, -INFINITY };
+        if (i < n) {
+            const f32x4 xv = *(const f32x4 *) (xr + (size_t) i * 4);
+            f32x4 m = { 0.0f, 0.0f, 0.0f, 0.0f };
+            if (mr) {
+                if (MASK_F16) { const u32x2 mh = *(const u32x2 *) (mr + (size_t) i * 2); m = f32x4{ h2f((uint16_t) (mh[0] & 0xffff)), h2f((uint16_t) (mh[0] >> 16)), h2f((uint16_t) (mh[1] & 0xffff)), h2f((uint16_t) (mh[1] >> 16)) }; }
+                else m = *(const f32x4 *) (mr + (size_t) i * 4);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { float t = xv[e] * scale; if (mr) t += slope * m[e]; v[k][e] = t; mx = fmaxf(mx, t); }
+        }
+    }
+    mx = wave_max(mx);
+    double sum = 0.0;
+#pragma unroll
+    for (int k = 0; k < MAXV; ++k) {
+        const int i = (lane + 64 * k) * 4;
+        if (i < n) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { const float ex = expf(v[k][e] - mx); v[k][e] = ex; sum += (double) ex; }
+        }
+    }
+    sum = wave_sum<double>(sum);
+    const float inv = (float) (1.0 / sum);
+    char * yr = y.p ? y.p + i1 * y.nb[1] + i2 * y.nb[2] + i3 * y.nb[3] : nullptr;
+    char * hr = y16 ? y16 + row * y16_rs : nullptr;
+#pragma unroll
+    for (int k = 0; k < MAXV; ++k) {
+        const int i = (lane + 64 * k) * 4;
+        if (i >= n) break;
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = v[k][e] * inv;
+        if (yr) *(f32x4 *) (yr + (size_t) i * 4) = o;
+        if (hr) { u32x2 hh; hh[0] = (uint32_t) f2h(o[0]) | ((uint32_t) f2h(o[1]) << 16); hh[1] = (uint32_t) f2h(o[2]) | ((uint32_t) f2h(o[3]) << 16); *(u32x2 *) (hr + (size_t) i * 2) = hh; }
+    }
+}
+
+bool soft_max_rows_ok(const tdesc & x, const tdesc * mask, int mask_type, const float * sinks, const tdesc & y) {
+    const int64_t n = x.ne[0], nrows = x.ne[1] * x.ne[2] * x.ne[3];
+    auto al = [](const tdesc & t, int es) { return ((uintptr_t) t.p & 15) == 0 && t.nb[0] == (size_t) es && t.nb[1] % (es * 4) == 0 && t.nb[2] % (es * 4) == 0 && t.nb[3] % (es * 4) == 0; };
+    if (sinks || nrows < 64 || n % 4 != 0 || n > 2048 || !al(x, 4) || (y.p && !al(y, 4))) return false;
+    if (mask && !al(*mask, mask_type == GGML_TYPE_F16 ? 2 : 4)) return false;
+    if (mask && mask_type == GGML_TYPE_F16 && ((uintptr_t) mask->p & 7) != 0) return false;
+    return true;
+}
+
+void soft_max_f32(const tdesc & x, const tdesc * mask, int mask_type, const float * sinks, const tdesc & y, float scale, float max_bias, hipStream_t st, uint16_t * y16, size_t y16_rs, bool write_f32) {
     if (x.ne[0] * x.ne[1] * x.ne[2] * x.ne[3] == 0) return;
     const int64_t n = x.ne[0];
+    if (soft_max_rows_ok(x, mask, mask_type, sinks, y)) {
+        const int64_t nrows = x.ne[1] * x.ne[2] * x.ne[3];
+        const uint32_t n_head = (uint32_t) x.ne[2];
+        const uint32_t nhl2 = 1u << (uint32_t) floorf(log2f((float) n_head));
+        const float m0 = powf(2.0f, -(max_bias) / nhl2), m1 = powf(2.0f, -(max_bias / 2.0f) / nhl2);
+        td4 yd = to_td4(y); if (!write_f32) yd.p = nullptr;
+        td4 mk = mask ? to_td4(*mask) : to_td4(x);
+        const dim3 grid((unsigned) ((nrows + 3) / 4));
+        const bool mh = mask && mask_type == GGML_TYPE_F16;
+#define SM_GO(V) do { if (mh) k_soft_max_rows<V, true><<<grid, dim3(256), 0, st>>>(to_td4(x), yd, mk, mask != nullptr, scale, max_bias, m0, m1, nhl2, (char *) y16, (int64_t) y16_rs, nrows); \
+                      else    k_soft_max_rows<V, false><<<grid, dim3(256), 0, st>>>(to_td4(x), yd, mk, mask != nullptr, scale, max_bias, m0, m1, nhl2, (char *) y16, (int64_t) y16_rs, nrows); } while (0)
+        if (n <= 512) SM_GO(2); else if (n <= 1024) SM_GO(4); else SM_GO(8);
+#undef SM_GO
+        return;
+    }
+    if (y16) { fprintf(stderr, "[mi355x] soft_max: f16 emission needs the row kernel (soft_max_rows_ok)\n"); abort(); }
     int bs = n <= 64 ? 64 : n <= 1024 ? 256 : 1024;
     const uint32_t n_head = (uint32_t) x.ne[2];
     const uint32_t n_head_log2 = 1u << (uint32_t) floorf(log2f((float) n_head));
@@ -841,8 +924,54 @@ __global__ void __launch_bounds__(256) k_set_rows(td4 s, td4 idx, td4 d) {
     TD *          dr = (TD *) (d.p + i1 * d.nb[1] + i02 * d.nb[2] + i03 * d.nb[3]);
     for (int64_t c = threadIdx.x; c < s.ne[0]; c += blockDim.x) dr[c] = cvt_elem<float, TD>(sr[c]);
 }
-void set_rows(const tdesc & src, const tdesc & idx, int idx_type, const tdesc & dst, int dst_type, hipStream_t st) {
+// Single-element rows (the transposed V cache of the flash-attention-off graphs: llama-kv-cache.cpp:1091-1109 scatters every element of a
+// [n_embd_v_gqa, n_tokens] block to index d * kv_size + cell): one workgroup per row would be half a million 64-thread workgroups per layer
+// at ubatch 512 (115 us).  Rows r = t * P + j are read coalesced along j, and -- after a 64 x 64 exchange through LDS -- written along t,
+// where the reference's indices are consecutive cells: coalesced on both sides whenever the indices have that shape, correct for any indices
+// (P only orders the work).
+template <typename TD, typename TI>
+__global__ void __launch_bounds__(256) k_set_rows_1elem(const char * __restrict__ src, int64_t s_rs, const char * __restrict__ idx, int64_t i_rs, char * __restrict__ dst, int64_t d_rs, int P, int T) {
+    __shared__ TD v[64][65];
+    __shared__ long long ix[64][65];
+    const int j0 = blockIdx.x * 64, t0 = blockIdx.y * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+#pragma unroll 4
+    for (int k = 0; k < 16; ++k) {
+        const int tl = ty + 4 * k, t = t0 + tl, j = j0 + tx;
+        if (t < T && j < P) {
+            const int64_t r = (int64_t) t * P + j;
+            v[tl][tx] = cvt_elem<float, TD>(*(const float *) (src + r * s_rs));
+            ix[tl][tx] = (long long) *(const TI *) (idx + r * i_rs);
+        }
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int k = 0; k < 16; ++k) {
+        const int jl = ty + 4 * k, t = t0 + tx, j = j0 + jl;
+        if (t < T && j < P) *(TD *) (dst + ix[tx][jl] * d_rs) = v[tx][jl];
+    }
+}
+
+void set_rows(const tdesc & src, const tdesc & idx, int idx_type, const tdesc & dst, int dst_type, hipStream_t st, int64_t period) {
     if (src.ne[0] * src.ne[1] * src.ne[2] * src.ne[3] == 0) return;
+    if (src.ne[0] == 1 && src.ne[2] == 1 && src.ne[3] == 1 && src.ne[1] >= 4096 && (dst_type == GGML_TYPE_F16 || dst_type == GGML_TYPE_F32) && idx.ne[1] * idx.ne[2] * idx.ne[3] == 1) {
+        const int64_t R = src.ne[1];
+        int64_t P = period > 0 && R % period == 0 ? period : (R % 1024 == 0 ? 1024 : (R % 64 == 0 ? 64 : 1));
+        if (P > 1 && R / P <= 0x7fffffff && P <= 0x7fffffff) {
+            const int T = (int) (R / P);
+            const dim3 grid((unsigned) ((P + 63) / 64), (unsigned) ((T + 63) / 64));
+            const bool i64 = idx_type == GGML_TYPE_I64;
+            const char * sp = (const char *) src.p; const char * ip = (const char *) idx.p; char * dp = (char *) dst.p;
+            if (dst_type == GGML_TYPE_F16) {
+                if (i64) k_set_rows_1elem<uint16_t, int64_t><<<grid, dim3(256), 0, st>>>(sp, (int64_t) src.nb[1], ip, (int64_t) idx.nb[0], dp, (int64_t) dst.nb[1], (int) P, T);
+                else     k_set_rows_1elem<uint16_t, int32_t><<<grid, dim3(256), 0, st>>>(sp, (int64_t) src.nb[1], ip, (int64_t) idx.nb[0], dp, (int64_t) dst.nb[1], (int) P, T);
+            } else {
+                if (i64) k_set_rows_1elem<float, int64_t><<<grid, dim3(256), 0, st>>>(sp, (int64_t) src.nb[1], ip, (int64_t) idx.nb[0], dp, (int64_t) dst.nb[1], (int) P, T);
+                else     k_set_rows_1elem<float, int32_t><<<grid, dim3(256), 0, st>>>(sp, (int64_t) src.nb[1], ip, (int64_t) idx.nb[0], dp, (int64_t) dst.nb[1], (int) P, T);
+            }
+            return;
+        }
+    }
     dim3 grid((unsigned) src.ne[1], (unsigned) src.ne[2], (unsigned) src.ne[3]);
     const int bs = src.ne[0] <= 64 ? 64 : 256;
     const td4 s = to_td4(src), i = to_td4(idx), d = to_td4(dst);

@@ -16,6 +16,7 @@ struct nr_job {
     const float * w;                                  // [D] norm weight; null = no norm
     int plain;                                        // plain f32 -> f16 store job (no norm, no rope)
     char * y; int64_t ynb1, ynb2;                     // f32 rope output (may be null)
+    char * y16; int64_t y16_rs;                       // f16 rope output as image rows h * T + t (may be null)
     char * kv; int64_t kv_rs;                         // f16 table base + row stride (may be null)
     const char * idx; int idx_is64; int64_t idx_nb0;  // row index per token
     int H; int wave_end;                              // waves [prev.wave_end, wave_end) belong to this job
@@ -71,6 +72,10 @@ __global__ void __launch_bounds__(256) k_norm_rope(const nr_dev a) {
             uint16_t * kr = (uint16_t *) (J.kv + row * J.kv_rs) + (int64_t) h * a.D;
             kr[e0[q]] = f2h(r0[q]); kr[e1[q]] = f2h(r1[q]);
         }
+        if (J.y16) {
+            uint16_t * hr = (uint16_t *) (J.y16 + ((int64_t) h * a.T + t) * J.y16_rs);
+            hr[e0[q]] = f2h(r0[q]); hr[e1[q]] = f2h(r1[q]);
+        }
     }
 }
 
@@ -125,6 +130,10 @@ __global__ void __launch_bounds__(256) k_norm_rope_v4(const nr_dev a) {
         char * kr = J.kv + row * J.kv_rs + (int64_t) h * D * 2;
         *(u32x2 *) (kr + j * 8) = pack(r0); *(u32x2 *) (kr + 128 + j * 8) = pack(r1);
     }
+    if (J.y16) {
+        char * hr = J.y16 + ((int64_t) h * a.T + t) * J.y16_rs;
+        *(u32x2 *) (hr + j * 8) = pack(r0); *(u32x2 *) (hr + 128 + j * 8) = pack(r1);
+    }
 }
 
 void rope_table(const int32_t * pos, const float * ff, const rope_params & rp, int T, int D, float * tab, hipStream_t st) {
@@ -147,7 +156,7 @@ void norm_rope_store(const norm_rope_args & f, hipStream_t st) {
         const norm_rope_job & s = f.j[i < f.njobs ? i : 0];
         nr_job & d = a.j[i];
         d.x = (const char *) s.x; d.xnb1 = s.xnb1; d.xnb2 = s.xnb2; d.w = s.w; d.plain = (!s.w && !s.rope_only) ? 1 : 0;
-        d.y = (char *) s.y; d.ynb1 = s.ynb1; d.ynb2 = s.ynb2;
+        d.y = (char *) s.y; d.ynb1 = s.ynb1; d.ynb2 = s.ynb2; d.y16 = (char *) s.y16; d.y16_rs = s.y16_rs;
         d.kv = (char *) s.kv; d.kv_rs = s.kv_rs; d.idx = (const char *) s.idx; d.idx_is64 = s.idx_is64; d.idx_nb0 = s.idx_nb0;
         d.H = s.H;
         if (i < f.njobs) acc += s.H * f.T;
@@ -159,7 +168,7 @@ void norm_rope_store(const norm_rope_args & f, hipStream_t st) {
         for (int i = 0; i < f.njobs && v4; ++i) {
             const nr_job & d = a.j[i];
             v4 = d.H % 4 == 0 && ((uintptr_t) d.x & 15) == 0 && d.xnb1 % 16 == 0 && d.xnb2 % 16 == 0 && (!d.w || ((uintptr_t) d.w & 15) == 0) &&
-                 (!d.y || (((uintptr_t) d.y & 15) == 0 && d.ynb1 % 16 == 0 && d.ynb2 % 16 == 0)) && (!d.kv || (((uintptr_t) d.kv & 7) == 0 && d.kv_rs % 8 == 0)) && (!d.plain || d.kv);
+                 (!d.y || (((uintptr_t) d.y & 15) == 0 && d.ynb1 % 16 == 0 && d.ynb2 % 16 == 0)) && (!d.kv || (((uintptr_t) d.kv & 7) == 0 && d.kv_rs % 8 == 0)) && (!d.plain || d.kv) && (!d.y16 || (((uintptr_t) d.y16 & 7) == 0 && d.y16_rs % 8 == 0));
         }
         if (v4) { k_norm_rope_v4<<<dim3((unsigned) ((acc / 4 + 3) / 4)), dim3(256), 0, st>>>(a); return; }
     }
