@@ -1,0 +1,159 @@
+"""Round-2 prefill kernels, each against the REFERENCE CPU backend on the same graph (oracle/_ref) or numpy:
+the eight-phase 256 x 256 GEMM at ragged shapes and odd K-step counts, the wave-per-row RMS_NORM / SOFT_MAX (incl. the f16 activation image they
+emit for the next MUL_MAT), the transposing single-element SET_ROWS with arbitrary indices, and the 16-lanes-per-row norm / rope kernel."""
+import numpy as np
+import pytest
+
+from conftest import nmse
+
+pytestmark = pytest.mark.gpu
+
+
+def _both(pkg, be, ref_be, build, feeds):
+    res = []
+    for backend in (be, ref_be):
+        c = pkg.Context(backend)
+        ins, outs = build(c)
+        c.alloc()
+        for name, t in ins.items():
+            backend.tensor_set(t, feeds[name])
+        backend.graph_compute(c.graph())
+        res.append([backend.tensor_get(o).copy() for o in outs])
+        c.free()
+    return res
+
+
+@pytest.mark.parametrize("M,N,K", [(8190, 4090, 320), (4096, 4096, 1088), (8192, 2048, 64)])
+def test_eight_phase_gemm_full_result_ragged_and_odd_ksteps(pkg, be, M, N, K):
+    """k_gemm_f16_ph8: every output element (not a sample) against numpy on f16-rounded activations, with tile rows / columns past M / N
+    (clamped DMA sources, guarded stores), an odd number of K-steps (the unrolled pair loop's tail) and a single K-step (prologue only);
+    six repetitions must be bit-identical (the schedule's RAW / WAR distances do not depend on timing)."""
+    from test_gpu_parity import run_graph  # noqa: F401
+    rng = np.random.default_rng(M + N + K)
+    wv = (rng.standard_normal((M, K)) * 0.05).astype(np.float16)
+    xv = rng.standard_normal((N, K)).astype(np.float32)
+    c = pkg.Context(be)
+    w = c.new_tensor(pkg.GGML_TYPE_F16, K, M); x = c.new_tensor(pkg.GGML_TYPE_F32, K, N)
+    y = c.mul_mat(w, x)
+    c.alloc()
+    be.tensor_set(w, wv); be.tensor_set(x, xv)
+    before = be.get_stat("gemm256_launches")
+    outs = []
+    for _ in range(6):
+        be.graph_compute(c.graph())
+        outs.append(be.tensor_get(y).copy().reshape(N, M))
+    assert be.get_stat("gemm256_launches") - before == 6, "the shape did not select the 256 x 256 kernel"
+    c.free()
+    want = xv.astype(np.float16).astype(np.float32) @ wv.astype(np.float32).T
+    assert np.isfinite(outs[0]).all()
+    assert np.abs(outs[0] - want).max() <= 2e-5 * max(1.0, np.abs(want).max()) * np.sqrt(K / 64)
+    for o in outs[1:]:
+        assert np.array_equal(outs[0], o)
+
+
+@pytest.mark.parametrize("n,rows", [(4096, 700), (1152, 333), (8192, 65), (2048, 64)])
+def test_rms_norm_rows_vs_reference_backend(pkg, be, ref_be, n, rows):
+    rng = np.random.default_rng(n)
+
+    def build(c):
+        x = c.new_tensor(pkg.GGML_TYPE_F32, n, rows); w = c.new_tensor(pkg.GGML_TYPE_F32, n)
+        return dict(x=x, w=w), [c.mul(c.rms_norm(x, 1e-6), w), c.rms_norm(x, 1e-5)]
+    feeds = dict(x=(rng.standard_normal(n * rows) * 3).astype(np.float32), w=(1 + 0.1 * rng.standard_normal(n)).astype(np.float32))
+    got, want = _both(pkg, be, ref_be, build, feeds)
+    for g, w in zip(got, want):
+        assert nmse(g, w) < 1e-13, nmse(g, w)
+
+
+@pytest.mark.parametrize("n,mask_type", [(512, "f32"), (1000, "f16"), (2048, "f32"), (256, None)])
+def test_soft_max_rows_and_its_f16_image_vs_reference_backend(pkg, be, ref_be, n, mask_type):
+    """SOFT_MAX over [n, 96, 6] with a causal-style mask (rows with -inf tails), alone (f32 result) and followed by the per-head MUL_MAT that
+    makes the kernel emit the f16 activation image instead of the f32 block (V^T . P of the flash-attention-off graph)."""
+    rng = np.random.default_rng(n)
+    T, H, D = 96, 6, 64
+    F32, F16 = pkg.GGML_TYPE_F32, pkg.GGML_TYPE_F16
+
+    def build(c):
+        x = c.new_tensor(F32, n, T, H)
+        ins = dict(x=x)
+        m = None
+        if mask_type:
+            m = c.new_tensor(F16 if mask_type == "f16" else F32, n, T)
+            ins["m"] = m
+        vt = c.new_tensor(F16, n, D, H)
+        ins["vt"] = vt
+        p = c.soft_max_ext(x, m, 0.125, 0.0)
+        p2 = c.soft_max_ext(c.scale(x, 1.0), m, 0.125, 0.0)
+        return ins, [p, c.mul_mat(vt, p2)]
+    mask = np.zeros((T, n), np.float32)
+    for t in range(T):
+        mask[t, 1 + (t * 7) % n:] = -np.inf
+    feeds = dict(x=(rng.standard_normal(n * T * H) * 4).astype(np.float32), vt=rng.standard_normal(n * D * H).astype(np.float16))
+    if mask_type:
+        feeds["m"] = mask.astype(np.float16 if mask_type == "f16" else np.float32).ravel()
+    got, want = _both(pkg, be, ref_be, build, feeds)
+    assert np.isfinite(got[0]).all() and np.isfinite(got[1]).all()
+    assert nmse(got[0], want[0]) < 1e-12, nmse(got[0], want[0])
+    assert nmse(got[1], want[1]) < 1e-6, nmse(got[1], want[1])          # f16-rounded probabilities, f32 accumulate: the reference's MUL_MAT bar is 5e-4
+
+
+@pytest.mark.parametrize("structured", [True, False])
+def test_set_rows_single_element_rows_any_indices(pkg, be, structured):
+    """SET_ROWS with one-element rows (the transposed V cache scatter, llama-kv-cache.cpp:1091-1109): the transposing kernel orders its work
+    by a period hint taken from the reshape chain; the result must not depend on it -- the reference's index pattern (d * kv_size + cell)
+    and a random permutation, with and without a reshape chain to take the hint from."""
+    rng = np.random.default_rng(5)
+    nv, T, kv = 1024, 40, 96
+    R = nv * T
+    src = rng.standard_normal(R).astype(np.float32)
+    if structured:
+        cells = rng.permutation(kv)[:T].astype(np.int64)
+        idx = (np.arange(nv, dtype=np.int64)[None, :] * kv + cells[:, None]).ravel()
+    else:
+        idx = rng.permutation(nv * kv)[:R].astype(np.int64)
+    for chain in (True, False):
+        c = pkg.Context(be)
+        cache = c.new_tensor(pkg.GGML_TYPE_F16, 1, nv * kv)
+        if chain:
+            v = c.new_tensor(pkg.GGML_TYPE_F32, nv, T)
+            s1 = c.reshape(v, 1, R)
+        else:
+            v = c.new_tensor(pkg.GGML_TYPE_F32, 1, R)
+            s1 = v
+        ix = c.new_tensor(pkg.GGML_TYPE_I64, R)
+        out = c.set_rows(cache, s1, ix)
+        c.alloc()
+        be.tensor_set(cache, np.zeros(nv * kv, np.float16)); be.tensor_set(v, src); be.tensor_set(ix, idx)
+        be.graph_compute(c.graph())
+        got = be.tensor_get(out).copy().ravel()
+        c.free()
+        want = np.zeros(nv * kv, np.float16)
+        want[idx] = src.astype(np.float16)
+        assert np.array_equal(got.view(np.uint16), want.view(np.uint16)), (structured, chain)
+
+
+@pytest.mark.parametrize("T,H,HK", [(64, 32, 8), (19, 8, 4)])
+def test_norm_rope_prefill_chains_vs_reference_backend(pkg, be, ref_be, T, H, HK):
+    """The q chain (RMS_NORM -> MUL -> ROPE neox), the k chain + SET_ROWS into an f16 cache and the plain v SET_ROWS of a prefill ubatch at head
+    size 128 (one k_norm_rope_v4 launch: 16 lanes per row) against the reference CPU backend: rope output and both cache tables."""
+    rng = np.random.default_rng(T)
+    D, n_ctx = 128, 256
+    F32, F16, I32, I64 = pkg.GGML_TYPE_F32, pkg.GGML_TYPE_F16, pkg.GGML_TYPE_I32, pkg.GGML_TYPE_I64
+    rope = dict(n_dims=D, mode=2, n_ctx_orig=40960, freq_base=1e6, freq_scale=1.0, ext_factor=0.0, attn_factor=1.0, beta_fast=32.0, beta_slow=1.0)
+
+    def build(c):
+        q = c.new_tensor(F32, D, H, T); k = c.new_tensor(F32, D, HK, T); v = c.new_tensor(F32, D, HK, T)
+        qw = c.new_tensor(F32, D); kw = c.new_tensor(F32, D); pos = c.new_tensor(I32, T); idx = c.new_tensor(I64, T)
+        kc = c.new_tensor(F16, HK * D, n_ctx); vc = c.new_tensor(F16, HK * D, n_ctx)
+        Q = c.rope_ext(c.mul(c.rms_norm(q, 1e-6), qw), pos, None, **rope)
+        K = c.rope_ext(c.mul(c.rms_norm(k, 1e-6), kw), pos, None, **rope)
+        ks = c.set_rows(kc, c.view_2d(K, HK * D, T, K.nb[2], 0), idx)
+        vs = c.set_rows(vc, c.view_2d(v, HK * D, T, v.nb[2], 0), idx)
+        return dict(q=q, k=k, v=v, qw=qw, kw=kw, pos=pos, idx=idx, kc=kc, vc=vc), [Q, ks, vs]
+    cells = rng.permutation(n_ctx)[:T].astype(np.int64)
+    feeds = dict(q=rng.standard_normal(D * H * T).astype(np.float32), k=rng.standard_normal(D * HK * T).astype(np.float32), v=rng.standard_normal(D * HK * T).astype(np.float32),
+                 qw=(1 + 0.1 * rng.standard_normal(D)).astype(np.float32), kw=(1 + 0.1 * rng.standard_normal(D)).astype(np.float32),
+                 pos=(np.arange(T) * 3 + 5).astype(np.int32), idx=cells, kc=np.zeros(HK * D * n_ctx, np.float16), vc=np.zeros(HK * D * n_ctx, np.float16))
+    got, want = _both(pkg, be, ref_be, build, feeds)
+    assert nmse(got[0], want[0]) < 1e-10, nmse(got[0], want[0])
+    assert nmse(got[1].astype(np.float32), want[1].astype(np.float32)) < 1e-6                     # f16 cache rows: a last-bit angle difference may flip a rounding
+    assert np.array_equal(got[2].view(np.uint16), want[2].view(np.uint16))                          # v: a pure f32 -> f16 store
