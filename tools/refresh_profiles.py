@@ -12,8 +12,8 @@ import sys
 P = sys.argv[1]
 TAG = sys.argv[2] if len(sys.argv) > 2 else "r02"
 COMMIT = sys.argv[3] if len(sys.argv) > 3 else None
-stats = glob.glob(P + "/trace/**/*kernel_stats.csv", recursive=True)[0]
-pmc = glob.glob(P + "/pmc/**/*counter_collection.csv", recursive=True)[0]
+stats = max(glob.glob(P + "/trace/**/*kernel_stats.csv", recursive=True), key=os.path.getmtime)      # (gpurun merges every run into the same local directory: newest)
+pmc = max(glob.glob(P + "/pmc/**/*counter_collection.csv", recursive=True), key=os.path.getmtime)
 shutil.copy(stats, "profiles/" + TAG + "_kernel_stats.csv")
 shutil.copy(P + "/bench_under_rocprof.json", "profiles/" + TAG + "_bench_under_rocprof.json")
 if os.path.exists("gpurun_out/bench_default.json"):
