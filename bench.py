@@ -339,7 +339,63 @@ def extra_legs(pkg, be, headline_no_fa):
             dec.g.free(); dec.model.wctx.free()
     except Exception as e:  # extras never cost the headline
         res["error"] = repr(e)
+    try:
+        res["omni_modules"] = omni_module_legs(pkg, be)
+    except Exception as e:
+        res["omni_modules_error"] = repr(e)
     return res
+
+
+def omni_module_legs(pkg, be):
+    """SURVEY.md 8(f) ranks 3 / 4 measured beside the headline: one layer of each omni encoder and the Token2Wav blocks at their real shapes
+    (the graphs of llama.cpp-omni_amd/encoders.py / token2wav.py, random weights), best of 5 submissions between two HIP events; the
+    per-module figure is that layer time x the module's layer count (front ends / tails included once)."""
+    from llama_cpp_omni_amd import encoders as E, token2wav as T
+    rng = np.random.default_rng(99)
+
+    def timed(c, tensors):
+        c.alloc()
+        for t in tensors:
+            n = t.nelements()
+            v = (rng.standard_normal(n) * 0.05).astype(np.float32)
+            be.tensor_set(t, v.astype(np.float16) if t.type == 1 else (np.abs(v) + 0.5 if t.type == 0 and n <= 4096 else v) if t.type == 0 else np.zeros(n, np.int32))
+        g = c.graph()
+        for _ in range(2):
+            be.graph_compute(g)
+        be.synchronize()
+        best = 1e9
+        for _ in range(5):
+            a, b = be.timed_event(), be.timed_event()
+            be.record(a); be.graph_compute(g); be.record(b)
+            best = min(best, be.elapsed_ms(a, b))
+        k = be.get_stat("kernels_last_graph")
+        c.free()
+        return round(best, 4), int(k)
+
+    def flat(W):
+        out = [v for k, v in W.items() if k != "layers" and hasattr(v, "nelements")]
+        for L in W.get("layers", []):
+            out += list(L.values())
+        return out
+    out = {}
+    c = pkg.Context(be)
+    W = E.whisper_weights(c, E.WHISPER, 1); inp, _ = E.whisper(c, E.WHISPER, W, 3000)
+    ms, k = timed(c, flat(W) + [inp])
+    out["whisper_apm_front_1layer_tail_ms"] = ms; out["whisper_kernels"] = k
+    c = pkg.Context(be)
+    W = E.siglip2_weights(c, E.SIGLIP2, 1); inp, vit = E.siglip2(c, E.SIGLIP2, W)
+    Wr = E.resampler_weights(c, E.RESAMPLER); pe, _ = E.resampler(c, E.RESAMPLER, Wr, vit, (E.SIGLIP2["image"] // E.SIGLIP2["patch"]) ** 2)
+    ms, k = timed(c, flat(W) + flat(Wr) + [inp, pe])
+    out["siglip2_vpm_embed_1layer_resampler_ms"] = ms; out["siglip2_kernels"] = k
+    c = pkg.Context(be)
+    W = T.dit_weights(c, T.DIT); x, cond, _ = T.dit_block(c, T.DIT, W, 200)
+    ms, k = timed(c, flat(W) + [x, cond])
+    out["token2wav_dit_block_200_frames_ms"] = ms; out["dit_kernels"] = k
+    c = pkg.Context(be)
+    W = T.hift_weights(c, T.HIFT); x, _ = T.hift_upsample_stage(c, T.HIFT, W, 120)
+    ms, k = timed(c, flat(W) + [x])
+    out["token2wav_hift_stage_120_frames_ms"] = ms; out["hift_kernels"] = k
+    return out
 
 
 class Replicas:

@@ -485,6 +485,32 @@ static void op_mul_mat(exec_state & s, const ggml_tensor * dst) {
     }
 
     const act_kind kind = act_kind_for(w->type);
+    // more than 8 columns against F32 weights, or F16 weights with a contraction length the F16 GEMM does not take (the omni encoders, Token2Wav):
+    // one f32-MFMA launch over every (head, batch) instead of a mat-vec launch per 8 columns per head
+    static const bool no_gemm_any = getenv("MI355X_NO_GEMM_ANY") != nullptr;
+    if (!no_gemm_any && (w->type == GGML_TYPE_F32 || w->type == GGML_TYPE_F16) && N > MI_MMVQ_MAX_COLS &&
+        ((x->type == GGML_TYPE_F32 && x->nb[0] == 4) || (x->type == GGML_TYPE_F16 && x->nb[0] == 2 && w->type == GGML_TYPE_F16)) && w->nb[0] == (w->type == GGML_TYPE_F16 ? 2u : 4u) && dst->nb[0] == 4 && ne12 * ne13 <= 65535 && M < (1ll << 31) && N < (1ll << 31) && K < (1ll << 31)) {
+        if (s.pn.m && x == s.pn.m) materialise_norm(s);
+        gemm_any_args a;
+        int64_t k_done = 0;
+        // F16 weights, K a few columns past a multiple of 64 (SigLip2's n_ff 4304): the F16 MFMA GEMM takes the first K - K % 64 columns, this kernel adds the tail
+        if (w->type == GGML_TYPE_F16 && x->type == GGML_TYPE_F32 && ne12 * ne13 == 1 && K % 64 != 0 && K >= 512 && w->nb[1] % 16 == 0 && ((uintptr_t) w->data & 15) == 0 &&
+            dst->nb[1] % 16 == 0 && act_image_bytes(ACT_F16, K) * (size_t) N <= s.c->act_scratch_bytes) {
+            const size_t ximg = prepare_act(s, x, ACT_F16);
+            k_done = K - K % 64;
+            prof_scope ps(s, "gemm_f16", 2.0 * (double) M * (double) N * (double) k_done);
+            gemm_f16_mfma((const uint16_t *) w->data, w->nb[1], (const uint16_t *) s.c->act_scratch, ximg, (float *) dst->data, dst->nb[1], M, N, k_done, s.st);
+            ++s.n_kernels;
+        }
+        a.W = (const char *) w->data + k_done * (w->type == GGML_TYPE_F16 ? 2 : 4); a.w_rs = w->nb[1]; a.w_nb2 = w->nb[2]; a.w_nb3 = w->nb[3]; a.w_f16 = w->type == GGML_TYPE_F16;
+        a.X = (const char *) x->data + k_done * (x->type == GGML_TYPE_F16 ? 2 : 4); a.x_rs = x->nb[1]; a.x_nb2 = x->nb[2]; a.x_nb3 = x->nb[3]; a.x_f16 = x->type == GGML_TYPE_F16;
+        a.dst = (float *) dst->data; a.dst_cs = dst->nb[1]; a.dst_nb2 = dst->nb[2]; a.dst_nb3 = dst->nb[3]; a.accumulate = k_done > 0;
+        a.M = M; a.N = N; a.K = K - k_done; a.nbatch = (int) (ne12 * ne13); a.ne12 = (int) ne12; a.r2 = (int) r2; a.r3 = (int) r3;
+        prof_scope ps(s, w->type == GGML_TYPE_F16 ? "gemm_any_f16" : "gemm_any_f32", 2.0 * (double) M * (double) N * (double) (K - k_done) * (double) (ne12 * ne13));
+        gemm_any(a, s.st);
+        ++s.n_kernels;
+        return;
+    }
     const size_t img = prepare_act(s, x, kind);
 
     const double wbytes = (double) M * (double) row_size(w->type, K);

@@ -245,5 +245,14 @@ void   gemm_f16_multi(const gemm_multi_args & a, hipStream_t st);
 size_t gemm_split_scratch_bytes(int64_t M, int64_t N, int64_t K);
 long   gemm_variant_launches(int v);      // launches so far of the 256 x 256 (0) / 192-row (1) / gate-up-SWIGLU (2) tile kernels (test instrumentation)
 bool   gemm_glu_ok(const gemm_multi_args & a);
+// any-shape f32-MFMA GEMM (gemm_any.hip): F32 weights, or F16 weights whose K the F16 GEMM does not take; X f32 rows (rounded to f16 when w_f16)
+struct gemm_any_args {
+    const void * W; size_t w_rs, w_nb2 = 0, w_nb3 = 0; bool w_f16;
+    const void * X; size_t x_rs, x_nb2 = 0, x_nb3 = 0; bool x_f16 = false;     // f32 rows, or f16 rows (with F16 weights)
+    float * dst; size_t dst_cs, dst_nb2 = 0, dst_nb3 = 0;
+    int64_t M, N, K; int nbatch = 1, ne12 = 1, r2 = 1, r3 = 1;
+    bool accumulate = false;                 // dst += W.X (the K tail behind a gemm_f16 launch over the first K - K % 64 columns)
+};
+void   gemm_any(const gemm_any_args & a, hipStream_t st);
 
 } // namespace mi

@@ -1,0 +1,87 @@
+// gemm_any.hip -- MUL_MAT with more than 8 columns for the operand shapes the F16 MFMA GEMM (gemm.hip) does not take: F32 weights (the
+// Token2Wav graphs are all-F32; SigLip2's K . Q^T, tools/omni/vision.cpp:648-703) and F16 weights whose contraction length is not a
+// multiple of 32 (Whisper's V^T . P over 1500 frames, audition.cpp:600-640).  Before this kernel those mat-muls ran as mat-vecs in chunks
+// of 8 columns: 3136 launches / 86 ms for ONE Whisper encoder layer, 4608 / 56 ms for one SigLip2 layer.
+//
+//     dst[n][m] = sum_k W[m][k] * X[n][k]      W: F32 or F16 rows, X: f32 rows (rounded to f16 first when W is F16 -- the reference's
+//                                              vec_dot_type conversion, ggml-cpu.c:1245-1268), f32 accumulate
+// on v_mfma_f32_32x32x2f32: f32 x f32 fused multiply-add into f32, i.e. the CPU's arithmetic (ggml_vec_dot_f32 / _f16 accumulate in f32
+// FMA lanes), only the summation order differs.  Any M, N, K >= 1 (tiles are zero-filled past the edges), rows K-contiguous with any
+// row stride, broadcast batch over dims 2, 3 like ggml_compute_forward_mul_mat.  Workgroup = 4 waves on a 64 x 64 tile, 16-wide K-steps
+// staged through LDS (padded rows, single buffer: these matrices are small -- the point is one launch instead of thousands).
+#include "../kernels.hpp"
+
+namespace mi {
+
+typedef float ga_acc __attribute__((ext_vector_type(16)));
+
+struct gemm_any_dev {
+    const char * W; size_t w_rs, w_nb2, w_nb3;
+    const char * X; size_t x_rs, x_nb2, x_nb3;
+    char * dst; size_t dst_cs, dst_nb2, dst_nb3;
+    int M, N, K, tiles_m, ne12, r2, r3, round_x, accumulate;
+};
+
+template <typename WT, typename XT>
+__global__ void __launch_bounds__(256) k_gemm_any(const gemm_any_dev g) {
+    constexpr int KS = 16, LD = KS + 1;
+    __shared__ float Ws[64 * LD], Xs[64 * LD];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, wm = wave & 1, wn = wave >> 1;
+    const int tm = (int) blockIdx.x % g.tiles_m, tn = (int) blockIdx.x / g.tiles_m;
+    const int i12 = (int) blockIdx.y % g.ne12, i13 = (int) blockIdx.y / g.ne12;
+    const char * W = g.W + (size_t) (i12 / g.r2) * g.w_nb2 + (size_t) (i13 / g.r3) * g.w_nb3;
+    const char * X = g.X + (size_t) i12 * g.x_nb2 + (size_t) i13 * g.x_nb3;
+    const int m0 = tm * 64, n0 = tn * 64;
+    ga_acc acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.0f;
+    const int fr = lane & 31, kh = lane >> 5;
+    for (int k0 = 0; k0 < g.K; k0 += KS) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int e = t + 256 * i, r = e >> 4, c = e & 15, k = k0 + c;
+            float wv = 0.0f, xv = 0.0f;
+            if (k < g.K) {
+                if (m0 + r < g.M) {
+                    const char * p = W + (size_t) (m0 + r) * g.w_rs + (size_t) k * sizeof(WT);
+                    wv = sizeof(WT) == 2 ? h2f(*(const uint16_t *) p) : *(const float *) p;
+                }
+                if (n0 + r < g.N) {
+                    const char * p = X + (size_t) (n0 + r) * g.x_rs + (size_t) k * sizeof(XT);
+                    if (sizeof(XT) == 2) xv = h2f(*(const uint16_t *) p);                     // F16 x F16: the im2col columns of the encoders' convolutions
+                    else { xv = *(const float *) p; if (g.round_x) xv = h2f(f2h(xv)); }
+                }
+            }
+            Ws[r * LD + c] = wv; Xs[r * LD + c] = xv;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < KS / 2; ++kk) {
+            const float a = Xs[(wn * 32 + fr) * LD + 2 * kk + kh], b = Ws[(wm * 32 + fr) * LD + 2 * kk + kh];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    char * dst = g.dst + (size_t) i12 * g.dst_nb2 + (size_t) i13 * g.dst_nb3;
+    const int m = m0 + wm * 32 + fr;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int n = n0 + wn * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh;
+        if (m < g.M && n < g.N) { float * p = (float *) (dst + (size_t) n * g.dst_cs + (size_t) m * 4); *p = g.accumulate ? *p + acc[e] : acc[e]; }
+    }
+}
+
+void gemm_any(const gemm_any_args & a, hipStream_t st) {
+    if (a.M == 0 || a.N == 0 || a.nbatch == 0) return;
+    gemm_any_dev g;
+    g.W = (const char *) a.W; g.w_rs = a.w_rs; g.w_nb2 = a.w_nb2; g.w_nb3 = a.w_nb3;
+    g.X = (const char *) a.X; g.x_rs = a.x_rs; g.x_nb2 = a.x_nb2; g.x_nb3 = a.x_nb3;
+    g.dst = (char *) a.dst; g.dst_cs = a.dst_cs; g.dst_nb2 = a.dst_nb2; g.dst_nb3 = a.dst_nb3;
+    g.M = (int) a.M; g.N = (int) a.N; g.K = (int) a.K; g.tiles_m = (int) ((a.M + 63) / 64); g.ne12 = a.ne12; g.r2 = a.r2; g.r3 = a.r3; g.round_x = a.w_f16 ? 1 : 0; g.accumulate = a.accumulate ? 1 : 0;
+    const dim3 grid((unsigned) (g.tiles_m * ((a.N + 63) / 64)), (unsigned) a.nbatch);
+    if (a.x_f16)      k_gemm_any<uint16_t, uint16_t><<<grid, dim3(256), 0, st>>>(g);       // (F16 activations only come with F16 weights: supports_op)
+    else if (a.w_f16) k_gemm_any<uint16_t, float><<<grid, dim3(256), 0, st>>>(g);
+    else              k_gemm_any<float, float><<<grid, dim3(256), 0, st>>>(g);
+}
+
+} // namespace mi

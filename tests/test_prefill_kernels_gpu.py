@@ -157,3 +157,25 @@ def test_norm_rope_prefill_chains_vs_reference_backend(pkg, be, ref_be, T, H, HK
     assert nmse(got[0], want[0]) < 1e-10, nmse(got[0], want[0])
     assert nmse(got[1].astype(np.float32), want[1].astype(np.float32)) < 1e-6                     # f16 cache rows: a last-bit angle difference may flip a rounding
     assert np.array_equal(got[2].view(np.uint16), want[2].view(np.uint16))                          # v: a pure f32 -> f16 store
+
+
+@pytest.mark.parametrize("wtype,xtype,M,N,K,H,HK", [("f32", "f32", 200, 130, 72, 4, 4), ("f32", "f32", 512, 200, 1000, 1, 1), ("f16", "f32", 64, 150, 1500, 6, 2),
+                                                    ("f16", "f16", 300, 600, 588, 1, 1), ("f16", "f32", 1152, 100, 4304, 1, 1)])
+def test_any_shape_gemm_vs_reference_backend(pkg, be, ref_be, wtype, xtype, M, N, K, H, HK):
+    """gemm_any.hip: MUL_MAT with more than 8 columns for F32 weights (Token2Wav, SigLip2's f32 K . Q^T with K = 72), F16 weights with a
+    contraction length that is not a multiple of 32 (Whisper's V^T . P over 1500 frames, with a GQA-style broadcast), F16 x F16 (im2col
+    columns of the patch embedding, K = 588) and the split form (SigLip2's n_ff 4304: F16 MFMA GEMM over 4288 columns + accumulated tail),
+    against the reference CPU backend.  f32 fused multiply-adds on both sides: only the summation order differs."""
+    rng = np.random.default_rng(M + N + K)
+    F = dict(f32=pkg.GGML_TYPE_F32, f16=pkg.GGML_TYPE_F16)
+    npt = dict(f32=np.float32, f16=np.float16)
+
+    def build(c):
+        w = c.new_tensor(F[wtype], K, M, HK); x = c.new_tensor(F[xtype], K, N, H)
+        return dict(w=w, x=x), [c.mul_mat(w, x)]
+    feeds = dict(w=(rng.standard_normal(K * M * HK) / np.sqrt(K)).astype(npt[wtype]), x=rng.standard_normal(K * N * H).astype(npt[xtype]))
+    before = be.get_stat("kernels_last_graph")
+    got, want = _both(pkg, be, ref_be, build, feeds)
+    assert be.get_stat("kernels_last_graph") <= 3, "one launch (two for the split form, plus the activation image), not a mat-vec per 8 columns"
+    assert np.isfinite(got[0]).all()
+    assert nmse(got[0], want[0]) < 1e-10, nmse(got[0], want[0])
