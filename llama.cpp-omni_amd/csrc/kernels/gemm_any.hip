@@ -7,8 +7,9 @@
 //                                              vec_dot_type conversion, ggml-cpu.c:1245-1268), f32 accumulate
 // on v_mfma_f32_32x32x2f32: f32 x f32 fused multiply-add into f32, i.e. the CPU's arithmetic (ggml_vec_dot_f32 / _f16 accumulate in f32
 // FMA lanes), only the summation order differs.  Any M, N, K >= 1 (tiles are zero-filled past the edges), rows K-contiguous with any
-// row stride, broadcast batch over dims 2, 3 like ggml_compute_forward_mul_mat.  Workgroup = 4 waves on a 64 x 64 tile, 16-wide K-steps
-// staged through LDS (padded rows, single buffer: these matrices are small -- the point is one launch instead of thousands).
+// row stride, broadcast batch over dims 2, 3 like ggml_compute_forward_mul_mat.  Workgroup = 4 waves on a 64 x 64 tile, 32-wide K-steps
+// through two padded LDS buffers (one barrier per step, the next step's global loads in flight under the MFMAs): these matrices are small --
+// the point is one launch instead of thousands, and a short per-workgroup latency chain.
 #include "../kernels.hpp"
 
 namespace mi {
@@ -24,8 +25,8 @@ struct gemm_any_dev {
 
 template <typename WT, typename XT>
 __global__ void __launch_bounds__(256) k_gemm_any(const gemm_any_dev g) {
-    constexpr int KS = 16, LD = KS + 1;
-    __shared__ float Ws[64 * LD], Xs[64 * LD];
+    constexpr int KS = 32, LD = KS + 1, PT = 64 * KS / 256;        // 8 elements of each operand per thread and K-step
+    __shared__ float Ws[2][64 * LD], Xs[2][64 * LD];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, wm = wave & 1, wn = wave >> 1;
     const int tm = (int) blockIdx.x % g.tiles_m, tn = (int) blockIdx.x / g.tiles_m;
     const int i12 = (int) blockIdx.y % g.ne12, i13 = (int) blockIdx.y / g.ne12;
@@ -36,31 +37,43 @@ __global__ void __launch_bounds__(256) k_gemm_any(const gemm_any_dev g) {
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[e] = 0.0f;
     const int fr = lane & 31, kh = lane >> 5;
-    for (int k0 = 0; k0 < g.K; k0 += KS) {
+    // element i of this thread: tile row (t >> 5) + 8 i, column t & 31 -- consecutive lanes read consecutive k of one row
+    const int c = t & 31, r0 = t >> 5;
+    float wv[PT], xv[PT];
+    auto fetch = [&](int k0) {                                     // branch-free: clamped addresses, zero selected afterwards (a conditional load is a branch + a full wait)
+        const int k = k0 + c, kc = k < g.K ? k : g.K - 1;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int e = t + 256 * i, r = e >> 4, c = e & 15, k = k0 + c;
-            float wv = 0.0f, xv = 0.0f;
-            if (k < g.K) {
-                if (m0 + r < g.M) {
-                    const char * p = W + (size_t) (m0 + r) * g.w_rs + (size_t) k * sizeof(WT);
-                    wv = sizeof(WT) == 2 ? h2f(*(const uint16_t *) p) : *(const float *) p;
-                }
-                if (n0 + r < g.N) {
-                    const char * p = X + (size_t) (n0 + r) * g.x_rs + (size_t) k * sizeof(XT);
-                    if (sizeof(XT) == 2) xv = h2f(*(const uint16_t *) p);                     // F16 x F16: the im2col columns of the encoders' convolutions
-                    else { xv = *(const float *) p; if (g.round_x) xv = h2f(f2h(xv)); }
-                }
-            }
-            Ws[r * LD + c] = wv; Xs[r * LD + c] = xv;
+        for (int i = 0; i < PT; ++i) {
+            const int r = r0 + 8 * i;
+            const int mr = m0 + r < g.M ? m0 + r : g.M - 1, nr = n0 + r < g.N ? n0 + r : g.N - 1;
+            const char * pw = W + (size_t) mr * g.w_rs + (size_t) kc * sizeof(WT);
+            const char * px = X + (size_t) nr * g.x_rs + (size_t) kc * sizeof(XT);
+            wv[i] = sizeof(WT) == 2 ? h2f(*(const uint16_t *) pw) : *(const float *) pw;
+            xv[i] = sizeof(XT) == 2 ? h2f(*(const uint16_t *) px) : *(const float *) px;       // (F16 x F16: the im2col columns of the encoders' convolutions)
         }
-        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < PT; ++i) {
+            const int r = r0 + 8 * i;
+            if (sizeof(XT) == 4 && g.round_x) xv[i] = h2f(f2h(xv[i]));
+            if (k >= g.K || m0 + r >= g.M) wv[i] = 0.0f;
+            if (k >= g.K || n0 + r >= g.N) xv[i] = 0.0f;
+        }
+    };
+    auto park = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < PT; ++i) { Ws[buf][(r0 + 8 * i) * LD + c] = wv[i]; Xs[buf][(r0 + 8 * i) * LD + c] = xv[i]; }
+    };
+    fetch(0);
+    int buf = 0;
+    for (int k0 = 0; k0 < g.K; k0 += KS, buf ^= 1) {
+        park(buf);
+        __syncthreads();                                           // K-step k0 visible; everybody is past the MFMAs that read the other buffer
+        if (k0 + KS < g.K) fetch(k0 + KS);                         // in flight under this step's MFMAs
 #pragma unroll
         for (int kk = 0; kk < KS / 2; ++kk) {
-            const float a = Xs[(wn * 32 + fr) * LD + 2 * kk + kh], b = Ws[(wm * 32 + fr) * LD + 2 * kk + kh];
+            const float a = Xs[buf][(wn * 32 + fr) * LD + 2 * kk + kh], b = Ws[buf][(wm * 32 + fr) * LD + 2 * kk + kh];
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
         }
-        __syncthreads();
     }
     char * dst = g.dst + (size_t) i12 * g.dst_nb2 + (size_t) i13 * g.dst_nb3;
     const int m = m0 + wm * 32 + fr;
