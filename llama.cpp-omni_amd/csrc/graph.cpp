@@ -1995,11 +1995,18 @@ enum ggml_status graph_compute(backend_ctx * c, ggml_cgraph * g) {
 
     // hipGraph replay pays for launch-bound graphs (decode: hundreds of ~5 us kernels).  A prefill ubatch runs 50-100 us kernels, the
     // host stays far ahead of the device when it simply enqueues them, and capture + instantiation would cost a submission several ms
-    int64_t max_cols = 0;
+    // ... but a graph of many SMALL wide mat-muls is launch-bound again (a Token2Wav DiT block: 77 launches of ~5 us; an omni encoder layer): those
+    // replay too, judged by their total mat-mul work
+    int64_t max_cols = 0; double mm_flops = 0.0;
     for (int i = 0; i < g->n_nodes; ++i)
-        if (g->nodes[i]->op == GGML_OP_MUL_MAT && g->nodes[i]->src[1]->ne[1] > max_cols) max_cols = g->nodes[i]->src[1]->ne[1];
+        if (g->nodes[i]->op == GGML_OP_MUL_MAT) {
+            const ggml_tensor * w = g->nodes[i]->src[0], * x = g->nodes[i]->src[1];
+            if (x->ne[1] > max_cols) max_cols = x->ne[1];
+            mm_flops += 2.0 * (double) w->ne[0] * (double) w->ne[1] * (double) x->ne[1] * (double) (x->ne[2] * x->ne[3]);
+        }
     static const int64_t graph_max_cols = getenv("MI355X_GRAPH_MAX_COLS") ? atoll(getenv("MI355X_GRAPH_MAX_COLS")) : (mmq_max_cols() > 32 ? mmq_max_cols() : 32);
-    const bool try_graph = c->opt_graphs && !c->opt_profile && n_real >= 8 && max_cols <= graph_max_cols;
+    static const double graph_max_flops = getenv("MI355X_GRAPH_MAX_GFLOP") ? atof(getenv("MI355X_GRAPH_MAX_GFLOP")) * 1e9 : 20e9;
+    const bool try_graph = c->opt_graphs && !c->opt_profile && n_real >= 8 && (max_cols <= graph_max_cols || mm_flops <= graph_max_flops);
     if (try_graph) {
         if (!have_fp) fp = fingerprint(g);
         graph_exec * ge = nullptr;

@@ -624,7 +624,7 @@ void gemm_reduce_rms_norm(const float * partial, int nsplit, const float * resid
 
 // dynamic LDS above 64 KB needs a function attribute, once per (kernel, device): a process may drive several GPUs
 static void allow_big_lds(const void * kernel, int bytes, int slot) {
-    static bool done[3][64] = {};
+    static bool done[6][64] = {};
     int dev = 0;
     HIP_CHECK(hipGetDevice(&dev));
     if (dev < 0 || dev >= 64 || !done[slot][dev]) {
@@ -737,19 +737,19 @@ void gemm_f16_multi(const gemm_multi_args & a, hipStream_t st) {
             k_gemm_f16_glds256<<<dim3((unsigned) (tm * tiles_n256)), dim3(512), lds256, st>>>(g);
         } else {
             static const int abl = getenv("MI355X_GEMM_ABL") ? atoi(getenv("MI355X_GEMM_ABL")) : 0;
-            auto go = [&](auto kern) { HIP_CHECK(hipFuncSetAttribute((const void *) kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds256)); kern<<<dim3((unsigned) (tm * tiles_n256)), dim3(512), lds256, st>>>(g); };
+            auto go = [&](auto kern, int slot) { allow_big_lds((const void *) kern, lds256, slot); kern<<<dim3((unsigned) (tm * tiles_n256)), dim3(512), lds256, st>>>(g); };
             if (abl == 8) {
                 static unsigned long long * dbg = nullptr; static int shown = 0;
                 if (!dbg) HIP_CHECK(hipMalloc(&dbg, 24 * 8));
                 g.dbg = dbg;
-                go(k_gemm_f16_ph8<8, false>);
+                go(k_gemm_f16_ph8<8, false>, 5);
                 if (shown++ < 2) {
                     unsigned long long h[24]; HIP_CHECK(hipStreamSynchronize(st)); HIP_CHECK(hipMemcpy(h, dbg, sizeof(h), hipMemcpyDeviceToHost));
                     for (int w = 0; w < 2; ++w) { fprintf(stderr, "[ph8 stamps] group %d, cycles per K-step:", w); for (int i = 0; i < 12; ++i) fprintf(stderr, " %s%.0f", i % 3 == 0 ? "| " : "", (double) h[w * 12 + i] / (a.K / 64)); fprintf(stderr, "\n"); }
                 }
                 return;
             }
-            if (abl == 1) go(k_gemm_f16_ph8<1, false>); else go(k_gemm_f16_ph8<0, false>);
+            if (abl == 1) go(k_gemm_f16_ph8<1, false>, 4); else go(k_gemm_f16_ph8<0, false>, 3);
         }
         ++g_gemm_variant_launches[0];
         return;
