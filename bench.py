@@ -378,15 +378,17 @@ def omni_module_legs(pkg, be):
             out += list(L.values())
         return out
     out = {}
-    c = pkg.Context(be)
-    W = E.whisper_weights(c, E.WHISPER, 1); inp, _ = E.whisper(c, E.WHISPER, W, 3000)
-    ms, k = timed(c, flat(W) + [inp])
-    out["whisper_apm_front_1layer_tail_ms"] = ms; out["whisper_kernels"] = k
-    c = pkg.Context(be)
-    W = E.siglip2_weights(c, E.SIGLIP2, 1); inp, vit = E.siglip2(c, E.SIGLIP2, W)
-    Wr = E.resampler_weights(c, E.RESAMPLER); pe, _ = E.resampler(c, E.RESAMPLER, Wr, vit, (E.SIGLIP2["image"] // E.SIGLIP2["patch"]) ** 2)
-    ms, k = timed(c, flat(W) + flat(Wr) + [inp, pe])
-    out["siglip2_vpm_embed_1layer_resampler_ms"] = ms; out["siglip2_kernels"] = k
+    for nl in (1, 24):                                             # Whisper-medium encoder: 24 layers (30 s of audio: 3000 mel frames -> 1500 tokens -> 300 embeddings)
+        c = pkg.Context(be)
+        W = E.whisper_weights(c, E.WHISPER, nl); inp, _ = E.whisper(c, E.WHISPER, W, 3000)
+        ms, k = timed(c, flat(W) + [inp])
+        out[f"whisper_apm_{nl}_layer{'s' if nl > 1 else ''}_30s_audio_ms"] = ms; out[f"whisper_{nl}l_kernels"] = k
+    for nl in (1, 27):                                             # SigLip2-so400m: 27 layers, one 448 x 448 slice -> 1024 patches -> 64 resampled queries
+        c = pkg.Context(be)
+        W = E.siglip2_weights(c, E.SIGLIP2, nl); inp, vit = E.siglip2(c, E.SIGLIP2, W)
+        Wr = E.resampler_weights(c, E.RESAMPLER); pe, _ = E.resampler(c, E.RESAMPLER, Wr, vit, (E.SIGLIP2["image"] // E.SIGLIP2["patch"]) ** 2)
+        ms, k = timed(c, flat(W) + flat(Wr) + [inp, pe])
+        out[f"siglip2_vpm_{nl}_layer{'s' if nl > 1 else ''}_resampler_one_slice_ms"] = ms; out[f"siglip2_{nl}l_kernels"] = k
     c = pkg.Context(be)
     W = T.dit_weights(c, T.DIT); x, cond, _ = T.dit_block(c, T.DIT, W, 200)
     ms, k = timed(c, flat(W) + [x, cond])
