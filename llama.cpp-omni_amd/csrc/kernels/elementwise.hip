@@ -574,7 +574,7 @@ __global__ void __launch_bounds__(256) k_soft_max_rows(td4 x, td4 y, td4 mk, boo
 bool soft_max_rows_ok(const tdesc & x, const tdesc * mask, int mask_type, const float * sinks, const tdesc & y) {
     const int64_t n = x.ne[0], nrows = x.ne[1] * x.ne[2] * x.ne[3];
     auto al = [](const tdesc & t, int es) { return ((uintptr_t) t.p & 15) == 0 && t.nb[0] == (size_t) es && t.nb[1] % (es * 4) == 0 && t.nb[2] % (es * 4) == 0 && t.nb[3] % (es * 4) == 0; };
-    if (sinks || nrows < 64 || n % 4 != 0 || n > 2048 || !al(x, 4) || (y.p && !al(y, 4))) return false;
+    if (sinks || nrows < 64 || n % 4 != 0 || n > 8192 || !al(x, 4) || (y.p && !al(y, 4))) return false;
     if (mask && !al(*mask, mask_type == GGML_TYPE_F16 ? 2 : 4)) return false;
     if (mask && mask_type == GGML_TYPE_F16 && ((uintptr_t) mask->p & 7) != 0) return false;
     return true;
@@ -594,7 +594,7 @@ void soft_max_f32(const tdesc & x, const tdesc * mask, int mask_type, const floa
         const bool mh = mask && mask_type == GGML_TYPE_F16;
 #define SM_GO(V) do { if (mh) k_soft_max_rows<V, true><<<grid, dim3(256), 0, st>>>(to_td4(x), yd, mk, mask != nullptr, scale, max_bias, m0, m1, nhl2, (char *) y16, (int64_t) y16_rs, nrows); \
                       else    k_soft_max_rows<V, false><<<grid, dim3(256), 0, st>>>(to_td4(x), yd, mk, mask != nullptr, scale, max_bias, m0, m1, nhl2, (char *) y16, (int64_t) y16_rs, nrows); } while (0)
-        if (n <= 512) SM_GO(2); else if (n <= 1024) SM_GO(4); else SM_GO(8);
+        if (n <= 512) SM_GO(2); else if (n <= 1024) SM_GO(4); else if (n <= 2048) SM_GO(8); else if (n <= 4096) SM_GO(16); else SM_GO(32);
 #undef SM_GO
         return;
     }

@@ -64,7 +64,7 @@ def test_rms_norm_rows_vs_reference_backend(pkg, be, ref_be, n, rows):
         assert nmse(g, w) < 1e-13, nmse(g, w)
 
 
-@pytest.mark.parametrize("n,mask_type", [(512, "f32"), (1000, "f16"), (2048, "f32"), (256, None)])
+@pytest.mark.parametrize("n,mask_type", [(512, "f32"), (1000, "f16"), (2048, "f32"), (256, None), (2560, "f32"), (8192, "f16")])
 def test_soft_max_rows_and_its_f16_image_vs_reference_backend(pkg, be, ref_be, n, mask_type):
     """SOFT_MAX over [n, 96, 6] with a causal-style mask (rows with -inf tails), alone (f32 result) and followed by the per-head MUL_MAT that
     makes the kernel emit the f16 activation image instead of the f32 block (V^T . P of the flash-attention-off graph)."""
