@@ -600,3 +600,37 @@ def test_c1_stories15m_shape_f16_vs_reference_backend(pkg, be, ref_be):
         if got[t].argmax() != want[t].argmax():
             rms = float(np.sqrt(np.mean((got[t] - want[t]) ** 2)))
             assert want[t][got[t].argmax()] >= want[t].max() - 4.0 * rms, t
+
+
+def test_one_ubatch_of_several_sequences_equals_the_sequences_one_by_one(pkg, be):
+    """The C3 leg's one-ubatch form (bench.py c3_prefill(one_ubatch=True): n_seq sequences back to back in a unified KV cache, positions restarting
+    per sequence, block-diagonal causal mask -- llama_kv_cache::set_input_kq_mask with several seq_ids) must compute what the sequences
+    compute alone: 3 sequences x 96 tokens through two F16 layers at the 8B widths, last-token logits of every sequence against separate runs
+    (same kernels on different tilings / mask tiles: NMSE < 1e-6)."""
+    from llama_cpp_omni_amd import qwen3
+    cfg = dict(W8, n_vocab=2048)
+    types = qwen3.uniform_types(cfg, pkg.GGML_TYPE_F16)
+    rng = np.random.default_rng(33)
+    n_seq, ln = 3, 96
+    embd = rng.standard_normal((n_seq * ln, cfg["n_embd"])).astype(np.float32)
+    mdl = qwen3.Model(be, cfg, types, n_ctx=n_seq * ln, seed=5, flash_attn=True)
+    g, I, logits = mdl.build(n_seq * ln, n_seq * ln, n_outputs=n_seq)
+    mdl.set_inputs(I, embd, 0, n_seq * ln, n_seq=n_seq)
+    be.tensor_set(I["out_ids"], (np.arange(n_seq, dtype=np.int32) + 1) * ln - 1)
+    be.graph_compute(g.graph())
+    together = be.tensor_get(logits).copy().reshape(n_seq, -1)
+    g.free()
+    alone = []
+    for s in range(n_seq):
+        g, I, logits = mdl.build(ln, ln, n_outputs=1)
+        mdl.set_inputs(I, embd[s * ln:(s + 1) * ln], 0, ln)
+        be.tensor_set(I["out_ids"], np.array([ln - 1], np.int32))
+        be.graph_compute(g.graph())
+        alone.append(be.tensor_get(logits).copy().ravel())
+        g.free()
+    mdl.wctx.free()
+    alone = np.stack(alone)
+    assert np.isfinite(together).all()
+    e = nmse(together, alone)
+    print("one ubatch of 3 sequences vs one by one: logits NMSE", e)
+    assert e < 1e-6, e
