@@ -344,7 +344,15 @@ static size_t graph_gemm_partial_need(const ggml_cgraph * g) {
     for (int i = 0; i < g->n_nodes; ++i) {
         const ggml_tensor * n = g->nodes[i];
         if (n->op != GGML_OP_MUL_MAT || is_empty(n) || !mm_uses_gemm(n) || n->src[1]->ne[2] != 1 || n->src[1]->ne[3] != 1) continue;
-        const size_t b = gemm_split_scratch_bytes(n->src[0]->ne[1], n->src[1]->ne[1], n->src[0]->ne[0]);
+        int64_t m_sum = n->src[0]->ne[1];                    // the mat-muls that share this activation may go out as one launch (exec_gemm_group)
+        if (n->src[1]->ne[1] <= 256) {
+            int grouped = 1;
+            for (int j = i + 1; j < g->n_nodes && j < i + 32 && grouped < 3; ++j) {
+                const ggml_tensor * c = g->nodes[j];
+                if (c->op == GGML_OP_MUL_MAT && !is_empty(c) && c->src[1]->data == n->src[1]->data && c->src[1]->ne[0] == n->src[1]->ne[0] && c->src[1]->ne[1] == n->src[1]->ne[1]) { m_sum += c->src[0]->ne[1]; ++grouped; }
+            }
+        }
+        const size_t b = gemm_split_scratch_bytes(m_sum, n->src[1]->ne[1], n->src[0]->ne[0]);
         if (b > need) need = b;
     }
     return need;
@@ -748,6 +756,18 @@ static void materialise_reduce(exec_state & s) {
     gemm_reduce((const float *) s.c->gemm_partial, s.pr.nsplit, s.pr.resid, s.pr.resid_cs, (float *) A->data, A->nb[1], A->ne[0], A->ne[1], s.st);
     ++s.n_kernels;
 }
+// Q4_K / Q6_K weights with NO resident F16 image (MI355X_NO_F16_SHADOW, the image budget spent, out of memory): the GEMM de-quantises the blocks
+// inside its LDS staging (k_gemm_kq_glds) instead of running a de-quantise-to-scratch launch in front of every mat-mul.  With the image resident
+// the F16 kernel is faster at every column count (the in-staging form spends ~900 VALU cycles per wave and K-step on nibbles, scales and f16
+// rounding against 512 MFMA cycles: measured pp100 9.9 vs 7.6 ms, pp256 13.5 vs 9.4 ms), so otherwise it is only taken on request: MI355X_KQ_STAGING=1 / set_option("kq_staging") (<= MAX_COLS columns).
+static bool kq_in_staging(exec_state & s, const ggml_tensor * w, int64_t N) {
+    static const bool off = getenv("MI355X_NO_KQ_STAGING") != nullptr;
+    static const int64_t max_n = getenv("MI355X_KQ_STAGING_MAX_COLS") ? atoll(getenv("MI355X_KQ_STAGING_MAX_COLS")) : 256;
+    if (off || !(w->type == GGML_TYPE_Q4_K || w->type == GGML_TYPE_Q6_K) || w->ne[0] % 256 != 0 || w->ne[2] != 1 || w->ne[3] != 1 ||
+        w->nb[1] % (w->type == GGML_TYPE_Q4_K ? 16 : 2) != 0 || ((uintptr_t) w->data & 15) != 0) return false;
+    if (s.c->opt_kq_staging) return N <= max_n;
+    return weight_shadow(s, w, (const char *) w->data, w->ne[0], w->ne[1]) == nullptr;
+}
 static bool gemm_operand(exec_state & s, const ggml_tensor * w, const uint16_t ** w16, size_t * rs) {
     if (w->ne[2] != 1 || w->ne[3] != 1) return false;
     if (w->type == GGML_TYPE_F16) { *w16 = (const uint16_t *) w->data; *rs = w->nb[1]; return true; }
@@ -772,19 +792,23 @@ static bool exec_gemm_group(exec_state & s, int i) {
     gemm_multi_args a;
     a.nmat = 0; a.N = N; a.K = K; a.partial = nullptr;
     int mm_idx[3] = { i, -1, -1 };
+    const bool kq = kq_in_staging(s, n->src[0], N);            // then every matrix of the launch must be K-quant blocks too
     {
         const uint16_t * w16; size_t rs;
-        if (!gemm_operand(s, n->src[0], &w16, &rs)) return false;
-        a.m[a.nmat++] = { w16, rs, (float *) n->data, n->nb[1], n->src[0]->ne[1], nullptr, 0 };
+        if (kq) { w16 = (const uint16_t *) n->src[0]->data; rs = n->src[0]->nb[1]; }
+        else if (!gemm_operand(s, n->src[0], &w16, &rs)) return false;
+        a.m[a.nmat++] = { w16, rs, (float *) n->data, n->nb[1], n->src[0]->ne[1], nullptr, 0, kq ? (int) n->src[0]->type : 0 };
     }
     for (int j = i + 1; j < g->n_nodes && j < i + 32 && a.nmat < 3; ++j) {
         ggml_tensor * c = g->nodes[j];
         if (s.done[j] || !gemm_groupable(c) || !same_act(c->src[1], x)) continue;
         if (!can_hoist(s, i, j, mm_idx, a.nmat)) continue;
+        if (kq != kq_in_staging(s, c->src[0], N)) continue;
         const uint16_t * w16; size_t rs;
-        if (!gemm_operand(s, c->src[0], &w16, &rs)) continue;
+        if (kq) { w16 = (const uint16_t *) c->src[0]->data; rs = c->src[0]->nb[1]; }
+        else if (!gemm_operand(s, c->src[0], &w16, &rs)) continue;
         mm_idx[a.nmat] = j;
-        a.m[a.nmat++] = { w16, rs, (float *) c->data, c->nb[1], c->src[0]->ne[1], nullptr, 0 };
+        a.m[a.nmat++] = { w16, rs, (float *) c->data, c->nb[1], c->src[0]->ne[1], nullptr, 0, kq ? (int) c->src[0]->type : 0 };
     }
     // residual: the only consumer is ADD(c, r) / ADD(r, c) with r of the same shape, available now
     int add_idx[3] = { -1, -1, -1 };
@@ -811,7 +835,7 @@ static bool exec_gemm_group(exec_state & s, int i) {
     // ffn_gate / ffn_up whose only reader is one GLU(SWIGLU, split) that only feeds GEMMs: SWIGLU runs in the epilogue and the launch writes
     // the f16 activation image of ffn_down (into the alternate scratch: this launch still reads its own input image from act_scratch)
     int glu_idx = -1; const ggml_tensor * glu_x = nullptr;
-    if (a.nmat == 2 && add_idx[0] < 0 && add_idx[1] < 0 && s.c->act_scratch_alt) {
+    if (a.nmat == 2 && !kq && add_idx[0] < 0 && add_idx[1] < 0 && s.c->act_scratch_alt) {
         const int g0 = sole_user(s, g->nodes[mm_idx[0]]), g1 = sole_user(s, g->nodes[mm_idx[1]]);
         if (g0 >= 0 && g0 == g1 && g0 > mm_idx[1] && !s.done[g0]) {
             const ggml_tensor * G = g->nodes[g0];
@@ -842,6 +866,8 @@ static bool exec_gemm_group(exec_state & s, int i) {
         return true;
     }
     if (a.nmat == 1 && a.m[0].dst_cs % 16 == 0 && gemm_split_scratch_bytes(a.m[0].M, N, K) <= s.c->gemm_partial_bytes) a.partial = (float *) s.c->gemm_partial;
+    else if (a.nmat > 1 && N <= 256 && s.c->gemm_partial_bytes > 0) a.partial = (float *) s.c->gemm_partial;      // short prompts: split-K for the grouped launches too
+    a.partial_bytes = s.c->gemm_partial_bytes;
     double flops = 0;
     for (int q = 0; q < a.nmat; ++q) flops += 2.0 * (double) a.m[q].M * (double) N * (double) K;
     // a split-K result whose next reader is RMS_NORM (wo / ffn_down + residual -> the next norm): leave the slabs, the norm reduces them
@@ -2112,6 +2138,7 @@ void backend_ctx_init(backend_ctx * c) {
     if ((e = getenv("MI355X_PROFILE"))) c->opt_profile = atoi(e) != 0;
     if ((e = getenv("MI355X_NORM_IN_KERNEL"))) c->opt_norm_in_kernel = atoi(e) != 0;
     if ((e = getenv("MI355X_MV1")))     c->opt_mv1     = atoi(e) != 0;
+    if ((e = getenv("MI355X_KQ_STAGING"))) c->opt_kq_staging = atoi(e) != 0;
 }
 void backend_ctx_release(backend_ctx * c) {
     drop_graph_execs(c);
@@ -2137,6 +2164,7 @@ int mi355x_set_option(struct ggml_backend * backend, const char * key, long valu
     if (!strcmp(key, "profile")) { c->opt_profile = value != 0; return 0; }
     if (!strcmp(key, "norm_in_kernel")) { c->opt_norm_in_kernel = value != 0; mi::drop_graph_execs(c); return 0; }
     if (!strcmp(key, "mv1")) { c->opt_mv1 = value != 0; mi::drop_graph_execs(c); return 0; }
+    if (!strcmp(key, "kq_staging")) { c->opt_kq_staging = value != 0; mi::drop_graph_execs(c); return 0; }
     if (!strcmp(key, "fattn_gqa")) { mi::fattn_set_gqa(value != 0); mi::drop_graph_execs(c); return 0; }
     if (!strcmp(key, "fattn_one")) { mi::fattn_set_one(value != 0); mi::drop_graph_execs(c); return 0; }
     if (!strcmp(key, "f16_shadow")) { mi::shadow_set_enabled(value != 0); mi::drop_graph_execs(c); return 0; }
@@ -2153,6 +2181,7 @@ double mi355x_get_stat(struct ggml_backend * backend, const char * key) {
     if (!strcmp(key, "gemm256_launches"))   return (double) mi::gemm_variant_launches(0);
     if (!strcmp(key, "gemm192_launches"))   return (double) mi::gemm_variant_launches(1);
     if (!strcmp(key, "gemm_glu_launches"))  return (double) mi::gemm_variant_launches(2);
+    if (!strcmp(key, "gemm_kq_launches"))   return (double) mi::gemm_variant_launches(3);
     if (!strncmp(key, "prof_", 5)) {
         std::string k(key + 5);
         const size_t us = k.rfind("_us"), nn = k.rfind("_n"), by = k.rfind("_bytes");

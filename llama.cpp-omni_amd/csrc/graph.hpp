@@ -45,6 +45,7 @@ struct backend_ctx {
     bool opt_fusion = true;
     bool opt_profile = false;
     bool opt_norm_in_kernel = false;   // RMS_NORM+MUL computed inside the consuming mat-vec launches (mmvk.hip act_norm)
+    bool opt_kq_staging = false;       // K-quant blocks de-quantised inside the GEMM's staging even when an F16 image could be used (<= 256 columns; measurement / tests)
     bool opt_mv1 = true;               // batch-1 decode mat-vecs on mmv1.hip (f32 activation in, image built in the prologue)
 
     // hipGraph cache

@@ -224,9 +224,10 @@ void gemm_f16_mfma(const uint16_t * W, size_t w_rs, const uint16_t * X, size_t x
 
 // grouped form: up to three matrices sharing X in one launch, optional residual epilogue (dst = W.x + resid), and -- for a lone
 // under-filled matrix when `partial` scratch (gemm_split_scratch_bytes) is supplied -- deterministic split-K
-struct gemm_mat { const uint16_t * W; size_t w_rs; float * dst; size_t dst_cs; int64_t M; const float * resid; size_t resid_cs; };
+struct gemm_mat { const uint16_t * W; size_t w_rs; float * dst; size_t dst_cs; int64_t M; const float * resid; size_t resid_cs;
+                  int qtype = 0; };       // qtype != 0 (GGML_TYPE_Q4_K / Q6_K): W points at the block rows, de-quantised inside the GEMM's staging (all matrices of a launch alike; forces 128-row tiles)
 struct gemm_multi_args {
-    gemm_mat m[3]; int nmat; const uint16_t * X; size_t x_rs; int64_t N, K; float * partial;
+    gemm_mat m[3]; int nmat; const uint16_t * X; size_t x_rs; int64_t N, K; float * partial; size_t partial_bytes = (size_t) -1;
     // broadcast batch (nmat == 1, K % 64 == 0): nbatch = ne12 * ne13 products in one launch; batch b = i13 * ne12 + i12 reads
     // W + (i12 / r2) * w_nb2 + (i13 / r3) * w_nb3 and X + b * x_bs, writes dst + i12 * dst_nb2 + i13 * dst_nb3
     int nbatch = 1, ne12 = 1, r2 = 1, r3 = 1; size_t w_nb2 = 0, w_nb3 = 0, x_bs = 0, dst_nb2 = 0, dst_nb3 = 0;

@@ -138,6 +138,7 @@ struct gemm_dev {
     // head): batch b = i13 * ne12 + i12 uses W + (i12 / r2) * w_nb2 + (i13 / r3) * w_nb3, X + b * x_bs, dst + i12 * dst_nb2 + i13 * dst_nb3
     int ne12, r2, r3; size_t w_nb2, w_nb3, x_bs, dst_nb2, dst_nb3;
     unsigned long long * dbg;
+    int wtype[3];                                    // k_gemm_kq_glds: GGML_TYPE_Q4_K / GGML_TYPE_Q6_K per matrix (W points at the block rows)
     char * out16; size_t out16_rs; int glu_gate;      // k_gemm_f16_ph8<.., true>: f16 rows of silu(W[glu_gate].x) * (W[1 - glu_gate].x)
 };
 
@@ -246,6 +247,184 @@ __global__ void __launch_bounds__(256) k_gemm_f16_glds(const gemm_dev g) {
 #pragma unroll
         for (int b = 0; b < MB; ++b) {
             const int m = m0 + wm * 32 * MB + b * 32 + (lane & 31);
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int n = n0 + wn * 64 + a * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+                if (m < M && n < N) {
+                    float v = acc[a][b][e];
+                    if (resid) v += *(const float *) (resid + (size_t) n * resid_cs + (size_t) m * 4);
+                    *(float *) (dst + (size_t) n * dst_cs + (size_t) m * 4) = v;
+                }
+            }
+        }
+}
+
+// ---- K-quant weights de-quantised INSIDE the LDS staging (few columns: short prompts, omni stream_prefill chunks).  At N <= 256 the F16 GEMM
+// above is bound by streaming the resident F16 weight images (2 B per weight: 386 MB per Qwen3-8B layer); here the workgroup reads the Q4_K /
+// Q6_K blocks themselves (0.5625 / 0.8203 B per weight) and turns each K-step's slice into the same f16 tile the F16 kernel would have staged:
+// thread (row r = t / 2, half h = t % 2) fetches its 16-byte piece(s) and the block header one K-step ahead (registers), and after the step's
+// MFMAs de-quantises them -- the reference's arithmetic (dequantize_row_q4_K / _q6_K, ggml-quants.c:1352-1374 / 1762-1791: d * sc * q - dmin * m,
+// d * sc * q, then the f32 -> f16 rounding of the weight image) -- into 32 halves = four ds_write_b128 at the swizzled chunk positions.
+//   Q4_K, K-step ks: super-block ks / 4, 64-weight group j = ks % 4: bytes qs[32 j + 16 h .. +16); low nibbles = weights 16 h + i of the step
+//                    (sub-block 2 j), high nibbles = weights 32 + 16 h + i (sub-block 2 j + 1)
+//   Q6_K, K-step ks: half n = (ks / 2) % 2, e = ks % 2: ql[64 n + 16 h + i], ql[64 n + 32 + 16 h + i], qh[32 n + 16 h + i]; e picks the nibble and
+//                    the qh bit pair; scales[8 n + h + 4 e] and [.. + 2]  (blocks are only 2-byte aligned: dword loads, the hardware handles the phase)
+// The activation tile still arrives by LDS-DMA.  Same tile, wave layout, MFMA order and split-K as k_gemm_f16_glds<2>: results are bit-identical
+// to the F16-image path.
+static __device__ __forceinline__ uint32_t ld_u32_a2(const char * p) { typedef uint32_t __attribute__((aligned(2))) u32a2; return *(const u32a2 *) p; }
+static __device__ __forceinline__ void kq_scale_min(int s, const uint8_t * q, int & sc, int & m) {   // get_scale_min_k4, ggml-quants.c:703-710
+    if (s < 4) { sc = q[s] & 63; m = q[s + 4] & 63; }
+    else       { sc = (q[s + 4] & 0xF) | ((q[s - 4] >> 6) << 4); m = (q[s + 4] >> 4) | ((q[s] >> 6) << 4); }
+}
+
+__global__ void __launch_bounds__(256) k_gemm_kq_glds(const gemm_dev g) {
+    constexpr int BM = 128, WTILEB = BM * H_ROWB, BUFB = WTILEB + H_TILEB;
+    char * const lds = gemm_lds;
+
+    const int nt    = g.tiles_m * g.tiles_n;
+    const int split = blockIdx.x / nt;
+    const int bid   = blockIdx.x % nt;
+    const int q = nt / 8, rr = nt % 8, xcd = bid % 8, idx = bid / 8;
+    const int tile = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + idx;
+    int tm = tile / g.tiles_n; const int tn = tile % g.tiles_n;
+    int mi = 0;
+    if (g.nmat > 1 && tm >= g.tm_end[0]) { mi = 1; if (g.nmat > 2 && tm >= g.tm_end[1]) mi = 2; }
+    tm -= mi == 0 ? 0 : g.tm_end[mi - 1];
+    const char * W = mi == 0 ? g.W[0] : (mi == 1 ? g.W[1] : g.W[2]);
+    const size_t w_rs = mi == 0 ? g.w_rs[0] : (mi == 1 ? g.w_rs[1] : g.w_rs[2]);
+    const int M = mi == 0 ? g.M[0] : (mi == 1 ? g.M[1] : g.M[2]);
+    const bool q4 = (mi == 0 ? g.wtype[0] : (mi == 1 ? g.wtype[1] : g.wtype[2])) == GGML_TYPE_Q4_K;      // (workgroup-uniform)
+    const int N = g.N;
+    const int m0 = tm * BM, n0 = tn * G_BN;
+
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wm = wave & 1, wn = wave >> 1;
+
+    // activation tile: LDS-DMA exactly as k_gemm_f16_glds
+    const int r8 = lane >> 3;
+    const char * xp[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int gc = (lane & 7) ^ (((j * 8 + r8) >> 1) & 7);
+        int nr = n0 + wave * 32 + j * 8 + r8; nr = nr < N ? nr : N - 1;
+        xp[j] = g.X + (size_t) nr * g.x_rs + gc * 16;
+    }
+    auto stage_x = [&](int buf, int ks) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            __builtin_amdgcn_global_load_lds((gbl_ptr_t) (xp[j] + (size_t) ks * H_ROWB), (lds_ptr_t) (lds + buf * BUFB + WTILEB + (wave * 32 + j * 8) * H_ROWB), 16, 0, 0);
+    };
+    // weight tile: this thread's row and half
+    const int r = t >> 1, h = t & 1;
+    const char * wrow = W + (size_t) (m0 + r < M ? m0 + r : M - 1) * w_rs;
+    uint32_t qreg[12], hreg[4];
+    auto fetch_w = [&](int ks) {
+        if (q4) {
+            const char * blk = wrow + (size_t) (ks >> 2) * 144;
+            const u32x4 hd = *(const u32x4 *) blk, qq = *(const u32x4 *) (blk + 16 + 32 * (ks & 3) + 16 * h);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { hreg[i] = hd[i]; qreg[i] = qq[i]; }
+        } else {
+            const char * blk = wrow + (size_t) (ks >> 2) * 210;
+            const int n = (ks >> 1) & 1, e = ks & 1;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                qreg[i]     = ld_u32_a2(blk + 64 * n + 16 * h + 4 * i);
+                qreg[4 + i] = ld_u32_a2(blk + 64 * n + 32 + 16 * h + 4 * i);
+                qreg[8 + i] = ld_u32_a2(blk + 128 + 32 * n + 16 * h + 4 * i);
+            }
+            hreg[0] = (uint32_t) (uint8_t) blk[192 + 8 * n + h + 4 * e];
+            hreg[1] = (uint32_t) (uint8_t) blk[192 + 8 * n + h + 4 * e + 2];
+            hreg[2] = (uint32_t) *(const uint16_t *) (blk + 208);
+        }
+    };
+    auto park_w = [&](int buf, int ks) {
+        float a[16], b[16];                                  // weights 16 h + i and 32 + 16 h + i of this K-step
+        if (q4) {
+            uint8_t sc12[12];
+            __builtin_memcpy(sc12, &hreg[1], 12);
+            int sca, ma, scb, mb;
+            kq_scale_min(2 * (ks & 3), sc12, sca, ma); kq_scale_min(2 * (ks & 3) + 1, sc12, scb, mb);
+            const float d = h2f((uint16_t) (hreg[0] & 0xffffu)), dmin = h2f((uint16_t) (hreg[0] >> 16));
+            const float d1 = d * (float) sca, m1 = dmin * (float) ma, d2 = d * (float) scb, m2 = dmin * (float) mb;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const uint32_t by = (qreg[i >> 2] >> (8 * (i & 3))) & 0xffu;
+                a[i] = d1 * (float) (int) (by & 0xFu) - m1;
+                b[i] = d2 * (float) (int) (by >> 4) - m2;
+            }
+        } else {
+            const int e = ks & 1;
+            const float d = h2f((uint16_t) hreg[2]);
+            const float s1 = d * (float) (int) (int8_t) hreg[0], s2 = d * (float) (int) (int8_t) hreg[1];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const uint32_t la = (qreg[i >> 2] >> (8 * (i & 3))) & 0xffu, lb = (qreg[4 + (i >> 2)] >> (8 * (i & 3))) & 0xffu, hq = (qreg[8 + (i >> 2)] >> (8 * (i & 3))) & 0xffu;
+                const int q1 = (int) (e ? (la >> 4) | (((hq >> 4) & 3u) << 4) : (la & 0xFu) | ((hq & 3u) << 4)) - 32;
+                const int q2 = (int) (e ? (lb >> 4) | (((hq >> 6) & 3u) << 4) : (lb & 0xFu) | (((hq >> 2) & 3u) << 4)) - 32;
+                a[i] = s1 * (float) q1;
+                b[i] = s2 * (float) q2;
+            }
+        }
+        char * row = lds + buf * BUFB + r * H_ROWB;
+        const int sw = (r >> 1) & 7;
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            u32x4 pa, pb;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                pa[j] = (uint32_t) f2h(a[8 * c + 2 * j]) | ((uint32_t) f2h(a[8 * c + 2 * j + 1]) << 16);
+                pb[j] = (uint32_t) f2h(b[8 * c + 2 * j]) | ((uint32_t) f2h(b[8 * c + 2 * j + 1]) << 16);
+            }
+            *(u32x4 *) (row + (((2 * h + c) ^ sw) << 4)) = pa;
+            *(u32x4 *) (row + (((4 + 2 * h + c) ^ sw) << 4)) = pb;
+        }
+    };
+
+    f16v acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.0f;
+
+    const int nk_all = g.K / H_BK;
+    const int k_lo = split * g.ksteps_per_split;
+    const int k_hi = k_lo + g.ksteps_per_split < nk_all ? k_lo + g.ksteps_per_split : nk_all;
+    const int fr = lane & 31, hb = lane >> 5, sw = (fr >> 1) & 7;
+    if (k_lo < k_hi) { stage_x(0, k_lo); fetch_w(k_lo); park_w(0, k_lo); }
+    for (int ks = k_lo; ks < k_hi; ++ks) {
+        const int cur = (ks - k_lo) & 1;
+        __syncthreads();                                   // tile ks is complete (DMA drained by the fence, every thread's weight slice parked); buffer cur^1 is free
+        if (ks + 1 < k_hi) { stage_x(cur ^ 1, ks + 1); fetch_w(ks + 1); }
+        const char * wb = lds + cur * BUFB; const char * xb = wb + WTILEB;
+#pragma unroll
+        for (int kk = 0; kk < H_BK / 16; ++kk) {
+            const int co = ((kk * 2 + hb) ^ sw) << 4;
+            h8 af[2], bf[2];
+#pragma unroll
+            for (int a = 0; a < 2; ++a) af[a] = *(const h8 *) (xb + (wn * 64 + a * 32 + fr) * H_ROWB + co);
+#pragma unroll
+            for (int b = 0; b < 2; ++b) bf[b] = *(const h8 *) (wb + (wm * 64 + b * 32 + fr) * H_ROWB + co);
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[a], bf[b], acc[a][b], 0, 0, 0);
+        }
+        if (ks + 1 < k_hi) park_w(cur ^ 1, ks + 1);
+    }
+
+    char * dst = (mi == 0 ? g.dst[0] : (mi == 1 ? g.dst[1] : g.dst[2])) + (size_t) split * g.split_stride;
+    const size_t dst_cs = mi == 0 ? g.dst_cs[0] : (mi == 1 ? g.dst_cs[1] : g.dst_cs[2]);
+    const char * resid = mi == 0 ? g.resid[0] : (mi == 1 ? g.resid[1] : g.resid[2]);
+    const size_t resid_cs = mi == 0 ? g.resid_cs[0] : (mi == 1 ? g.resid_cs[1] : g.resid_cs[2]);
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int m = m0 + wm * 64 + b * 32 + (lane & 31);
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int n = n0 + wn * 64 + a * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
@@ -633,24 +812,29 @@ static void allow_big_lds(const void * kernel, int bytes, int slot) {
     }
 }
 
-// choose a K split that brings a lone, under-filled launch up to about two workgroups per CU
-static int pick_ksplit(int64_t tiles, int64_t nk) {
+// choose a K split that brings an under-filled launch up to about two workgroups per CU.  Few columns (N <= 256: short prompts, omni chunks):
+// a launch is then 32 .. 192 tiles whose 64 .. 192-step K loops run one after the other on a fraction of the CUs and the time is that loop's
+// latency, not bandwidth or flops -- split up to 8 ways, down to 8 K-steps per workgroup
+static int pick_ksplit(int64_t tiles, int64_t nk, int64_t N) {
     if (tiles >= 256 || nk < 32) return 1;
+    const int smax = N <= 256 ? 8 : 4, min_steps = N <= 256 ? 8 : 16;
     int s = (int) (512 / tiles);
-    if (s > 4) s = 4;
-    while (s > 1 && nk / s < 16) --s;
+    if (s > smax) s = smax;
+    while (s > 1 && nk / s < min_steps) --s;
     return s < 1 ? 1 : s;
 }
+// M: rows of the launch (the sum over its matrices); an upper bound (the launcher's own tile count decides the split)
 size_t gemm_split_scratch_bytes(int64_t M, int64_t N, int64_t K) {
     if (K % H_BK != 0 || M % 4 != 0) return 0;
     const int64_t tiles = ((M + G_BM - 1) / G_BM) * ((N + G_BN - 1) / G_BN);
-    const int s = pick_ksplit(tiles, K / H_BK);
+    int s = pick_ksplit(tiles, K / H_BK, N);
+    if (N <= 256 && tiles < 256 && K / H_BK >= 32) s = 8;     // (a group's tile count may differ by a few tiles from this estimate)
     return s > 1 ? (size_t) s * (size_t) M * (size_t) N * 4 : 0;
 }
 
 // launches per tile variant (tests assert that a shape really selected the kernel it is meant to cover): 0 = 256 x 256, 1 = 192-row
-static long g_gemm_variant_launches[3] = { 0, 0, 0 };
-long gemm_variant_launches(int v) { return v >= 0 && v < 3 ? g_gemm_variant_launches[v] : 0; }
+static long g_gemm_variant_launches[4] = { 0, 0, 0, 0 };
+long gemm_variant_launches(int v) { return v >= 0 && v < 4 ? g_gemm_variant_launches[v] : 0; }
 // gate / up + SWIGLU in one launch: equal shapes and row strides, whole 128-row blocks, enough tiles to occupy the chip
 bool gemm_glu_ok(const gemm_multi_args & a) {
     static const bool off = getenv("MI355X_NO_GEMM_GLU") != nullptr;
@@ -714,6 +898,9 @@ void gemm_f16_multi(const gemm_multi_args & a, hipStream_t st) {
         if (force == 0) big = false;
         if (force == 1 && a.nbatch <= 1) big = true;
     }
+    bool any_q = false;
+    for (int i = 0; i < a.nmat; ++i) any_q = any_q || a.m[i].qtype != 0;
+    if (any_q) { BM = G_BM; big = false; }                    // K-quant blocks de-quantised in the staging: the 128 x 128 kernel (few columns by construction)
     if (big) BM = 256;
     int tm = 0;
     for (int i = 0; i < 3; ++i) {
@@ -760,15 +947,37 @@ void gemm_f16_multi(const gemm_multi_args & a, hipStream_t st) {
     g.w_nb2 = a.w_nb2; g.w_nb3 = a.w_nb3; g.x_bs = a.x_bs; g.dst_nb2 = a.dst_nb2; g.dst_nb3 = a.dst_nb3;
     const int nk = (int) (a.K / H_BK);
     int ksplit = 1;
-    if (BM == G_BM && a.nmat == 1 && nbatch == 1 && a.partial && a.m[0].M % 4 == 0) ksplit = pick_ksplit((int64_t) tm * tiles_n, nk);
+    bool kq = a.nmat > 0;                                      // every matrix given as K-quant blocks: de-quantise inside the staging
+    for (int i = 0; i < a.nmat; ++i) kq = kq && a.m[i].qtype != 0;
+    for (int i = 0; i < 3; ++i) g.wtype[i] = a.m[i < a.nmat ? i : 0].qtype;
+    if (any_q && (!kq || BM != G_BM || nbatch != 1 || a.K % 256 != 0)) { fprintf(stderr, "[mi355x] gemm: K-quant staging needs every matrix of the launch as K-quant blocks, K %% 256 == 0, no batch\n"); abort(); }
+    int64_t m_sum = 0; bool m4 = true;
+    for (int i = 0; i < a.nmat; ++i) { m_sum += a.m[i].M; m4 = m4 && a.m[i].M % 4 == 0 && a.m[i].dst_cs % 16 == 0; }
+    if (BM == G_BM && nbatch == 1 && a.partial && m4 && (a.nmat == 1 || a.N <= 256)) {
+        ksplit = pick_ksplit((int64_t) tm * tiles_n, nk, a.N);
+        while (ksplit > 1 && (size_t) ksplit * (size_t) m_sum * (size_t) a.N * 4 > a.partial_bytes) --ksplit;
+    }
     g.ksteps_per_split = (nk + ksplit - 1) / ksplit; g.split_stride = 0;
     if (tm == 0) return;
     if (ksplit > 1) {
-        const gemm_mat & m = a.m[0];
-        g.dst[0] = (char *) a.partial; g.dst_cs[0] = (size_t) m.M * 4; g.resid[0] = nullptr; g.split_stride = (size_t) m.M * (size_t) a.N * 4;
-        k_gemm_f16_glds<2><<<dim3((unsigned) (tm * tiles_n * ksplit)), dim3(256), 2 * (128 * H_ROWB + H_TILEB), st>>>(g);
-        if (a.deferred_split) { *a.deferred_split = ksplit; return; }          // the caller fuses the reduction into its next kernel
-        gemm_reduce(a.partial, ksplit, m.resid, m.resid_cs, m.dst, m.dst_cs, m.M, a.N, st);
+        // slab s of the scratch holds, matrix after matrix, the dense [N][M_i] partial sums of K range s
+        const size_t slab = (size_t) m_sum * (size_t) a.N;
+        size_t off = 0;
+        for (int i = 0; i < a.nmat; ++i) {
+            g.dst[i] = (char *) (a.partial + off); g.dst_cs[i] = (size_t) a.m[i].M * 4; g.resid[i] = nullptr;
+            off += (size_t) a.m[i].M * (size_t) a.N;
+        }
+        g.split_stride = slab * 4;
+        if (kq) { k_gemm_kq_glds<<<dim3((unsigned) (tm * tiles_n * ksplit)), dim3(256), 2 * (128 * H_ROWB + H_TILEB), st>>>(g); ++g_gemm_variant_launches[3]; }
+        else    k_gemm_f16_glds<2><<<dim3((unsigned) (tm * tiles_n * ksplit)), dim3(256), 2 * (128 * H_ROWB + H_TILEB), st>>>(g);
+        if (a.nmat == 1 && a.deferred_split) { *a.deferred_split = ksplit; return; }          // the caller fuses the reduction into its next kernel
+        off = 0;
+        for (int i = 0; i < a.nmat; ++i) {
+            const gemm_mat & m = a.m[i];
+            const int64_t quads = m.M * a.N / 4;
+            if (quads > 0) k_gemm_reduce<<<dim3((unsigned) ((quads + 255) / 256)), dim3(256), 0, st>>>(a.partial + off, ksplit, slab, (const char *) m.resid, m.resid_cs, (char *) m.dst, m.dst_cs, (int) m.M, (int) a.N);
+            off += (size_t) m.M * (size_t) a.N;
+        }
         return;
     }
     if (BM == 64) {
@@ -778,6 +987,9 @@ void gemm_f16_multi(const gemm_multi_args & a, hipStream_t st) {
         allow_big_lds((const void *) k_gemm_f16_glds<3>, lds192, 1);
         k_gemm_f16_glds<3><<<dim3((unsigned) (tm * tiles_n), (unsigned) nbatch), dim3(256), lds192, st>>>(g);
         ++g_gemm_variant_launches[1];
+    } else if (kq) {
+        k_gemm_kq_glds<<<dim3((unsigned) (tm * tiles_n)), dim3(256), 2 * (128 * H_ROWB + H_TILEB), st>>>(g);
+        ++g_gemm_variant_launches[3];
     } else {
         k_gemm_f16_glds<2><<<dim3((unsigned) (tm * tiles_n), (unsigned) nbatch), dim3(256), 2 * (128 * H_ROWB + H_TILEB), st>>>(g);
     }

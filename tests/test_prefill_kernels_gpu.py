@@ -179,3 +179,34 @@ def test_any_shape_gemm_vs_reference_backend(pkg, be, ref_be, wtype, xtype, M, N
     assert be.get_stat("kernels_last_graph") <= 3, "one launch (two for the split form, plus the activation image), not a mat-vec per 8 columns"
     assert np.isfinite(got[0]).all()
     assert nmse(got[0], want[0]) < 1e-10, nmse(got[0], want[0])
+
+
+@pytest.mark.parametrize("name,M,K,N", [("q4_K", 4096, 4096, 100), ("q6_K", 1024, 4096, 128), ("q4_K", 12288, 4096, 256), ("q6_K", 4096, 12288, 72), ("q4_K", 200, 512, 65)])
+def test_kquant_blocks_dequantised_in_the_gemm_staging_bit_identical_to_the_f16_image(pkg, be, name, M, K, N):
+    """k_gemm_kq_glds (65 .. 256 columns against Q4_K / Q6_K weights): the blocks are de-quantised inside the GEMM's LDS staging instead of being
+    read from a resident F16 image (the form taken when no image is resident; slower than the image path otherwise).  The same product with the oracle's dequantize_row_* output rounded to f16 as an F16 weight tensor goes
+    through k_gemm_f16_glds with the same tiles, split and MFMA order: the two results must be BIT-identical (this pins the in-kernel nibble /
+    scale arithmetic to the reference's de-quantiser), and the launch counter confirms the path."""
+    import oracle.oracle_py as orc_
+    from llama_cpp_omni_amd import qwen3
+    rng = np.random.default_rng(M + K + N)
+    ty = dict(q4_K=pkg.GGML_TYPE_Q4_K, q6_K=pkg.GGML_TYPE_Q6_K)[name]
+    blocks = qwen3.random_blocks(rng, ty, M, K, std=0.05)
+    w16 = orc_.dequantize(ty, blocks.view(np.uint8).reshape(M, -1), M * K).reshape(M, K).astype(np.float16)
+    xv = rng.standard_normal((N, K)).astype(np.float32)
+    outs = []
+    be.set_option("kq_staging", 1)                              # (by default this form is the fallback for weights without a resident F16 image)
+    for quant in (True, False):
+        c = pkg.Context(be)
+        w = c.new_tensor(ty if quant else pkg.GGML_TYPE_F16, K, M); x = c.new_tensor(pkg.GGML_TYPE_F32, K, N)
+        y = c.mul_mat(w, x)
+        c.alloc()
+        be.tensor_set(w, blocks if quant else w16); be.tensor_set(x, xv)
+        before = be.get_stat("gemm_kq_launches")
+        be.graph_compute(c.graph())
+        assert (be.get_stat("gemm_kq_launches") - before == 1) == quant
+        outs.append(be.tensor_get(y).copy())
+        c.free()
+    be.set_option("kq_staging", 0)
+    assert np.isfinite(outs[0]).all()
+    assert np.array_equal(outs[0].view(np.uint32), outs[1].view(np.uint32))
