@@ -21,7 +21,7 @@ if os.path.exists("gpurun_out/bench_default.json"):
 rows = list(csv.DictReader(open(stats)))
 with open("profiles/" + TAG + "_kernel_stats_summary.txt", "w") as f:
     f.write("rocprofv3 --kernel-trace --stats --output-format csv -- MI355X_GRAPHS=0 python bench.py --steps 32 --warmup 8 --no-cpu-baseline\n")
-    f.write("(decode steps + the roofline replay + the pp512 leg; graph replay off under the profiler)  tools/profile_round.sh\n\n")
+    f.write("(decode steps + the roofline replay + the extras [no-FA decode, TTS decoder, omni encoder / Token2Wav graphs] + the pp512 leg; graph replay off under the profiler)  tools/profile_round.sh\n\n")
     f.write("%-100s %8s %12s %8s\n" % ("kernel", "calls", "avg_ns", "pct"))
     for r in rows:
         f.write("%-100s %8s %12.1f %8s\n" % (r["Name"][:100], r["Calls"], float(r["AverageNs"]), r["Percentage"]))
