@@ -393,9 +393,62 @@ __global__ void __launch_bounds__(1024) k_norm(td4 x, td4 y, float eps) {
     const float scale = 1.0f / sqrtf(variance + eps);
     for (int64_t i = threadIdx.x; i < n; i += blockDim.x) yr[i] = (xr[i] - mean) * scale;
 }
+// many rows (the encoders' [n_state, n_tokens] activations): one WAVE per row, the row in registers, both double sums folded across the wave
+template <int MAXV>
+__global__ void __launch_bounds__(256) k_norm_rows(td4 x, td4 y, float eps, int64_t nrows) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t) blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= nrows) return;
+    const int64_t i1 = row % x.ne[1], i2 = (row / x.ne[1]) % x.ne[2], i3 = row / (x.ne[1] * x.ne[2]);
+    const char * xr = x.p + i1 * x.nb[1] + i2 * x.nb[2] + i3 * x.nb[3];
+    char *       yr = y.p + i1 * y.nb[1] + i2 * y.nb[2] + i3 * y.nb[3];
+    const int n = (int) x.ne[0];
+    f32x4 v[MAXV];
+    double s = 0.0;
+#pragma unroll
+    for (int k = 0; k < MAXV; ++k) {
+        const int i = (lane + 64 * k) * 4;
+        v[k] = f32x4{ 0.0f, 0.0f, 0.0f, 0.0f };
+        if (i < n) { v[k] = *(const f32x4 *) (xr + (size_t) i * 4); s += (double) v[k][0] + (double) v[k][1] + (double) v[k][2] + (double) v[k][3]; }
+    }
+    s = wave_sum<double>(s);
+    const float mean = (float) s / (float) n;
+    double q = 0.0;
+#pragma unroll
+    for (int k = 0; k < MAXV; ++k) {
+        const int i = (lane + 64 * k) * 4;
+        if (i < n) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { const float d = v[k][e] - mean; v[k][e] = d; q += (double) (d * d); }
+        }
+    }
+    q = wave_sum<double>(q);
+    const float variance = (float) (q / (double) n);
+    const float scale = 1.0f / sqrtf(variance + eps);
+#pragma unroll
+    for (int k = 0; k < MAXV; ++k) {
+        const int i = (lane + 64 * k) * 4;
+        if (i >= n) break;
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = v[k][e] * scale;
+        *(f32x4 *) (yr + (size_t) i * 4) = o;
+    }
+}
 void norm_f32(const tdesc & x, const tdesc & y, float eps, hipStream_t st) {
     if (x.ne[0] == 0 || x.ne[1] * x.ne[2] * x.ne[3] == 0) return;
     const int64_t n = x.ne[0];
+    {
+        const int64_t nrows = x.ne[1] * x.ne[2] * x.ne[3];
+        auto al16 = [](const tdesc & t) { return ((uintptr_t) t.p & 15) == 0 && t.nb[0] == 4 && t.nb[1] % 16 == 0 && t.nb[2] % 16 == 0 && t.nb[3] % 16 == 0; };
+        if (nrows >= 64 && n % 4 == 0 && n <= 4096 && al16(x) && al16(y)) {
+            const dim3 grid((unsigned) ((nrows + 3) / 4));
+            if (n <= 1024)      k_norm_rows<4><<<grid, dim3(256), 0, st>>>(to_td4(x), to_td4(y), eps, nrows);
+            else if (n <= 2048) k_norm_rows<8><<<grid, dim3(256), 0, st>>>(to_td4(x), to_td4(y), eps, nrows);
+            else                k_norm_rows<16><<<grid, dim3(256), 0, st>>>(to_td4(x), to_td4(y), eps, nrows);
+            return;
+        }
+    }
     const int bs = n <= 128 ? 64 : n < 1024 ? 256 : n < 8192 ? 512 : 1024;
     k_norm<<<dim3((unsigned) x.ne[1], (unsigned) x.ne[2], (unsigned) x.ne[3]), dim3(bs), 0, st>>>(to_td4(x), to_td4(y), eps);
 }

@@ -210,3 +210,16 @@ def test_kquant_blocks_dequantised_in_the_gemm_staging_bit_identical_to_the_f16_
     be.set_option("kq_staging", 0)
     assert np.isfinite(outs[0]).all()
     assert np.array_equal(outs[0].view(np.uint32), outs[1].view(np.uint32))
+
+
+@pytest.mark.parametrize("n,rows", [(1024, 1500), (1152, 1024), (512, 200), (4096, 64)])
+def test_layer_norm_rows_vs_reference_backend(pkg, be, ref_be, n, rows):
+    """NORM (LayerNorm without affine part; the encoders' and the DiT's normalisation) through the wave-per-row kernel against the reference CPU
+    backend: mean and variance in double on both sides."""
+    rng = np.random.default_rng(n + rows)
+
+    def build(c):
+        x = c.new_tensor(pkg.GGML_TYPE_F32, n, rows)
+        return dict(x=x), [c.norm(x, 1e-5)]
+    got, want = _both(pkg, be, ref_be, build, dict(x=(rng.standard_normal(n * rows) * 2 + 0.3).astype(np.float32)))
+    assert nmse(got[0], want[0]) < 1e-12, nmse(got[0], want[0])
