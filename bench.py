@@ -529,6 +529,17 @@ def main():
                 pp, ok = prefill_tok_s(pkg, be, dec.model)
                 out["pp512_tok_s"] = round(pp, 1) if ok else None
                 out["ttft_ms_pp512"] = round(512.0 / pp * 1e3, 2) if ok else None      # time to first token of a 512-token prompt: one ubatch through the same graphs
+                om = (out.get("extras") or {}).get("omni_modules") or {}
+                apm, vpm = om.get("whisper_apm_24_layers_30s_audio_ms"), om.get("siglip2_vpm_27_layers_resampler_one_slice_ms")
+                if ok and apm and vpm and not args.tiny:
+                    # BASELINE configs[3] (omni stream_prefill) composed from legs measured in THIS run on one GPU: one APM pass (30 s of audio ->
+                    # 300 embeddings), one VPM pass (one 448 x 448 slice -> 64 queries), then the LLM prefill of those 364 embeddings + 30 text tokens
+                    n_llm = 300 + 64 + 30
+                    ppn, okn = prefill_tok_s(pkg, be, dec.model, n_tokens=n_llm)
+                    llm_ms = n_llm / ppn * 1e3
+                    out["c4_stream_prefill_ttft"] = {"apm_ms": apm, "vpm_ms": vpm, "llm_prefill_tokens": n_llm, "llm_prefill_ms": round(llm_ms, 2),
+                                                     "one_gpu_ms": round(apm + vpm + llm_ms, 2), "modules_on_own_gpus_ms": round(max(apm, vpm) + llm_ms, 2),
+                                                     "note": "legs measured on this GPU; the pinned form (APM / VPM / LLM on three GPUs, module map) adds the two embedding hand-offs (<= 4.7 MB over xGMI)"} if okn else None
             except Exception as e:
                 out["pp512_tok_s"] = None
                 out["pp512_error"] = repr(e)
