@@ -35,6 +35,8 @@ def main():
               (4096, 12288, 2048), (4096, 4096, 4096), (8192, 8192, 8192)]
     if len(sys.argv) > 1 and sys.argv[1] == "--quick":
         shapes = shapes[:4]
+    if "--attn-only" in sys.argv:
+        shapes = []
     for (M, K, N) in shapes:
         c = Context(be)
         w = c.new_tensor(GGML_TYPE_F16, K, M)
