@@ -84,6 +84,77 @@ __global__ void __launch_bounds__(256) k_gemm_any(const gemm_any_dev g) {
     }
 }
 
+// Small products (a Token2Wav DiT projection: 512 x 200 x 512 is 32 tiles of 64 x 64): a wave's 32 x 32 tile needs K / 2 dependent f32 MFMAs of 64
+// cycles each whatever the workgroup tile, so few large tiles mean a long chain on a few CUs.  Here a workgroup owns ONE 32 x 32 tile and its
+// four waves split K (each stages its own 32-wide K-steps through a wave-private LDS region: no workgroup barrier inside the loop); the four
+// partial tiles are folded through LDS in wave order.
+template <typename WT, typename XT>
+__global__ void __launch_bounds__(256) k_gemm_any_sk(const gemm_any_dev g) {
+    constexpr int KS = 32, LD = KS + 1;
+    __shared__ float Ws[4][32 * LD], Xs[4][32 * LD];               // wave-private: a wave's LDS operations execute in order, one buffer is enough
+    __shared__ float red[3][64 * 16];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int tm = (int) blockIdx.x % g.tiles_m, tn = (int) blockIdx.x / g.tiles_m;        // (tiles_m counts 32-row tiles here)
+    const int i12 = (int) blockIdx.y % g.ne12, i13 = (int) blockIdx.y / g.ne12;
+    const char * W = g.W + (size_t) (i12 / g.r2) * g.w_nb2 + (size_t) (i13 / g.r3) * g.w_nb3;
+    const char * X = g.X + (size_t) i12 * g.x_nb2 + (size_t) i13 * g.x_nb3;
+    const int m0 = tm * 32, n0 = tn * 32;
+    // this wave's K range: whole K-steps, the ranges of the four waves cover [0, K)
+    const int nsteps = (g.K + KS - 1) / KS, per = (nsteps + 3) / 4;
+    const int s_lo = wave * per, s_hi = s_lo + per < nsteps ? s_lo + per : nsteps;
+    ga_acc acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.0f;
+    const int fr = lane & 31, kh = lane >> 5, c = lane & 31, r0 = lane >> 5;
+    float wv[16], xv[16];
+    auto fetch = [&](int k0) {                                     // branch-free: clamped addresses, zero selected afterwards
+        const int k = k0 + c, kc = k < g.K ? k : g.K - 1;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int r = r0 + 2 * i;
+            const int mr = m0 + r < g.M ? m0 + r : g.M - 1, nr = n0 + r < g.N ? n0 + r : g.N - 1;
+            const char * pw = W + (size_t) mr * g.w_rs + (size_t) kc * sizeof(WT);
+            const char * px = X + (size_t) nr * g.x_rs + (size_t) kc * sizeof(XT);
+            wv[i] = sizeof(WT) == 2 ? h2f(*(const uint16_t *) pw) : *(const float *) pw;
+            xv[i] = sizeof(XT) == 2 ? h2f(*(const uint16_t *) px) : *(const float *) px;
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int r = r0 + 2 * i;
+            if (sizeof(XT) == 4 && g.round_x) xv[i] = h2f(f2h(xv[i]));
+            if (k >= g.K || m0 + r >= g.M) wv[i] = 0.0f;
+            if (k >= g.K || n0 + r >= g.N) xv[i] = 0.0f;
+        }
+    };
+    if (s_lo < s_hi) fetch(s_lo * KS);
+    for (int s = s_lo; s < s_hi; ++s) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { Ws[wave][(r0 + 2 * i) * LD + c] = wv[i]; Xs[wave][(r0 + 2 * i) * LD + c] = xv[i]; }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (s + 1 < s_hi) fetch((s + 1) * KS);
+#pragma unroll
+        for (int kk = 0; kk < KS / 2; ++kk)
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(Xs[wave][fr * LD + 2 * kk + kh], Ws[wave][fr * LD + 2 * kk + kh], acc, 0, 0, 0);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    if (wave > 0) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) red[wave - 1][e * 64 + lane] = acc[e];
+    }
+    __syncthreads();
+    if (wave > 0) return;
+    char * dst = g.dst + (size_t) i12 * g.dst_nb2 + (size_t) i13 * g.dst_nb3;
+    const int m = m0 + fr;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int n = n0 + (e & 3) + 8 * (e >> 2) + 4 * kh;
+        float v = acc[e];
+#pragma unroll
+        for (int w = 0; w < 3; ++w) v += red[w][e * 64 + lane];
+        if (m < g.M && n < g.N) { float * p = (float *) (dst + (size_t) n * g.dst_cs + (size_t) m * 4); *p = g.accumulate ? *p + v : v; }
+    }
+}
+
 void gemm_any(const gemm_any_args & a, hipStream_t st) {
     if (a.M == 0 || a.N == 0 || a.nbatch == 0) return;
     gemm_any_dev g;
@@ -91,6 +162,15 @@ void gemm_any(const gemm_any_args & a, hipStream_t st) {
     g.X = (const char *) a.X; g.x_rs = a.x_rs; g.x_nb2 = a.x_nb2; g.x_nb3 = a.x_nb3;
     g.dst = (char *) a.dst; g.dst_cs = a.dst_cs; g.dst_nb2 = a.dst_nb2; g.dst_nb3 = a.dst_nb3;
     g.M = (int) a.M; g.N = (int) a.N; g.K = (int) a.K; g.tiles_m = (int) ((a.M + 63) / 64); g.ne12 = a.ne12; g.r2 = a.r2; g.r3 = a.r3; g.round_x = a.w_f16 ? 1 : 0; g.accumulate = a.accumulate ? 1 : 0;
+    static const bool no_sk = getenv("MI355X_GEMM_ANY_NO_SPLIT") != nullptr;
+    if (!no_sk && (int64_t) g.tiles_m * ((a.N + 63) / 64) * a.nbatch < 128 && a.K >= 256) {          // few tiles, long chains: one 32 x 32 tile per workgroup, K split over its waves
+        g.tiles_m = (int) ((a.M + 31) / 32);
+        const dim3 grid((unsigned) (g.tiles_m * ((a.N + 31) / 32)), (unsigned) a.nbatch);
+        if (a.x_f16)      k_gemm_any_sk<uint16_t, uint16_t><<<grid, dim3(256), 0, st>>>(g);
+        else if (a.w_f16) k_gemm_any_sk<uint16_t, float><<<grid, dim3(256), 0, st>>>(g);
+        else              k_gemm_any_sk<float, float><<<grid, dim3(256), 0, st>>>(g);
+        return;
+    }
     const dim3 grid((unsigned) (g.tiles_m * ((a.N + 63) / 64)), (unsigned) a.nbatch);
     if (a.x_f16)      k_gemm_any<uint16_t, uint16_t><<<grid, dim3(256), 0, st>>>(g);       // (F16 activations only come with F16 weights: supports_op)
     else if (a.w_f16) k_gemm_any<uint16_t, float><<<grid, dim3(256), 0, st>>>(g);
