@@ -177,7 +177,8 @@ __global__ void __launch_bounds__(256) k_conv_transpose_1d(const char * __restri
         for (int l = l0; l < L && l * s0 <= pos; ++l) {
             const int k = pos - l * s0;
             float v = 0.0f;
-            for (int c = 0; c < Cin; ++c) {
+#pragma unroll 8
+            for (int c = 0; c < Cin; ++c) {                               // (unrolled: eight channel pairs of loads in flight, the additions in the same order)
                 const float xv = *(const float *) (x + (int64_t) c * x_nb1 + (int64_t) l * 4);
                 if (W16) v += h2f(f2h(xv)) * h2f(*(const uint16_t *) (w + (int64_t) c * w_nb2 + (int64_t) o * w_nb1 + (int64_t) k * 2));
                 else     v += xv * *(const float *) (w + (int64_t) c * w_nb2 + (int64_t) o * w_nb1 + (int64_t) k * 4);
