@@ -818,14 +818,16 @@ static bool exec_gemm_group(exec_state & s, int i) {
         if (ai > mm_idx[q] && g->nodes[ai]->op == GGML_OP_ADD && !s.done[ai]) {
             ggml_tensor * A = g->nodes[ai];
             const ggml_tensor * r = A->src[0] == c ? A->src[1] : A->src[0];
-            if (((A->src[0] == c) != (A->src[1] == c)) && r && r != c && r->type == GGML_TYPE_F32 && same_shape(r, c) && same_shape(A, c) && r->nb[0] == 4 && A->nb[0] == 4 &&
-                A->type == GGML_TYPE_F32 && r->nb[1] % 16 == 0 && A->nb[1] % 16 == 0) {
+            // ... or a bias: r one row of ne0 elements broadcast over the columns (the encoders' linear layers) = a residual with column stride 0
+            const bool bias = r && A->src[0] == c && r->ne[0] == c->ne[0] && r->ne[1] * r->ne[2] * r->ne[3] == 1 && c->ne[1] > 1 && ((uintptr_t) r->data & 15) == 0;
+            if (((A->src[0] == c) != (A->src[1] == c)) && r && r != c && r->type == GGML_TYPE_F32 && (same_shape(r, c) || bias) && same_shape(A, c) && r->nb[0] == 4 && A->nb[0] == 4 &&
+                A->type == GGML_TYPE_F32 && (bias || r->nb[1] % 16 == 0) && A->nb[1] % 16 == 0) {
                 int item[7]; int ni = 0;
                 for (int t = 0; t < a.nmat; ++t) item[ni++] = mm_idx[t];
                 for (int t = 0; t < q; ++t) if (add_idx[t] >= 0) item[ni++] = add_idx[t];
                 item[ni++] = ai;
                 if (can_hoist(s, i, ai, item, ni)) {
-                    a.m[q].resid = (const float *) r->data; a.m[q].resid_cs = r->nb[1];
+                    a.m[q].resid = (const float *) r->data; a.m[q].resid_cs = bias ? 0 : r->nb[1];
                     a.m[q].dst = (float *) A->data; a.m[q].dst_cs = A->nb[1];
                     add_idx[q] = ai;
                 }
