@@ -4,8 +4,14 @@
 // activations cast F32 -> F16, FP32 accumulate and FP32 output on CDNA, :1293-1303), and is what the CPU oracle computes in
 // ggml_compute_forward_mul_mat for F16 weights (src1 rounded to the F16 vec_dot_type, f32 accumulation; ggml-cpu.c:1245-1268).
 //     dst[n][m] = sum_k W[m][k] * X[n][k]          W: M x K f16 rows, X: N x K f16 rows (K contiguous in both), dst f32
-// Quantised weights reach this kernel through a de-quantise-to-f16 pass (dequant_rows_f16); fusing that into the LDS staging is
-// the next step.
+// Quantised weights reach these kernels as resident F16 images (shadow.cpp), or -- without an image -- as the K-quant blocks themselves,
+// de-quantised inside the LDS staging (k_gemm_kq_glds).  Kernels in this file, by shape:
+//     k_gemm_f16           K % 64 != 0 (K % 32 == 0): 128 x 128 x 32, register staging                       (below)
+//     k_gemm_f16_glds<MB>  the general prefill kernel: 64 MB x 128 x 64, LDS-DMA staging, up to 3 matrices, residual / bias epilogue,
+//                          deterministic split-K (grouped launches too at <= 256 columns), batch over heads
+//     k_gemm_kq_glds       the same tile on Q4_K / Q6_K blocks de-quantised in the staging (weights without a resident image)
+//     k_gemm_f16_glds256   256 x 256, one barrier per K-step (kept for A/B)
+//     k_gemm_f16_ph8       256 x 256, eight-phase never-draining pipeline; <.., true>: ffn_gate / ffn_up + SWIGLU in one launch
 //
 // v_mfma_f32_32x32x16_f16: the A fragment of lane l is 8 consecutive k of row l%32 (k-octet l/32), the B fragment likewise --
 // both operands are K-contiguous rows here, so each fragment is ONE 16-byte LDS read.  X supplies the rows (i) and W the columns
