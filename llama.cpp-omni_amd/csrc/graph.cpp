@@ -243,10 +243,11 @@ bool supports_op(const ggml_tensor * op) {
             const ggml_tensor * q = s0, * k = s1, * v = op->src[2], * m = op->src[3];
             if (!q || !k || !v) return false;
             if (q->type != GGML_TYPE_F32 || k->type != GGML_TYPE_F16 || v->type != GGML_TYPE_F16 || op->type != GGML_TYPE_F32) return false;
-            if (q->ne[0] != k->ne[0] || k->ne[0] != v->ne[0]) return false;
-            if (q->ne[0] != 64 && q->ne[0] != 128) return false;
+            if (q->ne[0] != k->ne[0]) return false;
+            const bool special = (q->ne[0] == 64 || q->ne[0] == 128) && v->ne[0] == q->ne[0];          // the MFMA / streaming / one-token kernels; anything else: fattn_any.hip
+            if (!special && (q->ne[0] > 576 || v->ne[0] > 576)) return false;
             if (q->nb[0] != 4 || k->nb[0] != 2 || v->nb[0] != 2) return false;
-            if (k->nb[1] % 16 != 0 || v->nb[1] % 16 != 0 || k->nb[2] % 16 != 0 || v->nb[2] % 16 != 0) return false;
+            if (special && (k->nb[1] % 16 != 0 || v->nb[1] % 16 != 0 || k->nb[2] % 16 != 0 || v->nb[2] % 16 != 0)) return false;
             if (m && (m->type != GGML_TYPE_F16 || m->nb[0] != 2)) return false;
             if (op->src[4] && op->src[4]->type != GGML_TYPE_F32) return false;
             if (k->ne[2] == 0 || q->ne[2] % k->ne[2] != 0 || k->ne[2] != v->ne[2] || q->ne[3] != k->ne[3]) return false;
@@ -1128,7 +1129,7 @@ static void seed_act_f16(exec_state & s, const ggml_tensor * x) {              /
 static bool try_defer_qkv_to_attention(exec_state & s, const nr_chain & A, const nr_chain * B, int vj, const int * item, int ni) {
     static const bool off = getenv("MI355X_NO_QKV_IN_ATTN") != nullptr;
     ggml_cgraph * g = s.g;
-    if (off || A.T != 1 || !B || B->store < 0 || vj < 0 || A.store >= 0 || A.D > 128) return false;
+    if (off || A.T != 1 || !B || B->store < 0 || vj < 0 || A.store >= 0 || (A.D != 64 && A.D != 128)) return false;
     const ggml_tensor * rq = g->nodes[A.rope];
     // follow the single-consumer view chain from rope(q) to the attention node
     const ggml_tensor * t = rq; int fi = -1;
@@ -1820,6 +1821,11 @@ static void compute_node(exec_state & s, int i) {
         case GGML_OP_FLASH_ATTN_EXT: {
             fattn_args f; tdesc m;
             fill_fattn_args(n, f, m);
+            if ((n->src[0]->ne[0] != 64 && n->src[0]->ne[0] != 128) || n->src[2]->ne[0] != n->src[0]->ne[0]) {      // other head sizes: the generic kernel, no fused stage
+                prof_scope ps(s, "fattn", 0);
+                flash_attn_ext_f16(f, s.st); ++s.n_kernels;
+                break;
+            }
             const bool with_pre = s.pq.fa == i;
             if (with_pre) f.pre = &s.pq.pre;
             // one token over a shallow cache: the latency-optimised kernel (fattn_one.hip) takes the token's (cos, sin) from a table that is

@@ -565,10 +565,12 @@ def test_gate_up_swiglu_in_the_gemm_epilogue_vs_oracle(pkg, be):
 C1 = dict(arch="llama", n_embd=288, n_layer=6, n_head=6, n_head_kv=6, head_dim=48, n_ff=768, n_vocab=32000, rms_eps=1e-5, rope_base=1e4, n_ctx_orig=2048)
 
 
-def test_c1_stories15m_shape_f16_vs_reference_backend(pkg, be, ref_be):
+@pytest.mark.parametrize("fa", [False, True])
+def test_c1_stories15m_shape_f16_vs_reference_backend(pkg, be, ref_be, fa):
     """BASELINE.json configs[0] (the reference's own CPU-runnable case): llama architecture at the stories15M widths --
     n_embd 288, 6 layers, 6 heads x 48 (a head size the attention kernels are not specialised for), n_ff 768, vocabulary 32000, every
-    matrix F16, flash-attention off (llama-bench's default): a 24-token prefill ubatch and 8 decode steps on the device against the reference
+    matrix F16, flash-attention off (llama-bench's default) and on (head size 48 -> the generic k_fattn_any, no CPU hand-off): a 24-token prefill
+    ubatch and 8 decode steps on the device against the reference
     CPU backend on the same graphs.  F16 weights: products identical, only the f32 summation order differs -> logits NMSE < 1e-6 and
     identical arg-max wherever the reference's top two logits are not within that noise."""
     from llama_cpp_omni_amd import qwen3
@@ -578,7 +580,7 @@ def test_c1_stories15m_shape_f16_vs_reference_backend(pkg, be, ref_be):
     embd = rng.standard_normal((n_pre + steps, C1["n_embd"])).astype(np.float32)
     res = []
     for backend in (be, ref_be):
-        mdl = qwen3.Model(backend, C1, types, n_ctx=n_kv, seed=21, flash_attn=False)
+        mdl = qwen3.Model(backend, C1, types, n_ctx=n_kv, seed=21, flash_attn=fa)
         gp, Ip, lp = mdl.build(n_pre, n_kv)
         mdl.set_inputs(Ip, embd[:n_pre], 0, n_kv)
         backend.graph_compute(gp.graph())
@@ -594,8 +596,8 @@ def test_c1_stories15m_shape_f16_vs_reference_backend(pkg, be, ref_be):
     got, want = res
     assert np.isfinite(got).all()
     e = nmse(got, want)
-    print("C1 shape: logits NMSE vs the reference CPU backend", e)
-    assert e < 1e-6, e
+    print("C1 shape, flash-attention", fa, ": logits NMSE vs the reference CPU backend", e)
+    assert e < (1e-4 if fa else 1e-6), e                        # (flash-attention on: the reference accumulates V in f16, ops.cpp:8069-8083)
     for t in range(got.shape[0]):
         if got[t].argmax() != want[t].argmax():
             rms = float(np.sqrt(np.mean((got[t] - want[t]) ** 2)))
