@@ -242,11 +242,14 @@ bool supports_op(const ggml_tensor * op) {
         case GGML_OP_FLASH_ATTN_EXT: {
             const ggml_tensor * q = s0, * k = s1, * v = op->src[2], * m = op->src[3];
             if (!q || !k || !v) return false;
-            if (q->type != GGML_TYPE_F32 || k->type != GGML_TYPE_F16 || v->type != GGML_TYPE_F16 || op->type != GGML_TYPE_F32) return false;
+            if (q->type != GGML_TYPE_F32 || k->type != v->type || op->type != GGML_TYPE_F32) return false;
+            if (k->type != GGML_TYPE_F16 && k->type != GGML_TYPE_F32 && k->type != GGML_TYPE_BF16 && k->type != GGML_TYPE_Q8_0 && k->type != GGML_TYPE_Q4_0) return false;
             if (q->ne[0] != k->ne[0]) return false;
-            const bool special = (q->ne[0] == 64 || q->ne[0] == 128) && v->ne[0] == q->ne[0];          // the MFMA / streaming / one-token kernels; anything else: fattn_any.hip
+            // the MFMA / streaming / one-token kernels (F16 cache, head 64 / 128); anything else -- other head sizes, a quantised / BF16 / F32 cache -- fattn_any.hip
+            const bool special = k->type == GGML_TYPE_F16 && (q->ne[0] == 64 || q->ne[0] == 128) && v->ne[0] == q->ne[0];
             if (!special && (q->ne[0] > 576 || v->ne[0] > 576)) return false;
-            if (q->nb[0] != 4 || k->nb[0] != 2 || v->nb[0] != 2) return false;
+            if ((k->type == GGML_TYPE_Q8_0 || k->type == GGML_TYPE_Q4_0) && (k->ne[0] % 32 != 0 || v->ne[0] % 32 != 0)) return false;
+            if (q->nb[0] != 4 || k->nb[0] != type_size(k->type) || v->nb[0] != type_size(v->type)) return false;
             if (special && (k->nb[1] % 16 != 0 || v->nb[1] % 16 != 0 || k->nb[2] % 16 != 0 || v->nb[2] % 16 != 0)) return false;
             if (m && (m->type != GGML_TYPE_F16 || m->nb[0] != 2)) return false;
             if (op->src[4] && op->src[4]->type != GGML_TYPE_F32) return false;
@@ -316,7 +319,7 @@ static void fill_fattn_args(const ggml_tensor * n, fattn_args & f, tdesc & m) {
     f.mask = n->src[3] ? &m : nullptr;
     f.sinks = n->src[4] ? (const float *) n->src[4]->data : nullptr;
     f.scale = op_param_f32(n, 0); f.max_bias = op_param_f32(n, 1); f.logit_softcap = op_param_f32(n, 2);
-    f.scratch = nullptr; f.scratch_bytes = 0;
+    f.scratch = nullptr; f.scratch_bytes = 0; f.kv_type = n->src[1]->type;
 }
 static size_t graph_fa_scratch_need(const ggml_cgraph * g) {
     size_t need = 0;
@@ -1821,7 +1824,7 @@ static void compute_node(exec_state & s, int i) {
         case GGML_OP_FLASH_ATTN_EXT: {
             fattn_args f; tdesc m;
             fill_fattn_args(n, f, m);
-            if ((n->src[0]->ne[0] != 64 && n->src[0]->ne[0] != 128) || n->src[2]->ne[0] != n->src[0]->ne[0]) {      // other head sizes: the generic kernel, no fused stage
+            if ((n->src[0]->ne[0] != 64 && n->src[0]->ne[0] != 128) || n->src[2]->ne[0] != n->src[0]->ne[0] || n->src[1]->type != GGML_TYPE_F16) {      // other head sizes / cache types: the generic kernel, no fused stage
                 prof_scope ps(s, "fattn", 0);
                 flash_attn_ext_f16(f, s.st); ++s.n_kernels;
                 break;

@@ -157,6 +157,7 @@ struct fattn_pre {
 // FLASH_ATTN_EXT (ops.cpp:7912-8148): q f32 [D, nq, nh, ns], k/v f16 [D, nkv, nhkv, ns], mask f16 [nkv, >=nq, 1|nh?, ns]
 struct fattn_args {
     tdesc q, k, v, dst;
+    int kv_type = 1;         // GGML type of K and V (F16 = 1: every specialised kernel; F32 / BF16 / Q8_0 / Q4_0: fattn_any.hip)
     const tdesc * mask;      // may be null
     const float * sinks;     // may be null
     float scale, max_bias, logit_softcap;

@@ -531,10 +531,10 @@ void flash_attn_ext_f16(const fattn_args & f, hipStream_t st) {
         a.pre = { (const char *) p.qraw, p.q_hs, (const char *) p.kraw, p.k_hs, (const char *) p.vraw, p.v_hs, p.qw, p.kw, p.pos, p.ff, p.eps, make_rope_dev(p.rp),
                   (char *) p.kcache, p.kc_rs, (char *) p.vcache, p.vc_rs, (const char *) p.kidx, (const char *) p.vidx, p.idx_is64 };
     }
-    if ((f.q.ne[0] != 64 && f.q.ne[0] != 128) || f.v.ne[0] != f.q.ne[0]) {          // other head sizes: the generic kernel (no pre-stage, no images)
+    if ((f.q.ne[0] != 64 && f.q.ne[0] != 128) || f.v.ne[0] != f.q.ne[0] || f.kv_type != GGML_TYPE_F16) {     // other head sizes / cache types: the generic kernel (no pre-stage, no images)
         if (f.pre || f.img || f.out16 || !fattn_any_ok(f.q.ne[0], f.v.ne[0])) { fprintf(stderr, "[mi355x] flash_attn: head size %d / %d with a fused stage\n", (int) f.q.ne[0], (int) f.v.ne[0]); abort(); }
         a.nsplit = 1; a.part = nullptr; a.tile_map = nullptr; a.map_nqb = 0;
-        flash_attn_ext_any(a, (int) f.q.ne[0], (int) f.v.ne[0], st);
+        flash_attn_ext_any(a, (int) f.q.ne[0], (int) f.v.ne[0], f.kv_type, st);
         return;
     }
     if (f.pre && f.rope_tab && fattn_one_ok(f)) {                    // one token, up to 4096 cache rows: the latency-optimised one-token kernel

@@ -43,6 +43,6 @@ void flash_attn_ext_gqa(const fa_dev & a, int D, int nw, hipStream_t st);
 void flash_attn_one(const fa_dev & a, int D, const float * rope_tab, hipStream_t st);
 // any other head size (fattn_any.hip): one wave per (query row, head, sequence)
 bool fattn_any_ok(int64_t Dk, int64_t Dv);
-void flash_attn_ext_any(const fa_dev & a, int Dk, int Dv, hipStream_t st);
+void flash_attn_ext_any(const fa_dev & a, int Dk, int Dv, int kv_type, hipStream_t st);      // kv_type: F16 / F32 / BF16 / Q8_0 / Q4_0 (K and V alike)
 
 } // namespace mi

@@ -49,6 +49,7 @@ _TRAITS = {  # type -> (block elements, block bytes, numpy dtype or None)
     GGML_TYPE_I32: (1, 4, np.int32), GGML_TYPE_I64: (1, 8, np.int64),
     2: (32, 18, None), 3: (32, 20, None), 6: (32, 22, None), 7: (32, 24, None),      # Q4_0 Q4_1 Q5_0 Q5_1
     10: (256, 84, None), 11: (256, 110, None), 13: (256, 176, None),                # Q2_K Q3_K Q5_K
+    30: (1, 2, np.uint16),                                                          # BF16 (as raw 16-bit words)
 }
 
 

@@ -223,3 +223,60 @@ def test_layer_norm_rows_vs_reference_backend(pkg, be, ref_be, n, rows):
         return dict(x=x), [c.norm(x, 1e-5)]
     got, want = _both(pkg, be, ref_be, build, dict(x=(rng.standard_normal(n * rows) * 2 + 0.3).astype(np.float32)))
     assert nmse(got[0], want[0]) < 1e-12, nmse(got[0], want[0])
+
+
+@pytest.mark.parametrize("kv_type,D,Dv,nq,nkv,H,HK", [("f16", 96, 96, 5, 70, 4, 2), ("f16", 192, 128, 3, 113, 4, 4), ("q8_0", 128, 128, 4, 96, 8, 2), ("q4_0", 64, 64, 35, 130, 4, 4),
+                                                      ("bf16", 80, 80, 2, 64, 2, 1), ("f32", 40, 40, 7, 50, 2, 2), ("q8_0", 256, 256, 1, 300, 4, 1)])
+def test_flash_attn_other_head_sizes_and_cache_types_vs_reference_backend(pkg, be, ref_be, kv_type, D, Dv, nq, nkv, H, HK):
+    """fattn_any.hip: FLASH_ATTN_EXT at head sizes other than 64 / 128 (incl. K and V heads of different size) and with F32 / BF16 / Q8_0 / Q4_0
+    K / V (a quantised KV cache), causal mask with a -inf tail, GQA broadcast, against the reference CPU backend.  The node must be accepted by
+    supports_op (no hand-off to the CPU backend under the scheduler)."""
+    from llama_cpp_omni_amd import encoders as E, qwen3
+    rng = np.random.default_rng(D + nq + nkv)
+    T = dict(f16=pkg.GGML_TYPE_F16, f32=pkg.GGML_TYPE_F32, bf16=30, q8_0=pkg.GGML_TYPE_Q8_0, q4_0=2)[kv_type]
+    kf = rng.standard_normal((HK * nkv, D)).astype(np.float32); vf = rng.standard_normal((HK * nkv, Dv)).astype(np.float32)
+
+    def enc(x):
+        if kv_type == "f16":
+            return x.astype(np.float16)
+        if kv_type == "f32":
+            return x
+        if kv_type == "bf16":
+            u = x.view(np.uint32); return ((u + 0x7fff + ((u >> 16) & 1)) >> 16).astype(np.uint16)
+        rows, n = x.shape
+        b = x.reshape(rows, n // 32, 32)
+        if kv_type == "q8_0":
+            d = (np.abs(b).max(-1) / 127.0).astype(np.float16)
+            q = np.rint(b / np.where(d == 0, 1, d).astype(np.float32)[..., None]).clip(-127, 127).astype(np.int8)
+            out = np.zeros((rows, n // 32, 34), np.uint8)
+            out[..., :2] = d[..., None].view(np.uint8).reshape(rows, n // 32, 2); out[..., 2:] = q.view(np.uint8)
+            return out
+        amax_i = np.abs(b).argmax(-1)
+        mx = np.take_along_axis(b, amax_i[..., None], -1)[..., 0]
+        d = (mx / -8.0).astype(np.float16)
+        q = np.clip(np.floor(b / np.where(d == 0, 1, d).astype(np.float32)[..., None] + 8.5), 0, 15).astype(np.uint8)
+        out = np.zeros((rows, n // 32, 18), np.uint8)
+        out[..., :2] = d[..., None].view(np.uint8).reshape(rows, n // 32, 2); out[..., 2:] = q[..., :16] | (q[..., 16:] << 4)
+        return out
+    mask = np.zeros((((nq + 63) // 64) * 64, nkv), np.float32)
+    for i in range(nq):
+        mask[i, nkv - nq + i + 1:] = -np.inf
+    res = []
+    for backend in (be, ref_be):
+        c = pkg.Context(backend)
+        q = c.new_tensor(pkg.GGML_TYPE_F32, D, nq, H); k = c.new_tensor(T, D, nkv, HK); v = c.new_tensor(T, Dv, nkv, HK)
+        m = c.new_tensor(pkg.GGML_TYPE_F16, nkv, mask.shape[0])
+        y = c.flash_attn_ext(q, k, v, m, 1.0 / np.sqrt(D))
+        if backend is be:
+            assert not E.declined_nodes(backend, c)
+        c.alloc()
+        backend.tensor_set(q, rng.standard_normal(D * nq * H).astype(np.float32) if backend is be else qv)
+        if backend is be:
+            qv = backend.tensor_get(q).copy()
+        backend.tensor_set(k, enc(kf)); backend.tensor_set(v, enc(vf)); backend.tensor_set(m, mask.astype(np.float16))
+        backend.graph_compute(c.graph())
+        res.append(backend.tensor_get(y).copy())
+        c.free()
+    assert np.isfinite(res[0]).all()
+    e = nmse(res[0], res[1])
+    assert e < (1e-5 if kv_type == "f16" else 1e-9), (kv_type, e)          # F16 V: the reference accumulates V in f16 (ops.cpp:8069-8083), this kernel in f32
