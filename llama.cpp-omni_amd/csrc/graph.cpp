@@ -237,7 +237,8 @@ bool supports_op(const ggml_tensor * op) {
             }
         }
         case GGML_OP_SET_ROWS:
-            return s0 && s1 && s0->type == GGML_TYPE_F32 && (op->type == GGML_TYPE_F16 || op->type == GGML_TYPE_F32) &&
+            return s0 && s1 && s0->type == GGML_TYPE_F32 &&
+                   (op->type == GGML_TYPE_F16 || op->type == GGML_TYPE_F32 || op->type == GGML_TYPE_BF16 || ((op->type == GGML_TYPE_Q8_0 || op->type == GGML_TYPE_Q4_0) && s0->ne[0] % 32 == 0)) &&
                    (s1->type == GGML_TYPE_I64 || s1->type == GGML_TYPE_I32) && s0->nb[0] == 4 && op->nb[0] == type_size(op->type);
         case GGML_OP_FLASH_ATTN_EXT: {
             const ggml_tensor * q = s0, * k = s1, * v = op->src[2], * m = op->src[3];

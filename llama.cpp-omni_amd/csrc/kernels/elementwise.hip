@@ -1043,8 +1043,61 @@ __global__ void __launch_bounds__(256) k_set_rows_1elem(const char * __restrict_
     }
 }
 
+// SET_ROWS into a quantised / BF16 table (a KV cache kept as Q8_0 / Q4_0 / BF16: llama_kv_cache::cpy_k / cpy_v with -ctk / -ctv): the row goes
+// through the type's from_float like ggml_compute_forward_set_rows_f32 does -- quantize_row_q8_0 as the x86 build compiles it (d = amax / 127 stored
+// as f16, id = 127 / amax, round-half-even), quantize_row_q4_0_ref (ggml-quants.c: the FIRST value of largest magnitude decides d = max / -8,
+// q = min(15, (int8) (x / d + 8.5))), ggml_compute_fp32_to_bf16.  One thread per 32-element block (per element for BF16).
+template <int T, typename TI>
+__global__ void __launch_bounds__(256) k_set_rows_q(td4 s, td4 idx, td4 d, int64_t total) {
+    const int64_t t = (int64_t) blockIdx.x * 256 + threadIdx.x;
+    if (t >= total) return;
+    const int64_t per_row = T == GGML_TYPE_BF16 ? s.ne[0] : s.ne[0] / 32;
+    const int64_t ib = t % per_row; int64_t r = t / per_row;
+    const int64_t i = r % s.ne[1]; r /= s.ne[1];
+    const int64_t i02 = r % s.ne[2], i03 = r / s.ne[2];
+    const int64_t i1 = (int64_t) *(const TI *) (idx.p + i * idx.nb[0] + (i02 % idx.ne[1]) * idx.nb[1] + (i03 % idx.ne[2]) * idx.nb[2]);
+    const float * sr = (const float *) (s.p + i * s.nb[1] + i02 * s.nb[2] + i03 * s.nb[3]);
+    char * dr = d.p + i1 * d.nb[1] + i02 * d.nb[2] + i03 * d.nb[3];
+    if (T == GGML_TYPE_BF16) {
+        uint32_t u = __float_as_uint(sr[ib]);
+        u = (u & 0x7fffffffu) > 0x7f800000u ? (u >> 16) | 64u : (u + (0x7fffu + ((u >> 16) & 1u))) >> 16;
+        ((uint16_t *) dr)[ib] = (uint16_t) u;
+        return;
+    }
+    const float * x = sr + ib * 32;
+    if (T == GGML_TYPE_Q8_0) {
+        float amax = 0.0f;
+        for (int j = 0; j < 32; ++j) amax = fmaxf(amax, fabsf(x[j]));
+        const float dd = amax / 127.0f, id = amax != 0.0f ? 127.0f / amax : 0.0f;
+        char * b = dr + ib * 34;
+        *(uint16_t *) b = f2h(dd);
+        for (int j = 0; j < 32; ++j) b[2 + j] = (char) (int8_t) (int) rintf(x[j] * id);
+    } else {                                                             // Q4_0
+        float amax = 0.0f, mx = 0.0f;
+        for (int j = 0; j < 32; ++j) { const float v = x[j]; if (amax < fabsf(v)) { amax = fabsf(v); mx = v; } }
+        const float dd = mx / -8.0f, id = dd != 0.0f ? 1.0f / dd : 0.0f;
+        char * b = dr + ib * 18;
+        *(uint16_t *) b = amax == 0.0f ? (uint16_t) 0x8000u : f2h(dd);     // an all-zero block: d = +0 / -8 = -0 in the reference (kept explicit: the compiler's division drops the sign)
+        for (int j = 0; j < 16; ++j) {
+            const int q0 = (int) (int8_t) (x[j] * id + 8.5f), q1 = (int) (int8_t) (x[16 + j] * id + 8.5f);
+            b[2 + j] = (char) ((q0 < 15 ? q0 : 15) | ((q1 < 15 ? q1 : 15) << 4));
+        }
+    }
+}
+
 void set_rows(const tdesc & src, const tdesc & idx, int idx_type, const tdesc & dst, int dst_type, hipStream_t st, int64_t period) {
     if (src.ne[0] * src.ne[1] * src.ne[2] * src.ne[3] == 0) return;
+    if (dst_type == GGML_TYPE_Q8_0 || dst_type == GGML_TYPE_Q4_0 || dst_type == GGML_TYPE_BF16) {
+        const int64_t per_row = dst_type == GGML_TYPE_BF16 ? src.ne[0] : src.ne[0] / 32;
+        const int64_t total = per_row * src.ne[1] * src.ne[2] * src.ne[3];
+        const dim3 grid((unsigned) ((total + 255) / 256));
+        const td4 s = to_td4(src), i = to_td4(idx), d = to_td4(dst);
+        const bool i64 = idx_type == GGML_TYPE_I64;
+#define SRQ(T) do { if (i64) k_set_rows_q<T, int64_t><<<grid, dim3(256), 0, st>>>(s, i, d, total); else k_set_rows_q<T, int32_t><<<grid, dim3(256), 0, st>>>(s, i, d, total); } while (0)
+        if (dst_type == GGML_TYPE_Q8_0) SRQ(GGML_TYPE_Q8_0); else if (dst_type == GGML_TYPE_Q4_0) SRQ(GGML_TYPE_Q4_0); else SRQ(GGML_TYPE_BF16);
+#undef SRQ
+        return;
+    }
     if (src.ne[0] == 1 && src.ne[2] == 1 && src.ne[3] == 1 && src.ne[1] >= 4096 && (dst_type == GGML_TYPE_F16 || dst_type == GGML_TYPE_F32) && idx.ne[1] * idx.ne[2] * idx.ne[3] == 1) {
         const int64_t R = src.ne[1];
         int64_t P = period > 0 && R % period == 0 ? period : (R % 1024 == 0 ? 1024 : (R % 64 == 0 ? 64 : 1));

@@ -280,3 +280,31 @@ def test_flash_attn_other_head_sizes_and_cache_types_vs_reference_backend(pkg, b
     assert np.isfinite(res[0]).all()
     e = nmse(res[0], res[1])
     assert e < (1e-5 if kv_type == "f16" else 1e-9), (kv_type, e)          # F16 V: the reference accumulates V in f16 (ops.cpp:8069-8083), this kernel in f32
+
+
+@pytest.mark.parametrize("tname", ["q8_0", "q4_0", "bf16"])
+def test_set_rows_into_a_quantised_cache_bit_exact_vs_reference_backend(pkg, be, ref_be, tname):
+    """SET_ROWS f32 -> Q8_0 / Q4_0 / BF16 rows (a KV cache with -ctk / -ctv): the table bytes must equal the reference CPU backend's -- the
+    from_float of each type (quantize_row_q8_0 as compiled for x86, quantize_row_q4_0_ref, fp32 -> bf16 round-to-nearest-even), incl. an all-zero
+    block, ties of the largest magnitude and values that round at .5."""
+    rng = np.random.default_rng(7)
+    T = dict(q8_0=pkg.GGML_TYPE_Q8_0, q4_0=2, bf16=30)[tname]
+    n, rows, table = 256, 37, 64
+    x = rng.standard_normal((rows, n)).astype(np.float32)
+    x[3, :32] = 0.0                                               # an all-zero block
+    x[5, 32:64] = np.tile(np.array([1.5, -1.5], np.float32), 16)  # ties of the largest magnitude (first one decides Q4_0's sign)
+    x[7, :32] = (np.arange(32, dtype=np.float32) - 16) * 0.5      # halves after scaling
+    ids = rng.permutation(table)[:rows].astype(np.int64)
+    res = []
+    for backend in (be, ref_be):
+        c = pkg.Context(backend)
+        tab = c.new_tensor(T, n, table); src = c.new_tensor(pkg.GGML_TYPE_F32, n, rows); ix = c.new_tensor(pkg.GGML_TYPE_I64, rows)
+        out = c.set_rows(tab, src, ix)
+        c.alloc()
+        nb = tab.nbytes()
+        backend.tensor_set(tab, np.zeros(nb // 2, np.uint16) if tname == "bf16" else np.zeros(nb, np.uint8))
+        backend.tensor_set(src, x); backend.tensor_set(ix, ids)
+        backend.graph_compute(c.graph())
+        res.append(np.asarray(backend.tensor_get(out)).copy().view(np.uint8))
+        c.free()
+    assert np.array_equal(res[0], res[1]), tname
