@@ -124,6 +124,9 @@ bool supports_op(const ggml_tensor * op) {
             return true;
         case GGML_OP_MUL_MAT: {
             if (!s0 || !s1) return false;
+            if (s0->type == GGML_TYPE_BF16)                          // BF16 weights: the any-shape f32-MFMA GEMM at every column count (gemm_any.hip)
+                return s1->type == GGML_TYPE_F32 && op->type == GGML_TYPE_F32 && s0->nb[0] == 2 && s1->nb[0] == 4 && op->nb[0] == 4 && s0->nb[1] >= (size_t) s0->ne[0] * 2 &&
+                       s0->ne[2] != 0 && s0->ne[3] != 0 && s1->ne[2] % s0->ne[2] == 0 && s1->ne[3] % s0->ne[3] == 0 && s1->ne[2] * s1->ne[3] <= 65535;
             const act_kind k = act_kind_for(s0->type);
             if (k == ACT_NONE || op->type != GGML_TYPE_F32) return false;
             if (s1->type != GGML_TYPE_F32 && !(s1->type == GGML_TYPE_F16 && k == ACT_F16)) return false;      // F16 x F16: the convolutions' mat-mul
@@ -497,6 +500,18 @@ static void op_mul_mat(exec_state & s, const ggml_tensor * dst) {
         return;
     }
 
+    if (w->type == GGML_TYPE_BF16) {
+        if (s.pn.m && x == s.pn.m) materialise_norm(s);
+        gemm_any_args a;
+        a.W = w->data; a.w_rs = w->nb[1]; a.w_nb2 = w->nb[2]; a.w_nb3 = w->nb[3]; a.w_f16 = false; a.w_bf16 = true;
+        a.X = x->data; a.x_rs = x->nb[1]; a.x_nb2 = x->nb[2]; a.x_nb3 = x->nb[3];
+        a.dst = (float *) dst->data; a.dst_cs = dst->nb[1]; a.dst_nb2 = dst->nb[2]; a.dst_nb3 = dst->nb[3];
+        a.M = M; a.N = N; a.K = K; a.nbatch = (int) (ne12 * ne13); a.ne12 = (int) ne12; a.r2 = (int) r2; a.r3 = (int) r3;
+        prof_scope ps(s, "gemm_any_bf16", 2.0 * (double) M * (double) N * (double) K * (double) (ne12 * ne13));
+        gemm_any(a, s.st);
+        ++s.n_kernels;
+        return;
+    }
     const act_kind kind = act_kind_for(w->type);
     // more than 8 columns against F32 weights, or F16 weights with a contraction length the F16 GEMM does not take (the omni encoders, Token2Wav):
     // one f32-MFMA launch over every (head, batch) instead of a mat-vec launch per 8 columns per head

@@ -249,7 +249,7 @@ long   gemm_variant_launches(int v);      // launches so far of the 256 x 256 (0
 bool   gemm_glu_ok(const gemm_multi_args & a);
 // any-shape f32-MFMA GEMM (gemm_any.hip): F32 weights, or F16 weights whose K the F16 GEMM does not take; X f32 rows (rounded to f16 when w_f16)
 struct gemm_any_args {
-    const void * W; size_t w_rs, w_nb2 = 0, w_nb3 = 0; bool w_f16;
+    const void * W; size_t w_rs, w_nb2 = 0, w_nb3 = 0; bool w_f16; bool w_bf16 = false;      // (w_bf16: 16-bit weights are BF16, activations rounded to bf16: ggml_vec_dot_bf16)
     const void * X; size_t x_rs, x_nb2 = 0, x_nb3 = 0; bool x_f16 = false;     // f32 rows, or f16 rows (with F16 weights)
     float * dst; size_t dst_cs, dst_nb2 = 0, dst_nb3 = 0;
     int64_t M, N, K; int nbatch = 1, ne12 = 1, r2 = 1, r3 = 1;

@@ -20,7 +20,7 @@ struct gemm_any_dev {
     const char * W; size_t w_rs, w_nb2, w_nb3;
     const char * X; size_t x_rs, x_nb2, x_nb3;
     char * dst; size_t dst_cs, dst_nb2, dst_nb3;
-    int M, N, K, tiles_m, ne12, r2, r3, round_x, accumulate;
+    int M, N, K, tiles_m, ne12, r2, r3, round_x, accumulate;      // round_x: 0 none, 1 activations rounded to f16, 2 to bf16 (and the 16-bit weights are bf16)
 };
 
 template <typename WT, typename XT>
@@ -48,13 +48,14 @@ __global__ void __launch_bounds__(256) k_gemm_any(const gemm_any_dev g) {
             const int mr = m0 + r < g.M ? m0 + r : g.M - 1, nr = n0 + r < g.N ? n0 + r : g.N - 1;
             const char * pw = W + (size_t) mr * g.w_rs + (size_t) kc * sizeof(WT);
             const char * px = X + (size_t) nr * g.x_rs + (size_t) kc * sizeof(XT);
-            wv[i] = sizeof(WT) == 2 ? h2f(*(const uint16_t *) pw) : *(const float *) pw;
+            wv[i] = sizeof(WT) == 2 ? (g.round_x == 2 ? __uint_as_float((uint32_t) *(const uint16_t *) pw << 16) : h2f(*(const uint16_t *) pw)) : *(const float *) pw;
             xv[i] = sizeof(XT) == 2 ? h2f(*(const uint16_t *) px) : *(const float *) px;       // (F16 x F16: the im2col columns of the encoders' convolutions)
         }
 #pragma unroll
         for (int i = 0; i < PT; ++i) {
             const int r = r0 + 8 * i;
-            if (sizeof(XT) == 4 && g.round_x) xv[i] = h2f(f2h(xv[i]));
+            if (sizeof(XT) == 4 && g.round_x == 1) xv[i] = h2f(f2h(xv[i]));
+            if (sizeof(XT) == 4 && g.round_x == 2) { uint32_t u = __float_as_uint(xv[i]); u = (u & 0x7fffffffu) > 0x7f800000u ? (u | 0x00400000u) & 0xffff0000u : (u + (0x7fffu + ((u >> 16) & 1u))) & 0xffff0000u; xv[i] = __uint_as_float(u); }
             if (k >= g.K || m0 + r >= g.M) wv[i] = 0.0f;
             if (k >= g.K || n0 + r >= g.N) xv[i] = 0.0f;
         }
@@ -115,13 +116,14 @@ __global__ void __launch_bounds__(256) k_gemm_any_sk(const gemm_any_dev g) {
             const int mr = m0 + r < g.M ? m0 + r : g.M - 1, nr = n0 + r < g.N ? n0 + r : g.N - 1;
             const char * pw = W + (size_t) mr * g.w_rs + (size_t) kc * sizeof(WT);
             const char * px = X + (size_t) nr * g.x_rs + (size_t) kc * sizeof(XT);
-            wv[i] = sizeof(WT) == 2 ? h2f(*(const uint16_t *) pw) : *(const float *) pw;
+            wv[i] = sizeof(WT) == 2 ? (g.round_x == 2 ? __uint_as_float((uint32_t) *(const uint16_t *) pw << 16) : h2f(*(const uint16_t *) pw)) : *(const float *) pw;
             xv[i] = sizeof(XT) == 2 ? h2f(*(const uint16_t *) px) : *(const float *) px;
         }
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const int r = r0 + 2 * i;
-            if (sizeof(XT) == 4 && g.round_x) xv[i] = h2f(f2h(xv[i]));
+            if (sizeof(XT) == 4 && g.round_x == 1) xv[i] = h2f(f2h(xv[i]));
+            if (sizeof(XT) == 4 && g.round_x == 2) { uint32_t u = __float_as_uint(xv[i]); u = (u & 0x7fffffffu) > 0x7f800000u ? (u | 0x00400000u) & 0xffff0000u : (u + (0x7fffu + ((u >> 16) & 1u))) & 0xffff0000u; xv[i] = __uint_as_float(u); }
             if (k >= g.K || m0 + r >= g.M) wv[i] = 0.0f;
             if (k >= g.K || n0 + r >= g.N) xv[i] = 0.0f;
         }
@@ -161,19 +163,19 @@ void gemm_any(const gemm_any_args & a, hipStream_t st) {
     g.W = (const char *) a.W; g.w_rs = a.w_rs; g.w_nb2 = a.w_nb2; g.w_nb3 = a.w_nb3;
     g.X = (const char *) a.X; g.x_rs = a.x_rs; g.x_nb2 = a.x_nb2; g.x_nb3 = a.x_nb3;
     g.dst = (char *) a.dst; g.dst_cs = a.dst_cs; g.dst_nb2 = a.dst_nb2; g.dst_nb3 = a.dst_nb3;
-    g.M = (int) a.M; g.N = (int) a.N; g.K = (int) a.K; g.tiles_m = (int) ((a.M + 63) / 64); g.ne12 = a.ne12; g.r2 = a.r2; g.r3 = a.r3; g.round_x = a.w_f16 ? 1 : 0; g.accumulate = a.accumulate ? 1 : 0;
+    g.M = (int) a.M; g.N = (int) a.N; g.K = (int) a.K; g.tiles_m = (int) ((a.M + 63) / 64); g.ne12 = a.ne12; g.r2 = a.r2; g.r3 = a.r3; g.round_x = a.w_bf16 ? 2 : (a.w_f16 ? 1 : 0); g.accumulate = a.accumulate ? 1 : 0;
     static const bool no_sk = getenv("MI355X_GEMM_ANY_NO_SPLIT") != nullptr;
     if (!no_sk && (int64_t) g.tiles_m * ((a.N + 63) / 64) * a.nbatch < 128 && a.K >= 256) {          // few tiles, long chains: one 32 x 32 tile per workgroup, K split over its waves
         g.tiles_m = (int) ((a.M + 31) / 32);
         const dim3 grid((unsigned) (g.tiles_m * ((a.N + 31) / 32)), (unsigned) a.nbatch);
         if (a.x_f16)      k_gemm_any_sk<uint16_t, uint16_t><<<grid, dim3(256), 0, st>>>(g);
-        else if (a.w_f16) k_gemm_any_sk<uint16_t, float><<<grid, dim3(256), 0, st>>>(g);
+        else if (a.w_f16 || a.w_bf16) k_gemm_any_sk<uint16_t, float><<<grid, dim3(256), 0, st>>>(g);
         else              k_gemm_any_sk<float, float><<<grid, dim3(256), 0, st>>>(g);
         return;
     }
     const dim3 grid((unsigned) (g.tiles_m * ((a.N + 63) / 64)), (unsigned) a.nbatch);
     if (a.x_f16)      k_gemm_any<uint16_t, uint16_t><<<grid, dim3(256), 0, st>>>(g);       // (F16 activations only come with F16 weights: supports_op)
-    else if (a.w_f16) k_gemm_any<uint16_t, float><<<grid, dim3(256), 0, st>>>(g);
+    else if (a.w_f16 || a.w_bf16) k_gemm_any<uint16_t, float><<<grid, dim3(256), 0, st>>>(g);
     else              k_gemm_any<float, float><<<grid, dim3(256), 0, st>>>(g);
 }
 

@@ -308,3 +308,19 @@ def test_set_rows_into_a_quantised_cache_bit_exact_vs_reference_backend(pkg, be,
         res.append(np.asarray(backend.tensor_get(out)).copy().view(np.uint8))
         c.free()
     assert np.array_equal(res[0], res[1]), tname
+
+
+@pytest.mark.parametrize("M,N,K,H", [(300, 1, 512, 1), (1024, 5, 4096, 1), (256, 70, 1000, 3)])
+def test_bf16_weights_vs_reference_backend(pkg, be, ref_be, M, N, K, H):
+    """MUL_MAT with BF16 weights (bf16 GGUFs) at one, a few and many columns: gemm_any.hip with the weights widened exactly and the activations rounded
+    to bf16 (ggml_vec_dot_bf16's vec_dot_type), f32 accumulate -- against the reference CPU backend."""
+    rng = np.random.default_rng(M + N + K)
+    wf = (rng.standard_normal(K * M * H) / np.sqrt(K)).astype(np.float32)
+    u = wf.view(np.uint32); wb = ((u + 0x7fff + ((u >> 16) & 1)) >> 16).astype(np.uint16)
+
+    def build(c):
+        w = c.new_tensor(30, K, M, H); x = c.new_tensor(pkg.GGML_TYPE_F32, K, N, H)
+        return dict(w=w, x=x), [c.mul_mat(w, x)]
+    got, want = _both(pkg, be, ref_be, build, dict(w=wb, x=rng.standard_normal(K * N * H).astype(np.float32)))
+    assert np.isfinite(got[0]).all()
+    assert nmse(got[0], want[0]) < 1e-9, nmse(got[0], want[0])
