@@ -233,7 +233,7 @@ bool supports_op(const ggml_tensor * op) {
         case GGML_OP_GET_ROWS: {
             if (!s0 || !s1 || s1->type != GGML_TYPE_I32 || op->type != GGML_TYPE_F32 || op->nb[0] != 4) return false;
             switch (s0->type) {
-                case GGML_TYPE_F32: case GGML_TYPE_F16: case GGML_TYPE_Q8_0: case GGML_TYPE_Q4_K: case GGML_TYPE_Q6_K:
+                case GGML_TYPE_F32: case GGML_TYPE_F16: case GGML_TYPE_BF16: case GGML_TYPE_Q8_0: case GGML_TYPE_Q4_K: case GGML_TYPE_Q6_K:
                 case GGML_TYPE_Q4_0: case GGML_TYPE_Q4_1: case GGML_TYPE_Q5_0: case GGML_TYPE_Q5_1: case GGML_TYPE_Q2_K: case GGML_TYPE_Q3_K: case GGML_TYPE_Q5_K:
                     return s0->nb[0] == type_size(s0->type);
                 default: return false;

@@ -885,6 +885,8 @@ template <> __device__ __forceinline__ uint16_t cvt_elem<float, uint16_t>(float 
 template <> __device__ __forceinline__ float    cvt_elem<uint16_t, float>(uint16_t v)    { return h2f(v); }
 template <> __device__ __forceinline__ uint16_t cvt_elem<uint16_t, uint16_t>(uint16_t v) { return v; }
 template <> __device__ __forceinline__ int32_t  cvt_elem<int32_t, int32_t>(int32_t v)    { return v; }
+struct bf16_t { uint16_t v; };
+template <> __device__ __forceinline__ float    cvt_elem<bf16_t, float>(bf16_t b)        { return __uint_as_float((uint32_t) b.v << 16); }
 
 // IX: index type of the element counter -- 32-bit whenever the tensor has fewer than 2^31 elements (a 64-bit div/mod is a ~100-instruction
 // sequence and there are eight per element: the KQ-mask cast of every libllama decode graph took 63 us with them, 2.4 % of the step)
@@ -996,6 +998,7 @@ void get_rows(const tdesc & src, int src_type, const tdesc & idx, const tdesc & 
         case GGML_TYPE_F32: k_get_rows<float><<<grid, dim3(256), 0, st>>>(s, i, d); break;
         case GGML_TYPE_I32: k_get_rows<float><<<grid, dim3(256), 0, st>>>(s, i, d); break;   // bit copy (4-byte elements)
         case GGML_TYPE_F16: k_get_rows<uint16_t><<<grid, dim3(256), 0, st>>>(s, i, d); break;
+        case GGML_TYPE_BF16: k_get_rows<bf16_t><<<grid, dim3(256), 0, st>>>(s, i, d); break;
         case GGML_TYPE_Q8_0: case GGML_TYPE_Q4_K: case GGML_TYPE_Q6_K:
         case GGML_TYPE_Q4_0: case GGML_TYPE_Q4_1: case GGML_TYPE_Q5_0: case GGML_TYPE_Q5_1: case GGML_TYPE_Q2_K: case GGML_TYPE_Q3_K: case GGML_TYPE_Q5_K:
             k_get_rows_q<<<grid, dim3(256), 0, st>>>(src_type, s, i, d); break;
