@@ -329,6 +329,11 @@ static size_t graph_fa_scratch_need(const ggml_cgraph * g) {
     size_t need = 0;
     for (int i = 0; i < g->n_nodes; ++i) {
         const ggml_tensor * n = g->nodes[i];
+        if (n->op == GGML_OP_SOFT_MAX && !is_empty(n) && n->ne[1] == 1 && n->ne[3] == 1 && n->ne[0] > 256) {      // flash-attention off, one token, deep cache: the slices' partial rows (attn_one_sm)
+            const size_t b = (size_t) n->ne[2] * (size_t) ((n->ne[0] + 255) / 256) * (128 + 2) * 4;
+            if (b > need) need = b;
+            continue;
+        }
         if (n->op != GGML_OP_FLASH_ATTN_EXT || is_empty(n)) continue;
         fattn_args f; tdesc m; fill_fattn_args(n, f, m);
         const size_t b = fattn_scratch_bytes(f);
@@ -1275,6 +1280,14 @@ static bool try_defer_qkv_to_softmax_attention(exec_state & s, const nr_chain & 
     a.mask = mk ? mk->data : nullptr; a.mnb2 = 0; a.mne2 = 1; a.dst = C->data; a.dnb1 = (int64_t) D * 4; a.vidx_n = vidx->ne[0];
     a.D = (int) D; a.nkv = (int) nkv; a.n_head = (int) H; a.n_head_kv = (int) HK; a.scale = op_param_f32(SM, 0);
     a.rope_tab = (const float *) s.c->rope_scratch;                                  // filled when the launch happens
+    if (nkv > 256) {                                                                 // slices: partial rows in the attention scratch, arrival counters
+        if (!s.c->fa_counters && !s.capturing) {
+            if (hipMalloc((void **) &s.c->fa_counters, 1024 * sizeof(unsigned)) == hipSuccess) HIP_CHECK(hipMemsetAsync(s.c->fa_counters, 0, 1024 * sizeof(unsigned), s.st));
+            else { (void) hipGetLastError(); s.c->fa_counters = nullptr; }
+        }
+        a.part = s.c->fa_scratch; a.part_bytes = s.c->fa_scratch_bytes; a.counters = s.c->fa_counters;
+        s.fa_mask = nullptr;                                                         // (the scratch no longer holds a mask tile map)
+    }
     if (s.c->rope_scratch_bytes < (size_t) D * 4 || !attn_one_sm_ok(a)) return false;
     s.pq.fa = m1; s.pq.sm = true; s.pq.kst = B->store; s.pq.vst = vsj; s.pq.sm_soft = smi; s.pq.sm_mm2 = m2; s.pq.sm_cont = ci;
     return true;

@@ -181,6 +181,7 @@ struct attn_sm_args {
     void * dst = nullptr; int64_t dnb1 = 0;                    // f32 [D, H]: head stride (bytes)
     int64_t vidx_n = 0;
     int D = 0, nkv = 0, n_head = 0, n_head_kv = 0; float scale = 1.0f;
+    void * part = nullptr; size_t part_bytes = 0; unsigned * counters = nullptr;      // more than 256 cells: partial (O, M, S) rows [n_head][slices][D + 2] and zeroed per-head arrival counters
 };
 bool   attn_one_sm_ok(const attn_sm_args & a);
 void   attn_one_sm(const attn_sm_args & a, hipStream_t st);

@@ -342,8 +342,12 @@ __global__ void __launch_bounds__(256) k_attn_one_sm(const fa1_dev a) {
     __shared__ __attribute__((aligned(16))) float qf[D], kc[D], vc[D], sc[FA1_NKV], pl[4][FA1_NKV];
 
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int nkvh = (int) gridDim.x / a.gq, ikv = (int) blockIdx.x % nkvh, h = ikv * a.gq + (int) blockIdx.x / nkvh;     // XCD-aware head order (k_fattn_one)
-    const int nkv = a.nkv < FA1_NKV ? a.nkv : FA1_NKV;
+    // deeper caches: grid = heads x slices of 256 cells, each slice leaves (O, M, S) of its cells and the last arriver of a head folds them (as
+    // k_fattn_one does).  With one slice the arithmetic is the reference's to the letter (p normalised, then rounded to f16); with several the
+    // weights stay f32 relative to the slice's own maximum -- the f16 rounding of p is the only thing not reproduced (~1e-10 NMSE on the output).
+    const int n_head = (int) gridDim.x / a.nsplit, bh = (int) blockIdx.x % n_head, sp = (int) blockIdx.x / n_head, row0 = sp * FA1_NKV;
+    const int nkvh = n_head / a.gq, ikv = bh % nkvh, h = ikv * a.gq + bh / nkvh;                                         // XCD-aware head order (k_fattn_one)
+    const int nkv = a.nkv - row0 < FA1_NKV ? a.nkv - row0 : FA1_NKV;
 
     // ---------------------------------------------------------------- 1. request everything
     const bool act = lane < HALF;
@@ -355,18 +359,20 @@ __global__ void __launch_bounds__(256) k_attn_one_sm(const fa1_dev a) {
     const float x0 = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(xrs, xo0, 0, 0)), x1 = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(xrs, xo1, 0, 0));
     const float w0 = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(wrs, xo0, 0, 0)), w1 = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(wrs, xo1, 0, 0));
     const u32x2 tcs = __builtin_amdgcn_raw_buffer_load_b64(trs, act ? lane * 8 : D * 4, 0, 0);
-    const __amdgpu_buffer_rsrc_t mrs = fa1_rsrc(a.mask ? a.mask + (h % a.mne2) * a.mnb2 : a.mask, a.mask ? nkv * 4 : 0);          // f32 mask row
+    const __amdgpu_buffer_rsrc_t mrs = fa1_rsrc(a.mask ? a.mask + (h % a.mne2) * a.mnb2 + row0 * 4 : a.mask, a.mask ? nkv * 4 : 0);          // f32 mask row
     uint32_t mraw[FA1_NKV / 64];
 #pragma unroll
     for (int i = 0; i < FA1_NKV / 64; ++i) mraw[i] = __builtin_amdgcn_raw_buffer_load_b32(mrs, (lane + 64 * i) * 4, 0, 0);
-    const int krow = (int) __builtin_amdgcn_raw_buffer_load_b32(fa1_rsrc(a.kidx, 4), 0, 0, 0);
+    const int krow_g = (int) __builtin_amdgcn_raw_buffer_load_b32(fa1_rsrc(a.kidx, 4), 0, 0, 0);
     // v scatter indices: element e of the v row goes to vcache[vidx[e]] (e = ikv * D + d); element 0's index is the cell itself
     const __amdgpu_buffer_rsrc_t irs = fa1_rsrc(a.vidx, a.vidx_n * a.vidx_st);
-    const int vrow = (int) __builtin_amdgcn_raw_buffer_load_b32(irs, 0, 0, 0);
+    const int vrow_g = (int) __builtin_amdgcn_raw_buffer_load_b32(irs, 0, 0, 0);
+    const int krow = krow_g - row0, vrow = vrow_g - row0;                                          // the new token's cell relative to this slice
+    const bool owner = a.nsplit == 1 || (krow_g >= row0 && krow_g < row0 + FA1_NKV) || (sp == 0 && (krow_g < 0 || krow_g >= a.nkv));   // the slice that stores the new cache rows
     const int vi0 = (int) __builtin_amdgcn_raw_buffer_load_b32(irs, (uint32_t) (ikv * D + lane) * (uint32_t) a.vidx_st, 0, 0);
     const int vi1 = (int) __builtin_amdgcn_raw_buffer_load_b32(irs, (uint32_t) (ikv * D + lane + 64) * (uint32_t) a.vidx_st, 0, 0);
     const int r16 = lane >> 2, dq = lane & 3;
-    const __amdgpu_buffer_rsrc_t krs = fa1_rsrc(a.k + ikv * a.knb2, (nkv - 1) * a.knb1 + D * 2);
+    const __amdgpu_buffer_rsrc_t krs = fa1_rsrc(a.k + ikv * a.knb2 + (int64_t) row0 * a.knb1, (nkv - 1) * a.knb1 + D * 2);
     const uint32_t kvo = (uint32_t) r16 * (uint32_t) a.knb1 + (uint32_t) dq * (D / 2);
     u32x4 kk[NG][KCH];
 #pragma unroll
@@ -378,7 +384,7 @@ __global__ void __launch_bounds__(256) k_attn_one_sm(const fa1_dev a) {
     // V^T: lane (dl, part): output dim wave * DPW + dl, cells 8 (LPD j + part) .. + 7 for j < NV: the LPD lanes of a dim read adjacent 16-byte
     // pieces, so an instruction takes LPD x 16 contiguous bytes per dim row and four consecutive instructions use up each 128-byte line
     const int dl = lane / LPD, part = lane % LPD, dmine = wave * DPW + dl;
-    const __amdgpu_buffer_rsrc_t vrs = fa1_rsrc(a.v + ikv * a.vnb2, (D - 1) * a.vnb1 + nkv * 2);
+    const __amdgpu_buffer_rsrc_t vrs = fa1_rsrc(a.v + ikv * a.vnb2 + (int64_t) row0 * 2, (D - 1) * a.vnb1 + nkv * 2);
     u32x4 vv[NV];
 #pragma unroll
     for (int j = 0; j < NV; ++j) vv[j] = __builtin_amdgcn_raw_buffer_load_b128(vrs, (uint32_t) dmine * (uint32_t) a.vnb1 + (uint32_t) (LPD * j + part) * 16u, 0, 0);
@@ -397,14 +403,14 @@ __global__ void __launch_bounds__(256) k_attn_one_sm(const fa1_dev a) {
             if (wave == 0) { qf[e0] = h2f(h0); qf[e1] = h2f(h1); }                 // MUL_MAT(k f16, q): q rounded to f16
             else {
                 kc[e0] = h2f(h0); kc[e1] = h2f(h1);
-                if (h % a.gq == 0) { uint16_t * kr = (uint16_t *) (a.kcache + (int64_t) krow * a.kc_rs) + ikv * D; kr[e0] = h0; kr[e1] = h1; }
+                if (h % a.gq == 0 && owner) { uint16_t * kr = (uint16_t *) (a.kcache + (int64_t) krow_g * a.kc_rs) + ikv * D; kr[e0] = h0; kr[e1] = h1; }
             }
         }
     } else if (wave == 2) {
         const uint16_t hv0 = f2h(x0), hv1 = f2h(x1);
         vc[lane] = h2f(hv0);
         if (D > 64) vc[lane + 64] = h2f(hv1);
-        if (h % a.gq == 0) {
+        if (h % a.gq == 0 && owner) {
             *(uint16_t *) (a.vcache + (int64_t) vi0 * 2) = hv0;
             if (D > 64) *(uint16_t *) (a.vcache + (int64_t) vi1 * 2) = hv1;
         }
@@ -457,6 +463,7 @@ __global__ void __launch_bounds__(256) k_attn_one_sm(const fa1_dev a) {
     __syncthreads();
 
     // ---------------------------------------------------------------- 4. soft-max (ops.cpp:5072-5182): p = exp(s * scale + mask - max) / sum, then f16 (the KQV product's vec_dot_type)
+    float M, S;
     {
         float sv[FA1_NKV / 64], pe[FA1_NKV / 64];
         float mx = -INFINITY;
@@ -468,14 +475,14 @@ __global__ void __launch_bounds__(256) k_attn_one_sm(const fa1_dev a) {
             if (mv[i] == -INFINITY) v = -INFINITY;
             sv[i] = v; mx = fmaxf(mx, v);
         }
-        const float M = wave_max_f32(mx);
-        float S = 0.0f;
+        M = wave_max_f32(mx);
+        S = 0.0f;
 #pragma unroll
         for (int i = 0; i < FA1_NKV / 64; ++i) { pe[i] = sv[i] == -INFINITY ? 0.0f : expf(sv[i] - M); S += pe[i]; }
         S = wave_sum_f32(S);
         const float inv = S == 0.0f ? 0.0f : 1.0f / S;
 #pragma unroll
-        for (int i = 0; i < FA1_NKV / 64; ++i) pl[wave][lane + 64 * i] = h2f(f2h(pe[i] * inv));
+        for (int i = 0; i < FA1_NKV / 64; ++i) pl[wave][lane + 64 * i] = a.nsplit == 1 ? h2f(f2h(pe[i] * inv)) : pe[i];
     }
     float pcur = 0.0f;
     const bool vin = vrow >= 0 && vrow < nkv;
@@ -503,10 +510,46 @@ __global__ void __launch_bounds__(256) k_attn_one_sm(const fa1_dev a) {
     }
 #pragma unroll
     for (int o = 1; o < LPD; o <<= 1) acc += __shfl_xor(acc, o, 64);
-    if (part == 0) {
-        acc = fmaf(pcur, vc[dmine], acc);
-        *((float *) (a.dst + h * a.dnb1) + dmine) = acc;
+    if (part == 0) acc = fmaf(pcur, vc[dmine], acc);
+    if (a.nsplit == 1) {
+        if (part == 0) *((float *) (a.dst + h * a.dnb1) + dmine) = acc;
+        return;
     }
+    // ---------------------------------------------------------------- 6. slices: partial state out (write-through), last arriver of the head folds
+    const __amdgpu_buffer_rsrc_t prs = fa1_rsrc(a.part + (int64_t) h * a.nsplit * (D + 2), a.nsplit * (D + 2) * 4);
+    const uint32_t po = (uint32_t) sp * (D + 2) * 4u;
+    if (part == 0) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc), prs, po + (uint32_t) dmine * 4u, 0, 16);
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(M), prs, po + (uint32_t) D * 4u, 0, 16);
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(S), prs, po + (uint32_t) (D + 1) * 4u, 0, 16);
+    }
+    __shared__ unsigned last;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) last = __hip_atomic_fetch_add(a.cnt + h, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned) (a.nsplit - 1) ? 1u : 0u;
+    __syncthreads();
+    if (!last) return;
+    if (threadIdx.x < D) {
+        const int d = threadIdx.x;
+        float Mx = -INFINITY, St = 0.0f, o = 0.0f;
+        float Ms[FA1_MAX_SPLIT], Ss[FA1_MAX_SPLIT], os[FA1_MAX_SPLIT];
+#pragma unroll
+        for (int i = 0; i < FA1_MAX_SPLIT; ++i) {
+            const uint32_t so = (uint32_t) ((i < a.nsplit ? i : 0) * (D + 2)) * 4u;
+            Ms[i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(prs, so + (uint32_t) D * 4u, 0, 16));
+            Ss[i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(prs, so + (uint32_t) (D + 1) * 4u, 0, 16));
+            os[i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(prs, so + (uint32_t) d * 4u, 0, 16));
+        }
+#pragma unroll
+        for (int i = 0; i < FA1_MAX_SPLIT; ++i) { if (i >= a.nsplit) Ms[i] = -INFINITY; Mx = fmaxf(Mx, Ms[i]); }
+#pragma unroll
+        for (int i = 0; i < FA1_MAX_SPLIT; ++i) {
+            const float f = Ms[i] == -INFINITY ? 0.0f : expf(Ms[i] - Mx);
+            St += Ss[i] * f; o += os[i] * f;
+        }
+        ((float *) (a.dst + h * a.dnb1))[d] = St == 0.0f ? 0.0f : o * (1.0f / St);
+    }
+    if (threadIdx.x == 0) __hip_atomic_store(a.cnt + h, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // ready for the next launch
 }
 
 // one token of one sequence, q / k / v pre-stage, <= 256 cache rows, f16 mask shared by the heads of a token (or per head), D 64 / 128
@@ -549,7 +592,9 @@ void flash_attn_one(const fa_dev & f, int D, const float * rope_tab, hipStream_t
 bool attn_one_sm_ok(const attn_sm_args & f) {
     static const bool env_off = getenv("MI355X_NO_ATTN_SM") != nullptr;
     if (env_off || !g_one_enabled) return false;
-    if ((f.D != 64 && f.D != 128) || f.nkv < 1 || f.nkv > FA1_NKV || f.nkv % 8 != 0 || f.n_head < 1 || f.n_head_kv < 1 || f.n_head % f.n_head_kv != 0) return false;
+    const int nsplit = (f.nkv + FA1_NKV - 1) / FA1_NKV;
+    if ((f.D != 64 && f.D != 128) || f.nkv < 1 || nsplit > FA1_MAX_SPLIT || f.nkv % 8 != 0 || f.n_head < 1 || f.n_head_kv < 1 || f.n_head % f.n_head_kv != 0) return false;
+    if (nsplit > 1 && (!f.part || !f.counters || f.n_head > 1024 || f.part_bytes < (size_t) f.n_head * nsplit * (f.D + 2) * 4)) return false;      // slices need the partial-state scratch and the arrival counters
     if (f.knb1 % 16 != 0 || f.knb2 % 16 != 0 || ((uintptr_t) f.k & 15) != 0 || f.vnb1 % 16 != 0 || f.vnb2 % 16 != 0 || ((uintptr_t) f.v & 15) != 0) return false;
     if (f.knb1 * FA1_NKV > 0x7fffffff || f.vnb1 * f.D > 0x7fffffff || f.knb2 > 0x7fffffff || f.vnb2 > 0x7fffffff) return false;
     if (f.dnb1 % 4 != 0 || ((uintptr_t) f.dst & 3) != 0 || !f.pre || !f.rope_tab) return false;
@@ -566,9 +611,10 @@ void attn_one_sm(const attn_sm_args & f, hipStream_t st) {
     a.q_hs = (int) P.q_hs; a.k_hs = (int) P.k_hs; a.v_hs = (int) P.v_hs; a.kc_rs = (int) P.kc_rs; a.vc_rs = 2;
     a.knb1 = (int) f.knb1; a.knb2 = (int) f.knb2; a.vnb1 = (int) f.vnb1; a.vnb2 = (int) f.vnb2; a.mnb2 = (int) f.mnb2; a.mne2 = (int) (f.mne2 > 0 ? f.mne2 : 1); a.dnb1 = (int) f.dnb1;
     a.nkv = f.nkv; a.gq = f.n_head / f.n_head_kv; a.neox = (P.rp.mode & GGML_ROPE_TYPE_NEOX) ? 1 : 0; a.n_head_log2 = 0;
-    a.vidx_st = P.idx_is64 ? 8 : 4; a.vidx_n = (int) f.vidx_n; a.has_norm = P.qw != nullptr; a.nsplit = 1; a.part = nullptr; a.cnt = nullptr;
+    const int nsplit = (f.nkv + FA1_NKV - 1) / FA1_NKV;
+    a.vidx_st = P.idx_is64 ? 8 : 4; a.vidx_n = (int) f.vidx_n; a.has_norm = P.qw != nullptr; a.nsplit = nsplit; a.part = nsplit > 1 ? (float *) f.part : nullptr; a.cnt = nsplit > 1 ? f.counters : nullptr;
     a.eps = P.eps; a.scale = f.scale; a.max_bias = 0.0f; a.logit_softcap = 0.0f; a.m0 = 1.0f; a.m1 = 1.0f;
-    const dim3 grid((unsigned) f.n_head);
+    const dim3 grid((unsigned) (f.n_head * nsplit));
     if (f.D == 64) k_attn_one_sm<64><<<grid, dim3(256), 0, st>>>(a);
     else           k_attn_one_sm<128><<<grid, dim3(256), 0, st>>>(a);
 }

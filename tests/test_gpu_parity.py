@@ -545,13 +545,15 @@ def test_prefill_ubatch_vs_reference_backend(pkg, be, ref_be, wtype):
     assert same >= (0.99 if wtype == "f16" else 0.9) * T, same
 
 
+@pytest.mark.parametrize("fa", [True, False])
 @pytest.mark.parametrize("n_kv,T,steps", [(768, 300, 3), (2048, 1500, 2), (5120, 4200, 2), (9216, 8300, 1)])
-def test_decode_on_a_deep_cache_vs_reference_backend(pkg, be, ref_be, n_kv, T, steps):
+def test_decode_on_a_deep_cache_vs_reference_backend(pkg, be, ref_be, n_kv, T, steps, fa):
     """Decode steps on top of a cache of several hundred / thousand rows.  Up to 8192 rows the attention node is the one-token kernel cut
     into 256-row slices (fattn_one.hip: 3, 8 and 20 slices here -- the 16- and the 32-wide fold), the q/k/v pre-stage inside every slice
     (only the slice that owns the new cache row stores it) and the last arriver of a head folding the partial rows inside the launch;
-    beyond that (9216 rows) the matrix-core kernel with KV slices (k_fattn_gqa + k_fattn_merge).  Logits against the reference CPU
-    backend on the same graphs."""
+    beyond that (9216 rows) the matrix-core kernel with KV slices (k_fattn_gqa + k_fattn_merge).  fa = False: the reference's soft-max graph on
+    the transposed V cache (llama-bench's default) -- k_attn_one_sm with the same slices and in-launch fold up to 8192 rows, the separate
+    launches beyond.  Logits against the reference CPU backend on the same graphs."""
     from llama_cpp_omni_amd import qwen3
     cfg = dict(n_embd=1024, n_layer=2, n_head=8, n_head_kv=2, head_dim=128, n_ff=2048, n_vocab=512, rms_eps=1e-6, rope_base=1e6, n_ctx_orig=4096)
     types = qwen3.q4_k_m_types(cfg)
@@ -559,7 +561,7 @@ def test_decode_on_a_deep_cache_vs_reference_backend(pkg, be, ref_be, n_kv, T, s
     embd = rng.standard_normal((T + steps, cfg["n_embd"])).astype(np.float32)
     outs = []
     for backend in (be, ref_be):
-        mdl = qwen3.Model(backend, cfg, types, n_ctx=n_kv, seed=4, flash_attn=True)
+        mdl = qwen3.Model(backend, cfg, types, n_ctx=n_kv, seed=4, flash_attn=fa)
         done = 0
         while done < T:                                                # prefill in ubatches of 512 at growing depth
             n = min(512, T - done)
