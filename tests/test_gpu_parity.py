@@ -585,6 +585,42 @@ def test_decode_on_a_deep_cache_vs_reference_backend(pkg, be, ref_be, n_kv, T, s
     assert np.array_equal(outs[0].argmax(-1), outs[1].argmax(-1))
 
 
+@pytest.mark.parametrize("fa", [True, False])
+def test_tts_shape_decode_on_a_deep_cache_vs_reference_backend(pkg, be, ref_be, fa):
+    """The omni TTS decoder's shape (llama architecture: ROPE-only chains, head size 64, Q8_0 weights) decoding on top of 700 cache rows: the
+    head-64 instances of the sliced one-token kernels (k_fattn_one<64> / k_attn_one_sm<64>, three slices) against the reference CPU backend."""
+    from llama_cpp_omni_amd import qwen3
+    cfg = dict(arch="llama", n_embd=768, n_layer=2, n_head=12, n_head_kv=12, head_dim=64, n_ff=3072, n_vocab=1024, rms_eps=1e-5, rope_base=1e4, n_ctx_orig=4096)
+    types = qwen3.uniform_types(cfg, pkg.GGML_TYPE_Q8_0)
+    rng = np.random.default_rng(64)
+    n_kv, T, steps = 768, 700, 3
+    embd = rng.standard_normal((T + steps, cfg["n_embd"])).astype(np.float32)
+    outs = []
+    for backend in (be, ref_be):
+        mdl = qwen3.Model(backend, cfg, types, n_ctx=n_kv, seed=6, flash_attn=fa)
+        done = 0
+        while done < T:
+            n = min(512, T - done)
+            g, I, logits = mdl.build(n, n_kv)
+            mdl.set_inputs(I, embd[done:done + n], done, n_kv)
+            backend.graph_compute(g.graph()); backend.synchronize()
+            g.free()
+            done += n
+        g1, I1, logits1 = mdl.build(1, n_kv)
+        ls = []
+        for k in range(steps):
+            mdl.set_inputs(I1, embd[T + k:T + k + 1], T + k, n_kv)
+            backend.graph_compute(g1.graph())
+            ls.append(backend.tensor_get(logits1).copy())
+        outs.append(np.stack(ls))
+        g1.free(); mdl.wctx.free()
+    assert np.isfinite(outs[0]).all()
+    e = nmse(outs[0], outs[1])
+    print("TTS shape at depth 700, flash-attention", fa, ": logits NMSE", e)
+    assert e < 2e-3, e
+    assert np.array_equal(outs[0].argmax(-1), outs[1].argmax(-1))
+
+
 def test_encoder_block_vs_reference_backend(pkg, be, ref_be):
     """First ops of the omni audio encoder (tools/omni/audition.cpp: conv1d -> GELU -> LayerNorm * w + b -> F16 linear), i.e. IM2COL,
     the F16 x F16 MUL_MAT of ggml_conv_1d, UNARY(GELU), CONT(transpose), NORM, MUL, ADD, MUL_MAT -- against the reference CPU backend."""
