@@ -153,7 +153,7 @@ def cpu_baseline(pkg, cfg, types, n_kv, seconds_budget=24.0):
 
 
 def kernel_roofline(pkg, be, model, reps=5):
-    """Live roofline of the dominant kernel, mi::k_mv1<8,2,2,1,1,true,false> (mmv1.hip: RMS norm + Q8_K image in the prologue, ffn_gate +
+    """Live roofline of the dominant kernel, mi::k_mv1<8,2,2,1,1,true,false,false> (mmv1.hip: RMS norm + Q8_K image in the prologue, ffn_gate +
     ffn_up + SWIGLU: 2 x 12288 x 4096 Q4_K rows = 56.6 MB per launch, 36 launches and 2.04 of the 4.67 GB of every decoded token).  One cgraph holding the 36 launches of one
     decode step -- the real layers' weights, 2 GB, 8x the Infinity Cache -- is replayed as a hipGraph and bracketed by two HIP
     events on the backend's stream; avg launch = elapsed / 36 (so it includes the launch-to-launch boundary, like the
@@ -206,7 +206,7 @@ def kernel_roofline(pkg, be, model, reps=5):
                 break
     except Exception:
         pass
-    return {"bound": "hbm", "kernel": "mi::k_mv1<8,2,2,1,1,true,false> (RMS norm + Q8_K image prologue, Q4_K ffn_gate+ffn_up mat-vec, SWIGLU epilogue)",
+    return {"bound": "hbm", "kernel": "mi::k_mv1<8,2,2,1,1,true,false,false> (RMS norm + Q8_K image prologue, Q4_K ffn_gate+ffn_up mat-vec, SWIGLU epilogue)",
             "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
             "bytes_per_launch": nbytes // launches, "avg_launch_us": round(us / launches, 3), "launches": launches,
             "method": "hipGraph replay of the step's 36 launches of this kernel, two HIP events on the backend stream, best of 5"}

@@ -650,7 +650,7 @@ static bool q80_mv1_node(exec_state & s, const ggml_tensor * n) {
     v.img = (const void *) 16;
     return mmv1_ok(v);
 }
-// batch-1 decode form (mmv1.hip): one column, Q4_K / Q6_K, K a multiple of 4096 up to 12288, aligned rows; or the Q8_0 twin
+// batch-1 decode form (mmv1.hip): one column, Q4_K / Q6_K, K a multiple of 256 up to 16384, aligned rows; or the Q8_0 twin
 static bool mv1_node_ok(exec_state & s, const ggml_tensor * n) {
     if (q80_mv1_node(s, n)) return true;
     if (!s.c->opt_mv1 || !plain_kq_matvec(n, 1)) return false;

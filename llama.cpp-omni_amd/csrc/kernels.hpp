@@ -62,7 +62,7 @@ void mmv_kquant_multi(const mmv_multi_args & a, hipStream_t st);
 void mmv_kquant_pair_swiglu(int type, const void * Wg, const void * Wu, size_t w_rs, const void * act, size_t act_cs, float * dst, size_t dst_cs,
                             int64_t K, int64_t nrows, int ncols, hipStream_t st, const mmv_norm * norm = nullptr);
 
-// ---- batch-1 decode form (mmv1.hip): ONE activation column, Q4_K / Q6_K, K a multiple of 4096 up to 12288.  The launch takes the f32
+// ---- batch-1 decode form (mmv1.hip): ONE activation column, Q4_K / Q6_K, K a multiple of 256 up to 16384 (whole steps of 4096 at the Qwen3-8B widths, TAIL instances otherwise).  The launch takes the f32
 // activation row itself -- x, or rms_norm(x) * norm_w (the RMS_NORM + MUL nodes in front of src1) -- and every workgroup builds the Q8_K
 // image in its prologue, so no norm / quantise launch precedes it; img != null hands over a ready image (q8k_image_bytes layout) instead.
 // W_up != null: m[0] is ffn_gate, W_up ffn_up (same type / shape / stride), dst = silu(gate.x) * (up.x).  dst / resid strides unused.

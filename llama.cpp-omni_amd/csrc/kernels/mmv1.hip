@@ -218,15 +218,17 @@ static __device__ __forceinline__ void mv1_range(int ngrp, int lw, int nw, int &
 // of the up matrix); DEPTH stages of loads in flight.  The kernel is VALU-issue-bound before it is HBM-bound (rocprofv3 SQ_INSTS_VALU),
 // so everything per-lane that can be a kernel-lifetime constant is one: global loads are `scalar base + lane offset`, LDS reads are
 // `lane base + immediate`, the 6-bit fields are picked with v_perm_b32 under a lane-constant selector, 24-bit multiplies.
-// Requires K % 4096 == 0, 16-byte aligned rows; R == 2 without PAIR requires an even row count (launcher-checked).
-template <int R, int DEPTH, bool PAIR, bool NT, typename PRO>
+// Requires K % 256 == 0 (TAIL unless K % 4096 == 0), 16-byte aligned rows; R == 2 without PAIR requires an even row count (launcher-checked).
+template <int R, int DEPTH, bool PAIR, bool NT, bool TAIL, typename PRO>
 static __device__ __forceinline__ void mv1_q4k(const char * __restrict__ W0, const char * __restrict__ W1, size_t w_rs, char * __restrict__ dst, const char * __restrict__ resid,
                                                int K, int nrows, int lw, int nw, PRO & pro) {
     constexpr int NBUF = DEPTH + 1;
     const int lane = threadIdx.x & 63;
     const int blk = lane >> 2, q = lane & 3;
     const int nb  = K >> 8;
-    const int nit = nb >> 4;                              // steps per row
+    // steps per row.  TAIL (K % 4096 != 0: other model widths -- 2560, 3584, 5120, 14336 ...): the last step of a row covers fewer than 16 super-blocks;
+    // the lanes past the row still load (into the next row, or zeros past the matrix) and multiply, but with d = dmin = yd = 0
+    const int nit = TAIL ? (nb + 15) >> 4 : nb >> 4;
     const int ntask = PAIR ? nrows : nrows / R;
     int g0, g1; mv1_range(ntask, lw, nw, g0, g1);
 
@@ -293,7 +295,8 @@ static __device__ __forceinline__ void mv1_q4k(const char * __restrict__ W0, con
                 const u32x4 a2 = *(const u32x4 *) (la + so * 272 + 32), a3 = *(const u32x4 *) (la + so * 272 + 48); // ... of sub-block 2q+1
                 const uint32_t bsw = *(const uint32_t *) (lb + so * 16);                                           // their two sums of 32
                 const int bs0 = (int) (int16_t) (bsw & 0xffff), bs1 = (int) (int16_t) (bsw >> 16);
-                const float yd = *(const float *) (ld + so * 4);
+                const bool live = !TAIL || so + blk < nb;
+                const float yd = live ? *(const float *) (ld + so * 4) : 0.0f;
 #pragma unroll
                 for (int r = 0; r < R; ++r) {
                     const u32x4 Q = qa[ph][r], P = qb[ph][r];
@@ -305,8 +308,8 @@ static __device__ __forceinline__ void mv1_q4k(const char * __restrict__ W0, con
                     const uint32_t sw = __builtin_amdgcn_perm(s_hi, s_lo, sel), mw = __builtin_amdgcn_perm(m_hi, m_lo, sel);
                     const int sc0 = sw & 0xff, sc1 = sw >> 8;
                     const int mn0 = mw & 0xff, mn1 = mw >> 8;
-                    const float dx   = h2f((uint16_t) (H[0] & 0xffff));
-                    const float dmin = h2f((uint16_t) (H[0] >> 16));
+                    const float dx   = live ? h2f((uint16_t) (H[0] & 0xffff)) : 0.0f;
+                    const float dmin = live ? h2f((uint16_t) (H[0] >> 16)) : 0.0f;
                     int dl = 0, dh = 0;
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
@@ -354,14 +357,14 @@ static __device__ __forceinline__ void mv1_q4k(const char * __restrict__ W0, con
 typedef u32x4 __attribute__((aligned(2))) u32x4_a2;
 typedef uint32_t __attribute__((aligned(2))) u32_a2;
 
-template <int R, int DEPTH, bool PAIR, typename PRO>
+template <int R, int DEPTH, bool PAIR, bool TAIL, typename PRO>
 static __device__ __forceinline__ void mv1_q6k(const char * __restrict__ W0, const char * __restrict__ W1, size_t w_rs, char * __restrict__ dst, const char * __restrict__ resid,
                                                int K, int nrows, int lw, int nw, PRO & pro) {
     constexpr int NBUF = DEPTH + 1;
     const int lane = threadIdx.x & 63;
     const int blk = lane >> 2, n = (lane >> 1) & 1, hf = lane & 1;
     const int nb  = K >> 8;
-    const int nit = nb >> 4;
+    const int nit = TAIL ? (nb + 15) >> 4 : nb >> 4;       // (TAIL: see mv1_q4k)
     const int ntask = PAIR ? nrows : nrows / R;
     int g0, g1; mv1_range(ntask, lw, nw, g0, g1);
 
@@ -414,12 +417,13 @@ static __device__ __forceinline__ void mv1_q6k(const char * __restrict__ W0, con
                 for (int m = 0; m < 4; ++m) a[m] = *(const u32x4 *) (la + so * 272 + 32 * m);
                 const u32x2 bq = *(const u32x2 *) (lb + so * 32);
                 const int bs[4] = { (int) (int16_t) (bq[0] & 0xffff), (int) (int16_t) (bq[0] >> 16), (int) (int16_t) (bq[1] & 0xffff), (int) (int16_t) (bq[1] >> 16) };
-                const float yd = *(const float *) (ld + so * 4);
+                const bool live = !TAIL || so + blk < nb;
+                const float yd = live ? *(const float *) (ld + so * 4) : 0.0f;
 #pragma unroll
                 for (int r = 0; r < R; ++r) {
                     const uint32_t sq = sc[ph][r];                                  // quad_perm [0,0,2,2] / [1,1,3,3]: scale dwords 2n and 2n+1
                     const uint32_t scw = __builtin_amdgcn_perm(dpp_u32q<0xF5>(sq), dpp_u32q<0xA0>(sq), sel);
-                    const float dx = h2f((uint16_t) dw[ph][r]);
+                    const float dx = live ? h2f((uint16_t) dw[ph][r]) : 0.0f;
                     int d[4] = { 0, 0, 0, 0 };
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
@@ -471,7 +475,7 @@ template <int NW, int XB> struct mv1_pro {
     __device__ __forceinline__ void finish() { mv1_act_finish<NW, XB>(s, K, r, mv1_lds, red); }
 };
 
-template <int NW, int XB, int R, int DEPTH, int TM, bool PAIR, bool NT>
+template <int NW, int XB, int R, int DEPTH, int TM, bool PAIR, bool NT, bool TAIL = false>
 __global__ void __launch_bounds__(64 * NW) k_mv1(const mv1_dev a) {
     __shared__ double red[NW];
     const int wave = __builtin_amdgcn_readfirstlane(blockIdx.x * NW + (threadIdx.x >> 6));
@@ -483,8 +487,8 @@ __global__ void __launch_bounds__(64 * NW) k_mv1(const mv1_dev a) {
     const mv1_mat M = mi_ == 0 ? a.m[0] : (mi_ == 1 ? a.m[1] : a.m[2]);
     const int lw = wave - w0, nw = M.wave_end - w0;
     mv1_pro<NW, XB> pro = { a.src, a.K, red, {} };
-    if (TM == 1 || ((TM & 1) && M.type == GGML_TYPE_Q4_K)) mv1_q4k<R, DEPTH, PAIR, NT>(M.W, a.W1, M.w_rs, M.dst, M.resid, a.K, M.nrows, lw, nw, pro);
-    else                                                    mv1_q6k<R, DEPTH, PAIR>(M.W, a.W1, M.w_rs, M.dst, M.resid, a.K, M.nrows, lw, nw, pro);
+    if (TM == 1 || ((TM & 1) && M.type == GGML_TYPE_Q4_K)) mv1_q4k<R, DEPTH, PAIR, NT, TAIL>(M.W, a.W1, M.w_rs, M.dst, M.resid, a.K, M.nrows, lw, nw, pro);
+    else                                                    mv1_q6k<R, DEPTH, PAIR, TAIL>(M.W, a.W1, M.w_rs, M.dst, M.resid, a.K, M.nrows, lw, nw, pro);
 }
 
 } // namespace mi
@@ -499,7 +503,7 @@ static const int MV1_WAVES = 4096;
 
 bool mmv1_ok(const mv1_args & a) {
     if (a.nmat >= 1 && (a.m[0].type == GGML_TYPE_Q8_0 || a.m[0].type == GGML_TYPE_F16)) return mmv1q_ok(a);          // the Q8_0 / F16 twins (mmv1q.hip)
-    if (a.nmat < 1 || a.nmat > 3 || a.K <= 0 || a.K % 4096 != 0 || a.K > 12288) return false;
+    if (a.nmat < 1 || a.nmat > 3 || a.K <= 0 || a.K % 256 != 0 || a.K > 16384) return false;              // (K % 4096 != 0: the TAIL instances)
     if (a.W_up && a.nmat != 1) return false;
     for (int i = 0; i < a.nmat; ++i) {
         const mmv_mat & m = a.m[i];
@@ -514,12 +518,12 @@ bool mmv1_ok(const mv1_args & a) {
     return a.x && ((uintptr_t) a.x & 15) == 0 && ((uintptr_t) a.norm_w & 15) == 0;
 }
 
-template <int NW, int XB, int R, bool PAIR>
+template <int NW, int XB, int R, bool PAIR, bool TAIL = false>
 static void mv1_go(const mv1_dev & d, int tm, int grid, hipStream_t st) {
     const size_t lds = mv1_image_bytes(d.K);
-    if (tm == 1)      k_mv1<NW, XB, R, 1, 1, PAIR, false><<<dim3(grid), dim3(64 * NW), lds, st>>>(d);
-    else if (tm == 2) k_mv1<NW, XB, R, 1, 2, PAIR, false><<<dim3(grid), dim3(64 * NW), lds, st>>>(d);
-    else if (!PAIR)   k_mv1<NW, XB, R, 1, 3, false, false><<<dim3(grid), dim3(64 * NW), lds, st>>>(d);
+    if (tm == 1)      k_mv1<NW, XB, R, 1, 1, PAIR, false, TAIL><<<dim3(grid), dim3(64 * NW), lds, st>>>(d);
+    else if (tm == 2) k_mv1<NW, XB, R, 1, 2, PAIR, false, TAIL><<<dim3(grid), dim3(64 * NW), lds, st>>>(d);
+    else if (!PAIR)   k_mv1<NW, XB, R, 1, 3, false, false, TAIL><<<dim3(grid), dim3(64 * NW), lds, st>>>(d);
     else { fprintf(stderr, "[mi355x] mmv1: a gate / up pair of mixed types\n"); abort(); }
 }
 
@@ -551,6 +555,11 @@ void mmv1(const mv1_args & a, hipStream_t st) {
         acc_w = end;
     }
     const int nb = (int) (a.K / 256);
+    if (nb % 16 != 0 || nb > 48) {                           // other widths: the TAIL instances (XB: image blocks per wave, rounded up to what is compiled)
+        if (pair) { if (nb <= 16) mv1_go<8, 2, 2, true, true>(d, tm, (int) grid, st); else if (nb <= 32) mv1_go<8, 4, 2, true, true>(d, tm, (int) grid, st); else mv1_go<8, 8, 2, true, true>(d, tm, (int) grid, st); }
+        else      { if (nb <= 16) mv1_go<16, 1, 1, false, true>(d, tm, (int) grid, st); else if (nb <= 32) mv1_go<16, 2, 1, false, true>(d, tm, (int) grid, st); else mv1_go<16, 4, 1, false, true>(d, tm, (int) grid, st); }
+        return;
+    }
     if (pair) { if (nb <= 16) mv1_go<8, 2, 2, true>(d, tm, (int) grid, st); else mv1_go<8, 6, 2, true>(d, tm, (int) grid, st); }
     else      { if (nb <= 16) mv1_go<16, 1, 1, false>(d, tm, (int) grid, st); else mv1_go<16, 3, 1, false>(d, tm, (int) grid, st); }
 }

@@ -73,15 +73,20 @@ def test_decode_steps_at_8b_width_vs_reference_backend(pkg, be, ref_be, fa):
         assert ref[t][int(np.argmax(got[t]))] >= ref[t].max() - 4.0 * err, t
 
 
-def test_mmv1_activation_sources_vs_oracle(pkg, be):
-    """The three activation sources of the batch-1 kernels on one 4096-wide row: plain f32 (quantised in the prologue), RMS_NORM + MUL folded
-    in, and the residual epilogue -- each against the C oracle (integer dot of the reference's Q8_K image), Q4_K and Q6_K."""
+@pytest.mark.parametrize("K", [4096, 256, 2560, 3584, 5120, 9728, 12288, 14336, 16384])
+def test_mmv1_activation_sources_vs_oracle(pkg, be, K):
+    """The three activation sources of the batch-1 kernels on one row: plain f32 (quantised in the prologue), RMS_NORM + MUL folded in, and
+    the residual epilogue -- each against the C oracle (integer dot of the reference's Q8_K image), Q4_K and Q6_K.  K = 4096 / 12288 are
+    the Qwen3-8B widths (whole steps of 16 super-blocks per wave); the others take the TAIL instances (a partly filled last step: the
+    widths of the 4B / 7B / 14B / Llama-3 siblings) and must give the same results."""
     from llama_cpp_omni_amd import qwen3
-    rng = np.random.default_rng(17)
-    K, M = 4096, 512
+    rng = np.random.default_rng(17 + K)
+    M = 512
     x = (rng.standard_normal((1, K)) * 2.0).astype(np.float32)
-    x[0, 256:512] = 0.0                                       # an all-zero Q8_K block
-    x[0, 700] = -x[0, 701]                                    # a +/- tie candidate
+    if K >= 1024:
+        x[0, 256:512] = 0.0                                   # an all-zero Q8_K block
+        x[0, 700] = -x[0, 701]                                # a +/- tie candidate
+    x[0, K - 256:K - 128] = 0.0
     nw = rng.standard_normal(K).astype(np.float32)
     r = rng.standard_normal((1, M)).astype(np.float32)
     for name in ("q4_K", "q6_K"):
@@ -95,11 +100,40 @@ def test_mmv1_activation_sources_vs_oracle(pkg, be):
         y_norm = c.add(c.mul_mat(w, xn), rt)
         from test_gpu_parity import run_graph
         got_plain, got_norm = run_graph(be, c, [y_plain, y_norm], [(w, wv), (xt, x), (nt, nw), (rt, r)])
+        assert be.get_stat("kernels_last_graph") <= 2, (K, be.get_stat("kernels_last_graph"))    # norm + image + residual inside the two mat-vec launches
         want_plain = orc.mul_mat(ty, wb, x)
         xn_ref = orc.rms_norm(x, 1e-6) * nw
         want_norm = orc.mul_mat(ty, wb, xn_ref.astype(np.float32)) + r
         assert nmse(got_plain, want_plain) < 1e-9, name
         assert nmse(got_norm, want_norm) < 1e-9, name
+
+
+@pytest.mark.parametrize("name,cfg", [
+    ("4b",  dict(n_embd=2560, n_layer=2, n_head=32, n_head_kv=8, head_dim=128, n_ff=9728,  n_vocab=2048, rms_eps=1e-6, rope_base=1e6, n_ctx_orig=4096)),
+    ("l3",  dict(n_embd=4096, n_layer=2, n_head=32, n_head_kv=8, head_dim=128, n_ff=14336, n_vocab=2048, rms_eps=1e-6, rope_base=1e6, n_ctx_orig=4096)),
+    ("14b", dict(n_embd=5120, n_layer=2, n_head=40, n_head_kv=8, head_dim=128, n_ff=17408, n_vocab=2048, rms_eps=1e-6, rope_base=1e6, n_ctx_orig=4096))])
+def test_decode_steps_at_other_model_widths(pkg, be, ref_be, name, cfg):
+    """The decode step at the widths of the target's siblings (Qwen3-4B, Llama-3-8B's 14336-wide FFN, Qwen3-14B): K is not a multiple of 4096, so
+    the grouped Q/K/V launch, the gate/up pair with its SwiGLU epilogue and the residual launches run the TAIL instances of k_mv1 (17408 > 16384
+    stays on the multi-column family).  Same bars as the 8B-width test, plus agreement with the round-1 kernels on the first step (the same
+    integer sums: only the f32 summation order over super-blocks differs)."""
+    from llama_cpp_omni_amd import qwen3
+    types = qwen3.q4_k_m_types(cfg)
+    rng = np.random.default_rng(5)
+    steps, n_kv = 6, 256
+    embd = rng.standard_normal((steps, cfg["n_embd"])).astype(np.float32)
+    ref, _ = _decode_run(pkg, ref_be, cfg, types, embd, steps, n_kv, True)
+    got, kern = _decode_run(pkg, be, cfg, types, embd, steps, n_kv, True)
+    old, kern_old = _decode_run(pkg, be, cfg, types, embd, steps, n_kv, True, {"mv1": 0})
+    assert np.isfinite(got).all()
+    if name != "14b":
+        assert kern <= 5 * cfg["n_layer"] + 3, kern
+    assert kern < kern_old
+    assert nmse(got[0], old[0]) < 1e-9, nmse(got[0], old[0])
+    for t in range(steps):
+        assert nmse(got[t], ref[t]) < 2e-3, (t, nmse(got[t], ref[t]))
+        err = float(np.sqrt(np.mean((got[t] - ref[t]) ** 2)))
+        assert ref[t][int(np.argmax(got[t]))] >= ref[t].max() - 4.0 * err, t
 
 
 # ------------------------------------------------------------------------------------------------ C3: the kernels configs[2] selects
