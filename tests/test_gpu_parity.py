@@ -793,21 +793,27 @@ def test_f16_model_logits_within_1e3(pkg, be, ref_be):
 
 
 def test_norm_in_kernel_option(pkg, be, golden):
-    """opt-in variant: RMS_NORM + MUL computed inside the consuming mat-vec launches (no stand-alone norm kernel) -- same tokens,
-    fewer launches"""
+    """opt-in variant of the multi-column family: RMS_NORM + MUL computed inside the consuming mat-vec launches (no stand-alone norm
+    kernel) -- same tokens, fewer launches.  (The batch-1 kernels, which always do this and now take every K % 256 == 0, are switched off for
+    the comparison and then checked to need fewer launches still.)"""
     from test_host_mirror import run_tiny
     tm = golden["tiny_model"]
-    t0, l0 = run_tiny(pkg, be, tm, 16)
-    k0 = be.get_stat("kernels_last_graph")
-    be.set_option("norm_in_kernel", 1)
+    be.set_option("mv1", 0)
     try:
+        t0, l0 = run_tiny(pkg, be, tm, 16)
+        k0 = be.get_stat("kernels_last_graph")
+        be.set_option("norm_in_kernel", 1)
         t1, l1 = run_tiny(pkg, be, tm, 16)
         k1 = be.get_stat("kernels_last_graph")
     finally:
         be.set_option("norm_in_kernel", 0)
-    assert t0 == t1 == list(tm["tokens"])[:16]
+        be.set_option("mv1", 1)
+    t2, l2 = run_tiny(pkg, be, tm, 16)
+    k2 = be.get_stat("kernels_last_graph")
+    assert t0 == t1 == t2 == list(tm["tokens"])[:16]
     assert nmse(l1, l0) < 1e-9
-    assert k1 < k0
+    assert nmse(l2, l0) < 5e-4, nmse(l2, l0)                 # (another f32 summation order, re-quantised 16 tokens deep: the golden-logits bar)
+    assert k2 <= k1 < k0
 
 
 def test_graph_replay_is_bit_identical(pkg, be, golden):
