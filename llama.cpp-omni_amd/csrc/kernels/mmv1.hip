@@ -199,6 +199,7 @@ struct mv1_dev { mv1_mat m[3]; int nmat; const char * W1; mv1_src src; int K; };
 
 // buffer descriptor of a whole matrix (raw buffer, byte-addressed, bounds = the matrix; built from wave-uniform values only)
 typedef __amdgpu_buffer_rsrc_t mv1_rsrc;
+#define MV1_KILL 0xF0000000u                            // lane offset that no TAIL matrix's descriptor covers
 static __device__ __forceinline__ mv1_rsrc mv1_make_rsrc(const char * p, size_t bytes) {
     return __builtin_amdgcn_make_buffer_rsrc((void *) p, (short) 0, (int) (bytes > 0xfffffffful ? 0xffffffffu : (uint32_t) bytes), 0x00020000);
 }
@@ -246,15 +247,19 @@ static __device__ __forceinline__ void mv1_q4k(const char * __restrict__ W0, con
     // no per-load address arithmetic, no 64-bit pointer pairs in VGPRs
     const mv1_rsrc rs0 = mv1_make_rsrc(W0, (size_t) nrows * w_rs), rs1 = mv1_make_rsrc(PAIR ? W1 : W0, (size_t) nrows * w_rs);
     const uint32_t rs32 = (uint32_t) w_rs;
+    // TAIL: the lanes past the row in its last step request nothing -- their offset is pushed out of the descriptor's range (reads as zero, no
+    // memory traffic; mmv1_ok keeps TAIL matrices below MV1_KILL bytes) -- so the launch still moves exactly the matrix
+    const uint32_t kill = TAIL && (nit - 1) * 16 + blk >= nb ? MV1_KILL : 0u;
     auto issue = [&](int task, int it, int bf) {
+        const uint32_t kl = TAIL && it == nit - 1 ? kill : 0u;
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const int row = PAIR ? task : task * R + r;
             const uint32_t so = (uint32_t) row * rs32 + (uint32_t) it * 2304u;                           // wave-uniform
             const mv1_rsrc rs = (PAIR && r == 1) ? rs1 : rs0;
-            hq[bf][r] = __builtin_amdgcn_raw_buffer_load_b32(rs, voff_h, so, NT ? 2 : 0);
-            qa[bf][r] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff_q, so, NT ? 2 : 0);
-            qb[bf][r] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff_q + MV1_QB_OFF, so, NT ? 2 : 0);
+            hq[bf][r] = __builtin_amdgcn_raw_buffer_load_b32(rs, voff_h | kl, so, NT ? 2 : 0);
+            qa[bf][r] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff_q | kl, so, NT ? 2 : 0);
+            qb[bf][r] = __builtin_amdgcn_raw_buffer_load_b128(rs, (voff_q + MV1_QB_OFF) | kl, so, NT ? 2 : 0);
         }
     };
 #ifndef MV1_KO
@@ -374,17 +379,19 @@ static __device__ __forceinline__ void mv1_q6k(const char * __restrict__ W0, con
     const mv1_rsrc rs0 = mv1_make_rsrc(W0, (size_t) nrows * w_rs), rs1 = mv1_make_rsrc(PAIR ? W1 : W0, (size_t) nrows * w_rs);
     const uint32_t rs32 = (uint32_t) w_rs;
     const uint32_t voff_s = vb + 192u + 4u * (uint32_t) (lane & 3);
+    const uint32_t kill = TAIL && (nit - 1) * 16 + blk >= nb ? MV1_KILL : 0u;                      // (see mv1_q4k)
     auto issue = [&](int task, int it, int bf) {
+        const uint32_t kl = TAIL && it == nit - 1 ? kill : 0u;
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const int row = PAIR ? task : task * R + r;
             const uint32_t so = (uint32_t) row * rs32 + (uint32_t) it * 3360u;                           // wave-uniform
             const mv1_rsrc rs = (PAIR && r == 1) ? rs1 : rs0;
-            qla[bf][r] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff_l, so, 0);
-            qlb[bf][r] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff_l + 32u, so, 0);
-            qh[bf][r]  = __builtin_amdgcn_raw_buffer_load_b128(rs, voff_h, so, 0);
-            sc[bf][r]  = __builtin_amdgcn_raw_buffer_load_b32(rs, voff_s, so, 0);
-            dw[bf][r]  = __builtin_amdgcn_raw_buffer_load_b16(rs, vb + 208u, so, 0);
+            qla[bf][r] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff_l | kl, so, 0);
+            qlb[bf][r] = __builtin_amdgcn_raw_buffer_load_b128(rs, (voff_l + 32u) | kl, so, 0);
+            qh[bf][r]  = __builtin_amdgcn_raw_buffer_load_b128(rs, voff_h | kl, so, 0);
+            sc[bf][r]  = __builtin_amdgcn_raw_buffer_load_b32(rs, voff_s | kl, so, 0);
+            dw[bf][r]  = __builtin_amdgcn_raw_buffer_load_b16(rs, (vb + 208u) | kl, so, 0);
         }
     };
     if (!(MV1_KO & 1)) pro.issue();
@@ -508,7 +515,7 @@ bool mmv1_ok(const mv1_args & a) {
     for (int i = 0; i < a.nmat; ++i) {
         const mmv_mat & m = a.m[i];
         if (m.type != GGML_TYPE_Q4_K && m.type != GGML_TYPE_Q6_K) return false;
-        if (m.nrows <= 0 || (uint64_t) m.nrows * m.w_rs > 0xffffffffull) return false;
+        if (m.nrows <= 0 || (uint64_t) m.nrows * m.w_rs > (a.K % 4096 ? (uint64_t) MV1_KILL : 0xffffffffull)) return false;
         if (m.type == GGML_TYPE_Q4_K && (m.w_rs % 16 != 0 || ((uintptr_t) m.W & 15) != 0)) return false;
         if (m.type == GGML_TYPE_Q6_K && (m.w_rs % 2 != 0 || ((uintptr_t) m.W & 1) != 0)) return false;
         if (((uintptr_t) m.dst & 3) != 0 || ((uintptr_t) m.resid & 3) != 0) return false;
