@@ -103,9 +103,11 @@ struct prof_scope {
     hipStream_t st = nullptr;
 };
 static void prof_drain(backend_ctx * c) {
+    static const bool each = getenv("MI355X_PROFILE_EACH") != nullptr;            // one line per launch (class, the class's byte / flop figure, us) on stderr
     for (auto & p : c->prof_pending) {
         HIP_CHECK(hipEventSynchronize(p.b));
         float ms = 0; HIP_CHECK(hipEventElapsedTime(&ms, p.a, p.b));
+        if (each) fprintf(stderr, "[mi355x prof] %-18s %14.0f %9.2f us\n", p.cls.c_str(), p.bytes, ms * 1000.0);
         prof_class & pc = c->prof[p.cls];
         pc.us += ms * 1000.0; pc.bytes += p.bytes; pc.n += 1;
         c->prof_event_pool.push_back(p.a); c->prof_event_pool.push_back(p.b);

@@ -85,6 +85,77 @@ __global__ void __launch_bounds__(256) k_gemm_any(const gemm_any_dev g) {
     }
 }
 
+// F16 weights on the f16 matrix cores: the same tiles and edge rules as k_gemm_any, both operands parked in LDS as f16 (the activations rounded
+// first -- what the reference's vec_dot_type conversion does; f16 x f16 products are exact in f32, f32 accumulate) and multiplied with
+// v_mfma_f32_32x32x16_f16: 64-wide K-steps, 4 MFMAs per wave and step instead of 16 f32 ones per 32.  Whisper's V^T . P (K = 1500 frames, rows
+// of 3000 bytes: no 16-byte alignment for the DMA GEMMs of gemm.hip) went from 118 us to the figure in DESIGN.md.  VEC = 2: element pairs
+// (4-byte f16 / 8-byte f32 loads; the launcher checks alignment and K even), VEC = 1: single elements, any alignment.
+template <typename XT, int VEC>
+__global__ void __launch_bounds__(256) k_gemm_any_h(const gemm_any_dev g) {
+    constexpr int KS = 64, LD = KS + 8, CPR = KS / VEC, RPP = 256 / CPR, PT = 64 / RPP;     // LD in halves: rows of 144 bytes (16-byte aligned 8-half reads)
+    __shared__ __attribute__((aligned(16))) uint16_t Ws[2][64 * LD], Xs[2][64 * LD];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, wm = wave & 1, wn = wave >> 1;
+    const int tm = (int) blockIdx.x % g.tiles_m, tn = (int) blockIdx.x / g.tiles_m;
+    const int i12 = (int) blockIdx.y % g.ne12, i13 = (int) blockIdx.y / g.ne12;
+    const char * W = g.W + (size_t) (i12 / g.r2) * g.w_nb2 + (size_t) (i13 / g.r3) * g.w_nb3;
+    const char * X = g.X + (size_t) i12 * g.x_nb2 + (size_t) i13 * g.x_nb3;
+    const int m0 = tm * 64, n0 = tn * 64;
+    ga_acc acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.0f;
+    const int fr = lane & 31, kh = lane >> 5;
+    const int c = t % CPR, r0 = t / CPR;                           // element (pair) i of this thread: tile row r0 + RPP i, columns VEC c ..
+    uint32_t wv[PT], xv[PT];                                       // VEC f16 values each
+    auto fetch = [&](int k0) {                                     // branch-free: clamped addresses, zero selected afterwards
+        const int k = k0 + VEC * c, kc = k < g.K ? k : g.K - VEC;  // (VEC = 2: K is even, a pair is inside or outside as a whole)
+#pragma unroll
+        for (int i = 0; i < PT; ++i) {
+            const int r = r0 + RPP * i;
+            const int mr = m0 + r < g.M ? m0 + r : g.M - 1, nr = n0 + r < g.N ? n0 + r : g.N - 1;
+            const char * pw = W + (size_t) mr * g.w_rs + (size_t) kc * 2;
+            const char * px = X + (size_t) nr * g.x_rs + (size_t) kc * sizeof(XT);
+            wv[i] = VEC == 2 ? *(const uint32_t *) pw : (uint32_t) *(const uint16_t *) pw;
+            if (sizeof(XT) == 2) xv[i] = VEC == 2 ? *(const uint32_t *) px : (uint32_t) *(const uint16_t *) px;
+            else if (VEC == 2)   { const float2 f = *(const float2 *) px; xv[i] = (uint32_t) f2h(f.x) | ((uint32_t) f2h(f.y) << 16); }
+            else                 xv[i] = (uint32_t) f2h(*(const float *) px);
+        }
+#pragma unroll
+        for (int i = 0; i < PT; ++i) {
+            const int r = r0 + RPP * i;
+            if (k >= g.K || m0 + r >= g.M) wv[i] = 0u;
+            if (k >= g.K || n0 + r >= g.N) xv[i] = 0u;
+        }
+    };
+    auto park = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < PT; ++i) {
+            const int o = (r0 + RPP * i) * LD + VEC * c;
+            if (VEC == 2) { *(uint32_t *) &Ws[buf][o] = wv[i]; *(uint32_t *) &Xs[buf][o] = xv[i]; }
+            else          { Ws[buf][o] = (uint16_t) wv[i]; Xs[buf][o] = (uint16_t) xv[i]; }
+        }
+    };
+    fetch(0);
+    int buf = 0;
+    for (int k0 = 0; k0 < g.K; k0 += KS, buf ^= 1) {
+        park(buf);
+        __syncthreads();                                           // K-step k0 visible; everybody is past the MFMAs that read the other buffer
+        if (k0 + KS < g.K) fetch(k0 + KS);                         // in flight under this step's MFMAs
+#pragma unroll
+        for (int kk = 0; kk < KS / 16; ++kk) {
+            const f16x8 a = *(const f16x8 *) &Xs[buf][(wn * 32 + fr) * LD + 16 * kk + 8 * kh];
+            const f16x8 b = *(const f16x8 *) &Ws[buf][(wm * 32 + fr) * LD + 16 * kk + 8 * kh];
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc, 0, 0, 0);
+        }
+    }
+    char * dst = g.dst + (size_t) i12 * g.dst_nb2 + (size_t) i13 * g.dst_nb3;
+    const int m = m0 + wm * 32 + fr;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int n = n0 + wn * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh;
+        if (m < g.M && n < g.N) { float * p = (float *) (dst + (size_t) n * g.dst_cs + (size_t) m * 4); *p = g.accumulate ? *p + acc[e] : acc[e]; }
+    }
+}
+
 // Small products (a Token2Wav DiT projection: 512 x 200 x 512 is 32 tiles of 64 x 64): a wave's 32 x 32 tile needs K / 2 dependent f32 MFMAs of 64
 // cycles each whatever the workgroup tile, so few large tiles mean a long chain on a few CUs.  Here a workgroup owns ONE 32 x 32 tile and its
 // four waves split K (each stages its own 32-wide K-steps through a wave-private LDS region: no workgroup barrier inside the loop); the four
@@ -174,6 +245,14 @@ void gemm_any(const gemm_any_args & a, hipStream_t st) {
         return;
     }
     const dim3 grid((unsigned) (g.tiles_m * ((a.N + 63) / 64)), (unsigned) a.nbatch);
+    static const bool no_h = getenv("MI355X_NO_GEMM_ANY_H") != nullptr;
+    if (a.w_f16 && !a.w_bf16 && !no_h) {                            // F16 weights: the f16 matrix cores (pairs when every row start and K allow it)
+        const size_t xe = a.x_f16 ? 2 : 4;
+        const bool vec2 = a.K % 2 == 0 && ((uintptr_t) a.W | a.w_rs | a.w_nb2 | a.w_nb3) % 4 == 0 && ((uintptr_t) a.X | a.x_rs | a.x_nb2 | a.x_nb3) % (2 * xe) == 0;
+        if (a.x_f16) { if (vec2) k_gemm_any_h<uint16_t, 2><<<grid, dim3(256), 0, st>>>(g); else k_gemm_any_h<uint16_t, 1><<<grid, dim3(256), 0, st>>>(g); }
+        else         { if (vec2) k_gemm_any_h<float, 2><<<grid, dim3(256), 0, st>>>(g);    else k_gemm_any_h<float, 1><<<grid, dim3(256), 0, st>>>(g); }
+        return;
+    }
     if (a.x_f16)      k_gemm_any<uint16_t, uint16_t><<<grid, dim3(256), 0, st>>>(g);       // (F16 activations only come with F16 weights: supports_op)
     else if (a.w_f16 || a.w_bf16) k_gemm_any<uint16_t, float><<<grid, dim3(256), 0, st>>>(g);
     else              k_gemm_any<float, float><<<grid, dim3(256), 0, st>>>(g);

@@ -160,12 +160,14 @@ def test_norm_rope_prefill_chains_vs_reference_backend(pkg, be, ref_be, T, H, HK
 
 
 @pytest.mark.parametrize("wtype,xtype,M,N,K,H,HK", [("f32", "f32", 200, 130, 72, 4, 4), ("f32", "f32", 512, 200, 1000, 1, 1), ("f16", "f32", 64, 150, 1500, 6, 2),
-                                                    ("f16", "f16", 300, 600, 588, 1, 1), ("f16", "f32", 1152, 100, 4304, 1, 1)])
+                                                    ("f16", "f16", 300, 600, 588, 1, 1), ("f16", "f32", 1152, 100, 4304, 1, 1),
+                                                    ("f16", "f32", 70, 300, 333, 4, 2), ("f16", "f16", 65, 200, 77, 3, 1), ("f16", "f32", 64, 1500, 1500, 2, 2)])
 def test_any_shape_gemm_vs_reference_backend(pkg, be, ref_be, wtype, xtype, M, N, K, H, HK):
     """gemm_any.hip: MUL_MAT with more than 8 columns for F32 weights (Token2Wav, SigLip2's f32 K . Q^T with K = 72), F16 weights with a
     contraction length that is not a multiple of 32 (Whisper's V^T . P over 1500 frames, with a GQA-style broadcast), F16 x F16 (im2col
     columns of the patch embedding, K = 588) and the split form (SigLip2's n_ff 4304: F16 MFMA GEMM over 4288 columns + accumulated tail),
-    against the reference CPU backend.  f32 fused multiply-adds on both sides: only the summation order differs."""
+    against the reference CPU backend.  f32 fused multiply-adds on both sides: only the summation order differs.  (F16 weights run on the f16
+    matrix cores -- k_gemm_any_h: exact f16 x f16 products, f32 accumulate; odd K / 2-byte aligned rows take its single-element loads.)"""
     rng = np.random.default_rng(M + N + K)
     F = dict(f32=pkg.GGML_TYPE_F32, f16=pkg.GGML_TYPE_F16)
     npt = dict(f32=np.float32, f16=np.float16)
