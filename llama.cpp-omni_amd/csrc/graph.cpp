@@ -298,6 +298,14 @@ static bool mm_uses_gemm(const ggml_tensor * n) {
     if (w->type == GGML_TYPE_F16 && (w->nb[1] % 16 != 0 || w->nb[2] % 16 != 0 || w->nb[3] % 16 != 0 || ((uintptr_t) w->data & 15) != 0)) return false;
     return true;
 }
+// MUL_MAT that op_mul_mat sends to the any-shape GEMM's f16 kernel (gemm_any.hip k_gemm_any_h): F16 weights the DMA GEMMs do not take (odd K,
+// unaligned rows) against more than 8 f32 columns -- it reads a ready-made f16 activation image as well as the f32 rows
+static bool mm_uses_gemm_any_f16(const ggml_tensor * n) {
+    const ggml_tensor * w = n->src[0], * x = n->src[1];
+    static const bool off = getenv("MI355X_NO_GEMM_ANY") != nullptr || getenv("MI355X_NO_GEMM_ANY_H") != nullptr;
+    return !off && !mm_uses_gemm(n) && w->type == GGML_TYPE_F16 && x->type == GGML_TYPE_F32 && x->ne[1] > MI_MMVQ_MAX_COLS && x->nb[0] == 4 && w->nb[0] == 2 && n->nb[0] == 4 &&
+           x->ne[2] * x->ne[3] <= 65535 && w->ne[1] < (1ll << 31) && x->ne[1] < (1ll << 31) && w->ne[0] < (1ll << 31);
+}
 static size_t graph_act_scratch_need(const ggml_cgraph * g) {
     size_t need = 0;
     for (int i = 0; i < g->n_nodes; ++i) {
@@ -528,6 +536,20 @@ static void op_mul_mat(exec_state & s, const ggml_tensor * dst) {
         if (s.pn.m && x == s.pn.m) materialise_norm(s);
         gemm_any_args a;
         int64_t k_done = 0;
+        // the producer (SOFT_MAX of an encoder's / a flash-attention-off prefill's scores) left the f16 image of x in the scratch and did not write the f32 block
+        const bool x_img = w->type == GGML_TYPE_F16 && x->type == GGML_TYPE_F32 && s.a_src == x->data && s.a_kind == ACT_F16 && s.a_K == K && s.a_ne[0] == N && s.a_ne[1] == ne12 &&
+                           s.a_ne[2] == ne13 && s.a_nb[0] == x->nb[1] && s.a_nb[1] == x->nb[2] && s.a_nb[2] == x->nb[3];
+        if (x_img) {
+            const size_t img = act_image_bytes(ACT_F16, K);
+            a.W = w->data; a.w_rs = w->nb[1]; a.w_nb2 = w->nb[2]; a.w_nb3 = w->nb[3]; a.w_f16 = true;
+            a.X = s.c->act_scratch; a.x_rs = img; a.x_nb2 = img * (size_t) N; a.x_nb3 = img * (size_t) (N * ne12); a.x_f16 = true;
+            a.dst = (float *) dst->data; a.dst_cs = dst->nb[1]; a.dst_nb2 = dst->nb[2]; a.dst_nb3 = dst->nb[3]; a.accumulate = false;
+            a.M = M; a.N = N; a.K = K; a.nbatch = (int) (ne12 * ne13); a.ne12 = (int) ne12; a.r2 = (int) r2; a.r3 = (int) r3;
+            prof_scope ps(s, "gemm_any_f16", 2.0 * (double) M * (double) N * (double) K * (double) (ne12 * ne13));
+            gemm_any(a, s.st);
+            ++s.n_kernels;
+            return;
+        }
         // F16 weights, K a few columns past a multiple of 64 (SigLip2's n_ff 4304): the F16 MFMA GEMM takes the first K - K % 64 columns, this kernel adds the tail
         if (w->type == GGML_TYPE_F16 && x->type == GGML_TYPE_F32 && ne12 * ne13 == 1 && K % 64 != 0 && K >= 512 && w->nb[1] % 16 == 0 && ((uintptr_t) w->data & 15) == 0 &&
             dst->nb[1] % 16 == 0 && act_image_bytes(ACT_F16, K) * (size_t) N <= s.c->act_scratch_bytes) {
@@ -701,6 +723,10 @@ static int sole_user(exec_state & s, const ggml_tensor * t) {           // index
     auto it = s.users.find(t);
     if (it == s.users.end() || it->second.size() != 1 || is_out(s, t)) return -1;
     return it->second[0];
+}
+static int next_real_node(exec_state & s, int i) {                      // the next node after i that will launch something (-1: none)
+    for (int j = i + 1; j < s.g->n_nodes; ++j) if (!s.done[j] && !is_noop(s.g->nodes[j])) return j;
+    return -1;
 }
 static bool ready_before(exec_state & s, const ggml_tensor * src, int i, const int * item, int n_item) {
     if (!src) return true;
@@ -1794,7 +1820,7 @@ static void compute_node(exec_state & s, int i) {
                 const int u = s.c->opt_fusion && !is_out(s, n) ? sole_user(s, n) : -1;
                 const ggml_tensor * c = u > i ? g->nodes[u] : nullptr;
                 static const bool off = getenv("MI355X_NO_F16_EMIT") != nullptr;
-                if (!off && c && c->op == GGML_OP_MUL_MAT && c->src[1] == n && c->src[0] != n && mm_uses_gemm(c) && is_contiguous(n) && n->ne[1] > MI_MMVQ_MAX_COLS &&
+                if (!off && c && c->op == GGML_OP_MUL_MAT && c->src[1] == n && c->src[0] != n && (mm_uses_gemm(c) || mm_uses_gemm_any_f16(c)) && next_real_node(s, i) == u && is_contiguous(n) && n->ne[1] > MI_MMVQ_MAX_COLS &&
                     act_image_bytes(ACT_F16, n->ne[0]) * (size_t) (n->ne[1] * n->ne[2] * n->ne[3]) <= s.c->act_scratch_bytes &&
                     soft_max_rows_ok(td(n->src[0]), n->src[1] ? &m : nullptr, n->src[1] ? n->src[1]->type : 0, n->src[2] ? (const float *) n->src[2]->data : nullptr, td(n)))
                     xg = n;
