@@ -1174,6 +1174,54 @@ static void seed_act_f16(exec_state & s, const ggml_tensor * x) {              /
     s.a_range_lo = (const char *) x->data; s.a_range_hi = (const char *) x->data + nbytes(x);
 }
 
+// The encoders' LayerNorm: NORM -> MUL by the [n] weight -> ADD of the [n] bias (audition.cpp / vision.cpp build_norm), each the next launching node
+// and the only reader of the one before, on many rows: one launch of the wave-per-row kernel, which also emits the f16 image when only MFMA GEMMs
+// read the result (wq / wk / wv, fc1).  Same three f32 roundings as the separate ops.
+static bool exec_norm(exec_state & s, int i) {
+    static const bool off = getenv("MI355X_NO_NORM_FUSE") != nullptr;
+    ggml_cgraph * g = s.g;
+    const ggml_tensor * n = g->nodes[i];
+    if (off || !s.c->opt_fusion || is_out(s, n) || n->src[0]->type != GGML_TYPE_F32) return false;
+    auto vec_of = [&](const ggml_tensor * op, const ggml_tensor * in) -> const ggml_tensor * {
+        const ggml_tensor * v = op->src[0] == in ? op->src[1] : (op->src[1] == in ? op->src[0] : nullptr);
+        if (!v || v == in || v->type != GGML_TYPE_F32 || v->ne[0] != in->ne[0] || v->ne[1] * v->ne[2] * v->ne[3] != 1 || v->nb[0] != 4 || ((uintptr_t) v->data & 15) != 0) return nullptr;
+        for (int d = 0; d < 4; ++d) if (op->ne[d] != in->ne[d] || op->nb[d] != in->nb[d]) return nullptr;
+        return op->type == GGML_TYPE_F32 ? v : nullptr;
+    };
+    const int mi_ = sole_user(s, n);
+    if (mi_ <= i || next_real_node(s, i) != mi_ || g->nodes[mi_]->op != GGML_OP_MUL) return false;
+    const ggml_tensor * m = g->nodes[mi_];
+    const ggml_tensor * wt = vec_of(m, n);
+    if (!wt) return false;
+    const ggml_tensor * out = m, * bt = nullptr;
+    int ai = -1;
+    if (!is_out(s, m)) {
+        const int u = sole_user(s, m);
+        if (u > mi_ && next_real_node(s, mi_) == u && g->nodes[u]->op == GGML_OP_ADD) {
+            bt = vec_of(g->nodes[u], m);
+            if (bt) { ai = u; out = g->nodes[u]; }
+        }
+    }
+    if (!norm_rows_ok(td(n->src[0]), td(out))) return false;
+    const int last = ai >= 0 ? ai : mi_;
+    const ggml_tensor * xg = nullptr;
+    const bool emit16 = out->ne[2] == 1 && out->ne[3] == 1 && out->nb[1] == (size_t) out->ne[0] * 4 && gemm_only_consumers(s, out, out->ne[0], out->ne[1], &xg);
+    // the f32 rows may be skipped only when the single reader is the very next launch (the image is still in the scratch then)
+    const int u1 = emit16 ? sole_user(s, out) : -1;
+    const bool w32 = !(emit16 && u1 > last && next_real_node(s, last) == u1);
+    {
+        prof_scope ps(s, "norm", 0);
+        norm_rows_f32(td(n->src[0]), td(out), op_param_f32(n, 0), (const float *) wt->data, bt ? (const float *) bt->data : nullptr,
+                      emit16 ? (uint16_t *) s.c->act_scratch : nullptr, emit16 ? act_image_bytes(ACT_F16, out->ne[0]) : 0, w32, s.st);
+    }
+    ++s.n_kernels;
+    s.done[mi_] = 1; ++s.n_fused;
+    if (ai >= 0) { s.done[ai] = 1; ++s.n_fused; }
+    note_write(s, out);
+    if (emit16) { seed_act_f16(s, xg); ++s.n_fused; }
+    return true;
+}
+
 // Decode (one token, one sequence): can the layer's q chain, k chain + store and v store run INSIDE the attention kernel?  Needs the
 // rope(q) output to be consumed by exactly one FLASH_ATTN_EXT node (through views), that node to read the very cache rows the two
 // stores write, and nothing but views between the chains and the attention node.  On success the chains are not launched; the
@@ -1690,6 +1738,7 @@ static void compute_node(exec_state & s, int i) {
             break;
         }
         case GGML_OP_NORM: {
+            if (exec_norm(s, i)) return;
             prof_scope ps(s, "norm", 0);
             norm_f32(td(n->src[0]), td(n), op_param_f32(n, 0), s.st); ++s.n_kernels;
             break;

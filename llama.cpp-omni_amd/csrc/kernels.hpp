@@ -108,6 +108,8 @@ void im2col_f32(const tdesc & kernel, const tdesc & x, const tdesc & y, int y_ty
 void pool_f32(const tdesc & x, int x_type, const tdesc & y, const int32_t * p, bool is_2d, hipStream_t st);
 // NORM (ops.cpp:3450-3495): y = (x - mean) / sqrt(var + eps) per row
 void norm_f32(const tdesc & x, const tdesc & y, float eps, hipStream_t st);
+bool norm_rows_ok(const tdesc & x, const tdesc & y);                      // many 16-byte aligned rows of at most 4096 elements: the wave-per-row kernel
+void norm_rows_f32(const tdesc & x, const tdesc & y, float eps, const float * w, const float * b, uint16_t * y16, size_t y16_rs, bool write_f32, hipStream_t st);   // + MUL w, ADD b, f16 image
 // ROPE f32 (ops.cpp:5534-5720): modes NORMAL / NEOX, optional freq factors, YaRN
 struct rope_params {
     int   n_dims, mode, n_ctx_orig;

@@ -394,14 +394,17 @@ __global__ void __launch_bounds__(1024) k_norm(td4 x, td4 y, float eps) {
     for (int64_t i = threadIdx.x; i < n; i += blockDim.x) yr[i] = (xr[i] - mean) * scale;
 }
 // many rows (the encoders' [n_state, n_tokens] activations): one WAVE per row, the row in registers, both double sums folded across the wave
+// w / b != null: the MUL by the norm weight and the ADD of the norm bias that follow a LayerNorm in the encoders (three roundings to f32, as the
+// separate ops do: no contraction into a fused multiply-add); y16 != null: also (or, with y.p == null, only) the f16-rounded row for the GEMM
 template <int MAXV>
-__global__ void __launch_bounds__(256) k_norm_rows(td4 x, td4 y, float eps, int64_t nrows) {
+__global__ void __launch_bounds__(256) k_norm_rows(td4 x, td4 y, float eps, int64_t nrows, const float * __restrict__ w, const float * __restrict__ b, char * __restrict__ y16, int64_t y16_rs) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t) blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= nrows) return;
     const int64_t i1 = row % x.ne[1], i2 = (row / x.ne[1]) % x.ne[2], i3 = row / (x.ne[1] * x.ne[2]);
     const char * xr = x.p + i1 * x.nb[1] + i2 * x.nb[2] + i3 * x.nb[3];
-    char *       yr = y.p + i1 * y.nb[1] + i2 * y.nb[2] + i3 * y.nb[3];
+    char *       yr = y.p ? y.p + i1 * y.nb[1] + i2 * y.nb[2] + i3 * y.nb[3] : nullptr;
+    char *       hr = y16 ? y16 + row * y16_rs : nullptr;
     const int n = (int) x.ne[0];
     f32x4 v[MAXV];
     double s = 0.0;
@@ -432,23 +435,38 @@ __global__ void __launch_bounds__(256) k_norm_rows(td4 x, td4 y, float eps, int6
         f32x4 o;
 #pragma unroll
         for (int e = 0; e < 4; ++e) o[e] = v[k][e] * scale;
-        *(f32x4 *) (yr + (size_t) i * 4) = o;
+        if (w) { const f32x4 ww = *(const f32x4 *) (w + i);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = __fmul_rn(o[e], ww[e]);
+        }
+        if (b) { const f32x4 bb = *(const f32x4 *) (b + i);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = __fadd_rn(o[e], bb[e]);
+        }
+        if (yr) *(f32x4 *) (yr + (size_t) i * 4) = o;
+        if (hr) { u32x2 h; h[0] = (uint32_t) f2h(o[0]) | ((uint32_t) f2h(o[1]) << 16); h[1] = (uint32_t) f2h(o[2]) | ((uint32_t) f2h(o[3]) << 16); *(u32x2 *) (hr + (size_t) i * 2) = h; }
     }
+}
+// the rows kernel's shapes: many rows of at most 4096 elements, 16-byte aligned
+bool norm_rows_ok(const tdesc & x, const tdesc & y) {
+    auto al16 = [](const tdesc & t) { return ((uintptr_t) t.p & 15) == 0 && t.nb[0] == 4 && t.nb[1] % 16 == 0 && t.nb[2] % 16 == 0 && t.nb[3] % 16 == 0; };
+    const int64_t n = x.ne[0], nrows = x.ne[1] * x.ne[2] * x.ne[3];
+    return nrows >= 64 && n > 0 && n % 4 == 0 && n <= 4096 && al16(x) && al16(y);
+}
+// LayerNorm rows with the following MUL (w) / ADD (b) by [n] vectors folded in and, optionally, the f16 image of the result (write_f32 false: only that)
+void norm_rows_f32(const tdesc & x, const tdesc & y, float eps, const float * w, const float * b, uint16_t * y16, size_t y16_rs, bool write_f32, hipStream_t st) {
+    const int64_t n = x.ne[0], nrows = x.ne[1] * x.ne[2] * x.ne[3];
+    if (!norm_rows_ok(x, y) || ((uintptr_t) w & 15) || ((uintptr_t) b & 15) || (y16 && (y16_rs % 8 != 0 || ((uintptr_t) y16 & 7) != 0)) || (!write_f32 && !y16)) { fprintf(stderr, "[mi355x] norm_rows_f32: unsupported arguments\n"); abort(); }
+    td4 yd = to_td4(y); if (!write_f32) yd.p = nullptr;
+    const dim3 grid((unsigned) ((nrows + 3) / 4));
+    if (n <= 1024)      k_norm_rows<4><<<grid, dim3(256), 0, st>>>(to_td4(x), yd, eps, nrows, w, b, (char *) y16, (int64_t) y16_rs);
+    else if (n <= 2048) k_norm_rows<8><<<grid, dim3(256), 0, st>>>(to_td4(x), yd, eps, nrows, w, b, (char *) y16, (int64_t) y16_rs);
+    else                k_norm_rows<16><<<grid, dim3(256), 0, st>>>(to_td4(x), yd, eps, nrows, w, b, (char *) y16, (int64_t) y16_rs);
 }
 void norm_f32(const tdesc & x, const tdesc & y, float eps, hipStream_t st) {
     if (x.ne[0] == 0 || x.ne[1] * x.ne[2] * x.ne[3] == 0) return;
     const int64_t n = x.ne[0];
-    {
-        const int64_t nrows = x.ne[1] * x.ne[2] * x.ne[3];
-        auto al16 = [](const tdesc & t) { return ((uintptr_t) t.p & 15) == 0 && t.nb[0] == 4 && t.nb[1] % 16 == 0 && t.nb[2] % 16 == 0 && t.nb[3] % 16 == 0; };
-        if (nrows >= 64 && n % 4 == 0 && n <= 4096 && al16(x) && al16(y)) {
-            const dim3 grid((unsigned) ((nrows + 3) / 4));
-            if (n <= 1024)      k_norm_rows<4><<<grid, dim3(256), 0, st>>>(to_td4(x), to_td4(y), eps, nrows);
-            else if (n <= 2048) k_norm_rows<8><<<grid, dim3(256), 0, st>>>(to_td4(x), to_td4(y), eps, nrows);
-            else                k_norm_rows<16><<<grid, dim3(256), 0, st>>>(to_td4(x), to_td4(y), eps, nrows);
-            return;
-        }
-    }
+    if (norm_rows_ok(x, y)) { norm_rows_f32(x, y, eps, nullptr, nullptr, nullptr, 0, true, st); return; }
     const int bs = n <= 128 ? 64 : n < 1024 ? 256 : n < 8192 ? 512 : 1024;
     k_norm<<<dim3((unsigned) x.ne[1], (unsigned) x.ne[2], (unsigned) x.ne[3]), dim3(bs), 0, st>>>(to_td4(x), to_td4(y), eps);
 }

@@ -227,6 +227,40 @@ def test_layer_norm_rows_vs_reference_backend(pkg, be, ref_be, n, rows):
     assert nmse(got[0], want[0]) < 1e-12, nmse(got[0], want[0])
 
 
+@pytest.mark.parametrize("n,rows,bias,consumer", [(1024, 1500, True, "gemm"), (1152, 1024, True, "gemm3"), (1024, 300, False, "gemm"), (512, 200, True, "none"), (1024, 100, True, "gemm+add")])
+def test_layer_norm_with_weight_and_bias_folded_in_vs_reference_backend(pkg, be, ref_be, n, rows, bias, consumer):
+    """The encoders' LayerNorm as the graphs spell it -- NORM, MUL by the weight, ADD of the bias -- runs as one launch of the wave-per-row kernel
+    (three f32 roundings, as the separate ops), which also leaves the f16 activation image for the MFMA GEMMs behind it: one reader (fc1: the
+    f32 rows are not written at all), three readers (wq / wk / wv), no GEMM at all, and a second non-GEMM reader (f32 rows needed)."""
+    rng = np.random.default_rng(n + rows)
+    M = 256
+
+    def build(c):
+        x = c.new_tensor(pkg.GGML_TYPE_F32, n, rows); w = c.new_tensor(pkg.GGML_TYPE_F32, n); b = c.new_tensor(pkg.GGML_TYPE_F32, n)
+        ws = [c.new_tensor(pkg.GGML_TYPE_F16, n, M) for _ in range(3)]
+        y = c.mul(c.norm(x, 1e-5), w)
+        if bias:
+            y = c.add(y, b)
+        if consumer == "none":
+            outs = [y]
+        elif consumer == "gemm":
+            outs = [c.mul_mat(ws[0], y)]
+        elif consumer == "gemm3":
+            outs = [c.mul_mat(wi, y) for wi in ws]
+        else:
+            outs = [c.mul_mat(ws[0], y), c.add(y, x)]
+        return dict(x=x, w=w, b=b, w0=ws[0], w1=ws[1], w2=ws[2]), outs
+    feeds = dict(x=(rng.standard_normal(n * rows) * 2 + 0.3).astype(np.float32), w=(1 + 0.2 * rng.standard_normal(n)).astype(np.float32), b=(0.1 * rng.standard_normal(n)).astype(np.float32))
+    for k in ("w0", "w1", "w2"):
+        feeds[k] = (rng.standard_normal(n * M) / np.sqrt(n)).astype(np.float16)
+    got, want = _both(pkg, be, ref_be, build, feeds)
+    launches = be.get_stat("kernels_last_graph")
+    assert launches <= {"none": 1, "gemm": 2, "gemm3": 2, "gemm+add": 3}[consumer] + (1 if rows < 128 else 0), launches       # (norm [+ f16 image] + the GEMM launch)
+    for g_, w_ in zip(got, want):
+        assert np.isfinite(g_).all()
+        assert nmse(g_, w_) < 1e-10, nmse(g_, w_)
+
+
 @pytest.mark.parametrize("kv_type,D,Dv,nq,nkv,H,HK", [("f16", 96, 96, 5, 70, 4, 2), ("f16", 192, 128, 3, 113, 4, 4), ("q8_0", 128, 128, 4, 96, 8, 2), ("q4_0", 64, 64, 35, 130, 4, 4),
                                                       ("bf16", 80, 80, 2, 64, 2, 1), ("f32", 40, 40, 7, 50, 2, 2), ("q8_0", 256, 256, 1, 300, 4, 1)])
 def test_flash_attn_other_head_sizes_and_cache_types_vs_reference_backend(pkg, be, ref_be, kv_type, D, Dv, nq, nkv, H, HK):
