@@ -1806,8 +1806,19 @@ static void compute_node(exec_state & s, int i) {
             break;
         }
         case GGML_OP_UNARY: {
-            prof_scope ps(s, "unary", 0);
-            unary_f32(op_param_i32(n, 0), (const float *) n->src[0]->data, (float *) n->data, nelements(n), s.st); ++s.n_kernels;
+            // the activation between two mat-muls of a prefill-sized block (the encoders' GELU between fc1 and fc2): only MFMA GEMMs read it -> its f16 image is
+            // written here (dense when the row length is a multiple of 8); the f32 block only when the reader is not the very next launch
+            const ggml_tensor * xg = nullptr;
+            const bool emit16 = n->ne[2] == 1 && n->ne[3] == 1 && n->ne[0] % 8 == 0 && n->nb[1] == (size_t) n->ne[0] * 4 && (((uintptr_t) n->data | (uintptr_t) n->src[0]->data) & 15) == 0 &&
+                                gemm_only_consumers(s, n, n->ne[0], n->ne[1], &xg);
+            const int u1 = emit16 ? sole_user(s, n) : -1;
+            const bool w32 = !(emit16 && u1 > i && next_real_node(s, i) == u1);
+            {
+                prof_scope ps(s, "unary", 0);
+                unary_f32(op_param_i32(n, 0), (const float *) n->src[0]->data, (float *) n->data, nelements(n), s.st, emit16 ? (uint16_t *) s.c->act_scratch : nullptr, w32);
+            }
+            ++s.n_kernels;
+            if (emit16) { note_write(s, n); seed_act_f16(s, xg); ++s.n_fused; return; }
             break;
         }
         case GGML_OP_GLU: {

@@ -127,7 +127,7 @@ void glu_f32(int glu_op, const tdesc & a, const tdesc * b, bool swapped, const t
 bool swiglu_q8k_ok(const tdesc & a, const tdesc & b, const tdesc & y);
 void swiglu_q8k(const tdesc & a, const tdesc & b, const tdesc & y, bool write_f32, void * img, hipStream_t st);
 // unary ops on contiguous f32
-void unary_f32(int uop, const float * x, float * y, int64_t n, hipStream_t st);
+void unary_f32(int uop, const float * x, float * y, int64_t n, hipStream_t st, uint16_t * y16 = nullptr, bool write_f32 = true);   // y16: dense f16 copy of the result (n % 4 == 0, aligned)
 // ADD / SUB / MUL / DIV with ggml broadcast semantics (src1 repeats over src0)
 void bin_bcast_f32(int op, const tdesc & a, const tdesc & b, const tdesc & y, hipStream_t st);
 void scale_f32(const float * x, float * y, int64_t n, float s, float b, hipStream_t st);

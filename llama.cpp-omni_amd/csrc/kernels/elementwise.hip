@@ -691,10 +691,20 @@ void soft_max_f32(const tdesc & x, const tdesc * mask, int mask_type, const floa
 // GLU family (ops.cpp:2934-2990 swiglu; reglu/geglu variants alongside) and unary ops (unary-ops.cpp)
 // ================================================================================================
 static __device__ __forceinline__ float op_silu(float x) { return x / (1.0f + expf(-x)); }                 // vec.h:958
-static __device__ __forceinline__ float op_gelu(float x) {                                                 // vec.h ggml_gelu_f32
-    return 0.5f * x * (1.0f + tanhf(0.79788456080286535587989211986876f * x * (1.0f + 0.044715f * x * x)));
+// GELU / GELU_QUICK of an f32 value go through the reference's f16 tables (GGML_GELU_FP16 / GGML_GELU_QUICK_FP16, vec.h:17-18, :892-906, :933-941;
+// tables filled in ggml-cpu.c:3555-3556 with f16(ggml_gelu_f32(f)) for every f16 value f): the argument is rounded to f16, the formula evaluated in
+// f32 and the result rounded to f16 -- evaluated here instead of looked up (same value unless the device tanhf / expf differs from glibc's by more
+// than the f16 rounding absorbs); GELU short-cuts x <= -10 to 0 and x >= 10 to x before the table.
+static __device__ __forceinline__ float op_gelu(float x) {
+    if (x <= -10.0f) return 0.0f;
+    if (x >= 10.0f)  return x;
+    const float f = h2f(f2h(x));
+    return h2f(f2h(0.5f * f * (1.0f + tanhf(0.79788456080286535587989211986876f * f * (1.0f + 0.044715f * f * f)))));
 }
-static __device__ __forceinline__ float op_gelu_quick(float x) { return x * (1.0f / (1.0f + expf(-1.702f * x))); }
+static __device__ __forceinline__ float op_gelu_quick(float x) {
+    const float f = h2f(f2h(x));
+    return h2f(f2h(f * (1.0f / (1.0f + expf(-1.702f * f)))));
+}
 static __device__ __forceinline__ float op_gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 
 __global__ void __launch_bounds__(256) k_glu(int op, const char * __restrict__ a, int64_t a_rs, const char * __restrict__ b, int64_t b_rs,
@@ -785,32 +795,49 @@ void glu_f32(int glu_op, const tdesc & a, const tdesc * b, bool swapped, const t
     k_glu<<<dim3((unsigned) ((nc * nr + 255) / 256)), dim3(256), 0, st>>>(glu_op, ap, a_rs, bp, b_rs, write_f32 ? (char *) y.p : nullptr, (int64_t) y.nb[1], nc, nr, (char *) y16, (int64_t) y16_rs);
 }
 
+static __device__ __forceinline__ float unary_apply(int op, float v) {
+    switch (op) {
+        case GGML_UNARY_OP_ABS:        return fabsf(v);
+        case GGML_UNARY_OP_SGN:        return v > 0.0f ? 1.0f : (v < 0.0f ? -1.0f : 0.0f);
+        case GGML_UNARY_OP_NEG:        return -v;
+        case GGML_UNARY_OP_STEP:       return v > 0.0f ? 1.0f : 0.0f;
+        case GGML_UNARY_OP_TANH:       return tanhf(v);
+        case GGML_UNARY_OP_ELU:        return v > 0.0f ? v : expm1f(v);
+        case GGML_UNARY_OP_RELU:       return v > 0.0f ? v : 0.0f;
+        case GGML_UNARY_OP_SIGMOID:    return 1.0f / (1.0f + expf(-v));
+        case GGML_UNARY_OP_GELU:       return op_gelu(v);
+        case GGML_UNARY_OP_GELU_QUICK: return op_gelu_quick(v);
+        case GGML_UNARY_OP_SILU:       return op_silu(v);
+        case GGML_UNARY_OP_HARDSWISH:  return v * fminf(1.0f, fmaxf(0.0f, (v + 3.0f) / 6.0f));
+        case GGML_UNARY_OP_HARDSIGMOID:return fminf(1.0f, fmaxf(0.0f, (v + 3.0f) / 6.0f));
+        case GGML_UNARY_OP_EXP:        return expf(v);
+        case GGML_UNARY_OP_GELU_ERF:   return op_gelu_erf(v);
+        default: return v;
+    }
+}
 __global__ void __launch_bounds__(256) k_unary(int op, const float * __restrict__ x, float * __restrict__ y, int64_t n) {
     const int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const float v = x[i]; float r;
-    switch (op) {
-        case GGML_UNARY_OP_ABS:        r = fabsf(v); break;
-        case GGML_UNARY_OP_SGN:        r = v > 0.0f ? 1.0f : (v < 0.0f ? -1.0f : 0.0f); break;
-        case GGML_UNARY_OP_NEG:        r = -v; break;
-        case GGML_UNARY_OP_STEP:       r = v > 0.0f ? 1.0f : 0.0f; break;
-        case GGML_UNARY_OP_TANH:       r = tanhf(v); break;
-        case GGML_UNARY_OP_ELU:        r = v > 0.0f ? v : expm1f(v); break;
-        case GGML_UNARY_OP_RELU:       r = v > 0.0f ? v : 0.0f; break;
-        case GGML_UNARY_OP_SIGMOID:    r = 1.0f / (1.0f + expf(-v)); break;
-        case GGML_UNARY_OP_GELU:       r = op_gelu(v); break;
-        case GGML_UNARY_OP_GELU_QUICK: r = op_gelu_quick(v); break;
-        case GGML_UNARY_OP_SILU:       r = op_silu(v); break;
-        case GGML_UNARY_OP_HARDSWISH:  r = v * fminf(1.0f, fmaxf(0.0f, (v + 3.0f) / 6.0f)); break;
-        case GGML_UNARY_OP_HARDSIGMOID:r = fminf(1.0f, fmaxf(0.0f, (v + 3.0f) / 6.0f)); break;
-        case GGML_UNARY_OP_EXP:        r = expf(v); break;
-        case GGML_UNARY_OP_GELU_ERF:   r = op_gelu_erf(v); break;
-        default: r = v;
-    }
-    y[i] = r;
+    y[i] = unary_apply(op, x[i]);
 }
-void unary_f32(int uop, const float * x, float * y, int64_t n, hipStream_t st) {
+// four elements per thread (16-byte aligned, n % 4 == 0); y16 != null: also (or, with y == null, only) the f16-rounded values -- the dense f16
+// activation image of the MFMA GEMM that reads the result (the encoders' GELU between fc1 and fc2)
+__global__ void __launch_bounds__(256) k_unary_v4(int op, const f32x4 * __restrict__ x, f32x4 * __restrict__ y, u32x2 * __restrict__ y16, int64_t n4) {
+    const int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n4) return;
+    const f32x4 v = x[i]; f32x4 r;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) r[e] = unary_apply(op, v[e]);
+    if (y) y[i] = r;
+    if (y16) { u32x2 h; h[0] = (uint32_t) f2h(r[0]) | ((uint32_t) f2h(r[1]) << 16); h[1] = (uint32_t) f2h(r[2]) | ((uint32_t) f2h(r[3]) << 16); y16[i] = h; }
+}
+void unary_f32(int uop, const float * x, float * y, int64_t n, hipStream_t st, uint16_t * y16, bool write_f32) {
     if (n == 0) return;
+    if (n % 4 == 0 && (((uintptr_t) x | (uintptr_t) y) & 15) == 0 && ((uintptr_t) y16 & 7) == 0) {
+        k_unary_v4<<<dim3((unsigned) ((n / 4 + 255) / 256)), dim3(256), 0, st>>>(uop, (const f32x4 *) x, write_f32 ? (f32x4 *) y : nullptr, (u32x2 *) y16, n / 4);
+        return;
+    }
+    if (y16 || !write_f32) { fprintf(stderr, "[mi355x] unary_f32: f16 emission needs 16-byte aligned operands and n %% 4 == 0\n"); abort(); }
     k_unary<<<dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, st>>>(uop, x, y, n);
 }
 

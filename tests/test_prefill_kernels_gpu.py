@@ -261,6 +261,54 @@ def test_layer_norm_with_weight_and_bias_folded_in_vs_reference_backend(pkg, be,
         assert nmse(g_, w_) < 1e-10, nmse(g_, w_)
 
 
+@pytest.mark.parametrize("op", ["gelu", "gelu_quick"])
+def test_gelu_follows_the_reference_f16_tables(pkg, be, ref_be, op):
+    """The reference evaluates GELU / GELU_QUICK of f32 values through f16 tables (vec.h GGML_GELU_FP16: argument rounded to f16, result an f16 value;
+    GELU passes x >= 10 through and returns 0 for x <= -10): the device evaluates the same roundings instead of the f32 formula -- bit-identical to the
+    reference CPU backend where the formula is well conditioned (|x| <= 2.5: > 99.9 % of the values), within an f16 ulp or two elsewhere."""
+    from llama_cpp_omni_amd.ggml import UNARY
+    rng = np.random.default_rng(5)
+    n = 1 << 18
+    xv = (rng.standard_normal(n) * 4.0).astype(np.float32)
+    xv[:8] = [-10.0, 10.0, -10.000001, 9.999999, 0.0, -0.0, 70000.0, -70000.0]
+
+    def build(c):
+        x = c.new_tensor(pkg.GGML_TYPE_F32, n)
+        return dict(x=x), [c.unary(x, getattr(UNARY, op.upper()))]
+    got, want = _both(pkg, be, ref_be, build, dict(x=xv))
+    g_, w_ = got[0].ravel(), want[0].ravel()
+    fin = np.isfinite(w_)
+    assert np.array_equal(np.isfinite(g_), fin)
+    same = g_.view(np.uint32) == w_.view(np.uint32)
+    core = fin & (np.abs(xv) <= 2.5)
+    assert same[core].mean() > 0.999, same[core].mean()
+    # far on the negative side 1 + tanh(u) cancels: the last f32 bit of tanhf (device libm vs glibc) decides between neighbouring tiny f16 values
+    assert np.all(np.abs(g_[fin] - w_[fin]) <= 3e-7 + np.abs(w_[fin]) * 2.0 ** -9)
+    assert nmse(g_[fin], w_[fin]) < 1e-12
+
+
+@pytest.mark.parametrize("op,n,rows,second_reader", [("gelu", 1024, 300, False), ("gelu_quick", 4096, 130, False), ("silu", 512, 100, True), ("gelu", 1020, 70, False)])
+def test_unary_between_two_gemms_emits_the_f16_image_vs_reference_backend(pkg, be, ref_be, op, n, rows, second_reader):
+    """fc1 -> GELU -> fc2 of an encoder block: the unary op writes the f16 activation image of fc2's GEMM itself (and no f32 block when fc2 is its only
+    reader and the next launch); a row length that is not a multiple of 8 and a second reader keep the f32 path.  Against the reference CPU backend."""
+    rng = np.random.default_rng(n + rows)
+    M = 192
+
+    def build(c):
+        x = c.new_tensor(pkg.GGML_TYPE_F32, n, rows); w = c.new_tensor(pkg.GGML_TYPE_F16, n, M)
+        from llama_cpp_omni_amd.ggml import UNARY
+        y = c.unary(x, getattr(UNARY, op.upper()))
+        outs = [c.mul_mat(w, y)] + ([c.add(y, x)] if second_reader else [])
+        return dict(x=x, w=w), outs
+    feeds = dict(x=(rng.standard_normal(n * rows) * 1.5).astype(np.float32), w=(rng.standard_normal(n * M) / np.sqrt(n)).astype(np.float16))
+    got, want = _both(pkg, be, ref_be, build, feeds)
+    if n % 8 == 0 and not second_reader:
+        assert be.get_stat("kernels_last_graph") <= 2 + (1 if n > 2048 else 0), be.get_stat("kernels_last_graph")      # (+ the split-K reduce of a long, lone GEMM)
+    for g_, w_ in zip(got, want):
+        assert np.isfinite(g_).all()
+        assert nmse(g_, w_) < 1e-10, nmse(g_, w_)
+
+
 @pytest.mark.parametrize("kv_type,D,Dv,nq,nkv,H,HK", [("f16", 96, 96, 5, 70, 4, 2), ("f16", 192, 128, 3, 113, 4, 4), ("q8_0", 128, 128, 4, 96, 8, 2), ("q4_0", 64, 64, 35, 130, 4, 4),
                                                       ("bf16", 80, 80, 2, 64, 2, 1), ("f32", 40, 40, 7, 50, 2, 2), ("q8_0", 256, 256, 1, 300, 4, 1)])
 def test_flash_attn_other_head_sizes_and_cache_types_vs_reference_backend(pkg, be, ref_be, kv_type, D, Dv, nq, nkv, H, HK):
