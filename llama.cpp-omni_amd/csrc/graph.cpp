@@ -366,7 +366,15 @@ static size_t graph_gemm_partial_need(const ggml_cgraph * g) {
     size_t need = 0;
     for (int i = 0; i < g->n_nodes; ++i) {
         const ggml_tensor * n = g->nodes[i];
-        if (n->op != GGML_OP_MUL_MAT || is_empty(n) || !mm_uses_gemm(n) || n->src[1]->ne[2] != 1 || n->src[1]->ne[3] != 1) continue;
+        if (n->op != GGML_OP_MUL_MAT || is_empty(n) || n->src[1]->ne[2] != 1 || n->src[1]->ne[3] != 1) continue;
+        if (!mm_uses_gemm(n)) {                              // the split form of op_mul_mat (F16 weights, K a few columns past a multiple of 64): its MFMA part is a lone, usually under-filled GEMM
+            const int64_t K = n->src[0]->ne[0];
+            if (n->src[0]->type == GGML_TYPE_F16 && n->src[1]->type == GGML_TYPE_F32 && K % 64 != 0 && K >= 512 && n->src[1]->ne[1] > MI_MMVQ_MAX_COLS) {
+                const size_t b = gemm_split_scratch_bytes(n->src[0]->ne[1], n->src[1]->ne[1], K - K % 64);
+                if (b > need) need = b;
+            }
+            continue;
+        }
         int64_t m_sum = n->src[0]->ne[1];                    // the mat-muls that share this activation may go out as one launch (exec_gemm_group)
         if (n->src[1]->ne[1] <= 256) {
             int grouped = 1;
@@ -536,31 +544,31 @@ static void op_mul_mat(exec_state & s, const ggml_tensor * dst) {
         if (s.pn.m && x == s.pn.m) materialise_norm(s);
         gemm_any_args a;
         int64_t k_done = 0;
-        // the producer (SOFT_MAX of an encoder's / a flash-attention-off prefill's scores) left the f16 image of x in the scratch and did not write the f32 block
-        const bool x_img = w->type == GGML_TYPE_F16 && x->type == GGML_TYPE_F32 && s.a_src == x->data && s.a_kind == ACT_F16 && s.a_K == K && s.a_ne[0] == N && s.a_ne[1] == ne12 &&
-                           s.a_ne[2] == ne13 && s.a_nb[0] == x->nb[1] && s.a_nb[1] == x->nb[2] && s.a_nb[2] == x->nb[3];
-        if (x_img) {
-            const size_t img = act_image_bytes(ACT_F16, K);
-            a.W = w->data; a.w_rs = w->nb[1]; a.w_nb2 = w->nb[2]; a.w_nb3 = w->nb[3]; a.w_f16 = true;
-            a.X = s.c->act_scratch; a.x_rs = img; a.x_nb2 = img * (size_t) N; a.x_nb3 = img * (size_t) (N * ne12); a.x_f16 = true;
-            a.dst = (float *) dst->data; a.dst_cs = dst->nb[1]; a.dst_nb2 = dst->nb[2]; a.dst_nb3 = dst->nb[3]; a.accumulate = false;
-            a.M = M; a.N = N; a.K = K; a.nbatch = (int) (ne12 * ne13); a.ne12 = (int) ne12; a.r2 = (int) r2; a.r3 = (int) r3;
-            prof_scope ps(s, "gemm_any_f16", 2.0 * (double) M * (double) N * (double) K * (double) (ne12 * ne13));
-            gemm_any(a, s.st);
-            ++s.n_kernels;
-            return;
-        }
+        // the producer (SOFT_MAX of an encoder's / a flash-attention-off prefill's scores, or an earlier mat-mul on the same x) left the f16 image of x in
+        // the scratch -- and possibly did not write the f32 block at all
+        bool x_img = w->type == GGML_TYPE_F16 && x->type == GGML_TYPE_F32 && s.a_src == x->data && s.a_kind == ACT_F16 && s.a_K == K && s.a_ne[0] == N && s.a_ne[1] == ne12 &&
+                     s.a_ne[2] == ne13 && s.a_nb[0] == x->nb[1] && s.a_nb[1] == x->nb[2] && s.a_nb[2] == x->nb[3];
         // F16 weights, K a few columns past a multiple of 64 (SigLip2's n_ff 4304): the F16 MFMA GEMM takes the first K - K % 64 columns, this kernel adds the tail
         if (w->type == GGML_TYPE_F16 && x->type == GGML_TYPE_F32 && ne12 * ne13 == 1 && K % 64 != 0 && K >= 512 && w->nb[1] % 16 == 0 && ((uintptr_t) w->data & 15) == 0 &&
             dst->nb[1] % 16 == 0 && act_image_bytes(ACT_F16, K) * (size_t) N <= s.c->act_scratch_bytes) {
-            const size_t ximg = prepare_act(s, x, ACT_F16);
+            const size_t ximg = prepare_act(s, x, ACT_F16);        // (nothing to do when the image is there already)
+            x_img = true;
             k_done = K - K % 64;
             prof_scope ps(s, "gemm_f16", 2.0 * (double) M * (double) N * (double) k_done);
-            gemm_f16_mfma((const uint16_t *) w->data, w->nb[1], (const uint16_t *) s.c->act_scratch, ximg, (float *) dst->data, dst->nb[1], M, N, k_done, s.st);
+            gemm_multi_args ga;                                  // (split along K when the tiles do not fill the chip: SigLip2's fc2, 1152 x 1024 outputs, went from 79 to 24 us)
+            ga.nmat = 1; ga.m[0] = { (const uint16_t *) w->data, w->nb[1], (float *) dst->data, dst->nb[1], M, nullptr, 0 };
+            ga.X = (const uint16_t *) s.c->act_scratch; ga.x_rs = ximg; ga.N = N; ga.K = k_done;
+            ga.partial = gemm_split_scratch_bytes(M, N, k_done) <= s.c->gemm_partial_bytes ? (float *) s.c->gemm_partial : nullptr; ga.partial_bytes = s.c->gemm_partial_bytes;
+            gemm_f16_multi(ga, s.st);
             ++s.n_kernels;
         }
         a.W = (const char *) w->data + k_done * (w->type == GGML_TYPE_F16 ? 2 : 4); a.w_rs = w->nb[1]; a.w_nb2 = w->nb[2]; a.w_nb3 = w->nb[3]; a.w_f16 = w->type == GGML_TYPE_F16;
-        a.X = (const char *) x->data + k_done * (x->type == GGML_TYPE_F16 ? 2 : 4); a.x_rs = x->nb[1]; a.x_nb2 = x->nb[2]; a.x_nb3 = x->nb[3]; a.x_f16 = x->type == GGML_TYPE_F16;
+        if (x_img) {                                             // rows of the image: [ne13][ne12][N] x act_image_bytes
+            const size_t img = act_image_bytes(ACT_F16, K);
+            a.X = (const char *) s.c->act_scratch + k_done * 2; a.x_rs = img; a.x_nb2 = img * (size_t) N; a.x_nb3 = img * (size_t) (N * ne12); a.x_f16 = true;
+        } else {
+            a.X = (const char *) x->data + k_done * (x->type == GGML_TYPE_F16 ? 2 : 4); a.x_rs = x->nb[1]; a.x_nb2 = x->nb[2]; a.x_nb3 = x->nb[3]; a.x_f16 = x->type == GGML_TYPE_F16;
+        }
         a.dst = (float *) dst->data; a.dst_cs = dst->nb[1]; a.dst_nb2 = dst->nb[2]; a.dst_nb3 = dst->nb[3]; a.accumulate = k_done > 0;
         a.M = M; a.N = N; a.K = K - k_done; a.nbatch = (int) (ne12 * ne13); a.ne12 = (int) ne12; a.r2 = (int) r2; a.r3 = (int) r3;
         prof_scope ps(s, w->type == GGML_TYPE_F16 ? "gemm_any_f16" : "gemm_any_f32", 2.0 * (double) M * (double) N * (double) (K - k_done) * (double) (ne12 * ne13));
