@@ -362,6 +362,10 @@ static size_t graph_rope_scratch_need(const ggml_cgraph * g) {
     }
     return need;
 }
+static int64_t gemm_group_split_max_cols() {                 // grouped launches (wq / wk / wv) may split K up to this many columns
+    static const int64_t v = getenv("MI355X_GROUP_SPLIT_MAX_COLS") ? atoll(getenv("MI355X_GROUP_SPLIT_MAX_COLS")) : 512;
+    return v;
+}
 static size_t graph_gemm_partial_need(const ggml_cgraph * g) {
     size_t need = 0;
     for (int i = 0; i < g->n_nodes; ++i) {
@@ -376,7 +380,7 @@ static size_t graph_gemm_partial_need(const ggml_cgraph * g) {
             continue;
         }
         int64_t m_sum = n->src[0]->ne[1];                    // the mat-muls that share this activation may go out as one launch (exec_gemm_group)
-        if (n->src[1]->ne[1] <= 256) {
+        if (n->src[1]->ne[1] <= gemm_group_split_max_cols()) {
             int grouped = 1;
             for (int j = i + 1; j < g->n_nodes && j < i + 32 && grouped < 3; ++j) {
                 const ggml_tensor * c = g->nodes[j];
@@ -929,7 +933,7 @@ static bool exec_gemm_group(exec_state & s, int i) {
         return true;
     }
     if (a.nmat == 1 && a.m[0].dst_cs % 16 == 0 && gemm_split_scratch_bytes(a.m[0].M, N, K) <= s.c->gemm_partial_bytes) a.partial = (float *) s.c->gemm_partial;
-    else if (a.nmat > 1 && N <= 256 && s.c->gemm_partial_bytes > 0) a.partial = (float *) s.c->gemm_partial;      // short prompts: split-K for the grouped launches too
+    else if (a.nmat > 1 && N <= gemm_group_split_max_cols() && s.c->gemm_partial_bytes > 0) a.partial = (float *) s.c->gemm_partial;      // short prompts: split-K for the grouped launches too
     a.partial_bytes = s.c->gemm_partial_bytes;
     double flops = 0;
     for (int q = 0; q < a.nmat; ++q) flops += 2.0 * (double) a.m[q].M * (double) N * (double) K;

@@ -959,7 +959,7 @@ void gemm_f16_multi(const gemm_multi_args & a, hipStream_t st) {
     if (any_q && (!kq || BM != G_BM || nbatch != 1 || a.K % 256 != 0)) { fprintf(stderr, "[mi355x] gemm: K-quant staging needs every matrix of the launch as K-quant blocks, K %% 256 == 0, no batch\n"); abort(); }
     int64_t m_sum = 0; bool m4 = true;
     for (int i = 0; i < a.nmat; ++i) { m_sum += a.m[i].M; m4 = m4 && a.m[i].M % 4 == 0 && a.m[i].dst_cs % 16 == 0; }
-    if (BM == G_BM && nbatch == 1 && a.partial && m4 && (a.nmat == 1 || a.N <= 256)) {
+    if (BM == G_BM && nbatch == 1 && a.partial && m4 && (a.nmat == 1 || a.N <= 512)) {      // (the caller hands grouped launches a scratch only up to its own column limit)
         ksplit = pick_ksplit((int64_t) tm * tiles_n, nk, a.N);
         while (ksplit > 1 && (size_t) ksplit * (size_t) m_sum * (size_t) a.N * 4 > a.partial_bytes) --ksplit;
     }
