@@ -824,7 +824,8 @@ static void allow_big_lds(const void * kernel, int bytes, int slot) {
 static int pick_ksplit(int64_t tiles, int64_t nk, int64_t N) {
     if (tiles >= 256 || nk < 32) return 1;
     const int smax = N <= 256 ? 8 : 4, min_steps = N <= 256 ? 8 : 16;
-    int s = (int) (512 / tiles);
+    static const int64_t target = getenv("MI355X_GEMM_SPLIT_TARGET") ? atoll(getenv("MI355X_GEMM_SPLIT_TARGET")) : 512;
+    int s = (int) (target / tiles);
     if (s > smax) s = smax;
     while (s > 1 && nk / s < min_steps) --s;
     return s < 1 ? 1 : s;
