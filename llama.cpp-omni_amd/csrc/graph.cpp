@@ -480,9 +480,21 @@ static const uint16_t * weight_shadow(exec_state & s, const ggml_tensor * w, con
     return p;
 }
 
-static void op_mul_mat(exec_state & s, const ggml_tensor * dst) {
+// does op_mul_mat send this MUL_MAT to the any-shape GEMM (gemm_any.hip)?  (after the MFMA GEMM and BF16 branches)
+static bool mm_takes_gemm_any(const ggml_tensor * n) {
+    static const bool no_gemm_any = getenv("MI355X_NO_GEMM_ANY") != nullptr;
+    const ggml_tensor * w = n->src[0], * x = n->src[1];
+    const int64_t K = w->ne[0], M = w->ne[1], N = x->ne[1];
+    if (no_gemm_any || mm_uses_gemm(n) || w->type == GGML_TYPE_BF16) return false;
+    return (w->type == GGML_TYPE_F32 || w->type == GGML_TYPE_F16) && N > MI_MMVQ_MAX_COLS &&
+           ((x->type == GGML_TYPE_F32 && x->nb[0] == 4) || (x->type == GGML_TYPE_F16 && x->nb[0] == 2 && w->type == GGML_TYPE_F16)) && w->nb[0] == (w->type == GGML_TYPE_F16 ? 2u : 4u) && n->nb[0] == 4 &&
+           x->ne[2] * x->ne[3] <= 65535 && M < (1ll << 31) && N < (1ll << 31) && K < (1ll << 31);
+}
+// out / bias: the ADD of a [M] row vector behind the mat-mul, folded into the any-shape GEMM's epilogue (exec_mul_mat decides; only that path takes them)
+static void op_mul_mat(exec_state & s, const ggml_tensor * dst, const ggml_tensor * out = nullptr, const float * bias = nullptr) {
     const ggml_tensor * w = dst->src[0];
     const ggml_tensor * x = dst->src[1];
+    if (!out) out = dst;
     const int64_t K = w->ne[0], M = w->ne[1], N = x->ne[1];
     const int64_t ne12 = x->ne[2], ne13 = x->ne[3];
     const int64_t r2 = ne12 / w->ne[2], r3 = ne13 / w->ne[3];
@@ -542,9 +554,7 @@ static void op_mul_mat(exec_state & s, const ggml_tensor * dst) {
     const act_kind kind = act_kind_for(w->type);
     // more than 8 columns against F32 weights, or F16 weights with a contraction length the F16 GEMM does not take (the omni encoders, Token2Wav):
     // one f32-MFMA launch over every (head, batch) instead of a mat-vec launch per 8 columns per head
-    static const bool no_gemm_any = getenv("MI355X_NO_GEMM_ANY") != nullptr;
-    if (!no_gemm_any && (w->type == GGML_TYPE_F32 || w->type == GGML_TYPE_F16) && N > MI_MMVQ_MAX_COLS &&
-        ((x->type == GGML_TYPE_F32 && x->nb[0] == 4) || (x->type == GGML_TYPE_F16 && x->nb[0] == 2 && w->type == GGML_TYPE_F16)) && w->nb[0] == (w->type == GGML_TYPE_F16 ? 2u : 4u) && dst->nb[0] == 4 && ne12 * ne13 <= 65535 && M < (1ll << 31) && N < (1ll << 31) && K < (1ll << 31)) {
+    if (mm_takes_gemm_any(dst)) {
         if (s.pn.m && x == s.pn.m) materialise_norm(s);
         gemm_any_args a;
         int64_t k_done = 0;
@@ -554,13 +564,13 @@ static void op_mul_mat(exec_state & s, const ggml_tensor * dst) {
                      s.a_ne[2] == ne13 && s.a_nb[0] == x->nb[1] && s.a_nb[1] == x->nb[2] && s.a_nb[2] == x->nb[3];
         // F16 weights, K a few columns past a multiple of 64 (SigLip2's n_ff 4304): the F16 MFMA GEMM takes the first K - K % 64 columns, this kernel adds the tail
         if (w->type == GGML_TYPE_F16 && x->type == GGML_TYPE_F32 && ne12 * ne13 == 1 && K % 64 != 0 && K >= 512 && w->nb[1] % 16 == 0 && ((uintptr_t) w->data & 15) == 0 &&
-            dst->nb[1] % 16 == 0 && act_image_bytes(ACT_F16, K) * (size_t) N <= s.c->act_scratch_bytes) {
+            out->nb[1] % 16 == 0 && act_image_bytes(ACT_F16, K) * (size_t) N <= s.c->act_scratch_bytes) {
             const size_t ximg = prepare_act(s, x, ACT_F16);        // (nothing to do when the image is there already)
             x_img = true;
             k_done = K - K % 64;
             prof_scope ps(s, "gemm_f16", 2.0 * (double) M * (double) N * (double) k_done);
             gemm_multi_args ga;                                  // (split along K when the tiles do not fill the chip: SigLip2's fc2, 1152 x 1024 outputs, went from 79 to 24 us)
-            ga.nmat = 1; ga.m[0] = { (const uint16_t *) w->data, w->nb[1], (float *) dst->data, dst->nb[1], M, nullptr, 0 };
+            ga.nmat = 1; ga.m[0] = { (const uint16_t *) w->data, w->nb[1], (float *) out->data, out->nb[1], M, nullptr, 0 };
             ga.X = (const uint16_t *) s.c->act_scratch; ga.x_rs = ximg; ga.N = N; ga.K = k_done;
             ga.partial = gemm_split_scratch_bytes(M, N, k_done) <= s.c->gemm_partial_bytes ? (float *) s.c->gemm_partial : nullptr; ga.partial_bytes = s.c->gemm_partial_bytes;
             gemm_f16_multi(ga, s.st);
@@ -573,7 +583,7 @@ static void op_mul_mat(exec_state & s, const ggml_tensor * dst) {
         } else {
             a.X = (const char *) x->data + k_done * (x->type == GGML_TYPE_F16 ? 2 : 4); a.x_rs = x->nb[1]; a.x_nb2 = x->nb[2]; a.x_nb3 = x->nb[3]; a.x_f16 = x->type == GGML_TYPE_F16;
         }
-        a.dst = (float *) dst->data; a.dst_cs = dst->nb[1]; a.dst_nb2 = dst->nb[2]; a.dst_nb3 = dst->nb[3]; a.accumulate = k_done > 0;
+        a.dst = (float *) out->data; a.dst_cs = out->nb[1]; a.dst_nb2 = out->nb[2]; a.dst_nb3 = out->nb[3]; a.accumulate = k_done > 0; a.bias = bias;
         a.M = M; a.N = N; a.K = K - k_done; a.nbatch = (int) (ne12 * ne13); a.ne12 = (int) ne12; a.r2 = (int) r2; a.r3 = (int) r3;
         prof_scope ps(s, w->type == GGML_TYPE_F16 ? "gemm_any_f16" : "gemm_any_f32", 2.0 * (double) M * (double) N * (double) (K - k_done) * (double) (ne12 * ne13));
         gemm_any(a, s.st);
@@ -967,6 +977,25 @@ static void exec_mul_mat(exec_state & s, int i) {
     ggml_tensor * n = g->nodes[i];
     if (s.c->opt_fusion && exec_gemm_group(s, i)) return;
     const bool q80 = s.c->opt_fusion && q80_mv1_node(s, n);                  // Q8_0, one column: the same fusions on mmv1q.hip
+    if (s.c->opt_fusion && mm_takes_gemm_any(n) && !is_out(s, n)) {
+        // the bias ADD behind an F32-weight / odd-K linear layer (Token2Wav's DiT and HiFT blocks): a [M] row vector, the only reader, the next launch -> the GEMM's epilogue
+        static const bool off = getenv("MI355X_NO_GEMM_ANY_BIAS") != nullptr;
+        const int ai = off ? -1 : sole_user(s, n);
+        if (ai > i && next_real_node(s, i) == ai && g->nodes[ai]->op == GGML_OP_ADD) {
+            const ggml_tensor * A = g->nodes[ai];
+            const ggml_tensor * r = A->src[0] == n ? A->src[1] : (A->src[1] == n ? A->src[0] : nullptr);
+            bool ok = r && r != n && r->type == GGML_TYPE_F32 && A->type == GGML_TYPE_F32 && r->ne[0] == n->ne[0] && r->ne[1] * r->ne[2] * r->ne[3] == 1 && r->nb[0] == 4 && n->ne[1] > 1;
+            for (int d = 0; ok && d < 4; ++d) ok = A->ne[d] == n->ne[d] && A->nb[d] == n->nb[d];
+            // (ggml-alloc may have given the ADD's result the memory of the mat-mul's dead operands: the launch reads them while it writes the result)
+            ok = ok && !overlap(range_of(A), range_of(n->src[0])) && !overlap(range_of(A), range_of(n->src[1])) && !overlap(range_of(A), range_of(r));
+            if (ok) {
+                op_mul_mat(s, n, A, (const float *) r->data);
+                s.done[ai] = 1; ++s.n_fused;
+                note_write(s, A);
+                return;
+            }
+        }
+    }
     if (!s.c->opt_fusion || (!kq_mm_ok(n) && !q80)) { op_mul_mat(s, n); note_write(s, n); return; }
     const ggml_tensor * x = n->src[1];
     const int64_t K = x->ne[0]; const int N = (int) x->ne[1];

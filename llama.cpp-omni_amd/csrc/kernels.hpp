@@ -257,6 +257,7 @@ struct gemm_any_args {
     float * dst; size_t dst_cs, dst_nb2 = 0, dst_nb3 = 0;
     int64_t M, N, K; int nbatch = 1, ne12 = 1, r2 = 1, r3 = 1;
     bool accumulate = false;                 // dst += W.X (the K tail behind a gemm_f16 launch over the first K - K % 64 columns)
+    const float * bias = nullptr;            // dst[n][m] = W.X + bias[m]: the ADD of a [M] row vector that follows the mat-mul (one more f32 rounding, as the separate op)
 };
 void   gemm_any(const gemm_any_args & a, hipStream_t st);
 

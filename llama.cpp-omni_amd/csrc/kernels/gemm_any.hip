@@ -20,6 +20,7 @@ struct gemm_any_dev {
     const char * W; size_t w_rs, w_nb2, w_nb3;
     const char * X; size_t x_rs, x_nb2, x_nb3;
     char * dst; size_t dst_cs, dst_nb2, dst_nb3;
+    const float * bias;
     int M, N, K, tiles_m, ne12, r2, r3, round_x, accumulate;      // round_x: 0 none, 1 activations rounded to f16, 2 to bf16 (and the 16-bit weights are bf16)
 };
 
@@ -81,7 +82,7 @@ __global__ void __launch_bounds__(256) k_gemm_any(const gemm_any_dev g) {
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
         const int n = n0 + wn * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh;
-        if (m < g.M && n < g.N) { float * p = (float *) (dst + (size_t) n * g.dst_cs + (size_t) m * 4); *p = g.accumulate ? *p + acc[e] : acc[e]; }
+        if (m < g.M && n < g.N) { float * p = (float *) (dst + (size_t) n * g.dst_cs + (size_t) m * 4); float v = g.accumulate ? *p + acc[e] : acc[e]; if (g.bias) v = __fadd_rn(v, g.bias[m]); *p = v; }
     }
 }
 
@@ -152,7 +153,7 @@ __global__ void __launch_bounds__(256) k_gemm_any_h(const gemm_any_dev g) {
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
         const int n = n0 + wn * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh;
-        if (m < g.M && n < g.N) { float * p = (float *) (dst + (size_t) n * g.dst_cs + (size_t) m * 4); *p = g.accumulate ? *p + acc[e] : acc[e]; }
+        if (m < g.M && n < g.N) { float * p = (float *) (dst + (size_t) n * g.dst_cs + (size_t) m * 4); float v = g.accumulate ? *p + acc[e] : acc[e]; if (g.bias) v = __fadd_rn(v, g.bias[m]); *p = v; }
     }
 }
 
@@ -224,7 +225,7 @@ __global__ void __launch_bounds__(256) k_gemm_any_sk(const gemm_any_dev g) {
         float v = acc[e];
 #pragma unroll
         for (int w = 0; w < 3; ++w) v += red[w][e * 64 + lane];
-        if (m < g.M && n < g.N) { float * p = (float *) (dst + (size_t) n * g.dst_cs + (size_t) m * 4); *p = g.accumulate ? *p + v : v; }
+        if (m < g.M && n < g.N) { float * p = (float *) (dst + (size_t) n * g.dst_cs + (size_t) m * 4); if (g.accumulate) v = *p + v; if (g.bias) v = __fadd_rn(v, g.bias[m]); *p = v; }
     }
 }
 
@@ -234,7 +235,7 @@ void gemm_any(const gemm_any_args & a, hipStream_t st) {
     g.W = (const char *) a.W; g.w_rs = a.w_rs; g.w_nb2 = a.w_nb2; g.w_nb3 = a.w_nb3;
     g.X = (const char *) a.X; g.x_rs = a.x_rs; g.x_nb2 = a.x_nb2; g.x_nb3 = a.x_nb3;
     g.dst = (char *) a.dst; g.dst_cs = a.dst_cs; g.dst_nb2 = a.dst_nb2; g.dst_nb3 = a.dst_nb3;
-    g.M = (int) a.M; g.N = (int) a.N; g.K = (int) a.K; g.tiles_m = (int) ((a.M + 63) / 64); g.ne12 = a.ne12; g.r2 = a.r2; g.r3 = a.r3; g.round_x = a.w_bf16 ? 2 : (a.w_f16 ? 1 : 0); g.accumulate = a.accumulate ? 1 : 0;
+    g.M = (int) a.M; g.N = (int) a.N; g.K = (int) a.K; g.tiles_m = (int) ((a.M + 63) / 64); g.ne12 = a.ne12; g.r2 = a.r2; g.r3 = a.r3; g.round_x = a.w_bf16 ? 2 : (a.w_f16 ? 1 : 0); g.accumulate = a.accumulate ? 1 : 0; g.bias = a.bias;
     static const bool no_sk = getenv("MI355X_GEMM_ANY_NO_SPLIT") != nullptr;
     if (!no_sk && (int64_t) g.tiles_m * ((a.N + 63) / 64) * a.nbatch < 128 && a.K >= 256) {          // few tiles, long chains: one 32 x 32 tile per workgroup, K split over its waves
         g.tiles_m = (int) ((a.M + 31) / 32);

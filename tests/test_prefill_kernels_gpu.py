@@ -309,6 +309,28 @@ def test_unary_between_two_gemms_emits_the_f16_image_vs_reference_backend(pkg, b
         assert nmse(g_, w_) < 1e-10, nmse(g_, w_)
 
 
+@pytest.mark.parametrize("wtype,M,N,K", [("f32", 512, 200, 512), ("f32", 80, 120, 1000), ("f16", 1152, 100, 4304), ("f16", 300, 70, 333)])
+def test_bias_add_folded_into_the_any_shape_gemm_vs_reference_backend(pkg, be, ref_be, wtype, M, N, K):
+    """Token2Wav's linear layers: MUL_MAT with F32 weights (or F16 with an odd K) followed by the ADD of a [M] bias row -- the bias goes into the any-shape
+    GEMM's epilogue (one more f32 rounding, as the separate op; the small split-K variant, the plain tiles, the f16 kernel and the split form with its
+    accumulating tail).  A second product on the same x keeps its own bias; against the reference CPU backend."""
+    rng = np.random.default_rng(M + N + K)
+    F = dict(f32=pkg.GGML_TYPE_F32, f16=pkg.GGML_TYPE_F16); npt = dict(f32=np.float32, f16=np.float16)
+
+    def build(c):
+        w = c.new_tensor(F[wtype], K, M); w2 = c.new_tensor(F[wtype], K, M); x = c.new_tensor(pkg.GGML_TYPE_F32, K, N)
+        b = c.new_tensor(pkg.GGML_TYPE_F32, M); b2 = c.new_tensor(pkg.GGML_TYPE_F32, M)
+        return dict(w=w, w2=w2, x=x, b=b, b2=b2), [c.add(c.mul_mat(w, x), b), c.add(c.mul_mat(w2, x), b2)]
+    feeds = dict(w=(rng.standard_normal(K * M) / np.sqrt(K)).astype(npt[wtype]), w2=(rng.standard_normal(K * M) / np.sqrt(K)).astype(npt[wtype]),
+                 x=rng.standard_normal(K * N).astype(np.float32), b=rng.standard_normal(M).astype(np.float32), b2=rng.standard_normal(M).astype(np.float32))
+    got, want = _both(pkg, be, ref_be, build, feeds)
+    launches = be.get_stat("kernels_last_graph")
+    assert launches <= (5 if K == 4304 else 2), launches          # (split form: image + MFMA part [+ reduce] + tail)... no ADD launches
+    for g_, w_ in zip(got, want):
+        assert np.isfinite(g_).all()
+        assert nmse(g_, w_) < 1e-10, nmse(g_, w_)
+
+
 @pytest.mark.parametrize("kv_type,D,Dv,nq,nkv,H,HK", [("f16", 96, 96, 5, 70, 4, 2), ("f16", 192, 128, 3, 113, 4, 4), ("q8_0", 128, 128, 4, 96, 8, 2), ("q4_0", 64, 64, 35, 130, 4, 4),
                                                       ("bf16", 80, 80, 2, 64, 2, 1), ("f32", 40, 40, 7, 50, 2, 2), ("q8_0", 256, 256, 1, 300, 4, 1)])
 def test_flash_attn_other_head_sizes_and_cache_types_vs_reference_backend(pkg, be, ref_be, kv_type, D, Dv, nq, nkv, H, HK):
