@@ -196,3 +196,27 @@ def test_t2w_blocks_at_real_shape_vs_reference_backend(pkg, be, ref_be, which):
             print(which, "NMSE vs the reference CPU backend:", e)
             # f32 weights: > 8 columns run the MFMA GEMM on f16-rounded operands (the reference's own MUL_MAT bar: 5e-4)
             assert e < (5e-4 if which in ("dit_block", "hift_stage", "timestep") else 1e-10), (which, e)
+
+
+def test_dit_block_graph_replay_matches_the_eager_run(pkg, be):
+    """A Token2Wav DiT block is launch-bound (59 launches of a few microseconds), so the backend replays it as a hipGraph from the third submission: the
+    replayed results -- with the fused LayerNorm / bias epilogues / f16 images decided at capture time -- are bit-identical to the first, eager run."""
+    from llama_cpp_omni_amd import token2wav as T
+    c = pkg.Context(be)
+    W = T.dit_weights(c, T.DIT)
+    x, cond, out = T.dit_block(c, T.DIT, W, 200)
+    ins = dict(W, x=x, cond=cond)
+    c.alloc()
+    rng = np.random.default_rng(5)
+    for name, t in ins.items():
+        be.tensor_set(t, _fill_scaled(rng, name, t))
+    g = c.graph()
+    before = be.get_stat("graph_replays")
+    runs = []
+    for _ in range(5):
+        be.graph_compute(g)
+        runs.append(be.tensor_get(out).copy())
+    assert be.get_stat("graph_replays") > before, "the block did not replay"
+    for r in runs[1:]:
+        assert np.array_equal(r.view(np.uint32), runs[0].view(np.uint32))
+    c.free()
