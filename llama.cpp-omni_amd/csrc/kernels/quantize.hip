@@ -137,9 +137,27 @@ __global__ void __launch_bounds__(256) k_f32_to_f16_rows3(const char * __restric
     uint16_t *    yr = (uint16_t *) (y + row * ys);
     for (int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x; i < K; i += (int64_t) gridDim.x * blockDim.x) yr[i] = f2h(xr[i]);
 }
+// short rows (attention heads: K = 64 / 128 per (token, head) row -- a workgroup per row would be 24 000 workgroups of one or two live waves): four elements
+// per thread, K / 4 threads per row, rows packed into the workgroups
+__global__ void __launch_bounds__(256) k_f32_to_f16_rows3_v4(const char * __restrict__ x, size_t nb1, size_t nb2, size_t nb3, int n1, int n2,
+                                                            char * __restrict__ y, size_t ys, int k4, int64_t nrows) {
+    const int64_t gt = (int64_t) blockIdx.x * 256 + threadIdx.x;
+    const int64_t row = gt / k4;
+    if (row >= nrows) return;
+    const int i = (int) (gt - row * k4) * 4;
+    const int i1 = (int) (row % n1), i2 = (int) ((row / n1) % n2), i3 = (int) (row / ((int64_t) n1 * n2));
+    const f32x4 v = *(const f32x4 *) (x + i1 * nb1 + i2 * nb2 + i3 * nb3 + (size_t) i * 4);
+    u32x2 h; h[0] = (uint32_t) f2h(v[0]) | ((uint32_t) f2h(v[1]) << 16); h[1] = (uint32_t) f2h(v[2]) | ((uint32_t) f2h(v[3]) << 16);
+    *(u32x2 *) (y + row * ys + (size_t) i * 2) = h;
+}
 void convert_f32_f16_rows3(const float * x, size_t nb1, size_t nb2, size_t nb3, int64_t n1, int64_t n2, int64_t n3, uint16_t * y, size_t ys, int64_t K, hipStream_t st) {
     const int64_t nrows = n1 * n2 * n3;
     if (K == 0 || nrows == 0) return;
+    if (K % 4 == 0 && K <= 1024 && (((uintptr_t) x | nb1 | nb2 | nb3) & 15) == 0 && (((uintptr_t) y | ys) & 7) == 0 && nrows * (K / 4) < ((int64_t) 1 << 38)) {
+        const int64_t threads = nrows * (K / 4);
+        k_f32_to_f16_rows3_v4<<<dim3((unsigned) ((threads + 255) / 256)), dim3(256), 0, st>>>((const char *) x, nb1, nb2, nb3, (int) n1, (int) n2, (char *) y, ys, (int) (K / 4), nrows);
+        return;
+    }
     unsigned gx = (unsigned) ((K + 255) / 256); if (gx > 64) gx = 64;
     k_f32_to_f16_rows3<<<dim3(gx, (unsigned) nrows), dim3(256), 0, st>>>((const char *) x, nb1, nb2, nb3, (int) n1, (int) n2, (char *) y, ys, K);
 }
