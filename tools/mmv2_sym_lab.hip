@@ -1,0 +1,210 @@
+// tools/mmv2_sym_lab.hip -- measurement bench (not part of the product): the dense-load LDS-DMA decode mat-vec (mmv2.hip) against the register-load
+// family (mmv1.hip) in every decode shape of Qwen3-8B Q4_K_M, as nodes of a replayed hipGraph with rotating weights (nothing cache-resident),
+// with a result check, and -- built with -DMV2_TRACE -- a per-wave time line of one launch (s_memrealtime stamps).
+//   build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off [-DMV2_TRACE] tools/mmv2_sym_lab.hip -o build/mmv2_lab      run: build/mmv2_lab [shape]
+#include "../llama.cpp-omni_amd/csrc/kernels/quantize.hip"
+#include "../llama.cpp-omni_amd/csrc/kernels/mmv1.hip"
+#include "../llama.cpp-omni_amd/csrc/kernels/mmv1q.hip"
+#include "mv2_sym.hip"
+#include <vector>
+#include <string>
+#include <functional>
+#include <algorithm>
+#include <cmath>
+
+using namespace mi;
+
+__global__ void k_fill(uint32_t * p, size_t n32, uint32_t seed) {
+    for (size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x; i < n32; i += (size_t) gridDim.x * blockDim.x) {
+        uint32_t h = (uint32_t) i * 2654435761u ^ seed; h ^= h >> 15; h *= 2246822519u; h ^= h >> 13; h *= 3266489917u; h ^= h >> 16;
+        p[i] = h;
+    }
+}
+__global__ void k_fix_scales(char * p, size_t nblk, int bs, int off, int nf16) {
+    for (size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x; i < nblk; i += (size_t) gridDim.x * blockDim.x) {
+        uint16_t * d = (uint16_t *) (p + i * bs + off);
+        for (int k = 0; k < nf16; ++k) d[k] = (uint16_t) (0x1c00 + ((i * 7 + k * 13) & 0x3ff));
+    }
+}
+__global__ void k_fill_f32(float * p, size_t n, uint32_t seed, float amp) {
+    for (size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t) gridDim.x * blockDim.x) {
+        uint32_t h = (uint32_t) i * 2654435761u ^ seed; h ^= h >> 15; h *= 2246822519u; h ^= h >> 13; h *= 3266489917u; h ^= h >> 16;
+        p[i] = amp * ((float) (h & 0xffffff) / 8388608.0f - 1.0f);
+    }
+}
+
+static hipStream_t st;
+static hipEvent_t e0, e1;
+
+static double time_graph(int N, const std::function<void(int)> & launch) {
+    for (int s = 0; s < 3; ++s) launch(s);
+    HIP_CHECK(hipStreamSynchronize(st));
+    hipGraph_t graph; hipGraphExec_t exec;
+    HIP_CHECK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+    for (int s = 0; s < N; ++s) launch(s);
+    HIP_CHECK(hipStreamEndCapture(st, &graph));
+    HIP_CHECK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+    float best = 1e30f;
+    for (int r = 0; r < 5; ++r) {
+        HIP_CHECK(hipEventRecord(e0, st)); HIP_CHECK(hipGraphLaunch(exec, st)); HIP_CHECK(hipEventRecord(e1, st)); HIP_CHECK(hipEventSynchronize(e1));
+        float ms; HIP_CHECK(hipEventElapsedTime(&ms, e0, e1)); if (ms < best) best = ms;
+    }
+    HIP_CHECK(hipGraphExecDestroy(exec)); HIP_CHECK(hipGraphDestroy(graph));
+    return best * 1e3 / N;
+}
+
+struct shape { const char * name; int K; int nmat; int nrows[3]; int types[3]; bool pair; bool norm; bool resid; };
+
+#ifdef MV2_TRACE
+static unsigned long long * trace_dev = nullptr;
+static void trace_report(const char * nm, int nwaves) {
+    std::vector<unsigned long long> h((size_t) nwaves * 8);
+    HIP_CHECK(hipMemcpy(h.data(), trace_dev, h.size() * 8, hipMemcpyDeviceToHost));
+    unsigned long long t0 = ~0ull;
+    for (int w = 0; w < nwaves; ++w) if (h[(size_t) w * 8]) t0 = std::min(t0, h[(size_t) w * 8]);
+    static const char * lab[8] = { "start", "rows issued", "pre-DMA issued", "row arrived", "image done", "ring issued", "step 0 landed", "end" };
+    printf("      time line of %s (us after the first wave's start; min / median / max over %d waves)\n", nm, nwaves);
+    for (int i = 0; i < 8; ++i) {
+        std::vector<double> v(nwaves);
+        for (int w = 0; w < nwaves; ++w) v[w] = (double) (h[(size_t) w * 8 + i] - t0) * 0.01;
+        std::sort(v.begin(), v.end());
+        printf("        %-14s %6.2f / %6.2f / %6.2f\n", lab[i], v[0], v[nwaves / 2], v[nwaves - 1]);
+    }
+}
+#endif
+
+int main(int argc, char ** argv) {
+    setvbuf(stdout, nullptr, _IONBF, 0);
+    HIP_CHECK(hipStreamCreate(&st));
+    HIP_CHECK(hipEventCreate(&e0)); HIP_CHECK(hipEventCreate(&e1));
+    const size_t ARENA = (size_t) 768 << 20;
+    char * a4, * a6;
+    HIP_CHECK(hipMalloc(&a4, ARENA)); HIP_CHECK(hipMalloc(&a6, ARENA));
+    k_fill<<<4096, 256, 0, st>>>((uint32_t *) a4, ARENA / 4, 1u); k_fill<<<4096, 256, 0, st>>>((uint32_t *) a6, ARENA / 4, 2u);
+    k_fix_scales<<<4096, 256, 0, st>>>(a4, ARENA / 144, 144, 0, 2); k_fix_scales<<<4096, 256, 0, st>>>(a6, ARENA / 210, 210, 208, 1);
+    float * x, * nw, * resid, * out_a, * out_b;
+    HIP_CHECK(hipMalloc(&x, 12288 * 4)); HIP_CHECK(hipMalloc(&nw, 12288 * 4)); HIP_CHECK(hipMalloc(&resid, 160000 * 4));
+    HIP_CHECK(hipMalloc(&out_a, 160000 * 4)); HIP_CHECK(hipMalloc(&out_b, 160000 * 4));
+    k_fill_f32<<<64, 256, 0, st>>>(x, 12288, 11u, 1.0f); k_fill_f32<<<64, 256, 0, st>>>(nw, 12288, 12u, 1.0f); k_fill_f32<<<64, 256, 0, st>>>(resid, 160000, 13u, 1.0f);
+#ifdef MV2_TRACE
+    HIP_CHECK(hipMalloc(&trace_dev, 8192 * 8 * 8));
+    HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(mv2_trace_buf), &trace_dev, sizeof trace_dev));
+#endif
+    HIP_CHECK(hipStreamSynchronize(st));
+
+    const int Q4 = GGML_TYPE_Q4_K, Q6 = GGML_TYPE_Q6_K;
+    const shape shapes[] = {
+        { "gate/up pair Q4_K 12288x4096 (56.6 MB) + norm",   4096, 1, { 12288, 0, 0 }, { Q4, 0, 0 }, true,  true,  false },
+        { "qkv Q4_K 4096+1024+1024 x4096 (14.2 MB) + norm",  4096, 3, { 4096, 1024, 1024 }, { Q4, Q4, Q4 }, false, true, false },
+        { "wo Q4_K 4096x4096 (9.4 MB) + resid",              4096, 1, { 4096, 0, 0 }, { Q4, 0, 0 }, false, false, true },
+        { "down Q4_K 4096x12288 (28.3 MB) + resid",          12288, 1, { 4096, 0, 0 }, { Q4, 0, 0 }, false, false, true },
+        { "big Q4_K 151936x4096 (350 MB) + norm",            4096, 1, { 151936, 0, 0 }, { Q4, 0, 0 }, false, true, false },
+        { "down Q6_K 4096x12288 (41.3 MB) + resid",          12288, 1, { 4096, 0, 0 }, { Q6, 0, 0 }, false, false, true },
+        { "lm-head Q6_K 151936x4096 (510 MB) + norm",        4096, 1, { 151936, 0, 0 }, { Q6, 0, 0 }, false, true, false },
+    };
+    const int only = argc > 1 ? atoi(argv[1]) : -1;
+    int si = -1;
+    for (const shape & S : shapes) {
+        ++si;
+        if (only >= 0 && si != only) continue;
+        const int K = S.K, nb = K / 256;
+        size_t mbytes[3] = { 0, 0, 0 }, total = 0;
+        for (int i = 0; i < S.nmat; ++i) { mbytes[i] = (size_t) S.nrows[i] * nb * (S.types[i] == Q4 ? 144 : 210); total += mbytes[i]; }
+        if (S.pair) total *= 2;
+        const size_t stride = ((total + (1 << 20) - 1) >> 20) << 20;
+        int nrot = (int) std::max<size_t>(1, std::min<size_t>(ARENA / stride, 64));
+        const int N = total > (100u << 20) ? 8 : 48;
+        printf("\n== %s : %.1f MB per launch, %d rotating weight sets\n", S.name, total / 1e6, nrot);
+        auto wptr = [&](int s, int i, bool second) -> const char * {
+            size_t off = (size_t) (s % nrot) * stride;
+            for (int k = 0; k < i; ++k) off += mbytes[k];
+            if (second) off += mbytes[0];
+            const int t = S.types[i];
+            off = off / (t == Q4 ? 144 : 210) * (t == Q4 ? 144 : 210);
+            if (t == Q4) off = off / 2304 * 2304;                                  // 128-B aligned rows
+            else         off = off / 3360 * 3360;
+            return (t == Q4 ? a4 : a6) + off;
+        };
+        int ntot = 0; for (int i = 0; i < S.nmat; ++i) ntot += S.nrows[i];
+        // the product's launch (mmv1)
+        auto base = [&](int s, float * out) {
+            mv1_args v; v.nmat = S.nmat; v.K = K; v.W_up = S.pair ? wptr(s, 0, true) : nullptr;
+            v.x = x; v.norm_w = S.norm ? nw : nullptr; v.eps = 1e-6f;
+            size_t o = 0;
+            for (int i = 0; i < S.nmat; ++i) { v.m[i] = { wptr(s, i, false), (size_t) nb * (S.types[i] == Q4 ? 144 : 210), out + o, 0, S.resid ? resid + o : nullptr, 0, S.nrows[i], S.types[i] }; o += S.nrows[i]; }
+            mmv1(v, st);
+        };
+        auto mk = [&](int s, float * out, int nwaves) {
+            mv1_dev d; d.nmat = S.nmat; d.K = K; d.W1 = S.pair ? wptr(s, 0, true) : nullptr;
+            d.src = { x, S.norm ? nw : nullptr, 1e-6f, nullptr };
+            size_t o = 0; double acc_b = 0; int acc_w = 0; double tb = 0;
+            for (int i = 0; i < S.nmat; ++i) tb += (double) mbytes[i];
+            for (int i = 0; i < 3; ++i) {
+                if (i >= S.nmat) { d.m[i] = d.m[0]; d.m[i].wave_end = nwaves; continue; }
+                acc_b += (double) mbytes[i];
+                int end = i == S.nmat - 1 ? nwaves : (int) (nwaves * (acc_b / tb) + 0.5);
+                if (end <= acc_w) end = acc_w + 1;
+                d.m[i] = { wptr(s, i, false), (size_t) nb * (S.types[i] == Q4 ? 144 : 210), (char *) (out + o), S.resid ? (const char *) (resid + o) : nullptr, S.nrows[i], S.types[i], end };
+                acc_w = end; o += S.nrows[i];
+            }
+            return d;
+        };
+        std::vector<float> ha(ntot), hb(ntot);
+        auto check = [&](const std::function<void(int, float *)> & f) {
+            HIP_CHECK(hipMemsetAsync(out_a, 0, ntot * 4, st)); HIP_CHECK(hipMemsetAsync(out_b, 0xff, ntot * 4, st));
+            base(1, out_a); f(1, out_b);
+            HIP_CHECK(hipMemcpyAsync(ha.data(), out_a, ntot * 4, hipMemcpyDeviceToHost, st)); HIP_CHECK(hipMemcpyAsync(hb.data(), out_b, ntot * 4, hipMemcpyDeviceToHost, st));
+            HIP_CHECK(hipStreamSynchronize(st));
+            double num = 0, den = 0; int nbad = 0, nexact = 0;
+            for (int i = 0; i < ntot; ++i) { const double dlt = (double) ha[i] - hb[i]; num += dlt * dlt; den += (double) ha[i] * ha[i]; if (!(std::fabs(dlt) <= 1e-3 * (std::fabs(ha[i]) + 1e-2))) ++nbad; if (ha[i] == hb[i]) ++nexact; }
+            char b[96]; snprintf(b, sizeof b, "%s nmse %.1e (%d/%d identical)", nbad == 0 ? "ok" : "MISMATCH", num / (den + 1e-30), nexact, ntot); return std::string(b);
+        };
+        const double tb = time_graph(N, [&](int s) { base(s, out_a); });
+        printf("   %-58s %7.2f us  (%.2f TB/s)\n", "mmv1 (product launch)", tb, total / tb / 1e6);
+        if (S.types[0] != Q4 || (S.nmat > 1 && (S.types[1] != Q4 || S.types[2] != Q4))) continue;
+
+#define VAR2(NW, R, S_, P_, NT, WAVES)                                                                                            \
+        do {                                                                                                                   \
+            constexpr int XB4 = (16 + NW - 1) / NW, XB12 = (48 + NW - 1) / NW;                                                  \
+            const int waves = (WAVES);                                                                                         \
+            if (S.pair != (R == 2)) break;                                                                                     \
+            if (mv1_image_bytes(K) + (size_t) NW * S_ * R * 2304 + 256 > 160 * 1024) { printf("   (NW=%d R=%d S=%d: LDS)\n", NW, R, S_); break; }   \
+            auto f = [&](int s, float * out) {                                                                                 \
+                const mv1_dev d = mk(s, out, waves);                                                                           \
+                if (K == 4096) { if constexpr (XB4 <= 3) mv2_launch<NW, XB4, R, S_, P_, 1, (R == 2), NT>(d, waves / NW, st); }    \
+                else           { if constexpr (XB12 <= 3 && R == 1) mv2_launch<NW, XB12, R, S_, P_, 3, false, NT>(d, waves / NW, st); }  \
+            };                                                                                                                 \
+            if ((K == 4096 && XB4 > 3) || (K == 12288 && (XB12 > 3 || R != 1))) break;                                          \
+            const std::string c = check(f);                                                                                    \
+            const double t = time_graph(N, [&](int s) { f(s, out_b); });                                                        \
+            char nm[96]; snprintf(nm, sizeof nm, "mv2 NW=%d R=%d S=%d P=%d NT=%d waves=%d", NW, R, S_, P_, NT, waves);                   \
+            printf("   %-58s %7.2f us  (%.2f TB/s)  %s\n", nm, t, total / t / 1e6, c.c_str());                                  \
+            TRACE_REPORT(nm, waves, f);                                                                                        \
+        } while (0)
+#ifdef MV2_TRACE
+#define TRACE_REPORT(nm, waves, f) do { HIP_CHECK(hipMemsetAsync(trace_dev, 0, 8192 * 64, st)); for (int s_ = 0; s_ < 4; ++s_) f(s_ + 7, out_b); HIP_CHECK(hipStreamSynchronize(st)); trace_report(nm, waves); } while (0)
+#else
+#define TRACE_REPORT(nm, waves, f) do { } while (0)
+#endif
+        // pair (R == 2)
+        VAR2(16, 2, 2, 2, true, 4096);
+        VAR2(16, 2, 2, 1, true, 4096);
+        VAR2(16, 2, 2, 0, true, 4096);
+        VAR2(8, 2, 2, 1, true, 4096);
+        VAR2(8, 2, 3, 1, true, 2048);
+        VAR2(8, 2, 4, 1, true, 2048);
+        VAR2(4, 2, 3, 1, true, 3072);
+        // single (R == 1)
+        VAR2(16, 1, 2, 2, true, 4096);
+        VAR2(16, 1, 2, 1, true, 4096);
+        VAR2(16, 1, 2, 0, true, 4096);
+        VAR2(16, 1, 4, 1, true, 4096);
+        VAR2(16, 1, 4, 2, true, 4096);
+        VAR2(16, 1, 3, 1, true, 4096);
+        VAR2(8, 1, 6, 1, true, 2048);
+        VAR2(8, 1, 6, 2, true, 2048);
+        VAR2(8, 1, 3, 1, true, 4096);
+        VAR2(16, 1, 4, 1, true, 2048);
+    }
+    return 0;
+}
