@@ -73,6 +73,11 @@ struct mv1_args {
 };
 bool mmv1_ok(const mv1_args & a);                 // Q4_K / Q6_K (mmv1.hip) or Q8_0 (mmv1q.hip: K % 32 == 0, K <= 4096; img = Q8_0 image)
 void mmv1(const mv1_args & a, hipStream_t st);
+// the loader / consumer LDS-DMA engine (mmv2.hip): K = 4096 / 12288, Q4_K / Q6_K, 16-byte aligned rows; mmv1() routes to it when it applies
+// (MI355X_MV2=0 or mmv2_enable(false) keeps the register-load kernels)
+bool mmv2_ok(const mv1_args & a);
+void mmv2(const mv1_args & a, hipStream_t st);
+void mmv2_enable(bool on);
 bool mmv1q_ok(const mv1_args & a);
 void mmv1q(const mv1_args & a, hipStream_t st);
 

@@ -344,8 +344,13 @@ static void mv1_go(const mv1_dev & d, int tm, int grid, hipStream_t st) {
     else { fprintf(stderr, "[mi355x] mmv1: a gate / up pair of mixed types\n"); abort(); }
 }
 
+static int g_mv2 = -1;
+void mmv2_enable(bool on) { g_mv2 = on ? 1 : 0; }
+
 void mmv1(const mv1_args & a, hipStream_t st) {
     if (a.nmat >= 1 && (a.m[0].type == GGML_TYPE_Q8_0 || a.m[0].type == GGML_TYPE_F16)) { mmv1q(a, st); return; }
+    if (g_mv2 < 0) { const char * e = getenv("MI355X_MV2"); g_mv2 = e ? (atoi(e) != 0) : 1; }
+    if (g_mv2 && mmv2_ok(a)) { mmv2(a, st); return; }
     if (!mmv1_ok(a)) { fprintf(stderr, "[mi355x] mmv1: unsupported arguments (K=%lld)\n", (long long) a.K); abort(); }
     const bool pair = a.W_up != nullptr;
     const int nw_wg = pair ? 8 : 16;

@@ -48,6 +48,7 @@ __device__ unsigned long long * mv2_trace_buf = nullptr;
 template <int N> static __device__ __forceinline__ void mv2_vmcnt() { static_assert(N >= 0 && N < 64, "vmcnt is 6 bits"); asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
 
 #define MV2_WAVES 16
+#define MV2_ROW_WAVES 4          // consumers that fetch the activation row before they consume
 
 // kernel arguments: everything a wave needs is a load and an integer multiply-add away (no division, no search): workgroups [wg0, next wg0) stream
 // matrix m; workgroup lw of them owns rows lw * q + min(lw, r) .. (q + 1 rows in the first r workgroups)
@@ -164,7 +165,7 @@ template <int VM, int K_> struct mv2_drain {            // at most K_ of my n st
     }
 };
 template <int PIECE, int R, int NIT, int C, bool NT>
-static __device__ __forceinline__ void mv2_loader(const mv1_rsrc rs0, const mv1_rsrc rs1, uint32_t rs32, int G0, int T, uint32_t ring, mv2_flags * F) {
+static __device__ __forceinline__ void mv2_loader(const mv1_rsrc rs0, const mv1_rsrc rs1, uint32_t rs32, int G0, int T, uint32_t ring, mv2_flags * F MV2_TR_PARAM) {
     typedef mv2_geo<PIECE, R, NIT> geo;
     constexpr int VM = geo::VM, D = geo::D, B = geo::B, SLOTB = geo::SLOTB, NS = geo::NS;
     const int lane = threadIdx.x & 63;
@@ -185,6 +186,14 @@ static __device__ __forceinline__ void mv2_loader(const mv1_rsrc rs0, const mv1_
     // ring space: every task below free_tasks has been read by its consumer.  Consumer c reads its tasks c, c + C, ... in order, so the first task
     // not yet read is min over c of (c + consumed[c] * C): ONE LDS read + a 16-lane minimum, and only when the cached bound no longer covers the round
     int n = 0, free_tasks = 0;                          // steps issued; tasks known consumed
+#ifndef MV2_PRE
+#define MV2_PRE 1
+#endif
+    // the first step goes out at once -- it takes the loader's cold-start latency (address translation, first DRAM page) in parallel with the row
+    // waves' -- the rest of the stream behind the row requests
+    for (; n < MV2_PRE && n < T; ++n) issue();
+    mv2_await(MV2_FLAG(F->rows_issued), MV2_ROW_WAVES);
+    MV2_STAMP(2);
     while (n < T) {
         const int nb_ = T - n < B ? T - n : B;
         const int last = n + nb_ - 1;                   // the round's last step overwrites the slot of step last - NS = task (last - NS) / NIT
@@ -215,7 +224,6 @@ static __device__ __forceinline__ void mv2_loader(const mv1_rsrc rs0, const mv1_
 // The activation row (f32), the norm weights and the residual of the workgroup's rows go into the staging area by LDS-DMA, requested before the
 // loader's first weight request (rows_issued), so they are at the head of the CU's memory queue; nothing else of this wave is in flight, so
 // vmcnt(0) is exactly "the row is here".
-#define MV2_ROW_WAVES 4
 static __device__ __forceinline__ void mv2_row_loader(const mv1_src src, int K, int rw, const char * resid, int G0, int ntask, uint32_t stg, uint32_t rstg, mv2_flags * F) {
     const int lane = threadIdx.x & 63;
     const uint32_t v16 = 16u * (uint32_t) lane, v4 = 4u * (uint32_t) lane;
@@ -283,8 +291,7 @@ static __device__ __forceinline__ void mv2_q8k_rows(const f32x4 (&y)[4], int lan
     if (i == 0) *((float *) (im + mv1_img_d(nb)) + b) = zero ? 0.0f : 1.0f / iscale;
 }
 
-#define MV2_PRO_WAVES 4
-// prologue wave mw of 4: image blocks (4 p + mw) * 4 + row, p = 0 .. NIT - 1
+// prologue wave mw of 4 NIT (consumers 0 .. 4 NIT - 1: NIT per SIMD): image blocks 4 mw + row
 template <int NIT>
 static __device__ __forceinline__ void mv2_prologue(const mv1_src s, int K, int mw, char * im, const char * stg, double * red, mv2_flags * F MV2_TR_PARAM) {
     const int lane = threadIdx.x & 63, row = lane >> 4, i = lane & 15, nb = K >> 8;
@@ -292,7 +299,7 @@ static __device__ __forceinline__ void mv2_prologue(const mv1_src s, int K, int 
     MV2_STAMP(2);
     float scale = 1.0f;
     f32x4 x[4];
-    if (s.nw) {                                         // RMS norm (K = 4096: one pass per wave): sum of squares in double like the reference
+    if (s.nw) {                                         // RMS norm: sum of squares in double like the reference
         const char * xp = stg + (mw * 4 + row) * 1024 + 16 * i;
 #pragma unroll
         for (int m = 0; m < 4; ++m) x[m] = *(const f32x4 *) (xp + 256 * m);
@@ -308,10 +315,10 @@ static __device__ __forceinline__ void mv2_prologue(const mv1_src s, int K, int 
         if (lane == 0) prev = __hip_atomic_fetch_add(MV2_FLAG(F->sum_cnt), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         prev = __builtin_amdgcn_readfirstlane(prev);
         asm volatile("" ::: "memory");
-        if (prev == (uint32_t) (MV2_PRO_WAVES - 1)) {   // last to arrive: every partial sum is in LDS (the DS operations of a wave execute in order)
+        if (prev == (uint32_t) (4 * NIT - 1)) {         // last to arrive: every partial sum is in LDS (the DS operations of a wave execute in order)
             double tot = 0.0;
 #pragma unroll
-            for (int w = 0; w < MV2_PRO_WAVES; ++w) tot += *(const volatile double *) &red[w];
+            for (int w = 0; w < 4 * NIT; ++w) tot += *(const volatile double *) &red[w];
             const float mean = (float) ((K & (K - 1)) == 0 ? tot * (1.0 / (double) K) : tot / (double) K);     // (a power of two: the same double)
             const float sc = 1.0f / sqrtf(mean + s.eps);
             if (lane == 0) *(volatile __attribute__((address_space(3))) float *) &F->scale = sc;
@@ -323,9 +330,8 @@ static __device__ __forceinline__ void mv2_prologue(const mv1_src s, int K, int 
         }
     }
     MV2_STAMP(3);
-#pragma unroll
-    for (int p = 0; p < NIT; ++p) {
-        const int b = (p * 4 + mw) * 4 + row;
+    {
+        const int b = mw * 4 + row;
         f32x4 y[4];
         if (s.nw) {
             const char * wp = stg + K * 4 + b * 1024 + 16 * i;
@@ -547,21 +553,17 @@ __global__ void __launch_bounds__(64 * MV2_WAVES) k_mv2(const mv2_dev a) {
     MV2_STAMP(1);
     if (wiw == 0) {
         const mv1_rsrc rs0 = mv1_make_rsrc(M.W, (size_t) M.nrows * M.w_rs), rs1 = mv1_make_rsrc(PAIR ? a.W1 : M.W, (size_t) M.nrows * M.w_rs);
-#ifndef MV2_NOWAITROWS
-        mv2_await(MV2_FLAG(F.rows_issued), MV2_ROW_WAVES);
-#endif
-        MV2_STAMP(2);
-        if (q4) mv2_loader<2304, PAIR ? 2 : 1, NIT, C, NT>(rs0, rs1, (uint32_t) M.w_rs, G0, ntask * NIT, mv2_lds_addr(ringp), &F);
-        else if constexpr ((TM & 2) != 0 && !PAIR) mv2_loader<3360, 1, NIT, C, NT>(rs0, rs1, (uint32_t) M.w_rs, G0, ntask * NIT, mv2_lds_addr(ringp), &F);
+        if (q4) mv2_loader<2304, PAIR ? 2 : 1, NIT, C, NT>(rs0, rs1, (uint32_t) M.w_rs, G0, ntask * NIT, mv2_lds_addr(ringp), &F MV2_TR_ARG);
+        else if constexpr ((TM & 2) != 0 && !PAIR) mv2_loader<3360, 1, NIT, C, NT>(rs0, rs1, (uint32_t) M.w_rs, G0, ntask * NIT, mv2_lds_addr(ringp), &F MV2_TR_ARG);
         MV2_STAMP(7);
     } else {
         const int c = wiw - 1, lane = threadIdx.x & 63;
         const char * resid_p = PAIR ? nullptr : M.resid;
-        // roles before the stream is consumed: consumers 7 .. 10 fetch the row, consumers 3 .. 6 (one per SIMD) build the image, the rest wait
-        if (c >= 7 && c < 7 + MV2_ROW_WAVES) mv2_row_loader(a.src, K, c - 7, resid_p, G0, ntask, mv2_lds_addr(stg), mv2_lds_addr(rstg), &F);
-        uint32_t img_need = MV2_PRO_WAVES;
+        // roles before the stream is consumed: the last 4 consumers fetch the row, consumers 0 .. 4 NIT - 1 (NIT per SIMD) build the image, the rest wait
+        if (c >= C - MV2_ROW_WAVES) mv2_row_loader(a.src, K, c - (C - MV2_ROW_WAVES), resid_p, G0, ntask, mv2_lds_addr(stg), mv2_lds_addr(rstg), &F);
+        uint32_t img_need = 4 * NIT;
         if (a.src.img) { mv2_image_copy<C>(a.src.img, K, c, im, &F); img_need = C; }
-        else if (c >= 3 && c < 3 + MV2_PRO_WAVES) mv2_prologue<NIT>(a.src, K, c - 3, im, stg, red, &F MV2_TR_ARG);
+        else if (c < 4 * NIT) mv2_prologue<NIT>(a.src, K, c, im, stg, red, &F MV2_TR_ARG);
         { uint32_t spins = 0; while (mv2_peek(MV2_FLAG(F.img_cnt)) < img_need) { __builtin_amdgcn_s_sleep(4); if (++spins > MV2_SPIN_MAX) __builtin_trap(); } asm volatile("" ::: "memory"); }
         // the residual of this consumer's tasks, one per lane (task k of the consumer is row G0 + c + k C), from the staging area: the consumers
         // issue NO vector-memory loads -- one would wait for a place in the CU's memory queue behind the loader's stream
