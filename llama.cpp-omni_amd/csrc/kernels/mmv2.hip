@@ -48,7 +48,9 @@ __device__ unsigned long long * mv2_trace_buf = nullptr;
 template <int N> static __device__ __forceinline__ void mv2_vmcnt() { static_assert(N >= 0 && N < 64, "vmcnt is 6 bits"); asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
 
 #define MV2_WAVES 16
+#ifndef MV2_ROW_WAVES
 #define MV2_ROW_WAVES 4          // consumers that fetch the activation row before they consume
+#endif
 
 // kernel arguments: everything a wave needs is a load and an integer multiply-add away (no division, no search): workgroups [wg0, next wg0) stream
 // matrix m; workgroup lw of them owns rows lw * q + min(lw, r) .. (q + 1 rows in the first r workgroups)
@@ -187,7 +189,7 @@ static __device__ __forceinline__ void mv2_loader(const mv1_rsrc rs0, const mv1_
     // not yet read is min over c of (c + consumed[c] * C): ONE LDS read + a 16-lane minimum, and only when the cached bound no longer covers the round
     int n = 0, free_tasks = 0;                          // steps issued; tasks known consumed
 #ifndef MV2_PRE
-#define MV2_PRE 1
+#define MV2_PRE 0
 #endif
     // the first step goes out at once -- it takes the loader's cold-start latency (address translation, first DRAM page) in parallel with the row
     // waves' -- the rest of the stream behind the row requests
@@ -224,14 +226,19 @@ static __device__ __forceinline__ void mv2_loader(const mv1_rsrc rs0, const mv1_
 // The activation row (f32), the norm weights and the residual of the workgroup's rows go into the staging area by LDS-DMA, requested before the
 // loader's first weight request (rows_issued), so they are at the head of the CU's memory queue; nothing else of this wave is in flight, so
 // vmcnt(0) is exactly "the row is here".
-static __device__ __forceinline__ void mv2_row_loader(const mv1_src src, int K, int rw, const char * resid, int G0, int ntask, uint32_t stg, uint32_t rstg, mv2_flags * F) {
+static __device__ __forceinline__ void mv2_row_loader(const mv1_src src, int K, int rw, const char * resid, int G0, int ntask, uint32_t stg, uint32_t rstg, mv2_flags * F MV2_TR_PARAM) {
     const int lane = threadIdx.x & 63;
     const uint32_t v16 = 16u * (uint32_t) lane, v4 = 4u * (uint32_t) lane;
+#ifdef MV2_ROWSTART
+    mv2_arrive(MV2_FLAG(F->rows_issued));
+#endif
     if (!src.img) {                                     // instruction b of the row (1 KiB each; the norm weights follow the row) belongs to row wave b % MV2_ROW_WAVES
         const int nb = K >> 8, ni = src.nw ? 2 * nb : nb;
         const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void *) src.x, (short) 0, K * 4, 0x00020000);
         const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void *) src.nw, (short) 0, src.nw ? K * 4 : 0, 0x00020000);
+        MV2_STAMP(2);
         for (int b = rw; b < ni; b += MV2_ROW_WAVES) {
+            if (b == rw + MV2_ROW_WAVES) MV2_STAMP(3);
             const bool isw = b >= nb;
             const uint32_t off = (uint32_t) (isw ? b - nb : b) * 1024u;
             asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" :: "s"(__builtin_amdgcn_readfirstlane(stg + (uint32_t) b * 1024u)), "v"(v16), "s"(isw ? wr : xr), "s"(__builtin_amdgcn_readfirstlane(off)) : "memory", "m0");
@@ -242,7 +249,10 @@ static __device__ __forceinline__ void mv2_row_loader(const mv1_src src, int K, 
         for (int b = 0; b * 64 < ntask; ++b)
             asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dword %1, %2, %3 offen lds" :: "s"(__builtin_amdgcn_readfirstlane(rstg + (uint32_t) b * 256u)), "v"(v4), "s"(rr), "s"(__builtin_amdgcn_readfirstlane((uint32_t) b * 256u)) : "memory", "m0");
     }
+    MV2_STAMP(5);
+#ifndef MV2_ROWSTART
     mv2_arrive(MV2_FLAG(F->rows_issued));
+#endif
     mv2_vmcnt<0>();
     mv2_arrive(MV2_FLAG(F->rows_landed));
 }
@@ -535,6 +545,13 @@ __global__ void __launch_bounds__(64 * MV2_WAVES) k_mv2(const mv2_dev a) {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     const int wiw = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wg  = blockIdx.x;
+    // The scalar unit is one per CU: sixteen waves running their set-up at once take ~0.5 us of it.  The loader and the row waves are on the
+    // launch's critical path and go first (and at raised priority); the waves that only build the image or only consume stay out of the way.
+#ifndef MV2_NO_STAGGER
+    if (wiw == 0 || wiw >= MV2_WAVES - MV2_ROW_WAVES) __builtin_amdgcn_s_setprio(3);
+    else if (wiw <= 4 * NIT) __builtin_amdgcn_s_sleep(12);
+    else { __builtin_amdgcn_s_sleep(40); }
+#endif
     int mi_ = 0;
     if (!PAIR) {
         if (a.nmat > 1 && wg >= a.m[1].wg0) mi_ = 1;
@@ -560,7 +577,7 @@ __global__ void __launch_bounds__(64 * MV2_WAVES) k_mv2(const mv2_dev a) {
         const int c = wiw - 1, lane = threadIdx.x & 63;
         const char * resid_p = PAIR ? nullptr : M.resid;
         // roles before the stream is consumed: the last 4 consumers fetch the row, consumers 0 .. 4 NIT - 1 (NIT per SIMD) build the image, the rest wait
-        if (c >= C - MV2_ROW_WAVES) mv2_row_loader(a.src, K, c - (C - MV2_ROW_WAVES), resid_p, G0, ntask, mv2_lds_addr(stg), mv2_lds_addr(rstg), &F);
+        if (c >= C - MV2_ROW_WAVES) mv2_row_loader(a.src, K, c - (C - MV2_ROW_WAVES), resid_p, G0, ntask, mv2_lds_addr(stg), mv2_lds_addr(rstg), &F MV2_TR_ARG);
         uint32_t img_need = 4 * NIT;
         if (a.src.img) { mv2_image_copy<C>(a.src.img, K, c, im, &F); img_need = C; }
         else if (c < 4 * NIT) mv2_prologue<NIT>(a.src, K, c, im, stg, red, &F MV2_TR_ARG);

@@ -64,17 +64,18 @@ static void trace_report(const char * nm, int nwg, int nl) {
     unsigned long long t0 = ~0ull;
     for (int w = 0; w < nwaves; ++w) if (h[(size_t) w * 8]) t0 = std::min(t0, h[(size_t) w * 8]);
     static const char * labl[8] = { "start", "setup done", "first issue", "rows landed", "-", "-", "-", "end" };
+    static const char * labr[8] = { "start", "setup done", "before 1st DMA", "1st DMA issued", "(consume starts)", "all DMA issued", "-", "end" };
     static const char * labc[8] = { "start", "setup done", "rows seen", "scale known", "image done", "my blocks done", "-", "end" };
     { printf("      wave -> SIMD of workgroup 0 (HW_ID bits 4-5):"); for (int w = 0; w < 16; ++w) printf(" %d", (int) ((h[(size_t) w * 8 + 6] >> 4) & 3)); printf("   CU ids of WG 0..3: %d %d %d %d\n", (int) ((h[6] >> 8) & 15), (int) ((h[16 * 8 + 6] >> 8) & 15), (int) ((h[32 * 8 + 6] >> 8) & 15), (int) ((h[48 * 8 + 6] >> 8) & 15)); }
     printf("      time line of %s (us after the first wave's start; min / median / max)\n", nm);
-    for (int role = 0; role < 2; ++role) for (int i = 0; i < 8; ++i) {
-        const char * const * lab = role == 0 ? labl : labc;
+    for (int role = 0; role < 3; ++role) for (int i = 0; i < 8; ++i) {
+        const char * const * lab = role == 0 ? labl : role == 1 ? labc : labr;
         if (lab[i][0] == '-') continue;
         std::vector<double> v;
-        for (int w = 0; w < nwaves; ++w) if (((w % 16) < nl) == (role == 0) && h[(size_t) w * 8 + i]) v.push_back((double) (h[(size_t) w * 8 + i] - t0) * 0.01);
+        for (int w = 0; w < nwaves; ++w) if ((role == 0 ? (w % 16) < nl : role == 1 ? ((w % 16) >= nl && (w % 16) < 12) : (w % 16) >= 12) && h[(size_t) w * 8 + i]) v.push_back((double) (h[(size_t) w * 8 + i] - t0) * 0.01);
         if (v.empty()) continue;
         std::sort(v.begin(), v.end());
-        printf("        %-9s %-20s %6.2f / %6.2f / %6.2f\n", role == 0 ? "loader" : "consumer", lab[i], v[0], v[v.size() / 2], v[v.size() - 1]);
+        printf("        %-9s %-20s %6.2f / %6.2f / %6.2f\n", role == 0 ? "loader" : role == 1 ? "consumer" : "row wave", lab[i], v[0], v[v.size() / 2], v[v.size() - 1]);
     }
 }
 #endif
@@ -97,6 +98,7 @@ int main(int argc, char ** argv) {
     HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(mv2_trace_buf), &trace_dev, sizeof trace_dev));
 #endif
     HIP_CHECK(hipStreamSynchronize(st));
+    mmv2_enable(false);                 // the baseline is the register-load family
 
     const int Q4 = GGML_TYPE_Q4_K, Q6 = GGML_TYPE_Q6_K;
     const shape shapes[] = {
