@@ -153,8 +153,9 @@ def cpu_baseline(pkg, cfg, types, n_kv, seconds_budget=24.0):
 
 
 def kernel_roofline(pkg, be, model, reps=5):
-    """Live roofline of the dominant kernel, mi::k_mv1<8,2,2,1,1,true,false,false> (mmv1.hip: RMS norm + Q8_K image in the prologue, ffn_gate +
-    ffn_up + SWIGLU: 2 x 12288 x 4096 Q4_K rows = 56.6 MB per launch, 36 launches and 2.04 of the 4.67 GB of every decoded token).  One cgraph holding the 36 launches of one
+    """Live roofline of the dominant kernel, mi::k_mv2<1,1,true,true> (mmv2.hip, the LDS-DMA loader / consumer engine: RMS norm + Q8_K image in
+    the prologue, ffn_gate + ffn_up + SWIGLU: 2 x 12288 x 4096 Q4_K rows = 56.6 MB per launch, 36 launches and 2.04 of the 4.67 GB of every decoded token;
+    MI355X_MV2=0 runs the register-load form mi::k_mv1<8,2,2,1,1,true,...> in its place).  One cgraph holding the 36 launches of one
     decode step -- the real layers' weights, 2 GB, 8x the Infinity Cache -- is replayed as a hipGraph and bracketed by two HIP
     events on the backend's stream; avg launch = elapsed / 36 (so it includes the launch-to-launch boundary, like the
     per-dispatch duration rocprofv3 --kernel-trace reports; profiles/).  achieved = algorithmic weight bytes / time."""
@@ -194,19 +195,21 @@ def kernel_roofline(pkg, be, model, reps=5):
     # --pmc FETCH_SIZE pass of this same command (tools/profile_round.sh -> profiles/<round>_pmc_fetch_size.json, corrected x2 per
     # MI355X_MICROARCH.md); it is used only when that file names THIS kernel, and the file / kernel symbol are printed beside it
     traffic, traffic_src = None, None
+    mv2 = os.environ.get("MI355X_MV2", "1") != "0"
     try:
         cands = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc_fetch_size.json"))
         for fn in reversed(cands):
             pmc = json.load(open(os.path.join(ROOT, "profiles", fn)))
             for k, v in pmc["kernels"].items():
-                if "k_mv1<8, 2, 2, 1, 1, true" in k:
+                if ("k_mv2<1, 1, true" in k) if mv2 else ("k_mv1<8, 2, 2, 1, 1, true" in k):
                     traffic = v["hbm_bytes_per_dispatch_corrected"]
                     traffic_src = {"file": "profiles/" + fn, "kernel": k[:80], "commit": pmc.get("commit")}
             if traffic is not None:
                 break
     except Exception:
         pass
-    return {"bound": "hbm", "kernel": "mi::k_mv1<8,2,2,1,1,true,false,false> (RMS norm + Q8_K image prologue, Q4_K ffn_gate+ffn_up mat-vec, SWIGLU epilogue)",
+    kname = "mi::k_mv2<1,1,true,true> (LDS-DMA engine: " if mv2 else "mi::k_mv1<8,2,2,1,1,true,false,false> ("
+    return {"bound": "hbm", "kernel": kname + "RMS norm + Q8_K image prologue, Q4_K ffn_gate+ffn_up mat-vec, SWIGLU epilogue)",
             "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
             "bytes_per_launch": nbytes // launches, "avg_launch_us": round(us / launches, 3), "launches": launches,
             "method": "hipGraph replay of the step's 36 launches of this kernel, two HIP events on the backend stream, best of 5"}

@@ -485,7 +485,10 @@ static __device__ __forceinline__ void mv2_consume_q6k(const char * im, const ch
         A[it].bq = *(const u32x2 *) (im + mv1_img_b16(nb) + (it * 16 + blk) * 32 + (8 * n + 4 * hf) * 2);
         A[it].yd = *(const float *) (im + mv1_img_d(nb) + (it * 16 + blk) * 4);
     }
-    const char * wl = ringp + blk * 210;
+    const char * wl = ringp + blk * 210;             // (+ slot * 3360: the slot is 16-byte aligned, so the alignment of every piece is a lane constant)
+    const int qraw = blk * 210 + 64 * n + 16 * hf;
+    const int qoff = (qraw & ~3) - blk * 210, hoff = 128 + 32 * n - 64 * n, soff = 192 + 8 * n - 64 * n - 16 * hf;
+    const uint32_t sh = (qraw & 2) ? 16u : 0u;
     uint32_t seen = 0;
     mv2_out o = { 0.0f, 0, 0 };
     int k = 0;
@@ -496,9 +499,20 @@ static __device__ __forceinline__ void mv2_consume_q6k(const char * im, const ch
             const int t = __builtin_amdgcn_readfirstlane(j * NIT + it);
             mv2_wait_step(t, seen, F);
             const char * p = wl + (t % NS) * SLOTB;
-            const u32x4 qla = *(const mv2_u32x4_a2 *) (p + 64 * n + 16 * hf), qlb = *(const mv2_u32x4_a2 *) (p + 64 * n + 16 * hf + 32);
-            const u32x4 qh  = *(const mv2_u32x4_a2 *) (p + 128 + 32 * n + 16 * hf);
-            const u32x2 sc  = *(const mv2_u32x2_a2 *) (p + 192 + 8 * n);                   // scales[8n .. 8n+8)
+            // a misaligned DS read of any width takes the lane-serial path (~256 cycles, tools/lds_align.hip): every piece is fetched as aligned
+            // dwords (5 for 16 bytes) and funnel-shifted by the lane's half-word phase
+            u32x4 qla, qlb, qh; u32x2 sc;
+            {
+                const __attribute__((address_space(3))) char * pa = (const __attribute__((address_space(3))) char *) (p + qoff);      // (qoff: the lane's first piece rounded down to a dword, relative to its block)
+                uint32_t d0[5], d1[5], d2[5], d3[3];
+#pragma unroll
+                for (int e = 0; e < 5; ++e) { d0[e] = *(const volatile mv2_lds_u32 *) (pa + 4 * e); d1[e] = *(const volatile mv2_lds_u32 *) (pa + 32 + 4 * e); d2[e] = *(const volatile mv2_lds_u32 *) (pa + hoff + 4 * e); }
+#pragma unroll
+                for (int e = 0; e < 3; ++e) d3[e] = *(const volatile mv2_lds_u32 *) (pa + soff + 4 * e);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { qla[e] = __builtin_amdgcn_alignbit(d0[e + 1], d0[e], sh); qlb[e] = __builtin_amdgcn_alignbit(d1[e + 1], d1[e], sh); qh[e] = __builtin_amdgcn_alignbit(d2[e + 1], d2[e], sh); }
+                sc[0] = __builtin_amdgcn_alignbit(d3[1], d3[0], sh); sc[1] = __builtin_amdgcn_alignbit(d3[2], d3[1], sh);
+            }
             const uint16_t dw = *(const uint16_t *) (p + 208);
             if (it == NIT - 1) { MV2_LGKM0(); mv2_poke(MV2_FLAG(F->consumed[c]), (uint32_t) (k + 1)); }
             const uint32_t scw = __builtin_amdgcn_perm(sc[1], sc[0], sel);                  // scales[8n + hf + 2m], m = 0..3
