@@ -237,6 +237,7 @@ static const ggml_backend_i k_backend_iface = {
     be_graph_compute, be_event_record, be_event_wait, be_graph_optimize,
 };
 static bool backend_is_ours(ggml_backend_t b) { return b && b->iface.graph_compute == be_graph_compute; }
+bool backend_is_mi355x(const struct ggml_backend * b) { return backend_is_ours((ggml_backend_t) b); }
 
 // ---------------------------------------------------------------------------------------------- device
 static const char * dev_name(ggml_backend_dev_t d) { return ((device_ctx *) d->context)->name.c_str(); }

@@ -118,6 +118,7 @@ static void prof_drain(backend_ctx * c) {
 // ------------------------------------------------------------------------------------------------ supports_op
 static bool mm_uses_mmq(const ggml_tensor * n);
 static bool mm_uses_gemm(const ggml_tensor * n);
+static bool mm_takes_gemm_any(const ggml_tensor * n);
 bool supports_op(const ggml_tensor * op) {
     const ggml_tensor * s0 = op->src[0];
     const ggml_tensor * s1 = op->src[1];
@@ -142,7 +143,7 @@ bool supports_op(const ggml_tensor * op) {
             }
             // every mat-vec path (up to 8 columns per launch; F32 weights at any width) stages one activation column in LDS: a column
             // beyond 152 KiB has no kernel (e.g. attention without FLASH_ATTN_EXT past ~77k cache rows: K = n_kv) -> leave it to the CPU
-            if (!mm_uses_gemm(op) && !mm_uses_mmq(op)) {
+            if (!mm_uses_gemm(op) && !mm_uses_mmq(op) && !mm_takes_gemm_any(op)) {       // (gemm_any stages nothing in LDS)
                 const size_t col = k == ACT_F32 ? (size_t) s0->ne[0] * 4 : act_image_bytes(is_image_quant(s0->type) ? ACT_F16 : k, s0->ne[0]);
                 if (col > (size_t) 152 * 1024) return false;
             }
@@ -1951,8 +1952,12 @@ static void compute_node(exec_state & s, int i) {
             else {
                 // CONT(PERMUTE(kqv)) of a prefill ubatch whose only readers are MFMA GEMMs (wo): gather straight into the f16 activation image
                 const ggml_tensor * xg = nullptr;
+                // The f32 tensor itself is then never written, so the path is taken only when the one reader is the NEXT launching node (the rule of
+                // SOFT_MAX / UNARY / exec_norm): anything in between that prepares another activation image would evict this one, and the reader
+                // would convert from n->data.
+                const int cu = s.c->opt_fusion && !is_out(s, n) ? sole_user(s, n) : -1;
                 if (n->op == GGML_OP_CONT && src->type == GGML_TYPE_F32 && n->type == GGML_TYPE_F32 && n->ne[2] == 1 && n->ne[3] == 1 && n->nb[1] == (size_t) n->ne[0] * 4 &&
-                    n_users(s, n) == 1 && gemm_only_consumers(s, n, n->ne[0], n->ne[1], &xg)) {
+                    cu > i && next_real_node(s, i) == cu && n_users(s, n) == 1 && gemm_only_consumers(s, n, n->ne[0], n->ne[1], &xg)) {
                     tdesc d; d.p = s.c->act_scratch; d.ne[0] = n->ne[0]; d.ne[1] = n->ne[1]; d.ne[2] = 1; d.ne[3] = 1;
                     const size_t img = act_image_bytes(ACT_F16, n->ne[0]);
                     d.nb[0] = 2; d.nb[1] = img; d.nb[2] = img * (size_t) n->ne[1]; d.nb[3] = d.nb[2];
@@ -2137,7 +2142,9 @@ static inline uint64_t mix(uint64_t h, uint64_t v) { h ^= v + 0x9e3779b97f4a7c15
 // Runs on the host once per graph_compute, in front of the launch (the device idles meanwhile: ~1200 nodes per decode step), so the
 // ~100 k word mixes are spread over four independent accumulators -- the serial xor-shift-add chain of one accumulator was ~50 us per
 // token (tools/host_overhead.py), a quarter of that with four.
+bool g_fp_collide = false;                       // test hook (set_option "fp_collide"): every graph gets the same fingerprint
 static uint64_t fingerprint(const ggml_cgraph * g) {
+    if (g_fp_collide) return 42;
     uint64_t h[4] = { 0xcbf29ce484222325ull, 0x84222325cbf29ce4ull, 0x9e3779b97f4a7c15ull, 0xc2b2ae3d27d4eb4full };
     h[0] = mix(h[0], (uint64_t) g->n_nodes);
     for (int i = 0; i < g->n_nodes; ++i) {
@@ -2156,17 +2163,76 @@ static uint64_t fingerprint(const ggml_cgraph * g) {
     return mix(mix(mix(h[0], h[1]), h[2]), h[3]);
 }
 
+// ------------------------------------------------------------------------------------------------ capture records
+// whole-graph use count of t (ggml_hash_find, ggml-impl.h:257-270: pointer >> 4, linear probing), -1 when the graph carries none
+static inline int whole_use_count(const ggml_cgraph * g, const ggml_tensor * t) {
+    const ggml_hash_set & hs = g->visited_hash_set;
+    const size_t h = ((size_t) (uintptr_t) t >> 4) % hs.size;
+    size_t i = h;
+    while ((hs.used[i >> 5] >> (i & 31)) & 1u) {
+        if (hs.keys[i] == t) return g->use_counts[i];
+        i = (i + 1) % hs.size;
+        if (i == h) break;
+    }
+    return -1;
+}
+static inline bool graph_has_use_counts(const ggml_cgraph * g) { return g->use_counts && g->visited_hash_set.size > 0 && g->visited_hash_set.keys && g->visited_hash_set.used; }
+static void make_recs(backend_ctx * c, const ggml_cgraph * g, graph_exec & e) {
+    e.recs.assign((size_t) g->n_nodes, node_rec());
+    std::unordered_map<const ggml_tensor *, int> direct;
+    direct.reserve((size_t) g->n_nodes * 2);
+    for (int i = 0; i < g->n_nodes; ++i)
+        for (int k = 0; k < GGML_MAX_SRC; ++k) if (g->nodes[i]->src[k]) ++direct[g->nodes[i]->src[k]];
+    e.with_ext = c->opt_fusion && graph_has_use_counts(g);          // (the condition under which run_nodes derives `external`)
+    for (int i = 0; i < g->n_nodes; ++i) {
+        const ggml_tensor * n = g->nodes[i];
+        node_rec & r = e.recs[(size_t) i];
+        memset(&r, 0, sizeof r);
+        r.data = n->data; r.op = (uint32_t) n->op; r.type = (uint32_t) n->type; r.flags = n->flags;
+        for (int d = 0; d < 4; ++d) { r.ne[d] = n->ne[d]; r.nb[d] = n->nb[d]; }
+        memcpy(r.op_params, n->op_params, sizeof r.op_params);
+        for (int k = 0; k < GGML_MAX_SRC; ++k) r.src[k] = n->src[k] ? n->src[k]->data : nullptr;
+        auto it = direct.find(n);
+        r.direct = it == direct.end() ? 0 : it->second;
+        r.ext = e.with_ext ? (whole_use_count(g, n) > r.direct ? 1 : 0) : 0;
+    }
+}
+// does the submitted cgraph equal what capture e was built from?  (the hot path of a decode step: ~1200 nodes, a handful of compares each)
+static bool recs_match(backend_ctx * c, const ggml_cgraph * g, const graph_exec & e) {
+    if ((size_t) g->n_nodes != e.recs.size()) return false;
+    if (e.with_ext != (c->opt_fusion && graph_has_use_counts(g))) return false;
+    for (int i = 0; i < g->n_nodes; ++i) {
+        const ggml_tensor * n = g->nodes[i];
+        const node_rec & r = e.recs[(size_t) i];
+        if (r.data != n->data || r.op != (uint32_t) n->op || r.type != (uint32_t) n->type || r.flags != n->flags) return false;
+        if (memcmp(r.ne, n->ne, sizeof r.ne) != 0 || memcmp(r.nb, n->nb, sizeof r.nb) != 0 || memcmp(r.op_params, n->op_params, sizeof r.op_params) != 0) return false;
+        for (int k = 0; k < GGML_MAX_SRC; ++k) if (r.src[k] != (n->src[k] ? n->src[k]->data : nullptr)) return false;
+    }
+    // (the source SHAPES need no compare of their own: a source is a node of this graph -- compared above -- or a leaf, whose shape cannot change
+    //  under an unchanged node that reads it; the reference compares the same set of fields)
+    if (e.with_ext)
+        for (int i = 0; i < g->n_nodes; ++i) {
+            const node_rec & r = e.recs[(size_t) i];
+            if ((whole_use_count(g, g->nodes[i]) > r.direct ? 1 : 0) != r.ext) return false;
+        }
+    return true;
+}
+
 // ------------------------------------------------------------------------------------------------ graph_compute
 enum ggml_status graph_compute(backend_ctx * c, ggml_cgraph * g) {
     if (g->n_nodes == 0) return GGML_STATUS_SUCCESS;
     // Replay fast path: a graph that was captured before is launched straight from its fingerprint -- the five scratch-size passes and
     // the eligibility scans below are per-node host work in front of the launch, with the device idle (decode: ~1200 nodes).  Safe
     // because a capture exists only for an eligible graph whose scratch was sized, and growing any scratch block drops every capture.
+    // Identity is the per-node record of the capture compared field by field (recs_match), most recently used capture first; no hash on this path.
     uint64_t fp = 0; bool have_fp = false;
     if (c->opt_graphs && !c->opt_profile && !c->execs.empty()) {
-        fp = fingerprint(g); have_fp = true;
-        for (auto & e : c->execs)
-            if (e.fingerprint == fp && e.exec && e.shadow_gen == shadow_generation()) {
+        graph_exec * order[8]; int no = 0;
+        for (auto & e : c->execs) if (e.exec && e.shadow_gen == shadow_generation() && no < 8) order[no++] = &e;
+        for (int a = 1; a < no; ++a) for (int b = a; b > 0 && order[b]->last_use > order[b - 1]->last_use; --b) std::swap(order[b], order[b - 1]);
+        for (int a = 0; a < no; ++a)
+            if (recs_match(c, g, *order[a])) {
+                graph_exec & e = *order[a];
                 e.last_use = ++c->tick; e.seen++;
                 HIP_CHECK(hipGraphLaunch(e.exec, c->stream));
                 c->stat_replays++; c->stat_kernels_last = e.n_kernels;
@@ -2224,6 +2290,11 @@ enum ggml_status graph_compute(backend_ctx * c, ggml_cgraph * g) {
             HIP_CHECK(hipGraphExecDestroy(ge->exec)); HIP_CHECK(hipGraphDestroy(ge->graph));
             ge->exec = nullptr; ge->graph = nullptr; ge->seen = 1;  // run eagerly once (rebuilds the images), capture next time
         }
+        if (ge->exec && !recs_match(c, g, *ge)) {                  // same fingerprint, different graph (a collision, or other readers outside the cgraph): never replay it
+            HIP_CHECK(hipGraphExecDestroy(ge->exec)); HIP_CHECK(hipGraphDestroy(ge->graph));
+            ge->exec = nullptr; ge->graph = nullptr; ge->seen = 1; ge->recs.clear();
+            c->stat_fp_mismatch++;
+        }
         if (ge->exec) {
             HIP_CHECK(hipGraphLaunch(ge->exec, c->stream));
             c->stat_replays++; c->stat_kernels_last = ge->n_kernels;
@@ -2242,6 +2313,7 @@ enum ggml_status graph_compute(backend_ctx * c, ggml_cgraph * g) {
                 e = hipGraphInstantiate(&ex, graph, nullptr, nullptr, 0);
                 if (e == hipSuccess) {
                     ge->graph = graph; ge->exec = ex; ge->n_kernels = (int) s.n_kernels; ge->shadow_gen = shadow_generation();
+                    make_recs(c, g, *ge);
                     HIP_CHECK(hipGraphLaunch(ex, c->stream));
                     c->stat_captures++; c->stat_kernels_last = s.n_kernels;
                     return GGML_STATUS_SUCCESS;
@@ -2320,6 +2392,7 @@ void backend_ctx_release(backend_ctx * c) {
     if (c->rope_scratch) (void) hipFree(c->rope_scratch);
     if (c->gemm_partial) (void) hipFree(c->gemm_partial);
     if (c->copy_event) (void) hipEventDestroy(c->copy_event);
+    if (c->handoff_event) (void) hipEventDestroy(c->handoff_event);
     if (c->stream) (void) hipStreamDestroy(c->stream);
 }
 
@@ -2329,10 +2402,11 @@ extern "C" {
 int mi355x_set_option(struct ggml_backend * backend, const char * key, long value) {
     mi::backend_ctx * c = (mi::backend_ctx *) backend->context;
     if (!strcmp(key, "graphs"))  { c->opt_graphs = value != 0; return 0; }
-    if (!strcmp(key, "fusion"))  { c->opt_fusion = value != 0; c->execs.clear(); return 0; }
+    if (!strcmp(key, "fusion"))  { c->opt_fusion = value != 0; mi::drop_graph_execs(c); return 0; }
     if (!strcmp(key, "profile")) { c->opt_profile = value != 0; return 0; }
     if (!strcmp(key, "norm_in_kernel")) { c->opt_norm_in_kernel = value != 0; mi::drop_graph_execs(c); return 0; }
     if (!strcmp(key, "mv1")) { c->opt_mv1 = value != 0; mi::drop_graph_execs(c); return 0; }
+    if (!strcmp(key, "fp_collide")) { mi::g_fp_collide = value != 0; return 0; }
     if (!strcmp(key, "mv2")) { mi::mmv2_enable(value != 0); mi::drop_graph_execs(c); return 0; }       // (process-wide: the LDS-DMA engine form of the decode mat-vec)
     if (!strcmp(key, "kq_staging")) { c->opt_kq_staging = value != 0; mi::drop_graph_execs(c); return 0; }
     if (!strcmp(key, "fattn_gqa")) { mi::fattn_set_gqa(value != 0); mi::drop_graph_execs(c); return 0; }
@@ -2344,6 +2418,7 @@ int mi355x_set_option(struct ggml_backend * backend, const char * key, long valu
 double mi355x_get_stat(struct ggml_backend * backend, const char * key) {
     mi::backend_ctx * c = (mi::backend_ctx *) backend->context;
     if (!strcmp(key, "graph_replays"))      return (double) c->stat_replays;
+    if (!strcmp(key, "graph_fp_mismatch"))  return (double) c->stat_fp_mismatch;      // captures dropped because the graph differed under an equal fingerprint
     if (!strcmp(key, "graph_captures"))     return (double) c->stat_captures;
     if (!strcmp(key, "eager_graphs"))       return (double) c->stat_eager;
     if (!strcmp(key, "kernels_last_graph")) return (double) c->stat_kernels_last;

@@ -11,14 +11,24 @@ void log_msg(int level, const char * fmt, ...);
 
 struct prof_class { double us = 0; double bytes = 0; long n = 0; };
 
+// what a captured hipGraph was built from, node by node (the reference keeps the same record for its CUDA graphs, ggml-cuda.cu:2721-2796 and
+// compares it before every launch): a replay is only issued when EVERY field of EVERY node matches -- a 64-bit fingerprint alone would replay
+// the wrong capture silently on a collision -- and when the same nodes have readers outside the cgraph (`ext`: the fusion decisions baked
+// into the capture depend on it, and ggml_cgraph::use_counts can change while the nodes stay the same)
+struct node_rec {
+    const void * data; uint32_t op, type; int32_t flags; int32_t ext;
+    int64_t ne[4]; size_t nb[4]; int32_t op_params[GGML_MAX_OP_PARAMS / 4]; const void * src[GGML_MAX_SRC]; int32_t direct, pad;
+};
 struct graph_exec {                    // one captured cgraph
-    uint64_t        fingerprint = 0;
+    uint64_t        fingerprint = 0;   // (bookkeeping of graphs seen but not yet captured; identity of a capture is `recs`)
     int             seen = 0;          // times this fingerprint was submitted
     hipGraph_t      graph = nullptr;
     hipGraphExec_t  exec = nullptr;
     int             n_kernels = 0;
     uint64_t        last_use = 0;
     uint64_t        shadow_gen = 0;    // shadow_generation() at capture time
+    bool            with_ext = false;  // recs[].ext was derived from use_counts (the graph carried them and fusion was on)
+    std::vector<node_rec> recs;
 };
 
 struct backend_ctx {
@@ -26,6 +36,7 @@ struct backend_ctx {
     std::string  name;
     hipStream_t  stream = nullptr;
     hipEvent_t   copy_event = nullptr;
+    hipEvent_t   handoff_event = nullptr;   // mi355x_handoff's own event (cpy_tensor_async uses copy_event on the same stream)
 
     // scratch for quantised / converted activations (grown outside of graph capture only)
     void *  act_scratch = nullptr;  size_t act_scratch_bytes = 0;
@@ -53,7 +64,7 @@ struct backend_ctx {
     uint64_t tick = 0;
 
     // statistics
-    long stat_replays = 0, stat_captures = 0, stat_eager = 0, stat_kernels_last = 0;
+    long stat_replays = 0, stat_captures = 0, stat_eager = 0, stat_kernels_last = 0, stat_fp_mismatch = 0;
     std::map<std::string, prof_class> prof;
     struct pending_prof { std::string cls; double bytes; hipEvent_t a, b; };
     std::vector<pending_prof> prof_pending;
@@ -67,5 +78,7 @@ void drop_graph_execs(backend_ctx * c);      // destroy every captured hipGraph 
 bool             supports_op(const ggml_tensor * op);
 enum ggml_status graph_compute(backend_ctx * c, ggml_cgraph * g);
 void             graph_optimize(backend_ctx * c, ggml_cgraph * g);   // node re-ordering before allocation (ggml_backend_i.graph_optimize)
+
+bool backend_is_mi355x(const struct ggml_backend * b);      // (backend.cpp) is this one of OUR backends -- its context a backend_ctx?
 
 } // namespace mi

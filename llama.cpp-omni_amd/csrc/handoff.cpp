@@ -81,11 +81,17 @@ int mi355x_handoff_init(void) {
     return mi::handoff_init_locked() == 1 ? (int) mi::g_comms.size() : 0;
 }
 
+// Neither backend may be submitting work from another thread while the hand-off enqueues on its stream (one ggml_backend = one stream, driven
+// by one thread at a time: the omni pipeline calls this from the producer's thread after its graph_compute and before the consumer's).
 int mi355x_handoff(struct ggml_backend * src_backend, const void * src, struct ggml_backend * dst_backend, void * dst, size_t nbytes) {
     if (!src_backend || !dst_backend || (!src && nbytes) || (!dst && nbytes)) return -1;
+    if (!mi::backend_is_mi355x(src_backend) || !mi::backend_is_mi355x(dst_backend)) return -1;     // (a CPU backend's context is not a backend_ctx)
     if (nbytes == 0) return 0;
     mi::backend_ctx * cs = (mi::backend_ctx *) src_backend->context; mi::backend_ctx * cd = (mi::backend_ctx *) dst_backend->context;
     std::lock_guard<std::mutex> lk(mi::g_ho_mu);                // (RCCL group calls of one process are not re-entrant across threads)
+    int dev_before = 0;
+    HIP_CHECK(hipGetDevice(&dev_before));                       // the caller's current device is restored on every path
+    struct restore { int d; ~restore() { (void) hipSetDevice(d); } } rs_{ dev_before };
     // RCCL between different devices (the real case), or inside ONE backend (self send / recv on one stream: how a 1-GPU box exercises the
     // RCCL plumbing).  Two backends on the same device would put the two halves of a self-exchange on different streams of one communicator,
     // which NCCL's group semantics do not allow -- that case is a plain device copy.
@@ -106,10 +112,10 @@ int mi355x_handoff(struct ggml_backend * src_backend, const void * src, struct g
     if (cs->device == cd->device) HIP_CHECK(hipMemcpyAsync(dst, src, nbytes, hipMemcpyDeviceToDevice, cs->stream));
     else                          HIP_CHECK(hipMemcpyPeerAsync(dst, cd->device, src, cs->device, nbytes, cs->stream));
     if (cs != cd) {
-        if (!cs->copy_event) HIP_CHECK(hipEventCreateWithFlags(&cs->copy_event, hipEventDisableTiming));
-        HIP_CHECK(hipEventRecord(cs->copy_event, cs->stream));
+        if (!cs->handoff_event) HIP_CHECK(hipEventCreateWithFlags(&cs->handoff_event, hipEventDisableTiming));
+        HIP_CHECK(hipEventRecord(cs->handoff_event, cs->stream));
         HIP_CHECK(hipSetDevice(cd->device));
-        HIP_CHECK(hipStreamWaitEvent(cd->stream, cs->copy_event, 0));
+        HIP_CHECK(hipStreamWaitEvent(cd->stream, cs->handoff_event, 0));
     }
     ++mi::g_ho_peer_calls;
     return 2;
