@@ -170,7 +170,9 @@ static const char * be_name(ggml_backend_t b) { return ((backend_ctx *) b->conte
 static void be_free(ggml_backend_t b) {
     backend_ctx * c = (backend_ctx *) b->context;
     set_device(c->device);
+    flush_uploads(c);
     HIP_CHECK(hipStreamSynchronize(c->stream));
+    for (int h = 0; h < 2; ++h) { if (c->up_host[h]) (void) hipHostFree(c->up_host[h]); if (c->up_ents[h]) (void) hipHostFree(c->up_ents[h]); if (c->up_done[h]) (void) hipEventDestroy(c->up_done[h]); }
     if (getenv("MI355X_LOG_STATS"))
         log_msg(GGML_LOG_LEVEL_INFO, "[mi355x] %s: graphs eager=%ld captured=%ld replayed=%ld, kernels in last graph=%ld\n", c->name.c_str(),
                 c->stat_eager, c->stat_captures, c->stat_replays, c->stat_kernels_last);
@@ -182,13 +184,47 @@ static void be_free(ggml_backend_t b) {
     delete b;
 }
 static bool backend_is_ours(ggml_backend_t b);
+void flush_uploads(backend_ctx * c);
+// ---- small uploads: staged, then written by one launch (ggml_backend_tensor_set_async is how llama_decode hands over the five per-token inputs)
+static const size_t UP_HALF = 256 * 1024, UP_SMALL = 64 * 1024; static const int UP_MAX = 64;
+void flush_uploads(backend_ctx * c) {                     // everything staged so far goes onto the stream, in order, in front of what follows
+    if (c->up_n == 0) return;
+    const int h = c->up_half;
+    void * dents = nullptr, * dbase = nullptr;
+    HIP_CHECK(hipHostGetDevicePointer(&dents, c->up_ents[h], 0));
+    HIP_CHECK(hipHostGetDevicePointer(&dbase, c->up_host[h], 0));
+    upload_small((const upload_ent *) dents, (const char *) dbase, c->up_n, c->stream);
+    HIP_CHECK(hipEventRecord(c->up_done[h], c->stream));
+    c->up_half = h ^ 1; c->up_n = 0; c->up_used = 0;
+    HIP_CHECK(hipEventSynchronize(c->up_done[c->up_half]));          // the other half's launch (two flushes ago) has long run
+}
+static bool stage_upload(backend_ctx * c, void * dst, const void * data, size_t sz) {
+    if (!c->opt_batch_uploads || sz == 0 || sz > UP_SMALL) return false;
+    if (!c->up_host[0]) {
+        for (int h = 0; h < 2; ++h) {
+            if (hipHostMalloc((void **) &c->up_host[h], UP_HALF, hipHostMallocDefault) != hipSuccess || hipHostMalloc((void **) &c->up_ents[h], sizeof(backend_ctx::up_ent) * UP_MAX, hipHostMallocDefault) != hipSuccess) {
+                (void) hipGetLastError(); c->opt_batch_uploads = false; return false;
+            }
+            HIP_CHECK(hipEventCreateWithFlags(&c->up_done[h], hipEventDisableTiming));
+        }
+    }
+    const size_t at = (c->up_used + 15) & ~(size_t) 15;
+    if (at + sz > UP_HALF || c->up_n == UP_MAX) { flush_uploads(c); return stage_upload(c, dst, data, sz); }
+    memcpy(c->up_host[c->up_half] + at, data, sz);
+    c->up_ents[c->up_half][c->up_n++] = { dst, (uint32_t) at, (uint32_t) sz };
+    c->up_used = at + sz;
+    return true;
+}
 static void be_set_async(ggml_backend_t b, struct ggml_tensor * t, const void * data, size_t off, size_t sz) {
     backend_ctx * c = (backend_ctx *) b->context; set_device(c->device);
     shadow_invalidate(c->device, (char *) t->data + off, sz);
+    if (stage_upload(c, (char *) t->data + off, data, sz)) return;
+    flush_uploads(c);
     HIP_CHECK(hipMemcpyAsync((char *) t->data + off, data, sz, hipMemcpyHostToDevice, c->stream));
 }
 static void be_get_async(ggml_backend_t b, const struct ggml_tensor * t, void * data, size_t off, size_t sz) {
     backend_ctx * c = (backend_ctx *) b->context; set_device(c->device);
+    flush_uploads(c);
     HIP_CHECK(hipMemcpyAsync(data, (const char *) t->data + off, sz, hipMemcpyDeviceToHost, c->stream));
 }
 static bool be_cpy_async(ggml_backend_t bs, ggml_backend_t bd, const struct ggml_tensor * src, struct ggml_tensor * dst) {
@@ -198,6 +234,7 @@ static bool be_cpy_async(ggml_backend_t bs, ggml_backend_t bd, const struct ggml
     if (!sb || !db || !buffer_is_ours(sb) || !buffer_is_ours(db)) return false;
     backend_ctx * cs = (backend_ctx *) bs->context; backend_ctx * cd = (backend_ctx *) bd->context;
     if (((buffer_ctx *) sb->context)->device != cs->device || ((buffer_ctx *) db->context)->device != cd->device) return false;
+    flush_uploads(cs); if (cd != cs) flush_uploads(cd);
     const size_t n = nbytes(dst);
     shadow_invalidate(cd->device, dst->data, n);
     set_device(cs->device);
@@ -216,15 +253,18 @@ static bool be_cpy_async(ggml_backend_t bs, ggml_backend_t bd, const struct ggml
 }
 static void be_sync(ggml_backend_t b) {
     backend_ctx * c = (backend_ctx *) b->context; set_device(c->device);
+    flush_uploads(c);
     HIP_CHECK(hipStreamSynchronize(c->stream));
 }
 static enum ggml_status be_graph_compute(ggml_backend_t b, struct ggml_cgraph * g) {
     backend_ctx * c = (backend_ctx *) b->context; set_device(c->device);
+    flush_uploads(c);
     return graph_compute(c, g);
 }
 static void be_graph_optimize(ggml_backend_t b, struct ggml_cgraph * g) { graph_optimize((backend_ctx *) b->context, g); }
 static void be_event_record(ggml_backend_t b, ggml_backend_event_t e) {
     backend_ctx * c = (backend_ctx *) b->context; set_device(c->device);
+    flush_uploads(c);
     HIP_CHECK(hipEventRecord((hipEvent_t) e->context, c->stream));
 }
 static void be_event_wait(ggml_backend_t b, ggml_backend_event_t e) {
@@ -395,6 +435,7 @@ void * mi355x_timed_event_new(void) { hipEvent_t e; HIP_CHECK(hipEventCreate(&e)
 void   mi355x_timed_event_record(void * ev, ggml_backend_t backend) {
     mi::backend_ctx * c = (mi::backend_ctx *) backend->context;
     HIP_CHECK(hipSetDevice(c->device));
+    mi::flush_uploads(c);
     HIP_CHECK(hipEventRecord((hipEvent_t) ev, c->stream));
 }
 float  mi355x_timed_event_elapsed_ms(void * start, void * stop) {

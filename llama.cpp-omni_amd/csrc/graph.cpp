@@ -2406,6 +2406,7 @@ int mi355x_set_option(struct ggml_backend * backend, const char * key, long valu
     if (!strcmp(key, "profile")) { c->opt_profile = value != 0; return 0; }
     if (!strcmp(key, "norm_in_kernel")) { c->opt_norm_in_kernel = value != 0; mi::drop_graph_execs(c); return 0; }
     if (!strcmp(key, "mv1")) { c->opt_mv1 = value != 0; mi::drop_graph_execs(c); return 0; }
+    if (!strcmp(key, "batch_uploads")) { flush_uploads(c); c->opt_batch_uploads = value != 0; return 0; }
     if (!strcmp(key, "fp_collide")) { mi::g_fp_collide = value != 0; return 0; }
     if (!strcmp(key, "mv2")) { mi::mmv2_enable(value != 0); mi::drop_graph_execs(c); return 0; }       // (process-wide: the LDS-DMA engine form of the decode mat-vec)
     if (!strcmp(key, "kq_staging")) { c->opt_kq_staging = value != 0; mi::drop_graph_execs(c); return 0; }

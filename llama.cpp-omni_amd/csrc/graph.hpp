@@ -51,6 +51,15 @@ struct backend_ctx {
     // split-K partial sums of the prefill GEMM
     void *  gemm_partial = nullptr; size_t gemm_partial_bytes = 0;
 
+    // small host -> device uploads (the per-token inputs of a decode step: embedding row, position, cache indices, mask row) are staged in
+    // pinned memory and written by ONE launch in front of the next piece of stream work instead of one ~4 us copy each (backend.cpp)
+    struct up_ent { void * dst; uint32_t off, size; };
+    char *   up_host[2] = { nullptr, nullptr };      // pinned staging halves (device-visible)
+    up_ent * up_ents[2] = { nullptr, nullptr };      // pinned descriptor tables
+    hipEvent_t up_done[2] = { nullptr, nullptr };    // the half's last flush has run
+    int      up_half = 0, up_n = 0; size_t up_used = 0;
+    bool     opt_batch_uploads = true;
+
     // options
     bool opt_graphs = true;
     bool opt_fusion = true;
@@ -73,6 +82,7 @@ struct backend_ctx {
 
 void backend_ctx_init(backend_ctx * c);
 void backend_ctx_release(backend_ctx * c);
+void flush_uploads(backend_ctx * c);          // (backend.cpp) staged small uploads -> the stream; every entry point that enqueues stream work calls it first
 void drop_graph_execs(backend_ctx * c);      // destroy every captured hipGraph of the context (option changes, scratch re-allocation)
 
 bool             supports_op(const ggml_tensor * op);

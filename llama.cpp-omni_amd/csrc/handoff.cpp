@@ -92,6 +92,8 @@ int mi355x_handoff(struct ggml_backend * src_backend, const void * src, struct g
     int dev_before = 0;
     HIP_CHECK(hipGetDevice(&dev_before));                       // the caller's current device is restored on every path
     struct restore { int d; ~restore() { (void) hipSetDevice(d); } } rs_{ dev_before };
+    HIP_CHECK(hipSetDevice(cs->device)); mi::flush_uploads(cs);
+    if (cd != cs) { HIP_CHECK(hipSetDevice(cd->device)); mi::flush_uploads(cd); }
     // RCCL between different devices (the real case), or inside ONE backend (self send / recv on one stream: how a 1-GPU box exercises the
     // RCCL plumbing).  Two backends on the same device would put the two halves of a self-exchange on different streams of one communicator,
     // which NCCL's group semantics do not allow -- that case is a plain device copy.

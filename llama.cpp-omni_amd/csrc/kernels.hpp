@@ -150,6 +150,9 @@ void conv_transpose_1d_f32(const tdesc & w, int w_type, const tdesc & x, const t
 void cast_f32_i32(const tdesc & src, bool src_is_f32, const tdesc & dst, hipStream_t st);                          // ops.cpp:555, 558-561
 // CPY / CONT / DUP between f32 / f16 with arbitrary strides (same element count)
 void cpy_strided(const tdesc & src, int src_type, const tdesc & dst, int dst_type, hipStream_t st);
+// n small copies in one launch: entry i copies ents[i].size bytes from base + ents[i].off to ents[i].dst (base / ents: device-visible pinned memory)
+struct upload_ent { void * dst; uint32_t off, size; };
+void upload_small(const upload_ent * ents, const char * base, int n, hipStream_t st);
 // GET_ROWS (f32 / f16 / quantised tables -> f32), SET_ROWS (f32 -> f32 / f16, i64 or i32 indices)
 void get_rows(const tdesc & src, int src_type, const tdesc & idx, const tdesc & dst, hipStream_t st);
 void set_rows(const tdesc & src, const tdesc & idx, int idx_type, const tdesc & dst, int dst_type, hipStream_t st, int64_t period = 0);   // period: rows r = t * period + j of single-element rows (a work-order hint)

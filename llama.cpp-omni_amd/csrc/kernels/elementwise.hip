@@ -1175,4 +1175,22 @@ void set_rows(const tdesc & src, const tdesc & idx, int idx_type, const tdesc & 
     } else { fprintf(stderr, "[mi355x] set_rows: unsupported dst type %d\n", dst_type); abort(); }
 }
 
+// ------------------------------------------------------------------------------------------------ batched small uploads
+// one workgroup per entry; 16-byte pieces where source and destination allow, bytes at the edges
+__global__ void __launch_bounds__(256) k_upload_small(const upload_ent * __restrict__ ents, const char * __restrict__ base) {
+    const upload_ent e = ents[blockIdx.x];
+    const char * src = base + e.off; char * dst = (char *) e.dst;
+    const uint32_t n = e.size;
+    if ((((uintptr_t) src | (uintptr_t) dst) & 15) == 0) {
+        const uint32_t nv = n >> 4;
+        for (uint32_t i = threadIdx.x; i < nv; i += 256) ((u32x4 *) dst)[i] = ((const u32x4 *) src)[i];
+        for (uint32_t i = (nv << 4) + threadIdx.x; i < n; i += 256) dst[i] = src[i];
+    } else {
+        for (uint32_t i = threadIdx.x; i < n; i += 256) dst[i] = src[i];
+    }
+}
+void upload_small(const upload_ent * ents, const char * base, int n, hipStream_t st) {
+    if (n > 0) k_upload_small<<<dim3(n), dim3(256), 0, st>>>(ents, base);
+}
+
 } // namespace mi

@@ -61,10 +61,10 @@ struct mv2_dev { mv2_mat m[3]; int nmat; const char * W1; mv1_src src; int K; };
 struct mv2_flags {
     uint32_t landed;                // steps of the workgroup's stream that have landed in the ring
     uint32_t rows_issued;           // row waves that have requested their part of the activation row -- the weight stream starts behind them
-    uint32_t rows_landed;           // row waves whose part of the activation row (norm weights, residual rows) is in the staging area
+    uint32_t x_landed;              // row waves whose part of the activation row (and of the residual rows) is in the staging area
+    uint32_t rows_landed;           // ... and of the norm weights
     uint32_t sum_cnt, img_cnt;      // prologue waves that have published their sum of squares / finished their image blocks
     uint32_t scale_ready; float scale;   // the RMS-norm scale, computed by the prologue wave that arrived last at sum_cnt
-    uint32_t pad;
     uint32_t consumed[16];          // per consumer: tasks whose ring slots it has read into registers
 };
 // The flags are touched through address-space-3 pointers ONLY: through a generic pointer hipcc emits flat_load / flat_store + s_waitcnt
@@ -232,16 +232,15 @@ static __device__ __forceinline__ void mv2_row_loader(const mv1_src src, int K, 
 #ifdef MV2_ROWSTART
     mv2_arrive(MV2_FLAG(F->rows_issued));
 #endif
-    if (!src.img) {                                     // instruction b of the row (1 KiB each; the norm weights follow the row) belongs to row wave b % MV2_ROW_WAVES
-        const int nb = K >> 8, ni = src.nw ? 2 * nb : nb;
+    // Only the row itself (and the residual) is requested in front of the weight stream; the norm weights -- needed a microsecond later, when the
+    // sum of squares is known -- go in behind the loader's first requests.  Piece b (1 KiB) of either belongs to row wave b % MV2_ROW_WAVES.
+    const int nb = K >> 8;
+    if (!src.img) {
         const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void *) src.x, (short) 0, K * 4, 0x00020000);
-        const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void *) src.nw, (short) 0, src.nw ? K * 4 : 0, 0x00020000);
         MV2_STAMP(2);
-        for (int b = rw; b < ni; b += MV2_ROW_WAVES) {
-            if (b == rw + MV2_ROW_WAVES) MV2_STAMP(3);
-            const bool isw = b >= nb;
-            const uint32_t off = (uint32_t) (isw ? b - nb : b) * 1024u;
-            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" :: "s"(__builtin_amdgcn_readfirstlane(stg + (uint32_t) b * 1024u)), "v"(v16), "s"(isw ? wr : xr), "s"(__builtin_amdgcn_readfirstlane(off)) : "memory", "m0");
+        for (int b = rw, i = 0; b < nb; b += MV2_ROW_WAVES, ++i) {
+            if (i == 1) MV2_STAMP(3);
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" :: "s"(__builtin_amdgcn_readfirstlane(stg + (uint32_t) b * 1024u)), "v"(v16), "s"(xr), "s"(__builtin_amdgcn_readfirstlane((uint32_t) b * 1024u)) : "memory", "m0");
         }
     }
     if (resid && rw == 0) {                             // rows G0 .. G0 + ntask: 64 per instruction
@@ -250,9 +249,20 @@ static __device__ __forceinline__ void mv2_row_loader(const mv1_src src, int K, 
             asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dword %1, %2, %3 offen lds" :: "s"(__builtin_amdgcn_readfirstlane(rstg + (uint32_t) b * 256u)), "v"(v4), "s"(rr), "s"(__builtin_amdgcn_readfirstlane((uint32_t) b * 256u)) : "memory", "m0");
     }
     MV2_STAMP(5);
-#ifndef MV2_ROWSTART
-    mv2_arrive(MV2_FLAG(F->rows_issued));
-#endif
+    mv2_arrive(MV2_FLAG(F->rows_issued));             // (measured: letting the loader start before ALL of a 48 KB row is requested delays the row more than it gains)
+    if (!src.img && src.nw) {                           // (K = 4096: the launcher refuses a norm at K = 12288) 4 pieces per wave
+        const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void *) src.nw, (short) 0, K * 4, 0x00020000);
+#pragma unroll
+        for (int i = 0; i < 16 / MV2_ROW_WAVES; ++i) {
+            const int b = rw + i * MV2_ROW_WAVES;
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" :: "s"(__builtin_amdgcn_readfirstlane(stg + (uint32_t) (K * 4) + (uint32_t) b * 1024u)), "v"(v16), "s"(wr), "s"(__builtin_amdgcn_readfirstlane((uint32_t) b * 1024u)) : "memory", "m0");
+        }
+        mv2_vmcnt<16 / MV2_ROW_WAVES>();                 // everything but the norm-weight pieces: the row is here
+        mv2_arrive(MV2_FLAG(F->x_landed));
+    } else {
+        mv2_vmcnt<0>();
+        mv2_arrive(MV2_FLAG(F->x_landed));
+    }
     mv2_vmcnt<0>();
     mv2_arrive(MV2_FLAG(F->rows_landed));
 }
@@ -305,7 +315,7 @@ static __device__ __forceinline__ void mv2_q8k_rows(const f32x4 (&y)[4], int lan
 template <int NIT>
 static __device__ __forceinline__ void mv2_prologue(const mv1_src s, int K, int mw, char * im, const char * stg, double * red, mv2_flags * F MV2_TR_PARAM) {
     const int lane = threadIdx.x & 63, row = lane >> 4, i = lane & 15, nb = K >> 8;
-    mv2_await(MV2_FLAG(F->rows_landed), MV2_ROW_WAVES);
+    mv2_await(MV2_FLAG(F->x_landed), MV2_ROW_WAVES);
     MV2_STAMP(2);
     float scale = 1.0f;
     f32x4 x[4];
@@ -344,6 +354,7 @@ static __device__ __forceinline__ void mv2_prologue(const mv1_src s, int K, int 
         const int b = mw * 4 + row;
         f32x4 y[4];
         if (s.nw) {
+            mv2_await(MV2_FLAG(F->rows_landed), MV2_ROW_WAVES);
             const char * wp = stg + K * 4 + b * 1024 + 16 * i;
 #pragma unroll
             for (int m = 0; m < 4; ++m) {
@@ -599,7 +610,7 @@ __global__ void __launch_bounds__(64 * MV2_WAVES) k_mv2(const mv2_dev a) {
         // the residual of this consumer's tasks, one per lane (task k of the consumer is row G0 + c + k C), from the staging area: the consumers
         // issue NO vector-memory loads -- one would wait for a place in the CU's memory queue behind the loader's stream
         float resid = 0.0f;
-        if (resid_p) { mv2_await(MV2_FLAG(F.rows_landed), MV2_ROW_WAVES); const int r = c + lane * C; if (r < ntask) resid = *(const float *) (rstg + r * 4); }
+        if (resid_p) { mv2_await(MV2_FLAG(F.x_landed), MV2_ROW_WAVES); const int r = c + lane * C; if (r < ntask) resid = *(const float *) (rstg + r * 4); }
         MV2_STAMP(4);
         if (q4) mv2_consume_q4k<PAIR ? 2 : 1, NIT, C, PAIR>(im, ringp, K, c, ntask, M.dst, G0 + c, resid, &F);
         else if constexpr ((TM & 2) != 0 && !PAIR) mv2_consume_q6k<NIT, C>(im, ringp, K, c, ntask, M.dst, G0 + c, resid, &F);

@@ -159,3 +159,36 @@ def test_replay_is_guarded_by_the_per_node_record_not_by_the_fingerprint(pkg, be
         ca.free(); cb.free()
     finally:
         be.set_option("fp_collide", 0)
+
+
+def test_batched_small_uploads_keep_stream_order(pkg, be):
+    """set_tensor_async of small inputs is staged and written by one launch in front of the next stream work: later writes win over earlier
+    ones whatever their size (staged or direct copy), reads see them, and the result equals the one-copy-per-call path."""
+    rng = np.random.default_rng(2)
+    n_big = 64 * 1024                                            # 256 KB: above the staging limit -> direct copy
+    c = pkg.Context(be)
+    t = c.new_tensor(pkg.GGML_TYPE_F32, n_big, 1)
+    s = c.new_tensor(pkg.GGML_TYPE_F32, 1000, 1)
+    y = c.add(s, s)
+    c.alloc()
+    small = [rng.standard_normal(1000).astype(np.float32) for _ in range(3)]
+    big = [rng.standard_normal(n_big).astype(np.float32) for _ in range(2)]
+    out = np.empty(n_big, np.float32)
+    for batch in (1, 0):
+        be.set_option("batch_uploads", batch)
+        try:
+            be.tensor_set_async(t, big[0])
+            be.tensor_set_async(t, small[0])                    # staged, after the direct copy: overwrites the first 1000 values
+            be.tensor_get_async(t, out); be.synchronize()
+            assert np.array_equal(out[:1000], small[0]) and np.array_equal(out[1000:], big[0][1000:])
+            be.tensor_set_async(t, small[1])                    # staged ...
+            be.tensor_set_async(t, big[1])                      # ... then a direct copy over it: the direct copy must come second
+            be.tensor_get_async(t, out); be.synchronize()
+            assert np.array_equal(out, big[1])
+            for k in range(70):                                 # more entries than one staging table holds
+                be.tensor_set_async(s, small[k % 3])
+            be.graph_compute(c.graph())
+            assert np.array_equal(be.tensor_get(y).ravel(), small[69 % 3] * 2)
+        finally:
+            be.set_option("batch_uploads", 1)
+    c.free()
