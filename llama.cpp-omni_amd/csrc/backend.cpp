@@ -208,6 +208,11 @@ static bool stage_upload(backend_ctx * c, void * dst, const void * data, size_t 
             HIP_CHECK(hipEventCreateWithFlags(&c->up_done[h], hipEventDisableTiming));
         }
     }
+    // entries of one launch are written by concurrent workgroups: two writes to overlapping bytes must be in different launches to keep their order
+    for (int i = 0; i < c->up_n; ++i) {
+        const backend_ctx::up_ent & e = c->up_ents[c->up_half][i];
+        if ((char *) dst < (char *) e.dst + e.size && (char *) e.dst < (char *) dst + sz) { flush_uploads(c); break; }
+    }
     const size_t at = (c->up_used + 15) & ~(size_t) 15;
     if (at + sz > UP_HALF || c->up_n == UP_MAX) { flush_uploads(c); return stage_upload(c, dst, data, sz); }
     memcpy(c->up_host[c->up_half] + at, data, sz);

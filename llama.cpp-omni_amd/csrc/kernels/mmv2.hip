@@ -555,8 +555,17 @@ static __device__ __forceinline__ void mv2_consume_q6k(const char * im, const ch
 // ================================================================================================= kernel
 // mv1_dev as in mmv1.hip, with wave_end = the first WORKGROUP past the matrix's range.  TM: bit0 = Q4_K body compiled in, bit1 = Q6_K.
 // NIT = K / 4096.  PAIR: m[0] = gate, W1 = up (same type / shape), epilogue silu(g) * u (Q4_K only).  NL loader waves, 16 - NL consumers.
+// The first ten arguments -- 14 dwords: what the loader and the row waves need to put their first requests out -- are marked for KERNARG PRELOAD
+// (-mllvm -amdgpu-kernarg-preload-count=10, csrc/Makefile): the command processor writes them into SGPRs at wave launch, so the launch's critical
+// waves do not begin with a ~0.3 us scalar-load round trip.  (Firmware without the feature runs the compiler's compatibility prologue: the same
+// loads, as before.)  Everything else (`rest`: destination pointers, the second and third matrix of a grouped launch, a ready-made image) is read
+// through the kernarg segment pointer where it is first needed -- never by name, or hipcc hoists its loads to the entry and every early
+// s_waitcnt lgkmcnt(0) waits for them.
+typedef const __attribute__((address_space(4))) mv2_dev * mv2_karg;
+#define MV2_REST_OFFSET 56
 template <int TM, int NIT, bool PAIR, bool NT>
-__global__ void __launch_bounds__(64 * MV2_WAVES) k_mv2(const mv2_dev a) {
+__global__ void __launch_bounds__(64 * MV2_WAVES) k_mv2(const char * W0, const float * x, const float * nw, const char * aux /* pair: the up matrix; else: m[0]'s residual */,
+                                                         uint32_t w_rs0, int nrows0, int q0, int r0, float eps, int wg1 /* first workgroup of m[1] (the grid if none) */, const mv2_dev rest) {
     __shared__ mv2_flags F;
     __shared__ double red[16];
     constexpr int C = MV2_WAVES - 1;
@@ -577,13 +586,27 @@ __global__ void __launch_bounds__(64 * MV2_WAVES) k_mv2(const mv2_dev a) {
     else if (wiw <= 4 * NIT) __builtin_amdgcn_s_sleep(12);
     else { __builtin_amdgcn_s_sleep(40); }
 #endif
+    uint64_t kp = (uint64_t) (uintptr_t) __builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(kp));                        // (laundered: loads through it stay where they are written)
+    const mv2_karg R = (mv2_karg) (uintptr_t) (kp + MV2_REST_OFFSET);
+    (void) rest;
+    const int K = 4096 * NIT;
+    mv2_mat M;
+    M.W = W0; M.w_rs = w_rs0; M.nrows = nrows0; M.q = q0; M.r = r0; M.wg0 = 0; M.resid = PAIR ? nullptr : aux; M.dst = nullptr;
+    M.type = TM == 2 ? GGML_TYPE_Q6_K : GGML_TYPE_Q4_K;
     int mi_ = 0;
-    if (!PAIR) {
-        if (a.nmat > 1 && wg >= a.m[1].wg0) mi_ = 1;
-        if (a.nmat > 2 && wg >= a.m[2].wg0) mi_ = 2;
-    }
-    const mv2_mat M = mi_ == 0 ? a.m[0] : (mi_ == 1 ? a.m[1] : a.m[2]);
-    const int K = a.K;
+    if (!PAIR && wg >= wg1) {                           // a workgroup of the second / third matrix: its description comes from the argument block
+        mi_ = (R->nmat > 2 && wg >= R->m[2].wg0) ? 2 : 1;
+        const __attribute__((address_space(4))) uint32_t * wsrc = (const __attribute__((address_space(4))) uint32_t *) &R->m[mi_];
+        uint32_t wbuf[sizeof(mv2_mat) / 4];
+#pragma unroll
+        for (size_t k = 0; k < sizeof(mv2_mat) / 4; ++k) wbuf[k] = wsrc[k];
+        __builtin_memcpy(&M, wbuf, sizeof M);
+    } else if (TM == 3) { asm volatile("" ::: "memory"); M.type = R->m[0].type; }
+    const char * img = nullptr;
+    if (x == nullptr) { asm volatile("" ::: "memory"); img = R->src.img; }      // (a real branch: a speculated scalar load would put a round trip in front of every wave)
+    const mv1_src src = { x, nw, eps, img };
+    const char * W1 = aux;
     const int lw = wg - M.wg0;
     const int G0 = __builtin_amdgcn_readfirstlane(lw * M.q + (lw < M.r ? lw : M.r));
     const int ntask = __builtin_amdgcn_readfirstlane(M.q + (lw < M.r ? 1 : 0));
@@ -594,7 +617,7 @@ __global__ void __launch_bounds__(64 * MV2_WAVES) k_mv2(const mv2_dev a) {
     const bool q4 = TM == 1 || ((TM & 1) && M.type == GGML_TYPE_Q4_K);
     MV2_STAMP(1);
     if (wiw == 0) {
-        const mv1_rsrc rs0 = mv1_make_rsrc(M.W, (size_t) M.nrows * M.w_rs), rs1 = mv1_make_rsrc(PAIR ? a.W1 : M.W, (size_t) M.nrows * M.w_rs);
+        const mv1_rsrc rs0 = mv1_make_rsrc(M.W, (size_t) M.nrows * M.w_rs), rs1 = mv1_make_rsrc(PAIR ? W1 : M.W, (size_t) M.nrows * M.w_rs);
         if (q4) mv2_loader<2304, PAIR ? 2 : 1, NIT, C, NT>(rs0, rs1, (uint32_t) M.w_rs, G0, ntask * NIT, mv2_lds_addr(ringp), &F MV2_TR_ARG);
         else if constexpr ((TM & 2) != 0 && !PAIR) mv2_loader<3360, 1, NIT, C, NT>(rs0, rs1, (uint32_t) M.w_rs, G0, ntask * NIT, mv2_lds_addr(ringp), &F MV2_TR_ARG);
         MV2_STAMP(7);
@@ -602,18 +625,19 @@ __global__ void __launch_bounds__(64 * MV2_WAVES) k_mv2(const mv2_dev a) {
         const int c = wiw - 1, lane = threadIdx.x & 63;
         const char * resid_p = PAIR ? nullptr : M.resid;
         // roles before the stream is consumed: the last 4 consumers fetch the row, consumers 0 .. 4 NIT - 1 (NIT per SIMD) build the image, the rest wait
-        if (c >= C - MV2_ROW_WAVES) mv2_row_loader(a.src, K, c - (C - MV2_ROW_WAVES), resid_p, G0, ntask, mv2_lds_addr(stg), mv2_lds_addr(rstg), &F MV2_TR_ARG);
+        if (c >= C - MV2_ROW_WAVES) mv2_row_loader(src, K, c - (C - MV2_ROW_WAVES), resid_p, G0, ntask, mv2_lds_addr(stg), mv2_lds_addr(rstg), &F MV2_TR_ARG);
         uint32_t img_need = 4 * NIT;
-        if (a.src.img) { mv2_image_copy<C>(a.src.img, K, c, im, &F); img_need = C; }
-        else if (c < 4 * NIT) mv2_prologue<NIT>(a.src, K, c, im, stg, red, &F MV2_TR_ARG);
+        if (src.img) { mv2_image_copy<C>(src.img, K, c, im, &F); img_need = C; }
+        else if (c < 4 * NIT) mv2_prologue<NIT>(src, K, c, im, stg, red, &F MV2_TR_ARG);
         { uint32_t spins = 0; while (mv2_peek(MV2_FLAG(F.img_cnt)) < img_need) { __builtin_amdgcn_s_sleep(4); if (++spins > MV2_SPIN_MAX) __builtin_trap(); } asm volatile("" ::: "memory"); }
         // the residual of this consumer's tasks, one per lane (task k of the consumer is row G0 + c + k C), from the staging area: the consumers
         // issue NO vector-memory loads -- one would wait for a place in the CU's memory queue behind the loader's stream
         float resid = 0.0f;
         if (resid_p) { mv2_await(MV2_FLAG(F.x_landed), MV2_ROW_WAVES); const int r = c + lane * C; if (r < ntask) resid = *(const float *) (rstg + r * 4); }
         MV2_STAMP(4);
-        if (q4) mv2_consume_q4k<PAIR ? 2 : 1, NIT, C, PAIR>(im, ringp, K, c, ntask, M.dst, G0 + c, resid, &F);
-        else if constexpr ((TM & 2) != 0 && !PAIR) mv2_consume_q6k<NIT, C>(im, ringp, K, c, ntask, M.dst, G0 + c, resid, &F);
+        char * dst = mi_ == 0 ? R->m[0].dst : M.dst;     // (needed when the first results are stored)
+        if (q4) mv2_consume_q4k<PAIR ? 2 : 1, NIT, C, PAIR>(im, ringp, K, c, ntask, dst, G0 + c, resid, &F);
+        else if constexpr ((TM & 2) != 0 && !PAIR) mv2_consume_q6k<NIT, C>(im, ringp, K, c, ntask, dst, G0 + c, resid, &F);
         MV2_STAMP(7);
     }
     MV2_STAMP_FLUSH;
@@ -652,7 +676,9 @@ static void mv2_launch(const mv2_dev & d, int grid, hipStream_t st) {
     const size_t lds = 160 * 1024 - 512;                                                       // image + staging + ring: the whole CU (mv2_geo)
     static bool attr = false;
     if (!attr) { HIP_CHECK(hipFuncSetAttribute((const void *) k_mv2<TM, NIT, PAIR, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds)); attr = true; }
-    k_mv2<TM, NIT, PAIR, NT><<<dim3(grid), dim3(64 * MV2_WAVES), lds, st>>>(d);
+    static_assert(offsetof(mv2_dev, src) % 8 == 0, "argument block layout");
+    k_mv2<TM, NIT, PAIR, NT><<<dim3(grid), dim3(64 * MV2_WAVES), lds, st>>>(d.m[0].W, d.src.img ? nullptr : d.src.x, d.src.nw, PAIR ? d.W1 : d.m[0].resid, d.m[0].w_rs, d.m[0].nrows, d.m[0].q, d.m[0].r,
+                                                                           d.src.eps, d.nmat > 1 ? d.m[1].wg0 : grid, d);
 }
 
 // workgroup ranges of the matrices of a launch: by bytes, every matrix at least one workgroup
