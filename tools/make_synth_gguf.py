@@ -41,6 +41,59 @@ def kv_str(k, v):
     return _s(k) + struct.pack("<I", T_STR) + _s(v)
 
 
+# ---- block formats needed by the separated-logits fixture (ggml-common.h:295-305, :330-335; dequantize_row_q4_K / _q6_K, ggml-quants.c:1352-1374, :1762-1791)
+def dequant_q4_K(rows, K):
+    n, nb = rows.shape[0], K // 256
+    b = rows.reshape(n, nb, 144)
+    d = b[..., 0:2].copy().view(np.float16).astype(np.float32)[..., 0]; dmin = b[..., 2:4].copy().view(np.float16).astype(np.float32)[..., 0]
+    sc8 = b[..., 4:16].astype(np.int32); qs = b[..., 16:144]
+    out = np.empty((n, nb, 256), np.float32)
+    for j in range(8):
+        if j < 4:
+            sc, m = sc8[..., j] & 63, sc8[..., j + 4] & 63
+        else:
+            sc = (sc8[..., j + 4] & 0xF) | ((sc8[..., j - 4] >> 6) << 4); m = (sc8[..., j + 4] >> 4) | ((sc8[..., j] >> 6) << 4)
+        q = qs[..., 32 * (j // 2): 32 * (j // 2) + 32]
+        q = (q & 0xF) if j % 2 == 0 else (q >> 4)
+        out[..., 32 * j: 32 * j + 32] = (d * sc)[..., None] * q - (dmin * m)[..., None]
+    return out.reshape(n, K)
+
+
+def quant_q6_K(x):
+    """a plain (not the reference's search) Q6_K encoder: per 16 weights scale = max|x| / 31, super-block d = max|scale| / 127"""
+    n, K = x.shape
+    nb = K // 256
+    xb = x.reshape(n, nb, 16, 16)
+    s = np.abs(xb).max(axis=3) / 31.0
+    d = np.maximum(s.max(axis=2) / 127.0, 1e-30).astype(np.float16).astype(np.float32)
+    sc = np.clip(np.rint(s / d[..., None]), 1, 127).astype(np.int32)
+    q = np.clip(np.rint(xb / (d[..., None, None] * sc[..., None])) + 32, 0, 63).astype(np.uint8).reshape(n, nb, 256)
+    blk = np.zeros((n, nb, 210), np.uint8)
+    for h in range(2):                                          # each half: 128 weights = 4 groups of 32 (l, l + 32, l + 64, l + 96)
+        q1, q2, q3, q4 = (q[..., 128 * h + 32 * g: 128 * h + 32 * g + 32] for g in range(4))
+        blk[..., 64 * h: 64 * h + 32] = (q1 & 0xF) | ((q3 & 0xF) << 4)
+        blk[..., 64 * h + 32: 64 * h + 64] = (q2 & 0xF) | ((q4 & 0xF) << 4)
+        blk[..., 128 + 32 * h: 128 + 32 * h + 32] = (q1 >> 4) | ((q2 >> 4) << 2) | ((q3 >> 4) << 4) | ((q4 >> 4) << 6)
+    blk[..., 192:208] = sc.astype(np.int8).view(np.uint8)
+    blk[..., 208:210] = d.astype(np.float16)[..., None].view(np.uint8).reshape(n, nb, 2)
+    return blk.reshape(n, nb * 210)
+
+
+def dequant_q6_K(rows, K):
+    n, nb = rows.shape[0], K // 256
+    b = rows.reshape(n, nb, 210)
+    ql, qh, sc = b[..., 0:128], b[..., 128:192], b[..., 192:208].view(np.int8).astype(np.float32)
+    d = b[..., 208:210].copy().view(np.float16).astype(np.float32)[..., 0]
+    out = np.empty((n, nb, 256), np.float32)
+    for h in range(2):
+        l, hh = ql[..., 64 * h: 64 * h + 64].astype(np.int32), qh[..., 32 * h: 32 * h + 32].astype(np.int32)
+        qs = [(l[..., :32] & 0xF) | ((hh & 3) << 4), (l[..., 32:] & 0xF) | (((hh >> 2) & 3) << 4), (l[..., :32] >> 4) | (((hh >> 4) & 3) << 4), (l[..., 32:] >> 4) | (((hh >> 6) & 3) << 4)]
+        for g in range(4):
+            scale = np.repeat(sc[..., 8 * h + 2 * g: 8 * h + 2 * g + 2], 16, axis=-1)
+            out[..., 128 * h + 32 * g: 128 * h + 32 * g + 32] = d[..., None] * scale * (qs[g] - 32)
+    return out.reshape(n, K)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--config", choices=["8b", "tiny", "tts", "tts-tiny"], default="8b",
@@ -50,6 +103,10 @@ def main():
     ap.add_argument("--seed", type=int, default=1234)
     ap.add_argument("--distinct-layers", action="store_true", help="fresh random bytes per layer (small configs)")
     ap.add_argument("--n-ctx", type=int, default=40960)
+    ap.add_argument("--separated", type=int, default=0, metavar="S",
+                    help="greedy-decoding fixture with separated logits: S special tokens whose embedding dominates the residual stream, and whose "
+                         "successor's lm-head row points along it (token s_i -> s_(i+1)): the winning logit leads by a margin far above any "
+                         "summation-order noise, so two correct backends produce IDENTICAL greedy ids.  The ids are printed.")
     args = ap.parse_args()
 
     load_pkg()
@@ -122,6 +179,26 @@ def main():
             cache[key] = qwen3.random_blocks(rng, ty, ne[1], ne[0]).reshape(-1)
         return cache[key]
 
+    # ---- separated-logits fixture (see --separated)
+    special, patch = [], {}
+    if args.separated:
+        S = args.separated
+        assert embd_ty == GGML_TYPE_Q4_K and types["output"] == 14 and E % 256 == 0, "--separated: Q4_K token_embd, Q6_K output"
+        special = [int(V // 16 + (V - V // 8) * i // S) for i in range(S)]
+        r2 = np.random.default_rng(args.seed + 77)
+        big = qwen3.random_blocks(r2, GGML_TYPE_Q4_K, S, E, std=300.0)                 # embedding rows ~ 20x the size of what 36 random layers add
+        ehat = dequant_q4_K(big.reshape(S, -1), E)
+        ehat /= np.sqrt((ehat ** 2).mean(axis=1, keepdims=True))
+        out_rows = quant_q6_K(ehat)                                                      # successor rows: unit-rms copies of the embedding directions
+        deq = dequant_q6_K(out_rows, E)
+        logit = deq @ ehat.T                                                             # [row j, token i]: the lm head applied to the pure embedding direction
+        for i in range(S):
+            col = logit[:, i].copy(); top = col[i]; col[i] = -np.inf
+            assert top > 0.9 * E and col.max() < 0.7 * top, (i, top, col.max())          # the margin the fixture is built for (8B: runner-up ~ 0.06 top)
+        patch["token_embd.weight"] = {special[i]: big[i] for i in range(S)}
+        patch["output.weight"] = {special[(i + 1) % S]: out_rows[i] for i in range(S)}
+        print("separated-logits fixture: start token", special[0], "cycle", special[:4], "...")
+
     with open(args.out, "wb") as f:
         f.write(head)
         base = f.tell()
@@ -131,6 +208,13 @@ def main():
             f.write(b"\0" * pad)
             d = data_for(name, ty, ne)
             assert d.nbytes == nbytes(ty, ne), (name, d.nbytes, nbytes(ty, ne))
+            if name in patch:
+                d = d.reshape(ne[1], -1).copy()
+                if name == "output.weight":
+                    d = qwen3.random_blocks(np.random.default_rng(args.seed + 78), ty, ne[1], ne[0], std=1e-3).reshape(ne[1], -1)    # every other row: tiny
+                for row, bytes_ in patch[name].items():
+                    d[row] = bytes_
+                d = d.reshape(-1)
             f.write(d.tobytes() if d.nbytes < (1 << 26) else memoryview(np.ascontiguousarray(d)))
         f.write(b"\0" * ((-f.tell()) % ALIGN))
     print(f"wrote {args.out}: {len(tensors)} tensors, {os.path.getsize(args.out) / 1e6:.1f} MB")
