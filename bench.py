@@ -215,6 +215,50 @@ def kernel_roofline(pkg, be, model, reps=5):
             "method": "hipGraph replay of the step's 36 launches of this kernel, two HIP events on the backend stream, best of 5"}
 
 
+def via_libllama(threads=8, reps=5):
+    """The same metric through the REFERENCE's own libllama + ggml_backend_sched with this backend loaded as a plug-in (GGML_BACKEND_PATH):
+    oracle/_ref/llama-bench-min (the reference's llama-bench measurement loops on the public llama.h API, tools/llama_bench_min.cpp) on a
+    synthetic Qwen3-8B Q4_K_M GGUF written by tools/make_synth_gguf.py -- pp512 and tg128, flash-attention off (llama-bench's default) and on.
+    Only when oracle/_ref travelled with the snapshot (checker-side binaries; the product library is what is measured).  The difference to
+    `value` is host work outside the plug-in that llama_decode + llama_synchronize serialise with the device: graph build / scheduling, the CPU
+    split that looks the token up (token_embd stays on the CPU), and six blocking input copies per step (ggml_backend_tensor_copy)."""
+    import shutil
+    import subprocess
+    import tempfile
+    binp = os.path.join(ROOT, "oracle", "_ref", "llama-bench-min")
+    lib = os.path.join(ROOT, "llama.cpp-omni_amd", "lib", "libggml-mi355x.so")
+    if not os.path.exists(binp):
+        return None
+    tmp = tempfile.mkdtemp(prefix="mi355x_bench_")
+    try:
+        if shutil.disk_usage(tmp).free < 7e9:
+            return {"error": "needs 5 GB of scratch disk for the synthetic GGUF"}
+        gguf = os.path.join(tmp, "q8b.gguf")
+        subprocess.run([sys.executable, os.path.join(ROOT, "tools", "make_synth_gguf.py"), "--config", "8b", "--types", "q4_k_m", "-o", gguf], check=True, timeout=900,
+                       stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        env = dict(os.environ); env["GGML_BACKEND_PATH"] = lib
+        out = {"harness": "oracle/_ref/llama-bench-min (reference libllama + ggml_backend_sched, plug-in from GGML_BACKEND_PATH), -ngl 99 -p 512 -n 128 "
+                          f"-r {reps} -t {threads}, synthetic Qwen3-8B Q4_K_M GGUF"}
+        for fa in (0, 1):
+            r = subprocess.run([binp, "-m", gguf, "-ngl", "99", "-fa", str(fa), "-p", "512", "-n", "128", "-r", str(reps), "-t", str(threads)],
+                               env=env, capture_output=True, text=True, timeout=900)
+            if r.returncode != 0:
+                out[f"fa{fa}"] = {"error": r.stderr[-300:]}
+                continue
+            res = {}
+            for line in r.stdout.strip().splitlines():
+                j = json.loads(line)
+                res[j["test"] + "_tok_s"] = j["avg_ts"]; res[j["test"] + "_stddev"] = j["stddev_ts"]
+            splits = [ln for ln in r.stderr.splitlines() if "graph splits" in ln]
+            res["graph_splits"] = int(splits[-1].split("=")[-1]) if splits else None
+            out[f"fa{fa}"] = res
+        return out
+    except Exception as e:
+        return {"error": repr(e)}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def prefill_tok_s(pkg, be, model, n_tokens=512, reps=3):
     """llama-bench pp512 analogue: one ubatch of 512 tokens at depth 0 through the same backend (MFMA GEMM path for the mat-muls)."""
     g, I, logits = model.build(n_tokens, n_tokens, n_outputs=1)
@@ -472,6 +516,7 @@ def main():
     ap.add_argument("--no-fa", action="store_true")
     ap.add_argument("--c3", action="store_true", help="(default on at N = 1) BASELINE configs[2]: Qwen3-8B F16 prefill 8 x 2048 tokens (the `c3_f16_prefill` object)")
     ap.add_argument("--no-c3", action="store_true", help="skip the C3 leg")
+    ap.add_argument("--no-libllama", action="store_true", help="skip the via_libllama leg (the metric through the reference's libllama with this plug-in)")
     args = ap.parse_args()
 
     rep = Replicas()
@@ -552,6 +597,12 @@ def main():
                                         "ub16384": c3_prefill(pkg, be, tiny=args.tiny, one_ubatch=True)}
             except Exception as e:
                 out["c3_f16_prefill"] = {"error": repr(e)}
+        if world == 1 and not args.tiny and not args.no_libllama and not os.environ.get("MI355X_BENCH_NO_EXTRAS"):
+            be.synchronize()
+            out["via_libllama"] = via_libllama()
+            v = out["via_libllama"]
+            if v and isinstance(v.get("fa1"), dict) and v["fa1"].get("tg128_tok_s"):
+                v["tg128_fa1_over_value"] = round(v["fa1"]["tg128_tok_s"] / out["value"], 3)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(pkg, cfg, types, n_kv)
         else:

@@ -10,6 +10,7 @@
 #include "ggml_util.hpp"
 #include "kernels.hpp"
 #include "graph.hpp"
+#include <chrono>
 #include "shadow.hpp"
 
 #include <mutex>
@@ -177,6 +178,10 @@ static void be_free(ggml_backend_t b) {
         log_msg(GGML_LOG_LEVEL_INFO, "[mi355x] %s: graphs eager=%ld captured=%ld replayed=%ld, kernels in last graph=%ld\n", c->name.c_str(),
                 c->stat_eager, c->stat_captures, c->stat_replays, c->stat_kernels_last);
     if (getenv("MI355X_LOG_STATS"))
+        log_msg(GGML_LOG_LEVEL_INFO, "[mi355x] %s: host time inside the backend: graph_compute %ld calls %.1f us avg, set_tensor_async %ld calls %.2f us avg, get_tensor_async %ld calls %.2f us avg, synchronize %ld calls %.1f us avg (includes waiting for the device)\n",
+                c->name.c_str(), c->n_graph, c->n_graph ? c->host_ns_graph * 1e-3 / c->n_graph : 0.0, c->n_set, c->n_set ? c->host_ns_set * 1e-3 / c->n_set : 0.0, c->n_get, c->n_get ? c->host_ns_get * 1e-3 / c->n_get : 0.0,
+                c->n_sync, c->n_sync ? c->host_ns_sync * 1e-3 / c->n_sync : 0.0);
+    if (getenv("MI355X_LOG_STATS"))
         for (auto & kv : c->prof)                                         // per-class event timing (only filled in "profile" mode)
             log_msg(GGML_LOG_LEVEL_INFO, "[mi355x]   %-22s n=%8ld  total %10.1f us  avg %8.2f us\n", kv.first.c_str(), kv.second.n, kv.second.us, kv.second.n ? kv.second.us / kv.second.n : 0.0);
     backend_ctx_release(c);
@@ -187,6 +192,7 @@ static bool backend_is_ours(ggml_backend_t b);
 void flush_uploads(backend_ctx * c);
 // ---- small uploads: staged, then written by one launch (ggml_backend_tensor_set_async is how llama_decode hands over the five per-token inputs)
 static const size_t UP_HALF = 256 * 1024, UP_SMALL = 64 * 1024; static const int UP_MAX = 64;
+struct host_timer { uint64_t & acc; std::chrono::steady_clock::time_point t0; host_timer(uint64_t & a) : acc(a), t0(std::chrono::steady_clock::now()) {} ~host_timer() { acc += (uint64_t) std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count(); } };
 void flush_uploads(backend_ctx * c) {                     // everything staged so far goes onto the stream, in order, in front of what follows
     if (c->up_n == 0) return;
     const int h = c->up_half;
@@ -221,14 +227,14 @@ static bool stage_upload(backend_ctx * c, void * dst, const void * data, size_t 
     return true;
 }
 static void be_set_async(ggml_backend_t b, struct ggml_tensor * t, const void * data, size_t off, size_t sz) {
-    backend_ctx * c = (backend_ctx *) b->context; set_device(c->device);
+    backend_ctx * c = (backend_ctx *) b->context; host_timer ht(c->host_ns_set); ++c->n_set; set_device(c->device);
     shadow_invalidate(c->device, (char *) t->data + off, sz);
     if (stage_upload(c, (char *) t->data + off, data, sz)) return;
     flush_uploads(c);
     HIP_CHECK(hipMemcpyAsync((char *) t->data + off, data, sz, hipMemcpyHostToDevice, c->stream));
 }
 static void be_get_async(ggml_backend_t b, const struct ggml_tensor * t, void * data, size_t off, size_t sz) {
-    backend_ctx * c = (backend_ctx *) b->context; set_device(c->device);
+    backend_ctx * c = (backend_ctx *) b->context; host_timer ht(c->host_ns_get); ++c->n_get; set_device(c->device);
     flush_uploads(c);
     HIP_CHECK(hipMemcpyAsync(data, (const char *) t->data + off, sz, hipMemcpyDeviceToHost, c->stream));
 }
@@ -257,12 +263,12 @@ static bool be_cpy_async(ggml_backend_t bs, ggml_backend_t bd, const struct ggml
     return true;
 }
 static void be_sync(ggml_backend_t b) {
-    backend_ctx * c = (backend_ctx *) b->context; set_device(c->device);
+    backend_ctx * c = (backend_ctx *) b->context; host_timer ht(c->host_ns_sync); ++c->n_sync; set_device(c->device);
     flush_uploads(c);
     HIP_CHECK(hipStreamSynchronize(c->stream));
 }
 static enum ggml_status be_graph_compute(ggml_backend_t b, struct ggml_cgraph * g) {
-    backend_ctx * c = (backend_ctx *) b->context; set_device(c->device);
+    backend_ctx * c = (backend_ctx *) b->context; host_timer ht(c->host_ns_graph); ++c->n_graph; set_device(c->device);
     flush_uploads(c);
     return graph_compute(c, g);
 }

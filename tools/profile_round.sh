@@ -8,9 +8,9 @@ cd "$(dirname "$0")/.."
 export TMPDIR=/tmp MI355X_GRAPHS=0
 OUT=gpurun_out/prof_$TAG
 rm -rf "$OUT"; mkdir -p "$OUT"
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python bench.py --steps 32 --warmup 8 --no-cpu-baseline --no-c3 > "$OUT/bench_under_rocprof.json" 2> "$OUT/trace.err"
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python bench.py --steps 32 --warmup 8 --no-cpu-baseline --no-c3 --no-libllama > "$OUT/bench_under_rocprof.json" 2> "$OUT/trace.err"
 echo "trace rc=$?"
-MI355X_BENCH_NO_PP=1 timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/pmc" -- python bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-c3 > "$OUT/bench_under_pmc.json" 2> "$OUT/pmc.err"
+MI355X_BENCH_NO_PP=1 timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/pmc" -- python bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-c3 --no-libllama > "$OUT/bench_under_pmc.json" 2> "$OUT/pmc.err"
 echo "pmc rc=$?"
 find "$OUT" -name "*.csv" | head -20
 python3 - "$OUT" <<'PY'
