@@ -302,3 +302,49 @@ def test_8b_layer_by_layer_on_identical_inputs(tmp_path):
             assert e0 < bar, e0
     finally:
         os.remove(gguf)
+
+
+# ------------------------------------------------------------------------------------------------ the reference's omni encoders through the plug-in
+ENC = os.path.join(ROOT, "oracle", "_ref", "omni-enc-min")
+
+
+def _enc_min(module, gguf, out, gpu, extra, threads):
+    env = dict(os.environ)
+    env.pop("GGML_BACKEND_PATH", None)
+    env.pop("MTMD_BACKEND_DEVICE", None)
+    if gpu:
+        env["GGML_BACKEND_PATH"] = LIB
+        env["MTMD_BACKEND_DEVICE"] = "MI355X0"
+    r = subprocess.run([ENC, module, gguf, out, "--threads", str(threads)] + (["--gpu"] if gpu else []) + extra, env=env, capture_output=True, text=True, timeout=1800)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    if gpu:
+        assert "using MI355X0 backend" in (r.stdout + r.stderr), (r.stdout + r.stderr)[-3000:]        # audition.cpp:255 / vision.cpp's twin
+    return json.loads(r.stdout.strip().splitlines()[-1])
+
+
+@pytest.mark.parametrize("module,extra,n_tok", [("apm", ["--chunks", "3", "--frames", "100"], 30), ("vpm", ["--chunks", "2", "--size", "448x448"], 128)])
+def test_reference_omni_encoder_code_runs_on_the_plugin(tmp_path, module, extra, n_tok):
+    """SURVEY.md 8(f) rank 3/4 with the REFERENCE's graph builders instead of a mirror: tools/omni/audition.cpp (build_whisper :341-715 -- conv stem,
+    24 Whisper-medium blocks over the streaming K/V cache, avg-pool, audio projector) and tools/omni/vision.cpp (build_minicpmv :292-380 -- 27 SigLIP
+    blocks at 1024 patches, the 64-query resampler), compiled from /root/reference by oracle/Makefile.ref `omni`, load a full-size synthetic module GGUF
+    (tools/make_synth_omni_gguf.py, written the way convert_apm.py / convert_vpm.py lay it out) and run it through ggml_backend_sched once on the CPU
+    backend and once on the plug-in (MTMD_BACKEND_DEVICE=MI355X0).  Bar: NMSE of every chunk's embeddings <= 5e-4 (f16 weights; the CPU backend rounds
+    the activations to f16 for its f16 dot products, the plug-in's MFMA GEMM does the same, the accumulation orders differ)."""
+    if not os.path.exists(ENC):
+        pytest.skip("oracle/_ref/omni-enc-min not built (make -f oracle/Makefile.ref omni)")
+    gguf = str(tmp_path / f"{module}.gguf")
+    subprocess.run([sys.executable, os.path.join(ROOT, "tools", "make_synth_omni_gguf.py"), "--module", module, "-o", gguf], check=True, timeout=900)
+    threads = max(4, min(48, len(os.sched_getaffinity(0)) // 2))
+    try:
+        co, go = str(tmp_path / "c.bin"), str(tmp_path / "g.bin")
+        jc = _enc_min(module, gguf, co, False, extra, threads)
+        jg = _enc_min(module, gguf, go, True, extra, threads)
+        assert jc["tokens"] == jg["tokens"] == n_tok and jc["n_embd"] == 4096
+        c = np.fromfile(co, np.float32).reshape(n_tok, 4096); g = np.fromfile(go, np.float32).reshape(n_tok, 4096)
+        assert np.isfinite(g).all() and float(c.std()) > 0.05
+        n_chunks = int(extra[1]); per = n_tok // n_chunks
+        errs = [float(((g[i * per:(i + 1) * per] - c[i * per:(i + 1) * per]) ** 2).sum() / (c[i * per:(i + 1) * per] ** 2).sum()) for i in range(n_chunks)]
+        print(f"{module}: NMSE per chunk {errs}; cpu {jc['ms_last_chunk']:.1f} ms/chunk ({threads} threads), plug-in {jg['ms_last_chunk']:.2f} ms/chunk")
+        assert max(errs) <= 5e-4, errs
+    finally:
+        os.remove(gguf)

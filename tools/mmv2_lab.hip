@@ -90,9 +90,9 @@ int main(int argc, char ** argv) {
     k_fill<<<4096, 256, 0, st>>>((uint32_t *) a4, ARENA / 4, 1u); k_fill<<<4096, 256, 0, st>>>((uint32_t *) a6, ARENA / 4, 2u);
     k_fix_scales<<<4096, 256, 0, st>>>(a4, ARENA / 144, 144, 0, 2); k_fix_scales<<<4096, 256, 0, st>>>(a6, ARENA / 210, 210, 208, 1);
     float * x, * nw, * resid, * out_a, * out_b;
-    HIP_CHECK(hipMalloc(&x, 12288 * 4)); HIP_CHECK(hipMalloc(&nw, 12288 * 4)); HIP_CHECK(hipMalloc(&resid, 160000 * 4));
-    HIP_CHECK(hipMalloc(&out_a, 160000 * 4)); HIP_CHECK(hipMalloc(&out_b, 160000 * 4));
-    k_fill_f32<<<64, 256, 0, st>>>(x, 12288, 11u, 1.0f); k_fill_f32<<<64, 256, 0, st>>>(nw, 12288, 12u, 1.0f); k_fill_f32<<<64, 256, 0, st>>>(resid, 160000, 13u, 1.0f);
+    HIP_CHECK(hipMalloc(&x, 12288 * 4)); HIP_CHECK(hipMalloc(&nw, 12288 * 4)); HIP_CHECK(hipMalloc(&resid, 230000 * 4));
+    HIP_CHECK(hipMalloc(&out_a, 230000 * 4)); HIP_CHECK(hipMalloc(&out_b, 230000 * 4));
+    k_fill_f32<<<64, 256, 0, st>>>(x, 12288, 11u, 1.0f); k_fill_f32<<<64, 256, 0, st>>>(nw, 12288, 12u, 1.0f); k_fill_f32<<<64, 256, 0, st>>>(resid, 230000, 13u, 1.0f);
 #ifdef MV2_TRACE
     HIP_CHECK(hipMalloc(&trace_dev, 8192 * 8 * 8));
     HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(mv2_trace_buf), &trace_dev, sizeof trace_dev));
@@ -108,6 +108,7 @@ int main(int argc, char ** argv) {
         { "wo Q4_K 4096x4096 (9.4 MB) + resid",              4096, 1, { 4096, 0, 0 }, { Q4, 0, 0 }, false, false, true },
         { "down Q4_K 4096x12288 (28.3 MB) + resid",          12288, 1, { 4096, 0, 0 }, { Q4, 0, 0 }, false, false, true },
         { "big Q4_K 151936x4096 (350 MB) + norm",            4096, 1, { 151936, 0, 0 }, { Q4, 0, 0 }, false, true, false },
+        { "huge Q4_K 225280x4096 (519 MB) + norm",           4096, 1, { 225280, 0, 0 }, { Q4, 0, 0 }, false, true, false },
         { "down Q6_K 4096x12288 (41.3 MB) + resid",          12288, 1, { 4096, 0, 0 }, { Q6, 0, 0 }, false, false, true },
         { "lm-head Q6_K 151936x4096 (510 MB) + norm",        4096, 1, { 151936, 0, 0 }, { Q6, 0, 0 }, false, true, false },
     };
