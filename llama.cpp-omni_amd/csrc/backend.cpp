@@ -181,6 +181,9 @@ static void be_free(ggml_backend_t b) {
         log_msg(GGML_LOG_LEVEL_INFO, "[mi355x] %s: host time inside the backend: graph_compute %ld calls %.1f us avg, set_tensor_async %ld calls %.2f us avg, get_tensor_async %ld calls %.2f us avg, synchronize %ld calls %.1f us avg (includes waiting for the device)\n",
                 c->name.c_str(), c->n_graph, c->n_graph ? c->host_ns_graph * 1e-3 / c->n_graph : 0.0, c->n_set, c->n_set ? c->host_ns_set * 1e-3 / c->n_set : 0.0, c->n_get, c->n_get ? c->host_ns_get * 1e-3 / c->n_get : 0.0,
                 c->n_sync, c->n_sync ? c->host_ns_sync * 1e-3 / c->n_sync : 0.0);
+    if (getenv("MI355X_LOG_STATS") && c->stat_eager)
+        log_msg(GGML_LOG_LEVEL_INFO, "[mi355x] %s: eager graphs: %.1f us avg walking the nodes and enqueueing (%ld launches, %.2f us per launch)\n", c->name.c_str(),
+                c->host_ns_eager_run * 1e-3 / c->stat_eager, c->n_eager_kernels, c->n_eager_kernels ? c->host_ns_eager_run * 1e-3 / c->n_eager_kernels : 0.0);
     if (getenv("MI355X_LOG_STATS"))
         for (auto & kv : c->prof)                                         // per-class event timing (only filled in "profile" mode)
             log_msg(GGML_LOG_LEVEL_INFO, "[mi355x]   %-22s n=%8ld  total %10.1f us  avg %8.2f us\n", kv.first.c_str(), kv.second.n, kv.second.us, kv.second.n ? kv.second.us / kv.second.n : 0.0);

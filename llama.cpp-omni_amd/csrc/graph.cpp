@@ -13,6 +13,7 @@
 //                         same buffers, only input *data* changes) is captured on its second submission and
 //                         replayed afterwards -- ~10 us of host time per token instead of ~3.5 us per kernel
 #include "graph.hpp"
+#include <chrono>
 #include "ggml_util.hpp"
 #include "kernels.hpp"
 #include "shadow.hpp"
@@ -297,6 +298,9 @@ static bool mm_uses_gemm(const ggml_tensor * n) {
     const int64_t K = w->ne[0];
     if (K % 32 != 0) return false;
     if (w->type == GGML_TYPE_F16 && (w->nb[1] % 16 != 0 || w->nb[2] % 16 != 0 || w->nb[3] % 16 != 0 || ((uintptr_t) w->data & 15) != 0)) return false;
+    // per-head products (an encoder's V^T . P over a growing K/V cache: K = 50, 100, ... positions): the DMA GEMM batches heads only at K % 64 == 0 and would
+    // otherwise go out head by head (Whisper streaming chunk 16, K = 800: 384 extra launches); the any-shape f16 kernel takes every head in one launch
+    if (w->type == GGML_TYPE_F16 && x->ne[2] * x->ne[3] > 1 && K % 64 != 0 && x->type == GGML_TYPE_F32 && x->ne[2] * x->ne[3] <= 65535) return false;
     return true;
 }
 // MUL_MAT that op_mul_mat sends to the any-shape GEMM's f16 kernel (gemm_any.hip k_gemm_any_h): F16 weights the DMA GEMMs do not take (odd K,
@@ -2327,7 +2331,9 @@ enum ggml_status graph_compute(backend_ctx * c, ggml_cgraph * g) {
     }
 
     exec_state s; s.c = c; s.st = c->stream;
+    const auto t_run = std::chrono::steady_clock::now();
     run_nodes(s, g);
+    c->host_ns_eager_run += (uint64_t) std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t_run).count(); c->n_eager_kernels += s.n_kernels;
     c->stat_eager++; c->stat_kernels_last = s.n_kernels;
     if (c->opt_profile) prof_drain(c);
     return GGML_STATUS_SUCCESS;

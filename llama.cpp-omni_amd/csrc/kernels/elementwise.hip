@@ -451,7 +451,7 @@ __global__ void __launch_bounds__(256) k_norm_rows(td4 x, td4 y, float eps, int6
 bool norm_rows_ok(const tdesc & x, const tdesc & y) {
     auto al16 = [](const tdesc & t) { return ((uintptr_t) t.p & 15) == 0 && t.nb[0] == 4 && t.nb[1] % 16 == 0 && t.nb[2] % 16 == 0 && t.nb[3] % 16 == 0; };
     const int64_t n = x.ne[0], nrows = x.ne[1] * x.ne[2] * x.ne[3];
-    return nrows >= 64 && n > 0 && n % 4 == 0 && n <= 4096 && al16(x) && al16(y);
+    return nrows >= 2 && n > 0 && n % 4 == 0 && n <= 4096 && al16(x) && al16(y);
 }
 // LayerNorm rows with the following MUL (w) / ADD (b) by [n] vectors folded in and, optionally, the f16 image of the result (write_f32 false: only that)
 void norm_rows_f32(const tdesc & x, const tdesc & y, float eps, const float * w, const float * b, uint16_t * y16, size_t y16_rs, bool write_f32, hipStream_t st) {

@@ -822,7 +822,16 @@ static void allow_big_lds(const void * kernel, int bytes, int slot) {
 // a launch is then 32 .. 192 tiles whose 64 .. 192-step K loops run one after the other on a fraction of the CUs and the time is that loop's
 // latency, not bandwidth or flops -- split up to 8 ways, down to 8 K-steps per workgroup
 static int pick_ksplit(int64_t tiles, int64_t nk, int64_t N) {
-    if (tiles >= 256 || nk < 32) return 1;
+    if (tiles >= 256) return 1;
+    if (nk < 32) {
+        // short K (the omni encoders: 1024 / 1152): worth splitting only when the launch is a handful of workgroups -- a streaming audio chunk is 50 columns,
+        // wq at 128 x 128 is 8 workgroups, each bound by what ONE CU can pull (~1.5 us per 64-deep K-step: measured 25 us for 2 MB of weights)
+        static const bool off = getenv("MI355X_NO_SHORT_K_SPLIT") != nullptr;
+        if (off || tiles > 64 || nk < 4 || N > 128) return 1;
+        int s = (int) (nk / 2); if (s > 8) s = 8;
+        while (s > 1 && tiles * s > 512) --s;
+        return s < 1 ? 1 : s;
+    }
     const int smax = N <= 256 ? 8 : 4, min_steps = N <= 256 ? 8 : 16;
     static const int64_t target = getenv("MI355X_GEMM_SPLIT_TARGET") ? atoll(getenv("MI355X_GEMM_SPLIT_TARGET")) : 512;
     int s = (int) (target / tiles);
@@ -836,6 +845,7 @@ size_t gemm_split_scratch_bytes(int64_t M, int64_t N, int64_t K) {
     const int64_t tiles = ((M + G_BM - 1) / G_BM) * ((N + G_BN - 1) / G_BN);
     int s = pick_ksplit(tiles, K / H_BK, N);
     if (N <= 256 && tiles < 256 && K / H_BK >= 32) s = 8;     // (a group's tile count may differ by a few tiles from this estimate)
+    if (N <= 128 && tiles <= 72 && K / H_BK >= 4 && K / H_BK < 32) s = 8;
     return s > 1 ? (size_t) s * (size_t) M * (size_t) N * 4 : 0;
 }
 

@@ -237,7 +237,10 @@ void gemm_any(const gemm_any_args & a, hipStream_t st) {
     g.dst = (char *) a.dst; g.dst_cs = a.dst_cs; g.dst_nb2 = a.dst_nb2; g.dst_nb3 = a.dst_nb3;
     g.M = (int) a.M; g.N = (int) a.N; g.K = (int) a.K; g.tiles_m = (int) ((a.M + 63) / 64); g.ne12 = a.ne12; g.r2 = a.r2; g.r3 = a.r3; g.round_x = a.w_bf16 ? 2 : (a.w_f16 ? 1 : 0); g.accumulate = a.accumulate ? 1 : 0; g.bias = a.bias;
     static const bool no_sk = getenv("MI355X_GEMM_ANY_NO_SPLIT") != nullptr;
-    if (!no_sk && (int64_t) g.tiles_m * ((a.N + 63) / 64) * a.nbatch < 128 && a.K >= 256) {          // few tiles, long chains: one 32 x 32 tile per workgroup, K split over its waves
+    // (F16 weights have the f16 matrix cores below -- 8x the K per MFMA, paired loads: their chains are short without a split; measured on Whisper's
+    //  V^T . P of a streaming chunk, 64 x 50 x 400 x 16 heads: 24 us here, 6 us there)
+    const bool h_path = a.w_f16 && !a.w_bf16 && !getenv("MI355X_NO_GEMM_ANY_H") && a.K < 2048;
+    if (!no_sk && !h_path && (int64_t) g.tiles_m * ((a.N + 63) / 64) * a.nbatch < 128 && a.K >= 256) {          // few tiles, long chains: one 32 x 32 tile per workgroup, K split over its waves
         g.tiles_m = (int) ((a.M + 31) / 32);
         const dim3 grid((unsigned) (g.tiles_m * ((a.N + 31) / 32)), (unsigned) a.nbatch);
         if (a.x_f16)      k_gemm_any_sk<uint16_t, uint16_t><<<grid, dim3(256), 0, st>>>(g);

@@ -315,20 +315,23 @@ def _enc_min(module, gguf, out, gpu, extra, threads):
     if gpu:
         env["GGML_BACKEND_PATH"] = LIB
         env["MTMD_BACKEND_DEVICE"] = "MI355X0"
+        env["MI355X_LOG_STATS"] = "1"
     r = subprocess.run([ENC, module, gguf, out, "--threads", str(threads)] + (["--gpu"] if gpu else []) + extra, env=env, capture_output=True, text=True, timeout=1800)
     assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
     if gpu:
-        assert "using MI355X0 backend" in (r.stdout + r.stderr), (r.stdout + r.stderr)[-3000:]        # audition.cpp:255 / vision.cpp's twin
+        import re                                          # the plug-in's own account of what it ran (printed when the encoder frees its backend)
+        m = re.search(r"\[mi355x\] MI355X0: graphs eager=(\d+) captured=(\d+) replayed=(\d+), kernels in last graph=(\d+)", r.stdout + r.stderr)
+        assert m and int(m.group(1)) + int(m.group(2)) + int(m.group(3)) >= 2 and int(m.group(4)) > 100, (r.stdout + r.stderr)[-3000:]
     return json.loads(r.stdout.strip().splitlines()[-1])
 
 
-@pytest.mark.parametrize("module,extra,n_tok", [("apm", ["--chunks", "3", "--frames", "100"], 30), ("vpm", ["--chunks", "2", "--size", "448x448"], 128)])
+@pytest.mark.parametrize("module,extra,n_tok", [("apm", ["--chunks", "17", "--frames", "100"], 170), ("vpm", ["--chunks", "2", "--size", "448x448"], 128)])
 def test_reference_omni_encoder_code_runs_on_the_plugin(tmp_path, module, extra, n_tok):
     """SURVEY.md 8(f) rank 3/4 with the REFERENCE's graph builders instead of a mirror: tools/omni/audition.cpp (build_whisper :341-715 -- conv stem,
     24 Whisper-medium blocks over the streaming K/V cache, avg-pool, audio projector) and tools/omni/vision.cpp (build_minicpmv :292-380 -- 27 SigLIP
     blocks at 1024 patches, the 64-query resampler), compiled from /root/reference by oracle/Makefile.ref `omni`, load a full-size synthetic module GGUF
     (tools/make_synth_omni_gguf.py, written the way convert_apm.py / convert_vpm.py lay it out) and run it through ggml_backend_sched once on the CPU
-    backend and once on the plug-in (MTMD_BACKEND_DEVICE=MI355X0).  Bar: NMSE of every chunk's embeddings <= 5e-4 (f16 weights; the CPU backend rounds
+    backend and once on the plug-in (MTMD_BACKEND_DEVICE=MI355X0).  Bar: NMSE of every chunk's embeddings <= 5e-6 (f16 weights; the CPU backend rounds
     the activations to f16 for its f16 dot products, the plug-in's MFMA GEMM does the same, the accumulation orders differ)."""
     if not os.path.exists(ENC):
         pytest.skip("oracle/_ref/omni-enc-min not built (make -f oracle/Makefile.ref omni)")
@@ -344,7 +347,7 @@ def test_reference_omni_encoder_code_runs_on_the_plugin(tmp_path, module, extra,
         assert np.isfinite(g).all() and float(c.std()) > 0.05
         n_chunks = int(extra[1]); per = n_tok // n_chunks
         errs = [float(((g[i * per:(i + 1) * per] - c[i * per:(i + 1) * per]) ** 2).sum() / (c[i * per:(i + 1) * per] ** 2).sum()) for i in range(n_chunks)]
-        print(f"{module}: NMSE per chunk {errs}; cpu {jc['ms_last_chunk']:.1f} ms/chunk ({threads} threads), plug-in {jg['ms_last_chunk']:.2f} ms/chunk")
-        assert max(errs) <= 5e-4, errs
+        print(f"{module}: plug-in ms per chunk {jg.get('ms_chunks')}"); print(f"{module}: NMSE per chunk {['%.1e' % e for e in errs]}; cpu {jc['ms_last_chunk']:.1f} ms/chunk ({threads} threads), plug-in {jg['ms_last_chunk']:.2f} ms/chunk")
+        assert max(errs) <= 5e-6, errs                      # measured 1e-7 (apm) and 7e-8 (vpm)
     finally:
         os.remove(gguf)

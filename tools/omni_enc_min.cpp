@@ -67,7 +67,7 @@ int main(int argc, char ** argv) {
     if (!ctx) { fprintf(stderr, "audition_init failed\n"); return 1; }
     const int n_embd = audition_n_mmproj_embd(ctx);
     FILE * f = fopen(out.c_str(), "wb");
-    double ms_total = 0, ms_last = 0; int n_tok_total = 0;
+    double ms_total = 0, ms_last = 0; int n_tok_total = 0; std::string per_chunk;
     for (int c = 0; c < chunks; ++c) {
         audition_audio_f32 audio; audio.nx = frames; audio.ny = 80; audio.buf.resize((size_t) frames * 80);
         for (float & x : audio.buf) x = lcg_unit();
@@ -77,11 +77,12 @@ int main(int argc, char ** argv) {
         if (!audition_audio_encode(ctx, threads, &audio, vec.data())) { fprintf(stderr, "audition_audio_encode failed\n"); return 1; }
         ms_last = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); ms_total += ms_last;
         fwrite(vec.data(), sizeof(float), vec.size(), f);
+        char b[32]; snprintf(b, sizeof b, "%s%.2f", c ? ", " : "", ms_last); per_chunk += b;
         n_tok_total += n_tok;
     }
     fclose(f);
-    printf("{\"module\": \"apm\", \"gpu\": %s, \"chunks\": %d, \"frames\": %d, \"n_embd\": %d, \"tokens\": %d, \"ms_per_chunk\": %.3f, \"ms_last_chunk\": %.3f}\n",
-           gpu ? "true" : "false", chunks, frames, n_embd, n_tok_total, ms_total / chunks, ms_last);
+    printf("{\"module\": \"apm\", \"gpu\": %s, \"chunks\": %d, \"frames\": %d, \"n_embd\": %d, \"tokens\": %d, \"ms_per_chunk\": %.3f, \"ms_last_chunk\": %.3f, \"ms_chunks\": [%s]}\n",
+           gpu ? "true" : "false", chunks, frames, n_embd, n_tok_total, ms_total / chunks, ms_last, per_chunk.c_str());
     audition_free(ctx);
     return 0;
 }
