@@ -10,6 +10,7 @@
 #include "ggml_util.hpp"
 #include "kernels.hpp"
 #include "graph.hpp"
+#include <atomic>
 #include <chrono>
 #include "shadow.hpp"
 
@@ -85,13 +86,22 @@ static void buf_memset_tensor(ggml_backend_buffer_t b, struct ggml_tensor * t, u
     HIP_CHECK(hipMemsetAsync((char *) t->data + off, v, sz, hipStreamPerThread));
     HIP_CHECK(hipStreamSynchronize(hipStreamPerThread));
 }
+// blocking buffer-level transfers (ggml_backend_tensor_set / _get: model load, the omni encoders' inputs and outputs): bytes and host time, for the MI355X_LOG_STATS account
+static std::atomic<uint64_t> g_buf_set_ns{0}, g_buf_set_bytes{0}, g_buf_set_n{0}, g_buf_get_ns{0}, g_buf_get_bytes{0}, g_buf_get_n{0};
+struct buf_timer {
+    std::atomic<uint64_t> & ns; std::chrono::steady_clock::time_point t0;
+    buf_timer(std::atomic<uint64_t> & a, std::atomic<uint64_t> & bytes, std::atomic<uint64_t> & n, size_t sz) : ns(a), t0(std::chrono::steady_clock::now()) { bytes += sz; ++n; }
+    ~buf_timer() { ns += (uint64_t) std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count(); }
+};
 static void buf_set_tensor(ggml_backend_buffer_t b, struct ggml_tensor * t, const void * data, size_t off, size_t sz) {
+    buf_timer bt(g_buf_set_ns, g_buf_set_bytes, g_buf_set_n, sz);
     buffer_ctx * c = (buffer_ctx *) b->context; set_device(c->device);
     shadow_invalidate(c->device, (char *) t->data + off, sz);
     HIP_CHECK(hipMemcpyAsync((char *) t->data + off, data, sz, hipMemcpyHostToDevice, hipStreamPerThread));
     HIP_CHECK(hipStreamSynchronize(hipStreamPerThread));
 }
 static void buf_get_tensor(ggml_backend_buffer_t b, const struct ggml_tensor * t, void * data, size_t off, size_t sz) {
+    buf_timer bt(g_buf_get_ns, g_buf_get_bytes, g_buf_get_n, sz);
     buffer_ctx * c = (buffer_ctx *) b->context; set_device(c->device);
     HIP_CHECK(hipMemcpyAsync(data, (const char *) t->data + off, sz, hipMemcpyDeviceToHost, hipStreamPerThread));
     HIP_CHECK(hipStreamSynchronize(hipStreamPerThread));
@@ -181,6 +191,9 @@ static void be_free(ggml_backend_t b) {
         log_msg(GGML_LOG_LEVEL_INFO, "[mi355x] %s: host time inside the backend: graph_compute %ld calls %.1f us avg, set_tensor_async %ld calls %.2f us avg, get_tensor_async %ld calls %.2f us avg, synchronize %ld calls %.1f us avg (includes waiting for the device)\n",
                 c->name.c_str(), c->n_graph, c->n_graph ? c->host_ns_graph * 1e-3 / c->n_graph : 0.0, c->n_set, c->n_set ? c->host_ns_set * 1e-3 / c->n_set : 0.0, c->n_get, c->n_get ? c->host_ns_get * 1e-3 / c->n_get : 0.0,
                 c->n_sync, c->n_sync ? c->host_ns_sync * 1e-3 / c->n_sync : 0.0);
+    if (getenv("MI355X_LOG_STATS"))
+        log_msg(GGML_LOG_LEVEL_INFO, "[mi355x] blocking buffer transfers (process-wide): tensor_set %lu calls %.1f MB %.1f ms, tensor_get %lu calls %.1f MB %.1f ms\n",
+                (unsigned long) g_buf_set_n.load(), g_buf_set_bytes.load() * 1e-6, g_buf_set_ns.load() * 1e-6, (unsigned long) g_buf_get_n.load(), g_buf_get_bytes.load() * 1e-6, g_buf_get_ns.load() * 1e-6);
     if (getenv("MI355X_LOG_STATS") && c->stat_eager)
         log_msg(GGML_LOG_LEVEL_INFO, "[mi355x] %s: eager graphs: %.1f us avg walking the nodes and enqueueing (%ld launches, %.2f us per launch)\n", c->name.c_str(),
                 c->host_ns_eager_run * 1e-3 / c->stat_eager, c->n_eager_kernels, c->n_eager_kernels ? c->host_ns_eager_run * 1e-3 / c->n_eager_kernels : 0.0);
