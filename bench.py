@@ -92,62 +92,126 @@ class Decoder:
         be.synchronize()
 
 
-def cpu_baseline(pkg, cfg, types, n_kv, seconds_budget=24.0):
+def _cpu_order(allowed):
+    """The allowed logical CPUs in the order threads should be added: one per physical core first, the NUMA node this thread runs on (where its
+    allocations are first-touched) before the other nodes, round-robin over the node's L3 domains (a CCD's link to memory carries ~60 GB/s: eight
+    threads on one CCD get less than eight threads on eight), hyper-thread siblings last."""
+    import ctypes
+    import glob
+    try:
+        here = ctypes.CDLL(None).sched_getcpu()
+    except Exception:
+        here = allowed[0]
+    info = {}
+    for c in allowed:
+        base = f"/sys/devices/system/cpu/cpu{c}"
+        try:
+            pkg_id = int(open(base + "/topology/physical_package_id").read()); core = int(open(base + "/topology/core_id").read())
+        except Exception:
+            pkg_id, core = 0, c
+        nodes = glob.glob(base + "/node*")
+        node = int(os.path.basename(nodes[0])[4:]) if nodes else pkg_id
+        try:
+            l3 = open(base + "/cache/index3/shared_cpu_list").read().strip()
+        except Exception:
+            l3 = str(pkg_id)
+        info[c] = (node, pkg_id, core, l3)
+    home = info.get(here, info[allowed[0]])
+    first, rest, seen = [], [], set()
+    node_list = sorted({v[0] for v in info.values()}, key=lambda n: (n != home[0], n))
+    for n in node_list:
+        groups = {}
+        for c in sorted(allowed):
+            if info[c][0] == n:
+                groups.setdefault(info[c][3], []).append(c)
+        cores, sibs = [], []
+        for g in groups.values():                                  # per L3 domain: one CPU per physical core, then its siblings
+            gc, gs = [], []
+            for c in g:
+                key = info[c][1:3]
+                (gs if key in seen else gc).append(c)
+                seen.add(key)
+            cores.append(gc); sibs.append(gs)
+        for lst, dst in ((cores, first), (sibs, rest)):
+            i = 0
+            while any(lst):
+                if lst[i % len(lst)]:
+                    dst.append(lst[i % len(lst)].pop(0))
+                i += 1
+    return first + rest, {"home_node": home[0], "nodes": len(node_list), "l3_domains": len({v[3] for v in info.values()}), "physical_cores": len(first)}
+
+
+def _cpu_baseline_worker(pkg, cfg, types, n_kv, th, seconds):
+    """One thread count, in a process of its own (started by cpu_baseline with OMP_PLACES / OMP_PROC_BIND in the environment, so the reference
+    backend's OpenMP team is pinned one thread per listed CPU from its first parallel region)."""
+    sys.path.insert(0, ROOT)
+    from oracle.ref_backend import make_ref_cpu_backend, ref_variant
+    be = make_ref_cpu_backend(pkg, th)
+    dec = Decoder(pkg, be, cfg, types, n_ctx=n_kv, n_kv=n_kv, flash_attn=True, pinned=False)
+    wbytes = dec.model.weight_bytes()
+    t0 = time.perf_counter()
+    dec.step(0)                                                  # warm-up (page-in, team start)
+    pilot = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    dec.step(1)
+    pilot = min(pilot, time.perf_counter() - t0)
+    n, pos = 0, 2
+    t0 = time.perf_counter()
+    while n < 48 and (time.perf_counter() - t0) < seconds and (n < 2 or pilot < 2.0):
+        dec.step(pos); pos += 1; n += 1
+    dt = time.perf_counter() - t0
+    be.close()
+    return {"tok_s": n / dt if n else 1.0 / pilot, "steps": n, "wbytes": wbytes, "build": ref_variant()[0]}
+
+
+def cpu_baseline(pkg, cfg, types, n_kv, seconds_budget=24.0, tiny=False):
     """Reference CPU backend (oracle/_ref, built from /root/reference sources) on the SAME decode graph, timed on this box's host
     cores for a bounded sample.  Thread counts come from the cores this process may actually run on (sched_getaffinity: a cgroup /
     affinity mask smaller than the machine would otherwise be oversubscribed); an ascending sweep up to that count is timed and the best is
-    reported together with the bandwidth it implies."""
+    reported together with the bandwidth it implies.  Each count runs in its own process with the OpenMP team pinned one thread per CPU
+    (OMP_PLACES lists the CPUs in _cpu_order: one per physical core, this process's NUMA node first, round-robin over its L3 domains):
+    a team floating over all allowed CPUs peaked at 16 threads / 175-195 GB/s on the 2 x 64-core box and lost half of that at 32."""
+    import subprocess
     try:
         sys.path.insert(0, ROOT)
-        from oracle.ref_backend import make_ref_cpu_backend, ref_available
+        from oracle.ref_backend import ref_available
         if not ref_available():
             return None
         allowed = sorted(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else list(range(os.cpu_count() or 1))
         n_aff = len(allowed)
-        phys = set()
-        try:  # physical cores among the allowed CPUs: unique (package, core) pairs
-            for c in allowed:
-                p = f"/sys/devices/system/cpu/cpu{c}/topology"
-                phys.add((open(p + "/physical_package_id").read().strip(), open(p + "/core_id").read().strip()))
-        except Exception:
-            phys = set()
-        n_phys = len(phys) if phys else n_aff
-        # ascending sweep, stopped at the first thread count that is slower than the one before (an oversubscribed pool of spinning
-        # ggml workers can be 100x slower: one step at 256 threads took 90 s on a 256-CPU box whose best was 64) -- the pilot step of
-        # each count is what bounds the time, a slow one ends the sweep
-        cands = sorted({c for c in (8, 16, 32, 64, max(1, n_phys // 2), n_phys, n_aff) if 1 <= c <= n_aff})
-        wbytes = None
-        results = []
-        be = make_ref_cpu_backend(pkg, cands[0])
-        dec = Decoder(pkg, be, cfg, types, n_ctx=n_kv, n_kv=n_kv, flash_attn=True, pinned=False)
-        wbytes = dec.model.weight_bytes()
-        dec.step(0)                                              # warm-up (page-in, thread pool)
-        pos = 1
-        per = seconds_budget / 4
+        order, topo = _cpu_order(allowed)
+        n_phys = topo["physical_cores"]
+        per_node = max(1, n_phys // max(1, topo["nodes"]))
+        pin = os.environ.get("MI355X_CPU_BASELINE_NO_PIN") is None
+        cands = sorted({c for c in (8, 16, 24, 32, 48, 64, per_node, n_phys) if 1 <= c <= n_phys})
+        results, build, wbytes = [], None, None
+        t_start = time.perf_counter()
         for th in cands:
-            be.set_n_threads(th)
-            t0 = time.perf_counter()
-            dec.step(pos); pos += 1                              # pilot: thread-pool resize outside the timed region
-            pilot = time.perf_counter() - t0
-            if results and pilot > 3.0 / max(results)[0]:        # 3x slower than the best so far: past the knee
-                results.append((1.0 / pilot, th, 1))
+            env = dict(os.environ)
+            env["ORACLE_REF_VARIANT"] = "v4"                      # the AVX-512 build of the same sources when this host has the level (oracle/ref_backend.py)
+            env["OMP_NUM_THREADS"] = str(th)
+            if pin:
+                env["OMP_PLACES"] = ",".join("{%d}" % c for c in order[:th]); env["OMP_PROC_BIND"] = "true"
+            cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker", str(th), "--cpu-baseline-seconds", str(seconds_budget / 4)] + (["--tiny"] if tiny else [])
+            r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+            if r.returncode != 0:
+                results.append((0.0, th, 0)); break
+            d = json.loads(r.stdout.strip().splitlines()[-1])
+            build, wbytes = d["build"], d["wbytes"]
+            results.append((d["tok_s"], th, d["steps"]))
+            # ascending sweep, stopped past the knee (an oversubscribed team of spinning workers can be 100x slower) or when the budget is used up
+            if len(results) >= 2 and results[-1][0] < 0.8 * max(results[:-1])[0]:
                 break
-            t0 = time.perf_counter()
-            n = 0
-            while n < 48 and (time.perf_counter() - t0) < per:
-                dec.step(pos); pos += 1; n += 1
-            dt = time.perf_counter() - t0
-            results.append((n / dt, th, n))
-            if len(results) >= 2 and results[-1][0] < 0.8 * results[-2][0]:
+            if time.perf_counter() - t_start > 3 * seconds_budget:
                 break
-        be.close()
         best = max(results)
         return {"value": round(best[0], 3), "unit": "tok/s", "cores": best[1], "kind": "reference",
-                "gb_per_s": round(best[0] * wbytes / 1e9, 1),
+                "gb_per_s": round(best[0] * wbytes / 1e9, 1) if wbytes else None,
                 "allowed_cpus": n_aff, "physical_cores_allowed": n_phys,
                 "thread_sweep_tok_s": {str(th): round(v, 3) for v, th, _ in results},
-                "sample": f"{best[2]} decode steps of the same Qwen3-8B Q4_K_M graph on the reference ggml CPU backend (oracle/_ref, x86-64-v3 build, "
-                          f"its own thread pool), best of the thread sweep over the {n_aff} CPUs this process is allowed on"}
+                "build": build, "placement": ("one pinned thread per CPU (OMP_PLACES): one per physical core, home NUMA node first, round-robin over its L3 domains" if pin else "unpinned"), "topology": topo,
+                "sample": f"{best[2]} decode steps of the same Qwen3-8B Q4_K_M graph on the reference ggml CPU backend (oracle/_ref, {build} build, "
+                          f"its own OpenMP team), best of the thread sweep over the {n_phys} physical cores this process is allowed on"}
     except Exception as e:  # the baseline is a reported extra, never a reason to lose the GPU number
         return {"value": None, "unit": "tok/s", "cores": 0, "kind": "reference", "sample": f"failed: {e!r}"}
 
@@ -512,6 +576,9 @@ def main():
     ap.add_argument("--steps", type=int, default=128)
     ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-only", action="store_true", help="print only the cpu_baseline object (no GPU work)")
+    ap.add_argument("--cpu-baseline-worker", type=int, default=0, help=argparse.SUPPRESS)
+    ap.add_argument("--cpu-baseline-seconds", type=float, default=6.0, help=argparse.SUPPRESS)
     ap.add_argument("--tiny", action="store_true", help="tiny shapes (plumbing check)")
     ap.add_argument("--no-fa", action="store_true")
     ap.add_argument("--c3", action="store_true", help="(default on at N = 1) BASELINE configs[2]: Qwen3-8B F16 prefill 8 x 2048 tokens (the `c3_f16_prefill` object)")
@@ -519,6 +586,15 @@ def main():
     ap.add_argument("--no-libllama", action="store_true", help="skip the via_libllama leg (the metric through the reference's libllama with this plug-in)")
     args = ap.parse_args()
 
+    if args.cpu_baseline_only or args.cpu_baseline_worker:
+        pkg = load_pkg()
+        from llama_cpp_omni_amd import qwen3
+        cfg = qwen3.TINY if args.tiny else qwen3.QWEN3_8B
+        if args.cpu_baseline_worker:
+            print(json.dumps(_cpu_baseline_worker(pkg, cfg, qwen3.q4_k_m_types(cfg), 256, args.cpu_baseline_worker, args.cpu_baseline_seconds)), flush=True)
+        else:
+            print(json.dumps(cpu_baseline(pkg, cfg, qwen3.q4_k_m_types(cfg), 256, tiny=args.tiny)), flush=True)
+        return
     rep = Replicas()
     world, rank = rep.world, rep.rank
     pkg = load_pkg()
@@ -604,7 +680,7 @@ def main():
             if v and isinstance(v.get("fa1"), dict) and v["fa1"].get("tg128_tok_s"):
                 v["tg128_fa1_over_value"] = round(v["fa1"]["tg128_tok_s"] / out["value"], 3)
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(pkg, cfg, types, n_kv)
+            out["cpu_baseline"] = cpu_baseline(pkg, cfg, types, n_kv, tiny=args.tiny)
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)

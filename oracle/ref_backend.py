@@ -14,8 +14,25 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 REF_LIB = os.path.join(HERE, "_ref", "libggml-ref.so")
 
 
+REF_LIB_V4 = os.path.join(HERE, "_ref", "v4", "libggml-ref.so")          # the same sources at -march=x86-64-v4 (oracle/Makefile.ref `v4`)
+_V4_FLAGS = ("avx512f", "avx512bw", "avx512cd", "avx512dq", "avx512vl")
+
+
 def ref_available():
     return os.path.exists(REF_LIB)
+
+
+def ref_variant():
+    """Which build ref_lib() loads.  The parity tests always use the x86-64-v3 build (the AVX2 code paths the golden vectors were checked on);
+    ORACLE_REF_VARIANT=v4 -- set by bench.py's cpu_baseline leg only -- selects the AVX-512 build when it exists and this host CPU has the level."""
+    if os.environ.get("ORACLE_REF_VARIANT") == "v4" and os.path.exists(REF_LIB_V4):
+        try:
+            flags = next(l for l in open("/proc/cpuinfo") if l.startswith("flags")).split()
+            if all(f in flags for f in _V4_FLAGS):
+                return "x86-64-v4", REF_LIB_V4
+        except Exception:
+            pass
+    return "x86-64-v3", REF_LIB
 
 
 _REF = None
@@ -26,7 +43,7 @@ def ref_lib():
     if _REF is None:
         if not ref_available():
             raise RuntimeError(f"{REF_LIB} missing: run `make -f oracle/Makefile.ref` where /root/reference exists")
-        lib = C.CDLL(REF_LIB, mode=C.RTLD_GLOBAL)
+        lib = C.CDLL(ref_variant()[1], mode=C.RTLD_GLOBAL)
         lib.ggml_backend_cpu_init.restype = C.c_void_p
         lib.ggml_backend_cpu_buffer_type.restype = C.c_void_p
         lib.ggml_backend_cpu_set_n_threads.argtypes = [C.c_void_p, C.c_int]
