@@ -511,6 +511,131 @@ def omni_module_legs(pkg, be):
     return out
 
 
+def omni_pinned(pkg, be, llm_model):
+    """`--omni-pinned` (BASELINE configs[3] / [4] on the module map): every omni module on the backend mi355x_module_device() pins it to -- distinct
+    GPUs when several are visible, otherwise several streams of device 0 -- with the embeddings moved by real mi355x_handoff calls (RCCL send / recv
+    between devices, device copy + event on one device; csrc/handoff.cpp) and no host copy or host synchronisation between the modules.
+      C4 stream_prefill TTFT: APM (Whisper-medium, 30 s of audio -> 300 embeddings) and VPM (SigLip2 + resampler, one slice -> 64) are submitted
+        back to back on their own backends, both hand their rows into the LLM's input, the LLM prefills 300 + 64 + 30 rows; wall time from the first
+        submission to the LLM's logits, best of 5.
+      C5 chunk: the LLM prefills a 26-row chunk, result_norm rows are handed to the TTS backend, projector (4096 -> 768, F16) + the 768-wide Q8_0 TTS
+        decoder over the 26 rows; wall time from the LLM submission to the TTS logits."""
+    from llama_cpp_omni_amd import encoders as E, qwen3
+    lib = be.lib
+    mods = {m: int(lib.mi355x_module_device(m.encode())) for m in ("apm", "vpm", "llm", "tts")}
+    n_dev = int(be.reg.contents.iface.get_device_count(be.reg))
+    rng = np.random.default_rng(123)
+    made = []
+
+    def backend_for(m):
+        b = pkg.Backend(mods[m]); made.append(b); return b
+
+    def fill(b, tensors):
+        for t in tensors:
+            n = t.nelements()
+            v = (rng.standard_normal(n) * 0.05).astype(np.float32)
+            b.tensor_set(t, v.astype(np.float16) if t.type == 1 else (np.abs(v) + 0.5 if t.type == 0 and n <= 4096 else v) if t.type == 0 else np.zeros(n, np.int32))
+
+    def flat(W):
+        out = [v for k, v in W.items() if k != "layers" and hasattr(v, "nelements")]
+        for L in W.get("layers", []):
+            out += list(L.values())
+        return out
+    res = {"module_devices": mods, "devices_visible": n_dev}
+    try:
+        b_apm, b_vpm, b_tts = backend_for("apm"), backend_for("vpm"), backend_for("tts")
+        if mods["llm"] == 0:
+            b_llm, llm = be, llm_model                             # the benchmark's own 8B Q4_K_M weights (already resident on device 0)
+        else:
+            b_llm = backend_for("llm")
+            llm = qwen3.Model(b_llm, qwen3.QWEN3_8B, qwen3.q4_k_m_types(qwen3.QWEN3_8B), n_ctx=512, seed=1234, flash_attn=True)
+        E_ = qwen3.QWEN3_8B["n_embd"]
+        # ---- APM / VPM graphs on their own backends
+        ca = pkg.Context(b_apm)
+        Wa = E.whisper_weights(ca, E.WHISPER, 24); mel, aud = E.whisper(ca, E.WHISPER, Wa, 3000)
+        aud_out = ca.scale(aud, 1.0); ca.alloc(); fill(b_apm, flat(Wa) + [mel]); ga = ca.graph()
+        cv = pkg.Context(b_vpm)
+        Wv = E.siglip2_weights(cv, E.SIGLIP2, 27); img, vit = E.siglip2(cv, E.SIGLIP2, Wv)
+        Wr = E.resampler_weights(cv, E.RESAMPLER); pe, vis = E.resampler(cv, E.RESAMPLER, Wr, vit, (E.SIGLIP2["image"] // E.SIGLIP2["patch"]) ** 2)
+        vis_out = cv.scale(vis, 1.0); cv.alloc(); fill(b_vpm, flat(Wv) + flat(Wr) + [img, pe]); gv = cv.graph()
+        n_a, n_v, n_t = int(aud_out.ne[1]), int(vis_out.ne[1]), 30
+        assert aud_out.ne[0] == E_ and vis_out.ne[0] == E_, (aud_out.ne, vis_out.ne)
+        n_llm = n_a + n_v + n_t
+        # ---- LLM prefill graph over the handed-over rows
+        gl, Il, logits = llm.build(n_llm, n_llm, n_outputs=1)
+        llm.set_inputs(Il, (rng.standard_normal((n_llm, E_)) * 0.05).astype(np.float32), 0, n_llm)       # (the 30 text rows stay; the module rows are overwritten by the hand-offs)
+        b_llm.tensor_set(Il["out_ids"], np.array([n_llm - 1], np.int32))
+        glr = gl.graph()
+        dst = Il["inp_embd"].t.data
+        row = E_ * 4
+
+        def c4_once():
+            t0 = time.perf_counter()
+            b_apm.graph_compute(ga)
+            b_vpm.graph_compute(gv)
+            r1 = lib.mi355x_handoff(b_apm.be, aud_out.t.data, b_llm.be, dst, n_a * row)
+            r2 = lib.mi355x_handoff(b_vpm.be, vis_out.t.data, b_llm.be, dst + n_a * row, n_v * row)
+            b_llm.graph_compute(glr)
+            b_llm.synchronize()
+            return time.perf_counter() - t0, (r1, r2)
+        for _ in range(2):
+            c4_once()
+        best, kinds = min(c4_once() for _ in range(5))
+        ok = bool(np.isfinite(b_llm.tensor_get(logits)).all())
+        # the legs alone (same graphs, each synchronised): what the composed figure of the default run adds up
+        legs = {}
+        for name, b, g in (("apm_ms", b_apm, ga), ("vpm_ms", b_vpm, gv), ("llm_prefill_ms", b_llm, glr)):
+            b.synchronize(); t = 1e9
+            for _ in range(3):
+                t0 = time.perf_counter(); b.graph_compute(g); b.synchronize(); t = min(t, time.perf_counter() - t0)
+            legs[name] = round(t * 1e3, 3)
+        res["c4_stream_prefill_ttft"] = {"measured_ttft_ms": round(best * 1e3, 3) if ok else None, "llm_prefill_tokens": n_llm, "handoff_kinds": {"apm": kinds[0], "vpm": kinds[1]},
+                                         **legs, "sum_of_legs_ms": round(sum(legs.values()), 3),
+                                         "note": "hand-off kind 1 = RCCL send/recv, 2 = device copy + event; APM and VPM run concurrently (own devices or own streams), the LLM waits on both hand-off events"}
+        gl.free(); ca.free(); cv.free()
+        # ---- C5: LLM chunk -> TTS
+        n_c = 26
+        TTS = qwen3.TTS
+        llm.tap_hidden = True
+        gl, Il, _ = llm.build(n_c, 256)
+        hid = llm.hidden_out
+        llm.tap_hidden = False
+        llm.set_inputs(Il, (rng.standard_normal((n_c, E_)) * 0.05).astype(np.float32), 0, 256)
+        glr = gl.graph()
+        tts = qwen3.Model(b_tts, TTS, qwen3.uniform_types(TTS, pkg.GGML_TYPE_Q8_0), n_ctx=256, seed=9, flash_attn=True)
+        cp = pkg.Context(b_tts)
+        hin = cp.new_tensor(pkg.GGML_TYPE_F32, E_, n_c); pw = cp.new_tensor(pkg.GGML_TYPE_F16, E_, TTS["n_embd"]); proj = cp.mul_mat(pw, hin)
+        cp.alloc(); b_tts.tensor_set(pw, (rng.standard_normal(pw.nelements()) / 64.0).astype(np.float16)); gp = cp.graph()
+        gt, It, tl = tts.build(n_c, 256)
+        tts.set_inputs(It, np.zeros((n_c, TTS["n_embd"]), np.float32), 0, 256)
+        gtr = gt.graph()
+
+        def c5_once():
+            t0 = time.perf_counter()
+            b_llm.graph_compute(glr)
+            k1 = b_llm.handoff_tensor(hid, b_tts, hin)
+            b_tts.graph_compute(gp)
+            k2 = b_tts.handoff_tensor(proj, b_tts, It["inp_embd"])
+            b_tts.graph_compute(gtr)
+            b_tts.synchronize()
+            return time.perf_counter() - t0, (k1, k2)
+        for _ in range(2):
+            c5_once()
+        best5, kinds5 = min(c5_once() for _ in range(5))
+        ok5 = bool(np.isfinite(b_tts.tensor_get(tl)).all())
+        res["c5_llm_to_tts_chunk"] = {"measured_ms": round(best5 * 1e3, 3) if ok5 else None, "chunk_rows": n_c, "handoff_kinds": {"llm_to_tts": kinds5[0], "projector_to_decoder": kinds5[1]}}
+        gl.free(); cp.free(); gt.free(); tts.wctx.free()
+    except Exception as e:
+        res["error"] = repr(e)
+    finally:
+        for b in made:
+            try:
+                b.close()
+            except Exception:
+                pass
+    return res
+
+
 class Replicas:
     """N > 1: one process per GPU (torch.distributed.run), each a whole-model replica; no data-path collective (decode of one sequence does
     not shard).  The only communication is the contract's: barrier + synchronize on both sides of the timed region and the
@@ -583,6 +708,7 @@ def main():
     ap.add_argument("--no-fa", action="store_true")
     ap.add_argument("--c3", action="store_true", help="(default on at N = 1) BASELINE configs[2]: Qwen3-8B F16 prefill 8 x 2048 tokens (the `c3_f16_prefill` object)")
     ap.add_argument("--no-c3", action="store_true", help="skip the C3 leg")
+    ap.add_argument("--omni-pinned", action="store_true", help="add `omni_pinned`: C4 TTFT / C5 chunk measured with every module on its mi355x_module_device() backend and real hand-offs")
     ap.add_argument("--no-libllama", action="store_true", help="skip the via_libllama leg (the metric through the reference's libllama with this plug-in)")
     args = ap.parse_args()
 
@@ -679,6 +805,9 @@ def main():
             v = out["via_libllama"]
             if v and isinstance(v.get("fa1"), dict) and v["fa1"].get("tg128_tok_s"):
                 v["tg128_fa1_over_value"] = round(v["fa1"]["tg128_tok_s"] / out["value"], 3)
+        if args.omni_pinned and world == 1 and not args.tiny:
+            be.synchronize()
+            out["omni_pinned"] = omni_pinned(pkg, be, dec.model)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(pkg, cfg, types, n_kv, tiny=args.tiny)
         else:

@@ -351,3 +351,40 @@ def test_reference_omni_encoder_code_runs_on_the_plugin(tmp_path, module, extra,
         assert max(errs) <= 5e-6, errs                      # measured 1e-7 (apm) and 7e-8 (vpm)
     finally:
         os.remove(gguf)
+
+
+# ------------------------------------------------------------------------------------------------ module pinning / multi-GPU forms
+def test_bench_two_ranks_over_rccl_when_two_gpus_are_visible(pkg, be):
+    """The driver's N > 1 launch of bench.py with NO test hook: backend nccl (= RCCL), one GPU per rank, barrier + max-over-ranks.  Needs two MI355X
+    in the box; the same code runs on every 1-GPU box through the gloo hooks (test_round2_gpu.py::test_bench_runs_as_two_ranks_through_its_gloo_hooks)."""
+    if int(be.reg.contents.iface.get_device_count(be.reg)) < 2:
+        pytest.skip("needs two MI355X in one box")
+    env = dict(os.environ, MI355X_BENCH_NO_PP="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("MI355X_BENCH_DIST_BACKEND", "MI355X_BENCH_SHARE_GPU"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29573",
+                          os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "8", "--warmup", "2", "--tiny", "--no-cpu-baseline"],
+                         env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    j = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
+    assert j["n_gpus"] == 2 and j["value"] > 0
+
+
+def test_bench_omni_pinned_mode_measures_c4_and_c5_with_real_handoffs():
+    """bench.py --omni-pinned: APM / VPM / LLM / TTS on their mi355x_module_device() backends (several streams of device 0 on a 1-GPU box), the
+    embeddings moved by mi355x_handoff, TTFT and chunk time MEASURED end to end (not composed from legs).  Plumbing + sanity: finite results, every
+    hand-off really went through the library (kind 1 = RCCL, 2 = device copy + event), and the concurrent APM / VPM submission does not take longer
+    than the legs one after the other."""
+    env = dict(os.environ, MI355X_BENCH_NO_PP="1", MI355X_BENCH_NO_EXTRAS="1")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "16", "--warmup", "4", "--no-cpu-baseline", "--no-c3", "--no-libllama", "--omni-pinned"],
+                         env=env, capture_output=True, text=True, timeout=1200, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    j = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    o = j["omni_pinned"]
+    assert "error" not in o, o
+    c4, c5 = o["c4_stream_prefill_ttft"], o["c5_llm_to_tts_chunk"]
+    print("omni_pinned:", json.dumps(o))
+    assert c4["measured_ttft_ms"] and c5["measured_ms"]
+    assert set(c4["handoff_kinds"].values()) <= {1, 2} and set(c5["handoff_kinds"].values()) <= {1, 2}
+    assert c4["llm_prefill_tokens"] == 394
+    assert c4["measured_ttft_ms"] <= 1.15 * c4["sum_of_legs_ms"] + 1.0
