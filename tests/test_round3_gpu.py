@@ -388,3 +388,50 @@ def test_bench_omni_pinned_mode_measures_c4_and_c5_with_real_handoffs():
     assert set(c4["handoff_kinds"].values()) <= {1, 2} and set(c5["handoff_kinds"].values()) <= {1, 2}
     assert c4["llm_prefill_tokens"] == 394
     assert c4["measured_ttft_ms"] <= 1.15 * c4["sum_of_legs_ms"] + 1.0
+
+
+# ------------------------------------------------------------------------------------------------ the reference's Token2Wav end to end on the plug-in
+T2W = os.path.join(ROOT, "oracle", "_ref", "t2w-min")
+
+
+def test_reference_token2wav_end_to_end_on_the_plugin(tmp_path):
+    """SURVEY.md 8(f) rank 4 / BASELINE configs[4] with the REFERENCE's own module: tools/omni/token2wav/token2wav-impl.cpp (Token2WavSession -- conformer
+    token encoder with streaming caches, flow-matching DiT with 10 Euler steps and classifier-free guidance, HiFT vocoder with the f0 predictor, NSF source,
+    three transposed-conv stages, snake resblocks and the 16-point iSTFT; compiled from /root/reference by oracle/Makefile.ref `omni`) on the full-size synthetic
+    module set of tools/make_synth_omni_gguf.py --module t2w: prompt set-up, then three streaming windows of 25 + 3 tokens -> 3.1 s of 24 kHz audio.
+    The module has no scheduler (token2wav-impl.cpp:6287-6345: one backend per sub-model), so a single node the plug-in declined would fail the run: the
+    plug-in's stats line must show the graphs, and the waveform must match the CPU backend's.  Bar: NMSE <= 1e-4 over the whole waveform (the reference
+    clamps it to +-0.99; f32 weights throughout: the differences are f32 summation order through ~15 000 nodes per window, and the sin / cos / exp of the source
+    and iSTFT stages)."""
+    if not os.path.exists(T2W):
+        pytest.skip("oracle/_ref/t2w-min not built (make -f oracle/Makefile.ref omni)")
+    d = str(tmp_path / "t2w")
+    subprocess.run([sys.executable, os.path.join(ROOT, "tools", "make_synth_omni_gguf.py"), "--module", "t2w", "-o", d], check=True, timeout=900)
+
+    def run(dev, out):
+        env = dict(os.environ)
+        env.pop("GGML_BACKEND_PATH", None)
+        if dev == "gpu":
+            env["GGML_BACKEND_PATH"] = LIB
+            env["MI355X_LOG_STATS"] = "1"
+        r = subprocess.run([T2W, d, out, dev, "--windows", "3"], env=env, capture_output=True, text=True, timeout=1800)
+        assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+        if dev == "gpu":
+            assert "flowGGUFModelLoader: init_backend device=gpu, gpu_idx=0, backend=MI355X0" in r.stderr and "voc_hg2_model: init_backend device=gpu, gpu_idx=0, backend=MI355X0" in r.stderr, r.stderr[-3000:]
+            import re
+            m = re.findall(r"\[mi355x\] MI355X0: graphs eager=(\d+) captured=(\d+) replayed=(\d+), kernels in last graph=(\d+)", r.stderr)
+            assert len(m) >= 1 and all(int(a) + int(b) + int(c) >= 3 for a, b, c, _ in m), r.stderr[-3000:]        # (printed when a backend is freed: the session frees the flow model's)
+        return json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    import shutil
+    try:
+        jg = run("gpu", str(tmp_path / "g.f32"))
+        jc = run("cpu", str(tmp_path / "c.f32"))
+        g = np.fromfile(str(tmp_path / "g.f32"), np.float32); c = np.fromfile(str(tmp_path / "c.f32"), np.float32)
+        assert g.shape == c.shape and g.size == jc["samples"] == 74880 and np.isfinite(g).all()
+        assert float(c.std()) > 0.02 and float((np.abs(c) >= 0.98).mean()) < 0.2           # a live waveform, mostly inside the clamp
+        e = float(((g - c) ** 2).sum() / (c ** 2).sum())
+        per = [float(((g[i:i + 24000] - c[i:i + 24000]) ** 2).sum() / (c[i:i + 24000] ** 2).sum()) for i in range(0, g.size - 1, 24000)]
+        print(f"t2w: waveform NMSE {e:.2e} (per second {['%.1e' % x for x in per]}); plug-in RTF {jg['rtf']:.4f} ({jg['ms_windows']} ms per 1 s window), CPU backend RTF {jc['rtf']:.2f}")
+        assert e <= 1e-4, (e, per)
+    finally:
+        shutil.rmtree(d, ignore_errors=True)

@@ -2,6 +2,7 @@
 """tools/make_synth_omni_gguf.py -- synthetic GGUFs of the omni encoder modules, in the layout the reference's loaders read.
 
   --module vpm : the image module (SigLIP-so400m tower + the 64-query resampler) as convert_vpm.py writes it and vision.cpp:787-1055 loads it.
+  --module t2w : the Token2Wav module set (four GGUFs + a prompt bundle) into the directory given with -o; see t2w() below.
   --module apm : the audio module (Whisper-medium encoder + audio projector) as tools/omni/convert/convert_apm.py writes it and
                  tools/omni/audition.cpp:790-1135 loads it: arch "whisper", KVs d_model / encoder_attention_heads / encoder_layers / n_mel /
                  n_fft / filters, tensors encoder.conv{1,2}.*, encoder.positional_embedding, encoder.blocks.N.{attn_ln, attn.{query,key,value,out},
@@ -126,14 +127,109 @@ def vpm(path, n_layer, seed, n_embd=1152, n_head=16, n_ff=4304, patch=14, image=
     print(f"wrote {path}: {len(t)} tensors")
 
 
+def t2w(out_dir, seed, n_prompt_tokens=78):
+    """The Token2Wav module set tools/omni/token2wav/token2wav-impl.cpp loads (every tensor F32, names and layouts as its binders request them):
+      encoder.gguf        UpsampleConformerEncoderV2 (:2783-2860): embed / up_embed (linear + LayerNorm), pre_lookahead convs [K, Cin, Cout], 6 + 4 rel-pos conformer
+                          blocks (512 wide, 8 heads, ffn 2048), up_layer conv (K 5), after_norm
+      flow_matching.gguf  DiT estimator (:1840-1882; in 320, hidden 512, 16 blocks, 8 heads x 64, mlp 2048, out 80)
+      flow_extra.gguf     input_embedding [6561 x 512], spk_embed_affine_layer 192 -> 80, encoder_proj 512 -> 80 (:6977)
+      hifigan2.gguf       HiFT generator (:5503-5565): f0 predictor, source module, conv_pre, 3 transposed-conv stages [K, Cout, Cin] (x8, x5, x3) with 3 + 9 snake
+                          resblocks, source_downs, conv_post (18 = n_fft + 2 channels for the 16-point iSTFT)
+      prompt/             the prompt bundle of Token2Mel::load_prompt_bundle_dir (:8020-8070): spk_f32.bin [192], prompt_tokens_i32.bin [T], prompt_mel_btc_f32.bin [(T - 3) * 2, 80]"""
+    import os
+    os.makedirs(os.path.join(out_dir, "prompt"), exist_ok=True)
+    rng = np.random.default_rng(seed)
+    f = np.float32
+    lin = lambda i, o: (rng.standard_normal((o, i)) / np.sqrt(i)).astype(f)                      # noqa: E731  torch [out, in] -> ne [in, out]
+    conv = lambda k, ci, co: (rng.standard_normal((co, ci, k)) / np.sqrt(ci * k)).astype(f)       # noqa: E731  torch [Cout, Cin, K] -> ne [K, Cin, Cout]
+    vec = lambda n, m=0.0, sd=0.02: (m + rng.standard_normal(n) * sd).astype(f)                   # noqa: E731
+    arch = lambda name: [kv_str("general.architecture", name), kv_str("general.description", "synthetic Token2Wav module (random weights)")]     # noqa: E731
+    # ---- encoder
+    D, H, FF = 512, 8, 2048
+    t = []
+
+    def lin_ln(p):
+        return [(p + ".out.0.weight", lin(D, D)), (p + ".out.0.bias", vec(D)), (p + ".out.1.weight", vec(D, 1.0)), (p + ".out.1.bias", vec(D))]
+
+    def conformer(p):
+        r = [(p + ".norm_ff.weight", vec(D, 1.0)), (p + ".norm_ff.bias", vec(D)), (p + ".norm_mha.weight", vec(D, 1.0)), (p + ".norm_mha.bias", vec(D))]
+        for w in ("linear_q", "linear_k", "linear_v", "linear_out"):
+            r += [(p + ".self_attn." + w + ".weight", lin(D, D)), (p + ".self_attn." + w + ".bias", vec(D))]
+        r += [(p + ".self_attn.linear_pos.weight", lin(D, D)), (p + ".self_attn.pos_bias_u", vec((H, D // H), 0.0, 0.1)), (p + ".self_attn.pos_bias_v", vec((H, D // H), 0.0, 0.1)),
+              (p + ".feed_forward.w_1.weight", lin(D, FF)), (p + ".feed_forward.w_1.bias", vec(FF)), (p + ".feed_forward.w_2.weight", lin(FF, D)), (p + ".feed_forward.w_2.bias", vec(D))]
+        return r
+    t += lin_ln("embed")
+    t += [("pre_lookahead_layer.conv1.weight", conv(4, D, D)), ("pre_lookahead_layer.conv1.bias", vec(D)), ("pre_lookahead_layer.conv2.weight", conv(3, D, D)), ("pre_lookahead_layer.conv2.bias", vec(D))]
+    for i in range(6):
+        t += conformer(f"encoders.{i}")
+    t += [("up_layer.conv.weight", conv(5, D, D)), ("up_layer.conv.bias", vec(D))]
+    t += lin_ln("up_embed")
+    for i in range(4):
+        t += conformer(f"up_encoders.{i}")
+    t += [("after_norm.weight", vec(D, 1.0)), ("after_norm.bias", vec(D))]
+    write_gguf(os.path.join(out_dir, "encoder.gguf"), arch("t2w-encoder"), t)
+    # ---- flow matching (DiT)
+    E, HD, MLP = 512, 64, 2048
+    t = [("estimator.t_embedder.mlp.0.weight", lin(256, E)), ("estimator.t_embedder.mlp.0.bias", vec(E)), ("estimator.t_embedder.mlp.2.weight", lin(E, E)), ("estimator.t_embedder.mlp.2.bias", vec(E)),
+         ("estimator.in_proj.weight", lin(320, E)), ("estimator.in_proj.bias", vec(E))]
+    for i in range(16):
+        p = f"estimator.blocks.{i}."
+        t += [(p + "adaLN_modulation.1.weight", (lin(E, 9 * E) * 0.3).astype(f)), (p + "adaLN_modulation.1.bias", vec(9 * E))]
+        for w in ("to_q", "to_k", "to_v", "proj"):
+            t += [(p + "attn." + w + ".weight", lin(E, E)), (p + "attn." + w + ".bias", vec(E))]
+        t += [(p + "attn.q_norm.weight", vec(HD, 1.0)), (p + "attn.q_norm.bias", vec(HD)), (p + "attn.k_norm.weight", vec(HD, 1.0)), (p + "attn.k_norm.bias", vec(HD)),
+              (p + "conv.block.1.weight", conv(3, E, E)), (p + "conv.block.1.bias", vec(E)), (p + "conv.block.3.weight", vec(E, 1.0)), (p + "conv.block.3.bias", vec(E)),
+              (p + "conv.block.6.weight", conv(3, E, E)), (p + "conv.block.6.bias", vec(E)),
+              (p + "mlp.fc1.weight", lin(E, MLP)), (p + "mlp.fc1.bias", vec(MLP)), (p + "mlp.fc2.weight", lin(MLP, E)), (p + "mlp.fc2.bias", vec(E))]
+    t += [("estimator.final_layer.adaLN_modulation.1.weight", (lin(E, 2 * E) * 0.3).astype(f)), ("estimator.final_layer.adaLN_modulation.1.bias", vec(2 * E)),
+          ("estimator.final_layer.linear.weight", lin(E, 80)), ("estimator.final_layer.linear.bias", vec(80))]
+    write_gguf(os.path.join(out_dir, "flow_matching.gguf"), arch("t2w-flow-matching"), t)
+    # ---- flow extra
+    t = [("input_embedding.weight", (rng.standard_normal((6561, D)) * 0.5).astype(f)), ("spk_embed_affine_layer.weight", lin(192, 80)), ("spk_embed_affine_layer.bias", vec(80)),
+         ("encoder_proj.weight", lin(D, 80)), ("encoder_proj.bias", vec(80))]
+    write_gguf(os.path.join(out_dir, "flow_extra.gguf"), arch("t2w-flow-extra"), t)
+    # ---- vocoder
+    def resblock(p, ch, k):
+        r = []
+        for j in range(3):
+            r += [(f"{p}.convs1.{j}.weight", conv(k, ch, ch)), (f"{p}.convs1.{j}.bias", vec(ch)), (f"{p}.convs2.{j}.weight", conv(k, ch, ch)), (f"{p}.convs2.{j}.bias", vec(ch)),
+                  (f"{p}.activations1.{j}.alpha", vec(ch, 1.0, 0.1)), (f"{p}.activations2.{j}.alpha", vec(ch, 1.0, 0.1))]
+        return r
+    t = [("f0_predictor.condnet.0.weight", conv(3, 80, 512)), ("f0_predictor.condnet.0.bias", vec(512))]
+    for j in (2, 4, 6, 8):
+        t += [(f"f0_predictor.condnet.{j}.weight", conv(3, 512, 512)), (f"f0_predictor.condnet.{j}.bias", vec(512))]
+    t += [("f0_predictor.classifier.weight", (lin(512, 1) * 40.0).astype(f)), ("f0_predictor.classifier.bias", vec(1, 120.0, 1.0)),      # f0 around 100..200 Hz: voiced frames
+          ("m_source.l_linear.weight", lin(9, 1)), ("m_source.l_linear.bias", vec(1)),
+          ("conv_pre.weight", conv(7, 80, 512)), ("conv_pre.bias", vec(512)), ("conv_post.weight", (conv(7, 64, 18) * 0.15).astype(f)),
+          ("conv_post.bias", np.concatenate([vec(9, -1.0, 0.1), vec(9)]))]                          # 9 log-magnitude channels (kept below the +-0.99 clamp of the waveform), 9 phase channels
+    for i, (k, co, ci) in enumerate(((16, 256, 512), (11, 128, 256), (7, 64, 128))):             # ConvTranspose1d: torch [Cin, Cout, K] -> ne [K, Cout, Cin]
+        t += [(f"ups.{i}.weight", (rng.standard_normal((ci, co, k)) / np.sqrt(ci * k / (8, 5, 3)[i])).astype(f)), (f"ups.{i}.bias", vec(co))]
+    for i, (k, co) in enumerate(((30, 256), (6, 128), (1, 64))):
+        t += [(f"source_downs.{i}.weight", conv(k, 18, co)), (f"source_downs.{i}.bias", vec(co))]
+    for i, (ch, k) in enumerate(((256, 7), (128, 7), (64, 11))):
+        t += resblock(f"source_resblocks.{i}", ch, k)
+    for stage, ch in enumerate((256, 128, 64)):
+        for j, k in enumerate((3, 7, 11)):
+            t += resblock(f"resblocks.{stage * 3 + j}", ch, k)
+    write_gguf(os.path.join(out_dir, "hifigan2.gguf"), arch("t2w-hifigan2"), t)
+    # ---- prompt bundle
+    spk = rng.standard_normal(192).astype(f)
+    (spk / np.linalg.norm(spk)).astype(f).tofile(os.path.join(out_dir, "prompt", "spk_f32.bin"))
+    rng.integers(0, 6561, n_prompt_tokens).astype(np.int32).tofile(os.path.join(out_dir, "prompt", "prompt_tokens_i32.bin"))
+    (rng.standard_normal(((n_prompt_tokens - 3) * 2, 80)) * 0.5 - 4.0).astype(f).tofile(os.path.join(out_dir, "prompt", "prompt_mel_btc_f32.bin"))
+    print(f"wrote {out_dir}/{{encoder,flow_matching,flow_extra,hifigan2}}.gguf + prompt/")
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
-    ap.add_argument("--module", choices=["apm", "vpm"], required=True)
+    ap.add_argument("--module", choices=["apm", "vpm", "t2w"], required=True)
     ap.add_argument("-o", "--out", required=True)
     ap.add_argument("--layers", type=int, default=0, help="encoder blocks (default: 24 for apm, 27 for vpm)")
     ap.add_argument("--seed", type=int, default=7)
     a = ap.parse_args()
-    if a.module == "apm":
+    if a.module == "t2w":
+        t2w(a.out, a.seed)
+    elif a.module == "apm":
         apm(a.out, a.layers or 24, a.seed)
     else:
         vpm(a.out, a.layers or 27, a.seed)
