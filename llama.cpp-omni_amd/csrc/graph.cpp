@@ -2271,7 +2271,11 @@ enum ggml_status graph_compute(backend_ctx * c, ggml_cgraph * g) {
         }
     static const int64_t graph_max_cols = getenv("MI355X_GRAPH_MAX_COLS") ? atoll(getenv("MI355X_GRAPH_MAX_COLS")) : (mmq_max_cols() > 32 ? mmq_max_cols() : 32);
     static const double graph_max_flops = getenv("MI355X_GRAPH_MAX_GFLOP") ? atof(getenv("MI355X_GRAPH_MAX_GFLOP")) * 1e9 : 20e9;
-    const bool try_graph = c->opt_graphs && !c->opt_profile && n_real >= 8 && (max_cols <= graph_max_cols || mm_flops <= graph_max_flops);
+    // ... and so is a very long graph of small products whatever their total (the reference's Token2Wav window: 10 flow-matching steps x 16 DiT blocks at ~200 columns,
+    // 15 000 launches, ~13 MFLOP of mat-mul per node): eager submission is bound by the host's ~3.4 us per launch
+    static const double graph_max_flops_per_node = getenv("MI355X_GRAPH_MAX_MFLOP_PER_NODE") ? atof(getenv("MI355X_GRAPH_MAX_MFLOP_PER_NODE")) * 1e6 : 50e6;
+    const bool try_graph = c->opt_graphs && !c->opt_profile && n_real >= 8 &&
+                           (max_cols <= graph_max_cols || mm_flops <= graph_max_flops || (n_real >= 512 && mm_flops <= (double) n_real * graph_max_flops_per_node));
     if (try_graph) {
         if (!have_fp) fp = fingerprint(g);
         graph_exec * ge = nullptr;

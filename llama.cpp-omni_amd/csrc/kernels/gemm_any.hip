@@ -229,6 +229,67 @@ __global__ void __launch_bounds__(256) k_gemm_any_sk(const gemm_any_dev g) {
     }
 }
 
+// The same small f32 x f32 products without the LDS staging, for 16-byte aligned rows (the reference's Token2Wav: every DiT / conformer projection of a streaming
+// window is 512..2048 rows x 56 columns x K 512..2048, 8600 of them per second of audio).  k_gemm_any_sk spends its time in round trips: 32-wide K-steps, each a
+// dependent global load -> LDS -> 16 MFMAs (17-26 us per product).  In the v_mfma_f32_32x32x2f32 operand layout lane l supplies row l % 32 and ONE k per MFMA, and
+// any assignment of a step's k values to (MFMA index, lane half) is valid as long as both operands use the same one -- so each lane reads 64 CONTIGUOUS floats of
+// its own row (half 0: k0 .. k0+63, half 1: k0+64 .. k0+127) with sixteen 16-byte loads per operand, all in flight at once, and feeds element kk to MFMA kk:
+// one round trip per 128 k.  NW waves split K (4 up to K 512, 8 beyond); the partial tiles are folded through LDS in wave order (deterministic).
+template <int NW>
+__global__ void __launch_bounds__(NW * 64) k_gemm_f32_rows(const gemm_any_dev g) {
+    constexpr int KS = 128;
+    __shared__ float red[NW - 1][64 * 16];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int tm = (int) blockIdx.x % g.tiles_m, tn = (int) blockIdx.x / g.tiles_m;        // (tiles_m counts 32-row tiles)
+    const int i12 = (int) blockIdx.y % g.ne12, i13 = (int) blockIdx.y / g.ne12;
+    const char * W = g.W + (size_t) (i12 / g.r2) * g.w_nb2 + (size_t) (i13 / g.r3) * g.w_nb3;
+    const char * X = g.X + (size_t) i12 * g.x_nb2 + (size_t) i13 * g.x_nb3;
+    const int m0 = tm * 32, n0 = tn * 32, fr = lane & 31, kh = lane >> 5;
+    const int mr = m0 + fr < g.M ? m0 + fr : g.M - 1, nr = n0 + fr < g.N ? n0 + fr : g.N - 1;      // rows past the edge re-read the last row; their results are not stored
+    const char * pw = W + (size_t) mr * g.w_rs, * px = X + (size_t) nr * g.x_rs;
+    const int nsteps = (g.K + KS - 1) / KS, per = (nsteps + NW - 1) / NW;
+    const int s_lo = wave * per, s_hi = s_lo + per < nsteps ? s_lo + per : nsteps;
+    ga_acc acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.0f;
+    for (int s = s_lo; s < s_hi; ++s) {
+        const int kb = s * KS + kh * 64;
+        float4 wv[16], xv[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {                             // branch-free: clamped addresses (K % 4 == 0: a quad is inside or outside as a whole), zero selected afterwards
+            const int k = kb + 4 * j, kc = k < g.K ? k : g.K - 4;
+            wv[j] = *(const float4 *) (pw + (size_t) kc * 4);
+            xv[j] = *(const float4 *) (px + (size_t) kc * 4);
+        }
+#pragma unroll
+        for (int j = 0; j < 16; ++j)
+            if (kb + 4 * j >= g.K) { wv[j] = make_float4(0.f, 0.f, 0.f, 0.f); xv[j] = make_float4(0.f, 0.f, 0.f, 0.f); }
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xv[j].x, wv[j].x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xv[j].y, wv[j].y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xv[j].z, wv[j].z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xv[j].w, wv[j].w, acc, 0, 0, 0);
+        }
+    }
+    if (wave > 0) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) red[wave - 1][e * 64 + lane] = acc[e];
+    }
+    __syncthreads();
+    if (wave > 0) return;
+    char * dst = g.dst + (size_t) i12 * g.dst_nb2 + (size_t) i13 * g.dst_nb3;
+    const int m = m0 + fr;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int n = n0 + (e & 3) + 8 * (e >> 2) + 4 * kh;
+        float v = acc[e];
+#pragma unroll
+        for (int w = 0; w < NW - 1; ++w) v += red[w][e * 64 + lane];
+        if (m < g.M && n < g.N) { float * p = (float *) (dst + (size_t) n * g.dst_cs + (size_t) m * 4); if (g.accumulate) v = *p + v; if (g.bias) v = __fadd_rn(v, g.bias[m]); *p = v; }
+    }
+}
+
 void gemm_any(const gemm_any_args & a, hipStream_t st) {
     if (a.M == 0 || a.N == 0 || a.nbatch == 0) return;
     gemm_any_dev g;
@@ -243,6 +304,12 @@ void gemm_any(const gemm_any_args & a, hipStream_t st) {
     if (!no_sk && !h_path && (int64_t) g.tiles_m * ((a.N + 63) / 64) * a.nbatch < 128 && a.K >= 256) {          // few tiles, long chains: one 32 x 32 tile per workgroup, K split over its waves
         g.tiles_m = (int) ((a.M + 31) / 32);
         const dim3 grid((unsigned) (g.tiles_m * ((a.N + 31) / 32)), (unsigned) a.nbatch);
+        static const bool no_rows = getenv("MI355X_NO_GEMM_F32_ROWS") != nullptr;
+        if (!no_rows && !a.x_f16 && !a.w_f16 && !a.w_bf16 && a.K % 4 == 0 &&
+            (((uintptr_t) a.W | a.w_rs | a.w_nb2 | a.w_nb3 | (uintptr_t) a.X | a.x_rs | a.x_nb2 | a.x_nb3) & 15) == 0) {       // f32 x f32, 16-byte aligned rows: no LDS staging, one round trip per 128 k
+            if (a.K <= 512) k_gemm_f32_rows<4><<<grid, dim3(256), 0, st>>>(g); else k_gemm_f32_rows<8><<<grid, dim3(512), 0, st>>>(g);
+            return;
+        }
         if (a.x_f16)      k_gemm_any_sk<uint16_t, uint16_t><<<grid, dim3(256), 0, st>>>(g);
         else if (a.w_f16 || a.w_bf16) k_gemm_any_sk<uint16_t, float><<<grid, dim3(256), 0, st>>>(g);
         else              k_gemm_any_sk<float, float><<<grid, dim3(256), 0, st>>>(g);
