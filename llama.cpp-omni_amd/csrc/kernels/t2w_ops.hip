@@ -188,9 +188,47 @@ __global__ void __launch_bounds__(256) k_conv_transpose_1d(const char * __restri
         *(float *) (y + (int64_t) o * y_nb1 + (int64_t) pos * 4) = acc;
     }
 }
+// The HiFT up-sampling stages (512 -> 256 channels, K 16, stride 8, ...): one workgroup per (output channel, 256 output positions).  The channel's taps
+// w[c][o][0..K) of ALL input channels are staged in LDS once (coalesced K-float runs; Cin * K floats: 32 KB at most there) instead of being re-read from global
+// memory with a channel stride by every thread of every position; x[c][l] is read coalesced (neighbouring positions share or neighbour l).  Same visiting
+// order as the kernel above: taps in ascending l, channels in ascending c inside a tap.
+template <bool W16>
+__global__ void __launch_bounds__(256) k_conv_transpose_1d_lds(const char * __restrict__ w, int64_t w_nb1, int64_t w_nb2, const char * __restrict__ x, int64_t x_nb1,
+                                                               char * __restrict__ y, int64_t y_nb1, int K, int Cin, int L, int OL, int s0) {
+    extern __shared__ float ct_w[];                                        // [Cin][K]
+    const int o = (int) blockIdx.y, pos = (int) blockIdx.x * 256 + (int) threadIdx.x;
+    for (int i = (int) threadIdx.x; i < Cin * K; i += 256) {
+        const int c = i / K, k = i - c * K;
+        const char * p = w + (int64_t) c * w_nb2 + (int64_t) o * w_nb1;
+        ct_w[i] = W16 ? h2f(*(const uint16_t *) (p + (int64_t) k * 2)) : *(const float *) (p + (int64_t) k * 4);
+    }
+    __syncthreads();
+    if (pos >= OL) return;
+    const int l0 = pos >= K ? (pos - K + s0) / s0 : 0;
+    float acc = 0.0f;
+    for (int l = l0; l < L && l * s0 <= pos; ++l) {
+        const int k = pos - l * s0;
+        float v = 0.0f;
+#pragma unroll 8
+        for (int c = 0; c < Cin; ++c) {
+            const float xv = *(const float *) (x + (int64_t) c * x_nb1 + (int64_t) l * 4);
+            v += (W16 ? h2f(f2h(xv)) : xv) * ct_w[c * K + k];
+        }
+        acc += v;
+    }
+    *(float *) (y + (int64_t) o * y_nb1 + (int64_t) pos * 4) = acc;
+}
 void conv_transpose_1d_f32(const tdesc & w, int w_type, const tdesc & x, const tdesc & y, int s0, hipStream_t st) {
     const int K = (int) w.ne[0], Cout = (int) w.ne[1], Cin = (int) w.ne[2], L = (int) x.ne[0], OL = (int) y.ne[0];
     if ((int64_t) OL * Cout == 0) return;
+    static const bool no_lds = getenv("MI355X_NO_CONVT_LDS") != nullptr;
+    const size_t lds = (size_t) Cin * (size_t) K * 4;
+    if (!no_lds && lds <= 48 * 1024 && Cout <= 65535 && Cin >= 16) {
+        const dim3 grid((unsigned) ((OL + 255) / 256), (unsigned) Cout);
+        if (w_type == GGML_TYPE_F16) k_conv_transpose_1d_lds<true><<<grid, dim3(256), lds, st>>>((const char *) w.p, (int64_t) w.nb[1], (int64_t) w.nb[2], (const char *) x.p, (int64_t) x.nb[1], (char *) y.p, (int64_t) y.nb[1], K, Cin, L, OL, s0);
+        else                         k_conv_transpose_1d_lds<false><<<grid, dim3(256), lds, st>>>((const char *) w.p, (int64_t) w.nb[1], (int64_t) w.nb[2], (const char *) x.p, (int64_t) x.nb[1], (char *) y.p, (int64_t) y.nb[1], K, Cin, L, OL, s0);
+        return;
+    }
     if (w_type == GGML_TYPE_F16) k_conv_transpose_1d<true><<<grid_for((int64_t) OL * Cout), dim3(256), 0, st>>>((const char *) w.p, (int64_t) w.nb[1], (int64_t) w.nb[2], (const char *) x.p, (int64_t) x.nb[1], (char *) y.p, (int64_t) y.nb[1], K, Cout, Cin, L, OL, s0);
     else                         k_conv_transpose_1d<false><<<grid_for((int64_t) OL * Cout), dim3(256), 0, st>>>((const char *) w.p, (int64_t) w.nb[1], (int64_t) w.nb[2], (const char *) x.p, (int64_t) x.nb[1], (char *) y.p, (int64_t) y.nb[1], K, Cout, Cin, L, OL, s0);
 }
