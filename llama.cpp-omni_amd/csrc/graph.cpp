@@ -2223,8 +2223,27 @@ static bool recs_match(backend_ctx * c, const ggml_cgraph * g, const graph_exec 
 }
 
 // ------------------------------------------------------------------------------------------------ graph_compute
+// MI355X_DUMP_GRAPH=<file>: every submitted cgraph is appended to <file>, one line per node (op id, sub-op, type and shape of the result and of each source) --
+// how tools/graph_diff.py compares what the reference's graph builders submit with what this repo's Python mirrors build (debug facility; off by default)
+static void dump_graph(const ggml_cgraph * g, const char * path) {
+    static long serial = 0;
+    FILE * f = fopen(path, "a");
+    if (!f) return;
+    fprintf(f, "graph %ld nodes %d\n", serial++, g->n_nodes);
+    for (int i = 0; i < g->n_nodes; ++i) {
+        const ggml_tensor * n = g->nodes[i];
+        fprintf(f, "%d %d t%d [%lld,%lld,%lld,%lld]", (int) n->op, (n->op == GGML_OP_UNARY || n->op == GGML_OP_GLU) ? n->op_params[0] : -1, (int) n->type,
+                (long long) n->ne[0], (long long) n->ne[1], (long long) n->ne[2], (long long) n->ne[3]);
+        for (int k = 0; k < GGML_MAX_SRC && n->src[k]; ++k)
+            fprintf(f, " | t%d [%lld,%lld,%lld,%lld]", (int) n->src[k]->type, (long long) n->src[k]->ne[0], (long long) n->src[k]->ne[1], (long long) n->src[k]->ne[2], (long long) n->src[k]->ne[3]);
+        fputc('\n', f);
+    }
+    fclose(f);
+}
 enum ggml_status graph_compute(backend_ctx * c, ggml_cgraph * g) {
     if (g->n_nodes == 0) return GGML_STATUS_SUCCESS;
+    static const char * dump_path = getenv("MI355X_DUMP_GRAPH");
+    if (dump_path) dump_graph(g, dump_path);
     // Replay fast path: a graph that was captured before is launched straight from its fingerprint -- the five scratch-size passes and
     // the eligibility scans below are per-node host work in front of the launch, with the device idle (decode: ~1200 nodes).  Safe
     // because a capture exists only for an eligible graph whose scratch was sized, and growing any scratch block drops every capture.
