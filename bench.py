@@ -205,7 +205,16 @@ def cpu_baseline(pkg, cfg, types, n_kv, seconds_budget=24.0, tiny=False):
             if time.perf_counter() - t_start > 3 * seconds_budget:
                 break
         best = max(results)
-        return {"value": round(best[0], 3), "unit": "tok/s", "cores": best[1], "kind": "reference",
+        v3 = None
+        if build == "x86-64-v4":                                   # the same point on the AVX2 build (what the parity tests run): both figures are reported
+            env = dict(os.environ); env["ORACLE_REF_VARIANT"] = "v3"; env["OMP_NUM_THREADS"] = str(best[1])
+            if pin:
+                env["OMP_PLACES"] = ",".join("{%d}" % c for c in order[:best[1]]); env["OMP_PROC_BIND"] = "true"
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker", str(best[1]), "--cpu-baseline-seconds", str(seconds_budget / 4)] + (["--tiny"] if tiny else []),
+                               env=env, capture_output=True, text=True, timeout=300)
+            if r.returncode == 0:
+                v3 = round(json.loads(r.stdout.strip().splitlines()[-1])["tok_s"], 3)
+        return {"value": round(best[0], 3), "unit": "tok/s", "cores": best[1], "kind": "reference", "value_x86_64_v3_build": v3,
                 "gb_per_s": round(best[0] * wbytes / 1e9, 1) if wbytes else None,
                 "allowed_cpus": n_aff, "physical_cores_allowed": n_phys,
                 "thread_sweep_tok_s": {str(th): round(v, 3) for v, th, _ in results},
@@ -319,6 +328,50 @@ def via_libllama(threads=8, reps=5):
         return out
     except Exception as e:
         return {"error": repr(e)}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+def via_reference_omni_modules():
+    """BASELINE configs[3] / [4] legs through the REFERENCE's own module code with this backend loaded as a plug-in: oracle/_ref/omni-enc-min (tools/omni/audition.cpp,
+    vision.cpp) and oracle/_ref/t2w-min (tools/omni/token2wav/token2wav-impl.cpp) on the full-size synthetic module files of tools/make_synth_omni_gguf.py.  Wall time as the
+    caller of audition_audio_encode / vision_image_encode / Token2WavSession::feed_window sees it (host + device): one streaming second of audio through Whisper-medium,
+    one 448 x 448 slice through SigLip2 + resampler, and the Token2Wav real-time factor (seconds of compute per second of 24 kHz audio, windows after the first).
+    Checker-side binaries, present only when oracle/_ref travelled with the snapshot; the product library is what they run on."""
+    import shutil
+    import subprocess
+    import tempfile
+    enc, t2w = os.path.join(ROOT, "oracle", "_ref", "omni-enc-min"), os.path.join(ROOT, "oracle", "_ref", "t2w-min")
+    lib = os.path.join(ROOT, "llama.cpp-omni_amd", "lib", "libggml-mi355x.so")
+    if not (os.path.exists(enc) and os.path.exists(t2w)):
+        return None
+    tmp = tempfile.mkdtemp(prefix="mi355x_omni_")
+    gen = os.path.join(ROOT, "tools", "make_synth_omni_gguf.py")
+    env = dict(os.environ); env["GGML_BACKEND_PATH"] = lib; env["MTMD_BACKEND_DEVICE"] = "MI355X0"
+    out = {"harness": "oracle/_ref/omni-enc-min + oracle/_ref/t2w-min (reference audition.cpp / vision.cpp / token2wav-impl.cpp, plug-in from GGML_BACKEND_PATH), synthetic full-size module files"}
+
+    def last_json(r):
+        return json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    try:
+        for mod, args, key in (("apm", ["--chunks", "12", "--frames", "100"], "apm_whisper_1s_stream_chunk_ms"), ("vpm", ["--chunks", "4"], "vpm_siglip2_resampler_slice_ms")):
+            g = os.path.join(tmp, mod + ".gguf")
+            subprocess.run([sys.executable, gen, "--module", mod, "-o", g], check=True, timeout=600, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+            r = subprocess.run([enc, mod, g, os.path.join(tmp, mod + ".bin"), "--gpu"] + args, env=env, capture_output=True, text=True, timeout=600)
+            out[key] = round(last_json(r)["ms_last_chunk"], 3) if r.returncode == 0 else {"error": r.stderr[-300:]}
+            os.remove(g)
+        d = os.path.join(tmp, "t2w")
+        subprocess.run([sys.executable, gen, "--module", "t2w", "-o", d], check=True, timeout=600, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        r = subprocess.run([t2w, d, os.path.join(tmp, "w.f32"), "gpu", "--windows", "8"], env=env, capture_output=True, text=True, timeout=900)
+        if r.returncode == 0:
+            j = last_json(r)
+            steady = j["ms_windows"][2:-1]                          # (window 0 carries the first-touch costs, window 1 the hipGraph capture of the window graph, the last one is the longer final window)
+            out["t2w_rtf"] = round(sum(steady) / len(steady) / 1e3, 5); out["t2w_ms_per_1s_window"] = steady; out["t2w_rtf_all_windows"] = round(j["rtf"], 5)
+        else:
+            out["t2w_rtf"] = {"error": r.stderr[-300:]}
+        return out
+    except Exception as e:
+        out["error"] = repr(e)
+        return out
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
 
@@ -801,6 +854,7 @@ def main():
                 out["c3_f16_prefill"] = {"error": repr(e)}
         if world == 1 and not args.tiny and not args.no_libllama and not os.environ.get("MI355X_BENCH_NO_EXTRAS"):
             be.synchronize()
+            out["via_reference_omni_modules"] = via_reference_omni_modules()
             out["via_libllama"] = via_libllama()
             v = out["via_libllama"]
             if v and isinstance(v.get("fa1"), dict) and v["fa1"].get("tg128_tok_s"):
