@@ -2076,6 +2076,41 @@ static void compute_node(exec_state & s, int i) {
     note_write(s, n);
 }
 
+// The reference's Token2Wav builders put a ggml_cont behind most ops -- on tensors that are contiguous already (a third of a window's 15 000 launches are such
+// copies).  When the producer is a plain element-wise / gather op, the copy is the very next launching node and the producer's only reader (directly or through
+// RESHAPEs), the producer writes straight into the copy's buffer and the copy is not launched.  ggml-alloc may have placed the copy's buffer over memory that
+// became free when the producer ran -- the producer's own sources -- so that overlap is checked.  Returns the CONT's node index or -1.
+static int cont_sink(exec_state & s, int i) {
+    static const bool off = getenv("MI355X_NO_CONT_SINK") != nullptr;
+    if (off || !s.c->opt_fusion) return -1;
+    ggml_cgraph * g = s.g;
+    const ggml_tensor * p = g->nodes[i];
+    switch (p->op) {
+        case GGML_OP_ADD: case GGML_OP_SUB: case GGML_OP_MUL: case GGML_OP_DIV: case GGML_OP_SCALE: case GGML_OP_SQR: case GGML_OP_SQRT: case GGML_OP_LOG: case GGML_OP_SIN: case GGML_OP_COS:
+        case GGML_OP_CLAMP: case GGML_OP_LEAKY_RELU: case GGML_OP_CONCAT: case GGML_OP_REPEAT: case GGML_OP_PAD: case GGML_OP_PAD_REFLECT_1D: case GGML_OP_CONT: case GGML_OP_CONV_TRANSPOSE_1D:
+            break;
+        case GGML_OP_UNARY: break;
+        default: return -1;
+    }
+    if (!p->data || !is_contiguous(p) || is_out(s, p) || p->view_src) return -1;
+    const int j = next_real_node(s, i);
+    if (j < 0) return -1;
+    const ggml_tensor * c = g->nodes[j];
+    if (c->op != GGML_OP_CONT || c->type != p->type || !c->data || c->view_src || !is_contiguous(c) || nbytes(c) != nbytes(p) || c->data == p->data) return -1;
+    for (const ggml_tensor * t = c->src[0]; t != p; t = t->src[0]) {                  // directly, or through RESHAPEs of the contiguous result
+        if (!t || t->op != GGML_OP_RESHAPE || !is_contiguous(t) || is_out(s, t)) return -1;
+        auto it = s.users.find(t);
+        if (it == s.users.end() || it->second.size() != 1 || it->second[0] != j) return -1;
+    }
+    if (sole_user(s, p) != j) return -1;
+    const char * lo = (const char *) c->data, * hi = lo + nbytes(c);
+    for (int k = 0; k < GGML_MAX_SRC && p->src[k]; ++k) {
+        const char * a = (const char *) p->src[k]->data, * b = a + nbytes(p->src[k]);
+        if (a < hi && lo < b) return -1;
+    }
+    return j;
+}
+
 static void run_nodes(exec_state & s, ggml_cgraph * g) {
     s.g = g;
     s.done.assign(g->n_nodes, 0);
@@ -2128,7 +2163,16 @@ static void run_nodes(exec_state & s, ggml_cgraph * g) {
     }
     for (int i = 0; i < g->n_nodes; ++i) {
         if (s.done[i]) continue;
-        compute_node(s, i);
+        const int sink = cont_sink(s, i);
+        if (sink >= 0) {
+            void * own = g->nodes[i]->data;
+            g->nodes[i]->data = g->nodes[sink]->data;            // (the launches take the pointer now; the node gets its own back right after)
+            compute_node(s, i);
+            g->nodes[i]->data = own;
+            s.done[sink] = 1; ++s.n_fused;
+            note_write(s, g->nodes[sink]);
+        } else
+            compute_node(s, i);
         if (!s.capturing) {                                  // a launch with an invalid configuration fails silently otherwise (and poisons a later capture)
             const hipError_t e = hipGetLastError();
             if (e != hipSuccess) {
@@ -2230,8 +2274,16 @@ static void dump_graph(const ggml_cgraph * g, const char * path) {
     FILE * f = fopen(path, "a");
     if (!f) return;
     fprintf(f, "graph %ld nodes %d\n", serial++, g->n_nodes);
+    static const bool detail = getenv("MI355X_DUMP_GRAPH_DETAIL") != nullptr;       // + per source: its node index in this graph (-1: leaf) and whether it is contiguous
+    std::unordered_map<const ggml_tensor *, int> idx;
+    if (detail) for (int i = 0; i < g->n_nodes; ++i) idx[g->nodes[i]] = i;
     for (int i = 0; i < g->n_nodes; ++i) {
         const ggml_tensor * n = g->nodes[i];
+        if (detail) {
+            fprintf(f, "%d: op %d contig %d flags %d", i, (int) n->op, (int) is_contiguous(n), n->flags);
+            for (int k = 0; k < GGML_MAX_SRC && n->src[k]; ++k) { auto it = idx.find(n->src[k]); fprintf(f, " src %d contig %d op %d", it == idx.end() ? -1 : it->second, (int) is_contiguous(n->src[k]), (int) n->src[k]->op); }
+            fprintf(f, " ;; ");
+        }
         fprintf(f, "%d %d t%d [%lld,%lld,%lld,%lld]", (int) n->op, (n->op == GGML_OP_UNARY || n->op == GGML_OP_GLU) ? n->op_params[0] : -1, (int) n->type,
                 (long long) n->ne[0], (long long) n->ne[1], (long long) n->ne[2], (long long) n->ne[3]);
         for (int k = 0; k < GGML_MAX_SRC && n->src[k]; ++k)
