@@ -950,6 +950,29 @@ static bool exec_gemm_group(exec_state & s, int i) {
     if (a.nmat == 1 && a.m[0].dst_cs % 16 == 0 && gemm_split_scratch_bytes(a.m[0].M, N, K) <= s.c->gemm_partial_bytes) a.partial = (float *) s.c->gemm_partial;
     else if (a.nmat > 1 && N <= gemm_group_split_max_cols() && s.c->gemm_partial_bytes > 0) a.partial = (float *) s.c->gemm_partial;      // short prompts: split-K for the grouped launches too
     a.partial_bytes = s.c->gemm_partial_bytes;
+    // a streaming encoder chunk (<= 128 columns: split K, the result goes through the reduction launch): linear -> + bias -> + residual stream.  The second ADD
+    // (only reader of the first, same shape, its other operand ready) rides in the reduction's epilogue too: (acc + bias) + residual, the two roundings of the two nodes.
+    int add2_idx[3] = { -1, -1, -1 };
+    static const bool no_add2 = getenv("MI355X_NO_GEMM_ADD2") != nullptr;
+    if (!no_add2 && N <= 128 && gemm_f16_small_n_ksplit(a) > 1)
+        for (int q = 0; q < a.nmat; ++q) {
+            if (add_idx[q] < 0 || a.m[q].resid_cs != 0) continue;                       // (first addend: a bias row)
+            ggml_tensor * A = g->nodes[add_idx[q]];
+            const int a2 = sole_user(s, A);
+            if (a2 <= add_idx[q] || g->nodes[a2]->op != GGML_OP_ADD || s.done[a2]) continue;
+            ggml_tensor * A2 = g->nodes[a2];
+            const ggml_tensor * r2 = A2->src[0] == A ? A2->src[1] : A2->src[0];
+            if (((A2->src[0] == A) == (A2->src[1] == A)) || !r2 || r2 == A || r2->type != GGML_TYPE_F32 || A2->type != GGML_TYPE_F32 || !same_shape(r2, A) || !same_shape(A2, A) ||
+                r2->nb[0] != 4 || A2->nb[0] != 4 || r2->nb[1] % 16 != 0 || A2->nb[1] % 16 != 0 || A->ne[2] * A->ne[3] != 1) continue;
+            int item[10]; int ni = 0;
+            for (int t = 0; t < a.nmat; ++t) { item[ni++] = mm_idx[t]; if (add_idx[t] >= 0) item[ni++] = add_idx[t]; }
+            for (int t = 0; t < q; ++t) if (add2_idx[t] >= 0) item[ni++] = add2_idx[t];
+            item[ni++] = a2;
+            if (!can_hoist(s, i, a2, item, ni)) continue;
+            a.m[q].resid2 = (const float *) r2->data; a.m[q].resid2_cs = r2->nb[1];
+            a.m[q].dst = (float *) A2->data; a.m[q].dst_cs = A2->nb[1];
+            add2_idx[q] = a2;
+        }
     double flops = 0;
     for (int q = 0; q < a.nmat; ++q) flops += 2.0 * (double) a.m[q].M * (double) N * (double) K;
     // a split-K result whose next reader is RMS_NORM (wo / ffn_down + residual -> the next norm): leave the slabs, the norm reduces them
@@ -960,7 +983,7 @@ static bool exec_gemm_group(exec_state & s, int i) {
         (!a.m[0].resid || a.m[0].resid_cs % 16 == 0)) {
         int nx = (add_idx[0] >= 0 ? add_idx[0] : i) + 1;
         while (nx < g->n_nodes && (s.done[nx] || is_noop(g->nodes[nx]) || nx == add_idx[0])) ++nx;
-        if (nx < g->n_nodes && g->nodes[nx]->op == GGML_OP_RMS_NORM && g->nodes[nx]->src[0] == Aout) a.deferred_split = &nsplit;
+        if (nx < g->n_nodes && g->nodes[nx]->op == GGML_OP_RMS_NORM && g->nodes[nx]->src[0] == Aout && add2_idx[0] < 0) a.deferred_split = &nsplit;
     }
     {
         prof_scope ps(s, "gemm_f16", flops);
@@ -970,7 +993,8 @@ static bool exec_gemm_group(exec_state & s, int i) {
     if (nsplit > 1) { s.pr.A = Aout; s.pr.nsplit = nsplit; s.pr.resid = a.m[0].resid; s.pr.resid_cs = a.m[0].resid_cs; }
     for (int q = 0; q < a.nmat; ++q) {
         if (q > 0) { s.done[mm_idx[q]] = 1; ++s.n_fused; }
-        if (add_idx[q] >= 0) { s.done[add_idx[q]] = 1; ++s.n_fused; note_write(s, g->nodes[add_idx[q]]); }
+        if (add2_idx[q] >= 0) { s.done[add_idx[q]] = 1; s.done[add2_idx[q]] = 1; s.n_fused += 2; note_write(s, g->nodes[add2_idx[q]]); }
+        else if (add_idx[q] >= 0) { s.done[add_idx[q]] = 1; ++s.n_fused; note_write(s, g->nodes[add_idx[q]]); }
         else note_write(s, g->nodes[mm_idx[q]]);
     }
     return true;
@@ -2163,6 +2187,15 @@ static void run_nodes(exec_state & s, ggml_cgraph * g) {
     }
     for (int i = 0; i < g->n_nodes; ++i) {
         if (s.done[i]) continue;
+        static const bool host_prof = getenv("MI355X_HOST_PROF") != nullptr;          // host time of the node walk by op (stderr, per graph): where an eager graph's enqueue time goes
+        static double hp_ns[GGML_OP_COUNT]; static long hp_n[GGML_OP_COUNT];
+        const auto hp_t0 = host_prof ? std::chrono::steady_clock::now() : std::chrono::steady_clock::time_point();
+        struct hp_guard { bool on; int op; std::chrono::steady_clock::time_point t0; ~hp_guard() { if (on) { hp_ns[op] += (double) std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count(); ++hp_n[op]; } } } hp_g{ host_prof, (int) g->nodes[i]->op, hp_t0 };
+        if (host_prof && i == g->n_nodes - 1) {
+            fprintf(stderr, "[mi355x] host walk by op (cumulative):");
+            for (int o = 0; o < GGML_OP_COUNT; ++o) if (hp_n[o]) fprintf(stderr, " op%d n=%ld %.2fus/node", o, hp_n[o], hp_ns[o] / hp_n[o] * 1e-3);
+            fprintf(stderr, "\n");
+        }
         const int sink = cont_sink(s, i);
         if (sink >= 0) {
             void * own = g->nodes[i]->data;

@@ -237,7 +237,8 @@ void gemm_f16_mfma(const uint16_t * W, size_t w_rs, const uint16_t * X, size_t x
 // grouped form: up to three matrices sharing X in one launch, optional residual epilogue (dst = W.x + resid), and -- for a lone
 // under-filled matrix when `partial` scratch (gemm_split_scratch_bytes) is supplied -- deterministic split-K
 struct gemm_mat { const uint16_t * W; size_t w_rs; float * dst; size_t dst_cs; int64_t M; const float * resid; size_t resid_cs;
-                  int qtype = 0; };       // qtype != 0 (GGML_TYPE_Q4_K / Q6_K): W points at the block rows, de-quantised inside the GEMM's staging (all matrices of a launch alike; forces 128-row tiles)
+                  int qtype = 0;
+                  const float * resid2 = nullptr; size_t resid2_cs = 0; };    // a second addend behind the first (an encoder's bias, then the residual stream): (acc + resid) + resid2, each an f32 rounding like the two ADD nodes       // qtype != 0 (GGML_TYPE_Q4_K / Q6_K): W points at the block rows, de-quantised inside the GEMM's staging (all matrices of a launch alike; forces 128-row tiles)
 struct gemm_multi_args {
     gemm_mat m[3]; int nmat; const uint16_t * X; size_t x_rs; int64_t N, K; float * partial; size_t partial_bytes = (size_t) -1;
     // broadcast batch (nmat == 1, K % 64 == 0): nbatch = ne12 * ne13 products in one launch; batch b = i13 * ne12 + i12 reads
@@ -255,6 +256,7 @@ bool   gemm_reduce_rms_norm_ok(int64_t M);
 void   gemm_reduce_rms_norm(const float * partial, int nsplit, const float * resid, size_t resid_cs, float * dst, size_t dst_cs, const float * w, float eps,
                             float * y32, size_t y32_cs, uint16_t * y16, size_t y16_rs, int64_t M, int64_t N, hipStream_t st);
 void   gemm_f16_multi(const gemm_multi_args & a, hipStream_t st);
+int    gemm_f16_small_n_ksplit(const gemm_multi_args & a);      // the K split a launch of <= 128 columns will get (> 1: reduction epilogue, two addends per matrix possible)
 size_t gemm_split_scratch_bytes(int64_t M, int64_t N, int64_t K);
 long   gemm_variant_launches(int v);      // launches so far of the 256 x 256 (0) / 192-row (1) / gate-up-SWIGLU (2) tile kernels (test instrumentation)
 bool   gemm_glu_ok(const gemm_multi_args & a);

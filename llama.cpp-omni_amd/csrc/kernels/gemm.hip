@@ -745,6 +745,31 @@ __global__ void __launch_bounds__(256) k_gemm_reduce(const float * __restrict__ 
     *(f32x4 *) (dst + (size_t) n * dst_cs + (size_t) m * 4) = v;
 }
 
+// the same for every matrix of a grouped launch in ONE launch (wq / wk / wv of a short prompt or a streaming encoder chunk: three reductions of a few us each were three
+// dependent launches), with an optional second addend per matrix.  Slab s holds the matrices back to back as dense [N][M_i] blocks; quads never straddle (M_i % 4 == 0).
+struct gemm_reduce_multi_dev { int nmat, nsplit, N; size_t split_elems; size_t off[3]; int M[3]; const char * resid[3]; size_t resid_cs[3]; const char * resid2[3]; size_t resid2_cs[3]; char * dst[3]; size_t dst_cs[3]; };
+__global__ void __launch_bounds__(256) k_gemm_reduce_multi(const float * __restrict__ part, const gemm_reduce_multi_dev g) {
+    int64_t i = ((int64_t) blockIdx.x * 256 + threadIdx.x) * 4;
+    int q = 0;
+    for (; q < g.nmat; ++q) { const int64_t n = (int64_t) g.M[q] * g.N; if (i < n) break; i -= n; }
+    if (q >= g.nmat) return;
+    const int M = g.M[q], n = (int) (i / M), m = (int) (i % M);
+    const float * p = part + g.off[q] + i;
+    f32x4 v = *(const f32x4 *) p;
+    for (int s = 1; s < g.nsplit; ++s) { const f32x4 w = *(const f32x4 *) (p + s * g.split_elems); v += w; }
+    if (g.resid[q])  { const f32x4 w = *(const f32x4 *) (g.resid[q]  + (size_t) n * g.resid_cs[q]  + (size_t) m * 4); v += w; }
+    if (g.resid2[q]) { const f32x4 w = *(const f32x4 *) (g.resid2[q] + (size_t) n * g.resid2_cs[q] + (size_t) m * 4); v += w; }
+    *(f32x4 *) (g.dst[q] + (size_t) n * g.dst_cs[q] + (size_t) m * 4) = v;
+}
+// dst[n][m] += r[n][m] (rows of M % 4 == 0 floats): the second addend of a launch that did not split K
+__global__ void __launch_bounds__(256) k_gemm_add_rows(char * __restrict__ dst, size_t dst_cs, const char * __restrict__ r, size_t r_cs, int M, int N) {
+    const int64_t i = ((int64_t) blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i >= (int64_t) M * N) return;
+    const int n = (int) (i / M), m = (int) (i % M);
+    f32x4 * d = (f32x4 *) (dst + (size_t) n * dst_cs + (size_t) m * 4);
+    *d = *d + *(const f32x4 *) (r + (size_t) n * r_cs + (size_t) m * 4);
+}
+
 bool gemm_f16_ok(const void * W, size_t w_rs, const void * X, size_t x_rs, int64_t K) {
     return K % G_BK == 0 && K >= G_BK && w_rs % 16 == 0 && x_rs % 16 == 0 && ((uintptr_t) W & 15) == 0 && ((uintptr_t) X & 15) == 0;
 }
@@ -857,6 +882,18 @@ bool gemm_glu_ok(const gemm_multi_args & a) {
     static const bool off = getenv("MI355X_NO_GEMM_GLU") != nullptr;
     if (off || a.nmat != 2 || a.nbatch > 1 || a.K % H_BK != 0 || a.m[0].M != a.m[1].M || a.m[0].w_rs != a.m[1].w_rs || a.m[0].M % 128 != 0 || a.m[0].resid || a.m[1].resid) return false;
     return (a.m[0].M / 128) * ((a.N + 255) / 256) >= 128;
+}
+
+// K split gemm_f16_multi will choose for a launch of at most 128 columns (one column tile: neither the 192-row nor the 256 x 256 kernels apply); > 1 means the
+// result goes through the reduction, whose epilogue takes two addends per matrix.  Callers that want the second addend fused ask first.
+int gemm_f16_small_n_ksplit(const gemm_multi_args & a) {
+    if (a.N <= 0 || a.N > 128 || a.nmat <= 0 || a.nbatch > 1 || !a.partial || a.glu_out16 || a.K % H_BK != 0) return 1;
+    int64_t tm = 0, m_sum = 0; bool m4 = true;
+    for (int i = 0; i < a.nmat; ++i) { if (a.m[i].qtype != 0) return 1; tm += (a.m[i].M + G_BM - 1) / G_BM; m_sum += a.m[i].M; m4 = m4 && a.m[i].M % 4 == 0 && a.m[i].dst_cs % 16 == 0; }
+    if (!m4 || tm == 0) return 1;
+    int ksplit = pick_ksplit(tm, a.K / H_BK, a.N);
+    while (ksplit > 1 && (size_t) ksplit * (size_t) m_sum * (size_t) a.N * 4 > a.partial_bytes) --ksplit;
+    return ksplit;
 }
 
 void gemm_f16_multi(const gemm_multi_args & a, hipStream_t st) {
@@ -988,13 +1025,15 @@ void gemm_f16_multi(const gemm_multi_args & a, hipStream_t st) {
         if (kq) { k_gemm_kq_glds<<<dim3((unsigned) (tm * tiles_n * ksplit)), dim3(256), 2 * (128 * H_ROWB + H_TILEB), st>>>(g); ++g_gemm_variant_launches[3]; }
         else    k_gemm_f16_glds<2><<<dim3((unsigned) (tm * tiles_n * ksplit)), dim3(256), 2 * (128 * H_ROWB + H_TILEB), st>>>(g);
         if (a.nmat == 1 && a.deferred_split) { *a.deferred_split = ksplit; return; }          // the caller fuses the reduction into its next kernel
-        off = 0;
-        for (int i = 0; i < a.nmat; ++i) {
-            const gemm_mat & m = a.m[i];
-            const int64_t quads = m.M * a.N / 4;
-            if (quads > 0) k_gemm_reduce<<<dim3((unsigned) ((quads + 255) / 256)), dim3(256), 0, st>>>(a.partial + off, ksplit, slab, (const char *) m.resid, m.resid_cs, (char *) m.dst, m.dst_cs, (int) m.M, (int) a.N);
-            off += (size_t) m.M * (size_t) a.N;
+        gemm_reduce_multi_dev r; r.nmat = a.nmat; r.nsplit = ksplit; r.N = (int) a.N; r.split_elems = slab;
+        off = 0; int64_t quads = 0;
+        for (int i = 0; i < 3; ++i) {
+            const gemm_mat & m = a.m[i < a.nmat ? i : 0];
+            r.off[i] = off; r.M[i] = i < a.nmat ? (int) m.M : 0; r.resid[i] = (const char *) m.resid; r.resid_cs[i] = m.resid_cs; r.resid2[i] = (const char *) m.resid2; r.resid2_cs[i] = m.resid2_cs;
+            r.dst[i] = (char *) m.dst; r.dst_cs[i] = m.dst_cs;
+            if (i < a.nmat) { off += (size_t) m.M * (size_t) a.N; quads += m.M * a.N / 4; }
         }
+        if (quads > 0) k_gemm_reduce_multi<<<dim3((unsigned) ((quads + 255) / 256)), dim3(256), 0, st>>>(a.partial, r);
         return;
     }
     if (BM == 64) {
@@ -1010,6 +1049,9 @@ void gemm_f16_multi(const gemm_multi_args & a, hipStream_t st) {
     } else {
         k_gemm_f16_glds<2><<<dim3((unsigned) (tm * tiles_n), (unsigned) nbatch), dim3(256), 2 * (128 * H_ROWB + H_TILEB), st>>>(g);
     }
+    for (int i = 0; i < a.nmat; ++i)                               // (the tile epilogue takes one addend; a second one of an un-split launch goes on top)
+        if (a.m[i].resid2 && a.m[i].M * a.N > 0)
+            k_gemm_add_rows<<<dim3((unsigned) ((a.m[i].M * a.N / 4 + 255) / 256)), dim3(256), 0, st>>>((char *) a.m[i].dst, a.m[i].dst_cs, (const char *) a.m[i].resid2, a.m[i].resid2_cs, (int) a.m[i].M, (int) a.N);
 }
 
 void gemm_f16_mfma(const uint16_t * W, size_t w_rs, const uint16_t * X, size_t x_rs, float * dst, size_t dst_cs,
