@@ -56,6 +56,7 @@ struct fa1_dev {
     const char * k, * v, * mask; const float * sinks; char * dst;
     int q_hs, k_hs, v_hs, kc_rs, vc_rs, knb1, knb2, vnb1, vnb2, mnb2, mne2, dnb1;
     int nkv, gq, neox, n_head_log2;
+    int n_head, nkvh_log2;                                                   // query heads of the launch; log2 of the KV head count when it is a power of two (else -1): the head index without a division
     int vidx_st, vidx_n;                                                     // soft-max path: bytes per v scatter index, number of indices
     int has_norm;                                                            // q / k chains start with RMS_NORM * w (Qwen3) or are ROPE only (llama architecture)
     int nsplit; float * part;                                                // KV range cut into 256-row slices, one workgroup per (head, slice): partial (O, M, S) rows
@@ -67,8 +68,22 @@ static __device__ __forceinline__ __amdgpu_buffer_rsrc_t fa1_rsrc(const void * p
     return __builtin_amdgcn_make_buffer_rsrc((void *) p, (short) 0, bytes, 0x00020000);
 }
 
+// The first fourteen kernel-argument dwords -- what the first vector loads need: the raw q / k / v pointers, their head strides, the group size and the split count --
+// are plain scalar arguments in front of the block, so that they arrive pre-loaded in SGPRs (Makefile: -amdgpu-kernarg-preload-count for this object) and the
+// raw loads are issued before the scalar loads of the rest of the block have returned.
+#define FA1_LEAD_PARAMS const char * qraw_, const char * kraw_, const char * vraw_, int q_hs_, int k_hs_, int v_hs_, int gq_, int nsplit_, int n_head_, int nkvh_log2_, int neox_
+#define FA1_LEAD_ARGS(a) (a).qraw, (a).kraw, (a).vraw, (a).q_hs, (a).k_hs, (a).v_hs, (a).gq, (a).nsplit, (a).n_head, (a).nkvh_log2, (a).neox
+// head index of a workgroup: XCD-aware order (see k_fattn_one); one slice -- every cache view up to 256 rows -- has no division in front of its loads
+#define FA1_HEAD_INDEX \
+    int bh = (int) blockIdx.x, sp = 0; \
+    if (nsplit_ != 1) { sp = bh / n_head_; bh -= sp * n_head_; } \
+    const int row0 = sp * FA1_NKV; \
+    int ikv, hq; \
+    if (nkvh_log2_ >= 0) { ikv = bh & ((1 << nkvh_log2_) - 1); hq = bh >> nkvh_log2_; } \
+    else { const int nkvh_ = n_head_ / gq_; hq = bh / nkvh_; ikv = bh - hq * nkvh_; } \
+    const int h = ikv * gq_ + hq;
 template <int D>
-__global__ void __launch_bounds__(256) k_fattn_one(const fa1_dev a) {
+__global__ void __launch_bounds__(256) k_fattn_one(FA1_LEAD_PARAMS, const fa1_dev a) {
     constexpr int KCH = D / 32;                   // 16-B K chunks per lane (a quarter row)
     constexpr int NG  = FA1_NKV / 16 / 4;         // 16-row granules per wave
     constexpr int DPW = D / 4;                    // output dims per wave
@@ -84,21 +99,22 @@ __global__ void __launch_bounds__(256) k_fattn_one(const fa1_dev a) {
     // (rocprofv3 FETCH_SIZE: 4.4 MB -> ~1.1 MB per launch at n_kv 256)
     // deeper caches (257 .. 4096 rows): grid = heads x slices, slice sp takes rows [256 sp, 256 sp + 256) and leaves the partial state of its rows
     // (unnormalised O, running max M, sum S) for k_fattn_merge -- flash-decoding with this kernel's latency chain instead of the MFMA kernel's
-    const int n_head = (int) gridDim.x / a.nsplit, bh = (int) blockIdx.x % n_head, sp = (int) blockIdx.x / n_head, row0 = sp * FA1_NKV;
-    const int nkvh = n_head / a.gq, ikv = bh % nkvh, h = ikv * a.gq + bh / nkvh;
+    FA1_HEAD_INDEX
     const int nkv = a.nkv - row0 < FA1_NKV ? a.nkv - row0 : FA1_NKV;              // rows of this slice
 
     // ---------------------------------------------------------------- 1. request everything: one burst of vector loads, no wait in between
     // (buffer loads with exact bounds instead of branches or clamps: an out-of-range element reads as zero.  The row indices are fetched
     //  as VECTOR loads too: a scalar load of them would sit in front of every later kernarg read -- one more serial round trip.)
     const bool act = lane < HALF;
-    const int  e0 = a.neox ? lane : 2 * lane, e1 = a.neox ? lane + HALF : 2 * lane + 1;
-    const __amdgpu_buffer_rsrc_t xrs = fa1_rsrc(wave == 0 ? a.qraw + h * a.q_hs : (wave == 1 ? a.kraw + ikv * a.k_hs : a.vraw + ikv * a.v_hs), wave < 3 ? D * 4 : 0);
-    const __amdgpu_buffer_rsrc_t wrs = fa1_rsrc(wave == 0 ? a.qw : a.kw, (wave < 2 && a.has_norm) ? D * 4 : 0);
-    const __amdgpu_buffer_rsrc_t trs = fa1_rsrc(a.tab, wave < 2 ? D * 4 : 0);
+    const int  e0 = neox_ ? lane : 2 * lane, e1 = neox_ ? lane + HALF : 2 * lane + 1;
+    const __amdgpu_buffer_rsrc_t xrs = fa1_rsrc(wave == 0 ? qraw_ + h * q_hs_ : (wave == 1 ? kraw_ + ikv * k_hs_ : vraw_ + ikv * v_hs_), wave < 3 ? D * 4 : 0);
     // waves 0 / 1: rotation pair `lane` of the q / k head (elements e0, e1); wave 2: elements lane, lane + 64 of the v head
     const uint32_t xo0 = wave < 2 ? (act ? e0 * 4 : D * 4) : lane * 4, xo1 = wave < 2 ? (act ? e1 * 4 : D * 4) : (lane + 64) * 4;
     const float x0 = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(xrs, xo0, 0, 0)), x1 = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(xrs, xo1, 0, 0));
+    __builtin_amdgcn_sched_barrier(0);                             // (everything above needs only the pre-loaded arguments: the raw rows are requested before the first wait on the block's scalar loads)
+    int wave_b = wave; asm volatile("" : "+s"(wave_b));            // (an opaque copy: keeps the selects below out of the control flow of the select above, which must not wait for the block)
+    const __amdgpu_buffer_rsrc_t wrs = fa1_rsrc(wave_b == 0 ? a.qw : a.kw, (wave_b < 2 && a.has_norm) ? D * 4 : 0);
+    const __amdgpu_buffer_rsrc_t trs = fa1_rsrc(a.tab, wave_b < 2 ? D * 4 : 0);
     const float w0 = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(wrs, xo0, 0, 0)), w1 = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(wrs, xo1, 0, 0));
     const u32x2 tcs = __builtin_amdgcn_raw_buffer_load_b64(trs, act ? lane * 8 : D * 4, 0, 0);
     // mask row of this head: lane owns rows lane + 64 i
@@ -143,14 +159,14 @@ __global__ void __launch_bounds__(256) k_fattn_one(const fa1_dev a) {
             if (wave == 0) { qf[e0] = h2f(h0); qf[e1] = h2f(h1); }                 // q_to_vec_dot rounding (ops.cpp:8040)
             else {
                 kc[e0] = h2f(h0); kc[e1] = h2f(h1);
-                if (h % a.gq == 0 && owner) { uint16_t * kr = (uint16_t *) (a.kcache + (int64_t) krow_g * a.kc_rs) + ikv * D; kr[e0] = h0; kr[e1] = h1; }
+                if (hq == 0 && owner) { uint16_t * kr = (uint16_t *) (a.kcache + (int64_t) krow_g * a.kc_rs) + ikv * D; kr[e0] = h0; kr[e1] = h1; }
             }
         }
     } else if (wave == 2) {
         const uint16_t hv0 = f2h(x0), hv1 = f2h(x1);
         vc[lane] = h2f(hv0);
         if (D > 64) vc[lane + 64] = h2f(hv1);
-        if (h % a.gq == 0 && owner) {
+        if (hq == 0 && owner) {
             uint16_t * vr = (uint16_t *) (a.vcache + (int64_t) vrow_g * a.vc_rs) + ikv * D;
             vr[lane] = hv0;
             if (D > 64) vr[lane + 64] = hv1;
@@ -334,7 +350,7 @@ __global__ void __launch_bounds__(256) k_fattn_one(const fa1_dev a) {
 // (norm_rope, scatter, f32->f16 x2, batched mat-vec x2, soft-max, cont: 436 launches and 356 tok/s per decode step against 181 / 509 with
 // flash-attention on); here it is one.
 template <int D>
-__global__ void __launch_bounds__(256) k_attn_one_sm(const fa1_dev a) {
+__global__ void __launch_bounds__(256) k_attn_one_sm(FA1_LEAD_PARAMS, const fa1_dev a) {
     constexpr int KCH = D / 32, NG = FA1_NKV / 16 / 4, DPW = D / 4, HALF = D / 2;
     constexpr int LPD = 64 / DPW;                 // lanes per output dim (2 at D = 128, 4 at D = 64): each takes FA1_NKV / LPD consecutive cells
     constexpr int CPL = FA1_NKV / LPD;            // cells per lane
@@ -345,18 +361,19 @@ __global__ void __launch_bounds__(256) k_attn_one_sm(const fa1_dev a) {
     // deeper caches: grid = heads x slices of 256 cells, each slice leaves (O, M, S) of its cells and the last arriver of a head folds them (as
     // k_fattn_one does).  With one slice the arithmetic is the reference's to the letter (p normalised, then rounded to f16); with several the
     // weights stay f32 relative to the slice's own maximum -- the f16 rounding of p is the only thing not reproduced (~1e-10 NMSE on the output).
-    const int n_head = (int) gridDim.x / a.nsplit, bh = (int) blockIdx.x % n_head, sp = (int) blockIdx.x / n_head, row0 = sp * FA1_NKV;
-    const int nkvh = n_head / a.gq, ikv = bh % nkvh, h = ikv * a.gq + bh / nkvh;                                         // XCD-aware head order (k_fattn_one)
+    FA1_HEAD_INDEX
     const int nkv = a.nkv - row0 < FA1_NKV ? a.nkv - row0 : FA1_NKV;
 
     // ---------------------------------------------------------------- 1. request everything
     const bool act = lane < HALF;
-    const int  e0 = a.neox ? lane : 2 * lane, e1 = a.neox ? lane + HALF : 2 * lane + 1;
-    const __amdgpu_buffer_rsrc_t xrs = fa1_rsrc(wave == 0 ? a.qraw + h * a.q_hs : (wave == 1 ? a.kraw + ikv * a.k_hs : a.vraw + ikv * a.v_hs), wave < 3 ? D * 4 : 0);
-    const __amdgpu_buffer_rsrc_t wrs = fa1_rsrc(wave == 0 ? a.qw : a.kw, (wave < 2 && a.has_norm) ? D * 4 : 0);
-    const __amdgpu_buffer_rsrc_t trs = fa1_rsrc(a.tab, wave < 2 ? D * 4 : 0);
+    const int  e0 = neox_ ? lane : 2 * lane, e1 = neox_ ? lane + HALF : 2 * lane + 1;
+    const __amdgpu_buffer_rsrc_t xrs = fa1_rsrc(wave == 0 ? qraw_ + h * q_hs_ : (wave == 1 ? kraw_ + ikv * k_hs_ : vraw_ + ikv * v_hs_), wave < 3 ? D * 4 : 0);
     const uint32_t xo0 = wave < 2 ? (act ? e0 * 4 : D * 4) : lane * 4, xo1 = wave < 2 ? (act ? e1 * 4 : D * 4) : (lane + 64) * 4;
     const float x0 = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(xrs, xo0, 0, 0)), x1 = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(xrs, xo1, 0, 0));
+    __builtin_amdgcn_sched_barrier(0);                             // (everything above needs only the pre-loaded arguments: the raw rows are requested before the first wait on the block's scalar loads)
+    int wave_b = wave; asm volatile("" : "+s"(wave_b));            // (an opaque copy: keeps the selects below out of the control flow of the select above, which must not wait for the block)
+    const __amdgpu_buffer_rsrc_t wrs = fa1_rsrc(wave_b == 0 ? a.qw : a.kw, (wave_b < 2 && a.has_norm) ? D * 4 : 0);
+    const __amdgpu_buffer_rsrc_t trs = fa1_rsrc(a.tab, wave_b < 2 ? D * 4 : 0);
     const float w0 = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(wrs, xo0, 0, 0)), w1 = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(wrs, xo1, 0, 0));
     const u32x2 tcs = __builtin_amdgcn_raw_buffer_load_b64(trs, act ? lane * 8 : D * 4, 0, 0);
     const __amdgpu_buffer_rsrc_t mrs = fa1_rsrc(a.mask ? a.mask + (h % a.mne2) * a.mnb2 + row0 * 4 : a.mask, a.mask ? nkv * 4 : 0);          // f32 mask row
@@ -403,14 +420,14 @@ __global__ void __launch_bounds__(256) k_attn_one_sm(const fa1_dev a) {
             if (wave == 0) { qf[e0] = h2f(h0); qf[e1] = h2f(h1); }                 // MUL_MAT(k f16, q): q rounded to f16
             else {
                 kc[e0] = h2f(h0); kc[e1] = h2f(h1);
-                if (h % a.gq == 0 && owner) { uint16_t * kr = (uint16_t *) (a.kcache + (int64_t) krow_g * a.kc_rs) + ikv * D; kr[e0] = h0; kr[e1] = h1; }
+                if (hq == 0 && owner) { uint16_t * kr = (uint16_t *) (a.kcache + (int64_t) krow_g * a.kc_rs) + ikv * D; kr[e0] = h0; kr[e1] = h1; }
             }
         }
     } else if (wave == 2) {
         const uint16_t hv0 = f2h(x0), hv1 = f2h(x1);
         vc[lane] = h2f(hv0);
         if (D > 64) vc[lane + 64] = h2f(hv1);
-        if (h % a.gq == 0 && owner) {
+        if (hq == 0 && owner) {
             *(uint16_t *) (a.vcache + (int64_t) vi0 * 2) = hv0;
             if (D > 64) *(uint16_t *) (a.vcache + (int64_t) vi1 * 2) = hv1;
         }
@@ -582,9 +599,10 @@ void flash_attn_one(const fa_dev & f, int D, const float * rope_tab, hipStream_t
     a.has_norm = P.qw != nullptr; a.vidx_st = 0; a.vidx_n = 0;
     a.nsplit = f.nsplit > 1 ? f.nsplit : 1; a.part = f.part; a.cnt = f.nsplit > 1 ? f.cnt : nullptr;
     a.eps = P.eps; a.scale = f.scale; a.max_bias = f.max_bias; a.logit_softcap = f.logit_softcap; a.m0 = f.m0; a.m1 = f.m1;
+    a.n_head = f.nh; { const int nkvh = f.nh / (a.gq > 0 ? a.gq : 1); a.nkvh_log2 = (nkvh > 0 && (nkvh & (nkvh - 1)) == 0) ? __builtin_ctz((unsigned) nkvh) : -1; }
     const dim3 grid((unsigned) (f.nh * a.nsplit));
-    if (D == 64) k_fattn_one<64><<<grid, dim3(256), 0, st>>>(a);
-    else         k_fattn_one<128><<<grid, dim3(256), 0, st>>>(a);
+    if (D == 64) k_fattn_one<64><<<grid, dim3(256), 0, st>>>(FA1_LEAD_ARGS(a), a);
+    else         k_fattn_one<128><<<grid, dim3(256), 0, st>>>(FA1_LEAD_ARGS(a), a);
 }
 
 
@@ -614,9 +632,10 @@ void attn_one_sm(const attn_sm_args & f, hipStream_t st) {
     const int nsplit = (f.nkv + FA1_NKV - 1) / FA1_NKV;
     a.vidx_st = P.idx_is64 ? 8 : 4; a.vidx_n = (int) f.vidx_n; a.has_norm = P.qw != nullptr; a.nsplit = nsplit; a.part = nsplit > 1 ? (float *) f.part : nullptr; a.cnt = nsplit > 1 ? f.counters : nullptr;
     a.eps = P.eps; a.scale = f.scale; a.max_bias = 0.0f; a.logit_softcap = 0.0f; a.m0 = 1.0f; a.m1 = 1.0f;
+    a.n_head = f.n_head; a.nkvh_log2 = (f.n_head_kv & (f.n_head_kv - 1)) == 0 ? __builtin_ctz((unsigned) f.n_head_kv) : -1;
     const dim3 grid((unsigned) (f.n_head * nsplit));
-    if (f.D == 64) k_attn_one_sm<64><<<grid, dim3(256), 0, st>>>(a);
-    else           k_attn_one_sm<128><<<grid, dim3(256), 0, st>>>(a);
+    if (f.D == 64) k_attn_one_sm<64><<<grid, dim3(256), 0, st>>>(FA1_LEAD_ARGS(a), a);
+    else           k_attn_one_sm<128><<<grid, dim3(256), 0, st>>>(FA1_LEAD_ARGS(a), a);
 }
 
 } // namespace mi
