@@ -409,7 +409,7 @@ static bool ensure_scratch(backend_ctx * c, void ** p, size_t * have, size_t nee
     size_t n = need + need / 4; n = (n + ((size_t) 1 << 20) - 1) & ~(((size_t) 1 << 20) - 1);
     if (hipMalloc(p, n) != hipSuccess) {                    // the resident F16 weight images are the first thing to give back
         (void) hipGetLastError();
-        shadow_drop_all(c->device);
+        shadow_drop_all(c->device, c->shadow_hold);
         if (hipMalloc(p, n) != hipSuccess) { (void) hipGetLastError(); *p = nullptr; drop_graph_execs(c); return false; }
     }
     *have = n;
@@ -2329,6 +2329,9 @@ enum ggml_status graph_compute(backend_ctx * c, ggml_cgraph * g) {
     if (g->n_nodes == 0) return GGML_STATUS_SUCCESS;
     static const char * dump_path = getenv("MI355X_DUMP_GRAPH");
     if (dump_path) dump_graph(g, dump_path);
+    shadow_reader image_hold(c->device);                           // weight images looked up / baked into captures below stay alive until the launches are enqueued (shadow.hpp)
+    struct hold_guard { backend_ctx * c; ~hold_guard() { c->shadow_hold = nullptr; } } hg{ c };
+    c->shadow_hold = &image_hold;
     // Replay fast path: a graph that was captured before is launched straight from its fingerprint -- the five scratch-size passes and
     // the eligibility scans below are per-node host work in front of the launch, with the device idle (decode: ~1200 nodes).  Safe
     // because a capture exists only for an eligible graph whose scratch was sized, and growing any scratch block drops every capture.

@@ -60,6 +60,8 @@ struct backend_ctx {
     int      up_half = 0, up_n = 0; size_t up_used = 0;
     bool     opt_batch_uploads = true;
 
+    struct shadow_reader * shadow_hold = nullptr;   // graph_compute's reader hold on the device's weight-image table (shadow.hpp), for the out-of-memory path that drops the images
+
     // options
     bool opt_graphs = true;
     bool opt_fusion = true;

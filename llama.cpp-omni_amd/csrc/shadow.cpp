@@ -3,6 +3,7 @@
 #include <atomic>
 #include <cstring>
 #include <mutex>
+#include <shared_mutex>
 #include <vector>
 
 namespace mi {
@@ -87,7 +88,20 @@ void shadow_mark_ready(const void * image, hipStream_t st) {
         if (e.f16 == image) { HIP_CHECK(hipEventRecord(e.ready, st)); e.recorded = true; return; }
 }
 
-size_t shadow_drop_all(int device) {
+static std::shared_mutex & use_lock(int device) {
+    static std::shared_mutex locks[16];
+    return locks[device >= 0 && device < 16 ? device : 0];
+}
+shadow_reader::shadow_reader(int d) : device(d), held(false) { lock(); }
+shadow_reader::~shadow_reader() { unlock(); }
+void shadow_reader::lock()   { if (!held) { use_lock(device).lock_shared(); held = true; } }
+void shadow_reader::unlock() { if (held) { use_lock(device).unlock_shared(); held = false; } }
+
+size_t shadow_drop_all(int device, shadow_reader * mine) {
+    const bool had = mine && mine->held;
+    if (had) mine->unlock();
+    struct relock { shadow_reader * m; bool on; ~relock() { if (on) m->lock(); } } rl{ mine, had };
+    std::unique_lock<std::shared_mutex> ex(use_lock(device));          // no submission of any context of this device is between an image look-up and its launches
     std::vector<shadow_entry> dead;
     {
         std::lock_guard<std::mutex> lk(g_mu);

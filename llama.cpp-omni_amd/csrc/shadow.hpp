@@ -21,7 +21,11 @@ const uint16_t * shadow_find(int device, const void * src, int type, int64_t K, 
 uint16_t *       shadow_get_or_create(int device, const void * src, size_t src_bytes, int type, int64_t K, int64_t M, size_t src_rs, hipStream_t st, bool capturing, bool * created);
 void             shadow_mark_ready(const void * image, hipStream_t st);
 // drop every image of the device (an allocation failed: the images are the first thing to give back); returns the bytes freed
-size_t           shadow_drop_all(int device);
+// Images are shared by every backend context of a device (the omni pipeline runs LLM / TTS / Token2Wav on separate threads): a context that looks images up and
+// enqueues launches reading them holds the device's image table as a READER for that whole submission (graph_compute does: shadow_reader); shadow_drop_all takes it
+// exclusively, so it frees only when no submission is between "pointer looked up" and "launch enqueued" -- hipFree then waits for the enqueued work itself.
+struct shadow_reader { int device; bool held; explicit shadow_reader(int device); ~shadow_reader(); void unlock(); void lock(); };
+size_t           shadow_drop_all(int device, shadow_reader * mine = nullptr);      // mine: the caller's own reader hold (released around the exclusive section)
 size_t           shadow_bytes(int device);
 // bytes [p, p+n) of device memory are about to change: drop the overlapping images
 void             shadow_invalidate(int device, const void * p, size_t n);
