@@ -435,3 +435,83 @@ def test_reference_token2wav_end_to_end_on_the_plugin(tmp_path):
         assert e <= 1e-4, (e, per)
     finally:
         shutil.rmtree(d, ignore_errors=True)
+
+
+# ------------------------------------------------------------------------------------------------ concurrent module threads on one device
+def test_three_module_threads_on_one_device_give_their_single_thread_results(pkg):
+    """SURVEY.md 8(b) threading: the omni pipeline drives LLM, TTS / encoders and Token2Wav from separate host threads, each with its own backend (= stream) on the same
+    device (omni.h:194-196).  Three threads -- a decoder at the 8B widths (LDS-DMA mat-vec engine, one-token attention, hipGraph replay, staged uploads), a Whisper layer over
+    500 frames (f16 MFMA GEMMs, LayerNorm fusion, soft-max) and a Token2Wav DiT block (f32 MFMA products, im2col convolutions, element-wise chains) -- run at the same
+    time on three backends of device 0; every output must be bit-identical to what the same thread body produces when it runs alone.  Catches shared state between
+    contexts (scratch blocks, weight-image table, arrival counters, kernel-side statics)."""
+    import threading
+    sys.path.insert(0, ROOT)
+    import bench
+    from llama_cpp_omni_amd import encoders as E, qwen3, token2wav as T
+    cfg = dict(qwen3.QWEN3_8B); cfg["n_layer"] = 2; cfg["n_vocab"] = 4096
+
+    def flat(W):
+        out = [v for k, v in W.items() if k != "layers" and hasattr(v, "nelements")]
+        for L in W.get("layers", []):
+            out += list(L.values())
+        return out
+
+    def fill(b, tensors, seed):
+        rng = np.random.default_rng(seed)
+        for t in tensors:
+            n = t.nelements()
+            v = (rng.standard_normal(n) * 0.05).astype(np.float32)
+            b.tensor_set(t, v.astype(np.float16) if t.type == 1 else (np.abs(v) + 0.5 if t.type == 0 and n <= 4096 else v) if t.type == 0 else np.zeros(n, np.int32))
+
+    def body_llm(out):
+        b = pkg.Backend(0)
+        dec = bench.Decoder(pkg, b, cfg, qwen3.q4_k_m_types(cfg), n_ctx=256, n_kv=256, flash_attn=True, seed=77)
+        for p in range(200):
+            dec.step(p)
+            out.append(dec.h_logits.copy())
+        dec.g.free(); dec.model.wctx.free(); b.close()
+
+    def body_apm(out):
+        b = pkg.Backend(0)
+        c = pkg.Context(b)
+        W = E.whisper_weights(c, E.WHISPER, 1); inp, res = E.whisper(c, E.WHISPER, W, 500)
+        c.alloc(); fill(b, flat(W) + [inp], 5)
+        g = c.graph()
+        for _ in range(120):
+            b.graph_compute(g)
+            out.append(b.tensor_get(res).copy())
+        c.free(); b.close()
+
+    def body_t2w(out):
+        b = pkg.Backend(0)
+        c = pkg.Context(b)
+        W = T.dit_weights(c, T.DIT); x, cond, res = T.dit_block(c, T.DIT, W, 56)
+        c.alloc(); fill(b, flat(W) + [x, cond], 9)
+        g = c.graph()
+        for _ in range(300):
+            b.graph_compute(g)
+            out.append(b.tensor_get(res).copy())
+        c.free(); b.close()
+    bodies = (body_llm, body_apm, body_t2w)
+    alone = []
+    for f in bodies:
+        o = []; f(o); alone.append(o)
+    together = [[] for _ in bodies]
+    errs = []
+
+    def run(f, o):
+        try:
+            f(o)
+        except Exception as e:           # noqa: BLE001
+            errs.append(repr(e))
+    th = [threading.Thread(target=run, args=(f, o)) for f, o in zip(bodies, together)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(600)
+    assert not errs, errs
+    for name, a, b in zip(("llm", "apm", "t2w"), alone, together):
+        assert len(a) == len(b) and len(a) > 0, name
+        assert all(np.isfinite(x).all() for x in b), name
+        bad = [i for i, (x, y) in enumerate(zip(a, b)) if not np.array_equal(x, y)]
+        assert not bad, (name, bad[:8])
