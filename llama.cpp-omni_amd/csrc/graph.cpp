@@ -2135,6 +2135,100 @@ static int cont_sink(exec_state & s, int i) {
     return j;
 }
 
+// A run of element-wise f32 nodes, each the next launching node and the only reader of the one before (directly or through RESHAPEs), all over the same number of
+// contiguous elements: one k_ew_chain launch writes the last node's result (kernels.hpp ew_chain_args).  Other operands are "external": the chain's shape element for
+// element, one row of ne0 floats repeated (bias / gain / modulation vectors), or one value.  Returns the number of nodes taken (0: none; the caller marks them done).
+static int exec_ew_chain(exec_state & s, int i, int * taken) {
+    static const bool off = getenv("MI355X_NO_EW_CHAIN") != nullptr;
+    if (off || !s.c->opt_fusion) return 0;
+    ggml_cgraph * g = s.g;
+    auto ew_kind = [](const ggml_tensor * n) -> bool {
+        switch (n->op) {
+            case GGML_OP_ADD: case GGML_OP_SUB: case GGML_OP_MUL: case GGML_OP_DIV: case GGML_OP_SCALE: case GGML_OP_UNARY: case GGML_OP_SQR: case GGML_OP_SQRT: case GGML_OP_LOG:
+            case GGML_OP_SIN: case GGML_OP_COS: case GGML_OP_CLAMP: case GGML_OP_LEAKY_RELU: return true;
+            default: return false;
+        }
+    };
+    auto plain = [](const ggml_tensor * t) { return t && t->type == GGML_TYPE_F32 && t->data && is_contiguous(t) && ((uintptr_t) t->data & 15) == 0; };
+    const ggml_tensor * first = g->nodes[i];
+    if (!ew_kind(first) || !plain(first) || nelements(first) % 4 != 0 || nelements(first) < 4) return 0;
+    const int64_t total = nelements(first);
+    ew_chain_args a;
+    a.total = total;
+    const ggml_tensor * ext[6]; int n_ext = 0;
+    const ggml_tensor * res[8]; int idx[8]; int n = 0;
+    auto through_reshapes = [&](const ggml_tensor * t, const ggml_tensor * target, int consumer) -> bool {       // t is `target` seen through RESHAPEs read only by `consumer`
+        for (; t != target; t = t->src[0]) {
+            if (!t || t->op != GGML_OP_RESHAPE || is_out(s, t)) return false;
+            auto it = s.users.find(t);
+            if (it == s.users.end() || it->second.size() != 1 || it->second[0] != consumer) return false;
+        }
+        return true;
+    };
+    int j = i;
+    while (n < 8) {
+        const ggml_tensor * nd = g->nodes[j];
+        if (!ew_kind(nd) || !plain(nd) || nelements(nd) != total) break;
+        const bool binary = nd->op == GGML_OP_ADD || nd->op == GGML_OP_SUB || nd->op == GGML_OP_MUL || nd->op == GGML_OP_DIV;
+        int sel[2] = { -1, -1 };
+        const int n_ext0 = n_ext;
+        bool ok = true, uses_prev = n == 0;
+        for (int k = 0; k < (binary ? 2 : 1) && ok; ++k) {
+            const ggml_tensor * o = nd->src[k];
+            if (!o) { ok = false; break; }
+            if (n > 0 && through_reshapes(o, res[n - 1], j)) { sel[k] = 8 + (n - 1); uses_prev = true; continue; }
+            // an external operand
+            if (o->type != GGML_TYPE_F32 || !o->data || !is_contiguous(o)) { ok = false; break; }
+            int mode;
+            if (nelements(o) == total && (k == 0 || same_shape(o, nd))) mode = 0;
+            else if (k == 1 && nelements(o) == 1) mode = 2;
+            else if (k == 1 && o->ne[0] == nd->ne[0] && o->ne[1] * o->ne[2] * o->ne[3] == 1 && o->ne[0] % 4 == 0) mode = 1;
+            else { ok = false; break; }
+            if (mode != 2 && ((uintptr_t) o->data & 15) != 0) { ok = false; break; }
+            int e = -1;
+            for (int q = 0; q < n_ext; ++q) if (ext[q]->data == o->data && a.in_mode[q] == mode && (mode != 1 || a.in_n04[q] == (uint32_t) (o->ne[0] / 4))) e = q;
+            if (e < 0) {
+                if (n_ext >= 6) { ok = false; break; }
+                e = n_ext++; ext[e] = o; a.in[e] = (const float *) o->data; a.in_mode[e] = mode; a.in_n04[e] = mode == 1 ? (uint32_t) (o->ne[0] / 4) : 1;
+            }
+            sel[k] = e;
+        }
+        if (ok && binary && nd->src[0] && nelements(nd->src[0]) != total) ok = false;      // (ggml: the result has src0's shape)
+        if (!ok || !uses_prev) { n_ext = n_ext0; break; }
+        ew_op_desc & d = a.op[n];
+        d.kind = (int) nd->op; d.sub = nd->op == GGML_OP_UNARY ? op_param_i32(nd, 0) : 0; d.a = sel[0]; d.b = binary ? sel[1] : sel[0];
+        d.p0 = op_param_f32(nd, 0); d.p1 = op_param_f32(nd, 1);
+        res[n] = nd; idx[n] = j; ++n;
+        // may the chain go on?  the result must have exactly one reader, the next launching node
+        if (is_out(s, nd)) break;
+        const int u = sole_user(s, nd);
+        const int nx = next_real_node(s, j);
+        if (u < 0 || u != nx) break;
+        j = nx;
+    }
+    if (n < 2) return 0;
+    // trim: the last node's readers are free, but a chain must not end where a fused consumer expects to see the node itself (f16-emitting UNARY in front of a GEMM)
+    const ggml_tensor * last = res[n - 1];
+    const ggml_tensor * xg = nullptr;
+    if (last->ne[2] == 1 && last->ne[3] == 1 && gemm_only_consumers(s, last, last->ne[0], last->ne[1], &xg)) return 0;
+    // the result's buffer may sit on memory of the chain's dead inputs: identical position (mode 0) is fine, anything else is not
+    const byte_range out = range_of(last);
+    for (int q = 0; q < n_ext; ++q) {
+        const byte_range r = range_of(ext[q]);
+        if (overlap(out, r) && !(a.in_mode[q] == 0 && ext[q]->data == last->data)) return 0;
+    }
+    a.n_ops = n; a.n_in = n_ext; a.out = (float *) last->data;
+    if (n_ext == 0) return 0;
+    {
+        prof_scope ps(s, "ew_chain", 0);
+        ew_chain(a, s.st);
+    }
+    ++s.n_kernels; s.n_fused += n - 1;
+    for (int k = 0; k < n; ++k) taken[k] = idx[k];
+    note_write(s, last);
+    return n;
+}
+
 static void run_nodes(exec_state & s, ggml_cgraph * g) {
     s.g = g;
     s.done.assign(g->n_nodes, 0);
@@ -2195,6 +2289,11 @@ static void run_nodes(exec_state & s, ggml_cgraph * g) {
             fprintf(stderr, "[mi355x] host walk by op (cumulative):");
             for (int o = 0; o < GGML_OP_COUNT; ++o) if (hp_n[o]) fprintf(stderr, " op%d n=%ld %.2fus/node", o, hp_n[o], hp_ns[o] / hp_n[o] * 1e-3);
             fprintf(stderr, "\n");
+        }
+        {
+            int taken[8];
+            const int nt = is_noop(g->nodes[i]) ? 0 : exec_ew_chain(s, i, taken);
+            if (nt > 0) { for (int k = 0; k < nt; ++k) s.done[taken[k]] = 1; continue; }
         }
         const int sink = cont_sink(s, i);
         if (sink >= 0) {

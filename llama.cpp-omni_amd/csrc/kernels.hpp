@@ -255,6 +255,16 @@ void   gemm_reduce(const float * partial, int nsplit, const float * resid, size_
 bool   gemm_reduce_rms_norm_ok(int64_t M);
 void   gemm_reduce_rms_norm(const float * partial, int nsplit, const float * resid, size_t resid_cs, float * dst, size_t dst_cs, const float * w, float eps,
                             float * y32, size_t y32_cs, uint16_t * y16, size_t y16_rs, int64_t M, int64_t N, hipStream_t st);
+// A chain of element-wise f32 nodes in one launch (elementwise.hip k_ew_chain): op j reads external inputs (selector 0..5) or the result of an earlier op of the chain
+// (selector 8 + index) and only the last result is stored.  Each op is the arithmetic of its stand-alone kernel (the library is built with -ffp-contract=off: nothing fuses
+// across ops), so a chain gives the stand-alone launches' values bit for bit.
+struct ew_op_desc { int kind; int sub; int a, b; float p0, p1; };     // kind: GGML_OP_ADD / SUB / MUL / DIV / SCALE / UNARY (sub = the unary op) / SQR / SQRT / LOG / SIN / COS / CLAMP / LEAKY_RELU
+struct ew_chain_args {
+    int n_ops = 0; ew_op_desc op[8];
+    int n_in = 0; const float * in[6]; int in_mode[6]; uint32_t in_n04[6];      // mode 0: the chain's shape, element for element; 1: one row of 4 * in_n04 floats repeated; 2: one value
+    float * out = nullptr; int64_t total = 0;                                  // total % 4 == 0, every pointer 16-byte aligned (mode 2: 4-byte)
+};
+void   ew_chain(const ew_chain_args & a, hipStream_t st);
 void   gemm_f16_multi(const gemm_multi_args & a, hipStream_t st);
 int    gemm_f16_small_n_ksplit(const gemm_multi_args & a);      // the K split a launch of <= 128 columns will get (> 1: reduction epilogue, two addends per matrix possible)
 size_t gemm_split_scratch_bytes(int64_t M, int64_t N, int64_t K);

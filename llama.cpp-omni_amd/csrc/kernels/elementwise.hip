@@ -921,6 +921,64 @@ void bin_bcast_f32(int op, const tdesc & a, const tdesc & b, const tdesc & y, hi
 }
 
 // ================================================================================================
+// chains of element-wise nodes (kernels.hpp ew_chain_args): the reference's Token2Wav graphs spell Mish as sub / exp / exp / add / log / tanh / mul and the DiT's
+// modulation as mul / add / add -- 3500 of a window's launches are links of such chains, each a ~4 us dependent launch over a few hundred KB
+// ================================================================================================
+struct ew_chain_dev { int n_ops, n_in; uint32_t total4; ew_op_desc op[8]; const float * in[6]; int in_mode[6]; uint32_t in_n04[6]; float * out; };
+static __device__ __forceinline__ float ew_apply(const ew_op_desc & o, float a, float b) {
+    switch (o.kind) {
+        case GGML_OP_ADD:        return a + b;
+        case GGML_OP_SUB:        return a - b;
+        case GGML_OP_MUL:        return a * b;
+        case GGML_OP_DIV:        return a / b;
+        case GGML_OP_SCALE:      return a * o.p0 + o.p1;                                   // k_scale
+        case GGML_OP_UNARY:      return unary_apply(o.sub, a);
+        case GGML_OP_SQR:        return a * a;                                             // k_math (t2w_ops.hip)
+        case GGML_OP_SQRT:       return sqrtf(a);
+        case GGML_OP_LOG:        return logf(a);
+        case GGML_OP_SIN:        return sinf(a);
+        case GGML_OP_COS:        return cosf(a);
+        case GGML_OP_CLAMP:      return fmaxf(fminf(a, o.p1), o.p0);
+        case GGML_OP_LEAKY_RELU: return (a > 0.0f ? a : 0.0f) + o.p0 * (a < 0.0f ? a : 0.0f);
+        default:                 return a;
+    }
+}
+__global__ void __launch_bounds__(256) k_ew_chain(const ew_chain_dev c) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= c.total4) return;
+    f32x4 v[6 + 8];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        if (k >= c.n_in) break;
+        if (c.in_mode[k] == 2) { const float s = c.in[k][0]; v[k] = f32x4{ s, s, s, s }; }
+        else v[k] = ((const f32x4 *) c.in[k])[c.in_mode[k] == 1 ? i % c.in_n04[k] : i];
+    }
+    f32x4 r = v[0];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        if (j >= c.n_ops) break;
+        const ew_op_desc o = c.op[j];
+        f32x4 a = r, b = r;
+        // (selectors are wave-uniform: a short uniform switch instead of dynamically indexed registers)
+#pragma unroll
+        for (int k = 0; k < 14; ++k) { if ((o.a < 8 ? o.a : 6 + o.a - 8) == k) a = v[k]; if ((o.b < 8 ? o.b : 6 + o.b - 8) == k) b = v[k]; }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) r[e] = ew_apply(o, a[e], b[e]);
+        v[6 + j] = r;
+    }
+    ((f32x4 *) c.out)[i] = r;
+}
+void ew_chain(const ew_chain_args & a, hipStream_t st) {
+    if (a.total == 0) return;
+    if (a.n_ops < 1 || a.n_ops > 8 || a.n_in < 1 || a.n_in > 6 || a.total % 4 != 0 || a.total / 4 >= (1ll << 32) || ((uintptr_t) a.out & 15) != 0) { fprintf(stderr, "[mi355x] ew_chain: unsupported arguments\n"); abort(); }
+    ew_chain_dev c;
+    c.n_ops = a.n_ops; c.n_in = a.n_in; c.total4 = (uint32_t) (a.total / 4); c.out = a.out;
+    for (int j = 0; j < 8; ++j) c.op[j] = a.op[j < a.n_ops ? j : 0];
+    for (int k = 0; k < 6; ++k) { const int q = k < a.n_in ? k : 0; c.in[k] = a.in[q]; c.in_mode[k] = a.in_mode[q]; c.in_n04[k] = a.in_n04[q] ? a.in_n04[q] : 1; }
+    k_ew_chain<<<dim3((c.total4 + 255) / 256), dim3(256), 0, st>>>(c);
+}
+
+// ================================================================================================
 // CPY / CONT / DUP: element i (row-major over src->ne) of src -> element i of dst (row-major over dst->ne)
 // (ggml_compute_forward_dup, ops.cpp): types f32 <-> f16, arbitrary strides on both sides.
 // ================================================================================================

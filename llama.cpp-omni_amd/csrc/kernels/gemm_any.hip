@@ -307,7 +307,8 @@ void gemm_any(const gemm_any_args & a, hipStream_t st) {
         static const bool no_rows = getenv("MI355X_NO_GEMM_F32_ROWS") != nullptr;
         if (!no_rows && !a.x_f16 && !a.w_f16 && !a.w_bf16 && a.K % 4 == 0 &&
             (((uintptr_t) a.W | a.w_rs | a.w_nb2 | a.w_nb3 | (uintptr_t) a.X | a.x_rs | a.x_nb2 | a.x_nb3) & 15) == 0) {       // f32 x f32, 16-byte aligned rows: no LDS staging, one round trip per 128 k
-            if (a.K <= 512) k_gemm_f32_rows<4><<<grid, dim3(256), 0, st>>>(g); else k_gemm_f32_rows<8><<<grid, dim3(512), 0, st>>>(g);
+            static const int force_nw = getenv("MI355X_GEMM_F32_ROWS_NW") ? atoi(getenv("MI355X_GEMM_F32_ROWS_NW")) : 0;
+            if (force_nw == 4 || (force_nw == 0 && a.K <= 512)) k_gemm_f32_rows<4><<<grid, dim3(256), 0, st>>>(g); else k_gemm_f32_rows<8><<<grid, dim3(512), 0, st>>>(g);
             return;
         }
         if (a.x_f16)      k_gemm_any_sk<uint16_t, uint16_t><<<grid, dim3(256), 0, st>>>(g);
