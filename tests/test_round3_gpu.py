@@ -515,3 +515,35 @@ def test_three_module_threads_on_one_device_give_their_single_thread_results(pkg
         assert all(np.isfinite(x).all() for x in b), name
         bad = [i for i, (x, y) in enumerate(zip(a, b)) if not np.array_equal(x, y)]
         assert not bad, (name, bad[:8])
+
+
+def test_elementwise_chains_are_one_launch_and_bit_identical(pkg, be):
+    """k_ew_chain: Token2Wav's Mish spelling (sub / exp / exp / add / log / tanh / mul) and a DiT-style modulation (mul by a row vector, add, add a row vector, scale, leaky_relu)
+    over [512, 56]: with fusion on the runs collapse into chain launches, and every value equals the one-launch-per-node result bit for bit (-ffp-contract=off: nothing fuses
+    across the ops)."""
+    from llama_cpp_omni_amd import token2wav as T
+    from llama_cpp_omni_amd.ggml import UNARY
+    rng = np.random.default_rng(31)
+    res = {}
+    for fusion in (0, 1):
+        be.set_option("fusion", fusion)
+        c = pkg.Context(be)
+        x = c.new_tensor(pkg.GGML_TYPE_F32, 512, 56, 1)
+        sc = c.new_tensor(pkg.GGML_TYPE_F32, 512, 1, 1); sh = c.new_tensor(pkg.GGML_TYPE_F32, 512, 1, 1)
+        m = T.mish(c, x)                                               # 7 nodes
+        y = c.add(c.add(m, c.mul(m, sc)), sh)                          # modulate: the first add reads m twice -> a chain boundary
+        z = c.leaky_relu(c.scale(y, 0.5, 0.25), 0.1) if hasattr(c, "leaky_relu") else c.scale(y, 0.5, 0.25)
+        out = c.unary(z, UNARY.TANH)
+        keep = c.scale(out, 1.0)                                       # (a plain reader so that `out` is materialised whatever follows)
+        c.alloc()
+        rs = np.random.default_rng(32)
+        be.tensor_set(x, rs.standard_normal(512 * 56).astype(np.float32))
+        be.tensor_set(sc, (rs.standard_normal(512) * 0.2).astype(np.float32)); be.tensor_set(sh, (rs.standard_normal(512) * 0.2).astype(np.float32))
+        be.graph_compute(c.graph())
+        res[fusion] = (be.tensor_get(keep).copy(), int(be.get_stat("kernels_last_graph")))
+        c.free()
+    be.set_option("fusion", 1)
+    (a, ka), (b, kb) = res[0], res[1]
+    print(f"element-wise graph: {ka} launches one per node, {kb} with chains")
+    assert np.isfinite(a).all() and np.array_equal(a, b)
+    assert kb <= ka - 6, (ka, kb)
