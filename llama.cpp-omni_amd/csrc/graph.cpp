@@ -376,6 +376,10 @@ static size_t graph_gemm_partial_need(const ggml_cgraph * g) {
     for (int i = 0; i < g->n_nodes; ++i) {
         const ggml_tensor * n = g->nodes[i];
         if (n->op != GGML_OP_MUL_MAT || is_empty(n) || n->src[1]->ne[2] != 1 || n->src[1]->ne[3] != 1) continue;
+        if (mm_takes_gemm_any(n) && n->src[0]->type == GGML_TYPE_F32 && n->src[1]->type == GGML_TYPE_F32) {      // small f32 x f32 products may split K over workgroups (gemm_any.hip)
+            const size_t b = gemm_any_split_scratch_bytes(n->src[0]->ne[1], n->src[1]->ne[1], n->src[0]->ne[0], 1, true);
+            if (b > need) need = b;
+        }
         if (!mm_uses_gemm(n)) {                              // the split form of op_mul_mat (F16 weights, K a few columns past a multiple of 64): its MFMA part is a lone, usually under-filled GEMM
             const int64_t K = n->src[0]->ne[0];
             if (n->src[0]->type == GGML_TYPE_F16 && n->src[1]->type == GGML_TYPE_F32 && K % 64 != 0 && K >= 512 && n->src[1]->ne[1] > MI_MMVQ_MAX_COLS) {
@@ -590,6 +594,11 @@ static void op_mul_mat(exec_state & s, const ggml_tensor * dst, const ggml_tenso
         }
         a.dst = (float *) out->data; a.dst_cs = out->nb[1]; a.dst_nb2 = out->nb[2]; a.dst_nb3 = out->nb[3]; a.accumulate = k_done > 0; a.bias = bias;
         a.M = M; a.N = N; a.K = K - k_done; a.nbatch = (int) (ne12 * ne13); a.ne12 = (int) ne12; a.r2 = (int) r2; a.r3 = (int) r3;
+        if (s.c->gemm_partial && !s.c->fa_counters && !s.capturing) {      // (first use is an eager submission: captures come from the second on)
+            if (hipMalloc((void **) &s.c->fa_counters, 1024 * sizeof(unsigned)) == hipSuccess) HIP_CHECK(hipMemsetAsync(s.c->fa_counters, 0, 1024 * sizeof(unsigned), s.st));
+            else { (void) hipGetLastError(); s.c->fa_counters = nullptr; }
+        }
+        if (s.c->gemm_partial && s.c->fa_counters) { a.partial = (float *) s.c->gemm_partial; a.partial_bytes = s.c->gemm_partial_bytes; a.counters = s.c->fa_counters; a.n_counters = 1024; }
         prof_scope ps(s, w->type == GGML_TYPE_F16 ? "gemm_any_f16" : "gemm_any_f32", 2.0 * (double) M * (double) N * (double) (K - k_done) * (double) (ne12 * ne13));
         gemm_any(a, s.st);
         ++s.n_kernels;

@@ -278,7 +278,11 @@ struct gemm_any_args {
     int64_t M, N, K; int nbatch = 1, ne12 = 1, r2 = 1, r3 = 1;
     bool accumulate = false;                 // dst += W.X (the K tail behind a gemm_f16 launch over the first K - K % 64 columns)
     const float * bias = nullptr;            // dst[n][m] = W.X + bias[m]: the ADD of a [M] row vector that follows the mat-mul (one more f32 rounding, as the separate op)
+    // optional, for small f32 x f32 products with a long K: split K over workgroups too; partial tiles go to `partial`, the last workgroup of a tile to arrive (ticket in
+    // `counters`, zero between launches) folds them in split order.  Both belong to the calling backend context (one stream: launches do not overlap).
+    float * partial = nullptr; size_t partial_bytes = 0; unsigned * counters = nullptr; int n_counters = 0;
 };
 void   gemm_any(const gemm_any_args & a, hipStream_t st);
+size_t gemm_any_split_scratch_bytes(int64_t M, int64_t N, int64_t K, int nbatch, bool f32_operands);      // what the split above needs for this shape (0: it would not split)
 
 } // namespace mi

@@ -22,6 +22,7 @@ struct gemm_any_dev {
     char * dst; size_t dst_cs, dst_nb2, dst_nb3;
     const float * bias;
     int M, N, K, tiles_m, ne12, r2, r3, round_x, accumulate;      // round_x: 0 none, 1 activations rounded to f16, 2 to bf16 (and the 16-bit weights are bf16)
+    float * partial; unsigned * counters; int ksplit;             // k_gemm_f32_sk128: K split over gridDim.z workgroups (1: none)
 };
 
 template <typename WT, typename XT>
@@ -290,12 +291,129 @@ __global__ void __launch_bounds__(NW * 64) k_gemm_f32_rows(const gemm_any_dev g)
     }
 }
 
+// The small f32 x f32 products once more, with COALESCED operand reads.  k_gemm_f32_rows' per-lane row reads fetch each 128-byte line with eight separate 16-byte
+// requests from eight different instructions; with a few waves per CU in flight the lines are gone from the 16 KB L1 in between and every request goes back to L2
+// (4 MB of fc2 weights: 23 us on 32 workgroups).  Here a wave reads TWO rows x 512 contiguous bytes per instruction (whole lines), stages its own 32 x 128 slice of
+// each operand in a wave-private LDS region (rows padded to 132 floats) and feeds v_mfma_f32_32x32x2f32 from 16-byte LDS reads -- lane (row, half) takes the quad at
+// k = 8 q + 4 half of its row for MFMAs 4 q .. 4 q + 3: both operands use the same assignment, which is all the instruction needs.  K is split over the four waves in
+// 128-deep steps, the next step's global reads are in flight under the current step's 64 MFMAs, no workgroup barrier inside the loop; partial tiles folded in wave order.
+extern __shared__ float ga_dyn_lds[];
+__global__ void __launch_bounds__(256) k_gemm_f32_sk128(const gemm_any_dev g) {
+    constexpr int KS = 128, LD = KS + 4;
+    float * Ws = ga_dyn_lds + (threadIdx.x >> 6) * (2 * 32 * LD), * Xs = Ws + 32 * LD;
+    float * red = ga_dyn_lds + 4 * (2 * 32 * LD);                  // [3][64 * 16]
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int tm = (int) blockIdx.x % g.tiles_m, tn = (int) blockIdx.x / g.tiles_m;        // (tiles_m counts 32-row tiles)
+    const int i12 = (int) blockIdx.y % g.ne12, i13 = (int) blockIdx.y / g.ne12;
+    const char * W = g.W + (size_t) (i12 / g.r2) * g.w_nb2 + (size_t) (i13 / g.r3) * g.w_nb3;
+    const char * X = g.X + (size_t) i12 * g.x_nb2 + (size_t) i13 * g.x_nb3;
+    const int m0 = tm * 32, n0 = tn * 32, fr = lane & 31, kh = lane >> 5;
+    const int nsteps = (g.K + KS - 1) / KS;
+    const int kz = (int) blockIdx.z, spz = (nsteps + g.ksplit - 1) / g.ksplit;                     // this workgroup's steps [z_lo, z_hi)
+    const int z_lo = kz * spz, z_hi = z_lo + spz < nsteps ? z_lo + spz : nsteps;
+    const int per = (z_hi - z_lo + 3) / 4;
+    const int s_lo = z_lo + wave * per, s_hi = s_lo + per < z_hi ? s_lo + per : z_hi;
+    ga_acc acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.0f;
+    // staging map: instruction i of 16 covers tile rows 2 i, 2 i + 1; lane (kh, fr) the quad fr of row 2 i + kh
+    float4 wv[16], xv[16];
+    auto fetch = [&](int k0) {                                     // branch-free: clamped addresses (K % 4 == 0), zero selected afterwards
+        const int k = k0 + 4 * fr, kc = k < g.K ? k : g.K - 4;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int r = 2 * i + kh;
+            const int mr = m0 + r < g.M ? m0 + r : g.M - 1, nr = n0 + r < g.N ? n0 + r : g.N - 1;
+            wv[i] = *(const float4 *) (W + (size_t) mr * g.w_rs + (size_t) kc * 4);
+            xv[i] = *(const float4 *) (X + (size_t) nr * g.x_rs + (size_t) kc * 4);
+        }
+        if (k >= g.K) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { wv[i] = make_float4(0.f, 0.f, 0.f, 0.f); xv[i] = make_float4(0.f, 0.f, 0.f, 0.f); }
+        }
+    };
+    if (s_lo < s_hi) fetch(s_lo * KS);
+    for (int s = s_lo; s < s_hi; ++s) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { *(float4 *) &Ws[(2 * i + kh) * LD + 4 * fr] = wv[i]; *(float4 *) &Xs[(2 * i + kh) * LD + 4 * fr] = xv[i]; }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (s + 1 < s_hi) fetch((s + 1) * KS);
+#pragma unroll
+        for (int q = 0; q < KS / 8; ++q) {
+            const float4 a = *(const float4 *) &Xs[fr * LD + 8 * q + 4 * kh], b = *(const float4 *) &Ws[fr * LD + 8 * q + 4 * kh];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc, 0, 0, 0);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    if (wave > 0) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) red[(wave - 1) * 1024 + e * 64 + lane] = acc[e];
+    }
+    __syncthreads();
+    if (wave > 0) return;
+    float v[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        v[e] = acc[e];
+#pragma unroll
+        for (int w = 0; w < 3; ++w) v[e] += red[w * 1024 + e * 64 + lane];
+    }
+    if (g.ksplit > 1) {                                            // (batch 1 only: the launcher)
+        const int tile = (int) blockIdx.x, ntiles = (int) gridDim.x;
+        float * mine = g.partial + ((size_t) kz * ntiles + tile) * 1024;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) mine[e * 64 + lane] = v[e];
+        __threadfence();                                           // the partial tile is visible device-wide before the ticket is taken
+        unsigned ticket = 0;
+        if (lane == 0) ticket = __hip_atomic_fetch_add(g.counters + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ticket = __builtin_amdgcn_readfirstlane(ticket);
+        if (ticket != (unsigned) (g.ksplit - 1)) return;
+        __threadfence();
+#pragma unroll
+        for (int e = 0; e < 16; ++e) v[e] = 0.0f;
+        for (int z = 0; z < g.ksplit; ++z) {                       // split order, whoever arrives last: deterministic
+            const float * p = g.partial + ((size_t) z * ntiles + tile) * 1024;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) v[e] += __builtin_nontemporal_load(p + e * 64 + lane);
+        }
+        if (lane == 0) __hip_atomic_store(g.counters + tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // zero again for the next launch
+    }
+    char * dst = g.dst + (size_t) i12 * g.dst_nb2 + (size_t) i13 * g.dst_nb3;
+    const int m = m0 + fr;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int n = n0 + (e & 3) + 8 * (e >> 2) + 4 * kh;
+        float r = v[e];
+        if (m < g.M && n < g.N) { float * p = (float *) (dst + (size_t) n * g.dst_cs + (size_t) m * 4); if (g.accumulate) r = *p + r; if (g.bias) r = __fadd_rn(r, g.bias[m]); *p = r; }
+    }
+}
+
+// K split over workgroups for k_gemm_f32_sk128: only when the tiles leave most CUs idle and every workgroup still gets whole 128-deep steps for its four waves
+static int gemm_any_ksplit(int64_t M, int64_t N, int64_t K, int nbatch) {
+    static const bool off = getenv("MI355X_NO_GEMM_F32_KSPLIT") != nullptr;
+    if (off || nbatch != 1 || K % 4 != 0) return 1;
+    const int64_t tiles = ((M + 31) / 32) * ((N + 31) / 32), nsteps = (K + 127) / 128;
+    if (tiles > 96 || nsteps < 8) return 1;
+    int s = (int) (nsteps / 4); if (s > 4) s = 4;
+    while (s > 1 && tiles * s > 256) --s;
+    return s < 1 ? 1 : s;
+}
+size_t gemm_any_split_scratch_bytes(int64_t M, int64_t N, int64_t K, int nbatch, bool f32_operands) {
+    if (!f32_operands) return 0;
+    const int s = gemm_any_ksplit(M, N, K, nbatch);
+    return s > 1 ? (size_t) s * (size_t) (((M + 31) / 32) * ((N + 31) / 32)) * 1024 * 4 : 0;
+}
+
 void gemm_any(const gemm_any_args & a, hipStream_t st) {
     if (a.M == 0 || a.N == 0 || a.nbatch == 0) return;
     gemm_any_dev g;
     g.W = (const char *) a.W; g.w_rs = a.w_rs; g.w_nb2 = a.w_nb2; g.w_nb3 = a.w_nb3;
     g.X = (const char *) a.X; g.x_rs = a.x_rs; g.x_nb2 = a.x_nb2; g.x_nb3 = a.x_nb3;
     g.dst = (char *) a.dst; g.dst_cs = a.dst_cs; g.dst_nb2 = a.dst_nb2; g.dst_nb3 = a.dst_nb3;
+    g.partial = nullptr; g.counters = nullptr; g.ksplit = 1;
     g.M = (int) a.M; g.N = (int) a.N; g.K = (int) a.K; g.tiles_m = (int) ((a.M + 63) / 64); g.ne12 = a.ne12; g.r2 = a.r2; g.r3 = a.r3; g.round_x = a.w_bf16 ? 2 : (a.w_f16 ? 1 : 0); g.accumulate = a.accumulate ? 1 : 0; g.bias = a.bias;
     static const bool no_sk = getenv("MI355X_GEMM_ANY_NO_SPLIT") != nullptr;
     // (F16 weights have the f16 matrix cores below -- 8x the K per MFMA, paired loads: their chains are short without a split; measured on Whisper's
@@ -307,6 +425,21 @@ void gemm_any(const gemm_any_args & a, hipStream_t st) {
         static const bool no_rows = getenv("MI355X_NO_GEMM_F32_ROWS") != nullptr;
         if (!no_rows && !a.x_f16 && !a.w_f16 && !a.w_bf16 && a.K % 4 == 0 &&
             (((uintptr_t) a.W | a.w_rs | a.w_nb2 | a.w_nb3 | (uintptr_t) a.X | a.x_rs | a.x_nb2 | a.x_nb3) & 15) == 0) {       // f32 x f32, 16-byte aligned rows: no LDS staging, one round trip per 128 k
+            static const bool no_sk128 = getenv("MI355X_NO_GEMM_F32_SK128") != nullptr;
+            if (!no_sk128) {
+                constexpr int lds = (4 * 2 * 32 * 132 + 3 * 1024) * 4;     // 147 456 B: one workgroup per CU
+                static bool attr[64] = {};
+                int dev = 0; HIP_CHECK(hipGetDevice(&dev));
+                if (dev < 0 || dev >= 64 || !attr[dev]) { HIP_CHECK(hipFuncSetAttribute((const void *) k_gemm_f32_sk128, hipFuncAttributeMaxDynamicSharedMemorySize, lds)); if (dev >= 0 && dev < 64) attr[dev] = true; }
+                const int ks = gemm_any_ksplit(a.M, a.N, a.K, a.nbatch);
+                const size_t need = gemm_any_split_scratch_bytes(a.M, a.N, a.K, a.nbatch, true);
+                if (ks > 1 && a.partial && a.counters && need <= a.partial_bytes && (int64_t) grid.x <= a.n_counters) {
+                    g.partial = a.partial; g.counters = a.counters; g.ksplit = ks;
+                    k_gemm_f32_sk128<<<dim3(grid.x, grid.y, (unsigned) ks), dim3(256), lds, st>>>(g);
+                } else
+                    k_gemm_f32_sk128<<<grid, dim3(256), lds, st>>>(g);
+                return;
+            }
             static const int force_nw = getenv("MI355X_GEMM_F32_ROWS_NW") ? atoi(getenv("MI355X_GEMM_F32_ROWS_NW")) : 0;
             if (force_nw == 4 || (force_nw == 0 && a.K <= 512)) k_gemm_f32_rows<4><<<grid, dim3(256), 0, st>>>(g); else k_gemm_f32_rows<8><<<grid, dim3(512), 0, st>>>(g);
             return;
