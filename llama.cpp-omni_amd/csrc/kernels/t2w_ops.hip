@@ -58,9 +58,26 @@ __global__ void __launch_bounds__(256) k_concat(t4 a, t4 b, t4 y, int dim) {
         *(T *) (y.p + i[0] * y.nb[0] + i[1] * y.nb[1] + i[2] * y.nb[2] + i[3] * y.nb[3]) = *(const T *) s;
     }
 }
+// dense operands: the result is `outer` repetitions of [A elements of a][B elements of b] (A, B = the operands' extents below and including `dim`), 16 bytes per thread
+__global__ void __launch_bounds__(256) k_concat_dense(const uint4 * __restrict__ a, const uint4 * __restrict__ b, uint4 * __restrict__ y, uint32_t A4, uint32_t B4, uint32_t total4) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= total4) return;
+    const uint32_t o = i / (A4 + B4), r = i - o * (A4 + B4);
+    y[i] = r < A4 ? a[o * A4 + r] : b[o * B4 + (r - A4)];
+}
 void concat(const tdesc & a, const tdesc & b, const tdesc & y, int dim, int elem_size, hipStream_t st) {
     const int64_t total = y.ne[0] * y.ne[1] * y.ne[2] * y.ne[3];
     if (total == 0) return;
+    {
+        auto dense = [&](const tdesc & t) { size_t s = (size_t) elem_size; for (int d = 0; d < 4; ++d) { if (t.ne[d] > 1 && t.nb[d] != s) return false; s *= (size_t) t.ne[d]; } return ((uintptr_t) t.p & 15) == 0; };
+        int64_t A = elem_size, B = elem_size;
+        for (int d = 0; d <= dim; ++d) { A *= a.ne[d]; B *= b.ne[d]; }
+        if (dim >= 0 && dim < 4 && dense(a) && dense(b) && dense(y) && A % 16 == 0 && B % 16 == 0 && A > 0 && B > 0 && total * elem_size / 16 < (1ll << 32)) {
+            const uint32_t total4 = (uint32_t) (total * elem_size / 16);
+            k_concat_dense<<<dim3((total4 + 255) / 256), dim3(256), 0, st>>>((const uint4 *) a.p, (const uint4 *) b.p, (uint4 *) y.p, (uint32_t) (A / 16), (uint32_t) (B / 16), total4);
+            return;
+        }
+    }
     if (elem_size == 4) k_concat<uint32_t><<<grid_for(total), dim3(256), 0, st>>>(to_t4(a), to_t4(b), to_t4(y), dim);
     else                k_concat<uint16_t><<<grid_for(total), dim3(256), 0, st>>>(to_t4(a), to_t4(b), to_t4(y), dim);
 }
