@@ -194,6 +194,11 @@ static __device__ __forceinline__ void mv2_loader(const mv1_rsrc rs0, const mv1_
     // the first step goes out at once -- it takes the loader's cold-start latency (address translation, first DRAM page) in parallel with the row
     // waves' -- the rest of the stream behind the row requests
     for (; n < MV2_PRE && n < T; ++n) issue();
+    // (the gate / up launch is bound by this wave's stream -- its consumers start with > 1 us of slack -- so its stream does not wait for the row requests; the short
+    //  launches are bound by when consumption can start, there the row goes first)
+#ifndef MV2_PAIR_WAITS
+    if (R != 2)
+#endif
     mv2_await(MV2_FLAG(F->rows_issued), MV2_ROW_WAVES);
     MV2_STAMP(2);
     while (n < T) {
