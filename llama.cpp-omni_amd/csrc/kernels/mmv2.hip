@@ -197,7 +197,7 @@ static __device__ __forceinline__ void mv2_loader(const mv1_rsrc rs0, const mv1_
     // (the gate / up launch is bound by this wave's stream -- its consumers start with > 1 us of slack -- so its stream does not wait for the row requests; the short
     //  launches are bound by when consumption can start, there the row goes first)
 #ifndef MV2_PAIR_WAITS
-    if (R != 2)
+    if (R != 2)                                         // (tried for ffn_down too -- 48 KB row: 8.1 -> 9.3 us)
 #endif
     mv2_await(MV2_FLAG(F->rows_issued), MV2_ROW_WAVES);
     MV2_STAMP(2);
