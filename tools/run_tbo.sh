@@ -10,7 +10,7 @@ OPS="$@"
 [ -z "$OPS" ] && OPS="MUL_MAT ADD SUB MUL DIV RMS_NORM SCALE ROPE SOFT_MAX CPY CONT DUP GET_ROWS SET_ROWS FLASH_ATTN_EXT SWIGLU REGLU GEGLU GEGLU_ERF GEGLU_QUICK ABS SGN NEG STEP TANH ELU RELU SIGMOID GELU GELU_QUICK SILU HARDSWISH HARDSIGMOID EXP GELU_ERF NORM IM2COL POOL_2D SQR SQRT LOG SIN COS CLAMP LEAKY_RELU CONCAT REPEAT PAD PAD_REFLECT_1D ARANGE TIMESTEP_EMBEDDING SUM_ROWS CONV_TRANSPOSE_1D"
 rc=0
 for op in $OPS; do
-  timeout ${TBO_TIMEOUT:-600} ./oracle/_ref/test-backend-ops test -b MI355X0 -o $op > gpurun_out/tbo_$op.log 2>&1
+  timeout ${TBO_TIMEOUT:-2400} ./oracle/_ref/test-backend-ops test -b MI355X0 -o $op > gpurun_out/tbo_$op.log 2>&1
   r=$?
   echo "== $op rc=$r: $(grep -E 'tests passed' gpurun_out/tbo_$op.log | tail -1)  fails: $(grep -c 'FAIL' gpurun_out/tbo_$op.log)"
   grep -E "FAIL" gpurun_out/tbo_$op.log | sed -E 's/\x1b\[[0-9;]*m//g' | head -6
