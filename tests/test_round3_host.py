@@ -59,3 +59,20 @@ def test_graph_diff_tool_counts_compute_nodes_and_ignores_layout_nodes(tmp_path)
     assert r.returncode == 0, r.stderr
     assert "A: 3 compute nodes" in r.stdout and "B: 2 compute nodes" in r.stdout
     assert "identical (op, types, shapes) nodes: 2; only in A: 1; only in B: 0" in r.stdout and "CONT" in r.stdout
+
+
+def test_synthetic_token2wav_set_runs_in_the_reference_module_on_cpu(tmp_path):
+    """tools/make_synth_omni_gguf.py --module t2w writes what tools/omni/token2wav/token2wav-impl.cpp binds (every tensor name and layout of the conformer encoder, the DiT,
+    the flow extras and the HiFT vocoder, plus the prompt bundle): the reference's own Token2WavSession sets up the prompt caches and produces one window of audio on the CPU backend."""
+    t2w = os.path.join(ROOT, "oracle", "_ref", "t2w-min")
+    if not os.path.exists(t2w):
+        pytest.skip("oracle/_ref/t2w-min not built (make -f oracle/Makefile.ref omni)")
+    d = str(tmp_path / "t2w")
+    subprocess.run([sys.executable, os.path.join(ROOT, "tools", "make_synth_omni_gguf.py"), "--module", "t2w", "--prompt-tokens", "28", "-o", d], check=True, timeout=600)
+    env = dict(os.environ); env.pop("GGML_BACKEND_PATH", None)
+    o = str(tmp_path / "w.f32")
+    r = subprocess.run([t2w, d, o, "cpu", "--windows", "1"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-2000:]
+    j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    w = np.fromfile(o, np.float32)
+    assert j["samples"] == w.size and w.size >= 24000 and np.isfinite(w).all() and float(w.std()) > 0.01 and float(np.abs(w).max()) <= 1.1

@@ -226,9 +226,10 @@ if __name__ == "__main__":
     ap.add_argument("-o", "--out", required=True)
     ap.add_argument("--layers", type=int, default=0, help="encoder blocks (default: 24 for apm, 27 for vpm)")
     ap.add_argument("--seed", type=int, default=7)
+    ap.add_argument("--prompt-tokens", type=int, default=78, help="t2w: tokens of the prompt bundle (its mel has (n - 3) * 2 frames)")
     a = ap.parse_args()
     if a.module == "t2w":
-        t2w(a.out, a.seed)
+        t2w(a.out, a.seed, a.prompt_tokens)
     elif a.module == "apm":
         apm(a.out, a.layers or 24, a.seed)
     else:
