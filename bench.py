@@ -487,6 +487,8 @@ def extra_legs(pkg, be, headline_no_fa):
         legs = [("tts_q8_0_decode", qwen3.TTS, qwen3.uniform_types(qwen3.TTS, pkg.GGML_TYPE_Q8_0), True)]
         if not headline_no_fa:
             legs.insert(0, ("qwen3_8b_q4_k_m_decode_no_fa", qwen3.QWEN3_8B, qwen3.q4_k_m_types(qwen3.QWEN3_8B), False))
+        # BASELINE configs[4] ships the 8B LLM as Q8_0 (tools/omni/convert/run_convert.sh:67-70): the same decode step on all-Q8_0 weights (8.7 GB per token)
+        legs.append(("qwen3_8b_q8_0_decode", qwen3.QWEN3_8B, qwen3.uniform_types(qwen3.QWEN3_8B, pkg.GGML_TYPE_Q8_0), True))
         for name, cfg, types, fa in legs:
             dec = Decoder(pkg, be, cfg, types, n_ctx=256, n_kv=256, flash_attn=fa, seed=4321)
             for p in range(8):
@@ -500,6 +502,10 @@ def extra_legs(pkg, be, headline_no_fa):
             ok = bool(np.isfinite(dec.h_logits).all())
             res[name] = {"tok_s": round(64 / dt, 1) if ok else None, "ms_per_step": round(dt / 64 * 1e3, 4), "kernels_per_token": be.get_stat("kernels_last_graph"),
                          "n_layer": cfg["n_layer"], "n_embd": cfg["n_embd"]}
+            if name == "qwen3_8b_q8_0_decode" and ok:
+                wb = dec.model.weight_bytes()
+                res[name]["weight_bytes_per_token"] = wb
+                res[name]["hbm_frac_whole_step"] = round(wb * (64 / dt) / 1e9 / HBM_PEAK_GBS, 4)
             dec.g.free(); dec.model.wctx.free()
     except Exception as e:  # extras never cost the headline
         res["error"] = repr(e)

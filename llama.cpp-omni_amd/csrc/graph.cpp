@@ -1121,6 +1121,19 @@ static void exec_mul_mat(exec_state & s, int i) {
             }
         }
     }
+    if (N == 1 && !use_mmq) {
+        // the launch as a whole (the node checks above looked at every matrix alone, without its residual): e.g. a residual on a matrix of more rows than
+        // the engine's residual staging holds -- drop the epilogue fusion rather than the batch-1 kernel
+        mv1_args t; t.nmat = nm; t.K = K; t.img = (const void *) 16;
+        for (int q = 0; q < nm; ++q) t.m[q] = a.m[q];
+        if (!mmv1_ok(t)) {
+            for (int q = 0; q < nm; ++q) if (add_idx[q] >= 0) {
+                ggml_tensor * c = g->nodes[mm_idx[q]];
+                a.m[q].resid = nullptr; a.m[q].resid_cs = 0; a.m[q].dst = (float *) c->data; a.m[q].dst_cs = c->nb[1];
+                add_idx[q] = -1;
+            }
+        }
+    }
     const ggml_tensor * outs[3] = { nullptr, nullptr, nullptr };
     for (int q = 0; q < nm; ++q) outs[q] = add_idx[q] >= 0 ? g->nodes[add_idx[q]] : g->nodes[mm_idx[q]];
     bool all_mv1 = N == 1 && !use_mmq;

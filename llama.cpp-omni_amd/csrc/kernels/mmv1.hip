@@ -318,8 +318,13 @@ namespace mi {
 // with one row per task
 static const int MV1_WAVES = 4096;
 
+static int g_mv2 = -1;
+void mmv2_enable(bool on) { g_mv2 = on ? 1 : 0; }
+static bool mv2_on() { if (g_mv2 < 0) { const char * e = getenv("MI355X_MV2"); g_mv2 = e ? (atoi(e) != 0) : 1; } return g_mv2 != 0; }
+
 bool mmv1_ok(const mv1_args & a) {
-    if (a.nmat >= 1 && (a.m[0].type == GGML_TYPE_Q8_0 || a.m[0].type == GGML_TYPE_F16)) return mmv1q_ok(a);          // the Q8_0 / F16 twins (mmv1q.hip)
+    if (a.nmat >= 1 && (a.m[0].type == GGML_TYPE_Q8_0 || a.m[0].type == GGML_TYPE_F16))                                 // the Q8_0 / F16 twins (mmv1q.hip), or the engine for Q8_0 at the 8B widths
+        return mmv1q_ok(a) || (a.m[0].type == GGML_TYPE_Q8_0 && mv2_on() && mmv2_ok(a));
     if (a.nmat < 1 || a.nmat > 3 || a.K <= 0 || a.K % 256 != 0 || a.K > 16384) return false;              // (K % 4096 != 0: the TAIL instances)
     if (a.W_up && a.nmat != 1) return false;
     for (int i = 0; i < a.nmat; ++i) {
@@ -344,13 +349,13 @@ static void mv1_go(const mv1_dev & d, int tm, int grid, hipStream_t st) {
     else { fprintf(stderr, "[mi355x] mmv1: a gate / up pair of mixed types\n"); abort(); }
 }
 
-static int g_mv2 = -1;
-void mmv2_enable(bool on) { g_mv2 = on ? 1 : 0; }
 
 void mmv1(const mv1_args & a, hipStream_t st) {
-    if (a.nmat >= 1 && (a.m[0].type == GGML_TYPE_Q8_0 || a.m[0].type == GGML_TYPE_F16)) { mmv1q(a, st); return; }
-    if (g_mv2 < 0) { const char * e = getenv("MI355X_MV2"); g_mv2 = e ? (atoi(e) != 0) : 1; }
-    if (g_mv2 && mmv2_ok(a)) { mmv2(a, st); return; }
+    if (a.nmat >= 1 && (a.m[0].type == GGML_TYPE_Q8_0 || a.m[0].type == GGML_TYPE_F16)) {
+        if (a.m[0].type == GGML_TYPE_Q8_0 && mv2_on() && mmv2_ok(a)) { mmv2(a, st); return; }   // the 8B widths (K = 4096 / 12288, any row count): the LDS-DMA engine
+        mmv1q(a, st); return;
+    }
+    if (mv2_on() && mmv2_ok(a)) { mmv2(a, st); return; }
     if (!mmv1_ok(a)) { fprintf(stderr, "[mi355x] mmv1: unsupported arguments (K=%lld)\n", (long long) a.K); abort(); }
     const bool pair = a.W_up != nullptr;
     const int nw_wg = pair ? 8 : 16;

@@ -66,7 +66,7 @@ __global__ void __launch_bounds__(64 * MV2_WAVES) k_mv2(const char * W0, const f
     const int K = 4096 * NIT;
     mv2_mat M;
     M.W = W0; M.w_rs = w_rs0; M.nrows = nrows0; M.q = q0; M.r = r0; M.wg0 = 0; M.resid = PAIR ? nullptr : aux; M.dst = nullptr;
-    M.type = TM == 2 ? GGML_TYPE_Q6_K : GGML_TYPE_Q4_K;
+    M.type = TM == 2 ? GGML_TYPE_Q6_K : (TM == 4 ? GGML_TYPE_Q8_0 : GGML_TYPE_Q4_K);
     int mi_ = 0;
     if (!PAIR && wg >= wg1) {                           // a workgroup of the second / third matrix: its description comes from the argument block
         mi_ = (R->nmat > 2 && wg >= R->m[2].wg0) ? 2 : 1;
@@ -87,11 +87,13 @@ __global__ void __launch_bounds__(64 * MV2_WAVES) k_mv2(const char * W0, const f
     char * stg = mv1_lds + geo0::IMG;
     char * rstg = stg + geo0::STG;
     char * ringp = rstg + geo0::RSTG;
+    constexpr bool Q80 = TM == 4;                        // (Q8_0 matrices never share a launch with K-quants: the activation image differs)
     const bool q4 = TM == 1 || ((TM & 1) && M.type == GGML_TYPE_Q4_K);
     MV2_STAMP(1);
     if (wiw == 0) {
         const mv1_rsrc rs0 = mv1_make_rsrc(M.W, (size_t) M.nrows * M.w_rs), rs1 = mv1_make_rsrc(PAIR ? W1 : M.W, (size_t) M.nrows * M.w_rs);
-        if (q4) mv2_loader<2304, PAIR ? 2 : 1, NIT, C, NT>(rs0, rs1, (uint32_t) M.w_rs, G0, ntask * NIT, mv2_lds_addr(ringp), &F MV2_TR_ARG);
+        if constexpr (Q80) mv2_loader<4352, PAIR ? 2 : 1, NIT, C, NT>(rs0, rs1, (uint32_t) M.w_rs, G0, ntask * NIT, mv2_lds_addr(ringp), &F MV2_TR_ARG);
+        else if (q4) mv2_loader<2304, PAIR ? 2 : 1, NIT, C, NT>(rs0, rs1, (uint32_t) M.w_rs, G0, ntask * NIT, mv2_lds_addr(ringp), &F MV2_TR_ARG);
         else if constexpr ((TM & 2) != 0 && !PAIR) mv2_loader<3360, 1, NIT, C, NT>(rs0, rs1, (uint32_t) M.w_rs, G0, ntask * NIT, mv2_lds_addr(ringp), &F MV2_TR_ARG);
         MV2_STAMP(7);
     } else {
@@ -100,8 +102,8 @@ __global__ void __launch_bounds__(64 * MV2_WAVES) k_mv2(const char * W0, const f
         // roles before the stream is consumed: the last 4 consumers fetch the row, consumers 0 .. 4 NIT - 1 (NIT per SIMD) build the image, the rest wait
         if (c >= C - MV2_ROW_WAVES) mv2_row_loader(src, K, c - (C - MV2_ROW_WAVES), resid_p, G0, ntask, mv2_lds_addr(stg), mv2_lds_addr(rstg), &F MV2_TR_ARG);
         uint32_t img_need = 4 * NIT;
-        if (src.img) { mv2_image_copy<C>(src.img, K, c, im, &F); img_need = C; }
-        else if (c < 4 * NIT) mv2_prologue<NIT>(src, K, c, im, stg, red, &F MV2_TR_ARG);
+        if (src.img) { if constexpr (Q80) mv2_image_copy_q80<C>(src.img, K, c, im, &F); else mv2_image_copy<C>(src.img, K, c, im, &F); img_need = C; }
+        else if (c < 4 * NIT) mv2_prologue<NIT, Q80>(src, K, c, im, stg, red, &F MV2_TR_ARG);
         { uint32_t spins = 0; while (mv2_peek(MV2_FLAG(F.img_cnt)) < img_need) { __builtin_amdgcn_s_sleep(4); if (++spins > MV2_SPIN_MAX) __builtin_trap(); } asm volatile("" ::: "memory"); }
         // the residual of this consumer's tasks, one per lane (task k of the consumer is row G0 + c + k C), from the staging area: the consumers
         // issue NO vector-memory loads -- one would wait for a place in the CU's memory queue behind the loader's stream
@@ -109,7 +111,8 @@ __global__ void __launch_bounds__(64 * MV2_WAVES) k_mv2(const char * W0, const f
         if (resid_p) { mv2_await(MV2_FLAG(F.x_landed), MV2_ROW_WAVES); const int r = c + lane * C; if (r < ntask) resid = *(const float *) (rstg + r * 4); }
         MV2_STAMP(4);
         char * dst = mi_ == 0 ? R->m[0].dst : M.dst;     // (needed when the first results are stored)
-        if (q4) mv2_consume_q4k<PAIR ? 2 : 1, NIT, C, PAIR>(im, ringp, K, c, ntask, dst, G0 + c, resid, &F);
+        if constexpr (Q80) mv2_consume_q80<PAIR ? 2 : 1, NIT, C, PAIR>(im, ringp, K, c, ntask, dst, G0 + c, resid, &F);
+        else if (q4) mv2_consume_q4k<PAIR ? 2 : 1, NIT, C, PAIR>(im, ringp, K, c, ntask, dst, G0 + c, resid, &F);
         else if constexpr ((TM & 2) != 0 && !PAIR) mv2_consume_q6k<NIT, C>(im, ringp, K, c, ntask, dst, G0 + c, resid, &F);
         MV2_STAMP(7);
     }
@@ -134,13 +137,14 @@ int mv2_cus() {
 bool mmv2_ok(const mv1_args & a) {
     if (a.nmat < 1 || a.nmat > 3 || (a.K != 4096 && a.K != 12288)) return false;
     if (a.K == 12288 && a.norm_w && !a.img) return false;                                    // (the staging area holds the row OR row + norm weights of 4096)
-    if (a.W_up && (a.nmat != 1 || a.m[0].type != GGML_TYPE_Q4_K || a.K != 4096 || a.m[0].resid || ((uintptr_t) a.W_up & 15) != 0)) return false;
+    const bool q80 = a.m[0].type == GGML_TYPE_Q8_0;                                          // all-Q8_0 launches (the 8B LLM of BASELINE configs[4]): their own activation image
+    if (a.W_up && (a.nmat != 1 || (a.m[0].type != GGML_TYPE_Q4_K && !q80) || a.K != 4096 || a.m[0].resid || ((uintptr_t) a.W_up & 15) != 0)) return false;
     const int cus = mv2_cus();
     for (int i = 0; i < a.nmat; ++i) {
         const mmv_mat & m = a.m[i];
-        if (m.type != GGML_TYPE_Q4_K && m.type != GGML_TYPE_Q6_K) return false;
+        if (q80 ? m.type != GGML_TYPE_Q8_0 : (m.type != GGML_TYPE_Q4_K && m.type != GGML_TYPE_Q6_K)) return false;
         if (m.nrows <= 0 || (uint64_t) m.nrows * m.w_rs > 0xffffffffull) return false;
-        if (((uintptr_t) m.W & 15) != 0 || m.w_rs % 16 != 0) return false;                   // LDS-DMA pieces are 16-byte (the last of a Q4_K step 4-byte) requests
+        if (((uintptr_t) m.W & 15) != 0 || m.w_rs % 16 != 0) return false;                   // LDS-DMA pieces are 16-byte (the last of a Q4_K / Q8_0 step 4-byte) requests
         if (((uintptr_t) m.dst & 3) != 0 || ((uintptr_t) m.resid & 3) != 0) return false;
         if (m.resid && m.nrows > (int64_t) cus * 256) return false;                           // the residual staging area holds 256 rows per workgroup
     }
@@ -164,9 +168,9 @@ static int mv2_plan(const mv1_args & a, mv2_dev & d, int & tm) {
     const int cus = mv2_cus();
     double bytes[3], total = 0; int64_t tasks = 0; tm = 0;
     for (int i = 0; i < a.nmat; ++i) {
-        bytes[i] = (double) a.m[i].nrows * (double) (a.m[i].type == GGML_TYPE_Q4_K ? 144 : 210) * (double) (a.K / 256);
+        bytes[i] = (double) a.m[i].nrows * (double) (a.m[i].type == GGML_TYPE_Q4_K ? 144 : a.m[i].type == GGML_TYPE_Q6_K ? 210 : 272) * (double) (a.K / 256);
         total += bytes[i]; tasks += a.m[i].nrows;
-        tm |= a.m[i].type == GGML_TYPE_Q4_K ? 1 : 2;
+        tm |= a.m[i].type == GGML_TYPE_Q4_K ? 1 : a.m[i].type == GGML_TYPE_Q6_K ? 2 : 4;
     }
     int grid = (int) (tasks < cus ? tasks : cus);
     if (grid < a.nmat) grid = a.nmat;
@@ -191,6 +195,12 @@ void mmv2(const mv1_args & a, hipStream_t st) {
     mv2_dev d; int tm;
     const int grid = mv2_plan(a, d, tm);
     const bool pair = a.W_up != nullptr;
+    if (tm == 4) {                                                                           // Q8_0
+        if (pair)              mv2_launch<4, 1, true, true>(d, grid, st);
+        else if (a.K == 4096)  mv2_launch<4, 1, false, true>(d, grid, st);
+        else                   mv2_launch<4, 3, false, true>(d, grid, st);
+        return;
+    }
     if (pair)               { mv2_launch<1, 1, true, true>(d, grid, st); return; }
     if (a.K == 4096) {
         if (tm == 1)      mv2_launch<1, 1, false, true>(d, grid, st);

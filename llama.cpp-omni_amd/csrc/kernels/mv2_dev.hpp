@@ -96,8 +96,30 @@ static __device__ __forceinline__ void mv2_lane_map(int lane, int & blk, int & q
 // 16-byte instruction of 18 lanes.  v16 = 16 * lane, v4 = 4 * lane.
 template <int PIECE, bool NT>
 static __device__ __forceinline__ void mv2_dma_piece(const mv1_rsrc rs, uint32_t soff, uint32_t lds, uint32_t v16, uint32_t v4) {
-    static_assert(PIECE == 2304 || PIECE == 3360, "16 Q4_K / Q6_K super-blocks");
-    if constexpr (PIECE == 2304) {
+    static_assert(PIECE == 2304 || PIECE == 3360 || PIECE == 4352, "16 Q4_K / Q6_K super-blocks, or 128 Q8_0 blocks");
+    if constexpr (PIECE == 4352) {
+        // Q8_0: 4096 weights = 128 blocks of 34 B = four 1 KiB instructions + 256 B as a dword instruction.  The instruction offset field ends at 4095, and
+        // it is the instruction offset that advances the LDS address: the fifth instruction gets its own m0 and scalar offset instead (s_mov, not s_add: an
+        // s_add_u32 inside the statement would clobber SCC under the compiler's feet -- the loader's ring-wrap compare sat across it).
+        if constexpr (NT)
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\t"
+                         "buffer_load_dwordx4 %1, %3, %4 offen nt lds\n\t"
+                         "buffer_load_dwordx4 %1, %3, %4 offen offset:1024 nt lds\n\t"
+                         "buffer_load_dwordx4 %1, %3, %4 offen offset:2048 nt lds\n\t"
+                         "buffer_load_dwordx4 %1, %3, %4 offen offset:3072 nt lds\n\t"
+                         "s_mov_b32 m0, %6\n\ts_nop 0\n\t"
+                         "buffer_load_dword %2, %3, %5 offen nt lds"
+                         :: "s"(lds), "v"(v16), "v"(v4), "s"(rs), "s"(soff), "s"(soff + 4096u), "s"(lds + 4096u) : "memory", "m0");
+        else
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\t"
+                         "buffer_load_dwordx4 %1, %3, %4 offen lds\n\t"
+                         "buffer_load_dwordx4 %1, %3, %4 offen offset:1024 lds\n\t"
+                         "buffer_load_dwordx4 %1, %3, %4 offen offset:2048 lds\n\t"
+                         "buffer_load_dwordx4 %1, %3, %4 offen offset:3072 lds\n\t"
+                         "s_mov_b32 m0, %6\n\ts_nop 0\n\t"
+                         "buffer_load_dword %2, %3, %5 offen lds"
+                         :: "s"(lds), "v"(v16), "v"(v4), "s"(rs), "s"(soff), "s"(soff + 4096u), "s"(lds + 4096u) : "memory", "m0");
+    } else if constexpr (PIECE == 2304) {
         if constexpr (NT)
             asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\t"
                          "buffer_load_dwordx4 %1, %3, %4 offen nt lds\n\t"
@@ -136,7 +158,7 @@ static __device__ __forceinline__ void mv2_dma_piece(const mv1_rsrc rs, uint32_t
 
 // ring geometry of a (type, rows per task, K) combination: as many slots of one step as the CU's LDS holds next to the image
 template <int PIECE, int R, int NIT> struct mv2_geo {
-    static constexpr int VM    = (PIECE == 2304 ? 3 : 4) * R;                // VMEM instructions per step
+    static constexpr int VM    = (PIECE == 2304 ? 3 : PIECE == 3360 ? 4 : 5) * R;   // VMEM instructions per step
     static constexpr int D     = 60 / VM;                                     // steps the loader keeps in flight (vmcnt counts to 63)
     static constexpr int B     = R == 2 ? 2 : 4;                              // steps per loader round: one flag round trip per round
     static constexpr int SLOTB = PIECE * R;
@@ -307,8 +329,29 @@ static __device__ __forceinline__ void mv2_q8k_rows(const f32x4 (&y)[4], int lan
     if (i == 0) *((float *) (im + mv1_img_d(nb)) + b) = zero ? 0.0f : 1.0f / iscale;
 }
 
+// The Q8_0 activation image ([qs : K int8][d : K / 32 f32], common.hpp q80_image_bytes) from the same register layout: a 32-element block is the 8 lanes
+// i = 0..7 or 8..15 of the DPP row for one m.  Arithmetic of the compiled x86 quantiser (arch/x86/quants.c:290-345, as quantize.hip / mmv1q.hip): d = amax / 127
+// stored as f16, id = 127 / amax, q = round-half-even(x * id).
+static __device__ __forceinline__ void mv2_q80_rows(const f32x4 (&y)[4], int lane, int b, int K, char * im) {
+    const int i = lane & 15;
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        float amax = fmaxf(fmaxf(fabsf(y[m][0]), fabsf(y[m][1])), fmaxf(fabsf(y[m][2]), fabsf(y[m][3])));
+        amax = fmaxf(amax, __uint_as_float(mv2_dpp_row<0xB1>(__float_as_uint(amax))));       // (non-negative floats: the bit patterns order like the values)
+        amax = fmaxf(amax, __uint_as_float(mv2_dpp_row<0x4E>(__float_as_uint(amax))));
+        amax = fmaxf(amax, __uint_as_float(mv2_dpp_row<0x141>(__float_as_uint(amax))));      // row_half_mirror: the 8 lanes of the block
+        const float d = amax / 127.0f;
+        const float id = amax != 0.0f ? 127.0f / amax : 0.0f;
+        uint32_t qd = 0;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) qd |= ((uint32_t) (int) __builtin_rintf(y[m][e] * id) & 0xffu) << (8 * e);
+        *(uint32_t *) (im + 256 * b + 64 * m + 4 * i) = qd;
+        if ((i & 7) == 0) *(float *) (im + K + (8 * b + 2 * m + (i >> 3)) * 4) = h2f(f2h(d));
+    }
+}
+
 // prologue wave mw of 4 NIT (consumers 0 .. 4 NIT - 1: NIT per SIMD): image blocks 4 mw + row
-template <int NIT>
+template <int NIT, bool Q80 = false>
 static __device__ __forceinline__ void mv2_prologue(const mv1_src s, int K, int mw, char * im, const char * stg, double * red, mv2_flags * F MV2_TR_PARAM) {
     const int lane = threadIdx.x & 63, row = lane >> 4, i = lane & 15, nb = K >> 8;
     mv2_await(MV2_FLAG(F->x_landed), MV2_ROW_WAVES);
@@ -363,9 +406,16 @@ static __device__ __forceinline__ void mv2_prologue(const mv1_src s, int K, int 
 #pragma unroll
             for (int m = 0; m < 4; ++m) y[m] = *(const f32x4 *) (xp + 256 * m);
         }
-        mv2_q8k_rows(y, lane, b, nb, im);
+        if constexpr (Q80) mv2_q80_rows(y, lane, b, K, im); else mv2_q8k_rows(y, lane, b, nb, im);
     }
     MV2_STAMP(5);
+    mv2_arrive(MV2_FLAG(F->img_cnt));
+}
+// ready-made Q8_0 image (the same layout): a plain copy by all C consumers
+template <int C>
+static __device__ __forceinline__ void mv2_image_copy_q80(const char * img, int K, int c, char * im, mv2_flags * F) {
+    const int lane = threadIdx.x & 63;
+    for (int i = c * 64 + lane; i < (K + K / 8) / 16; i += 64 * C) ((u32x4 *) im)[i] = ((const u32x4 *) img)[i];
     mv2_arrive(MV2_FLAG(F->img_cnt));
 }
 // ready-made image (common.hpp layout) -> this family's layout, by all C consumers
@@ -559,6 +609,70 @@ static __device__ __forceinline__ void mv2_consume_q6k(const char * im, const ch
         }
         const float s = wave_sum_f32(acc);
         if (lane == o.nres) o.res = s;
+        if (++o.nres == 64) mv2_out_flush<C>(o, dst, row0, resid);
+    }
+    mv2_out_flush<C>(o, dst, row0, resid);
+}
+
+// ================================================================================================= Q8_0 consumer
+// 34-B blocks {f16 d, int8 qs[32]} (ggml-common.h:219-224), 128 per step.  Lane l owns blocks 2l and 2l + 1 of the step: 68 bytes at 68 l -- dword-aligned, an
+// odd dword stride over the lanes (17): seventeen conflict-free ds_read_b32.  Block 2l: d = low half of dword 0, quants = dwords 0..8 shifted by 16 bits;
+// block 2l + 1: d = high half of dword 8, quants = dwords 9..16 as they are.  Reference arithmetic: ggml_vec_dot_q8_0_q8_0 (ggml-cpu/quants.c:305-333):
+// sumi over the 32 products, sumf += sumi * (d_w * d_a), blocks in ascending order per lane; the lanes fold on the DPP network.
+struct mv2_q80_act { u32x4 a[4]; float yd[2]; };
+static __device__ __forceinline__ void mv2_q80_act_load(const char * im, int K, int ib0 /* first of the lane's two blocks */, mv2_q80_act & A) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) A.a[k] = *(const u32x4 *) (im + ib0 * 32 + 16 * k);
+    A.yd[0] = *(const float *) (im + K + ib0 * 4); A.yd[1] = *(const float *) (im + K + ib0 * 4 + 4);
+}
+static __device__ __forceinline__ float mv2_q80_dot(const uint32_t (&w)[17], const mv2_q80_act & A, float acc) {
+    int s0 = 0, s1 = 0;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        s0 = dot4(__builtin_amdgcn_alignbit(w[e + 1], w[e], 16), A.a[e >> 2][e & 3], s0);
+        s1 = dot4(w[9 + e], A.a[2 + (e >> 2)][e & 3], s1);
+    }
+    acc = fmaf((float) s0, h2f((uint16_t) (w[0] & 0xffff)) * A.yd[0], acc);
+    acc = fmaf((float) s1, h2f((uint16_t) (w[8] >> 16)) * A.yd[1], acc);
+    return acc;
+}
+template <int R, int NIT, int C, bool PAIR>
+static __device__ __forceinline__ void mv2_consume_q80(const char * im, const char * ringp, int K, int c, int ntask, char * dst, int row0, float resid, mv2_flags * F) {
+    typedef mv2_geo<4352, R, NIT> geo;
+    constexpr int SLOTB = geo::SLOTB, NS = geo::NS;
+    const int lane = threadIdx.x & 63;
+    mv2_q80_act A[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) mv2_q80_act_load(im, K, it * 128 + 2 * lane, A[it]);
+    const __attribute__((address_space(3))) char * wl = (const __attribute__((address_space(3))) char *) (ringp + lane * 68);
+    uint32_t seen = 0;
+    mv2_out o = { 0.0f, 0, 0 };
+    int k = 0;
+    for (int j = c; j < ntask; j += C, ++k) {
+        float acc[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) acc[r] = 0.0f;
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int t = __builtin_amdgcn_readfirstlane(j * NIT + it);
+            mv2_wait_step(t, seen, F);
+            const __attribute__((address_space(3))) char * p = wl + (t % NS) * SLOTB;
+            uint32_t w[R][17];
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+#pragma unroll
+                for (int e = 0; e < 17; ++e) w[r][e] = *(const volatile mv2_lds_u32 *) (p + r * 4352 + 4 * e);
+            if (it == NIT - 1) { MV2_LGKM0(); mv2_poke(MV2_FLAG(F->consumed[c]), (uint32_t) (k + 1)); }
+#pragma unroll
+            for (int r = 0; r < R; ++r) acc[r] = mv2_q80_dot(w[r], A[it], acc[r]);
+        }
+        if (PAIR) {
+            const float gsum = wave_sum_f32(acc[0]), usum = wave_sum_f32(acc[R - 1]);
+            if (lane == o.nres) o.res = mv1_silu(gsum) * usum;
+        } else {
+            const float s = wave_sum_f32(acc[0]);
+            if (lane == o.nres) o.res = s;
+        }
         if (++o.nres == 64) mv2_out_flush<C>(o, dst, row0, resid);
     }
     mv2_out_flush<C>(o, dst, row0, resid);

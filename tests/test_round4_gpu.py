@@ -36,3 +36,142 @@ def test_persistent_engine_lab_is_bit_identical_to_the_launch_form(tmp_path, sta
     assert "GAVE UP" not in out and "MISMATCH" not in out and "RESULTS DIFFER" not in out, out[-3000:]
     assert out.count("results identical") == 2, out[-3000:]                   # both layer variants
     assert out.count(" identical (0 /") == 2 * 3 * (stages[1] - stages[0] + 1), out[-3000:]
+
+
+# ------------------------------------------------------------------------------------------------ Q8_0 on the LDS-DMA engine (the 8B LLM of BASELINE configs[4])
+import numpy as np
+
+from conftest import nmse
+from oracle import oracle_py as orc
+
+
+def _run(be, c, outs, feeds):
+    from test_gpu_parity import run_graph
+    return run_graph(be, c, outs, feeds)
+
+
+def _act(rng, K):
+    x = (rng.standard_normal((1, K)) * 2.0).astype(np.float32)
+    x[0, 256:320] = 0.0                                       # two all-zero Q8_0 blocks (amax = 0: d = 0, id = 0)
+    x[0, 700] = -x[0, 701]
+    return x
+
+
+def _silu(x):
+    return x / (1.0 + np.exp(-x))
+
+
+@pytest.mark.parametrize("K,M", [(4096, 4096), (12288, 4096), (4096, 70000)])
+def test_q8_0_engine_single_matrix_vs_oracle_and_row_kernels(pkg, be, K, M):
+    """One Q8_0 matrix + residual epilogue (wo / ffn_down of the Q8_0 8B model; 70000 rows: more than k_mv1q takes, ring slots re-used many times).
+    mv2 = 1: k_mv2<4, NIT, false>; mv2 = 0: the round-1 / round-2 Q8_0 kernels.  Both form the reference's integer sums (ggml_vec_dot_q8_0_q8_0,
+    ggml-cpu/quants.c:305-333) over the reference's Q8_0 activation blocks; only the order of the f32 sums differs."""
+    from llama_cpp_omni_amd import qwen3
+    ty = pkg.GGML_TYPE_Q8_0
+    rng = np.random.default_rng(K + M)
+    x = _act(rng, K)
+    r = rng.standard_normal((1, M)).astype(np.float32)
+    wv = qwen3.random_blocks(rng, ty, M, K, std=0.05)
+    res = {}
+    for mv2 in (1, 0):
+        be.set_option("mv2", mv2)
+        try:
+            c = pkg.Context(be)
+            w = c.new_tensor(ty, K, M); xt = c.new_tensor(pkg.GGML_TYPE_F32, K, 1); rt = c.new_tensor(pkg.GGML_TYPE_F32, M, 1)
+            y = c.add(c.mul_mat(w, xt), rt)
+            (res[mv2],) = _run(be, c, [y], [(w, wv), (xt, x), (rt, r)])
+            if mv2:                                                     # (the engine stages at most 256 residual rows per workgroup: beyond 65536 rows the ADD stays its own launch)
+                assert be.get_stat("kernels_last_graph") == (1 if M <= 65536 else 2)
+        finally:
+            be.set_option("mv2", 1)
+    want = orc.mul_mat(ty, wv.view(np.uint8).reshape(M, -1), x) + r
+    assert nmse(res[1], want) < 1e-9, nmse(res[1], want)
+    assert nmse(res[1], res[0]) < 1e-11, nmse(res[1], res[0])
+
+
+def test_q8_0_engine_gate_up_pair_with_norm_and_swiglu(pkg, be):
+    from llama_cpp_omni_amd import qwen3
+    K, M = 4096, 12288
+    ty = pkg.GGML_TYPE_Q8_0
+    rng = np.random.default_rng(15)
+    x = _act(rng, K)
+    nw = rng.standard_normal(K).astype(np.float32)
+    gv = qwen3.random_blocks(rng, ty, M, K, std=0.05); uv = qwen3.random_blocks(rng, ty, M, K, std=0.05)
+    res = {}
+    for mv2 in (1, 0):
+        be.set_option("mv2", mv2)
+        try:
+            c = pkg.Context(be)
+            wg = c.new_tensor(ty, K, M); wu = c.new_tensor(ty, K, M); xt = c.new_tensor(pkg.GGML_TYPE_F32, K, 1); nt = c.new_tensor(pkg.GGML_TYPE_F32, K)
+            xn = c.mul(c.rms_norm(xt, 1e-6), nt)
+            up = c.mul_mat(wu, xn); gate = c.mul_mat(wg, xn)
+            y = c.swiglu_split(gate, up)
+            (res[mv2],) = _run(be, c, [y], [(wg, gv), (wu, uv), (xt, x), (nt, nw)])
+            assert be.get_stat("kernels_last_graph") == 1
+        finally:
+            be.set_option("mv2", 1)
+    xn_ref = (orc.rms_norm(x, 1e-6) * nw).astype(np.float32)
+    g = orc.mul_mat(ty, gv.view(np.uint8).reshape(M, -1), xn_ref); u = orc.mul_mat(ty, uv.view(np.uint8).reshape(M, -1), xn_ref)
+    want = (_silu(g.astype(np.float64)) * u.astype(np.float64)).astype(np.float32)
+    assert nmse(res[1], want) < 1e-9, nmse(res[1], want)
+    assert nmse(res[1], res[0]) < 1e-11, nmse(res[1], res[0])
+
+
+def test_q8_0_engine_grouped_qkv_launch(pkg, be):
+    from llama_cpp_omni_amd import qwen3
+    K = 4096
+    rows = [4096, 1024, 1024]
+    ty = pkg.GGML_TYPE_Q8_0
+    rng = np.random.default_rng(19)
+    x = _act(rng, K)
+    nw = rng.standard_normal(K).astype(np.float32)
+    wvs = [qwen3.random_blocks(rng, ty, m, K, std=0.05) for m in rows]
+    res = {}
+    for mv2 in (1, 0):
+        be.set_option("mv2", mv2)
+        try:
+            c = pkg.Context(be)
+            ws = [c.new_tensor(ty, K, m) for m in rows]
+            xt = c.new_tensor(pkg.GGML_TYPE_F32, K, 1); nt = c.new_tensor(pkg.GGML_TYPE_F32, K)
+            xn = c.mul(c.rms_norm(xt, 1e-6), nt)
+            ys = [c.mul_mat(w, xn) for w in ws]
+            res[mv2] = _run(be, c, ys, list(zip(ws, wvs)) + [(xt, x), (nt, nw)])
+            assert be.get_stat("kernels_last_graph") == 1
+        finally:
+            be.set_option("mv2", 1)
+    xn_ref = (orc.rms_norm(x, 1e-6) * nw).astype(np.float32)
+    for i, m in enumerate(rows):
+        want = orc.mul_mat(ty, wvs[i].view(np.uint8).reshape(m, -1), xn_ref)
+        assert nmse(res[1][i], want) < 1e-9, (i, nmse(res[1][i], want))
+        assert nmse(res[1][i], res[0][i]) < 1e-11, i
+
+
+def test_8b_q8_0_greedy_ids_identical_through_libllama(tmp_path):
+    """BASELINE configs[4]: the omni pipeline ships its 8B LLM as Q8_0 (tools/omni/convert/run_convert.sh:67-70).  The 36-layer Qwen3-8B GGUF with EVERY matrix
+    Q8_0 (8.7 GB), separated-logits fixture as in test_round3_gpu.py, decoded by the reference's libllama on the plug-in and on the reference CPU backend:
+    128 / 128 free-running greedy ids identical, flash-attention off and on; wq / wk / wv, wo, ffn_gate / ffn_up, ffn_down (K = 12288) and the 151936-row
+    lm-head all run on the LDS-DMA engine's Q8_0 body (k_mv2<4, ..>)."""
+    import sys
+    import shutil
+    import test_round3_gpu as r3
+    r3._need_ref(tmp_path)
+    if shutil.disk_usage(str(tmp_path)).free < 12e9:
+        pytest.skip("needs 9 GB of scratch disk for the synthetic Q8_0 8B GGUF")
+    gguf = str(tmp_path / "q8b_q80.gguf")
+    gen = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "make_synth_gguf.py"), "--config", "8b", "--types", "q8_0", "-o", gguf, "--n-ctx", "4096",
+                          "--separated", "160"], check=True, timeout=1800, capture_output=True, text=True)
+    start = int(gen.stdout.split("start token")[1].split()[0])
+    threads = max(4, min(48, len(os.sched_getaffinity(0)) // 2))
+    n = 128
+    try:
+        for fa in (0, 1):
+            ids_cpu = r3._bench_min(gguf, 0, fa, n, threads, ["--start-token", str(start), "--dump-all-logits", str(tmp_path / "c.bin")], False)
+            ids_gpu = r3._bench_min(gguf, 99, fa, n, threads, ["--start-token", str(start), "--dump-all-logits", str(tmp_path / "g.bin")], True)
+            assert len(set(ids_cpu)) == n, "the fixture's cycle is longer than the run"
+            assert ids_gpu == ids_cpu, (fa, [i for i in range(n) if ids_gpu[i] != ids_cpu[i]])
+            lc = np.fromfile(str(tmp_path / "c.bin"), np.float32).reshape(n, -1); lg = np.fromfile(str(tmp_path / "g.bin"), np.float32).reshape(n, -1)
+            worst = max(float(((lg[t] - lc[t]) ** 2).sum() / (lc[t] ** 2).sum()) for t in range(n))
+            print(f"Q8_0 8B, fa={fa}: {n}/{n} greedy ids identical, worst logits NMSE {worst:.2e}")
+            assert worst < 1e-3, worst
+    finally:
+        os.remove(gguf)

@@ -94,6 +94,25 @@ def dequant_q6_K(rows, K):
     return out.reshape(n, K)
 
 
+def dequant_q8_0(rows, K):
+    """block_q8_0 (ggml-common.h:219-224): x = d * q, 32 per block.  rows: uint8 [n, K / 32 * 34]"""
+    n = rows.shape[0]; b = rows.reshape(n, K // 32, 34)
+    d = b[..., 0:2].copy().view(np.float16).astype(np.float32)                           # [n, nb, 1]
+    return (d * b[..., 2:].view(np.int8).astype(np.float32)).reshape(n, K)
+
+
+def quant_q8_0(x):
+    """quantize_row_q8_0_ref (ggml-quants.c:199-222): d = amax / 127, q = round(x / d)"""
+    n, K = x.shape
+    xb = x.reshape(n, K // 32, 32).astype(np.float32)
+    d = np.abs(xb).max(axis=2, keepdims=True) / 127.0
+    q = np.where(d > 0, np.round(xb / np.where(d > 0, d, 1)), 0).astype(np.int8)
+    out = np.empty((n, K // 32, 34), np.uint8)
+    out[..., 0:2] = d.astype(np.float16).view(np.uint8).reshape(n, K // 32, 2)
+    out[..., 2:] = q.view(np.uint8)
+    return out.reshape(n, -1)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--config", choices=["8b", "tiny", "tts", "tts-tiny"], default="8b",
@@ -183,14 +202,15 @@ def main():
     special, patch = [], {}
     if args.separated:
         S = args.separated
-        assert embd_ty == GGML_TYPE_Q4_K and types["output"] == 14 and E % 256 == 0, "--separated: Q4_K token_embd, Q6_K output"
+        q80 = embd_ty == GGML_TYPE_Q8_0 and types["output"] == GGML_TYPE_Q8_0
+        assert ((embd_ty == GGML_TYPE_Q4_K and types["output"] == 14) or q80) and E % 256 == 0, "--separated: Q4_K token_embd + Q6_K output, or all Q8_0"
         special = [int(V // 16 + (V - V // 8) * i // S) for i in range(S)]
         r2 = np.random.default_rng(args.seed + 77)
-        big = qwen3.random_blocks(r2, GGML_TYPE_Q4_K, S, E, std=300.0)                 # embedding rows ~ 20x the size of what 36 random layers add
-        ehat = dequant_q4_K(big.reshape(S, -1), E)
+        big = qwen3.random_blocks(r2, embd_ty, S, E, std=300.0)                        # embedding rows ~ 20x the size of what 36 random layers add
+        ehat = dequant_q8_0(big.reshape(S, -1), E) if q80 else dequant_q4_K(big.reshape(S, -1), E)
         ehat /= np.sqrt((ehat ** 2).mean(axis=1, keepdims=True))
-        out_rows = quant_q6_K(ehat)                                                      # successor rows: unit-rms copies of the embedding directions
-        deq = dequant_q6_K(out_rows, E)
+        out_rows = quant_q8_0(ehat) if q80 else quant_q6_K(ehat)                         # successor rows: unit-rms copies of the embedding directions
+        deq = dequant_q8_0(out_rows, E) if q80 else dequant_q6_K(out_rows, E)
         logit = deq @ ehat.T                                                             # [row j, token i]: the lm head applied to the pure embedding direction
         for i in range(S):
             col = logit[:, i].copy(); top = col[i]; col[i] = -np.inf
