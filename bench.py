@@ -325,6 +325,32 @@ def via_libllama(threads=8, reps=5):
             splits = [ln for ln in r.stderr.splitlines() if "graph splits" in ln]
             res["graph_splits"] = int(splits[-1].split("=")[-1]) if splits else None
             out[f"fa{fa}"] = res
+        # where the difference to `value` sits: the plug-in's own host-time account of a tg128-only run at llama-bench's default (-fa 0), from MI355X_LOG_STATS
+        try:
+            import re
+            env2 = dict(env); env2["MI355X_LOG_STATS"] = "1"
+            r = subprocess.run([binp, "-m", gguf, "-ngl", "99", "-fa", "0", "-p", "0", "-n", "128", "-r", "3", "-t", str(threads)], env=env2, capture_output=True, text=True, timeout=600)
+            acc = {}
+            for ln in r.stderr.splitlines():
+                if "host time inside the backend" in ln:
+                    for key, name in (("graph_compute", "graph_compute"), ("set_tensor_async", "set_tensor_async"), ("get_tensor_async", "get_tensor_async"), ("synchronize", "synchronize")):
+                        m = re.search(name + r" (\d+) calls ([0-9.]+) us avg", ln)
+                        if m:
+                            acc[key] = {"calls": int(m.group(1)), "us_avg": float(m.group(2))}
+                if "blocking buffer transfers" in ln:
+                    m = re.search(r"tensor_set (\d+) calls ([0-9.]+) MB ([0-9.]+) ms, tensor_get (\d+) calls ([0-9.]+) MB ([0-9.]+) ms", ln)
+                    if m:
+                        acc["blocking_tensor_set"] = {"calls": int(m.group(1)), "ms_total": float(m.group(3))}; acc["blocking_tensor_get"] = {"calls": int(m.group(4)), "ms_total": float(m.group(6))}
+            ng = (acc.get("graph_compute") or {}).get("calls")
+            if ng:
+                # one graph_compute per decoded token (+ warm-up): per-token host microseconds inside the plug-in; `synchronize` is mostly waiting for the device
+                acc["per_token_us"] = {k: round(v["calls"] * v["us_avg"] / ng, 1) for k, v in acc.items() if isinstance(v, dict) and "us_avg" in v}
+                tg = [json.loads(x) for x in r.stdout.strip().splitlines() if x.startswith("{")]
+                if tg:
+                    acc["tg128_tok_s_this_run"] = tg[-1].get("avg_ts")
+            out["plugin_host_account_tg128_fa0"] = acc or None
+        except Exception as e:
+            out["plugin_host_account_tg128_fa0"] = {"error": repr(e)}
         return out
     except Exception as e:
         return {"error": repr(e)}
@@ -736,6 +762,8 @@ class Replicas:
         t0 = time.perf_counter()
         for _ in range(steps):
             step(pos); pos += 1
+        device_sync()
+        self.dt_local = time.perf_counter() - t0                     # this rank's own time for its K steps (before it waits for the others): per-rank tok/s in `per_rank`
         self.barrier(device_sync)
         dt = time.perf_counter() - t0
         if self.dist is not None:
@@ -747,6 +775,25 @@ class Replicas:
 
     def aggregate(self, steps, dt):
         return self.world * steps / dt                               # whole-job units per second (weak scaling: per-rank work is fixed)
+
+    def evidence(self, steps, dt_local):
+        """N > 1: what proves the line came from N ranks on N devices -- the world size the process group reports, and per rank its device ordinal, the
+        device's PCI bus id (all-gathered) and its own tok/s over the timed region.  None at N = 1."""
+        if self.dist is None:
+            return None
+        pci = None
+        if self.backend == "nccl":
+            import torch
+            p = torch.cuda.get_device_properties(self.dev_index)
+            if hasattr(p, "pci_bus_id"):
+                pci = "%04x:%02x:%02x.0" % (getattr(p, "pci_domain_id", 0), p.pci_bus_id, getattr(p, "pci_device_id", 0))
+            else:
+                pci = str(getattr(p, "uuid", ""))
+        mine = {"rank": self.rank, "local_rank": self.local_rank, "device": self.dev_index, "pci": pci, "host": os.uname().nodename, "pid": os.getpid(),
+                "tok_s": round(steps / dt_local, 2)}
+        allr = [None] * self.world
+        self.dist.all_gather_object(allr, mine)
+        return {"rccl_world": int(self.dist.get_world_size()), "dist_backend": "rccl (torch.distributed nccl)" if self.backend == "nccl" else self.backend, "per_rank": allr}
 
     def finish(self):
         if self.dist is not None:
@@ -794,6 +841,7 @@ def main():
     wbytes = dec.model.weight_bytes()
 
     dt, pos = rep.timed(dec.step, args.steps, args.warmup, be.synchronize)
+    evidence = rep.evidence(args.steps, rep.dt_local)              # (a collective: every rank takes part)
     replays = be.get_stat("graph_replays")
     kernels = be.get_stat("kernels_last_graph")
 
@@ -831,6 +879,8 @@ def main():
             "hbm_frac_whole_step": round(wbytes * (args.steps / dt) / 1e9 / HBM_PEAK_GBS, 4),
             "roofline": roof,
         }
+        if evidence:
+            out.update(evidence)
         if world == 1 and not args.tiny and not os.environ.get("MI355X_BENCH_NO_EXTRAS"):
             out["extras"] = extra_legs(pkg, be, args.no_fa)        # (before the prefill legs: they leave 15 GB of F16 weight images behind)
         if world == 1 and not os.environ.get("MI355X_BENCH_NO_PP"):
@@ -865,6 +915,11 @@ def main():
             v = out["via_libllama"]
             if v and isinstance(v.get("fa1"), dict) and v["fa1"].get("tg128_tok_s"):
                 v["tg128_fa1_over_value"] = round(v["fa1"]["tg128_tok_s"] / out["value"], 3)
+            # which number is llama-bench's: `value` is this repo's harness on the plug-in's C-ABI; the figures below come from the reference's own libllama +
+            # scheduler at llama-bench's defaults (-fa 0), the closest thing to the llama-bench binary that builds here (tools/llama_bench_min.cpp)
+            if v and isinstance(v.get("fa0"), dict):
+                out["value_via_libllama"] = v["fa0"].get("tg128_tok_s")
+                out["pp512_via_libllama"] = v["fa0"].get("pp512_tok_s")
         if args.omni_pinned and world == 1 and not args.tiny:
             be.synchronize()
             out["omni_pinned"] = omni_pinned(pkg, be, dec.model)

@@ -90,7 +90,10 @@ def test_bench_replica_logic_world2_gloo(tmp_path):
         "calls, syncs = [], []\n"
         "def step(pos): calls.append(pos); time.sleep(0.02 * (rep.rank + 1))\n"
         "dt, pos = rep.timed(step, 5, 2, lambda: syncs.append(1))\n"
-        "assert calls == list(range(7)) and pos == 7 and len(syncs) == 2\n"
+        "assert calls == list(range(7)) and pos == 7 and len(syncs) == 3        # barrier + synchronize on both sides, + the rank's own synchronize that stamps its per-rank time\n"
+        "ev = rep.evidence(5, rep.dt_local)\n"
+        "assert ev['rccl_world'] == 2 and [r['rank'] for r in ev['per_rank']] == [0, 1] and len({r['pid'] for r in ev['per_rank']}) == 2\n"
+        "assert ev['per_rank'][0]['tok_s'] > ev['per_rank'][1]['tok_s'] > 0        # each rank's own rate over the timed region: rank 1's steps are twice as long\n"
         "if rep.rank == 0: print('VALUE', rep.aggregate(5, dt), dt)\n"
         "rep.finish()\n")
     env = dict(os.environ, MI355X_BENCH_DIST_BACKEND="gloo", MI355X_BENCH_SHARE_GPU="1")
