@@ -959,6 +959,14 @@ static bool exec_gemm_group(exec_state & s, int i) {
     if (a.nmat == 1 && a.m[0].dst_cs % 16 == 0 && gemm_split_scratch_bytes(a.m[0].M, N, K) <= s.c->gemm_partial_bytes) a.partial = (float *) s.c->gemm_partial;
     else if (a.nmat > 1 && N <= gemm_group_split_max_cols() && s.c->gemm_partial_bytes > 0) a.partial = (float *) s.c->gemm_partial;      // short prompts: split-K for the grouped launches too
     a.partial_bytes = s.c->gemm_partial_bytes;
+    if (N > 128 && !kq) {                                       // more than one column tile: the stream-K launch may take it (gemm_f16_sk_ok); its scratch belongs to this context
+        if (!s.c->sk_part && !s.capturing) {                      // (first use is an eager submission: captures come from the second on)
+            if (hipMalloc(&s.c->sk_part, gemm_sk_part_bytes()) != hipSuccess) { (void) hipGetLastError(); s.c->sk_part = nullptr; }
+            else if (hipMalloc((void **) &s.c->sk_cnt, gemm_sk_count_bytes()) != hipSuccess) { (void) hipGetLastError(); (void) hipFree(s.c->sk_part); s.c->sk_part = nullptr; s.c->sk_cnt = nullptr; }
+            else HIP_CHECK(hipMemsetAsync(s.c->sk_cnt, 0, gemm_sk_count_bytes(), s.st));
+        }
+        a.sk_part = (float *) s.c->sk_part; a.sk_cnt = s.c->sk_cnt;
+    }
     // a streaming encoder chunk (<= 128 columns: split K, the result goes through the reduction launch): linear -> + bias -> + residual stream.  The second ADD
     // (only reader of the first, same shape, its other operand ready) rides in the reduction's epilogue too: (acc + bias) + residual, the two roundings of the two nodes.
     int add2_idx[3] = { -1, -1, -1 };
@@ -988,7 +996,7 @@ static bool exec_gemm_group(exec_state & s, int i) {
     int nsplit = 0;
     const ggml_tensor * Aout = a.nmat == 1 ? g->nodes[add_idx[0] >= 0 ? add_idx[0] : i] : nullptr;
     static const bool no_defer_reduce = getenv("MI355X_NO_REDUCE_IN_NORM") != nullptr;
-    if (!no_defer_reduce && a.partial && Aout && Aout->ne[2] == 1 && Aout->ne[3] == 1 && gemm_reduce_rms_norm_ok(Aout->ne[0]) && Aout->nb[1] % 16 == 0 &&
+    if (!no_defer_reduce && a.partial && !gemm_f16_sk_ok(a) && Aout && Aout->ne[2] == 1 && Aout->ne[3] == 1 && gemm_reduce_rms_norm_ok(Aout->ne[0]) && Aout->nb[1] % 16 == 0 &&
         (!a.m[0].resid || a.m[0].resid_cs % 16 == 0)) {
         int nx = (add_idx[0] >= 0 ? add_idx[0] : i) + 1;
         while (nx < g->n_nodes && (s.done[nx] || is_noop(g->nodes[nx]) || nx == add_idx[0])) ++nx;
@@ -2629,6 +2637,8 @@ void backend_ctx_release(backend_ctx * c) {
     if (c->fa_counters) (void) hipFree(c->fa_counters);
     if (c->rope_scratch) (void) hipFree(c->rope_scratch);
     if (c->gemm_partial) (void) hipFree(c->gemm_partial);
+    if (c->sk_part) (void) hipFree(c->sk_part);
+    if (c->sk_cnt) (void) hipFree(c->sk_cnt);
     if (c->copy_event) (void) hipEventDestroy(c->copy_event);
     if (c->handoff_event) (void) hipEventDestroy(c->handoff_event);
     if (c->stream) (void) hipStreamDestroy(c->stream);
@@ -2650,6 +2660,7 @@ int mi355x_set_option(struct ggml_backend * backend, const char * key, long valu
     if (!strcmp(key, "kq_staging")) { c->opt_kq_staging = value != 0; mi::drop_graph_execs(c); return 0; }
     if (!strcmp(key, "fattn_gqa")) { mi::fattn_set_gqa(value != 0); mi::drop_graph_execs(c); return 0; }
     if (!strcmp(key, "fattn_one")) { mi::fattn_set_one(value != 0); mi::drop_graph_execs(c); return 0; }
+    if (!strcmp(key, "gemm_sk")) { mi::gemm_sk_set_mode((int) value); mi::drop_graph_execs(c); return 0; }      // (process-wide: the persistent stream-K form of the F16 GEMM, gemm_sk.hip)
     if (!strcmp(key, "f16_shadow")) { mi::shadow_set_enabled(value != 0); mi::drop_graph_execs(c); return 0; }
     if (!strcmp(key, "reset_stats")) { c->prof.clear(); c->stat_replays = c->stat_captures = c->stat_eager = 0; return 0; }
     return -1;
@@ -2666,6 +2677,7 @@ double mi355x_get_stat(struct ggml_backend * backend, const char * key) {
     if (!strcmp(key, "gemm192_launches"))   return (double) mi::gemm_variant_launches(1);
     if (!strcmp(key, "gemm_glu_launches"))  return (double) mi::gemm_variant_launches(2);
     if (!strcmp(key, "gemm_kq_launches"))   return (double) mi::gemm_variant_launches(3);
+    if (!strcmp(key, "gemm_sk_launches"))   return (double) mi::gemm_variant_launches(4);
     if (!strncmp(key, "prof_", 5)) {
         std::string k(key + 5);
         const size_t us = k.rfind("_us"), nn = k.rfind("_n"), by = k.rfind("_bytes");

@@ -249,7 +249,15 @@ struct gemm_multi_args {
     int * deferred_split = nullptr;
     // gate / up + SWIGLU (gemm_glu_ok): no f32 outputs; f16 rows of silu(W[glu_gate].x) * (W[1 - glu_gate].x) go to glu_out16
     uint16_t * glu_out16 = nullptr; size_t glu_out16_rs = 0; int glu_gate = 0;
+    // persistent stream-K form (gemm_sk.hip) for launches the tile grid fills badly: partial-tile slots (gemm_sk_part_bytes()) and zeroed
+    // arrival counters (gemm_sk_count_bytes()) of the calling backend context (one stream: launches do not overlap)
+    float * sk_part = nullptr; unsigned * sk_cnt = nullptr;
 };
+bool   gemm_f16_sk_ok(const gemm_multi_args & a);               // gemm_f16_multi will take the stream-K launch for these arguments (no split-K slabs, no deferred reduction)
+void   gemm_f16_sk(const gemm_multi_args & a, hipStream_t st);
+size_t gemm_sk_part_bytes();
+size_t gemm_sk_count_bytes();
+void   gemm_sk_set_mode(int m);                                   // -1: MI355X_GEMM_SK decides (default off), 0 off, 1 wherever legal, 2 by the shape rule
 void   gemm_reduce(const float * partial, int nsplit, const float * resid, size_t resid_cs, float * dst, size_t dst_cs, int64_t M, int64_t N, hipStream_t st);
 // the same reduction fused with the RMS_NORM -> MUL(w) of the result: dst = sum + resid (f32); y = rms_norm(dst) * w -> y32 / f16 rows y16
 bool   gemm_reduce_rms_norm_ok(int64_t M);

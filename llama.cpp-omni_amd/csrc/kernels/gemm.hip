@@ -875,8 +875,8 @@ size_t gemm_split_scratch_bytes(int64_t M, int64_t N, int64_t K) {
 }
 
 // launches per tile variant (tests assert that a shape really selected the kernel it is meant to cover): 0 = 256 x 256, 1 = 192-row
-static long g_gemm_variant_launches[4] = { 0, 0, 0, 0 };
-long gemm_variant_launches(int v) { return v >= 0 && v < 4 ? g_gemm_variant_launches[v] : 0; }
+static long g_gemm_variant_launches[5] = { 0, 0, 0, 0, 0 };     // ... 2 = gate / up + SWIGLU, 3 = K-quant staging, 4 = stream-K (gemm_sk.hip)
+long gemm_variant_launches(int v) { return v >= 0 && v < 5 ? g_gemm_variant_launches[v] : 0; }
 // gate / up + SWIGLU in one launch: equal shapes and row strides, whole 128-row blocks, enough tiles to occupy the chip
 bool gemm_glu_ok(const gemm_multi_args & a) {
     static const bool off = getenv("MI355X_NO_GEMM_GLU") != nullptr;
@@ -955,6 +955,11 @@ void gemm_f16_multi(const gemm_multi_args & a, hipStream_t st) {
     bool any_q = false;
     for (int i = 0; i < a.nmat; ++i) any_q = any_q || a.m[i].qtype != 0;
     if (any_q) { BM = G_BM; big = false; }                    // K-quant blocks de-quantised in the staging: the 128 x 128 kernel (few columns by construction)
+    if (!big && gemm_f16_sk_ok(a)) {                          // tile grids that fill the chip badly (a 512-token ubatch: 128-192 tiles): one persistent stream-K launch, no slabs
+        gemm_f16_sk(a, st);
+        ++g_gemm_variant_launches[4];
+        return;
+    }
     if (big) BM = 256;
     int tm = 0;
     for (int i = 0; i < 3; ++i) {

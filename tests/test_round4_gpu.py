@@ -175,3 +175,46 @@ def test_8b_q8_0_greedy_ids_identical_through_libllama(tmp_path):
             assert worst < 1e-3, worst
     finally:
         os.remove(gguf)
+
+
+# ---- the persistent stream-K form of the F16 GEMM (gemm_sk.hip): off by default (measured slower than the launch form, profiles/r04_gemm_streamk.txt),
+# kept selectable (option "gemm_sk") -- so its results stay pinned: against the products of the f16-rounded operands in float64, and against itself
+@pytest.mark.parametrize("Ms,K,N,resid", [((4096,), 4096, 512, True),             # wo at ubatch 512: two contributors per 256 x 128 tile ... four
+                                          ((4096, 1024, 1024), 4096, 512, False),   # wq / wk / wv as one launch: ranges that straddle tiles and matrices
+                                          ((1000, 520), 1024, 300, False),          # ragged M and N
+                                          ((384,), 8192, 129, False),               # a second column tile of one column
+                                          ((128,), 64 * 300, 256, True)])           # one tile row, a long K: many contributors per tile
+def test_stream_k_gemm_vs_float64_and_repeatable(pkg, be, Ms, K, N, resid):
+    import numpy as np
+    from llama_cpp_omni_amd.ggml import GGML_TYPE_F16, GGML_TYPE_F32, Context
+    be.set_option("gemm_sk", 1)
+    try:
+        rng = np.random.default_rng(len(Ms) * 1000 + N)
+        c = Context(be)
+        x = c.new_tensor(GGML_TYPE_F32, K, N)
+        ws = [c.new_tensor(GGML_TYPE_F16, K, M) for M in Ms]
+        ys = [c.mul_mat(w, x) for w in ws]
+        rs = [c.new_tensor(GGML_TYPE_F32, M, N) for M in Ms] if resid else []
+        if resid: ys = [c.add(y, r) for y, r in zip(ys, rs)]
+        c.alloc()
+        xv = rng.standard_normal((N, K), dtype=np.float32)
+        wv = [(rng.standard_normal((M, K), dtype=np.float32) * 0.05).astype(np.float16) for M in Ms]
+        rv = [rng.standard_normal((N, M), dtype=np.float32) for M in Ms] if resid else []
+        be.tensor_set(x, xv.ravel())
+        for w, v in zip(ws, wv): be.tensor_set(w, v.ravel())
+        for r, v in zip(rs, rv): be.tensor_set(r, v.ravel())
+        g = c.graph()
+        before = be.get_stat("gemm_sk_launches")
+        runs = []
+        for _ in range(3):
+            be.graph_compute(g); be.synchronize()
+            runs.append([be.tensor_get(y).copy().reshape(N, -1) for y in ys])
+        assert be.get_stat("gemm_sk_launches") - before == 3, "the launches did not take the stream-K kernel"
+        xh = xv.astype(np.float16).astype(np.float64)
+        for i, M in enumerate(Ms):
+            ref = xh @ wv[i].astype(np.float64).T + (rv[i] if resid else 0.0)
+            err = float(np.abs(runs[0][i] - ref).max() / np.abs(ref).max())
+            assert err < 2e-6, (M, err)                                             # f32 accumulation of K <= 19200 products
+            assert (runs[0][i] == runs[1][i]).all() and (runs[0][i] == runs[2][i]).all(), "the fold depends on the arrival order"
+    finally:
+        be.set_option("gemm_sk", -1)
