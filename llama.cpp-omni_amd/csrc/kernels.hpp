@@ -203,6 +203,8 @@ void   rope_table(const int32_t * pos, const float * ff, const rope_params & rp,
 size_t fattn_scratch_bytes(const fattn_args & a);
 bool   fattn_can_emit_image(const fattn_args & a);
 bool   fattn_pre_ok(const fattn_args & a);
+void   fattn_set_dma(int m);      // the LDS-DMA ring form of the prefill kernel (head 128, >= 512 workgroups): -1 default (on), 0 off, 1 on
+long   fattn_dma_launches();
 void   fattn_set_gqa(bool on);   // matrix-core decode kernel on (default) / off: the streaming kernel takes every few-token shape (cross-check)
 bool   fattn_uses_mma(const fattn_args & a);      // the matrix-core (prefill) kernel will run: out16 is honoured
 void   flash_attn_ext_f16(const fattn_args & a, hipStream_t st);

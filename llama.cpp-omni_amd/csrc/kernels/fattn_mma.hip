@@ -31,6 +31,8 @@ typedef _Float16 h8v  __attribute__((ext_vector_type(8)));
 typedef _Float16 h2v  __attribute__((ext_vector_type(2)));
 typedef float    f16a __attribute__((ext_vector_type(16)));
 typedef float    f32x2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) void * lds_ptr_t;
+typedef const __attribute__((address_space(1))) void * gbl_ptr_t;
 
 constexpr int FM_KT = 32;                       // KV rows per tile
 constexpr int FM_MAXT = 4096;                   // live-tile bitmap capacity: nkv <= 131072
@@ -43,20 +45,24 @@ template <int D> struct fm_cfg {
     static constexpr int VB  = D * VLD * 2;     // bytes of one V^T buffer
 };
 
-// KS = KV split inside the workgroup: NW*KS waves; wave (qb, ks) owns query block qb and the ks-th 32-row tile of every staged group of
-// KS tiles, with its own running (M, S, O); the KS partial states of a query block are merged through LDS at the end.  Used when a
+// KS = KV split inside the workgroup: NW*KS waves; wave (qb, ks) owns query block qb and the ks-th run of SQ 32-row tiles of every staged group of
+// KS * SQ tiles, with its own running (M, S, O); the KS partial states of a query block are merged through LDS at the end.  Used when a
 // single wave per 32 queries would leave half of the chip's SIMDs without a wave (one 512-token ubatch of one sequence: 512 blocks).
-template <int D, int NW, int KS>
+// SQ = tiles a wave works through, one after the other, between two barriers: the K / V rows of the NEXT group are requested right after the barrier that
+// publishes this one and have the whole group's matrix work to arrive -- with one tile per barrier (16 KB per workgroup in flight against a 1-2 us
+// round trip) every tile waited for its rows: the kernel ran at the request latency, not at the matrix or vector rate.
+template <int D, int NW, int KS, int SQ, int ABL = 0>      // ABL (measurement only, MI355X_FA_ABL): 1 no K / V requests or LDS stores inside the loop (stale tiles), 2 no soft-max arithmetic, 4 no P.V product
 __global__ void __launch_bounds__(64 * NW * KS) __attribute__((amdgpu_waves_per_eu(2))) k_fattn_mma(const fa_dev a, const int nqt) {
     constexpr int KLD = fm_cfg<D>::KLD, VLD = fm_cfg<D>::VLD;
     constexpr int NKS = D / 16;                 // MFMA k-steps of the score product
     constexpr int NDB = D / 32;                 // 32-row blocks of O^T
     constexpr int NT  = 64 * NW * KS;
-    constexpr int GT  = FM_KT * KS;             // KV rows staged per iteration (a group of KS tiles)
+    constexpr int NTL = KS * SQ;                // 32-row tiles per staged group
+    constexpr int GT  = FM_KT * NTL;            // KV rows staged per iteration
     constexpr int KCH = (GT * (D / 8) + NT - 1) / NT;               // 16-byte K chunks per thread per group
     constexpr int VIT = ((GT / 2) * (D / 8) + NT - 1) / NT;         // V row-pair items per thread per group
-    __shared__ __attribute__((aligned(16))) _Float16 Ks[2][KS][FM_KT * KLD];
-    __shared__ __attribute__((aligned(16))) uint32_t Vt[2][KS][D * VLD / 2];
+    __shared__ __attribute__((aligned(16))) _Float16 Ks[2][NTL][FM_KT * KLD];
+    __shared__ __attribute__((aligned(16))) uint32_t Vt[2][NTL][D * VLD / 2];
 
     const int tid = threadIdx.x, lane = tid & 63, wave_all = tid >> 6;
     const int wave = wave_all % NW, kvs = wave_all / NW;    // query block within the workgroup, KV split
@@ -99,12 +105,29 @@ __global__ void __launch_bounds__(64 * NW * KS) __attribute__((amdgpu_waves_per_
     const char * kbase = a.k + ikv * a.knb2 + is3 * a.knb3;
     const char * vbase = a.v + ikv * a.vnb2 + is3 * a.vnb3;
     const int ntile32 = (a.nkv + FM_KT - 1) / FM_KT;              // 32-row mask / compute tiles
-    const int ntile = (ntile32 + KS - 1) / KS;                    // staged groups of KS tiles
+    const int ntile = (ntile32 + NTL - 1) / NTL;                  // staged groups of NTL tiles
 
-    // ---- which tiles does any query of this workgroup see?  one bit per tile, built from the mask tile map
+    // ---- which tiles does any query of this workgroup see?  The classes of the workgroup's NW x ntile32 tiles are copied out of the mask tile map once, two bits each,
+    // into LDS (a class looked up in global memory inside the loop was a dependent L2 round trip per group and wave, in front of the barrier: the loop ran at that
+    // latency); one bit per staged group says whether anybody needs it
     __shared__ uint64_t live_bits[FM_MAXT / 64];
+    __shared__ uint32_t cls2[NW][FM_MAXT / 16];
     const int qb0 = qt * NW;                                        // first 32-row query block of the workgroup
     const uint8_t * maprow = a.tile_map ? a.tile_map + (((int64_t) (is3 % (int) a.mne3) * a.mne2 + (h % (int) a.mne2)) * a.map_nqb) * ntile32 : nullptr;
+    if (maprow) {
+        const int nwords = (ntile32 + 15) / 16;
+        for (int j = tid; j < NW * nwords; j += NT) {
+            const int w = j / nwords, wd = j % nwords;
+            uint32_t word = 0;
+            if (qb0 + w < a.map_nqb) {
+                const uint8_t * r = maprow + (int64_t) (qb0 + w) * ntile32;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) { const int t32 = wd * 16 + i; word |= (t32 < ntile32 ? (uint32_t) r[t32] & 3u : 0u) << (2 * i); }
+            }
+            cls2[w][wd] = word;
+        }
+        __syncthreads();
+    }
     for (int c = wave_all; c * 64 < ntile; c += NW * KS) {
         const int tt = c * 64 + lane;
         bool lv = false;
@@ -114,8 +137,10 @@ __global__ void __launch_bounds__(64 * NW * KS) __attribute__((amdgpu_waves_per_
 #pragma unroll
                 for (int w = 0; w < NW; ++w)
 #pragma unroll
-                    for (int k = 0; k < KS; ++k)
-                        if (qb0 + w < a.map_nqb && tt * KS + k < ntile32) lv |= maprow[(int64_t) (qb0 + w) * ntile32 + tt * KS + k] != 0;
+                    for (int k = 0; k < NTL; ++k) {
+                        const int t32 = tt * NTL + k;
+                        if (t32 < ntile32) lv |= ((cls2[w][t32 >> 4] >> (2 * (t32 & 15))) & 3u) != 0;
+                    }
         }
         const uint64_t bits = __ballot(lv);
         if (lane == 0) live_bits[c] = bits;
@@ -129,12 +154,11 @@ __global__ void __launch_bounds__(64 * NW * KS) __attribute__((amdgpu_waves_per_
         }
         return __builtin_amdgcn_readfirstlane(u < ntile ? u : ntile);
     };
-    const uint8_t * myrow = (maprow && qb0 + wave < a.map_nqb) ? maprow + (int64_t) (qb0 + wave) * ntile32 : nullptr;
-    auto tile_class = [&](int g) -> int {                            // this wave's 32 queries x its tile of group g
-        const int t = g * KS + kvs;
+    auto tile_class = [&](int g, int sq) -> int {                    // this wave's 32 queries x its sq-th tile of group g
+        const int t = g * NTL + kvs * SQ + sq;
         if (q0 >= a.nq || t >= ntile32) return 0;
         if (!maprow) return (t + 1) * FM_KT <= a.nkv ? 1 : 2;
-        return myrow ? (int) myrow[t] : 0;
+        return (int) ((cls2[wave][t >> 4] >> (2 * (t & 15))) & 3u);
     };
 
     // mask words of this lane's query for tile t: word pair g (0..3) = halfs kv0 + 4*hb + 8*g + {0..3}; cells past nkv read as -inf
@@ -199,41 +223,50 @@ __global__ void __launch_bounds__(64 * NW * KS) __attribute__((amdgpu_waves_per_
 
     int t = next_live(0), nlive = 0;
     if (t < ntile) load_kv(t);
-    int cls = t < ntile ? tile_class(t) : 0;
+    const bool c2pos = c2 > 0.0f;                                     // (then the row maximum may be taken before the scale is applied)
     while (t < ntile) {
         const int buf = nlive & 1;
-        u32x2 mw[4] = {};
-        if (cls == 2) load_mask(t * KS + kvs, mw);                              // mixed tile: this lane's mask words (latency under the stores)
-        store_kv(buf);
-        // barrier: tile t is visible; everybody is past the previous live tile's matrix work, so the other buffer may be refilled
+        int cls[SQ]; u32x2 mw[SQ][4] = {};
+#pragma unroll
+        for (int sq = 0; sq < SQ; ++sq) {
+            cls[sq] = tile_class(t, sq);
+            if (cls[sq] == 2) load_mask(t * NTL + kvs * SQ + sq, mw[sq]);       // mixed tile: this lane's mask words (latency under the stores)
+        }
+        if (!(ABL & 1) || nlive == 0) store_kv(buf);
+        // barrier: group t is visible; everybody is past the previous live group's matrix work, so the other buffer may be refilled
         __syncthreads();
         const int tn = next_live(t + 1);
-        if (tn < ntile) load_kv(tn);                                 // in flight under this tile's MFMAs
-        const int cls_n = tn < ntile ? tile_class(tn) : 0;
+        if (tn < ntile && !(ABL & 1)) load_kv(tn);                   // in flight under this group's MFMAs
 
-        if (cls != 0) {
+#pragma unroll
+        for (int sq = 0; sq < SQ; ++sq) {
+            if (cls[sq] == 0) continue;
+            const int li = kvs * SQ + sq;
             // ---- S^T = K . Q^T
             f16a sc;
 #pragma unroll
             for (int e = 0; e < 16; ++e) sc[e] = 0.0f;
 #pragma unroll
             for (int ks = 0; ks < NKS; ++ks) {
-                const h8v kf = *(const h8v *) &Ks[buf][kvs][lq * KLD + ks * 16 + hb * 8];
+                const h8v kf = *(const h8v *) &Ks[buf][li][lq * KLD + ks * 16 + hb * 8];
                 sc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], sc, 0, 0, 0);
             }
             // ---- scale / softcap / mask (all-zero mask tiles skip the mask arithmetic), base-2 online softmax
             float tmax = -INFINITY;
-            if (cls == 1 && a.logit_softcap == 0.0f && slope == 1.0f) {
+            const bool plain = cls[sq] == 1 && a.logit_softcap == 0.0f && slope == 1.0f && c2pos;
+            if (ABL & 2) {
+            } else if (plain) {                                              // p = exp2(s * c2 - M): the scale rides in the exponent's FMA
 #pragma unroll
-                for (int e = 0; e < 16; ++e) { sc[e] *= c2; tmax = fmaxf(tmax, sc[e]); }
+                for (int e = 0; e < 16; ++e) tmax = fmaxf(tmax, sc[e]);
+                tmax *= c2;
             } else {
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
-                    const uint32_t w = mw[e >> 2][(e >> 1) & 1];
+                    const uint32_t w = mw[sq][e >> 2][(e >> 1) & 1];
                     const uint16_t hbits = (uint16_t) ((e & 1) ? (w >> 16) : (w & 0xffffu));
                     float v = sc[e] * c2;
                     if (a.logit_softcap != 0.0f) v = a.logit_softcap * FM_LOG2E * tanhf(v);
-                    v = (hbits == 0xfc00u || !row_ok) ? -INFINITY : v + slope2 * h2f(hbits);
+                    v = (hbits == 0xfc00u || !row_ok) ? -INFINITY : (cls[sq] == 1 ? v : v + slope2 * h2f(hbits));
                     sc[e] = v;
                     tmax = fmaxf(tmax, v);
                 }
@@ -246,7 +279,7 @@ __global__ void __launch_bounds__(64 * NW * KS) __attribute__((amdgpu_waves_per_
             union { h2v h2[4]; h8v v; } pf[2];
 #pragma unroll
             for (int e = 0; e < 16; e += 2) {
-                const float p0 = __builtin_amdgcn_exp2f(sc[e] - Mu), p1 = __builtin_amdgcn_exp2f(sc[e + 1] - Mu);   // masked -> 0
+                const float p0 = (ABL & 2) ? sc[e] : __builtin_amdgcn_exp2f(plain ? fmaf(sc[e], c2, -Mu) : sc[e] - Mu), p1 = (ABL & 2) ? sc[e + 1] : __builtin_amdgcn_exp2f(plain ? fmaf(sc[e + 1], c2, -Mu) : sc[e + 1] - Mu);   // masked -> 0
                 psum += p0 + p1;
                 const f32x2 pp = { p0, p1 };
                 pf[e >> 3].h2[(e & 7) >> 1] = __builtin_convertvector(pp, h2v);          // v_cvt_pk_f16_f32 (round-to-nearest-even)
@@ -259,19 +292,19 @@ __global__ void __launch_bounds__(64 * NW * KS) __attribute__((amdgpu_waves_per_
 #pragma unroll
                     for (int e = 0; e < 16; ++e) acc_o[db][e] *= alpha;
             }
-            // ---- O^T += V^T . P^T
+            // ---- O^T += V^T . P^T  (the NDB accumulators in turn: consecutive MFMAs are independent)
 #pragma unroll
-            for (int db = 0; db < NDB; ++db) {
+            for (int s2 = 0; s2 < ((ABL & 4) ? 0 : 2); ++s2) {
 #pragma unroll
-                for (int s2 = 0; s2 < 2; ++s2) {
-                    const uint32_t * vr = &Vt[buf][kvs][(db * 32 + lq) * (VLD / 2) + 8 * s2 + 2 * hb];
+                for (int db = 0; db < NDB; ++db) {
+                    const uint32_t * vr = &Vt[buf][li][(db * 32 + lq) * (VLD / 2) + 8 * s2 + 2 * hb];
                     union { uint32_t u[4]; h8v v; } vf;
                     vf.u[0] = vr[0]; vf.u[1] = vr[1]; vf.u[2] = vr[4]; vf.u[3] = vr[5];
                     acc_o[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf.v, pf[s2].v, acc_o[db], 0, 0, 0);
                 }
             }
         }
-        t = tn; cls = cls_n; ++nlive;
+        t = tn; ++nlive;
     }
 
     // ---- merge the KS partial states of each query block (same lane layout in every wave of a block): the ks > 0 waves park
@@ -303,6 +336,347 @@ __global__ void __launch_bounds__(64 * NW * KS) __attribute__((amdgpu_waves_per_
         }
     }
     // ---- finish: fold the two lane halves' partial sums, sinks (ops.cpp:8116-8130), normalise, store permuted
+    S += __shfl_xor(S, 32, 64);
+    float osc = 1.0f;
+    if (a.sinks) {
+        const float sk = a.sinks[h] * FM_LOG2E;
+        if (sk > M) { const float f = __builtin_amdgcn_exp2f(M - sk); S = S * f + 1.0f; osc = f; }
+        else S += __builtin_amdgcn_exp2f(sk - M);
+    }
+    const float inv = S == 0.0f ? 0.0f : osc / S;
+    if (row_ok) {
+        char * out = a.dst + h * a.dnb1 + q * a.dnb2 + is3 * a.dnb3;
+#pragma unroll
+        for (int db = 0; db < NDB; ++db)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4 o4;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) o4[i] = acc_o[db][4 * g + i] * inv;
+                if (a.write_f32) *(f32x4 *) (out + (db * 32 + 8 * g + 4 * hb) * 4) = o4;
+                if (a.out16) {
+                    u32x2 hw;
+                    hw[0] = (uint32_t) f2h(o4[0]) | ((uint32_t) f2h(o4[1]) << 16); hw[1] = (uint32_t) f2h(o4[2]) | ((uint32_t) f2h(o4[3]) << 16);
+                    *(u32x2 *) (a.out16 + ((int64_t) is3 * a.nq + q) * a.out16_rs + ((int64_t) h * D + db * 32 + 8 * g + 4 * hb) * 2) = hw;
+                }
+            }
+    }
+}
+
+// ---- head size 128, many query blocks: the same maths with K / V tiles that never pass through registers.
+// The kernel above stages a tile's rows global -> VGPR -> LDS (V transposed on the way: 8 ds_write_b32 + 16 bit operations per thread and tile) and has ONE group of
+// rows in flight per workgroup; PMC and knock-outs (profiles/r04_fattn.txt) show its waves parked 40 % of their life behind that chain and its vector pipe busier
+// than its matrix pipe.  Here:
+//   * K and V tiles (32 rows x 256 B each) arrive by LDS-DMA (global_load_lds_dwordx4) in a 4-slot ring, three tiles ahead, behind a counted s_waitcnt vmcnt(8) and one
+//     barrier per tile; rows past the end of the cache re-read its last row (finite data: their probabilities are zero)
+//   * both tiles stay ROW-MAJOR in LDS.  K fragments (lane = kv row, 8 consecutive d) are ds_read_b128 at the 16-byte chunk (ks*2 + hb) ^ (row & 15) -- the DMA
+//     source side applies the same XOR, so the 16 lanes the hardware serves together hit 16 different chunk positions
+//   * V^T fragments come from ds_read_b64_tr_b16: in every group of 16 lanes, lane 4i + r passes the address of 4 consecutive halves (d0 + 4r ..) of kv row k0 + i, and
+//     lane j gets back column d0 + j of rows k0 .. k0 + 3 (measured: tools/tr_probe.hip) -- exactly the four consecutive kv of one d that half an MFMA operand is under the
+//     kv labelling above; V chunks are XORed with 4 * (row & 3) so that the four rows of a read lie in different bank quarters
+// Same arithmetic as k_fattn_mma (P rounded to f16, exponentials in the base-2 domain, the scale folded into the exponent's FMA on unmasked tiles).
+constexpr float FD_THR = 8.0f;
+constexpr int FD_NST = 4, FD_ROWB = 256, FD_TILEB = FM_KT * FD_ROWB, FD_STAGEB = 2 * FD_TILEB;
+constexpr int FD_LIVE_OFF = FD_NST * FD_STAGEB, FD_CLS_OFF = FD_LIVE_OFF + FM_MAXT / 8, FD_LDS = FD_CLS_OFF + 4 * (FM_MAXT / 16) * 4;
+extern __shared__ __attribute__((aligned(16))) char fd_lds[];
+
+// the 16 V^T reads of a tile (4 d-blocks x {s2 = 0: rows +0 / +8, s2 = 1: rows +16 / +24}) are ISSUED in one statement and WAITED for in another: the soft-max
+// arithmetic between the two runs under their latency.  The registers are written by the hardware after the first statement returns: nothing may read, move or
+// spill them before fd_tr_wait (the kernel has no scratch: checked with -Rpass-analysis=kernel-resource-usage).
+struct fd_vfrag { u32x2 r[4][4]; };                               // [db][2 * s2 + half]
+static __device__ __forceinline__ void fd_tr_issue(const uint32_t (&ad)[4], fd_vfrag & f) {
+    asm volatile("ds_read_b64_tr_b16 %0, %16\n\tds_read_b64_tr_b16 %1, %16 offset:2048\n\tds_read_b64_tr_b16 %2, %16 offset:4096\n\tds_read_b64_tr_b16 %3, %16 offset:6144\n\t"
+                 "ds_read_b64_tr_b16 %4, %17\n\tds_read_b64_tr_b16 %5, %17 offset:2048\n\tds_read_b64_tr_b16 %6, %17 offset:4096\n\tds_read_b64_tr_b16 %7, %17 offset:6144\n\t"
+                 "ds_read_b64_tr_b16 %8, %18\n\tds_read_b64_tr_b16 %9, %18 offset:2048\n\tds_read_b64_tr_b16 %10, %18 offset:4096\n\tds_read_b64_tr_b16 %11, %18 offset:6144\n\t"
+                 "ds_read_b64_tr_b16 %12, %19\n\tds_read_b64_tr_b16 %13, %19 offset:2048\n\tds_read_b64_tr_b16 %14, %19 offset:4096\n\tds_read_b64_tr_b16 %15, %19 offset:6144"
+                 : "=&v"(f.r[0][0]), "=&v"(f.r[0][1]), "=&v"(f.r[0][2]), "=&v"(f.r[0][3]), "=&v"(f.r[1][0]), "=&v"(f.r[1][1]), "=&v"(f.r[1][2]), "=&v"(f.r[1][3]),
+                   "=&v"(f.r[2][0]), "=&v"(f.r[2][1]), "=&v"(f.r[2][2]), "=&v"(f.r[2][3]), "=&v"(f.r[3][0]), "=&v"(f.r[3][1]), "=&v"(f.r[3][2]), "=&v"(f.r[3][3])
+                 : "v"(ad[0]), "v"(ad[1]), "v"(ad[2]), "v"(ad[3]) : "memory");
+}
+static __device__ __forceinline__ void fd_tr_wait(fd_vfrag & f) {
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(f.r[0][0]), "+v"(f.r[0][1]), "+v"(f.r[0][2]), "+v"(f.r[0][3]), "+v"(f.r[1][0]), "+v"(f.r[1][1]), "+v"(f.r[1][2]), "+v"(f.r[1][3]),
+                   "+v"(f.r[2][0]), "+v"(f.r[2][1]), "+v"(f.r[2][2]), "+v"(f.r[2][3]), "+v"(f.r[3][0]), "+v"(f.r[3][1]), "+v"(f.r[3][2]), "+v"(f.r[3][3]) :: "memory");
+}
+static __device__ __forceinline__ float fd_max_halves(float x) {      // max of lanes l and l ^ 32 without the LDS crossbar (v_permlane32_swap)
+#if __has_builtin(__builtin_amdgcn_permlane32_swap)
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+#else
+    return fmaxf(x, __shfl_xor(x, 32, 64));
+#endif
+}
+
+// HW = heads per workgroup: 2 = eight waves, the four query blocks of TWO heads of one KV head (same mask tiles, same K / V rows): half the requests per unit of matrix work
+template <int ABL, int HW>
+__global__ void __launch_bounds__(256 * HW) __attribute__((amdgpu_waves_per_eu(2))) k_fattn_dma128(const fa_dev a, const int nqt) {
+    constexpr int D = 128, NW = 4, NKS = D / 16, NDB = D / 32, NT = 64 * NW * HW;
+    char * const lds = fd_lds;
+    uint64_t * const live_bits = (uint64_t *) (lds + FD_LIVE_OFF);
+    uint32_t (* const cls2)[FM_MAXT / 16] = (uint32_t (*)[FM_MAXT / 16]) (lds + FD_CLS_OFF);
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lq = lane & 31, hb = lane >> 5;
+    int b = (int) blockIdx.x;
+    const int qt  = nqt - 1 - b % nqt; b /= nqt;          // longest (latest, for causal masks) query tiles first
+    const int qbw = wave & 3;                                       // query block of this wave within the workgroup's 128 queries
+    const int h   = (b % (a.nh / HW)) * HW + (wave >> 2);  const int is3 = b / (a.nh / HW);
+    const int ikv = h / a.gq;
+    const int q0  = (qt * NW + qbw) * 32;
+    const int q   = q0 + lq;
+    const int qc  = q < a.nq ? q : a.nq - 1;
+    const bool row_ok = q < a.nq;
+
+    h8v qf[NKS];
+    {
+        const char * qr = a.q + qc * a.qnb1 + h * a.qnb2 + is3 * a.qnb3;
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+            const f32x4 v0 = *(const f32x4 *) (qr + (ks * 16 + hb * 8) * 4);
+            const f32x4 v1 = *(const f32x4 *) (qr + (ks * 16 + hb * 8 + 4) * 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { qf[ks][e] = (_Float16) v0[e]; qf[ks][4 + e] = (_Float16) v1[e]; }
+        }
+    }
+    const uint32_t hu = (uint32_t) h;
+    const float slope = a.max_bias > 0.0f ? (hu < a.n_head_log2 ? powf(a.m0, (float) (hu + 1)) : powf(a.m1, (float) (2 * (hu - a.n_head_log2) + 1))) : 1.0f;
+    const float slope2 = slope * FM_LOG2E;
+    const float c2 = a.logit_softcap != 0.0f ? a.scale : a.scale * FM_LOG2E;
+    const uint16_t * mrow = a.mask ? (const uint16_t *) (a.mask + qc * a.mnb1 + (h % (int) a.mne2) * a.mnb2 + (is3 % (int) a.mne3) * a.mnb3) : nullptr;
+    const bool mask_vec = a.mask && (a.mnb1 % 8 == 0) && (((uintptr_t) mrow) % 8 == 0);
+
+    f16a acc_o[NDB];
+#pragma unroll
+    for (int db = 0; db < NDB; ++db)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc_o[db][e] = 0.0f;
+    float M = -INFINITY, S = 0.0f;
+
+    const char * kbase = a.k + ikv * a.knb2 + is3 * a.knb3;
+    const char * vbase = a.v + ikv * a.vnb2 + is3 * a.vnb3;
+    const int ntile = (a.nkv + FM_KT - 1) / FM_KT;
+
+    // ---- tile classes of the workgroup's four query blocks -> LDS, live bits (as above)
+    const int qb0 = qt * NW;
+    const uint8_t * maprow = a.tile_map ? a.tile_map + (((int64_t) (is3 % (int) a.mne3) * a.mne2 + (h % (int) a.mne2)) * a.map_nqb) * ntile : nullptr;
+    if (maprow) {
+        const int nwords = (ntile + 15) / 16;
+        for (int j = tid; j < NW * nwords; j += NT) {
+            const int w = j / nwords, wd = j % nwords;
+            uint32_t word = 0;
+            if (qb0 + w < a.map_nqb) {
+                const uint8_t * r = maprow + (int64_t) (qb0 + w) * ntile;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) { const int t32 = wd * 16 + i; word |= (t32 < ntile ? (uint32_t) r[t32] & 3u : 0u) << (2 * i); }
+            }
+            cls2[w][wd] = word;
+        }
+        __syncthreads();
+    }
+    for (int c = wave; c * 64 < ntile; c += NW * HW) {
+        const int tt = c * 64 + lane;
+        bool lv = false;
+        if (tt < ntile) {
+            if (!maprow) lv = true;
+            else
+#pragma unroll
+                for (int w = 0; w < NW; ++w) lv |= ((cls2[w][tt >> 4] >> (2 * (tt & 15))) & 3u) != 0;
+        }
+        const uint64_t bits = __ballot(lv);
+        if (lane == 0) live_bits[c] = bits;
+    }
+    __syncthreads();
+    auto next_live = [&](int u) {
+        while (u < ntile) {
+            const uint64_t w = live_bits[u >> 6] >> (u & 63);
+            if (w) { u += __builtin_ctzll(w); break; }
+            u = (u | 63) + 1;
+        }
+        return __builtin_amdgcn_readfirstlane(u < ntile ? u : ntile);
+    };
+    auto tile_class = [&](int t) -> int {
+        if (q0 >= a.nq || t >= ntile) return 0;
+        if (!maprow) return (t + 1) * FM_KT <= a.nkv ? 1 : 2;
+        return (int) ((cls2[qbw][t >> 4] >> (2 * (t & 15))) & 3u);
+    };
+    auto load_mask = [&](int t, u32x2 (&w)[4]) {
+        const int kv0 = t * FM_KT;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int kvb = kv0 + 4 * hb + 8 * g;
+            if (kvb + 3 < a.nkv && (!mrow || mask_vec)) {
+                if (mrow) w[g] = *(const u32x2 *) (mrow + kvb); else { w[g][0] = 0u; w[g][1] = 0u; }
+            } else {
+                uint32_t hv[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) hv[i] = kvb + i < a.nkv ? (mrow ? (uint32_t) mrow[kvb + i] : 0u) : 0xfc00u;
+                w[g][0] = hv[0] | (hv[1] << 16); w[g][1] = hv[2] | (hv[3] << 16);
+            }
+        }
+    };
+
+    // ---- DMA side: instruction j of wave w fills rows (w*NJ + j)*4 + [0,4) of a tile, lane l the chunk l & 15 of row l >> 4 from the source chunk the swizzle asks for
+    constexpr int NJ = 2 / HW;                                      // K (and V) instructions per wave and tile
+    const int c16 = lane & 15;
+    int rit[NJ]; uint32_t kso[NJ], vso[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        rit[j] = (wave * NJ + j) * 4 + (lane >> 4);
+        kso[j] = (uint32_t) ((c16 ^ (rit[j] & 15)) * 16);
+        vso[j] = (uint32_t) ((c16 ^ (4 * (rit[j] & 3))) * 16);
+    }
+    int slot_d = 0, t_dma = next_live(0), t_last = 0;
+    auto dma_tile = [&]() {                                          // the next live tile (past the last one: that one again, into a slot nobody reads)
+        const int t = t_dma < ntile ? t_dma : t_last;
+        char * const sb = lds + slot_d * FD_STAGEB + (wave * NJ * 4) * FD_ROWB;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            int r = t * FM_KT + rit[j]; r = r < a.nkv ? r : a.nkv - 1;
+            __builtin_amdgcn_global_load_lds((gbl_ptr_t) (kbase + (int64_t) r * a.knb1 + kso[j]), (lds_ptr_t) (sb + j * 4 * FD_ROWB), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gbl_ptr_t) (vbase + (int64_t) r * a.vnb1 + vso[j]), (lds_ptr_t) (sb + FD_TILEB + j * 4 * FD_ROWB), 16, 0, 0);
+        }
+        if (t_dma < ntile) { t_last = t_dma; t_dma = next_live(t_dma + 1); }
+        slot_d = slot_d == FD_NST - 1 ? 0 : slot_d + 1;
+    };
+
+    // ---- reader side, per lane: K row lq, chunk (ks*2 + hb) ^ (lq & 15); V^T: group g = lane / 16, s = lane % 16 -> row 4*hb + s/4 (+ 8 r + 16 s2), halves d0 + 4 (s & 3) ..
+    const uint32_t lds0 = (uint32_t) (uintptr_t) lds;
+    const char * const krow = lds + lq * FD_ROWB;
+    const int ksw = lq & 15;
+    const int gi = lane >> 4, si = lane & 15;
+    const uint32_t vlane = lds0 + FD_TILEB + (uint32_t) ((4 * (gi >> 1) + (si >> 2)) * FD_ROWB + (2 * (gi & 1) + ((si & 3) >> 1)) * 16 + (si & 1) * 8);
+    uint32_t vdb[NDB];
+#pragma unroll
+    for (int db = 0; db < NDB; ++db) vdb[db] = vlane + (uint32_t) (64 * (db ^ (si >> 2)));
+
+    const bool c2pos = c2 > 0.0f;
+    // ---- the phases of a tile; the two tiles of a pair are interleaved below so that one's soft-max arithmetic issues while the other's matrix products execute
+    // the running maximum is only a reference point of the exponents: it follows the row maximum when that has grown by more than 2^FD_THR since the last update
+    // (wave-uniform decision: then every lane rescales), so p <= 2^FD_THR instead of <= 1 -- f16 holds it, O and S are f32 -- and the 64-multiply rescale of O^T,
+    // which random scores trigger in almost every tile of the first hundred, runs a handful of times per row
+    typedef union { h2v h2[4]; h8v v; } pfrag;
+    auto soft_max = [&](const int cls, const u32x2 (&mw)[4], f16a & sc, pfrag (&pf)[2]) {
+        float tmax = -INFINITY, Mn, Mu, alpha, psum = 0.0f;
+        const bool plain = cls == 1 && a.logit_softcap == 0.0f && slope == 1.0f && c2pos;
+        if (plain) {                                                  // p = exp2(s * c2 - M): the scale rides in the exponent's FMA
+#pragma unroll
+            for (int e = 0; e < 16; ++e) tmax = fmaxf(tmax, sc[e]);
+            tmax *= c2;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const uint32_t w = mw[e >> 2][(e >> 1) & 1];
+                const uint16_t hbits = (uint16_t) ((e & 1) ? (w >> 16) : (w & 0xffffu));
+                float v = sc[e] * c2;
+                if (a.logit_softcap != 0.0f) v = a.logit_softcap * FM_LOG2E * tanhf(v);
+                v = (hbits == 0xfc00u || !row_ok) ? -INFINITY : (cls == 1 ? v : v + slope2 * h2f(hbits));
+                sc[e] = v;
+                tmax = fmaxf(tmax, v);
+            }
+        }
+        tmax = fd_max_halves(tmax);
+        if (__any(tmax > M + FD_THR)) { Mn = fmaxf(M, tmax); Mu = Mn == -INFINITY ? 0.0f : Mn; alpha = __builtin_amdgcn_exp2f(M - Mu); }
+        else                          { Mn = M; Mu = M == -INFINITY ? 0.0f : M; alpha = 1.0f; }
+        if (plain) {
+            const float nMu = -Mu;
+#pragma unroll
+            for (int e = 0; e < 16; e += 2) {
+                const float p0 = __builtin_amdgcn_exp2f(fmaf(sc[e], c2, nMu)), p1 = __builtin_amdgcn_exp2f(fmaf(sc[e + 1], c2, nMu));
+                psum += p0 + p1;
+                const f32x2 pp = { p0, p1 };
+                pf[e >> 3].h2[(e & 7) >> 1] = __builtin_convertvector(pp, h2v);
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 16; e += 2) {
+                const float p0 = __builtin_amdgcn_exp2f(sc[e] - Mu), p1 = __builtin_amdgcn_exp2f(sc[e + 1] - Mu);   // masked -> 0
+                psum += p0 + p1;
+                const f32x2 pp = { p0, p1 };
+                pf[e >> 3].h2[(e & 7) >> 1] = __builtin_convertvector(pp, h2v);
+            }
+        }
+        S = S * alpha + psum;
+        M = Mn;
+        if (!__all(alpha == 1.0f)) {
+#pragma unroll
+            for (int db = 0; db < NDB; ++db)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc_o[db][e] *= alpha;
+        }
+    };
+    auto pv = [&](fd_vfrag & vf, const pfrag (&pf)[2]) {              // O^T += V^T . P^T (the four accumulators in turn: consecutive MFMAs are independent)
+        fd_tr_wait(vf);
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+            for (int db = 0; db < NDB; ++db) {
+                union { u32x4 u; h8v v; } vv;
+                vv.u = u32x4{ vf.r[db][2 * s2][0], vf.r[db][2 * s2][1], vf.r[db][2 * s2 + 1][0], vf.r[db][2 * s2 + 1][1] };
+                acc_o[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vv.v, pf[s2].v, acc_o[db], 0, 0, 0);
+            }
+    };
+    // the two tiles of a pair: both score products first, alternating (consecutive MFMAs are independent), then per tile V^T requested | soft-max | P.V -- tile 0's
+    // P.V executes while tile 1's soft-max issues.  (Measured against a hand-ordered form with the K fragments requested eight at a time by inline asm and waited for
+    // in halves: 538 vs 577 TFLOP/s at 8 x (512 x 2048) -- the compiler's own ds_read / MFMA interleave is the better one.)
+    auto pair_work = [&](const int cls0, const int cls1, const u32x2 (&mw0)[4], const u32x2 (&mw1)[4], const uint32_t so0, const uint32_t so1) {
+        f16a s0, s1;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { s0[e] = 0.0f; s1[e] = 0.0f; }
+        if (cls0 != 0 && cls1 != 0) {
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) {
+                const h8v k0 = *(const h8v *) (krow + so0 + (((ks * 2 + hb) ^ ksw) << 4));
+                const h8v k1 = *(const h8v *) (krow + so1 + (((ks * 2 + hb) ^ ksw) << 4));
+                s0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(k0, qf[ks], s0, 0, 0, 0);
+                s1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(k1, qf[ks], s1, 0, 0, 0);
+            }
+        } else if (cls0 != 0 || cls1 != 0) {
+            const uint32_t so = cls0 != 0 ? so0 : so1;
+            f16a sb;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) sb[e] = 0.0f;
+#pragma unroll
+            for (int ks = 0; ks < NKS; ks += 2) {
+                const h8v k0 = *(const h8v *) (krow + so + (((ks * 2 + hb) ^ ksw) << 4));
+                const h8v k1 = *(const h8v *) (krow + so + ((((ks + 1) * 2 + hb) ^ ksw) << 4));
+                s0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(k0, qf[ks], s0, 0, 0, 0);
+                sb = __builtin_amdgcn_mfma_f32_32x32x16_f16(k1, qf[ks + 1], sb, 0, 0, 0);
+            }
+#pragma unroll
+            for (int e = 0; e < 16; ++e) s0[e] += sb[e];
+            if (cls0 == 0) { s1 = s0; }
+        }
+        if (ABL & 4) {
+            pfrag pf[2];
+            if (cls0 != 0) soft_max(cls0, mw0, s0, pf);
+            if (cls1 != 0) soft_max(cls1, mw1, s1, pf);
+            return;
+        }
+        fd_vfrag v0, v1; pfrag pf0[2], pf1[2];
+        if (cls0 != 0) { const uint32_t ad[4] = { vdb[0] + so0, vdb[1] + so0, vdb[2] + so0, vdb[3] + so0 }; fd_tr_issue(ad, v0); soft_max(cls0, mw0, s0, pf0); pv(v0, pf0); }
+        if (cls1 != 0) { const uint32_t ad[4] = { vdb[0] + so1, vdb[1] + so1, vdb[2] + so1, vdb[3] + so1 }; fd_tr_issue(ad, v1); soft_max(cls1, mw1, s1, pf1); pv(v1, pf1); }
+    };
+    // ---- two live tiles per barrier: the ring is two pairs of slots; while a pair is worked on, the next pair's rows are in flight (a pair of tiles of matrix work to arrive)
+    int t = next_live(0);
+    dma_tile(); dma_tile();
+    int pair = 0;
+    while (t < ntile) {
+        const int t1 = next_live(t + 1);
+        const int cls0 = tile_class(t), cls1 = t1 < ntile ? tile_class(t1) : 0;
+        u32x2 mw0[4] = {}, mw1[4] = {};
+        if (cls0 == 2) load_mask(t, mw0);
+        if (cls1 == 2) load_mask(t1, mw1);
+        // own requests of this pair have landed; after the barrier everybody's have, and everybody is past the previous pair, whose slots take the next one
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        if (!(ABL & 1)) { dma_tile(); dma_tile(); }
+        const uint32_t so = (uint32_t) (pair * 2 * FD_STAGEB);
+        pair ^= 1;
+        pair_work(cls0, cls1, mw0, mw1, so, so + FD_STAGEB);
+        t = t1 < ntile ? next_live(t1 + 1) : ntile;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // (requests past the last live tile)
+
     S += __shfl_xor(S, 32, 64);
     float osc = 1.0f;
     if (a.sinks) {
@@ -686,19 +1060,58 @@ void fattn_mask_map(const fa_dev & a, uint8_t * map, hipStream_t st) {
     k_fattn_mask_map<<<dim3((unsigned) ((nw + 3) / 4)), dim3(256), 0, st>>>(a.mask, a.mnb1, a.mnb2, a.mnb3, (int) a.mne2, (int) a.mne3, a.nq, a.nkv, nqb, ntile, map);
 }
 
+static int  g_fd_mode = -1;                                        // -1: MI355X_FA_NO_DMA decides, 0 off, 1 on
+static long g_fd_launches = 0;
+void fattn_set_dma(int m) { g_fd_mode = m; }
+long fattn_dma_launches() { return g_fd_launches; }
+
 template <int D>
 static void launch_fm(const fa_dev & a, hipStream_t st) {
     const int nqt4 = (a.nq + 127) / 128;
     static const bool no_split = getenv("MI355X_FA_NO_KVSPLIT") != nullptr;
+    static const int sq_env = getenv("MI355X_FA_SQ") ? atoi(getenv("MI355X_FA_SQ")) : 2;      // (tuning: tiles per wave between two barriers, 1 or 2)
     const int64_t blocks32 = (int64_t) ((a.nq + 31) / 32) * a.nh * a.ns;          // one wave each without a KV split
     if (a.nq <= 32) {
-        k_fattn_mma<D, 1, 1><<<dim3((unsigned) (a.nh * a.ns)), dim3(64), 0, st>>>(a, 1);
+        k_fattn_mma<D, 1, 1, 1><<<dim3((unsigned) (a.nh * a.ns)), dim3(64), 0, st>>>(a, 1);
     } else if ((int64_t) nqt4 * a.nh * a.ns >= 512) {
-        k_fattn_mma<D, 4, 1><<<dim3((unsigned) (nqt4 * a.nh * a.ns)), dim3(256), 0, st>>>(a, nqt4);
+        static const int abl = getenv("MI355X_FA_ABL") ? atoi(getenv("MI355X_FA_ABL")) : 0;
+        static const bool env_no_dma = getenv("MI355X_FA_NO_DMA") != nullptr;
+        const bool no_dma = g_fd_mode >= 0 ? g_fd_mode == 0 : env_no_dma;
+        if (D == 128 && !no_dma && a.nkv >= 128 && a.knb1 % 16 == 0 && a.vnb1 % 16 == 0 && a.knb2 % 16 == 0 && a.vnb2 % 16 == 0 && a.knb3 % 16 == 0 && a.vnb3 % 16 == 0 &&
+            (((uintptr_t) a.k | (uintptr_t) a.v) & 15) == 0) {
+            static bool attr[64] = {};
+            int dev = 0; HIP_CHECK(hipGetDevice(&dev));
+            if (dev < 0 || dev >= 64 || !attr[dev]) {
+#define FD_ALL(F) F(0, 1) F(1, 1) F(4, 1) F(0, 2) F(1, 2) F(4, 2)
+#define FD_ATTR(A, H) HIP_CHECK(hipFuncSetAttribute((const void *) k_fattn_dma128<A, H>, hipFuncAttributeMaxDynamicSharedMemorySize, FD_LDS));
+                FD_ALL(FD_ATTR)
+                if (dev >= 0 && dev < 64) attr[dev] = true;
+            }
+            static const int hw_env = getenv("MI355X_FA_HW") ? atoi(getenv("MI355X_FA_HW")) : 2;
+            const int hw = (hw_env >= 2 && a.gq % 2 == 0 && a.mne2 <= 1 && (int64_t) nqt4 * (a.nh / 2) * a.ns >= 256) ? 2 : 1;      // pairs of heads of one KV head, one mask for every head
+            const dim3 grid((unsigned) (nqt4 * (a.nh / hw) * a.ns));
+            bool done = false;
+#define FD_GO(A, H) if (!done && abl == A && hw == H) { k_fattn_dma128<A, H><<<grid, dim3(256 * H), FD_LDS, st>>>(a, nqt4); done = true; }
+            ++g_fd_launches;
+            FD_ALL(FD_GO)
+            if (!done) { if (hw == 2) k_fattn_dma128<0, 2><<<grid, dim3(512), FD_LDS, st>>>(a, nqt4); else k_fattn_dma128<0, 1><<<grid, dim3(256), FD_LDS, st>>>(a, nqt4); }
+#undef FD_GO
+#undef FD_ATTR
+#undef FD_ALL
+            return;
+        }
+        if (abl == 1)      k_fattn_mma<D, 4, 1, 2, 1><<<dim3((unsigned) (nqt4 * a.nh * a.ns)), dim3(256), 0, st>>>(a, nqt4);
+        else if (abl == 2) k_fattn_mma<D, 4, 1, 2, 2><<<dim3((unsigned) (nqt4 * a.nh * a.ns)), dim3(256), 0, st>>>(a, nqt4);
+        else if (abl == 3) k_fattn_mma<D, 4, 1, 2, 3><<<dim3((unsigned) (nqt4 * a.nh * a.ns)), dim3(256), 0, st>>>(a, nqt4);
+        else if (abl == 6) k_fattn_mma<D, 4, 1, 2, 6><<<dim3((unsigned) (nqt4 * a.nh * a.ns)), dim3(256), 0, st>>>(a, nqt4);
+        else if (abl == 7) k_fattn_mma<D, 4, 1, 2, 7><<<dim3((unsigned) (nqt4 * a.nh * a.ns)), dim3(256), 0, st>>>(a, nqt4);
+        else if (sq_env >= 2 && a.nkv >= 128) k_fattn_mma<D, 4, 1, 2><<<dim3((unsigned) (nqt4 * a.nh * a.ns)), dim3(256), 0, st>>>(a, nqt4);
+        else                             k_fattn_mma<D, 4, 1, 1><<<dim3((unsigned) (nqt4 * a.nh * a.ns)), dim3(256), 0, st>>>(a, nqt4);
     } else {
         const int nqt = (a.nq + 63) / 64;
-        if (!no_split && blocks32 <= 768 && a.nkv >= 128) k_fattn_mma<D, 2, 2><<<dim3((unsigned) (nqt * a.nh * a.ns)), dim3(256), 0, st>>>(a, nqt);   // fewer waves than SIMDs
-        else                                             k_fattn_mma<D, 2, 1><<<dim3((unsigned) (nqt * a.nh * a.ns)), dim3(128), 0, st>>>(a, nqt);
+        if (!no_split && blocks32 <= 768 && a.nkv >= 128) k_fattn_mma<D, 2, 2, 1><<<dim3((unsigned) (nqt * a.nh * a.ns)), dim3(256), 0, st>>>(a, nqt);   // fewer waves than SIMDs
+        else if (sq_env >= 2 && a.nkv >= 128)            k_fattn_mma<D, 2, 1, 2><<<dim3((unsigned) (nqt * a.nh * a.ns)), dim3(128), 0, st>>>(a, nqt);
+        else                                             k_fattn_mma<D, 2, 1, 1><<<dim3((unsigned) (nqt * a.nh * a.ns)), dim3(128), 0, st>>>(a, nqt);
     }
 }
 

@@ -218,3 +218,61 @@ def test_stream_k_gemm_vs_float64_and_repeatable(pkg, be, Ms, K, N, resid):
             assert (runs[0][i] == runs[1][i]).all() and (runs[0][i] == runs[2][i]).all(), "the fold depends on the arrival order"
     finally:
         be.set_option("gemm_sk", -1)
+
+
+# ---- the LDS-DMA ring form of the prefill FLASH_ATTN_EXT kernel (fattn_mma.hip k_fattn_dma128: K / V tiles by global_load_lds, V^T fragments by
+# ds_read_b64_tr_b16, two heads of a KV head per workgroup, deferred running maximum): taken for head size 128 from 512 workgroups on.  Against the
+# float64 restatement of ggml_compute_forward_flash_attn_ext_f16 (ops.cpp:7912-8148), bar = the reference's NMSE 5e-4 for this op, and against the
+# register-staged kernel it replaces (option fattn_dma 0).
+@pytest.mark.parametrize("nq,nh,nhkv,nkv,ns,kind", [
+    (256, 32, 8, 300, 8, "causal"),        # ragged last tile, diagonal tiles, dead tiles; pairs of heads per workgroup
+    (384, 16, 16, 777, 11, "none"),        # no mask, no GQA (one head per workgroup), odd number of live tiles
+    (256, 32, 8, 1024, 8, "padded"),       # the second half of the cache view unused
+    (256, 32, 4, 512, 8, "sinks"),
+    (256, 32, 8, 640, 8, "softcap"),
+    (128, 64, 8, 4096, 8, "spike")])       # one key far above the rest late in the row: the deferred maximum must follow it
+def test_flash_attn_prefill_dma_ring(pkg, be, nq, nh, nhkv, nkv, ns, kind):
+    import numpy as np
+    from conftest import nmse
+    from test_gpu_parity import _attn_f64, run_graph
+    D = 128
+    rng = np.random.default_rng(nq + nkv + nh)
+    qv = rng.standard_normal((ns, nh, nq, D)).astype(np.float32)
+    kv = rng.standard_normal((ns, nhkv, nkv, D)).astype(np.float16)
+    vv = rng.standard_normal((ns, nhkv, nkv, D)).astype(np.float16)
+    if kind == "spike":                      # q . k of one late key ~ 40 x the typical score: forces the rescale long after the first tiles
+        kv[:, :, nkv - 37, :] = (qv[:, ::nh // nhkv, nq // 2, :] * 3.0).astype(np.float16)
+    mask = None
+    if kind not in ("none",):
+        mask = np.zeros((nq, nkv), np.float16)
+        off = nkv - nq if kind != "padded" else nkv // 2 - nq
+        for i in range(nq):
+            mask[i, max(0, min(nkv, off + i + 1)):] = -np.inf
+    sinks = rng.standard_normal(nh).astype(np.float32) if kind == "sinks" else None
+    softcap = 7.0 if kind == "softcap" else 0.0
+    scale = 1.0 / np.sqrt(D)
+    outs = []
+    for dma in (1, 0):
+        be.set_option("fattn_dma", dma)
+        try:
+            c = pkg.Context(be)
+            q = c.new_tensor(pkg.GGML_TYPE_F32, D, nq, nh, ns)
+            k = c.new_tensor(pkg.GGML_TYPE_F16, D, nkv, nhkv, ns)
+            v = c.new_tensor(pkg.GGML_TYPE_F16, D, nkv, nhkv, ns)
+            feeds = [(q, qv), (k, kv), (v, vv)]
+            m = sk = None
+            if mask is not None:
+                m = c.new_tensor(pkg.GGML_TYPE_F16, nkv, nq); feeds.append((m, mask))
+            if sinks is not None:
+                sk = c.new_tensor(pkg.GGML_TYPE_F32, nh); feeds.append((sk, sinks))
+            y = c.flash_attn_ext(q, k, v, m, scale, 0.0, softcap, sk)
+            before = be.get_stat("fattn_dma_launches")
+            (got,) = run_graph(be, c, [y], feeds)
+            assert (be.get_stat("fattn_dma_launches") - before >= 1) == (dma == 1), "the shape did not select the kernel under test"
+            outs.append(got.astype(np.float64).reshape(ns, nq, nh, D))
+        finally:
+            be.set_option("fattn_dma", -1)
+    want = _attn_f64(qv, kv, vv, mask, scale, softcap, sinks)
+    assert np.isfinite(outs[0]).all()
+    assert nmse(outs[0], want) < 2e-6, nmse(outs[0], want)           # (bar 5e-4; P is rounded to f16: ~1e-7)
+    assert nmse(outs[0], outs[1]) < 2e-6
