@@ -349,6 +349,11 @@ static size_t graph_fa_scratch_need(const ggml_cgraph * g) {
             if (b > need) need = b;
             continue;
         }
+        if (n->op == GGML_OP_SOFT_MAX && !is_empty(n) && n->ne[1] > 8 && n->src[1] && n->src[1]->ne[2] == 1 && n->src[1]->ne[3] == 1) {      // flash-attention off, a batch of rows: mask tile map + f16 copy of an f32 mask (exec_attn_sm_prefill)
+            const size_t b = ((fattn_map_bytes_host(n->ne[1], n->ne[0]) + 255) & ~(size_t) 255) + (size_t) n->src[1]->ne[1] * (size_t) n->ne[0] * 2;
+            if (b > need) need = b;
+            continue;
+        }
         if (n->op != GGML_OP_FLASH_ATTN_EXT || is_empty(n)) continue;
         fattn_args f; tdesc m; fill_fattn_args(n, f, m);
         const size_t b = fattn_scratch_bytes(f);
@@ -1797,6 +1802,88 @@ static bool exec_rms_norm(exec_state & s, int i) {
     return true;
 }
 
+// Flash-attention OFF, a batch of query rows (llama-bench's default prefill, the Whisper / SigLip encoders): MUL_MAT(k, q) -> SOFT_MAX_EXT(mask, scale) -> MUL_MAT(v^T, p) ->
+// PERMUTE -> CONT is one flash-attention launch reading V^T as it lies (reference: ggml_compute_forward_soft_max_f32, ops.cpp:5072-5182, between two ggml_compute_forward_mul_mat;
+// the [n_kv, n_q, H] blocks -- 146 MB written and read back per Whisper layer -- are never materialised).  An f32 mask is cast to f16 once per graph run (what the
+// reference's own flash-attention graphs do, llama-graph.cpp build_attn_inp_kv: ggml_cast(kq_mask, F16); 0 and -inf are exact) behind the mask tile map in the attention scratch.
+static size_t attn_sm_mask16_off(int64_t nq, int64_t nkv) { return (fattn_map_bytes_host(nq, nkv) + 255) & ~(size_t) 255; }
+static bool exec_attn_sm_prefill(exec_state & s, int i) {
+    static const bool off = getenv("MI355X_NO_ATTN_SM_PREFILL") != nullptr;
+    ggml_cgraph * g = s.g;
+    const ggml_tensor * M1 = g->nodes[i];
+    if (off || !s.c->opt_fusion || M1->op != GGML_OP_MUL_MAT || is_out(s, M1)) return false;
+    const ggml_tensor * fk = M1->src[0], * fq = M1->src[1];
+    if (fk->type != GGML_TYPE_F16 || fq->type != GGML_TYPE_F32 || M1->type != GGML_TYPE_F32 || fk->nb[0] != 2 || fq->nb[0] != 4) return false;
+    const int64_t D = fk->ne[0], nkv = fk->ne[1], HK = fk->ne[2], ns = fk->ne[3], nq = fq->ne[1], H = fq->ne[2];
+    if ((D != 64 && D != 128) || fq->ne[0] != D || nq <= 8 || HK <= 0 || H % HK != 0 || fq->ne[3] != ns || nkv <= 0) return false;
+    const int smi = sole_user(s, M1);
+    if (smi <= i || s.done[smi]) return false;
+    const ggml_tensor * SM = g->nodes[smi];
+    if (SM->op != GGML_OP_SOFT_MAX || SM->src[0] != M1 || SM->src[2] || op_param_f32(SM, 1) != 0.0f || !same_shape(SM, M1) || is_out(s, SM)) return false;
+    const ggml_tensor * mk = SM->src[1];
+    if (mk && ((mk->type != GGML_TYPE_F32 && mk->type != GGML_TYPE_F16) || mk->ne[0] != nkv || mk->ne[1] < nq || mk->ne[2] != 1 || mk->ne[3] != 1 ||
+               mk->nb[0] != (mk->type == GGML_TYPE_F32 ? 4u : 2u))) return false;
+    const int m2 = sole_user(s, SM);
+    if (m2 <= smi || s.done[m2]) return false;
+    const ggml_tensor * M2 = g->nodes[m2];
+    if (M2->op != GGML_OP_MUL_MAT || M2->src[1] != SM || M2->type != GGML_TYPE_F32 || is_out(s, M2)) return false;
+    const ggml_tensor * fv = M2->src[0];
+    if (fv->type != GGML_TYPE_F16 || fv->ne[0] != nkv || fv->ne[1] != D || fv->ne[2] != HK || fv->ne[3] != ns || fv->nb[0] != 2) return false;
+    if (M2->ne[0] != D || M2->ne[1] != nq || M2->ne[2] != H || M2->ne[3] != ns || M2->nb[0] != 4) return false;
+    // -> views -> CONT of the [D, H, nq, ns] permutation
+    auto views_back_to = [](const ggml_tensor * w, const ggml_tensor * t) { while (w && w != t) w = w->view_src; return w != nullptr; };
+    const ggml_tensor * t = M2; int ci = -1;
+    for (int hop = 0; hop < 4; ++hop) {
+        const int u = sole_user(s, t);
+        if (u < 0) return false;
+        const ggml_tensor * c = g->nodes[u];
+        if (c->op == GGML_OP_CONT) { if (!views_back_to(c->src[0], t)) return false; ci = u; break; }
+        if (!is_noop(c)) return false;
+        t = c;
+    }
+    if (ci <= m2 || s.done[ci]) return false;
+    const ggml_tensor * C = g->nodes[ci], * cs = C->src[0];
+    if (C->type != GGML_TYPE_F32 || !is_contiguous(C) || nelements(C) != D * H * nq * ns || cs->data != M2->data || cs->ne[0] != D || cs->ne[1] != H || cs->ne[2] != nq || cs->ne[3] != ns ||
+        cs->nb[0] != 4 || cs->nb[1] != M2->nb[2] || cs->nb[2] != M2->nb[1] || (ns > 1 && cs->nb[3] != M2->nb[3])) return false;
+    for (int k = i + 1; k < ci; ++k)
+        if (k != smi && k != m2 && !s.done[k] && !is_noop(g->nodes[k])) return false;       // something else runs in between: keep the separate launches
+    fattn_args f; tdesc m;
+    f.q = td(fq); f.k = td(fk); f.v = td(fv); f.v_transposed = true; f.kv_type = GGML_TYPE_F16;
+    f.dst = td(C);
+    f.dst.ne[0] = D; f.dst.ne[1] = H; f.dst.ne[2] = nq; f.dst.ne[3] = ns;
+    f.dst.nb[0] = 4; f.dst.nb[1] = (size_t) D * 4; f.dst.nb[2] = (size_t) D * H * 4; f.dst.nb[3] = (size_t) D * H * nq * 4;
+    f.mask = nullptr; f.sinks = nullptr; f.scale = op_param_f32(SM, 0); f.max_bias = 0.0f; f.logit_softcap = 0.0f;
+    f.scratch = nullptr; f.scratch_bytes = 0;
+    if (!fattn_sm_prefill_ok(f)) return false;
+    if (mk) {
+        m = td(mk);
+        const size_t map_b = attn_sm_mask16_off(nq, nkv), m16_b = mk->type == GGML_TYPE_F32 ? (size_t) mk->ne[1] * (size_t) nkv * 2 : 0;
+        if (!s.c->fa_scratch || s.c->fa_scratch_bytes < map_b + m16_b) return false;
+        const bool valid = s.fa_mask == mk->data && s.fa_dims[0] == mk->ne[0] && s.fa_dims[1] == nq && s.fa_dims[2] == mk->ne[2] && s.fa_dims[3] == mk->ne[3] && s.fa_mnb1 == mk->nb[1];
+        if (mk->type == GGML_TYPE_F32) {
+            tdesc m16 = m;
+            m16.p = (char *) s.c->fa_scratch + map_b; m16.nb[0] = 2; m16.nb[1] = (size_t) nkv * 2; m16.nb[2] = m16.nb[1] * (size_t) mk->ne[1]; m16.nb[3] = m16.nb[2];
+            if (!valid) { prof_scope ps(s, "cpy", 0); cpy_strided(m, GGML_TYPE_F32, m16, GGML_TYPE_F16, s.st); ++s.n_kernels; }
+            m = m16;
+        }
+        f.mask = &m; f.scratch = s.c->fa_scratch; f.scratch_bytes = map_b; f.map_valid = valid;
+        if (!valid) { s.fa_mask = mk->data; s.fa_dims[0] = mk->ne[0]; s.fa_dims[1] = nq; s.fa_dims[2] = mk->ne[2]; s.fa_dims[3] = mk->ne[3]; s.fa_mnb1 = mk->nb[1]; ++s.n_kernels; }
+    }
+    // the CONT's rows [D * H, nq * ns] read only by GEMMs (wo): emit them in f16 from the kernel
+    const ggml_tensor * xg16 = nullptr;
+    if (gemm_only_consumers(s, C, D * H, nq * ns, &xg16)) {
+        f.out16 = (uint16_t *) s.c->act_scratch; f.out16_rs = act_image_bytes(ACT_F16, D * H); f.write_f32 = n_users(s, C) > 1;
+    }
+    {
+        prof_scope ps(s, "fattn", 0);
+        flash_attn_ext_f16(f, s.st); ++s.n_kernels;
+    }
+    s.done[smi] = 1; s.done[m2] = 1; s.done[ci] = 1; s.n_fused += 3;
+    note_write(s, C);
+    if (xg16) { seed_act_f16(s, xg16); ++s.n_fused; }
+    return true;
+}
+
 // ------------------------------------------------------------------------------------------------ node dispatch
 static void compute_node(exec_state & s, int i) {
     ggml_cgraph * g = s.g;
@@ -1825,6 +1912,7 @@ static void compute_node(exec_state & s, int i) {
                 s.pq.fa = -1; s.pq.sm = false;
                 return;
             }
+            if (exec_attn_sm_prefill(s, i)) return;
             exec_mul_mat(s, i);
             return;
         case GGML_OP_IM2COL: {

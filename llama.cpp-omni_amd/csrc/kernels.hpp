@@ -179,7 +179,14 @@ struct fattn_args {
     const fattn_pre * pre = nullptr;   // optional q/k/v pre-stage (decode)
     uint16_t * out16 = nullptr; size_t out16_rs = 0; bool write_f32 = true;   // prefill kernel: also / only emit f16 rows [nh*D] per (seq, query)
     const float * rope_tab = nullptr;  // (cos, sin) pairs [D/2] of the token (rope_table), required by the one-token kernel (fattn_one_ok)
+    // v is V^T: tdesc of the [n_kv, D, HK, ns] tensor (cells contiguous, nb[1] = stride between d rows) -- the flash-attention-OFF graphs' MUL_MAT(v, soft_max(..))
+    // operand; only the matrix-core prefill kernel takes it (fattn_sm_prefill_ok)
+    bool v_transposed = false;
 };
+// MUL_MAT(k, q) -> SOFT_MAX_EXT -> MUL_MAT(v^T, p) -> PERMUTE -> CONT for a batch of query rows as ONE flash-attention launch (the prefill kernel with V^T staging): the
+// [n_kv, n_q, H] score / probability blocks are never written.  Same roundings as the separate nodes up to the order of the soft-max sums (q and p rounded to f16, f32 sums).
+bool   fattn_sm_prefill_ok(const fattn_args & f);
+size_t fattn_map_bytes_host(int64_t nq, int64_t nkv);           // bytes of the prefill kernel's mask tile map for one shared [n_kv, n_q] mask
 // One decode token through the reference's flash-attention-OFF attention (MUL_MAT(k, q) -> SOFT_MAX_EXT -> MUL_MAT(v^T, p) -> PERMUTE -> CONT on
 // the TRANSPOSED v cache) with the q / k / v pre-stage, as ONE launch (fattn_one.hip: k_attn_one_sm)
 struct attn_sm_args {

@@ -431,12 +431,20 @@ template <int D, int R, int NW>
 static size_t fa_lds_bytes() { return (size_t) R * D * 4 + NW * 16 * R * 4 + NW * R * (D + 2) * 4; }
 
 static bool fa_use_mma(const fattn_args & f) {
+    if (f.v_transposed) return true;                                  // (fattn_sm_prefill_ok checked the shape)
     if (!(f.q.ne[1] > 8 && !f.img && (f.q.ne[0] == 64 || f.q.ne[0] == 128) && fattn_mma_ok(f.k.ne[1]))) return false;
     fattn_args g = f; g.pre = nullptr; g.out16 = nullptr;
     return f.out16 != nullptr || !fa_gqa_plan(g).ok;              // 9 .. 32 tokens: the decode-shape kernel, unless the f16 rows of a GEMM consumer are wanted
 }
 bool fattn_uses_mma(const fattn_args & f) { return fa_use_mma(f); }
+bool fattn_sm_prefill_ok(const fattn_args & f) {
+    static const bool off = getenv("MI355X_NO_ATTN_SM_PREFILL") != nullptr;
+    const int64_t D = f.q.ne[0];
+    return !off && f.v_transposed && (D == 64 || D == 128) && f.q.ne[1] > 8 && f.kv_type == GGML_TYPE_F16 && !f.img && !f.pre && fattn_mma_ok(f.k.ne[1]) && f.max_bias == 0.0f &&
+           f.v.ne[0] == f.k.ne[1] && f.v.ne[1] == D && f.v.nb[0] == 2 && f.k.nb[0] == 2 && f.k.ne[2] > 0 && f.q.ne[2] % f.k.ne[2] == 0 && f.v.ne[2] == f.k.ne[2];
+}
 size_t fattn_map_bytes(int64_t nq, int64_t nkv, int64_t mne2, int64_t mne3);
+size_t fattn_map_bytes_host(int64_t nq, int64_t nkv) { return fattn_map_bytes(nq, nkv, 1, 1); }
 size_t fattn_scratch_bytes(const fattn_args & f) {
     if (!fa_use_mma(f)) {                                             // decode kernels: partial rows of the KV split
         fattn_args g = f; g.pre = nullptr;
@@ -512,6 +520,8 @@ void flash_attn_ext_f16(const fattn_args & f, hipStream_t st) {
     a.qnb1 = f.q.nb[1]; a.qnb2 = f.q.nb[2]; a.qnb3 = f.q.nb[3];
     a.knb1 = f.k.nb[1]; a.knb2 = f.k.nb[2]; a.knb3 = f.k.nb[3];
     a.vnb1 = f.v.nb[1]; a.vnb2 = f.v.nb[2]; a.vnb3 = f.v.nb[3];
+    a.vt = 0;
+    if (f.v_transposed) { const uintptr_t al = (uintptr_t) f.v.p | f.v.nb[1] | f.v.nb[2] | f.v.nb[3]; a.vt = al % 16 == 0 ? 16 : (al % 4 == 0 ? 4 : 2); }
     if (f.mask) { a.mnb1 = f.mask->nb[1]; a.mnb2 = f.mask->nb[2]; a.mnb3 = f.mask->nb[3]; a.mne2 = f.mask->ne[2]; a.mne3 = f.mask->ne[3]; }
     else { a.mnb1 = a.mnb2 = a.mnb3 = 0; a.mne2 = a.mne3 = 1; }
     a.dnb1 = f.dst.nb[1]; a.dnb2 = f.dst.nb[2]; a.dnb3 = f.dst.nb[3];
@@ -531,7 +541,7 @@ void flash_attn_ext_f16(const fattn_args & f, hipStream_t st) {
         a.pre = { (const char *) p.qraw, p.q_hs, (const char *) p.kraw, p.k_hs, (const char *) p.vraw, p.v_hs, p.qw, p.kw, p.pos, p.ff, p.eps, make_rope_dev(p.rp),
                   (char *) p.kcache, p.kc_rs, (char *) p.vcache, p.vc_rs, (const char *) p.kidx, (const char *) p.vidx, p.idx_is64 };
     }
-    if ((f.q.ne[0] != 64 && f.q.ne[0] != 128) || f.v.ne[0] != f.q.ne[0] || f.kv_type != GGML_TYPE_F16) {     // other head sizes / cache types: the generic kernel (no pre-stage, no images)
+    if (!f.v_transposed && ((f.q.ne[0] != 64 && f.q.ne[0] != 128) || f.v.ne[0] != f.q.ne[0] || f.kv_type != GGML_TYPE_F16)) {     // other head sizes / cache types: the generic kernel (no pre-stage, no images)
         if (f.pre || f.img || f.out16 || !fattn_any_ok(f.q.ne[0], f.v.ne[0])) { fprintf(stderr, "[mi355x] flash_attn: head size %d / %d with a fused stage\n", (int) f.q.ne[0], (int) f.v.ne[0]); abort(); }
         a.nsplit = 1; a.part = nullptr; a.tile_map = nullptr; a.map_nqb = 0;
         flash_attn_ext_any(a, (int) f.q.ne[0], (int) f.v.ne[0], f.kv_type, st);

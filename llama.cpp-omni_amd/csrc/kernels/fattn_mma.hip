@@ -188,6 +188,31 @@ __global__ void __launch_bounds__(64 * NW * KS) __attribute__((amdgpu_waves_per_
             kreg[i] = u32x4{ 0u, 0u, 0u, 0u };
             if (c < GT * (D / 8) && kv0 + row < a.nkv) kreg[i] = *(const u32x4 *) (kbase + (int64_t) (kv0 + row) * a.knb1 + col * 16);
         }
+        if (a.vt) {
+            // V given TRANSPOSED (the flash-attention-off graphs: a [n_kv, D] view of the transposed cache, or an encoder's permuted V): row d holds its kv cells
+            // contiguously -- already the layout of the V^T tile; item = 8 cells (16 bytes) of one row
+#pragma unroll
+            for (int i = 0; i < 2 * VIT; ++i) {
+                const int c = tid + i * NT;
+                const int ch = c % (GT / 8), d = c / (GT / 8);
+                u32x4 r = u32x4{ 0u, 0u, 0u, 0u };
+                if (c < D * (GT / 8)) {
+                    const int kvc = kv0 + 8 * ch;
+                    const char * src = vbase + (int64_t) d * a.vnb1 + (int64_t) kvc * 2;
+                    if (kvc + 7 < a.nkv && a.vt == 16) r = *(const u32x4 *) src;
+                    else if (kvc + 7 < a.nkv && a.vt == 4) { const uint32_t * s4 = (const uint32_t *) src; r = u32x4{ s4[0], s4[1], s4[2], s4[3] }; }
+                    else {
+                        const uint16_t * s2 = (const uint16_t *) src;
+                        uint32_t hv[8];
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) hv[e] = kvc + e < a.nkv ? (uint32_t) s2[e] : 0u;
+                        r = u32x4{ hv[0] | (hv[1] << 16), hv[2] | (hv[3] << 16), hv[4] | (hv[5] << 16), hv[6] | (hv[7] << 16) };
+                    }
+                }
+                vreg[i >> 1][i & 1] = r;
+            }
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < VIT; ++i) {
             const int c = tid + i * NT;
@@ -205,6 +230,19 @@ __global__ void __launch_bounds__(64 * NW * KS) __attribute__((amdgpu_waves_per_
             const int c = tid + i * NT;
             const int row = c / (D / 8), col = c % (D / 8);
             if (c < GT * (D / 8)) *(u32x4 *) &Ks[buf][row / FM_KT][(row % FM_KT) * KLD + col * 8] = kreg[i];
+        }
+        if (a.vt) {
+#pragma unroll
+            for (int i = 0; i < 2 * VIT; ++i) {
+                const int c = tid + i * NT;
+                const int ch = c % (GT / 8), d = c / (GT / 8);
+                if (c < D * (GT / 8)) {
+                    uint32_t * w = &Vt[buf][ch / 4][d * (VLD / 2) + (ch % 4) * 4];      // (cell pairs 4 (ch % 4) .. + 3 of tile ch / 4)
+                    const u32x4 r = vreg[i >> 1][i & 1];
+                    w[0] = r[0]; w[1] = r[1]; w[2] = r[2]; w[3] = r[3];
+                }
+            }
+            return;
         }
 #pragma unroll
         for (int i = 0; i < VIT; ++i) {
@@ -1077,7 +1115,7 @@ static void launch_fm(const fa_dev & a, hipStream_t st) {
         static const int abl = getenv("MI355X_FA_ABL") ? atoi(getenv("MI355X_FA_ABL")) : 0;
         static const bool env_no_dma = getenv("MI355X_FA_NO_DMA") != nullptr;
         const bool no_dma = g_fd_mode >= 0 ? g_fd_mode == 0 : env_no_dma;
-        if (D == 128 && !no_dma && a.nkv >= 128 && a.knb1 % 16 == 0 && a.vnb1 % 16 == 0 && a.knb2 % 16 == 0 && a.vnb2 % 16 == 0 && a.knb3 % 16 == 0 && a.vnb3 % 16 == 0 &&
+        if (D == 128 && !no_dma && !a.vt && a.nkv >= 128 && a.knb1 % 16 == 0 && a.vnb1 % 16 == 0 && a.knb2 % 16 == 0 && a.vnb2 % 16 == 0 && a.knb3 % 16 == 0 && a.vnb3 % 16 == 0 &&
             (((uintptr_t) a.k | (uintptr_t) a.v) & 15) == 0) {
             static bool attr[64] = {};
             int dev = 0; HIP_CHECK(hipGetDevice(&dev));

@@ -276,3 +276,76 @@ def test_flash_attn_prefill_dma_ring(pkg, be, nq, nh, nhkv, nkv, ns, kind):
     assert np.isfinite(outs[0]).all()
     assert nmse(outs[0], want) < 2e-6, nmse(outs[0], want)           # (bar 5e-4; P is rounded to f16: ~1e-7)
     assert nmse(outs[0], outs[1]) < 2e-6
+
+
+# ---- flash-attention OFF, batches of query rows: MUL_MAT(k, q) -> SOFT_MAX_EXT -> MUL_MAT(v^T, p) -> PERMUTE -> CONT runs as ONE flash-attention launch that reads V^T as it
+# lies (graph.cpp exec_attn_sm_prefill, fattn_mma.hip V^T staging).  Against the REFERENCE CPU backend running the same five nodes (ops.cpp:5072-5182 between two
+# ggml_compute_forward_mul_mat): q and p rounded to f16 on both sides, f32 sums -- bar 2e-6 NMSE (the reference's own MUL_MAT / SOFT_MAX bars are 5e-4 / 1e-6).
+@pytest.mark.parametrize("D,nq,H,HK,nkv,n_ctx,mask,kind", [
+    (128, 77, 8, 2, 256, 512, "f32", "llama"),        # the llama -fa 0 graph: K rows and V^T rows are views of caches with room for n_ctx cells, f32 causal mask padded to 96 rows
+    (128, 512, 32, 8, 512, 512, "f32", "llama"),      # pp512 at the 8B head counts
+    (64, 150, 4, 4, 150, 150, None, "whisper"),       # encoder: no mask, K a strided permutation, V^T rows of 300 bytes (4-byte aligned only)
+    (64, 151, 4, 4, 151, 151, None, "whisper"),       # ... 302 bytes (2-byte aligned only), ragged last tile
+    (128, 40, 4, 1, 1000, 1024, "f16", "llama")])     # an f16 mask, 4 query heads per KV head
+def test_soft_max_attention_of_a_batch_is_one_launch_vs_reference_backend(pkg, be, ref_be, D, nq, H, HK, nkv, n_ctx, mask, kind):
+    import numpy as np
+    from conftest import nmse
+    F32, F16 = pkg.GGML_TYPE_F32, pkg.GGML_TYPE_F16
+    rng = np.random.default_rng(D + nq + nkv)
+    nq_pad = (nq + 31) // 32 * 32
+
+    def build(c):
+        ins = {}
+        if kind == "llama":
+            qc = c.new_tensor(F32, D, H, nq)                                   # [D, H, nq] as the rope leaves it -> permuted view [D, nq, H]
+            kc = c.new_tensor(F16, D * HK, n_ctx)                              # K cache rows [HK * D] per cell
+            vc = c.new_tensor(F16, n_ctx, D * HK)                              # transposed V cache: a row per (kv head, d)
+            ins.update(q=qc, k=kc, v=vc)
+            q = c.permute(qc, 0, 2, 1, 3)
+            k = c.view_3d(kc, D, nkv, HK, D * HK * 2, D * 2, 0)
+            v = c.view_3d(vc, nkv, D, HK, n_ctx * 2, n_ctx * 2 * D, 0)
+        else:
+            qc = c.new_tensor(F32, D, H, nq); kc = c.new_tensor(F32, D, H, nkv); vc = c.new_tensor(F32, D, H, nkv)
+            ins.update(q=qc, k=kc, v=vc)
+            q = c.permute(qc, 0, 2, 1, 3)
+            k = c.permute(c.cast(kc, F16), 0, 2, 1, 3)
+            v = c.cast(c.permute(vc, 1, 2, 0, 3), F16)
+        m = None
+        if mask:
+            m = c.new_tensor(F16 if mask == "f16" else F32, nkv, nq_pad); ins["m"] = m
+        kq = c.mul_mat(k, q)
+        p = c.soft_max_ext(kq, m, 1.0 / np.sqrt(D), 0.0)
+        kqv = c.mul_mat(v, p)
+        out = c.cont(c.permute(kqv, 0, 2, 1, 3), D * H, nq)
+        return ins, [out]
+
+    feeds = {}
+    if kind == "llama":
+        feeds["q"] = rng.standard_normal(D * H * nq).astype(np.float32)
+        feeds["k"] = rng.standard_normal(D * HK * n_ctx).astype(np.float16)
+        feeds["v"] = rng.standard_normal(n_ctx * D * HK).astype(np.float16)
+    else:
+        feeds["q"] = rng.standard_normal(D * H * nq).astype(np.float32)
+        feeds["k"] = rng.standard_normal(D * H * nkv).astype(np.float32)
+        feeds["v"] = rng.standard_normal(D * H * nkv).astype(np.float32)
+    if mask:
+        mv = np.zeros((nq_pad, nkv), np.float32)
+        for i in range(nq_pad):
+            mv[i, max(1, min(nkv, nkv - nq + min(i, nq - 1) + 1)):] = -np.inf
+        feeds["m"] = mv.astype(np.float16 if mask == "f16" else np.float32).ravel()
+    res = []
+    for backend in (be, ref_be):
+        c = pkg.Context(backend)
+        ins, outs = build(c)
+        c.alloc()
+        for name, t in ins.items():
+            backend.tensor_set(t, feeds[name])
+        backend.graph_compute(c.graph())
+        if backend is be:
+            launches = be.get_stat("kernels_last_graph")
+        res.append(backend.tensor_get(outs[0]).copy())
+        c.free()
+    got, want = res
+    assert np.isfinite(got).all()
+    assert nmse(got, want) < 2e-6, nmse(got, want)
+    assert launches <= (5 if kind == "whisper" else 3), launches       # the attention itself is one launch (+ mask cast / tile map, or the encoder's two casts and their copies)
