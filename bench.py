@@ -199,10 +199,11 @@ def cpu_baseline(pkg, cfg, types, n_kv, seconds_budget=24.0, tiny=False):
             d = json.loads(r.stdout.strip().splitlines()[-1])
             build, wbytes = d["build"], d["wbytes"]
             results.append((d["tok_s"], th, d["steps"]))
-            # ascending sweep, stopped past the knee (an oversubscribed team of spinning workers can be 100x slower) or when the budget is used up
-            if len(results) >= 2 and results[-1][0] < 0.8 * max(results[:-1])[0]:
+            # ascending sweep through 32 / 48 / 64 threads too (the reference's per-node barrier makes them slower than 16 on this box: the line carries the numbers),
+            # stopped only on a collapse (an oversubscribed team of spinning workers can be 100x slower) or when the budget is used up
+            if len(results) >= 2 and results[-1][0] < 0.4 * max(results[:-1])[0]:
                 break
-            if time.perf_counter() - t_start > 3 * seconds_budget:
+            if time.perf_counter() - t_start > 4 * seconds_budget:
                 break
         best = max(results)
         v3 = None

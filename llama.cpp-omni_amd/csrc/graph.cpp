@@ -349,7 +349,7 @@ static size_t graph_fa_scratch_need(const ggml_cgraph * g) {
             if (b > need) need = b;
             continue;
         }
-        if (n->op == GGML_OP_SOFT_MAX && !is_empty(n) && n->ne[1] > 8 && n->src[1] && n->src[1]->ne[2] == 1 && n->src[1]->ne[3] == 1) {      // flash-attention off, a batch of rows: mask tile map + f16 copy of an f32 mask (exec_attn_sm_prefill)
+        if (n->op == GGML_OP_SOFT_MAX && !is_empty(n) && n->ne[1] > 32 && n->src[1] && n->src[1]->ne[2] == 1 && n->src[1]->ne[3] == 1) {      // flash-attention off, a batch of rows: mask tile map + f16 copy of an f32 mask (exec_attn_sm_prefill)
             const size_t b = ((fattn_map_bytes_host(n->ne[1], n->ne[0]) + 255) & ~(size_t) 255) + (size_t) n->src[1]->ne[1] * (size_t) n->ne[0] * 2;
             if (b > need) need = b;
             continue;
@@ -877,6 +877,7 @@ static bool gemm_groupable(const ggml_tensor * c) {
 }
 static bool gemm_only_consumers(exec_state & s, const ggml_tensor * t, int64_t K, int64_t N, const ggml_tensor ** x_out);
 static void seed_act_f16(exec_state & s, const ggml_tensor * x);
+static bool exec_attn_sm_prefill(exec_state & s, int i, bool dry);
 static bool exec_gemm_group(exec_state & s, int i) {
     ggml_cgraph * g = s.g;
     ggml_tensor * n = g->nodes[i];
@@ -1673,7 +1674,8 @@ static bool exec_rms_norm(exec_state & s, int i) {
                 if (bj >= 0) a.j[a.njobs++] = chain_job(s, B);
                 if (vj >= 0) a.j[a.njobs++] = vjob;
                 // flash-attention off, prefill: rope(q) is read (through views) by exactly one per-head MUL_MAT on the MFMA GEMM (K . q): write
-                // its f16 activation image here instead of the f32 rows + a conversion launch
+                // its f16 activation image here instead of the f32 rows + a conversion launch (not when that MUL_MAT starts a soft-max attention chain that runs as
+                // one flash-attention launch: that kernel reads the f32 rows and rounds them itself)
                 const ggml_tensor * q16 = nullptr;
                 if (A.store < 0 && A.T > MI_MMVQ_MAX_COLS && !getenv("MI355X_NO_F16_EMIT")) {
                     const ggml_tensor * rq = g->nodes[A.rope];
@@ -1682,7 +1684,7 @@ static bool exec_rms_norm(exec_state & s, int i) {
                     const ggml_tensor * t = c && c->op == GGML_OP_MUL_MAT ? c->src[1] : nullptr;
                     const ggml_tensor * base = t;
                     while (base && base != rq && (base->op == GGML_OP_RESHAPE || base->op == GGML_OP_VIEW || base->op == GGML_OP_PERMUTE || base->op == GGML_OP_TRANSPOSE)) base = base->src[0];
-                    if (t && base == rq && c->src[0] != t && mm_uses_gemm(c) && t->data == rq->data && t->type == GGML_TYPE_F32 && !is_out(s, t) &&
+                    if (t && base == rq && c->src[0] != t && mm_uses_gemm(c) && !exec_attn_sm_prefill(s, u, true) && t->data == rq->data && t->type == GGML_TYPE_F32 && !is_out(s, t) &&
                         t->ne[0] == A.D && t->ne[1] == A.T && t->ne[2] == A.H && t->ne[3] == 1 && t->nb[0] == 4 && t->nb[1] == (size_t) rq->nb[2] &&
                         t->nb[2] == (size_t) rq->nb[1] && act_image_bytes(ACT_F16, A.D) * (size_t) (A.T * A.H) <= s.c->act_scratch_bytes) q16 = t;
                 }
@@ -1807,7 +1809,7 @@ static bool exec_rms_norm(exec_state & s, int i) {
 // the [n_kv, n_q, H] blocks -- 146 MB written and read back per Whisper layer -- are never materialised).  An f32 mask is cast to f16 once per graph run (what the
 // reference's own flash-attention graphs do, llama-graph.cpp build_attn_inp_kv: ggml_cast(kq_mask, F16); 0 and -inf are exact) behind the mask tile map in the attention scratch.
 static size_t attn_sm_mask16_off(int64_t nq, int64_t nkv) { return (fattn_map_bytes_host(nq, nkv) + 255) & ~(size_t) 255; }
-static bool exec_attn_sm_prefill(exec_state & s, int i) {
+static bool exec_attn_sm_prefill(exec_state & s, int i, bool dry) {       // dry: would this MUL_MAT be taken?  (no launches, no state)
     static const bool off = getenv("MI355X_NO_ATTN_SM_PREFILL") != nullptr;
     ggml_cgraph * g = s.g;
     const ggml_tensor * M1 = g->nodes[i];
@@ -1815,7 +1817,7 @@ static bool exec_attn_sm_prefill(exec_state & s, int i) {
     const ggml_tensor * fk = M1->src[0], * fq = M1->src[1];
     if (fk->type != GGML_TYPE_F16 || fq->type != GGML_TYPE_F32 || M1->type != GGML_TYPE_F32 || fk->nb[0] != 2 || fq->nb[0] != 4) return false;
     const int64_t D = fk->ne[0], nkv = fk->ne[1], HK = fk->ne[2], ns = fk->ne[3], nq = fq->ne[1], H = fq->ne[2];
-    if ((D != 64 && D != 128) || fq->ne[0] != D || nq <= 8 || HK <= 0 || H % HK != 0 || fq->ne[3] != ns || nkv <= 0) return false;
+    if ((D != 64 && D != 128) || fq->ne[0] != D || nq <= 32 || HK <= 0 || H % HK != 0 || fq->ne[3] != ns || nkv <= 0) return false;
     const int smi = sole_user(s, M1);
     if (smi <= i || s.done[smi]) return false;
     const ggml_tensor * SM = g->nodes[smi];
@@ -1855,6 +1857,11 @@ static bool exec_attn_sm_prefill(exec_state & s, int i) {
     f.mask = nullptr; f.sinks = nullptr; f.scale = op_param_f32(SM, 0); f.max_bias = 0.0f; f.logit_softcap = 0.0f;
     f.scratch = nullptr; f.scratch_bytes = 0;
     if (!fattn_sm_prefill_ok(f)) return false;
+    if (mk) {
+        const size_t map_b0 = attn_sm_mask16_off(nq, nkv), m16_b0 = mk->type == GGML_TYPE_F32 ? (size_t) mk->ne[1] * (size_t) nkv * 2 : 0;
+        if (!s.c->fa_scratch || s.c->fa_scratch_bytes < map_b0 + m16_b0) return false;
+    }
+    if (dry) return true;
     if (mk) {
         m = td(mk);
         const size_t map_b = attn_sm_mask16_off(nq, nkv), m16_b = mk->type == GGML_TYPE_F32 ? (size_t) mk->ne[1] * (size_t) nkv * 2 : 0;
@@ -1912,7 +1919,7 @@ static void compute_node(exec_state & s, int i) {
                 s.pq.fa = -1; s.pq.sm = false;
                 return;
             }
-            if (exec_attn_sm_prefill(s, i)) return;
+            if (exec_attn_sm_prefill(s, i, false)) return;
             exec_mul_mat(s, i);
             return;
         case GGML_OP_IM2COL: {
