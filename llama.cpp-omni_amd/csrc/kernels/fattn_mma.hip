@@ -597,9 +597,9 @@ __global__ void __launch_bounds__(256 * HW) __attribute__((amdgpu_waves_per_eu(2
     auto soft_max = [&](const int cls, const u32x2 (&mw)[4], f16a & sc, pfrag (&pf)[2]) {
         float tmax = -INFINITY, Mn, Mu, alpha, psum = 0.0f;
         const bool plain = cls == 1 && a.logit_softcap == 0.0f && slope == 1.0f && c2pos;
-        if (plain) {                                                  // p = exp2(s * c2 - M): the scale rides in the exponent's FMA
+        if (plain) {                                                  // p = exp2(s * c2 - M): the scale rides in the exponent's FMA; three-input maxima
 #pragma unroll
-            for (int e = 0; e < 16; ++e) tmax = fmaxf(tmax, sc[e]);
+            for (int e = 0; e < 16; e += 2) asm("v_max3_f32 %0, %1, %2, %3" : "=v"(tmax) : "v"(tmax), "v"(sc[e]), "v"(sc[e + 1]));
             tmax *= c2;
         } else {
 #pragma unroll
@@ -616,15 +616,18 @@ __global__ void __launch_bounds__(256 * HW) __attribute__((amdgpu_waves_per_eu(2
         tmax = fd_max_halves(tmax);
         if (__any(tmax > M + FD_THR)) { Mn = fmaxf(M, tmax); Mu = Mn == -INFINITY ? 0.0f : Mn; alpha = __builtin_amdgcn_exp2f(M - Mu); }
         else                          { Mn = M; Mu = M == -INFINITY ? 0.0f : M; alpha = 1.0f; }
-        if (plain) {
-            const float nMu = -Mu;
+        if (plain) {                                                  // pairs: v_pk_fma_f32 for the exponents' arguments, v_pk_add_f32 for the row sums
+            const f32x2 c2v = { c2, c2 }, nMu = { -Mu, -Mu };
+            f32x2 ps2 = { 0.0f, 0.0f };
 #pragma unroll
             for (int e = 0; e < 16; e += 2) {
-                const float p0 = __builtin_amdgcn_exp2f(fmaf(sc[e], c2, nMu)), p1 = __builtin_amdgcn_exp2f(fmaf(sc[e + 1], c2, nMu));
-                psum += p0 + p1;
-                const f32x2 pp = { p0, p1 };
+                const f32x2 x = { sc[e], sc[e + 1] };
+                const f32x2 y = __builtin_elementwise_fma(x, c2v, nMu);
+                const f32x2 pp = { __builtin_amdgcn_exp2f(y[0]), __builtin_amdgcn_exp2f(y[1]) };
+                ps2 += pp;
                 pf[e >> 3].h2[(e & 7) >> 1] = __builtin_convertvector(pp, h2v);
             }
+            psum = ps2[0] + ps2[1];
         } else {
 #pragma unroll
             for (int e = 0; e < 16; e += 2) {
@@ -1103,6 +1106,8 @@ static long g_fd_launches = 0;
 void fattn_set_dma(int m) { g_fd_mode = m; }
 long fattn_dma_launches() { return g_fd_launches; }
 
+static int64_t fa_dma_min_wgs() { static const int64_t v = getenv("MI355X_FA_BIG_MIN_WGS") ? atoll(getenv("MI355X_FA_BIG_MIN_WGS")) : 512; return v; }
+
 template <int D>
 static void launch_fm(const fa_dev & a, hipStream_t st) {
     const int nqt4 = (a.nq + 127) / 128;
@@ -1111,7 +1116,7 @@ static void launch_fm(const fa_dev & a, hipStream_t st) {
     const int64_t blocks32 = (int64_t) ((a.nq + 31) / 32) * a.nh * a.ns;          // one wave each without a KV split
     if (a.nq <= 32) {
         k_fattn_mma<D, 1, 1, 1><<<dim3((unsigned) (a.nh * a.ns)), dim3(64), 0, st>>>(a, 1);
-    } else if ((int64_t) nqt4 * a.nh * a.ns >= 512) {
+    } else if ((int64_t) nqt4 * a.nh * a.ns >= fa_dma_min_wgs()) {
         static const int abl = getenv("MI355X_FA_ABL") ? atoi(getenv("MI355X_FA_ABL")) : 0;
         static const bool env_no_dma = getenv("MI355X_FA_NO_DMA") != nullptr;
         const bool no_dma = g_fd_mode >= 0 ? g_fd_mode == 0 : env_no_dma;
@@ -1126,7 +1131,7 @@ static void launch_fm(const fa_dev & a, hipStream_t st) {
                 if (dev >= 0 && dev < 64) attr[dev] = true;
             }
             static const int hw_env = getenv("MI355X_FA_HW") ? atoi(getenv("MI355X_FA_HW")) : 2;
-            const int hw = (hw_env >= 2 && a.gq % 2 == 0 && a.mne2 <= 1 && (int64_t) nqt4 * (a.nh / 2) * a.ns >= 256) ? 2 : 1;      // pairs of heads of one KV head, one mask for every head
+            const int hw = (hw_env >= 2 && a.gq % 2 == 0 && a.mne2 <= 1 && (int64_t) nqt4 * (a.nh / 2) * a.ns >= 256) ? 2 : 1;      // (fewer workgroups than CUs otherwise)      // pairs of heads of one KV head, one mask for every head
             const dim3 grid((unsigned) (nqt4 * (a.nh / hw) * a.ns));
             bool done = false;
 #define FD_GO(A, H) if (!done && abl == A && hw == H) { k_fattn_dma128<A, H><<<grid, dim3(256 * H), FD_LDS, st>>>(a, nqt4); done = true; }

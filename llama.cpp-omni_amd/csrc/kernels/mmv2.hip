@@ -8,7 +8,7 @@
 // quantize_row_q8_K_ref ggml-quants.c:2555-2592; ggml_vec_dot_q4_K_q8_K / _q6_K_q8_K ggml-cpu/quants.c:550-623 / 705-758; RMS norm
 // ggml-cpu/ops.cpp:3517-3566), the integer sub-block sums exact, one f32 partial sum per lane folded on the DPP network.
 //
-// Why this shape (tools/mmv2_lab.hip and tools/mmv2_sym_lab.hip, per-wave s_memrealtime stamps; profiles/r03_microbench.txt):
+// Why this shape (tools/mmv2_lab.hip -- and a symmetric every-wave-loads-and-consumes variant, removed in round 4: 12.0 vs 11.1 us --, per-wave s_memrealtime stamps; profiles/r03_microbench.txt):
 //   * mmv1's 4-lanes-per-block register loads touch every 128-B line of a step with three wave instructions; dense 1 KiB instructions stream
 //     a 350 MB Q4_K matrix at 6.4 TB/s against 5.0 TB/s (non-temporal policy, aux nt: +12 %).
 //   * a wave's VMEM instructions ISSUE only as fast as its CU's memory queue drains (~25 KB deep): a symmetric kernel whose waves put their ring
