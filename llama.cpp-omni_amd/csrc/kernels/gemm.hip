@@ -755,10 +755,17 @@ __global__ void __launch_bounds__(256) k_gemm_reduce_multi(const float * __restr
     if (q >= g.nmat) return;
     const int M = g.M[q], n = (int) (i / M), m = (int) (i % M);
     const float * p = part + g.off[q] + i;
-    f32x4 v = *(const f32x4 *) p;
-    for (int s = 1; s < g.nsplit; ++s) { const f32x4 w = *(const f32x4 *) (p + s * g.split_elems); v += w; }
-    if (g.resid[q])  { const f32x4 w = *(const f32x4 *) (g.resid[q]  + (size_t) n * g.resid_cs[q]  + (size_t) m * 4); v += w; }
-    if (g.resid2[q]) { const f32x4 w = *(const f32x4 *) (g.resid2[q] + (size_t) n * g.resid2_cs[q] + (size_t) m * 4); v += w; }
+    f32x4 sl[8];                                                   // (all requests first, additions in slab order: see k_gemm_reduce_rms_norm)
+#pragma unroll
+    for (int s = 0; s < 8; ++s) sl[s] = s < g.nsplit ? *(const f32x4 *) (p + s * g.split_elems) : f32x4{0, 0, 0, 0};
+    f32x4 r1 = f32x4{0, 0, 0, 0}, r2 = f32x4{0, 0, 0, 0};
+    if (g.resid[q])  r1 = *(const f32x4 *) (g.resid[q]  + (size_t) n * g.resid_cs[q]  + (size_t) m * 4);
+    if (g.resid2[q]) r2 = *(const f32x4 *) (g.resid2[q] + (size_t) n * g.resid2_cs[q] + (size_t) m * 4);
+    f32x4 v = sl[0];
+#pragma unroll
+    for (int s = 1; s < 8; ++s) if (s < g.nsplit) v += sl[s];
+    if (g.resid[q])  v += r1;
+    if (g.resid2[q]) v += r2;
     *(f32x4 *) (g.dst[q] + (size_t) n * g.dst_cs[q] + (size_t) m * 4) = v;
 }
 // dst[n][m] += r[n][m] (rows of M % 4 == 0 floats): the second addend of a launch that did not split K
@@ -790,9 +797,17 @@ __global__ void __launch_bounds__(256) k_gemm_reduce_rms_norm(const float * __re
         const int i = (threadIdx.x + k * 256) * 4;
         v[k] = f32x4{0, 0, 0, 0};
         if (i < M) {
-            f32x4 a = *(const f32x4 *) (part + (size_t) n * M + i);
-            for (int s = 1; s < nsplit; ++s) { const f32x4 b = *(const f32x4 *) (part + s * split_elems + (size_t) n * M + i); a += b; }
-            if (resid) { const f32x4 b = *(const f32x4 *) (resid + (size_t) n * resid_cs + (size_t) i * 4); a += b; }
+            // every slab's piece and the residual's requested before the first addition (a run-time loop of load -> add serialises the round trips: 14.3 us for 52 MB);
+            // the additions keep their order: slab 0 + slab 1 + ... + residual
+            f32x4 sl[8];
+#pragma unroll
+            for (int s = 0; s < 8; ++s) sl[s] = s < nsplit ? *(const f32x4 *) (part + s * split_elems + (size_t) n * M + i) : f32x4{0, 0, 0, 0};
+            f32x4 rr = f32x4{0, 0, 0, 0};
+            if (resid) rr = *(const f32x4 *) (resid + (size_t) n * resid_cs + (size_t) i * 4);
+            f32x4 a = sl[0];
+#pragma unroll
+            for (int s = 1; s < 8; ++s) if (s < nsplit) a += sl[s];
+            if (resid) a += rr;
             *(f32x4 *) (dst + (size_t) n * dst_cs + (size_t) i * 4) = a;
             v[k] = a;
 #pragma unroll
