@@ -66,9 +66,31 @@ static void set_device(int d) { HIP_CHECK(hipSetDevice(d)); }
 // ---------------------------------------------------------------------------------------------- device buffers
 struct buffer_ctx { int device; void * base; size_t size; };
 
+// ---- staged small uploads (be_set_async below) and the buffer-level entry points: a staged write sits in host memory until the owning backend's next entry point flushes it.
+// The blocking buffer-level paths (set / get / memset / cpy / clear) and a buffer's release know nothing about backends, so they settle what is staged for the bytes
+// they touch first: every live backend context of the device with a staged entry inside [lo, hi) is flushed and its stream drained.  (Before this, a compute buffer freed
+// ahead of its backend was written by the flush in be_free, after the free; a blocking tensor_set issued behind a staged async one to the same bytes was overwritten by
+// the older data at the next flush.)
+void flush_uploads(backend_ctx * c);
+static std::recursive_mutex g_live_mu;                 // (stage_upload re-enters itself after a flush)
+static std::vector<backend_ctx *> g_live;
+static void settle_staged(int device, const void * lo_, size_t n) {
+    const char * lo = (const char *) lo_, * hi = lo + n;
+    std::lock_guard<std::recursive_mutex> lk(g_live_mu);
+    for (backend_ctx * c : g_live) {
+        if (c->device != device || c->up_n == 0) continue;
+        bool hit = false;
+        for (int i = 0; i < c->up_n && !hit; ++i) {
+            const backend_ctx::up_ent & e = c->up_ents[c->up_half][i];
+            hit = (const char *) e.dst < hi && lo < (const char *) e.dst + e.size;
+        }
+        if (hit) { flush_uploads(c); HIP_CHECK(hipStreamSynchronize(c->stream)); }
+    }
+}
 static void buf_free(ggml_backend_buffer_t b) {
     buffer_ctx * c = (buffer_ctx *) b->context;
     set_device(c->device);
+    settle_staged(c->device, c->base, c->size);
     shadow_invalidate(c->device, c->base, c->size);
     HIP_CHECK(hipFree(c->base));
     delete c;
@@ -82,6 +104,7 @@ static enum ggml_status buf_init_tensor(ggml_backend_buffer_t, struct ggml_tenso
 }
 static void buf_memset_tensor(ggml_backend_buffer_t b, struct ggml_tensor * t, uint8_t v, size_t off, size_t sz) {
     buffer_ctx * c = (buffer_ctx *) b->context; set_device(c->device);
+    settle_staged(c->device, (char *) t->data + off, sz);
     shadow_invalidate(c->device, (char *) t->data + off, sz);
     HIP_CHECK(hipMemsetAsync((char *) t->data + off, v, sz, hipStreamPerThread));
     HIP_CHECK(hipStreamSynchronize(hipStreamPerThread));
@@ -96,6 +119,7 @@ struct buf_timer {
 static void buf_set_tensor(ggml_backend_buffer_t b, struct ggml_tensor * t, const void * data, size_t off, size_t sz) {
     buf_timer bt(g_buf_set_ns, g_buf_set_bytes, g_buf_set_n, sz);
     buffer_ctx * c = (buffer_ctx *) b->context; set_device(c->device);
+    settle_staged(c->device, (char *) t->data + off, sz);
     shadow_invalidate(c->device, (char *) t->data + off, sz);
     HIP_CHECK(hipMemcpyAsync((char *) t->data + off, data, sz, hipMemcpyHostToDevice, hipStreamPerThread));
     HIP_CHECK(hipStreamSynchronize(hipStreamPerThread));
@@ -103,6 +127,7 @@ static void buf_set_tensor(ggml_backend_buffer_t b, struct ggml_tensor * t, cons
 static void buf_get_tensor(ggml_backend_buffer_t b, const struct ggml_tensor * t, void * data, size_t off, size_t sz) {
     buf_timer bt(g_buf_get_ns, g_buf_get_bytes, g_buf_get_n, sz);
     buffer_ctx * c = (buffer_ctx *) b->context; set_device(c->device);
+    settle_staged(c->device, (const char *) t->data + off, sz);
     HIP_CHECK(hipMemcpyAsync(data, (const char *) t->data + off, sz, hipMemcpyDeviceToHost, hipStreamPerThread));
     HIP_CHECK(hipStreamSynchronize(hipStreamPerThread));
 }
@@ -113,6 +138,7 @@ static bool buf_cpy_tensor(ggml_backend_buffer_t b, const struct ggml_tensor * s
     buffer_ctx * sc = (buffer_ctx *) sb->context; buffer_ctx * dc = (buffer_ctx *) b->context;
     set_device(dc->device);
     const size_t n = nbytes(src);
+    settle_staged(sc->device, src->data, n); settle_staged(dc->device, dst->data, n);
     shadow_invalidate(dc->device, dst->data, n);
     if (sc->device == dc->device) HIP_CHECK(hipMemcpyAsync(dst->data, src->data, n, hipMemcpyDeviceToDevice, hipStreamPerThread));
     else                          HIP_CHECK(hipMemcpyPeerAsync(dst->data, dc->device, src->data, sc->device, n, hipStreamPerThread));
@@ -121,6 +147,7 @@ static bool buf_cpy_tensor(ggml_backend_buffer_t b, const struct ggml_tensor * s
 }
 static void buf_clear(ggml_backend_buffer_t b, uint8_t v) {
     buffer_ctx * c = (buffer_ctx *) b->context; set_device(c->device);
+    settle_staged(c->device, c->base, c->size);
     shadow_invalidate(c->device, c->base, c->size);
     HIP_CHECK(hipMemsetAsync(c->base, v, c->size, hipStreamPerThread));
     HIP_CHECK(hipStreamSynchronize(hipStreamPerThread));
@@ -200,6 +227,7 @@ static void be_free(ggml_backend_t b) {
     if (getenv("MI355X_LOG_STATS"))
         for (auto & kv : c->prof)                                         // per-class event timing (only filled in "profile" mode)
             log_msg(GGML_LOG_LEVEL_INFO, "[mi355x]   %-22s n=%8ld  total %10.1f us  avg %8.2f us\n", kv.first.c_str(), kv.second.n, kv.second.us, kv.second.n ? kv.second.us / kv.second.n : 0.0);
+    { std::lock_guard<std::recursive_mutex> lk(g_live_mu); g_live.erase(std::remove(g_live.begin(), g_live.end(), c), g_live.end()); }
     backend_ctx_release(c);
     delete c;
     delete b;
@@ -222,6 +250,7 @@ void flush_uploads(backend_ctx * c) {                     // everything staged s
 }
 static bool stage_upload(backend_ctx * c, void * dst, const void * data, size_t sz) {
     if (!c->opt_batch_uploads || sz == 0 || sz > UP_SMALL) return false;
+    std::lock_guard<std::recursive_mutex> lk(g_live_mu);                      // (settle_staged walks the entries from whatever thread frees / sets a buffer)
     if (!c->up_host[0]) {
         for (int h = 0; h < 2; ++h) {
             if (hipHostMalloc((void **) &c->up_host[h], UP_HALF, hipHostMallocDefault) != hipSuccess || hipHostMalloc((void **) &c->up_ents[h], sizeof(backend_ctx::up_ent) * UP_MAX, hipHostMallocDefault) != hipSuccess) {
@@ -333,6 +362,7 @@ static ggml_backend_t dev_init_backend(ggml_backend_dev_t d, const char *) {
     c->name   = dc->name;
     HIP_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     backend_ctx_init(c);
+    { std::lock_guard<std::recursive_mutex> lk(g_live_mu); g_live.push_back(c); }
     return new ggml_backend{ &g_guid, k_backend_iface, d, c };
 }
 static ggml_backend_buffer_type_t dev_buft(ggml_backend_dev_t d) { return &((device_ctx *) d->context)->buft; }

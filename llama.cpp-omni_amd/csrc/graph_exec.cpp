@@ -1902,8 +1902,9 @@ static int exec_ew_chain(exec_state & s, int i, int * taken) {
         d.kind = (int) nd->op; d.sub = nd->op == GGML_OP_UNARY ? op_param_i32(nd, 0) : 0; d.a = sel[0]; d.b = binary ? sel[1] : sel[0];
         d.p0 = op_param_f32(nd, 0); d.p1 = op_param_f32(nd, 1);
         res[n] = nd; idx[n] = j; ++n;
-        // may the chain go on?  the result must have exactly one reader, the next launching node
-        if (is_out(s, nd)) break;
+        // may the chain go on?  the result must have exactly one reader, the next launching node -- and it must not be an in-place / view result: an intermediate of the
+        // chain is never written, and a view's memory (ggml_add_inplace on a tensor somebody reads later, persistent state) has to change as the eager run changes it
+        if (is_out(s, nd) || nd->view_src) break;
         const int u = sole_user(s, nd);
         const int nx = next_real_node(s, j);
         if (u < 0 || u != nx) break;

@@ -1031,6 +1031,13 @@ void gemm_f16_multi(const gemm_multi_args & a, hipStream_t st) {
         ksplit = pick_ksplit((int64_t) tm * tiles_n, nk, a.N);
         while (ksplit > 1 && (size_t) ksplit * (size_t) m_sum * (size_t) a.N * 4 > a.partial_bytes) --ksplit;
     }
+    // a second addend rides in the REDUCTION's epilogue only (it reads both addends before it writes; ggml-alloc usually gives the second ADD's result the memory of
+    // its residual operand, which the tile epilogue of an un-split launch would overwrite before k_gemm_add_rows reads it): when the split the caller counted on did
+    // not happen (a tuning override of the tile height), split in two anyway
+    bool has_r2 = false, r2_alias = false;
+    for (int i = 0; i < a.nmat; ++i) { has_r2 = has_r2 || a.m[i].resid2; r2_alias = r2_alias || (a.m[i].resid2 && (const void *) a.m[i].resid2 == (const void *) a.m[i].dst); }
+    if (has_r2 && ksplit == 1 && BM == G_BM && nbatch == 1 && a.partial && m4 && nk >= 2 && (size_t) 2 * (size_t) m_sum * (size_t) a.N * 4 <= a.partial_bytes) ksplit = 2;
+    if (r2_alias && ksplit == 1) { fprintf(stderr, "[mi355x] gemm: a second addend in the result's own memory needs the split-K reduction (no scratch for it)\n"); abort(); }
     g.ksteps_per_split = (nk + ksplit - 1) / ksplit; g.split_stride = 0;
     if (tm == 0) return;
     if (ksplit > 1) {

@@ -385,3 +385,35 @@ def test_8b_width_f16_prefill_512_logits_within_1e3(pkg, be, ref_be, flash_attn)
     assert stats[1] < 1e-4, stats
     assert stats[2] < 2e-3, stats
     assert (got.argmax(1) == want.argmax(1)).mean() > 0.99                     # (near-ties among 4096 random logits may flip)
+
+
+# ---- small asynchronous uploads sit in host staging until the backend's next entry point; the buffer-level paths settle them first now
+def test_staged_async_upload_is_ordered_with_buffer_level_writes_and_survives_a_free(pkg, be):
+    import numpy as np
+    F32 = pkg.GGML_TYPE_F32
+    c = pkg.Context(be)
+    x = c.new_tensor(F32, 1024)
+    y = c.scale(x, 2.0)
+    c.alloc()
+    a = np.full(1024, 1.0, np.float32); b = np.full(1024, 3.0, np.float32)
+    be.tensor_set(x, np.zeros(1024, np.float32))
+    be.tensor_set_async(x, a)                        # staged (4 KB)
+    be.tensor_set(x, b)                              # blocking, buffer level, same bytes, LATER: must win
+    be.graph_compute(c.graph())                      # (a backend entry point: would flush anything still staged)
+    assert np.array_equal(be.tensor_get(y), 2.0 * b)
+    # partial overlap: the staged write covers the first half only
+    be.tensor_set_async(x, a[:512])
+    be.tensor_set(x, b[:256], offset=1024)           # bytes 1024 .. 2047 = elements 256 .. 511
+    be.graph_compute(c.graph())
+    want = b.copy(); want[:256] = 1.0
+    assert np.array_equal(be.tensor_get(y), 2.0 * want)
+    # a buffer released with a write still staged for it: the write is settled (or dropped) before the free, later work is unaffected
+    be.tensor_set_async(x, a)
+    c.free()
+    c2 = pkg.Context(be)
+    z = c2.new_tensor(F32, 1024); w = c2.scale(z, 0.5)
+    c2.alloc()
+    be.tensor_set(z, b)
+    be.graph_compute(c2.graph())
+    assert np.array_equal(be.tensor_get(w), 0.5 * b)
+    c2.free()
