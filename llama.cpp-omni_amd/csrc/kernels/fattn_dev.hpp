@@ -30,6 +30,7 @@ struct fa_dev {
     fa_pre pre;
     char * out16; int64_t out16_rs; int write_f32;      // prefill kernel: f16 copy of the output rows (activation image of wo's GEMM)
     char * img; size_t img_bytes;                       // optional Q8_K image output (one image per (seq, query row)), else null
+    unsigned long long * stamps = nullptr;              // measurement only (MI355X_FA_STAMPS): s_memrealtime marks of workgroup 0, wave 0
     int vt = 0;                                         // prefill kernel: v is V^T ([n_kv] cells contiguous per d row, vnb1 = row stride); value = the alignment every row start has (16 / 4 / 2)
 };
 

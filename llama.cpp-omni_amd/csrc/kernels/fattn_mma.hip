@@ -45,6 +45,42 @@ template <int D> struct fm_cfg {
     static constexpr int VB  = D * VLD * 2;     // bytes of one V^T buffer
 };
 
+// ---- the finished O^T of a wave (lane = query lq, 16 x NDB f32 values = d scattered as db*32 + 8g + 4hb + i) out to memory as whole rows: through a wave-private LDS block
+// [32 queries][D + 4] (the +4 keeps the 16-byte writes of eight consecutive queries on distinct banks), read back row-wise, so that one store instruction writes 64 / (D / 4)
+// whole rows of D f32 (or D f16 for the image) instead of 64 separate 16-byte pieces a row stride apart -- the per-lane form cost 6.4 us per workgroup at 512 x 512 x 128
+// (a CU's memory path takes a request per line touched: 64 per instruction against 8)
+template <int D>
+__device__ __forceinline__ void fa_store_rows(const f16a (&acc_o)[D / 32], const float inv, float * scr, const int lane, const fa_dev & a, const int h, const int q0, const int is3) {
+    constexpr int NDB = D / 32, P = D + 4, LPR = D / 4, RPI = 64 / LPR;
+    const int lq = lane & 31, hb = lane >> 5;
+#pragma unroll
+    for (int db = 0; db < NDB; ++db)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            f32x4 o4;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) o4[i] = acc_o[db][4 * g + i] * inv;
+            *(f32x4 *) (scr + lq * P + db * 32 + 8 * g + 4 * hb) = o4;
+        }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const int rl = lane / LPR, c4 = lane % LPR;
+#pragma unroll
+    for (int r = 0; r < 32; r += RPI) {
+        const int row = r + rl, qrow = q0 + row;
+        const f32x4 o4 = *(const f32x4 *) (scr + row * P + c4 * 4);
+        if (qrow < a.nq) {
+            if (a.write_f32) *(f32x4 *) (a.dst + h * a.dnb1 + qrow * a.dnb2 + is3 * a.dnb3 + c4 * 16) = o4;
+            if (a.out16) {
+                u32x2 hw;
+                hw[0] = (uint32_t) f2h(o4[0]) | ((uint32_t) f2h(o4[1]) << 16); hw[1] = (uint32_t) f2h(o4[2]) | ((uint32_t) f2h(o4[3]) << 16);
+                *(u32x2 *) (a.out16 + ((int64_t) is3 * a.nq + qrow) * a.out16_rs + ((int64_t) h * D + c4 * 4) * 2) = hw;
+            }
+        }
+    }
+}
+
 // KS = KV split inside the workgroup: NW*KS waves; wave (qb, ks) owns query block qb and the ks-th run of SQ 32-row tiles of every staged group of
 // KS * SQ tiles, with its own running (M, S, O); the KS partial states of a query block are merged through LDS at the end.  Used when a
 // single wave per 32 queries would leave half of the chip's SIMDs without a wave (one 512-token ubatch of one sequence: 512 blocks).
@@ -61,10 +97,21 @@ __global__ void __launch_bounds__(64 * NW * KS) __attribute__((amdgpu_waves_per_
     constexpr int GT  = FM_KT * NTL;            // KV rows staged per iteration
     constexpr int KCH = (GT * (D / 8) + NT - 1) / NT;               // 16-byte K chunks per thread per group
     constexpr int VIT = ((GT / 2) * (D / 8) + NT - 1) / NT;         // V row-pair items per thread per group
-    __shared__ __attribute__((aligned(16))) _Float16 Ks[2][NTL][FM_KT * KLD];
-    __shared__ __attribute__((aligned(16))) uint32_t Vt[2][NTL][D * VLD / 2];
+    // one pool: the K and V^T tiles of both buffers, and -- after the loop, when the tiles are dead -- the parked states of the KV split (KS = 4 at head size 128 would
+    // not fit next to them: 139 + 101 KB)
+    constexpr int KSB = 2 * NTL * FM_KT * KLD * 2, VTB = 2 * NTL * (D * VLD / 2) * 4;
+    constexpr int MRGB = KS > 1 ? (KS - 1) * NW * 64 * (NDB * 16 + 2) * 4 : 0;
+    constexpr int POOLB = KSB + VTB > MRGB ? KSB + VTB : MRGB;
+    constexpr int OWB = 32 * (D + 4) * 4, ORW = POOLB / OWB >= NW ? NW : POOLB / OWB;      // output rows' staging: bytes per wave, waves per round
+    static_assert(ORW >= 1 && (KS == 1 || ORW == NW), "the output rows' staging fits the pool");
+    __shared__ __attribute__((aligned(16))) char pool[POOLB];
+    _Float16 (* const Ks)[NTL][FM_KT * KLD] = (_Float16 (*)[NTL][FM_KT * KLD]) pool;
+    uint32_t (* const Vt)[NTL][D * VLD / 2] = (uint32_t (*)[NTL][D * VLD / 2]) (pool + KSB);
 
     const int tid = threadIdx.x, lane = tid & 63, wave_all = tid >> 6;
+    int n_st = 0;
+    auto stamp = [&]() { if (a.stamps && blockIdx.x == 0 && tid == 0 && n_st < 30) a.stamps[n_st++] = __builtin_amdgcn_s_memrealtime(); };
+    stamp();
     const int wave = wave_all % NW, kvs = wave_all / NW;    // query block within the workgroup, KV split
     const int lq = lane & 31, hb = lane >> 5;
     int b = (int) blockIdx.x;
@@ -95,6 +142,7 @@ __global__ void __launch_bounds__(64 * NW * KS) __attribute__((amdgpu_waves_per_
     const uint16_t * mrow = a.mask ? (const uint16_t *) (a.mask + qc * a.mnb1 + (h % (int) a.mne2) * a.mnb2 + (is3 % (int) a.mne3) * a.mnb3) : nullptr;
     const bool mask_vec = a.mask && (a.mnb1 % 8 == 0) && (((uintptr_t) mrow) % 8 == 0);
 
+    stamp();                                              // 1: q fragments
     f16a acc_o[NDB];
 #pragma unroll
     for (int db = 0; db < NDB; ++db)
@@ -106,6 +154,55 @@ __global__ void __launch_bounds__(64 * NW * KS) __attribute__((amdgpu_waves_per_
     const char * vbase = a.v + ikv * a.vnb2 + is3 * a.vnb3;
     const int ntile32 = (a.nkv + FM_KT - 1) / FM_KT;              // 32-row mask / compute tiles
     const int ntile = (ntile32 + NTL - 1) / NTL;                  // staged groups of NTL tiles
+    // K / V rows of tile t into registers (rows past nkv are zero)
+    // two register sets: the rows of the next TWO live groups are in flight (one group's matrix work is shorter than a round trip to L2 / HBM on the small grids this kernel
+    // serves: with one set every group waited ~2 us for its rows)
+    u32x4 kregA[KCH], vregA[VIT][2], kregB[KCH], vregB[VIT][2];
+    auto load_kv = [&](int t, u32x4 (&kreg)[KCH], u32x4 (&vreg)[VIT][2]) {
+        const int kv0 = t * GT;
+#pragma unroll
+        for (int i = 0; i < KCH; ++i) {
+            const int c = tid + i * NT;
+            const int row = c / (D / 8), col = c % (D / 8);
+            kreg[i] = u32x4{ 0u, 0u, 0u, 0u };
+            if (c < GT * (D / 8) && kv0 + row < a.nkv) kreg[i] = *(const u32x4 *) (kbase + (int64_t) (kv0 + row) * a.knb1 + col * 16);
+        }
+        if (a.vt) {
+            // V given TRANSPOSED (the flash-attention-off graphs: a [n_kv, D] view of the transposed cache, or an encoder's permuted V): row d holds its kv cells
+            // contiguously -- already the layout of the V^T tile; item = 8 cells (16 bytes) of one row
+#pragma unroll
+            for (int i = 0; i < 2 * VIT; ++i) {
+                const int c = tid + i * NT;
+                const int ch = c % (GT / 8), d = c / (GT / 8);
+                u32x4 r = u32x4{ 0u, 0u, 0u, 0u };
+                if (c < D * (GT / 8)) {
+                    const int kvc = kv0 + 8 * ch;
+                    const char * src = vbase + (int64_t) d * a.vnb1 + (int64_t) kvc * 2;
+                    if (kvc + 7 < a.nkv && a.vt == 16) r = *(const u32x4 *) src;
+                    else if (kvc + 7 < a.nkv && a.vt == 4) { const uint32_t * s4 = (const uint32_t *) src; r = u32x4{ s4[0], s4[1], s4[2], s4[3] }; }
+                    else {
+                        const uint16_t * s2 = (const uint16_t *) src;
+                        uint32_t hv[8];
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) hv[e] = kvc + e < a.nkv ? (uint32_t) s2[e] : 0u;
+                        r = u32x4{ hv[0] | (hv[1] << 16), hv[2] | (hv[3] << 16), hv[4] | (hv[5] << 16), hv[6] | (hv[7] << 16) };
+                    }
+                }
+                vreg[i >> 1][i & 1] = r;
+            }
+            return;
+        }
+#pragma unroll
+        for (int i = 0; i < VIT; ++i) {
+            const int c = tid + i * NT;
+            const int o = c % (D / 8), p = c / (D / 8);
+            vreg[i][0] = vreg[i][1] = u32x4{ 0u, 0u, 0u, 0u };
+            if (c < (GT / 2) * (D / 8)) {
+                if (kv0 + 2 * p     < a.nkv) vreg[i][0] = *(const u32x4 *) (vbase + (int64_t) (kv0 + 2 * p)     * a.vnb1 + o * 16);
+                if (kv0 + 2 * p + 1 < a.nkv) vreg[i][1] = *(const u32x4 *) (vbase + (int64_t) (kv0 + 2 * p + 1) * a.vnb1 + o * 16);
+            }
+        }
+    };
 
     // ---- which tiles does any query of this workgroup see?  The classes of the workgroup's NW x ntile32 tiles are copied out of the mask tile map once, two bits each,
     // into LDS (a class looked up in global memory inside the loop was a dependent L2 round trip per group and wave, in front of the barrier: the loop ran at that
@@ -114,6 +211,7 @@ __global__ void __launch_bounds__(64 * NW * KS) __attribute__((amdgpu_waves_per_
     __shared__ uint32_t cls2[NW][FM_MAXT / 16];
     const int qb0 = qt * NW;                                        // first 32-row query block of the workgroup
     const uint8_t * maprow = a.tile_map ? a.tile_map + (((int64_t) (is3 % (int) a.mne3) * a.mne2 + (h % (int) a.mne2)) * a.map_nqb) * ntile32 : nullptr;
+    stamp();                                              // 1b: before the classes
     if (maprow) {
         const int nwords = (ntile32 + 15) / 16;
         for (int j = tid; j < NW * nwords; j += NT) {
@@ -128,6 +226,7 @@ __global__ void __launch_bounds__(64 * NW * KS) __attribute__((amdgpu_waves_per_
         }
         __syncthreads();
     }
+    stamp();                                              // 1c: classes in LDS
     for (int c = wave_all; c * 64 < ntile; c += NW * KS) {
         const int tt = c * 64 + lane;
         bool lv = false;
@@ -177,54 +276,7 @@ __global__ void __launch_bounds__(64 * NW * KS) __attribute__((amdgpu_waves_per_
             }
         }
     };
-    // K / V rows of tile t into registers (rows past nkv are zero)
-    u32x4 kreg[KCH], vreg[VIT][2];
-    auto load_kv = [&](int t) {
-        const int kv0 = t * GT;
-#pragma unroll
-        for (int i = 0; i < KCH; ++i) {
-            const int c = tid + i * NT;
-            const int row = c / (D / 8), col = c % (D / 8);
-            kreg[i] = u32x4{ 0u, 0u, 0u, 0u };
-            if (c < GT * (D / 8) && kv0 + row < a.nkv) kreg[i] = *(const u32x4 *) (kbase + (int64_t) (kv0 + row) * a.knb1 + col * 16);
-        }
-        if (a.vt) {
-            // V given TRANSPOSED (the flash-attention-off graphs: a [n_kv, D] view of the transposed cache, or an encoder's permuted V): row d holds its kv cells
-            // contiguously -- already the layout of the V^T tile; item = 8 cells (16 bytes) of one row
-#pragma unroll
-            for (int i = 0; i < 2 * VIT; ++i) {
-                const int c = tid + i * NT;
-                const int ch = c % (GT / 8), d = c / (GT / 8);
-                u32x4 r = u32x4{ 0u, 0u, 0u, 0u };
-                if (c < D * (GT / 8)) {
-                    const int kvc = kv0 + 8 * ch;
-                    const char * src = vbase + (int64_t) d * a.vnb1 + (int64_t) kvc * 2;
-                    if (kvc + 7 < a.nkv && a.vt == 16) r = *(const u32x4 *) src;
-                    else if (kvc + 7 < a.nkv && a.vt == 4) { const uint32_t * s4 = (const uint32_t *) src; r = u32x4{ s4[0], s4[1], s4[2], s4[3] }; }
-                    else {
-                        const uint16_t * s2 = (const uint16_t *) src;
-                        uint32_t hv[8];
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) hv[e] = kvc + e < a.nkv ? (uint32_t) s2[e] : 0u;
-                        r = u32x4{ hv[0] | (hv[1] << 16), hv[2] | (hv[3] << 16), hv[4] | (hv[5] << 16), hv[6] | (hv[7] << 16) };
-                    }
-                }
-                vreg[i >> 1][i & 1] = r;
-            }
-            return;
-        }
-#pragma unroll
-        for (int i = 0; i < VIT; ++i) {
-            const int c = tid + i * NT;
-            const int o = c % (D / 8), p = c / (D / 8);
-            vreg[i][0] = vreg[i][1] = u32x4{ 0u, 0u, 0u, 0u };
-            if (c < (GT / 2) * (D / 8)) {
-                if (kv0 + 2 * p     < a.nkv) vreg[i][0] = *(const u32x4 *) (vbase + (int64_t) (kv0 + 2 * p)     * a.vnb1 + o * 16);
-                if (kv0 + 2 * p + 1 < a.nkv) vreg[i][1] = *(const u32x4 *) (vbase + (int64_t) (kv0 + 2 * p + 1) * a.vnb1 + o * 16);
-            }
-        }
-    };
-    auto store_kv = [&](int buf) {
+    auto store_kv = [&](int buf, const u32x4 (&kreg)[KCH], const u32x4 (&vreg)[VIT][2]) {
 #pragma unroll
         for (int i = 0; i < KCH; ++i) {
             const int c = tid + i * NT;
@@ -259,10 +311,13 @@ __global__ void __launch_bounds__(64 * NW * KS) __attribute__((amdgpu_waves_per_
         }
     };
 
+    stamp();                                              // 2: classes, live bits
     int t = next_live(0), nlive = 0;
-    if (t < ntile) load_kv(t);
+    int t_nx = t < ntile ? next_live(t + 1) : ntile;
+    if (t < ntile) load_kv(t, kregA, vregA);
+    if (t_nx < ntile) load_kv(t_nx, kregB, vregB);
     const bool c2pos = c2 > 0.0f;                                     // (then the row maximum may be taken before the scale is applied)
-    while (t < ntile) {
+    auto step = [&](u32x4 (&kreg)[KCH], u32x4 (&vreg)[VIT][2]) {
         const int buf = nlive & 1;
         int cls[SQ]; u32x2 mw[SQ][4] = {};
 #pragma unroll
@@ -270,11 +325,14 @@ __global__ void __launch_bounds__(64 * NW * KS) __attribute__((amdgpu_waves_per_
             cls[sq] = tile_class(t, sq);
             if (cls[sq] == 2) load_mask(t * NTL + kvs * SQ + sq, mw[sq]);       // mixed tile: this lane's mask words (latency under the stores)
         }
-        if (!(ABL & 1) || nlive == 0) store_kv(buf);
+        stamp();                                          // group: top
+        if (!(ABL & 1) || nlive == 0) store_kv(buf, kreg, vreg);
+        stamp();                                          // group: stored (rows had landed)
         // barrier: group t is visible; everybody is past the previous live group's matrix work, so the other buffer may be refilled
         __syncthreads();
-        const int tn = next_live(t + 1);
-        if (tn < ntile && !(ABL & 1)) load_kv(tn);                   // in flight under this group's MFMAs
+        stamp();                                          // group: past the barrier
+        const int t2 = t_nx < ntile ? next_live(t_nx + 1) : ntile;
+        if (t2 < ntile && !(ABL & 1)) load_kv(t2, kreg, vreg);       // (this set has just been stored) in flight under this group's and the next one's MFMAs
 
 #pragma unroll
         for (int sq = 0; sq < SQ; ++sq) {
@@ -342,13 +400,16 @@ __global__ void __launch_bounds__(64 * NW * KS) __attribute__((amdgpu_waves_per_
                 }
             }
         }
-        t = tn; ++nlive;
-    }
+        t = t_nx; t_nx = t2; ++nlive;
+    };
+    while (t < ntile) { step(kregA, vregA); if (t >= ntile) break; step(kregB, vregB); }
+    stamp();                                              // loop done
 
     // ---- merge the KS partial states of each query block (same lane layout in every wave of a block): the ks > 0 waves park
     // (M, S, O^T) in LDS, the ks == 0 wave folds them in and finishes
     if (KS > 1) {
-        __shared__ float mrg[KS > 1 ? (KS - 1) * NW * 64 * (NDB * 16 + 2) : 1];
+        float * const mrg = (float *) pool;
+        __syncthreads();                                             // (every wave is past its last tile: the pool changes hands)
         float * mine = mrg + ((size_t) ((kvs > 0 ? kvs - 1 : 0) * NW + wave) * 64 + lane) * (NDB * 16 + 2);
         if (kvs > 0) {
             mine[0] = M; mine[1] = S;
@@ -373,6 +434,7 @@ __global__ void __launch_bounds__(64 * NW * KS) __attribute__((amdgpu_waves_per_
                 for (int e = 0; e < 16; ++e) acc_o[db][e] = acc_o[db][e] * f0 + oth[2 + db * 16 + e] * f1;
         }
     }
+    stamp();                                              // merged
     // ---- finish: fold the two lane halves' partial sums, sinks (ops.cpp:8116-8130), normalise, store permuted
     S += __shfl_xor(S, 32, 64);
     float osc = 1.0f;
@@ -382,23 +444,16 @@ __global__ void __launch_bounds__(64 * NW * KS) __attribute__((amdgpu_waves_per_
         else S += __builtin_amdgcn_exp2f(sk - M);
     }
     const float inv = S == 0.0f ? 0.0f : osc / S;
-    if (row_ok) {
-        char * out = a.dst + h * a.dnb1 + q * a.dnb2 + is3 * a.dnb3;
+    // (KS == 1: every wave is past its last tile before the pool becomes the rows' staging; KS > 1: the slot this wave has just folded in)
+    if (KS == 1) {
 #pragma unroll
-        for (int db = 0; db < NDB; ++db)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                f32x4 o4;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) o4[i] = acc_o[db][4 * g + i] * inv;
-                if (a.write_f32) *(f32x4 *) (out + (db * 32 + 8 * g + 4 * hb) * 4) = o4;
-                if (a.out16) {
-                    u32x2 hw;
-                    hw[0] = (uint32_t) f2h(o4[0]) | ((uint32_t) f2h(o4[1]) << 16); hw[1] = (uint32_t) f2h(o4[2]) | ((uint32_t) f2h(o4[3]) << 16);
-                    *(u32x2 *) (a.out16 + ((int64_t) is3 * a.nq + q) * a.out16_rs + ((int64_t) h * D + db * 32 + 8 * g + 4 * hb) * 2) = hw;
-                }
-            }
-    }
+        for (int rnd = 0; rnd * ORW < NW; ++rnd) {
+            __syncthreads();
+            if (wave / ORW == rnd) fa_store_rows<D>(acc_o, inv, (float *) (pool + (wave % ORW) * OWB), lane, a, h, q0, is3);
+        }
+    } else fa_store_rows<D>(acc_o, inv, (float *) (pool + wave * OWB), lane, a, h, q0, is3);
+    stamp();                                              // stored
+    if (a.stamps && blockIdx.x == 0 && tid == 0) a.stamps[31] = (unsigned long long) n_st;
 }
 
 // ---- head size 128, many query blocks: the same maths with K / V tiles that never pass through registers.
@@ -726,6 +781,8 @@ __global__ void __launch_bounds__(256 * HW) __attribute__((amdgpu_waves_per_eu(2
         else S += __builtin_amdgcn_exp2f(sk - M);
     }
     const float inv = S == 0.0f ? 0.0f : osc / S;
+    // (per-lane 16-byte stores: two workgroups share a CU here and the other one's matrix work covers them -- staging the rows through LDS as k_fattn_mma does, behind two more
+    // barriers, measured the same within the box-to-box spread: 562-563 TFLOP/s either way at 8 x 512 x 2048)
     if (row_ok) {
         char * out = a.dst + h * a.dnb1 + q * a.dnb2 + is3 * a.dnb3;
 #pragma unroll
@@ -1152,7 +1209,22 @@ static void launch_fm(const fa_dev & a, hipStream_t st) {
         else                             k_fattn_mma<D, 4, 1, 1><<<dim3((unsigned) (nqt4 * a.nh * a.ns)), dim3(256), 0, st>>>(a, nqt4);
     } else {
         const int nqt = (a.nq + 63) / 64;
-        if (!no_split && blocks32 <= 768 && a.nkv >= 128) k_fattn_mma<D, 2, 2, 1><<<dim3((unsigned) (nqt * a.nh * a.ns)), dim3(256), 0, st>>>(a, nqt);   // fewer waves than SIMDs
+        static const int ks_env = getenv("MI355X_FA_KS") ? atoi(getenv("MI355X_FA_KS")) : 4;
+        static const bool want_stamps = getenv("MI355X_FA_STAMPS") != nullptr;
+        if (want_stamps) {
+            static unsigned long long * dst = nullptr; static int shown = 0;
+            if (!dst) HIP_CHECK(hipMalloc(&dst, 32 * 8));
+            fa_dev b2 = a; b2.stamps = dst;
+            HIP_CHECK(hipMemsetAsync(dst, 0, 32 * 8, st));
+            if (ks_env >= 4) k_fattn_mma<D, 2, 4, 1><<<dim3((unsigned) (nqt * a.nh * a.ns)), dim3(512), 0, st>>>(b2, nqt); else k_fattn_mma<D, 2, 2, 1><<<dim3((unsigned) (nqt * a.nh * a.ns)), dim3(256), 0, st>>>(b2, nqt);
+            ++shown; if (shown == 100 || shown == 101 || shown == 230 || shown == 231) {
+                unsigned long long h[32]; HIP_CHECK(hipStreamSynchronize(st)); HIP_CHECK(hipMemcpy(h, dst, sizeof(h), hipMemcpyDeviceToHost));
+                fprintf(stderr, "[fa stamps] n=%llu (10 ns ticks after the first):", h[31]); for (int i = 1; i < (int) h[31] && i < 30; ++i) fprintf(stderr, " %.2f", (double) (h[i] - h[0]) / 100.0); fprintf(stderr, " us\n");
+            }
+            return;
+        }
+        if (!no_split && ks_env >= 4 && blocks32 <= 512 && a.nkv >= 256) k_fattn_mma<D, 2, 4, 1><<<dim3((unsigned) (nqt * a.nh * a.ns)), dim3(512), 0, st>>>(a, nqt);   // at most one wave per two SIMDs otherwise: four waves per query block, a quarter of the KV range each
+        else if (!no_split && blocks32 <= 768 && a.nkv >= 128) k_fattn_mma<D, 2, 2, 1><<<dim3((unsigned) (nqt * a.nh * a.ns)), dim3(256), 0, st>>>(a, nqt);   // fewer waves than SIMDs
         else if (sq_env >= 2 && a.nkv >= 128)            k_fattn_mma<D, 2, 1, 2><<<dim3((unsigned) (nqt * a.nh * a.ns)), dim3(128), 0, st>>>(a, nqt);
         else                                             k_fattn_mma<D, 2, 1, 1><<<dim3((unsigned) (nqt * a.nh * a.ns)), dim3(128), 0, st>>>(a, nqt);
     }
