@@ -563,8 +563,13 @@ __global__ void __launch_bounds__(512) k_gemm_f16_glds256(const gemm_dev g) {
 // silu(gate) * up (vec.h:958 arithmetic, f32) is rounded to f16 straight into the activation image of the next GEMM; the two f32
 // [n_ff x n_tokens] intermediates and the GLU launch never exist.
 // MI355X_GEMM_ABL (measurement only): 1 no DMA inside the loop (stale operands), 8 cycle stamps per phase part.
-template <int ABL, bool GLU>
+// R96 (GLU only): the tile is 96 rows of both matrices instead of 128 -- the waves of the second group (wm = 1) own ONE 32-row fragment of gate and of up instead of two.
+// Waves w and w + 4 share a SIMD, so every SIMD has three quarters of the matrix work per K-step, and a grid that filled 192 of the 256 CUs (n_ff 12288 x 512 tokens:
+// 96 x 2 tiles) becomes 128 x 2 = 256 workgroups.  The LDS rows 96..127 of the W items are not used; the DMA instructions that would fill them stay (the counted
+// vmcnt waits rest on every wave issuing the same number) but all their lanes ask for one and the same 16 bytes.
+template <int ABL, bool GLU, bool R96 = false>
 __global__ void __launch_bounds__(512) k_gemm_f16_ph8(const gemm_dev g) {
+    static_assert(GLU || !R96, "96-row tiles exist for the GLU form only");
     constexpr int HALFB = 128 * H_ROWB, BUFB = 4 * HALFB;          // 16 KB per item, 64 KB per buffer: slots W-h0, W-h1, X-h0, X-h1
     constexpr int S_W0 = 0, S_W1 = 1, S_X0 = 2, S_X1 = 3;
     char * const lds = gemm_lds;
@@ -584,7 +589,7 @@ __global__ void __launch_bounds__(512) k_gemm_f16_ph8(const gemm_dev g) {
     const size_t w_rs = mi == 0 ? g.w_rs[0] : (mi == 1 ? g.w_rs[1] : g.w_rs[2]);
     const int M = mi == 0 ? g.M[0] : (mi == 1 ? g.M[1] : g.M[2]);
     const int N = g.N;
-    const int m0 = tm * (GLU ? 128 : 256), n0 = tn * 256;
+    const int m0 = tm * (GLU ? (R96 ? 96 : 128) : 256), n0 = tn * 256;
 
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -593,7 +598,9 @@ __global__ void __launch_bounds__(512) k_gemm_f16_ph8(const gemm_dev g) {
     // staging: an item is 128 LDS rows; instruction i of wave w fills local rows i*64 + w*8 + [0,8), lane l the 16-B chunk l & 7 of row l >> 3
     // from source chunk (l & 7) ^ ((row >> 1) & 7) (the bank swizzle of the kernels above, applied on the source side)
     const int r8 = lane >> 3;
-    const char * src[4][2];                                        // [slot][instruction]
+    // (32-bit offsets from wave-uniform bases: 8 registers instead of the 32 of sixteen pointers -- the kernel sits at the 256-register line)
+    uint32_t soff[4][2];                                           // [slot][instruction]
+    const char * const wb0 = GLU ? g.W[g.glu_gate] : W, * const wb1 = GLU ? g.W[1 - g.glu_gate] : W;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int lr = i * 64 + wave * 8 + r8;
@@ -602,9 +609,9 @@ __global__ void __launch_bounds__(512) k_gemm_f16_ph8(const gemm_dev g) {
         for (int h = 0; h < 2; ++h) {
             int mr = GLU ? m0 + lr : m0 + (lr >> 6) * 128 + h * 64 + (lr & 63); mr = mr < M ? mr : M - 1;
             int nr = n0 + (lr >> 5) * 64 + h * 32 + (lr & 31);  nr = nr < N ? nr : N - 1;
-            const int wi = GLU ? (h == 0 ? g.glu_gate : 1 - g.glu_gate) : 0;                         // (GLU: M and the row stride are checked equal)
-            src[S_W0 + h][i] = (GLU ? g.W[wi] : W) + (size_t) mr * w_rs + gc * 16;
-            src[S_X0 + h][i] = g.X + (size_t) nr * g.x_rs + gc * 16;
+            soff[S_W0 + h][i] = (uint32_t) ((size_t) mr * w_rs + gc * 16);                          // (GLU: M and the row stride are checked equal; launcher: M * w_rs < 4 GB)
+            if (R96 && lr >= 96) soff[S_W0 + h][i] = (uint32_t) ((size_t) (m0 < M ? m0 : M - 1) * w_rs);   // (rows nobody reads: one request for the whole wave)
+            soff[S_X0 + h][i] = (uint32_t) ((size_t) nr * g.x_rs + gc * 16);
         }
     }
     const int nk = g.K / H_BK;
@@ -612,7 +619,8 @@ __global__ void __launch_bounds__(512) k_gemm_f16_ph8(const gemm_dev g) {
     auto dma = [&](int buf, int slot, int i, int kt) {             // one DMA instruction: half i of an item
         if ((ABL & 1) && in_loop) return;
         const size_t ko = (size_t) (kt < nk ? kt : nk - 1) * H_ROWB; // past the end: the last K-step again, into a slot nobody reads any more
-        __builtin_amdgcn_global_load_lds((gbl_ptr_t) (src[slot][i] + ko), (lds_ptr_t) (lds + buf * BUFB + slot * HALFB + (i * 64 + wave * 8) * H_ROWB), 16, 0, 0);
+        const char * const base = (slot == S_W0 ? wb0 : slot == S_W1 ? wb1 : g.X) + ko;
+        __builtin_amdgcn_global_load_lds((gbl_ptr_t) (base + (size_t) soff[slot][i]), (lds_ptr_t) (lds + buf * BUFB + slot * HALFB + (i * 64 + wave * 8) * H_ROWB), 16, 0, 0);
     };
 
     f16v acc[2][4];
@@ -630,22 +638,35 @@ __global__ void __launch_bounds__(512) k_gemm_f16_ph8(const gemm_dev g) {
     const char * const wrow = lds + (wm * 64 + fr) * H_ROWB;        // + buffer, slot, (second 32-row fragment) 32 * H_ROWB
     const char * const xrow = lds + (wn * 32 + fr) * H_ROWB;
     h8 wr[2][4], x0[4], x1[4];
-    auto read_w = [&](int buf, int slot) {
+    // (SH: the short form of a 96-row tile's second wave group -- one W fragment per item; the whole loop exists once per form, straight-line: a test per fragment
+    // inside one loop made the register allocator spill)
+    auto read_w = [&](auto SHc, int buf, int slot) {
 #pragma unroll
-        for (int bb = 0; bb < 2; ++bb)
+        for (int kk = 0; kk < 4; ++kk) wr[0][kk] = *(const h8 *) (wrow + buf * BUFB + slot * HALFB + co[kk]);
+        if (!(R96 && wm == 1)) {
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk) wr[bb][kk] = *(const h8 *) (wrow + buf * BUFB + slot * HALFB + bb * 32 * H_ROWB + co[kk]);
+            for (int kk = 0; kk < 4; ++kk) wr[1][kk] = *(const h8 *) (wrow + buf * BUFB + slot * HALFB + 32 * H_ROWB + co[kk]);
+        }
     };
     auto read_x = [&](int buf, int slot, h8 (&x)[4]) {
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) x[kk] = *(const h8 *) (xrow + buf * BUFB + slot * HALFB + co[kk]);
     };
-    auto mma = [&](int a, int bh, const h8 (&x)[4]) {
+    auto mma = [&](auto SHc, int a, int bh, const h8 (&x)[4]) {
         __builtin_amdgcn_s_setprio(1);
+        if (R96) {                                                 // (fragment 0, then -- first wave group only -- fragment 1: one wave-uniform branch per phase)
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk)
+            for (int kk = 0; kk < 4; ++kk) acc[a][2 * bh] = __builtin_amdgcn_mfma_f32_32x32x16_f16(x[kk], wr[0][kk], acc[a][2 * bh], 0, 0, 0);
+            if (wm == 0) {
 #pragma unroll
-            for (int bb = 0; bb < 2; ++bb) acc[a][2 * bh + bb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(x[kk], wr[bb][kk], acc[a][2 * bh + bb], 0, 0, 0);
+                for (int kk = 0; kk < 4; ++kk) acc[a][2 * bh + 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(x[kk], wr[1][kk], acc[a][2 * bh + 1], 0, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                for (int bb = 0; bb < 2; ++bb) acc[a][2 * bh + bb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(x[kk], wr[bb][kk], acc[a][2 * bh + bb], 0, 0, 0);
+        }
         __builtin_amdgcn_s_setprio(0);
     };
 #define PH8_BAR()     asm volatile("s_barrier" ::: "memory")
@@ -676,17 +697,20 @@ __global__ void __launch_bounds__(512) k_gemm_f16_ph8(const gemm_dev g) {
     if (wm == 1) PH8_BAR();
     in_loop = true;
     if (ABL & 8) tc = __builtin_readcyclecounter();
-    auto kstep = [&](auto PARc, int kt) {
+    auto kstep = [&](auto PARc, auto SHc, int kt) {
         constexpr int P = decltype(PARc)::value;
         h8 (&xa)[4] = P ? x1 : x0; h8 (&xb)[4] = P ? x0 : x1;      // X-h0 of this K-step sits where the previous K-step's X-h1 was
-        read_w(P, S_W0);       dma(P ^ 1, S_W1, 0, kt + 1);                                                                        PH8_T(0); PH8_ISSUED(9);  PH8_T(1);  PH8_READ(); mma(0, 0, xa); PH8_BAR(); PH8_T(2);
-        read_x(P, S_X1, xb);   dma(P ^ 1, S_W1, 1, kt + 1); dma(P, S_X0, 0, kt + 2); dma(P, S_X0, 1, kt + 2);                      PH8_T(3); PH8_ISSUED(10); PH8_T(4);  PH8_READ(); mma(1, 0, xb); PH8_BAR(); PH8_T(5);
-        read_w(P, S_W1);       dma(P, S_W0, 0, kt + 2);                                                                            PH8_T(6); PH8_ISSUED(9);  PH8_T(7);  PH8_READ(); mma(1, 1, xb); PH8_BAR(); PH8_T(8);
-        read_x(P ^ 1, S_X0, xb); dma(P, S_W0, 1, kt + 2); dma(P, S_X1, 0, kt + 2); dma(P, S_X1, 1, kt + 2);                        PH8_T(9); PH8_ISSUED(10); PH8_T(10); PH8_READ(); mma(0, 1, xa); PH8_BAR(); PH8_T(11);
+        read_w(SHc, P, S_W0);  dma(P ^ 1, S_W1, 0, kt + 1);                                                                        PH8_T(0); PH8_ISSUED(9);  PH8_T(1);  PH8_READ(); mma(SHc, 0, 0, xa); PH8_BAR(); PH8_T(2);
+        read_x(P, S_X1, xb);   dma(P ^ 1, S_W1, 1, kt + 1); dma(P, S_X0, 0, kt + 2); dma(P, S_X0, 1, kt + 2);                      PH8_T(3); PH8_ISSUED(10); PH8_T(4);  PH8_READ(); mma(SHc, 1, 0, xb); PH8_BAR(); PH8_T(5);
+        read_w(SHc, P, S_W1);  dma(P, S_W0, 0, kt + 2);                                                                            PH8_T(6); PH8_ISSUED(9);  PH8_T(7);  PH8_READ(); mma(SHc, 1, 1, xb); PH8_BAR(); PH8_T(8);
+        read_x(P ^ 1, S_X0, xb); dma(P, S_W0, 1, kt + 2); dma(P, S_X1, 0, kt + 2); dma(P, S_X1, 1, kt + 2);                        PH8_T(9); PH8_ISSUED(10); PH8_T(10); PH8_READ(); mma(SHc, 0, 1, xa); PH8_BAR(); PH8_T(11);
     };
-    int kt = 0;
-    for (; kt + 1 < nk; kt += 2) { kstep(std::integral_constant<int, 0>(), kt); kstep(std::integral_constant<int, 1>(), kt + 1); }
-    if (kt < nk) kstep(std::integral_constant<int, 0>(), kt);
+    auto loop = [&](auto SHc) {
+        int kt = 0;
+        for (; kt + 1 < nk; kt += 2) { kstep(std::integral_constant<int, 0>(), SHc, kt); kstep(std::integral_constant<int, 1>(), SHc, kt + 1); }
+        if (kt < nk) kstep(std::integral_constant<int, 0>(), SHc, kt);
+    };
+    loop(std::false_type());
     if (wm == 0) PH8_BAR();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if ((ABL & 8) && g.dbg && blockIdx.x == 300 && lane == 0 && (wave & 3) == 0)
@@ -701,6 +725,7 @@ __global__ void __launch_bounds__(512) k_gemm_f16_ph8(const gemm_dev g) {
         for (int a = 0; a < 2; ++a)
 #pragma unroll
             for (int bb = 0; bb < 2; ++bb) {
+                if (R96 && wm == 1 && bb == 1) continue;
                 const int m = m0 + wm * 64 + bb * 32 + (lane & 31);
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
@@ -849,7 +874,7 @@ void gemm_reduce_rms_norm(const float * partial, int nsplit, const float * resid
 
 // dynamic LDS above 64 KB needs a function attribute, once per (kernel, device): a process may drive several GPUs
 static void allow_big_lds(const void * kernel, int bytes, int slot) {
-    static bool done[6][64] = {};
+    static bool done[8][64] = {};
     int dev = 0;
     HIP_CHECK(hipGetDevice(&dev));
     if (dev < 0 || dev >= 64 || !done[slot][dev]) {
@@ -890,12 +915,13 @@ size_t gemm_split_scratch_bytes(int64_t M, int64_t N, int64_t K) {
 }
 
 // launches per tile variant (tests assert that a shape really selected the kernel it is meant to cover): 0 = 256 x 256, 1 = 192-row
-static long g_gemm_variant_launches[5] = { 0, 0, 0, 0, 0 };     // ... 2 = gate / up + SWIGLU, 3 = K-quant staging, 4 = stream-K (gemm_sk.hip)
-long gemm_variant_launches(int v) { return v >= 0 && v < 5 ? g_gemm_variant_launches[v] : 0; }
+static long g_gemm_variant_launches[6] = { 0, 0, 0, 0, 0, 0 };  // ... 2 = gate / up + SWIGLU, 3 = K-quant staging, 4 = stream-K (gemm_sk.hip), 5 = the 96-row tiles among 2
+long gemm_variant_launches(int v) { return v >= 0 && v < 6 ? g_gemm_variant_launches[v] : 0; }
 // gate / up + SWIGLU in one launch: equal shapes and row strides, whole 128-row blocks, enough tiles to occupy the chip
 bool gemm_glu_ok(const gemm_multi_args & a) {
     static const bool off = getenv("MI355X_NO_GEMM_GLU") != nullptr;
     if (off || a.nmat != 2 || a.nbatch > 1 || a.K % H_BK != 0 || a.m[0].M != a.m[1].M || a.m[0].w_rs != a.m[1].w_rs || a.m[0].M % 128 != 0 || a.m[0].resid || a.m[1].resid) return false;
+    if ((size_t) a.m[0].M * a.m[0].w_rs >= (1ull << 32) || (size_t) a.N * ((size_t) a.K * 2 + 256) >= (1ull << 32)) return false;   // (32-bit operand offsets in the kernel; the caller has not laid the activation image out yet: its row is K halfs plus padding)
     return (a.m[0].M / 128) * ((a.N + 255) / 256) >= 128;
 }
 
@@ -929,7 +955,14 @@ void gemm_f16_multi(const gemm_multi_args & a, hipStream_t st) {
     if (a.deferred_split) *a.deferred_split = 0;
     gemm_dev g;
     if (a.glu_out16) {                                        // ffn_gate / ffn_up + SWIGLU in one launch (gemm_glu_ok() said yes)
-        const int tiles_n256 = (int) ((a.N + 255) / 256), tm128 = (int) (a.m[0].M / 128);
+        // 96-row tiles when they take fewer rounds of the CUs, a tile of theirs counted as three quarters of a 128-row one (n_ff 12288 x 512 tokens: 192 tiles -> 256)
+        static const int r96_env = getenv("MI355X_GEMM_GLU96") ? atoi(getenv("MI355X_GEMM_GLU96")) : -1;
+        if ((size_t) a.N * a.x_rs >= (1ull << 32)) { fprintf(stderr, "[mi355x] gemm: activation image of %lld rows x %zu bytes is past the 32-bit offsets of the GLU kernel\n", (long long) a.N, a.x_rs); abort(); }
+        const int tiles_n256 = (int) ((a.N + 255) / 256);
+        const int64_t cus = (int64_t) gemm_sk_groups();                  // (CUs of the current device)
+        const int64_t t128 = (a.m[0].M / 128) * tiles_n256, t96 = ((a.m[0].M + 95) / 96) * tiles_n256;
+        const bool r96 = r96_env >= 0 ? r96_env != 0 : ((t96 + cus - 1) / cus) * 3 < ((t128 + cus - 1) / cus) * 4;
+        const int tm128 = r96 ? (int) ((a.m[0].M + 95) / 96) : (int) (a.m[0].M / 128);
         for (int i = 0; i < 3; ++i) {
             const gemm_mat & m = a.m[i < 2 ? i : 0];
             g.W[i] = (const char *) m.W; g.w_rs[i] = m.w_rs; g.dst[i] = nullptr; g.dst_cs[i] = 0; g.resid[i] = nullptr; g.resid_cs[i] = 0; g.M[i] = (int) m.M; g.tm_end[i] = tm128;
@@ -939,8 +972,14 @@ void gemm_f16_multi(const gemm_multi_args & a, hipStream_t st) {
         g.ne12 = g.r2 = g.r3 = 1; g.w_nb2 = g.w_nb3 = g.x_bs = g.dst_nb2 = g.dst_nb3 = 0;
         g.dbg = nullptr; g.out16 = (char *) a.glu_out16; g.out16_rs = a.glu_out16_rs; g.glu_gate = a.glu_gate;
         constexpr int lds256 = 2 * 2 * 256 * H_ROWB;
-        allow_big_lds((const void *) k_gemm_f16_ph8<0, true>, lds256, 2);
-        k_gemm_f16_ph8<0, true><<<dim3((unsigned) (tm128 * tiles_n256)), dim3(512), lds256, st>>>(g);
+        if (r96) {
+            allow_big_lds((const void *) k_gemm_f16_ph8<0, true, true>, lds256, 6);
+            k_gemm_f16_ph8<0, true, true><<<dim3((unsigned) (tm128 * tiles_n256)), dim3(512), lds256, st>>>(g);
+            ++g_gemm_variant_launches[5];
+        } else {
+            allow_big_lds((const void *) k_gemm_f16_ph8<0, true>, lds256, 2);
+            k_gemm_f16_ph8<0, true><<<dim3((unsigned) (tm128 * tiles_n256)), dim3(512), lds256, st>>>(g);
+        }
         ++g_gemm_variant_launches[2];
         return;
     }
@@ -969,6 +1008,8 @@ void gemm_f16_multi(const gemm_multi_args & a, hipStream_t st) {
     }
     bool any_q = false;
     for (int i = 0; i < a.nmat; ++i) any_q = any_q || a.m[i].qtype != 0;
+    for (int i = 0; i < a.nmat; ++i) if ((size_t) a.m[i].M * a.m[i].w_rs >= (1ull << 32)) big = false;     // (k_gemm_f16_ph8 addresses its operands with 32-bit offsets)
+    if ((size_t) a.N * a.x_rs >= (1ull << 32)) big = false;
     if (any_q) { BM = G_BM; big = false; }                    // K-quant blocks de-quantised in the staging: the 128 x 128 kernel (few columns by construction)
     if (!big && gemm_f16_sk_ok(a)) {                          // tile grids that fill the chip badly (a 512-token ubatch: 128-192 tiles): one persistent stream-K launch, no slabs
         gemm_f16_sk(a, st);

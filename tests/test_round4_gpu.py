@@ -417,3 +417,42 @@ def test_staged_async_upload_is_ordered_with_buffer_level_writes_and_survives_a_
     be.graph_compute(c2.graph())
     assert np.array_equal(be.tensor_get(w), 0.5 * b)
     c2.free()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("F", [8448, 8320])
+def test_gate_up_swiglu_96_row_tiles_vs_oracle(pkg, be, F):
+    """ffn_gate / ffn_up + SWIGLU in one launch with 96-row tiles (k_gemm_f16_ph8<.., GLU, R96>): chosen when 128-row tiles leave a quarter of the CUs without a
+    workgroup (n_ff 12288 x 512 tokens: 192 tiles on 256 CUs).  F = 8448 is a whole number of 96-row tiles (88), F = 8320 ends in a tile of 64 rows (clamped
+    source rows, rows past F not stored).  The launch counter confirms the variant; ffn_down's output against the oracle's chain on sampled tokens and against the
+    same graph with the fusion broken by a second reader of the GLU result."""
+    from test_gpu_parity import run_graph
+    from conftest import nmse
+    from oracle import oracle_py as orc
+    rng = np.random.default_rng(96 + F)
+    E, N = 256, 512
+    ty = pkg.GGML_TYPE_F16
+    wg = (rng.standard_normal((F, E)) * 0.05).astype(np.float16); wu = (rng.standard_normal((F, E)) * 0.05).astype(np.float16)
+    wd = (rng.standard_normal((E, F)) * 0.05).astype(np.float16)
+    xv = rng.standard_normal((N, E)).astype(np.float32)
+    outs = []
+    for second_reader in (False, True):
+        c = pkg.Context(be)
+        x = c.new_tensor(pkg.GGML_TYPE_F32, E, N)
+        tg, tu, td_ = c.new_tensor(ty, E, F), c.new_tensor(ty, E, F), c.new_tensor(ty, F, E)
+        up = c.mul_mat(tu, x); gate = c.mul_mat(tg, x)
+        act = c.swiglu_split(gate, up)
+        y = c.mul_mat(td_, act)
+        roots = [y] + ([c.scale(act, 1.0)] if second_reader else [])
+        before = be.get_stat("gemm_glu96_launches")
+        got = run_graph(be, c, roots, [(x, xv), (tg, wg), (tu, wu), (td_, wd)])
+        fused = be.get_stat("gemm_glu96_launches") - before
+        assert (fused == 0) if second_reader else (fused == 1), fused
+        outs.append(got[0].reshape(N, E))
+    cols = rng.choice(N, 48, replace=False)
+    g_ = orc.mul_mat(ty, wg.view(np.uint8).reshape(F, -1), xv[cols]); u_ = orc.mul_mat(ty, wu.view(np.uint8).reshape(F, -1), xv[cols])
+    a_ = (g_ / (1.0 + np.exp(-g_.astype(np.float64)))).astype(np.float32) * u_
+    want = orc.mul_mat(ty, wd.view(np.uint8).reshape(E, -1), a_.astype(np.float32))
+    assert np.isfinite(outs[0]).all()
+    assert nmse(outs[0][cols], want) < 1e-6, nmse(outs[0][cols], want)
+    assert nmse(outs[0], outs[1]) < 1e-9, nmse(outs[0], outs[1])
