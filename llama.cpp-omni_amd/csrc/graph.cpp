@@ -334,6 +334,7 @@ int mi355x_set_option(struct ggml_backend * backend, const char * key, long valu
     if (!strcmp(key, "fattn_gqa")) { mi::fattn_set_gqa(value != 0); mi::drop_graph_execs(c); return 0; }
     if (!strcmp(key, "fattn_one")) { mi::fattn_set_one(value != 0); mi::drop_graph_execs(c); return 0; }
     if (!strcmp(key, "fattn_dma")) { mi::fattn_set_dma((int) value); mi::drop_graph_execs(c); return 0; }      // (process-wide)
+    if (!strcmp(key, "gemm_rf")) { mi::gemm_rf_set_mode((int) value); mi::drop_graph_execs(c); return 0; }      // (process-wide: register-ring staging of the 128 x 128 F16 GEMM tile, k_gemm_f16_rf)
     if (!strcmp(key, "gemm_sk")) { mi::gemm_sk_set_mode((int) value); mi::drop_graph_execs(c); return 0; }      // (process-wide: the persistent stream-K form of the F16 GEMM, gemm_sk.hip)
     if (!strcmp(key, "f16_shadow")) { mi::shadow_set_enabled(value != 0); mi::drop_graph_execs(c); return 0; }
     if (!strcmp(key, "reset_stats")) { c->prof.clear(); c->stat_replays = c->stat_captures = c->stat_eager = 0; return 0; }
@@ -351,6 +352,7 @@ double mi355x_get_stat(struct ggml_backend * backend, const char * key) {
     if (!strcmp(key, "gemm192_launches"))   return (double) mi::gemm_variant_launches(1);
     if (!strcmp(key, "gemm_glu_launches"))  return (double) mi::gemm_variant_launches(2);
     if (!strcmp(key, "gemm_glu96_launches")) return (double) mi::gemm_variant_launches(5);
+    if (!strcmp(key, "gemm_rf_launches"))   return (double) mi::gemm_variant_launches(6);
     if (!strcmp(key, "gemm_kq_launches"))   return (double) mi::gemm_variant_launches(3);
     if (!strcmp(key, "gemm_sk_launches"))   return (double) mi::gemm_variant_launches(4);
     if (!strcmp(key, "fattn_dma_launches")) return (double) mi::fattn_dma_launches();

@@ -267,6 +267,7 @@ void   gemm_f16_sk(const gemm_multi_args & a, hipStream_t st);
 size_t gemm_sk_part_bytes();
 size_t gemm_sk_count_bytes();
 int    gemm_sk_groups();                                          // CUs of the current device
+void   gemm_rf_set_mode(int m);                                   // -1: MI355X_GEMM_RF decides, 0 off, 2 / 4: k_gemm_f16_rf<depth> where legal
 void   gemm_sk_set_mode(int m);                                   // -1: MI355X_GEMM_SK decides (default off), 0 off, 1 wherever legal, 2 by the shape rule
 void   gemm_reduce(const float * partial, int nsplit, const float * resid, size_t resid_cs, float * dst, size_t dst_cs, int64_t M, int64_t N, hipStream_t st);
 // the same reduction fused with the RMS_NORM -> MUL(w) of the result: dst = sum + resid (f32); y = rms_norm(dst) * w -> y32 / f16 rows y16

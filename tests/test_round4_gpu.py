@@ -456,3 +456,34 @@ def test_gate_up_swiglu_96_row_tiles_vs_oracle(pkg, be, F):
     assert np.isfinite(outs[0]).all()
     assert nmse(outs[0][cols], want) < 1e-6, nmse(outs[0][cols], want)
     assert nmse(outs[0], outs[1]) < 1e-9, nmse(outs[0], outs[1])
+
+
+def test_register_ring_gemm_is_bit_identical_to_the_lds_dma_form(pkg, be):
+    """k_gemm_f16_rf<D> (option "gemm_rf" = 2 / 4: both operands through a ring of D x 8 vector registers per thread, D K-steps ahead; OFF by default -- it measured
+    parity: the 512-column GEMMs are bound by the CU's line-request rate, not by bytes in flight) keeps k_gemm_f16_glds<2>'s tile, MFMA order, split-K slabs and
+    epilogue: every bit of the result must agree, at a shape with split-K and a residual-free epilogue and at one whose column count is ragged."""
+    rng = np.random.default_rng(404)
+    try:
+        for (M, K, N) in [(1024, 4096, 512), (512, 2048, 200)]:
+            c = pkg.Context(be)
+            w = c.new_tensor(pkg.GGML_TYPE_F16, K, M); x = c.new_tensor(pkg.GGML_TYPE_F32, K, N)
+            y = c.mul_mat(w, x)
+            c.alloc()
+            wv = (rng.standard_normal((M, K)) * 0.05).astype(np.float16); xv = rng.standard_normal((N, K)).astype(np.float32)
+            be.tensor_set(w, wv); be.tensor_set(x, xv)
+            g = c.graph()
+            outs = {}
+            for mode in (0, 4, 2):
+                be.set_option("gemm_rf", mode)
+                n0 = be.get_stat("gemm_rf_launches")
+                be.graph_compute(g); be.synchronize()
+                outs[mode] = be.tensor_get(y).copy()
+                assert (be.get_stat("gemm_rf_launches") - n0 > 0) == (mode != 0), (mode, M, K, N)
+            for mode in (2, 4):
+                assert np.array_equal(outs[0].view(np.uint32), outs[mode].view(np.uint32)), (mode, M, K, N)
+            want = xv.astype(np.float16).astype(np.float64) @ wv.astype(np.float64).T
+            err = np.abs(outs[4].reshape(N, M) - want).max() / np.abs(want).max()
+            assert err < 1e-5, err
+            c.free()
+    finally:
+        be.set_option("gemm_rf", -1)
