@@ -944,14 +944,41 @@ bool gemm_f16_ok(const void * W, size_t w_rs, const void * X, size_t x_rs, int64
 // split-K reduction fused with the RMS_NORM -> MUL(w) that follows the residual ADD (ops.cpp:3517-3566 arithmetic: sum of squares in
 // double): x = sum_s part[s] + resid -> dst (f32, the next residual); y = (x * scale) * w -> y32 (optional) and / or f16 rows y16
 // (the activation image of the next GEMM).  One workgroup per row, the row stays in registers (M <= 16384, M % 4 == 0).
+template <int MAXV>
 __global__ void __launch_bounds__(256) k_gemm_reduce_rms_norm(const float * __restrict__ part, int nsplit, size_t split_elems, const char * __restrict__ resid, size_t resid_cs,
                                                               char * __restrict__ dst, size_t dst_cs, const float * __restrict__ w, float eps,
                                                               char * __restrict__ y32, size_t y32_cs, char * __restrict__ y16, size_t y16_rs, int M) {
     __shared__ double red[4];
     const int n = blockIdx.x;
-    constexpr int MAXV = 16;
     f32x4 v[MAXV];
     double ss = 0.0;
+    if (MAXV <= 4) {
+        // rows of at most 4096: EVERY piece of every slab, and the residual's, requested before the first addition -- a thread's four quads one after the other were four
+        // dependent round trips (the store of a quad sits between the loads of two quads), 13.9 us for 52 MB; the additions keep their order: slab 0 + slab 1 + ... + residual
+        f32x4 sl[MAXV][8], rr[MAXV];
+#pragma unroll
+        for (int k = 0; k < MAXV; ++k) {
+            const int i = (threadIdx.x + k * 256) * 4;
+#pragma unroll
+            for (int s = 0; s < 8; ++s) sl[k][s] = (i < M && s < nsplit) ? *(const f32x4 *) (part + s * split_elems + (size_t) n * M + i) : f32x4{0, 0, 0, 0};
+            rr[k] = (i < M && resid) ? *(const f32x4 *) (resid + (size_t) n * resid_cs + (size_t) i * 4) : f32x4{0, 0, 0, 0};
+        }
+#pragma unroll
+        for (int k = 0; k < MAXV; ++k) {
+            const int i = (threadIdx.x + k * 256) * 4;
+            v[k] = f32x4{0, 0, 0, 0};
+            if (i < M) {
+                f32x4 a = sl[k][0];
+#pragma unroll
+                for (int s = 1; s < 8; ++s) if (s < nsplit) a += sl[k][s];
+                if (resid) a += rr[k];
+                *(f32x4 *) (dst + (size_t) n * dst_cs + (size_t) i * 4) = a;
+                v[k] = a;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) ss += (double) (a[e] * a[e]);
+            }
+        }
+    } else {
 #pragma unroll
     for (int k = 0; k < MAXV; ++k) {
         const int i = (threadIdx.x + k * 256) * 4;
@@ -973,6 +1000,7 @@ __global__ void __launch_bounds__(256) k_gemm_reduce_rms_norm(const float * __re
 #pragma unroll
             for (int e = 0; e < 4; ++e) ss += (double) (a[e] * a[e]);
         }
+    }
     }
     ss = block_sum<double>(ss, red);
     const float mean  = (float) (ss / (double) M);
@@ -1003,8 +1031,10 @@ bool gemm_reduce_rms_norm_ok(int64_t M) { return M % 4 == 0 && M <= 16384; }
 void gemm_reduce_rms_norm(const float * partial, int nsplit, const float * resid, size_t resid_cs, float * dst, size_t dst_cs, const float * w, float eps,
                           float * y32, size_t y32_cs, uint16_t * y16, size_t y16_rs, int64_t M, int64_t N, hipStream_t st) {
     if (M == 0 || N == 0) return;
-    k_gemm_reduce_rms_norm<<<dim3((unsigned) N), dim3(256), 0, st>>>(partial, nsplit, (size_t) M * (size_t) N, (const char *) resid, resid_cs, (char *) dst, dst_cs, w, eps,
-                                                                    (char *) y32, y32_cs, (char *) y16, y16_rs, (int) M);
+    if (M <= 4096) k_gemm_reduce_rms_norm<4><<<dim3((unsigned) N), dim3(256), 0, st>>>(partial, nsplit, (size_t) M * (size_t) N, (const char *) resid, resid_cs, (char *) dst, dst_cs, w, eps,
+                                                                                   (char *) y32, y32_cs, (char *) y16, y16_rs, (int) M);
+    else           k_gemm_reduce_rms_norm<16><<<dim3((unsigned) N), dim3(256), 0, st>>>(partial, nsplit, (size_t) M * (size_t) N, (const char *) resid, resid_cs, (char *) dst, dst_cs, w, eps,
+                                                                                    (char *) y32, y32_cs, (char *) y16, y16_rs, (int) M);
 }
 
 // dynamic LDS above 64 KB needs a function attribute, once per (kernel, device): a process may drive several GPUs
