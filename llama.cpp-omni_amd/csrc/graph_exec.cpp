@@ -425,7 +425,7 @@ static void materialise_reduce(exec_state & s) {
     const ggml_tensor * A = s.pr.A;
     s.pr.A = nullptr;
     prof_scope ps(s, "gemm_reduce", 0);
-    gemm_reduce((const float *) s.c->gemm_partial, s.pr.nsplit, s.pr.resid, s.pr.resid_cs, (float *) A->data, A->nb[1], A->ne[0], A->ne[1], s.st);
+    gemm_reduce2((const float *) s.c->gemm_partial, s.pr.nsplit, s.pr.resid, s.pr.resid_cs, s.pr.resid2, s.pr.resid2_cs, (float *) A->data, A->nb[1], A->ne[0], A->ne[1], s.st);
     ++s.n_kernels;
 }
 // Q4_K / Q6_K weights with NO resident F16 image (MI355X_NO_F16_SHADOW, the image budget spent, out of memory): the GEMM de-quantises the blocks
@@ -553,9 +553,30 @@ static bool exec_gemm_group(exec_state & s, int i) {
     }
     // a streaming encoder chunk (<= 128 columns: split K, the result goes through the reduction launch): linear -> + bias -> + residual stream.  The second ADD
     // (only reader of the first, same shape, its other operand ready) rides in the reduction's epilogue too: (acc + bias) + residual, the two roundings of the two nodes.
+    // ... and so does the GELU behind the bias of fc1 (linear -> + bias -> GELU -> fc2, the only reader chain): the reduction applies it and writes the f16 image fc2 reads; the f32
+    // rows only when somebody else reads them
+    int un_idx = -1; const ggml_tensor * un_x = nullptr;
+    static const bool no_act = getenv("MI355X_NO_GEMM_ACT") != nullptr;
+    if (!no_act && a.nmat == 1 && add_idx[0] >= 0 && a.m[0].resid_cs == 0 && N <= 128 && gemm_f16_small_n_ksplit(a) > 1) {
+        const ggml_tensor * A = g->nodes[add_idx[0]];
+        const int u = sole_user(s, A);
+        if (u > add_idx[0] && !s.done[u] && next_real_node(s, add_idx[0]) == u && g->nodes[u]->op == GGML_OP_UNARY && !is_out(s, A)) {
+            const ggml_tensor * U = g->nodes[u];
+            const int uop = op_param_i32(U, 0);
+            const ggml_tensor * xg = nullptr;
+            if ((uop == GGML_UNARY_OP_GELU || uop == GGML_UNARY_OP_GELU_QUICK) && U->src[0] == A && U->type == GGML_TYPE_F32 && same_shape(U, A) && U->ne[2] == 1 && U->ne[3] == 1 && U->ne[0] % 8 == 0 &&
+                U->nb[0] == 4 && U->nb[1] == (size_t) U->ne[0] * 4 && ((uintptr_t) U->data & 15) == 0 && gemm_only_consumers(s, U, U->ne[0], U->ne[1], &xg)) {
+                const int u1 = sole_user(s, U);
+                a.m[0].unary = uop; a.m[0].y16 = (uint16_t *) s.c->act_scratch; a.m[0].y16_rs = act_image_bytes(ACT_F16, U->ne[0]);
+                a.m[0].y32 = !(u1 > u && next_real_node(s, u) == u1);
+                a.m[0].dst = (float *) U->data; a.m[0].dst_cs = U->nb[1];
+                un_idx = u; un_x = xg;
+            }
+        }
+    }
     int add2_idx[3] = { -1, -1, -1 };
     static const bool no_add2 = getenv("MI355X_NO_GEMM_ADD2") != nullptr;
-    if (!no_add2 && N <= 128 && gemm_f16_small_n_ksplit(a) > 1)
+    if (!no_add2 && un_idx < 0 && N <= 128 && gemm_f16_small_n_ksplit(a) > 1)
         for (int q = 0; q < a.nmat; ++q) {
             if (add_idx[q] < 0 || a.m[q].resid_cs != 0) continue;                       // (first addend: a bias row)
             ggml_tensor * A = g->nodes[add_idx[q]];
@@ -578,20 +599,31 @@ static bool exec_gemm_group(exec_state & s, int i) {
     for (int q = 0; q < a.nmat; ++q) flops += 2.0 * (double) a.m[q].M * (double) N * (double) K;
     // a split-K result whose next reader is RMS_NORM (wo / ffn_down + residual -> the next norm): leave the slabs, the norm reduces them
     int nsplit = 0;
-    const ggml_tensor * Aout = a.nmat == 1 ? g->nodes[add_idx[0] >= 0 ? add_idx[0] : i] : nullptr;
+    const ggml_tensor * Aout = a.nmat == 1 ? g->nodes[add2_idx[0] >= 0 ? add2_idx[0] : (add_idx[0] >= 0 ? add_idx[0] : i)] : nullptr;
     static const bool no_defer_reduce = getenv("MI355X_NO_REDUCE_IN_NORM") != nullptr;
-    if (!no_defer_reduce && a.partial && !gemm_f16_sk_ok(a) && Aout && Aout->ne[2] == 1 && Aout->ne[3] == 1 && gemm_reduce_rms_norm_ok(Aout->ne[0]) && Aout->nb[1] % 16 == 0 &&
+    if (!no_defer_reduce && un_idx < 0 && a.partial && !gemm_f16_sk_ok(a) && Aout && Aout->ne[2] == 1 && Aout->ne[3] == 1 && gemm_reduce_rms_norm_ok(Aout->ne[0]) && Aout->nb[1] % 16 == 0 &&
         (!a.m[0].resid || a.m[0].resid_cs % 16 == 0)) {
-        int nx = (add_idx[0] >= 0 ? add_idx[0] : i) + 1;
-        while (nx < g->n_nodes && (s.done[nx] || is_noop(g->nodes[nx]) || nx == add_idx[0])) ++nx;
+        int nx = (add2_idx[0] >= 0 ? add2_idx[0] : (add_idx[0] >= 0 ? add_idx[0] : i)) + 1;
+        while (nx < g->n_nodes && (s.done[nx] || is_noop(g->nodes[nx]) || nx == add_idx[0] || nx == add2_idx[0])) ++nx;
         if (nx < g->n_nodes && g->nodes[nx]->op == GGML_OP_RMS_NORM && g->nodes[nx]->src[0] == Aout && add2_idx[0] < 0) a.deferred_split = &nsplit;
+        // ... or a LayerNorm (the encoders' wo / fc2 + bias + residual -> ln): k_norm_rows sums the slabs and both addends itself (exec_norm decides; it falls back to the
+        // reduction launch when it cannot take the row)
+        static const bool no_defer_ln = getenv("MI355X_NO_REDUCE_IN_LAYER_NORM") != nullptr;
+        if (!no_defer_ln && nx < g->n_nodes && g->nodes[nx]->op == GGML_OP_NORM && g->nodes[nx]->src[0] == Aout && Aout->ne[0] <= 4096 && Aout->ne[1] >= 2 &&
+            (!a.m[0].resid2 || a.m[0].resid2_cs % 16 == 0)) a.deferred_split = &nsplit;
     }
     {
         prof_scope ps(s, "gemm_f16", flops);
         gemm_f16_multi(a, s.st);
     }
     ++s.n_kernels;
-    if (nsplit > 1) { s.pr.A = Aout; s.pr.nsplit = nsplit; s.pr.resid = a.m[0].resid; s.pr.resid_cs = a.m[0].resid_cs; }
+    if (nsplit > 1) { s.pr.A = Aout; s.pr.nsplit = nsplit; s.pr.resid = a.m[0].resid; s.pr.resid_cs = a.m[0].resid_cs; s.pr.resid2 = a.m[0].resid2; s.pr.resid2_cs = a.m[0].resid2_cs; }
+    if (un_idx >= 0) {                                          // (the bias ADD's rows are never written: its one reader ran in the reduction)
+        s.done[add_idx[0]] = 1; s.done[un_idx] = 1; s.n_fused += 2;
+        note_write(s, g->nodes[un_idx]);
+        seed_act_f16(s, un_x);
+        return true;
+    }
     for (int q = 0; q < a.nmat; ++q) {
         if (q > 0) { s.done[mm_idx[q]] = 1; ++s.n_fused; }
         if (add2_idx[q] >= 0) { s.done[add_idx[q]] = 1; s.done[add2_idx[q]] = 1; s.n_fused += 2; note_write(s, g->nodes[add2_idx[q]]); }
@@ -893,8 +925,17 @@ static bool exec_norm(exec_state & s, int i) {
     // the f32 rows may be skipped only when the single reader is the very next launch (the image is still in the scratch then)
     const int u1 = emit16 ? sole_user(s, out) : -1;
     const bool w32 = !(emit16 && u1 > last && next_real_node(s, last) == u1);
+    // the rows still lie as split-K slabs of the mat-mul in front (+ bias / residual): summed, written and normalised in this launch
+    const bool from_split = s.pr.A && s.pr.A == n->src[0];
+    if (from_split && !norm_rows_from_split_ok(td(n->src[0]), td(out), s.pr.nsplit, s.pr.resid_cs, s.pr.resid2_cs, s.pr.resid, s.pr.resid2, s.c->gemm_partial)) materialise_reduce(s);
     {
         prof_scope ps(s, "norm", 0);
+        if (s.pr.A && s.pr.A == n->src[0]) {
+            norm_rows_from_split(td(n->src[0]), td(out), op_param_f32(n, 0), (const float *) wt->data, bt ? (const float *) bt->data : nullptr,
+                                 emit16 ? (uint16_t *) s.c->act_scratch : nullptr, emit16 ? act_image_bytes(ACT_F16, out->ne[0]) : 0, w32,
+                                 (const float *) s.c->gemm_partial, s.pr.nsplit, (size_t) n->src[0]->ne[0] * (size_t) n->src[0]->ne[1], s.pr.resid, s.pr.resid_cs, s.pr.resid2, s.pr.resid2_cs, s.st);
+            s.pr.A = nullptr; ++s.n_fused;
+        } else
         norm_rows_f32(td(n->src[0]), td(out), op_param_f32(n, 0), (const float *) wt->data, bt ? (const float *) bt->data : nullptr,
                       emit16 ? (uint16_t *) s.c->act_scratch : nullptr, emit16 ? act_image_bytes(ACT_F16, out->ne[0]) : 0, w32, s.st);
     }
@@ -1474,7 +1515,7 @@ static void compute_node(exec_state & s, int i) {
     ggml_cgraph * g = s.g;
     ggml_tensor * n = g->nodes[i];
     if (is_noop(n)) return;
-    if (s.pr.A && !(n->op == GGML_OP_RMS_NORM && n->src[0] == s.pr.A)) materialise_reduce(s);      // somebody else reads the split-K result first
+    if (s.pr.A && !((n->op == GGML_OP_RMS_NORM || n->op == GGML_OP_NORM) && n->src[0] == s.pr.A)) materialise_reduce(s);      // somebody else reads the split-K result first
 
     switch (n->op) {
         case GGML_OP_MUL_MAT:
@@ -1512,6 +1553,7 @@ static void compute_node(exec_state & s, int i) {
         }
         case GGML_OP_NORM: {
             if (exec_norm(s, i)) return;
+            if (s.pr.A) materialise_reduce(s);
             prof_scope ps(s, "norm", 0);
             norm_f32(td(n->src[0]), td(n), op_param_f32(n, 0), s.st); ++s.n_kernels;
             break;

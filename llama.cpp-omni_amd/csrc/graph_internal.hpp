@@ -71,7 +71,7 @@ struct exec_state {
              bool sm = false; int sm_soft = -1, sm_mm2 = -1, sm_cont = -1; attn_sm_args sma; } pq;   // sm: the flash-attention-off form, `fa` = its first MUL_MAT
     // deferred split-K reduction: `A` (the mat-mul + residual result) still lies as `nsplit` slabs in gemm_partial; the RMS_NORM that
     // reads it next folds the reduction in (gemm_reduce_rms_norm), anything else materialises it first
-    struct { const ggml_tensor * A = nullptr; int nsplit = 0; const float * resid = nullptr; size_t resid_cs = 0; } pr;
+    struct { const ggml_tensor * A = nullptr; int nsplit = 0; const float * resid = nullptr; size_t resid_cs = 0; const float * resid2 = nullptr; size_t resid2_cs = 0; } pr;   // (resid2: only in front of a LayerNorm)
     // (pos, rope parameters) whose (cos, sin) table currently sits in rope_scratch (prefill: shared by every layer of the graph)
     struct { const void * pos = nullptr; const void * ff = nullptr; int T = 0, D = 0; rope_params rp; } rt;
     // mask whose tile map currently sits in fa_scratch

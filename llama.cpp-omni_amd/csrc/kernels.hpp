@@ -115,6 +115,10 @@ void pool_f32(const tdesc & x, int x_type, const tdesc & y, const int32_t * p, b
 void norm_f32(const tdesc & x, const tdesc & y, float eps, hipStream_t st);
 bool norm_rows_ok(const tdesc & x, const tdesc & y);                      // many 16-byte aligned rows of at most 4096 elements: the wave-per-row kernel
 void norm_rows_f32(const tdesc & x, const tdesc & y, float eps, const float * w, const float * b, uint16_t * y16, size_t y16_rs, bool write_f32, hipStream_t st);   // + MUL w, ADD b, f16 image
+long norm_from_split_launches();
+bool norm_rows_from_split_ok(const tdesc & x, const tdesc & y, int nsplit, size_t resid_cs, size_t resid2_cs, const void * resid, const void * resid2, const void * part);
+void norm_rows_from_split(const tdesc & x, const tdesc & y, float eps, const float * w, const float * b, uint16_t * y16, size_t y16_rs, bool write_f32,
+                          const float * part, int nsplit, size_t split_elems, const float * resid, size_t resid_cs, const float * resid2, size_t resid2_cs, hipStream_t st);   // x = split-K slabs + addends, written, then the LayerNorm
 // ROPE f32 (ops.cpp:5534-5720): modes NORMAL / NEOX, optional freq factors, YaRN
 struct rope_params {
     int   n_dims, mode, n_ctx_orig;
@@ -247,7 +251,10 @@ void gemm_f16_mfma(const uint16_t * W, size_t w_rs, const uint16_t * X, size_t x
 // under-filled matrix when `partial` scratch (gemm_split_scratch_bytes) is supplied -- deterministic split-K
 struct gemm_mat { const uint16_t * W; size_t w_rs; float * dst; size_t dst_cs; int64_t M; const float * resid; size_t resid_cs;
                   int qtype = 0;
-                  const float * resid2 = nullptr; size_t resid2_cs = 0; };    // a second addend behind the first (an encoder's bias, then the residual stream): (acc + resid) + resid2, each an f32 rounding like the two ADD nodes       // qtype != 0 (GGML_TYPE_Q4_K / Q6_K): W points at the block rows, de-quantised inside the GEMM's staging (all matrices of a launch alike; forces 128-row tiles)
+                  const float * resid2 = nullptr; size_t resid2_cs = 0;       // a second addend behind the first (an encoder's bias, then the residual stream): (acc + resid) + resid2, each an f32
+                  // split-K launches of at most 128 columns only (gemm_f16_small_n_ksplit() > 1): a GELU / GELU_QUICK (GGML_UNARY_OP_*, -1 = none) applied to the reduced value in the
+                  // reduction's epilogue, its f16 rows written to y16 (the activation image of the next mat-mul), the f32 rows to dst only when y32
+                  int unary = -1; uint16_t * y16 = nullptr; size_t y16_rs = 0; bool y32 = true; };   // rounding like the two ADD nodes       // qtype != 0 (GGML_TYPE_Q4_K / Q6_K): W points at the block rows, de-quantised inside the GEMM's staging (all matrices of a launch alike; forces 128-row tiles)
 struct gemm_multi_args {
     gemm_mat m[3]; int nmat; const uint16_t * X; size_t x_rs; int64_t N, K; float * partial; size_t partial_bytes = (size_t) -1;
     // broadcast batch (nmat == 1, K % 64 == 0): nbatch = ne12 * ne13 products in one launch; batch b = i13 * ne12 + i12 reads
@@ -270,6 +277,7 @@ int    gemm_sk_groups();                                          // CUs of the 
 void   gemm_rf_set_mode(int m);                                   // -1: MI355X_GEMM_RF decides, 0 off, 2 / 4: k_gemm_f16_rf<depth> where legal
 void   gemm_sk_set_mode(int m);                                   // -1: MI355X_GEMM_SK decides (default off), 0 off, 1 wherever legal, 2 by the shape rule
 void   gemm_reduce(const float * partial, int nsplit, const float * resid, size_t resid_cs, float * dst, size_t dst_cs, int64_t M, int64_t N, hipStream_t st);
+void   gemm_reduce2(const float * partial, int nsplit, const float * resid, size_t resid_cs, const float * resid2, size_t resid2_cs, float * dst, size_t dst_cs, int64_t M, int64_t N, hipStream_t st);
 // the same reduction fused with the RMS_NORM -> MUL(w) of the result: dst = sum + resid (f32); y = rms_norm(dst) * w -> y32 / f16 rows y16
 bool   gemm_reduce_rms_norm_ok(int64_t M);
 void   gemm_reduce_rms_norm(const float * partial, int nsplit, const float * resid, size_t resid_cs, float * dst, size_t dst_cs, const float * w, float eps,

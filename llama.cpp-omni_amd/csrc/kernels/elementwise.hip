@@ -2,6 +2,7 @@
 // Each kernel restates one `ggml_compute_forward_*` of the reference CPU backend
 // (ggml/src/ggml-cpu/ops.cpp); the line ranges are cited per kernel.
 #include "../kernels.hpp"
+#include "act_dev.hpp"
 #include <float.h>
 
 namespace mi {
@@ -396,8 +397,13 @@ __global__ void __launch_bounds__(1024) k_norm(td4 x, td4 y, float eps) {
 // many rows (the encoders' [n_state, n_tokens] activations): one WAVE per row, the row in registers, both double sums folded across the wave
 // w / b != null: the MUL by the norm weight and the ADD of the norm bias that follow a LayerNorm in the encoders (three roundings to f32, as the
 // separate ops do: no contraction into a fused multiply-add); y16 != null: also (or, with y.p == null, only) the f16-rounded row for the GEMM
+// sp.part != null: the row does not lie in memory yet -- it is the sum of `nsplit` split-K slabs of the GEMM in front (dense [rows][n] blocks, `split_elems` floats apart) plus up
+// to two addends (a bias row with stride 0, the residual), added in k_gemm_reduce_multi's order (slab 0 + slab 1 + ... + addend 1 + addend 2), written to x (the ADD's result,
+// the next residual) and normalised from the registers: the reduction launch between a split mat-mul and the LayerNorm behind it (wo / fc2 of an encoder layer) is gone
+struct norm_split_src { const float * part; int nsplit; size_t split_elems; const char * resid; size_t resid_cs; const char * resid2; size_t resid2_cs; };
 template <int MAXV>
-__global__ void __launch_bounds__(256) k_norm_rows(td4 x, td4 y, float eps, int64_t nrows, const float * __restrict__ w, const float * __restrict__ b, char * __restrict__ y16, int64_t y16_rs) {
+__global__ void __launch_bounds__(256) k_norm_rows(td4 x, td4 y, float eps, int64_t nrows, const float * __restrict__ w, const float * __restrict__ b, char * __restrict__ y16, int64_t y16_rs,
+                                                   const norm_split_src sp) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t) blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= nrows) return;
@@ -408,11 +414,58 @@ __global__ void __launch_bounds__(256) k_norm_rows(td4 x, td4 y, float eps, int6
     const int n = (int) x.ne[0];
     f32x4 v[MAXV];
     double s = 0.0;
+    if (MAXV <= 4 && sp.part) {
+        // (rows of at most 1024: every slab's and addend's piece of all the lane's quads requested before the first addition -- a streaming chunk is ~50 rows = 50 waves on the
+        //  whole chip, and four dependent round trips per wave made the folded launch cost what the reduction launch had cost)
+        f32x4 sl[MAXV][8], r1[MAXV], r2[MAXV];
+#pragma unroll
+        for (int k = 0; k < MAXV; ++k) {
+            const int i = (lane + 64 * k) * 4;
+            const float * p = sp.part + (size_t) row * n + i;
+#pragma unroll
+            for (int t = 0; t < 8; ++t) sl[k][t] = (i < n && t < sp.nsplit) ? *(const f32x4 *) (p + t * sp.split_elems) : f32x4{ 0.0f, 0.0f, 0.0f, 0.0f };
+            r1[k] = (i < n && sp.resid)  ? *(const f32x4 *) (sp.resid  + (size_t) row * sp.resid_cs  + (size_t) i * 4) : f32x4{ 0.0f, 0.0f, 0.0f, 0.0f };
+            r2[k] = (i < n && sp.resid2) ? *(const f32x4 *) (sp.resid2 + (size_t) row * sp.resid2_cs + (size_t) i * 4) : f32x4{ 0.0f, 0.0f, 0.0f, 0.0f };
+        }
+#pragma unroll
+        for (int k = 0; k < MAXV; ++k) {
+            const int i = (lane + 64 * k) * 4;
+            v[k] = f32x4{ 0.0f, 0.0f, 0.0f, 0.0f };
+            if (i < n) {
+                f32x4 a = sl[k][0];
+#pragma unroll
+                for (int t = 1; t < 8; ++t) if (t < sp.nsplit) a += sl[k][t];
+                if (sp.resid)  a += r1[k];
+                if (sp.resid2) a += r2[k];
+                *(f32x4 *) (const_cast<char *>(xr) + (size_t) i * 4) = a;
+                v[k] = a;
+                s += (double) a[0] + (double) a[1] + (double) a[2] + (double) a[3];
+            }
+        }
+    } else
 #pragma unroll
     for (int k = 0; k < MAXV; ++k) {
         const int i = (lane + 64 * k) * 4;
         v[k] = f32x4{ 0.0f, 0.0f, 0.0f, 0.0f };
-        if (i < n) { v[k] = *(const f32x4 *) (xr + (size_t) i * 4); s += (double) v[k][0] + (double) v[k][1] + (double) v[k][2] + (double) v[k][3]; }
+        if (i < n) {
+            if (sp.part) {                                           // (launcher: x is 2-D here, row = its second index)
+                const float * p = sp.part + (size_t) row * n + i;
+                f32x4 sl[8];
+#pragma unroll
+                for (int t = 0; t < 8; ++t) sl[t] = t < sp.nsplit ? *(const f32x4 *) (p + t * sp.split_elems) : f32x4{ 0.0f, 0.0f, 0.0f, 0.0f };
+                f32x4 r1 = f32x4{ 0.0f, 0.0f, 0.0f, 0.0f }, r2 = f32x4{ 0.0f, 0.0f, 0.0f, 0.0f };
+                if (sp.resid)  r1 = *(const f32x4 *) (sp.resid  + (size_t) row * sp.resid_cs  + (size_t) i * 4);
+                if (sp.resid2) r2 = *(const f32x4 *) (sp.resid2 + (size_t) row * sp.resid2_cs + (size_t) i * 4);
+                f32x4 a = sl[0];
+#pragma unroll
+                for (int t = 1; t < 8; ++t) if (t < sp.nsplit) a += sl[t];
+                if (sp.resid)  a += r1;
+                if (sp.resid2) a += r2;
+                *(f32x4 *) (const_cast<char *>(xr) + (size_t) i * 4) = a;
+                v[k] = a;
+            } else v[k] = *(const f32x4 *) (xr + (size_t) i * 4);
+            s += (double) v[k][0] + (double) v[k][1] + (double) v[k][2] + (double) v[k][3];
+        }
     }
     s = wave_sum<double>(s);
     const float mean = (float) s / (float) n;
@@ -459,9 +512,30 @@ void norm_rows_f32(const tdesc & x, const tdesc & y, float eps, const float * w,
     if (!norm_rows_ok(x, y) || ((uintptr_t) w & 15) || ((uintptr_t) b & 15) || (y16 && (y16_rs % 8 != 0 || ((uintptr_t) y16 & 7) != 0)) || (!write_f32 && !y16)) { fprintf(stderr, "[mi355x] norm_rows_f32: unsupported arguments\n"); abort(); }
     td4 yd = to_td4(y); if (!write_f32) yd.p = nullptr;
     const dim3 grid((unsigned) ((nrows + 3) / 4));
-    if (n <= 1024)      k_norm_rows<4><<<grid, dim3(256), 0, st>>>(to_td4(x), yd, eps, nrows, w, b, (char *) y16, (int64_t) y16_rs);
-    else if (n <= 2048) k_norm_rows<8><<<grid, dim3(256), 0, st>>>(to_td4(x), yd, eps, nrows, w, b, (char *) y16, (int64_t) y16_rs);
-    else                k_norm_rows<16><<<grid, dim3(256), 0, st>>>(to_td4(x), yd, eps, nrows, w, b, (char *) y16, (int64_t) y16_rs);
+    const norm_split_src sp = { nullptr, 0, 0, nullptr, 0, nullptr, 0 };
+    if (n <= 1024)      k_norm_rows<4><<<grid, dim3(256), 0, st>>>(to_td4(x), yd, eps, nrows, w, b, (char *) y16, (int64_t) y16_rs, sp);
+    else if (n <= 2048) k_norm_rows<8><<<grid, dim3(256), 0, st>>>(to_td4(x), yd, eps, nrows, w, b, (char *) y16, (int64_t) y16_rs, sp);
+    else                k_norm_rows<16><<<grid, dim3(256), 0, st>>>(to_td4(x), yd, eps, nrows, w, b, (char *) y16, (int64_t) y16_rs, sp);
+}
+// the same with the rows still lying as split-K slabs (+ up to two addends): x = slabs + addends is written, then normalised
+static long g_norm_from_split_launches = 0;
+long norm_from_split_launches() { return g_norm_from_split_launches; }
+bool norm_rows_from_split_ok(const tdesc & x, const tdesc & y, int nsplit, size_t resid_cs, size_t resid2_cs, const void * resid, const void * resid2, const void * part) {
+    return norm_rows_ok(x, y) && x.ne[2] == 1 && x.ne[3] == 1 && nsplit >= 1 && nsplit <= 8 && resid_cs % 16 == 0 && resid2_cs % 16 == 0 &&
+           ((uintptr_t) resid & 15) == 0 && ((uintptr_t) resid2 & 15) == 0 && ((uintptr_t) part & 15) == 0;
+}
+void norm_rows_from_split(const tdesc & x, const tdesc & y, float eps, const float * w, const float * b, uint16_t * y16, size_t y16_rs, bool write_f32,
+                          const float * part, int nsplit, size_t split_elems, const float * resid, size_t resid_cs, const float * resid2, size_t resid2_cs, hipStream_t st) {
+    const int64_t n = x.ne[0], nrows = x.ne[1];
+    if (!norm_rows_from_split_ok(x, y, nsplit, resid_cs, resid2_cs, resid, resid2, part) || ((uintptr_t) w & 15) || ((uintptr_t) b & 15) ||
+        (y16 && (y16_rs % 8 != 0 || ((uintptr_t) y16 & 7) != 0)) || (!write_f32 && !y16)) { fprintf(stderr, "[mi355x] norm_rows_from_split: unsupported arguments\n"); abort(); }
+    td4 yd = to_td4(y); if (!write_f32) yd.p = nullptr;
+    const dim3 grid((unsigned) ((nrows + 3) / 4));
+    const norm_split_src sp = { part, nsplit, split_elems, (const char *) resid, resid_cs, (const char *) resid2, resid2_cs };
+    ++g_norm_from_split_launches;
+    if (n <= 1024)      k_norm_rows<4><<<grid, dim3(256), 0, st>>>(to_td4(x), yd, eps, nrows, w, b, (char *) y16, (int64_t) y16_rs, sp);
+    else if (n <= 2048) k_norm_rows<8><<<grid, dim3(256), 0, st>>>(to_td4(x), yd, eps, nrows, w, b, (char *) y16, (int64_t) y16_rs, sp);
+    else                k_norm_rows<16><<<grid, dim3(256), 0, st>>>(to_td4(x), yd, eps, nrows, w, b, (char *) y16, (int64_t) y16_rs, sp);
 }
 void norm_f32(const tdesc & x, const tdesc & y, float eps, hipStream_t st) {
     if (x.ne[0] == 0 || x.ne[1] * x.ne[2] * x.ne[3] == 0) return;
@@ -695,16 +769,7 @@ static __device__ __forceinline__ float op_silu(float x) { return x / (1.0f + ex
 // tables filled in ggml-cpu.c:3555-3556 with f16(ggml_gelu_f32(f)) for every f16 value f): the argument is rounded to f16, the formula evaluated in
 // f32 and the result rounded to f16 -- evaluated here instead of looked up (same value unless the device tanhf / expf differs from glibc's by more
 // than the f16 rounding absorbs); GELU short-cuts x <= -10 to 0 and x >= 10 to x before the table.
-static __device__ __forceinline__ float op_gelu(float x) {
-    if (x <= -10.0f) return 0.0f;
-    if (x >= 10.0f)  return x;
-    const float f = h2f(f2h(x));
-    return h2f(f2h(0.5f * f * (1.0f + tanhf(0.79788456080286535587989211986876f * f * (1.0f + 0.044715f * f * f)))));
-}
-static __device__ __forceinline__ float op_gelu_quick(float x) {
-    const float f = h2f(f2h(x));
-    return h2f(f2h(f * (1.0f / (1.0f + expf(-1.702f * f)))));
-}
+// (op_gelu / op_gelu_quick: kernels/act_dev.hpp -- the split-K reduction applies them too)
 static __device__ __forceinline__ float op_gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 
 __global__ void __launch_bounds__(256) k_glu(int op, const char * __restrict__ a, int64_t a_rs, const char * __restrict__ b, int64_t b_rs,

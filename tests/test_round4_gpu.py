@@ -487,3 +487,77 @@ def test_register_ring_gemm_is_bit_identical_to_the_lds_dma_form(pkg, be):
             c.free()
     finally:
         be.set_option("gemm_rf", -1)
+
+
+@pytest.mark.parametrize("E,F,N,two_addends", [(1024, 4096, 50, True), (1024, 1024, 100, True), (1152, 4304 - 16, 64, True), (1024, 4096, 50, False)])
+def test_split_k_reduction_inside_the_layer_norm_vs_reference_backend(pkg, be, ref_be, E, F, N, two_addends):
+    """An encoder layer's tail as the graphs spell it: x1 = W . h + bias + x0 (fc2 / wo of a streaming audio chunk: few columns, so the mat-mul is split along K),
+    y = LayerNorm(x1) * w + b, z = W2 . y, r = z + x1.  The split-K slabs, the bias and the residual are summed by the LayerNorm launch itself (k_norm_rows with a
+    norm_split_src: no reduction launch in between), x1 is still written for the later residual.  Against the reference CPU backend, and bit-identical to the same graph
+    with the fold switched off (MI355X_NO_REDUCE_IN_LAYER_NORM is read once per process: the un-folded arithmetic is reached here through a second reader of x1 BEFORE the
+    norm, which forces the reduction launch)."""
+    from conftest import nmse
+    rng = np.random.default_rng(E + F + N)
+
+    def make(force_materialise):
+        def build(c):
+            h = c.new_tensor(pkg.GGML_TYPE_F32, F, N); x0 = c.new_tensor(pkg.GGML_TYPE_F32, E, N)
+            W = c.new_tensor(pkg.GGML_TYPE_F16, F, E); bias = c.new_tensor(pkg.GGML_TYPE_F32, E)
+            lw = c.new_tensor(pkg.GGML_TYPE_F32, E); lb = c.new_tensor(pkg.GGML_TYPE_F32, E); W2 = c.new_tensor(pkg.GGML_TYPE_F16, E, 256)
+            x1 = c.add(c.mul_mat(W, h), bias)
+            if two_addends:
+                x1 = c.add(x1, x0)
+            outs = []
+            if force_materialise:
+                outs.append(c.scale(x1, 1.0))                         # a reader of x1 in front of the norm
+            y = c.add(c.mul(c.norm(x1, 1e-5), lw), lb)
+            z = c.mul_mat(W2, y)
+            outs = [z, c.scale(x1, 2.0)] + outs
+            return dict(h=h, x0=x0, W=W, bias=bias, lw=lw, lb=lb, W2=W2), outs
+        return build
+    feeds = dict(h=rng.standard_normal(F * N).astype(np.float32), x0=rng.standard_normal(E * N).astype(np.float32),
+                 W=(rng.standard_normal(E * F) / np.sqrt(F)).astype(np.float16), bias=(0.1 * rng.standard_normal(E)).astype(np.float32),
+                 lw=(1 + 0.2 * rng.standard_normal(E)).astype(np.float32), lb=(0.1 * rng.standard_normal(E)).astype(np.float32),
+                 W2=(rng.standard_normal(E * 256) / np.sqrt(E)).astype(np.float16))
+    from test_prefill_kernels_gpu import _both
+    f0 = be.get_stat("norm_from_split_launches")
+    got, want = _both(pkg, be, ref_be, make(False), feeds)
+    assert be.get_stat("norm_from_split_launches") == f0 + 1            # the LayerNorm launch took the slabs
+    got2, _ = _both(pkg, be, be, make(True), feeds)
+    assert be.get_stat("norm_from_split_launches") == f0 + 1            # ... and did not when x1 has a reader in front of it
+    for g_, w_ in zip(got, want):
+        assert np.isfinite(g_).all()
+        assert nmse(g_, w_) < 1e-9, nmse(g_, w_)
+    assert np.array_equal(got[0].view(np.uint32), got2[0].view(np.uint32))       # same bits with and without the fold
+    assert np.array_equal(got[1].view(np.uint32), got2[1].view(np.uint32))
+
+
+@pytest.mark.parametrize("E,F,N,op", [(1024, 4096, 50, "gelu"), (1152, 4304, 64, "gelu"), (1024, 4096, 100, "gelu_quick"), (1024, 512, 7, "gelu")])
+def test_gelu_in_the_split_k_reduction_vs_reference_backend(pkg, be, ref_be, E, F, N, op):
+    """An encoder's MLP on a streaming chunk: fc1 . y + bias -> GELU -> fc2.  fc1 has few columns, so it is split along K; the reduction launch adds the bias, applies the GELU
+    (the reference's f16-table form) and writes the f16 activation image fc2 reads -- no unary launch, no f32 block.  Against the reference CPU backend, and bit-identical
+    to the same graph with a second reader of the bias ADD (which keeps the GELU a launch of its own)."""
+    from conftest import nmse
+    from llama_cpp_omni_amd.ggml import UNARY
+    from test_prefill_kernels_gpu import _both
+    rng = np.random.default_rng(E + F + N)
+    uop = UNARY.GELU if op == "gelu" else UNARY.GELU_QUICK
+
+    def make(second_reader):
+        def build(c):
+            y = c.new_tensor(pkg.GGML_TYPE_F32, E, N); W1 = c.new_tensor(pkg.GGML_TYPE_F16, E, F); b1 = c.new_tensor(pkg.GGML_TYPE_F32, F); W2 = c.new_tensor(pkg.GGML_TYPE_F16, F, E)
+            pre = c.add(c.mul_mat(W1, y), b1)
+            z = c.mul_mat(W2, c.unary(pre, uop))
+            return dict(y=y, W1=W1, b1=b1, W2=W2), [z] + ([c.scale(pre, 2.0)] if second_reader else [])
+        return build
+    feeds = dict(y=rng.standard_normal(E * N).astype(np.float32), W1=(rng.standard_normal(E * F) / np.sqrt(E) * 2).astype(np.float16), b1=(0.2 * rng.standard_normal(F)).astype(np.float32),
+                 W2=(rng.standard_normal(E * F) / np.sqrt(F)).astype(np.float16))
+    got, want = _both(pkg, be, ref_be, make(False), feeds)
+    n_folded = be.get_stat("kernels_last_graph")
+    got2, _ = _both(pkg, be, be, make(True), feeds)
+    n_plain = be.get_stat("kernels_last_graph")
+    if F % 64 == 0:                                                    # (fc2 with K = 4304 is not an MFMA-only reader: the GELU stays a launch, the results must still agree)
+        assert n_folded <= n_plain - 2, (n_folded, n_plain)              # (the second reader's launch and the GELU launch)
+    assert np.isfinite(got[0]).all()
+    assert nmse(got[0], want[0]) < 1e-9, nmse(got[0], want[0])
+    assert np.array_equal(got[0].view(np.uint32), got2[0].view(np.uint32))
