@@ -1469,7 +1469,7 @@ static bool exec_attn_sm_prefill(exec_state & s, int i, bool dry) {       // dry
     for (int k = i + 1; k < ci; ++k)
         if (k != smi && k != m2 && !s.done[k] && !is_noop(g->nodes[k])) return false;       // something else runs in between: keep the separate launches
     fattn_args f; tdesc m;
-    f.q = td(fq); f.k = td(fk); f.v = td(fv); f.v_transposed = true; f.kv_type = GGML_TYPE_F16;
+    f.q = td(fq); f.k = td(fk); f.v = s.va.cast == fv ? s.va.v : td(fv); f.v_transposed = true; f.kv_type = GGML_TYPE_F16;
     f.dst = td(C);
     f.dst.ne[0] = D; f.dst.ne[1] = H; f.dst.ne[2] = nq; f.dst.ne[3] = ns;
     f.dst.nb[0] = 4; f.dst.nb[1] = (size_t) D * 4; f.dst.nb[2] = (size_t) D * H * 4; f.dst.nb[3] = (size_t) D * H * nq * 4;
@@ -1505,8 +1505,73 @@ static bool exec_attn_sm_prefill(exec_state & s, int i, bool dry) {       // dry
         flash_attn_ext_f16(f, s.st); ++s.n_kernels;
     }
     s.done[smi] = 1; s.done[m2] = 1; s.done[ci] = 1; s.n_fused += 3;
+    if (s.va.cast == fv) s.va.cast = nullptr;
     note_write(s, C);
     if (xg16) { seed_act_f16(s, xg16); ++s.n_fused; }
+    return true;
+}
+
+// The streaming Whisper graph (audition.cpp:519-607) stores V TRANSPOSED in its cache -- row (h, d) of V^T holds the cells contiguously, kv_size apart -- and then, every
+// chunk, copies the whole window back twice: V_2d_t = CONT(TRANSPOSE(view of the cache)) and V = CAST(PERMUTE(RESHAPE(V_2d_t)), F16), a contiguous [n_kv, D, H] block, which is
+// what the second mat-mul of the attention reads.  Element (kv, d, h) of that block is element (h D + d, kv) of the cache view: exactly the V^T rows the fused soft-max
+// attention stages as they lie (fa_dev::vt).  At the CONT node: if its only reader chain is that CAST and the CAST's only reader is the second mat-mul of a chain
+// exec_attn_sm_prefill accepts with the aliased V, neither copy runs -- 2 launches and 2 x the window per layer and chunk.
+// (the attention was not fused after all -- cannot happen while the dry run and the real one see the same graph state, but a reader of the CAST's block must never find it
+// unwritten: run the two copies now)
+static void materialise_vt(exec_state & s) {
+    ggml_cgraph * g = s.g;
+    const ggml_tensor * C = g->nodes[s.va.cont_i], * K = g->nodes[s.va.cast_i];
+    s.va.cast = nullptr;
+    prof_scope ps(s, "cpy", 0);
+    cpy_strided(td(C->src[0]), C->src[0]->type, td(C), C->type, s.st);
+    cpy_strided(td(K->src[0]), K->src[0]->type, td(K), K->type, s.st);
+    s.n_kernels += 2;
+}
+static bool try_alias_vt(exec_state & s, int i) {
+    static const bool off = getenv("MI355X_NO_ATTN_VT_ALIAS") != nullptr;
+    ggml_cgraph * g = s.g;
+    const ggml_tensor * C = g->nodes[i];
+    if (off || !s.c->opt_fusion || s.va.cast || C->op != GGML_OP_CONT || C->type != GGML_TYPE_F16 || is_out(s, C) || !is_contiguous(C) || C->ne[2] != 1 || C->ne[3] != 1) return false;
+    const ggml_tensor * T = C->src[0];                                  // [n_state, n_kv] with the cells contiguous: nb[1] == 2, nb[0] = the cache's row pitch
+    if (!T || T->type != GGML_TYPE_F16 || T->ne[0] != C->ne[0] || T->ne[1] != C->ne[1] || T->ne[2] != 1 || T->ne[3] != 1 || T->nb[1] != 2 || T->nb[0] < (size_t) T->ne[1] * 2 || T->nb[0] % 2 != 0) return false;
+    const int64_t n_state = C->ne[0], nkv = C->ne[1];
+    int ci = -1;                                                        // the CAST: a CPY whose source is a [n_kv, D, H] view of C, behind the RESHAPE / PERMUTE view nodes
+    { const ggml_tensor * t = C;
+      for (int hop = 0; hop < 4; ++hop) {
+          const int u = sole_user(s, t);
+          if (u < 0) return false;
+          if (g->nodes[u]->op == GGML_OP_CPY) { ci = u; break; }
+          if (!is_noop(g->nodes[u])) return false;
+          t = g->nodes[u];
+      } }
+    if (ci <= i || s.done[ci]) return false;
+    const ggml_tensor * K = g->nodes[ci];
+    const ggml_tensor * P = K->src[0];
+    if (K->op != GGML_OP_CPY || K->type != GGML_TYPE_F16 || is_out(s, K) || !is_contiguous(K) || !P || P->type != GGML_TYPE_F16 || P->data != C->data) return false;
+    { const ggml_tensor * w = P; while (w && w != C) w = w->view_src; if (!w) return false; }
+    const int64_t D = P->ne[1], H = P->ne[2];
+    if (P->ne[0] != nkv || D <= 0 || H <= 0 || D * H != n_state || P->ne[3] != 1 || P->nb[0] != (size_t) n_state * 2 || P->nb[1] != 2 || P->nb[2] != (size_t) D * 2) return false;
+    if (K->ne[0] != nkv || K->ne[1] != D || K->ne[2] != H || K->ne[3] != 1) return false;
+    for (int k = i + 1; k < ci; ++k) if (!s.done[k] && !is_noop(g->nodes[k])) return false;
+    int m2 = -1;                                                        // (ggml_cast names its result as its own src[1]: the CAST is among its own users)
+    { auto uit = s.users.find(K);
+      if (uit == s.users.end() || is_out(s, K)) return false;
+      for (int u : uit->second) { if (u == ci) continue; if (m2 >= 0 && u != m2) return false; m2 = u; } }
+    if (m2 <= ci || s.done[m2]) return false;
+    const ggml_tensor * M2 = g->nodes[m2];
+    if (M2->op != GGML_OP_MUL_MAT || M2->src[0] != K || !M2->src[1] || M2->src[1]->op != GGML_OP_SOFT_MAX) return false;
+    const ggml_tensor * M1 = M2->src[1]->src[0];
+    auto it = M1 ? s.index.find(M1) : s.index.end();
+    if (it == s.index.end() || it->second <= ci || s.done[it->second]) return false;
+    // nothing between the CAST and the attention may write the cache rows (it is read at the attention launch, not here)
+    const byte_range rv = { (const char *) T->data, (const char *) T->data + (size_t) (n_state - 1) * T->nb[0] + (size_t) nkv * 2 };
+    for (int k = ci + 1; k < it->second; ++k) if (!s.done[k] && !is_noop(g->nodes[k]) && overlap(range_of(g->nodes[k]), rv)) return false;
+    s.va.cast = K; s.va.cont_i = i; s.va.cast_i = ci;
+    s.va.v.p = (char *) T->data;
+    s.va.v.ne[0] = nkv; s.va.v.ne[1] = D; s.va.v.ne[2] = H; s.va.v.ne[3] = 1;
+    s.va.v.nb[0] = 2; s.va.v.nb[1] = T->nb[0]; s.va.v.nb[2] = (size_t) D * T->nb[0]; s.va.v.nb[3] = (size_t) n_state * T->nb[0];
+    if (!exec_attn_sm_prefill(s, it->second, true)) { s.va.cast = nullptr; return false; }
+    s.done[ci] = 1; s.n_fused += 2;                                      // (this CONT and the CAST: never launched, their blocks never written)
     return true;
 }
 
@@ -1539,6 +1604,7 @@ static void compute_node(exec_state & s, int i) {
                 return;
             }
             if (exec_attn_sm_prefill(s, i, false)) return;
+            if (s.va.cast && (n->src[0] == s.va.cast || g->nodes[i]->src[1]->op == GGML_OP_SOFT_MAX)) materialise_vt(s);
             exec_mul_mat(s, i);
             return;
         case GGML_OP_IM2COL: {
@@ -1715,6 +1781,7 @@ static void compute_node(exec_state & s, int i) {
             break;
         }
         case GGML_OP_CPY: case GGML_OP_CONT: case GGML_OP_DUP: {
+            if (n->op == GGML_OP_CONT && try_alias_vt(s, i)) return;
             prof_scope ps(s, "cpy", 0);
             const ggml_tensor * src = n->src[0];
             static const bool dbg_cpy = getenv("MI355X_DEBUG_CPY") != nullptr;

@@ -76,6 +76,9 @@ struct exec_state {
     struct { const void * pos = nullptr; const void * ff = nullptr; int T = 0, D = 0; rope_params rp; } rt;
     // mask whose tile map currently sits in fa_scratch
     const void *  fa_mask = nullptr; int64_t fa_dims[4] = {0, 0, 0, 0}; size_t fa_mnb1 = 0;
+    // a V^T that a fused soft-max attention will read where it LIES (a transposed V cache) instead of from the CONT + CAST copies the graph makes of it: `cast` = the CAST node the
+    // attention's second mat-mul names, `v` = the same elements in the cache (try_alias_vt in graph_exec.cpp)
+    struct { const ggml_tensor * cast = nullptr; tdesc v; int cont_i = -1, cast_i = -1; } va;
 };
 
 // ------------------------------------------------------------------------------------------------ profiling
