@@ -595,6 +595,44 @@ static bool exec_gemm_group(exec_state & s, int i) {
             a.m[q].dst = (float *) A2->data; a.m[q].dst_cs = A2->nb[1];
             add2_idx[q] = a2;
         }
+    // ... and the CPY of a streaming encoder's new K / V rows into its f16 cache (audition.cpp:519-556: Kcur -> a contiguous run of the K cache; Vcur (+ bias) -> TRANSPOSE -> a
+    // [n_tokens, n_state] view of the transposed V cache, rows a cache pitch apart): the only reader of the f32 rows, so the reduction writes the f16 cells itself and the f32
+    // rows never exist
+    int cpy_idx[3] = { -1, -1, -1 };
+    static const bool no_cpy16 = getenv("MI355X_NO_GEMM_CPY16") != nullptr;
+    if (!no_cpy16 && un_idx < 0 && N <= 128 && gemm_f16_small_n_ksplit(a) > 1)
+        for (int q = 0; q < a.nmat; ++q) {
+            if (add2_idx[q] >= 0 || a.m[q].M % 4 != 0) continue;
+            const int ri = add_idx[q] >= 0 ? add_idx[q] : mm_idx[q];
+            const ggml_tensor * R = g->nodes[ri];
+            if (is_out(s, R) || R->ne[2] != 1 || R->ne[3] != 1 || R->nb[0] != 4 || R->nb[1] != (size_t) R->ne[0] * 4) continue;
+            const ggml_tensor * t = R; int cj = -1;
+            for (int hop = 0; hop < 5; ++hop) {
+                const int u = sole_user(s, t);
+                if (u < 0) break;
+                if (g->nodes[u]->op == GGML_OP_CPY) { cj = u; break; }
+                if (!is_noop(g->nodes[u])) break;
+                t = g->nodes[u];
+            }
+            if (cj <= ri || s.done[cj]) continue;
+            const ggml_tensor * Cp = g->nodes[cj], * S = Cp->src[0];
+            if (Cp->type != GGML_TYPE_F16 || !S || S->type != GGML_TYPE_F32 || S->data != R->data || nelements(S) != nelements(R) || nelements(Cp) != nelements(R) || is_out(s, Cp)) continue;
+            { const ggml_tensor * w = S; while (w && w != R) w = w->view_src; if (!w) continue; }
+            const int64_t M = R->ne[0];
+            size_t ms = 0, rs = 0;
+            if (is_contiguous(S) && is_contiguous(Cp)) { ms = 2; rs = (size_t) M * 2; }                                                  // same linear order: K rows
+            else if (S->ne[0] == N && S->ne[1] == M && S->ne[2] == 1 && S->ne[3] == 1 && S->nb[0] == R->nb[1] && S->nb[1] == 4 &&
+                     Cp->ne[0] == N && Cp->ne[1] == M && Cp->ne[2] == 1 && Cp->ne[3] == 1 && Cp->nb[0] == 2 && Cp->nb[1] % 2 == 0) { ms = Cp->nb[1]; rs = 2; }   // the transposed view: V rows
+            else continue;
+            if (ms == 2 && (((uintptr_t) Cp->data & 7) != 0 || rs % 8 != 0)) continue;
+            int item[8]; int ni = 0;
+            for (int k = 0; k < a.nmat; ++k) { item[ni++] = mm_idx[k]; if (add_idx[k] >= 0) item[ni++] = add_idx[k]; }
+            for (int k = 0; k < q; ++k) if (cpy_idx[k] >= 0 && ni < 8) item[ni++] = cpy_idx[k];
+            if (!can_hoist(s, i, cj, item, ni)) continue;
+            a.m[q].y16 = (uint16_t *) Cp->data; a.m[q].y16_ms = ms; a.m[q].y16_rs = rs; a.m[q].y32 = false;
+            if (add_idx[q] < 0) { a.m[q].dst = (float *) R->data; a.m[q].dst_cs = R->nb[1]; }
+            cpy_idx[q] = cj;
+        }
     double flops = 0;
     for (int q = 0; q < a.nmat; ++q) flops += 2.0 * (double) a.m[q].M * (double) N * (double) K;
     // a split-K result whose next reader is RMS_NORM (wo / ffn_down + residual -> the next norm): leave the slabs, the norm reduces them
@@ -624,6 +662,7 @@ static bool exec_gemm_group(exec_state & s, int i) {
         seed_act_f16(s, un_x);
         return true;
     }
+    for (int q = 0; q < a.nmat; ++q) if (cpy_idx[q] >= 0) { s.done[cpy_idx[q]] = 1; ++s.n_fused; note_write(s, g->nodes[cpy_idx[q]]); }
     for (int q = 0; q < a.nmat; ++q) {
         if (q > 0) { s.done[mm_idx[q]] = 1; ++s.n_fused; }
         if (add2_idx[q] >= 0) { s.done[add_idx[q]] = 1; s.done[add2_idx[q]] = 1; s.n_fused += 2; note_write(s, g->nodes[add2_idx[q]]); }

@@ -254,7 +254,8 @@ struct gemm_mat { const uint16_t * W; size_t w_rs; float * dst; size_t dst_cs; i
                   const float * resid2 = nullptr; size_t resid2_cs = 0;       // a second addend behind the first (an encoder's bias, then the residual stream): (acc + resid) + resid2, each an f32
                   // split-K launches of at most 128 columns only (gemm_f16_small_n_ksplit() > 1): a GELU / GELU_QUICK (GGML_UNARY_OP_*, -1 = none) applied to the reduced value in the
                   // reduction's epilogue, its f16 rows written to y16 (the activation image of the next mat-mul), the f32 rows to dst only when y32
-                  int unary = -1; uint16_t * y16 = nullptr; size_t y16_rs = 0; bool y32 = true; };   // rounding like the two ADD nodes       // qtype != 0 (GGML_TYPE_Q4_K / Q6_K): W points at the block rows, de-quantised inside the GEMM's staging (all matrices of a launch alike; forces 128-row tiles)
+                  int unary = -1; uint16_t * y16 = nullptr; size_t y16_rs = 0; bool y32 = true; size_t y16_ms = 2; };   // (y16 without unary: the plain f16 copy of the rows -- a K / V cache store -- element (m, n) at y16 + m * y16_ms + n * y16_rs bytes)
+                  //   // rounding like the two ADD nodes       // qtype != 0 (GGML_TYPE_Q4_K / Q6_K): W points at the block rows, de-quantised inside the GEMM's staging (all matrices of a launch alike; forces 128-row tiles)
 struct gemm_multi_args {
     gemm_mat m[3]; int nmat; const uint16_t * X; size_t x_rs; int64_t N, K; float * partial; size_t partial_bytes = (size_t) -1;
     // broadcast batch (nmat == 1, K % 64 == 0): nbatch = ne12 * ne13 products in one launch; batch b = i13 * ne12 + i12 reads

@@ -909,7 +909,7 @@ __global__ void __launch_bounds__(256) k_gemm_reduce(const float * __restrict__ 
 // the same for every matrix of a grouped launch in ONE launch (wq / wk / wv of a short prompt or a streaming encoder chunk: three reductions of a few us each were three
 // dependent launches), with an optional second addend per matrix.  Slab s holds the matrices back to back as dense [N][M_i] blocks; quads never straddle (M_i % 4 == 0).
 struct gemm_reduce_multi_dev { int nmat, nsplit, N; size_t split_elems; size_t off[3]; int M[3]; const char * resid[3]; size_t resid_cs[3]; const char * resid2[3]; size_t resid2_cs[3]; char * dst[3]; size_t dst_cs[3];
-                               int unary[3] = { -1, -1, -1 }; char * y16[3] = { nullptr, nullptr, nullptr }; size_t y16_rs[3] = { 0, 0, 0 }; };      // (unary >= 0: GELU / GELU_QUICK of the value, f16 rows to y16, dst optional)
+                               int unary[3] = { -1, -1, -1 }; char * y16[3] = { nullptr, nullptr, nullptr }; size_t y16_rs[3] = { 0, 0, 0 }; size_t y16_ms[3] = { 2, 2, 2 }; };      // (unary >= 0: GELU / GELU_QUICK of the value, f16 rows to y16, dst optional)
 __global__ void __launch_bounds__(256) k_gemm_reduce_multi(const float * __restrict__ part, const gemm_reduce_multi_dev g) {
     int64_t i = ((int64_t) blockIdx.x * 256 + threadIdx.x) * 4;
     int q = 0;
@@ -928,11 +928,19 @@ __global__ void __launch_bounds__(256) k_gemm_reduce_multi(const float * __restr
     for (int s = 1; s < 8; ++s) if (s < g.nsplit) v += sl[s];
     if (g.resid[q])  v += r1;
     if (g.resid2[q]) v += r2;
-    if (g.unary[q] >= 0) {                                         // the activation behind the bias ADD (an encoder's fc1 -> GELU -> fc2): applied here, f16 image out
+    if (g.y16[q]) {
+        // f16 rows out: behind an activation (an encoder's fc1 -> + bias -> GELU -> fc2: the image fc2 reads), or plain (the CPY of a streaming encoder's K / V rows into
+        // its f16 cache; a transposed V cache has the rows a cache pitch apart: four 2-byte stores)
+        if (g.unary[q] >= 0) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = g.unary[q] == GGML_UNARY_OP_GELU ? op_gelu(v[e]) : op_gelu_quick(v[e]);
-        u32x2 h; h[0] = (uint32_t) f2h(v[0]) | ((uint32_t) f2h(v[1]) << 16); h[1] = (uint32_t) f2h(v[2]) | ((uint32_t) f2h(v[3]) << 16);
-        *(u32x2 *) (g.y16[q] + (size_t) n * g.y16_rs[q] + (size_t) m * 2) = h;
+            for (int e = 0; e < 4; ++e) v[e] = g.unary[q] == GGML_UNARY_OP_GELU ? op_gelu(v[e]) : op_gelu_quick(v[e]);
+        }
+        char * const o = g.y16[q] + (size_t) n * g.y16_rs[q] + (size_t) m * g.y16_ms[q];
+        if (g.y16_ms[q] == 2) { u32x2 h; h[0] = (uint32_t) f2h(v[0]) | ((uint32_t) f2h(v[1]) << 16); h[1] = (uint32_t) f2h(v[2]) | ((uint32_t) f2h(v[3]) << 16); *(u32x2 *) o = h; }
+        else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) *(uint16_t *) (o + (size_t) e * g.y16_ms[q]) = f2h(v[e]);
+        }
         if (!g.dst[q]) return;
     }
     *(f32x4 *) (g.dst[q] + (size_t) n * g.dst_cs[q] + (size_t) m * 4) = v;
@@ -1267,8 +1275,9 @@ void gemm_f16_multi(const gemm_multi_args & a, hipStream_t st) {
     g.ksteps_per_split = (nk + ksplit - 1) / ksplit; g.split_stride = 0;
     if (tm == 0) return;
     for (int i = 0; i < a.nmat; ++i)
-        if (a.m[i].unary >= 0 && (ksplit == 1 || a.deferred_split || (a.m[i].unary != GGML_UNARY_OP_GELU && a.m[i].unary != GGML_UNARY_OP_GELU_QUICK) || !a.m[i].y16 || a.m[i].y16_rs % 8 != 0 || a.m[i].M % 4 != 0)) {
-            fprintf(stderr, "[mi355x] gemm: an activation epilogue needs the split-K reduction launch (ask gemm_f16_small_n_ksplit first), GELU / GELU_QUICK and an 8-byte aligned f16 image\n"); abort();
+        if ((a.m[i].unary >= 0 || a.m[i].y16) && (ksplit == 1 || a.deferred_split || (a.m[i].unary >= 0 && a.m[i].unary != GGML_UNARY_OP_GELU && a.m[i].unary != GGML_UNARY_OP_GELU_QUICK) || !a.m[i].y16 ||
+                                                  (a.m[i].y16_ms == 2 && (a.m[i].y16_rs % 8 != 0 || ((uintptr_t) a.m[i].y16 & 7) != 0)) || a.m[i].y16_ms % 2 != 0 || a.m[i].y16_rs % 2 != 0 || a.m[i].M % 4 != 0)) {
+            fprintf(stderr, "[mi355x] gemm: f16 rows / an activation out of the epilogue need the split-K reduction launch (ask gemm_f16_small_n_ksplit first), GELU / GELU_QUICK and aligned f16 rows\n"); abort();
         }
     // register-ring staging (k_gemm_f16_rf): the plain F16 tile form only (no batch, no K-quant staging, 128-row tiles), operands within 32-bit offsets
     static const int rf_env0 = getenv("MI355X_GEMM_RF") ? atoi(getenv("MI355X_GEMM_RF")) : 0;
@@ -1295,7 +1304,7 @@ void gemm_f16_multi(const gemm_multi_args & a, hipStream_t st) {
             const gemm_mat & m = a.m[i < a.nmat ? i : 0];
             r.off[i] = off; r.M[i] = i < a.nmat ? (int) m.M : 0; r.resid[i] = (const char *) m.resid; r.resid_cs[i] = m.resid_cs; r.resid2[i] = (const char *) m.resid2; r.resid2_cs[i] = m.resid2_cs;
             r.dst[i] = (char *) m.dst; r.dst_cs[i] = m.dst_cs;
-            if (i < a.nmat && m.unary >= 0) { r.unary[i] = m.unary; r.y16[i] = (char *) m.y16; r.y16_rs[i] = m.y16_rs; if (!m.y32) r.dst[i] = nullptr; }
+            if (i < a.nmat && m.y16) { r.unary[i] = m.unary; r.y16[i] = (char *) m.y16; r.y16_rs[i] = m.y16_rs; r.y16_ms[i] = m.y16_ms; if (!m.y32) r.dst[i] = nullptr; }
             if (i < a.nmat) { off += (size_t) m.M * (size_t) a.N; quads += m.M * a.N / 4; }
         }
         if (quads > 0) k_gemm_reduce_multi<<<dim3((unsigned) ((quads + 255) / 256)), dim3(256), 0, st>>>(a.partial, r);

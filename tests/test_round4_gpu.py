@@ -561,3 +561,56 @@ def test_gelu_in_the_split_k_reduction_vs_reference_backend(pkg, be, ref_be, E, 
     assert np.isfinite(got[0]).all()
     assert nmse(got[0], want[0]) < 1e-9, nmse(got[0], want[0])
     assert np.array_equal(got[0].view(np.uint32), got2[0].view(np.uint32))
+
+
+@pytest.mark.parametrize("it,n_tok,kv_size", [(0, 50, 1500), (3, 50, 1500), (1, 100, 750)])
+def test_streaming_encoder_attention_block_vs_reference_backend(pkg, be, ref_be, it, n_tok, kv_size):
+    """One attention block of the streaming Whisper graph as the reference spells it (audition.cpp:455-636), chunk `it` of a stream: q / k / v projections of the chunk's tokens
+    (k without bias), Kcur -> CPY into a contiguous run of the f16 K cache, Vcur -> TRANSPOSE -> CPY into a [n_tok, n_state] view of the TRANSPOSED f16 V cache (rows a cache pitch
+    apart), then K = a view of the cache window, V = CAST(PERMUTE(RESHAPE(CONT(TRANSPOSE(view of the V cache window))))), soft-max attention over the window, wo + bias + residual,
+    LayerNorm.  On the device: the two cache stores are written by the q / k / v reduction launch (no CPY launches, no f32 K / V rows), the CONT + CAST copies of the V window are
+    skipped (the fused attention reads V^T in the cache), the wo reduction runs inside the LayerNorm launch.  Compared with the reference CPU backend: the attention output, the
+    normalised rows and BOTH caches afterwards (cells of earlier chunks untouched, the new cells equal)."""
+    from conftest import nmse
+    from test_prefill_kernels_gpu import _both
+    E, H, D = 1024, 16, 64
+    rng = np.random.default_rng(100 + it + n_tok)
+    tot = (it + 1) * n_tok
+
+    def build(c):
+        F32, F16 = pkg.GGML_TYPE_F32, pkg.GGML_TYPE_F16
+        x = c.new_tensor(F32, E, n_tok); res = c.new_tensor(F32, E, n_tok)
+        W = {k: c.new_tensor(F16, E, E) for k in ("q", "k", "v", "o")}
+        B = {k: c.new_tensor(F32, E) for k in ("q", "v", "o", "lw", "lb")}
+        kc = c.new_tensor(F16, E * kv_size); vc = c.new_tensor(F16, E * kv_size)
+        Q = c.reshape(c.add(c.mul_mat(W["q"], x), B["q"]), D, H, n_tok)
+        Kc = c.reshape(c.mul_mat(W["k"], x), D, H, n_tok)
+        Vc = c.reshape(c.add(c.mul_mat(W["v"], x), B["v"]), D, H, n_tok)
+        st_k = c.cpy(Kc, c.view_1d(kc, n_tok * E, 2 * E * it * n_tok) if hasattr(c, "view_1d") else c.view_2d(kc, n_tok * E, 1, 2 * n_tok * E, 2 * E * it * n_tok))
+        st_v = c.cpy(c.transpose(c.reshape(Vc, E, n_tok)), c.view_2d(vc, n_tok, E, 2 * kv_size, 2 * it * n_tok))
+        K = c.view_3d(kc, D, tot, H, 2 * E, 2 * D, 0)
+        V2t = c.cont(c.transpose(c.view_2d(vc, tot, E, 2 * kv_size, 0)))
+        V = c.cast(c.permute(c.reshape(V2t, D, H, tot), 1, 2, 0, 3), F16)
+        KQ = c.soft_max_ext(c.mul_mat(K, c.permute(Q, 0, 2, 1, 3)), None, 1.0 / 8.0, 0.0)
+        att = c.cont(c.permute(c.mul_mat(V, KQ), 0, 2, 1, 3), E, n_tok)
+        x1 = c.add(c.add(c.mul_mat(W["o"], att), B["o"]), res)
+        y = c.add(c.mul(c.norm(x1, 1e-5), B["lw"]), B["lb"])
+        ins = dict(x=x, res=res, kc=kc, vc=vc, **{"W" + k: v for k, v in W.items()}, **{"B" + k: v for k, v in B.items()})
+        # the stores are graph roots (ggml_build_forward_expand on the CPY nodes) in front of their readers
+        return ins, [st_k, st_v, c.scale(att, 1.0), y, c.scale(x1, 1.0)]      # (a reader each for att and x1: rows only GEMMs / the norm read are not written in f32)
+    feeds = dict(x=rng.standard_normal(E * n_tok).astype(np.float32), res=rng.standard_normal(E * n_tok).astype(np.float32),
+                 kc=(rng.standard_normal(E * kv_size) * 0.5).astype(np.float16), vc=(rng.standard_normal(E * kv_size) * 0.5).astype(np.float16))
+    for k in ("q", "k", "v", "o"):
+        feeds["W" + k] = (rng.standard_normal(E * E) / np.sqrt(E)).astype(np.float16)
+    for k in ("q", "v", "o", "lb"):
+        feeds["B" + k] = (0.1 * rng.standard_normal(E)).astype(np.float32)
+    feeds["Blw"] = (1 + 0.2 * rng.standard_normal(E)).astype(np.float32)
+    f0 = be.get_stat("norm_from_split_launches")
+    got, want = _both(pkg, be, ref_be, build, feeds)
+    launches = be.get_stat("kernels_last_graph")
+    assert be.get_stat("norm_from_split_launches") == f0 + 1
+    assert launches <= 8, launches              # x image, q/k/v GEMM (+ reduction with the two cache stores), attention, wo GEMM, LayerNorm (+ reduction), the two extra readers (+ slack 1)
+    for name, g_, w_ in zip(("k cache run", "v cache view", "attention", "layer norm", "x1"), got, want):
+        g32, w32 = g_.astype(np.float32), w_.astype(np.float32)
+        assert np.isfinite(g32).all(), name
+        assert nmse(g32, w32) < 2e-6, (name, nmse(g32, w32))
