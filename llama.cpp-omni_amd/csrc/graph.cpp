@@ -354,6 +354,7 @@ double mi355x_get_stat(struct ggml_backend * backend, const char * key) {
     if (!strcmp(key, "gemm_glu96_launches")) return (double) mi::gemm_variant_launches(5);
     if (!strcmp(key, "gemm_rf_launches"))   return (double) mi::gemm_variant_launches(6);
     if (!strcmp(key, "norm_from_split_launches")) return (double) mi::norm_from_split_launches();
+    if (!strcmp(key, "norm_rope_split_launches")) return (double) mi::norm_rope_split_launches();
     if (!strcmp(key, "gemm_kq_launches"))   return (double) mi::gemm_variant_launches(3);
     if (!strcmp(key, "gemm_sk_launches"))   return (double) mi::gemm_variant_launches(4);
     if (!strcmp(key, "fattn_dma_launches")) return (double) mi::fattn_dma_launches();

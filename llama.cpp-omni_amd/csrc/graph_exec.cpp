@@ -428,6 +428,19 @@ static void materialise_reduce(exec_state & s) {
     gemm_reduce2((const float *) s.c->gemm_partial, s.pr.nsplit, s.pr.resid, s.pr.resid_cs, s.pr.resid2, s.pr.resid2_cs, (float *) A->data, A->nb[1], A->ne[0], A->ne[1], s.st);
     ++s.n_kernels;
 }
+static void materialise_group(exec_state & s) {
+    float * dst[3] = { nullptr, nullptr, nullptr }; size_t cs[3] = { 0, 0, 0 };
+    for (int q = 0; q < s.prm.n; ++q) { dst[q] = (float *) s.prm.A[q]->data; cs[q] = s.prm.A[q]->nb[1]; }
+    prof_scope ps(s, "gemm_reduce", 0);
+    gemm_reduce_group((const float *) s.c->gemm_partial, s.prm.nsplit, s.prm.n, s.prm.M, s.prm.N, dst, cs, s.st);
+    ++s.n_kernels;
+    s.prm.n = 0;
+}
+static bool reads_pending_group(exec_state & s, const ggml_tensor * n) {          // an RMS_NORM on (a view of) one of the pending grouped results
+    if (n->op != GGML_OP_RMS_NORM || !n->src[0]) return false;
+    for (int q = 0; q < s.prm.n; ++q) if (n->src[0]->data == s.prm.A[q]->data) return true;
+    return false;
+}
 // Q4_K / Q6_K weights with NO resident F16 image (MI355X_NO_F16_SHADOW, the image budget spent, out of memory): the GEMM de-quantises the blocks
 // inside its LDS staging (k_gemm_kq_glds) instead of running a de-quantise-to-scratch launch in front of every mat-mul.  With the image resident
 // the F16 kernel is faster at every column count (the in-staging form spends ~900 VALU cycles per wave and K-step on nibbles, scales and f16
@@ -650,11 +663,37 @@ static bool exec_gemm_group(exec_state & s, int i) {
         if (!no_defer_ln && nx < g->n_nodes && g->nodes[nx]->op == GGML_OP_NORM && g->nodes[nx]->src[0] == Aout && Aout->ne[0] <= 4096 && Aout->ne[1] >= 2 &&
             (!a.m[0].resid2 || a.m[0].resid2_cs % 16 == 0)) a.deferred_split = &nsplit;
     }
+    // a grouped launch of a prefill ubatch (wq / wk / wv, two K halves at 512 tokens) whose results go straight into the q / k norm + rope + store launch: leave the slabs, that
+    // launch sums them (k_norm_rope_v4 with slab sources) -- judged here only by the next launching node being an RMS_NORM on one of the results; exec_rms_norm takes the slabs when
+    // every chain of its launch maps onto them and runs the reduction launch itself otherwise
+    bool group_deferred = false;
+    static const bool no_defer_group = getenv("MI355X_NO_REDUCE_IN_NORM_ROPE") != nullptr;
+    if (!no_defer_group && !no_defer_reduce && a.nmat >= 2 && un_idx < 0 && a.partial && !kq && N > MI_MMVQ_MAX_COLS && !s.prm.n && !gemm_f16_sk_ok(a)) {
+        bool ok = true;
+        for (int q = 0; q < a.nmat && ok; ++q) {
+            const ggml_tensor * R = g->nodes[mm_idx[q]];
+            ok = add_idx[q] < 0 && add2_idx[q] < 0 && cpy_idx[q] < 0 && !a.m[q].resid && R->ne[2] == 1 && R->ne[3] == 1 && R->nb[1] == (size_t) R->ne[0] * 4 && a.m[q].M % 4 == 0 && !is_out(s, R);
+        }
+        int nx = i + 1;                                                   // (the group's other mat-muls were hoisted up to node i: skip them)
+        auto mine = [&](int k) { for (int q = 0; q < a.nmat; ++q) if (mm_idx[q] == k) return true; return false; };
+        while (nx < g->n_nodes && (s.done[nx] || is_noop(g->nodes[nx]) || mine(nx))) ++nx;
+        bool hit = false;
+        if (ok && nx < g->n_nodes && g->nodes[nx]->op == GGML_OP_RMS_NORM && g->nodes[nx]->src[0])
+            for (int q = 0; q < a.nmat; ++q) hit = hit || g->nodes[nx]->src[0]->data == g->nodes[mm_idx[q]]->data;
+        if (ok && hit) { a.deferred_split = &nsplit; a.defer_multi = true; group_deferred = true; }
+    }
     {
         prof_scope ps(s, "gemm_f16", flops);
         gemm_f16_multi(a, s.st);
     }
     ++s.n_kernels;
+    if (group_deferred && nsplit > 1) {
+        s.prm.n = a.nmat; s.prm.nsplit = nsplit; s.prm.N = N;
+        size_t off = 0;
+        for (int q = 0; q < a.nmat; ++q) { s.prm.A[q] = g->nodes[mm_idx[q]]; s.prm.off[q] = off; s.prm.M[q] = a.m[q].M; off += (size_t) a.m[q].M * (size_t) N; }
+        s.prm.slab = off;
+        nsplit = 0;
+    }
     if (nsplit > 1) { s.pr.A = Aout; s.pr.nsplit = nsplit; s.pr.resid = a.m[0].resid; s.pr.resid_cs = a.m[0].resid_cs; s.pr.resid2 = a.m[0].resid2; s.pr.resid2_cs = a.m[0].resid2_cs; }
     if (un_idx >= 0) {                                          // (the bias ADD's rows are never written: its one reader ran in the reduction)
         s.done[add_idx[0]] = 1; s.done[un_idx] = 1; s.n_fused += 2;
@@ -1244,6 +1283,10 @@ static bool exec_rms_norm(exec_state & s, int i) {
     const float eps = op_param_f32(n, 0);
     // (a pending split-K result is folded in only by the plain 2-D norm + mul path at the end; every other path reads it from memory)
     if (s.pr.A && s.pr.A == n->src[0] && !(n->ne[2] == 1 && n->ne[3] == 1 && n->ne[1] > MI_MMVQ_MAX_COLS && n->ne[0] > 256)) materialise_reduce(s);
+    if (s.prm.n) {                                                       // pending slabs of wq / wk / wv: only the prefill norm + rope launch below can take them
+        nr_chain A0;
+        if (!s.c->opt_fusion || !match_norm_rope(s, i, A0) || A0.T <= MI_MMVQ_MAX_COLS) materialise_group(s);
+    }
     if (!s.c->opt_fusion) return false;
     const int mi_ = sole_user(s, n);
     if (mi_ != i + 1 || g->nodes[mi_]->op != GGML_OP_MUL) return false;
@@ -1354,6 +1397,19 @@ static bool exec_rms_norm(exec_state & s, int i) {
                                        memcmp(&s.rt.rp, &A.rp, sizeof(rope_params)) == 0;
                     if (!a.rope_tab_valid) { s.rt.pos = A.pos->data; s.rt.ff = A.ff ? A.ff->data : nullptr; s.rt.T = A.T; s.rt.D = A.D; s.rt.rp = A.rp; ++s.n_kernels; }
                 }
+                if (s.prm.n) {
+                    // every job of this launch reads one of the pending results whole, each result once: point the jobs at the slabs; anything else gets the reduction launch
+                    norm_rope_args b = a;
+                    bool ok = a.njobs == s.prm.n; int used = 0;
+                    for (int jb = 0; jb < a.njobs && ok; ++jb) {
+                        int q = -1;
+                        for (int k = 0; k < s.prm.n; ++k) if ((const void *) a.j[jb].x == s.prm.A[k]->data && !(used & (1 << k))) q = k;
+                        ok = q >= 0 && a.j[jb].xnb1 == (int64_t) a.D * 4 && a.j[jb].xnb2 == s.prm.M[q] * 4 && (int64_t) a.j[jb].H * a.D == s.prm.M[q] && a.T == s.prm.N;
+                        if (ok) { used |= 1 << q; b.j[jb].x = (const float *) s.c->gemm_partial + s.prm.off[q]; b.j[jb].nsplit = s.prm.nsplit; b.j[jb].split_bytes = (int64_t) s.prm.slab * 4; }
+                    }
+                    if (ok && norm_rope_takes_split(b)) { a = b; s.prm.n = 0; ++s.n_fused; }
+                    else materialise_group(s);
+                }
                 {
                     prof_scope ps(s, "norm_rope", 0);
                     norm_rope_store(a, s.st);
@@ -1397,6 +1453,7 @@ static bool exec_rms_norm(exec_state & s, int i) {
             }
         }
     }
+    if (s.prm.n) materialise_group(s);                                  // (the norm + rope launch did not happen: the paths below read the rows from memory)
     // image variant: row-contiguous 2-D activation, weight a plain [ne0] vector, every consumer a K-quant mat-vec on it
     bool want_img = rms_norm_mul_quant_ok(n->ne[0]) && n->ne[2] == 1 && n->ne[3] == 1 && n->ne[1] <= mmq_max_cols() && wt->ne[0] == n->ne[0] &&
                     wt->ne[1] * wt->ne[2] * wt->ne[3] == 1 && n->src[0]->nb[0] == 4 && n_users(s, m) > 0;
@@ -1620,6 +1677,7 @@ static void compute_node(exec_state & s, int i) {
     ggml_tensor * n = g->nodes[i];
     if (is_noop(n)) return;
     if (s.pr.A && !((n->op == GGML_OP_RMS_NORM || n->op == GGML_OP_NORM) && n->src[0] == s.pr.A)) materialise_reduce(s);      // somebody else reads the split-K result first
+    if (s.prm.n && !reads_pending_group(s, n)) materialise_group(s);
 
     switch (n->op) {
         case GGML_OP_MUL_MAT:
@@ -1666,6 +1724,7 @@ static void compute_node(exec_state & s, int i) {
         case GGML_OP_RMS_NORM: {
             if (exec_rms_norm(s, i)) return;
             if (s.pr.A) materialise_reduce(s);
+            if (s.prm.n) materialise_group(s);
             prof_scope ps(s, "rms_norm", 0);
             rms_norm(td(n->src[0]), td(n), op_param_f32(n, 0), nullptr, s.st); ++s.n_kernels;
             break;

@@ -232,6 +232,7 @@ struct norm_rope_job {
     int rope_only = 0;                       // w == null and the job still rotates (llama-architecture q / k chains)
     // optional f16 copy of the rope output as the activation image of a per-head MUL_MAT (flash-attention off: K . q): row h * T + t, y16_rs bytes apart
     void * y16 = nullptr; int64_t y16_rs = 0;
+    int nsplit = 1; int64_t split_bytes = 0; // > 1: x is slab 0 of the split-K slabs of the mat-mul in front (dense [T][M] blocks, split_bytes apart): the rows are their sum (norm_rope_takes_split)
 };
 struct norm_rope_args {
     norm_rope_job j[3]; int njobs;
@@ -240,6 +241,8 @@ struct norm_rope_args {
     // optional scratch for the ubatch's (cos, sin) table, T * D/2 float pairs; rope_tab_valid: it already holds THIS (pos, rope params)
     float * rope_tab = nullptr; bool rope_tab_valid = false;
 };
+long norm_rope_split_launches();
+bool norm_rope_takes_split(const norm_rope_args & a);                   // norm_rope_store will run the kernel that sums split-K slab sources (nsplit > 1)
 void norm_rope_store(const norm_rope_args & a, hipStream_t st);
 bool rms_norm_mul_quant_ok(int64_t n);
 
@@ -264,6 +267,7 @@ struct gemm_multi_args {
     // non-null: when a split-K is chosen the reduction is NOT run; *deferred_split = number of [N][M] slabs left in `partial` (0: none,
     // dst is complete) and the caller owes gemm_reduce() or gemm_reduce_rms_norm()
     int * deferred_split = nullptr;
+    bool defer_multi = false;                 // the same for a grouped launch (nmat > 1, no addends): slab s = partial + s * (sum of M_i) * N floats, matrix i a dense [N][M_i] block at + (M_0 + .. + M_{i-1}) * N
     // gate / up + SWIGLU (gemm_glu_ok): no f32 outputs; f16 rows of silu(W[glu_gate].x) * (W[1 - glu_gate].x) go to glu_out16
     uint16_t * glu_out16 = nullptr; size_t glu_out16_rs = 0; int glu_gate = 0;
     // persistent stream-K form (gemm_sk.hip) for launches the tile grid fills badly: partial-tile slots (gemm_sk_part_bytes()) and zeroed
@@ -278,6 +282,7 @@ int    gemm_sk_groups();                                          // CUs of the 
 void   gemm_rf_set_mode(int m);                                   // -1: MI355X_GEMM_RF decides, 0 off, 2 / 4: k_gemm_f16_rf<depth> where legal
 void   gemm_sk_set_mode(int m);                                   // -1: MI355X_GEMM_SK decides (default off), 0 off, 1 wherever legal, 2 by the shape rule
 void   gemm_reduce(const float * partial, int nsplit, const float * resid, size_t resid_cs, float * dst, size_t dst_cs, int64_t M, int64_t N, hipStream_t st);
+void   gemm_reduce_group(const float * partial, int nsplit, int nmat, const int64_t * M, int64_t N, float * const * dst, const size_t * dst_cs, hipStream_t st);   // the reduction a deferred grouped launch owes (no addends)
 void   gemm_reduce2(const float * partial, int nsplit, const float * resid, size_t resid_cs, const float * resid2, size_t resid2_cs, float * dst, size_t dst_cs, int64_t M, int64_t N, hipStream_t st);
 // the same reduction fused with the RMS_NORM -> MUL(w) of the result: dst = sum + resid (f32); y = rms_norm(dst) * w -> y32 / f16 rows y16
 bool   gemm_reduce_rms_norm_ok(int64_t M);

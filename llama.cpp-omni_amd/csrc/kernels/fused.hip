@@ -20,6 +20,7 @@ struct nr_job {
     char * kv; int64_t kv_rs;                         // f16 table base + row stride (may be null)
     const char * idx; int idx_is64; int64_t idx_nb0;  // row index per token
     int H; int wave_end;                              // waves [prev.wave_end, wave_end) belong to this job
+    int nsplit; int64_t split_bytes;                  // > 1 (k_norm_rope_v4 only): x is slab 0 of `nsplit` split-K slabs of the mat-mul in front, split_bytes apart -- the rows are their sum, in slab order
 };
 struct nr_dev {
     nr_job j[3]; int njobs;
@@ -95,7 +96,17 @@ __global__ void __launch_bounds__(256) k_norm_rope_v4(const nr_dev a) {
     const int lw = wid * 4 + sub - w0;
     const int h = lw % J.H, t = lw / J.H;
     const char * xr = J.x + h * J.xnb1 + t * J.xnb2;
-    const f32x4 lo = *(const f32x4 *) (xr + j * 16), hi = *(const f32x4 *) (xr + 256 + j * 16);
+    f32x4 lo = *(const f32x4 *) (xr + j * 16), hi = *(const f32x4 *) (xr + 256 + j * 16);
+    if (J.nsplit > 1) {                               // the wq / wk / wv launch left its K halves as slabs: summed here (slab 0 + slab 1 + ..., k_gemm_reduce_multi's order), never written
+        f32x4 l2[7], h2[7];
+#pragma unroll
+        for (int s = 1; s < 8; ++s) {
+            l2[s - 1] = s < J.nsplit ? *(const f32x4 *) (xr + s * J.split_bytes + j * 16)       : f32x4{ 0.0f, 0.0f, 0.0f, 0.0f };
+            h2[s - 1] = s < J.nsplit ? *(const f32x4 *) (xr + s * J.split_bytes + 256 + j * 16) : f32x4{ 0.0f, 0.0f, 0.0f, 0.0f };
+        }
+#pragma unroll
+        for (int s = 1; s < 8; ++s) if (s < J.nsplit) { lo += l2[s - 1]; hi += h2[s - 1]; }
+    }
     int64_t row = 0;
     if (J.kv) row = J.idx_is64 ? *(const int64_t *) (J.idx + t * J.idx_nb0) : (int64_t) *(const int32_t *) (J.idx + t * J.idx_nb0);
     auto pack = [](const f32x4 v) { u32x2 h; h[0] = (uint32_t) f2h(v[0]) | ((uint32_t) f2h(v[1]) << 16); h[1] = (uint32_t) f2h(v[2]) | ((uint32_t) f2h(v[3]) << 16); return h; };
@@ -142,6 +153,21 @@ void rope_table(const int32_t * pos, const float * ff, const rope_params & rp, i
     k_rope_table<<<dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, st>>>(pos, ff, make_rope_dev(rp), T, D / 2, tab);
 }
 
+static long g_norm_rope_split_launches = 0;
+long norm_rope_split_launches() { return g_norm_rope_split_launches; }
+// would norm_rope_store run the kernel that can sum split-K slabs (k_norm_rope_v4), for these jobs?  (the same test as below, on the host arguments)
+bool norm_rope_takes_split(const norm_rope_args & f) {
+    static const bool off = getenv("MI355X_NO_NORM_ROPE_V4") != nullptr;
+    if (off || f.D != 128 || f.T < 16 || !(f.rp.mode & GGML_ROPE_TYPE_NEOX) || !f.rope_tab || f.njobs <= 0) return false;
+    for (int i = 0; i < f.njobs; ++i) {
+        const norm_rope_job & d = f.j[i];
+        const bool plain = !d.w && !d.rope_only;
+        if (!(d.H % 4 == 0 && ((uintptr_t) d.x & 15) == 0 && d.xnb1 % 16 == 0 && d.xnb2 % 16 == 0 && (!d.w || ((uintptr_t) d.w & 15) == 0) &&
+              (!d.y || (((uintptr_t) d.y & 15) == 0 && d.ynb1 % 16 == 0 && d.ynb2 % 16 == 0)) && (!d.kv || (((uintptr_t) d.kv & 7) == 0 && d.kv_rs % 8 == 0)) && (!plain || d.kv) &&
+              (!d.y16 || (((uintptr_t) d.y16 & 7) == 0 && d.y16_rs % 8 == 0)) && d.nsplit >= 1 && d.nsplit <= 8 && d.split_bytes % 16 == 0)) return false;
+    }
+    return true;
+}
 void norm_rope_store(const norm_rope_args & f, hipStream_t st) {
     if (f.D == 0 || f.T == 0 || f.njobs == 0) return;
     nr_dev a;
@@ -158,7 +184,7 @@ void norm_rope_store(const norm_rope_args & f, hipStream_t st) {
         d.x = (const char *) s.x; d.xnb1 = s.xnb1; d.xnb2 = s.xnb2; d.w = s.w; d.plain = (!s.w && !s.rope_only) ? 1 : 0;
         d.y = (char *) s.y; d.ynb1 = s.ynb1; d.ynb2 = s.ynb2; d.y16 = (char *) s.y16; d.y16_rs = s.y16_rs;
         d.kv = (char *) s.kv; d.kv_rs = s.kv_rs; d.idx = (const char *) s.idx; d.idx_is64 = s.idx_is64; d.idx_nb0 = s.idx_nb0;
-        d.H = s.H;
+        d.H = s.H; d.nsplit = s.nsplit; d.split_bytes = s.split_bytes;
         if (i < f.njobs) acc += s.H * f.T;
         d.wave_end = acc;
     }
@@ -170,7 +196,9 @@ void norm_rope_store(const norm_rope_args & f, hipStream_t st) {
             v4 = d.H % 4 == 0 && ((uintptr_t) d.x & 15) == 0 && d.xnb1 % 16 == 0 && d.xnb2 % 16 == 0 && (!d.w || ((uintptr_t) d.w & 15) == 0) &&
                  (!d.y || (((uintptr_t) d.y & 15) == 0 && d.ynb1 % 16 == 0 && d.ynb2 % 16 == 0)) && (!d.kv || (((uintptr_t) d.kv & 7) == 0 && d.kv_rs % 8 == 0)) && (!d.plain || d.kv) && (!d.y16 || (((uintptr_t) d.y16 & 7) == 0 && d.y16_rs % 8 == 0));
         }
-        if (v4) { k_norm_rope_v4<<<dim3((unsigned) ((acc / 4 + 3) / 4)), dim3(256), 0, st>>>(a); return; }
+        if (v4) { for (int i = 0; i < f.njobs; ++i) if (f.j[i].nsplit > 1) { ++g_norm_rope_split_launches; break; }
+                  k_norm_rope_v4<<<dim3((unsigned) ((acc / 4 + 3) / 4)), dim3(256), 0, st>>>(a); return; }
+        for (int i = 0; i < f.njobs; ++i) if (f.j[i].nsplit > 1) { fprintf(stderr, "[mi355x] norm_rope_store: split-K sources need the 16-lanes-per-row kernel (ask norm_rope_takes_split first)\n"); abort(); }
     }
     dim3 grid((unsigned) ((acc + 3) / 4));
     if (f.D <= 128) k_norm_rope<1><<<grid, dim3(256), 0, st>>>(a);

@@ -1044,6 +1044,18 @@ void gemm_reduce(const float * partial, int nsplit, const float * resid, size_t 
     if (quads == 0) return;
     k_gemm_reduce<<<dim3((unsigned) ((quads + 255) / 256)), dim3(256), 0, st>>>(partial, nsplit, (size_t) M * (size_t) N, (const char *) resid, resid_cs, (char *) dst, dst_cs, (int) M, (int) N);
 }
+// the reduction of a grouped launch whose caller deferred it (defer_multi) and could not fold it into its next kernel after all
+void gemm_reduce_group(const float * partial, int nsplit, int nmat, const int64_t * M, int64_t N, float * const * dst, const size_t * dst_cs, hipStream_t st) {
+    gemm_reduce_multi_dev r; r.nmat = nmat; r.nsplit = nsplit; r.N = (int) N;
+    size_t off = 0; int64_t quads = 0;
+    for (int i = 0; i < 3; ++i) {
+        const int k = i < nmat ? i : 0;
+        r.off[i] = off; r.M[i] = i < nmat ? (int) M[k] : 0; r.resid[i] = nullptr; r.resid_cs[i] = 0; r.resid2[i] = nullptr; r.resid2_cs[i] = 0; r.dst[i] = (char *) dst[k]; r.dst_cs[i] = dst_cs[k];
+        if (i < nmat) { off += (size_t) M[k] * (size_t) N; quads += M[k] * N / 4; }
+    }
+    r.split_elems = off;
+    if (quads > 0) k_gemm_reduce_multi<<<dim3((unsigned) ((quads + 255) / 256)), dim3(256), 0, st>>>(partial, r);
+}
 // the same with a second addend (k_gemm_reduce_multi's order: slabs, addend 1, addend 2)
 void gemm_reduce2(const float * partial, int nsplit, const float * resid, size_t resid_cs, const float * resid2, size_t resid2_cs, float * dst, size_t dst_cs, int64_t M, int64_t N, hipStream_t st) {
     if (!resid2) { gemm_reduce(partial, nsplit, resid, resid_cs, dst, dst_cs, M, N, st); return; }
@@ -1297,7 +1309,7 @@ void gemm_f16_multi(const gemm_multi_args & a, hipStream_t st) {
         else if (use_rf == 4) { k_gemm_f16_rf<4><<<dim3((unsigned) (tm * tiles_n * ksplit)), dim3(256), 2 * (128 * H_ROWB + H_TILEB), st>>>(g); ++g_gemm_variant_launches[6]; }
         else if (use_rf == 2) { k_gemm_f16_rf<2><<<dim3((unsigned) (tm * tiles_n * ksplit)), dim3(256), 2 * (128 * H_ROWB + H_TILEB), st>>>(g); ++g_gemm_variant_launches[6]; }
         else    k_gemm_f16_glds<2><<<dim3((unsigned) (tm * tiles_n * ksplit)), dim3(256), 2 * (128 * H_ROWB + H_TILEB), st>>>(g);
-        if (a.nmat == 1 && a.deferred_split) { *a.deferred_split = ksplit; return; }          // the caller fuses the reduction into its next kernel
+        if (a.deferred_split && (a.nmat == 1 || a.defer_multi)) { *a.deferred_split = ksplit; return; }          // the caller fuses the reduction into its next kernel
         gemm_reduce_multi_dev r; r.nmat = a.nmat; r.nsplit = ksplit; r.N = (int) a.N; r.split_elems = slab;
         off = 0; int64_t quads = 0;
         for (int i = 0; i < 3; ++i) {

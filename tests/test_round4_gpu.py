@@ -614,3 +614,32 @@ def test_streaming_encoder_attention_block_vs_reference_backend(pkg, be, ref_be,
         g32, w32 = g_.astype(np.float32), w_.astype(np.float32)
         assert np.isfinite(g32).all(), name
         assert nmse(g32, w32) < 2e-6, (name, nmse(g32, w32))
+
+
+def test_grouped_split_k_slabs_are_summed_by_the_norm_rope_launch(pkg, be, ref_be):
+    """Prefill ubatch of 512 tokens at the 8B widths, one layer: wq / wk / wv run as ONE grouped launch with two K halves; the q / k norm + rope + K / V store launch behind it sums
+    the slabs itself (k_norm_rope_v4 with slab sources) -- k_gemm_reduce_multi does not run for them.  Logits of the last 64 tokens against the reference CPU backend on the same graph; the launch counter
+    confirms the path."""
+    from conftest import nmse
+    from llama_cpp_omni_amd import qwen3
+    cfg = dict(qwen3.QWEN3_8B, n_layer=1, n_vocab=4096)
+    T, n_kv = 512, 512
+    rng = np.random.default_rng(12)
+    embd = rng.standard_normal((T, cfg["n_embd"])).astype(np.float32)
+    outs = []; launches = None
+    for backend in (be, ref_be):
+        mdl = qwen3.Model(backend, cfg, qwen3.uniform_types(cfg, pkg.GGML_TYPE_F16), n_ctx=n_kv, seed=5, flash_attn=True)
+        g, I, logits = mdl.build(T, n_kv, n_outputs=64)
+        mdl.set_inputs(I, embd, 0, n_kv)
+        backend.tensor_set(I["out_ids"], np.arange(T - 64, T, dtype=np.int32))
+        gr = g.graph()
+        if backend is be:
+            launches = backend.get_stat("norm_rope_split_launches")
+        backend.graph_compute(gr); backend.synchronize()
+        if backend is be:
+            launches = backend.get_stat("norm_rope_split_launches") - launches
+        outs.append(backend.tensor_get(logits).copy())
+        g.free(); mdl.wctx.free()
+    assert np.isfinite(outs[0]).all()
+    assert nmse(outs[0], outs[1]) < 1e-6, nmse(outs[0], outs[1])
+    assert launches == 1, launches                                     # the layer's norm + rope + store launch took the slabs
