@@ -428,12 +428,14 @@ static void materialise_reduce(exec_state & s) {
     gemm_reduce2((const float *) s.c->gemm_partial, s.pr.nsplit, s.pr.resid, s.pr.resid_cs, s.pr.resid2, s.pr.resid2_cs, (float *) A->data, A->nb[1], A->ne[0], A->ne[1], s.st);
     ++s.n_kernels;
 }
-static void materialise_group(exec_state & s) {
-    float * dst[3] = { nullptr, nullptr, nullptr }; size_t cs[3] = { 0, 0, 0 };
-    for (int q = 0; q < s.prm.n; ++q) { dst[q] = (float *) s.prm.A[q]->data; cs[q] = s.prm.A[q]->nb[1]; }
-    prof_scope ps(s, "gemm_reduce", 0);
-    gemm_reduce_group((const float *) s.c->gemm_partial, s.prm.nsplit, s.prm.n, s.prm.M, s.prm.N, dst, cs, s.st);
-    ++s.n_kernels;
+static void materialise_group(exec_state & s, int skip_mask = 0) {       // skip_mask: results somebody has taken as slabs
+    float * dst[3] = { nullptr, nullptr, nullptr }; size_t cs[3] = { 0, 0, 0 }, off[3] = { 0, 0, 0 }; int64_t M[3] = { 0, 0, 0 }; int n = 0;
+    for (int q = 0; q < s.prm.n; ++q) if (!(skip_mask & (1 << q))) { dst[n] = (float *) s.prm.A[q]->data; cs[n] = s.prm.A[q]->nb[1]; off[n] = s.prm.off[q]; M[n] = s.prm.M[q]; ++n; }
+    if (n > 0) {
+        prof_scope ps(s, "gemm_reduce", 0);
+        gemm_reduce_group((const float *) s.c->gemm_partial, s.prm.nsplit, s.prm.slab, n, off, M, s.prm.N, dst, cs, s.st);
+        ++s.n_kernels;
+    }
     s.prm.n = 0;
 }
 static bool reads_pending_group(exec_state & s, const ggml_tensor * n) {          // an RMS_NORM on (a view of) one of the pending grouped results
@@ -1399,15 +1401,16 @@ static bool exec_rms_norm(exec_state & s, int i) {
                 }
                 if (s.prm.n) {
                     // every job of this launch reads one of the pending results whole, each result once: point the jobs at the slabs; anything else gets the reduction launch
+                    // (a result no job reads -- the V rows of a flash-attention-off graph, whose store is a scatter launch of its own -- gets the reduction launch alone)
                     norm_rope_args b = a;
-                    bool ok = a.njobs == s.prm.n; int used = 0;
+                    bool ok = a.njobs <= s.prm.n; int used = 0;
                     for (int jb = 0; jb < a.njobs && ok; ++jb) {
                         int q = -1;
                         for (int k = 0; k < s.prm.n; ++k) if ((const void *) a.j[jb].x == s.prm.A[k]->data && !(used & (1 << k))) q = k;
                         ok = q >= 0 && a.j[jb].xnb1 == (int64_t) a.D * 4 && a.j[jb].xnb2 == s.prm.M[q] * 4 && (int64_t) a.j[jb].H * a.D == s.prm.M[q] && a.T == s.prm.N;
                         if (ok) { used |= 1 << q; b.j[jb].x = (const float *) s.c->gemm_partial + s.prm.off[q]; b.j[jb].nsplit = s.prm.nsplit; b.j[jb].split_bytes = (int64_t) s.prm.slab * 4; }
                     }
-                    if (ok && norm_rope_takes_split(b)) { a = b; s.prm.n = 0; ++s.n_fused; }
+                    if (ok && norm_rope_takes_split(b)) { a = b; materialise_group(s, used); ++s.n_fused; }
                     else materialise_group(s);
                 }
                 {

@@ -282,7 +282,7 @@ int    gemm_sk_groups();                                          // CUs of the 
 void   gemm_rf_set_mode(int m);                                   // -1: MI355X_GEMM_RF decides, 0 off, 2 / 4: k_gemm_f16_rf<depth> where legal
 void   gemm_sk_set_mode(int m);                                   // -1: MI355X_GEMM_SK decides (default off), 0 off, 1 wherever legal, 2 by the shape rule
 void   gemm_reduce(const float * partial, int nsplit, const float * resid, size_t resid_cs, float * dst, size_t dst_cs, int64_t M, int64_t N, hipStream_t st);
-void   gemm_reduce_group(const float * partial, int nsplit, int nmat, const int64_t * M, int64_t N, float * const * dst, const size_t * dst_cs, hipStream_t st);   // the reduction a deferred grouped launch owes (no addends)
+void   gemm_reduce_group(const float * partial, int nsplit, size_t slab_elems, int nmat, const size_t * off, const int64_t * M, int64_t N, float * const * dst, const size_t * dst_cs, hipStream_t st);   // the reduction a deferred grouped launch owes (no addends)
 void   gemm_reduce2(const float * partial, int nsplit, const float * resid, size_t resid_cs, const float * resid2, size_t resid2_cs, float * dst, size_t dst_cs, int64_t M, int64_t N, hipStream_t st);
 // the same reduction fused with the RMS_NORM -> MUL(w) of the result: dst = sum + resid (f32); y = rms_norm(dst) * w -> y32 / f16 rows y16
 bool   gemm_reduce_rms_norm_ok(int64_t M);

@@ -1045,15 +1045,14 @@ void gemm_reduce(const float * partial, int nsplit, const float * resid, size_t 
     k_gemm_reduce<<<dim3((unsigned) ((quads + 255) / 256)), dim3(256), 0, st>>>(partial, nsplit, (size_t) M * (size_t) N, (const char *) resid, resid_cs, (char *) dst, dst_cs, (int) M, (int) N);
 }
 // the reduction of a grouped launch whose caller deferred it (defer_multi) and could not fold it into its next kernel after all
-void gemm_reduce_group(const float * partial, int nsplit, int nmat, const int64_t * M, int64_t N, float * const * dst, const size_t * dst_cs, hipStream_t st) {
-    gemm_reduce_multi_dev r; r.nmat = nmat; r.nsplit = nsplit; r.N = (int) N;
-    size_t off = 0; int64_t quads = 0;
+void gemm_reduce_group(const float * partial, int nsplit, size_t slab_elems, int nmat, const size_t * off, const int64_t * M, int64_t N, float * const * dst, const size_t * dst_cs, hipStream_t st) {
+    gemm_reduce_multi_dev r; r.nmat = nmat; r.nsplit = nsplit; r.N = (int) N; r.split_elems = slab_elems;
+    int64_t quads = 0;
     for (int i = 0; i < 3; ++i) {
         const int k = i < nmat ? i : 0;
-        r.off[i] = off; r.M[i] = i < nmat ? (int) M[k] : 0; r.resid[i] = nullptr; r.resid_cs[i] = 0; r.resid2[i] = nullptr; r.resid2_cs[i] = 0; r.dst[i] = (char *) dst[k]; r.dst_cs[i] = dst_cs[k];
-        if (i < nmat) { off += (size_t) M[k] * (size_t) N; quads += M[k] * N / 4; }
+        r.off[i] = off[k]; r.M[i] = i < nmat ? (int) M[k] : 0; r.resid[i] = nullptr; r.resid_cs[i] = 0; r.resid2[i] = nullptr; r.resid2_cs[i] = 0; r.dst[i] = (char *) dst[k]; r.dst_cs[i] = dst_cs[k];
+        if (i < nmat) quads += M[k] * N / 4;
     }
-    r.split_elems = off;
     if (quads > 0) k_gemm_reduce_multi<<<dim3((unsigned) ((quads + 255) / 256)), dim3(256), 0, st>>>(partial, r);
 }
 // the same with a second addend (k_gemm_reduce_multi's order: slabs, addend 1, addend 2)
