@@ -221,6 +221,9 @@ static void be_free(ggml_backend_t b) {
     if (getenv("MI355X_LOG_STATS"))
         log_msg(GGML_LOG_LEVEL_INFO, "[mi355x] blocking buffer transfers (process-wide): tensor_set %lu calls %.1f MB %.1f ms, tensor_get %lu calls %.1f MB %.1f ms\n",
                 (unsigned long) g_buf_set_n.load(), g_buf_set_bytes.load() * 1e-6, g_buf_set_ns.load() * 1e-6, (unsigned long) g_buf_get_n.load(), g_buf_get_bytes.load() * 1e-6, g_buf_get_ns.load() * 1e-6);
+    if (getenv("MI355X_LOG_STATS") && c->stat_replays)
+        log_msg(GGML_LOG_LEVEL_INFO, "[mi355x] %s: replayed graphs: %.1f us avg comparing the node records, %.1f us avg in hipGraphLaunch (%ld replays)\n", c->name.c_str(),
+                c->host_ns_match * 1e-3 / c->stat_replays, c->host_ns_launch * 1e-3 / c->stat_replays, c->stat_replays);
     if (getenv("MI355X_LOG_STATS") && c->stat_eager)
         log_msg(GGML_LOG_LEVEL_INFO, "[mi355x] %s: eager graphs: %.1f us avg walking the nodes and enqueueing (%ld launches, %.2f us per launch)\n", c->name.c_str(),
                 c->host_ns_eager_run * 1e-3 / c->stat_eager, c->n_eager_kernels, c->n_eager_kernels ? c->host_ns_eager_run * 1e-3 / c->n_eager_kernels : 0.0);

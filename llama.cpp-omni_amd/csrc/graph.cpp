@@ -143,14 +143,20 @@ enum ggml_status graph_compute(backend_ctx * c, ggml_cgraph * g) {
         graph_exec * order[8]; int no = 0;
         for (auto & e : c->execs) if (e.exec && e.shadow_gen == shadow_generation() && no < 8) order[no++] = &e;
         for (int a = 1; a < no; ++a) for (int b = a; b > 0 && order[b]->last_use > order[b - 1]->last_use; --b) std::swap(order[b], order[b - 1]);
-        for (int a = 0; a < no; ++a)
-            if (recs_match(c, g, *order[a])) {
+        for (int a = 0; a < no; ++a) {
+            const auto t0 = std::chrono::steady_clock::now();
+            const bool hit = recs_match(c, g, *order[a]);
+            const auto t1 = std::chrono::steady_clock::now();
+            c->host_ns_match += (uint64_t) std::chrono::duration_cast<std::chrono::nanoseconds>(t1 - t0).count();
+            if (hit) {
                 graph_exec & e = *order[a];
                 e.last_use = ++c->tick; e.seen++;
                 HIP_CHECK(hipGraphLaunch(e.exec, c->stream));
+                c->host_ns_launch += (uint64_t) std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t1).count();
                 c->stat_replays++; c->stat_kernels_last = e.n_kernels;
                 return GGML_STATUS_SUCCESS;
             }
+        }
     }
     bool any_gemm_cols = false;                                   // a prefill graph: the GEMM that fuses SWIGLU writes its f16 result image next to its input image
     for (int i = 0; i < g->n_nodes && !any_gemm_cols; ++i) any_gemm_cols = g->nodes[i]->op == GGML_OP_GLU && g->nodes[i]->ne[1] > MI_MMVQ_MAX_COLS;
