@@ -371,7 +371,7 @@ static bool ready_before(exec_state & s, const ggml_tensor * src, int i, const i
 }
 static bool can_hoist(exec_state & s, int i, int j, const int * item, int n_item) {
     const ggml_tensor * nj = s.g->nodes[j];
-    for (int k = 0; k < GGML_MAX_SRC; ++k) if (!ready_before(s, nj->src[k], i, item, n_item)) return false;
+    for (int k = 0; k < GGML_MAX_SRC; ++k) if (nj->src[k] != nj && !ready_before(s, nj->src[k], i, item, n_item)) return false;      // (ggml_cast names its result as its own src[1])
     const byte_range dj = range_of(nj);
     for (int m = i + 1; m < j; ++m) {
         const ggml_tensor * nm = s.g->nodes[m];
@@ -615,7 +615,13 @@ static bool exec_gemm_group(exec_state & s, int i) {
     // rows never exist
     int cpy_idx[3] = { -1, -1, -1 };
     static const bool no_cpy16 = getenv("MI355X_NO_GEMM_CPY16") != nullptr;
-    if (!no_cpy16 && un_idx < 0 && N <= 128 && gemm_f16_small_n_ksplit(a) > 1)
+    bool y16_path = N <= 128 && gemm_f16_small_n_ksplit(a) > 1;          // the reduction launch writes the f16 rows ...
+    if (!no_cpy16 && un_idx < 0 && !y16_path && !kq) {                    // ... and so does the tile epilogue of the k_gemm_f16_glds<MB> family (an encoder's K / V CAST at full length)
+        gemm_multi_args pa = a; int path = 0; pa.probe_path = &path;
+        gemm_f16_multi(pa, s.st);
+        y16_path = path == 1;
+    }
+    if (!no_cpy16 && un_idx < 0 && y16_path)
         for (int q = 0; q < a.nmat; ++q) {
             if (add2_idx[q] >= 0 || a.m[q].M % 4 != 0) continue;
             const int ri = add_idx[q] >= 0 ? add_idx[q] : mm_idx[q];
@@ -638,6 +644,8 @@ static bool exec_gemm_group(exec_state & s, int i) {
             if (is_contiguous(S) && is_contiguous(Cp)) { ms = 2; rs = (size_t) M * 2; }                                                  // same linear order: K rows
             else if (S->ne[0] == N && S->ne[1] == M && S->ne[2] == 1 && S->ne[3] == 1 && S->nb[0] == R->nb[1] && S->nb[1] == 4 &&
                      Cp->ne[0] == N && Cp->ne[1] == M && Cp->ne[2] == 1 && Cp->ne[3] == 1 && Cp->nb[0] == 2 && Cp->nb[1] % 2 == 0) { ms = Cp->nb[1]; rs = 2; }   // the transposed view: V rows
+            else if (S->ne[0] == N && S->ne[1] > 0 && S->ne[1] * S->ne[2] == M && S->ne[3] == 1 && S->nb[0] == R->nb[1] && S->nb[1] == 4 && S->nb[2] == (size_t) S->ne[1] * 4 &&
+                     is_contiguous(Cp) && Cp->ne[0] == N && Cp->ne[1] == S->ne[1] && Cp->ne[2] == S->ne[2] && Cp->ne[3] == 1) { ms = (size_t) N * 2; rs = 2; }       // [n_tokens, D, H] of PERMUTE(1, 2, 0, 3): V^T per head (an encoder's V CAST)
             else continue;
             if (ms == 2 && (((uintptr_t) Cp->data & 7) != 0 || rs % 8 != 0)) continue;
             int item[8]; int ni = 0;

@@ -267,6 +267,7 @@ struct gemm_multi_args {
     // non-null: when a split-K is chosen the reduction is NOT run; *deferred_split = number of [N][M] slabs left in `partial` (0: none,
     // dst is complete) and the caller owes gemm_reduce() or gemm_reduce_rms_norm()
     int * deferred_split = nullptr;
+    int * probe_path = nullptr;               // non-null: NO launch; *probe_path = 1 when these arguments go to the k_gemm_f16_glds<MB> family (whose tile epilogue and reduction both write gemm_mat::y16 rows), else 0
     bool defer_multi = false;                 // the same for a grouped launch (nmat > 1, no addends): slab s = partial + s * (sum of M_i) * N floats, matrix i a dense [N][M_i] block at + (M_0 + .. + M_{i-1}) * N
     // gate / up + SWIGLU (gemm_glu_ok): no f32 outputs; f16 rows of silu(W[glu_gate].x) * (W[1 - glu_gate].x) go to glu_out16
     uint16_t * glu_out16 = nullptr; size_t glu_out16_rs = 0; int glu_gate = 0;

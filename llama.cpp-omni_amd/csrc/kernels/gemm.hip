@@ -147,6 +147,7 @@ struct gemm_dev {
     unsigned long long * dbg;
     int wtype[3];                                    // k_gemm_kq_glds: GGML_TYPE_Q4_K / GGML_TYPE_Q6_K per matrix (W points at the block rows)
     char * out16; size_t out16_rs; int glu_gate;      // k_gemm_f16_ph8<.., true>: f16 rows of silu(W[glu_gate].x) * (W[1 - glu_gate].x)
+    char * y16[3] = { nullptr, nullptr, nullptr }; size_t y16_rs[3] = { 0, 0, 0 }, y16_ms[3] = { 2, 2, 2 };   // k_gemm_f16_glds<MB>, un-split: f16 copy of matrix i's result, element (m, n) at y16 + m * ms + n * rs (dst null: only that)
 };
 
 // MB = 32-row MFMA tiles per wave along m: the workgroup tile is (64*MB) x 128.  MB = 2 is the default; MB = 3 (192 x 128) is chosen
@@ -245,10 +246,14 @@ __global__ void __launch_bounds__(256) k_gemm_f16_glds(const gemm_dev g) {
         }
     }
 
-    char * dst = (mi == 0 ? g.dst[0] : (mi == 1 ? g.dst[1] : g.dst[2])) + (size_t) split * g.split_stride + (size_t) bi12 * g.dst_nb2 + (size_t) bi13 * g.dst_nb3;
+    char * dst = (mi == 0 ? g.dst[0] : (mi == 1 ? g.dst[1] : g.dst[2]));
+    if (dst) dst += (size_t) split * g.split_stride + (size_t) bi12 * g.dst_nb2 + (size_t) bi13 * g.dst_nb3;
     const size_t dst_cs = mi == 0 ? g.dst_cs[0] : (mi == 1 ? g.dst_cs[1] : g.dst_cs[2]);
     const char * resid = mi == 0 ? g.resid[0] : (mi == 1 ? g.resid[1] : g.resid[2]);
     const size_t resid_cs = mi == 0 ? g.resid_cs[0] : (mi == 1 ? g.resid_cs[1] : g.resid_cs[2]);
+    // (un-split launches: an f16 copy of the rows -- the CAST behind a K / V projection of an encoder -- element (m, n) at y16 + m * ms + n * rs; dst null: nobody reads the f32 rows)
+    char * const y16 = mi == 0 ? g.y16[0] : (mi == 1 ? g.y16[1] : g.y16[2]);
+    const size_t y16_rs = mi == 0 ? g.y16_rs[0] : (mi == 1 ? g.y16_rs[1] : g.y16_rs[2]), y16_ms = mi == 0 ? g.y16_ms[0] : (mi == 1 ? g.y16_ms[1] : g.y16_ms[2]);
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -260,7 +265,8 @@ __global__ void __launch_bounds__(256) k_gemm_f16_glds(const gemm_dev g) {
                 if (m < M && n < N) {
                     float v = acc[a][b][e];
                     if (resid) v += *(const float *) (resid + (size_t) n * resid_cs + (size_t) m * 4);
-                    *(float *) (dst + (size_t) n * dst_cs + (size_t) m * 4) = v;
+                    if (y16) *(uint16_t *) (y16 + (size_t) n * y16_rs + (size_t) m * y16_ms) = f2h(v);
+                    if (dst) *(float *) (dst + (size_t) n * dst_cs + (size_t) m * 4) = v;
                 }
             }
         }
@@ -1144,6 +1150,7 @@ int gemm_f16_small_n_ksplit(const gemm_multi_args & a) {
 void gemm_f16_multi(const gemm_multi_args & a, hipStream_t st) {
     if (a.N == 0 || a.nmat == 0) return;
     const int tiles_n = (int) ((a.N + G_BN - 1) / G_BN);
+    if (a.probe_path && (a.K % H_BK != 0 || a.glu_out16)) { *a.probe_path = 0; return; }
     if (a.K % H_BK != 0) {                                    // padded register-staged kernel, one matrix at a time
         if (a.nbatch > 1) { fprintf(stderr, "[mi355x] gemm: batched launch needs K %% 64 == 0\n"); abort(); }
         for (int i = 0; i < a.nmat; ++i) {
@@ -1215,6 +1222,7 @@ void gemm_f16_multi(const gemm_multi_args & a, hipStream_t st) {
     for (int i = 0; i < a.nmat; ++i) if ((size_t) a.m[i].M * a.m[i].w_rs >= (1ull << 32)) big = false;     // (k_gemm_f16_ph8 addresses its operands with 32-bit offsets)
     if ((size_t) a.N * a.x_rs >= (1ull << 32)) big = false;
     if (any_q) { BM = G_BM; big = false; }                    // K-quant blocks de-quantised in the staging: the 128 x 128 kernel (few columns by construction)
+    if (a.probe_path) { *a.probe_path = (!big && !any_q && !gemm_f16_sk_ok(a) && a.nbatch <= 1) ? 1 : 0; return; }
     if (!big && gemm_f16_sk_ok(a)) {                          // tile grids that fill the chip badly (a 512-token ubatch: 128-192 tiles): one persistent stream-K launch, no slabs
         gemm_f16_sk(a, st);
         ++g_gemm_variant_launches[4];
@@ -1230,6 +1238,7 @@ void gemm_f16_multi(const gemm_multi_args & a, hipStream_t st) {
         g.tm_end[i] = tm;
     }
     if (big) {
+        for (int i = 0; i < a.nmat; ++i) if (a.m[i].y16) { fprintf(stderr, "[mi355x] gemm: f16 rows out of the epilogue are not a feature of the 256 x 256 kernels (ask with probe_path first)\n"); abort(); }
         if (tm == 0) return;
         const int tiles_n256 = (int) ((a.N + 255) / 256);
         g.nmat = a.nmat; g.X = (const char *) a.X; g.x_rs = a.x_rs; g.N = (int) a.N; g.K = (int) a.K; g.tiles_m = tm; g.tiles_n = tiles_n256;
@@ -1286,7 +1295,7 @@ void gemm_f16_multi(const gemm_multi_args & a, hipStream_t st) {
     g.ksteps_per_split = (nk + ksplit - 1) / ksplit; g.split_stride = 0;
     if (tm == 0) return;
     for (int i = 0; i < a.nmat; ++i)
-        if ((a.m[i].unary >= 0 || a.m[i].y16) && (ksplit == 1 || a.deferred_split || (a.m[i].unary >= 0 && a.m[i].unary != GGML_UNARY_OP_GELU && a.m[i].unary != GGML_UNARY_OP_GELU_QUICK) || !a.m[i].y16 ||
+        if ((a.m[i].unary >= 0 || a.m[i].y16) && ((ksplit == 1 && (a.m[i].unary >= 0 || kq)) || a.deferred_split || (a.m[i].unary >= 0 && a.m[i].unary != GGML_UNARY_OP_GELU && a.m[i].unary != GGML_UNARY_OP_GELU_QUICK) || !a.m[i].y16 ||
                                                   (a.m[i].y16_ms == 2 && (a.m[i].y16_rs % 8 != 0 || ((uintptr_t) a.m[i].y16 & 7) != 0)) || a.m[i].y16_ms % 2 != 0 || a.m[i].y16_rs % 2 != 0 || a.m[i].M % 4 != 0)) {
             fprintf(stderr, "[mi355x] gemm: f16 rows / an activation out of the epilogue need the split-K reduction launch (ask gemm_f16_small_n_ksplit first), GELU / GELU_QUICK and aligned f16 rows\n"); abort();
         }
@@ -1295,6 +1304,8 @@ void gemm_f16_multi(const gemm_multi_args & a, hipStream_t st) {
     const int rf_env = g_rf_mode >= 0 ? g_rf_mode : rf_env0;
     int use_rf = (rf_env == 2 || rf_env == 4) && BM == G_BM && nbatch == 1 && !kq && (size_t) a.N * a.x_rs < (1ull << 32) && nk % ksplit == 0 && (nk / ksplit) % rf_env == 0 ? rf_env : 0;
     for (int i = 0; i < a.nmat; ++i) if ((size_t) a.m[i].M * a.m[i].w_rs >= (1ull << 32)) use_rf = 0;
+    if (ksplit == 1)
+        for (int i = 0; i < a.nmat; ++i) if (a.m[i].y16) { g.y16[i] = (char *) a.m[i].y16; g.y16_rs[i] = a.m[i].y16_rs; g.y16_ms[i] = a.m[i].y16_ms; if (!a.m[i].y32) g.dst[i] = nullptr; }
     if (ksplit > 1) {
         // slab s of the scratch holds, matrix after matrix, the dense [N][M_i] partial sums of K range s
         const size_t slab = (size_t) m_sum * (size_t) a.N;
