@@ -56,8 +56,6 @@ GGML_MI355X_API void   mi355x_timed_event_free(void * ev);
  * the prefill GEMM, process-wide), "norm_in_kernel" (0/1 RMS_NORM+MUL built inside the consuming decode mat-vec launches; default 0),
  * "fattn_gqa" (0/1 matrix-core kernel for few-token FLASH_ATTN_EXT; 0 = streaming kernel for every such shape; default 1, process-wide),
  * "fattn_dma" (-1 default / 0 / 1: the LDS-DMA ring form of the prefill attention kernel for head size 128 on large grids, process-wide),
- * "gemm_rf" (-1 default = off / 0 / 2 / 4: register-ring staging of the 128 x 128 F16 GEMM tile, ring depth in K-steps, process-wide; bit-identical, measured not faster),
- * "gemm_sk" (-1 default = off / 0 / 1 wherever legal / 2 by shape: the persistent stream-K form of the F16 GEMM, process-wide; measured not faster),
  * "mv1", "mv2", "fattn_one", "kq_staging", "batch_uploads" (cross-check switches of the decode kernels),
  * "reset_stats".  Returns 0 on success, -1 for an unknown key. */
 GGML_MI355X_API int    mi355x_set_option(struct ggml_backend * backend, const char * key, long value);

@@ -84,7 +84,12 @@ static void settle_staged(int device, const void * lo_, size_t n) {
             const backend_ctx::up_ent & e = c->up_ents[c->up_half][i];
             hit = (const char *) e.dst < hi && lo < (const char *) e.dst + e.size;
         }
-        if (hit) { flush_uploads(c); HIP_CHECK(hipStreamSynchronize(c->stream)); }
+        if (hit) {                                         // (the launch goes onto c's stream -- make c's device current for it, the caller's afterwards)
+            int cur = 0; HIP_CHECK(hipGetDevice(&cur));
+            if (cur != c->device) HIP_CHECK(hipSetDevice(c->device));
+            flush_uploads(c); HIP_CHECK(hipStreamSynchronize(c->stream));
+            if (cur != c->device) HIP_CHECK(hipSetDevice(cur));
+        }
     }
 }
 static void buf_free(ggml_backend_buffer_t b) {
@@ -241,6 +246,7 @@ void flush_uploads(backend_ctx * c);
 static const size_t UP_HALF = 256 * 1024, UP_SMALL = 64 * 1024; static const int UP_MAX = 64;
 struct host_timer { uint64_t & acc; std::chrono::steady_clock::time_point t0; host_timer(uint64_t & a) : acc(a), t0(std::chrono::steady_clock::now()) {} ~host_timer() { acc += (uint64_t) std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count(); } };
 void flush_uploads(backend_ctx * c) {                     // everything staged so far goes onto the stream, in order, in front of what follows
+    std::lock_guard<std::recursive_mutex> lk(g_live_mu);  // (the owner thread's flush and a settle_staged() from another thread's buffer call both reach this)
     if (c->up_n == 0) return;
     const int h = c->up_half;
     void * dents = nullptr, * dbase = nullptr;

@@ -316,8 +316,6 @@ void backend_ctx_release(backend_ctx * c) {
     if (c->fa_counters) (void) hipFree(c->fa_counters);
     if (c->rope_scratch) (void) hipFree(c->rope_scratch);
     if (c->gemm_partial) (void) hipFree(c->gemm_partial);
-    if (c->sk_part) (void) hipFree(c->sk_part);
-    if (c->sk_cnt) (void) hipFree(c->sk_cnt);
     if (c->copy_event) (void) hipEventDestroy(c->copy_event);
     if (c->handoff_event) (void) hipEventDestroy(c->handoff_event);
     if (c->stream) (void) hipStreamDestroy(c->stream);
@@ -340,8 +338,6 @@ int mi355x_set_option(struct ggml_backend * backend, const char * key, long valu
     if (!strcmp(key, "fattn_gqa")) { mi::fattn_set_gqa(value != 0); mi::drop_graph_execs(c); return 0; }
     if (!strcmp(key, "fattn_one")) { mi::fattn_set_one(value != 0); mi::drop_graph_execs(c); return 0; }
     if (!strcmp(key, "fattn_dma")) { mi::fattn_set_dma((int) value); mi::drop_graph_execs(c); return 0; }      // (process-wide)
-    if (!strcmp(key, "gemm_rf")) { mi::gemm_rf_set_mode((int) value); mi::drop_graph_execs(c); return 0; }      // (process-wide: register-ring staging of the 128 x 128 F16 GEMM tile, k_gemm_f16_rf)
-    if (!strcmp(key, "gemm_sk")) { mi::gemm_sk_set_mode((int) value); mi::drop_graph_execs(c); return 0; }      // (process-wide: the persistent stream-K form of the F16 GEMM, gemm_sk.hip)
     if (!strcmp(key, "f16_shadow")) { mi::shadow_set_enabled(value != 0); mi::drop_graph_execs(c); return 0; }
     if (!strcmp(key, "reset_stats")) { c->prof.clear(); c->stat_replays = c->stat_captures = c->stat_eager = 0; return 0; }
     return -1;
@@ -358,11 +354,9 @@ double mi355x_get_stat(struct ggml_backend * backend, const char * key) {
     if (!strcmp(key, "gemm192_launches"))   return (double) mi::gemm_variant_launches(1);
     if (!strcmp(key, "gemm_glu_launches"))  return (double) mi::gemm_variant_launches(2);
     if (!strcmp(key, "gemm_glu96_launches")) return (double) mi::gemm_variant_launches(5);
-    if (!strcmp(key, "gemm_rf_launches"))   return (double) mi::gemm_variant_launches(6);
     if (!strcmp(key, "norm_from_split_launches")) return (double) mi::norm_from_split_launches();
     if (!strcmp(key, "norm_rope_split_launches")) return (double) mi::norm_rope_split_launches();
     if (!strcmp(key, "gemm_kq_launches"))   return (double) mi::gemm_variant_launches(3);
-    if (!strcmp(key, "gemm_sk_launches"))   return (double) mi::gemm_variant_launches(4);
     if (!strcmp(key, "fattn_dma_launches")) return (double) mi::fattn_dma_launches();
     if (!strncmp(key, "prof_", 5)) {
         std::string k(key + 5);

@@ -50,7 +50,6 @@ struct backend_ctx {
     void *  rope_scratch = nullptr; size_t rope_scratch_bytes = 0;
     // split-K partial sums of the prefill GEMM
     void *  gemm_partial = nullptr; size_t gemm_partial_bytes = 0;
-    void *  sk_part = nullptr; unsigned * sk_cnt = nullptr;      // stream-K GEMM (gemm_sk.hip): partial-tile slots and arrival counters (zero between launches)
 
     // small host -> device uploads (the per-token inputs of a decode step: embedding row, position, cache indices, mask row) are staged in
     // pinned memory and written by ONE launch in front of the next piece of stream work instead of one ~4 us copy each (backend.cpp)

@@ -558,14 +558,6 @@ static bool exec_gemm_group(exec_state & s, int i) {
     if (a.nmat == 1 && a.m[0].dst_cs % 16 == 0 && gemm_split_scratch_bytes(a.m[0].M, N, K) <= s.c->gemm_partial_bytes) a.partial = (float *) s.c->gemm_partial;
     else if (a.nmat > 1 && N <= gemm_group_split_max_cols() && s.c->gemm_partial_bytes > 0) a.partial = (float *) s.c->gemm_partial;      // short prompts: split-K for the grouped launches too
     a.partial_bytes = s.c->gemm_partial_bytes;
-    if (N > 128 && !kq) {                                       // more than one column tile: the stream-K launch may take it (gemm_f16_sk_ok); its scratch belongs to this context
-        if (!s.c->sk_part && !s.capturing) {                      // (first use is an eager submission: captures come from the second on)
-            if (hipMalloc(&s.c->sk_part, gemm_sk_part_bytes()) != hipSuccess) { (void) hipGetLastError(); s.c->sk_part = nullptr; }
-            else if (hipMalloc((void **) &s.c->sk_cnt, gemm_sk_count_bytes()) != hipSuccess) { (void) hipGetLastError(); (void) hipFree(s.c->sk_part); s.c->sk_part = nullptr; s.c->sk_cnt = nullptr; }
-            else HIP_CHECK(hipMemsetAsync(s.c->sk_cnt, 0, gemm_sk_count_bytes(), s.st));
-        }
-        a.sk_part = (float *) s.c->sk_part; a.sk_cnt = s.c->sk_cnt;
-    }
     // a streaming encoder chunk (<= 128 columns: split K, the result goes through the reduction launch): linear -> + bias -> + residual stream.  The second ADD
     // (only reader of the first, same shape, its other operand ready) rides in the reduction's epilogue too: (acc + bias) + residual, the two roundings of the two nodes.
     // ... and so does the GELU behind the bias of fc1 (linear -> + bias -> GELU -> fc2, the only reader chain): the reduction applies it and writes the f16 image fc2 reads; the f32
@@ -662,7 +654,7 @@ static bool exec_gemm_group(exec_state & s, int i) {
     int nsplit = 0;
     const ggml_tensor * Aout = a.nmat == 1 ? g->nodes[add2_idx[0] >= 0 ? add2_idx[0] : (add_idx[0] >= 0 ? add_idx[0] : i)] : nullptr;
     static const bool no_defer_reduce = getenv("MI355X_NO_REDUCE_IN_NORM") != nullptr;
-    if (!no_defer_reduce && un_idx < 0 && a.partial && !gemm_f16_sk_ok(a) && Aout && Aout->ne[2] == 1 && Aout->ne[3] == 1 && gemm_reduce_rms_norm_ok(Aout->ne[0]) && Aout->nb[1] % 16 == 0 &&
+    if (!no_defer_reduce && un_idx < 0 && a.partial && Aout && Aout->ne[2] == 1 && Aout->ne[3] == 1 && gemm_reduce_rms_norm_ok(Aout->ne[0]) && Aout->nb[1] % 16 == 0 &&
         (!a.m[0].resid || a.m[0].resid_cs % 16 == 0)) {
         int nx = (add2_idx[0] >= 0 ? add2_idx[0] : (add_idx[0] >= 0 ? add_idx[0] : i)) + 1;
         while (nx < g->n_nodes && (s.done[nx] || is_noop(g->nodes[nx]) || nx == add_idx[0] || nx == add2_idx[0])) ++nx;
@@ -678,11 +670,12 @@ static bool exec_gemm_group(exec_state & s, int i) {
     // every chain of its launch maps onto them and runs the reduction launch itself otherwise
     bool group_deferred = false;
     static const bool no_defer_group = getenv("MI355X_NO_REDUCE_IN_NORM_ROPE") != nullptr;
-    if (!no_defer_group && !no_defer_reduce && a.nmat >= 2 && un_idx < 0 && a.partial && !kq && N > MI_MMVQ_MAX_COLS && !s.prm.n && !gemm_f16_sk_ok(a)) {
+    if (!no_defer_group && !no_defer_reduce && a.nmat >= 2 && un_idx < 0 && a.partial && !kq && N > MI_MMVQ_MAX_COLS && !s.prm.n) {
         bool ok = true;
         for (int q = 0; q < a.nmat && ok; ++q) {
             const ggml_tensor * R = g->nodes[mm_idx[q]];
-            ok = add_idx[q] < 0 && add2_idx[q] < 0 && cpy_idx[q] < 0 && !a.m[q].resid && R->ne[2] == 1 && R->ne[3] == 1 && R->nb[1] == (size_t) R->ne[0] * 4 && a.m[q].M % 4 == 0 && !is_out(s, R);
+            ok = add_idx[q] < 0 && add2_idx[q] < 0 && cpy_idx[q] < 0 && !a.m[q].resid && R->ne[2] == 1 && R->ne[3] == 1 && R->nb[1] == (size_t) R->ne[0] * 4 && a.m[q].M % 4 == 0 && !is_out(s, R) &&
+                 n_users(s, R) == 1;      // (the norm chain / V store must be R's ONLY reader -- a second one would read rows materialise_group() skipped)
         }
         int nx = i + 1;                                                   // (the group's other mat-muls were hoisted up to node i: skip them)
         auto mine = [&](int k) { for (int q = 0; q < a.nmat; ++q) if (mm_idx[q] == k) return true; return false; };

@@ -271,17 +271,8 @@ struct gemm_multi_args {
     bool defer_multi = false;                 // the same for a grouped launch (nmat > 1, no addends): slab s = partial + s * (sum of M_i) * N floats, matrix i a dense [N][M_i] block at + (M_0 + .. + M_{i-1}) * N
     // gate / up + SWIGLU (gemm_glu_ok): no f32 outputs; f16 rows of silu(W[glu_gate].x) * (W[1 - glu_gate].x) go to glu_out16
     uint16_t * glu_out16 = nullptr; size_t glu_out16_rs = 0; int glu_gate = 0;
-    // persistent stream-K form (gemm_sk.hip) for launches the tile grid fills badly: partial-tile slots (gemm_sk_part_bytes()) and zeroed
-    // arrival counters (gemm_sk_count_bytes()) of the calling backend context (one stream: launches do not overlap)
-    float * sk_part = nullptr; unsigned * sk_cnt = nullptr;
 };
-bool   gemm_f16_sk_ok(const gemm_multi_args & a);               // gemm_f16_multi will take the stream-K launch for these arguments (no split-K slabs, no deferred reduction)
-void   gemm_f16_sk(const gemm_multi_args & a, hipStream_t st);
-size_t gemm_sk_part_bytes();
-size_t gemm_sk_count_bytes();
-int    gemm_sk_groups();                                          // CUs of the current device
-void   gemm_rf_set_mode(int m);                                   // -1: MI355X_GEMM_RF decides, 0 off, 2 / 4: k_gemm_f16_rf<depth> where legal
-void   gemm_sk_set_mode(int m);                                   // -1: MI355X_GEMM_SK decides (default off), 0 off, 1 wherever legal, 2 by the shape rule
+int    device_cu_count();                                        // CUs of the current device
 void   gemm_reduce(const float * partial, int nsplit, const float * resid, size_t resid_cs, float * dst, size_t dst_cs, int64_t M, int64_t N, hipStream_t st);
 void   gemm_reduce_group(const float * partial, int nsplit, size_t slab_elems, int nmat, const size_t * off, const int64_t * M, int64_t N, float * const * dst, const size_t * dst_cs, hipStream_t st);   // the reduction a deferred grouped launch owes (no addends)
 void   gemm_reduce2(const float * partial, int nsplit, const float * resid, size_t resid_cs, const float * resid2, size_t resid2_cs, float * dst, size_t dst_cs, int64_t M, int64_t N, hipStream_t st);

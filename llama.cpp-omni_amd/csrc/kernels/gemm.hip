@@ -272,140 +272,6 @@ __global__ void __launch_bounds__(256) k_gemm_f16_glds(const gemm_dev g) {
         }
 }
 
-// ---- the 128 x 128 x 64 tile with BOTH operands staged through REGISTERS, D K-steps ahead (k_gemm_f16_rf<D>).  What a CU can pull in per unit of time is
-// bytes in flight / round trip (profiles/r04_gemm_streamk.txt): the LDS-DMA kernels above can only keep what their LDS ring holds in flight -- one K-step per workgroup
-// here (2 x 32 KB with two workgroups per CU), against a ~2 us round trip for weight lines that come from HBM.  The register file is the bigger store: 512 KB per CU
-// against 160 KB of LDS.  Every thread asks for its 8 x 16 bytes of K-step s + D with plain loads into a ring of D x 8 vector registers (D = 4: 128 KB per workgroup
-// in flight, 256 KB per CU), and writes the registers of step s + 1 into the other LDS buffer after the MFMAs of step s (ds_write_b128 at the swizzled chunk position;
-// loads return in order, so the wait the compiler places there leaves the younger D - 1 steps in flight).  One barrier per K-step, LDS double-buffered as before.
-// Tile, wave layout, MFMA order, split-K slabs and epilogue are k_gemm_f16_glds<2>'s: results are bit-identical.
-typedef uint32_t u32x4g __attribute__((ext_vector_type(4)));
-template <int D>
-__global__ void __launch_bounds__(256) k_gemm_f16_rf(const gemm_dev g) {
-    static_assert(D == 2 || D == 4, "the ring depth is even (LDS buffer = ring slot & 1)");
-    constexpr int MB = 2, BM = 64 * MB, WTILEB = BM * H_ROWB, BUFB = WTILEB + H_TILEB;
-    char * const lds = gemm_lds;
-
-    const int nt    = g.tiles_m * g.tiles_n;
-    const int split = blockIdx.x / nt;
-    const int bid   = blockIdx.x % nt;
-    const int q = nt / 8, r = nt % 8, xcd = bid % 8, idx = bid / 8;
-    const int tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    int tm = tile / g.tiles_n; const int tn = tile % g.tiles_n;
-    int mi = 0;
-    if (g.nmat > 1 && tm >= g.tm_end[0]) { mi = 1; if (g.nmat > 2 && tm >= g.tm_end[1]) mi = 2; }
-    tm -= mi == 0 ? 0 : g.tm_end[mi - 1];
-    const char * const W = mi == 0 ? g.W[0] : (mi == 1 ? g.W[1] : g.W[2]);
-    const size_t w_rs = mi == 0 ? g.w_rs[0] : (mi == 1 ? g.w_rs[1] : g.w_rs[2]);
-    const int M = mi == 0 ? g.M[0] : (mi == 1 ? g.M[1] : g.M[2]);
-    const int N = g.N;
-    const int m0 = tm * BM, n0 = tn * G_BN;
-
-    const int t = threadIdx.x, lane = t & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-    const int wm = wave & 1, wn = wave >> 1;
-
-    // staging: instruction j of wave w covers rows 32 w + 8 j + [0, 8) of the W tile and of the X tile, lane l the 16-byte chunk l & 7 of row l >> 3 (8 whole 128-byte
-    // lines per instruction); in LDS the chunk sits at position (l & 7) ^ ((row >> 1) & 7) of its row (the fragment reads' swizzle)
-    const int r8 = lane >> 3, c8 = lane & 7;
-    uint32_t woff[4], xoff[4], loff[4];                                // (32-bit offsets from wave-uniform bases; launcher: M * w_rs, N * x_rs < 4 GB)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int row = wave * 32 + j * 8 + r8;
-        int mr = m0 + row; mr = mr < M ? mr : M - 1;
-        int nr = n0 + row; nr = nr < N ? nr : N - 1;
-        woff[j] = (uint32_t) ((size_t) mr * w_rs + c8 * 16);
-        xoff[j] = (uint32_t) ((size_t) nr * g.x_rs + c8 * 16);
-        loff[j] = (uint32_t) (row * H_ROWB + ((c8 ^ ((row >> 1) & 7)) << 4));
-    }
-    const int nk_all = g.K / H_BK;
-    const int k_lo = split * g.ksteps_per_split;
-    const int k_hi = k_lo + g.ksteps_per_split < nk_all ? k_lo + g.ksteps_per_split : nk_all;
-    const int nsteps = k_hi - k_lo;
-    u32x4g fw[D][4], fx[D][4];
-    auto load = [&](auto SLc, int ks) {
-        constexpr int SL = decltype(SLc)::value;
-        const bool in = ks < k_hi;
-        const char * const wb = in ? W + (size_t) ks * H_ROWB : W, * const xb = in ? g.X + (size_t) ks * H_ROWB : g.X;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { fx[SL][j] = *(const u32x4g *) (xb + (size_t) (in ? xoff[j] : 0u)); fw[SL][j] = *(const u32x4g *) (wb + (size_t) (in ? woff[j] : 0u)); }
-    };
-    auto store = [&](auto SLc) {                                       // ring slot SL -> LDS buffer SL & 1
-        constexpr int SL = decltype(SLc)::value;
-        char * const b = lds + (SL & 1) * BUFB;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { *(u32x4g *) (b + WTILEB + loff[j]) = fx[SL][j]; *(u32x4g *) (b + loff[j]) = fw[SL][j]; }
-    };
-
-    f16v acc[2][MB];
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < MB; ++b)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.0f;
-
-    const int fr = lane & 31, hb = lane >> 5, sw = (fr >> 1) & 7;
-    auto compute = [&](int buf) {
-        const char * wb = lds + buf * BUFB; const char * xb = wb + WTILEB;
-#pragma unroll
-        for (int kk = 0; kk < H_BK / 16; ++kk) {
-            const int co = ((kk * 2 + hb) ^ sw) << 4;
-            h8 af[2], bf[MB];
-#pragma unroll
-            for (int a = 0; a < 2; ++a) af[a] = *(const h8 *) (xb + (wn * 64 + a * 32 + fr) * H_ROWB + co);
-#pragma unroll
-            for (int b = 0; b < MB; ++b) bf[b] = *(const h8 *) (wb + (wm * 32 * MB + b * 32 + fr) * H_ROWB + co);
-#pragma unroll
-            for (int a = 0; a < 2; ++a)
-#pragma unroll
-                for (int b = 0; b < MB; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[a], bf[b], acc[a][b], 0, 0, 0);
-        }
-    };
-    // step i (ring slot i % D, LDS buffer i & 1): barrier -- its tile is visible and the other buffer is free --, ask for step i + D into the slot just consumed, the MFMAs,
-    // then step i + 1's registers into the other buffer.  The loop is branch-free (launcher: the K range of a workgroup is a multiple of D steps): with conditions inside
-    // -- or two forms of the prologue -- the compiler's s_waitcnt in front of the ds_writes must be safe on every path and becomes vmcnt(0): the ring drained once per
-    // round.  Requests past the range's end go, all lanes alike, to the first 16 bytes of the operands (one line per instruction), their registers are never written out.
-    auto step = [&](auto SLc, int i) {
-        constexpr int SL = decltype(SLc)::value;
-        __syncthreads();
-        load(SLc, k_lo + i + D);
-        __builtin_amdgcn_sched_barrier(0);                             // (the requests first: left alone, the scheduler puts the ds_writes -- and their wait -- in front of them)
-        compute(SL & 1);
-        __builtin_amdgcn_sched_barrier(0);
-        store(std::integral_constant<int, (SL + 1) % D>());
-    };
-    load(std::integral_constant<int, 0>(), k_lo);
-    load(std::integral_constant<int, 1>(), k_lo + 1);
-    if (D > 2) { load(std::integral_constant<int, 2 % D>(), k_lo + 2); load(std::integral_constant<int, 3 % D>(), k_lo + 3); }
-    __builtin_amdgcn_sched_barrier(0);
-    store(std::integral_constant<int, 0>());
-    for (int i = 0; i < nsteps; i += D) {
-        step(std::integral_constant<int, 0>(), i);
-        step(std::integral_constant<int, 1>(), i + 1);
-        if (D > 2) { step(std::integral_constant<int, 2 % D>(), i + 2); step(std::integral_constant<int, 3 % D>(), i + 3); }
-    }
-
-    char * dst = (mi == 0 ? g.dst[0] : (mi == 1 ? g.dst[1] : g.dst[2])) + (size_t) split * g.split_stride;
-    const size_t dst_cs = mi == 0 ? g.dst_cs[0] : (mi == 1 ? g.dst_cs[1] : g.dst_cs[2]);
-    const char * resid = mi == 0 ? g.resid[0] : (mi == 1 ? g.resid[1] : g.resid[2]);
-    const size_t resid_cs = mi == 0 ? g.resid_cs[0] : (mi == 1 ? g.resid_cs[1] : g.resid_cs[2]);
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < MB; ++b) {
-            const int m = m0 + wm * 32 * MB + b * 32 + (lane & 31);
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int n = n0 + wn * 64 + a * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
-                if (m < M && n < N) {
-                    float v = acc[a][b][e];
-                    if (resid) v += *(const float *) (resid + (size_t) n * resid_cs + (size_t) m * 4);
-                    *(float *) (dst + (size_t) n * dst_cs + (size_t) m * 4) = v;
-                }
-            }
-        }
-}
 
 // ---- K-quant weights de-quantised INSIDE the LDS staging (few columns: short prompts, omni stream_prefill chunks).  At N <= 256 the F16 GEMM
 // above is bound by streaming the resident F16 weight images (2 B per weight: 386 MB per Qwen3-8B layer); here the workgroup reads the Q4_K /
@@ -1045,6 +911,12 @@ __global__ void __launch_bounds__(256) k_gemm_reduce_rms_norm(const float * __re
     }
 }
 
+// the reduction kernels that read the slabs into registers (k_gemm_reduce_multi, k_gemm_reduce_rms_norm; k_norm_rows / k_norm_rope_v4 with slab sources) hold at most
+// this many -- pick_ksplit never asks for more; a caller that does is a programming error, not a silently short sum
+constexpr int GEMM_MAX_SPLIT = 8;
+static void check_nsplit(int nsplit, const char * who) {
+    if (nsplit < 1 || nsplit > GEMM_MAX_SPLIT) { fprintf(stderr, "[mi355x] %s: %d K slabs, the reduction kernels sum at most %d\n", who, nsplit, GEMM_MAX_SPLIT); abort(); }
+}
 void gemm_reduce(const float * partial, int nsplit, const float * resid, size_t resid_cs, float * dst, size_t dst_cs, int64_t M, int64_t N, hipStream_t st) {
     const int64_t quads = M * N / 4;
     if (quads == 0) return;
@@ -1052,6 +924,7 @@ void gemm_reduce(const float * partial, int nsplit, const float * resid, size_t 
 }
 // the reduction of a grouped launch whose caller deferred it (defer_multi) and could not fold it into its next kernel after all
 void gemm_reduce_group(const float * partial, int nsplit, size_t slab_elems, int nmat, const size_t * off, const int64_t * M, int64_t N, float * const * dst, const size_t * dst_cs, hipStream_t st) {
+    check_nsplit(nsplit, "gemm_reduce_group");
     gemm_reduce_multi_dev r; r.nmat = nmat; r.nsplit = nsplit; r.N = (int) N; r.split_elems = slab_elems;
     int64_t quads = 0;
     for (int i = 0; i < 3; ++i) {
@@ -1066,6 +939,7 @@ void gemm_reduce2(const float * partial, int nsplit, const float * resid, size_t
     if (!resid2) { gemm_reduce(partial, nsplit, resid, resid_cs, dst, dst_cs, M, N, st); return; }
     const int64_t quads = M * N / 4;
     if (quads == 0) return;
+    check_nsplit(nsplit, "gemm_reduce2");
     gemm_reduce_multi_dev r; r.nmat = 1; r.nsplit = nsplit; r.N = (int) N; r.split_elems = (size_t) M * (size_t) N;
     for (int i = 0; i < 3; ++i) { r.off[i] = 0; r.M[i] = i == 0 ? (int) M : 0; r.resid[i] = (const char *) resid; r.resid_cs[i] = resid_cs; r.resid2[i] = (const char *) resid2; r.resid2_cs[i] = resid2_cs; r.dst[i] = (char *) dst; r.dst_cs[i] = dst_cs; }
     k_gemm_reduce_multi<<<dim3((unsigned) ((quads + 255) / 256)), dim3(256), 0, st>>>(partial, r);
@@ -1074,6 +948,7 @@ bool gemm_reduce_rms_norm_ok(int64_t M) { return M % 4 == 0 && M <= 16384; }
 void gemm_reduce_rms_norm(const float * partial, int nsplit, const float * resid, size_t resid_cs, float * dst, size_t dst_cs, const float * w, float eps,
                           float * y32, size_t y32_cs, uint16_t * y16, size_t y16_rs, int64_t M, int64_t N, hipStream_t st) {
     if (M == 0 || N == 0) return;
+    check_nsplit(nsplit, "gemm_reduce_rms_norm");
     if (M <= 4096) k_gemm_reduce_rms_norm<4><<<dim3((unsigned) N), dim3(256), 0, st>>>(partial, nsplit, (size_t) M * (size_t) N, (const char *) resid, resid_cs, (char *) dst, dst_cs, w, eps,
                                                                                    (char *) y32, y32_cs, (char *) y16, y16_rs, (int) M);
     else           k_gemm_reduce_rms_norm<16><<<dim3((unsigned) N), dim3(256), 0, st>>>(partial, nsplit, (size_t) M * (size_t) N, (const char *) resid, resid_cs, (char *) dst, dst_cs, w, eps,
@@ -1122,10 +997,16 @@ size_t gemm_split_scratch_bytes(int64_t M, int64_t N, int64_t K) {
     return s > 1 ? (size_t) s * (size_t) M * (size_t) N * 4 : 0;
 }
 
+int device_cu_count() {                                        // CUs of the current device (cached per device)
+    static int cus[64] = {};
+    int dev = 0; HIP_CHECK(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 64) dev = 0;
+    if (!cus[dev]) { hipDeviceProp_t pr; HIP_CHECK(hipGetDeviceProperties(&pr, dev)); cus[dev] = pr.multiProcessorCount > 0 ? pr.multiProcessorCount : 1; }
+    return cus[dev];
+}
+
 // launches per tile variant (tests assert that a shape really selected the kernel it is meant to cover): 0 = 256 x 256, 1 = 192-row
-static int g_rf_mode = -1;                                      // option "gemm_rf": -1 = MI355X_GEMM_RF decides, 0 off, 2 / 4 = ring depth
-void gemm_rf_set_mode(int m) { g_rf_mode = m; }
-static long g_gemm_variant_launches[7] = { 0, 0, 0, 0, 0, 0, 0 };  // ... 2 = gate / up + SWIGLU, 3 = K-quant staging, 4 = stream-K (gemm_sk.hip), 5 = the 96-row tiles among 2, 6 = register-ring staging (k_gemm_f16_rf)
+static long g_gemm_variant_launches[7] = { 0, 0, 0, 0, 0, 0, 0 };  // ... 2 = gate / up + SWIGLU, 3 = K-quant staging, 4 = unused (the stream-K lab form, tools/lab), 5 = the 96-row tiles among 2, 6 = unused (the register-ring lab form)
 long gemm_variant_launches(int v) { return v >= 0 && v < 7 ? g_gemm_variant_launches[v] : 0; }
 // gate / up + SWIGLU in one launch: equal shapes and row strides, whole 128-row blocks, enough tiles to occupy the chip
 bool gemm_glu_ok(const gemm_multi_args & a) {
@@ -1170,7 +1051,7 @@ void gemm_f16_multi(const gemm_multi_args & a, hipStream_t st) {
         static const int r96_env = getenv("MI355X_GEMM_GLU96") ? atoi(getenv("MI355X_GEMM_GLU96")) : -1;
         if ((size_t) a.N * a.x_rs >= (1ull << 32)) { fprintf(stderr, "[mi355x] gemm: activation image of %lld rows x %zu bytes is past the 32-bit offsets of the GLU kernel\n", (long long) a.N, a.x_rs); abort(); }
         const int tiles_n256 = (int) ((a.N + 255) / 256);
-        const int64_t cus = (int64_t) gemm_sk_groups();                  // (CUs of the current device)
+        const int64_t cus = (int64_t) device_cu_count();                  // (CUs of the current device)
         const int64_t t128 = (a.m[0].M / 128) * tiles_n256, t96 = ((a.m[0].M + 95) / 96) * tiles_n256;
         const bool r96 = r96_env >= 0 ? r96_env != 0 : ((t96 + cus - 1) / cus) * 3 < ((t128 + cus - 1) / cus) * 4;
         const int tm128 = r96 ? (int) ((a.m[0].M + 95) / 96) : (int) (a.m[0].M / 128);
@@ -1222,12 +1103,7 @@ void gemm_f16_multi(const gemm_multi_args & a, hipStream_t st) {
     for (int i = 0; i < a.nmat; ++i) if ((size_t) a.m[i].M * a.m[i].w_rs >= (1ull << 32)) big = false;     // (k_gemm_f16_ph8 addresses its operands with 32-bit offsets)
     if ((size_t) a.N * a.x_rs >= (1ull << 32)) big = false;
     if (any_q) { BM = G_BM; big = false; }                    // K-quant blocks de-quantised in the staging: the 128 x 128 kernel (few columns by construction)
-    if (a.probe_path) { *a.probe_path = (!big && !any_q && !gemm_f16_sk_ok(a) && a.nbatch <= 1) ? 1 : 0; return; }
-    if (!big && gemm_f16_sk_ok(a)) {                          // tile grids that fill the chip badly (a 512-token ubatch: 128-192 tiles): one persistent stream-K launch, no slabs
-        gemm_f16_sk(a, st);
-        ++g_gemm_variant_launches[4];
-        return;
-    }
+    if (a.probe_path) { *a.probe_path = (!big && !any_q && a.nbatch <= 1) ? 1 : 0; return; }
     if (big) BM = 256;
     int tm = 0;
     for (int i = 0; i < 3; ++i) {
@@ -1299,11 +1175,6 @@ void gemm_f16_multi(const gemm_multi_args & a, hipStream_t st) {
                                                   (a.m[i].y16_ms == 2 && (a.m[i].y16_rs % 8 != 0 || ((uintptr_t) a.m[i].y16 & 7) != 0)) || a.m[i].y16_ms % 2 != 0 || a.m[i].y16_rs % 2 != 0 || a.m[i].M % 4 != 0)) {
             fprintf(stderr, "[mi355x] gemm: f16 rows / an activation out of the epilogue need the split-K reduction launch (ask gemm_f16_small_n_ksplit first), GELU / GELU_QUICK and aligned f16 rows\n"); abort();
         }
-    // register-ring staging (k_gemm_f16_rf): the plain F16 tile form only (no batch, no K-quant staging, 128-row tiles), operands within 32-bit offsets
-    static const int rf_env0 = getenv("MI355X_GEMM_RF") ? atoi(getenv("MI355X_GEMM_RF")) : 0;
-    const int rf_env = g_rf_mode >= 0 ? g_rf_mode : rf_env0;
-    int use_rf = (rf_env == 2 || rf_env == 4) && BM == G_BM && nbatch == 1 && !kq && (size_t) a.N * a.x_rs < (1ull << 32) && nk % ksplit == 0 && (nk / ksplit) % rf_env == 0 ? rf_env : 0;
-    for (int i = 0; i < a.nmat; ++i) if ((size_t) a.m[i].M * a.m[i].w_rs >= (1ull << 32)) use_rf = 0;
     if (ksplit == 1)
         for (int i = 0; i < a.nmat; ++i) if (a.m[i].y16) { g.y16[i] = (char *) a.m[i].y16; g.y16_rs[i] = a.m[i].y16_rs; g.y16_ms[i] = a.m[i].y16_ms; if (!a.m[i].y32) g.dst[i] = nullptr; }
     if (ksplit > 1) {
@@ -1316,10 +1187,9 @@ void gemm_f16_multi(const gemm_multi_args & a, hipStream_t st) {
         }
         g.split_stride = slab * 4;
         if (kq) { k_gemm_kq_glds<<<dim3((unsigned) (tm * tiles_n * ksplit)), dim3(256), 2 * (128 * H_ROWB + H_TILEB), st>>>(g); ++g_gemm_variant_launches[3]; }
-        else if (use_rf == 4) { k_gemm_f16_rf<4><<<dim3((unsigned) (tm * tiles_n * ksplit)), dim3(256), 2 * (128 * H_ROWB + H_TILEB), st>>>(g); ++g_gemm_variant_launches[6]; }
-        else if (use_rf == 2) { k_gemm_f16_rf<2><<<dim3((unsigned) (tm * tiles_n * ksplit)), dim3(256), 2 * (128 * H_ROWB + H_TILEB), st>>>(g); ++g_gemm_variant_launches[6]; }
         else    k_gemm_f16_glds<2><<<dim3((unsigned) (tm * tiles_n * ksplit)), dim3(256), 2 * (128 * H_ROWB + H_TILEB), st>>>(g);
         if (a.deferred_split && (a.nmat == 1 || a.defer_multi)) { *a.deferred_split = ksplit; return; }          // the caller fuses the reduction into its next kernel
+        check_nsplit(ksplit, "gemm_f16_multi");
         gemm_reduce_multi_dev r; r.nmat = a.nmat; r.nsplit = ksplit; r.N = (int) a.N; r.split_elems = slab;
         off = 0; int64_t quads = 0;
         for (int i = 0; i < 3; ++i) {
@@ -1342,10 +1212,6 @@ void gemm_f16_multi(const gemm_multi_args & a, hipStream_t st) {
     } else if (kq) {
         k_gemm_kq_glds<<<dim3((unsigned) (tm * tiles_n)), dim3(256), 2 * (128 * H_ROWB + H_TILEB), st>>>(g);
         ++g_gemm_variant_launches[3];
-    } else if (use_rf == 4) {
-        k_gemm_f16_rf<4><<<dim3((unsigned) (tm * tiles_n)), dim3(256), 2 * (128 * H_ROWB + H_TILEB), st>>>(g); ++g_gemm_variant_launches[6];
-    } else if (use_rf == 2) {
-        k_gemm_f16_rf<2><<<dim3((unsigned) (tm * tiles_n)), dim3(256), 2 * (128 * H_ROWB + H_TILEB), st>>>(g); ++g_gemm_variant_launches[6];
     } else {
         k_gemm_f16_glds<2><<<dim3((unsigned) (tm * tiles_n), (unsigned) nbatch), dim3(256), 2 * (128 * H_ROWB + H_TILEB), st>>>(g);
     }

@@ -177,49 +177,6 @@ def test_8b_q8_0_greedy_ids_identical_through_libllama(tmp_path):
         os.remove(gguf)
 
 
-# ---- the persistent stream-K form of the F16 GEMM (gemm_sk.hip): off by default (measured slower than the launch form, profiles/r04_gemm_streamk.txt),
-# kept selectable (option "gemm_sk") -- so its results stay pinned: against the products of the f16-rounded operands in float64, and against itself
-@pytest.mark.parametrize("Ms,K,N,resid", [((4096,), 4096, 512, True),             # wo at ubatch 512: two contributors per 256 x 128 tile ... four
-                                          ((4096, 1024, 1024), 4096, 512, False),   # wq / wk / wv as one launch: ranges that straddle tiles and matrices
-                                          ((1000, 520), 1024, 300, False),          # ragged M and N
-                                          ((384,), 8192, 129, False),               # a second column tile of one column
-                                          ((128,), 64 * 300, 256, True)])           # one tile row, a long K: many contributors per tile
-def test_stream_k_gemm_vs_float64_and_repeatable(pkg, be, Ms, K, N, resid):
-    import numpy as np
-    from llama_cpp_omni_amd.ggml import GGML_TYPE_F16, GGML_TYPE_F32, Context
-    be.set_option("gemm_sk", 1)
-    try:
-        rng = np.random.default_rng(len(Ms) * 1000 + N)
-        c = Context(be)
-        x = c.new_tensor(GGML_TYPE_F32, K, N)
-        ws = [c.new_tensor(GGML_TYPE_F16, K, M) for M in Ms]
-        ys = [c.mul_mat(w, x) for w in ws]
-        rs = [c.new_tensor(GGML_TYPE_F32, M, N) for M in Ms] if resid else []
-        if resid: ys = [c.add(y, r) for y, r in zip(ys, rs)]
-        c.alloc()
-        xv = rng.standard_normal((N, K), dtype=np.float32)
-        wv = [(rng.standard_normal((M, K), dtype=np.float32) * 0.05).astype(np.float16) for M in Ms]
-        rv = [rng.standard_normal((N, M), dtype=np.float32) for M in Ms] if resid else []
-        be.tensor_set(x, xv.ravel())
-        for w, v in zip(ws, wv): be.tensor_set(w, v.ravel())
-        for r, v in zip(rs, rv): be.tensor_set(r, v.ravel())
-        g = c.graph()
-        before = be.get_stat("gemm_sk_launches")
-        runs = []
-        for _ in range(3):
-            be.graph_compute(g); be.synchronize()
-            runs.append([be.tensor_get(y).copy().reshape(N, -1) for y in ys])
-        assert be.get_stat("gemm_sk_launches") - before == 3, "the launches did not take the stream-K kernel"
-        xh = xv.astype(np.float16).astype(np.float64)
-        for i, M in enumerate(Ms):
-            ref = xh @ wv[i].astype(np.float64).T + (rv[i] if resid else 0.0)
-            err = float(np.abs(runs[0][i] - ref).max() / np.abs(ref).max())
-            assert err < 2e-6, (M, err)                                             # f32 accumulation of K <= 19200 products
-            assert (runs[0][i] == runs[1][i]).all() and (runs[0][i] == runs[2][i]).all(), "the fold depends on the arrival order"
-    finally:
-        be.set_option("gemm_sk", -1)
-
-
 # ---- the LDS-DMA ring form of the prefill FLASH_ATTN_EXT kernel (fattn_mma.hip k_fattn_dma128: K / V tiles by global_load_lds, V^T fragments by
 # ds_read_b64_tr_b16, two heads of a KV head per workgroup, deferred running maximum): taken for head size 128 from 512 workgroups on.  Against the
 # float64 restatement of ggml_compute_forward_flash_attn_ext_f16 (ops.cpp:7912-8148), bar = the reference's NMSE 5e-4 for this op, and against the
@@ -456,37 +413,6 @@ def test_gate_up_swiglu_96_row_tiles_vs_oracle(pkg, be, F):
     assert np.isfinite(outs[0]).all()
     assert nmse(outs[0][cols], want) < 1e-6, nmse(outs[0][cols], want)
     assert nmse(outs[0], outs[1]) < 1e-9, nmse(outs[0], outs[1])
-
-
-def test_register_ring_gemm_is_bit_identical_to_the_lds_dma_form(pkg, be):
-    """k_gemm_f16_rf<D> (option "gemm_rf" = 2 / 4: both operands through a ring of D x 8 vector registers per thread, D K-steps ahead; OFF by default -- it measured
-    parity: the 512-column GEMMs are bound by the CU's line-request rate, not by bytes in flight) keeps k_gemm_f16_glds<2>'s tile, MFMA order, split-K slabs and
-    epilogue: every bit of the result must agree, at a shape with split-K and a residual-free epilogue and at one whose column count is ragged."""
-    rng = np.random.default_rng(404)
-    try:
-        for (M, K, N) in [(1024, 4096, 512), (512, 2048, 200)]:
-            c = pkg.Context(be)
-            w = c.new_tensor(pkg.GGML_TYPE_F16, K, M); x = c.new_tensor(pkg.GGML_TYPE_F32, K, N)
-            y = c.mul_mat(w, x)
-            c.alloc()
-            wv = (rng.standard_normal((M, K)) * 0.05).astype(np.float16); xv = rng.standard_normal((N, K)).astype(np.float32)
-            be.tensor_set(w, wv); be.tensor_set(x, xv)
-            g = c.graph()
-            outs = {}
-            for mode in (0, 4, 2):
-                be.set_option("gemm_rf", mode)
-                n0 = be.get_stat("gemm_rf_launches")
-                be.graph_compute(g); be.synchronize()
-                outs[mode] = be.tensor_get(y).copy()
-                assert (be.get_stat("gemm_rf_launches") - n0 > 0) == (mode != 0), (mode, M, K, N)
-            for mode in (2, 4):
-                assert np.array_equal(outs[0].view(np.uint32), outs[mode].view(np.uint32)), (mode, M, K, N)
-            want = xv.astype(np.float16).astype(np.float64) @ wv.astype(np.float64).T
-            err = np.abs(outs[4].reshape(N, M) - want).max() / np.abs(want).max()
-            assert err < 1e-5, err
-            c.free()
-    finally:
-        be.set_option("gemm_rf", -1)
 
 
 @pytest.mark.parametrize("E,F,N,two_addends", [(1024, 4096, 50, True), (1024, 1024, 100, True), (1152, 4304 - 16, 64, True), (1024, 4096, 50, False)])

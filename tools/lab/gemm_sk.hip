@@ -1,3 +1,6 @@
+// tools/lab/gemm_sk.hip (LAB, not in the product build since round 5: the persistent stream-K form of the F16 GEMM measured slower than the launch form inside the model,
+// profiles/r04_gemm_streamk.txt).  The file as it stood at csrc/kernels/gemm_sk.hip in commit 5985770 (it needs that tree's kernels.hpp: gemm_multi_args::sk_part / sk_cnt and the
+// gemm_f16_sk_ok() / gemm_f16_sk() hooks in gemm_f16_multi(); tools/lab/gemm_sk_check.py drove it through the option "gemm_sk").
 // gemm_sk.hip -- the F16 GEMM on 256 (m) x 128 (n) tiles as ONE persistent, stream-K launch: a workgroup per CU walks an equal share of
 // the launch's (tile, K-step) units, whatever the tile count is.
 //
