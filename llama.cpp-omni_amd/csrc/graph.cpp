@@ -333,6 +333,7 @@ int mi355x_set_option(struct ggml_backend * backend, const char * key, long valu
     if (!strcmp(key, "mv1")) { c->opt_mv1 = value != 0; mi::drop_graph_execs(c); return 0; }
     if (!strcmp(key, "batch_uploads")) { flush_uploads(c); c->opt_batch_uploads = value != 0; return 0; }
     if (!strcmp(key, "fp_collide")) { mi::g_fp_collide = value != 0; return 0; }
+    if (!strcmp(key, "mmq_tile")) { mi::mmq_tile_set_mode((int) value); mi::drop_graph_execs(c); return 0; }      // (process-wide: the tiled int8-MFMA prefill kernel for Q4_K weights, mmq_tile.hip; 0 = the F16-image GEMM)
     if (!strcmp(key, "mv2")) { mi::mmv2_enable(value != 0); mi::drop_graph_execs(c); return 0; }       // (process-wide: the LDS-DMA engine form of the decode mat-vec)
     if (!strcmp(key, "kq_staging")) { c->opt_kq_staging = value != 0; mi::drop_graph_execs(c); return 0; }
     if (!strcmp(key, "fattn_gqa")) { mi::fattn_set_gqa(value != 0); mi::drop_graph_execs(c); return 0; }
@@ -356,6 +357,7 @@ double mi355x_get_stat(struct ggml_backend * backend, const char * key) {
     if (!strcmp(key, "gemm_glu96_launches")) return (double) mi::gemm_variant_launches(5);
     if (!strcmp(key, "norm_from_split_launches")) return (double) mi::norm_from_split_launches();
     if (!strcmp(key, "norm_rope_split_launches")) return (double) mi::norm_rope_split_launches();
+    if (!strcmp(key, "mmq_tile_launches"))  return (double) mi::mmq_tile_launches();
     if (!strcmp(key, "gemm_kq_launches"))   return (double) mi::gemm_variant_launches(3);
     if (!strcmp(key, "fattn_dma_launches")) return (double) mi::fattn_dma_launches();
     if (!strncmp(key, "prof_", 5)) {

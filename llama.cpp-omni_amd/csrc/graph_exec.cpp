@@ -16,11 +16,13 @@ static size_t prepare_act(exec_state & s, const ggml_tensor * x, act_kind kind) 
     const size_t img = act_image_bytes(kind, K);
     if (s.pn.m && x == s.pn.m) materialise_norm(s);                      // a consumer outside the in-kernel-norm launches
     if (kind == ACT_F32) return 0;
+    if (kind == ACT_Q8KT && (ne12 != 1 || ne13 != 1 || x->type != GGML_TYPE_F32)) { fprintf(stderr, "[mi355x] prepare_act: the block-major Q8_K image takes one 2-D f32 activation\n"); abort(); }
     const bool cached = s.a_src == x->data && s.a_kind == kind && s.a_K == K && s.a_ne[0] == N && s.a_ne[1] == ne12 &&
                         s.a_ne[2] == ne13 && s.a_nb[0] == x->nb[1] && s.a_nb[1] == x->nb[2] && s.a_nb[2] == x->nb[3];
     if (cached) return img;
     auto conv = [&](const float * src, size_t xs, void * out, int64_t rows) {
         if      (kind == ACT_Q8K) quantize_q8k_image(src, xs, out, K, rows, s.st);
+        else if (kind == ACT_Q8KT) quantize_q8k_tile_image(src, xs, out, K, rows, s.st);
         else if (kind == ACT_Q80) quantize_q80_image(src, xs, out, K, rows, s.st);
         else                      convert_f32_f16_rows(src, xs, (uint16_t *) out, img, K, rows, s.st);
         ++s.n_kernels;
@@ -91,6 +93,16 @@ static void op_mul_mat(exec_state & s, const ggml_tensor * dst, const ggml_tenso
     const int64_t ne12 = x->ne[2], ne13 = x->ne[3];
     const int64_t r2 = ne12 / w->ne[2], r3 = ne13 / w->ne[3];
 
+    if (mm_uses_mmq_tile(dst)) {                                // Q4_K x a prefill ubatch: the tiled int8-MFMA kernel on the Q8_K image (mmq_tile.hip)
+        prepare_act(s, x, ACT_Q8KT);
+        mmqt_args q;
+        q.nmat = 1; q.m[0] = { w->data, w->nb[1], (float *) dst->data, dst->nb[1], M }; q.img = s.c->act_scratch; q.N = N; q.K = K;
+        if (dst->nb[1] % 16 == 0 && gemm_split_scratch_bytes(M, N, K) <= s.c->gemm_partial_bytes) { q.partial = (float *) s.c->gemm_partial; q.partial_bytes = s.c->gemm_partial_bytes; }
+        prof_scope ps(s, "mmq_tile", 2.0 * (double) M * (double) N * (double) K);
+        mmq_tile(q, s.st);
+        ++s.n_kernels;
+        return;
+    }
     if (mm_uses_gemm(dst)) {
         // ---- prefill: MFMA GEMM.  X -> f16 rows (what the reference does for F16 weights, ggml-cpu.c:1245-1268); quantised W -> f16
         const size_t ximg = prepare_act(s, x, ACT_F16);
@@ -480,7 +492,8 @@ static bool exec_gemm_group(exec_state & s, int i) {
     gemm_multi_args a;
     a.nmat = 0; a.N = N; a.K = K; a.partial = nullptr;
     int mm_idx[3] = { i, -1, -1 };
-    const bool kq = kq_in_staging(s, n->src[0], N);            // then every matrix of the launch must be K-quant blocks too
+    const bool qt = mm_uses_mmq_tile(n);                       // Q4_K blocks x the block-major Q8_K image on the int8 matrix cores (mmq_tile.hip): raw blocks like kq
+    const bool kq = qt || kq_in_staging(s, n->src[0], N);      // then every matrix of the launch must be K-quant blocks too
     {
         const uint16_t * w16; size_t rs;
         if (kq) { w16 = (const uint16_t *) n->src[0]->data; rs = n->src[0]->nb[1]; }
@@ -491,7 +504,8 @@ static bool exec_gemm_group(exec_state & s, int i) {
         ggml_tensor * c = g->nodes[j];
         if (s.done[j] || !gemm_groupable(c) || !same_act(c->src[1], x)) continue;
         if (!can_hoist(s, i, j, mm_idx, a.nmat)) continue;
-        if (kq != kq_in_staging(s, c->src[0], N)) continue;
+        if (qt != mm_uses_mmq_tile(c)) continue;
+        if (!qt && kq != kq_in_staging(s, c->src[0], N)) continue;
         const uint16_t * w16; size_t rs;
         if (kq) { w16 = (const uint16_t *) c->src[0]->data; rs = c->src[0]->nb[1]; }
         else if (!gemm_operand(s, c->src[0], &w16, &rs)) continue;
@@ -541,8 +555,9 @@ static bool exec_gemm_group(exec_state & s, int i) {
             }
         }
     }
-    const size_t ximg = prepare_act(s, x, ACT_F16);
+    const size_t ximg = prepare_act(s, x, qt ? ACT_Q8KT : ACT_F16);
     a.X = (const uint16_t *) s.c->act_scratch; a.x_rs = ximg;
+    if (qt) a.qt_img = s.c->act_scratch;
     if (glu_idx >= 0) {
         double flops = 2.0 * 2.0 * (double) a.m[0].M * (double) N * (double) K;
         {
@@ -670,7 +685,7 @@ static bool exec_gemm_group(exec_state & s, int i) {
     // every chain of its launch maps onto them and runs the reduction launch itself otherwise
     bool group_deferred = false;
     static const bool no_defer_group = getenv("MI355X_NO_REDUCE_IN_NORM_ROPE") != nullptr;
-    if (!no_defer_group && !no_defer_reduce && a.nmat >= 2 && un_idx < 0 && a.partial && !kq && N > MI_MMVQ_MAX_COLS && !s.prm.n) {
+    if (!no_defer_group && !no_defer_reduce && a.nmat >= 2 && un_idx < 0 && a.partial && (!kq || qt) && N > MI_MMVQ_MAX_COLS && !s.prm.n) {
         bool ok = true;
         for (int q = 0; q < a.nmat && ok; ++q) {
             const ggml_tensor * R = g->nodes[mm_idx[q]];
@@ -686,7 +701,7 @@ static bool exec_gemm_group(exec_state & s, int i) {
         if (ok && hit) { a.deferred_split = &nsplit; a.defer_multi = true; group_deferred = true; }
     }
     {
-        prof_scope ps(s, "gemm_f16", flops);
+        prof_scope ps(s, qt ? "mmq_tile" : "gemm_f16", flops);
         gemm_f16_multi(a, s.st);
     }
     ++s.n_kernels;
@@ -955,7 +970,7 @@ static bool gemm_only_consumers(exec_state & s, const ggml_tensor * t, int64_t K
     const ggml_tensor * x0 = nullptr;
     for (int u : it->second) {
         const ggml_tensor * c = s.g->nodes[u];
-        if (c->op != GGML_OP_MUL_MAT || is_empty(c) || !mm_uses_gemm(c)) return false;
+        if (c->op != GGML_OP_MUL_MAT || is_empty(c) || !mm_uses_gemm(c) || mm_uses_mmq_tile(c)) return false;      // (mmq_tile.hip reads the Q8_K image it builds from the f32 rows)
         const ggml_tensor * x = c->src[1];
         if (x->type != GGML_TYPE_F32 || x->data != t->data || x->ne[0] != K || x->ne[1] != N || x->ne[2] != 1 || x->ne[3] != 1 || x->nb[1] != (size_t) K * 4 ||
             c->src[0]->data == t->data) return false;

@@ -24,7 +24,7 @@ static inline bool is_noop(const ggml_tensor * t) {
            t->op == GGML_OP_TRANSPOSE || is_empty(t);
 }
 
-enum act_kind { ACT_NONE = 0, ACT_Q8K, ACT_Q80, ACT_F16, ACT_F32 };
+enum act_kind { ACT_NONE = 0, ACT_Q8K, ACT_Q80, ACT_F16, ACT_F32, ACT_Q8KT };      // Q8KT: the block-major Q8_K image of a whole ubatch (mmq_tile.hip), not a per-row format
 // block formats without integer-dot kernels of their own: every MUL_MAT runs on the F16 image of the weights (resident for model
 // tensors, shadow.hpp; else de-quantised into scratch per call) with f16-rounded activations -- the arithmetic of the prefill GEMM
 static inline bool is_image_quant(int t) {
@@ -118,6 +118,8 @@ static const int64_t ROPE_TABLE_MIN_TOKENS = 32;
 static const int64_t GEMM_MIN_COLS = MI_MMVQ_MAX_COLS + 1;
 bool mm_uses_mmq(const ggml_tensor * n);
 bool mm_uses_gemm(const ggml_tensor * n);
+bool mm_uses_mmq_tile(const ggml_tensor * n);
+void mmq_tile_set_mode(int m);
 int64_t mmq_max_cols();
 bool mm_uses_gemm_any_f16(const ggml_tensor * n);
 size_t graph_act_scratch_need(const ggml_cgraph * g);

@@ -173,6 +173,19 @@ bool mm_uses_mmq(const ggml_tensor * n) {
            mmq_ok(w->type, w->ne[0], w->data, w->nb[1]) && (w->ne[2] == 1 || mmq_ok(w->type, w->ne[0], (const char *) w->data + w->nb[2], w->nb[1])) &&
            (w->ne[3] == 1 || mmq_ok(w->type, w->ne[0], (const char *) w->data + w->nb[3], w->nb[1]));
 }
+// Q4_K weights against a prefill ubatch (more than mmq_max_cols() columns): the tiled int8-MFMA kernel on the blocks themselves and the Q8_K-quantised
+// activations -- the oracle's integers (mmq_tile.hip).  A sub-case of mm_uses_gemm(): the grouping / residual / split-K machinery of the GEMM path serves it.
+static int g_mmq_tile = -1;                                   // option "mmq_tile": -1 = MI355X_MMQ_TILE decides (default on), 0 off, 1 on
+void mmq_tile_set_mode(int m) { g_mmq_tile = m; }
+bool mm_uses_mmq_tile(const ggml_tensor * n) {
+    static const int env = getenv("MI355X_MMQ_TILE") ? atoi(getenv("MI355X_MMQ_TILE")) : 1;
+    if (!(g_mmq_tile >= 0 ? g_mmq_tile : env)) return false;
+    const ggml_tensor * w = n->src[0], * x = n->src[1];
+    if (n->op != GGML_OP_MUL_MAT || !w || !x || w->type != GGML_TYPE_Q4_K || x->type != GGML_TYPE_F32 || n->type != GGML_TYPE_F32) return false;
+    if (x->ne[1] <= mmq_max_cols() || x->ne[2] != 1 || x->ne[3] != 1 || w->ne[2] != 1 || w->ne[3] != 1 || x->nb[0] != 4 || n->nb[0] != 4) return false;
+    if (x->nb[1] % 16 != 0 || ((uintptr_t) x->data & 15) != 0) return false;
+    return mmq_tile_ok(w->type, w->ne[0], w->data, w->nb[1]);
+}
 bool mm_uses_gemm(const ggml_tensor * n) {
     const ggml_tensor * w = n->src[0], * x = n->src[1];
     static const bool no_gemm = getenv("MI355X_NO_GEMM") != nullptr;
@@ -201,7 +214,8 @@ size_t graph_act_scratch_need(const ggml_cgraph * g) {
         const ggml_tensor * n = g->nodes[i];
         if (n->op != GGML_OP_MUL_MAT || is_empty(n)) continue;
         const act_kind k = mm_uses_gemm(n) ? ACT_F16 : act_kind_for(n->src[0]->type);
-        const size_t b = act_image_bytes(k, n->src[1]->ne[0]) * (size_t) (n->src[1]->ne[1] * n->src[1]->ne[2] * n->src[1]->ne[3]);
+        size_t b = act_image_bytes(k, n->src[1]->ne[0]) * (size_t) (n->src[1]->ne[1] * n->src[1]->ne[2] * n->src[1]->ne[3]);
+        if (mm_uses_mmq_tile(n)) b = mmqt_image_bytes(n->src[1]->ne[0], n->src[1]->ne[1]);
         if (b > need) need = b;
     }
     return need;
@@ -210,7 +224,7 @@ size_t graph_w_scratch_need(const ggml_cgraph * g) {
     size_t need = 0;
     for (int i = 0; i < g->n_nodes; ++i) {
         const ggml_tensor * n = g->nodes[i];
-        if (n->op != GGML_OP_MUL_MAT || is_empty(n) || n->src[0]->type == GGML_TYPE_F16 || !(mm_uses_gemm(n) || is_image_quant(n->src[0]->type))) continue;
+        if (n->op != GGML_OP_MUL_MAT || is_empty(n) || n->src[0]->type == GGML_TYPE_F16 || !(mm_uses_gemm(n) || is_image_quant(n->src[0]->type)) || mm_uses_mmq_tile(n)) continue;
         const size_t b = (size_t) n->src[0]->ne[0] * (size_t) n->src[0]->ne[1] * 2;
         if (b > need) need = b;
     }
@@ -284,7 +298,12 @@ size_t graph_gemm_partial_need(const ggml_cgraph * g) {
                 if (c->op == GGML_OP_MUL_MAT && !is_empty(c) && c->src[1]->data == n->src[1]->data && c->src[1]->ne[0] == n->src[1]->ne[0] && c->src[1]->ne[1] == n->src[1]->ne[1]) { m_sum += c->src[0]->ne[1]; ++grouped; }
             }
         }
-        const size_t b = gemm_split_scratch_bytes(m_sum, n->src[1]->ne[1], n->src[0]->ne[0]);
+        size_t b = gemm_split_scratch_bytes(m_sum, n->src[1]->ne[1], n->src[0]->ne[0]);
+        if (mm_uses_mmq_tile(n)) {                           // (its own split rule: one workgroup per CU)
+            const size_t b1 = mmq_tile_split_scratch_bytes(n->src[0]->ne[1], n->src[1]->ne[1], n->src[0]->ne[0]), b2 = mmq_tile_split_scratch_bytes(m_sum, n->src[1]->ne[1], n->src[0]->ne[0]);
+            if (b1 > b) b = b1;
+            if (b2 > b) b = b2;
+        }
         if (b > need) need = b;
     }
     return need;

@@ -87,6 +87,19 @@ struct mmq_mat { const void * W; size_t w_rs; float * dst; size_t dst_cs; int64_
 struct mmq_args { mmq_mat m[3]; int nmat; const void * act; size_t act_cs; int64_t K; int ncols; };
 bool mmq_ok(int type, int64_t K, const void * W, size_t w_rs);
 void mmq_kquant(const mmq_args & a, hipStream_t st);
+// ---- Q4_K weights against a prefill ubatch (> 64 columns) on the int8 matrix cores, tiled (mmq_tile.hip): up to 3 matrices sharing the block-major
+// Q8_K image of the activations (quantize_q8k_tile_image); `resid`: dst = W.x + resid (single matrix, un-split); split-K slabs / deferred reductions as gemm_f16_multi
+struct mmqt_mat { const void * W; size_t w_rs; float * dst; size_t dst_cs; int64_t M; const float * resid = nullptr; size_t resid_cs = 0; };
+struct mmqt_args {
+    mmqt_mat m[3]; int nmat = 0; const void * img = nullptr; int64_t N = 0, K = 0;
+    float * partial = nullptr; size_t partial_bytes = 0; int * deferred_split = nullptr; bool defer_multi = false;
+};
+size_t mmqt_image_bytes(int64_t K, int64_t N);
+void   quantize_q8k_tile_image(const float * x, size_t xs, void * img, int64_t K, int64_t N, hipStream_t st);
+bool   mmq_tile_ok(int type, int64_t K, const void * W, size_t w_rs);
+void   mmq_tile(const mmqt_args & a, hipStream_t st);
+size_t mmq_tile_split_scratch_bytes(int64_t m_sum, int64_t N, int64_t K);
+long   mmq_tile_launches();
 
 // RMS_NORM + MUL(w) + Q8_K image of the result in one launch (one workgroup per row); y may be null when only the
 // image is consumed.  Same arithmetic as rms_norm() followed by quantize_q8k_image().
@@ -271,6 +284,8 @@ struct gemm_multi_args {
     bool defer_multi = false;                 // the same for a grouped launch (nmat > 1, no addends): slab s = partial + s * (sum of M_i) * N floats, matrix i a dense [N][M_i] block at + (M_0 + .. + M_{i-1}) * N
     // gate / up + SWIGLU (gemm_glu_ok): no f32 outputs; f16 rows of silu(W[glu_gate].x) * (W[1 - glu_gate].x) go to glu_out16
     uint16_t * glu_out16 = nullptr; size_t glu_out16_rs = 0; int glu_gate = 0;
+    // every matrix given as Q4_K blocks (qtype) AND the activations as the block-major Q8_K image: the launch goes to mmq_tile() (X / x_rs unused)
+    const void * qt_img = nullptr;
 };
 int    device_cu_count();                                        // CUs of the current device
 void   gemm_reduce(const float * partial, int nsplit, const float * resid, size_t resid_cs, float * dst, size_t dst_cs, int64_t M, int64_t N, hipStream_t st);

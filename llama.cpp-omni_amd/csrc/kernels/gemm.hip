@@ -1044,6 +1044,18 @@ void gemm_f16_multi(const gemm_multi_args & a, hipStream_t st) {
         }
         return;
     }
+    if (a.qt_img) {                                           // Q4_K blocks x the block-major Q8_K image: mmq_tile.hip (same slab layout, same deferred reductions)
+        if (a.probe_path) { *a.probe_path = 0; return; }
+        mmqt_args q; q.nmat = a.nmat; q.img = a.qt_img; q.N = a.N; q.K = a.K;
+        q.partial = a.partial; q.partial_bytes = a.partial_bytes; q.deferred_split = a.deferred_split; q.defer_multi = a.defer_multi;
+        for (int i = 0; i < a.nmat; ++i) {
+            const gemm_mat & m = a.m[i];
+            if (m.qtype != GGML_TYPE_Q4_K || m.resid2 || m.y16 || m.unary >= 0 || a.nbatch > 1 || a.glu_out16) { fprintf(stderr, "[mi355x] gemm: the tiled int8 kernel takes Q4_K blocks, one addend, f32 rows out\n"); abort(); }
+            q.m[i] = { m.W, m.w_rs, m.dst, m.dst_cs, m.M, m.resid, m.resid_cs };
+        }
+        mmq_tile(q, st);
+        return;
+    }
     if (a.deferred_split) *a.deferred_split = 0;
     gemm_dev g;
     if (a.glu_out16) {                                        // ffn_gate / ffn_up + SWIGLU in one launch (gemm_glu_ok() said yes)
