@@ -155,6 +155,34 @@ static __device__ __forceinline__ void q8k_block_from_regs(const f32x4 v, int la
     if (lane == 0) *ds = 1.0f / iscale;
 }
 
+// What the reference's Q8_K quantisation makes of one 256-block held by a wave (lane l owns elements 4l..4l+3): d * q per element, d = 1 / iscale, q as
+// quantize_row_q8_K_ref computes it (ggml-quants.c:2555-2592; q8k_block_from_regs above) -- the value ggml_vec_dot_q*_K_q8_K multiplies the weights with.
+// The prefill GEMMs that run on F16 images of K-quant weights take these values (rounded to f16) as their activations instead of the raw f32 rows, so the only
+// difference to the reference's integer arithmetic left is f16 rounding of the two factors, not the reference's own 8-bit quantisation noise.
+static __device__ __forceinline__ float wave_max_pos_f32(float v) {     // wave64 max of non-negative values on the DPP network (masked-out rows read 0)
+    v = fmaxf(v, dpp_f32<0xB1, 0xf>(v));
+    v = fmaxf(v, dpp_f32<0x4E, 0xf>(v));
+    v = fmaxf(v, dpp_f32<0x141, 0xf>(v));
+    v = fmaxf(v, dpp_f32<0x140, 0xf>(v));
+    v = fmaxf(v, dpp_f32<0x142, 0xa>(v));
+    v = fmaxf(v, dpp_f32<0x143, 0xc>(v));
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+static __device__ __forceinline__ f32x4 q8k_requant4(const f32x4 v, int lane) {
+    float am = fabsf(v[0]); float mv = v[0];
+#pragma unroll
+    for (int i = 1; i < 4; ++i) { const float a = fabsf(v[i]); if (a > am) { am = a; mv = v[i]; } }
+    const float amax = wave_max_pos_f32(am);
+    if (amax == 0.0f) return f32x4{ 0.0f, 0.0f, 0.0f, 0.0f };
+    const unsigned long long hit = __ballot(am == amax);               // the FIRST element with the largest |x| decides the sign of the scale (strict '>' scan)
+    const float maxv = __shfl(mv, (int) __builtin_ctzll(hit), 64);
+    const float iscale = -127.0f / maxv, d = 1.0f / iscale;
+    f32x4 o;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { int r = (int) __builtin_rintf(iscale * v[i]); r = r > 127 ? 127 : r; o[i] = d * (float) r; }
+    return o;
+}
+
 #endif // __HIPCC__
 
 // ---------------------------------------------------------------- activation scratch layout ("q8 image")

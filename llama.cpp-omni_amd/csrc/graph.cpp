@@ -333,6 +333,7 @@ int mi355x_set_option(struct ggml_backend * backend, const char * key, long valu
     if (!strcmp(key, "mv1")) { c->opt_mv1 = value != 0; mi::drop_graph_execs(c); return 0; }
     if (!strcmp(key, "batch_uploads")) { flush_uploads(c); c->opt_batch_uploads = value != 0; return 0; }
     if (!strcmp(key, "fp_collide")) { mi::g_fp_collide = value != 0; return 0; }
+    if (!strcmp(key, "prefill_q8k")) { mi::prefill_q8k_set_mode((int) value); mi::drop_graph_execs(c); return 0; }      // (process-wide: prefill GEMMs of K-quant weights take the Q8_K-quantised activations; 0 = plain f16 rows, the round-4 arithmetic)
     if (!strcmp(key, "mmq_tile")) { mi::mmq_tile_set_mode((int) value); mi::drop_graph_execs(c); return 0; }      // (process-wide: the tiled int8-MFMA prefill kernel for Q4_K weights, mmq_tile.hip; 0 = the F16-image GEMM)
     if (!strcmp(key, "mv2")) { mi::mmv2_enable(value != 0); mi::drop_graph_execs(c); return 0; }       // (process-wide: the LDS-DMA engine form of the decode mat-vec)
     if (!strcmp(key, "kq_staging")) { c->opt_kq_staging = value != 0; mi::drop_graph_execs(c); return 0; }

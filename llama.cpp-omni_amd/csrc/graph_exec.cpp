@@ -23,6 +23,7 @@ static size_t prepare_act(exec_state & s, const ggml_tensor * x, act_kind kind) 
     auto conv = [&](const float * src, size_t xs, void * out, int64_t rows) {
         if      (kind == ACT_Q8K) quantize_q8k_image(src, xs, out, K, rows, s.st);
         else if (kind == ACT_Q8KT) quantize_q8k_tile_image(src, xs, out, K, rows, s.st);
+        else if (kind == ACT_F16Q) convert_f32_f16q_rows(src, xs, (uint16_t *) out, img, K, rows, s.st);
         else if (kind == ACT_Q80) quantize_q80_image(src, xs, out, K, rows, s.st);
         else                      convert_f32_f16_rows(src, xs, (uint16_t *) out, img, K, rows, s.st);
         ++s.n_kernels;
@@ -38,7 +39,7 @@ static size_t prepare_act(exec_state & s, const ggml_tensor * x, act_kind kind) 
         ++s.n_kernels;
     } else if (flat) {
         conv((const float *) x->data, x->nb[1], s.c->act_scratch, N * ne12 * ne13);
-    } else if (kind == ACT_F16 && N * ne12 * ne13 <= 65535) {            // permuted rows (q seen per head): one strided launch
+    } else if (kind == ACT_F16 && N * ne12 * ne13 <= 65535) {      // (ACT_F16Q never gets here: K-quant weights take 2-D activations in every graph the planner sends to the GEMM)            // permuted rows (q seen per head): one strided launch
         convert_f32_f16_rows3((const float *) x->data, x->nb[1], x->nb[2], x->nb[3], N, ne12, ne13, (uint16_t *) s.c->act_scratch, img, K, s.st);
         ++s.n_kernels;
     } else {
@@ -105,7 +106,7 @@ static void op_mul_mat(exec_state & s, const ggml_tensor * dst, const ggml_tenso
     }
     if (mm_uses_gemm(dst)) {
         // ---- prefill: MFMA GEMM.  X -> f16 rows (what the reference does for F16 weights, ggml-cpu.c:1245-1268); quantised W -> f16
-        const size_t ximg = prepare_act(s, x, ACT_F16);
+        const size_t ximg = prepare_act(s, x, x->ne[2] * x->ne[3] == 1 ? gemm_act_kind(dst) : ACT_F16);
         // attention without FLASH_ATTN_EXT at prefill: every head's K.Q^T (or V^T.P) product in one launch
         if (w->type == GGML_TYPE_F16 && ne12 * ne13 > 1 && ne12 * ne13 <= 65535 && K % 64 == 0 && w->nb[1] % 16 == 0 && w->nb[2] % 16 == 0 && w->nb[3] % 16 == 0 &&
             ((uintptr_t) w->data & 15) == 0 && dst->nb[0] == 4) {
@@ -481,7 +482,7 @@ static bool gemm_groupable(const ggml_tensor * c) {
     return x->ne[2] == 1 && x->ne[3] == 1 && c->src[0]->ne[0] % 64 == 0 && c->nb[0] == 4 && c->type == GGML_TYPE_F32;
 }
 static bool gemm_only_consumers(exec_state & s, const ggml_tensor * t, int64_t K, int64_t N, const ggml_tensor ** x_out);
-static void seed_act_f16(exec_state & s, const ggml_tensor * x);
+static void seed_act_f16(exec_state & s, const ggml_tensor * x, bool quantised = false);
 static bool exec_attn_sm_prefill(exec_state & s, int i, bool dry);
 static bool exec_gemm_group(exec_state & s, int i) {
     ggml_cgraph * g = s.g;
@@ -494,6 +495,7 @@ static bool exec_gemm_group(exec_state & s, int i) {
     int mm_idx[3] = { i, -1, -1 };
     const bool qt = mm_uses_mmq_tile(n);                       // Q4_K blocks x the block-major Q8_K image on the int8 matrix cores (mmq_tile.hip): raw blocks like kq
     const bool kq = qt || kq_in_staging(s, n->src[0], N);      // then every matrix of the launch must be K-quant blocks too
+    const act_kind xkind = qt ? ACT_Q8KT : gemm_act_kind(n);    // (siblings join the launch only when they take the same image)
     {
         const uint16_t * w16; size_t rs;
         if (kq) { w16 = (const uint16_t *) n->src[0]->data; rs = n->src[0]->nb[1]; }
@@ -505,6 +507,7 @@ static bool exec_gemm_group(exec_state & s, int i) {
         if (s.done[j] || !gemm_groupable(c) || !same_act(c->src[1], x)) continue;
         if (!can_hoist(s, i, j, mm_idx, a.nmat)) continue;
         if (qt != mm_uses_mmq_tile(c)) continue;
+        if (!qt && gemm_act_kind(c) != xkind) continue;
         if (!qt && kq != kq_in_staging(s, c->src[0], N)) continue;
         const uint16_t * w16; size_t rs;
         if (kq) { w16 = (const uint16_t *) c->src[0]->data; rs = c->src[0]->nb[1]; }
@@ -555,7 +558,7 @@ static bool exec_gemm_group(exec_state & s, int i) {
             }
         }
     }
-    const size_t ximg = prepare_act(s, x, qt ? ACT_Q8KT : ACT_F16);
+    const size_t ximg = prepare_act(s, x, xkind);
     a.X = (const uint16_t *) s.c->act_scratch; a.x_rs = ximg;
     if (qt) a.qt_img = s.c->act_scratch;
     if (glu_idx >= 0) {
@@ -967,21 +970,35 @@ static bool gemm_only_consumers(exec_state & s, const ggml_tensor * t, int64_t K
     auto it = s.users.find(t);
     if (it == s.users.end() || it->second.empty()) return false;
     if (act_image_bytes(ACT_F16, K) * (size_t) N > s.c->act_scratch_bytes) return false;
-    const ggml_tensor * x0 = nullptr;
+    const ggml_tensor * x0 = nullptr; act_kind k0 = ACT_F16;
     for (int u : it->second) {
         const ggml_tensor * c = s.g->nodes[u];
         if (c->op != GGML_OP_MUL_MAT || is_empty(c) || !mm_uses_gemm(c) || mm_uses_mmq_tile(c)) return false;      // (mmq_tile.hip reads the Q8_K image it builds from the f32 rows)
         const ggml_tensor * x = c->src[1];
         if (x->type != GGML_TYPE_F32 || x->data != t->data || x->ne[0] != K || x->ne[1] != N || x->ne[2] != 1 || x->ne[3] != 1 || x->nb[1] != (size_t) K * 4 ||
             c->src[0]->data == t->data) return false;
-        if (x0 && !same_act(x0, x)) return false;
+        if (x0 && (!same_act(x0, x) || gemm_act_kind(c) != k0)) return false;
+        if (!x0) k0 = gemm_act_kind(c);
         x0 = x;
     }
     *x_out = x0;
     return true;
 }
-static void seed_act_f16(exec_state & s, const ggml_tensor * x) {              // the f16 image of x now sits in act_scratch
-    s.a_src = x->data; s.a_kind = ACT_F16; s.a_K = x->ne[0]; s.a_ne[0] = x->ne[1]; s.a_ne[1] = 1; s.a_ne[2] = 1;
+// which image do the GEMMs that read x want?  (gemm_only_consumers made sure they agree)
+static act_kind consumers_act_kind(exec_state & s, const ggml_tensor * x) {
+    auto it = s.users.find(x);
+    if (it == s.users.end()) return ACT_F16;
+    for (int u : it->second) { const ggml_tensor * c = s.g->nodes[u]; if (c->op == GGML_OP_MUL_MAT && c->src[1] && c->src[1]->data == x->data) return gemm_act_kind(c); }
+    return ACT_F16;
+}
+static void seed_act_f16(exec_state & s, const ggml_tensor * x, bool quantised) {   // the f16 image of x now sits in act_scratch (quantised: the emitter wrote the Q8_K-quantised values already)
+    const act_kind want = consumers_act_kind(s, x);
+    if (want == ACT_F16Q && !quantised) {                                // K-quant consumers: re-quantise the rows in place (from f16: the emitting launch -- attention, SwiGLU -- has no f32 copy)
+        prof_scope ps(s, "act_convert", 0);
+        requant_f16_rows_q8k((uint16_t *) s.c->act_scratch, act_image_bytes(ACT_F16, x->ne[0]), x->ne[0], x->ne[1] * x->ne[2] * x->ne[3], s.st);
+        ++s.n_kernels;
+    }
+    s.a_src = x->data; s.a_kind = want; s.a_K = x->ne[0]; s.a_ne[0] = x->ne[1]; s.a_ne[1] = 1; s.a_ne[2] = 1;
     s.a_nb[0] = x->nb[1]; s.a_nb[1] = x->nb[2]; s.a_nb[2] = x->nb[3];
     s.a_range_lo = (const char *) x->data; s.a_range_hi = (const char *) x->data + nbytes(x);
 }
@@ -1515,6 +1532,7 @@ static bool exec_rms_norm(exec_state & s, int i) {
     const tdesc wd = td(wt);
     const ggml_tensor * xg = nullptr;
     const bool emit16 = n->ne[2] == 1 && n->ne[3] == 1 && m->nb[1] == (size_t) m->ne[0] * 4 && gemm_only_consumers(s, m, m->ne[0], m->ne[1], &xg);
+    const bool q8 = emit16 && consumers_act_kind(s, xg) == ACT_F16Q;       // K-quant GEMMs read the rows: the image carries the Q8_K-quantised values (quantised from the f32 values, inside the norm launch)
     const bool from_split = s.pr.A && s.pr.A == n->src[0];
     if (from_split && !(n->ne[2] == 1 && n->ne[3] == 1 && wt->ne[0] == n->ne[0] && wt->ne[1] * wt->ne[2] * wt->ne[3] == 1 && m->nb[1] % 16 == 0 && ((uintptr_t) wt->data & 15) == 0))
         materialise_reduce(s);
@@ -1525,16 +1543,16 @@ static bool exec_rms_norm(exec_state & s, int i) {
         prof_scope ps(s, "rms_norm_mul", 0);
         gemm_reduce_rms_norm((const float *) s.c->gemm_partial, s.pr.nsplit, s.pr.resid, s.pr.resid_cs, (float *) A->data, A->nb[1], (const float *) wt->data, eps,
                              w32 ? (float *) m->data : nullptr, m->nb[1], emit16 ? (uint16_t *) s.c->act_scratch : nullptr, act_image_bytes(ACT_F16, m->ne[0]),
-                             A->ne[0], A->ne[1], s.st);
+                             A->ne[0], A->ne[1], s.st, q8);
         s.pr.A = nullptr; ++s.n_fused;
     } else {
         prof_scope ps(s, "rms_norm_mul", 0);
-        if (emit16) rms_norm(td(n->src[0]), td(m), eps, &wd, s.st, (uint16_t *) s.c->act_scratch, act_image_bytes(ACT_F16, m->ne[0]), n_users(s, m) > 1);
+        if (emit16) rms_norm(td(n->src[0]), td(m), eps, &wd, s.st, (uint16_t *) s.c->act_scratch, act_image_bytes(ACT_F16, m->ne[0]), n_users(s, m) > 1, q8);
         else        rms_norm(td(n->src[0]), td(m), eps, &wd, s.st);
     }
     ++s.n_kernels; s.n_fused += 1; s.done[mi_] = 1;
     note_write(s, m);
-    if (emit16) { seed_act_f16(s, xg); ++s.n_fused; }
+    if (emit16) { seed_act_f16(s, xg, q8); ++s.n_fused; }
     return true;
 }
 

@@ -24,7 +24,7 @@ static inline bool is_noop(const ggml_tensor * t) {
            t->op == GGML_OP_TRANSPOSE || is_empty(t);
 }
 
-enum act_kind { ACT_NONE = 0, ACT_Q8K, ACT_Q80, ACT_F16, ACT_F32, ACT_Q8KT };      // Q8KT: the block-major Q8_K image of a whole ubatch (mmq_tile.hip), not a per-row format
+enum act_kind { ACT_NONE = 0, ACT_Q8K, ACT_Q80, ACT_F16, ACT_F32, ACT_Q8KT, ACT_F16Q };      // F16Q: f16 rows of the Q8_K-quantised values (what the F16-image GEMMs of K-quant weights multiply with)      // Q8KT: the block-major Q8_K image of a whole ubatch (mmq_tile.hip), not a per-row format
 // block formats without integer-dot kernels of their own: every MUL_MAT runs on the F16 image of the weights (resident for model
 // tensors, shadow.hpp; else de-quantised into scratch per call) with f16-rounded activations -- the arithmetic of the prefill GEMM
 static inline bool is_image_quant(int t) {
@@ -46,7 +46,7 @@ static inline size_t act_image_bytes(act_kind k, int64_t K) {
     switch (k) {
         case ACT_Q8K: return q8k_image_bytes(K);
         case ACT_Q80: return q80_image_bytes(K);
-        case ACT_F16: return ((size_t) K * 2 + 15) & ~(size_t) 15;
+        case ACT_F16: case ACT_F16Q: return ((size_t) K * 2 + 15) & ~(size_t) 15;
         default: return 0;
     }
 }
@@ -119,6 +119,8 @@ static const int64_t GEMM_MIN_COLS = MI_MMVQ_MAX_COLS + 1;
 bool mm_uses_mmq(const ggml_tensor * n);
 bool mm_uses_gemm(const ggml_tensor * n);
 bool mm_uses_mmq_tile(const ggml_tensor * n);
+act_kind gemm_act_kind(const ggml_tensor * n);          // ACT_F16, or ACT_F16Q for K-quant weights (option "prefill_q8k")
+void prefill_q8k_set_mode(int m);
 void mmq_tile_set_mode(int m);
 int64_t mmq_max_cols();
 bool mm_uses_gemm_any_f16(const ggml_tensor * n);

@@ -175,16 +175,30 @@ bool mm_uses_mmq(const ggml_tensor * n) {
 }
 // Q4_K weights against a prefill ubatch (more than mmq_max_cols() columns): the tiled int8-MFMA kernel on the blocks themselves and the Q8_K-quantised
 // activations -- the oracle's integers (mmq_tile.hip).  A sub-case of mm_uses_gemm(): the grouping / residual / split-K machinery of the GEMM path serves it.
-static int g_mmq_tile = -1;                                   // option "mmq_tile": -1 = MI355X_MMQ_TILE decides (default on), 0 off, 1 on
+static int g_mmq_tile = -1;                                   // option "mmq_tile": -1 = MI355X_MMQ_TILE decides (default off), 0 off, 1 on
 void mmq_tile_set_mode(int m) { g_mmq_tile = m; }
 bool mm_uses_mmq_tile(const ggml_tensor * n) {
-    static const int env = getenv("MI355X_MMQ_TILE") ? atoi(getenv("MI355X_MMQ_TILE")) : 1;
+    static const int env = getenv("MI355X_MMQ_TILE") ? atoi(getenv("MI355X_MMQ_TILE")) : 0;      // (off by default: exact, but slower than the F16-image GEMM -- DESIGN.md section 7, profiles/r05_mmq_tile.txt)
     if (!(g_mmq_tile >= 0 ? g_mmq_tile : env)) return false;
     const ggml_tensor * w = n->src[0], * x = n->src[1];
     if (n->op != GGML_OP_MUL_MAT || !w || !x || w->type != GGML_TYPE_Q4_K || x->type != GGML_TYPE_F32 || n->type != GGML_TYPE_F32) return false;
     if (x->ne[1] <= mmq_max_cols() || x->ne[2] != 1 || x->ne[3] != 1 || w->ne[2] != 1 || w->ne[3] != 1 || x->nb[0] != 4 || n->nb[0] != 4) return false;
     if (x->nb[1] % 16 != 0 || ((uintptr_t) x->data & 15) != 0) return false;
     return mmq_tile_ok(w->type, w->ne[0], w->data, w->nb[1]);
+}
+// The activations of an MFMA GEMM node: f16-rounded rows -- or, for K-quant weights (the reference CPU backend quantises src1 to Q8_K for every one of them,
+// ggml-cpu.c:1272-1306 with vec_dot_type Q8_K), f16 rows of the Q8_K-QUANTISED values, so that the product on the weights' F16 image differs from the reference's
+// integer arithmetic by f16 rounding only (NMSE 2e-6 per mat-mul), not by the reference's own 8-bit quantisation noise (5e-5).  Option "prefill_q8k", default OFF: it costs two
+// re-quantisation launches per layer (pp512 44.7 k -> 41.5 k tok/s) and end to end both forms sit on the reference's own rounding-flip floor (tests/test_round5_gpu.py).
+static int g_prefill_q8k = -1;
+void prefill_q8k_set_mode(int m) { g_prefill_q8k = m; }
+act_kind gemm_act_kind(const ggml_tensor * n) {
+    static const int env = getenv("MI355X_PREFILL_Q8K") ? atoi(getenv("MI355X_PREFILL_Q8K")) : 0;
+    if (!(g_prefill_q8k >= 0 ? g_prefill_q8k : env)) return ACT_F16;
+    const ggml_tensor * w = n->src[0], * x = n->src[1];
+    const int t = w->type;
+    const bool kq = t == GGML_TYPE_Q2_K || t == GGML_TYPE_Q3_K || t == GGML_TYPE_Q4_K || t == GGML_TYPE_Q5_K || t == GGML_TYPE_Q6_K;
+    return kq && x->type == GGML_TYPE_F32 && x->ne[0] % 256 == 0 ? ACT_F16Q : ACT_F16;
 }
 bool mm_uses_gemm(const ggml_tensor * n) {
     const ggml_tensor * w = n->src[0], * x = n->src[1];

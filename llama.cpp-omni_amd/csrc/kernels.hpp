@@ -11,6 +11,9 @@ void quantize_q8k_image(const float * x, size_t xs, void * img, int64_t K, int64
 void quantize_q80_image(const float * x, size_t xs, void * img, int64_t K, int64_t nrows, hipStream_t st);
 // f32 -> f16 (RNE) rows, dst row stride ys bytes
 void convert_f32_f16_rows(const float * x, size_t xs, uint16_t * y, size_t ys, int64_t K, int64_t nrows, hipStream_t st);
+// f16 rows of the Q8_K-quantised values (d * q, what the reference's integer dot products multiply K-quant weights with): K % 256 == 0; in place for rows a launch left as f16
+void convert_f32_f16q_rows(const float * x, size_t xs, uint16_t * y, size_t ys, int64_t K, int64_t nrows, hipStream_t st);
+void requant_f16_rows_q8k(uint16_t * y, size_t ys, int64_t K, int64_t nrows, hipStream_t st);
 void convert_f32_f16_rows3(const float * x, size_t nb1, size_t nb2, size_t nb3, int64_t n1, int64_t n2, int64_t n3, uint16_t * y, size_t ys, int64_t K, hipStream_t st);
 
 // ---- mat-vec on quantised weights: dst[col*ds + row] = dot(W[row, :], act[col, :]), ncols <= MMVQ_MAX_COLS
@@ -119,7 +122,7 @@ struct tdesc {
 
 // RMS_NORM (ops.cpp:3517-3566), optionally fused with the following MUL by `w` (broadcast over rows) and ADD
 // y16 != null (2-D, with mul_w): also emit f16-rounded rows (row stride y16_rs) for the prefill GEMM; write_f32 = false skips y
-void rms_norm(const tdesc & x, const tdesc & y, float eps, const tdesc * mul_w, hipStream_t st, uint16_t * y16 = nullptr, size_t y16_rs = 0, bool write_f32 = true);
+void rms_norm(const tdesc & x, const tdesc & y, float eps, const tdesc * mul_w, hipStream_t st, uint16_t * y16 = nullptr, size_t y16_rs = 0, bool write_f32 = true, bool y16_q8 = false);   // y16_q8: as gemm_reduce_rms_norm (returns false semantics: aborts when the wave-per-row kernel cannot take the shape)
 // IM2COL (ops.cpp:6150-6301): x f32 [IW, IH, IC, N] (2-D) or [IW, IC, N] (1-D) -> y f16 / f32 [IC*KH*KW, OW, OH, N]; p = op_params (s0,s1,p0,p1,d0,d1,is_2D)
 void im2col_f32(const tdesc & kernel, const tdesc & x, const tdesc & y, int y_type, const int32_t * p, hipStream_t st);
 // POOL_2D (ops.cpp:7281-7355) / POOL_1D with k == s, p == 0 (ops.cpp:7212-7260): avg / max windows of f32 / f16 planes -> f32; p = op_params
@@ -294,7 +297,7 @@ void   gemm_reduce2(const float * partial, int nsplit, const float * resid, size
 // the same reduction fused with the RMS_NORM -> MUL(w) of the result: dst = sum + resid (f32); y = rms_norm(dst) * w -> y32 / f16 rows y16
 bool   gemm_reduce_rms_norm_ok(int64_t M);
 void   gemm_reduce_rms_norm(const float * partial, int nsplit, const float * resid, size_t resid_cs, float * dst, size_t dst_cs, const float * w, float eps,
-                            float * y32, size_t y32_cs, uint16_t * y16, size_t y16_rs, int64_t M, int64_t N, hipStream_t st);
+                            float * y32, size_t y32_cs, uint16_t * y16, size_t y16_rs, int64_t M, int64_t N, hipStream_t st, bool y16_q8 = false);      // y16_q8: the f16 rows carry the Q8_K-quantised values (q8k_requant4; M % 256 == 0)
 // A chain of element-wise f32 nodes in one launch (elementwise.hip k_ew_chain): op j reads external inputs (selector 0..5) or the result of an earlier op of the chain
 // (selector 8 + index) and only the last result is stored.  Each op is the arithmetic of its stand-alone kernel (the library is built with -ffp-contract=off: nothing fuses
 // across ops), so a chain gives the stand-alone launches' values bit for bit.

@@ -222,7 +222,7 @@ __global__ void __launch_bounds__(1024) k_rms_norm(td4 x, td4 y, td4 w, float ep
 // Many rows (prefill ubatches): one WAVE per row, the row held in registers (MAXV 16-byte pieces per lane), sum of squares in double per lane and
 // folded across the wave -- one read of x, no LDS, no barrier (k_rms_norm re-reads the row and issues 4-byte accesses: 1.8 TB/s on 16384 x 4096).
 template <int MAXV>
-__global__ void __launch_bounds__(256) k_rms_norm_rows(td4 x, td4 y, const float * __restrict__ w, float eps, char * __restrict__ y16, int64_t y16_rs, int64_t nrows) {
+__global__ void __launch_bounds__(256) k_rms_norm_rows(td4 x, td4 y, const float * __restrict__ w, float eps, char * __restrict__ y16, int64_t y16_rs, int64_t nrows, int y16_q8) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t) blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= nrows) return;
@@ -259,13 +259,15 @@ __global__ void __launch_bounds__(256) k_rms_norm_rows(td4 x, td4 y, const float
             for (int e = 0; e < 4; ++e) o[e] = v[k][e] * scale;
         }
         if (yr) *(f32x4 *) (yr + (size_t) i * 4) = o;
+        if (hr && y16_q8) o = q8k_requant4(o, lane);              // (n % 256 == 0: piece k of the wave IS the row's 256-block k, lane l its elements 4l..4l+3)
         if (hr) { u32x2 h; h[0] = (uint32_t) f2h(o[0]) | ((uint32_t) f2h(o[1]) << 16); h[1] = (uint32_t) f2h(o[2]) | ((uint32_t) f2h(o[3]) << 16); *(u32x2 *) (hr + (size_t) i * 2) = h; }
     }
 }
 
-void rms_norm(const tdesc & x, const tdesc & y, float eps, const tdesc * mul_w, hipStream_t st, uint16_t * y16, size_t y16_rs, bool write_f32) {
+void rms_norm(const tdesc & x, const tdesc & y, float eps, const tdesc * mul_w, hipStream_t st, uint16_t * y16, size_t y16_rs, bool write_f32, bool y16_q8) {
     if (x.ne[0] == 0 || x.ne[1] * x.ne[2] * x.ne[3] == 0) return;
     const int64_t n = x.ne[0];
+    if (y16_q8 && (!y16 || n % 256 != 0)) { fprintf(stderr, "[mi355x] rms_norm: the Q8_K image needs rows of whole 256-blocks\n"); abort(); }
     {
         const int64_t nrows = x.ne[1] * x.ne[2] * x.ne[3];
         auto al16 = [](const tdesc & t) { return ((uintptr_t) t.p & 15) == 0 && t.nb[0] == 4 && t.nb[1] % 16 == 0 && t.nb[2] % 16 == 0 && t.nb[3] % 16 == 0; };
@@ -275,9 +277,9 @@ void rms_norm(const tdesc & x, const tdesc & y, float eps, const tdesc * mul_w, 
             if (!write_f32) yd.p = nullptr;
             const dim3 grid((unsigned) ((nrows + 3) / 4));
             const float * wp = mul_w ? (const float *) mul_w->p : nullptr;
-            if (n <= 2048)      k_rms_norm_rows<8><<<grid, dim3(256), 0, st>>>(to_td4(x), yd, wp, eps, (char *) y16, (int64_t) y16_rs, nrows);
-            else if (n <= 4096) k_rms_norm_rows<16><<<grid, dim3(256), 0, st>>>(to_td4(x), yd, wp, eps, (char *) y16, (int64_t) y16_rs, nrows);
-            else                k_rms_norm_rows<32><<<grid, dim3(256), 0, st>>>(to_td4(x), yd, wp, eps, (char *) y16, (int64_t) y16_rs, nrows);
+            if (n <= 2048)      k_rms_norm_rows<8><<<grid, dim3(256), 0, st>>>(to_td4(x), yd, wp, eps, (char *) y16, (int64_t) y16_rs, nrows, y16_q8 ? 1 : 0);
+            else if (n <= 4096) k_rms_norm_rows<16><<<grid, dim3(256), 0, st>>>(to_td4(x), yd, wp, eps, (char *) y16, (int64_t) y16_rs, nrows, y16_q8 ? 1 : 0);
+            else                k_rms_norm_rows<32><<<grid, dim3(256), 0, st>>>(to_td4(x), yd, wp, eps, (char *) y16, (int64_t) y16_rs, nrows, y16_q8 ? 1 : 0);
             return;
         }
     }
@@ -288,6 +290,7 @@ void rms_norm(const tdesc & x, const tdesc & y, float eps, const tdesc * mul_w, 
     if (!write_f32) yd.p = nullptr;
     if (mul_w) k_rms_norm<true><<<grid, dim3(bs), 0, st>>>(to_td4(x), yd, to_td4(*mul_w), eps, (char *) y16, (int64_t) y16_rs);
     else       k_rms_norm<false><<<grid, dim3(bs), 0, st>>>(to_td4(x), yd, to_td4(x), eps, nullptr, 0);
+    if (mul_w && y16 && y16_q8) requant_f16_rows_q8k(y16, y16_rs, n, x.ne[1], st);      // (this kernel left the plain f16 rows: re-quantised in place -- from f16, the few-rows path only)
 }
 
 // ================================================================================================

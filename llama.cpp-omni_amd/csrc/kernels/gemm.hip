@@ -836,7 +836,7 @@ bool gemm_f16_ok(const void * W, size_t w_rs, const void * X, size_t x_rs, int64
 template <int MAXV>
 __global__ void __launch_bounds__(256) k_gemm_reduce_rms_norm(const float * __restrict__ part, int nsplit, size_t split_elems, const char * __restrict__ resid, size_t resid_cs,
                                                               char * __restrict__ dst, size_t dst_cs, const float * __restrict__ w, float eps,
-                                                              char * __restrict__ y32, size_t y32_cs, char * __restrict__ y16, size_t y16_rs, int M) {
+                                                              char * __restrict__ y32, size_t y32_cs, char * __restrict__ y16, size_t y16_rs, int M, int y16_q8) {
     __shared__ double red[4];
     const int n = blockIdx.x;
     f32x4 v[MAXV];
@@ -904,6 +904,7 @@ __global__ void __launch_bounds__(256) k_gemm_reduce_rms_norm(const float * __re
         for (int e = 0; e < 4; ++e) y[e] = (v[k][e] * scale) * ww[e];
         if (y32) *(f32x4 *) (y32 + (size_t) n * y32_cs + (size_t) i * 4) = y;
         if (y16) {
+            if (y16_q8) y = q8k_requant4(y, threadIdx.x & 63);      // (M % 256 == 0: a wave holds whole 256-blocks, lane l elements 4l..4l+3 -- the image carries the Q8_K-quantised values)
             u32x2 h;
             h[0] = (uint32_t) f2h(y[0]) | ((uint32_t) f2h(y[1]) << 16); h[1] = (uint32_t) f2h(y[2]) | ((uint32_t) f2h(y[3]) << 16);
             *(u32x2 *) (y16 + (size_t) n * y16_rs + (size_t) i * 2) = h;
@@ -946,13 +947,14 @@ void gemm_reduce2(const float * partial, int nsplit, const float * resid, size_t
 }
 bool gemm_reduce_rms_norm_ok(int64_t M) { return M % 4 == 0 && M <= 16384; }
 void gemm_reduce_rms_norm(const float * partial, int nsplit, const float * resid, size_t resid_cs, float * dst, size_t dst_cs, const float * w, float eps,
-                          float * y32, size_t y32_cs, uint16_t * y16, size_t y16_rs, int64_t M, int64_t N, hipStream_t st) {
+                          float * y32, size_t y32_cs, uint16_t * y16, size_t y16_rs, int64_t M, int64_t N, hipStream_t st, bool y16_q8) {
     if (M == 0 || N == 0) return;
+    if (y16_q8 && M % 256 != 0) { fprintf(stderr, "[mi355x] gemm_reduce_rms_norm: the Q8_K image needs rows of whole 256-blocks\n"); abort(); }
     check_nsplit(nsplit, "gemm_reduce_rms_norm");
     if (M <= 4096) k_gemm_reduce_rms_norm<4><<<dim3((unsigned) N), dim3(256), 0, st>>>(partial, nsplit, (size_t) M * (size_t) N, (const char *) resid, resid_cs, (char *) dst, dst_cs, w, eps,
-                                                                                   (char *) y32, y32_cs, (char *) y16, y16_rs, (int) M);
+                                                                                   (char *) y32, y32_cs, (char *) y16, y16_rs, (int) M, y16_q8 ? 1 : 0);
     else           k_gemm_reduce_rms_norm<16><<<dim3((unsigned) N), dim3(256), 0, st>>>(partial, nsplit, (size_t) M * (size_t) N, (const char *) resid, resid_cs, (char *) dst, dst_cs, w, eps,
-                                                                                    (char *) y32, y32_cs, (char *) y16, y16_rs, (int) M);
+                                                                                    (char *) y32, y32_cs, (char *) y16, y16_rs, (int) M, y16_q8 ? 1 : 0);
 }
 
 // dynamic LDS above 64 KB needs a function attribute, once per (kernel, device): a process may drive several GPUs

@@ -162,6 +162,35 @@ void convert_f32_f16_rows3(const float * x, size_t nb1, size_t nb2, size_t nb3, 
     k_f32_to_f16_rows3<<<dim3(gx, (unsigned) nrows), dim3(256), 0, st>>>((const char *) x, nb1, nb2, nb3, (int) n1, (int) n2, (char *) y, ys, K);
 }
 
+// f32 rows -> f16 rows of the Q8_K-quantised values (q8k_requant4): one wave per (row, 256-block); IN16: the source rows are f16 already (an attention / SwiGLU
+// launch wrote them into the image: re-quantised in place)
+template <bool IN16>
+__global__ void __launch_bounds__(256) k_rows_to_f16q(const char * __restrict__ x, size_t xs, char * __restrict__ y, size_t ys, int nblk, int64_t nrows) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wid = (int64_t) blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (wid >= nrows * nblk) return;
+    const int64_t row = wid / nblk; const int b = (int) (wid % nblk);
+    f32x4 v;
+    if (IN16) { const u32x2 h = *(const u32x2 *) (x + row * xs + (size_t) b * 512 + lane * 8);
+                v[0] = h2f((uint16_t) (h[0] & 0xffff)); v[1] = h2f((uint16_t) (h[0] >> 16)); v[2] = h2f((uint16_t) (h[1] & 0xffff)); v[3] = h2f((uint16_t) (h[1] >> 16)); }
+    else v = *(const f32x4 *) (x + row * xs + (size_t) b * 1024 + lane * 16);
+    const f32x4 o = q8k_requant4(v, lane);
+    u32x2 h; h[0] = (uint32_t) f2h(o[0]) | ((uint32_t) f2h(o[1]) << 16); h[1] = (uint32_t) f2h(o[2]) | ((uint32_t) f2h(o[3]) << 16);
+    *(u32x2 *) (y + row * ys + (size_t) b * 512 + lane * 8) = h;
+}
+void convert_f32_f16q_rows(const float * x, size_t xs, uint16_t * y, size_t ys, int64_t K, int64_t nrows, hipStream_t st) {
+    if (K == 0 || nrows == 0) return;
+    if (K % 256 != 0 || xs % 16 != 0 || ys % 8 != 0 || ((uintptr_t) x & 15) != 0 || ((uintptr_t) y & 7) != 0) { fprintf(stderr, "[mi355x] convert_f32_f16q_rows: K %% 256 == 0 and aligned rows\n"); abort(); }
+    const int64_t waves = nrows * (K / 256);
+    k_rows_to_f16q<false><<<dim3((unsigned) ((waves + 3) / 4)), dim3(256), 0, st>>>((const char *) x, xs, (char *) y, ys, (int) (K / 256), nrows);
+}
+void requant_f16_rows_q8k(uint16_t * y, size_t ys, int64_t K, int64_t nrows, hipStream_t st) {
+    if (K == 0 || nrows == 0) return;
+    if (K % 256 != 0 || ys % 8 != 0 || ((uintptr_t) y & 7) != 0) { fprintf(stderr, "[mi355x] requant_f16_rows_q8k: K %% 256 == 0 and aligned rows\n"); abort(); }
+    const int64_t waves = nrows * (K / 256);
+    k_rows_to_f16q<true><<<dim3((unsigned) ((waves + 3) / 4)), dim3(256), 0, st>>>((const char *) y, ys, (char *) y, ys, (int) (K / 256), nrows);
+}
+
 void convert_f32_f16_rows(const float * x, size_t xs, uint16_t * y, size_t ys, int64_t K, int64_t nrows, hipStream_t st) {
     if (K == 0 || nrows == 0) return;
     unsigned gx = (unsigned) ((K + 255) / 256); if (gx > 64) gx = 64;
