@@ -900,6 +900,17 @@ def main():
                     out["c4_stream_prefill_ttft"] = {"apm_ms": apm, "vpm_ms": vpm, "llm_prefill_tokens": n_llm, "llm_prefill_ms": round(llm_ms, 2),
                                                      "one_gpu_ms": round(apm + vpm + llm_ms, 2), "modules_on_own_gpus_ms": round(max(apm, vpm) + llm_ms, 2),
                                                      "note": "legs measured on this GPU; the pinned form (APM / VPM / LLM on three GPUs, module map) adds the two embedding hand-offs (<= 4.7 MB over xGMI)"} if okn else None
+                if ok and not args.tiny:
+                    # the two round-5 arithmetic options of the prefill GEMMs, same graph: off by default because they are slower
+                    var = {}
+                    for name, opts in (("prefill_q8k", {"prefill_q8k": 1}), ("prefill_q8k_mmq_tile", {"prefill_q8k": 1, "mmq_tile": 1})):
+                        try:
+                            for k, v in opts.items(): be.set_option(k, v)
+                            ppv, okv = prefill_tok_s(pkg, be, dec.model, reps=2)
+                            var[name] = round(ppv, 1) if okv else None
+                        finally:
+                            for k in opts: be.set_option(k, -1)
+                    out["pp512_arithmetic_options_tok_s"] = dict(var, note="prefill_q8k: K-quant GEMMs take the Q8_K-quantised activations (per-op NMSE vs the oracle 2e-6 instead of 5e-5); mmq_tile: Q4_K on the int8 matrix cores, the oracle's exact integers")
             except Exception as e:
                 out["pp512_tok_s"] = None
                 out["pp512_error"] = repr(e)
