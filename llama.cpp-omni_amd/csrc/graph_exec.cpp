@@ -2053,32 +2053,40 @@ static void compute_node(exec_state & s, int i) {
 // became free when the producer ran -- the producer's own sources -- so that overlap is checked.  Returns the CONT's node index or -1.
 static int cont_sink(exec_state & s, int i) {
     static const bool off = getenv("MI355X_NO_CONT_SINK") != nullptr;
+    static const bool dbg = getenv("MI355X_SINK_DEBUG") != nullptr;      // why a producer -> CONT pair was NOT folded, tallied per reason (stderr at process exit)
+    static long why[8] = { 0 };
+    struct dump { ~dump() { if (dbg) fprintf(stderr, "[mi355x] cont_sink: folded %ld | producer not a sink kind %ld | producer not plain %ld | next node no plain CONT %ld | path not RESHAPEs %ld | other readers %ld | CONT over the producer's sources %ld\n", why[0], why[1], why[2], why[3], why[4], why[5], why[6]); } };
+    static dump at_exit;
+    auto no = [&](int r) { if (dbg) ++why[r]; return -1; };
     if (off || !s.c->opt_fusion) return -1;
     ggml_cgraph * g = s.g;
     const ggml_tensor * p = g->nodes[i];
+    if (is_noop(p)) return -1;
     switch (p->op) {
         case GGML_OP_ADD: case GGML_OP_SUB: case GGML_OP_MUL: case GGML_OP_DIV: case GGML_OP_SCALE: case GGML_OP_SQR: case GGML_OP_SQRT: case GGML_OP_LOG: case GGML_OP_SIN: case GGML_OP_COS:
         case GGML_OP_CLAMP: case GGML_OP_LEAKY_RELU: case GGML_OP_CONCAT: case GGML_OP_REPEAT: case GGML_OP_PAD: case GGML_OP_PAD_REFLECT_1D: case GGML_OP_CONT: case GGML_OP_CONV_TRANSPOSE_1D:
             break;
         case GGML_OP_UNARY: break;
-        default: return -1;
+        default: { const int j0 = next_real_node(s, i); if (j0 >= 0 && g->nodes[j0]->op == GGML_OP_CONT) return no(1); return -1; }
     }
-    if (!p->data || !is_contiguous(p) || is_out(s, p) || p->view_src) return -1;
+    if (!p->data || !is_contiguous(p) || is_out(s, p) || p->view_src) return no(2);
     const int j = next_real_node(s, i);
     if (j < 0) return -1;
     const ggml_tensor * c = g->nodes[j];
-    if (c->op != GGML_OP_CONT || c->type != p->type || !c->data || c->view_src || !is_contiguous(c) || nbytes(c) != nbytes(p) || c->data == p->data) return -1;
+    if (c->op != GGML_OP_CONT) return -1;
+    if (c->type != p->type || !c->data || c->view_src || !is_contiguous(c) || nbytes(c) != nbytes(p) || c->data == p->data) return no(3);
     for (const ggml_tensor * t = c->src[0]; t != p; t = t->src[0]) {                  // directly, or through RESHAPEs of the contiguous result
-        if (!t || t->op != GGML_OP_RESHAPE || !is_contiguous(t) || is_out(s, t)) return -1;
+        if (!t || t->op != GGML_OP_RESHAPE || !is_contiguous(t) || is_out(s, t)) return no(4);
         auto it = s.users.find(t);
-        if (it == s.users.end() || it->second.size() != 1 || it->second[0] != j) return -1;
+        if (it == s.users.end() || it->second.size() != 1 || it->second[0] != j) return no(5);
     }
-    if (sole_user(s, p) != j) return -1;
+    if (sole_user(s, p) != j) return no(5);
     const char * lo = (const char *) c->data, * hi = lo + nbytes(c);
     for (int k = 0; k < GGML_MAX_SRC && p->src[k]; ++k) {
         const char * a = (const char *) p->src[k]->data, * b = a + nbytes(p->src[k]);
-        if (a < hi && lo < b) return -1;
+        if (a < hi && lo < b) return no(6);
     }
+    if (dbg) ++why[0];
     return j;
 }
 

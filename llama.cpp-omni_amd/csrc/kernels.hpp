@@ -159,6 +159,7 @@ void scale_f32(const float * x, float * y, int64_t n, float s, float b, hipStrea
 // ---- ops of the Token2Wav graphs (kernels/t2w_ops.hip; reference tools/omni/token2wav/token2wav-impl.cpp)
 // SQR / SQRT / LOG / SIN / COS / CLAMP(p0 = min, p1 = max) / LEAKY_RELU(p0 = slope) on dense f32
 void math_f32(int op, const float * x, float * y, int64_t n, float p0, float p1, hipStream_t st);
+void conv1d_weight_rows(const float * w, float * y, int KW, int C, int Cout, hipStream_t st);     // [KW, C, Cout] -> [Cout][KW][C] (exec_causal_conv)
 void concat(const tdesc & a, const tdesc & b, const tdesc & y, int dim, int elem_size, hipStream_t st);            // ops.cpp:1968-2009
 void repeat(const tdesc & x, const tdesc & y, int elem_size, hipStream_t st);                                      // ops.cpp:1637-1679
 void pad_f32(const tdesc & x, const tdesc & y, const int32_t * p, hipStream_t st);                                 // ops.cpp:7592-7638; p = {lp0, rp0, ..., lp3, rp3}

@@ -82,6 +82,21 @@ void concat(const tdesc & a, const tdesc & b, const tdesc & y, int dim, int elem
     else                k_concat<uint16_t><<<grid_for(total), dim3(256), 0, st>>>(to_t4(a), to_t4(b), to_t4(y), dim);
 }
 
+// ---------------------------------------------------------------------------------------------- 1-D convolution kernel [KW, C, Cout] -> rows [Cout][KW][C]
+// (the image the fused streaming causal convolution multiplies against KW consecutive C-fastest frames: graph_exec.cpp exec_causal_conv)
+__global__ void __launch_bounds__(256) k_conv1d_weight_rows(const float * __restrict__ w, float * __restrict__ y, int KW, int C, int64_t total) {
+    T2W_LOOP(total) {
+        const int64_t row = t / ((int64_t) KW * C); const int r = (int) (t - row * (int64_t) KW * C);
+        const int k = r / C, c = r - k * C;
+        y[t] = w[row * (int64_t) KW * C + (int64_t) c * KW + k];
+    }
+}
+void conv1d_weight_rows(const float * w, float * y, int KW, int C, int Cout, hipStream_t st) {
+    const int64_t total = (int64_t) KW * C * Cout;
+    if (total == 0) return;
+    k_conv1d_weight_rows<<<grid_for(total), dim3(256), 0, st>>>(w, y, KW, C, total);
+}
+
 // ---------------------------------------------------------------------------------------------- REPEAT (ops.cpp:1637-1679): dst[i] = src[i mod ne_src]
 template <typename T>
 __global__ void __launch_bounds__(256) k_repeat(t4 x, t4 y) {
