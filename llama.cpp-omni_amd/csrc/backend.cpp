@@ -209,6 +209,10 @@ static const ggml_backend_buffer_type_i k_hostbuft_iface = { hostbuft_name, host
 // ---------------------------------------------------------------------------------------------- backend (stream)
 static ggml_guid g_guid = { 0x4d, 0x49, 0x33, 0x35, 0x35, 0x58, 0x2d, 0x67, 0x66, 0x78, 0x39, 0x35, 0x30, 0x2d, 0x76, 0x31 };
 
+// MI355X_GRAPH_GPU_TIME=1: an event pair around every graph on the backend's stream; the device time of each (nodes, ms) is printed when the backend is freed
+// (how much of a caller's wall time per submission is the device -- the Token2Wav session builds and allocates a 27 000-node graph per window on the host)
+struct graph_gpu_time { hipEvent_t a, b; int nodes; };
+static std::vector<graph_gpu_time> g_graph_times;
 static const char * be_name(ggml_backend_t b) { return ((backend_ctx *) b->context)->name.c_str(); }
 static void be_free(ggml_backend_t b) {
     backend_ctx * c = (backend_ctx *) b->context;
@@ -216,6 +220,13 @@ static void be_free(ggml_backend_t b) {
     flush_uploads(c);
     HIP_CHECK(hipStreamSynchronize(c->stream));
     for (int h = 0; h < 2; ++h) { if (c->up_host[h]) (void) hipHostFree(c->up_host[h]); if (c->up_ents[h]) (void) hipHostFree(c->up_ents[h]); if (c->up_done[h]) (void) hipEventDestroy(c->up_done[h]); }
+    if (!g_graph_times.empty()) {
+        std::string line;
+        for (const graph_gpu_time & t : g_graph_times) { float ms = 0.0f; if (hipEventElapsedTime(&ms, t.a, t.b) == hipSuccess) { char buf[64]; snprintf(buf, sizeof buf, " %d:%.2f", t.nodes, ms); line += buf; } (void) hipEventDestroy(t.a); (void) hipEventDestroy(t.b); }
+        (void) hipGetLastError();
+        log_msg(GGML_LOG_LEVEL_INFO, "[mi355x] %s: device time per graph (nodes:ms):%s\n", c->name.c_str(), line.c_str());
+        g_graph_times.clear();
+    }
     if (getenv("MI355X_LOG_STATS"))
         log_msg(GGML_LOG_LEVEL_INFO, "[mi355x] %s: graphs eager=%ld captured=%ld replayed=%ld, kernels in last graph=%ld\n", c->name.c_str(),
                 c->stat_eager, c->stat_captures, c->stat_replays, c->stat_kernels_last);
@@ -324,7 +335,15 @@ static void be_sync(ggml_backend_t b) {
 static enum ggml_status be_graph_compute(ggml_backend_t b, struct ggml_cgraph * g) {
     backend_ctx * c = (backend_ctx *) b->context; host_timer ht(c->host_ns_graph); ++c->n_graph; set_device(c->device);
     flush_uploads(c);
-    return graph_compute(c, g);
+    static const bool gpu_time = getenv("MI355X_GRAPH_GPU_TIME") != nullptr;
+    if (!gpu_time) return graph_compute(c, g);
+    graph_gpu_time t; t.nodes = g->n_nodes;
+    HIP_CHECK(hipEventCreate(&t.a)); HIP_CHECK(hipEventCreate(&t.b));
+    HIP_CHECK(hipEventRecord(t.a, c->stream));
+    const enum ggml_status st = graph_compute(c, g);
+    HIP_CHECK(hipEventRecord(t.b, c->stream));
+    g_graph_times.push_back(t);
+    return st;
 }
 static void be_graph_optimize(ggml_backend_t b, struct ggml_cgraph * g) { graph_optimize((backend_ctx *) b->context, g); }
 static void be_event_record(ggml_backend_t b, ggml_backend_event_t e) {

@@ -252,6 +252,38 @@ enum ggml_status graph_compute(backend_ctx * c, ggml_cgraph * g) {
     exec_state s; s.c = c; s.st = c->stream;
     const auto t_run = std::chrono::steady_clock::now();
     run_nodes(s, g);
+    // MI355X_GRAPH_SLICE="nodes:lo:hi[,lo:hi...]": behind the eager run of a graph of exactly `nodes` nodes, each node range [lo, hi) is captured on its own and replayed
+    // 20 times between two events -- the in-graph device time of a block / a chain / one kernel (rocprofv3 cannot trace replayed graphs here).  The replays recompute
+    // the range on the data the eager run left: harmless for timing, so only for a throw-away run.
+    if (const char * sl = getenv("MI355X_GRAPH_SLICE")) {
+        static bool done_once = false;
+        int nodes = atoi(sl);
+        if (!done_once && nodes == g->n_nodes) {
+            done_once = true;
+            HIP_CHECK(hipStreamSynchronize(c->stream));
+            for (const char * p = strchr(sl, ':'); p; p = strchr(p, ',')) {
+                ++p;
+                int lo = 0, hi = 0;
+                if (sscanf(p, "%d:%d", &lo, &hi) != 2 || lo < 0 || hi <= lo || hi > g->n_nodes) break;
+                exec_state s2; s2.c = c; s2.st = c->stream; s2.capturing = true; s2.node_lo = lo; s2.node_hi = hi;
+                HIP_CHECK(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+                for (int rep = 0; rep < 10; ++rep) run_nodes(s2, g);                 // ten copies of the range per replay: the ~10 us floor of a hipGraphLaunch amortised
+                hipGraph_t graph = nullptr; hipGraphExec_t ex = nullptr;
+                HIP_CHECK(hipStreamEndCapture(c->stream, &graph));
+                HIP_CHECK(hipGraphInstantiate(&ex, graph, nullptr, nullptr, 0));
+                hipEvent_t e0, e1; HIP_CHECK(hipEventCreate(&e0)); HIP_CHECK(hipEventCreate(&e1));
+                for (int r = 0; r < 3; ++r) HIP_CHECK(hipGraphLaunch(ex, c->stream));
+                HIP_CHECK(hipEventRecord(e0, c->stream));
+                for (int r = 0; r < 20; ++r) HIP_CHECK(hipGraphLaunch(ex, c->stream));
+                HIP_CHECK(hipEventRecord(e1, c->stream));
+                HIP_CHECK(hipStreamSynchronize(c->stream));
+                float ms = 0.0f; HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+                log_msg(GGML_LOG_LEVEL_INFO, "[mi355x] slice [%d, %d): %ld launches, %.2f us per pass (%.2f us per launch)\n", lo, hi, s2.n_kernels / 10, ms * 1e3 / 200, s2.n_kernels ? ms * 1e3 / 20 / s2.n_kernels : 0.0);
+                (void) hipEventDestroy(e0); (void) hipEventDestroy(e1); (void) hipGraphExecDestroy(ex); (void) hipGraphDestroy(graph);
+                if (!strchr(p, ',')) break;
+            }
+        }
+    }
     c->host_ns_eager_run += (uint64_t) std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t_run).count(); c->n_eager_kernels += s.n_kernels;
     c->stat_eager++; c->stat_kernels_last = s.n_kernels;
     if (c->opt_profile) prof_drain(c);

@@ -1,6 +1,7 @@
 // graph_exec.cpp -- executor side: the node executors, the fusion matchers in front of them (activation images, grouped GEMMs, norm / rope chains, attention
 // chains, element-wise chains) and run_nodes.  (Split out of graph.cpp in round 4; no behaviour change.)
 #include "graph_internal.hpp"
+#include <map>
 
 namespace mi {
 
@@ -2133,18 +2134,24 @@ static int exec_ew_chain(exec_state & s, int i, int * taken) {
             if (!o) { ok = false; break; }
             if (n > 0 && through_reshapes(o, res[n - 1], j)) { sel[k] = 8 + (n - 1); uses_prev = true; continue; }
             // an external operand
-            if (o->type != GGML_TYPE_F32 || !o->data || !is_contiguous(o)) { ok = false; break; }
+            if (o->type != GGML_TYPE_F32 || !o->data) { ok = false; break; }
             int mode;
-            if (nelements(o) == total && (k == 0 || same_shape(o, nd))) mode = 0;
+            // one row per dim-2 slice (the DiT's shift / scale / gate: [C, 1, B] views of the adaLN product, repeated over the frames of batch element b)
+            const bool row_per_slice = k == 1 && nd->ne[3] == 1 && o->ne[0] == nd->ne[0] && o->ne[1] == 1 && nd->ne[1] > 1 && o->ne[2] == nd->ne[2] && o->ne[2] > 1 && o->ne[3] == 1 &&
+                                       o->nb[0] == 4 && o->nb[2] % 16 == 0 && o->ne[0] % 4 == 0 && o->nb[2] / 16 < (1ull << 32);
+            if (row_per_slice) mode = 3;
+            else if (!is_contiguous(o)) { ok = false; break; }
+            else if (nelements(o) == total && (k == 0 || same_shape(o, nd))) mode = 0;
             else if (k == 1 && nelements(o) == 1) mode = 2;
             else if (k == 1 && o->ne[0] == nd->ne[0] && o->ne[1] * o->ne[2] * o->ne[3] == 1 && o->ne[0] % 4 == 0) mode = 1;
             else { ok = false; break; }
             if (mode != 2 && ((uintptr_t) o->data & 15) != 0) { ok = false; break; }
             int e = -1;
-            for (int q = 0; q < n_ext; ++q) if (ext[q]->data == o->data && a.in_mode[q] == mode && (mode != 1 || a.in_n04[q] == (uint32_t) (o->ne[0] / 4))) e = q;
+            for (int q = 0; q < n_ext; ++q) if (ext[q]->data == o->data && a.in_mode[q] == mode && ((mode != 1 && mode != 3) || a.in_n04[q] == (uint32_t) (o->ne[0] / 4)) && (mode != 3 || a.in_bs4[q] == (uint32_t) (o->nb[2] / 16))) e = q;
             if (e < 0) {
                 if (n_ext >= 6) { ok = false; break; }
-                e = n_ext++; ext[e] = o; a.in[e] = (const float *) o->data; a.in_mode[e] = mode; a.in_n04[e] = mode == 1 ? (uint32_t) (o->ne[0] / 4) : 1;
+                e = n_ext++; ext[e] = o; a.in[e] = (const float *) o->data; a.in_mode[e] = mode; a.in_n04[e] = (mode == 1 || mode == 3) ? (uint32_t) (o->ne[0] / 4) : 1;
+                a.in_per4[e] = mode == 3 ? (uint32_t) (nd->ne[0] * nd->ne[1] / 4) : 1; a.in_bs4[e] = mode == 3 ? (uint32_t) (o->nb[2] / 16) : 0;
             }
             sel[k] = e;
         }
@@ -2185,7 +2192,171 @@ static int exec_ew_chain(exec_state & s, int i, int * taken) {
     return n;
 }
 
+// Token2Wav's streaming causal 1-D convolution the way the reference's builder spells it (token2wav-impl.cpp: the cached P = KW - 1 frames ++ x on the time axis of the
+// transposed [T, C, B] copies, then per batch element VIEW -> IM2COL -> MUL_MAT against the [KW*C, Cout] kernel, CONCAT of the batch elements, PERMUTE + CONT back to
+// [Cout, T, B], ADD of the bias): 11 launches, five of them transposes or copies.  With x and the cache in their C-fastest layouts the im2col column of frame t is the
+// KW*C consecutive floats from frame t of (cache ++ x) -- so: ONE dense concat into the pattern's own [T+P, C, B] buffer (as [C, T+P, B]) and ONE any-shape GEMM whose
+// activation rows overlap (row stride C floats, row length KW*C) against the kernel re-laid once to [Cout][KW][C] (a resident image next to the F16 weight images),
+// the bias in its epilogue, both batch elements in the launch.  The sums are the reference's with the KW*C products in (k, c) instead of (c, k) order.
+// `i` is the CONT of the transposed x.  Returns true when the pattern was taken (its nodes are marked done).
+static bool exec_causal_conv(exec_state & s, int i) {
+    static const bool off = getenv("MI355X_NO_CONV_FUSE") != nullptr;
+    if (off || !s.c->opt_fusion) return false;
+    ggml_cgraph * g = s.g;
+    static const bool dbg = getenv("MI355X_SINK_DEBUG") != nullptr;          // which line turned a CONT(PERMUTE(x)) candidate down, tallied (stderr at process exit)
+    static std::map<int, long> why;
+    struct dump { ~dump() { if (dbg) { fprintf(stderr, "[mi355x] causal_conv: refusals by source line:"); for (auto & kv : why) fprintf(stderr, " %d:%ld", kv.first, kv.second); fprintf(stderr, "\n"); } } };
+    static dump at_exit;
+    auto no = [&](int line) { if (dbg) ++why[line]; return false; };
+    auto plain = [](const ggml_tensor * t) { return t && t->type == GGML_TYPE_F32 && t->data && is_contiguous(t) && t->ne[3] == 1; };
+    // t = CONT(PERMUTE(q)) with q a plain [C, n, B] tensor and t its [n, C, B] transpose: returns q
+    auto untransposed = [&](const ggml_tensor * t) -> const ggml_tensor * {
+        if (!plain(t) || t->op != GGML_OP_CONT || t->view_src) return nullptr;
+        const ggml_tensor * p = t->src[0];
+        if (!p || p->op != GGML_OP_PERMUTE) return nullptr;
+        const ggml_tensor * q = p->src[0];
+        if (!plain(q) || p->ne[0] != q->ne[1] || p->ne[1] != q->ne[0] || p->ne[2] != q->ne[2] || p->nb[0] != q->nb[1] || p->nb[1] != q->nb[0] || p->nb[2] != q->nb[2] || p->data != q->data) return nullptr;
+        return q;
+    };
+    auto through_reshapes = [&](const ggml_tensor * t, const ggml_tensor * target) -> bool {
+        for (; t != target; t = t->src[0]) if (!t || t->op != GGML_OP_RESHAPE || is_out(s, t)) return false;
+        return true;
+    };
+    const ggml_tensor * n1 = g->nodes[i];
+    if (n1->op != GGML_OP_CONT) return false;
+    const ggml_tensor * x = untransposed(n1);
+    if (!x) return false;
+    const int64_t C = x->ne[0], T = x->ne[1], B = x->ne[2];
+    if (B < 1 || B > 2 || T < 1 || C % 4 != 0) return no(__LINE__);
+    const int j2 = sole_user(s, n1);
+    if (j2 <= i) return no(__LINE__);
+    const ggml_tensor * n2 = g->nodes[j2];
+    if (n2->op != GGML_OP_CONCAT || op_param_i32(n2, 0) != 0 || n2->src[1] != n1 || !plain(n2)) return no(__LINE__);
+    const ggml_tensor * cacheT = n2->src[0];
+    const ggml_tensor * cc = untransposed(cacheT);
+    if (!cc || cc->ne[0] != C || cc->ne[2] != B) return no(__LINE__);
+    const int64_t P = cc->ne[1], KW = P + 1;
+    // the cache frames are computed before x's copy; their C-fastest original is dead for ggml-alloc once the transposed copy exists, so it is only read when nothing
+    // between that copy and here wrote over it -- otherwise the transposed copy is read through swapped strides
+    bool cc_intact = true;
+    {
+        auto it = s.index.find(cacheT);
+        if (it == s.index.end() || it->second >= i) return no(__LINE__);
+        if (i - it->second > 64) cc_intact = false;
+        for (int k = it->second + 1; k < i && cc_intact; ++k) if (!is_noop(g->nodes[k]) && g->nodes[k]->data && overlap(range_of(g->nodes[k]), range_of(cc))) cc_intact = false;
+    }
+    const int j3 = sole_user(s, n2);
+    if (j3 <= j2) return no(__LINE__);
+    const ggml_tensor * n3 = g->nodes[j3];
+    if (n3->op != GGML_OP_CONT || n3->src[0] != n2 || !plain(n3) || n3->view_src || n3->ne[0] != T + P || n3->ne[1] != C || n3->ne[2] != B || is_out(s, n3)) return no(__LINE__);
+    auto u3 = s.users.find(n3);
+    if (u3 == s.users.end() || (int64_t) u3->second.size() != B) return no(__LINE__);
+    int im[2] = { -1, -1 }, mm[2] = { -1, -1 };
+    const ggml_tensor * Wk = nullptr;
+    for (int q = 0; q < (int) B; ++q) {
+        const int ji = u3->second[q];
+        const ggml_tensor * ic = g->nodes[ji];
+        if (ic->op != GGML_OP_IM2COL || !plain(ic) || ic->ne[0] != KW * C || ic->ne[1] != T || ic->ne[2] != 1) return no(__LINE__);
+        const int32_t * ip = ic->op_params;
+        if (ip[0] != 1 || ip[2] != 0 || ip[4] != 1 || ip[6] != 0) return no(__LINE__);                          // stride 1, no padding, dilation 1, 1-D
+        const ggml_tensor * v = ic->src[1];
+        if (!v || v->view_src != n3 || v->type != GGML_TYPE_F32 || v->ne[0] != T + P || v->ne[1] != C || v->ne[2] != 1 || v->ne[3] != 1 || v->nb[1] != n3->nb[1]) return no(__LINE__);
+        const size_t off_b = (size_t) ((const char *) v->data - (const char *) n3->data);
+        if (off_b % n3->nb[2] != 0) return no(__LINE__);
+        const int b = (int) (off_b / n3->nb[2]);
+        if (b < 0 || b >= B || im[b] >= 0) return no(__LINE__);
+        const ggml_tensor * k = ic->src[0];
+        if (!plain(k) || k->ne[0] != KW || k->ne[1] != C || k->op != GGML_OP_NONE || k->view_src || (Wk && k != Wk)) return no(__LINE__);
+        Wk = k; im[b] = ji;
+        const int jm = sole_user(s, ic);
+        if (jm <= ji) return no(__LINE__);
+        const ggml_tensor * m = g->nodes[jm];
+        if (m->op != GGML_OP_MUL_MAT || !plain(m) || m->ne[0] != T || m->ne[1] != Wk->ne[2] || m->ne[2] != 1 || !through_reshapes(m->src[0], ic)) return no(__LINE__);
+        const ggml_tensor * kr = m->src[1];
+        if (!kr || kr->ne[0] != KW * C || kr->ne[1] != Wk->ne[2] || kr->ne[2] != 1 || kr->data != Wk->data || !is_contiguous(kr) || kr->type != GGML_TYPE_F32) return no(__LINE__);
+        mm[b] = jm;
+    }
+    const int64_t Cout = Wk->ne[2];
+    if (Wk->ne[3] != 1 || !Wk->buffer || Wk->buffer->usage != GGML_BACKEND_BUFFER_USAGE_WEIGHTS) return no(__LINE__);
+    int j4 = -1;
+    const ggml_tensor * n4 = g->nodes[mm[0]];                                                             // [T, Cout, B], T fastest
+    if (B == 2) {
+        j4 = sole_user(s, g->nodes[mm[0]]);
+        if (j4 < 0 || j4 != sole_user(s, g->nodes[mm[1]]) || j4 <= mm[0] || j4 <= mm[1]) return no(__LINE__);
+        n4 = g->nodes[j4];
+        if (n4->op != GGML_OP_CONCAT || op_param_i32(n4, 0) != 2 || !plain(n4) || n4->ne[0] != T || n4->ne[1] != Cout || n4->ne[2] != 2 ||
+            !through_reshapes(n4->src[0], g->nodes[mm[0]]) || !through_reshapes(n4->src[1], g->nodes[mm[1]])) return no(__LINE__);
+    }
+    const int j6 = sole_user(s, n4);
+    if (j6 < 0 || j6 <= (B == 2 ? j4 : mm[0])) return no(__LINE__);
+    const ggml_tensor * n6 = g->nodes[j6];
+    if (n6->op != GGML_OP_CONT || !plain(n6) || n6->view_src || n6->ne[0] != Cout || n6->ne[1] != T || n6->ne[2] != B) return no(__LINE__);
+    {
+        const ggml_tensor * p = n6->src[0];
+        if (!p || p->op != GGML_OP_PERMUTE || p->ne[0] != Cout || p->ne[1] != T || p->ne[2] != B || p->nb[0] != (size_t) T * 4 || p->nb[1] != 4 ||
+            (B == 2 && p->nb[2] != (size_t) T * (size_t) Cout * 4) || p->data != n4->data || !through_reshapes(p->src[0], n4)) return no(__LINE__);
+    }
+    const ggml_tensor * out = n6; const float * bias = nullptr; int j7 = -1;
+    if (!is_out(s, n6)) {
+        const int ja = sole_user(s, n6);
+        if (ja > j6 && next_real_node(s, j6) == ja) {
+            const ggml_tensor * ad = g->nodes[ja];
+            const ggml_tensor * bv = ad->src[1];
+            if (ad->op == GGML_OP_ADD && ad->src[0] == n6 && plain(ad) && same_shape(ad, n6) && bv && bv->type == GGML_TYPE_F32 && bv->data && is_contiguous(bv) && bv->ne[0] == Cout && nelements(bv) == Cout) {
+                out = ad; bias = (const float *) bv->data; j7 = ja;
+            }
+        }
+    }
+    const int last = j7 >= 0 ? j7 : j6;
+    auto mine = [&](int k) { return k == i || k == j2 || k == j3 || k == im[0] || k == im[1] || k == mm[0] || k == mm[1] || k == j4 || k == j6 || k == j7; };
+    for (int k = i + 1; k < last; ++k) if (!mine(k) && !s.done[k] && !is_noop(g->nodes[k])) return no(__LINE__);   // nothing else runs inside the pattern
+    for (int k : { j2, j3, im[0], im[1], mm[0], mm[1], j4, j6 }) if (k >= 0 && k != last && is_out(s, g->nodes[k])) return no(__LINE__);
+    if (is_out(s, n1)) return no(__LINE__);
+    if (((uintptr_t) x->data & 15) || ((uintptr_t) cc->data & 15) || ((uintptr_t) out->data & 15)) return no(__LINE__);
+    // ggml-alloc may have put the pattern's buffers over memory that is free by the time their own node runs; here they are written at x's copy
+    // (the concatenated frames go to the CONT's buffer, or to the CONCAT's -- same size, both dead outside the pattern -- when the first sits on an input or under the result)
+    const ggml_tensor * xbuf = nullptr;
+    for (const ggml_tensor * cand : { n3, n2 })
+        if (!xbuf && !((uintptr_t) cand->data & 15) && !overlap(range_of(cand), range_of(x)) && !overlap(range_of(cand), range_of(cc_intact ? cc : cacheT)) && !overlap(range_of(out), range_of(cand))) xbuf = cand;
+    if (!xbuf) return no(__LINE__);
+    // the kernel rows [Cout][KW][C]: built on first use outside capture, kept with the weight images (dropped with them when the source bytes are written)
+    bool created = false;
+    float * wrows = (float *) shadow_get_or_create(s.c->device, Wk->data, nbytes(Wk), /*type: conv rows*/ 1000 + (int) KW, 2 * KW * C, Cout, (size_t) KW * 4, s.st, s.capturing, &created);
+    if (!wrows) return no(__LINE__);
+    if (s.pr.A) materialise_reduce(s);
+    if (s.prm.n) materialise_group(s);
+    if (s.pn.m && (s.pn.m == x || s.pn.m == cc)) materialise_norm(s);
+    if (created) {
+        prof_scope ps(s, "conv_weight_rows", 0);
+        conv1d_weight_rows((const float *) Wk->data, wrows, (int) KW, (int) C, (int) Cout, s.st); ++s.n_kernels;
+        shadow_mark_ready((uint16_t *) wrows, s.st);
+    }
+    {
+        prof_scope ps(s, "concat", 0);
+        tdesc y; y.p = xbuf->data; y.ne[0] = C; y.ne[1] = T + P; y.ne[2] = B; y.ne[3] = 1; y.nb[0] = 4; y.nb[1] = (size_t) C * 4; y.nb[2] = (size_t) C * (size_t) (T + P) * 4; y.nb[3] = y.nb[2] * (size_t) B;
+        tdesc ca = td(cc);
+        if (!cc_intact) { ca.p = cacheT->data; ca.nb[0] = cacheT->nb[1]; ca.nb[1] = cacheT->nb[0]; ca.nb[2] = cacheT->nb[2]; ca.nb[3] = cacheT->nb[3]; }
+        concat(ca, td(x), y, 1, 4, s.st); ++s.n_kernels;
+    }
+    note_write(s, xbuf);
+    {
+        gemm_any_args a;
+        a.W = wrows; a.w_rs = (size_t) KW * C * 4; a.w_f16 = false;
+        a.X = xbuf->data; a.x_rs = (size_t) C * 4; a.x_nb2 = (size_t) C * (size_t) (T + P) * 4;
+        a.dst = (float *) out->data; a.dst_cs = out->nb[1]; a.dst_nb2 = out->nb[2]; a.bias = bias;
+        a.M = Cout; a.N = T; a.K = KW * C; a.nbatch = (int) B; a.ne12 = (int) B; a.r2 = (int) B; a.r3 = 1;
+        if (s.c->gemm_partial && s.c->fa_counters) { a.partial = (float *) s.c->gemm_partial; a.partial_bytes = s.c->gemm_partial_bytes; a.counters = s.c->fa_counters; a.n_counters = 1024; }
+        prof_scope ps(s, "gemm_any_f32", 2.0 * (double) Cout * (double) T * (double) (KW * C) * (double) B);
+        gemm_any(a, s.st); ++s.n_kernels;
+    }
+    note_write(s, out);
+    for (int k : { j2, j3, im[0], im[1], mm[0], mm[1], j4, j6, j7 }) if (k >= 0) { s.done[k] = 1; ++s.n_fused; }
+    if (dbg) ++why[0];
+    return true;
+}
+
 void run_nodes(exec_state & s, ggml_cgraph * g) {
+    static FILE * const launch_log = getenv("MI355X_LAUNCH_LOG") ? fopen(getenv("MI355X_LAUNCH_LOG"), "w") : nullptr;      // one line per node that launched: what a graph's launches are made of (tools/launch_ngrams.py)
     s.g = g;
     s.done.assign(g->n_nodes, 0);
     s.index.clear(); s.users.clear();
@@ -2235,7 +2406,7 @@ void run_nodes(exec_state & s, ggml_cgraph * g) {
         // calibration sample: an event pair with nothing in between measures the bracket's own cost, which consumers subtract
         for (int k = 0; k < 4; ++k) { prof_scope ps(s, "empty", 0); }
     }
-    for (int i = 0; i < g->n_nodes; ++i) {
+    for (int i = s.node_lo; i < (s.node_hi < 0 || s.node_hi > g->n_nodes ? g->n_nodes : s.node_hi); ++i) {
         if (s.done[i]) continue;
         static const bool host_prof = getenv("MI355X_HOST_PROF") != nullptr;          // host time of the node walk by op (stderr, per graph): where an eager graph's enqueue time goes
         static double hp_ns[GGML_OP_COUNT]; static long hp_n[GGML_OP_COUNT];
@@ -2246,6 +2417,14 @@ void run_nodes(exec_state & s, ggml_cgraph * g) {
             for (int o = 0; o < GGML_OP_COUNT; ++o) if (hp_n[o]) fprintf(stderr, " op%d n=%ld %.2fus/node", o, hp_n[o], hp_ns[o] / hp_n[o] * 1e-3);
             fprintf(stderr, "\n");
         }
+        struct ll_guard { exec_state & s; ggml_cgraph * g; int i; long k0; long f0; ~ll_guard() {
+            if (!launch_log || s.capturing || s.n_kernels == k0) return;
+            const ggml_tensor * n = g->nodes[i];
+            fprintf(launch_log, "%d %d %ld %ld [%lld,%lld,%lld,%lld]", i, (int) n->op, s.n_kernels - k0, s.n_fused - f0, (long long) n->ne[0], (long long) n->ne[1], (long long) n->ne[2], (long long) n->ne[3]);
+            for (int k = 0; k < 3 && n->src[k]; ++k) fprintf(launch_log, " s%d:op%d%s[%lld,%lld,%lld,%lld]", k, (int) n->src[k]->op, is_contiguous(n->src[k]) ? "c" : "n", (long long) n->src[k]->ne[0], (long long) n->src[k]->ne[1], (long long) n->src[k]->ne[2], (long long) n->src[k]->ne[3]);
+            fprintf(launch_log, "\n");
+        } } ll_g{ s, g, i, s.n_kernels, s.n_fused };
+        if (g->nodes[i]->op == GGML_OP_CONT && exec_causal_conv(s, i)) continue;
         {
             int taken[8];
             const int nt = is_noop(g->nodes[i]) ? 0 : exec_ew_chain(s, i, taken);
@@ -2270,6 +2449,7 @@ void run_nodes(exec_state & s, ggml_cgraph * g) {
             }
         }
     }
+    if (launch_log && !s.capturing) { fprintf(launch_log, "== end of a graph of %d nodes\n", g->n_nodes); fflush(launch_log); }
 }
 
 

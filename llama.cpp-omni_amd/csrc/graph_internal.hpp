@@ -64,6 +64,7 @@ struct exec_state {
     // activation cache
     const void *  a_src = nullptr; act_kind a_kind = ACT_NONE; int64_t a_K = 0, a_ne[3] = {0, 0, 0}; size_t a_nb[3] = {0, 0, 0};
     bool          capturing = false;
+    int           node_lo = 0, node_hi = -1;      // run_nodes walks [node_lo, node_hi) (-1: to the end) -- the slice timer of graph_compute (MI355X_GRAPH_SLICE)
     // deferred RMS_NORM -> MUL(w): not computed yet; its K-quant mat-vec consumers build the Q8_K image in-kernel (mmvk.hip act_norm)
     struct { const ggml_tensor * m = nullptr; const ggml_tensor * x = nullptr; const ggml_tensor * wt = nullptr; float eps = 0; int left = 0; } pn;
     // deferred q chain + k chain/store + v store of a decode layer: executed by the FLASH_ATTN_EXT node `fa` itself (fattn_pre)

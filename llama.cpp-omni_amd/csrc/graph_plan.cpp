@@ -291,11 +291,17 @@ size_t graph_gemm_partial_need(const ggml_cgraph * g) {
     size_t need = 0;
     for (int i = 0; i < g->n_nodes; ++i) {
         const ggml_tensor * n = g->nodes[i];
-        if (n->op != GGML_OP_MUL_MAT || is_empty(n) || n->src[1]->ne[2] != 1 || n->src[1]->ne[3] != 1) continue;
+        if (n->op != GGML_OP_MUL_MAT || is_empty(n)) continue;
         if (mm_takes_gemm_any(n) && n->src[0]->type == GGML_TYPE_F32 && n->src[1]->type == GGML_TYPE_F32) {      // small f32 x f32 products may split K over workgroups (gemm_any.hip)
-            const size_t b = gemm_any_split_scratch_bytes(n->src[0]->ne[1], n->src[1]->ne[1], n->src[0]->ne[0], 1, true);
+            const int nbatch = (int) (n->src[1]->ne[2] * n->src[1]->ne[3]);
+            size_t b = gemm_any_split_scratch_bytes(n->src[0]->ne[1], n->src[1]->ne[1], n->src[0]->ne[0], nbatch, true);
+            if (n->src[0]->op == GGML_OP_RESHAPE && n->src[0]->src[0] && n->src[0]->src[0]->op == GGML_OP_IM2COL) {      // a streaming causal convolution's per-batch-element product: run with the roles swapped, both batch elements in one launch (exec_causal_conv)
+                const size_t b2 = gemm_any_split_scratch_bytes(n->src[1]->ne[1], n->src[0]->ne[1], n->src[0]->ne[0], 2, true);
+                if (b2 > b) b = b2;
+            }
             if (b > need) need = b;
         }
+        if (n->src[1]->ne[2] != 1 || n->src[1]->ne[3] != 1) continue;
         if (!mm_uses_gemm(n)) {                              // the split form of op_mul_mat (F16 weights, K a few columns past a multiple of 64): its MFMA part is a lone, usually under-filled GEMM
             const int64_t K = n->src[0]->ne[0];
             if (n->src[0]->type == GGML_TYPE_F16 && n->src[1]->type == GGML_TYPE_F32 && K % 64 != 0 && K >= 512 && n->src[1]->ne[1] > MI_MMVQ_MAX_COLS) {

@@ -305,7 +305,8 @@ void   gemm_reduce_rms_norm(const float * partial, int nsplit, const float * res
 struct ew_op_desc { int kind; int sub; int a, b; float p0, p1; };     // kind: GGML_OP_ADD / SUB / MUL / DIV / SCALE / UNARY (sub = the unary op) / SQR / SQRT / LOG / SIN / COS / CLAMP / LEAKY_RELU
 struct ew_chain_args {
     int n_ops = 0; ew_op_desc op[8];
-    int n_in = 0; const float * in[6]; int in_mode[6]; uint32_t in_n04[6];      // mode 0: the chain's shape, element for element; 1: one row of 4 * in_n04 floats repeated; 2: one value
+    int n_in = 0; const float * in[6]; int in_mode[6]; uint32_t in_n04[6];      // mode 0: the chain's shape, element for element; 1: one row of 4 * in_n04 floats repeated; 2: one value;
+    uint32_t in_per4[6] = { 0 }, in_bs4[6] = { 0 };                            // 3: one row per slice of 4 * in_per4 chain elements, the rows 4 * in_bs4 floats apart (the DiT's per-batch-element shift / scale / gate vectors)
     float * out = nullptr; int64_t total = 0;                                  // total % 4 == 0, every pointer 16-byte aligned (mode 2: 4-byte)
 };
 void   ew_chain(const ew_chain_args & a, hipStream_t st);

@@ -992,7 +992,7 @@ void bin_bcast_f32(int op, const tdesc & a, const tdesc & b, const tdesc & y, hi
 // chains of element-wise nodes (kernels.hpp ew_chain_args): the reference's Token2Wav graphs spell Mish as sub / exp / exp / add / log / tanh / mul and the DiT's
 // modulation as mul / add / add -- 3500 of a window's launches are links of such chains, each a ~4 us dependent launch over a few hundred KB
 // ================================================================================================
-struct ew_chain_dev { int n_ops, n_in; uint32_t total4; ew_op_desc op[8]; const float * in[6]; int in_mode[6]; uint32_t in_n04[6]; float * out; };
+struct ew_chain_dev { int n_ops, n_in; uint32_t total4; ew_op_desc op[8]; const float * in[6]; int in_mode[6]; uint32_t in_n04[6], in_per4[6], in_bs4[6]; float * out; };
 static __device__ __forceinline__ float ew_apply(const ew_op_desc & o, float a, float b) {
     switch (o.kind) {
         case GGML_OP_ADD:        return a + b;
@@ -1011,39 +1011,52 @@ static __device__ __forceinline__ float ew_apply(const ew_op_desc & o, float a, 
         default:                 return a;
     }
 }
+// V elements per thread: 4 (16-byte accesses), or 1 when the chain is short on threads and long on arithmetic -- Mish over a DiT activation of 57 344 floats is exp, exp,
+// log, tanh per element: 56 workgroups of four-element threads left three quarters of the chip idle behind a ~10 us dependent instruction chain per thread
+template <int V>
 __global__ void __launch_bounds__(256) k_ew_chain(const ew_chain_dev c) {
+    typedef float vec __attribute__((ext_vector_type(V)));
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    if (i >= c.total4) return;
-    f32x4 v[6 + 8];
+    if (i >= c.total4 * (4 / V)) return;
+    vec v[6 + 8];
 #pragma unroll
     for (int k = 0; k < 6; ++k) {
         if (k >= c.n_in) break;
-        if (c.in_mode[k] == 2) { const float s = c.in[k][0]; v[k] = f32x4{ s, s, s, s }; }
-        else v[k] = ((const f32x4 *) c.in[k])[c.in_mode[k] == 1 ? i % c.in_n04[k] : i];
+        const uint32_t n0 = c.in_n04[k] * (4 / V);
+        uint32_t idx = i;
+        if (c.in_mode[k] == 2) idx = 0;
+        else if (c.in_mode[k] == 3) idx = (i / (c.in_per4[k] * (4 / V))) * (c.in_bs4[k] * (4 / V)) + i % n0;
+        else if (c.in_mode[k] == 1) idx = i % n0;
+        if (c.in_mode[k] == 2) { const float s = c.in[k][0]; vec t; for (int e = 0; e < V; ++e) t[e] = s; v[k] = t; }
+        else v[k] = ((const vec *) c.in[k])[idx];
     }
-    f32x4 r = v[0];
+    vec r = v[0];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         if (j >= c.n_ops) break;
         const ew_op_desc o = c.op[j];
-        f32x4 a = r, b = r;
+        vec a = r, b = r;
         // (selectors are wave-uniform: a short uniform switch instead of dynamically indexed registers)
 #pragma unroll
         for (int k = 0; k < 14; ++k) { if ((o.a < 8 ? o.a : 6 + o.a - 8) == k) a = v[k]; if ((o.b < 8 ? o.b : 6 + o.b - 8) == k) b = v[k]; }
 #pragma unroll
-        for (int e = 0; e < 4; ++e) r[e] = ew_apply(o, a[e], b[e]);
+        for (int e = 0; e < V; ++e) r[e] = ew_apply(o, a[e], b[e]);
         v[6 + j] = r;
     }
-    ((f32x4 *) c.out)[i] = r;
+    ((vec *) c.out)[i] = r;
 }
 void ew_chain(const ew_chain_args & a, hipStream_t st) {
     if (a.total == 0) return;
-    if (a.n_ops < 1 || a.n_ops > 8 || a.n_in < 1 || a.n_in > 6 || a.total % 4 != 0 || a.total / 4 >= (1ll << 32) || ((uintptr_t) a.out & 15) != 0) { fprintf(stderr, "[mi355x] ew_chain: unsupported arguments\n"); abort(); }
+    if (a.n_ops < 1 || a.n_ops > 8 || a.n_in < 1 || a.n_in > 6 || a.total % 4 != 0 || a.total / 4 >= (1ll << 30) || ((uintptr_t) a.out & 15) != 0) { fprintf(stderr, "[mi355x] ew_chain: unsupported arguments\n"); abort(); }
     ew_chain_dev c;
     c.n_ops = a.n_ops; c.n_in = a.n_in; c.total4 = (uint32_t) (a.total / 4); c.out = a.out;
     for (int j = 0; j < 8; ++j) c.op[j] = a.op[j < a.n_ops ? j : 0];
-    for (int k = 0; k < 6; ++k) { const int q = k < a.n_in ? k : 0; c.in[k] = a.in[q]; c.in_mode[k] = a.in_mode[q]; c.in_n04[k] = a.in_n04[q] ? a.in_n04[q] : 1; }
-    k_ew_chain<<<dim3((c.total4 + 255) / 256), dim3(256), 0, st>>>(c);
+    for (int k = 0; k < 6; ++k) { const int q = k < a.n_in ? k : 0; c.in[k] = a.in[q]; c.in_mode[k] = a.in_mode[q]; c.in_n04[k] = a.in_n04[q] ? a.in_n04[q] : 1; c.in_per4[k] = a.in_per4[q] ? a.in_per4[q] : 1; c.in_bs4[k] = a.in_bs4[q]; }
+    int heavy = 0;                                                  // libm-grade ops in the chain
+    for (int j = 0; j < a.n_ops; ++j) heavy += a.op[j].kind == GGML_OP_UNARY || a.op[j].kind == GGML_OP_LOG || a.op[j].kind == GGML_OP_SIN || a.op[j].kind == GGML_OP_COS;
+    static const bool no_v1 = getenv("MI355X_EW_CHAIN_NO_V1") != nullptr;
+    if (!no_v1 && heavy >= 2 && c.total4 <= 256u * 1024u) k_ew_chain<1><<<dim3((c.total4 * 4 + 255) / 256), dim3(256), 0, st>>>(c);
+    else k_ew_chain<4><<<dim3((c.total4 + 255) / 256), dim3(256), 0, st>>>(c);
 }
 
 // ================================================================================================

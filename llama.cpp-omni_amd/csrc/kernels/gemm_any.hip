@@ -361,8 +361,8 @@ __global__ void __launch_bounds__(256) k_gemm_f32_sk128(const gemm_any_dev g) {
 #pragma unroll
         for (int w = 0; w < 3; ++w) v[e] += red[w * 1024 + e * 64 + lane];
     }
-    if (g.ksplit > 1) {                                            // (batch 1 only: the launcher)
-        const int tile = (int) blockIdx.x, ntiles = (int) gridDim.x;
+    if (g.ksplit > 1) {
+        const int tile = (int) (blockIdx.y * gridDim.x + blockIdx.x), ntiles = (int) (gridDim.x * gridDim.y);
         float * mine = g.partial + ((size_t) kz * ntiles + tile) * 1024;
 #pragma unroll
         for (int e = 0; e < 16; ++e) mine[e * 64 + lane] = v[e];
@@ -391,11 +391,80 @@ __global__ void __launch_bounds__(256) k_gemm_f32_sk128(const gemm_any_dev g) {
     }
 }
 
+// The small f32 x f32 products of a Token2Wav DiT block once more (512 .. 2048 rows x 50 .. 56 frames x batch 2, K 512 .. 2048; the attention's V^T . P with K = 200):
+// with 32 x 32 tiles such a product is 64 workgroups -- a quarter of the chip -- and each wave's chain is K / 8 dependent 64-cycle MFMAs (K = 2048: 16 us per product;
+// splitting K over workgroups buys nothing, the device-scope fences of the ticket fold cost what the split saves).  Here the tile is 16 x 16 on
+// v_mfma_f32_16x16x4f32 (32 cycles, the same 32 MAC per cycle): four times the workgroups, a quarter of the chain, the fold stays inside the workgroup.  Staging as in
+// k_gemm_f32_sk128: whole 512-byte row pieces per instruction into a wave-private LDS region (rows padded to 132 floats), 16-byte LDS reads -- lane (row, g) takes the
+// quad at k = 16 q + 4 g for MFMAs 4 q .. 4 q + 3, both operands alike.  The four waves split K in chunks that are multiples of 16, so K = 200 still uses all four.
+__global__ void __launch_bounds__(256) k_gemm_f32_t16(const gemm_any_dev g) {
+    constexpr int KS = 128, LD = KS + 4;
+    float * Ws = ga_dyn_lds + (threadIdx.x >> 6) * (2 * 16 * LD), * Xs = Ws + 16 * LD;
+    float * red = ga_dyn_lds + 4 * (2 * 16 * LD);                  // [3][64 * 4]
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int tm = (int) blockIdx.x % g.tiles_m, tn = (int) blockIdx.x / g.tiles_m;        // (tiles_m counts 16-row tiles)
+    const int i12 = (int) blockIdx.y % g.ne12, i13 = (int) blockIdx.y / g.ne12;
+    const char * W = g.W + (size_t) (i12 / g.r2) * g.w_nb2 + (size_t) (i13 / g.r3) * g.w_nb3;
+    const char * X = g.X + (size_t) i12 * g.x_nb2 + (size_t) i13 * g.x_nb3;
+    const int m0 = tm * 16, n0 = tn * 16, fr = lane & 31, kh = lane >> 5, r16 = lane & 15, gq = lane >> 4;
+    const int chunk = ((g.K + 3) / 4 + 15) & ~15;                  // this wave's k range [k_lo, k_hi)
+    const int k_lo = wave * chunk, k_hi = k_lo + chunk < g.K ? k_lo + chunk : g.K;
+    typedef float acc4 __attribute__((ext_vector_type(4)));
+    acc4 acc = { 0.0f, 0.0f, 0.0f, 0.0f };
+    float4 wv[8], xv[8];
+    auto fetch = [&](int k0) {                                     // branch-free: clamped addresses (K % 4 == 0), zero selected afterwards
+        const int k = k0 + 4 * fr, kc = k < g.K ? k : g.K - 4;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int r = 2 * i + kh;
+            const int mr = m0 + r < g.M ? m0 + r : g.M - 1, nr = n0 + r < g.N ? n0 + r : g.N - 1;
+            wv[i] = *(const float4 *) (W + (size_t) mr * g.w_rs + (size_t) kc * 4);
+            xv[i] = *(const float4 *) (X + (size_t) nr * g.x_rs + (size_t) kc * 4);
+        }
+        if (k >= k_hi) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { wv[i] = make_float4(0.f, 0.f, 0.f, 0.f); xv[i] = make_float4(0.f, 0.f, 0.f, 0.f); }
+        }
+    };
+    if (k_lo < k_hi) fetch(k_lo);
+    for (int k0 = k_lo; k0 < k_hi; k0 += KS) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { *(float4 *) &Ws[(2 * i + kh) * LD + 4 * fr] = wv[i]; *(float4 *) &Xs[(2 * i + kh) * LD + 4 * fr] = xv[i]; }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (k0 + KS < k_hi) fetch(k0 + KS);
+        const int nq = (k_hi - k0 < KS ? k_hi - k0 + 15 : KS) / 16;      // (wave-uniform)
+        for (int q = 0; q < nq; ++q) {
+            const float4 a = *(const float4 *) &Xs[r16 * LD + 16 * q + 4 * gq], b = *(const float4 *) &Ws[r16 * LD + 16 * q + 4 * gq];
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b.z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b.w, acc, 0, 0, 0);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    if (wave > 0) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) red[(wave - 1) * 256 + e * 64 + lane] = acc[e];
+    }
+    __syncthreads();
+    if (wave > 0) return;
+    char * dst = g.dst + (size_t) i12 * g.dst_nb2 + (size_t) i13 * g.dst_nb3;
+    const int m = m0 + r16;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int n = n0 + 4 * gq + e;
+        float v = acc[e];
+#pragma unroll
+        for (int w = 0; w < 3; ++w) v += red[w * 256 + e * 64 + lane];
+        if (m < g.M && n < g.N) { float * p = (float *) (dst + (size_t) n * g.dst_cs + (size_t) m * 4); if (g.accumulate) v = *p + v; if (g.bias) v = __fadd_rn(v, g.bias[m]); *p = v; }
+    }
+}
+
 // K split over workgroups for k_gemm_f32_sk128: only when the tiles leave most CUs idle and every workgroup still gets whole 128-deep steps for its four waves
 static int gemm_any_ksplit(int64_t M, int64_t N, int64_t K, int nbatch) {
     static const bool off = getenv("MI355X_NO_GEMM_F32_KSPLIT") != nullptr;
-    if (off || nbatch != 1 || K % 4 != 0) return 1;
-    const int64_t tiles = ((M + 31) / 32) * ((N + 31) / 32), nsteps = (K + 127) / 128;
+    if (off || nbatch < 1 || K % 4 != 0) return 1;
+    const int64_t tiles = ((M + 31) / 32) * ((N + 31) / 32) * nbatch, nsteps = (K + 127) / 128;
     if (tiles > 96 || nsteps < 8) return 1;
     int s = (int) (nsteps / 4); if (s > 4) s = 4;
     while (s > 1 && tiles * s > 256) --s;
@@ -404,7 +473,7 @@ static int gemm_any_ksplit(int64_t M, int64_t N, int64_t K, int nbatch) {
 size_t gemm_any_split_scratch_bytes(int64_t M, int64_t N, int64_t K, int nbatch, bool f32_operands) {
     if (!f32_operands) return 0;
     const int s = gemm_any_ksplit(M, N, K, nbatch);
-    return s > 1 ? (size_t) s * (size_t) (((M + 31) / 32) * ((N + 31) / 32)) * 1024 * 4 : 0;
+    return s > 1 ? (size_t) s * (size_t) (((M + 31) / 32) * ((N + 31) / 32) * nbatch) * 1024 * 4 : 0;
 }
 
 void gemm_any(const gemm_any_args & a, hipStream_t st) {
@@ -419,6 +488,18 @@ void gemm_any(const gemm_any_args & a, hipStream_t st) {
     // (F16 weights have the f16 matrix cores below -- 8x the K per MFMA, paired loads: their chains are short without a split; measured on Whisper's
     //  V^T . P of a streaming chunk, 64 x 50 x 400 x 16 heads: 24 us here, 6 us there)
     const bool h_path = a.w_f16 && !a.w_bf16 && !getenv("MI355X_NO_GEMM_ANY_H") && a.K < 2048;
+    static const bool no_t16 = getenv("MI355X_NO_GEMM_F32_T16") != nullptr;
+    static const int64_t t16_max_tiles = getenv("MI355X_GEMM_T16_MAX_TILES") ? atoll(getenv("MI355X_GEMM_T16_MAX_TILES")) : 128;
+    if (!no_t16 && !no_sk && !a.x_f16 && !a.w_f16 && !a.w_bf16 && a.K % 4 == 0 && a.K >= 64 && ((a.M + 31) / 32) * ((a.N + 31) / 32) * a.nbatch < t16_max_tiles && ((a.M + 15) / 16) * ((a.N + 15) / 16) <= 65535 &&
+        (((uintptr_t) a.W | a.w_rs | a.w_nb2 | a.w_nb3 | (uintptr_t) a.X | a.x_rs | a.x_nb2 | a.x_nb3) & 15) == 0) {       // f32 x f32, 16-byte aligned rows, fewer than 128 tiles of 32 x 32: 16 x 16 tiles
+        constexpr int lds = (4 * 2 * 16 * 132 + 3 * 256) * 4;       // 70 656 B: two workgroups per CU
+        static bool attr[64] = {};
+        int dev = 0; HIP_CHECK(hipGetDevice(&dev));
+        if (dev < 0 || dev >= 64 || !attr[dev]) { HIP_CHECK(hipFuncSetAttribute((const void *) k_gemm_f32_t16, hipFuncAttributeMaxDynamicSharedMemorySize, lds)); if (dev >= 0 && dev < 64) attr[dev] = true; }
+        g.tiles_m = (int) ((a.M + 15) / 16);
+        k_gemm_f32_t16<<<dim3((unsigned) (g.tiles_m * ((a.N + 15) / 16)), (unsigned) a.nbatch), dim3(256), lds, st>>>(g);
+        return;
+    }
     if (!no_sk && !h_path && (int64_t) g.tiles_m * ((a.N + 63) / 64) * a.nbatch < 128 && a.K >= 256) {          // few tiles, long chains: one 32 x 32 tile per workgroup, K split over its waves
         g.tiles_m = (int) ((a.M + 31) / 32);
         const dim3 grid((unsigned) (g.tiles_m * ((a.N + 31) / 32)), (unsigned) a.nbatch);
@@ -433,7 +514,9 @@ void gemm_any(const gemm_any_args & a, hipStream_t st) {
                 if (dev < 0 || dev >= 64 || !attr[dev]) { HIP_CHECK(hipFuncSetAttribute((const void *) k_gemm_f32_sk128, hipFuncAttributeMaxDynamicSharedMemorySize, lds)); if (dev >= 0 && dev < 64) attr[dev] = true; }
                 const int ks = gemm_any_ksplit(a.M, a.N, a.K, a.nbatch);
                 const size_t need = gemm_any_split_scratch_bytes(a.M, a.N, a.K, a.nbatch, true);
-                if (ks > 1 && a.partial && a.counters && need <= a.partial_bytes && (int64_t) grid.x <= a.n_counters) {
+                static const bool dbg = getenv("MI355X_GEMM_ANY_DEBUG") != nullptr;
+                if (dbg) fprintf(stderr, "[mi355x] gemm_any sk128: M %lld N %lld K %lld batch %d: ksplit %d, scratch need %zu have %zu, partial %p counters %p (%d)\n", (long long) a.M, (long long) a.N, (long long) a.K, a.nbatch, ks, need, a.partial_bytes, (void *) a.partial, (void *) a.counters, a.n_counters);
+                if (ks > 1 && a.partial && a.counters && need <= a.partial_bytes && (int64_t) grid.x * grid.y <= a.n_counters) {
                     g.partial = a.partial; g.counters = a.counters; g.ksplit = ks;
                     k_gemm_f32_sk128<<<dim3(grid.x, grid.y, (unsigned) ks), dim3(256), lds, st>>>(g);
                 } else

@@ -60,6 +60,36 @@ def causal_conv1d(c, x_ctb, w, b):
     return c.add(y, c.reshape(b, Cout, 1, 1)) if b is not None else y
 
 
+def causal_conv1d_chunk(c, x_ctb, cache_ctb, w, b, want_cache=True):
+    """Streaming form: x [C, dt, B] behind the cached K - 1 frames [C, K - 1, B] -> (y [Cout, dt, B], new cache [C, K - 1, B]);
+    fmCausalConv1d::build_forward_chunk_graph (token2wav-impl.cpp:925-1000), node for node with a cache given: the cache and x transposed
+    to [T, C, B] copies, CONCAT on the time axis + CONT, per batch element VIEW -> IM2COL(F32) -> MUL_MAT, CONCAT over the batch,
+    PERMUTE + CONT back, ADD of the bias; the new cache is the tail of CONT(CONCAT(cache, x) on dim 1).  The plug-in runs the y branch
+    as one dense concat + one any-shape GEMM over overlapping rows (graph_exec.cpp exec_causal_conv)."""
+    K, Cin, Cout = w.ne[0], w.ne[1], w.ne[2]
+    dt, B = x_ctb.ne[1], x_ctb.ne[2]
+    cache_in = c.cont(cache_ctb)
+    cache_tcb = c.cont(c.permute(cache_in, 1, 0, 2, 3))
+    x_tcb = c.cont(c.permute(x_ctb, 1, 0, 2, 3))
+    x_cat = c.cont(c.concat(cache_tcb, x_tcb, 0))
+    y_tcb = None
+    for bi in range(B):
+        xb = c.view_3d(x_cat, x_cat.ne[0], x_cat.ne[1], 1, x_cat.nb[1], x_cat.nb[2], x_cat.nb[2] * bi)
+        col = c.im2col(w, xb, 1, 0, 0, 0, 1, 0, False, GGML_TYPE_F32)
+        mm = c.mul_mat(c.reshape(col, col.ne[0], col.ne[2] * col.ne[1]), c.reshape(w, K * Cin, Cout))
+        yb = c.reshape(mm, col.ne[1], Cout, col.ne[2])
+        y_tcb = yb if y_tcb is None else c.concat(y_tcb, yb, 2)
+    y = c.cont(c.permute(y_tcb, 1, 0, 2, 3))
+    if b is not None:
+        y = c.add(y, c.reshape(b, Cout, 1, 1))
+    new_cache = None
+    if want_cache:
+        x_cont = x_ctb if x_ctb.t.op in (0, 35) else c.cont(x_ctb)      # (NONE / RESHAPE are taken as they are)
+        cat = c.cont(c.concat(cache_in, x_cont, 1))
+        new_cache = c.cont(c.view_3d(cat, Cin, K - 1, B, cat.nb[1], cat.nb[2], cat.nb[1] * dt))
+    return y, new_cache
+
+
 def dit_weights(c, hp):
     E, D, M = hp["hidden"], hp["head_dim"], hp["mlp"]
     f = GGML_TYPE_F32

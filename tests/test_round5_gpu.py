@@ -232,3 +232,107 @@ def test_8b_512_token_prompt_then_128_greedy_ids_identical_through_libllama(tmp_
             print(f"fa={fa}: 512-token prompt + {n}/{n} greedy ids identical (default and prefill_q8k)")
     finally:
         os.remove(gguf)
+
+
+# ------------------------------------------------------------------------------------------------ Token2Wav: the streaming causal convolution as one concat + one GEMM
+@pytest.mark.parametrize("C,Cout,KW,T,B", [(512, 512, 3, 56, 2), (512, 512, 3, 28, 1), (64, 96, 3, 7, 2), (128, 256, 5, 100, 2), (256, 512, 2, 1, 2)])
+def test_t2w_streaming_causal_conv_fused_vs_reference_backend(pkg, be, ref_be, C, Cout, KW, T, B):
+    """fmCausalConv1d::build_forward_chunk_graph node for node (llama.cpp-omni_amd/token2wav.py causal_conv1d_chunk; the flow-matching DiT
+    runs it 320 times per window at C = Cout = 512, KW = 3, 56 frames, batch 2): the reference CPU backend on the same graph is the check,
+    for y and for the new cache; the launch count shows the 11-launch y branch ran as two (exec_causal_conv), and with the fusions off
+    the plug-in gives the node-by-node result."""
+    from llama_cpp_omni_amd import token2wav as T2
+    F32 = pkg.GGML_TYPE_F32
+    P = KW - 1
+    rng = np.random.default_rng(C + Cout + T)
+    wv = (rng.standard_normal((Cout, C, KW)) / np.sqrt(C * KW)).astype(np.float32)
+    bv = rng.standard_normal(Cout).astype(np.float32)
+    xv = rng.standard_normal((B, T, C)).astype(np.float32)
+    cv = rng.standard_normal((B, P, 2 * C)).astype(np.float32)
+
+    def run(backend, fusion):
+        if backend is be:
+            backend.set_option("fusion", fusion)
+        c = pkg.Context(backend)
+        w = c.new_tensor(F32, KW, C, Cout); b = c.new_tensor(F32, Cout)
+        x_in = c.new_tensor(F32, C, T, B); packed = c.new_tensor(F32, 2 * C, P, B)
+        x = c.scale(x_in, 1.0)
+        cache = c.view_3d(packed, C, P, B, packed.nb[1], packed.nb[2], C * 4)          # (the reference keeps the layers' caches packed: a strided view)
+        y, nc = T2.causal_conv1d_chunk(c, x, cache, w, b)
+        act = c.unary(y, pkg.UNARY.TANH)                                                # a reader behind the bias ADD
+        c.alloc(usage=pkg.GGML_BACKEND_BUFFER_USAGE_WEIGHTS)
+        for t, v in ((w, wv), (b, bv), (x_in, xv), (packed, cv)):
+            backend.tensor_set(t, v)
+        g = c.graph()
+        backend.graph_compute(g)
+        k = backend.get_stat("kernels_last_graph") if backend is be else 0
+        res = [backend.tensor_get(o).copy() for o in (y, nc, act)]
+        if backend is be:                                                               # second submission (the resident kernel rows exist now)
+            backend.tensor_set(x_in, xv * 0.5)
+            backend.graph_compute(g)
+            k = backend.get_stat("kernels_last_graph")
+            half = backend.tensor_get(y).copy()
+            res.append(half)
+            backend.set_option("fusion", 1)
+        c.free()
+        return res, k
+
+    want, _ = run(ref_be, 1)
+    got, k_fused = run(be, 1)
+    plain, k_plain = run(be, 0)
+    ref = _causal_conv_f64(cv[:, :, C:], xv, wv, bv)
+    for name, r in (("fused", got), ("node by node", plain)):
+        e_ref, e_np = nmse(r[0], want[0]), nmse(r[0].reshape(B, T, Cout), ref)
+        print(name, "y NMSE vs the reference backend", e_ref, "vs float64", e_np)
+        assert e_ref < 1e-10 and e_np < 1e-10, (name, e_ref, e_np)
+        assert np.array_equal(r[1], want[1]), "new cache frames differ"
+        assert nmse(r[2], want[2]) < 1e-10
+    assert nmse(got[3].reshape(B, T, Cout), _causal_conv_f64(cv[:, :, C:], xv * np.float32(0.5), wv, bv)) < 1e-10, "second submission (resident kernel rows)"
+    print("launches: fused", k_fused, "node by node", k_plain)
+    assert k_plain - k_fused >= 3 + 2 * B, (k_fused, k_plain)
+
+
+def _causal_conv_f64(cache, x, w, bias):
+    """y[b, t, co] = bias[co] + sum_{c, k} w[co, c, k] * (cache ++ x)[b, t + k, c] in float64"""
+    KW, T = w.shape[2], x.shape[1]
+    xcat = np.concatenate([cache, x], axis=1).astype(np.float64)
+    y = np.zeros((x.shape[0], T, w.shape[0]))
+    for k in range(KW):
+        y += np.einsum("btc,oc->bto", xcat[:, k:k + T, :], w[:, :, k].astype(np.float64))
+    return y + bias
+
+
+@pytest.mark.parametrize("C,T,B", [(512, 56, 2), (64, 5, 3)])
+def test_t2w_modulate_chain_with_per_batch_rows_vs_reference_backend(pkg, be, ref_be, C, T, B):
+    """The DiT's modulation and gating with batch 2 (token2wav-impl.cpp:1121-1164, 1451-1487): shift / scale / gate are [C, 1, B] strided views of the adaLN product
+    [9C, 1, B], broadcast over the frames of their batch element -- norm * scale + norm + shift, then x + gate * y.  One k_ew_chain launch per chain on the plug-in
+    (operand mode 3); element-wise f32, so the reference CPU backend's values bit for bit."""
+    F32 = pkg.GGML_TYPE_F32
+    rng = np.random.default_rng(C + T)
+    xv = rng.standard_normal((B, T, C)).astype(np.float32)
+    av = rng.standard_normal((B, 1, 9 * C)).astype(np.float32)
+
+    def run(backend):
+        c = pkg.Context(backend)
+        x = c.new_tensor(F32, C, T, B); ada = c.new_tensor(F32, 9 * C, 1, B)
+        chunk = lambda k: c.view_3d(ada, C, 1, B, ada.nb[1], ada.nb[2], k * C * 4)
+        h = c.norm(x, 1e-5)
+        m = c.add(c.add(h, c.mul(h, chunk(1))), chunk(0))                # modulate(norm, shift, scale)
+        g = c.add(x, c.mul(m, chunk(2)))                                 # residual + gate * branch
+        m.t.flags |= 2                                                   # GGML_TENSOR_FLAG_OUTPUT (ggml_set_output): read back below, so the chain must end at it
+        c.alloc()
+        backend.tensor_set(x, xv); backend.tensor_set(ada, av)
+        backend.graph_compute(c.graph())
+        k = backend.get_stat("kernels_last_graph") if backend is be else 0
+        res = [backend.tensor_get(o).copy() for o in (m, g)]
+        c.free()
+        return res, k
+
+    want, _ = run(ref_be)
+    got, k = run(be)
+    assert nmse(got[0], want[0]) < 1e-12 and nmse(got[1], want[1]) < 1e-12
+    h = (xv - xv.mean(-1, keepdims=True)) / np.sqrt(xv.var(-1, keepdims=True) + 1e-5)
+    m = h * av[:, :, C:2 * C] + h + av[:, :, :C]
+    assert nmse(got[1].reshape(B, T, C), xv + m * av[:, :, 2 * C:3 * C]) < 1e-10
+    print("launches", k)
+    assert k <= 3, k                                                     # NORM, modulate chain, gate chain
