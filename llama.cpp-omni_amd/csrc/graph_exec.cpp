@@ -1562,6 +1562,80 @@ static bool exec_rms_norm(exec_state & s, int i) {
 // the [n_kv, n_q, H] blocks -- 146 MB written and read back per Whisper layer -- are never materialised).  An f32 mask is cast to f16 once per graph run (what the
 // reference's own flash-attention graphs do, llama-graph.cpp build_attn_inp_kv: ggml_cast(kq_mask, F16); 0 and -inf are exact) behind the mask tile map in the attention scratch.
 static size_t attn_sm_mask16_off(int64_t nq, int64_t nkv) { return (fattn_map_bytes_host(nq, nkv) + 255) & ~(size_t) 255; }
+// K.Q -> [SCALE] -> SOFT_MAX (no mask) -> V^T.P -> [views -> CONT of the [D, H, nq, ns] permutation], everything f32 and nothing else in between: one attn_f32 launch
+// (the reference's Token2Wav DiT attention, token2wav-impl.cpp:406-439).  `i` is the K.Q MUL_MAT.
+static bool exec_attn_f32(exec_state & s, int i) {
+    ggml_cgraph * g = s.g;
+    static const bool dbg = getenv("MI355X_SINK_DEBUG") != nullptr;          // which line turned an f32 x f32 batched MUL_MAT down, tallied (stderr at process exit)
+    static std::map<int, long> why;
+    struct dump { ~dump() { if (dbg) { fprintf(stderr, "[mi355x] attn_f32: taken %ld, refusals by source line:", why[0]); for (auto & kv : why) if (kv.first) fprintf(stderr, " %d:%ld", kv.first, kv.second); fprintf(stderr, "\n"); } } };
+    static dump at_exit;
+    auto no = [&](int line) { if (dbg) ++why[line]; return false; };
+    const ggml_tensor * M1 = g->nodes[i];
+    if (!s.c->opt_fusion || M1->op != GGML_OP_MUL_MAT || is_out(s, M1)) return false;
+    const ggml_tensor * fk = M1->src[0], * fq = M1->src[1];
+    if (fk->type != GGML_TYPE_F32 || fq->type != GGML_TYPE_F32 || M1->type != GGML_TYPE_F32 || fk->nb[0] != 4 || fq->nb[0] != 4 || fk->ne[3] != 1 || fq->ne[3] != 1 || !fk->data || !fq->data) return false;
+    const int64_t D = fk->ne[0], nkv = fk->ne[1], HB = fk->ne[2], nq = fq->ne[1];
+    if (fq->ne[0] != D || fq->ne[2] != HB || nq <= MI_MMVQ_MAX_COLS || !is_contiguous(M1)) return no(__LINE__);
+    int u = sole_user(s, M1);
+    if (u <= i || s.done[u]) return no(__LINE__);
+    const ggml_tensor * SC = nullptr, * prev = M1; int sci = -1;
+    if (g->nodes[u]->op == GGML_OP_SCALE) {
+        SC = g->nodes[u]; sci = u;
+        if (SC->src[0] != M1 || !same_shape(SC, M1) || SC->type != GGML_TYPE_F32 || is_out(s, SC)) return no(__LINE__);
+        prev = SC; u = sole_user(s, SC);
+        if (u <= sci || s.done[u]) return no(__LINE__);
+    }
+    const int smi = u;
+    const ggml_tensor * SM = g->nodes[smi];
+    if (SM->op != GGML_OP_SOFT_MAX || SM->src[0] != prev || SM->src[1] || SM->src[2] || op_param_f32(SM, 1) != 0.0f || !same_shape(SM, M1) || SM->type != GGML_TYPE_F32 || is_out(s, SM)) return no(__LINE__);
+    const int m2 = sole_user(s, SM);
+    if (m2 <= smi || s.done[m2]) return no(__LINE__);
+    const ggml_tensor * M2 = g->nodes[m2];
+    if (M2->op != GGML_OP_MUL_MAT || M2->src[1] != SM || M2->type != GGML_TYPE_F32 || !is_contiguous(M2)) return no(__LINE__);
+    const ggml_tensor * fv = M2->src[0];
+    if (fv->type != GGML_TYPE_F32 || fv->ne[0] != nkv || fv->ne[1] != D || fv->ne[2] != HB || fv->ne[3] != 1 || fv->nb[0] != 4 || !fv->data) return no(__LINE__);
+    if (M2->ne[0] != D || M2->ne[1] != nq || M2->ne[2] != HB || M2->ne[3] != 1) return no(__LINE__);
+    attn_f32_args a;
+    a.q = fq->data; a.q_rs = fq->nb[1]; a.q_bs = fq->nb[2]; a.k = fk->data; a.k_rs = fk->nb[1]; a.k_bs = fk->nb[2]; a.vt = fv->data; a.v_rs = fv->nb[1]; a.v_bs = fv->nb[2];
+    a.D = D; a.nq = nq; a.nkv = nkv; a.HB = HB;
+    a.has_scale = SC != nullptr; if (SC) { a.s1 = op_param_f32(SC, 0); a.b1 = op_param_f32(SC, 1); } a.s2 = op_param_f32(SM, 0);
+    // the result as it is, or through views into the CONT of its [D, H, nq, ns] permutation
+    const ggml_tensor * out = M2; int ci = -1;
+    a.dst = M2->data; a.d_nb_q = M2->nb[1]; a.d_nb_h = M2->nb[2]; a.d_nb_s = 0; a.H = HB;
+    if (!is_out(s, M2)) {
+        auto views_back_to = [](const ggml_tensor * w, const ggml_tensor * t) { while (w && w != t) w = (w->op == GGML_OP_RESHAPE || w->op == GGML_OP_VIEW || w->op == GGML_OP_PERMUTE || w->op == GGML_OP_TRANSPOSE) ? w->src[0] : nullptr; return w != nullptr; };
+        const int cu = sole_user(s, M2);
+        if (cu > m2 && !s.done[cu] && g->nodes[cu]->op == GGML_OP_CONT && next_real_node(s, m2) == cu) {
+            const ggml_tensor * C = g->nodes[cu], * cs = C->src[0];
+            const int64_t H = cs->ne[1], ns = cs->ne[3];
+            if (views_back_to(cs, M2) && C->type == GGML_TYPE_F32 && is_contiguous(C) && !C->view_src && C->data && cs->data == M2->data && cs->ne[0] == D && cs->ne[2] == nq && H * ns == HB &&
+                cs->nb[0] == 4 && cs->nb[1] == M2->nb[2] && cs->nb[2] == M2->nb[1] && (ns == 1 || cs->nb[3] == (size_t) H * M2->nb[2])) {
+                bool inner_ok = true;
+                for (const ggml_tensor * w = cs; w != M2; w = w->src[0]) if (is_out(s, w)) inner_ok = false;
+                if (inner_ok) { out = C; ci = cu; a.dst = C->data; a.d_nb_h = C->nb[1]; a.d_nb_q = C->nb[2]; a.d_nb_s = C->nb[3]; a.H = H; }
+            }
+        }
+    }
+    const int last = ci >= 0 ? ci : m2;
+    for (int k = i + 1; k < last; ++k)
+        if (k != sci && k != smi && k != m2 && !s.done[k] && !is_noop(g->nodes[k])) return no(__LINE__);       // something else runs in between: keep the separate launches
+    if (!attn_f32_ok(a)) return no(__LINE__);
+    // the result is written while other workgroups still read the operands: its buffer (placed by ggml-alloc for a later point of the graph) must not sit on them
+    if (overlap(range_of(out), range_of(fq)) || overlap(range_of(out), range_of(fk)) || overlap(range_of(out), range_of(fv))) return no(__LINE__);
+    if (s.pr.A) materialise_reduce(s);
+    if (s.prm.n) materialise_group(s);
+    if (s.pn.m && (s.pn.m == fq || s.pn.m == fk || s.pn.m == fv)) materialise_norm(s);
+    {
+        prof_scope ps(s, "attn_f32", 4.0 * (double) D * (double) nq * (double) nkv * (double) HB);
+        attn_f32(a, s.st); ++s.n_kernels;
+    }
+    for (int k : { sci, smi, m2, ci }) if (k >= 0) { s.done[k] = 1; ++s.n_fused; }
+    note_write(s, out);
+    if (dbg) ++why[0];
+    return true;
+}
+
 static bool exec_attn_sm_prefill(exec_state & s, int i, bool dry) {       // dry: would this MUL_MAT be taken?  (no launches, no state)
     static const bool off = getenv("MI355X_NO_ATTN_SM_PREFILL") != nullptr;
     ggml_cgraph * g = s.g;
@@ -1739,6 +1813,7 @@ static void compute_node(exec_state & s, int i) {
                 return;
             }
             if (exec_attn_sm_prefill(s, i, false)) return;
+            if (exec_attn_f32(s, i)) return;
             if (s.va.cast && (n->src[0] == s.va.cast || g->nodes[i]->src[1]->op == GGML_OP_SOFT_MAX)) materialise_vt(s);
             exec_mul_mat(s, i);
             return;
@@ -2355,6 +2430,57 @@ static bool exec_causal_conv(exec_state & s, int i) {
     return true;
 }
 
+// The new cache of a streaming causal convolution (fmCausalConv1d::build_forward_chunk_graph, token2wav-impl.cpp:977-994): CONT(x) -> CONCAT(cache, x) on the frame
+// axis -> CONT -> CONT(VIEW of the last K - 1 frames) -- four launches over [C, dt + K - 1, B] to keep K - 1 frames, 320 times per window.  When the kept frames all
+// come from x (dt >= K - 1) they are copied from x and the three other nodes are not run.  `i` is the CONT of x, or the CONCAT when x goes in as it is.
+static bool exec_concat_tail(exec_state & s, int i) {
+    static const bool off = getenv("MI355X_NO_CONCAT_TAIL") != nullptr;
+    if (off || !s.c->opt_fusion) return false;
+    ggml_cgraph * g = s.g;
+    auto plain = [](const ggml_tensor * t) { return t && t->type == GGML_TYPE_F32 && t->data && is_contiguous(t) && t->ne[3] == 1; };
+    const ggml_tensor * n = g->nodes[i];
+    const ggml_tensor * n0 = nullptr, * x = nullptr; int j1 = i;
+    if (n->op == GGML_OP_CONT) {
+        n0 = n; x = n->src[0];
+        if (!plain(n0) || n0->view_src || !plain(x) || !same_shape(x, n0) || is_out(s, n0)) return false;
+        j1 = sole_user(s, n0);
+        if (j1 <= i || next_real_node(s, i) != j1) return false;
+    } else if (n->op != GGML_OP_CONCAT) return false;
+    const ggml_tensor * n1 = g->nodes[j1];
+    if (n1->op != GGML_OP_CONCAT || op_param_i32(n1, 0) != 1 || !plain(n1) || is_out(s, n1)) return false;
+    if (n0) { if (n1->src[1] != n0) return false; } else { x = n1->src[1]; if (!plain(x)) return false; }
+    const ggml_tensor * cache = n1->src[0];
+    if (!cache || cache->ne[0] != x->ne[0] || cache->ne[2] != x->ne[2] || cache->ne[3] != 1) return false;
+    const int64_t P = cache->ne[1], dt = x->ne[1];
+    const int j2 = sole_user(s, n1);
+    if (j2 <= j1 || next_real_node(s, j1) != j2) return false;
+    const ggml_tensor * n2 = g->nodes[j2];
+    if (n2->op != GGML_OP_CONT || n2->src[0] != n1 || !plain(n2) || n2->view_src || !same_shape(n2, n1) || is_out(s, n2)) return false;
+    const int j3 = sole_user(s, n2);
+    if (j3 <= j2 || next_real_node(s, j2) != j3) return false;
+    const ggml_tensor * n3 = g->nodes[j3];
+    const ggml_tensor * v = n3->src[0];
+    if (n3->op != GGML_OP_CONT || !plain(n3) || n3->view_src || !v || v->op != GGML_OP_VIEW || v->view_src != n2 || v->type != GGML_TYPE_F32 || is_out(s, v)) return false;
+    if (v->ne[0] != n2->ne[0] || v->ne[2] != n2->ne[2] || v->ne[3] != 1 || v->nb[0] != 4 || v->nb[1] != n2->nb[1] || v->nb[2] != n2->nb[2] || !same_shape(n3, v)) return false;
+    const size_t off_b = (size_t) ((const char *) v->data - (const char *) n2->data);
+    if (off_b % n2->nb[1] != 0) return false;
+    const int64_t f0 = (int64_t) (off_b / n2->nb[1]), keep = v->ne[1];
+    if (f0 < P || f0 + keep > P + dt) return false;                                 // (kept frames that reach into the old cache: the nodes run as they are)
+    if (overlap(range_of(n3), range_of(x))) return false;                           // the copy's buffer was placed for a point of the graph where x may be dead
+    if (s.pr.A) materialise_reduce(s);
+    if (s.prm.n) materialise_group(s);
+    if (s.pn.m && s.pn.m == x) materialise_norm(s);
+    {
+        prof_scope ps(s, "cpy", 0);
+        tdesc src = td(x);
+        src.p = (char *) x->data + (size_t) (f0 - P) * x->nb[1]; src.ne[1] = keep;
+        cpy_strided(src, GGML_TYPE_F32, td(n3), GGML_TYPE_F32, s.st); ++s.n_kernels;
+    }
+    note_write(s, n3);
+    for (int k : { n0 ? j1 : -1, j2, j3 }) if (k >= 0) { s.done[k] = 1; ++s.n_fused; }
+    return true;
+}
+
 void run_nodes(exec_state & s, ggml_cgraph * g) {
     static FILE * const launch_log = getenv("MI355X_LAUNCH_LOG") ? fopen(getenv("MI355X_LAUNCH_LOG"), "w") : nullptr;      // one line per node that launched: what a graph's launches are made of (tools/launch_ngrams.py)
     s.g = g;
@@ -2425,6 +2551,7 @@ void run_nodes(exec_state & s, ggml_cgraph * g) {
             fprintf(launch_log, "\n");
         } } ll_g{ s, g, i, s.n_kernels, s.n_fused };
         if (g->nodes[i]->op == GGML_OP_CONT && exec_causal_conv(s, i)) continue;
+        if ((g->nodes[i]->op == GGML_OP_CONT || g->nodes[i]->op == GGML_OP_CONCAT) && exec_concat_tail(s, i)) continue;
         {
             int taken[8];
             const int nt = is_noop(g->nodes[i]) ? 0 : exec_ew_chain(s, i, taken);

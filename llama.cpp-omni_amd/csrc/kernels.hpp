@@ -328,6 +328,16 @@ struct gemm_any_args {
     float * partial = nullptr; size_t partial_bytes = 0; unsigned * counters = nullptr; int n_counters = 0;
 };
 void   gemm_any(const gemm_any_args & a, hipStream_t st);
+// attention as separate f32 nodes over a few hundred keys, one launch (attn_f32.hip): Q [D, nq, HB], K [D, nkv, HB], V^T [nkv, D, HB] f32 with K-contiguous rows;
+// scores x * s1 + b1 (the SCALE node, when has_scale) then * s2 (the soft-max's scale), soft-max, . V; element (d, q, h, s) of the result (head-batch = h + H * s) through the strides
+struct attn_f32_args {
+    const void * q, * k, * vt; void * dst;
+    size_t q_rs, q_bs, k_rs, k_bs, v_rs, v_bs, d_nb_q, d_nb_h, d_nb_s;
+    int64_t D, nq, nkv, HB, H;
+    float s1 = 1.0f, b1 = 0.0f, s2 = 1.0f; bool has_scale = false;
+};
+bool   attn_f32_ok(const attn_f32_args & a);
+void   attn_f32(const attn_f32_args & a, hipStream_t st);
 size_t gemm_any_split_scratch_bytes(int64_t M, int64_t N, int64_t K, int nbatch, bool f32_operands);      // what the split above needs for this shape (0: it would not split)
 
 } // namespace mi

@@ -336,3 +336,47 @@ def test_t2w_modulate_chain_with_per_batch_rows_vs_reference_backend(pkg, be, re
     assert nmse(got[1].reshape(B, T, C), xv + m * av[:, :, 2 * C:3 * C]) < 1e-10
     print("launches", k)
     assert k <= 3, k                                                     # NORM, modulate chain, gate chain
+
+
+@pytest.mark.parametrize("nq,nkv,H,ns,scale_node,cont", [(50, 200, 8, 2, True, True), (56, 206, 8, 2, True, True), (17, 36, 3, 1, False, True), (33, 64, 2, 2, True, False), (9, 5, 1, 1, True, True), (20, 1030, 2, 1, True, True)])
+def test_t2w_f32_attention_chain_in_one_launch_vs_reference_backend(pkg, be, ref_be, nq, nkv, H, ns, scale_node, cont):
+    """K.Q -> SCALE -> SOFT_MAX -> V^T.P -> RESHAPE / PERMUTE -> CONT, all f32, head size 64 (the Token2Wav DiT attention, token2wav-impl.cpp:406-439: 50..56 frames
+    against 200..206 keys, 8 heads x batch 2): one attn_f32 launch on the plug-in, the reference CPU backend on the same graph is the check (f32 products and sums on
+    both sides, another summation order: NMSE 1e-10)."""
+    F32 = pkg.GGML_TYPE_F32
+    D, HB = 64, H * ns
+    rng = np.random.default_rng(nq * 7 + nkv)
+    qv = rng.standard_normal((HB, nq, D)).astype(np.float32)
+    kv = rng.standard_normal((HB, nkv, D)).astype(np.float32)
+    vv = rng.standard_normal((HB, D, nkv)).astype(np.float32)
+    sc = 1.0 / np.sqrt(D)
+
+    def run(backend):
+        c = pkg.Context(backend)
+        q = c.new_tensor(F32, D, nq, HB); k = c.new_tensor(F32, D, nkv, HB); vt = c.new_tensor(F32, nkv, D, HB)
+        kq = c.mul_mat(k, q)
+        if scale_node:
+            kq = c.scale(kq, float(sc))
+        p = c.soft_max_ext(kq, None, 1.0 if scale_node else float(sc))
+        o = c.mul_mat(vt, p)                                               # [D, nq, HB]
+        out = c.cont(c.permute(c.reshape(o, D, nq, H, ns), 0, 2, 1, 3)) if cont else o
+        out.t.flags |= 2
+        c.alloc()
+        for t, v in ((q, qv), (k, kv), (vt, vv)):
+            backend.tensor_set(t, v)
+        backend.graph_compute(c.graph())
+        n = backend.get_stat("kernels_last_graph") if backend is be else 0
+        r = backend.tensor_get(out).copy()
+        c.free()
+        return r, n
+
+    want, _ = run(ref_be)
+    got, n = run(be)
+    s = np.einsum("bqd,bkd->bqk", qv.astype(np.float64), kv.astype(np.float64)) * sc
+    p = np.exp(s - s.max(-1, keepdims=True)); p /= p.sum(-1, keepdims=True)
+    o = np.einsum("bqk,bdk->bqd", p, vv.astype(np.float64))                # [HB, nq, D]
+    ref = o.reshape(ns, H, nq, D).transpose(0, 2, 1, 3) if cont else o     # [ns, nq, H, D] = ggml [D, H, nq, ns]
+    e1, e2 = nmse(got, want), nmse(got.reshape(ref.shape), ref)
+    print("NMSE vs the reference backend", e1, "vs float64", e2, "launches", n)
+    assert e1 < 1e-10 and e2 < 1e-10, (e1, e2)
+    assert n == 1, n
