@@ -87,7 +87,9 @@ bool mm_takes_gemm_any(const ggml_tensor * n) {
            x->ne[2] * x->ne[3] <= 65535 && M < (1ll << 31) && N < (1ll << 31) && K < (1ll << 31);
 }
 // out / bias: the ADD of a [M] row vector behind the mat-mul, folded into the any-shape GEMM's epilogue (exec_mul_mat decides; only that path takes them)
-static void op_mul_mat(exec_state & s, const ggml_tensor * dst, const ggml_tensor * out = nullptr, const float * bias = nullptr) {
+// sib / nsib: up to two more F32-weight mat-muls over the same activation (same weight shape and strides) for the launch; *sib_taken tells whether they went along
+struct mm_sibling { const ggml_tensor * w; const ggml_tensor * out; const float * bias; };
+static void op_mul_mat(exec_state & s, const ggml_tensor * dst, const ggml_tensor * out = nullptr, const float * bias = nullptr, const mm_sibling * sib = nullptr, int nsib = 0, bool * sib_taken = nullptr) {
     const ggml_tensor * w = dst->src[0];
     const ggml_tensor * x = dst->src[1];
     if (!out) out = dst;
@@ -196,7 +198,15 @@ static void op_mul_mat(exec_state & s, const ggml_tensor * dst, const ggml_tenso
             else { (void) hipGetLastError(); s.c->fa_counters = nullptr; }
         }
         if (s.c->gemm_partial && s.c->fa_counters) { a.partial = (float *) s.c->gemm_partial; a.partial_bytes = s.c->gemm_partial_bytes; a.counters = s.c->fa_counters; a.n_counters = 1024; }
-        prof_scope ps(s, w->type == GGML_TYPE_F16 ? "gemm_any_f16" : "gemm_any_f32", 2.0 * (double) M * (double) N * (double) (K - k_done) * (double) (ne12 * ne13));
+        if (nsib > 0 && sib_taken) {
+            *sib_taken = false;
+            if (k_done == 0 && !x_img && w->type == GGML_TYPE_F32 && x->type == GGML_TYPE_F32) {
+                a.nmat = 1 + nsib;
+                for (int q = 0; q < nsib; ++q) { a.W_more[q] = sib[q].w->data; a.dst_more[q] = (float *) sib[q].out->data; a.bias_more[q] = sib[q].bias; }
+                if (gemm_any_group_ok(a)) *sib_taken = true; else a.nmat = 1;
+            }
+        }
+        prof_scope ps(s, w->type == GGML_TYPE_F16 ? "gemm_any_f16" : "gemm_any_f32", 2.0 * (double) M * (double) N * (double) (K - k_done) * (double) (ne12 * ne13) * (double) a.nmat);
         gemm_any(a, s.st);
         ++s.n_kernels;
         return;
@@ -751,9 +761,40 @@ static void exec_mul_mat(exec_state & s, int i) {
             // (ggml-alloc may have given the ADD's result the memory of the mat-mul's dead operands: the launch reads them while it writes the result)
             ok = ok && !overlap(range_of(A), range_of(n->src[0])) && !overlap(range_of(A), range_of(n->src[1])) && !overlap(range_of(A), range_of(r));
             if (ok) {
-                op_mul_mat(s, n, A, (const float *) r->data);
+                // the block's other projections of the same activation (q / k / v of a DiT block: F32 weights of one shape, each with its bias ADD behind it) join the launch
+                static const bool no_group = getenv("MI355X_NO_GEMM_ANY_GROUP") != nullptr;
+                mm_sibling sib[2]; int sib_mm[2], sib_add[2], nsib = 0;
+                int item[6] = { i, ai, -1, -1, -1, -1 }; int ni = 2;
+                const ggml_tensor * w0 = n->src[0], * x0 = n->src[1];
+                for (int j = ai + 1; !no_group && j < g->n_nodes && j < i + 40 && nsib < 2; ++j) {
+                    const ggml_tensor * c = g->nodes[j];
+                    if (s.done[j] || c->op != GGML_OP_MUL_MAT || c->src[1] != x0 || !mm_takes_gemm_any(c) || is_out(s, c)) continue;
+                    const ggml_tensor * wc = c->src[0];
+                    if (wc->type != GGML_TYPE_F32 || w0->type != GGML_TYPE_F32 || !wc->data || wc == w0) continue;
+                    bool same = true;
+                    for (int d = 0; d < 4; ++d) same = same && wc->ne[d] == w0->ne[d] && wc->nb[d] == w0->nb[d] && c->ne[d] == n->ne[d] && c->nb[d] == n->nb[d];
+                    if (!same) continue;
+                    const int aj = sole_user(s, c);
+                    if (aj <= j || next_real_node(s, j) != aj || g->nodes[aj]->op != GGML_OP_ADD) continue;
+                    const ggml_tensor * Aj = g->nodes[aj];
+                    const ggml_tensor * rj = Aj->src[0] == c ? Aj->src[1] : (Aj->src[1] == c ? Aj->src[0] : nullptr);
+                    bool okj = rj && rj != c && rj->type == GGML_TYPE_F32 && Aj->type == GGML_TYPE_F32 && rj->ne[0] == c->ne[0] && rj->ne[1] * rj->ne[2] * rj->ne[3] == 1 && rj->nb[0] == 4 && rj->data;
+                    for (int d = 0; okj && d < 4; ++d) okj = Aj->ne[d] == c->ne[d] && Aj->nb[d] == c->nb[d];
+                    okj = okj && !overlap(range_of(Aj), range_of(wc)) && !overlap(range_of(Aj), range_of(x0)) && !overlap(range_of(Aj), range_of(rj)) && !overlap(range_of(Aj), range_of(A)) &&
+                          !overlap(range_of(Aj), range_of(w0)) && !overlap(range_of(Aj), range_of(r));
+                    for (int q = 0; okj && q < nsib; ++q) okj = !overlap(range_of(Aj), range_of(sib[q].out)) && !overlap(range_of(Aj), range_of(sib[q].w));
+                    if (!okj) continue;
+                    int it2[6]; for (int q = 0; q < ni; ++q) it2[q] = item[q];
+                    it2[ni] = j; it2[ni + 1] = aj;
+                    if (!can_hoist(s, i, j, it2, ni + 2) || !can_hoist(s, i, aj, it2, ni + 2)) continue;
+                    item[ni++] = j; item[ni++] = aj;
+                    sib[nsib] = { wc, Aj, (const float *) rj->data }; sib_mm[nsib] = j; sib_add[nsib] = aj; ++nsib;
+                }
+                bool taken = false;
+                op_mul_mat(s, n, A, (const float *) r->data, sib, nsib, &taken);
                 s.done[ai] = 1; ++s.n_fused;
                 note_write(s, A);
+                if (taken) for (int q = 0; q < nsib; ++q) { s.done[sib_mm[q]] = 1; s.done[sib_add[q]] = 1; s.n_fused += 2; note_write(s, sib[q].out); }
                 return;
             }
         }
@@ -1007,6 +1048,44 @@ static void seed_act_f16(exec_state & s, const ggml_tensor * x, bool quantised) 
 // The encoders' LayerNorm: NORM -> MUL by the [n] weight -> ADD of the [n] bias (audition.cpp / vision.cpp build_norm), each the next launching node
 // and the only reader of the one before, on many rows: one launch of the wave-per-row kernel, which also emits the f16 image when only MFMA GEMMs
 // read the result (wq / wk / wv, fc1).  Same three f32 roundings as the separate ops.
+// LayerNorm -> MUL(n, scale) -> ADD(n, .) -> ADD(., shift) with scale / shift one row per dim-2 slice ([C, 1, B] views of the DiT's adaLN product, token2wav-impl.cpp:1121-1164):
+// the three element-wise nodes ride in the norm launch's epilogue, rounded as they round.  The norm has exactly these two readers.
+static bool exec_norm_modulate(exec_state & s, int i) {
+    static const bool off = getenv("MI355X_NO_NORM_FUSE") != nullptr;
+    ggml_cgraph * g = s.g;
+    const ggml_tensor * n = g->nodes[i];
+    if (off || !s.c->opt_fusion || is_out(s, n) || n->src[0]->type != GGML_TYPE_F32 || n->type != GGML_TYPE_F32 || !is_contiguous(n) || n->ne[3] != 1) return false;
+    auto it = s.users.find(n);
+    if (it == s.users.end() || it->second.size() != 2) return false;
+    const int mi_ = it->second[0], a1i = it->second[1];
+    if (mi_ <= i || next_real_node(s, i) != mi_ || a1i <= mi_ || next_real_node(s, mi_) != a1i) return false;
+    const ggml_tensor * m = g->nodes[mi_], * a1 = g->nodes[a1i];
+    auto row_vec = [&](const ggml_tensor * v) {              // one row of C floats per dim-2 slice (or one row altogether)
+        return v && v->type == GGML_TYPE_F32 && v->data && v->ne[0] == n->ne[0] && v->ne[1] == 1 && (v->ne[2] == n->ne[2] || v->ne[2] == 1) && v->ne[3] == 1 && v->nb[0] == 4 &&
+               v->nb[2] % 16 == 0 && ((uintptr_t) v->data & 15) == 0;
+    };
+    if (m->op != GGML_OP_MUL || m->src[0] != n || !row_vec(m->src[1]) || !same_shape(m, n) || !is_contiguous(m) || is_out(s, m) || sole_user(s, m) != a1i) return false;
+    if (a1->op != GGML_OP_ADD || a1->src[0] != n || a1->src[1] != m || !same_shape(a1, n) || !is_contiguous(a1) || is_out(s, a1)) return false;
+    const int a2i = sole_user(s, a1);
+    if (a2i <= a1i || next_real_node(s, a1i) != a2i) return false;
+    const ggml_tensor * a2 = g->nodes[a2i];
+    if (a2->op != GGML_OP_ADD || a2->src[0] != a1 || !row_vec(a2->src[1]) || !same_shape(a2, n) || !is_contiguous(a2) || a2->type != GGML_TYPE_F32) return false;
+    const ggml_tensor * sv = m->src[1], * tv = a2->src[1];
+    if (!norm_rows_ok(td(n->src[0]), td(a2))) return false;
+    if (overlap(range_of(a2), range_of(sv)) || overlap(range_of(a2), range_of(tv)) || (overlap(range_of(a2), range_of(n->src[0])) && a2->data != n->src[0]->data)) return false;
+    if (s.pr.A) materialise_reduce(s);
+    if (s.prm.n) materialise_group(s);
+    {
+        prof_scope ps(s, "norm", 0);
+        norm_rows_f32(td(n->src[0]), td(a2), op_param_f32(n, 0), (const float *) sv->data, (const float *) tv->data, nullptr, 0, true, s.st,
+                      sv->ne[2] > 1 ? sv->nb[2] / 4 : 0, tv->ne[2] > 1 ? tv->nb[2] / 4 : 0, true);
+    }
+    ++s.n_kernels;
+    for (int k : { mi_, a1i, a2i }) { s.done[k] = 1; ++s.n_fused; }
+    note_write(s, a2);
+    return true;
+}
+
 static bool exec_norm(exec_state & s, int i) {
     static const bool off = getenv("MI355X_NO_NORM_FUSE") != nullptr;
     ggml_cgraph * g = s.g;
@@ -1828,6 +1907,7 @@ static void compute_node(exec_state & s, int i) {
             break;
         }
         case GGML_OP_NORM: {
+            if (exec_norm_modulate(s, i)) return;
             if (exec_norm(s, i)) return;
             if (s.pr.A) materialise_reduce(s);
             prof_scope ps(s, "norm", 0);
@@ -2158,9 +2238,15 @@ static int cont_sink(exec_state & s, int i) {
     }
     if (sole_user(s, p) != j) return no(5);
     const char * lo = (const char *) c->data, * hi = lo + nbytes(c);
+    // (an element-wise producer may write over an operand of its own shape that sits at exactly the copy's address: every thread reads its element before it writes it)
+    const bool ew = p->op == GGML_OP_ADD || p->op == GGML_OP_SUB || p->op == GGML_OP_MUL || p->op == GGML_OP_DIV || p->op == GGML_OP_SCALE || p->op == GGML_OP_SQR || p->op == GGML_OP_SQRT ||
+                    p->op == GGML_OP_LOG || p->op == GGML_OP_SIN || p->op == GGML_OP_COS || p->op == GGML_OP_CLAMP || p->op == GGML_OP_LEAKY_RELU || p->op == GGML_OP_UNARY;
     for (int k = 0; k < GGML_MAX_SRC && p->src[k]; ++k) {
         const char * a = (const char *) p->src[k]->data, * b = a + nbytes(p->src[k]);
-        if (a < hi && lo < b) return no(6);
+        if (a < hi && lo < b) {
+            if (ew && a == lo && p->src[k]->type == p->type && same_shape(p->src[k], p) && is_contiguous(p->src[k])) continue;
+            return no(6);
+        }
     }
     if (dbg) ++why[0];
     return j;

@@ -130,7 +130,7 @@ void pool_f32(const tdesc & x, int x_type, const tdesc & y, const int32_t * p, b
 // NORM (ops.cpp:3450-3495): y = (x - mean) / sqrt(var + eps) per row
 void norm_f32(const tdesc & x, const tdesc & y, float eps, hipStream_t st);
 bool norm_rows_ok(const tdesc & x, const tdesc & y);                      // many 16-byte aligned rows of at most 4096 elements: the wave-per-row kernel
-void norm_rows_f32(const tdesc & x, const tdesc & y, float eps, const float * w, const float * b, uint16_t * y16, size_t y16_rs, bool write_f32, hipStream_t st);   // + MUL w, ADD b, f16 image
+void norm_rows_f32(const tdesc & x, const tdesc & y, float eps, const float * w, const float * b, uint16_t * y16, size_t y16_rs, bool write_f32, hipStream_t st, size_t w_bs = 0, size_t b_bs = 0, bool mod = false);   // + MUL w, ADD b, f16 image
 long norm_from_split_launches();
 bool norm_rows_from_split_ok(const tdesc & x, const tdesc & y, int nsplit, size_t resid_cs, size_t resid2_cs, const void * resid, const void * resid2, const void * part);
 void norm_rows_from_split(const tdesc & x, const tdesc & y, float eps, const float * w, const float * b, uint16_t * y16, size_t y16_rs, bool write_f32,
@@ -326,8 +326,11 @@ struct gemm_any_args {
     // optional, for small f32 x f32 products with a long K: split K over workgroups too; partial tiles go to `partial`, the last workgroup of a tile to arrive (ticket in
     // `counters`, zero between launches) folds them in split order.  Both belong to the calling backend context (one stream: launches do not overlap).
     float * partial = nullptr; size_t partial_bytes = 0; unsigned * counters = nullptr; int n_counters = 0;
+    // up to two more products over the same X with weights of the same shape and strides (a DiT block's q / k / v projections) in the launch: gemm_any_group_ok() first
+    int nmat = 1; const void * W_more[2] = { nullptr, nullptr }; float * dst_more[2] = { nullptr, nullptr }; const float * bias_more[2] = { nullptr, nullptr };
 };
 void   gemm_any(const gemm_any_args & a, hipStream_t st);
+bool   gemm_any_group_ok(const gemm_any_args & a);       // would gemm_any take a.nmat > 1 (the 16 x 16-tile f32 kernel's shapes)?
 // attention as separate f32 nodes over a few hundred keys, one launch (attn_f32.hip): Q [D, nq, HB], K [D, nkv, HB], V^T [nkv, D, HB] f32 with K-contiguous rows;
 // scores x * s1 + b1 (the SCALE node, when has_scale) then * s2 (the soft-max's scale), soft-max, . V; element (d, q, h, s) of the result (head-batch = h + H * s) through the strides
 struct attn_f32_args {

@@ -403,7 +403,9 @@ __global__ void __launch_bounds__(1024) k_norm(td4 x, td4 y, float eps) {
 // sp.part != null: the row does not lie in memory yet -- it is the sum of `nsplit` split-K slabs of the GEMM in front (dense [rows][n] blocks, `split_elems` floats apart) plus up
 // to two addends (a bias row with stride 0, the residual), added in k_gemm_reduce_multi's order (slab 0 + slab 1 + ... + addend 1 + addend 2), written to x (the ADD's result,
 // the next residual) and normalised from the registers: the reduction launch between a split mat-mul and the LayerNorm behind it (wo / fc2 of an encoder layer) is gone
-struct norm_split_src { const float * part; int nsplit; size_t split_elems; const char * resid; size_t resid_cs; const char * resid2; size_t resid2_cs; };
+// w_bs / b_bs: the vectors of dim-2 slice i2 start w_bs / b_bs floats further on (0: one vector for all rows); mod: the result is (n * w + n) + b -- the Token2Wav DiT's
+// modulation MUL(n, scale) -> ADD(n, .) -> ADD(., shift) with per-batch-element scale / shift rows, rounded as the three nodes round
+struct norm_split_src { const float * part; int nsplit; size_t split_elems; const char * resid; size_t resid_cs; const char * resid2; size_t resid2_cs; size_t w_bs = 0, b_bs = 0; int mod = 0; };
 template <int MAXV>
 __global__ void __launch_bounds__(256) k_norm_rows(td4 x, td4 y, float eps, int64_t nrows, const float * __restrict__ w, const float * __restrict__ b, char * __restrict__ y16, int64_t y16_rs,
                                                    const norm_split_src sp) {
@@ -491,11 +493,11 @@ __global__ void __launch_bounds__(256) k_norm_rows(td4 x, td4 y, float eps, int6
         f32x4 o;
 #pragma unroll
         for (int e = 0; e < 4; ++e) o[e] = v[k][e] * scale;
-        if (w) { const f32x4 ww = *(const f32x4 *) (w + i);
+        if (w) { const f32x4 ww = *(const f32x4 *) (w + (size_t) i2 * sp.w_bs + i);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = __fmul_rn(o[e], ww[e]);
+            for (int e = 0; e < 4; ++e) { const float t = __fmul_rn(o[e], ww[e]); o[e] = sp.mod ? __fadd_rn(o[e], t) : t; }
         }
-        if (b) { const f32x4 bb = *(const f32x4 *) (b + i);
+        if (b) { const f32x4 bb = *(const f32x4 *) (b + (size_t) i2 * sp.b_bs + i);
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] = __fadd_rn(o[e], bb[e]);
         }
@@ -510,12 +512,13 @@ bool norm_rows_ok(const tdesc & x, const tdesc & y) {
     return nrows >= 2 && n > 0 && n % 4 == 0 && n <= 4096 && al16(x) && al16(y);
 }
 // LayerNorm rows with the following MUL (w) / ADD (b) by [n] vectors folded in and, optionally, the f16 image of the result (write_f32 false: only that)
-void norm_rows_f32(const tdesc & x, const tdesc & y, float eps, const float * w, const float * b, uint16_t * y16, size_t y16_rs, bool write_f32, hipStream_t st) {
+void norm_rows_f32(const tdesc & x, const tdesc & y, float eps, const float * w, const float * b, uint16_t * y16, size_t y16_rs, bool write_f32, hipStream_t st, size_t w_bs, size_t b_bs, bool mod) {
     const int64_t n = x.ne[0], nrows = x.ne[1] * x.ne[2] * x.ne[3];
     if (!norm_rows_ok(x, y) || ((uintptr_t) w & 15) || ((uintptr_t) b & 15) || (y16 && (y16_rs % 8 != 0 || ((uintptr_t) y16 & 7) != 0)) || (!write_f32 && !y16)) { fprintf(stderr, "[mi355x] norm_rows_f32: unsupported arguments\n"); abort(); }
     td4 yd = to_td4(y); if (!write_f32) yd.p = nullptr;
     const dim3 grid((unsigned) ((nrows + 3) / 4));
-    const norm_split_src sp = { nullptr, 0, 0, nullptr, 0, nullptr, 0 };
+    norm_split_src sp = { nullptr, 0, 0, nullptr, 0, nullptr, 0 };
+    sp.w_bs = w_bs; sp.b_bs = b_bs; sp.mod = mod ? 1 : 0;
     if (n <= 1024)      k_norm_rows<4><<<grid, dim3(256), 0, st>>>(to_td4(x), yd, eps, nrows, w, b, (char *) y16, (int64_t) y16_rs, sp);
     else if (n <= 2048) k_norm_rows<8><<<grid, dim3(256), 0, st>>>(to_td4(x), yd, eps, nrows, w, b, (char *) y16, (int64_t) y16_rs, sp);
     else                k_norm_rows<16><<<grid, dim3(256), 0, st>>>(to_td4(x), yd, eps, nrows, w, b, (char *) y16, (int64_t) y16_rs, sp);
@@ -534,7 +537,7 @@ void norm_rows_from_split(const tdesc & x, const tdesc & y, float eps, const flo
         (y16 && (y16_rs % 8 != 0 || ((uintptr_t) y16 & 7) != 0)) || (!write_f32 && !y16)) { fprintf(stderr, "[mi355x] norm_rows_from_split: unsupported arguments\n"); abort(); }
     td4 yd = to_td4(y); if (!write_f32) yd.p = nullptr;
     const dim3 grid((unsigned) ((nrows + 3) / 4));
-    const norm_split_src sp = { part, nsplit, split_elems, (const char *) resid, resid_cs, (const char *) resid2, resid2_cs };
+    norm_split_src sp = { part, nsplit, split_elems, (const char *) resid, resid_cs, (const char *) resid2, resid2_cs };
     ++g_norm_from_split_launches;
     if (n <= 1024)      k_norm_rows<4><<<grid, dim3(256), 0, st>>>(to_td4(x), yd, eps, nrows, w, b, (char *) y16, (int64_t) y16_rs, sp);
     else if (n <= 2048) k_norm_rows<8><<<grid, dim3(256), 0, st>>>(to_td4(x), yd, eps, nrows, w, b, (char *) y16, (int64_t) y16_rs, sp);

@@ -23,6 +23,7 @@ struct gemm_any_dev {
     const float * bias;
     int M, N, K, tiles_m, ne12, r2, r3, round_x, accumulate;      // round_x: 0 none, 1 activations rounded to f16, 2 to bf16 (and the 16-bit weights are bf16)
     float * partial; unsigned * counters; int ksplit;             // k_gemm_f32_sk128: K split over gridDim.z workgroups (1: none)
+    const char * W_more[2]; char * dst_more[2]; const float * bias_more[2];     // k_gemm_f32_t16: matrices 1, 2 of a grouped launch (blockIdx.z)
 };
 
 template <typename WT, typename XT>
@@ -404,7 +405,8 @@ __global__ void __launch_bounds__(256) k_gemm_f32_t16(const gemm_any_dev g) {
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int tm = (int) blockIdx.x % g.tiles_m, tn = (int) blockIdx.x / g.tiles_m;        // (tiles_m counts 16-row tiles)
     const int i12 = (int) blockIdx.y % g.ne12, i13 = (int) blockIdx.y / g.ne12;
-    const char * W = g.W + (size_t) (i12 / g.r2) * g.w_nb2 + (size_t) (i13 / g.r3) * g.w_nb3;
+    const int z = (int) blockIdx.z;                               // (grouped launch: which matrix)
+    const char * W = (z == 0 ? g.W : g.W_more[z - 1]) + (size_t) (i12 / g.r2) * g.w_nb2 + (size_t) (i13 / g.r3) * g.w_nb3;
     const char * X = g.X + (size_t) i12 * g.x_nb2 + (size_t) i13 * g.x_nb3;
     const int m0 = tm * 16, n0 = tn * 16, fr = lane & 31, kh = lane >> 5, r16 = lane & 15, gq = lane >> 4;
     const int chunk = ((g.K + 3) / 4 + 15) & ~15;                  // this wave's k range [k_lo, k_hi)
@@ -448,7 +450,8 @@ __global__ void __launch_bounds__(256) k_gemm_f32_t16(const gemm_any_dev g) {
     }
     __syncthreads();
     if (wave > 0) return;
-    char * dst = g.dst + (size_t) i12 * g.dst_nb2 + (size_t) i13 * g.dst_nb3;
+    char * dst = (z == 0 ? g.dst : g.dst_more[z - 1]) + (size_t) i12 * g.dst_nb2 + (size_t) i13 * g.dst_nb3;
+    const float * bias = z == 0 ? g.bias : g.bias_more[z - 1];
     const int m = m0 + r16;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -456,7 +459,7 @@ __global__ void __launch_bounds__(256) k_gemm_f32_t16(const gemm_any_dev g) {
         float v = acc[e];
 #pragma unroll
         for (int w = 0; w < 3; ++w) v += red[w * 256 + e * 64 + lane];
-        if (m < g.M && n < g.N) { float * p = (float *) (dst + (size_t) n * g.dst_cs + (size_t) m * 4); if (g.accumulate) v = *p + v; if (g.bias) v = __fadd_rn(v, g.bias[m]); *p = v; }
+        if (m < g.M && n < g.N) { float * p = (float *) (dst + (size_t) n * g.dst_cs + (size_t) m * 4); if (g.accumulate) v = *p + v; if (bias) v = __fadd_rn(v, bias[m]); *p = v; }
     }
 }
 
@@ -476,8 +479,20 @@ size_t gemm_any_split_scratch_bytes(int64_t M, int64_t N, int64_t K, int nbatch,
     return s > 1 ? (size_t) s * (size_t) (((M + 31) / 32) * ((N + 31) / 32) * nbatch) * 1024 * 4 : 0;
 }
 
+static bool gemm_any_t16_shape(const gemm_any_args & a) {
+    static const bool no_t16 = getenv("MI355X_NO_GEMM_F32_T16") != nullptr, no_sk = getenv("MI355X_GEMM_ANY_NO_SPLIT") != nullptr;
+    static const int64_t t16_max_tiles = getenv("MI355X_GEMM_T16_MAX_TILES") ? atoll(getenv("MI355X_GEMM_T16_MAX_TILES")) : 128;
+    return !no_t16 && !no_sk && !a.x_f16 && !a.w_f16 && !a.w_bf16 && a.K % 4 == 0 && a.K >= 64 && ((a.M + 31) / 32) * ((a.N + 31) / 32) * a.nbatch < t16_max_tiles && ((a.M + 15) / 16) * ((a.N + 15) / 16) <= 65535 &&
+           (((uintptr_t) a.W | a.w_rs | a.w_nb2 | a.w_nb3 | (uintptr_t) a.X | a.x_rs | a.x_nb2 | a.x_nb3) & 15) == 0;
+}
+bool gemm_any_group_ok(const gemm_any_args & a) {
+    if (a.nmat < 1 || a.nmat > 3 || !gemm_any_t16_shape(a) || a.accumulate) return false;
+    for (int q = 1; q < a.nmat; ++q) if (!a.W_more[q - 1] || !a.dst_more[q - 1] || ((uintptr_t) a.W_more[q - 1] & 15) != 0) return false;
+    return true;
+}
 void gemm_any(const gemm_any_args & a, hipStream_t st) {
     if (a.M == 0 || a.N == 0 || a.nbatch == 0) return;
+    if (a.nmat > 1 && !gemm_any_group_ok(a)) { fprintf(stderr, "[mi355x] gemm_any: grouped launch outside the 16 x 16-tile kernel's shapes\n"); abort(); }
     gemm_any_dev g;
     g.W = (const char *) a.W; g.w_rs = a.w_rs; g.w_nb2 = a.w_nb2; g.w_nb3 = a.w_nb3;
     g.X = (const char *) a.X; g.x_rs = a.x_rs; g.x_nb2 = a.x_nb2; g.x_nb3 = a.x_nb3;
@@ -488,16 +503,14 @@ void gemm_any(const gemm_any_args & a, hipStream_t st) {
     // (F16 weights have the f16 matrix cores below -- 8x the K per MFMA, paired loads: their chains are short without a split; measured on Whisper's
     //  V^T . P of a streaming chunk, 64 x 50 x 400 x 16 heads: 24 us here, 6 us there)
     const bool h_path = a.w_f16 && !a.w_bf16 && !getenv("MI355X_NO_GEMM_ANY_H") && a.K < 2048;
-    static const bool no_t16 = getenv("MI355X_NO_GEMM_F32_T16") != nullptr;
-    static const int64_t t16_max_tiles = getenv("MI355X_GEMM_T16_MAX_TILES") ? atoll(getenv("MI355X_GEMM_T16_MAX_TILES")) : 128;
-    if (!no_t16 && !no_sk && !a.x_f16 && !a.w_f16 && !a.w_bf16 && a.K % 4 == 0 && a.K >= 64 && ((a.M + 31) / 32) * ((a.N + 31) / 32) * a.nbatch < t16_max_tiles && ((a.M + 15) / 16) * ((a.N + 15) / 16) <= 65535 &&
-        (((uintptr_t) a.W | a.w_rs | a.w_nb2 | a.w_nb3 | (uintptr_t) a.X | a.x_rs | a.x_nb2 | a.x_nb3) & 15) == 0) {       // f32 x f32, 16-byte aligned rows, fewer than 128 tiles of 32 x 32: 16 x 16 tiles
+    if (gemm_any_t16_shape(a)) {       // f32 x f32, 16-byte aligned rows, fewer than 128 tiles of 32 x 32: 16 x 16 tiles
         constexpr int lds = (4 * 2 * 16 * 132 + 3 * 256) * 4;       // 70 656 B: two workgroups per CU
         static bool attr[64] = {};
         int dev = 0; HIP_CHECK(hipGetDevice(&dev));
         if (dev < 0 || dev >= 64 || !attr[dev]) { HIP_CHECK(hipFuncSetAttribute((const void *) k_gemm_f32_t16, hipFuncAttributeMaxDynamicSharedMemorySize, lds)); if (dev >= 0 && dev < 64) attr[dev] = true; }
         g.tiles_m = (int) ((a.M + 15) / 16);
-        k_gemm_f32_t16<<<dim3((unsigned) (g.tiles_m * ((a.N + 15) / 16)), (unsigned) a.nbatch), dim3(256), lds, st>>>(g);
+        for (int q = 0; q < 2; ++q) { g.W_more[q] = (const char *) a.W_more[q]; g.dst_more[q] = (char *) a.dst_more[q]; g.bias_more[q] = a.bias_more[q]; }
+        k_gemm_f32_t16<<<dim3((unsigned) (g.tiles_m * ((a.N + 15) / 16)), (unsigned) a.nbatch, (unsigned) a.nmat), dim3(256), lds, st>>>(g);
         return;
     }
     if (!no_sk && !h_path && (int64_t) g.tiles_m * ((a.N + 63) / 64) * a.nbatch < 128 && a.K >= 256) {          // few tiles, long chains: one 32 x 32 tile per workgroup, K split over its waves
