@@ -56,10 +56,16 @@ GGML_MI355X_API void   mi355x_timed_event_free(void * ev);
  * the prefill GEMM, process-wide), "norm_in_kernel" (0/1 RMS_NORM+MUL built inside the consuming decode mat-vec launches; default 0),
  * "fattn_gqa" (0/1 matrix-core kernel for few-token FLASH_ATTN_EXT; 0 = streaming kernel for every such shape; default 1, process-wide),
  * "fattn_dma" (-1 default / 0 / 1: the LDS-DMA ring form of the prefill attention kernel for head size 128 on large grids, process-wide),
+ * "prefill_q8k" (0 default / 1: the prefill GEMMs of K-quant weights take the Q8_K-QUANTISED activations -- the reference CPU backend's vec_dot_type
+ * arithmetic, ggml-cpu.c:1245-1268 -- instead of plain f16 rows; process-wide), "mmq_tile" (0 default / 1: Q4_K weights x more than 64 columns on the int8
+ * matrix cores from the blocks, csrc/kernels/mmq_tile.hip: the oracle's exact integer sums, slower than the F16-image GEMM; process-wide),
  * "mv1", "mv2", "fattn_one", "kq_staging", "batch_uploads" (cross-check switches of the decode kernels),
- * "reset_stats".  Returns 0 on success, -1 for an unknown key. */
+ * "reset_stats".  Returns 0 on success, -1 for an unknown key.
+ * Environment switches read once per process (measurement / cross-check only): MI355X_GRAPHS=0, MI355X_NO_CONV_FUSE, MI355X_NO_CONCAT_TAIL, MI355X_NO_ATTN_F32,
+ * MI355X_NO_GEMM_F32_T16, MI355X_NO_NORM_FUSE, MI355X_NO_GATE_NORM, MI355X_NO_EW_CHAIN, MI355X_NO_CONT_SINK (each turns one graph matcher / kernel choice off);
+ * MI355X_LOG_STATS, MI355X_GRAPH_GPU_TIME, MI355X_LAUNCH_LOG=file, MI355X_GRAPH_SLICE="nodes:lo:hi,..." (instrumentation, see tools/t2w_slices.sh). */
 GGML_MI355X_API int    mi355x_set_option(struct ggml_backend * backend, const char * key, long value);
-/* counters: "graph_replays", "graph_captures", "eager_graphs", "kernels_last_graph",
+/* counters: "graph_replays", "graph_captures", "eager_graphs", "kernels_last_graph", "mmq_tile_launches",
  * "shadow_bytes", "shadow_tensors", "prof_mmv_q4k_us", "prof_mmv_q4k_n", "prof_mmv_q4k_bytes", ....
  * Returns -1 if unknown. */
 GGML_MI355X_API double mi355x_get_stat(struct ggml_backend * backend, const char * key);

@@ -1050,15 +1050,18 @@ static void seed_act_f16(exec_state & s, const ggml_tensor * x, bool quantised) 
 // read the result (wq / wk / wv, fc1).  Same three f32 roundings as the separate ops.
 // LayerNorm -> MUL(n, scale) -> ADD(n, .) -> ADD(., shift) with scale / shift one row per dim-2 slice ([C, 1, B] views of the DiT's adaLN product, token2wav-impl.cpp:1121-1164):
 // the three element-wise nodes ride in the norm launch's epilogue, rounded as they round.  The norm has exactly these two readers.
-static bool exec_norm_modulate(exec_state & s, int i) {
+struct norm_mod_match { int mi_, a1i, a2i; const ggml_tensor * sv, * tv, * out; };
+// `consecutive`: the norm's readers must be the launches right behind it (false: the caller checks with can_hoist that they may run at its own position)
+static bool match_norm_modulate(exec_state & s, int i, norm_mod_match & M, bool consecutive) {
     static const bool off = getenv("MI355X_NO_NORM_FUSE") != nullptr;
     ggml_cgraph * g = s.g;
     const ggml_tensor * n = g->nodes[i];
-    if (off || !s.c->opt_fusion || is_out(s, n) || n->src[0]->type != GGML_TYPE_F32 || n->type != GGML_TYPE_F32 || !is_contiguous(n) || n->ne[3] != 1) return false;
+    if (off || !s.c->opt_fusion || n->op != GGML_OP_NORM || is_out(s, n) || n->src[0]->type != GGML_TYPE_F32 || n->type != GGML_TYPE_F32 || !is_contiguous(n) || n->ne[3] != 1) return false;
     auto it = s.users.find(n);
     if (it == s.users.end() || it->second.size() != 2) return false;
     const int mi_ = it->second[0], a1i = it->second[1];
-    if (mi_ <= i || next_real_node(s, i) != mi_ || a1i <= mi_ || next_real_node(s, mi_) != a1i) return false;
+    if (mi_ <= i || a1i <= mi_ || s.done[mi_] || s.done[a1i]) return false;
+    if (consecutive && (next_real_node(s, i) != mi_ || next_real_node(s, mi_) != a1i)) return false;
     const ggml_tensor * m = g->nodes[mi_], * a1 = g->nodes[a1i];
     auto row_vec = [&](const ggml_tensor * v) {              // one row of C floats per dim-2 slice (or one row altogether)
         return v && v->type == GGML_TYPE_F32 && v->data && v->ne[0] == n->ne[0] && v->ne[1] == 1 && (v->ne[2] == n->ne[2] || v->ne[2] == 1) && v->ne[3] == 1 && v->nb[0] == 4 &&
@@ -1067,22 +1070,77 @@ static bool exec_norm_modulate(exec_state & s, int i) {
     if (m->op != GGML_OP_MUL || m->src[0] != n || !row_vec(m->src[1]) || !same_shape(m, n) || !is_contiguous(m) || is_out(s, m) || sole_user(s, m) != a1i) return false;
     if (a1->op != GGML_OP_ADD || a1->src[0] != n || a1->src[1] != m || !same_shape(a1, n) || !is_contiguous(a1) || is_out(s, a1)) return false;
     const int a2i = sole_user(s, a1);
-    if (a2i <= a1i || next_real_node(s, a1i) != a2i) return false;
+    if (a2i <= a1i || s.done[a2i] || (consecutive && next_real_node(s, a1i) != a2i)) return false;
     const ggml_tensor * a2 = g->nodes[a2i];
     if (a2->op != GGML_OP_ADD || a2->src[0] != a1 || !row_vec(a2->src[1]) || !same_shape(a2, n) || !is_contiguous(a2) || a2->type != GGML_TYPE_F32) return false;
     const ggml_tensor * sv = m->src[1], * tv = a2->src[1];
     if (!norm_rows_ok(td(n->src[0]), td(a2))) return false;
     if (overlap(range_of(a2), range_of(sv)) || overlap(range_of(a2), range_of(tv)) || (overlap(range_of(a2), range_of(n->src[0])) && a2->data != n->src[0]->data)) return false;
+    M = { mi_, a1i, a2i, sv, tv, a2 };
+    return true;
+}
+static bool exec_norm_modulate(exec_state & s, int i) {
+    norm_mod_match M;
+    if (!match_norm_modulate(s, i, M, true)) return false;
+    const ggml_tensor * n = s.g->nodes[i];
     if (s.pr.A) materialise_reduce(s);
     if (s.prm.n) materialise_group(s);
     {
         prof_scope ps(s, "norm", 0);
-        norm_rows_f32(td(n->src[0]), td(a2), op_param_f32(n, 0), (const float *) sv->data, (const float *) tv->data, nullptr, 0, true, s.st,
-                      sv->ne[2] > 1 ? sv->nb[2] / 4 : 0, tv->ne[2] > 1 ? tv->nb[2] / 4 : 0, true);
+        norm_rows_f32(td(n->src[0]), td(M.out), op_param_f32(n, 0), (const float *) M.sv->data, (const float *) M.tv->data, nullptr, 0, true, s.st,
+                      M.sv->ne[2] > 1 ? M.sv->nb[2] / 4 : 0, M.tv->ne[2] > 1 ? M.tv->nb[2] / 4 : 0, true);
     }
     ++s.n_kernels;
-    for (int k : { mi_, a1i, a2i }) { s.done[k] = 1; ++s.n_fused; }
-    note_write(s, a2);
+    for (int k : { M.mi_, M.a1i, M.a2i }) { s.done[k] = 1; ++s.n_fused; }
+    note_write(s, M.out);
+    return true;
+}
+// The DiT's gated residual in front of that: MUL(y, gate) -> ADD(resid, .) = x, whose LayerNorm + modulation follows (possibly behind a few unrelated small copies --
+// the convolution caches' -- which the chain is hoisted over when can_hoist allows): x is computed and written in the norm launch.  `i` is the MUL.
+static bool exec_gate_norm(exec_state & s, int i) {
+    static const bool off = getenv("MI355X_NO_GATE_NORM") != nullptr;
+    ggml_cgraph * g = s.g;
+    const ggml_tensor * m = g->nodes[i];
+    if (off || !s.c->opt_fusion || m->op != GGML_OP_MUL || m->type != GGML_TYPE_F32 || !is_contiguous(m) || m->ne[3] != 1 || is_out(s, m) || m->view_src) return false;
+    const ggml_tensor * y = m->src[0], * gv = m->src[1];
+    if (!y || !gv || y->type != GGML_TYPE_F32 || !is_contiguous(y) || !same_shape(y, m) || !y->data) return false;
+    if (gv->type != GGML_TYPE_F32 || !gv->data || gv->ne[0] != m->ne[0] || gv->ne[1] != 1 || (gv->ne[2] != m->ne[2] && gv->ne[2] != 1) || gv->ne[3] != 1 || gv->nb[0] != 4 || gv->nb[2] % 16 != 0) return false;
+    const int ai = sole_user(s, m);
+    if (ai <= i || next_real_node(s, i) != ai) return false;
+    const ggml_tensor * a = g->nodes[ai];
+    if (a->op != GGML_OP_ADD || a->src[1] != m || a->type != GGML_TYPE_F32 || !is_contiguous(a) || !same_shape(a, m) || a->view_src) return false;
+    const ggml_tensor * r = a->src[0];
+    if (!r || r->type != GGML_TYPE_F32 || !is_contiguous(r) || !same_shape(r, a) || !r->data) return false;
+    // the LayerNorm of x among its readers, the first launching reader
+    auto it = s.users.find(a);
+    if (it == s.users.end()) return false;
+    int ni = -1;
+    for (int u : it->second) if (u > ai && g->nodes[u]->op == GGML_OP_NORM && g->nodes[u]->src[0] == a) { ni = u; break; }
+    if (ni < 0 || s.done[ni] || ni > ai + 24) return false;
+    for (int u : it->second) if (u < ni && u != ai) return false;               // somebody reads x before its norm: it must exist by then (keep the separate launches)
+    norm_mod_match M;
+    if (!match_norm_modulate(s, ni, M, false)) return false;
+    const int item[6] = { i, ai, ni, M.mi_, M.a1i, M.a2i };
+    if (next_real_node(s, ai) != ni || next_real_node(s, ni) != M.mi_ || next_real_node(s, M.mi_) != M.a1i || next_real_node(s, M.a1i) != M.a2i) {
+        for (int k : { ni, M.mi_, M.a1i, M.a2i }) if (!can_hoist(s, ai, k, item, 6)) return false;
+    }
+    if (((uintptr_t) y->data | (uintptr_t) r->data | (uintptr_t) gv->data | (uintptr_t) a->data) & 15) return false;
+    // x is written row by row while other rows of y / resid are still being read: it may sit exactly on one of them (same rows), not across
+    if ((overlap(range_of(a), range_of(y)) && a->data != y->data) || (overlap(range_of(a), range_of(r)) && a->data != r->data) || overlap(range_of(a), range_of(gv))) return false;
+    if (overlap(range_of(M.out), range_of(y)) || overlap(range_of(M.out), range_of(r)) || overlap(range_of(M.out), range_of(gv))) return false;
+    const ggml_tensor * n = g->nodes[ni];
+    if (s.pr.A) materialise_reduce(s);
+    if (s.prm.n) materialise_group(s);
+    if (s.pn.m && (s.pn.m == y || s.pn.m == r)) materialise_norm(s);
+    {
+        prof_scope ps(s, "norm", 0);
+        const norm_gate ng = { (const float *) y->data, (const float *) r->data, (const float *) gv->data, gv->ne[2] > 1 ? gv->nb[2] / 4 : 0 };
+        norm_rows_f32(td(a), td(M.out), op_param_f32(n, 0), (const float *) M.sv->data, (const float *) M.tv->data, nullptr, 0, true, s.st,
+                      M.sv->ne[2] > 1 ? M.sv->nb[2] / 4 : 0, M.tv->ne[2] > 1 ? M.tv->nb[2] / 4 : 0, true, &ng);
+    }
+    ++s.n_kernels;
+    for (int k : { ai, ni, M.mi_, M.a1i, M.a2i }) { s.done[k] = 1; ++s.n_fused; }
+    note_write(s, a); note_write(s, M.out);
     return true;
 }
 
@@ -2638,6 +2696,7 @@ void run_nodes(exec_state & s, ggml_cgraph * g) {
         } } ll_g{ s, g, i, s.n_kernels, s.n_fused };
         if (g->nodes[i]->op == GGML_OP_CONT && exec_causal_conv(s, i)) continue;
         if ((g->nodes[i]->op == GGML_OP_CONT || g->nodes[i]->op == GGML_OP_CONCAT) && exec_concat_tail(s, i)) continue;
+        if (g->nodes[i]->op == GGML_OP_MUL && exec_gate_norm(s, i)) continue;
         {
             int taken[8];
             const int nt = is_noop(g->nodes[i]) ? 0 : exec_ew_chain(s, i, taken);

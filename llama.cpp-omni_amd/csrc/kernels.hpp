@@ -130,7 +130,9 @@ void pool_f32(const tdesc & x, int x_type, const tdesc & y, const int32_t * p, b
 // NORM (ops.cpp:3450-3495): y = (x - mean) / sqrt(var + eps) per row
 void norm_f32(const tdesc & x, const tdesc & y, float eps, hipStream_t st);
 bool norm_rows_ok(const tdesc & x, const tdesc & y);                      // many 16-byte aligned rows of at most 4096 elements: the wave-per-row kernel
-void norm_rows_f32(const tdesc & x, const tdesc & y, float eps, const float * w, const float * b, uint16_t * y16, size_t y16_rs, bool write_f32, hipStream_t st, size_t w_bs = 0, size_t b_bs = 0, bool mod = false);   // + MUL w, ADD b, f16 image
+struct norm_gate { const float * y, * resid, * gate; size_t g_bs; };      // x = resid + y * gate computed (and written to x) in front of the norm: rows of y / resid laid out like x, gate one row per dim-2 slice
+void norm_rows_f32(const tdesc & x, const tdesc & y, float eps, const float * w, const float * b, uint16_t * y16, size_t y16_rs, bool write_f32, hipStream_t st, size_t w_bs = 0, size_t b_bs = 0, bool mod = false,
+                   const norm_gate * gate = nullptr);   // + MUL w, ADD b, f16 image
 long norm_from_split_launches();
 bool norm_rows_from_split_ok(const tdesc & x, const tdesc & y, int nsplit, size_t resid_cs, size_t resid2_cs, const void * resid, const void * resid2, const void * part);
 void norm_rows_from_split(const tdesc & x, const tdesc & y, float eps, const float * w, const float * b, uint16_t * y16, size_t y16_rs, bool write_f32,

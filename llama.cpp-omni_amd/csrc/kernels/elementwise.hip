@@ -405,7 +405,10 @@ __global__ void __launch_bounds__(1024) k_norm(td4 x, td4 y, float eps) {
 // the next residual) and normalised from the registers: the reduction launch between a split mat-mul and the LayerNorm behind it (wo / fc2 of an encoder layer) is gone
 // w_bs / b_bs: the vectors of dim-2 slice i2 start w_bs / b_bs floats further on (0: one vector for all rows); mod: the result is (n * w + n) + b -- the Token2Wav DiT's
 // modulation MUL(n, scale) -> ADD(n, .) -> ADD(., shift) with per-batch-element scale / shift rows, rounded as the three nodes round
-struct norm_split_src { const float * part; int nsplit; size_t split_elems; const char * resid; size_t resid_cs; const char * resid2; size_t resid2_cs; size_t w_bs = 0, b_bs = 0; int mod = 0; };
+struct norm_split_src { const float * part; int nsplit; size_t split_elems; const char * resid; size_t resid_cs; const char * resid2; size_t resid2_cs; size_t w_bs = 0, b_bs = 0; int mod = 0;
+                        // gy: the row is first COMPUTED as x = resid + gy * gate (MUL then ADD, rounded as the two nodes round; gate one row per dim-2 slice, g_bs floats apart) and written
+                        // to x -- the DiT's gated residual in front of its LayerNorm; resid / gy rows laid out like x
+                        const char * gy = nullptr; const char * gres = nullptr; const float * gate = nullptr; size_t g_bs = 0; };
 template <int MAXV>
 __global__ void __launch_bounds__(256) k_norm_rows(td4 x, td4 y, float eps, int64_t nrows, const float * __restrict__ w, const float * __restrict__ b, char * __restrict__ y16, int64_t y16_rs,
                                                    const norm_split_src sp) {
@@ -468,6 +471,14 @@ __global__ void __launch_bounds__(256) k_norm_rows(td4 x, td4 y, float eps, int6
                 if (sp.resid2) a += r2;
                 *(f32x4 *) (const_cast<char *>(xr) + (size_t) i * 4) = a;
                 v[k] = a;
+            } else if (sp.gy) {
+                const size_t ro = (size_t) (xr - x.p);                  // (resid / gy rows laid out like x)
+                const f32x4 yv = *(const f32x4 *) (sp.gy + ro + (size_t) i * 4), rv = *(const f32x4 *) (sp.gres + ro + (size_t) i * 4), gv = *(const f32x4 *) (sp.gate + (size_t) i2 * sp.g_bs + i);
+                f32x4 a;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) a[e] = __fadd_rn(rv[e], __fmul_rn(yv[e], gv[e]));
+                *(f32x4 *) (const_cast<char *>(xr) + (size_t) i * 4) = a;
+                v[k] = a;
             } else v[k] = *(const f32x4 *) (xr + (size_t) i * 4);
             s += (double) v[k][0] + (double) v[k][1] + (double) v[k][2] + (double) v[k][3];
         }
@@ -512,13 +523,18 @@ bool norm_rows_ok(const tdesc & x, const tdesc & y) {
     return nrows >= 2 && n > 0 && n % 4 == 0 && n <= 4096 && al16(x) && al16(y);
 }
 // LayerNorm rows with the following MUL (w) / ADD (b) by [n] vectors folded in and, optionally, the f16 image of the result (write_f32 false: only that)
-void norm_rows_f32(const tdesc & x, const tdesc & y, float eps, const float * w, const float * b, uint16_t * y16, size_t y16_rs, bool write_f32, hipStream_t st, size_t w_bs, size_t b_bs, bool mod) {
+void norm_rows_f32(const tdesc & x, const tdesc & y, float eps, const float * w, const float * b, uint16_t * y16, size_t y16_rs, bool write_f32, hipStream_t st, size_t w_bs, size_t b_bs, bool mod,
+                   const norm_gate * gate) {
     const int64_t n = x.ne[0], nrows = x.ne[1] * x.ne[2] * x.ne[3];
     if (!norm_rows_ok(x, y) || ((uintptr_t) w & 15) || ((uintptr_t) b & 15) || (y16 && (y16_rs % 8 != 0 || ((uintptr_t) y16 & 7) != 0)) || (!write_f32 && !y16)) { fprintf(stderr, "[mi355x] norm_rows_f32: unsupported arguments\n"); abort(); }
     td4 yd = to_td4(y); if (!write_f32) yd.p = nullptr;
     const dim3 grid((unsigned) ((nrows + 3) / 4));
     norm_split_src sp = { nullptr, 0, 0, nullptr, 0, nullptr, 0 };
     sp.w_bs = w_bs; sp.b_bs = b_bs; sp.mod = mod ? 1 : 0;
+    if (gate) {
+        if (((uintptr_t) gate->y | (uintptr_t) gate->resid | (uintptr_t) gate->gate) & 15) { fprintf(stderr, "[mi355x] norm_rows_f32: unaligned gated-residual operands\n"); abort(); }
+        sp.gy = (const char *) gate->y; sp.gres = (const char *) gate->resid; sp.gate = gate->gate; sp.g_bs = gate->g_bs;
+    }
     if (n <= 1024)      k_norm_rows<4><<<grid, dim3(256), 0, st>>>(to_td4(x), yd, eps, nrows, w, b, (char *) y16, (int64_t) y16_rs, sp);
     else if (n <= 2048) k_norm_rows<8><<<grid, dim3(256), 0, st>>>(to_td4(x), yd, eps, nrows, w, b, (char *) y16, (int64_t) y16_rs, sp);
     else                k_norm_rows<16><<<grid, dim3(256), 0, st>>>(to_td4(x), yd, eps, nrows, w, b, (char *) y16, (int64_t) y16_rs, sp);
