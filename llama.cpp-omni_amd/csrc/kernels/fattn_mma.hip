@@ -496,6 +496,17 @@ static __device__ __forceinline__ void fd_tr_wait(fd_vfrag & f) {
                  : "+v"(f.r[0][0]), "+v"(f.r[0][1]), "+v"(f.r[0][2]), "+v"(f.r[0][3]), "+v"(f.r[1][0]), "+v"(f.r[1][1]), "+v"(f.r[1][2]), "+v"(f.r[1][3]),
                    "+v"(f.r[2][0]), "+v"(f.r[2][1]), "+v"(f.r[2][2]), "+v"(f.r[2][3]), "+v"(f.r[3][0]), "+v"(f.r[3][1]), "+v"(f.r[3][2]), "+v"(f.r[3][3]) :: "memory");
 }
+// head size 64: two d-blocks, the rows of a tile 128 bytes apart (+8 rows = 1024 bytes)
+static __device__ __forceinline__ void fd_tr_issue64(const uint32_t (&ad)[2], fd_vfrag & f) {
+    asm volatile("ds_read_b64_tr_b16 %0, %8\n\tds_read_b64_tr_b16 %1, %8 offset:1024\n\tds_read_b64_tr_b16 %2, %8 offset:2048\n\tds_read_b64_tr_b16 %3, %8 offset:3072\n\t"
+                 "ds_read_b64_tr_b16 %4, %9\n\tds_read_b64_tr_b16 %5, %9 offset:1024\n\tds_read_b64_tr_b16 %6, %9 offset:2048\n\tds_read_b64_tr_b16 %7, %9 offset:3072"
+                 : "=&v"(f.r[0][0]), "=&v"(f.r[0][1]), "=&v"(f.r[0][2]), "=&v"(f.r[0][3]), "=&v"(f.r[1][0]), "=&v"(f.r[1][1]), "=&v"(f.r[1][2]), "=&v"(f.r[1][3])
+                 : "v"(ad[0]), "v"(ad[1]) : "memory");
+}
+static __device__ __forceinline__ void fd_tr_wait64(fd_vfrag & f) {
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(f.r[0][0]), "+v"(f.r[0][1]), "+v"(f.r[0][2]), "+v"(f.r[0][3]), "+v"(f.r[1][0]), "+v"(f.r[1][1]), "+v"(f.r[1][2]), "+v"(f.r[1][3]) :: "memory");
+}
 static __device__ __forceinline__ float fd_max_halves(float x) {      // max of lanes l and l ^ 32 without the LDS crossbar (v_permlane32_swap)
 #if __has_builtin(__builtin_amdgcn_permlane32_swap)
     const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
@@ -506,12 +517,18 @@ static __device__ __forceinline__ float fd_max_halves(float x) {      // max of 
 }
 
 // HW = heads per workgroup: 2 = eight waves, the four query blocks of TWO heads of one KV head (same mask tiles, same K / V rows): half the requests per unit of matrix work
-template <int ABL, int HW>
-__global__ void __launch_bounds__(256 * HW) __attribute__((amdgpu_waves_per_eu(2))) k_fattn_dma128(const fa_dev a, const int nqt) {
-    constexpr int D = 128, NW = 4, NKS = D / 16, NDB = D / 32, NT = 64 * NW * HW;
+// D = 64 (the omni encoders: Whisper 1500 x 1500 x 16 heads, round 5): rows of 128 bytes = 8 chunks, one DMA instruction = 8 rows (one per wave and tile, HW = 1 only);
+// K chunk c of row r sits at c ^ ((r >> 1) & 7) (rows two apart share a bank half), V's 64-byte d-block at db ^ ((r >> 1) & 1) (rows r, r + 2 of a transpose read
+// 64 bytes apart); the V^T reads' row offsets are 8 x 128 bytes.
+template <int D, int ABL, int HW>
+__global__ void __launch_bounds__(256 * HW) __attribute__((amdgpu_waves_per_eu(2))) k_fattn_dma(const fa_dev a, const int nqt) {
+    static_assert((D == 128) || (D == 64 && HW == 1), "head sizes 128 and 64 (one head per workgroup)");
+    constexpr int NW = 4, NKS = D / 16, NDB = D / 32, NT = 64 * NW * HW;
+    constexpr int ROWB = 2 * D, CPR = ROWB / 16, RPI = 64 / CPR, TILEB = FM_KT * ROWB, STAGEB = 2 * TILEB;      // chunks per row, rows per DMA instruction
+    constexpr int LIVE_OFF = FD_NST * STAGEB, CLS_OFF = LIVE_OFF + FM_MAXT / 8;
     char * const lds = fd_lds;
-    uint64_t * const live_bits = (uint64_t *) (lds + FD_LIVE_OFF);
-    uint32_t (* const cls2)[FM_MAXT / 16] = (uint32_t (*)[FM_MAXT / 16]) (lds + FD_CLS_OFF);
+    uint64_t * const live_bits = (uint64_t *) (lds + LIVE_OFF);
+    uint32_t (* const cls2)[FM_MAXT / 16] = (uint32_t (*)[FM_MAXT / 16]) (lds + CLS_OFF);
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -615,24 +632,24 @@ __global__ void __launch_bounds__(256 * HW) __attribute__((amdgpu_waves_per_eu(2
     };
 
     // ---- DMA side: instruction j of wave w fills rows (w*NJ + j)*4 + [0,4) of a tile, lane l the chunk l & 15 of row l >> 4 from the source chunk the swizzle asks for
-    constexpr int NJ = 2 / HW;                                      // K (and V) instructions per wave and tile
-    const int c16 = lane & 15;
+    constexpr int NJ = FM_KT / RPI / (NW * HW);                     // K (and V) instructions per wave and tile (D = 128: 2 / HW, D = 64: 1)
+    const int c16 = lane & (CPR - 1);
     int rit[NJ]; uint32_t kso[NJ], vso[NJ];
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
-        rit[j] = (wave * NJ + j) * 4 + (lane >> 4);
-        kso[j] = (uint32_t) ((c16 ^ (rit[j] & 15)) * 16);
-        vso[j] = (uint32_t) ((c16 ^ (4 * (rit[j] & 3))) * 16);
+        rit[j] = (wave * NJ + j) * RPI + lane / CPR;
+        kso[j] = (uint32_t) ((c16 ^ (D == 128 ? (rit[j] & 15) : ((rit[j] >> 1) & 7))) * 16);
+        vso[j] = (uint32_t) ((c16 ^ (4 * (D == 128 ? (rit[j] & 3) : ((rit[j] >> 1) & 1)))) * 16);
     }
     int slot_d = 0, t_dma = next_live(0), t_last = 0;
     auto dma_tile = [&]() {                                          // the next live tile (past the last one: that one again, into a slot nobody reads)
         const int t = t_dma < ntile ? t_dma : t_last;
-        char * const sb = lds + slot_d * FD_STAGEB + (wave * NJ * 4) * FD_ROWB;
+        char * const sb = lds + slot_d * STAGEB + (wave * NJ * RPI) * ROWB;
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
             int r = t * FM_KT + rit[j]; r = r < a.nkv ? r : a.nkv - 1;
-            __builtin_amdgcn_global_load_lds((gbl_ptr_t) (kbase + (int64_t) r * a.knb1 + kso[j]), (lds_ptr_t) (sb + j * 4 * FD_ROWB), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((gbl_ptr_t) (vbase + (int64_t) r * a.vnb1 + vso[j]), (lds_ptr_t) (sb + FD_TILEB + j * 4 * FD_ROWB), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gbl_ptr_t) (kbase + (int64_t) r * a.knb1 + kso[j]), (lds_ptr_t) (sb + j * RPI * ROWB), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gbl_ptr_t) (vbase + (int64_t) r * a.vnb1 + vso[j]), (lds_ptr_t) (sb + TILEB + j * RPI * ROWB), 16, 0, 0);
         }
         if (t_dma < ntile) { t_last = t_dma; t_dma = next_live(t_dma + 1); }
         slot_d = slot_d == FD_NST - 1 ? 0 : slot_d + 1;
@@ -640,13 +657,13 @@ __global__ void __launch_bounds__(256 * HW) __attribute__((amdgpu_waves_per_eu(2
 
     // ---- reader side, per lane: K row lq, chunk (ks*2 + hb) ^ (lq & 15); V^T: group g = lane / 16, s = lane % 16 -> row 4*hb + s/4 (+ 8 r + 16 s2), halves d0 + 4 (s & 3) ..
     const uint32_t lds0 = (uint32_t) (uintptr_t) lds;
-    const char * const krow = lds + lq * FD_ROWB;
-    const int ksw = lq & 15;
+    const char * const krow = lds + lq * ROWB;
+    const int ksw = D == 128 ? (lq & 15) : ((lq >> 1) & 7);
     const int gi = lane >> 4, si = lane & 15;
-    const uint32_t vlane = lds0 + FD_TILEB + (uint32_t) ((4 * (gi >> 1) + (si >> 2)) * FD_ROWB + (2 * (gi & 1) + ((si & 3) >> 1)) * 16 + (si & 1) * 8);
+    const uint32_t vlane = lds0 + TILEB + (uint32_t) ((4 * (gi >> 1) + (si >> 2)) * ROWB + (2 * (gi & 1) + ((si & 3) >> 1)) * 16 + (si & 1) * 8);
     uint32_t vdb[NDB];
 #pragma unroll
-    for (int db = 0; db < NDB; ++db) vdb[db] = vlane + (uint32_t) (64 * (db ^ (si >> 2)));
+    for (int db = 0; db < NDB; ++db) vdb[db] = vlane + (uint32_t) (64 * (db ^ (D == 128 ? (si >> 2) : ((si >> 3) & 1))));
 
     const bool c2pos = c2 > 0.0f;
     // ---- the phases of a tile; the two tiles of a pair are interleaved below so that one's soft-max arithmetic issues while the other's matrix products execute
@@ -707,7 +724,7 @@ __global__ void __launch_bounds__(256 * HW) __attribute__((amdgpu_waves_per_eu(2
         }
     };
     auto pv = [&](fd_vfrag & vf, const pfrag (&pf)[2]) {              // O^T += V^T . P^T (the four accumulators in turn: consecutive MFMAs are independent)
-        fd_tr_wait(vf);
+        if constexpr (D == 128) fd_tr_wait(vf); else fd_tr_wait64(vf);
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
@@ -755,8 +772,12 @@ __global__ void __launch_bounds__(256 * HW) __attribute__((amdgpu_waves_per_eu(2
             return;
         }
         fd_vfrag v0, v1; pfrag pf0[2], pf1[2];
-        if (cls0 != 0) { const uint32_t ad[4] = { vdb[0] + so0, vdb[1] + so0, vdb[2] + so0, vdb[3] + so0 }; fd_tr_issue(ad, v0); soft_max(cls0, mw0, s0, pf0); pv(v0, pf0); }
-        if (cls1 != 0) { const uint32_t ad[4] = { vdb[0] + so1, vdb[1] + so1, vdb[2] + so1, vdb[3] + so1 }; fd_tr_issue(ad, v1); soft_max(cls1, mw1, s1, pf1); pv(v1, pf1); }
+        auto v_issue = [&](const uint32_t so_, fd_vfrag & vf) {
+            if constexpr (D == 128) { const uint32_t ad[4] = { vdb[0] + so_, vdb[1] + so_, vdb[2] + so_, vdb[3] + so_ }; fd_tr_issue(ad, vf); }
+            else                    { const uint32_t ad[2] = { vdb[0] + so_, vdb[1] + so_ }; fd_tr_issue64(ad, vf); }
+        };
+        if (cls0 != 0) { v_issue(so0, v0); soft_max(cls0, mw0, s0, pf0); pv(v0, pf0); }
+        if (cls1 != 0) { v_issue(so1, v1); soft_max(cls1, mw1, s1, pf1); pv(v1, pf1); }
     };
     // ---- two live tiles per barrier: the ring is two pairs of slots; while a pair is worked on, the next pair's rows are in flight (a pair of tiles of matrix work to arrive)
     int t = next_live(0);
@@ -771,9 +792,9 @@ __global__ void __launch_bounds__(256 * HW) __attribute__((amdgpu_waves_per_eu(2
         // own requests of this pair have landed; after the barrier everybody's have, and everybody is past the previous pair, whose slots take the next one
         asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
         if (!(ABL & 1)) { dma_tile(); dma_tile(); }
-        const uint32_t so = (uint32_t) (pair * 2 * FD_STAGEB);
+        const uint32_t so = (uint32_t) (pair * 2 * STAGEB);
         pair ^= 1;
-        pair_work(cls0, cls1, mw0, mw1, so, so + FD_STAGEB);
+        pair_work(cls0, cls1, mw0, mw1, so, so + STAGEB);
         t = t1 < ntile ? next_live(t1 + 1) : ntile;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // (requests past the last live tile)
@@ -1168,6 +1189,7 @@ static long g_fd_launches = 0;
 void fattn_set_dma(int m) { g_fd_mode = m; }
 long fattn_dma_launches() { return g_fd_launches; }
 
+static int64_t fa_dma_min_wgs64() { static const int64_t v = getenv("MI355X_FA_BIG_MIN_WGS64") ? atoll(getenv("MI355X_FA_BIG_MIN_WGS64")) : 192; return v; }
 static int64_t fa_dma_min_wgs() { static const int64_t v = getenv("MI355X_FA_BIG_MIN_WGS") ? atoll(getenv("MI355X_FA_BIG_MIN_WGS")) : 512; return v; }
 
 template <int D>
@@ -1178,17 +1200,31 @@ static void launch_fm(const fa_dev & a, hipStream_t st) {
     const int64_t blocks32 = (int64_t) ((a.nq + 31) / 32) * a.nh * a.ns;          // one wave each without a KV split
     if (a.nq <= 32) {
         k_fattn_mma<D, 1, 1, 1><<<dim3((unsigned) (a.nh * a.ns)), dim3(64), 0, st>>>(a, 1);
-    } else if ((int64_t) nqt4 * a.nh * a.ns >= fa_dma_min_wgs()) {
+    } else if ((int64_t) nqt4 * a.nh * a.ns >= (D == 64 ? fa_dma_min_wgs64() : fa_dma_min_wgs())) {
         static const int abl = getenv("MI355X_FA_ABL") ? atoi(getenv("MI355X_FA_ABL")) : 0;
         static const bool env_no_dma = getenv("MI355X_FA_NO_DMA") != nullptr;
         const bool no_dma = g_fd_mode >= 0 ? g_fd_mode == 0 : env_no_dma;
-        if (D == 128 && !no_dma && !a.vt && a.nkv >= 128 && a.knb1 % 16 == 0 && a.vnb1 % 16 == 0 && a.knb2 % 16 == 0 && a.vnb2 % 16 == 0 && a.knb3 % 16 == 0 && a.vnb3 % 16 == 0 &&
+        if constexpr (D == 64) {                                     // the encoders' shapes (Whisper 1500 x 1500 x 16 heads: 192 workgroups): the LDS-DMA ring form, one head per workgroup
+            static const bool no_dma64 = getenv("MI355X_FA_NO_DMA64") != nullptr;
+            if (!no_dma && !no_dma64 && !a.vt && a.nkv >= 128 && a.knb1 % 16 == 0 && a.vnb1 % 16 == 0 && a.knb2 % 16 == 0 && a.vnb2 % 16 == 0 && a.knb3 % 16 == 0 && a.vnb3 % 16 == 0 &&
+                (((uintptr_t) a.k | (uintptr_t) a.v) & 15) == 0) {
+                constexpr int lds64 = FD_NST * 2 * FM_KT * 2 * 64 + FM_MAXT / 8 + 4 * (FM_MAXT / 16) * 4;
+                static bool attr[64] = {};
+                int dev = 0; HIP_CHECK(hipGetDevice(&dev));
+                if (dev < 0 || dev >= 64 || !attr[dev]) { HIP_CHECK(hipFuncSetAttribute((const void *) k_fattn_dma<64, 0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds64)); if (dev >= 0 && dev < 64) attr[dev] = true; }
+                ++g_fd_launches;
+                k_fattn_dma<64, 0, 1><<<dim3((unsigned) (nqt4 * a.nh * a.ns)), dim3(256), lds64, st>>>(a, nqt4);
+                return;
+            }
+        }
+        if constexpr (D == 128)
+        if (!no_dma && !a.vt && a.nkv >= 128 && a.knb1 % 16 == 0 && a.vnb1 % 16 == 0 && a.knb2 % 16 == 0 && a.vnb2 % 16 == 0 && a.knb3 % 16 == 0 && a.vnb3 % 16 == 0 &&
             (((uintptr_t) a.k | (uintptr_t) a.v) & 15) == 0) {
             static bool attr[64] = {};
             int dev = 0; HIP_CHECK(hipGetDevice(&dev));
             if (dev < 0 || dev >= 64 || !attr[dev]) {
 #define FD_ALL(F) F(0, 1) F(1, 1) F(4, 1) F(0, 2) F(1, 2) F(4, 2)
-#define FD_ATTR(A, H) HIP_CHECK(hipFuncSetAttribute((const void *) k_fattn_dma128<A, H>, hipFuncAttributeMaxDynamicSharedMemorySize, FD_LDS));
+#define FD_ATTR(A, H) HIP_CHECK(hipFuncSetAttribute((const void *) k_fattn_dma<128, A, H>, hipFuncAttributeMaxDynamicSharedMemorySize, FD_LDS));
                 FD_ALL(FD_ATTR)
                 if (dev >= 0 && dev < 64) attr[dev] = true;
             }
@@ -1196,10 +1232,10 @@ static void launch_fm(const fa_dev & a, hipStream_t st) {
             const int hw = (hw_env >= 2 && a.gq % 2 == 0 && a.mne2 <= 1 && (int64_t) nqt4 * (a.nh / 2) * a.ns >= 256) ? 2 : 1;      // (fewer workgroups than CUs otherwise)      // pairs of heads of one KV head, one mask for every head
             const dim3 grid((unsigned) (nqt4 * (a.nh / hw) * a.ns));
             bool done = false;
-#define FD_GO(A, H) if (!done && abl == A && hw == H) { k_fattn_dma128<A, H><<<grid, dim3(256 * H), FD_LDS, st>>>(a, nqt4); done = true; }
+#define FD_GO(A, H) if (!done && abl == A && hw == H) { k_fattn_dma<128, A, H><<<grid, dim3(256 * H), FD_LDS, st>>>(a, nqt4); done = true; }
             ++g_fd_launches;
             FD_ALL(FD_GO)
-            if (!done) { if (hw == 2) k_fattn_dma128<0, 2><<<grid, dim3(512), FD_LDS, st>>>(a, nqt4); else k_fattn_dma128<0, 1><<<grid, dim3(256), FD_LDS, st>>>(a, nqt4); }
+            if (!done) { if (hw == 2) k_fattn_dma<128, 0, 2><<<grid, dim3(512), FD_LDS, st>>>(a, nqt4); else k_fattn_dma<128, 0, 1><<<grid, dim3(256), FD_LDS, st>>>(a, nqt4); }
 #undef FD_GO
 #undef FD_ATTR
 #undef FD_ALL
@@ -1228,7 +1264,8 @@ static void launch_fm(const fa_dev & a, hipStream_t st) {
             }
             return;
         }
-        if (!no_split && ks_env >= 4 && blocks32 <= 512 && a.nkv >= 256) k_fattn_mma<D, 2, 4, 1><<<dim3((unsigned) (nqt * a.nh * a.ns)), dim3(512), 0, st>>>(a, nqt);   // at most one wave per two SIMDs otherwise: four waves per query block, a quarter of the KV range each
+        static const int64_t ks4_max = getenv("MI355X_FA_KS4_MAX_BLOCKS") ? atoll(getenv("MI355X_FA_KS4_MAX_BLOCKS")) : 512;
+        if (!no_split && ks_env >= 4 && blocks32 <= ks4_max && a.nkv >= 256) k_fattn_mma<D, 2, 4, 1><<<dim3((unsigned) (nqt * a.nh * a.ns)), dim3(512), 0, st>>>(a, nqt);   // at most one wave per two SIMDs otherwise: four waves per query block, a quarter of the KV range each
         else if (!no_split && blocks32 <= 768 && a.nkv >= 128) k_fattn_mma<D, 2, 2, 1><<<dim3((unsigned) (nqt * a.nh * a.ns)), dim3(256), 0, st>>>(a, nqt);   // fewer waves than SIMDs
         else if (sq_env >= 2 && a.nkv >= 128)            k_fattn_mma<D, 2, 1, 2><<<dim3((unsigned) (nqt * a.nh * a.ns)), dim3(128), 0, st>>>(a, nqt);
         else                                             k_fattn_mma<D, 2, 1, 1><<<dim3((unsigned) (nqt * a.nh * a.ns)), dim3(128), 0, st>>>(a, nqt);

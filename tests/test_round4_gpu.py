@@ -181,18 +181,25 @@ def test_8b_q8_0_greedy_ids_identical_through_libllama(tmp_path):
 # ds_read_b64_tr_b16, two heads of a KV head per workgroup, deferred running maximum): taken for head size 128 from 512 workgroups on.  Against the
 # float64 restatement of ggml_compute_forward_flash_attn_ext_f16 (ops.cpp:7912-8148), bar = the reference's NMSE 5e-4 for this op, and against the
 # register-staged kernel it replaces (option fattn_dma 0).
-@pytest.mark.parametrize("nq,nh,nhkv,nkv,ns,kind", [
-    (256, 32, 8, 300, 8, "causal"),        # ragged last tile, diagonal tiles, dead tiles; pairs of heads per workgroup
-    (384, 16, 16, 777, 11, "none"),        # no mask, no GQA (one head per workgroup), odd number of live tiles
-    (256, 32, 8, 1024, 8, "padded"),       # the second half of the cache view unused
-    (256, 32, 4, 512, 8, "sinks"),
-    (256, 32, 8, 640, 8, "softcap"),
-    (128, 64, 8, 4096, 8, "spike")])       # one key far above the rest late in the row: the deferred maximum must follow it
-def test_flash_attn_prefill_dma_ring(pkg, be, nq, nh, nhkv, nkv, ns, kind):
+@pytest.mark.parametrize("D,nq,nh,nhkv,nkv,ns,kind", [
+    (128, 256, 32, 8, 300, 8, "causal"),        # ragged last tile, diagonal tiles, dead tiles; pairs of heads per workgroup
+    (128, 384, 16, 16, 777, 11, "none"),        # no mask, no GQA (one head per workgroup), odd number of live tiles
+    (128, 256, 32, 8, 1024, 8, "padded"),       # the second half of the cache view unused
+    (128, 256, 32, 4, 512, 8, "sinks"),
+    (128, 256, 32, 8, 640, 8, "softcap"),
+    (128, 128, 64, 8, 4096, 8, "spike"),        # one key far above the rest late in the row: the deferred maximum must follow it
+    # head size 64 (round 5: the encoders' shape; rows of 128 bytes, one head per workgroup, taken from 192 workgroups on)
+    (64, 1500, 16, 16, 1500, 1, "none"),        # Whisper-medium over 30 s (tools/omni/audition.cpp:596-640): 1500 x 1500 x 16 heads, ragged last query and key tiles
+    (64, 256, 16, 16, 300, 6, "causal"),
+    (64, 200, 20, 20, 777, 5, "none"),
+    (64, 256, 16, 4, 512, 6, "sinks"),
+    (64, 256, 16, 16, 640, 6, "softcap"),
+    (64, 256, 16, 8, 1024, 6, "padded"),
+    (64, 128, 32, 8, 2048, 6, "spike")])
+def test_flash_attn_prefill_dma_ring(pkg, be, D, nq, nh, nhkv, nkv, ns, kind):
     import numpy as np
     from conftest import nmse
     from test_gpu_parity import _attn_f64, run_graph
-    D = 128
     rng = np.random.default_rng(nq + nkv + nh)
     qv = rng.standard_normal((ns, nh, nq, D)).astype(np.float32)
     kv = rng.standard_normal((ns, nhkv, nkv, D)).astype(np.float16)
