@@ -520,12 +520,15 @@ static __device__ __forceinline__ float fd_max_halves(float x) {      // max of 
 // D = 64 (the omni encoders: Whisper 1500 x 1500 x 16 heads, round 5): rows of 128 bytes = 8 chunks, one DMA instruction = 8 rows (one per wave and tile, HW = 1 only);
 // K chunk c of row r sits at c ^ ((r >> 1) & 7) (rows two apart share a bank half), V's 64-byte d-block at db ^ ((r >> 1) & 1) (rows r, r + 2 of a transpose read
 // 64 bytes apart); the V^T reads' row offsets are 8 x 128 bytes.
-template <int D, int ABL, int HW>
-__global__ void __launch_bounds__(256 * HW) __attribute__((amdgpu_waves_per_eu(2))) k_fattn_dma(const fa_dev a, const int nqt) {
-    static_assert((D == 128) || (D == 64 && HW == 1), "head sizes 128 and 64 (one head per workgroup)");
-    constexpr int NW = 4, NKS = D / 16, NDB = D / 32, NT = 64 * NW * HW;
+// KS = 2 (D = 64, grids that leave the chip under-filled -- Whisper's 1500 x 1500 x 16 heads is 192 workgroups): eight waves, waves 4 .. 7 work on the same four query
+// blocks but on every other PAIR of live tiles, with their own half of the ring (each group of four waves requests its own tiles); the two (O, M, S) states are
+// folded through LDS at the end.  Both groups pass the same number of barriers (the step count comes from the number of live tiles).
+template <int D, int ABL, int HW, int KS = 1>
+__global__ void __launch_bounds__(256 * HW * KS) __attribute__((amdgpu_waves_per_eu(2))) k_fattn_dma(const fa_dev a, const int nqt) {
+    static_assert((D == 128 && KS == 1) || (D == 64 && HW == 1), "head sizes 128 and 64 (one head per workgroup); the key split only at 64");
+    constexpr int NW = 4, NKS = D / 16, NDB = D / 32, NT = 64 * NW * HW * KS;
     constexpr int ROWB = 2 * D, CPR = ROWB / 16, RPI = 64 / CPR, TILEB = FM_KT * ROWB, STAGEB = 2 * TILEB;      // chunks per row, rows per DMA instruction
-    constexpr int LIVE_OFF = FD_NST * STAGEB, CLS_OFF = LIVE_OFF + FM_MAXT / 8;
+    constexpr int GRP_RING = FD_NST * STAGEB, LIVE_OFF = KS * GRP_RING, CLS_OFF = LIVE_OFF + FM_MAXT / 8;
     char * const lds = fd_lds;
     uint64_t * const live_bits = (uint64_t *) (lds + LIVE_OFF);
     uint32_t (* const cls2)[FM_MAXT / 16] = (uint32_t (*)[FM_MAXT / 16]) (lds + CLS_OFF);
@@ -536,7 +539,8 @@ __global__ void __launch_bounds__(256 * HW) __attribute__((amdgpu_waves_per_eu(2
     int b = (int) blockIdx.x;
     const int qt  = nqt - 1 - b % nqt; b /= nqt;          // longest (latest, for causal masks) query tiles first
     const int qbw = wave & 3;                                       // query block of this wave within the workgroup's 128 queries
-    const int h   = (b % (a.nh / HW)) * HW + (wave >> 2);  const int is3 = b / (a.nh / HW);
+    const int h   = (b % (a.nh / HW)) * HW + (HW == 2 ? wave >> 2 : 0);  const int is3 = b / (a.nh / HW);
+    const int grp = KS == 2 ? wave >> 2 : 0, wq = KS == 2 ? (wave & 3) : wave;        // key-split group; wave within the group's DMA team
     const int ikv = h / a.gq;
     const int q0  = (qt * NW + qbw) * 32;
     const int q   = q0 + lq;
@@ -589,7 +593,7 @@ __global__ void __launch_bounds__(256 * HW) __attribute__((amdgpu_waves_per_eu(2
         }
         __syncthreads();
     }
-    for (int c = wave; c * 64 < ntile; c += NW * HW) {
+    for (int c = wave; c * 64 < ntile; c += NW * HW * KS) {
         const int tt = c * 64 + lane;
         bool lv = false;
         if (tt < ntile) {
@@ -637,27 +641,34 @@ __global__ void __launch_bounds__(256 * HW) __attribute__((amdgpu_waves_per_eu(2
     int rit[NJ]; uint32_t kso[NJ], vso[NJ];
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
-        rit[j] = (wave * NJ + j) * RPI + lane / CPR;
+        rit[j] = (wq * NJ + j) * RPI + lane / CPR;
         kso[j] = (uint32_t) ((c16 ^ (D == 128 ? (rit[j] & 15) : ((rit[j] >> 1) & 7))) * 16);
         vso[j] = (uint32_t) ((c16 ^ (4 * (D == 128 ? (rit[j] & 3) : ((rit[j] >> 1) & 1)))) * 16);
     }
-    int slot_d = 0, t_dma = next_live(0), t_last = 0;
+    auto skip_live = [&](int t_, int n_) { for (int i_ = 0; i_ < n_ && t_ < ntile; ++i_) t_ = next_live(t_ + 1); return t_; };      // the n-th live tile after t
+    int nlive = 0;
+    for (int c = 0; c * 64 < ntile; ++c) nlive += __builtin_popcountll(live_bits[c]);
+    nlive = __builtin_amdgcn_readfirstlane(nlive);
+    const int npairs = (nlive + 1) / 2, nsteps = KS == 2 ? (npairs + 1) / 2 : npairs;
+    const int t_first = grp == 1 ? skip_live(next_live(0), 2) : next_live(0);
+    int slot_d = 0, t_dma = t_first, t_last = 0, n_dma = 0;
     auto dma_tile = [&]() {                                          // the next live tile (past the last one: that one again, into a slot nobody reads)
         const int t = t_dma < ntile ? t_dma : t_last;
-        char * const sb = lds + slot_d * STAGEB + (wave * NJ * RPI) * ROWB;
+        char * const sb = lds + grp * GRP_RING + slot_d * STAGEB + (wq * NJ * RPI) * ROWB;
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
             int r = t * FM_KT + rit[j]; r = r < a.nkv ? r : a.nkv - 1;
             __builtin_amdgcn_global_load_lds((gbl_ptr_t) (kbase + (int64_t) r * a.knb1 + kso[j]), (lds_ptr_t) (sb + j * RPI * ROWB), 16, 0, 0);
             __builtin_amdgcn_global_load_lds((gbl_ptr_t) (vbase + (int64_t) r * a.vnb1 + vso[j]), (lds_ptr_t) (sb + TILEB + j * RPI * ROWB), 16, 0, 0);
         }
-        if (t_dma < ntile) { t_last = t_dma; t_dma = next_live(t_dma + 1); }
+        if (t_dma < ntile) { t_last = t_dma; t_dma = (KS == 2 && (n_dma & 1)) ? skip_live(t_dma, 3) : next_live(t_dma + 1); }      // (key split: the other group's pair lies in between)
+        ++n_dma;
         slot_d = slot_d == FD_NST - 1 ? 0 : slot_d + 1;
     };
 
     // ---- reader side, per lane: K row lq, chunk (ks*2 + hb) ^ (lq & 15); V^T: group g = lane / 16, s = lane % 16 -> row 4*hb + s/4 (+ 8 r + 16 s2), halves d0 + 4 (s & 3) ..
-    const uint32_t lds0 = (uint32_t) (uintptr_t) lds;
-    const char * const krow = lds + lq * ROWB;
+    const uint32_t lds0 = (uint32_t) (uintptr_t) lds + (uint32_t) (grp * GRP_RING);
+    const char * const krow = lds + grp * GRP_RING + lq * ROWB;
     const int ksw = D == 128 ? (lq & 15) : ((lq >> 1) & 7);
     const int gi = lane >> 4, si = lane & 15;
     const uint32_t vlane = lds0 + TILEB + (uint32_t) ((4 * (gi >> 1) + (si >> 2)) * ROWB + (2 * (gi & 1) + ((si & 3) >> 1)) * 16 + (si & 1) * 8);
@@ -780,11 +791,11 @@ __global__ void __launch_bounds__(256 * HW) __attribute__((amdgpu_waves_per_eu(2
         if (cls1 != 0) { v_issue(so1, v1); soft_max(cls1, mw1, s1, pf1); pv(v1, pf1); }
     };
     // ---- two live tiles per barrier: the ring is two pairs of slots; while a pair is worked on, the next pair's rows are in flight (a pair of tiles of matrix work to arrive)
-    int t = next_live(0);
+    int t = t_first;
     dma_tile(); dma_tile();
     int pair = 0;
-    while (t < ntile) {
-        const int t1 = next_live(t + 1);
+    for (int step = 0; step < nsteps; ++step) {
+        const int t1 = t < ntile ? next_live(t + 1) : ntile;
         const int cls0 = tile_class(t), cls1 = t1 < ntile ? tile_class(t1) : 0;
         u32x2 mw0[4] = {}, mw1[4] = {};
         if (cls0 == 2) load_mask(t, mw0);
@@ -795,11 +806,32 @@ __global__ void __launch_bounds__(256 * HW) __attribute__((amdgpu_waves_per_eu(2
         const uint32_t so = (uint32_t) (pair * 2 * STAGEB);
         pair ^= 1;
         pair_work(cls0, cls1, mw0, mw1, so, so + STAGEB);
-        t = t1 < ntile ? next_live(t1 + 1) : ntile;
+        t = t1 < ntile ? (KS == 2 ? skip_live(t1, 3) : next_live(t1 + 1)) : ntile;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // (requests past the last live tile)
 
     S += __shfl_xor(S, 32, 64);
+    if constexpr (KS == 2) {                                         // fold the second group's state into the first's (exponents in the base-2 domain, as inside the loop)
+        __syncthreads();                                             // everybody is past the ring: it becomes the staging area
+        float * const mg = (float *) lds + wq * (64 * (NDB * 16 + 2));
+        if (grp == 1) {
+#pragma unroll
+            for (int db = 0; db < NDB; ++db)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) mg[(db * 16 + e) * 64 + lane] = acc_o[db][e];
+            mg[(NDB * 16) * 64 + lane] = M; mg[(NDB * 16 + 1) * 64 + lane] = S;
+        }
+        __syncthreads();
+        if (grp == 1) return;
+        const float M1 = mg[(NDB * 16) * 64 + lane], S1 = mg[(NDB * 16 + 1) * 64 + lane];
+        const float Mn = fmaxf(M, M1), Mu = Mn == -INFINITY ? 0.0f : Mn;
+        const float a0 = __builtin_amdgcn_exp2f(M - Mu), a1 = __builtin_amdgcn_exp2f(M1 - Mu);
+        S = S * a0 + S1 * a1; M = Mn;
+#pragma unroll
+        for (int db = 0; db < NDB; ++db)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc_o[db][e] = acc_o[db][e] * a0 + mg[(db * 16 + e) * 64 + lane] * a1;
+    }
     float osc = 1.0f;
     if (a.sinks) {
         const float sk = a.sinks[h] * FM_LOG2E;
@@ -1208,12 +1240,20 @@ static void launch_fm(const fa_dev & a, hipStream_t st) {
             static const bool no_dma64 = getenv("MI355X_FA_NO_DMA64") != nullptr;
             if (!no_dma && !no_dma64 && !a.vt && a.nkv >= 128 && a.knb1 % 16 == 0 && a.vnb1 % 16 == 0 && a.knb2 % 16 == 0 && a.vnb2 % 16 == 0 && a.knb3 % 16 == 0 && a.vnb3 % 16 == 0 &&
                 (((uintptr_t) a.k | (uintptr_t) a.v) & 15) == 0) {
-                constexpr int lds64 = FD_NST * 2 * FM_KT * 2 * 64 + FM_MAXT / 8 + 4 * (FM_MAXT / 16) * 4;
+                constexpr int lds64 = FD_NST * 2 * FM_KT * 2 * 64 + FM_MAXT / 8 + 4 * (FM_MAXT / 16) * 4, lds64x2 = lds64 + FD_NST * 2 * FM_KT * 2 * 64;
                 static bool attr[64] = {};
                 int dev = 0; HIP_CHECK(hipGetDevice(&dev));
-                if (dev < 0 || dev >= 64 || !attr[dev]) { HIP_CHECK(hipFuncSetAttribute((const void *) k_fattn_dma<64, 0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds64)); if (dev >= 0 && dev < 64) attr[dev] = true; }
+                if (dev < 0 || dev >= 64 || !attr[dev]) {
+                    HIP_CHECK(hipFuncSetAttribute((const void *) k_fattn_dma<64, 0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds64));
+                    HIP_CHECK(hipFuncSetAttribute((const void *) k_fattn_dma<64, 0, 1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds64x2));
+                    if (dev >= 0 && dev < 64) attr[dev] = true;
+                }
                 ++g_fd_launches;
-                k_fattn_dma<64, 0, 1><<<dim3((unsigned) (nqt4 * a.nh * a.ns)), dim3(256), lds64, st>>>(a, nqt4);
+                static const bool no_ks2 = getenv("MI355X_FA_DMA64_NO_KS2") != nullptr;
+                const dim3 grid((unsigned) (nqt4 * a.nh * a.ns));
+                static const int64_t ks2_max = getenv("MI355X_FA_DMA64_KS2_MAX_WGS") ? atoll(getenv("MI355X_FA_DMA64_KS2_MAX_WGS")) : 257;
+                if (!no_ks2 && (int64_t) grid.x < ks2_max && a.nkv >= 512) k_fattn_dma<64, 0, 1, 2><<<grid, dim3(512), lds64x2, st>>>(a, nqt4);      // fewer workgroups than CUs: two waves per SIMD from a split of the keys
+                else                                                   k_fattn_dma<64, 0, 1><<<grid, dim3(256), lds64, st>>>(a, nqt4);
                 return;
             }
         }
