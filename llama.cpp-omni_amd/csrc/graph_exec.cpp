@@ -1750,7 +1750,9 @@ static bool exec_attn_f32(exec_state & s, int i) {
                 cs->nb[0] == 4 && cs->nb[1] == M2->nb[2] && cs->nb[2] == M2->nb[1] && (ns == 1 || cs->nb[3] == (size_t) H * M2->nb[2])) {
                 bool inner_ok = true;
                 for (const ggml_tensor * w = cs; w != M2; w = w->src[0]) if (is_out(s, w)) inner_ok = false;
-                if (inner_ok) { out = C; ci = cu; a.dst = C->data; a.d_nb_h = C->nb[1]; a.d_nb_q = C->nb[2]; a.d_nb_s = C->nb[3]; a.H = H; }
+                if (inner_ok && nelements(C) == D * HB * nq) {           // (the CONT may carry any shape of the same elements -- ggml_cont_2d in the encoders: strides of the dense [D, H, nq, ns] order)
+                    out = C; ci = cu; a.dst = C->data; a.d_nb_h = (size_t) D * 4; a.d_nb_q = (size_t) D * (size_t) H * 4; a.d_nb_s = (size_t) D * (size_t) H * (size_t) nq * 4; a.H = H;
+                }
             }
         }
     }

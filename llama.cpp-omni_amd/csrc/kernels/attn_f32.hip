@@ -32,18 +32,23 @@ __global__ void __launch_bounds__(256) k_attn_f32(const attn_f32_dev a) {
     // ---- 1. scores
     {
         const int qr = q0 + r16 < a.nq ? q0 + r16 : a.nq - 1;
-        float4 qv[D / 16];
+        constexpr int NJ = (D + 15) / 16;                 // (D % 4 == 0: a quad of the last, partial 16-wide step is inside or outside the head as a whole; outside -> zeros)
+        float4 qv[NJ];
 #pragma unroll
-        for (int j = 0; j < D / 16; ++j) qv[j] = *(const float4 *) (Q + (size_t) qr * a.q_rs + (size_t) (16 * j + 4 * gq) * 4);
+        for (int j = 0; j < NJ; ++j) {
+            const int d = 16 * j + 4 * gq;
+            qv[j] = *(const float4 *) (Q + (size_t) qr * a.q_rs + (size_t) (d < D ? d : 0) * 4);
+            if (d >= D) qv[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
         // four 16-key tiles of this wave at a time, every operand quad requested before the first MFMA (the loads are the latency here, not the arithmetic)
         for (int kb = wave * 16; kb < a.nkv; kb += 256) {
-            float4 kv[4][D / 16];
+            float4 kv[4][NJ];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int k0 = kb + 64 * u;
                 const int kr = k0 + r16 < a.nkv ? k0 + r16 : a.nkv - 1;
 #pragma unroll
-                for (int j = 0; j < D / 16; ++j) kv[u][j] = *(const float4 *) (K + (size_t) kr * a.k_rs + (size_t) (16 * j + 4 * gq) * 4);
+                for (int j = 0; j < NJ; ++j) { const int d = 16 * j + 4 * gq; kv[u][j] = *(const float4 *) (K + (size_t) kr * a.k_rs + (size_t) (d < D ? d : 0) * 4); }      // (Q's zeros cover the quads past D)
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
@@ -51,7 +56,7 @@ __global__ void __launch_bounds__(256) k_attn_f32(const attn_f32_dev a) {
                 if (k0 >= a.nkv) break;
                 acc4 acc = { 0.0f, 0.0f, 0.0f, 0.0f };
 #pragma unroll
-                for (int j = 0; j < D / 16; ++j) {
+                for (int j = 0; j < NJ; ++j) {
                     acc = __builtin_amdgcn_mfma_f32_16x16x4f32(qv[j].x, kv[u][j].x, acc, 0, 0, 0);
                     acc = __builtin_amdgcn_mfma_f32_16x16x4f32(qv[j].y, kv[u][j].y, acc, 0, 0, 0);
                     acc = __builtin_amdgcn_mfma_f32_16x16x4f32(qv[j].z, kv[u][j].z, acc, 0, 0, 0);
@@ -90,7 +95,8 @@ __global__ void __launch_bounds__(256) k_attn_f32(const attn_f32_dev a) {
     // ---- 3. O = P . V: wave w the head slice d0 = 16 w .. (D = 64: one slice per wave)
     for (int d0 = wave * 16; d0 < D; d0 += 64) {
         acc4 acc = { 0.0f, 0.0f, 0.0f, 0.0f };
-        const char * vrow = VT + (size_t) (d0 + r16) * a.v_rs;
+        const bool d_ok = d0 + r16 < D;                  // (head sizes that are not multiples of 16: the last slice's spare rows re-read row D - 1 and are not stored)
+        const char * vrow = VT + (size_t) (d_ok ? d0 + r16 : D - 1) * a.v_rs;
         for (int kb = 0; kb < a.nkv; kb += 128) {        // eight 16-key steps at a time, the quads of V^T requested up front
             float4 vq[8];
 #pragma unroll
@@ -123,14 +129,14 @@ __global__ void __launch_bounds__(256) k_attn_f32(const attn_f32_dev a) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const int q = q0 + 4 * gq + e;
-            if (q < a.nq) *(float *) (a.dst + (size_t) (d0 + r16) * 4 + (size_t) q * a.d_nb_q + (size_t) h * a.d_nb_h + (size_t) sidx * a.d_nb_s) = acc[e];
+            if (q < a.nq && d_ok) *(float *) (a.dst + (size_t) (d0 + r16) * 4 + (size_t) q * a.d_nb_q + (size_t) h * a.d_nb_h + (size_t) sidx * a.d_nb_s) = acc[e];
         }
     }
 }
 
 bool attn_f32_ok(const attn_f32_args & a) {
     static const bool off = getenv("MI355X_NO_ATTN_F32") != nullptr;
-    if (off || a.D != 64 || a.nq < 1 || a.nkv < 1 || a.nkv > 4096 || a.HB < 1 || a.HB > 65535 || a.H < 1) return false;
+    if (off || (a.D != 64 && a.D != 72 && a.D != 80 && a.D != 96 && a.D != 128) || a.nq < 1 || a.nkv < 1 || a.nkv > 4096 || a.HB < 1 || a.HB > 65535 || a.H < 1) return false;
     if ((((uintptr_t) a.q | a.q_rs | a.q_bs | (uintptr_t) a.k | a.k_rs | a.k_bs) & 15) != 0) return false;
     return (((uintptr_t) a.dst | (uintptr_t) a.vt | a.v_rs | a.v_bs) & 3) == 0;
 }
@@ -143,16 +149,25 @@ void attn_f32(const attn_f32_args & a, hipStream_t st) {
     d.nq = (int) a.nq; d.nkv = (int) a.nkv; d.H = (int) a.H; d.ldp = (int) (((a.nkv + 63) / 64) * 64 + 4);
     d.s1 = a.s1; d.b1 = a.b1; d.s2 = a.s2; d.has_scale = a.has_scale ? 1 : 0;
     const int lds = 16 * d.ldp * 4;
-    static int attr_lds[64] = {};
-    int dev = 0; HIP_CHECK(hipGetDevice(&dev));
-    if (lds > 65536 && (dev < 0 || dev >= 64 || attr_lds[dev] < lds)) {
-        HIP_CHECK(hipFuncSetAttribute((const void *) k_attn_f32<64, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        HIP_CHECK(hipFuncSetAttribute((const void *) k_attn_f32<64, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        if (dev >= 0 && dev < 64) attr_lds[dev] = lds;
-    }
     const bool v4 = a.nkv % 4 == 0 && (((uintptr_t) a.vt | a.v_rs | a.v_bs) & 15) == 0;
     const dim3 grid((unsigned) ((a.nq + 15) / 16), (unsigned) a.HB);
-    if (v4) k_attn_f32<64, true><<<grid, dim3(256), lds, st>>>(d); else k_attn_f32<64, false><<<grid, dim3(256), lds, st>>>(d);
+    int dev = 0; HIP_CHECK(hipGetDevice(&dev));
+    auto go = [&](auto k4, auto k1, int slot) {
+        static int attr_lds[8][64] = {};
+        if (lds > 65536 && (dev < 0 || dev >= 64 || attr_lds[slot][dev] < lds)) {
+            HIP_CHECK(hipFuncSetAttribute((const void *) k4, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+            HIP_CHECK(hipFuncSetAttribute((const void *) k1, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+            if (dev >= 0 && dev < 64) attr_lds[slot][dev] = lds;
+        }
+        if (v4) k4<<<grid, dim3(256), lds, st>>>(d); else k1<<<grid, dim3(256), lds, st>>>(d);
+    };
+    switch ((int) a.D) {
+        case 64:  go(k_attn_f32<64, true>,  k_attn_f32<64, false>,  0); break;
+        case 72:  go(k_attn_f32<72, true>,  k_attn_f32<72, false>,  1); break;      // SigLip2: 1152 / 16 heads
+        case 80:  go(k_attn_f32<80, true>,  k_attn_f32<80, false>,  2); break;
+        case 96:  go(k_attn_f32<96, true>,  k_attn_f32<96, false>,  3); break;
+        default:  go(k_attn_f32<128, true>, k_attn_f32<128, false>, 4); break;
+    }
 }
 
 } // namespace mi

@@ -338,13 +338,14 @@ def test_t2w_modulate_chain_with_per_batch_rows_vs_reference_backend(pkg, be, re
     assert k <= 3, k                                                     # NORM, modulate chain, gate chain
 
 
-@pytest.mark.parametrize("nq,nkv,H,ns,scale_node,cont", [(50, 200, 8, 2, True, True), (56, 206, 8, 2, True, True), (17, 36, 3, 1, False, True), (33, 64, 2, 2, True, False), (9, 5, 1, 1, True, True), (20, 1030, 2, 1, True, True)])
-def test_t2w_f32_attention_chain_in_one_launch_vs_reference_backend(pkg, be, ref_be, nq, nkv, H, ns, scale_node, cont):
+@pytest.mark.parametrize("D,nq,nkv,H,ns,scale_node,cont", [(64, 50, 200, 8, 2, True, True), (64, 56, 206, 8, 2, True, True), (64, 17, 36, 3, 1, False, True), (64, 33, 64, 2, 2, True, False), (64, 9, 5, 1, 1, True, True),
+                                                             (64, 20, 1030, 2, 1, True, True), (72, 150, 1024, 4, 1, False, True), (72, 33, 77, 2, 2, True, True), (80, 40, 100, 2, 1, False, False), (128, 20, 64, 2, 1, True, True)])
+def test_t2w_f32_attention_chain_in_one_launch_vs_reference_backend(pkg, be, ref_be, D, nq, nkv, H, ns, scale_node, cont):
     """K.Q -> SCALE -> SOFT_MAX -> V^T.P -> RESHAPE / PERMUTE -> CONT, all f32, head size 64 (the Token2Wav DiT attention, token2wav-impl.cpp:406-439: 50..56 frames
     against 200..206 keys, 8 heads x batch 2): one attn_f32 launch on the plug-in, the reference CPU backend on the same graph is the check (f32 products and sums on
     both sides, another summation order: NMSE 1e-10)."""
     F32 = pkg.GGML_TYPE_F32
-    D, HB = 64, H * ns
+    HB = H * ns                                                        # (head size 72: SigLip2's 1152 / 16 heads, spelled the same way by tools/omni/vision.cpp:648-703)
     rng = np.random.default_rng(nq * 7 + nkv)
     qv = rng.standard_normal((HB, nq, D)).astype(np.float32)
     kv = rng.standard_normal((HB, nkv, D)).astype(np.float32)
@@ -359,7 +360,7 @@ def test_t2w_f32_attention_chain_in_one_launch_vs_reference_backend(pkg, be, ref
             kq = c.scale(kq, float(sc))
         p = c.soft_max_ext(kq, None, 1.0 if scale_node else float(sc))
         o = c.mul_mat(vt, p)                                               # [D, nq, HB]
-        out = c.cont(c.permute(c.reshape(o, D, nq, H, ns), 0, 2, 1, 3)) if cont else o
+        out = (c.cont(c.permute(c.reshape(o, D, nq, H, ns), 0, 2, 1, 3), D * H, nq * ns) if D == 72 else c.cont(c.permute(c.reshape(o, D, nq, H, ns), 0, 2, 1, 3))) if cont else o      # (72: ggml_cont_2d, as vision.cpp)
         out.t.flags |= 2
         c.alloc()
         for t, v in ((q, qv), (k, kv), (vt, vv)):

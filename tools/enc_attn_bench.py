@@ -17,14 +17,22 @@ def main():
     be = pkg.backend(0)
     D = int(os.environ.get("HD", "64"))
     nq, nkv, nh = int(os.environ.get("NQ", "1500")), int(os.environ.get("NKV", "1500")), int(os.environ.get("NH", "16"))
+    nhkv = int(os.environ.get("NHKV", str(nh)))                  # GQA: KV heads
+    causal = os.environ.get("MASK", "") == "causal"              # a prefill ubatch's mask (the last nq cells of the view are the ubatch's own)
     c = Context(be)
     q = c.new_tensor(GGML_TYPE_F32, D, nq, nh)
-    sets = [(c.new_tensor(GGML_TYPE_F16, D, nkv, nh), c.new_tensor(GGML_TYPE_F16, D, nkv, nh)) for _ in range(4)]
+    m = c.new_tensor(GGML_TYPE_F16, nkv, nq) if causal else None
+    sets = [(c.new_tensor(GGML_TYPE_F16, D, nkv, nhkv), c.new_tensor(GGML_TYPE_F16, D, nkv, nhkv)) for _ in range(4)]
     nodes = 24
     for i in range(nodes):
         k, v = sets[i % 4]
-        c.flash_attn_ext(q, k, v, None, 1.0 / np.sqrt(D))
+        c.flash_attn_ext(q, k, v, m, 1.0 / np.sqrt(D))
     c.alloc()
+    if causal:
+        mk = np.zeros((nq, nkv), np.float16)
+        for i in range(nq):
+            mk[i, nkv - nq + i + 1:] = -np.inf
+        be.tensor_set(m, mk)
     rng = np.random.default_rng(0)
     be.tensor_set(q, rng.standard_normal(q.nelements()).astype(np.float32))
     for k, v in sets:
@@ -41,7 +49,7 @@ def main():
         be.synchronize()
         best = min(best, be.elapsed_ms(a, b))
     us = best * 1e3 / nodes
-    print(f"D={D} nq={nq} nkv={nkv} heads={nh}: {us:.2f} us per node, {4.0 * D * nq * nkv * nh / us * 1e-6:.1f} TFLOP/s ({int(be.get_stat('kernels_last_graph'))} launches / {nodes})", flush=True)
+    print(f"D={D} nq={nq} nkv={nkv} heads={nh}/{nhkv}{' causal' if causal else ''}: {us:.2f} us per node, {4.0 * D * nq * nkv * nh / us * 1e-6:.1f} TFLOP/s ({int(be.get_stat('kernels_last_graph'))} launches / {nodes})", flush=True)
     c.free()
 
 
