@@ -2627,6 +2627,103 @@ static bool exec_concat_tail(exec_state & s, int i) {
     return true;
 }
 
+// The HiFT vocoder's 1-D convolutions over a T-fastest signal (token2wav-impl.cpp:5136-5235): IM2COL(F32) -> [CONT] -> MUL_MAT against the reshaped kernel ->
+// REPEAT(bias) -> ADD, five launches around a [KW*Cin, T] matrix of tens of megabytes.  One conv1d_tc launch (t2w_ops.hip) reads x itself; the kernel transposed once to
+// [KW*Cin][Cout] is a resident image.  `i` is the IM2COL; the nodes must be the launches right behind one another.
+static bool exec_conv1d_tc(exec_state & s, int i) {
+    static const bool off = getenv("MI355X_NO_CONV1D_TC") != nullptr;
+    if (off || !s.c->opt_fusion) return false;
+    ggml_cgraph * g = s.g;
+    const ggml_tensor * n = g->nodes[i];
+    auto plain = [](const ggml_tensor * t) { return t && t->type == GGML_TYPE_F32 && t->data && is_contiguous(t); };
+    if (n->op != GGML_OP_IM2COL || !plain(n) || is_out(s, n) || n->ne[2] != 1 || n->ne[3] != 1) return false;
+    const ggml_tensor * Wk = n->src[0], * x = n->src[1];
+    const int32_t * ip = n->op_params;
+    if (!plain(Wk) || !plain(x) || ip[0] != 1 || ip[6] != 0 || ip[4] < 1 || ip[2] < 0) return false;
+    const int64_t KW = Wk->ne[0], Cin = Wk->ne[1], Cout = Wk->ne[2], T = x->ne[0], OW = n->ne[1];
+    if (Wk->ne[3] != 1 || x->ne[1] != Cin || x->ne[2] != 1 || x->ne[3] != 1 || n->ne[0] != KW * Cin || Wk->op != GGML_OP_NONE || Wk->view_src || !Wk->buffer || Wk->buffer->usage != GGML_BACKEND_BUFFER_USAGE_WEIGHTS) return false;
+    if (T * Cin >= (1ll << 31) || KW * Cin * Cout >= (1ll << 31) || OW * Cout >= (1ll << 31)) return false;
+    // the launches behind the IM2COL, in order; the reference puts a CONT behind nearly every reshape (of the columns, of the KERNEL, of the product, of the bias)
+    auto root_of = [](const ggml_tensor * t) { while (t && t->op == GGML_OP_RESHAPE) t = t->src[0]; return t; };
+    int taken[8]; int nt = 0;
+    int j = next_real_node(s, i);
+    const ggml_tensor * col = n, * wsrc = Wk;
+    if (j > i && g->nodes[j]->op == GGML_OP_CONT && root_of(g->nodes[j]->src[0]) == n && sole_user(s, n) == j) {
+        const ggml_tensor * c1 = g->nodes[j];
+        if (!plain(c1) || nelements(c1) != nelements(n) || is_out(s, c1) || c1->view_src) return false;
+        taken[nt++] = j; col = c1; j = next_real_node(s, j);
+    }
+    if (j > i && g->nodes[j]->op == GGML_OP_CONT && root_of(g->nodes[j]->src[0]) == Wk) {                 // a copy of the (reshaped) kernel: not needed
+        const ggml_tensor * c2 = g->nodes[j];
+        if (!plain(c2) || nelements(c2) != nelements(Wk) || is_out(s, c2) || c2->view_src || !is_contiguous(c2->src[0])) return false;
+        taken[nt++] = j; wsrc = c2; j = next_real_node(s, j);
+    }
+    if (j <= i) return false;
+    const int mi_ = j;
+    const ggml_tensor * m = g->nodes[mi_];
+    if (m->op != GGML_OP_MUL_MAT || !plain(m) || m->ne[0] != OW || m->ne[1] != Cout || m->ne[2] != 1 || m->ne[3] != 1 || root_of(m->src[0]) != col || sole_user(s, col) != mi_) return false;
+    const ggml_tensor * kr = m->src[1];
+    if (!kr || kr->type != GGML_TYPE_F32 || root_of(kr) != wsrc || kr->ne[0] != KW * Cin || kr->ne[1] != Cout || kr->ne[2] != 1 || !is_contiguous(kr) || (wsrc != Wk && sole_user(s, wsrc) != mi_)) return false;
+    taken[nt++] = mi_;
+    // how far the launch reaches: up to the ADD of the bias (preferred), the product's CONT, or the product itself -- the first of them whose buffer does not sit on x
+    // (ggml-alloc placed those buffers for later points of the graph, where x may be dead; it is not dead here)
+    const int nt_m = nt;                                              // taken[0 .. nt_m): up to and including the MUL_MAT
+    const ggml_tensor * out = m; const float * bias = nullptr;
+    const ggml_tensor * y = m; int n_y = 0, yq = -1;
+    const ggml_tensor * out_add = nullptr; const float * bias_add = nullptr; int add_taken[3], n_add = 0;
+    if (!is_out(s, m)) {
+        int q = next_real_node(s, mi_);
+        if (q > mi_ && g->nodes[q]->op == GGML_OP_CONT && root_of(g->nodes[q]->src[0]) == m && sole_user(s, m) == q && plain(g->nodes[q]) && nelements(g->nodes[q]) == nelements(m) && !g->nodes[q]->view_src) {
+            y = g->nodes[q]; yq = q; n_y = 1; q = next_real_node(s, q);
+        }
+        // the bias: [CONT of] a [1, Cout] reshape of a vector -> REPEAT to the product's shape -> ADD
+        const ggml_tensor * bvec = nullptr, * bcont = nullptr; int bq = -1;
+        if (q > mi_ && g->nodes[q]->op == GGML_OP_CONT && !is_out(s, g->nodes[q]) && plain(g->nodes[q]) && nelements(g->nodes[q]) == Cout) {
+            const ggml_tensor * r0 = root_of(g->nodes[q]->src[0]);
+            if (r0 && r0->type == GGML_TYPE_F32 && r0->data && is_contiguous(r0) && nelements(r0) == Cout && is_contiguous(g->nodes[q]->src[0])) { bcont = g->nodes[q]; bvec = r0; bq = q; q = next_real_node(s, q); }
+        }
+        if (q > mi_ && g->nodes[q]->op == GGML_OP_REPEAT && !is_out(s, y)) {
+            const ggml_tensor * r = g->nodes[q], * rs = root_of(r->src[0]);
+            if (!bcont && rs && rs->type == GGML_TYPE_F32 && rs->data && is_contiguous(rs) && nelements(rs) == Cout && is_contiguous(r->src[0])) bvec = rs;
+            const bool src_ok = bcont ? (rs == bcont && sole_user(s, bcont) == q) : (bvec != nullptr);
+            const int a0 = sole_user(s, r);
+            if (src_ok && bvec && a0 > q && next_real_node(s, q) == a0 && sole_user(s, y) == a0 && plain(r) && !is_out(s, r) && r->ne[0] == OW && r->ne[1] == Cout && nelements(r) == OW * Cout) {
+                const ggml_tensor * ad = g->nodes[a0];
+                if (ad->op == GGML_OP_ADD && ad->src[1] == r && plain(ad) && nelements(ad) == OW * Cout && ad->ne[0] == OW && root_of(ad->src[0]) == y) {
+                    out_add = ad; bias_add = (const float *) bvec->data;
+                    if (bq >= 0) add_taken[n_add++] = bq;
+                    add_taken[n_add++] = q; add_taken[n_add++] = a0;
+                }
+            }
+        }
+    }
+    if (out_add && !overlap(range_of(out_add), range_of(x))) {
+        out = out_add; bias = bias_add;
+        if (n_y) taken[nt++] = yq;
+        for (int t = 0; t < n_add; ++t) taken[nt++] = add_taken[t];
+    } else if (n_y && !overlap(range_of(y), range_of(x))) { out = y; taken[nt++] = yq; }
+    else if (!overlap(range_of(m), range_of(x))) { out = m; nt = nt_m; }
+    else return false;
+    bool created = false;
+    float * wt = (float *) shadow_get_or_create(s.c->device, Wk->data, nbytes(Wk), /*type: transposed conv kernel*/ 2000, 2 * KW * Cin, Cout, (size_t) KW * 4 + 1, s.st, s.capturing, &created);
+    if (!wt) return false;
+    if (s.pr.A) materialise_reduce(s);
+    if (s.prm.n) materialise_group(s);
+    if (s.pn.m && s.pn.m == x) materialise_norm(s);
+    if (created) {
+        prof_scope ps(s, "conv_weight_rows", 0);
+        conv1d_weight_t((const float *) Wk->data, wt, (int) (KW * Cin), (int) Cout, s.st); ++s.n_kernels;
+        shadow_mark_ready((uint16_t *) wt, s.st);
+    }
+    {
+        prof_scope ps(s, "conv1d_tc", 2.0 * (double) KW * (double) Cin * (double) Cout * (double) OW);
+        conv1d_tc((const float *) x->data, wt, bias, (float *) out->data, (int) T, (int) OW, (int) Cin, (int) Cout, (int) KW, ip[4], ip[2], s.st); ++s.n_kernels;
+    }
+    for (int t = 0; t < nt; ++t) { s.done[taken[t]] = 1; ++s.n_fused; }
+    note_write(s, out);
+    return true;
+}
+
 void run_nodes(exec_state & s, ggml_cgraph * g) {
     static FILE * const launch_log = getenv("MI355X_LAUNCH_LOG") ? fopen(getenv("MI355X_LAUNCH_LOG"), "w") : nullptr;      // one line per node that launched: what a graph's launches are made of (tools/launch_ngrams.py)
     s.g = g;
@@ -2696,6 +2793,7 @@ void run_nodes(exec_state & s, ggml_cgraph * g) {
             for (int k = 0; k < 3 && n->src[k]; ++k) fprintf(launch_log, " s%d:op%d%s[%lld,%lld,%lld,%lld]", k, (int) n->src[k]->op, is_contiguous(n->src[k]) ? "c" : "n", (long long) n->src[k]->ne[0], (long long) n->src[k]->ne[1], (long long) n->src[k]->ne[2], (long long) n->src[k]->ne[3]);
             fprintf(launch_log, "\n");
         } } ll_g{ s, g, i, s.n_kernels, s.n_fused };
+        if (g->nodes[i]->op == GGML_OP_IM2COL && exec_conv1d_tc(s, i)) continue;
         if (g->nodes[i]->op == GGML_OP_CONT && exec_causal_conv(s, i)) continue;
         if ((g->nodes[i]->op == GGML_OP_CONT || g->nodes[i]->op == GGML_OP_CONCAT) && exec_concat_tail(s, i)) continue;
         if (g->nodes[i]->op == GGML_OP_MUL && exec_gate_norm(s, i)) continue;

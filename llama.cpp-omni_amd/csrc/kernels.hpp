@@ -161,6 +161,8 @@ void scale_f32(const float * x, float * y, int64_t n, float s, float b, hipStrea
 // ---- ops of the Token2Wav graphs (kernels/t2w_ops.hip; reference tools/omni/token2wav/token2wav-impl.cpp)
 // SQR / SQRT / LOG / SIN / COS / CLAMP(p0 = min, p1 = max) / LEAKY_RELU(p0 = slope) on dense f32
 void math_f32(int op, const float * x, float * y, int64_t n, float p0, float p1, hipStream_t st);
+void conv1d_weight_t(const float * w, float * y, int KK, int Cout, hipStream_t st);               // [Cout][KK] -> [KK][Cout] (exec_conv1d_tc)
+void conv1d_tc(const float * x, const float * wt, const float * bias, float * y, int T, int OW, int Cin, int Cout, int KW, int dil, int pad, hipStream_t st);      // y[t + OW co] = bias[co] + sum_{c,k} w[k, c, co] x[t + k dil - pad + T c]
 void conv1d_weight_rows(const float * w, float * y, int KW, int C, int Cout, hipStream_t st);     // [KW, C, Cout] -> [Cout][KW][C] (exec_causal_conv)
 void concat(const tdesc & a, const tdesc & b, const tdesc & y, int dim, int elem_size, hipStream_t st);            // ops.cpp:1968-2009
 void repeat(const tdesc & x, const tdesc & y, int elem_size, hipStream_t st);                                      // ops.cpp:1637-1679

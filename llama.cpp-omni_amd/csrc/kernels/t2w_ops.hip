@@ -97,6 +97,76 @@ void conv1d_weight_rows(const float * w, float * y, int KW, int C, int Cout, hip
     k_conv1d_weight_rows<<<grid_for(total), dim3(256), 0, st>>>(w, y, KW, C, total);
 }
 
+// ---------------------------------------------------------------------------------------------- 1-D convolution over a T-fastest signal without the im2col matrix
+// The HiFT vocoder's convolutions (token2wav-impl.cpp:5136-5235: x [T, Cin], kernel [KW, Cin, Cout], stride 1, dilation d, zero padding p) are spelled IM2COL (a
+// [KW*Cin, T] f32 matrix: 21 MB for 64 channels x 11 taps x 7681 samples) -> CONT -> MUL_MAT -> REPEAT(bias) -> ADD: 40..60 us of copies around 0.7 GFLOP.  Here the
+// product is formed straight from x on v_mfma_f32_16x16x4f32 with i = output channel, j = sample: the B operand of contraction index kk = c * KW + k is x[t + k d - p + T c]
+// -- sixteen consecutive samples per lane group, coalesced -- and the A operand comes from the kernel transposed once to [KW*Cin][Cout] (resident image, coalesced over
+// the output channels).  One workgroup = 16 channels x 16 samples, its four waves a quarter of the contraction each.  f32 products and sums like the separate nodes, summed in
+// kk order; the bias added last, one rounding, as the ADD node does.
+struct conv1d_tc_dev { const float * x; const float * wt; const float * bias; float * y; int T, OW, Cin, Cout, KW, dil, pad; };
+__global__ void __launch_bounds__(256) k_conv1d_tc(const conv1d_tc_dev a) {
+    typedef float acc4 __attribute__((ext_vector_type(4)));
+    __shared__ float red[3][64 * 4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r16 = lane & 15, g = lane >> 4;
+    const int t0 = (int) blockIdx.x * 16, co0 = (int) blockIdx.y * 16;
+    const int KK = a.KW * a.Cin;
+    const int t = t0 + r16, co = co0 + r16;
+    const bool co_ok = co < a.Cout, t_ok = t < a.OW;
+    // the four waves split the contraction (chunks that are multiples of 4), folded through LDS in wave order: one 16 x 16 tile per workgroup keeps small signals
+    // (512 samples x 256 channels) on every CU and the chain per wave short
+    const int chunk = (((KK + 3) / 4) + 3) & ~3;
+    const int k_lo = wave * chunk, k_hi = k_lo + chunk < KK ? k_lo + chunk : KK;
+    const float inv_kw = 1.0f / (float) a.KW;              // kk -> (c, k) without a division or a loop: exact for kk < 2^20 (the + 0.5 keeps the product off the integers' edges)
+    acc4 acc = { 0.0f, 0.0f, 0.0f, 0.0f };
+    constexpr int U = 16;                                  // contraction steps requested before the first MFMA of a round (the loads are the latency here)
+    for (int kk0 = k_lo; kk0 < k_hi; kk0 += 4 * U) {
+        float xv[U], wv[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int kk = kk0 + 4 * u + g;
+            const int c = (int) (((float) kk + 0.5f) * inv_kw), k = kk - c * a.KW;
+            const int ti = t + k * a.dil - a.pad;
+            const bool ok = kk < k_hi;
+            const bool xin = ok && t_ok && ti >= 0 && ti < a.T;
+            xv[u] = a.x[xin ? ti + a.T * c : 0];
+            wv[u] = a.wt[(ok && co_ok) ? (size_t) kk * a.Cout + co : 0];
+            if (!xin) xv[u] = 0.0f;
+            if (!(ok && co_ok)) wv[u] = 0.0f;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[u], xv[u], acc, 0, 0, 0);
+    }
+    if (wave > 0) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) red[wave - 1][e * 64 + lane] = acc[e];
+    }
+    __syncthreads();
+    if (wave > 0) return;
+    // acc[e] = y[sample t0 + r16][channel co0 + 4 g + e]
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int oc = co0 + 4 * g + e;
+        float v = acc[e];
+#pragma unroll
+        for (int w = 0; w < 3; ++w) v += red[w][e * 64 + lane];
+        if (t_ok && oc < a.Cout) { if (a.bias) v = __fadd_rn(v, a.bias[oc]); a.y[t + (size_t) a.OW * oc] = v; }
+    }
+}
+__global__ void __launch_bounds__(256) k_conv1d_weight_t(const float * __restrict__ w, float * __restrict__ y, int KK, int Cout, int64_t total) {      // [Cout][KK] -> [KK][Cout]
+    T2W_LOOP(total) { const int64_t kk = t / Cout; const int co = (int) (t - kk * Cout); y[t] = w[kk + (int64_t) KK * co]; }
+}
+void conv1d_weight_t(const float * w, float * y, int KK, int Cout, hipStream_t st) {
+    const int64_t total = (int64_t) KK * Cout;
+    if (total == 0) return;
+    k_conv1d_weight_t<<<grid_for(total), dim3(256), 0, st>>>(w, y, KK, Cout, total);
+}
+void conv1d_tc(const float * x, const float * wt, const float * bias, float * y, int T, int OW, int Cin, int Cout, int KW, int dil, int pad, hipStream_t st) {
+    if (OW <= 0 || Cout <= 0) return;
+    const conv1d_tc_dev a = { x, wt, bias, y, T, OW, Cin, Cout, KW, dil, pad };
+    k_conv1d_tc<<<dim3((unsigned) ((OW + 15) / 16), (unsigned) ((Cout + 15) / 16)), dim3(256), 0, st>>>(a);
+}
+
 // ---------------------------------------------------------------------------------------------- REPEAT (ops.cpp:1637-1679): dst[i] = src[i mod ne_src]
 template <typename T>
 __global__ void __launch_bounds__(256) k_repeat(t4 x, t4 y) {

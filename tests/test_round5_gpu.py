@@ -381,3 +381,53 @@ def test_t2w_f32_attention_chain_in_one_launch_vs_reference_backend(pkg, be, ref
     print("NMSE vs the reference backend", e1, "vs float64", e2, "launches", n)
     assert e1 < 1e-10 and e2 < 1e-10, (e1, e2)
     assert n == 1, n
+
+
+@pytest.mark.parametrize("T,Cin,Cout,KW,dil,cont", [(1000, 64, 64, 11, 1, True), (1000, 64, 64, 11, 5, True), (7681, 64, 64, 7, 3, False), (77, 20, 24, 3, 2, True), (512, 256, 256, 7, 1, False), (33, 8, 100, 1, 1, True)])
+def test_t2w_vocoder_conv1d_without_im2col_vs_reference_backend(pkg, be, ref_be, T, Cin, Cout, KW, dil, cont):
+    """The HiFT vocoder's 'same' convolution over a T-fastest signal (token2wav-impl.cpp:5136-5235; llama.cpp-omni_amd/token2wav.py conv1d_same, with the CONT the
+    reference puts behind the im2col): IM2COL -> [CONT] -> MUL_MAT -> REPEAT(bias) -> ADD as ONE conv1d_tc launch on the plug-in (plus the kernel's transpose the first
+    time); the reference CPU backend on the same nodes and a float64 convolution are the checks."""
+    F32 = pkg.GGML_TYPE_F32
+    rng = np.random.default_rng(T + Cin + KW + dil)
+    xv = rng.standard_normal((Cin, T)).astype(np.float32)
+    wv = (rng.standard_normal((Cout, Cin, KW)) / np.sqrt(Cin * KW)).astype(np.float32)
+    bv = rng.standard_normal(Cout).astype(np.float32)
+    pad = (KW - 1) * dil // 2
+
+    def run(backend):
+        c = pkg.Context(backend)
+        x = c.new_tensor(F32, T, Cin, 1); w = c.new_tensor(F32, KW, Cin, Cout); b = c.new_tensor(F32, Cout)
+        col = c.im2col(w, x, 1, 0, pad, 0, dil, 0, False, F32)
+        if cont:                                                         # the reference's spelling: a CONT behind every reshape -- of the columns, the kernel, the product, the bias
+            col2 = c.cont(c.reshape(col, col.ne[0], col.ne[2] * col.ne[1]))
+            mm = c.mul_mat(col2, c.cont(c.reshape(w, KW * Cin, Cout)))
+            y = c.cont(c.reshape(mm, col.ne[1], Cout, col.ne[2]))
+            out = c.add(y, c.repeat(c.cont(c.reshape(b, 1, Cout, 1)), y))
+        else:
+            mm = c.mul_mat(c.reshape(col, col.ne[0], col.ne[2] * col.ne[1]), c.reshape(w, KW * Cin, Cout))
+            y = c.reshape(mm, col.ne[1], Cout, col.ne[2])
+            out = c.add(y, c.repeat(c.reshape(b, 1, Cout, 1), y))
+        c.alloc(usage=pkg.GGML_BACKEND_BUFFER_USAGE_WEIGHTS)
+        for t, v in ((x, xv), (w, wv), (b, bv)):
+            backend.tensor_set(t, v)
+        g = c.graph()
+        backend.graph_compute(g)
+        backend.graph_compute(g)                                         # (second submission: the transposed kernel is resident)
+        n = backend.get_stat("kernels_last_graph") if backend is be else 0
+        r = backend.tensor_get(out).copy()
+        c.free()
+        return r, n
+
+    want, _ = run(ref_be)
+    got, n = run(be)
+    OW = T + 2 * pad - dil * (KW - 1)
+    xp = np.zeros((Cin, T + 2 * pad)); xp[:, pad:pad + T] = xv
+    ref = np.zeros((Cout, OW))
+    for k in range(KW):
+        ref += wv[:, :, k].astype(np.float64) @ xp[:, k * dil:k * dil + OW]
+    ref += bv[:, None]
+    e1, e2 = nmse(got, want), nmse(got.reshape(Cout, OW), ref)
+    print("NMSE vs the reference backend", e1, "vs float64", e2, "launches", n)
+    assert e1 < 1e-10 and e2 < 1e-10, (e1, e2)
+    assert n == 1, n
