@@ -10,7 +10,7 @@ echo "## 1. oracle/_ref/t2w-min /tmp/t2w out.f32 gpu --windows 8 (MI355X_GRAPH_G
 MI355X_GRAPH_GPU_TIME=1 MI355X_LOG_STATS=1 oracle/_ref/t2w-min /tmp/t2w /tmp/t2w.f32 gpu --windows 8 2>&1 | grep -E "device time|kernels in last|host time|replayed graphs|^\{" | cut -c1-400
 echo
 echo "## 2. one matcher off at a time (6 windows; read the replayed 27194-node graphs)"
-for e in MI355X_NO_CONV_FUSE=1 MI355X_NO_CONCAT_TAIL=1 MI355X_NO_ATTN_F32=1 MI355X_NO_GEMM_F32_T16=1 MI355X_NO_NORM_FUSE=1 MI355X_NO_EW_CHAIN=1 MI355X_EW_CHAIN_NO_V1=1 MI355X_NO_CONT_SINK=1; do
+for e in MI355X_NO_CONV_FUSE=1 MI355X_NO_CONCAT_TAIL=1 MI355X_NO_ATTN_F32=1 MI355X_NO_GEMM_F32_T16=1 MI355X_NO_NORM_FUSE=1 MI355X_NO_GATE_NORM=1 MI355X_NO_CONV1D_TC=1 MI355X_NO_EW_CHAIN=1 MI355X_EW_CHAIN_NO_V1=1 MI355X_NO_CONT_SINK=1; do
   echo "-- $e"; env $e MI355X_GRAPH_GPU_TIME=1 MI355X_LOG_STATS=1 oracle/_ref/t2w-min /tmp/t2w /tmp/t2w.f32 gpu --windows 6 2>&1 | grep -E "device time|kernels in last|^\{" | cut -c1-330
 done
 echo
