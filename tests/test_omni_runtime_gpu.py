@@ -1,0 +1,90 @@
+"""SURVEY.md 8 row g1 (north_star: "omni_init / stream_prefill / stream_decode see a drop-in backend"): the REFERENCE's omni runtime -- tools/omni/omni.cpp
+with its LLM / TTS / Token2Wav threads, audition.cpp, token2wav-impl.cpp, libllama, common/{common,sampling,log}.cpp, all compiled from /root/reference by
+oracle/Makefile.ref `omnirt` -- as the CALLER of the plug-in.  tools/omni_min.cpp is omni-cli.cpp's main() on the public omni.h API (one omni_init, the
+`--test` loop of synchronous stream_prefill calls, one stream_decode, the wait for generation_done.flag); nothing of the orchestration is restated.
+The module set is synthetic (tools/make_synth_omni_set.py: full-size shapes, random weights, a byte-level BPE tokenizer carrying omni's special tokens, synthetic
+speech-band audio), so what is asserted is placement, completion and the reference's own timestamps -- not content."""
+import json
+import os
+import re
+import shutil
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIN = os.path.join(ROOT, "oracle", "_ref", "omni-min")
+LIB = os.path.join(ROOT, "llama.cpp-omni_amd", "csrc", "libggml-mi355x.so")
+
+
+def _read_wav(path):
+    b = open(path, "rb").read()
+    i = b.find(b"data")
+    assert b[:4] == b"RIFF" and i > 0
+    return np.frombuffer(b[i + 8:], "<i2").astype(np.float32) / 32768.0
+
+
+def run_omni_min(root, out_dir, max_tgt=24, plug=True, turns=1, timeout=1500):
+    env = dict(os.environ)
+    env.pop("GGML_BACKEND_PATH", None)
+    env.pop("MTMD_BACKEND_DEVICE", None)
+    if plug:
+        env["GGML_BACKEND_PATH"] = LIB
+        env["MI355X_LOG_STATS"] = "1"
+    cmd = [BIN, "-m", "gguf/MiniCPM-o-4_5-Q4_K_M.gguf", "--test", "case/audio_", str(turns), "-ngl", "99" if plug else "0", "--t2w-device", "gpu:0" if plug else "cpu",
+           "--max-tgt", str(max_tgt), "--out", out_dir, "-c", "4096"]
+    r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=timeout, errors="replace")
+    return r, r.stdout + "\n" + r.stderr
+
+
+def summarise(log):
+    """the reference's own timestamps: first-audio time (omni.cpp's "First Audio Response" line) and the Token2Wav thread's per-window lines"""
+    j = json.loads([l for l in log.splitlines() if l.startswith('{"harness"')][-1])
+    m = re.search(r"First Audio Response\): (\d+)ms", log)
+    j["reference_first_audio_ms"] = int(m.group(1)) if m else None
+    w = [(float(a), float(b)) for a, b in re.findall(r"wav_\d+\.wav \| ([0-9.]+)s audio \| ([0-9.]+)ms inference", log)]
+    j["t2w_windows"] = len(w)
+    j["t2w_ms_per_window_median"] = float(np.median([b for _, b in w])) if w else None
+    j["t2w_rtf_median"] = float(np.median([b / 1e3 / a for a, b in w])) if w else None
+    m = re.search(r"prompt eval time =\s*([0-9.]+) ms /\s*(\d+) tokens", log)
+    j["llm_prompt_tok_s"] = int(m.group(2)) / float(m.group(1)) * 1e3 if m else None
+    m = re.search(r"\n[^\n]*eval time =\s*([0-9.]+) ms /\s*(\d+) runs", log.split("prompt eval time")[-1])
+    j["llm_decode_tok_s"] = int(m.group(2)) / float(m.group(1)) * 1e3 if m else None
+    return j
+
+
+def test_reference_omni_runtime_drives_the_plugin(tmp_path):
+    if not os.path.exists(BIN):
+        pytest.skip("oracle/_ref/omni-min not built (make -f oracle/Makefile.ref omnirt)")
+    if shutil.disk_usage(str(tmp_path)).free < 9e9:
+        pytest.skip("needs 7 GB of scratch disk for the synthetic module set")
+    root = str(tmp_path / "set")
+    subprocess.run([sys.executable, os.path.join(ROOT, "tools", "make_synth_omni_set.py"), "-o", root], check=True, timeout=1800, capture_output=True)
+    try:
+        out_dir = str(tmp_path / "out")
+        r, log = run_omni_min(root, out_dir)
+        assert r.returncode == 0, log[-4000:]
+        # ---- placement: every module that asks the registry for a GPU got the plug-in's device
+        assert len(re.findall(r"offloaded 37/37 layers to GPU", log)) >= 1, log[-3000:]                   # the LLM (36 layers + output)
+        assert len(re.findall(r"offloaded 21/21 layers to GPU", log)) >= 1, log[-3000:]                   # the TTS decoder (20 layers + output)
+        assert re.search(r"CLIP using MI355X0 backend", log), "audition.cpp did not pick the plug-in"       # audition.cpp:254
+        assert "init_backend device=gpu:0, gpu_idx=0, backend=MI355X0" in log                              # Token2Wav's flow model (token2wav-impl.cpp:1951)
+        stats = re.findall(r"\[mi355x\] MI355X0: graphs eager=(\d+) captured=(\d+) replayed=(\d+)", log)
+        assert len(stats) >= 3 and sum(int(a) + int(b) + int(c) for a, b, c in stats) > 50, stats           # LLM + TTS + APM + T2W contexts all computed graphs
+        j = summarise(log)
+        assert "MI355X0" in j["registry_devices"]
+        # ---- completion: the three threads ran to the end and wrote audio
+        assert j["generation_done_s"] > 0 and j["first_wav_s"] > 0 and j["n_past_after_decode"] > j["n_past_after_prefill"] > 100
+        wav_dir = os.path.join(out_dir, "round_000", "tts_wav")
+        wavs = sorted(f for f in os.listdir(wav_dir) if f.endswith(".wav"))
+        assert len(wavs) >= 2 and j["t2w_windows"] >= 2
+        for f in wavs[:4]:
+            x = _read_wav(os.path.join(wav_dir, f))
+            assert x.size >= 12000 and np.isfinite(x).all() and float(x.std()) > 1e-3, (f, x.size, float(x.std()))
+        print("omni runtime on the plug-in:", json.dumps(j))
+    finally:
+        shutil.rmtree(root, ignore_errors=True)

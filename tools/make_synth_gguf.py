@@ -42,6 +42,57 @@ def kv_str(k, v):
 
 
 # ---- block formats needed by the separated-logits fixture (ggml-common.h:295-305, :330-335; dequantize_row_q4_K / _q6_K, ggml-quants.c:1352-1374, :1762-1791)
+def kv_i32(k, v):
+    return _s(k) + struct.pack("<Ii", 5, v)
+
+
+def kv_bool(k, v):
+    return _s(k) + struct.pack("<IB", 7, 1 if v else 0)
+
+
+def kv_arr_str(k, items):
+    return _s(k) + struct.pack("<IIQ", 9, 8, len(items)) + b"".join(_s(x) for x in items)
+
+
+def kv_arr_i32(k, a):
+    a = np.asarray(a, np.int32)
+    return _s(k) + struct.pack("<IIQ", 9, 5, a.size) + a.tobytes()
+
+
+# The special tokens tools/omni/omni.cpp looks up by text (omni_init :3964-3982, the prompt strings of :3518-3537 and stream_prefill :8800-8880) or by
+# hard-coded id (g_special_token_ids :4432-4441).  Ids follow Qwen3's tokenizer for the first block and omni.cpp's constants for the rest; tokens the
+# reference names without an id sit in free slots of the same range.
+OMNI_SPECIALS = {151643: "<|endoftext|>", 151644: "<|im_start|>", 151645: "<|im_end|>", 151667: "<think>", 151668: "</think>",
+                 151669: "<image>", 151670: "</image>", 151671: "<slice>", 151672: "</slice>", 151673: "<unit>", 151674: "</unit>",
+                 151675: "<|audio_start|>", 151676: "<|audio_end|>", 151677: "<|tts_pad|>", 151703: "<|tts_bos|>", 151704: "<|tts_eos|>",
+                 151705: "<|listen|>", 151706: "<|speak|>", 151717: "<|turn_eos|>", 151718: "<|chunk_eos|>", 151721: "<|chunk_tts_eos|>"}
+
+
+def gpt2_byte_chars():
+    """the byte -> printable-character table of byte-level BPE (what src/unicode.cpp unicode_byte_to_utf8 encodes)"""
+    bs = list(range(ord("!"), ord("~") + 1)) + list(range(0xA1, 0xAC + 1)) + list(range(0xAE, 0xFF + 1))
+    cs, n = bs[:], 0
+    for b in range(256):
+        if b not in bs:
+            bs.append(b); cs.append(256 + n); n += 1
+    return {b: chr(c) for b, c in zip(bs, cs)}
+
+
+def omni_vocab_kvs(V):
+    """a byte-level BPE tokenizer (tokenizer.ggml.model gpt2, pre-tokenizer qwen2) with NO learned merges but one: text tokenises to its bytes (ids 0-255),
+    ids 256.. are unique ASCII filler words a random-weight model may sample, the specials above are CONTROL tokens parsed from text"""
+    b2c = gpt2_byte_chars()
+    toks = [b2c[b] for b in range(256)] + ["ab"] + [f"w{i}" for i in range(257, V)]
+    types = np.ones(V, np.int32)                               # LLAMA_TOKEN_TYPE_NORMAL
+    for i, t in OMNI_SPECIALS.items():
+        assert i < V
+        toks[i] = t; types[i] = 3                               # LLAMA_TOKEN_TYPE_CONTROL
+    return [kv_str("tokenizer.ggml.model", "gpt2"), kv_str("tokenizer.ggml.pre", "qwen2"), kv_arr_str("tokenizer.ggml.tokens", toks),
+            kv_arr_i32("tokenizer.ggml.token_type", types), kv_arr_str("tokenizer.ggml.merges", ["a b"]),
+            kv_u32("tokenizer.ggml.eos_token_id", 151645), kv_u32("tokenizer.ggml.padding_token_id", 151643), kv_u32("tokenizer.ggml.bos_token_id", 151643),
+            kv_bool("tokenizer.ggml.add_bos_token", False)]
+
+
 def dequant_q4_K(rows, K):
     n, nb = rows.shape[0], K // 256
     b = rows.reshape(n, nb, 144)
@@ -126,6 +177,12 @@ def main():
                     help="greedy-decoding fixture with separated logits: S special tokens whose embedding dominates the residual stream, and whose "
                          "successor's lm-head row points along it (token s_i -> s_(i+1)): the winning logit leads by a margin far above any "
                          "summation-order noise, so two correct backends produce IDENTICAL greedy ids.  The ids are printed.")
+    ap.add_argument("--vocab", choices=["none", "omni"], default="none",
+                    help="omni: a byte-level BPE tokenizer carrying the special tokens tools/omni/omni.cpp looks up (SURVEY.md 8 row g1)")
+    ap.add_argument("--layers", type=int, default=0, help="override the layer count (CPU-sized runs of the omni harness)")
+    ap.add_argument("--omni-tts-extra", action="store_true",
+                    help="tts config: add the tensors omni.cpp's load_tts_weights_from_gguf reads beside the decoder (emb_code.0 / emb_text / projector_semantic.* / head_code.0; "
+                         "src/llama-model.cpp:2458-2472 skips them in the model loader) and leave output.weight out (the decoder's head is head_code)")
     args = ap.parse_args()
 
     load_pkg()
@@ -135,6 +192,8 @@ def main():
     TTS_TINY = dict(n_embd=256, n_layer=2, n_head=4, n_head_kv=4, head_dim=64, n_ff=512, n_vocab=512, rms_eps=1e-6, rope_base=1e4, n_ctx_orig=4096)
     is_llama = args.config.startswith("tts")
     cfg = {"8b": qwen3.QWEN3_8B, "tiny": qwen3.TINY, "tts": TTS, "tts-tiny": TTS_TINY}[args.config]
+    if args.layers:
+        cfg = dict(cfg, n_layer=args.layers)
     if args.types == "q4_k_m":
         types, embd_ty, ftype = qwen3.q4_k_m_types(cfg), GGML_TYPE_Q4_K, 15        # LLAMA_FTYPE_MOSTLY_Q4_K_M
     elif args.types == "f16":
@@ -148,7 +207,15 @@ def main():
     E, H, HK, D, F, V, L = cfg["n_embd"], cfg["n_head"], cfg["n_head_kv"], cfg["head_dim"], cfg["n_ff"], cfg["n_vocab"], cfg["n_layer"]
 
     # ---- tensor list in file order: (name, type, ne) with ne[0] the contiguous dimension
-    tensors = [("token_embd.weight", embd_ty, (E, V)), ("output_norm.weight", GGML_TYPE_F32, (E,)), ("output.weight", types["output"], (E, V))]
+    tensors = [("token_embd.weight", embd_ty, (E, V)), ("output_norm.weight", GGML_TYPE_F32, (E,))]
+    if args.omni_tts_extra:
+        assert is_llama and E == 768
+        tensors += [("emb_code.0.weight", GGML_TYPE_F16, (768, 6562)), ("emb_text.weight", GGML_TYPE_F16, (768, 152064)),
+                    ("projector_semantic.linear1.weight", GGML_TYPE_F16, (4096, 768)), ("projector_semantic.linear1.bias", GGML_TYPE_F32, (768,)),
+                    ("projector_semantic.linear2.weight", GGML_TYPE_F16, (768, 768)), ("projector_semantic.linear2.bias", GGML_TYPE_F32, (768,)),
+                    ("head_code.0.weight", GGML_TYPE_F16, (768, 6562))]
+    else:
+        tensors.append(("output.weight", types["output"], (E, V)))
     for il in range(L):
         t = types[il]
         tensors += [(f"blk.{il}.attn_norm.weight", GGML_TYPE_F32, (E,)), (f"blk.{il}.attn_q.weight", t["attn_q"], (E, H * D)),
@@ -171,7 +238,8 @@ def main():
            kv_u32(f"{arch}.feed_forward_length", F), kv_u32(f"{arch}.attention.head_count", H), kv_u32(f"{arch}.attention.head_count_kv", HK),
            kv_u32(f"{arch}.attention.key_length", D), kv_u32(f"{arch}.attention.value_length", D),
            kv_f32(f"{arch}.attention.layer_norm_rms_epsilon", cfg["rms_eps"]), kv_f32(f"{arch}.rope.freq_base", cfg["rope_base"]),
-           kv_u32(f"{arch}.vocab_size", V), kv_str("tokenizer.ggml.model", "no_vocab")]
+           kv_u32(f"{arch}.vocab_size", V)]
+    kvs += omni_vocab_kvs(V) if args.vocab == "omni" else [kv_str("tokenizer.ggml.model", "no_vocab")]
     if is_llama:
         kvs.append(kv_u32(f"{arch}.rope.dimension_count", D))
 
