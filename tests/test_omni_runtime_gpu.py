@@ -18,7 +18,7 @@ pytestmark = pytest.mark.gpu
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 BIN = os.path.join(ROOT, "oracle", "_ref", "omni-min")
-LIB = os.path.join(ROOT, "llama.cpp-omni_amd", "csrc", "libggml-mi355x.so")
+LIB = os.path.join(ROOT, "llama.cpp-omni_amd", "lib", "libggml-mi355x.so")
 
 
 def _read_wav(path):
@@ -50,6 +50,9 @@ def summarise(log):
     j["t2w_windows"] = len(w)
     j["t2w_ms_per_window_median"] = float(np.median([b for _, b in w])) if w else None
     j["t2w_rtf_median"] = float(np.median([b / 1e3 / a for a, b in w])) if w else None
+    tm = [(float(a), float(b)) for a, b in re.findall(r"\[timing\] call=\d+ tokens=\d+ final=\d token2mel=([0-9.]+)ms vocoder=([0-9.]+)ms", log)]
+    j["t2w_token2mel_ms_median"] = float(np.median([a for a, _ in tm])) if tm else None       # the flow model: on the device omni_init was given ("gpu:0")
+    j["t2w_vocoder_ms_median"] = float(np.median([b for _, b in tm])) if tm else None         # the vocoder: omni.cpp:3779 pins it to "cpu" whatever the device
     m = re.search(r"prompt eval time =\s*([0-9.]+) ms /\s*(\d+) tokens", log)
     j["llm_prompt_tok_s"] = int(m.group(2)) / float(m.group(1)) * 1e3 if m else None
     m = re.search(r"\n[^\n]*eval time =\s*([0-9.]+) ms /\s*(\d+) runs", log.split("prompt eval time")[-1])
@@ -71,14 +74,17 @@ def test_reference_omni_runtime_drives_the_plugin(tmp_path):
         # ---- placement: every module that asks the registry for a GPU got the plug-in's device
         assert len(re.findall(r"offloaded 37/37 layers to GPU", log)) >= 1, log[-3000:]                   # the LLM (36 layers + output)
         assert len(re.findall(r"offloaded 21/21 layers to GPU", log)) >= 1, log[-3000:]                   # the TTS decoder (20 layers + output)
-        assert re.search(r"CLIP using MI355X0 backend", log), "audition.cpp did not pick the plug-in"       # audition.cpp:254
         assert "init_backend device=gpu:0, gpu_idx=0, backend=MI355X0" in log                              # Token2Wav's flow model (token2wav-impl.cpp:1951)
-        stats = re.findall(r"\[mi355x\] MI355X0: graphs eager=(\d+) captured=(\d+) replayed=(\d+)", log)
-        assert len(stats) >= 3 and sum(int(a) + int(b) + int(c) for a, b, c in stats) > 50, stats           # LLM + TTS + APM + T2W contexts all computed graphs
+        # the plug-in's own account, printed as each backend context is freed: the LLM, the TTS decoder, the audio encoder (audition.cpp:241-249 asks the
+        # registry for a GPU backend; its logger is silent at this level) and Token2Wav's flow model each computed graphs on it
+        stats = [(int(a), int(b), int(c), int(d)) for a, b, c, d in re.findall(r"\[mi355x\] MI355X0: graphs eager=(\d+) captured=(\d+) replayed=(\d+), kernels in last graph=(\d+)", log)]
+        live = [s for s in stats if s[0] + s[1] + s[2] > 0]
+        assert len(live) >= 4 and any(s[3] > 2000 for s in live) and any(s[2] > 500 for s in live), stats        # (Token2Wav's 4 000-launch window graph; the TTS decoder's replays)
         j = summarise(log)
         assert "MI355X0" in j["registry_devices"]
         # ---- completion: the three threads ran to the end and wrote audio
-        assert j["generation_done_s"] > 0 and j["first_wav_s"] > 0 and j["n_past_after_decode"] > j["n_past_after_prefill"] > 100
+        assert j["first_wav_s"] > 0 and j["n_wav"] >= 2 and j["n_past_after_decode"] > j["n_past_after_prefill"] > 100
+        assert j["reference_first_audio_ms"] is not None and j["t2w_token2mel_ms_median"] is not None
         wav_dir = os.path.join(out_dir, "round_000", "tts_wav")
         wavs = sorted(f for f in os.listdir(wav_dir) if f.endswith(".wav"))
         assert len(wavs) >= 2 and j["t2w_windows"] >= 2

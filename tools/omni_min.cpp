@@ -92,16 +92,23 @@ int main(int argc, char ** argv) {
     if (!stream_decode(ctx, "./")) { fprintf(stderr, "stream_decode failed\n"); return 1; }
     const double decode_call_s = now_s() - t_dec0;
 
-    // omni-cli.cpp:362-372: wait for the Token2Wav thread's completion flag; the first wav chunk's appearance is the pipeline's time to first audio
-    double first_wav_s = -1, done_s = -1;
+    // omni-cli.cpp:362-372: wait for the Token2Wav thread's completion flag (at most 120 s, as there); the first wav chunk's appearance is the pipeline's
+    // time to first audio.  A random-weight LLM stops at max_tgt_len without an end token, so the flag may never be written: the wait also ends when the
+    // output directory has been quiet for 3 s after its first wav.
+    double first_wav_s = -1, done_s = -1, last_change = now_s();
+    int n_wav = 0;
     if (use_tts) {
-        const std::string wav_dir = out_dir + "/round_000/tts_wav", done = wav_dir + "/generation_done.flag", first = wav_dir + "/wav_0.wav";
+        const std::string wav_dir = out_dir + "/round_000/tts_wav", done = wav_dir + "/generation_done.flag";
         for (int i = 0; i < 6000; ++i) {
-            if (first_wav_s < 0 && file_exists(first)) first_wav_s = now_s() - t_dec0;
+            int k = n_wav;
+            while (file_exists(wav_dir + "/wav_" + std::to_string(k) + ".wav")) ++k;
+            if (k != n_wav) { if (n_wav == 0) first_wav_s = now_s() - t_dec0; n_wav = k; last_change = now_s(); }
             if (file_exists(done)) { done_s = now_s() - t_dec0; break; }
+            if (n_wav > 0 && now_s() - last_change > 3.0) break;
             usleep(20000);
         }
     }
+    const double quiet_s = last_change - t_dec0;
     omni_stop_threads(ctx);
     if (ctx->llm_thread.joinable()) ctx->llm_thread.join();
     if (use_tts && ctx->tts_thread.joinable()) ctx->tts_thread.join();
@@ -114,8 +121,8 @@ int main(int argc, char ** argv) {
         devs += std::string(i ? ", " : "") + "\"" + ggml_backend_dev_name(d) + "\"";
     }
     printf("{\"harness\": \"omni-min\", \"registry_devices\": [%s], \"n_inputs\": %d, \"init_s\": %.3f, \"prefill_s\": %.4f, \"prefill_each_s\": [%s], \"n_past_after_prefill\": %d, "
-           "\"n_past_after_decode\": %d, \"stream_decode_call_s\": %.4f, \"first_wav_s\": %.4f, \"generation_done_s\": %.4f, \"tts\": %s}\n",
-           devs.c_str(), n, init_s, prefill_s, per.c_str(), n_past_prefill, ctx->n_past, decode_call_s, first_wav_s, done_s, use_tts ? "true" : "false");
+           "\"n_past_after_decode\": %d, \"stream_decode_call_s\": %.4f, \"first_wav_s\": %.4f, \"generation_done_s\": %.4f, \"n_wav\": %d, \"last_wav_s\": %.4f, \"tts\": %s}\n",
+           devs.c_str(), n, init_s, prefill_s, per.c_str(), n_past_prefill, ctx->n_past, decode_call_s, first_wav_s, done_s, n_wav, quiet_s, use_tts ? "true" : "false");
     fflush(stdout);
     llama_perf_context_print(ctx->ctx_llama);
     omni_free(ctx);
