@@ -403,6 +403,46 @@ def via_reference_omni_modules():
         shutil.rmtree(tmp, ignore_errors=True)
 
 
+def via_reference_omni_runtime():
+    """BASELINE configs[3] (C4 TTFT) through the REFERENCE's omni runtime itself: oracle/_ref/omni-min = tools/omni/omni.cpp (omni_init, stream_prefill,
+    stream_decode and its LLM / TTS / Token2Wav threads) + audition.cpp + token2wav-impl.cpp + libllama, with this backend loaded from GGML_BACKEND_PATH, over the synthetic
+    full-size module set of tools/make_synth_omni_set.py (one 2 s user turn after the system prompt with a 3 s reference voice).  Every number is the reference's own
+    timestamp (tests/test_omni_runtime_gpu.py summarise()); the HiFT vocoder runs on the host CPU because omni.cpp:3779 pins it there.  Checker-side binary; absent -> None."""
+    import shutil
+    import subprocess
+    import tempfile
+    exe = os.path.join(ROOT, "oracle", "_ref", "omni-min")
+    if not os.path.exists(exe):
+        return None
+    tmp = tempfile.mkdtemp(prefix="mi355x_omnirt_")
+    out = {"harness": "oracle/_ref/omni-min (reference tools/omni/omni.cpp + modules + libllama, plug-in from GGML_BACKEND_PATH), synthetic full-size module set"}
+    try:
+        if shutil.disk_usage(tmp).free < 9e9:
+            return {"skipped": "needs 7 GB of scratch disk"}
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import test_omni_runtime_gpu as T
+        subprocess.run([sys.executable, os.path.join(ROOT, "tools", "make_synth_omni_set.py"), "-o", tmp], check=True, timeout=900, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        j = None
+        for _ in range(2):                                         # (the first run pages the files in and pays the one-off image builds; the second is reported)
+            shutil.rmtree(os.path.join(tmp, "out"), ignore_errors=True)
+            r, log = T.run_omni_min(tmp, os.path.join(tmp, "out"), max_tgt=24, timeout=600)
+            if r.returncode != 0:
+                return dict(out, error=log[-300:])
+            j = T.summarise(log)
+        out.update({"llm_layers_on_plugin": "37/37" if "offloaded 37/37 layers to GPU" in log else None, "tts_layers_on_plugin": "21/21" if "offloaded 21/21 layers to GPU" in log else None,
+                    "t2w_flow_backend": "MI355X0" if "init_backend device=gpu:0, gpu_idx=0, backend=MI355X0" in log else None,
+                    "system_prompt_prefill_s": j["prefill_each_s"][0], "n_past_after_prefill": j["n_past_after_prefill"],
+                    "first_audio_ms_reference_timestamp": j["reference_first_audio_ms"], "llm_decode_tok_s_in_runtime": round(j["llm_decode_tok_s"], 1) if j["llm_decode_tok_s"] else None,
+                    "llm_prompt_tok_s_in_runtime": round(j["llm_prompt_tok_s"], 1) if j["llm_prompt_tok_s"] else None,
+                    "t2w_token2mel_ms_per_window_on_plugin": j["t2w_token2mel_ms_median"], "t2w_vocoder_ms_per_window_on_host_cpu": j["t2w_vocoder_ms_median"], "wav_windows": j["n_wav"]})
+        return out
+    except Exception as e:
+        out["error"] = repr(e)
+        return out
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def prefill_tok_s(pkg, be, model, n_tokens=512, reps=3):
     """llama-bench pp512 analogue: one ubatch of 512 tokens at depth 0 through the same backend (MFMA GEMM path for the mat-muls)."""
     g, I, logits = model.build(n_tokens, n_tokens, n_outputs=1)
@@ -816,6 +856,7 @@ def main():
     ap.add_argument("--c3", action="store_true", help="(default on at N = 1) BASELINE configs[2]: Qwen3-8B F16 prefill 8 x 2048 tokens (the `c3_f16_prefill` object)")
     ap.add_argument("--no-c3", action="store_true", help="skip the C3 leg")
     ap.add_argument("--omni-pinned", action="store_true", help="add `omni_pinned`: C4 TTFT / C5 chunk measured with every module on its mi355x_module_device() backend and real hand-offs")
+    ap.add_argument("--no-omni-runtime", action="store_true", help="skip the via_reference_omni_runtime leg (the reference's omni.cpp driving the plug-in; ~60 s)")
     ap.add_argument("--no-libllama", action="store_true", help="skip the via_libllama leg (the metric through the reference's libllama with this plug-in)")
     args = ap.parse_args()
 
@@ -923,6 +964,8 @@ def main():
         if world == 1 and not args.tiny and not args.no_libllama and not os.environ.get("MI355X_BENCH_NO_EXTRAS"):
             be.synchronize()
             out["via_reference_omni_modules"] = via_reference_omni_modules()
+            if not args.no_omni_runtime:
+                out["via_reference_omni_runtime"] = via_reference_omni_runtime()
             out["via_libllama"] = via_libllama()
             v = out["via_libllama"]
             if v and isinstance(v.get("fa1"), dict) and v["fa1"].get("tg128_tok_s"):
