@@ -28,7 +28,7 @@ def _read_wav(path):
     return np.frombuffer(b[i + 8:], "<i2").astype(np.float32) / 32768.0
 
 
-def run_omni_min(root, out_dir, max_tgt=24, plug=True, turns=1, timeout=1500):
+def run_omni_min(root, out_dir, max_tgt=24, plug=True, turns=1, timeout=1500, omni=False):
     env = dict(os.environ)
     env.pop("GGML_BACKEND_PATH", None)
     env.pop("MTMD_BACKEND_DEVICE", None)
@@ -36,7 +36,7 @@ def run_omni_min(root, out_dir, max_tgt=24, plug=True, turns=1, timeout=1500):
         env["GGML_BACKEND_PATH"] = LIB
         env["MI355X_LOG_STATS"] = "1"
     cmd = [BIN, "-m", "gguf/MiniCPM-o-4_5-Q4_K_M.gguf", "--test", "case/audio_", str(turns), "-ngl", "99" if plug else "0", "--t2w-device", "gpu:0" if plug else "cpu",
-           "--max-tgt", str(max_tgt), "--out", out_dir, "-c", "4096"]
+           "--max-tgt", str(max_tgt), "--out", out_dir, "-c", "4096"] + (["--omni"] if omni else [])
     r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=timeout, errors="replace")
     return r, r.stdout + "\n" + r.stderr
 
@@ -66,17 +66,21 @@ def test_reference_omni_runtime_drives_the_plugin(tmp_path):
     if shutil.disk_usage(str(tmp_path)).free < 9e9:
         pytest.skip("needs 7 GB of scratch disk for the synthetic module set")
     root = str(tmp_path / "set")
-    subprocess.run([sys.executable, os.path.join(ROOT, "tools", "make_synth_omni_set.py"), "-o", root], check=True, timeout=1800, capture_output=True)
+    # all five modules: the second user turn carries a 448 x 448 picture, so media_type 2 ("omni") also runs vision.cpp's SigLip2 tower + resampler
+    subprocess.run([sys.executable, os.path.join(ROOT, "tools", "make_synth_omni_set.py"), "-o", root, "--vision", "--turns", "2"], check=True, timeout=1800, capture_output=True)
     try:
         out_dir = str(tmp_path / "out")
-        r, log = run_omni_min(root, out_dir)
+        r, log = run_omni_min(root, out_dir, turns=2, omni=True)
         assert r.returncode == 0, log[-4000:]
+        m = re.search(r"vision using (\S+) backend", log)                                                   # vision.cpp's own line
+        assert m and m.group(1).startswith("MI355X"), m and m.group(0)
+        assert re.search(r"prefilled \d+ vision chunks \(64 tokens each\)", log), "the picture did not reach the LLM"
         # ---- placement: every module that asks the registry for a GPU got the plug-in's device
         assert len(re.findall(r"offloaded 37/37 layers to GPU", log)) >= 1, log[-3000:]                   # the LLM (36 layers + output)
         assert len(re.findall(r"offloaded 21/21 layers to GPU", log)) >= 1, log[-3000:]                   # the TTS decoder (20 layers + output)
         assert "init_backend device=gpu:0, gpu_idx=0, backend=MI355X0" in log                              # Token2Wav's flow model (token2wav-impl.cpp:1951)
         # the plug-in's own account, printed as each backend context is freed: the LLM, the TTS decoder, the audio encoder (audition.cpp:241-249 asks the
-        # registry for a GPU backend; its logger is silent at this level) and Token2Wav's flow model each computed graphs on it
+        # registry for a GPU backend; its logger is silent at this level) and Token2Wav's flow model each computed graphs on it (omni_free does not free the image encoder's backend: its evidence is vision.cpp's own line above)
         stats = [(int(a), int(b), int(c), int(d)) for a, b, c, d in re.findall(r"\[mi355x\] MI355X0: graphs eager=(\d+) captured=(\d+) replayed=(\d+), kernels in last graph=(\d+)", log)]
         live = [s for s in stats if s[0] + s[1] + s[2] > 0]
         assert len(live) >= 4 and any(s[3] > 2000 for s in live) and any(s[2] > 500 for s in live), stats        # (Token2Wav's 4 000-launch window graph; the TTS decoder's replays)

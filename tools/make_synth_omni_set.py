@@ -38,6 +38,24 @@ def write_wav(path, seconds, seed, rate=16000):
         f.write(pcm.tobytes())
 
 
+def write_png(path, w, h, seed):
+    """an 8-bit RGB PNG (stb_image, which omni.cpp's vision_image_load_from_bytes :518 uses, detects the format from the bytes, so the `.jpg` name omni-cli
+    looks for -- <prefix>NNNN.jpg -- may hold it): smooth colour gradients + blocks, deterministic"""
+    import zlib
+    rng = np.random.default_rng(seed)
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float32)
+    img = np.stack([127 + 120 * np.sin(xx / rng.uniform(20, 90) + yy / rng.uniform(30, 120) + c) for c in (0.0, 2.1, 4.2)], axis=-1)
+    for _ in range(12):
+        x0, y0 = int(rng.integers(0, w - 40)), int(rng.integers(0, h - 40))
+        img[y0:y0 + int(rng.integers(10, 120)), x0:x0 + int(rng.integers(10, 120))] = rng.integers(0, 255, 3)
+    raw = np.concatenate([np.zeros((h, 1), np.uint8), np.clip(img, 0, 255).astype(np.uint8).reshape(h, w * 3)], axis=1).tobytes()
+
+    def chunk(tag, data):
+        return struct.pack(">I", len(data)) + tag + data + struct.pack(">I", zlib.crc32(tag + data) & 0xffffffff)
+    with open(path, "wb") as f:
+        f.write(b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, 2, 0, 0, 0)) + chunk(b"IDAT", zlib.compress(raw, 6)) + chunk(b"IEND", b""))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("-o", "--out", required=True)
@@ -45,7 +63,8 @@ def main():
     ap.add_argument("--llm-types", default="q4_k_m")
     ap.add_argument("--tts-layers", type=int, default=0, help="0 = 20")
     ap.add_argument("--apm-layers", type=int, default=24)
-    ap.add_argument("--vision", action="store_true")
+    ap.add_argument("--vision", action="store_true", help="also the image module and one 448 x 448 picture beside every user turn after the first (omni mode, media_type 2)")
+    ap.add_argument("--vpm-layers", type=int, default=27)
     ap.add_argument("--turns", type=int, default=1)
     ap.add_argument("--turn-seconds", type=float, default=2.0)
     ap.add_argument("--seed", type=int, default=11)
@@ -75,7 +94,7 @@ def main():
                    ("linear2.weight", (rng.standard_normal((768, 768)) / 28).astype(h)), ("linear2.bias", np.zeros(768, np.float32))])
     mo.apm(os.path.join(g, "audio", "MiniCPM-o-4_5-audio-F16.gguf"), a.apm_layers, a.seed + 3)
     if a.vision:
-        mo.vpm(os.path.join(g, "vision", "MiniCPM-o-4_5-vision-F16.gguf"), 27, a.seed + 4)
+        mo.vpm(os.path.join(g, "vision", "MiniCPM-o-4_5-vision-F16.gguf"), a.vpm_layers, a.seed + 4)
     t2w_dir = os.path.join(g, "token2wav-gguf")
     mo.t2w(t2w_dir, a.seed + 5)
     for fn in ("spk_f32.bin", "prompt_tokens_i32.bin", "prompt_mel_btc_f32.bin"):
@@ -84,6 +103,8 @@ def main():
     write_wav(os.path.join(ref_dir, "default_ref_audio.wav"), 3.0, a.seed + 6)
     for i in range(a.turns):
         write_wav(os.path.join(root, "case", f"audio_{i:04d}.wav"), a.turn_seconds, a.seed + 7 + i)
+        if a.vision and i > 0:                                   # (index 0 only initialises the system prompt: omni.cpp:8766-8800)
+            write_png(os.path.join(root, "case", f"audio_{i:04d}.jpg"), 448, 448, a.seed + 40 + i)
     print("omni set in", root)
 
 
