@@ -1,10 +1,10 @@
 #!/bin/bash
 # tools/par_tail_ab.sh -- option par_tail (MI355X_PAR_TAIL=S: the layout-only suffix of a captured graph spread over S capture streams) on the reference's Token2Wav:
-# device time per window graph and wall time per window with S = 0 / 2 / 4 / 8, the waveforms compared byte for byte; first tools/graph_par_bench.hip's raw figures.
+# (the option lives in tools/lab/par_tail.diff -- measured slower, not in the product; apply the diff to llama.cpp-omni_amd/csrc to re-run this)
+# device time per window graph and wall time per window with S = 0 / 2 / 4 / 8, the waveforms compared byte for byte.
 set -u
 cd "$(dirname "$0")/.."
 ROOT=$PWD
-[ -x tools/bin/graph_par_bench ] && tools/bin/graph_par_bench 1440 64
 [ -d /tmp/t2w ] || python tools/make_synth_omni_gguf.py --module t2w -o /tmp/t2w > /dev/null
 export GGML_BACKEND_PATH=$ROOT/llama.cpp-omni_amd/lib/libggml-mi355x.so
 for S in 0 2 4 8; do
