@@ -2413,6 +2413,103 @@ static int exec_ew_chain(exec_state & s, int i, int * taken) {
     return n;
 }
 
+// ------------------------------------------------------------------------------------------------ lazy copies of cache views
+// fmCausalConv1d::build_forward_chunk_graph (token2wav-impl.cpp:952-957) makes two copies of the cached frames before it uses them: cache_in = CONT(view of the packed cache)
+// and cache_tcb = CONT(PERMUTE(cache_in)) -- two ~2.5 us launches over 8 KB, 640 of them per window -- and exec_causal_conv then reads the C-fastest frames through a tensor
+// descriptor anyway.  Both CONTs are therefore NOT run when they are met: the executor remembers what they would copy (a view of a tensor from outside the graph, intact until
+// `deadline`), exec_causal_conv reads the view itself, exec_concat_tail never reads the frames, and ANY other reader -- or the deadline -- materialises the copy first (lazy_net).
+static tdesc swapped01(tdesc d) { std::swap(d.ne[0], d.ne[1]); std::swap(d.nb[0], d.nb[1]); return d; }
+static byte_range range_of(const tdesc & d) {
+    size_t ext = 4;
+    for (int k = 0; k < 4; ++k) ext += (size_t) (d.ne[k] > 0 ? d.ne[k] - 1 : 0) * d.nb[k];
+    return { (const char *) d.p, (const char *) d.p + ext };
+}
+static void lazy_materialise(exec_state & s, const ggml_tensor * t, int reader_op = -1) {
+    auto it = s.lazy.find(t);
+    if (it == s.lazy.end()) return;
+    static const bool dbg = getenv("MI355X_SINK_DEBUG") != nullptr;          // who made a lazy copy real after all: reader op (-1: the deadline), tallied (stderr at process exit)
+    static std::map<int, long> who;
+    struct dump { ~dump() { if (dbg) { fprintf(stderr, "[mi355x] lazy_cont materialised by reader op:"); for (auto & kv : who) fprintf(stderr, " %d:%ld", kv.first, kv.second); fprintf(stderr, "\n"); } } };
+    static dump at_exit;
+    if (dbg) ++who[reader_op];
+    {
+        prof_scope ps(s, "cpy", 0);
+        cpy_strided(it->second.src, GGML_TYPE_F32, td(t), GGML_TYPE_F32, s.st); ++s.n_kernels;
+    }
+    s.lazy.erase(it);
+    note_write(s, t);
+}
+// before node i runs outside the lazy-aware matchers: whatever it reads (through view chains) must exist, and nothing lazy may outlive its source
+static void lazy_net(exec_state & s, int i) {
+    if (s.lazy.empty()) return;
+    const ggml_tensor * n = s.g->nodes[i];
+    for (int k = 0; k < GGML_MAX_SRC; ++k)
+        for (const ggml_tensor * t = n->src[k]; t; t = (t->op == GGML_OP_RESHAPE || t->op == GGML_OP_VIEW || t->op == GGML_OP_PERMUTE || t->op == GGML_OP_TRANSPOSE) ? t->src[0] : nullptr)
+            if (s.lazy.count(t)) lazy_materialise(s, t, (int) n->op);
+    for (auto it = s.lazy.begin(); it != s.lazy.end(); ) {
+        if (it->second.deadline > i) { ++it; continue; }
+        const ggml_tensor * t = it->first; ++it;
+        bool needed = false;                                               // a copy whose readers have all run (or were folded away) is simply never made
+        auto us = s.users.find(t);
+        if (us != s.users.end()) for (int u : us->second) if (u >= i && !s.done[u]) needed = true;
+        if (needed) lazy_materialise(s, t); else s.lazy.erase(t);
+    }
+}
+static bool lazy_try_register(exec_state & s, int i) {
+    static const bool off = getenv("MI355X_NO_LAZY_CACHE_CONT") != nullptr;
+    if (off || !s.c->opt_fusion) return false;
+    static const bool dbg = getenv("MI355X_SINK_DEBUG") != nullptr;          // which line turned a candidate down, tallied (stderr at process exit)
+    static std::map<int, long> why;
+    struct dump { ~dump() { if (dbg) { fprintf(stderr, "[mi355x] lazy_cont: taken %ld, refusals by source line:", why[0]); for (auto & kv : why) if (kv.first) fprintf(stderr, " %d:%ld", kv.first, kv.second); fprintf(stderr, "\n"); } } };
+    static dump at_exit;
+    auto no = [&](int line) { if (dbg) ++why[line]; return false; };
+    ggml_cgraph * g = s.g;
+    const ggml_tensor * n = g->nodes[i];
+    if (n->op != GGML_OP_CONT || n->type != GGML_TYPE_F32 || !n->data || !is_contiguous(n) || n->view_src || n->ne[3] != 1 || is_out(s, n)) return false;
+    const ggml_tensor * src = n->src[0];
+    if (!src || src->type != GGML_TYPE_F32 || !src->data || !same_shape(src, n)) return false;
+    auto conv_concat_user = [&](const ggml_tensor * t) -> bool {          // t's one reader is CONCAT(t, CONT(PERMUTE(x)), dim 0): the pattern exec_causal_conv takes
+        const int u = sole_user(s, t);
+        if (u <= i) return false;
+        const ggml_tensor * c = g->nodes[u];
+        return c->op == GGML_OP_CONCAT && op_param_i32(c, 0) == 0 && c->src[0] == t && c->src[1] && c->src[1]->op == GGML_OP_CONT && c->src[1]->src[0] && c->src[1]->src[0]->op == GGML_OP_PERMUTE;
+    };
+    exec_state::lazy_ent e;
+    if (src->op == GGML_OP_VIEW) {                                         // cache_in = CONT(view of the packed cache)
+        const ggml_tensor * base = src->view_src;
+        if (!base || base->op != GGML_OP_NONE || !base->data || src->nb[0] != 4 || (n->flags & GGML_TENSOR_FLAG_OUTPUT)) return no(__LINE__);
+        auto us = s.users.find(n);
+        if (us == s.users.end()) return no(__LINE__);
+        bool has_t = false;
+        for (int u : us->second) {
+            const ggml_tensor * c = g->nodes[u];
+            if (c->op == GGML_OP_CONCAT) continue;                         // (the new-cache chain: exec_concat_tail, which does not read the frames, or the net)
+            if (c->op != GGML_OP_CONT || !c->src[0] || c->src[0]->op != GGML_OP_PERMUTE || c->src[0]->src[0] != n || !conv_concat_user(c)) return no(__LINE__);
+            has_t = true;
+        }
+        if (!has_t) return no(__LINE__);
+        auto bd = s.lazy_base_deadline.find(base);
+        if (bd == s.lazy_base_deadline.end()) {                            // first node that writes over the base's bytes (a CPY into the cache at the end of the graph; a re-used address)
+            int dl = g->n_nodes;
+            const byte_range rb = range_of(base);
+            for (int k = i + 1; k < g->n_nodes; ++k) if (!is_noop(g->nodes[k]) && g->nodes[k]->data && overlap(range_of(g->nodes[k]), rb)) { dl = k; break; }
+            bd = s.lazy_base_deadline.emplace(base, dl).first;
+        }
+        if (bd->second <= i + 1) return no(__LINE__);
+        e.src = td(src); e.deadline = bd->second;
+    } else if (src->op == GGML_OP_PERMUTE) {                               // cache_tcb = CONT(PERMUTE(cache_in)), cache_in still lazy
+        const ggml_tensor * q = src->src[0];
+        auto lq = q ? s.lazy.find(q) : s.lazy.end();
+        if (lq == s.lazy.end() || src->data != q->data || src->ne[0] != q->ne[1] || src->ne[1] != q->ne[0] || src->ne[2] != q->ne[2] || src->nb[0] != q->nb[1] || src->nb[1] != q->nb[0] || src->nb[2] != q->nb[2]) return no(__LINE__);
+        if (!conv_concat_user(n)) return no(__LINE__);
+        e.src = swapped01(lq->second.src); e.deadline = lq->second.deadline;
+    } else return no(__LINE__);
+    if (dbg) ++why[0];
+    s.lazy[n] = e;
+    s.done[i] = 1; ++s.n_fused;
+    return true;
+}
+
 // Token2Wav's streaming causal 1-D convolution the way the reference's builder spells it (token2wav-impl.cpp: the cached P = KW - 1 frames ++ x on the time axis of the
 // transposed [T, C, B] copies, then per batch element VIEW -> IM2COL -> MUL_MAT against the [KW*C, Cout] kernel, CONCAT of the batch elements, PERMUTE + CONT back to
 // [Cout, T, B], ADD of the bias): 11 launches, five of them transposes or copies.  With x and the cache in their C-fastest layouts the im2col column of frame t is the
@@ -2457,10 +2554,15 @@ static bool exec_causal_conv(exec_state & s, int i) {
     const ggml_tensor * cc = untransposed(cacheT);
     if (!cc || cc->ne[0] != C || cc->ne[2] != B) return no(__LINE__);
     const int64_t P = cc->ne[1], KW = P + 1;
+    // the two copies of the cached frames may not have been run (lazy_try_register): then the frames are read where they lie, in the cache
+    const auto lzT = s.lazy.find(cacheT);
+    const bool frames_lazy = lzT != s.lazy.end();
+    const tdesc frames_src = frames_lazy ? swapped01(lzT->second.src) : tdesc();
     // the cache frames are computed before x's copy; their C-fastest original is dead for ggml-alloc once the transposed copy exists, so it is only read when nothing
     // between that copy and here wrote over it -- otherwise the transposed copy is read through swapped strides
-    bool cc_intact = true;
-    {
+    bool cc_intact = !s.lazy.count(cc);                                    // (a cache_in that was never written, behind a cache_tcb that was: read the latter)
+    if (frames_lazy) cc_intact = true;
+    else {
         auto it = s.index.find(cacheT);
         if (it == s.index.end() || it->second >= i) return no(__LINE__);
         if (i - it->second > 64) cc_intact = false;
@@ -2533,12 +2635,12 @@ static bool exec_causal_conv(exec_state & s, int i) {
     for (int k = i + 1; k < last; ++k) if (!mine(k) && !s.done[k] && !is_noop(g->nodes[k])) return no(__LINE__);   // nothing else runs inside the pattern
     for (int k : { j2, j3, im[0], im[1], mm[0], mm[1], j4, j6 }) if (k >= 0 && k != last && is_out(s, g->nodes[k])) return no(__LINE__);
     if (is_out(s, n1)) return no(__LINE__);
-    if (((uintptr_t) x->data & 15) || ((uintptr_t) cc->data & 15) || ((uintptr_t) out->data & 15)) return no(__LINE__);
+    if (((uintptr_t) x->data & 15) || ((uintptr_t) (frames_lazy ? frames_src.p : cc->data) & 15) || ((uintptr_t) out->data & 15)) return no(__LINE__);
     // ggml-alloc may have put the pattern's buffers over memory that is free by the time their own node runs; here they are written at x's copy
     // (the concatenated frames go to the CONT's buffer, or to the CONCAT's -- same size, both dead outside the pattern -- when the first sits on an input or under the result)
     const ggml_tensor * xbuf = nullptr;
     for (const ggml_tensor * cand : { n3, n2 })
-        if (!xbuf && !((uintptr_t) cand->data & 15) && !overlap(range_of(cand), range_of(x)) && !overlap(range_of(cand), range_of(cc_intact ? cc : cacheT)) && !overlap(range_of(out), range_of(cand))) xbuf = cand;
+        if (!xbuf && !((uintptr_t) cand->data & 15) && !overlap(range_of(cand), range_of(x)) && !overlap(range_of(cand), frames_lazy ? range_of(frames_src) : range_of(cc_intact ? cc : cacheT)) && !overlap(range_of(out), range_of(cand))) xbuf = cand;
     if (!xbuf) return no(__LINE__);
     // the kernel rows [Cout][KW][C]: built on first use outside capture, kept with the weight images (dropped with them when the source bytes are written)
     bool created = false;
@@ -2555,8 +2657,8 @@ static bool exec_causal_conv(exec_state & s, int i) {
     {
         prof_scope ps(s, "concat", 0);
         tdesc y; y.p = xbuf->data; y.ne[0] = C; y.ne[1] = T + P; y.ne[2] = B; y.ne[3] = 1; y.nb[0] = 4; y.nb[1] = (size_t) C * 4; y.nb[2] = (size_t) C * (size_t) (T + P) * 4; y.nb[3] = y.nb[2] * (size_t) B;
-        tdesc ca = td(cc);
-        if (!cc_intact) { ca.p = cacheT->data; ca.nb[0] = cacheT->nb[1]; ca.nb[1] = cacheT->nb[0]; ca.nb[2] = cacheT->nb[2]; ca.nb[3] = cacheT->nb[3]; }
+        tdesc ca = frames_lazy ? frames_src : td(cc);
+        if (!frames_lazy && !cc_intact) { ca.p = cacheT->data; ca.nb[0] = cacheT->nb[1]; ca.nb[1] = cacheT->nb[0]; ca.nb[2] = cacheT->nb[2]; ca.nb[3] = cacheT->nb[3]; }
         concat(ca, td(x), y, 1, 4, s.st); ++s.n_kernels;
     }
     note_write(s, xbuf);
@@ -2572,6 +2674,7 @@ static bool exec_causal_conv(exec_state & s, int i) {
     }
     note_write(s, out);
     for (int k : { j2, j3, im[0], im[1], mm[0], mm[1], j4, j6, j7 }) if (k >= 0) { s.done[k] = 1; ++s.n_fused; }
+    if (frames_lazy) s.lazy.erase(cacheT);                                 // its one reader is done: the copy is never made
     if (dbg) ++why[0];
     return true;
 }
@@ -2728,7 +2831,7 @@ void run_nodes(exec_state & s, ggml_cgraph * g) {
     static FILE * const launch_log = getenv("MI355X_LAUNCH_LOG") ? fopen(getenv("MI355X_LAUNCH_LOG"), "w") : nullptr;      // one line per node that launched: what a graph's launches are made of (tools/launch_ngrams.py)
     s.g = g;
     s.done.assign(g->n_nodes, 0);
-    s.index.clear(); s.users.clear();
+    s.index.clear(); s.users.clear(); s.lazy.clear(); s.lazy_base_deadline.clear();
     if (s.c->opt_fusion) {
         s.index.reserve(g->n_nodes * 2); s.users.reserve(g->n_nodes * 2);
         for (int i = 0; i < g->n_nodes; ++i) {
@@ -2796,6 +2899,8 @@ void run_nodes(exec_state & s, ggml_cgraph * g) {
         if (g->nodes[i]->op == GGML_OP_IM2COL && exec_conv1d_tc(s, i)) continue;
         if (g->nodes[i]->op == GGML_OP_CONT && exec_causal_conv(s, i)) continue;
         if ((g->nodes[i]->op == GGML_OP_CONT || g->nodes[i]->op == GGML_OP_CONCAT) && exec_concat_tail(s, i)) continue;
+        if (g->nodes[i]->op == GGML_OP_CONT && lazy_try_register(s, i)) continue;
+        if (!is_noop(g->nodes[i])) lazy_net(s, i);
         if (g->nodes[i]->op == GGML_OP_MUL && exec_gate_norm(s, i)) continue;
         {
             int taken[8];

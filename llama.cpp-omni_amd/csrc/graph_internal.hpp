@@ -83,6 +83,11 @@ struct exec_state {
     // deferred split-K reduction of a GROUPED launch (wq / wk / wv of a prefill ubatch): the results A[0..n) still lie as `nsplit` slabs in gemm_partial (slab = `slab` floats,
     // matrix q a dense [N][M[q]] block at + off[q]); the q / k norm + rope + store launch behind them sums the slabs itself (k_norm_rope_v4), anybody else gets materialise_group
     struct { int n = 0; const ggml_tensor * A[3] = { nullptr, nullptr, nullptr }; size_t off[3] = { 0, 0, 0 }; int64_t M[3] = { 0, 0, 0 }; int nsplit = 0; size_t slab = 0; int64_t N = 0; } prm;
+    // CONT nodes that have NOT been run: copies of a view of a tensor from outside the graph (a persistent cache) whose readers may take the view itself (lazy_* in
+    // graph_exec.cpp).  `src` = what the copy would read, `deadline` = the first node that writes over those bytes; any other reader materialises the copy first.
+    struct lazy_ent { tdesc src; int deadline; };
+    std::unordered_map<const ggml_tensor *, lazy_ent> lazy;
+    std::unordered_map<const ggml_tensor *, int> lazy_base_deadline;
 };
 
 // ------------------------------------------------------------------------------------------------ profiling
