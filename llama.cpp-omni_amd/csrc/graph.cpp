@@ -383,6 +383,8 @@ double mi355x_get_stat(struct ggml_backend * backend, const char * key) {
     if (!strcmp(key, "graph_captures"))     return (double) c->stat_captures;
     if (!strcmp(key, "eager_graphs"))       return (double) c->stat_eager;
     if (!strcmp(key, "kernels_last_graph")) return (double) c->stat_kernels_last;
+    if (!strcmp(key, "lazy_conts"))         return (double) c->stat_lazy_taken;
+    if (!strcmp(key, "lazy_conts_materialised")) return (double) c->stat_lazy_materialised;
     if (!strncmp(key, "shadow_", 7))        return mi::shadow_stat(key);
     if (!strcmp(key, "gemm256_launches"))   return (double) mi::gemm_variant_launches(0);
     if (!strcmp(key, "gemm192_launches"))   return (double) mi::gemm_variant_launches(1);

@@ -2432,6 +2432,7 @@ static void lazy_materialise(exec_state & s, const ggml_tensor * t, int reader_o
     struct dump { ~dump() { if (dbg) { fprintf(stderr, "[mi355x] lazy_cont materialised by reader op:"); for (auto & kv : who) fprintf(stderr, " %d:%ld", kv.first, kv.second); fprintf(stderr, "\n"); } } };
     static dump at_exit;
     if (dbg) ++who[reader_op];
+    ++s.c->stat_lazy_materialised;
     {
         prof_scope ps(s, "cpy", 0);
         cpy_strided(it->second.src, GGML_TYPE_F32, td(t), GGML_TYPE_F32, s.st); ++s.n_kernels;
@@ -2505,6 +2506,7 @@ static bool lazy_try_register(exec_state & s, int i) {
         e.src = swapped01(lq->second.src); e.deadline = lq->second.deadline;
     } else return no(__LINE__);
     if (dbg) ++why[0];
+    ++s.c->stat_lazy_taken;
     s.lazy[n] = e;
     s.done[i] = 1; ++s.n_fused;
     return true;

@@ -220,3 +220,34 @@ def test_dit_block_graph_replay_matches_the_eager_run(pkg, be):
     for r in runs[1:]:
         assert np.array_equal(r.view(np.uint32), runs[0].view(np.uint32))
     c.free()
+
+
+@pytest.mark.parametrize("C,T,B", [(512, 56, 2), (64, 7, 1)])
+def test_lazy_cache_copies_become_real_when_somebody_else_reads_them(pkg, be, ref_be, C, T, B):
+    """graph_exec.cpp lazy_try_register: the causal convolution's two copies of the cached frames (cache_in = CONT(view of the packed cache), cache_tcb =
+    CONT(PERMUTE(cache_in)); token2wav-impl.cpp:952-957) are not run when they are met.  This graph has the shape that makes them lazy but NOT the convolution
+    behind it, so every reader is an ordinary node: the CONCAT with the transposed x must get the transposed frames (materialised when it reads), and a late reader of
+    cache_in -- behind a CPY that overwrites those very frames in the cache -- must still see the OLD frames (materialised at the deadline, before the CPY runs).
+    Copies only: bit-exact against the reference CPU backend."""
+    F32 = pkg.GGML_TYPE_F32
+    P, slots, slot = 2, 5, 3
+
+    def build(c):
+        cache = c.new_tensor(F32, C, P * slots, B)
+        x = c.new_tensor(F32, C, T, B)
+        nb1, nb2 = C * 4, C * P * slots * 4
+        cv = c.view_3d(cache, C, P, B, nb1, nb2, slot * P * nb1)
+        cc = c.cont(cv)                                         # lazy (A)
+        ct = c.cont(c.permute(cc, 1, 0, 2, 3))                  # lazy (B)
+        xt = c.cont(c.permute(x, 1, 0, 2, 3))
+        cat = c.concat(ct, xt, 0)                               # ordinary reader of cache_tcb
+        y1 = c.cont(cat)
+        upd = c.cpy(c.view_3d(x, C, P, B, x.t.nb[1], x.t.nb[2], 0), c.view_3d(cache, C, P, B, nb1, nb2, slot * P * nb1))     # the cache slot is overwritten ...
+        y2 = c.cont(c.concat(cc, x, 1))                         # ... before cache_in's other reader runs
+        return {"cache": cache, "x": x}, [y1, y2, upd]
+
+    n0, m0 = be.get_stat("lazy_conts"), be.get_stat("lazy_conts_materialised")
+    got, want = _run_both(pkg, be, ref_be, build, lambda rng, name, t: _randn(rng, name, t), check_declined=False)
+    assert be.get_stat("lazy_conts") - n0 == 2 and be.get_stat("lazy_conts_materialised") - m0 == 2      # both copies were deferred, both were made real by their readers
+    for g, w in zip(got, want):
+        assert np.array_equal(g, w)
