@@ -12,6 +12,9 @@ static bool overlap(byte_range a, byte_range b) { return a.lo < b.hi && b.lo < a
 
 // convert src1 of a MUL_MAT into the activation format of `kind` (or reuse the cached conversion); returns the image stride
 static void materialise_norm(exec_state & s);
+static void lazy_net(exec_state & s, int i);
+static void lazy_materialise(exec_state & s, const ggml_tensor * t, int reader_op = -1);
+static byte_range range_of(const tdesc & d);
 static size_t prepare_act(exec_state & s, const ggml_tensor * x, act_kind kind) {
     const int64_t K = x->ne[0], N = x->ne[1], ne12 = x->ne[2], ne13 = x->ne[3];
     const size_t img = act_image_bytes(kind, K);
@@ -1736,6 +1739,14 @@ static bool exec_attn_f32(exec_state & s, int i) {
     attn_f32_args a;
     a.q = fq->data; a.q_rs = fq->nb[1]; a.q_bs = fq->nb[2]; a.k = fk->data; a.k_rs = fk->nb[1]; a.k_bs = fk->nb[2]; a.vt = fv->data; a.v_rs = fv->nb[1]; a.v_bs = fv->nb[2];
     a.D = D; a.nq = nq; a.nkv = nkv; a.HB = HB;
+    // Q / K whose flattening copy CONT(PERMUTE([D, H, n, B])) was left un-run (lazy_try_register, case C): read through the permuted view's strides
+    auto lazy_root = [&](const ggml_tensor * t) -> const ggml_tensor * { while (t && t->op == GGML_OP_RESHAPE) t = t->src[0]; return t && s.lazy.count(t) ? t : nullptr; };
+    const ggml_tensor * lq = lazy_root(fq), * lk = lazy_root(fk);
+    byte_range rq = range_of(fq), rk = range_of(fk);
+    if (lq) { const tdesc & d = s.lazy[lq].src; if (d.ne[0] != D || d.ne[1] != nq || d.ne[2] * d.ne[3] != HB || d.nb[0] != 4) return no(__LINE__);
+              a.q = d.p; a.q_rs = d.nb[1]; a.q_bs = d.nb[2]; a.q_bs2 = d.nb[3]; a.q_H = d.ne[2]; rq = range_of(d); }
+    if (lk) { const tdesc & d = s.lazy[lk].src; if (d.ne[0] != D || d.ne[1] != nkv || d.ne[2] * d.ne[3] != HB || d.nb[0] != 4) return no(__LINE__);
+              a.k = d.p; a.k_rs = d.nb[1]; a.k_bs = d.nb[2]; a.k_bs2 = d.nb[3]; a.k_H = d.ne[2]; rk = range_of(d); }
     a.has_scale = SC != nullptr; if (SC) { a.s1 = op_param_f32(SC, 0); a.b1 = op_param_f32(SC, 1); } a.s2 = op_param_f32(SM, 0);
     // the result as it is, or through views into the CONT of its [D, H, nq, ns] permutation
     const ggml_tensor * out = M2; int ci = -1;
@@ -1761,7 +1772,11 @@ static bool exec_attn_f32(exec_state & s, int i) {
         if (k != sci && k != smi && k != m2 && !s.done[k] && !is_noop(g->nodes[k])) return no(__LINE__);       // something else runs in between: keep the separate launches
     if (!attn_f32_ok(a)) return no(__LINE__);
     // the result is written while other workgroups still read the operands: its buffer (placed by ggml-alloc for a later point of the graph) must not sit on them
-    if (overlap(range_of(out), range_of(fq)) || overlap(range_of(out), range_of(fk)) || overlap(range_of(out), range_of(fv))) return no(__LINE__);
+    // (a lazy operand's source is dead for ggml-alloc behind its copy's node, so the result may have been placed on it: then the copy is made after all and read instead)
+    if (lq && overlap(range_of(out), rq)) { lazy_materialise(s, lq, (int) GGML_OP_MUL_MAT); lq = nullptr; a.q = fq->data; a.q_rs = fq->nb[1]; a.q_bs = fq->nb[2]; a.q_bs2 = 0; a.q_H = 0; rq = range_of(fq); }
+    if (lk && overlap(range_of(out), rk)) { lazy_materialise(s, lk, (int) GGML_OP_MUL_MAT); lk = nullptr; a.k = fk->data; a.k_rs = fk->nb[1]; a.k_bs = fk->nb[2]; a.k_bs2 = 0; a.k_H = 0; rk = range_of(fk); }
+    if (overlap(range_of(out), rq) || overlap(range_of(out), rk) || overlap(range_of(out), range_of(fv))) return no(__LINE__);
+    { const ggml_tensor * lv = lazy_root(fv); if (lv) lazy_materialise(s, lv, (int) GGML_OP_MUL_MAT); }       // (V^T is read as a dense transpose: its copy is made now)
     if (s.pr.A) materialise_reduce(s);
     if (s.prm.n) materialise_group(s);
     if (s.pn.m && (s.pn.m == fq || s.pn.m == fk || s.pn.m == fv)) materialise_norm(s);
@@ -1770,6 +1785,8 @@ static bool exec_attn_f32(exec_state & s, int i) {
         attn_f32(a, s.st); ++s.n_kernels;
     }
     for (int k : { sci, smi, m2, ci }) if (k >= 0) { s.done[k] = 1; ++s.n_fused; }
+    if (lq) s.lazy.erase(lq);                                             // their one reader has run: the copies are never made
+    if (lk) s.lazy.erase(lk);
     note_write(s, out);
     if (dbg) ++why[0];
     return true;
@@ -1932,6 +1949,10 @@ static void compute_node(exec_state & s, int i) {
 
     switch (n->op) {
         case GGML_OP_MUL_MAT:
+            if (!s.lazy.empty()) {                                        // (run_nodes leaves the net to this point for f32 x f32 products: the attention chain reads lazy operands in place)
+                if (n->src[0]->type == GGML_TYPE_F32 && n->src[1]->type == GGML_TYPE_F32 && exec_attn_f32(s, i)) return;
+                lazy_net(s, i);
+            }
             if (s.pq.sm && s.pq.fa == i) {                                // flash-attention off, one token: K.q, soft-max, V^T.p, permute + cont and the q / k / v pre-stage in one launch
                 const fattn_pre & P = s.pq.pre;
                 attn_sm_args & a = s.pq.sma;
@@ -2424,7 +2445,7 @@ static byte_range range_of(const tdesc & d) {
     for (int k = 0; k < 4; ++k) ext += (size_t) (d.ne[k] > 0 ? d.ne[k] - 1 : 0) * d.nb[k];
     return { (const char *) d.p, (const char *) d.p + ext };
 }
-static void lazy_materialise(exec_state & s, const ggml_tensor * t, int reader_op = -1) {
+static void lazy_materialise(exec_state & s, const ggml_tensor * t, int reader_op) {
     auto it = s.lazy.find(t);
     if (it == s.lazy.end()) return;
     static const bool dbg = getenv("MI355X_SINK_DEBUG") != nullptr;          // who made a lazy copy real after all: reader op (-1: the deadline), tallied (stderr at process exit)
@@ -2466,7 +2487,7 @@ static bool lazy_try_register(exec_state & s, int i) {
     auto no = [&](int line) { if (dbg) ++why[line]; return false; };
     ggml_cgraph * g = s.g;
     const ggml_tensor * n = g->nodes[i];
-    if (n->op != GGML_OP_CONT || n->type != GGML_TYPE_F32 || !n->data || !is_contiguous(n) || n->view_src || n->ne[3] != 1 || is_out(s, n)) return false;
+    if (n->op != GGML_OP_CONT || n->type != GGML_TYPE_F32 || !n->data || !is_contiguous(n) || n->view_src || is_out(s, n)) return false;
     const ggml_tensor * src = n->src[0];
     if (!src || src->type != GGML_TYPE_F32 || !src->data || !same_shape(src, n)) return false;
     auto conv_concat_user = [&](const ggml_tensor * t) -> bool {          // t's one reader is CONCAT(t, CONT(PERMUTE(x)), dim 0): the pattern exec_causal_conv takes
@@ -2478,7 +2499,7 @@ static bool lazy_try_register(exec_state & s, int i) {
     exec_state::lazy_ent e;
     if (src->op == GGML_OP_VIEW) {                                         // cache_in = CONT(view of the packed cache)
         const ggml_tensor * base = src->view_src;
-        if (!base || base->op != GGML_OP_NONE || !base->data || src->nb[0] != 4 || (n->flags & GGML_TENSOR_FLAG_OUTPUT)) return no(__LINE__);
+        if (n->ne[3] != 1 || !base || base->op != GGML_OP_NONE || !base->data || src->nb[0] != 4 || (n->flags & GGML_TENSOR_FLAG_OUTPUT)) return no(__LINE__);
         auto us = s.users.find(n);
         if (us == s.users.end()) return no(__LINE__);
         bool has_t = false;
@@ -2498,6 +2519,22 @@ static bool lazy_try_register(exec_state & s, int i) {
         }
         if (bd->second <= i + 1) return no(__LINE__);
         e.src = td(src); e.deadline = bd->second;
+    } else if (src->op == GGML_OP_PERMUTE && src->src[0] && !s.lazy.count(src->src[0])) {
+        // case C: the heads of Q / K flattened for the f32 attention chain, CONT(PERMUTE([D, H, n, B] -> [D, n, H, B])) read by one batched MUL_MAT (through reshapes):
+        // attn_f32 takes the permuted view itself.  The source is a tensor of this graph: lazy only while nothing up to that reader writes over it.
+        static const bool off_c = getenv("MI355X_NO_LAZY_ATTN_CONT") != nullptr;
+        const ggml_tensor * t = src->src[0];
+        if (off_c || n->ne[3] < 1 || src->nb[0] != 4 || !t->data || src->data != t->data || !is_contiguous(t) || src->ne[0] != t->ne[0] || src->ne[1] != t->ne[2] || src->ne[2] != t->ne[1] || src->ne[3] != t->ne[3]) return no(__LINE__);
+        const int u = sole_user(s, n);
+        if (u <= i) return no(__LINE__);
+        const ggml_tensor * M = g->nodes[u];
+        if (M->op != GGML_OP_MUL_MAT || M->type != GGML_TYPE_F32 || !M->src[0] || !M->src[1] || M->src[0]->type != GGML_TYPE_F32 || M->src[1]->type != GGML_TYPE_F32 || M->src[0]->ne[3] != 1 || M->src[1]->ne[3] != 1) return no(__LINE__);
+        { bool mine = false;
+          for (int k = 0; k < 2; ++k) { const ggml_tensor * w = M->src[k]; while (w && w->op == GGML_OP_RESHAPE) w = w->src[0]; if (w == n) mine = true; }
+          if (!mine || u - i > 64) return no(__LINE__); }
+        const byte_range rt = range_of(t);
+        for (int k = i + 1; k <= u; ++k) if (!is_noop(g->nodes[k]) && g->nodes[k]->data && overlap(range_of(g->nodes[k]), rt)) return no(__LINE__);
+        e.src = td(src); e.deadline = u + 1;
     } else if (src->op == GGML_OP_PERMUTE) {                               // cache_tcb = CONT(PERMUTE(cache_in)), cache_in still lazy
         const ggml_tensor * q = src->src[0];
         auto lq = q ? s.lazy.find(q) : s.lazy.end();
@@ -2902,7 +2939,7 @@ void run_nodes(exec_state & s, ggml_cgraph * g) {
         if (g->nodes[i]->op == GGML_OP_CONT && exec_causal_conv(s, i)) continue;
         if ((g->nodes[i]->op == GGML_OP_CONT || g->nodes[i]->op == GGML_OP_CONCAT) && exec_concat_tail(s, i)) continue;
         if (g->nodes[i]->op == GGML_OP_CONT && lazy_try_register(s, i)) continue;
-        if (!is_noop(g->nodes[i])) lazy_net(s, i);
+        if (!is_noop(g->nodes[i]) && !(g->nodes[i]->op == GGML_OP_MUL_MAT && g->nodes[i]->src[0]->type == GGML_TYPE_F32 && g->nodes[i]->src[1]->type == GGML_TYPE_F32)) lazy_net(s, i);
         if (g->nodes[i]->op == GGML_OP_MUL && exec_gate_norm(s, i)) continue;
         {
             int taken[8];

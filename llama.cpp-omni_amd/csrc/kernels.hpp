@@ -342,6 +342,7 @@ struct attn_f32_args {
     size_t q_rs, q_bs, k_rs, k_bs, v_rs, v_bs, d_nb_q, d_nb_h, d_nb_s;
     int64_t D, nq, nkv, HB, H;
     float s1 = 1.0f, b1 = 0.0f, s2 = 1.0f; bool has_scale = false;
+    size_t q_bs2 = 0, k_bs2 = 0; int64_t q_H = 0, k_H = 0;      // q_H / k_H > 0: that operand's head-batch index is h + H s at h * bs + s * bs2 (a permuted 4-D view read in place)
 };
 bool   attn_f32_ok(const attn_f32_args & a);
 void   attn_f32(const attn_f32_args & a, hipStream_t st);

@@ -14,6 +14,7 @@ namespace mi {
 struct attn_f32_dev {
     const char * q, * k, * vt; char * dst;
     size_t q_rs, q_bs, k_rs, k_bs, v_rs, v_bs;          // row / head-batch strides (bytes)
+    size_t q_bs2, k_bs2; int q_H, k_H;                  // Q / K read where a permuted view leaves them: head-batch index hb = h + H s at h * bs + s * bs2 (H = HB: one level)
     size_t d_nb_q, d_nb_h, d_nb_s;                      // dst: element (d, q, h, s) at d * 4 + q * d_nb_q + h * d_nb_h + s * d_nb_s
     int nq, nkv, H, ldp;                                // H: heads per batch element of the destination's split of the head-batch index
     float s1, b1, s2;
@@ -28,7 +29,7 @@ __global__ void __launch_bounds__(256) k_attn_f32(const attn_f32_dev a) {
     float * S = af_lds;                                  // [16][ldp]
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, r16 = lane & 15, gq = lane >> 4;
     const int q0 = (int) blockIdx.x * 16, hb = (int) blockIdx.y;
-    const char * Q = a.q + (size_t) hb * a.q_bs, * K = a.k + (size_t) hb * a.k_bs, * VT = a.vt + (size_t) hb * a.v_bs;
+    const char * Q = a.q + (size_t) (hb % a.q_H) * a.q_bs + (size_t) (hb / a.q_H) * a.q_bs2, * K = a.k + (size_t) (hb % a.k_H) * a.k_bs + (size_t) (hb / a.k_H) * a.k_bs2, * VT = a.vt + (size_t) hb * a.v_bs;
     // ---- 1. scores
     {
         const int qr = q0 + r16 < a.nq ? q0 + r16 : a.nq - 1;
@@ -138,6 +139,7 @@ bool attn_f32_ok(const attn_f32_args & a) {
     static const bool off = getenv("MI355X_NO_ATTN_F32") != nullptr;
     if (off || (a.D != 64 && a.D != 72 && a.D != 80 && a.D != 96 && a.D != 128) || a.nq < 1 || a.nkv < 1 || a.nkv > 4096 || a.HB < 1 || a.HB > 65535 || a.H < 1) return false;
     if ((((uintptr_t) a.q | a.q_rs | a.q_bs | (uintptr_t) a.k | a.k_rs | a.k_bs) & 15) != 0) return false;
+    if ((a.q_H > 0 && ((a.q_bs2 & 15) != 0 || a.HB % a.q_H != 0)) || (a.k_H > 0 && ((a.k_bs2 & 15) != 0 || a.HB % a.k_H != 0))) return false;
     return (((uintptr_t) a.dst | (uintptr_t) a.vt | a.v_rs | a.v_bs) & 3) == 0;
 }
 void attn_f32(const attn_f32_args & a, hipStream_t st) {
@@ -146,6 +148,7 @@ void attn_f32(const attn_f32_args & a, hipStream_t st) {
     d.q = (const char *) a.q; d.k = (const char *) a.k; d.vt = (const char *) a.vt; d.dst = (char *) a.dst;
     d.q_rs = a.q_rs; d.q_bs = a.q_bs; d.k_rs = a.k_rs; d.k_bs = a.k_bs; d.v_rs = a.v_rs; d.v_bs = a.v_bs;
     d.d_nb_q = a.d_nb_q; d.d_nb_h = a.d_nb_h; d.d_nb_s = a.d_nb_s;
+    d.q_H = a.q_H > 0 ? (int) a.q_H : (int) a.HB; d.q_bs2 = a.q_H > 0 ? a.q_bs2 : 0; d.k_H = a.k_H > 0 ? (int) a.k_H : (int) a.HB; d.k_bs2 = a.k_H > 0 ? a.k_bs2 : 0;
     d.nq = (int) a.nq; d.nkv = (int) a.nkv; d.H = (int) a.H; d.ldp = (int) (((a.nkv + 63) / 64) * 64 + 4);
     d.s1 = a.s1; d.b1 = a.b1; d.s2 = a.s2; d.has_scale = a.has_scale ? 1 : 0;
     const int lds = 16 * d.ldp * 4;
