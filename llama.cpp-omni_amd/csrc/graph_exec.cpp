@@ -1775,8 +1775,17 @@ static bool exec_attn_f32(exec_state & s, int i) {
     // (a lazy operand's source is dead for ggml-alloc behind its copy's node, so the result may have been placed on it: then the copy is made after all and read instead)
     if (lq && overlap(range_of(out), rq)) { lazy_materialise(s, lq, (int) GGML_OP_MUL_MAT); lq = nullptr; a.q = fq->data; a.q_rs = fq->nb[1]; a.q_bs = fq->nb[2]; a.q_bs2 = 0; a.q_H = 0; rq = range_of(fq); }
     if (lk && overlap(range_of(out), rk)) { lazy_materialise(s, lk, (int) GGML_OP_MUL_MAT); lk = nullptr; a.k = fk->data; a.k_rs = fk->nb[1]; a.k_bs = fk->nb[2]; a.k_bs2 = 0; a.k_H = 0; rk = range_of(fk); }
-    if (overlap(range_of(out), rq) || overlap(range_of(out), rk) || overlap(range_of(out), range_of(fv))) return no(__LINE__);
-    { const ggml_tensor * lv = lazy_root(fv); if (lv) lazy_materialise(s, lv, (int) GGML_OP_MUL_MAT); }       // (V^T is read as a dense transpose: its copy is made now)
+    if (overlap(range_of(out), rq) || overlap(range_of(out), rk)) return no(__LINE__);
+    // V^T = CONT(PERMUTE(V)) left un-run (case C'): the second product reads V itself, [nkv, D, H, B] with the keys a row apart
+    const ggml_tensor * lv = lazy_root(fv);
+    byte_range rv = range_of(fv);
+    if (lv) {
+        const tdesc & d = s.lazy[lv].src;
+        if (d.ne[0] == nkv && d.ne[1] == D && d.ne[2] * d.ne[3] == HB && d.nb[1] == 4 && (d.nb[0] & 3) == 0 && !overlap(range_of(out), range_of(d))) {
+            a.vt = d.p; a.v_ks = d.nb[0]; a.v_bs = d.nb[2]; a.v_bs2 = d.nb[3]; a.v_H = d.ne[2]; a.v_rs = 0; rv = range_of(d);
+        } else { lazy_materialise(s, lv, (int) GGML_OP_MUL_MAT); lv = nullptr; }
+    }
+    if (overlap(range_of(out), rv)) return no(__LINE__);
     if (s.pr.A) materialise_reduce(s);
     if (s.prm.n) materialise_group(s);
     if (s.pn.m && (s.pn.m == fq || s.pn.m == fk || s.pn.m == fv)) materialise_norm(s);
@@ -1787,6 +1796,7 @@ static bool exec_attn_f32(exec_state & s, int i) {
     for (int k : { sci, smi, m2, ci }) if (k >= 0) { s.done[k] = 1; ++s.n_fused; }
     if (lq) s.lazy.erase(lq);                                             // their one reader has run: the copies are never made
     if (lk) s.lazy.erase(lk);
+    if (lv) s.lazy.erase(lv);
     note_write(s, out);
     if (dbg) ++why[0];
     return true;
@@ -2519,28 +2529,59 @@ static bool lazy_try_register(exec_state & s, int i) {
         }
         if (bd->second <= i + 1) return no(__LINE__);
         e.src = td(src); e.deadline = bd->second;
-    } else if (src->op == GGML_OP_PERMUTE && src->src[0] && !s.lazy.count(src->src[0])) {
-        // case C: the heads of Q / K flattened for the f32 attention chain, CONT(PERMUTE([D, H, n, B] -> [D, n, H, B])) read by one batched MUL_MAT (through reshapes):
-        // attn_f32 takes the permuted view itself.  The source is a tensor of this graph: lazy only while nothing up to that reader writes over it.
+    } else if (src->op == GGML_OP_PERMUTE && src->src[0]) {
         static const bool off_c = getenv("MI355X_NO_LAZY_ATTN_CONT") != nullptr;
+        // is `M` (node index u) a batched f32 x f32 MUL_MAT reading `w` through reshapes only?
+        auto f32_product_of = [&](int u, const ggml_tensor * w, bool second_is_softmax) -> bool {
+            const ggml_tensor * M = g->nodes[u];
+            if (M->op != GGML_OP_MUL_MAT || M->type != GGML_TYPE_F32 || !M->src[0] || !M->src[1] || M->src[0]->type != GGML_TYPE_F32 || M->src[1]->type != GGML_TYPE_F32 || M->src[0]->ne[3] != 1 || M->src[1]->ne[3] != 1) return false;
+            if (second_is_softmax && M->src[1]->op != GGML_OP_SOFT_MAX) return false;
+            for (int k = 0; k < (second_is_softmax ? 1 : 2); ++k) { const ggml_tensor * r = M->src[k]; while (r && r->op == GGML_OP_RESHAPE) r = r->src[0]; if (r == w) return true; }
+            return false;
+        };
+        // V^T = CONT(PERMUTE(RESHAPE(c))) with c a CONT [D, n, H, B] and the PERMUTE swapping the first two dims of its [D, n, H B] reshape: returns c
+        auto transposed_flat = [&](const ggml_tensor * v) -> const ggml_tensor * {
+            if (v->op != GGML_OP_CONT || !v->src[0] || v->src[0]->op != GGML_OP_PERMUTE) return nullptr;
+            const ggml_tensor * pm = v->src[0], * r = pm->src[0], * c = r;
+            while (c && c->op == GGML_OP_RESHAPE) c = c->src[0];
+            if (!r || !c || c->op != GGML_OP_CONT || !is_contiguous(r) || r->data != c->data || pm->data != r->data) return nullptr;
+            if (r->ne[0] != c->ne[0] || r->ne[1] != c->ne[1] || r->ne[2] != c->ne[2] * c->ne[3] || r->ne[3] != 1) return nullptr;
+            if (pm->ne[0] != r->ne[1] || pm->ne[1] != r->ne[0] || pm->ne[2] != r->ne[2] || pm->ne[3] != 1 || pm->nb[0] != r->nb[1] || pm->nb[1] != r->nb[0] || pm->nb[2] != r->nb[2]) return nullptr;
+            return c;
+        };
         const ggml_tensor * t = src->src[0];
-        if (off_c || n->ne[3] < 1 || src->nb[0] != 4 || !t->data || src->data != t->data || !is_contiguous(t) || src->ne[0] != t->ne[0] || src->ne[1] != t->ne[2] || src->ne[2] != t->ne[1] || src->ne[3] != t->ne[3]) return no(__LINE__);
-        const int u = sole_user(s, n);
-        if (u <= i) return no(__LINE__);
-        const ggml_tensor * M = g->nodes[u];
-        if (M->op != GGML_OP_MUL_MAT || M->type != GGML_TYPE_F32 || !M->src[0] || !M->src[1] || M->src[0]->type != GGML_TYPE_F32 || M->src[1]->type != GGML_TYPE_F32 || M->src[0]->ne[3] != 1 || M->src[1]->ne[3] != 1) return no(__LINE__);
-        { bool mine = false;
-          for (int k = 0; k < 2; ++k) { const ggml_tensor * w = M->src[k]; while (w && w->op == GGML_OP_RESHAPE) w = w->src[0]; if (w == n) mine = true; }
-          if (!mine || u - i > 64) return no(__LINE__); }
-        const byte_range rt = range_of(t);
-        for (int k = i + 1; k <= u; ++k) if (!is_noop(g->nodes[k]) && g->nodes[k]->data && overlap(range_of(g->nodes[k]), rt)) return no(__LINE__);
-        e.src = td(src); e.deadline = u + 1;
-    } else if (src->op == GGML_OP_PERMUTE) {                               // cache_tcb = CONT(PERMUTE(cache_in)), cache_in still lazy
-        const ggml_tensor * q = src->src[0];
-        auto lq = q ? s.lazy.find(q) : s.lazy.end();
-        if (lq == s.lazy.end() || src->data != q->data || src->ne[0] != q->ne[1] || src->ne[1] != q->ne[0] || src->ne[2] != q->ne[2] || src->nb[0] != q->nb[1] || src->nb[1] != q->nb[0] || src->nb[2] != q->nb[2]) return no(__LINE__);
-        if (!conv_concat_user(n)) return no(__LINE__);
-        e.src = swapped01(lq->second.src); e.deadline = lq->second.deadline;
+        const ggml_tensor * cflat = transposed_flat(n);
+        auto lc = cflat ? s.lazy.find(cflat) : s.lazy.end();
+        auto lt = s.lazy.find(t);
+        const int u_n = sole_user(s, n);
+        if (lc != s.lazy.end() && !off_c && u_n > i && f32_product_of(u_n, n, true)) {
+            // case C', second half: V^T of a flattened V that is itself lazy -- the f32 attention chain's second product reads V where it lies, keys a row apart
+            const int u = u_n;
+            if (u - i > 96) return no(__LINE__);
+            const byte_range rt = range_of(lc->second.src);
+            for (int k = i + 1; k <= u; ++k) if (!is_noop(g->nodes[k]) && g->nodes[k]->data && overlap(range_of(g->nodes[k]), rt)) return no(__LINE__);
+            e.src = swapped01(lc->second.src); e.deadline = u + 1;
+        } else if (lt != s.lazy.end()) {                                   // cache_tcb = CONT(PERMUTE(cache_in)), cache_in still lazy
+            const ggml_tensor * q = t;
+            if (src->data != q->data || src->ne[0] != q->ne[1] || src->ne[1] != q->ne[0] || src->ne[2] != q->ne[2] || src->nb[0] != q->nb[1] || src->nb[1] != q->nb[0] || src->nb[2] != q->nb[2]) return no(__LINE__);
+            if (!conv_concat_user(n)) return no(__LINE__);
+            e.src = swapped01(lt->second.src); e.deadline = lt->second.deadline;
+        } else {
+            // case C: the heads of Q / K / V flattened for the f32 attention chain, CONT(PERMUTE([D, H, n, B] -> [D, n, H, B])), read by one batched MUL_MAT (through reshapes)
+            // -- attn_f32 takes the permuted view itself -- or, for V, by the transposing copy above.  The source is a tensor of this graph: lazy only while nothing up to
+            // that reader writes over it.
+            if (off_c || n->ne[3] < 1 || src->nb[0] != 4 || !t->data || src->data != t->data || !is_contiguous(t) || src->ne[0] != t->ne[0] || src->ne[1] != t->ne[2] || src->ne[2] != t->ne[1] || src->ne[3] != t->ne[3]) return no(__LINE__);
+            const int u = sole_user(s, n);
+            if (u <= i || u - i > 64) return no(__LINE__);
+            if (!f32_product_of(u, n, false)) {
+                const ggml_tensor * U = g->nodes[u];
+                const int u2 = transposed_flat(U) == n ? sole_user(s, U) : -1;
+                if (u2 <= u || u2 - u > 96 || !f32_product_of(u2, U, true)) return no(__LINE__);
+            }
+            const byte_range rt = range_of(t);
+            for (int k = i + 1; k <= u; ++k) if (!is_noop(g->nodes[k]) && g->nodes[k]->data && overlap(range_of(g->nodes[k]), rt)) return no(__LINE__);
+            e.src = td(src); e.deadline = u + 1;
+        }
     } else return no(__LINE__);
     if (dbg) ++why[0];
     ++s.c->stat_lazy_taken;

@@ -343,6 +343,7 @@ struct attn_f32_args {
     int64_t D, nq, nkv, HB, H;
     float s1 = 1.0f, b1 = 0.0f, s2 = 1.0f; bool has_scale = false;
     size_t q_bs2 = 0, k_bs2 = 0; int64_t q_H = 0, k_H = 0;      // q_H / k_H > 0: that operand's head-batch index is h + H s at h * bs + s * bs2 (a permuted 4-D view read in place)
+    size_t v_ks = 0, v_bs2 = 0; int64_t v_H = 0;                // v_ks != 0: `vt` is V itself, element (key k, dim d) at k * v_ks + d * 4; head-batch index h + v_H s at h * v_bs + s * v_bs2
 };
 bool   attn_f32_ok(const attn_f32_args & a);
 void   attn_f32(const attn_f32_args & a, hipStream_t st);

@@ -15,6 +15,7 @@ struct attn_f32_dev {
     const char * q, * k, * vt; char * dst;
     size_t q_rs, q_bs, k_rs, k_bs, v_rs, v_bs;          // row / head-batch strides (bytes)
     size_t q_bs2, k_bs2; int q_H, k_H;                  // Q / K read where a permuted view leaves them: head-batch index hb = h + H s at h * bs + s * bs2 (H = HB: one level)
+    size_t v_bs2, v_ks; int v_H;                        // v_ks != 0: V itself instead of V^T -- element (key k, dim d) at k * v_ks + d * 4, head-batch offsets like Q / K
     size_t d_nb_q, d_nb_h, d_nb_s;                      // dst: element (d, q, h, s) at d * 4 + q * d_nb_q + h * d_nb_h + s * d_nb_s
     int nq, nkv, H, ldp;                                // H: heads per batch element of the destination's split of the head-batch index
     float s1, b1, s2;
@@ -29,7 +30,8 @@ __global__ void __launch_bounds__(256) k_attn_f32(const attn_f32_dev a) {
     float * S = af_lds;                                  // [16][ldp]
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, r16 = lane & 15, gq = lane >> 4;
     const int q0 = (int) blockIdx.x * 16, hb = (int) blockIdx.y;
-    const char * Q = a.q + (size_t) (hb % a.q_H) * a.q_bs + (size_t) (hb / a.q_H) * a.q_bs2, * K = a.k + (size_t) (hb % a.k_H) * a.k_bs + (size_t) (hb / a.k_H) * a.k_bs2, * VT = a.vt + (size_t) hb * a.v_bs;
+    const char * Q = a.q + (size_t) (hb % a.q_H) * a.q_bs + (size_t) (hb / a.q_H) * a.q_bs2, * K = a.k + (size_t) (hb % a.k_H) * a.k_bs + (size_t) (hb / a.k_H) * a.k_bs2,
+               * VT = a.vt + (size_t) (hb % a.v_H) * a.v_bs + (size_t) (hb / a.v_H) * a.v_bs2;
     // ---- 1. scores
     {
         const int qr = q0 + r16 < a.nq ? q0 + r16 : a.nq - 1;
@@ -107,6 +109,10 @@ __global__ void __launch_bounds__(256) k_attn_f32(const attn_f32_dev a) {
                 if (V4) {                                // nkv % 4 == 0 and 16-byte aligned rows: a quad is inside or outside as a whole
                     v = *(const float4 *) (vrow + (size_t) (k < a.nkv ? k : a.nkv - 4) * 4);
                     if (k >= a.nkv) v = make_float4(0.f, 0.f, 0.f, 0.f);
+                } else if (a.v_ks) {                     // V as the graph has it ([D, H, n, B] permuted): four keys of this lane's dim, one row apart (16 lanes = 64 consecutive bytes of a row)
+                    const char * vb = VT + (size_t) (d_ok ? d0 + r16 : D - 1) * 4;
+                    v.x = k + 0 < a.nkv ? *(const float *) (vb + (size_t) (k + 0) * a.v_ks) : 0.f; v.y = k + 1 < a.nkv ? *(const float *) (vb + (size_t) (k + 1) * a.v_ks) : 0.f;
+                    v.z = k + 2 < a.nkv ? *(const float *) (vb + (size_t) (k + 2) * a.v_ks) : 0.f; v.w = k + 3 < a.nkv ? *(const float *) (vb + (size_t) (k + 3) * a.v_ks) : 0.f;
                 } else {                                 // (206 keys: rows of 824 bytes)
                     const float * vr = (const float *) vrow;
                     v.x = vr[k + 0 < a.nkv ? k + 0 : 0]; v.y = vr[k + 1 < a.nkv ? k + 1 : 0]; v.z = vr[k + 2 < a.nkv ? k + 2 : 0]; v.w = vr[k + 3 < a.nkv ? k + 3 : 0];
@@ -140,6 +146,7 @@ bool attn_f32_ok(const attn_f32_args & a) {
     if (off || (a.D != 64 && a.D != 72 && a.D != 80 && a.D != 96 && a.D != 128) || a.nq < 1 || a.nkv < 1 || a.nkv > 4096 || a.HB < 1 || a.HB > 65535 || a.H < 1) return false;
     if ((((uintptr_t) a.q | a.q_rs | a.q_bs | (uintptr_t) a.k | a.k_rs | a.k_bs) & 15) != 0) return false;
     if ((a.q_H > 0 && ((a.q_bs2 & 15) != 0 || a.HB % a.q_H != 0)) || (a.k_H > 0 && ((a.k_bs2 & 15) != 0 || a.HB % a.k_H != 0))) return false;
+    if (a.v_ks && ((a.v_ks & 3) != 0 || a.v_H < 1 || a.HB % a.v_H != 0 || (a.v_bs2 & 3) != 0)) return false;
     return (((uintptr_t) a.dst | (uintptr_t) a.vt | a.v_rs | a.v_bs) & 3) == 0;
 }
 void attn_f32(const attn_f32_args & a, hipStream_t st) {
@@ -149,10 +156,11 @@ void attn_f32(const attn_f32_args & a, hipStream_t st) {
     d.q_rs = a.q_rs; d.q_bs = a.q_bs; d.k_rs = a.k_rs; d.k_bs = a.k_bs; d.v_rs = a.v_rs; d.v_bs = a.v_bs;
     d.d_nb_q = a.d_nb_q; d.d_nb_h = a.d_nb_h; d.d_nb_s = a.d_nb_s;
     d.q_H = a.q_H > 0 ? (int) a.q_H : (int) a.HB; d.q_bs2 = a.q_H > 0 ? a.q_bs2 : 0; d.k_H = a.k_H > 0 ? (int) a.k_H : (int) a.HB; d.k_bs2 = a.k_H > 0 ? a.k_bs2 : 0;
+    d.v_ks = a.v_ks; d.v_H = a.v_ks ? (int) a.v_H : (int) a.HB; d.v_bs2 = a.v_ks ? a.v_bs2 : 0;
     d.nq = (int) a.nq; d.nkv = (int) a.nkv; d.H = (int) a.H; d.ldp = (int) (((a.nkv + 63) / 64) * 64 + 4);
     d.s1 = a.s1; d.b1 = a.b1; d.s2 = a.s2; d.has_scale = a.has_scale ? 1 : 0;
     const int lds = 16 * d.ldp * 4;
-    const bool v4 = a.nkv % 4 == 0 && (((uintptr_t) a.vt | a.v_rs | a.v_bs) & 15) == 0;
+    const bool v4 = !a.v_ks && a.nkv % 4 == 0 && (((uintptr_t) a.vt | a.v_rs | a.v_bs) & 15) == 0;
     const dim3 grid((unsigned) ((a.nq + 15) / 16), (unsigned) a.HB);
     int dev = 0; HIP_CHECK(hipGetDevice(&dev));
     auto go = [&](auto k4, auto k1, int slot) {
