@@ -251,3 +251,33 @@ def test_lazy_cache_copies_become_real_when_somebody_else_reads_them(pkg, be, re
     assert be.get_stat("lazy_conts") - n0 == 2 and be.get_stat("lazy_conts_materialised") - m0 == 2      # both copies were deferred, both were made real by their readers
     for g, w in zip(got, want):
         assert np.array_equal(g, w)
+
+
+@pytest.mark.parametrize("Tq,Tk", [(56, 206), (50, 200)])
+def test_attention_chain_reads_its_operands_through_the_permuted_views(pkg, be, ref_be, Tq, Tk):
+    """graph_exec.cpp lazy_try_register, case C: the DiT attention as token2wav-impl.cpp:245-291 / :470-497 spells it -- Q, K, V [D, H, T, B] each flattened by CONT(PERMUTE),
+    V transposed by a second CONT(PERMUTE), K.Q -> SCALE -> SOFT_MAX -> V^T.P -> merge.  The four copies are not run: k_attn_f32 reads the permuted 4-D views (two-level
+    head-batch strides; V itself, keys a row apart).  206 keys: rows of V^T would be 824 bytes, the odd-length path.  Bar: the fused chain's f32 arithmetic against the reference
+    CPU backend's separate nodes, NMSE <= 1e-10; the copies must have been deferred and only the merge's reader-less CONT may be real."""
+    F32 = pkg.GGML_TYPE_F32
+    D, H, B = 64, 8, 2
+
+    def build(c):
+        q, k, v = c.new_tensor(F32, D, H, Tq, B), c.new_tensor(F32, D, H, Tk, B), c.new_tensor(F32, D, H, Tk, B)
+
+        def flat(t, T):
+            return c.reshape(c.cont(c.permute(t, 0, 2, 1, 3)), D, T, H * B)
+        qf, kf = flat(q, Tq), flat(k, Tk)
+        vf = c.reshape(c.cont(c.permute(flat(v, Tk), 1, 0, 2, 3)), Tk, D, H * B)
+        scores = c.scale(c.mul_mat(kf, qf), 1.0 / 8.0)
+        probs = c.soft_max_ext(scores, None, 1.0, 0.0)
+        ctx = c.mul_mat(vf, probs)                                                        # [D, Tq, H B]
+        merged = c.cont(c.permute(c.reshape(ctx, D, Tq, H, B), 0, 2, 1, 3))               # [D, H, Tq, B]
+        return {"q": q, "k": k, "v": v}, [merged]
+
+    n0, m0 = be.get_stat("lazy_conts"), be.get_stat("lazy_conts_materialised")
+    got, want = _run_both(pkg, be, ref_be, build, lambda rng, name, t: _randn(rng, name, t))
+    assert be.get_stat("lazy_conts") - n0 == 4 and be.get_stat("lazy_conts_materialised") - m0 == 0, (be.get_stat("lazy_conts") - n0, be.get_stat("lazy_conts_materialised") - m0)
+    e = nmse(got[0], want[0])
+    print("attention chain through lazy operands, NMSE vs the reference CPU backend:", e)
+    assert e <= 1e-10, e
