@@ -2029,8 +2029,19 @@ static void compute_node(exec_state & s, int i) {
             break;
         }
         case GGML_OP_CONCAT: {
+            // an operand whose copy was left un-run (lazy_try_register) is read where its source lies; anything lazy further up a view chain is made real first
+            tdesc sd[2] = { td(n->src[0]), td(n->src[1]) };
+            const ggml_tensor * lz[2] = { nullptr, nullptr };
+            if (!s.lazy.empty()) {
+                for (int k = 0; k < 2; ++k) {
+                    auto it = s.lazy.find(n->src[k]);
+                    if (it != s.lazy.end() && it->second.deadline > i && n->type == GGML_TYPE_F32 && !overlap(range_of(n), range_of(it->second.src))) { sd[k] = it->second.src; lz[k] = n->src[k]; }
+                }
+                for (int k = 0; k < 2; ++k) if (lz[k]) s.lazy.erase(lz[k]);     // (taken in place: their one reader is this node)
+                lazy_net(s, i);                                            // everything else this node reads, and the deadlines
+            }
             prof_scope ps(s, "concat", 0);
-            concat(td(n->src[0]), td(n->src[1]), td(n), op_param_i32(n, 0), n->type == GGML_TYPE_F16 ? 2 : 4, s.st); ++s.n_kernels;
+            concat(sd[0], sd[1], td(n), op_param_i32(n, 0), n->type == GGML_TYPE_F16 ? 2 : 4, s.st); ++s.n_kernels;
             break;
         }
         case GGML_OP_REPEAT: {
@@ -2575,8 +2586,14 @@ static bool lazy_try_register(exec_state & s, int i) {
             if (u <= i || u - i > 64) return no(__LINE__);
             if (!f32_product_of(u, n, false)) {
                 const ggml_tensor * U = g->nodes[u];
-                const int u2 = transposed_flat(U) == n ? sole_user(s, U) : -1;
-                if (u2 <= u || u2 - u > 96 || !f32_product_of(u2, U, true)) return no(__LINE__);
+                // ... or by a CONCAT that takes it directly (the new K / V cache rows: CONCAT(CONT(PERMUTE(k)), CONT(PERMUTE(v)), 0), token2wav-impl.cpp:340-347): the generic
+                // concat kernel reads both operands through their strides (compute_node, CONCAT)
+                static const bool off_cc = getenv("MI355X_NO_LAZY_CONCAT_SRC") != nullptr;
+                const bool concat_reader = !off_cc && U->op == GGML_OP_CONCAT && U->type == GGML_TYPE_F32 && (U->src[0] == n || U->src[1] == n) && U->src[0]->type == GGML_TYPE_F32 && U->src[1]->type == GGML_TYPE_F32;
+                if (!concat_reader) {
+                    const int u2 = transposed_flat(U) == n ? sole_user(s, U) : -1;
+                    if (u2 <= u || u2 - u > 96 || !f32_product_of(u2, U, true)) return no(__LINE__);
+                }
             }
             const byte_range rt = range_of(t);
             for (int k = i + 1; k <= u; ++k) if (!is_noop(g->nodes[k]) && g->nodes[k]->data && overlap(range_of(g->nodes[k]), rt)) return no(__LINE__);
@@ -2980,7 +2997,7 @@ void run_nodes(exec_state & s, ggml_cgraph * g) {
         if (g->nodes[i]->op == GGML_OP_CONT && exec_causal_conv(s, i)) continue;
         if ((g->nodes[i]->op == GGML_OP_CONT || g->nodes[i]->op == GGML_OP_CONCAT) && exec_concat_tail(s, i)) continue;
         if (g->nodes[i]->op == GGML_OP_CONT && lazy_try_register(s, i)) continue;
-        if (!is_noop(g->nodes[i]) && !(g->nodes[i]->op == GGML_OP_MUL_MAT && g->nodes[i]->src[0]->type == GGML_TYPE_F32 && g->nodes[i]->src[1]->type == GGML_TYPE_F32)) lazy_net(s, i);
+        if (!is_noop(g->nodes[i]) && g->nodes[i]->op != GGML_OP_CONCAT && !(g->nodes[i]->op == GGML_OP_MUL_MAT && g->nodes[i]->src[0]->type == GGML_TYPE_F32 && g->nodes[i]->src[1]->type == GGML_TYPE_F32)) lazy_net(s, i);
         if (g->nodes[i]->op == GGML_OP_MUL && exec_gate_norm(s, i)) continue;
         {
             int taken[8];

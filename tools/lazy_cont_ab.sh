@@ -7,7 +7,7 @@ cd "$(dirname "$0")/.."
 ROOT=$PWD
 [ -d /tmp/t2w ] || python tools/make_synth_omni_gguf.py --module t2w -o /tmp/t2w > /dev/null
 export GGML_BACKEND_PATH=$ROOT/llama.cpp-omni_amd/lib/libggml-mi355x.so
-for V in off conv all; do
+for V in off conv all; do  # (MI355X_NO_LAZY_CONCAT_SRC=1 switches the CONCAT-operand form off separately)
   echo "-- lazy copies: $V"
   unset MI355X_NO_LAZY_CACHE_CONT MI355X_NO_LAZY_ATTN_CONT
   [ $V = off ] && export MI355X_NO_LAZY_CACHE_CONT=1 MI355X_NO_LAZY_ATTN_CONT=1
