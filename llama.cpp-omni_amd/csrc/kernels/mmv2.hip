@@ -34,19 +34,23 @@ namespace mi {
 // loads, as before.)  Everything else (`rest`: destination pointers, the second and third matrix of a grouped launch, a ready-made image) is read
 // through the kernarg segment pointer where it is first needed -- never by name, or hipcc hoists its loads to the entry and every early
 // s_waitcnt lgkmcnt(0) waits for them.
+#define MV2_WGT_PACKED 0x80000000u
+static __device__ __forceinline__ int mv2_wgt_type(uint32_t wgt, int i) { const uint32_t c = (wgt >> (24 + 2 * i)) & 3u; return c == 1u ? GGML_TYPE_Q4_K : c == 2u ? GGML_TYPE_Q6_K : GGML_TYPE_Q8_0; }
 typedef const __attribute__((address_space(4))) mv2_dev * mv2_karg;
 #define MV2_REST_OFFSET 56
-template <int TM, int NIT, bool PAIR, bool NT>
-__global__ void __launch_bounds__(64 * MV2_WAVES) k_mv2(const char * W0, const float * x, const float * nw, const char * aux /* pair: the up matrix; else: m[0]'s residual */,
-                                                         uint32_t w_rs0, int nrows0, int q0, int r0, float eps, int wg1 /* first workgroup of m[1] (the grid if none) */, const mv2_dev rest) {
+template <int TM, int NIT, bool PAIR, bool NT, int NW = MV2_WAVES>
+__global__ void __launch_bounds__(64 * NW) k_mv2(const char * W0, const float * x, const float * nw, const char * aux /* pair: the up matrix; one matrix: its residual; a group: the offsets of W1 / W2 */,
+                                                         uint32_t w_rs0, uint32_t qr0, uint32_t qr1, uint32_t qr2, float eps, uint32_t wgt /* MV2_WGT: first workgroups of m[1] / m[2], their types */, const mv2_dev rest) {
     __shared__ mv2_flags F;
     __shared__ double red[16];
-    constexpr int C = MV2_WAVES - 1;
+    constexpr int C = NW - 1;
+    constexpr int PW = 4 * NIT < C ? 4 * NIT : C;   // prologue waves
     typedef mv2_geo<2304, 1, NIT> geo0;                // (IMG and STG do not depend on the weight type)
     MV2_STAMP_DECL;
     MV2_STAMP(0);
 #ifdef MV2_TRACE
     tr_[6] = __builtin_amdgcn_s_getreg((4 /*HW_REG_HW_ID*/) | (0 << 6) | (31 << 11));
+    if (threadIdx.x < 64) tr_[5] = __builtin_amdgcn_s_getreg((20 /*HW_REG_XCC_ID*/) | (0 << 6) | (31 << 11));
 #endif
     if (threadIdx.x < sizeof(mv2_flags) / 4) ((uint32_t *) &F)[threadIdx.x] = 0u;
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -55,8 +59,8 @@ __global__ void __launch_bounds__(64 * MV2_WAVES) k_mv2(const char * W0, const f
     // The scalar unit is one per CU: sixteen waves running their set-up at once take ~0.5 us of it.  The loader and the row waves are on the
     // launch's critical path and go first (and at raised priority); the waves that only build the image or only consume stay out of the way.
 #ifndef MV2_NO_STAGGER
-    if (wiw == 0 || wiw >= MV2_WAVES - MV2_ROW_WAVES) __builtin_amdgcn_s_setprio(3);
-    else if (wiw <= 4 * NIT) __builtin_amdgcn_s_sleep(12);
+    if (wiw == 0 || wiw >= NW - MV2_ROW_WAVES) __builtin_amdgcn_s_setprio(3);
+    else if (wiw <= PW) __builtin_amdgcn_s_sleep(12);
     else { __builtin_amdgcn_s_sleep(40); }
 #endif
     uint64_t kp = (uint64_t) (uintptr_t) __builtin_amdgcn_kernarg_segment_ptr();
@@ -65,17 +69,32 @@ __global__ void __launch_bounds__(64 * MV2_WAVES) k_mv2(const char * W0, const f
     (void) rest;
     const int K = 4096 * NIT;
     mv2_mat M;
-    M.W = W0; M.w_rs = w_rs0; M.nrows = nrows0; M.q = q0; M.r = r0; M.wg0 = 0; M.resid = PAIR ? nullptr : aux; M.dst = nullptr;
-    M.type = TM == 2 ? GGML_TYPE_Q6_K : (TM == 4 ? GGML_TYPE_Q8_0 : GGML_TYPE_Q4_K);
+    M.W = W0; M.w_rs = w_rs0; M.nrows = 0; M.q = (int) (qr0 & 0xffffu); M.r = (int) (qr0 >> 16); M.wg0 = 0; M.resid = PAIR ? nullptr : aux; M.dst = nullptr;
+    M.type = TM == 2 ? GGML_TYPE_Q6_K : (TM == 4 ? GGML_TYPE_Q8_0 : (TM == 3 ? mv2_wgt_type(wgt, 0) : GGML_TYPE_Q4_K));
     int mi_ = 0;
-    if (!PAIR && wg >= wg1) {                           // a workgroup of the second / third matrix: its description comes from the argument block
-        mi_ = (R->nmat > 2 && wg >= R->m[2].wg0) ? 2 : 1;
-        const __attribute__((address_space(4))) uint32_t * wsrc = (const __attribute__((address_space(4))) uint32_t *) &R->m[mi_];
-        uint32_t wbuf[sizeof(mv2_mat) / 4];
+    const int wg1 = (int) (wgt & 0xfffu);
+    if (!PAIR && wg >= wg1) {                           // a workgroup of the second / third matrix
+        const int wg2 = (int) ((wgt >> 12) & 0xfffu);
+        mi_ = wg >= wg2 ? 2 : 1;
+        if (wgt & MV2_WGT_PACKED) {
+            // its description is in the pre-loaded scalars too (round 6: as two dependent scalar loads of the argument block -- the matrix index, then the
+            // matrix -- these workgroups' first weight request went out 0.9 us after everybody else's and the launch ended with them, tools/mmv2_lab.hip):
+            // W = W0 + 16 x a signed 32-bit offset (the two halves of `aux`: a group has neither a pair matrix nor residuals), rows tightly packed
+            const uint64_t offs = (uint64_t) (uintptr_t) aux;
+            const int32_t off16 = (int32_t) (mi_ == 2 ? (uint32_t) (offs >> 32) : (uint32_t) offs);
+            const uint32_t qr = mi_ == 2 ? qr2 : qr1;
+            M.W = W0 + (int64_t) off16 * 16; M.q = (int) (qr & 0xffffu); M.r = (int) (qr >> 16); M.wg0 = mi_ == 2 ? wg2 : wg1; M.resid = nullptr;
+            M.type = mv2_wgt_type(wgt, mi_);
+            M.w_rs = (uint32_t) (K / 256) * (M.type == GGML_TYPE_Q4_K ? 144u : M.type == GGML_TYPE_Q6_K ? 210u : 272u);
+        } else {                                        // (a group the scalars cannot describe -- residuals, padded rows, matrices > 32 GB apart: from the argument block)
+            const __attribute__((address_space(4))) uint32_t * wsrc = (const __attribute__((address_space(4))) uint32_t *) &R->m[mi_];
+            uint32_t wbuf[sizeof(mv2_mat) / 4];
 #pragma unroll
-        for (size_t k = 0; k < sizeof(mv2_mat) / 4; ++k) wbuf[k] = wsrc[k];
-        __builtin_memcpy(&M, wbuf, sizeof M);
-    } else if (TM == 3) { asm volatile("" ::: "memory"); M.type = R->m[0].type; }
+            for (size_t k = 0; k < sizeof(mv2_mat) / 4; ++k) wbuf[k] = wsrc[k];
+            __builtin_memcpy(&M, wbuf, sizeof M);
+        }
+    }
+    if (!PAIR && (wgt & MV2_WGT_PACKED)) M.resid = nullptr;      // (`aux` holds offsets)
     const char * img = nullptr;
     if (x == nullptr) { asm volatile("" ::: "memory"); img = R->src.img; }      // (a real branch: a speculated scalar load would put a round trip in front of every wave)
     const mv1_src src = { x, nw, eps, img };
@@ -91,7 +110,8 @@ __global__ void __launch_bounds__(64 * MV2_WAVES) k_mv2(const char * W0, const f
     const bool q4 = TM == 1 || ((TM & 1) && M.type == GGML_TYPE_Q4_K);
     MV2_STAMP(1);
     if (wiw == 0) {
-        const mv1_rsrc rs0 = mv1_make_rsrc(M.W, (size_t) M.nrows * M.w_rs), rs1 = mv1_make_rsrc(PAIR ? W1 : M.W, (size_t) M.nrows * M.w_rs);
+        const size_t wbytes = (size_t) (G0 + ntask) * M.w_rs;      // (the workgroup's rows end here: nothing of the launch is requested past them)
+        const mv1_rsrc rs0 = mv1_make_rsrc(M.W, wbytes), rs1 = mv1_make_rsrc(PAIR ? W1 : M.W, wbytes);
         if constexpr (Q80) mv2_loader<4352, PAIR ? 2 : 1, NIT, C, NT>(rs0, rs1, (uint32_t) M.w_rs, G0, ntask * NIT, mv2_lds_addr(ringp), &F MV2_TR_ARG);
         else if (q4) mv2_loader<2304, PAIR ? 2 : 1, NIT, C, NT>(rs0, rs1, (uint32_t) M.w_rs, G0, ntask * NIT, mv2_lds_addr(ringp), &F MV2_TR_ARG);
         else if constexpr ((TM & 2) != 0 && !PAIR) mv2_loader<3360, 1, NIT, C, NT>(rs0, rs1, (uint32_t) M.w_rs, G0, ntask * NIT, mv2_lds_addr(ringp), &F MV2_TR_ARG);
@@ -103,14 +123,14 @@ __global__ void __launch_bounds__(64 * MV2_WAVES) k_mv2(const char * W0, const f
         if (c >= C - MV2_ROW_WAVES) mv2_row_loader(src, K, c - (C - MV2_ROW_WAVES), resid_p, G0, ntask, mv2_lds_addr(stg), mv2_lds_addr(rstg), &F MV2_TR_ARG);
         uint32_t img_need = 4 * NIT;
         if (src.img) { if constexpr (Q80) mv2_image_copy_q80<C>(src.img, K, c, im, &F); else mv2_image_copy<C>(src.img, K, c, im, &F); img_need = C; }
-        else if (c < 4 * NIT) mv2_prologue<NIT, Q80>(src, K, c, im, stg, red, &F MV2_TR_ARG);
+        else if (c < PW) mv2_prologue<NIT, Q80, PW>(src, K, c, im, stg, red, &F MV2_TR_ARG);
         { uint32_t spins = 0; while (mv2_peek(MV2_FLAG(F.img_cnt)) < img_need) { __builtin_amdgcn_s_sleep(4); if (++spins > MV2_SPIN_MAX) __builtin_trap(); } asm volatile("" ::: "memory"); }
         // the residual of this consumer's tasks, one per lane (task k of the consumer is row G0 + c + k C), from the staging area: the consumers
         // issue NO vector-memory loads -- one would wait for a place in the CU's memory queue behind the loader's stream
         float resid = 0.0f;
         if (resid_p) { mv2_await(MV2_FLAG(F.x_landed), MV2_ROW_WAVES); const int r = c + lane * C; if (r < ntask) resid = *(const float *) (rstg + r * 4); }
         MV2_STAMP(4);
-        char * dst = mi_ == 0 ? R->m[0].dst : M.dst;     // (needed when the first results are stored)
+        char * dst = R->m[mi_].dst;                        // (needed when the first results are stored)
         if constexpr (Q80) mv2_consume_q80<PAIR ? 2 : 1, NIT, C, PAIR>(im, ringp, K, c, ntask, dst, G0 + c, resid, &F);
         else if (q4) mv2_consume_q4k<PAIR ? 2 : 1, NIT, C, PAIR>(im, ringp, K, c, ntask, dst, G0 + c, resid, &F);
         else if constexpr ((TM & 2) != 0 && !PAIR) mv2_consume_q6k<NIT, C>(im, ringp, K, c, ntask, dst, G0 + c, resid, &F);
@@ -152,15 +172,29 @@ bool mmv2_ok(const mv1_args & a) {
     return a.x && ((uintptr_t) a.x & 15) == 0 && ((uintptr_t) a.norm_w & 15) == 0;
 }
 
-template <int TM, int NIT, bool PAIR, bool NT>
+template <int TM, int NIT, bool PAIR, bool NT, int NW = MV2_WAVES>
 static void mv2_launch(const mv2_dev & d, int grid, hipStream_t st) {
     const size_t lds = 160 * 1024 - 512;                                                       // image + staging + ring: the whole CU (mv2_geo)
     static bool attr[64] = { false };
     const int dev = mv2_dev_ordinal();
-    if (!attr[dev]) { HIP_CHECK(hipFuncSetAttribute((const void *) k_mv2<TM, NIT, PAIR, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds)); attr[dev] = true; }
+    if (!attr[dev]) { HIP_CHECK(hipFuncSetAttribute((const void *) k_mv2<TM, NIT, PAIR, NT, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds)); attr[dev] = true; }
     static_assert(offsetof(mv2_dev, src) % 8 == 0, "argument block layout");
-    k_mv2<TM, NIT, PAIR, NT><<<dim3(grid), dim3(64 * MV2_WAVES), lds, st>>>(d.m[0].W, d.src.img ? nullptr : d.src.x, d.src.nw, PAIR ? d.W1 : d.m[0].resid, d.m[0].w_rs, d.m[0].nrows, d.m[0].q, d.m[0].r,
-                                                                           d.src.eps, d.nmat > 1 ? d.m[1].wg0 : grid, d);
+    // the scalars of the launch (see k_mv2): q | r << 16 per matrix; wgt = first workgroup of m[1] | of m[2] << 12 | the three types << 24 | MV2_WGT_PACKED
+    auto qr = [&](int i) { return (uint32_t) d.m[i].q | ((uint32_t) d.m[i].r << 16); };
+    auto tcode = [&](int i) { return d.m[i].type == GGML_TYPE_Q4_K ? 1u : d.m[i].type == GGML_TYPE_Q6_K ? 2u : 3u; };
+    const int wg1 = d.nmat > 1 ? d.m[1].wg0 : grid, wg2 = d.nmat > 2 ? d.m[2].wg0 : grid;
+    uint32_t wgt = (uint32_t) wg1 | ((uint32_t) wg2 << 12) | (tcode(0) << 24) | (tcode(d.nmat > 1 ? 1 : 0) << 26) | (tcode(d.nmat > 2 ? 2 : 0) << 28);
+    const char * aux = PAIR ? d.W1 : d.m[0].resid;
+    bool packed = !PAIR && d.nmat > 1 && grid < 4096;
+    int64_t off[3] = { 0, 0, 0 };
+    for (int i = 0; i < d.nmat && packed; ++i) {
+        const uint32_t tight = (uint32_t) (d.K / 256) * (d.m[i].type == GGML_TYPE_Q4_K ? 144u : d.m[i].type == GGML_TYPE_Q6_K ? 210u : 272u);
+        off[i] = ((int64_t) (intptr_t) d.m[i].W - (int64_t) (intptr_t) d.m[0].W) / 16;
+        if (d.m[i].resid || d.m[i].q > 0xffff || d.m[i].r > 0xffff || (i > 0 && (d.m[i].w_rs != tight || off[i] != (int64_t) (int32_t) off[i] || (((intptr_t) d.m[i].W - (intptr_t) d.m[0].W) & 15) != 0))) packed = false;
+    }
+    if (packed) { wgt |= MV2_WGT_PACKED; aux = (const char *) (uintptr_t) ((uint64_t) (uint32_t) (int32_t) off[1] | ((uint64_t) (uint32_t) (int32_t) off[2] << 32)); }
+    if (d.m[0].q > 0xffff || d.m[0].r > 0xffff || grid > 4095) { fprintf(stderr, "[mi355x] mmv2: %d rows per workgroup\n", d.m[0].q); abort(); }
+    k_mv2<TM, NIT, PAIR, NT, NW><<<dim3(grid), dim3(64 * NW), lds, st>>>(d.m[0].W, d.src.img ? nullptr : d.src.x, d.src.nw, aux, d.m[0].w_rs, qr(0), qr(d.nmat > 1 ? 1 : 0), qr(d.nmat > 2 ? 2 : 0), d.src.eps, wgt, d);
 }
 
 // workgroup ranges of the matrices of a launch: by bytes, every matrix at least one workgroup
@@ -195,6 +229,10 @@ void mmv2(const mv1_args & a, hipStream_t st) {
     mv2_dev d; int tm;
     const int grid = mv2_plan(a, d, tm);
     const bool pair = a.W_up != nullptr;
+    // waves per workgroup (1 loader + the consumers), by launch shape: tools/mmv2_lab.hip sweep (profiles/r06_mv2_waves.txt).  The long pair launch keeps sixteen; the short
+    // ones run faster with fewer waves contending for the CU's issue slots through the prologue and the tail: the three-matrix group with twelve (6.4 -> 6.1 us), one
+    // matrix of a few thousand rows with ten (ffn_down Q4_K 8.1 -> 7.5, Q6_K 11.4 -> 9.6, wo 5.0 -> 4.8); the lm-head (hundreds of steps per workgroup) keeps sixteen
+    const bool small = a.nmat == 1 && a.m[0].nrows <= 16384;
     if (tm == 4) {                                                                           // Q8_0
         if (pair)              mv2_launch<4, 1, true, true>(d, grid, st);
         else if (a.K == 4096)  mv2_launch<4, 1, false, true>(d, grid, st);
@@ -203,13 +241,29 @@ void mmv2(const mv1_args & a, hipStream_t st) {
     }
     if (pair)               { mv2_launch<1, 1, true, true>(d, grid, st); return; }
     if (a.K == 4096) {
-        if (tm == 1)      mv2_launch<1, 1, false, true>(d, grid, st);
-        else if (tm == 2) mv2_launch<2, 1, false, true>(d, grid, st);
-        else              mv2_launch<3, 1, false, true>(d, grid, st);
+        if (a.nmat > 1) {
+            if (tm == 1)      mv2_launch<1, 1, false, true, 12>(d, grid, st);
+            else if (tm == 2) mv2_launch<2, 1, false, true, 12>(d, grid, st);
+            else              mv2_launch<3, 1, false, true, 12>(d, grid, st);
+        } else if (small) {
+            if (tm == 1)      mv2_launch<1, 1, false, true, 10>(d, grid, st);
+            else              mv2_launch<2, 1, false, true, 10>(d, grid, st);
+        } else {
+            if (tm == 1)      mv2_launch<1, 1, false, true>(d, grid, st);
+            else              mv2_launch<2, 1, false, true>(d, grid, st);
+        }
     } else {
-        if (tm == 1)      mv2_launch<1, 3, false, true>(d, grid, st);
-        else if (tm == 2) mv2_launch<2, 3, false, true>(d, grid, st);
-        else              mv2_launch<3, 3, false, true>(d, grid, st);
+        if (a.nmat > 1) {
+            if (tm == 1)      mv2_launch<1, 3, false, true>(d, grid, st);
+            else if (tm == 2) mv2_launch<2, 3, false, true>(d, grid, st);
+            else              mv2_launch<3, 3, false, true>(d, grid, st);
+        } else if (small) {
+            if (tm == 1)      mv2_launch<1, 3, false, true, 10>(d, grid, st);
+            else              mv2_launch<2, 3, false, true, 10>(d, grid, st);
+        } else {
+            if (tm == 1)      mv2_launch<1, 3, false, true>(d, grid, st);
+            else              mv2_launch<2, 3, false, true>(d, grid, st);
+        }
     }
 }
 

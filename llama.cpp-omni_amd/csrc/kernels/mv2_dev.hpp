@@ -30,7 +30,9 @@ __device__ unsigned long long * mv2_trace_buf = nullptr;
 #define MV2_LGKM0()   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 template <int N> static __device__ __forceinline__ void mv2_vmcnt() { static_assert(N >= 0 && N < 64, "vmcnt is 6 bits"); asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
 
-#define MV2_WAVES 16
+#ifndef MV2_WAVES
+#define MV2_WAVES 16           // waves per workgroup: 1 loader + MV2_WAVES - 1 consumers (lab builds: 8 / 12)
+#endif
 #ifndef MV2_ROW_WAVES
 #define MV2_ROW_WAVES 4          // consumers that fetch the activation row before they consume
 #endif
@@ -350,31 +352,41 @@ static __device__ __forceinline__ void mv2_q80_rows(const f32x4 (&y)[4], int lan
     }
 }
 
-// prologue wave mw of 4 NIT (consumers 0 .. 4 NIT - 1: NIT per SIMD): image blocks 4 mw + row
-template <int NIT, bool Q80 = false>
-static __device__ __forceinline__ void mv2_prologue(const mv1_src s, int K, int mw, char * im, const char * stg, double * red, mv2_flags * F MV2_TR_PARAM) {
+// prologue wave pw of PW = min(4 NIT, C) (consumers 0 .. PW - 1): image block groups mw = pw, pw + PW, ... < 4 NIT, group mw = blocks 4 mw + row.
+// With sixteen waves PW = 4 NIT and every wave owns one group (NIT per SIMD); narrower workgroups loop.  A wave publishes the sums of ALL its
+// groups before it waits for the scale (the last arrival -- of 4 NIT -- computes it).
+template <int NIT, bool Q80 = false, int PW = 4 * NIT>
+static __device__ __forceinline__ void mv2_prologue(const mv1_src s, int K, int pw, char * im, const char * stg, double * red, mv2_flags * F MV2_TR_PARAM) {
     const int lane = threadIdx.x & 63, row = lane >> 4, i = lane & 15, nb = K >> 8;
+    constexpr int NG = (4 * NIT + PW - 1) / PW;          // groups per wave (at most)
     mv2_await(MV2_FLAG(F->x_landed), MV2_ROW_WAVES);
     MV2_STAMP(2);
     float scale = 1.0f;
-    f32x4 x[4];
+    f32x4 x[NG][4];
     if (s.nw) {                                         // RMS norm: sum of squares in double like the reference
-        const char * xp = stg + (mw * 4 + row) * 1024 + 16 * i;
+        bool last = false;
 #pragma unroll
-        for (int m = 0; m < 4; ++m) x[m] = *(const f32x4 *) (xp + 256 * m);
-        double ss = 0.0;
+        for (int g = 0; g < NG; ++g) {
+            const int mw = pw + g * PW;
+            if (mw >= 4 * NIT) break;
+            const char * xp = stg + (mw * 4 + row) * 1024 + 16 * i;
 #pragma unroll
-        for (int m = 0; m < 4; ++m)
+            for (int m = 0; m < 4; ++m) x[g][m] = *(const f32x4 *) (xp + 256 * m);
+            double ss = 0.0;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) ss += (double) (x[m][e] * x[m][e]);
-        ss = wave_sum_f64(ss);
-        if (lane == 0) red[mw] = ss;
-        asm volatile("" ::: "memory");
-        uint32_t prev = 0;
-        if (lane == 0) prev = __hip_atomic_fetch_add(MV2_FLAG(F->sum_cnt), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        prev = __builtin_amdgcn_readfirstlane(prev);
-        asm volatile("" ::: "memory");
-        if (prev == (uint32_t) (4 * NIT - 1)) {         // last to arrive: every partial sum is in LDS (the DS operations of a wave execute in order)
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) ss += (double) (x[g][m][e] * x[g][m][e]);
+            ss = wave_sum_f64(ss);
+            if (lane == 0) red[mw] = ss;
+            asm volatile("" ::: "memory");
+            uint32_t prev = 0;
+            if (lane == 0) prev = __hip_atomic_fetch_add(MV2_FLAG(F->sum_cnt), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            prev = __builtin_amdgcn_readfirstlane(prev);
+            asm volatile("" ::: "memory");
+            if (prev == (uint32_t) (4 * NIT - 1)) last = true;
+        }
+        if (last) {                                     // last to arrive: every partial sum is in LDS (the DS operations of a wave execute in order)
             double tot = 0.0;
 #pragma unroll
             for (int w = 0; w < 4 * NIT; ++w) tot += *(const volatile double *) &red[w];
@@ -389,17 +401,20 @@ static __device__ __forceinline__ void mv2_prologue(const mv1_src s, int K, int 
         }
     }
     MV2_STAMP(3);
-    {
+    if (s.nw) mv2_await(MV2_FLAG(F->rows_landed), MV2_ROW_WAVES);
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        const int mw = pw + g * PW;
+        if (mw >= 4 * NIT) break;
         const int b = mw * 4 + row;
         f32x4 y[4];
         if (s.nw) {
-            mv2_await(MV2_FLAG(F->rows_landed), MV2_ROW_WAVES);
             const char * wp = stg + K * 4 + b * 1024 + 16 * i;
 #pragma unroll
             for (int m = 0; m < 4; ++m) {
                 const f32x4 w = *(const f32x4 *) (wp + 256 * m);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) y[m][e] = (x[m][e] * scale) * w[e];
+                for (int e = 0; e < 4; ++e) y[m][e] = (x[g][m][e] * scale) * w[e];
             }
         } else {
             const char * xp = stg + b * 1024 + 16 * i;
@@ -407,9 +422,9 @@ static __device__ __forceinline__ void mv2_prologue(const mv1_src s, int K, int 
             for (int m = 0; m < 4; ++m) y[m] = *(const f32x4 *) (xp + 256 * m);
         }
         if constexpr (Q80) mv2_q80_rows(y, lane, b, K, im); else mv2_q8k_rows(y, lane, b, nb, im);
+        mv2_arrive(MV2_FLAG(F->img_cnt));
     }
     MV2_STAMP(5);
-    mv2_arrive(MV2_FLAG(F->img_cnt));
 }
 // ready-made Q8_0 image (the same layout): a plain copy by all C consumers
 template <int C>

@@ -57,8 +57,8 @@ struct shape { const char * name; int K; int nmat; int nrows[3]; int types[3]; b
 
 #ifdef MV2_TRACE
 static unsigned long long * trace_dev = nullptr;
-static void trace_report(const char * nm, int nwg, int nl) {
-    const int nwaves = nwg * 16;
+static void trace_report(const char * nm, int nwg, int nl, int NW) {
+    const int nwaves = nwg * NW;
     std::vector<unsigned long long> h((size_t) nwaves * 8);
     HIP_CHECK(hipMemcpy(h.data(), trace_dev, h.size() * 8, hipMemcpyDeviceToHost));
     unsigned long long t0 = ~0ull;
@@ -66,13 +66,21 @@ static void trace_report(const char * nm, int nwg, int nl) {
     static const char * labl[8] = { "start", "setup done", "first issue", "rows landed", "-", "-", "-", "end" };
     static const char * labr[8] = { "start", "setup done", "before 1st DMA", "1st DMA issued", "(consume starts)", "all DMA issued", "-", "end" };
     static const char * labc[8] = { "start", "setup done", "rows seen", "scale known", "image done", "my blocks done", "-", "end" };
-    { printf("      wave -> SIMD of workgroup 0 (HW_ID bits 4-5):"); for (int w = 0; w < 16; ++w) printf(" %d", (int) ((h[(size_t) w * 8 + 6] >> 4) & 3)); printf("   CU ids of WG 0..3: %d %d %d %d\n", (int) ((h[6] >> 8) & 15), (int) ((h[16 * 8 + 6] >> 8) & 15), (int) ((h[32 * 8 + 6] >> 8) & 15), (int) ((h[48 * 8 + 6] >> 8) & 15)); }
+    { printf("      wave -> SIMD of workgroup 0 (HW_ID bits 4-5):"); for (int w = 0; w < NW; ++w) printf(" %d", (int) ((h[(size_t) w * 8 + 6] >> 4) & 3)); printf("   CU ids of WG 0..3: %d %d %d %d\n", (int) ((h[6] >> 8) & 15), (int) ((h[NW * 8 + 6] >> 8) & 15), (int) ((h[2 * NW * 8 + 6] >> 8) & 15), (int) ((h[3 * NW * 8 + 6] >> 8) & 15)); }
+    if (getenv("MV2_DUMP")) {                    // per-workgroup: XCC id, loader start / first issue / end, last consumer end (us after the first wave's start)
+        printf("      per-workgroup dump of %s: wg xcc se cu  loader_start first_issue loader_end  last_consumer_end\n", nm);
+        for (int g = 0; g < nwg; ++g) {
+            const unsigned long long * L = &h[(size_t) g * NW * 8];
+            double cend = 0; for (int w = 1; w < NW; ++w) cend = std::max(cend, (double) (h[((size_t) g * NW + w) * 8 + 7] - t0) * 0.01);
+            printf("      WG %3d %2d %2d %2d  %6.2f %6.2f %6.2f  %6.2f\n", g, (int) (L[5] & 15), (int) ((L[6] >> 13) & 7), (int) ((L[6] >> 8) & 15), (double) (L[0] - t0) * 0.01, (double) (L[2] - t0) * 0.01, (double) (L[7] - t0) * 0.01, cend);
+        }
+    }
     printf("      time line of %s (us after the first wave's start; min / median / max)\n", nm);
     for (int role = 0; role < 3; ++role) for (int i = 0; i < 8; ++i) {
         const char * const * lab = role == 0 ? labl : role == 1 ? labc : labr;
         if (lab[i][0] == '-') continue;
         std::vector<double> v;
-        for (int w = 0; w < nwaves; ++w) if ((role == 0 ? (w % 16) < nl : role == 1 ? ((w % 16) >= nl && (w % 16) < 12) : (w % 16) >= 12) && h[(size_t) w * 8 + i]) v.push_back((double) (h[(size_t) w * 8 + i] - t0) * 0.01);
+        for (int w = 0; w < nwaves; ++w) if ((role == 0 ? (w % NW) < nl : role == 1 ? ((w % NW) >= nl && (w % NW) < NW - 4) : (w % NW) >= NW - 4) && h[(size_t) w * 8 + i]) v.push_back((double) (h[(size_t) w * 8 + i] - t0) * 0.01);
         if (v.empty()) continue;
         std::sort(v.begin(), v.end());
         printf("        %-9s %-20s %6.2f / %6.2f / %6.2f\n", role == 0 ? "loader" : role == 1 ? "consumer" : "row wave", lab[i], v[0], v[v.size() / 2], v[v.size() - 1]);
@@ -184,30 +192,35 @@ int main(int argc, char ** argv) {
         const double tb = time_graph(N, [&](int s) { base(s, out_a); });
         printf("   %-58s %7.2f us  (%.2f TB/s)\n", "mmv1 (product launch)", tb, total / tb / 1e6);
 
-#define VAR3(NT)                                                                                                               \
+#define VAR3(NT, NW)                                                                                                               \
         do {                                                                                                                   \
             const int grid = 256;                                                                                              \
             auto f = [&](int s, float * out) {                                                                                 \
                 const mv2_dev d = mk2(s, out, grid);                                                                           \
                 const bool q4 = S.types[0] == Q4 && (S.nmat == 1 || (S.types[1] == Q4 && S.types[2] == Q4));                    \
                 const bool q6 = S.types[0] == Q6 && (S.nmat == 1 || (S.types[1] == Q6 && S.types[2] == Q6));                    \
-                if (S.pair)         mv2_launch<1, 1, true, NT>(d, grid, st);                                                    \
-                else if (K == 4096) { if (q4) mv2_launch<1, 1, false, NT>(d, grid, st); else if (q6) mv2_launch<2, 1, false, NT>(d, grid, st); else mv2_launch<3, 1, false, NT>(d, grid, st); } \
-                else                { if (q4) mv2_launch<1, 3, false, NT>(d, grid, st); else if (q6) mv2_launch<2, 3, false, NT>(d, grid, st); else mv2_launch<3, 3, false, NT>(d, grid, st); } \
+                if (S.pair)         mv2_launch<1, 1, true, NT, NW>(d, grid, st);                                                    \
+                else if (K == 4096) { if (q4) mv2_launch<1, 1, false, NT, NW>(d, grid, st); else if (q6) mv2_launch<2, 1, false, NT, NW>(d, grid, st); else mv2_launch<3, 1, false, NT, NW>(d, grid, st); } \
+                else                { if (q4) mv2_launch<1, 3, false, NT, NW>(d, grid, st); else if (q6) mv2_launch<2, 3, false, NT, NW>(d, grid, st); else mv2_launch<3, 3, false, NT, NW>(d, grid, st); } \
             };                                                                                                                 \
             const std::string c = check(f);                                                                                    \
             const double t = time_graph(N, [&](int s) { f(s, out_b); });                                                        \
-            char nm[96]; snprintf(nm, sizeof nm, "mv2 engine NT=%d", NT);                                                       \
+            char nm[96]; snprintf(nm, sizeof nm, "mv2 engine NT=%d waves=%d", NT, NW);                                                       \
             printf("   %-58s %7.2f us  (%.2f TB/s)  %s\n", nm, t, total / t / 1e6, c.c_str());                                  \
-            TRACE_REPORT(nm, grid, 1, f);                                                                                      \
+            TRACE_REPORT(nm, grid, 1, f, NW);                                                                                      \
         } while (0)
 #ifdef MV2_TRACE
-#define TRACE_REPORT(nm, grid, nl, f) do { HIP_CHECK(hipMemsetAsync(trace_dev, 0, 8192 * 64, st)); for (int s_ = 0; s_ < 4; ++s_) f(s_ + 7, out_b); HIP_CHECK(hipStreamSynchronize(st)); trace_report(nm, grid, nl); } while (0)
+#define TRACE_REPORT(nm, grid, nl, f, NW) do { HIP_CHECK(hipMemsetAsync(trace_dev, 0, 8192 * 64, st)); for (int s_ = 0; s_ < 4; ++s_) f(s_ + 7, out_b); HIP_CHECK(hipStreamSynchronize(st)); trace_report(nm, grid, nl, NW); } while (0)
 #else
-#define TRACE_REPORT(nm, grid, nl, f) do { } while (0)
+#define TRACE_REPORT(nm, grid, nl, f, NW) do { } while (0)
 #endif
-        VAR3(true);
-        VAR3(false);
+        VAR3(true, 16);
+#ifndef MV2_LAB_ONE
+        VAR3(true, 13);
+        VAR3(true, 12);
+        VAR3(true, 10);
+        VAR3(true, 9);
+#endif
     }
     return 0;
 }
