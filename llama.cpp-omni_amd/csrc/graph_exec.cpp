@@ -335,7 +335,23 @@ static bool mv1_node_ok(exec_state & s, const ggml_tensor * n) {
 // (quantised inside the launch), or -- when an output would overwrite x while the launch reads it -- a quantise launch first
 static size_t prepare_act(exec_state & s, const ggml_tensor * x, act_kind kind);
 static bool norm_in_kernel(exec_state & s, const ggml_tensor * x, const ggml_tensor * const * outs, int n_outs, int n_consumers, mmv_norm & nr);
+// the attention rows this mat-vec reads still lie as slices' partial states: fold them in the launch's prologue if the LDS-DMA engine takes the launch, else write the rows first
+static void gs_materialise(exec_state & s) {
+    if (!s.gs.n) return;
+    prof_scope ps(s, "fattn", 0);
+    fattn_gs_merge((const float *) s.c->fa_scratch, (float *) s.gs.n->data, s.gs.nh, s.gs.D, s.st); ++s.n_kernels;
+    s.gs.n = nullptr; s.gs.consumer = -1;
+}
 static void mv1_source(exec_state & s, const ggml_tensor * x, const ggml_tensor * const * outs, int n_outs, int n_consumers, mv1_args & v) {
+    if (s.gs.n && x->data == s.gs.n->data) {
+        mv1_args t = v; t.x = nullptr; t.norm_w = nullptr; t.img = nullptr; t.parts = (const float *) s.c->fa_scratch; t.nslice = fattn_gs_nslice();
+        if (!(s.pn.m && x == s.pn.m) && x->ne[0] == (int64_t) s.gs.nh * s.gs.D && mmv2_enabled() && mmv2_ok(t)) {
+            v.parts = t.parts; v.nslice = t.nslice; v.x = nullptr; v.norm_w = nullptr; v.img = nullptr;
+            s.gs.n = nullptr; s.gs.consumer = -1; ++s.n_fused;
+            return;
+        }
+        gs_materialise(s);
+    }
     mmv_norm nr;
     if (s.pn.m && x == s.pn.m && ((uintptr_t) s.pn.x->data & 15) == 0 && ((uintptr_t) s.pn.wt->data & 15) == 0 && norm_in_kernel(s, x, outs, n_outs, n_consumers, nr)) {
         v.x = nr.x; v.norm_w = nr.w; v.eps = nr.eps;
@@ -2241,6 +2257,20 @@ static void compute_node(exec_state & s, int i) {
                 }
                 f.rope_tab = (const float *) s.c->rope_scratch;
                 one = true;
+                // ... as one workgroup per (KV head, 64-row slice) when the ONE reader of the rows is the next launching node, a batch-1 K-quant mat-vec the LDS-DMA engine
+                // takes (wo): the slices' partial states stay in fa_scratch and that launch folds them in its prologue (mv1_source) -- the f32 rows are never written
+                static const bool gs_off = getenv("MI355X_FA_NO_GS") != nullptr;
+                const int u = s.c->opt_fusion && !gs_off && !is_out(s, n) ? sole_user(s, n) : -1;
+                if (u > i && next_real_node(s, i) == u && fattn_gs_ok(f) && s.c->fa_scratch && s.c->fa_scratch_bytes >= fattn_gs_parts_bytes((int) n->ne[1], D) && mmv2_enabled()) {
+                    const ggml_tensor * c = g->nodes[u];
+                    const ggml_tensor * x = c->op == GGML_OP_MUL_MAT ? c->src[1] : nullptr;
+                    if (x && x->data == n->data && x->ne[0] == n->ne[0] * n->ne[1] && x->ne[1] == 1 && x->ne[2] == 1 && x->ne[3] == 1 && x != s.pn.m && mv1_node_ok(s, c) && !q80_mv1_node(s, c)) {
+                        mv1_args t; t.nmat = 1; t.K = x->ne[0];
+                        t.m[0] = { c->src[0]->data, c->src[0]->nb[1], (float *) c->data, 0, nullptr, 0, c->src[0]->ne[1], (int) c->src[0]->type };
+                        t.parts = (const float *) s.c->fa_scratch; t.nslice = fattn_gs_nslice();
+                        if (mmv2_ok(t)) { f.gs_parts = (float *) s.c->fa_scratch; s.gs.n = n; s.gs.consumer = u; s.gs.nh = (int) n->ne[1]; s.gs.D = D; s.fa_mask = nullptr; }
+                    }
+                }
             }
             // epilogue fusion: when the attention output only feeds K-quant mat-vecs (wo), emit its Q8_K image here
             const ggml_tensor * xuse = nullptr;
@@ -2928,7 +2958,7 @@ void run_nodes(exec_state & s, ggml_cgraph * g) {
     static FILE * const launch_log = getenv("MI355X_LAUNCH_LOG") ? fopen(getenv("MI355X_LAUNCH_LOG"), "w") : nullptr;      // one line per node that launched: what a graph's launches are made of (tools/launch_ngrams.py)
     s.g = g;
     s.done.assign(g->n_nodes, 0);
-    s.index.clear(); s.users.clear(); s.lazy.clear(); s.lazy_base_deadline.clear();
+    s.index.clear(); s.users.clear(); s.lazy.clear(); s.lazy_base_deadline.clear(); s.gs = {};
     if (s.c->opt_fusion) {
         s.index.reserve(g->n_nodes * 2); s.users.reserve(g->n_nodes * 2);
         for (int i = 0; i < g->n_nodes; ++i) {
@@ -2993,6 +3023,7 @@ void run_nodes(exec_state & s, ggml_cgraph * g) {
             for (int k = 0; k < 3 && n->src[k]; ++k) fprintf(launch_log, " s%d:op%d%s[%lld,%lld,%lld,%lld]", k, (int) n->src[k]->op, is_contiguous(n->src[k]) ? "c" : "n", (long long) n->src[k]->ne[0], (long long) n->src[k]->ne[1], (long long) n->src[k]->ne[2], (long long) n->src[k]->ne[3]);
             fprintf(launch_log, "\n");
         } } ll_g{ s, g, i, s.n_kernels, s.n_fused };
+        if (s.gs.n && i != s.gs.consumer && !is_noop(g->nodes[i]) && g->nodes[i] != s.gs.n) gs_materialise(s);       // (somebody else runs before wo folds the attention slices)
         if (g->nodes[i]->op == GGML_OP_IM2COL && exec_conv1d_tc(s, i)) continue;
         if (g->nodes[i]->op == GGML_OP_CONT && exec_causal_conv(s, i)) continue;
         if ((g->nodes[i]->op == GGML_OP_CONT || g->nodes[i]->op == GGML_OP_CONCAT) && exec_concat_tail(s, i)) continue;
@@ -3014,6 +3045,7 @@ void run_nodes(exec_state & s, ggml_cgraph * g) {
             note_write(s, g->nodes[sink]);
         } else
             compute_node(s, i);
+        if (s.gs.n && i == s.gs.consumer) { fprintf(stderr, "[mi355x] graph_compute: node %d (%s) did not take the attention slices it was chosen for\n", i, g->nodes[i]->name); abort(); }
         if (!s.capturing) {                                  // a launch with an invalid configuration fails silently otherwise (and poisons a later capture)
             const hipError_t e = hipGetLastError();
             if (e != hipSuccess) {
@@ -3023,6 +3055,7 @@ void run_nodes(exec_state & s, ggml_cgraph * g) {
             }
         }
     }
+    gs_materialise(s);                                       // (the attention node was the graph's last launching node)
     if (launch_log && !s.capturing) { fprintf(launch_log, "== end of a graph of %d nodes\n", g->n_nodes); fflush(launch_log); }
 }
 

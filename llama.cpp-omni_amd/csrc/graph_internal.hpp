@@ -73,6 +73,9 @@ struct exec_state {
     // deferred split-K reduction: `A` (the mat-mul + residual result) still lies as `nsplit` slabs in gemm_partial; the RMS_NORM that
     // reads it next folds the reduction in (gemm_reduce_rms_norm), anything else materialises it first
     struct { const ggml_tensor * A = nullptr; int nsplit = 0; const float * resid = nullptr; size_t resid_cs = 0; const float * resid2 = nullptr; size_t resid2_cs = 0; } pr;   // (resid2: only in front of a LayerNorm)
+    // one-token attention left as slices' partial states in fa_scratch (fattn_one.hip k_fattn_gs): `n` = the FLASH_ATTN_EXT node whose f32 rows were NOT written, `consumer` = the
+    // one MUL_MAT (wo) that folds them in its prologue (mv1_source); anything else that runs first materialises the rows (gs_materialise in graph_exec.cpp)
+    struct { const ggml_tensor * n = nullptr; int consumer = -1; int nh = 0, D = 0; } gs;
     // (pos, rope parameters) whose (cos, sin) table currently sits in rope_scratch (prefill: shared by every layer of the graph)
     struct { const void * pos = nullptr; const void * ff = nullptr; int T = 0, D = 0; rope_params rp; } rt;
     // mask whose tile map currently sits in fa_scratch

@@ -1,6 +1,7 @@
 // graph_plan.cpp -- planner side of the graph executor: supports_op (what the backend admits), which kernel family a MUL_MAT takes by shape and type,
 // and the scratch a cgraph needs before its first launch.  (Split out of graph.cpp in round 4; no behaviour change.)
 #include "graph_internal.hpp"
+#include <algorithm>
 
 namespace mi {
 
@@ -268,7 +269,8 @@ size_t graph_fa_scratch_need(const ggml_cgraph * g) {
         }
         if (n->op != GGML_OP_FLASH_ATTN_EXT || is_empty(n)) continue;
         fattn_args f; tdesc m; fill_fattn_args(n, f, m);
-        const size_t b = fattn_scratch_bytes(f);
+        size_t b = fattn_scratch_bytes(f);
+        if (n->src[0]->ne[1] == 1 && n->src[0]->ne[3] == 1 && n->src[0]->ne[0] == 128) b = std::max(b, fattn_gs_parts_bytes((int) n->src[0]->ne[2], 128));     // one token: the slices' partial states (k_fattn_gs)
         if (b > need) need = b;
     }
     return need;

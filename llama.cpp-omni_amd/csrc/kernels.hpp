@@ -73,6 +73,9 @@ struct mv1_args {
     mmv_mat m[3]; int nmat = 0; const void * W_up = nullptr;
     const float * x = nullptr; const float * norm_w = nullptr; float eps = 0.0f; const void * img = nullptr;
     int64_t K = 0;
+    // the activation row as attention slices' partial states (fattn_gs_parts_bytes: nslice x [K] partial outputs + nslice x [K / 128] x (M, S)), folded in the launch's
+    // prologue -- the LDS-DMA engine only (mmv2_ok): one K-quant matrix, K = 4096, no norm
+    const float * parts = nullptr; int nslice = 0;
 };
 bool mmv1_ok(const mv1_args & a);                 // Q4_K / Q6_K (mmv1.hip) or Q8_0 (mmv1q.hip: K % 32 == 0, K <= 4096; img = Q8_0 image)
 void mmv1(const mv1_args & a, hipStream_t st);
@@ -81,6 +84,7 @@ void mmv1(const mv1_args & a, hipStream_t st);
 bool mmv2_ok(const mv1_args & a);
 void mmv2(const mv1_args & a, hipStream_t st);
 void mmv2_enable(bool on);
+bool mmv2_enabled();                                // (mmv1() routes to the engine)
 bool mmv1q_ok(const mv1_args & a);
 void mmv1q(const mv1_args & a, hipStream_t st);
 
@@ -207,6 +211,9 @@ struct fattn_args {
     // v is V^T: tdesc of the [n_kv, D, HK, ns] tensor (cells contiguous, nb[1] = stride between d rows) -- the flash-attention-OFF graphs' MUL_MAT(v, soft_max(..))
     // operand; only the matrix-core prefill kernel takes it (fattn_sm_prefill_ok)
     bool v_transposed = false;
+    // one token over <= 256 rows, head size 128, four query heads per KV head (fattn_gs_ok): leave FGS slices' partial (O, M, S) states here instead of dst -- the wo
+    // mat-vec launch folds them in its prologue (mv1_args::parts); fattn_gs_merge() materialises dst from them when it cannot
+    float * gs_parts = nullptr;
 };
 // MUL_MAT(k, q) -> SOFT_MAX_EXT -> MUL_MAT(v^T, p) -> PERMUTE -> CONT for a batch of query rows as ONE flash-attention launch (the prefill kernel with V^T staging): the
 // [n_kv, n_q, H] score / probability blocks are never written.  Same roundings as the separate nodes up to the order of the soft-max sums (q and p rounded to f16, f32 sums).
@@ -230,6 +237,10 @@ void   attn_one_sm(const attn_sm_args & a, hipStream_t st);
 void   fattn_set_one(bool on);             // one-token kernel on (default) / off: the round-1 decode kernels take the shape (cross-check)
 int    fattn_one_nsplit(const fattn_args & a);   // 256-row KV slices of the one-token kernel (> 1: partial rows + k_fattn_merge, needs the scratch)
 bool   fattn_one_ok(const fattn_args & a);       // one token, one sequence, pre-stage, <= 256 cache rows: the latency-optimised kernel (fattn_one.hip) runs
+bool   fattn_gs_ok(const fattn_args & a);        // ... and the group-slice form applies (fattn_one.hip k_fattn_gs)
+size_t fattn_gs_parts_bytes(int n_head, int D);
+int    fattn_gs_nslice();
+void   fattn_gs_merge(const float * parts, float * dst, int n_head, int D, hipStream_t st);
 // (cos, sin) * mscale of every (token, rotation pair): tab[T][D/2][2], what ggml_rope_cache_init / rope_yarn give for these positions
 void   rope_table(const int32_t * pos, const float * ff, const rope_params & rp, int T, int D, float * tab, hipStream_t st);
 size_t fattn_scratch_bytes(const fattn_args & a);

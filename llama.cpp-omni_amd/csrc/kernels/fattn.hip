@@ -549,6 +549,11 @@ void flash_attn_ext_f16(const fattn_args & f, hipStream_t st) {
         flash_attn_ext_any(a, (int) f.q.ne[0], (int) f.v.ne[0], f.kv_type, st);
         return;
     }
+    if (f.pre && f.rope_tab && f.gs_parts && fattn_gs_ok(f)) {       // one token, <= 256 rows, the consumer folds the slices: one workgroup per (KV head, slice)
+        a.nsplit = 1; a.part = nullptr; a.tile_map = nullptr; a.map_nqb = 0;
+        flash_attn_gs(a, (int) f.q.ne[0], f.rope_tab, f.gs_parts, st);
+        return;
+    }
     if (f.pre && f.rope_tab && fattn_one_ok(f)) {                    // one token, up to 4096 cache rows: the latency-optimised one-token kernel
         const int ns1 = fattn_one_nsplit(f);
         const size_t need = (size_t) a.nh * (size_t) ns1 * (size_t) (f.q.ne[0] + 2) * 4;

@@ -43,6 +43,8 @@ bool fattn_mma_ok(int64_t nkv);
 void flash_attn_ext_gqa(const fa_dev & a, int D, int nw, hipStream_t st);
 // one token of one sequence over <= 256 cache rows with the pre-stage (fattn_one.hip); rope_tab: the token's (cos, sin) table
 void flash_attn_one(const fa_dev & a, int D, const float * rope_tab, hipStream_t st);
+// the same step as one workgroup per (KV head, 64-row slice) leaving partial (O, M, S) states in `parts` (fattn_gs_parts_bytes) for the wo launch's prologue to fold
+void flash_attn_gs(const fa_dev & a, int D, const float * rope_tab, float * parts, hipStream_t st);
 // any other head size (fattn_any.hip): one wave per (query row, head, sequence)
 bool fattn_any_ok(int64_t Dk, int64_t Dv);
 void flash_attn_ext_any(const fa_dev & a, int Dk, int Dv, int kv_type, hipStream_t st);      // kv_type: F16 / F32 / BF16 / Q8_0 / Q4_0 (K and V alike)

@@ -46,6 +46,17 @@ static __device__ __forceinline__ double wave_sum_f64o(double v) {
     return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 63), __builtin_amdgcn_readlane(__double2loint(v), 63));
 }
 
+#ifdef FA1_TRACE           // measurement builds (tools/fa1_lab.hip): per-wave s_memrealtime stamps (100 MHz) of the stages of k_fattn_one, written once at the end
+__device__ unsigned long long * fa1_trace_buf = nullptr;
+#define FA1_STAMP_DECL uint32_t tr_[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }
+#define FA1_STAMP(i) do { tr_[i] = (uint32_t) __builtin_amdgcn_s_memrealtime(); asm volatile("" : "+s"(tr_[i]) :: "memory"); } while (0)
+#define FA1_STAMP_FLUSH do { if (fa1_trace_buf) { const int l_ = threadIdx.x & 63; uint32_t v_ = 0; _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_) if (l_ == i_) v_ = tr_[i_]; \
+    if (l_ < 8) fa1_trace_buf[(size_t) (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 8 + l_] = v_; } } while (0)
+#else
+#define FA1_STAMP_DECL
+#define FA1_STAMP(i) do { } while (0)
+#define FA1_STAMP_FLUSH do { } while (0)
+#endif
 constexpr int FA1_NKV = 256;                      // cache rows a workgroup holds in registers
 constexpr int FA1_MAX_SPLIT = 32;                 // 256-row slices per head handled by this kernel + k_fattn_merge (deeper: k_fattn_gqa's MFMA tiles)
 
@@ -93,6 +104,7 @@ __global__ void __launch_bounds__(256) k_fattn_one(FA1_LEAD_PARAMS, const fa1_de
     constexpr int HALF = D / 2;
     __shared__ __attribute__((aligned(16))) float qf[D], kc[D], vc[D], sc[FA1_NKV], pl[4][FA1_NKV];
 
+    FA1_STAMP_DECL; FA1_STAMP(0);
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     // XCD-aware head order: workgroups go round-robin over the 8 XCDs (each with its own L2), so the gq heads that share one K / V head are
     // given workgroup ids that are congruent modulo the number of KV heads -- with 8 KV heads one XCD fetches each K / V head once
@@ -145,6 +157,7 @@ __global__ void __launch_bounds__(256) k_fattn_one(FA1_LEAD_PARAMS, const fa1_de
 #pragma unroll
     for (int j = 0; j < NJ; ++j) vv[j] = __builtin_amdgcn_raw_buffer_load_b32(vrs, vvo, (uint32_t) (j * RPI) * (uint32_t) a.vnb1, 0);
 
+    FA1_STAMP(1);
     // ---------------------------------------------------------------- 2. q chain, k chain + store, v store (norm_rope_dev.hpp arithmetic)
     if (wave < 2) {
         const float tc = __uint_as_float(tcs[0]), ts = __uint_as_float(tcs[1]);
@@ -172,6 +185,7 @@ __global__ void __launch_bounds__(256) k_fattn_one(FA1_LEAD_PARAMS, const fa1_de
             if (D > 64) vr[lane + 64] = hv1;
         }
     }
+    FA1_STAMP(2);
     // mask values + liveness (every wave computes the same)
     const float slope = a.max_bias > 0.0f ? (h < a.n_head_log2 ? powf(a.m0, (float) (h + 1)) : powf(a.m1, (float) (2 * (h - a.n_head_log2) + 1))) : 1.0f;
     float mv[FA1_NKV / 64]; int n_live = 0;
@@ -184,7 +198,9 @@ __global__ void __launch_bounds__(256) k_fattn_one(FA1_LEAD_PARAMS, const fa1_de
         const unsigned long long live = __ballot(m != -INFINITY);
         if (live) n_live = 64 * i + 64 - __builtin_clzll(live);                    // 1 + the last visible row
     }
+    FA1_STAMP(3);
     __syncthreads();
+    FA1_STAMP(4);
 
     // ---------------------------------------------------------------- 3. scores
     {
@@ -220,6 +236,7 @@ __global__ void __launch_bounds__(256) k_fattn_one(FA1_LEAD_PARAMS, const fa1_de
             if (lane == 0 && krow >= 0 && krow < nkv) sc[krow] = s;
         }
     }
+    FA1_STAMP(5);
     __syncthreads();
 
     // ---------------------------------------------------------------- 4. soft-max weights (every wave, own copy, rows regrouped for the V pass)
@@ -254,6 +271,7 @@ __global__ void __launch_bounds__(256) k_fattn_one(FA1_LEAD_PARAMS, const fa1_de
     if (vin && lane == 0) pl[wave][(vrow % RPI) * NJ + vrow / RPI] = 0.0f;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
+    FA1_STAMP(6);
     // ---------------------------------------------------------------- 5. P.V for this wave's dims
     float acc0 = 0.0f, acc1 = 0.0f;
 #pragma unroll
@@ -337,6 +355,214 @@ __global__ void __launch_bounds__(256) k_fattn_one(FA1_LEAD_PARAMS, const fa1_de
         float * out = (float *) (a.dst + h * a.dnb1) + wave * DPW + 2 * dp;
         out[0] = acc0 * inv; out[1] = acc1 * inv;
     }
+    FA1_STAMP(7);
+    FA1_STAMP_FLUSH;
+}
+
+// ================================================================================================= group-slice form (round 6)
+// The same one-token step over <= 256 cache rows with ONE workgroup per (KV head, 64-row slice of the view) instead of one per query head:
+// k_fattn_one's 32 workgroups each pull the WHOLE K / V head of their group (128 KB through one CU's vector-memory path: ~80 poorly coalesced
+// load instructions per wave, "every load requested" 2.0 us after the launch starts, the last V row used at 4.5 -- tools/fa1_lab.hip); here a
+// workgroup pulls the 64 rows of its slice once for the gq = 4 query heads of the group (16 + 16 KB as 32 LDS-DMA instructions of 1 KiB, four rows
+// of 256 contiguous bytes each) and leaves, per head, the UNNORMALISED partial output of its rows with their running maximum and sum:
+//     parts[slice][h * D + d] = sum_rows exp(s_row - M) v_row[d]      ms[slice][h] = (M, S)
+// The slices are merged by the prologue of the wo mat-vec launch that consumes them (mmv2.hip, PARTS: out = sum_s f_s O_s / sum_s f_s S_s,
+// f_s = exp(M_s - max M)), which every one of its workgroups runs anyway in front of the Q8_K quantiser -- no second launch, no arrival counters.
+// Arithmetic per row as k_fattn_one (f16-rounded q / k, v_dot2_f32_f16 scores, f32 soft-max and V accumulation), reference ops.cpp:7912-8148.
+// Restrictions (fattn_gs_ok): D = 128, gq = 4, one sequence, f16 mask shared by the heads or per head, no sinks / ALiBi / soft-cap, contiguous heads.
+constexpr int FGS_NSL = 4;                        // slices of the 256-row view
+constexpr int FGS_RS  = FA1_NKV / FGS_NSL;        // rows per slice
+constexpr int FGS_W   = 8;                        // waves per workgroup
+static __device__ __forceinline__ __amdgpu_buffer_rsrc_t fa1_rsrc_u(const void * p, int bytes) {      // wave-uniform by construction (an inline-asm "s" operand must be provably scalar)
+    const uint64_t a = (uint64_t) (uintptr_t) p;
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t) a), hi = __builtin_amdgcn_readfirstlane((uint32_t) (a >> 32));
+    return __builtin_amdgcn_make_buffer_rsrc((void *) (uintptr_t) (((uint64_t) hi << 32) | lo), (short) 0, __builtin_amdgcn_readfirstlane(bytes), 0x00020000);
+}
+#define FGS_LEAD_PARAMS const char * qraw_, const float * qw_, const float * tab_, const char * k_, int kraw_off_, int vraw_off_, int kw_off_, int v_off16_, int knb1_, uint32_t pk_      /* 14 dwords, no padding: pre-loaded */
+template <int D>
+__global__ void __launch_bounds__(64 * FGS_W) k_fattn_gs(FGS_LEAD_PARAMS, const fa1_dev a) {
+    static_assert(D == 128, "one 256-byte f16 row per (cache row, KV head)");
+    constexpr int GQ = 4, HALF = D / 2, RS = FGS_RS, RPW = RS / FGS_W;      // rows per wave in the score / P.V passes
+    __shared__ __attribute__((aligned(16))) char kt[RS * D * 2], vt[RS * D * 2];
+    __shared__ __attribute__((aligned(16))) float qf[GQ][D], kc[D], vc[D], pl[GQ][RS], pcur_s[GQ], ms_s[GQ][2];
+    __shared__ __attribute__((aligned(16))) uint16_t q16[GQ][D];
+    FA1_STAMP_DECL; FA1_STAMP(0);
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nkvh = (int) (pk_ & 0xffu), neox = (int) ((pk_ >> 8) & 1u), has_norm = (int) ((pk_ >> 9) & 1u), nkv_all = (int) (pk_ >> 16);
+    const int sp = __builtin_amdgcn_readfirstlane((int) blockIdx.x / nkvh), g = (int) blockIdx.x - sp * nkvh;        // workgroups of one KV head are congruent modulo the KV head count: one XCD's L2 serves the group
+    const int row0 = sp * RS;
+    const int nkv = nkv_all - row0 < RS ? (nkv_all - row0 > 0 ? nkv_all - row0 : 0) : RS;      // rows of this slice inside the view
+    // ---------------------------------------------------------------- 1. K / V slice by LDS-DMA (pre-loaded arguments only), then the raw rows
+    // lane -> (row of the instruction's four, 16-byte chunk of the row); exact bounds: rows past the view read nothing
+    {
+        const uint32_t vo = (uint32_t) (lane >> 4) * (uint32_t) knb1_ + (uint32_t) (lane & 15) * 16u;
+        const int nb = nkv > 0 ? (nkv - 1) * knb1_ + D * 2 : 0;
+        const __amdgpu_buffer_rsrc_t krs = fa1_rsrc_u(k_ + g * (D * 2) + (int64_t) row0 * knb1_, nb);
+        const __amdgpu_buffer_rsrc_t vrs = fa1_rsrc_u(k_ + (int64_t) v_off16_ * 16 + g * (D * 2) + (int64_t) row0 * knb1_, nb);
+        const uint32_t kl = (uint32_t) (uintptr_t) (__attribute__((address_space(3))) void *) kt, vl = (uint32_t) (uintptr_t) (__attribute__((address_space(3))) void *) vt;
+#pragma unroll
+        for (int i = 0; i < RS / 4 / FGS_W; ++i) {                        // instruction j of 16: rows 4 j .. 4 j + 3
+            const int j = wave + FGS_W * i;
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" :: "s"(__builtin_amdgcn_readfirstlane(kl + (uint32_t) j * 1024u)), "v"(vo), "s"(krs), "s"(__builtin_amdgcn_readfirstlane((uint32_t) (4 * j) * (uint32_t) knb1_)) : "memory", "m0");
+        }
+#pragma unroll
+        for (int i = 0; i < RS / 4 / FGS_W; ++i) {
+            const int j = wave + FGS_W * i;
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" :: "s"(__builtin_amdgcn_readfirstlane(vl + (uint32_t) j * 1024u)), "v"(vo), "s"(vrs), "s"(__builtin_amdgcn_readfirstlane((uint32_t) (4 * j) * (uint32_t) knb1_)) : "memory", "m0");
+        }
+    }
+    // waves 0 .. 3: the q chain of head 4 g + wave; wave 4: the k chain; wave 5: the v head (elements lane, lane + 64)
+    const int  e0 = neox ? lane : 2 * lane, e1 = neox ? lane + HALF : 2 * lane + 1;
+    const char * xb = wave < GQ ? qraw_ + (g * GQ + wave) * (D * 4) : (wave == GQ ? qraw_ + kraw_off_ + g * (D * 4) : qraw_ + vraw_off_ + g * (D * 4));
+    const __amdgpu_buffer_rsrc_t xrs = fa1_rsrc(xb, wave <= GQ + 1 ? D * 4 : 0);
+    const uint32_t xo0 = wave <= GQ ? e0 * 4 : lane * 4, xo1 = wave <= GQ ? e1 * 4 : (lane + 64) * 4;
+    const float x0 = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(xrs, xo0, 0, 0)), x1 = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(xrs, xo1, 0, 0));
+    const __amdgpu_buffer_rsrc_t wrs = fa1_rsrc(wave < GQ ? (const char *) qw_ : (const char *) qw_ + kw_off_, (wave <= GQ && has_norm) ? D * 4 : 0);
+    const __amdgpu_buffer_rsrc_t trs = fa1_rsrc(tab_, wave <= GQ ? D * 4 : 0);
+    const float w0 = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(wrs, xo0, 0, 0)), w1 = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(wrs, xo1, 0, 0));
+    const u32x2 tcs = __builtin_amdgcn_raw_buffer_load_b64(trs, lane * 8, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);                             // (everything above needs only the pre-loaded arguments)
+    // from the argument block (one scalar round trip later): the new token's row index, as SCALAR buffer loads (every vector-memory request of the wave is counted by
+    // hand below)
+    // every field of the argument block the kernel uses, fetched NOW in one scalar burst (an empty statement that takes them as operands): left to the compiler each would
+    // be loaded where it is first used -- behind a barrier, one ~0.45 us round trip per phase (scores 1.1 us, soft-max 0.35, P.V 0.7 on the time line of tools/fa1_lab.hip)
+    const char * a_mask = a.mask; int a_mne2 = a.mne2, a_mnb2 = a.mnb2, a_nh = a.n_head, a_kc_rs = a.kc_rs, a_vc_rs = a.vc_rs; float a_scale = a.scale, a_eps = a.eps;
+    float * a_part = a.part; char * a_kcache = a.kcache, * a_vcache = a.vcache; const char * a_kidx = a.kidx, * a_vidx = a.vidx;
+    asm volatile("" : "+s"(a_mask), "+s"(a_mne2), "+s"(a_mnb2), "+s"(a_nh), "+s"(a_kc_rs), "+s"(a_vc_rs), "+s"(a_scale), "+s"(a_eps), "+s"(a_part), "+s"(a_kcache), "+s"(a_vcache), "+s"(a_kidx), "+s"(a_vidx));
+    typedef const volatile __attribute__((address_space(4))) int * fgs_cint;       // (constant address space + a uniform address: s_load_dword; volatile: requested HERE, waited for at the first use)
+    const int krow_u = *(fgs_cint) (uintptr_t) a_kidx, vrow_u = *(fgs_cint) (uintptr_t) a_vidx;
+    // the mask row of head 4 g + wave, lane = row of the slice (exact bounds; rows past the view are set to -inf below): requested now, used by the soft-max
+    uint16_t mraw = 0;
+    if (wave < GQ) {
+        const int hm = g * GQ + wave;
+        const __amdgpu_buffer_rsrc_t mrs = fa1_rsrc(a_mask ? a_mask + (hm % a_mne2) * a_mnb2 + row0 * 2 : a_mask, a_mask ? nkv * 2 : 0);
+        mraw = __builtin_amdgcn_raw_buffer_load_b16(mrs, lane * 2, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    FA1_STAMP(1);
+    // ---------------------------------------------------------------- 2. q chains, k chain, v head (norm_rope_dev.hpp arithmetic); the cache stores wait for the row index (end of the kernel)
+    uint16_t hs0 = 0, hs1 = 0;
+    if (wave <= GQ) {
+        const float tc = __uint_as_float(tcs[0]), ts = __uint_as_float(tcs[1]);
+        double ss = (double) (x0 * x0) + (double) (x1 * x1);
+        ss = wave_sum_f64o(ss);
+        const float mean  = (float) (ss * (1.0 / D));
+        const float scale = 1.0f / sqrtf(mean + a_eps);
+        const float v0 = has_norm ? (x0 * scale) * w0 : x0, v1 = has_norm ? (x1 * scale) * w1 : x1;
+        const float r0 = v0 * tc - v1 * ts, r1 = v0 * ts + v1 * tc;
+        hs0 = f2h(r0); hs1 = f2h(r1);
+        if (wave < GQ) { qf[wave][e0] = h2f(hs0); qf[wave][e1] = h2f(hs1); q16[wave][e0] = hs0; q16[wave][e1] = hs1; }      // q_to_vec_dot rounding (ops.cpp:8040)
+        else           { kc[e0] = h2f(hs0); kc[e1] = h2f(hs1); }
+    } else if (wave == GQ + 1) {
+        hs0 = f2h(x0); hs1 = f2h(x1);
+        vc[lane] = h2f(hs0); vc[lane + 64] = h2f(hs1);
+    }
+    FA1_STAMP(2);
+    // The K / V instructions were the wave's FIRST vector-memory requests and return in order: a wave that has used its raw rows (waves 0 .. 5) has its part of the
+    // tiles in LDS; the two waves without a chain wait for theirs here.  (hipcc drains the queue -- vmcnt(0) -- in front of the first LDS read behind an inline-asm
+    // LDS-DMA anyway: the mask row, requested ~0.8 us earlier, has arrived by then.)
+    if (wave > GQ + 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    FA1_STAMP(3);
+    const int krow = krow_u - row0, vrow = vrow_u - row0;          // the new token's row relative to this slice (its cache row is being written: taken from LDS instead)
+    // ---------------------------------------------------------------- 3. + 4. scores and soft-max of head hh = wave < 4, lane = ROW of the slice: no cross-lane sums, the
+    // scores never leave the registers.  Lane r walks its row's sixteen 16-byte chunks in the order c ^ (r & 15): the 16 lanes one ds_read_b128 pass serves
+    // ({0-3, 12-15, 20-27}, ... MI355X_MICROARCH.md "LDS") then hit sixteen different bank quads although the rows are 256 bytes apart; q's chunks (f16, LDS) follow the same order
+    if (wave < GQ) {
+        float snew = 0.0f;                                          // score of the new token itself, from the k head in LDS
+#pragma unroll
+        for (int i = 0; i < D / 64; ++i) snew = fmaf(kc[lane + 64 * i], qf[wave][lane + 64 * i], snew);
+        snew = wave_sum_f32(snew);
+        const char * kr = kt + lane * (D * 2);
+        const char * qr = (const char *) &q16[wave][0];
+        const uint32_t x16 = (uint32_t) (lane & 15) * 16u;
+        // every chunk of the row and of q requested first (32 ds_read_b128), four independent partial sums: one wave per SIMD runs this phase, nothing else hides a latency
+        u32x4 kk[16], qq[16];
+#pragma unroll
+        for (int c = 0; c < 16; ++c) { const uint32_t o = (uint32_t) (c * 16) ^ x16; kk[c] = *(const u32x4 *) (kr + o); qq[c] = *(const u32x4 *) (qr + o); }
+        float s4[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
+#pragma unroll
+        for (int c = 0; c < 16; ++c)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { f16x2 kh, qh; const uint32_t kw = kk[c][e], qw2 = qq[c][e]; __builtin_memcpy(&kh, &kw, 4); __builtin_memcpy(&qh, &qw2, 4); s4[e] = __builtin_amdgcn_fdot2(kh, qh, s4[e], false); }
+        const float sv = (s4[0] + s4[1]) + (s4[2] + s4[3]);
+        float m = a_mask ? h2f(mraw) : 0.0f;
+        if (lane >= nkv) m = -INFINITY;
+        float v = m == -INFINITY ? -INFINITY : (lane == krow ? snew : sv) * a_scale + m;
+        const float M = wave_max_f32(v);
+        float p = v == -INFINITY ? 0.0f : expf(v - M);
+        const float S = wave_sum_f32(p);
+        float pc = 0.0f;
+        if (vrow >= 0 && vrow < nkv) { pc = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(p), vrow & 63)); if (lane == vrow) p = 0.0f; }     // the new token's V row is in LDS, not in the tile
+        pl[wave][lane] = p;
+        if (lane == 0) { pcur_s[wave] = pc; ms_s[wave][0] = M; ms_s[wave][1] = S; }
+    }
+    __syncthreads();
+    FA1_STAMP(5);
+    float (* part)[GQ][D] = (float (*)[GQ][D]) kt;                 // the waves' partial rows [FGS_W][GQ][D] take the K tile's place (its last reader is behind the barrier above)
+    static_assert(sizeof(float) * FGS_W * GQ * D <= sizeof kt, "partials alias the K tile");
+    // ---------------------------------------------------------------- 5. P.V: wave w takes rows 8 w .. 8 w + 7 for the four heads, TWO rows per step: lanes 0 .. 31 row 2 t, lanes 32 .. 63
+    // row 2 t + 1, four output dims per lane (ds_read_b64, 8 bytes x 32 lanes = the row)
+    {
+        const int half = lane >> 5, l5 = lane & 31;
+        float acc[GQ][4];
+#pragma unroll
+        for (int hh = 0; hh < GQ; ++hh)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[hh][e] = 0.0f;
+#pragma unroll
+        for (int t = 0; t < RPW / 2; ++t) {
+            const int row = wave * RPW + 2 * t + half;
+            u32x2 w = *(const u32x2 *) (vt + row * (D * 2) + 8 * l5);
+            float p[GQ];
+#pragma unroll
+            for (int hh = 0; hh < GQ; ++hh) p[hh] = pl[hh][row];
+            // masked cells are SKIPPED by the reference (ops.cpp:8047-8050), never multiplied: an uninitialised cache cell holding inf / NaN must not leak in through
+            // 0 * x.  A row every head of the group weights with zero is dropped whole (a cell that is live for one head is initialised, and 0 * finite adds nothing)
+            const bool any = (p[0] != 0.0f) | (p[1] != 0.0f) | (p[2] != 0.0f) | (p[3] != 0.0f);
+            if (!any) { w[0] = 0u; w[1] = 0u; }
+            const float v0 = h2f((uint16_t) (w[0] & 0xffff)), v1 = h2f((uint16_t) (w[0] >> 16)), v2 = h2f((uint16_t) (w[1] & 0xffff)), v3 = h2f((uint16_t) (w[1] >> 16));
+#pragma unroll
+            for (int hh = 0; hh < GQ; ++hh) {
+                acc[hh][0] = fmaf(p[hh], v0, acc[hh][0]); acc[hh][1] = fmaf(p[hh], v1, acc[hh][1]);
+                acc[hh][2] = fmaf(p[hh], v2, acc[hh][2]); acc[hh][3] = fmaf(p[hh], v3, acc[hh][3]);
+            }
+        }
+        // the two rows of a step fold inside the wave (its LDS operations execute in order): the lower half stores, the upper half adds
+        if (half == 0) {
+#pragma unroll
+            for (int hh = 0; hh < GQ; ++hh) *(f32x4 *) (&part[wave][hh][4 * l5]) = f32x4{ acc[hh][0], acc[hh][1], acc[hh][2], acc[hh][3] };
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (half == 1) {
+#pragma unroll
+            for (int hh = 0; hh < GQ; ++hh) {
+                const f32x4 t = *(const f32x4 *) (&part[wave][hh][4 * l5]);
+                *(f32x4 *) (&part[wave][hh][4 * l5]) = f32x4{ t[0] + acc[hh][0], t[1] + acc[hh][1], t[2] + acc[hh][2], t[3] + acc[hh][3] };
+            }
+        }
+    }
+    __syncthreads();
+    FA1_STAMP(6);
+    // ---------------------------------------------------------------- 6. fold the waves' row groups (fixed order), add the new token's own term, store the slice's partial state
+    {
+        const int hh = threadIdx.x >> 7, d = threadIdx.x & (D - 1);          // 512 threads = 4 heads x 128 dims
+        float o = 0.0f;
+#pragma unroll
+        for (int w = 0; w < FGS_W; ++w) o += part[w][hh][d];
+        o = fmaf(pcur_s[hh], vc[d], o);
+        const int h = g * GQ + hh;
+        a_part[(size_t) sp * (a_nh * D) + h * D + d] = o;
+        if (d < 2) a_part[(size_t) FGS_NSL * (a_nh * D) + ((size_t) sp * a_nh + h) * 2 + d] = ms_s[hh][d];
+    }
+    // the slice that holds the new token's row (or slice 0 when the index points outside the view) stores the new cache rows
+    const bool owner = (krow_u >= row0 && krow_u < row0 + RS) || (sp == 0 && (krow_u < 0 || krow_u >= nkv_all));
+    if (owner) {
+        if (wave == GQ)          { uint16_t * kr = (uint16_t *) (a_kcache + (int64_t) krow_u * a_kc_rs) + g * D; kr[e0] = hs0; kr[e1] = hs1; }
+        else if (wave == GQ + 1) { uint16_t * vr = (uint16_t *) (a_vcache + (int64_t) vrow_u * a_vc_rs) + g * D; vr[lane] = hs0; vr[lane + 64] = hs1; }
+    }
+    FA1_STAMP(7);
+    FA1_STAMP_FLUSH;
 }
 
 // ================================================================================================= flash-attention OFF (llama-bench's default)
@@ -605,6 +831,62 @@ void flash_attn_one(const fa_dev & f, int D, const float * rope_tab, hipStream_t
     else         k_fattn_one<128><<<grid, dim3(256), 0, st>>>(FA1_LEAD_ARGS(a), a);
 }
 
+
+// ---- group-slice form: applicability and launch.  parts: FGS_NSL x [n_head * D] partial outputs, then FGS_NSL x [n_head] x (M, S)
+size_t fattn_gs_parts_bytes(int n_head, int D) { return (size_t) FGS_NSL * n_head * D * 4 + (size_t) FGS_NSL * n_head * 2 * 4; }
+int    fattn_gs_nslice() { return FGS_NSL; }
+bool fattn_gs_ok(const fattn_args & f) {
+    static const bool env_off = getenv("MI355X_FA_NO_GS") != nullptr;
+    if (env_off || !fattn_one_ok(f)) return false;
+    const fattn_pre & P = *f.pre;
+    const int64_t D = f.q.ne[0], nh = f.q.ne[2], nkvh = f.k.ne[2];
+    if (D != 128 || nkvh < 1 || nkvh > 255 || nh != 4 * nkvh || f.k.ne[1] > FA1_NKV || f.sinks || f.max_bias != 0.0f || f.logit_softcap != 0.0f) return false;
+    if (P.q_hs != D * 4 || P.k_hs != D * 4 || P.v_hs != D * 4 || f.k.nb[2] != (size_t) D * 2 || f.v.nb[2] != (size_t) D * 2 || f.k.nb[1] != f.v.nb[1] || f.k.nb[1] > 0x7fffff) return false;
+    if (((uintptr_t) P.qraw & 15) != 0 || ((uintptr_t) P.kraw & 15) != 0 || ((uintptr_t) P.vraw & 15) != 0 || ((uintptr_t) f.k.p & 15) != 0 || ((uintptr_t) f.v.p & 15) != 0) return false;
+    if (f.mask && ((((uintptr_t) f.mask->p) & 3) != 0 || f.mask->nb[2] % 4 != 0)) return false;
+    const int64_t ko = (const char *) P.kraw - (const char *) P.qraw, vo = (const char *) P.vraw - (const char *) P.qraw, vco = ((const char *) f.v.p - (const char *) f.k.p) / 16;
+    if (ko != (int64_t) (int32_t) ko || vo != (int64_t) (int32_t) vo || vco != (int64_t) (int32_t) vco) return false;
+    if (P.qw) { const int64_t wo = (const char *) P.kw - (const char *) P.qw; if (!P.kw || wo != (int64_t) (int32_t) wo) return false; }
+    return true;
+}
+void flash_attn_gs(const fa_dev & f, int D, const float * rope_tab, float * parts, hipStream_t st) {
+    if (!rope_tab || !parts || D != 128) { fprintf(stderr, "[mi355x] flash_attn_gs: bad arguments\n"); abort(); }
+    const fa_pre & P = f.pre;
+    fa1_dev a{};
+    a.qraw = P.qraw; a.kraw = P.kraw; a.vraw = P.vraw; a.qw = P.qw; a.kw = P.kw; a.tab = rope_tab;
+    a.kcache = P.kcache; a.vcache = P.vcache; a.kidx = P.kidx; a.vidx = P.vidx;
+    a.k = f.k; a.v = f.v; a.mask = f.mask; a.sinks = nullptr; a.dst = f.dst;
+    a.q_hs = (int) P.q_hs; a.k_hs = (int) P.k_hs; a.v_hs = (int) P.v_hs; a.kc_rs = (int) P.kc_rs; a.vc_rs = (int) P.vc_rs;
+    a.knb1 = (int) f.knb1; a.knb2 = (int) f.knb2; a.vnb1 = (int) f.vnb1; a.vnb2 = (int) f.vnb2; a.mnb2 = (int) f.mnb2; a.mne2 = (int) f.mne2; a.dnb1 = (int) f.dnb1;
+    a.nkv = f.nkv; a.gq = f.gq; a.neox = (P.rd.mode & GGML_ROPE_TYPE_NEOX) ? 1 : 0; a.n_head_log2 = (int) f.n_head_log2;
+    a.has_norm = P.qw != nullptr; a.nsplit = FGS_NSL; a.part = parts; a.cnt = nullptr;
+    a.eps = P.eps; a.scale = f.scale; a.max_bias = 0.0f; a.logit_softcap = 0.0f; a.m0 = 1.0f; a.m1 = 1.0f;
+    a.n_head = f.nh; a.nkvh_log2 = -1;
+    const int nkvh = f.nh / 4;
+    const uint32_t pk = (uint32_t) nkvh | ((uint32_t) a.neox << 8) | ((uint32_t) a.has_norm << 9) | ((uint32_t) f.nkv << 16);
+    k_fattn_gs<128><<<dim3((unsigned) (nkvh * FGS_NSL)), dim3(64 * FGS_W), 0, st>>>(a.qraw, a.qw, a.tab, a.k, (int) (a.kraw - a.qraw), (int) (a.vraw - a.qraw), a.qw ? (int) ((const char *) a.kw - (const char *) a.qw) : 0,
+                                                                                      (int) ((a.v - a.k) / 16), a.knb1, pk, a);
+}
+// the slices' partial states folded into the f32 rows [n_head * D] (what the wo launch does in its prologue; used when that launch cannot take the parts)
+__global__ void k_fattn_gs_merge(const float * parts, float * dst, int n_head, int D) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_head * D) return;
+    const int h = i / D;
+    const float * ms = parts + (size_t) FGS_NSL * n_head * D;
+    float M = -INFINITY;
+#pragma unroll
+    for (int s = 0; s < FGS_NSL; ++s) M = fmaxf(M, ms[((size_t) s * n_head + h) * 2]);
+    float o = 0.0f, den = 0.0f;
+#pragma unroll
+    for (int s = 0; s < FGS_NSL; ++s) {
+        const float Ms = ms[((size_t) s * n_head + h) * 2], f = Ms == -INFINITY ? 0.0f : expf(Ms - M);
+        o = fmaf(f, parts[(size_t) s * n_head * D + i], o); den = fmaf(f, ms[((size_t) s * n_head + h) * 2 + 1], den);
+    }
+    dst[i] = den == 0.0f ? 0.0f : o * (1.0f / den);
+}
+void fattn_gs_merge(const float * parts, float * dst, int n_head, int D, hipStream_t st) {
+    k_fattn_gs_merge<<<dim3((unsigned) ((n_head * D + 255) / 256)), dim3(256), 0, st>>>(parts, dst, n_head, D);
+}
 
 // ---- host side of the soft-max path
 bool attn_one_sm_ok(const attn_sm_args & f) {

@@ -320,6 +320,7 @@ static const int MV1_WAVES = 4096;
 
 static int g_mv2 = -1;
 void mmv2_enable(bool on) { g_mv2 = on ? 1 : 0; }
+bool mmv2_enabled();
 static bool mv2_on() { if (g_mv2 < 0) { const char * e = getenv("MI355X_MV2"); g_mv2 = e ? (atoi(e) != 0) : 1; } return g_mv2 != 0; }
 
 bool mmv1_ok(const mv1_args & a) {
@@ -350,12 +351,15 @@ static void mv1_go(const mv1_dev & d, int tm, int grid, hipStream_t st) {
 }
 
 
+bool mmv2_enabled() { return mv2_on(); }
+
 void mmv1(const mv1_args & a, hipStream_t st) {
     if (a.nmat >= 1 && (a.m[0].type == GGML_TYPE_Q8_0 || a.m[0].type == GGML_TYPE_F16)) {
         if (a.m[0].type == GGML_TYPE_Q8_0 && mv2_on() && mmv2_ok(a)) { mmv2(a, st); return; }   // the 8B widths (K = 4096 / 12288, any row count): the LDS-DMA engine
         mmv1q(a, st); return;
     }
     if (mv2_on() && mmv2_ok(a)) { mmv2(a, st); return; }
+    if (a.parts) { fprintf(stderr, "[mi355x] mmv1: attention partial states on a launch the LDS-DMA engine refuses\n"); abort(); }
     if (!mmv1_ok(a)) { fprintf(stderr, "[mi355x] mmv1: unsupported arguments (K=%lld)\n", (long long) a.K); abort(); }
     const bool pair = a.W_up != nullptr;
     const int nw_wg = pair ? 8 : 16;

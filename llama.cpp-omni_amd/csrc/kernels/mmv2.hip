@@ -38,14 +38,19 @@ namespace mi {
 static __device__ __forceinline__ int mv2_wgt_type(uint32_t wgt, int i) { const uint32_t c = (wgt >> (24 + 2 * i)) & 3u; return c == 1u ? GGML_TYPE_Q4_K : c == 2u ? GGML_TYPE_Q6_K : GGML_TYPE_Q8_0; }
 typedef const __attribute__((address_space(4))) mv2_dev * mv2_karg;
 #define MV2_REST_OFFSET 56
-template <int TM, int NIT, bool PAIR, bool NT, int NW = MV2_WAVES>
+template <int TM, int NIT, bool PAIR, bool NT, int NW = MV2_WAVES, bool PARTS = false>
 __global__ void __launch_bounds__(64 * NW) k_mv2(const char * W0, const float * x, const float * nw, const char * aux /* pair: the up matrix; one matrix: its residual; a group: the offsets of W1 / W2 */,
                                                          uint32_t w_rs0, uint32_t qr0, uint32_t qr1, uint32_t qr2, float eps, uint32_t wgt /* MV2_WGT: first workgroups of m[1] / m[2], their types */, const mv2_dev rest) {
     __shared__ mv2_flags F;
     __shared__ double red[16];
+    static_assert(!PARTS || (!PAIR && NIT == 1 && TM != 4), "PARTS: one K-quant matrix of K = 4096 = n_head x 128 on the attention slices' partial states (x = the parts buffer)");
+    constexpr int PBYTES = MV2_PARTS_NSL * 4096 * 4 + MV2_PARTS_NSL * 32 * 8;                          // the parts buffer (K = 4096)
+    constexpr int XS = PARTS ? PBYTES + 512 - 32768 : 0;            // staging: the parts buffer + the fold's coefficient table instead of row + norm weights
+    constexpr int RWN = PARTS ? MV2_PARTS_RW : MV2_ROW_WAVES;
+    static_assert(RWN <= NW - 1, "row waves are consumers");
     constexpr int C = NW - 1;
     constexpr int PW = 4 * NIT < C ? 4 * NIT : C;   // prologue waves
-    typedef mv2_geo<2304, 1, NIT> geo0;                // (IMG and STG do not depend on the weight type)
+    typedef mv2_geo<2304, 1, NIT, XS> geo0;            // (IMG and STG do not depend on the weight type)
     MV2_STAMP_DECL;
     MV2_STAMP(0);
 #ifdef MV2_TRACE
@@ -59,7 +64,7 @@ __global__ void __launch_bounds__(64 * NW) k_mv2(const char * W0, const float * 
     // The scalar unit is one per CU: sixteen waves running their set-up at once take ~0.5 us of it.  The loader and the row waves are on the
     // launch's critical path and go first (and at raised priority); the waves that only build the image or only consume stay out of the way.
 #ifndef MV2_NO_STAGGER
-    if (wiw == 0 || wiw >= NW - MV2_ROW_WAVES) __builtin_amdgcn_s_setprio(3);
+    if (wiw == 0 || wiw >= NW - RWN) __builtin_amdgcn_s_setprio(3);
     else if (wiw <= PW) __builtin_amdgcn_s_sleep(12);
     else { __builtin_amdgcn_s_sleep(40); }
 #endif
@@ -112,28 +117,30 @@ __global__ void __launch_bounds__(64 * NW) k_mv2(const char * W0, const float * 
     if (wiw == 0) {
         const size_t wbytes = (size_t) (G0 + ntask) * M.w_rs;      // (the workgroup's rows end here: nothing of the launch is requested past them)
         const mv1_rsrc rs0 = mv1_make_rsrc(M.W, wbytes), rs1 = mv1_make_rsrc(PAIR ? W1 : M.W, wbytes);
-        if constexpr (Q80) mv2_loader<4352, PAIR ? 2 : 1, NIT, C, NT>(rs0, rs1, (uint32_t) M.w_rs, G0, ntask * NIT, mv2_lds_addr(ringp), &F MV2_TR_ARG);
-        else if (q4) mv2_loader<2304, PAIR ? 2 : 1, NIT, C, NT>(rs0, rs1, (uint32_t) M.w_rs, G0, ntask * NIT, mv2_lds_addr(ringp), &F MV2_TR_ARG);
-        else if constexpr ((TM & 2) != 0 && !PAIR) mv2_loader<3360, 1, NIT, C, NT>(rs0, rs1, (uint32_t) M.w_rs, G0, ntask * NIT, mv2_lds_addr(ringp), &F MV2_TR_ARG);
+        if constexpr (Q80) mv2_loader<4352, PAIR ? 2 : 1, NIT, C, NT, XS, RWN>(rs0, rs1, (uint32_t) M.w_rs, G0, ntask * NIT, mv2_lds_addr(ringp), &F MV2_TR_ARG);
+        else if (q4) mv2_loader<2304, PAIR ? 2 : 1, NIT, C, NT, XS, RWN>(rs0, rs1, (uint32_t) M.w_rs, G0, ntask * NIT, mv2_lds_addr(ringp), &F MV2_TR_ARG);
+        else if constexpr ((TM & 2) != 0 && !PAIR) mv2_loader<3360, 1, NIT, C, NT, XS, RWN>(rs0, rs1, (uint32_t) M.w_rs, G0, ntask * NIT, mv2_lds_addr(ringp), &F MV2_TR_ARG);
         MV2_STAMP(7);
     } else {
         const int c = wiw - 1, lane = threadIdx.x & 63;
         const char * resid_p = PAIR ? nullptr : M.resid;
         // roles before the stream is consumed: the last 4 consumers fetch the row, consumers 0 .. 4 NIT - 1 (NIT per SIMD) build the image, the rest wait
-        if (c >= C - MV2_ROW_WAVES) mv2_row_loader(src, K, c - (C - MV2_ROW_WAVES), resid_p, G0, ntask, mv2_lds_addr(stg), mv2_lds_addr(rstg), &F MV2_TR_ARG);
+        if constexpr (PARTS) { if (c >= C - RWN) mv2_parts_loader((const char *) x, K, c - (C - RWN), resid_p, G0, ntask, mv2_lds_addr(stg), mv2_lds_addr(rstg), &F MV2_TR_ARG); }
+        else if (c >= C - RWN) mv2_row_loader(src, K, c - (C - RWN), resid_p, G0, ntask, mv2_lds_addr(stg), mv2_lds_addr(rstg), &F MV2_TR_ARG);
         uint32_t img_need = 4 * NIT;
-        if (src.img) { if constexpr (Q80) mv2_image_copy_q80<C>(src.img, K, c, im, &F); else mv2_image_copy<C>(src.img, K, c, im, &F); img_need = C; }
+        if constexpr (PARTS) { if (c < 4) mv2_prologue_parts(K, c, im, stg, (float *) (stg + PBYTES), &F MV2_TR_ARG); }
+        else if (src.img) { if constexpr (Q80) mv2_image_copy_q80<C>(src.img, K, c, im, &F); else mv2_image_copy<C>(src.img, K, c, im, &F); img_need = C; }
         else if (c < PW) mv2_prologue<NIT, Q80, PW>(src, K, c, im, stg, red, &F MV2_TR_ARG);
         { uint32_t spins = 0; while (mv2_peek(MV2_FLAG(F.img_cnt)) < img_need) { __builtin_amdgcn_s_sleep(4); if (++spins > MV2_SPIN_MAX) __builtin_trap(); } asm volatile("" ::: "memory"); }
         // the residual of this consumer's tasks, one per lane (task k of the consumer is row G0 + c + k C), from the staging area: the consumers
         // issue NO vector-memory loads -- one would wait for a place in the CU's memory queue behind the loader's stream
         float resid = 0.0f;
-        if (resid_p) { mv2_await(MV2_FLAG(F.x_landed), MV2_ROW_WAVES); const int r = c + lane * C; if (r < ntask) resid = *(const float *) (rstg + r * 4); }
+        if (resid_p) { mv2_await(MV2_FLAG(F.x_landed), RWN); const int r = c + lane * C; if (r < ntask) resid = *(const float *) (rstg + r * 4); }
         MV2_STAMP(4);
         char * dst = R->m[mi_].dst;                        // (needed when the first results are stored)
         if constexpr (Q80) mv2_consume_q80<PAIR ? 2 : 1, NIT, C, PAIR>(im, ringp, K, c, ntask, dst, G0 + c, resid, &F);
-        else if (q4) mv2_consume_q4k<PAIR ? 2 : 1, NIT, C, PAIR>(im, ringp, K, c, ntask, dst, G0 + c, resid, &F);
-        else if constexpr ((TM & 2) != 0 && !PAIR) mv2_consume_q6k<NIT, C>(im, ringp, K, c, ntask, dst, G0 + c, resid, &F);
+        else if (q4) mv2_consume_q4k<PAIR ? 2 : 1, NIT, C, PAIR, XS>(im, ringp, K, c, ntask, dst, G0 + c, resid, &F);
+        else if constexpr ((TM & 2) != 0 && !PAIR) mv2_consume_q6k<NIT, C, XS>(im, ringp, K, c, ntask, dst, G0 + c, resid, &F);
         MV2_STAMP(7);
     }
     MV2_STAMP_FLUSH;
@@ -168,16 +175,18 @@ bool mmv2_ok(const mv1_args & a) {
         if (((uintptr_t) m.dst & 3) != 0 || ((uintptr_t) m.resid & 3) != 0) return false;
         if (m.resid && m.nrows > (int64_t) cus * 256) return false;                           // the residual staging area holds 256 rows per workgroup
     }
+    if (a.parts)                                                                             // attention slices' partial states: folded in the prologue (k_mv2 PARTS)
+        return a.nslice == MV2_PARTS_NSL && a.K == 4096 && a.nmat == 1 && !q80 && !a.W_up && !a.norm_w && !a.img && !a.x && ((uintptr_t) a.parts & 15) == 0;
     if (a.img) return ((uintptr_t) a.img & 15) == 0;
     return a.x && ((uintptr_t) a.x & 15) == 0 && ((uintptr_t) a.norm_w & 15) == 0;
 }
 
-template <int TM, int NIT, bool PAIR, bool NT, int NW = MV2_WAVES>
-static void mv2_launch(const mv2_dev & d, int grid, hipStream_t st) {
+template <int TM, int NIT, bool PAIR, bool NT, int NW = MV2_WAVES, bool PARTS = false>
+static void mv2_launch(const mv2_dev & d, int grid, hipStream_t st, const float * parts = nullptr) {
     const size_t lds = 160 * 1024 - 512;                                                       // image + staging + ring: the whole CU (mv2_geo)
     static bool attr[64] = { false };
     const int dev = mv2_dev_ordinal();
-    if (!attr[dev]) { HIP_CHECK(hipFuncSetAttribute((const void *) k_mv2<TM, NIT, PAIR, NT, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds)); attr[dev] = true; }
+    if (!attr[dev]) { HIP_CHECK(hipFuncSetAttribute((const void *) k_mv2<TM, NIT, PAIR, NT, NW, PARTS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds)); attr[dev] = true; }
     static_assert(offsetof(mv2_dev, src) % 8 == 0, "argument block layout");
     // the scalars of the launch (see k_mv2): q | r << 16 per matrix; wgt = first workgroup of m[1] | of m[2] << 12 | the three types << 24 | MV2_WGT_PACKED
     auto qr = [&](int i) { return (uint32_t) d.m[i].q | ((uint32_t) d.m[i].r << 16); };
@@ -194,7 +203,7 @@ static void mv2_launch(const mv2_dev & d, int grid, hipStream_t st) {
     }
     if (packed) { wgt |= MV2_WGT_PACKED; aux = (const char *) (uintptr_t) ((uint64_t) (uint32_t) (int32_t) off[1] | ((uint64_t) (uint32_t) (int32_t) off[2] << 32)); }
     if (d.m[0].q > 0xffff || d.m[0].r > 0xffff || grid > 4095) { fprintf(stderr, "[mi355x] mmv2: %d rows per workgroup\n", d.m[0].q); abort(); }
-    k_mv2<TM, NIT, PAIR, NT, NW><<<dim3(grid), dim3(64 * NW), lds, st>>>(d.m[0].W, d.src.img ? nullptr : d.src.x, d.src.nw, aux, d.m[0].w_rs, qr(0), qr(d.nmat > 1 ? 1 : 0), qr(d.nmat > 2 ? 2 : 0), d.src.eps, wgt, d);
+    k_mv2<TM, NIT, PAIR, NT, NW, PARTS><<<dim3(grid), dim3(64 * NW), lds, st>>>(d.m[0].W, PARTS ? parts : (d.src.img ? nullptr : d.src.x), PARTS ? nullptr : d.src.nw, aux, d.m[0].w_rs, qr(0), qr(d.nmat > 1 ? 1 : 0), qr(d.nmat > 2 ? 2 : 0), d.src.eps, wgt, d);
 }
 
 // workgroup ranges of the matrices of a launch: by bytes, every matrix at least one workgroup
@@ -232,7 +241,8 @@ void mmv2(const mv1_args & a, hipStream_t st) {
     // waves per workgroup (1 loader + the consumers), by launch shape: tools/mmv2_lab.hip sweep (profiles/r06_mv2_waves.txt).  The long pair launch keeps sixteen; the short
     // ones run faster with fewer waves contending for the CU's issue slots through the prologue and the tail: the three-matrix group with twelve (6.4 -> 6.1 us), one
     // matrix of a few thousand rows with ten (ffn_down Q4_K 8.1 -> 7.5, Q6_K 11.4 -> 9.6, wo 5.0 -> 4.8); the lm-head (hundreds of steps per workgroup) keeps sixteen
-    const bool small = a.nmat == 1 && a.m[0].nrows <= 16384;
+    static const bool nw16 = getenv("MI355X_MV2_NW16") != nullptr;                        // A/B: sixteen waves everywhere (the round-5 form)
+    const bool small = !nw16 && a.nmat == 1 && a.m[0].nrows <= 16384;
     if (tm == 4) {                                                                           // Q8_0
         if (pair)              mv2_launch<4, 1, true, true>(d, grid, st);
         else if (a.K == 4096)  mv2_launch<4, 1, false, true>(d, grid, st);
@@ -240,8 +250,13 @@ void mmv2(const mv1_args & a, hipStream_t st) {
         return;
     }
     if (pair)               { mv2_launch<1, 1, true, true>(d, grid, st); return; }
+    if (a.parts) {
+        if (tm == 1) mv2_launch<1, 1, false, true, 10, true>(d, grid, st, a.parts);
+        else         mv2_launch<2, 1, false, true, 10, true>(d, grid, st, a.parts);
+        return;
+    }
     if (a.K == 4096) {
-        if (a.nmat > 1) {
+        if (a.nmat > 1 && !nw16) {
             if (tm == 1)      mv2_launch<1, 1, false, true, 12>(d, grid, st);
             else if (tm == 2) mv2_launch<2, 1, false, true, 12>(d, grid, st);
             else              mv2_launch<3, 1, false, true, 12>(d, grid, st);
@@ -250,7 +265,8 @@ void mmv2(const mv1_args & a, hipStream_t st) {
             else              mv2_launch<2, 1, false, true, 10>(d, grid, st);
         } else {
             if (tm == 1)      mv2_launch<1, 1, false, true>(d, grid, st);
-            else              mv2_launch<2, 1, false, true>(d, grid, st);
+            else if (tm == 2) mv2_launch<2, 1, false, true>(d, grid, st);
+            else              mv2_launch<3, 1, false, true>(d, grid, st);
         }
     } else {
         if (a.nmat > 1) {

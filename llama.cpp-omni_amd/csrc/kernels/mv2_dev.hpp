@@ -159,13 +159,13 @@ static __device__ __forceinline__ void mv2_dma_piece(const mv1_rsrc rs, uint32_t
 }
 
 // ring geometry of a (type, rows per task, K) combination: as many slots of one step as the CU's LDS holds next to the image
-template <int PIECE, int R, int NIT> struct mv2_geo {
+template <int PIECE, int R, int NIT, int XS = 0> struct mv2_geo {       // XS: extra staging bytes (the attention slices' partial states, MV2 PARTS)
     static constexpr int VM    = (PIECE == 2304 ? 3 : PIECE == 3360 ? 4 : 5) * R;   // VMEM instructions per step
     static constexpr int D     = 60 / VM;                                     // steps the loader keeps in flight (vmcnt counts to 63)
     static constexpr int B     = R == 2 ? 2 : 4;                              // steps per loader round: one flag round trip per round
     static constexpr int SLOTB = PIECE * R;
     static constexpr int IMG   = NIT * 16 * 324 + 16;                         // mv1_image_bytes(4096 * NIT)
-    static constexpr int STG   = NIT == 1 ? 32768 : 49152;                    // f32 row + norm weights (K = 4096), row only (K = 12288)
+    static constexpr int STG   = (NIT == 1 ? 32768 : 49152) + XS;             // f32 row + norm weights (K = 4096), row only (K = 12288)
     static constexpr int RSTG  = 1024;                                        // the residual of the workgroup's rows (at most 256)
     static constexpr int NS    = (160 * 1024 - 512 - IMG - STG - RSTG) / SLOTB;
     static_assert(NS >= D + NIT + B, "ring too small");              // (+ a consumer sweep of slack where the loader uses the conservative test)
@@ -181,9 +181,9 @@ template <int VM, int K_> struct mv2_drain {            // at most K_ of my n st
         if constexpr (K_ > 0) mv2_drain<VM, K_ - 1>::go(n, landed);
     }
 };
-template <int PIECE, int R, int NIT, int C, bool NT>
+template <int PIECE, int R, int NIT, int C, bool NT, int XS = 0, int RWN = MV2_ROW_WAVES>
 static __device__ __forceinline__ void mv2_loader(const mv1_rsrc rs0, const mv1_rsrc rs1, uint32_t rs32, int G0, int T, uint32_t ring, mv2_flags * F MV2_TR_PARAM) {
-    typedef mv2_geo<PIECE, R, NIT> geo;
+    typedef mv2_geo<PIECE, R, NIT, XS> geo;
     constexpr int VM = geo::VM, D = geo::D, B = geo::B, SLOTB = geo::SLOTB, NS = geo::NS;
     const int lane = threadIdx.x & 63;
     const uint32_t v16 = 16u * (uint32_t) lane, v4 = 4u * (uint32_t) lane;
@@ -214,7 +214,7 @@ static __device__ __forceinline__ void mv2_loader(const mv1_rsrc rs0, const mv1_
 #ifndef MV2_PAIR_WAITS
     if (R != 2)                                         // (tried for ffn_down too -- 48 KB row: 8.1 -> 9.3 us)
 #endif
-    mv2_await(MV2_FLAG(F->rows_issued), MV2_ROW_WAVES);
+    mv2_await(MV2_FLAG(F->rows_issued), RWN);
     MV2_STAMP(2);
     while (n < T) {
         const int nb_ = T - n < B ? T - n : B;
@@ -426,6 +426,77 @@ static __device__ __forceinline__ void mv2_prologue(const mv1_src s, int K, int 
     }
     MV2_STAMP(5);
 }
+// ================================================================================================= PARTS: the activation row arrives as attention slices' partial states
+// (fattn_one.hip k_fattn_gs: NSL x [K] unnormalised partial outputs O_s, then NSL x [K / 128 heads] x (M_s, S_s) -- one contiguous buffer of NSL K 4 + NSL K / 16 bytes,
+// K = n_head x 128).  RWN row waves bring it into the staging area (1 KiB pieces), the prologue waves fold it
+//     x[h, d] = sum_s f_s O_s[h, d] / sum_s f_s S_s[h],  f_s = exp(M_s[h] - max_s M_s[h])      (flash-decoding's merge, here in front of the quantiser every workgroup runs anyway)
+// and quantise the folded row like any other.
+#define MV2_PARTS_NSL 4
+#define MV2_PARTS_RW  8
+static __device__ __forceinline__ void mv2_parts_loader(const char * parts, int K, int rw, const char * resid, int G0, int ntask, uint32_t stg, uint32_t rstg, mv2_flags * F MV2_TR_PARAM) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t v16 = 16u * (uint32_t) lane, v4 = 4u * (uint32_t) lane;
+    const int bytes = MV2_PARTS_NSL * K * 4 + MV2_PARTS_NSL * (K / 128) * 8, np = (bytes + 1023) >> 10;
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void *) parts, (short) 0, bytes, 0x00020000);
+    MV2_STAMP(2);
+    for (int b = rw, i = 0; b < np; b += MV2_PARTS_RW, ++i) {
+        if (i == 1) MV2_STAMP(3);
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" :: "s"(__builtin_amdgcn_readfirstlane(stg + (uint32_t) b * 1024u)), "v"(v16), "s"(xr), "s"(__builtin_amdgcn_readfirstlane((uint32_t) b * 1024u)) : "memory", "m0");
+    }
+    if (resid && rw == 0) {                             // rows G0 .. G0 + ntask: 64 per instruction
+        const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc((void *) (resid + (size_t) G0 * 4), (short) 0, ntask * 4, 0x00020000);
+        for (int b = 0; b * 64 < ntask; ++b)
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dword %1, %2, %3 offen lds" :: "s"(__builtin_amdgcn_readfirstlane(rstg + (uint32_t) b * 256u)), "v"(v4), "s"(rr), "s"(__builtin_amdgcn_readfirstlane((uint32_t) b * 256u)) : "memory", "m0");
+    }
+    MV2_STAMP(5);
+    mv2_arrive(MV2_FLAG(F->rows_issued));
+    mv2_vmcnt<0>();
+    mv2_arrive(MV2_FLAG(F->x_landed));
+    mv2_arrive(MV2_FLAG(F->rows_landed));
+}
+// prologue wave pw of 4 (K = 4096): blocks 4 pw + row; a 256-block is two heads (lane's m = 0, 1: head 2 b; m = 2, 3: head 2 b + 1)
+static __device__ __forceinline__ void mv2_prologue_parts(int K, int pw, char * im, const char * stg, float * coef /* [16 blocks][8] */, mv2_flags * F MV2_TR_PARAM) {
+    const int lane = threadIdx.x & 63, row = lane >> 4, i = lane & 15, nb = K >> 8, nh = K >> 7;
+    constexpr int NSL = MV2_PARTS_NSL;
+    mv2_await(MV2_FLAG(F->x_landed), MV2_PARTS_RW);
+    MV2_STAMP(2);
+    const int b = pw * 4 + row;
+    // the block's 2 x NSL coefficients f_s / sum_s f_s S_s: lane i of the DPP row takes (head i >> 2 & 1, slice i & 3) -- lanes 8 .. 15 repeat 0 .. 7 --, the slices of a head are a quad
+    {
+        const int h = 2 * b + ((i >> 2) & 1), sl = i & 3;
+        const u32x2 ms = *(const u32x2 *) (stg + (size_t) NSL * K * 4 + ((size_t) sl * nh + h) * 8);
+        const float Ms = __uint_as_float(ms[0]), Ss = __uint_as_float(ms[1]);
+        float M = fmaxf(Ms, __uint_as_float(mv2_dpp_row<0xB1>(__float_as_uint(Ms))));
+        M = fmaxf(M, __uint_as_float(mv2_dpp_row<0x4E>(__float_as_uint(M))));
+        const float f = Ms == -INFINITY ? 0.0f : expf(Ms - M);
+        float den = Ss * f;
+        den += __uint_as_float(mv2_dpp_row<0xB1>(__float_as_uint(den)));
+        den += __uint_as_float(mv2_dpp_row<0x4E>(__float_as_uint(den)));
+        const float cf = den == 0.0f ? 0.0f : f * (1.0f / den);
+        if (i < 8) coef[b * 8 + i] = cf;                // (the wave's own LDS operations execute in order: the reads below see it)
+    }
+    asm volatile("" ::: "memory");
+    const f32x4 c0 = *(const f32x4 *) (coef + b * 8), c1 = *(const f32x4 *) (coef + b * 8 + 4);
+    f32x4 y[4];
+    const char * xp = stg + b * 1024 + 16 * i;
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        const f32x4 cc = m < 2 ? c0 : c1;
+        f32x4 acc = { 0.0f, 0.0f, 0.0f, 0.0f };
+#pragma unroll
+        for (int sl = 0; sl < NSL; ++sl) {
+            const f32x4 o = *(const f32x4 *) (xp + (size_t) sl * K * 4 + 256 * m);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[e] = fmaf(cc[sl], o[e], acc[e]);
+        }
+        y[m] = acc;
+    }
+    MV2_STAMP(3);
+    mv2_q8k_rows(y, lane, b, nb, im);
+    mv2_arrive(MV2_FLAG(F->img_cnt));
+    MV2_STAMP(5);
+}
+
 // ready-made Q8_0 image (the same layout): a plain copy by all C consumers
 template <int C>
 static __device__ __forceinline__ void mv2_image_copy_q80(const char * img, int K, int c, char * im, mv2_flags * F) {
@@ -495,9 +566,9 @@ static __device__ __forceinline__ void mv2_q4k_act_load(const char * im, int nb,
     A.yd  = *(const float *) (im + mv1_img_d(nb) + ib * 4);
 }
 static __device__ __forceinline__ uint32_t mv2_q4k_sel(int q) { return 0x0c0c0000u | (uint32_t) ((q < 2 ? 0 : 4) + 2 * (q & 1)) | ((uint32_t) ((q < 2 ? 0 : 4) + 2 * (q & 1) + 1) << 8); }
-template <int R, int NIT, int C, bool PAIR>
+template <int R, int NIT, int C, bool PAIR, int XS = 0>
 static __device__ __forceinline__ void mv2_consume_q4k(const char * im, const char * ringp, int K, int c, int ntask, char * dst, int row0, float resid, mv2_flags * F) {
-    typedef mv2_geo<2304, R, NIT> geo;
+    typedef mv2_geo<2304, R, NIT, XS> geo;
     constexpr int SLOTB = geo::SLOTB, NS = geo::NS;
     const int lane = threadIdx.x & 63, nb = K >> 8;
     int blk, q; mv2_lane_map(lane, blk, q);
@@ -598,9 +669,9 @@ static __device__ __forceinline__ float mv2_q6k_dot(const mv2_q6k_regs & Rg, con
     }
     return fmaf(h2f(Rg.dw) * A.yd, (float) isum, acc);
 }
-template <int NIT, int C>
+template <int NIT, int C, int XS = 0>
 static __device__ __forceinline__ void mv2_consume_q6k(const char * im, const char * ringp, int K, int c, int ntask, char * dst, int row0, float resid, mv2_flags * F) {
-    typedef mv2_geo<3360, 1, NIT> geo;
+    typedef mv2_geo<3360, 1, NIT, XS> geo;
     constexpr int SLOTB = geo::SLOTB, NS = geo::NS;
     const int lane = threadIdx.x & 63, nb = K >> 8;
     const mv2_q6k_lane L = mv2_q6k_lane_of(lane);

@@ -6,6 +6,7 @@
 #include "../llama.cpp-omni_amd/csrc/kernels/mmv1.hip"
 #include "../llama.cpp-omni_amd/csrc/kernels/mmv1q.hip"
 #include "../llama.cpp-omni_amd/csrc/kernels/mmv2.hip"
+#include "../llama.cpp-omni_amd/csrc/kernels/fattn_one.hip"
 #include <vector>
 #include <string>
 #include <functional>
@@ -121,6 +122,33 @@ int main(int argc, char ** argv) {
         { "lm-head Q6_K 151936x4096 (510 MB) + norm",        4096, 1, { 151936, 0, 0 }, { Q6, 0, 0 }, false, true, false },
     };
     const int only = argc > 1 ? atoi(argv[1]) : -1;
+    if (only == 100) {      // wo (4096 x 4096 Q4_K + resid) on attention slices' partial states (k_mv2 PARTS) against merge kernel + the plain launch
+        const int K = 4096, M = 4096, NH = 32, D = 128, NSL = fattn_gs_nslice();
+        float * parts, * xm; HIP_CHECK(hipMalloc(&parts, fattn_gs_parts_bytes(NH, D))); HIP_CHECK(hipMalloc(&xm, K * 4));
+        std::vector<float> hp(fattn_gs_parts_bytes(NH, D) / 4);
+        uint32_t rng = 12345u; auto rnd = [&]() { rng = rng * 1664525u + 1013904223u; return (float) (rng >> 8) / 16777216.0f; };
+        for (int s = 0; s < NSL; ++s) for (int i = 0; i < K; ++i) hp[(size_t) s * K + i] = (rnd() - 0.5f) * (s == 3 ? 0.0f : 4.0f);
+        for (int s = 0; s < NSL; ++s) for (int h = 0; h < NH; ++h) { float * ms = &hp[(size_t) NSL * K + ((size_t) s * NH + h) * 2]; ms[0] = s == 3 ? -INFINITY : (rnd() - 0.5f) * 6.0f; ms[1] = s == 3 ? 0.0f : 1.0f + 20.0f * rnd(); if (h == 5) { ms[0] = -INFINITY; ms[1] = 0.0f; } }
+        HIP_CHECK(hipMemcpy(parts, hp.data(), hp.size() * 4, hipMemcpyHostToDevice));
+        const size_t wbytes = (size_t) M * 16 * 144, stride = ((wbytes + (1 << 20) - 1) >> 20) << 20; const int nrot = 48;
+        auto launch = [&](int s, float * out, bool use_parts) {
+            mv1_args v; v.nmat = 1; v.K = K; v.eps = 0.0f;
+            v.m[0] = { a4 + (size_t) (s % nrot) * stride / 2304 * 2304, (size_t) 16 * 144, out, 0, resid, 0, M, GGML_TYPE_Q4_K };
+            if (use_parts) { v.parts = parts; v.nslice = NSL; } else v.x = xm;
+            mmv2(v, st);
+        };
+        mmv2_enable(true);
+        fattn_gs_merge(parts, xm, NH, D, st);
+        launch(1, out_a, false); launch(1, out_b, true);
+        std::vector<float> ha(M), hb(M);
+        HIP_CHECK(hipMemcpyAsync(ha.data(), out_a, M * 4, hipMemcpyDeviceToHost, st)); HIP_CHECK(hipMemcpyAsync(hb.data(), out_b, M * 4, hipMemcpyDeviceToHost, st)); HIP_CHECK(hipStreamSynchronize(st));
+        double num = 0, den = 0; int nexact = 0; for (int i = 0; i < M; ++i) { const double d = (double) ha[i] - hb[i]; num += d * d; den += (double) ha[i] * ha[i]; nexact += ha[i] == hb[i]; }
+        printf("wo on partial states vs merge launch + wo: nmse %.2e (%d / %d identical)\n", num / (den + 1e-30), nexact, M);
+        const double t0 = time_graph(48, [&](int s) { launch(s, out_a, false); });
+        const double t1 = time_graph(48, [&](int s) { launch(s, out_b, true); });
+        printf("   wo 4096 x 4096 Q4_K + resid, plain row %.2f us | attention partial states folded in the prologue %.2f us\n", t0, t1);
+        return 0;
+    }
     int si = -1;
     for (const shape & S : shapes) {
         ++si;
