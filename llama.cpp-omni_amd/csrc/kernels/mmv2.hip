@@ -38,7 +38,7 @@ namespace mi {
 static __device__ __forceinline__ int mv2_wgt_type(uint32_t wgt, int i) { const uint32_t c = (wgt >> (24 + 2 * i)) & 3u; return c == 1u ? GGML_TYPE_Q4_K : c == 2u ? GGML_TYPE_Q6_K : GGML_TYPE_Q8_0; }
 typedef const __attribute__((address_space(4))) mv2_dev * mv2_karg;
 #define MV2_REST_OFFSET 56
-template <int TM, int NIT, bool PAIR, bool NT, int NW = MV2_WAVES, bool PARTS = false>
+template <int TM, int NIT, bool PAIR, bool NT, int NW = MV2_WAVES, bool PARTS = false, int RWK = MV2_ROW_WAVES>
 __global__ void __launch_bounds__(64 * NW) k_mv2(const char * W0, const float * x, const float * nw, const char * aux /* pair: the up matrix; one matrix: its residual; a group: the offsets of W1 / W2 */,
                                                          uint32_t w_rs0, uint32_t qr0, uint32_t qr1, uint32_t qr2, float eps, uint32_t wgt /* MV2_WGT: first workgroups of m[1] / m[2], their types */, const mv2_dev rest) {
     __shared__ mv2_flags F;
@@ -46,7 +46,7 @@ __global__ void __launch_bounds__(64 * NW) k_mv2(const char * W0, const float * 
     static_assert(!PARTS || (!PAIR && NIT == 1 && TM != 4), "PARTS: one K-quant matrix of K = 4096 = n_head x 128 on the attention slices' partial states (x = the parts buffer)");
     constexpr int PBYTES = MV2_PARTS_NSL * 4096 * 4 + MV2_PARTS_NSL * 32 * 8;                          // the parts buffer (K = 4096)
     constexpr int XS = PARTS ? PBYTES + 512 - 32768 : 0;            // staging: the parts buffer + the fold's coefficient table instead of row + norm weights
-    constexpr int RWN = PARTS ? MV2_PARTS_RW : MV2_ROW_WAVES;
+    constexpr int RWN = PARTS ? MV2_PARTS_RW : RWK;                   // row waves (RWK: lab sweeps; 4 in the product)
     static_assert(RWN <= NW - 1, "row waves are consumers");
     constexpr int C = NW - 1;
     constexpr int PW = 4 * NIT < C ? 4 * NIT : C;   // prologue waves
@@ -126,11 +126,11 @@ __global__ void __launch_bounds__(64 * NW) k_mv2(const char * W0, const float * 
         const char * resid_p = PAIR ? nullptr : M.resid;
         // roles before the stream is consumed: the last 4 consumers fetch the row, consumers 0 .. 4 NIT - 1 (NIT per SIMD) build the image, the rest wait
         if constexpr (PARTS) { if (c >= C - RWN) mv2_parts_loader((const char *) x, K, c - (C - RWN), resid_p, G0, ntask, mv2_lds_addr(stg), mv2_lds_addr(rstg), &F MV2_TR_ARG); }
-        else if (c >= C - RWN) mv2_row_loader(src, K, c - (C - RWN), resid_p, G0, ntask, mv2_lds_addr(stg), mv2_lds_addr(rstg), &F MV2_TR_ARG);
+        else if (c >= C - RWN) mv2_row_loader<RWN>(src, K, c - (C - RWN), resid_p, G0, ntask, mv2_lds_addr(stg), mv2_lds_addr(rstg), &F MV2_TR_ARG);
         uint32_t img_need = 4 * NIT;
         if constexpr (PARTS) { if (c < 4) mv2_prologue_parts(K, c, im, stg, (float *) (stg + PBYTES), &F MV2_TR_ARG); }
         else if (src.img) { if constexpr (Q80) mv2_image_copy_q80<C>(src.img, K, c, im, &F); else mv2_image_copy<C>(src.img, K, c, im, &F); img_need = C; }
-        else if (c < PW) mv2_prologue<NIT, Q80, PW>(src, K, c, im, stg, red, &F MV2_TR_ARG);
+        else if (c < PW) mv2_prologue<NIT, Q80, PW, RWN>(src, K, c, im, stg, red, &F MV2_TR_ARG);
         { uint32_t spins = 0; while (mv2_peek(MV2_FLAG(F.img_cnt)) < img_need) { __builtin_amdgcn_s_sleep(4); if (++spins > MV2_SPIN_MAX) __builtin_trap(); } asm volatile("" ::: "memory"); }
         // the residual of this consumer's tasks, one per lane (task k of the consumer is row G0 + c + k C), from the staging area: the consumers
         // issue NO vector-memory loads -- one would wait for a place in the CU's memory queue behind the loader's stream
@@ -181,12 +181,12 @@ bool mmv2_ok(const mv1_args & a) {
     return a.x && ((uintptr_t) a.x & 15) == 0 && ((uintptr_t) a.norm_w & 15) == 0;
 }
 
-template <int TM, int NIT, bool PAIR, bool NT, int NW = MV2_WAVES, bool PARTS = false>
+template <int TM, int NIT, bool PAIR, bool NT, int NW = MV2_WAVES, bool PARTS = false, int RWK = MV2_ROW_WAVES>
 static void mv2_launch(const mv2_dev & d, int grid, hipStream_t st, const float * parts = nullptr) {
     const size_t lds = 160 * 1024 - 512;                                                       // image + staging + ring: the whole CU (mv2_geo)
     static bool attr[64] = { false };
     const int dev = mv2_dev_ordinal();
-    if (!attr[dev]) { HIP_CHECK(hipFuncSetAttribute((const void *) k_mv2<TM, NIT, PAIR, NT, NW, PARTS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds)); attr[dev] = true; }
+    if (!attr[dev]) { HIP_CHECK(hipFuncSetAttribute((const void *) k_mv2<TM, NIT, PAIR, NT, NW, PARTS, RWK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds)); attr[dev] = true; }
     static_assert(offsetof(mv2_dev, src) % 8 == 0, "argument block layout");
     // the scalars of the launch (see k_mv2): q | r << 16 per matrix; wgt = first workgroup of m[1] | of m[2] << 12 | the three types << 24 | MV2_WGT_PACKED
     auto qr = [&](int i) { return (uint32_t) d.m[i].q | ((uint32_t) d.m[i].r << 16); };
@@ -203,7 +203,7 @@ static void mv2_launch(const mv2_dev & d, int grid, hipStream_t st, const float 
     }
     if (packed) { wgt |= MV2_WGT_PACKED; aux = (const char *) (uintptr_t) ((uint64_t) (uint32_t) (int32_t) off[1] | ((uint64_t) (uint32_t) (int32_t) off[2] << 32)); }
     if (d.m[0].q > 0xffff || d.m[0].r > 0xffff || grid > 4095) { fprintf(stderr, "[mi355x] mmv2: %d rows per workgroup\n", d.m[0].q); abort(); }
-    k_mv2<TM, NIT, PAIR, NT, NW, PARTS><<<dim3(grid), dim3(64 * NW), lds, st>>>(d.m[0].W, PARTS ? parts : (d.src.img ? nullptr : d.src.x), PARTS ? nullptr : d.src.nw, aux, d.m[0].w_rs, qr(0), qr(d.nmat > 1 ? 1 : 0), qr(d.nmat > 2 ? 2 : 0), d.src.eps, wgt, d);
+    k_mv2<TM, NIT, PAIR, NT, NW, PARTS, RWK><<<dim3(grid), dim3(64 * NW), lds, st>>>(d.m[0].W, PARTS ? parts : (d.src.img ? nullptr : d.src.x), PARTS ? nullptr : d.src.nw, aux, d.m[0].w_rs, qr(0), qr(d.nmat > 1 ? 1 : 0), qr(d.nmat > 2 ? 2 : 0), d.src.eps, wgt, d);
 }
 
 // workgroup ranges of the matrices of a launch: by bytes, every matrix at least one workgroup

@@ -212,8 +212,8 @@ static __device__ __forceinline__ void mv2_loader(const mv1_rsrc rs0, const mv1_
     // (the gate / up launch is bound by this wave's stream -- its consumers start with > 1 us of slack -- so its stream does not wait for the row requests; the short
     //  launches are bound by when consumption can start, there the row goes first)
 #ifndef MV2_PAIR_WAITS
-    if (R != 2)                                         // (tried for ffn_down too -- 48 KB row: 8.1 -> 9.3 us)
-#endif
+    if (R != 2)                                         // (tried for ffn_down too -- 48 KB row: 8.1 -> 9.3 us; and for the 65 KB of attention slices, PARTS: wo 5.4 -> 6.8 us -- whatever is
+#endif                                                  //  requested behind the weight stream arrives behind it)
     mv2_await(MV2_FLAG(F->rows_issued), RWN);
     MV2_STAMP(2);
     while (n < T) {
@@ -246,6 +246,7 @@ static __device__ __forceinline__ void mv2_loader(const mv1_rsrc rs0, const mv1_
 // The activation row (f32), the norm weights and the residual of the workgroup's rows go into the staging area by LDS-DMA, requested before the
 // loader's first weight request (rows_issued), so they are at the head of the CU's memory queue; nothing else of this wave is in flight, so
 // vmcnt(0) is exactly "the row is here".
+template <int RWN = MV2_ROW_WAVES>
 static __device__ __forceinline__ void mv2_row_loader(const mv1_src src, int K, int rw, const char * resid, int G0, int ntask, uint32_t stg, uint32_t rstg, mv2_flags * F MV2_TR_PARAM) {
     const int lane = threadIdx.x & 63;
     const uint32_t v16 = 16u * (uint32_t) lane, v4 = 4u * (uint32_t) lane;
@@ -258,7 +259,7 @@ static __device__ __forceinline__ void mv2_row_loader(const mv1_src src, int K, 
     if (!src.img) {
         const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void *) src.x, (short) 0, K * 4, 0x00020000);
         MV2_STAMP(2);
-        for (int b = rw, i = 0; b < nb; b += MV2_ROW_WAVES, ++i) {
+        for (int b = rw, i = 0; b < nb; b += RWN, ++i) {
             if (i == 1) MV2_STAMP(3);
             asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" :: "s"(__builtin_amdgcn_readfirstlane(stg + (uint32_t) b * 1024u)), "v"(v16), "s"(xr), "s"(__builtin_amdgcn_readfirstlane((uint32_t) b * 1024u)) : "memory", "m0");
         }
@@ -272,12 +273,13 @@ static __device__ __forceinline__ void mv2_row_loader(const mv1_src src, int K, 
     mv2_arrive(MV2_FLAG(F->rows_issued));             // (measured: letting the loader start before ALL of a 48 KB row is requested delays the row more than it gains)
     if (!src.img && src.nw) {                           // (K = 4096: the launcher refuses a norm at K = 12288) 4 pieces per wave
         const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void *) src.nw, (short) 0, K * 4, 0x00020000);
+        static_assert(16 % RWN == 0, "norm weights of K = 4096: 16 pieces over the row waves");
 #pragma unroll
-        for (int i = 0; i < 16 / MV2_ROW_WAVES; ++i) {
-            const int b = rw + i * MV2_ROW_WAVES;
+        for (int i = 0; i < 16 / RWN; ++i) {
+            const int b = rw + i * RWN;
             asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" :: "s"(__builtin_amdgcn_readfirstlane(stg + (uint32_t) (K * 4) + (uint32_t) b * 1024u)), "v"(v16), "s"(wr), "s"(__builtin_amdgcn_readfirstlane((uint32_t) b * 1024u)) : "memory", "m0");
         }
-        mv2_vmcnt<16 / MV2_ROW_WAVES>();                 // everything but the norm-weight pieces: the row is here
+        mv2_vmcnt<16 / RWN>();                           // everything but the norm-weight pieces: the row is here
         mv2_arrive(MV2_FLAG(F->x_landed));
     } else {
         mv2_vmcnt<0>();
@@ -355,11 +357,11 @@ static __device__ __forceinline__ void mv2_q80_rows(const f32x4 (&y)[4], int lan
 // prologue wave pw of PW = min(4 NIT, C) (consumers 0 .. PW - 1): image block groups mw = pw, pw + PW, ... < 4 NIT, group mw = blocks 4 mw + row.
 // With sixteen waves PW = 4 NIT and every wave owns one group (NIT per SIMD); narrower workgroups loop.  A wave publishes the sums of ALL its
 // groups before it waits for the scale (the last arrival -- of 4 NIT -- computes it).
-template <int NIT, bool Q80 = false, int PW = 4 * NIT>
+template <int NIT, bool Q80 = false, int PW = 4 * NIT, int RWN = MV2_ROW_WAVES>
 static __device__ __forceinline__ void mv2_prologue(const mv1_src s, int K, int pw, char * im, const char * stg, double * red, mv2_flags * F MV2_TR_PARAM) {
     const int lane = threadIdx.x & 63, row = lane >> 4, i = lane & 15, nb = K >> 8;
     constexpr int NG = (4 * NIT + PW - 1) / PW;          // groups per wave (at most)
-    mv2_await(MV2_FLAG(F->x_landed), MV2_ROW_WAVES);
+    mv2_await(MV2_FLAG(F->x_landed), RWN);
     MV2_STAMP(2);
     float scale = 1.0f;
     f32x4 x[NG][4];
@@ -401,7 +403,7 @@ static __device__ __forceinline__ void mv2_prologue(const mv1_src s, int K, int 
         }
     }
     MV2_STAMP(3);
-    if (s.nw) mv2_await(MV2_FLAG(F->rows_landed), MV2_ROW_WAVES);
+    if (s.nw) mv2_await(MV2_FLAG(F->rows_landed), RWN);
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
         const int mw = pw + g * PW;

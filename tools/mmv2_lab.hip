@@ -81,7 +81,7 @@ static void trace_report(const char * nm, int nwg, int nl, int NW) {
         const char * const * lab = role == 0 ? labl : role == 1 ? labc : labr;
         if (lab[i][0] == '-') continue;
         std::vector<double> v;
-        for (int w = 0; w < nwaves; ++w) if ((role == 0 ? (w % NW) < nl : role == 1 ? ((w % NW) >= nl && (w % NW) < NW - 4) : (w % NW) >= NW - 4) && h[(size_t) w * 8 + i]) v.push_back((double) (h[(size_t) w * 8 + i] - t0) * 0.01);
+        for (int w = 0; w < nwaves; ++w) if ((role == 0 ? (w % NW) < nl : role == 1 ? ((w % NW) >= nl && (w % NW) < 5) : (w % NW) >= NW - 4) && h[(size_t) w * 8 + i]) v.push_back((double) (h[(size_t) w * 8 + i] - t0) * 0.01);
         if (v.empty()) continue;
         std::sort(v.begin(), v.end());
         printf("        %-9s %-20s %6.2f / %6.2f / %6.2f\n", role == 0 ? "loader" : role == 1 ? "consumer" : "row wave", lab[i], v[0], v[v.size() / 2], v[v.size() - 1]);
@@ -122,6 +122,25 @@ int main(int argc, char ** argv) {
         { "lm-head Q6_K 151936x4096 (510 MB) + norm",        4096, 1, { 151936, 0, 0 }, { Q6, 0, 0 }, false, true, false },
     };
     const int only = argc > 1 ? atoi(argv[1]) : -1;
+    if (only == 101) {      // row-wave sweep: ffn_down (K = 12288, Q4_K / Q6_K, 10 waves), wo (K = 4096, 10 waves)
+        mmv2_enable(true);
+        for (int ty = 0; ty < 3; ++ty) {
+            const int K = ty == 2 ? 4096 : 12288, M = 4096, nb = K / 256, bs = ty == 1 ? 210 : 144; const int T = ty == 1 ? GGML_TYPE_Q6_K : GGML_TYPE_Q4_K;
+            const size_t wbytes = (size_t) M * nb * bs, stride = ((wbytes + (1 << 20) - 1) >> 20) << 20; const int nrot = (int) std::min<size_t>(ARENA / stride, 48);
+            auto dev = [&](int s, float * out) {
+                mv2_dev d{}; d.nmat = 1; d.K = K; d.W1 = nullptr; d.src = { x, nullptr, 0.0f, nullptr };
+                const char * W = (ty == 1 ? a6 : a4) + (size_t) (s % nrot) * stride / (bs * 16) * (bs * 16);
+                d.m[0] = { W, (char *) out, (const char *) resid, (uint32_t) (nb * bs), M, T, 0, M / 256, M % 256 };
+                d.m[1] = d.m[0]; d.m[1].wg0 = 256; d.m[2] = d.m[1];
+                return d;
+            };
+#define RWSWEEP(TMv, NITv, RW) { const double t = time_graph(48, [&](int s) { mv2_launch<TMv, NITv, false, true, 10, false, RW>(dev(s, out_b), 256, st); }); printf("   %s K %d, 10 waves, %d row waves: %.2f us\n", ty == 1 ? "Q6_K" : "Q4_K", K, RW, t); }
+            if (ty == 0) { RWSWEEP(1, 3, 4) RWSWEEP(1, 3, 8) RWSWEEP(1, 3, 2) }
+            if (ty == 1) { RWSWEEP(2, 3, 4) RWSWEEP(2, 3, 8) RWSWEEP(2, 3, 2) }
+            if (ty == 2) { RWSWEEP(1, 1, 4) RWSWEEP(1, 1, 8) RWSWEEP(1, 1, 2) }
+        }
+        return 0;
+    }
     if (only == 100) {      // wo (4096 x 4096 Q4_K + resid) on attention slices' partial states (k_mv2 PARTS) against merge kernel + the plain launch
         const int K = 4096, M = 4096, NH = 32, D = 128, NSL = fattn_gs_nslice();
         float * parts, * xm; HIP_CHECK(hipMalloc(&parts, fattn_gs_parts_bytes(NH, D))); HIP_CHECK(hipMalloc(&xm, K * 4));
@@ -147,6 +166,10 @@ int main(int argc, char ** argv) {
         const double t0 = time_graph(48, [&](int s) { launch(s, out_a, false); });
         const double t1 = time_graph(48, [&](int s) { launch(s, out_b, true); });
         printf("   wo 4096 x 4096 Q4_K + resid, plain row %.2f us | attention partial states folded in the prologue %.2f us\n", t0, t1);
+#ifdef MV2_TRACE
+        HIP_CHECK(hipMemsetAsync(trace_dev, 0, 8192 * 64, st)); for (int s_ = 0; s_ < 4; ++s_) launch(s_ + 7, out_b, false); HIP_CHECK(hipStreamSynchronize(st)); trace_report("wo, plain row (10 waves)", 256, 1, 10);
+        HIP_CHECK(hipMemsetAsync(trace_dev, 0, 8192 * 64, st)); for (int s_ = 0; s_ < 4; ++s_) launch(s_ + 7, out_b, true); HIP_CHECK(hipStreamSynchronize(st)); trace_report("wo, partial states (10 waves, 8 row waves)", 256, 1, 10);
+#endif
         return 0;
     }
     int si = -1;
@@ -238,11 +261,16 @@ int main(int argc, char ** argv) {
             TRACE_REPORT(nm, grid, 1, f, NW);                                                                                      \
         } while (0)
 #ifdef MV2_TRACE
-#define TRACE_REPORT(nm, grid, nl, f, NW) do { HIP_CHECK(hipMemsetAsync(trace_dev, 0, 8192 * 64, st)); for (int s_ = 0; s_ < 4; ++s_) f(s_ + 7, out_b); HIP_CHECK(hipStreamSynchronize(st)); trace_report(nm, grid, nl, NW); } while (0)
+// (the stamps of the LAST launch of the replayed graph that was just timed: in-graph behaviour; MV2_TRACE_EAGER=1: four eager launches instead)
+#define TRACE_REPORT(nm, grid, nl, f, NW) do { if (getenv("MV2_TRACE_EAGER")) { HIP_CHECK(hipMemsetAsync(trace_dev, 0, 8192 * 64, st)); for (int s_ = 0; s_ < 4; ++s_) f(s_ + 7, out_b); } HIP_CHECK(hipStreamSynchronize(st)); trace_report(nm, grid, nl, NW); } while (0)
 #else
 #define TRACE_REPORT(nm, grid, nl, f, NW) do { } while (0)
 #endif
+#ifdef MV2_LAB_ONE
+        if (S.pair) VAR3(true, 16); else if (S.nmat > 1) VAR3(true, 12); else if (S.nrows[0] <= 16384) VAR3(true, 10); else VAR3(true, 16);
+#else
         VAR3(true, 16);
+#endif
 #ifndef MV2_LAB_ONE
         VAR3(true, 13);
         VAR3(true, 12);
