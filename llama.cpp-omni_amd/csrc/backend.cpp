@@ -220,12 +220,13 @@ static void be_free(ggml_backend_t b) {
     flush_uploads(c);
     HIP_CHECK(hipStreamSynchronize(c->stream));
     for (int h = 0; h < 2; ++h) { if (c->up_host[h]) (void) hipHostFree(c->up_host[h]); if (c->up_ents[h]) (void) hipHostFree(c->up_ents[h]); if (c->up_done[h]) (void) hipEventDestroy(c->up_done[h]); }
-    if (!g_graph_times.empty()) {
+    std::vector<graph_gpu_time> times;
+    { std::lock_guard<std::recursive_mutex> lk(g_live_mu); times.swap(g_graph_times); }      // (every backend's graph_compute pushes here: the first one freed drains the list)
+    if (!times.empty()) {
         std::string line;
-        for (const graph_gpu_time & t : g_graph_times) { float ms = 0.0f; if (hipEventElapsedTime(&ms, t.a, t.b) == hipSuccess) { char buf[64]; snprintf(buf, sizeof buf, " %d:%.2f", t.nodes, ms); line += buf; } (void) hipEventDestroy(t.a); (void) hipEventDestroy(t.b); }
+        for (const graph_gpu_time & t : times) { float ms = 0.0f; if (hipEventElapsedTime(&ms, t.a, t.b) == hipSuccess) { char buf[64]; snprintf(buf, sizeof buf, " %d:%.2f", t.nodes, ms); line += buf; } (void) hipEventDestroy(t.a); (void) hipEventDestroy(t.b); }
         (void) hipGetLastError();
         log_msg(GGML_LOG_LEVEL_INFO, "[mi355x] %s: device time per graph (nodes:ms):%s\n", c->name.c_str(), line.c_str());
-        g_graph_times.clear();
     }
     if (getenv("MI355X_LOG_STATS"))
         log_msg(GGML_LOG_LEVEL_INFO, "[mi355x] %s: graphs eager=%ld captured=%ld replayed=%ld, kernels in last graph=%ld\n", c->name.c_str(),
@@ -342,7 +343,7 @@ static enum ggml_status be_graph_compute(ggml_backend_t b, struct ggml_cgraph * 
     HIP_CHECK(hipEventRecord(t.a, c->stream));
     const enum ggml_status st = graph_compute(c, g);
     HIP_CHECK(hipEventRecord(t.b, c->stream));
-    g_graph_times.push_back(t);
+    { std::lock_guard<std::recursive_mutex> lk(g_live_mu); g_graph_times.push_back(t); }
     return st;
 }
 static void be_graph_optimize(ggml_backend_t b, struct ggml_cgraph * g) { graph_optimize((backend_ctx *) b->context, g); }

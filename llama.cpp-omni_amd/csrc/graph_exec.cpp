@@ -416,6 +416,9 @@ static bool can_hoist(exec_state & s, int i, int j, const int * item, int n_item
     const ggml_tensor * nj = s.g->nodes[j];
     for (int k = 0; k < GGML_MAX_SRC; ++k) if (nj->src[k] != nj && !ready_before(s, nj->src[k], i, item, n_item)) return false;      // (ggml_cast names its result as its own src[1])
     const byte_range dj = range_of(nj);
+    // a copy that was left un-run (s.lazy) keeps READING its source until its last reader has run: ggml-alloc considers that source dead behind the CONT and may have placed
+    // nj's result on it -- writing it early would feed the lazy readers clobbered data.  The copies' own buffers count as written by whoever materialises them.
+    for (const auto & kv : s.lazy) if (overlap(dj, range_of(kv.second.src)) || overlap(dj, range_of(kv.first))) return false;
     for (int m = i + 1; m < j; ++m) {
         const ggml_tensor * nm = s.g->nodes[m];
         bool in_item = false;
@@ -2053,7 +2056,14 @@ static void compute_node(exec_state & s, int i) {
                     auto it = s.lazy.find(n->src[k]);
                     if (it != s.lazy.end() && it->second.deadline > i && n->type == GGML_TYPE_F32 && !overlap(range_of(n), range_of(it->second.src))) { sd[k] = it->second.src; lz[k] = n->src[k]; }
                 }
-                for (int k = 0; k < 2; ++k) if (lz[k]) s.lazy.erase(lz[k]);     // (taken in place: their one reader is this node)
+                // taken in place.  The entry goes only when this node was the copy's LAST reader: a cached-frames copy (lazy_try_register case A) is also read by the
+                // transposing CONT behind it -- dropped here, that reader would find no entry and copy from a buffer nobody wrote
+                for (int k = 0; k < 2; ++k) if (lz[k]) {
+                    bool other = false;
+                    auto us = s.users.find(lz[k]);
+                    if (us != s.users.end()) for (int u : us->second) if (u != i && u > i && !s.done[u]) other = true;
+                    if (!other) s.lazy.erase(lz[k]);
+                }
                 lazy_net(s, i);                                            // everything else this node reads, and the deadlines
             }
             prof_scope ps(s, "concat", 0);
@@ -2843,6 +2853,10 @@ static bool exec_concat_tail(exec_state & s, int i) {
     const int64_t f0 = (int64_t) (off_b / n2->nb[1]), keep = v->ne[1];
     if (f0 < P || f0 + keep > P + dt) return false;                                 // (kept frames that reach into the old cache: the nodes run as they are)
     if (overlap(range_of(n3), range_of(x))) return false;                           // the copy's buffer was placed for a point of the graph where x may be dead
+    // x itself (or what it is a view of) may be a copy that was left un-run (lazy_try_register accepts a CONCAT reader in either operand position): this matcher reads
+    // x->data directly and runs BEFORE lazy_net -- make such a copy real first
+    for (const ggml_tensor * t = x; t; t = (t->op == GGML_OP_RESHAPE || t->op == GGML_OP_VIEW || t->op == GGML_OP_PERMUTE || t->op == GGML_OP_TRANSPOSE) ? t->src[0] : nullptr)
+        if (s.lazy.count(t)) lazy_materialise(s, t, (int) GGML_OP_CONCAT);
     if (s.pr.A) materialise_reduce(s);
     if (s.prm.n) materialise_group(s);
     if (s.pn.m && s.pn.m == x) materialise_norm(s);

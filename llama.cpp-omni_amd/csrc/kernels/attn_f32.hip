@@ -141,9 +141,12 @@ __global__ void __launch_bounds__(256) k_attn_f32(const attn_f32_dev a) {
     }
 }
 
+// dynamic LDS of a launch: the 16 score rows of a workgroup, (nkv rounded up to 64) + 4 floats each.  A gfx950 workgroup owns at most 160 KiB, so the chain is taken
+// up to 2496 keys (refused beyond: the separate nodes run -- exec_attn_f32 falls back); 1 KiB is left for the kernel's static arrays
+static size_t attn_f32_lds_bytes(int64_t nkv) { return (size_t) 16 * (size_t) (((nkv + 63) / 64) * 64 + 4) * 4; }
 bool attn_f32_ok(const attn_f32_args & a) {
     static const bool off = getenv("MI355X_NO_ATTN_F32") != nullptr;
-    if (off || (a.D != 64 && a.D != 72 && a.D != 80 && a.D != 96 && a.D != 128) || a.nq < 1 || a.nkv < 1 || a.nkv > 4096 || a.HB < 1 || a.HB > 65535 || a.H < 1) return false;
+    if (off || (a.D != 64 && a.D != 72 && a.D != 80 && a.D != 96 && a.D != 128) || a.nq < 1 || a.nkv < 1 || attn_f32_lds_bytes(a.nkv) > 160 * 1024 - 1024 || a.HB < 1 || a.HB > 65535 || a.H < 1) return false;
     if ((((uintptr_t) a.q | a.q_rs | a.q_bs | (uintptr_t) a.k | a.k_rs | a.k_bs) & 15) != 0) return false;
     if ((a.q_H > 0 && ((a.q_bs2 & 15) != 0 || a.HB % a.q_H != 0)) || (a.k_H > 0 && ((a.k_bs2 & 15) != 0 || a.HB % a.k_H != 0))) return false;
     if (a.v_ks && ((a.v_ks & 3) != 0 || a.v_H < 1 || a.HB % a.v_H != 0 || (a.v_bs2 & 3) != 0)) return false;

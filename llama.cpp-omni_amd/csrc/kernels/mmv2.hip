@@ -28,8 +28,8 @@ namespace mi {
 // ================================================================================================= kernel
 // mv1_dev as in mmv1.hip, with wave_end = the first WORKGROUP past the matrix's range.  TM: bit0 = Q4_K body compiled in, bit1 = Q6_K.
 // NIT = K / 4096.  PAIR: m[0] = gate, W1 = up (same type / shape), epilogue silu(g) * u (Q4_K only).  NL loader waves, 16 - NL consumers.
-// The first ten arguments -- 14 dwords: what the loader and the row waves need to put their first requests out -- are marked for KERNARG PRELOAD
-// (-mllvm -amdgpu-kernarg-preload-count=10, csrc/Makefile): the command processor writes them into SGPRs at wave launch, so the launch's critical
+// The first ten arguments -- 14 dwords, no padding between them: what the loader and the row waves need to put their first requests out -- are marked for KERNARG PRELOAD
+// (-mllvm -amdgpu-kernarg-preload-count=14, csrc/Makefile; a hole in the pre-loaded region -- an int in front of a pointer -- faulted in round 6, keep pointers first): the command processor writes them into SGPRs at wave launch, so the launch's critical
 // waves do not begin with a ~0.3 us scalar-load round trip.  (Firmware without the feature runs the compiler's compatibility prologue: the same
 // loads, as before.)  Everything else (`rest`: destination pointers, the second and third matrix of a grouped launch, a ready-made image) is read
 // through the kernarg segment pointer where it is first needed -- never by name, or hipcc hoists its loads to the entry and every early
