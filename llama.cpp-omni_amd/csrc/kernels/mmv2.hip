@@ -25,6 +25,9 @@
 
 namespace mi {
 
+#ifndef MV2_BLOCK_LANE
+#define MV2_BLOCK_LANE 1
+#endif
 // ================================================================================================= kernel
 // mv1_dev as in mmv1.hip, with wave_end = the first WORKGROUP past the matrix's range.  TM: bit0 = Q4_K body compiled in, bit1 = Q6_K.
 // NIT = K / 4096.  PAIR: m[0] = gate, W1 = up (same type / shape), epilogue silu(g) * u (Q4_K only).  NL loader waves, 16 - NL consumers.
@@ -48,6 +51,10 @@ __global__ void __launch_bounds__(64 * NW) k_mv2(const char * W0, const float * 
     constexpr int XS = PARTS ? PBYTES + 512 - 32768 : 0;            // staging: the parts buffer + the fold's coefficient table instead of row + norm weights
     constexpr int RWN = PARTS ? MV2_PARTS_RW : RWK;                   // row waves (RWK: lab sweeps; 4 in the product)
     static_assert(RWN <= NW - 1, "row waves are consumers");
+    // Q4_K launches at K = 4096: one super-block per lane (mv2_consume_q4k_b); mixed / Q6_K / Q8_0 launches: the sub-block-pair form.  (K = 12288: a group of 4 rows is 12 of
+    // the ring's 29 slots and is released whole -- the loader stalls, ffn_down 7.6 -> 17.9 us; that launch is bound by its stream, not by the consumers' instructions.)
+    constexpr bool BL = MV2_BLOCK_LANE && (TM & 1) != 0 && TM != 4 + 1 && NIT == 1;      // (a mixed launch: its Q4_K workgroups)
+    constexpr int GRB = BL ? (PAIR ? 2 : 4) : 1;
     constexpr int C = NW - 1;
     constexpr int PW = 4 * NIT < C ? 4 * NIT : C;   // prologue waves
     typedef mv2_geo<2304, 1, NIT, XS> geo0;            // (IMG and STG do not depend on the weight type)
@@ -118,7 +125,7 @@ __global__ void __launch_bounds__(64 * NW) k_mv2(const char * W0, const float * 
         const size_t wbytes = (size_t) (G0 + ntask) * M.w_rs;      // (the workgroup's rows end here: nothing of the launch is requested past them)
         const mv1_rsrc rs0 = mv1_make_rsrc(M.W, wbytes), rs1 = mv1_make_rsrc(PAIR ? W1 : M.W, wbytes);
         if constexpr (Q80) mv2_loader<4352, PAIR ? 2 : 1, NIT, C, NT, XS, RWN>(rs0, rs1, (uint32_t) M.w_rs, G0, ntask * NIT, mv2_lds_addr(ringp), &F MV2_TR_ARG);
-        else if (q4) mv2_loader<2304, PAIR ? 2 : 1, NIT, C, NT, XS, RWN>(rs0, rs1, (uint32_t) M.w_rs, G0, ntask * NIT, mv2_lds_addr(ringp), &F MV2_TR_ARG);
+        else if (q4) mv2_loader<2304, PAIR ? 2 : 1, NIT, C, NT, XS, RWN, GRB>(rs0, rs1, (uint32_t) M.w_rs, G0, ntask * NIT, mv2_lds_addr(ringp), &F MV2_TR_ARG);
         else if constexpr ((TM & 2) != 0 && !PAIR) mv2_loader<3360, 1, NIT, C, NT, XS, RWN>(rs0, rs1, (uint32_t) M.w_rs, G0, ntask * NIT, mv2_lds_addr(ringp), &F MV2_TR_ARG);
         MV2_STAMP(7);
     } else {
@@ -139,7 +146,10 @@ __global__ void __launch_bounds__(64 * NW) k_mv2(const char * W0, const float * 
         MV2_STAMP(4);
         char * dst = R->m[mi_].dst;                        // (needed when the first results are stored)
         if constexpr (Q80) mv2_consume_q80<PAIR ? 2 : 1, NIT, C, PAIR>(im, ringp, K, c, ntask, dst, G0 + c, resid, &F);
-        else if (q4) mv2_consume_q4k<PAIR ? 2 : 1, NIT, C, PAIR, XS>(im, ringp, K, c, ntask, dst, G0 + c, resid, &F);
+        else if (q4) {
+            if constexpr (BL) mv2_consume_q4k_b<NIT, C, PAIR, XS>(im, ringp, K, c, ntask, dst, G0, rstg, resid_p != nullptr, &F);
+            else mv2_consume_q4k<PAIR ? 2 : 1, NIT, C, PAIR, XS>(im, ringp, K, c, ntask, dst, G0 + c, resid, &F);
+        }
         else if constexpr ((TM & 2) != 0 && !PAIR) mv2_consume_q6k<NIT, C, XS>(im, ringp, K, c, ntask, dst, G0 + c, resid, &F);
         MV2_STAMP(7);
     }
@@ -206,12 +216,21 @@ static void mv2_launch(const mv2_dev & d, int grid, hipStream_t st, const float 
     k_mv2<TM, NIT, PAIR, NT, NW, PARTS, RWK><<<dim3(grid), dim3(64 * NW), lds, st>>>(d.m[0].W, PARTS ? parts : (d.src.img ? nullptr : d.src.x), PARTS ? nullptr : d.src.nw, aux, d.m[0].w_rs, qr(0), qr(d.nmat > 1 ? 1 : 0), qr(d.nmat > 2 ? 2 : 0), d.src.eps, wgt, d);
 }
 
-// workgroup ranges of the matrices of a launch: by bytes, every matrix at least one workgroup
+// workgroup ranges of the matrices of a launch: by bytes -- a Q6_K matrix beside Q4_K ones counted MV2_Q6_SHARE times (its rows cost more instructions per byte and its
+// workgroups run the sub-block-pair consumer: the launch ended with them) --, every matrix at least one workgroup
+#ifndef MV2_Q6_SHARE
+#define MV2_Q6_SHARE 1.7                      // tools/mmv3_lab.hip, qkv with a Q6_K v: 1.0 6.46 us, 1.3 5.97, 1.6 5.95, 2.0 5.85, 2.5 6.59
+#endif
 static int mv2_plan(const mv1_args & a, mv2_dev & d, int & tm) {
     const int cus = mv2_cus();
     double bytes[3], total = 0; int64_t tasks = 0; tm = 0;
     for (int i = 0; i < a.nmat; ++i) {
         bytes[i] = (double) a.m[i].nrows * (double) (a.m[i].type == GGML_TYPE_Q4_K ? 144 : a.m[i].type == GGML_TYPE_Q6_K ? 210 : 272) * (double) (a.K / 256);
+#ifdef MV2_LAB_NW
+        { static const double q6w = getenv("MV2_Q6_WEIGHT") ? atof(getenv("MV2_Q6_WEIGHT")) : MV2_Q6_SHARE; if (a.nmat > 1 && a.m[i].type == GGML_TYPE_Q6_K) bytes[i] *= q6w; }
+#else
+        if (a.nmat > 1 && a.m[i].type == GGML_TYPE_Q6_K) bytes[i] *= MV2_Q6_SHARE;
+#endif
         total += bytes[i]; tasks += a.m[i].nrows;
         tm |= a.m[i].type == GGML_TYPE_Q4_K ? 1 : a.m[i].type == GGML_TYPE_Q6_K ? 2 : 4;
     }
@@ -239,10 +258,25 @@ void mmv2(const mv1_args & a, hipStream_t st) {
     const int grid = mv2_plan(a, d, tm);
     const bool pair = a.W_up != nullptr;
     // waves per workgroup (1 loader + the consumers), by launch shape: tools/mmv2_lab.hip sweep (profiles/r06_mv2_waves.txt).  The long pair launch keeps sixteen; the short
-    // ones run faster with fewer waves contending for the CU's issue slots through the prologue and the tail: the three-matrix group with twelve (6.4 -> 6.1 us), one
+    // ones run faster with fewer waves contending for the CU's issue slots through the prologue and the tail: the three-matrix group with twelve (6.4 -> 6.1 us; nine with
+    // the block-per-lane Q4_K consumer, whose groups of four rows need fewer consumers: 6.1 -> 5.55), one
     // matrix of a few thousand rows with ten (ffn_down Q4_K 8.1 -> 7.5, Q6_K 11.4 -> 9.6, wo 5.0 -> 4.8); the lm-head (hundreds of steps per workgroup) keeps sixteen
     static const bool nw16 = getenv("MI355X_MV2_NW16") != nullptr;                        // A/B: sixteen waves everywhere (the round-5 form)
     const bool small = !nw16 && a.nmat == 1 && a.m[0].nrows <= 16384;
+#ifdef MV2_LAB_NW       // lab builds (tools/mmv3_lab.hip: the dependent chain of a layer's four mat-vec launches): waves per workgroup by shape class from the environment
+    {
+        auto nw_env = [](const char * k, int dflt) { const char * e = getenv(k); return e ? atoi(e) : dflt; };
+        static const int nw_pair = nw_env("MV2_NW_PAIR", 16), nw_grp = nw_env("MV2_NW_GRP", 12), nw_s4 = nw_env("MV2_NW_SMALL4", 10), nw_s12 = nw_env("MV2_NW_SMALL12", 10);
+#define MV2_LAB_GO(TMv, NITv, PAIRv, nw) do { switch (nw) { case 9: mv2_launch<TMv, NITv, PAIRv, true, 9>(d, grid, st); break; case 10: mv2_launch<TMv, NITv, PAIRv, true, 10>(d, grid, st); break; \
+        case 12: mv2_launch<TMv, NITv, PAIRv, true, 12>(d, grid, st); break; case 13: mv2_launch<TMv, NITv, PAIRv, true, 13>(d, grid, st); break; default: mv2_launch<TMv, NITv, PAIRv, true, 16>(d, grid, st); } return; } while (0)
+        if (tm != 4 && !a.parts) {
+            if (pair) MV2_LAB_GO(1, 1, true, nw_pair);
+            if (a.K == 4096 && a.nmat > 1) { if (tm == 1) MV2_LAB_GO(1, 1, false, nw_grp); if (tm == 2) MV2_LAB_GO(2, 1, false, nw_grp); MV2_LAB_GO(3, 1, false, nw_grp); }
+            if (a.K == 4096 && small) { if (tm == 1) MV2_LAB_GO(1, 1, false, nw_s4); MV2_LAB_GO(2, 1, false, nw_s4); }
+            if (a.K == 12288 && small) { if (tm == 1) MV2_LAB_GO(1, 3, false, nw_s12); MV2_LAB_GO(2, 3, false, nw_s12); }
+        }
+    }
+#endif
     if (tm == 4) {                                                                           // Q8_0
         if (pair)              mv2_launch<4, 1, true, true>(d, grid, st);
         else if (a.K == 4096)  mv2_launch<4, 1, false, true>(d, grid, st);
@@ -257,9 +291,9 @@ void mmv2(const mv1_args & a, hipStream_t st) {
     }
     if (a.K == 4096) {
         if (a.nmat > 1 && !nw16) {
-            if (tm == 1)      mv2_launch<1, 1, false, true, 12>(d, grid, st);
+            if (tm == 1)      mv2_launch<1, 1, false, true, 9>(d, grid, st);
             else if (tm == 2) mv2_launch<2, 1, false, true, 12>(d, grid, st);
-            else              mv2_launch<3, 1, false, true, 12>(d, grid, st);
+            else              mv2_launch<3, 1, false, true, 9>(d, grid, st);
         } else if (small) {
             if (tm == 1)      mv2_launch<1, 1, false, true, 10>(d, grid, st);
             else              mv2_launch<2, 1, false, true, 10>(d, grid, st);

@@ -181,7 +181,7 @@ template <int VM, int K_> struct mv2_drain {            // at most K_ of my n st
         if constexpr (K_ > 0) mv2_drain<VM, K_ - 1>::go(n, landed);
     }
 };
-template <int PIECE, int R, int NIT, int C, bool NT, int XS = 0, int RWN = MV2_ROW_WAVES>
+template <int PIECE, int R, int NIT, int C, bool NT, int XS = 0, int RWN = MV2_ROW_WAVES, int GR = 1>
 static __device__ __forceinline__ void mv2_loader(const mv1_rsrc rs0, const mv1_rsrc rs1, uint32_t rs32, int G0, int T, uint32_t ring, mv2_flags * F MV2_TR_PARAM) {
     typedef mv2_geo<PIECE, R, NIT, XS> geo;
     constexpr int VM = geo::VM, D = geo::D, B = geo::B, SLOTB = geo::SLOTB, NS = geo::NS;
@@ -229,7 +229,7 @@ static __device__ __forceinline__ void mv2_loader(const mv1_rsrc rs0, const mv1_
                 { const uint32_t o = (uint32_t) __builtin_amdgcn_update_dpp(-1, (int) k, 0x4E, 0xf, 0xf, false);  k = __builtin_elementwise_min(k, o); }
                 { const uint32_t o = (uint32_t) __builtin_amdgcn_update_dpp(-1, (int) k, 0x141, 0xf, 0xf, false); k = __builtin_elementwise_min(k, o); }
                 { const uint32_t o = (uint32_t) __builtin_amdgcn_update_dpp(-1, (int) k, 0x140, 0xf, 0xf, false); k = __builtin_elementwise_min(k, o); }
-                free_tasks = (int) __builtin_amdgcn_readfirstlane(k);
+                free_tasks = (int) __builtin_amdgcn_readfirstlane(k) * GR;          // (GR > 1: consumers count GROUPS of GR rows, mv2_consume_q4k_b)
                 if (free_tasks < need) { __builtin_amdgcn_s_sleep(1); if (++spins > MV2_SPIN_MAX) __builtin_trap(); }
             }
             asm volatile("" ::: "memory");
@@ -608,6 +608,84 @@ static __device__ __forceinline__ void mv2_consume_q4k(const char * im, const ch
         if (++o.nres == 64) mv2_out_flush<C>(o, dst, row0, resid);
     }
     mv2_out_flush<C>(o, dst, row0, resid);
+}
+
+// ================================================================================================= Q4_K consumer, one super-block per LANE (round 6)
+// mv2_consume_q4k gives a (block, sub-block pair) to a lane: 64 lanes = the 16 blocks of ONE row's step, ~90 VALU instructions per row and step of which 40 are the
+// nibble unpack + dot4 -- the 6-bit scale unpack is repeated by the four lanes of a block, and every row pays a 64-lane sum (17 instructions with their DPP wait states).
+// Short launches are bound by exactly that instruction stream: their weights sit in the ring when the image is ready, and 16 .. 24 rows on a CU's four SIMDs took 0.7 ..
+// 1.6 us (tools/mmv2_lab.hip time lines; the same times with the weights resident in L2, MV2_NROT=1).  Here a lane takes a WHOLE super-block: GR = 4 rows per wave step
+// (lane = (row r of the group, block): a DPP row of 16 lanes is one row of the matrix) -- or GR = 2 row PAIRS (lane = (r, gate | up, block)) --, the scale unpack once per
+// block, ONE integer sum and one fma per block, and a 16-lane DPP-row sum that serves the four rows at once: ~54 instructions per row and step.  Same integers, same
+// products as the reference's vec_dot (quants.c:550-623); the float sums are taken in a different order (block sums exact in int32, then 16 per row).
+// Consumers count GROUPS (consumed[c] = groups read; the loader's free-slot rule multiplies by GR).  A group's rows are consecutive tasks: lane row j = g GR + r reads
+// ring slot (j NIT + it) % NS; rows past the workgroup's last task read a valid slot and are dropped.
+template <int NIT, int C, bool PAIR, int XS = 0>
+static __device__ __forceinline__ void mv2_consume_q4k_b(const char * im, const char * ringp, int K, int c, int ntask, char * dst, int G0, const char * rstg, bool has_resid, mv2_flags * F) {
+    constexpr int R = PAIR ? 2 : 1, GR = PAIR ? 2 : 4;
+    typedef mv2_geo<2304, R, NIT, XS> geo;
+    constexpr int SLOTB = geo::SLOTB, NS = geo::NS;
+    const int lane = threadIdx.x & 63, nb = K >> 8;
+    const int blk = lane & 15, r = PAIR ? lane >> 5 : lane >> 4, mat = PAIR ? (lane >> 4) & 1 : 0;
+    const int ng = (ntask + GR - 1) / GR;
+    uint32_t seen = 0;
+    int k = 0;
+    for (int g = c; g < ng; g += C, ++k) {
+        const int j = g * GR + r;                           // this lane's task (row, or gate / up row pair) of the workgroup
+        const bool valid = j < ntask;
+        const int jl = (g * GR + GR <= ntask ? g * GR + GR : ntask) - 1;        // the group's last existing task
+        float accv = 0.0f, accm = 0.0f;
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            mv2_wait_step(__builtin_amdgcn_readfirstlane(jl * NIT + it), seen, F);      // (steps land in order: the earlier rows' slices are in)
+            const int t = (valid ? j : jl) * NIT + it;
+            const int b0 = __builtin_amdgcn_readfirstlane((g * GR * NIT + it) % NS);    // slot of the group's first row; this lane's: + (t - first) , wrapped
+            int slot = b0 + (t - (g * GR * NIT + it));
+            if (slot >= NS) slot -= NS;
+            const char * p = ringp + slot * SLOTB + mat * 2304 + blk * 144;
+            const u32x4 H = *(const u32x4 *) p;
+            u32x4 Q[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) Q[e] = *(const u32x4 *) (p + 16 + 16 * e);
+            const int ib = it * 16 + blk;
+            const char * la = im + ib * 272;
+            const u32x4 bsv = *(const u32x4 *) (im + mv1_img_bs(nb) + ib * 16);            // bsums of the block's eight 32-element sub-blocks (int16)
+            const float yd = *(const float *) (im + mv1_img_d(nb) + ib * 4);
+            if (it == NIT - 1) { MV2_LGKM0(); mv2_poke(MV2_FLAG(F->consumed[c]), (uint32_t) (k + 1)); }      // the group's slots are in registers
+            // 6-bit scales / mins of the eight sub-blocks, one byte each (get_scale_min_k4, ggml-quants.c:703-710)
+            const uint32_t s_lo = H[1] & 0x3f3f3f3fu, s_hi = (H[3] & 0x0f0f0f0fu) | ((H[1] >> 2) & 0x30303030u);
+            const uint32_t m_lo = H[2] & 0x3f3f3f3fu, m_hi = ((H[3] >> 4) & 0x0f0f0f0fu) | ((H[2] >> 2) & 0x30303030u);
+            int isum = 0, msum = 0;
+#pragma unroll
+            for (int jg = 0; jg < 4; ++jg) {                // 64 weights: low nibbles = sub-block 2 jg, high nibbles = sub-block 2 jg + 1
+                const u32x4 a0 = *(const u32x4 *) (la + 64 * jg), a1 = *(const u32x4 *) (la + 64 * jg + 16), a2 = *(const u32x4 *) (la + 64 * jg + 32), a3 = *(const u32x4 *) (la + 64 * jg + 48);
+                int dl = 0, dh = 0;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    dl = dot4(Q[2 * jg][e] & 0x0f0f0f0fu, a0[e], dl); dh = dot4((Q[2 * jg][e] >> 4) & 0x0f0f0f0fu, a2[e], dh);
+                    dl = dot4(Q[2 * jg + 1][e] & 0x0f0f0f0fu, a1[e], dl); dh = dot4((Q[2 * jg + 1][e] >> 4) & 0x0f0f0f0fu, a3[e], dh);
+                }
+                const uint32_t sw = jg < 2 ? s_lo : s_hi, mw = jg < 2 ? m_lo : m_hi;
+                const int sh = 16 * (jg & 1);
+                const int sc0 = (int) ((sw >> sh) & 0xffu), sc1 = (int) ((sw >> (sh + 8)) & 0xffu), mn0 = (int) ((mw >> sh) & 0xffu), mn1 = (int) ((mw >> (sh + 8)) & 0xffu);
+                const uint32_t bw = bsv[jg];
+                isum = mad24(sc0, dl, mad24(sc1, dh, isum));
+                msum = mad24(mn0, (int) (int16_t) (bw & 0xffff), mad24(mn1, (int) (int16_t) (bw >> 16), msum));
+            }
+            const float dx = h2f((uint16_t) (H[0] & 0xffff)), dmin = h2f((uint16_t) (H[0] >> 16));
+            accv = fmaf(dx * yd, (float) isum, accv);
+            accm = fmaf(dmin * yd, (float) msum, accm);
+        }
+        float v = accv - accm;
+        v += __uint_as_float(mv2_dpp_row<0xB1>(__float_as_uint(v))); v += __uint_as_float(mv2_dpp_row<0x4E>(__float_as_uint(v)));
+        v += __uint_as_float(mv2_dpp_row<0x141>(__float_as_uint(v))); v += __uint_as_float(mv2_dpp_row<0x140>(__float_as_uint(v)));       // the 16 blocks of the row: every lane of the DPP row holds the sum
+        if constexpr (PAIR) {
+            const float o = __shfl_xor(v, 16, 64);              // gate rows (mat 0) receive up's sum
+            if (valid && mat == 0 && blk == 0) *(float *) (dst + (size_t) (G0 + j) * 4) = mv1_silu(v) * o;
+        } else {
+            if (valid && blk == 0) *(float *) (dst + (size_t) (G0 + j) * 4) = v + (has_resid ? *(const float *) (rstg + j * 4) : 0.0f);
+        }
+    }
 }
 
 // ================================================================================================= Q6_K consumer

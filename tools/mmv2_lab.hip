@@ -182,6 +182,7 @@ int main(int argc, char ** argv) {
         if (S.pair) total *= 2;
         const size_t stride = ((total + (1 << 20) - 1) >> 20) << 20;
         int nrot = (int) std::max<size_t>(1, std::min<size_t>(ARENA / stride, 64));
+        if (getenv("MV2_NROT")) nrot = std::max(1, std::min(nrot, atoi(getenv("MV2_NROT"))));      // 1: the same weights every launch (L2 / Infinity-Cache resident)
         const int N = total > (100u << 20) ? 8 : 48;
         printf("\n== %s : %.1f MB per launch, %d rotating weight sets\n", S.name, total / 1e6, nrot);
         auto wptr = [&](int s, int i, bool second) -> const char * {
@@ -276,6 +277,8 @@ int main(int argc, char ** argv) {
         VAR3(true, 12);
         VAR3(true, 10);
         VAR3(true, 9);
+        VAR3(true, 8);
+        VAR3(true, 6);
 #endif
     }
     return 0;
