@@ -371,6 +371,7 @@ int mi355x_set_option(struct ggml_backend * backend, const char * key, long valu
     if (!strcmp(key, "kq_staging")) { c->opt_kq_staging = value != 0; mi::drop_graph_execs(c); return 0; }
     if (!strcmp(key, "fattn_gqa")) { mi::fattn_set_gqa(value != 0); mi::drop_graph_execs(c); return 0; }
     if (!strcmp(key, "fattn_one")) { mi::fattn_set_one(value != 0); mi::drop_graph_execs(c); return 0; }
+    if (!strcmp(key, "fattn_gs")) { mi::fattn_set_gs((int) value); mi::drop_graph_execs(c); return 0; }       // (process-wide)
     if (!strcmp(key, "fattn_dma")) { mi::fattn_set_dma((int) value); mi::drop_graph_execs(c); return 0; }      // (process-wide)
     if (!strcmp(key, "f16_shadow")) { mi::shadow_set_enabled(value != 0); mi::drop_graph_execs(c); return 0; }
     if (!strcmp(key, "reset_stats")) { c->prof.clear(); c->stat_replays = c->stat_captures = c->stat_eager = 0; return 0; }
@@ -395,6 +396,7 @@ double mi355x_get_stat(struct ggml_backend * backend, const char * key) {
     if (!strcmp(key, "mmq_tile_launches"))  return (double) mi::mmq_tile_launches();
     if (!strcmp(key, "gemm_kq_launches"))   return (double) mi::gemm_variant_launches(3);
     if (!strcmp(key, "fattn_dma_launches")) return (double) mi::fattn_dma_launches();
+    if (!strcmp(key, "fattn_gs_launches"))  return (double) mi::fattn_gs_launches();
     if (!strncmp(key, "prof_", 5)) {
         std::string k(key + 5);
         const size_t us = k.rfind("_us"), nn = k.rfind("_n"), by = k.rfind("_bytes");

@@ -2269,8 +2269,7 @@ static void compute_node(exec_state & s, int i) {
                 one = true;
                 // ... as one workgroup per (KV head, 64-row slice) when the ONE reader of the rows is the next launching node, a batch-1 K-quant mat-vec the LDS-DMA engine
                 // takes (wo): the slices' partial states stay in fa_scratch and that launch folds them in its prologue (mv1_source) -- the f32 rows are never written
-                static const bool gs_off = getenv("MI355X_FA_NO_GS") != nullptr;
-                const int u = s.c->opt_fusion && !gs_off && !is_out(s, n) ? sole_user(s, n) : -1;
+                const int u = s.c->opt_fusion && !is_out(s, n) ? sole_user(s, n) : -1;        // (option "fattn_gs" / MI355X_FA_NO_GS: inside fattn_gs_ok)
                 if (u > i && next_real_node(s, i) == u && fattn_gs_ok(f) && s.c->fa_scratch && s.c->fa_scratch_bytes >= fattn_gs_parts_bytes((int) n->ne[1], D) && mmv2_enabled()) {
                     const ggml_tensor * c = g->nodes[u];
                     const ggml_tensor * x = c->op == GGML_OP_MUL_MAT ? c->src[1] : nullptr;

@@ -373,12 +373,17 @@ __global__ void __launch_bounds__(256) k_fattn_one(FA1_LEAD_PARAMS, const fa1_de
 constexpr int FGS_NSL = 4;                        // slices of the 256-row view
 constexpr int FGS_RS  = FA1_NKV / FGS_NSL;        // rows per slice
 constexpr int FGS_W   = 8;                        // waves per workgroup
+typedef const __attribute__((address_space(4))) char * fgs_kp;
+template <typename T> static __device__ __forceinline__ T fgs_ld(fgs_kp kp, size_t off) {      // a volatile scalar load of one kernel-argument field
+    typedef const volatile __attribute__((address_space(4))) T * P;
+    return *(P) (kp + off);
+}
 static __device__ __forceinline__ __amdgpu_buffer_rsrc_t fa1_rsrc_u(const void * p, int bytes) {      // wave-uniform by construction (an inline-asm "s" operand must be provably scalar)
     const uint64_t a = (uint64_t) (uintptr_t) p;
     const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t) a), hi = __builtin_amdgcn_readfirstlane((uint32_t) (a >> 32));
     return __builtin_amdgcn_make_buffer_rsrc((void *) (uintptr_t) (((uint64_t) hi << 32) | lo), (short) 0, __builtin_amdgcn_readfirstlane(bytes), 0x00020000);
 }
-#define FGS_LEAD_PARAMS const char * qraw_, const float * qw_, const float * tab_, const char * k_, int kraw_off_, int vraw_off_, int kw_off_, int v_off16_, int knb1_, uint32_t pk_      /* 14 dwords, no padding: pre-loaded */
+#define FGS_LEAD_PARAMS const char * qraw_, const float * qw_, const char * k_, int tab_off16_ /* (cos, sin) table - qraw, x 16 B */, int kidx_off8_ /* row index of the new token - qraw, x 8 B */, uint32_t kv_off16_ /* k | v raw rows: signed 16-bit offsets from qraw, x 16 B */, int mask_off16_ /* mask - qraw, x 16 B; 0: none */, int kw_off_, int v_off16_, float eps_, uint32_t pk_      /* 14 dwords, no padding: pre-loaded */
 template <int D>
 __global__ void __launch_bounds__(64 * FGS_W) k_fattn_gs(FGS_LEAD_PARAMS, const fa1_dev a) {
     static_assert(D == 128, "one 256-byte f16 row per (cache row, KV head)");
@@ -388,7 +393,11 @@ __global__ void __launch_bounds__(64 * FGS_W) k_fattn_gs(FGS_LEAD_PARAMS, const 
     __shared__ __attribute__((aligned(16))) uint16_t q16[GQ][D];
     FA1_STAMP_DECL; FA1_STAMP(0);
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int nkvh = (int) (pk_ & 0xffu), neox = (int) ((pk_ >> 8) & 1u), has_norm = (int) ((pk_ >> 9) & 1u), nkv_all = (int) (pk_ >> 16);
+    // pk_: [7:0] KV heads, [8] neox, [9] norm, [18:10] rows of the view (<= 256), [31:19] v's row index relative to k's, x 8 B (signed)
+    const int nkvh = (int) (pk_ & 0xffu), neox = (int) ((pk_ >> 8) & 1u), has_norm = (int) ((pk_ >> 9) & 1u), nkv_all = (int) ((pk_ >> 10) & 0x1ffu);
+    const float * tab_ = (const float *) (qraw_ + (int64_t) tab_off16_ * 16);
+    const int knb1_ = nkvh * D * 2;                               // cache rows hold the KV heads back to back (fattn_gs_ok); eps rides in the pre-loaded scalars instead: the
+                                                                  // chains then need nothing of the argument block (its scalar loads come back ~0.85 us into the launch)
     const int sp = __builtin_amdgcn_readfirstlane((int) blockIdx.x / nkvh), g = (int) blockIdx.x - sp * nkvh;        // workgroups of one KV head are congruent modulo the KV head count: one XCD's L2 serves the group
     const int row0 = sp * RS;
     const int nkv = nkv_all - row0 < RS ? (nkv_all - row0 > 0 ? nkv_all - row0 : 0) : RS;      // rows of this slice inside the view
@@ -411,8 +420,10 @@ __global__ void __launch_bounds__(64 * FGS_W) k_fattn_gs(FGS_LEAD_PARAMS, const 
             asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" :: "s"(__builtin_amdgcn_readfirstlane(vl + (uint32_t) j * 1024u)), "v"(vo), "s"(vrs), "s"(__builtin_amdgcn_readfirstlane((uint32_t) (4 * j) * (uint32_t) knb1_)) : "memory", "m0");
         }
     }
+    FA1_STAMP(4);
     // waves 0 .. 3: the q chain of head 4 g + wave; wave 4: the k chain; wave 5: the v head (elements lane, lane + 64)
     const int  e0 = neox ? lane : 2 * lane, e1 = neox ? lane + HALF : 2 * lane + 1;
+    const int kraw_off_ = (int) (int16_t) (kv_off16_ & 0xffffu) * 16, vraw_off_ = (int) (int16_t) (kv_off16_ >> 16) * 16;
     const char * xb = wave < GQ ? qraw_ + (g * GQ + wave) * (D * 4) : (wave == GQ ? qraw_ + kraw_off_ + g * (D * 4) : qraw_ + vraw_off_ + g * (D * 4));
     const __amdgpu_buffer_rsrc_t xrs = fa1_rsrc(xb, wave <= GQ + 1 ? D * 4 : 0);
     const uint32_t xo0 = wave <= GQ ? e0 * 4 : lane * 4, xo1 = wave <= GQ ? e1 * 4 : (lane + 64) * 4;
@@ -421,23 +432,26 @@ __global__ void __launch_bounds__(64 * FGS_W) k_fattn_gs(FGS_LEAD_PARAMS, const 
     const __amdgpu_buffer_rsrc_t trs = fa1_rsrc(tab_, wave <= GQ ? D * 4 : 0);
     const float w0 = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(wrs, xo0, 0, 0)), w1 = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(wrs, xo1, 0, 0));
     const u32x2 tcs = __builtin_amdgcn_raw_buffer_load_b64(trs, lane * 8, 0, 0);
+    // the mask row (one f16 row shared by the heads: fattn_gs_ok), lane = row of the slice, exact bounds (rows past the view are set to -inf in the soft-max): its address
+    // is pre-loaded too -- behind the argument block it would be requested 0.9 us into the launch and the soft-max would wait for it
+    const char * a_mask = mask_off16_ ? qraw_ + (int64_t) mask_off16_ * 16 : nullptr;
+    const __amdgpu_buffer_rsrc_t mrs = fa1_rsrc(a_mask ? a_mask + row0 * 2 : a_mask, (a_mask && wave < GQ) ? nkv * 2 : 0);
+    const uint16_t mraw = __builtin_amdgcn_raw_buffer_load_b16(mrs, lane * 2, 0, 0);
+    // ... and the new token's row index (k's and v's: scalar loads -- constant address space + a uniform address; the indices were written before the launch)
+    typedef const volatile __attribute__((address_space(4))) int * fgs_cint;
+    const char * kidx_p = qraw_ + (int64_t) kidx_off8_ * 8;
+    const int krow_u = *(fgs_cint) (uintptr_t) kidx_p, vrow_u = *(fgs_cint) (uintptr_t) (kidx_p + (int64_t) ((int32_t) pk_ >> 19) * 8);
     __builtin_amdgcn_sched_barrier(0);                             // (everything above needs only the pre-loaded arguments)
-    // from the argument block (one scalar round trip later): the new token's row index, as SCALAR buffer loads (every vector-memory request of the wave is counted by
-    // hand below)
-    // every field of the argument block the kernel uses, fetched NOW in one scalar burst (an empty statement that takes them as operands): left to the compiler each would
-    // be loaded where it is first used -- behind a barrier, one ~0.45 us round trip per phase (scores 1.1 us, soft-max 0.35, P.V 0.7 on the time line of tools/fa1_lab.hip)
-    const char * a_mask = a.mask; int a_mne2 = a.mne2, a_mnb2 = a.mnb2, a_nh = a.n_head, a_kc_rs = a.kc_rs, a_vc_rs = a.vc_rs; float a_scale = a.scale, a_eps = a.eps;
-    float * a_part = a.part; char * a_kcache = a.kcache, * a_vcache = a.vcache; const char * a_kidx = a.kidx, * a_vidx = a.vidx;
-    asm volatile("" : "+s"(a_mask), "+s"(a_mne2), "+s"(a_mnb2), "+s"(a_nh), "+s"(a_kc_rs), "+s"(a_vc_rs), "+s"(a_scale), "+s"(a_eps), "+s"(a_part), "+s"(a_kcache), "+s"(a_vcache), "+s"(a_kidx), "+s"(a_vidx));
-    typedef const volatile __attribute__((address_space(4))) int * fgs_cint;       // (constant address space + a uniform address: s_load_dword; volatile: requested HERE, waited for at the first use)
-    const int krow_u = *(fgs_cint) (uintptr_t) a_kidx, vrow_u = *(fgs_cint) (uintptr_t) a_vidx;
-    // the mask row of head 4 g + wave, lane = row of the slice (exact bounds; rows past the view are set to -inf below): requested now, used by the soft-max
-    uint16_t mraw = 0;
-    if (wave < GQ) {
-        const int hm = g * GQ + wave;
-        const __amdgpu_buffer_rsrc_t mrs = fa1_rsrc(a_mask ? a_mask + (hm % a_mne2) * a_mnb2 + row0 * 2 : a_mask, a_mask ? nkv * 2 : 0);
-        mraw = __builtin_amdgcn_raw_buffer_load_b16(mrs, lane * 2, 0, 0);
-    }
+    // Every field of the argument block the kernel uses is REQUESTED here (volatile scalar loads through the kernarg segment pointer: issued in program order, waited for
+    // at the first use) and none is used before barrier 1: the block's loads come back ~0.85 us into the launch, and the chains -- raw rows, norm weights, (cos, sin), eps:
+    // all behind pre-loaded scalars -- do not wait for them.  (Left to the compiler each field would be loaded where it is first used: one round trip per phase.)
+    const fgs_kp kp = (fgs_kp) __builtin_amdgcn_kernarg_segment_ptr() + 56;             // `a` behind the 14 pre-loaded dwords
+#define FGS_ARG(T, f) fgs_ld<T>(kp, offsetof(fa1_dev, f))
+    const int a_nh = FGS_ARG(int, n_head), a_kc_rs = FGS_ARG(int, kc_rs), a_vc_rs = FGS_ARG(int, vc_rs);
+    const float a_scale = FGS_ARG(float, scale);
+    float * a_part = FGS_ARG(float *, part); char * a_kcache = FGS_ARG(char *, kcache), * a_vcache = FGS_ARG(char *, vcache);
+#undef FGS_ARG
+    (void) a;
     __builtin_amdgcn_sched_barrier(0);
     FA1_STAMP(1);
     // ---------------------------------------------------------------- 2. q chains, k chain, v head (norm_rope_dev.hpp arithmetic); the cache stores wait for the row index (end of the kernel)
@@ -447,7 +461,7 @@ __global__ void __launch_bounds__(64 * FGS_W) k_fattn_gs(FGS_LEAD_PARAMS, const 
         double ss = (double) (x0 * x0) + (double) (x1 * x1);
         ss = wave_sum_f64o(ss);
         const float mean  = (float) (ss * (1.0 / D));
-        const float scale = 1.0f / sqrtf(mean + a_eps);
+        const float scale = 1.0f / sqrtf(mean + eps_);
         const float v0 = has_norm ? (x0 * scale) * w0 : x0, v1 = has_norm ? (x1 * scale) * w1 : x1;
         const float r0 = v0 * tc - v1 * ts, r1 = v0 * ts + v1 * tc;
         hs0 = f2h(r0); hs1 = f2h(r1);
@@ -835,18 +849,32 @@ void flash_attn_one(const fa_dev & f, int D, const float * rope_tab, hipStream_t
 // ---- group-slice form: applicability and launch.  parts: FGS_NSL x [n_head * D] partial outputs, then FGS_NSL x [n_head] x (M, S)
 size_t fattn_gs_parts_bytes(int n_head, int D) { return (size_t) FGS_NSL * n_head * D * 4 + (size_t) FGS_NSL * n_head * 2 * 4; }
 int    fattn_gs_nslice() { return FGS_NSL; }
+static int  g_gs_mode = -1;                          // option "fattn_gs": -1 = MI355X_FA_NO_GS decides (default on), 0 off, 1 on
+static long g_gs_launches = 0;
+void fattn_set_gs(int m) { g_gs_mode = m; }
+long fattn_gs_launches() { return g_gs_launches; }
 bool fattn_gs_ok(const fattn_args & f) {
     static const bool env_off = getenv("MI355X_FA_NO_GS") != nullptr;
-    if (env_off || !fattn_one_ok(f)) return false;
+    if (!(g_gs_mode >= 0 ? g_gs_mode != 0 : !env_off) || !fattn_one_ok(f)) return false;
     const fattn_pre & P = *f.pre;
     const int64_t D = f.q.ne[0], nh = f.q.ne[2], nkvh = f.k.ne[2];
     if (D != 128 || nkvh < 1 || nkvh > 255 || nh != 4 * nkvh || f.k.ne[1] > FA1_NKV || f.sinks || f.max_bias != 0.0f || f.logit_softcap != 0.0f) return false;
-    if (P.q_hs != D * 4 || P.k_hs != D * 4 || P.v_hs != D * 4 || f.k.nb[2] != (size_t) D * 2 || f.v.nb[2] != (size_t) D * 2 || f.k.nb[1] != f.v.nb[1] || f.k.nb[1] > 0x7fffff) return false;
+    if (P.q_hs != D * 4 || P.k_hs != D * 4 || P.v_hs != D * 4 || f.k.nb[2] != (size_t) D * 2 || f.v.nb[2] != (size_t) D * 2 || f.k.nb[1] != f.v.nb[1] || f.k.nb[1] != (size_t) nkvh * D * 2) return false;
     if (((uintptr_t) P.qraw & 15) != 0 || ((uintptr_t) P.kraw & 15) != 0 || ((uintptr_t) P.vraw & 15) != 0 || ((uintptr_t) f.k.p & 15) != 0 || ((uintptr_t) f.v.p & 15) != 0) return false;
     if (f.mask && ((((uintptr_t) f.mask->p) & 3) != 0 || f.mask->nb[2] % 4 != 0)) return false;
     const int64_t ko = (const char *) P.kraw - (const char *) P.qraw, vo = (const char *) P.vraw - (const char *) P.qraw, vco = ((const char *) f.v.p - (const char *) f.k.p) / 16;
-    if (ko != (int64_t) (int32_t) ko || vo != (int64_t) (int32_t) vo || vco != (int64_t) (int32_t) vco) return false;
+    if (ko / 16 != (int64_t) (int16_t) (ko / 16) || vo / 16 != (int64_t) (int16_t) (vo / 16) || vco != (int64_t) (int32_t) vco) return false;     // (k / v rows within +-512 KB of q's: ggml-alloc places the three results side by side)
+    if (f.mask) {                                                    // one mask row for every head, 16-byte aligned, within +-32 GB of the q rows
+        const int64_t mo = (const char *) f.mask->p - (const char *) P.qraw;
+        if (f.mask->ne[2] != 1 || (((uintptr_t) f.mask->p) & 15) != 0 || mo == 0 || mo / 16 != (int64_t) (int32_t) (mo / 16)) return false;
+    }
     if (P.qw) { const int64_t wo = (const char *) P.kw - (const char *) P.qw; if (!P.kw || wo != (int64_t) (int32_t) wo) return false; }
+    {   // the (cos, sin) table and the new token's row indices are reached through pre-loaded offsets from the q rows: the table 16-byte units, k's index 8-byte units, v's index
+        // within +-32 KB of k's (the two index tensors are graph inputs allocated side by side)
+        if (!f.rope_tab || !P.kidx || !P.vidx) return false;
+        const int64_t to = (const char *) f.rope_tab - (const char *) P.qraw, io = (const char *) P.kidx - (const char *) P.qraw, vi = (const char *) P.vidx - (const char *) P.kidx;
+        if ((to & 15) != 0 || to / 16 != (int64_t) (int32_t) (to / 16) || (io & 7) != 0 || io / 8 != (int64_t) (int32_t) (io / 8) || (vi & 7) != 0 || vi / 8 < -4096 || vi / 8 > 4095) return false;
+    }
     return true;
 }
 void flash_attn_gs(const fa_dev & f, int D, const float * rope_tab, float * parts, hipStream_t st) {
@@ -863,9 +891,11 @@ void flash_attn_gs(const fa_dev & f, int D, const float * rope_tab, float * part
     a.eps = P.eps; a.scale = f.scale; a.max_bias = 0.0f; a.logit_softcap = 0.0f; a.m0 = 1.0f; a.m1 = 1.0f;
     a.n_head = f.nh; a.nkvh_log2 = -1;
     const int nkvh = f.nh / 4;
-    const uint32_t pk = (uint32_t) nkvh | ((uint32_t) a.neox << 8) | ((uint32_t) a.has_norm << 9) | ((uint32_t) f.nkv << 16);
-    k_fattn_gs<128><<<dim3((unsigned) (nkvh * FGS_NSL)), dim3(64 * FGS_W), 0, st>>>(a.qraw, a.qw, a.tab, a.k, (int) (a.kraw - a.qraw), (int) (a.vraw - a.qraw), a.qw ? (int) ((const char *) a.kw - (const char *) a.qw) : 0,
-                                                                                      (int) ((a.v - a.k) / 16), a.knb1, pk, a);
+    const uint32_t pk = (uint32_t) nkvh | ((uint32_t) a.neox << 8) | ((uint32_t) a.has_norm << 9) | ((uint32_t) f.nkv << 10) | ((uint32_t) (int32_t) ((a.vidx - a.kidx) / 8) << 19);
+    ++g_gs_launches;
+    const uint32_t kv16 = (uint32_t) (uint16_t) (int16_t) ((a.kraw - a.qraw) / 16) | ((uint32_t) (uint16_t) (int16_t) ((a.vraw - a.qraw) / 16) << 16);
+    k_fattn_gs<128><<<dim3((unsigned) (nkvh * FGS_NSL)), dim3(64 * FGS_W), 0, st>>>(a.qraw, a.qw, a.k, (int) (((const char *) a.tab - a.qraw) / 16), (int) ((a.kidx - a.qraw) / 8), kv16, a.mask ? (int) ((a.mask - a.qraw) / 16) : 0, a.qw ? (int) ((const char *) a.kw - (const char *) a.qw) : 0,
+                                                                                      (int) ((a.v - a.k) / 16), a.eps, pk, a);
 }
 // the slices' partial states folded into the f32 rows [n_head * D] (what the wo launch does in its prologue; used when that launch cannot take the parts)
 __global__ void k_fattn_gs_merge(const float * parts, float * dst, int n_head, int D) {

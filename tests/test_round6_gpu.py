@@ -1,0 +1,108 @@
+"""Round 6 (-m gpu, through the C-ABI): the decode changes -- one-token attention as one workgroup per (KV head, 64-row slice) whose partial states the wo
+mat-vec launch folds in its prologue (fattn_one.hip k_fattn_gs, mmv2.hip PARTS), the block-per-lane Q4_K consumer and the per-shape wave counts of the
+LDS-DMA engine -- against the reference CPU backend (oracle/_ref) and against the round-5 forms of the same launches (options `fattn_gs`, `mv2`)."""
+import numpy as np
+import pytest
+
+from conftest import nmse
+
+pytestmark = pytest.mark.gpu
+
+# Qwen3-8B's attention / ffn widths (K = 4096 = 32 heads x 128, four query heads per KV head: what fattn_gs_ok asks for), two layers, a small vocabulary
+CFG = dict(n_embd=4096, n_layer=2, n_head=32, n_head_kv=8, head_dim=128, n_ff=12288, n_vocab=512, rms_eps=1e-6, rope_base=1e6, n_ctx_orig=4096)
+
+
+def _decode(pkg, backend, steps, embd, n_kv=256, seed=4):
+    from llama_cpp_omni_amd import qwen3
+    mdl = qwen3.Model(backend, CFG, qwen3.q4_k_m_types(CFG), n_ctx=n_kv, seed=seed, flash_attn=True)
+    g1, I1, logits1 = mdl.build(1, n_kv)
+    gr = g1.graph()
+    ls = []
+    for k in range(steps):                                             # (second submission onwards: hipGraph replay on the device backend)
+        mdl.set_inputs(I1, embd[k:k + 1], k, n_kv)
+        backend.graph_compute(gr)
+        ls.append(backend.tensor_get(logits1).copy())
+    g1.free(); mdl.wctx.free()
+    return np.stack(ls)
+
+
+def test_group_slice_attention_with_the_fold_in_wo_vs_reference_and_vs_the_per_head_kernel(pkg, be, ref_be):
+    """70 decode steps from an empty cache (positions 0 .. 69: the new token's row moves through slice 0 into slice 1; slices 2 and 3 of the 256-row view stay
+    empty: M = -inf, S = 0): logits of the group-slice attention + PARTS wo launch against (a) the reference CPU backend on the same graphs and (b) the
+    round-5 launches (one workgroup per head, plain wo) on the same backend.  (a) carries the documented deviation of flash-attention on this backend
+    (V accumulated in f32, reference f16) through two layers; (b) differs only in the order of float sums."""
+    steps = 70
+    rng = np.random.default_rng(61)
+    embd = rng.standard_normal((steps, CFG["n_embd"])).astype(np.float32)
+    n0 = be.get_stat("fattn_gs_launches")
+    be.set_option("fattn_gs", 1)
+    try:
+        lg = _decode(pkg, be, steps, embd)
+        n1 = be.get_stat("fattn_gs_launches")
+        assert n1 - n0 >= CFG["n_layer"] * 1, (n0, n1)                   # the path ran (captured launches are counted once, at capture)
+        be.set_option("fattn_gs", 0)
+        lo = _decode(pkg, be, steps, embd)
+        assert be.get_stat("fattn_gs_launches") == n1                   # ... and the option switches it off
+    finally:
+        be.set_option("fattn_gs", -1)
+    lr = _decode(pkg, ref_be, steps, embd)
+    assert np.isfinite(lg).all()
+    e_old = nmse(lg, lo)
+    e_ref, e_ref_old = nmse(lg, lr), nmse(lo, lr)
+    print(f"group-slice vs per-head kernel {e_old:.1e}; vs reference {e_ref:.1e} (per-head kernel vs reference {e_ref_old:.1e})")
+    assert e_old < 1e-4, e_old                                          # (a re-ordered float sum can move a Q8_K activation across a rounding step: cf. test_8b_layer_by_layer)
+    assert e_ref < 2e-3 and e_ref < 3.0 * e_ref_old + 1e-5, (e_ref, e_ref_old)
+    for t in (0, 1, 63, 64, 65, 69):                                    # per step, at the slice boundary too
+        assert nmse(lg[t], lr[t]) < 5e-3, (t, nmse(lg[t], lr[t]))
+        assert nmse(lg[t], lo[t]) < 5e-4, (t, nmse(lg[t], lo[t]))
+    same = int((lg.argmax(-1) == lr.argmax(-1)).sum())
+    assert same >= int(0.9 * steps), same
+
+
+def test_attention_rows_are_materialised_when_the_reader_is_not_a_fold_capable_launch(pkg, be, ref_be):
+    """The same decode graphs with the engine switched off (option mv2 = 0: no PARTS launch exists to fold the slices) -- the executor must not leave the
+    attention rows as partial states: the per-head kernel runs and fattn_gs_launches stays put.  Against the reference CPU backend and against the engine-on run."""
+    steps = 3
+    rng = np.random.default_rng(62)
+    embd = rng.standard_normal((steps, CFG["n_embd"])).astype(np.float32)
+    be.set_option("mv2", 0)
+    try:
+        n0 = be.get_stat("fattn_gs_launches")
+        l0 = _decode(pkg, be, steps, embd, seed=5)
+        assert be.get_stat("fattn_gs_launches") == n0                   # wo cannot fold: the attention launch does not leave slices
+    finally:
+        be.set_option("mv2", 1)
+    l1 = _decode(pkg, be, steps, embd, seed=5)
+    lr = _decode(pkg, ref_be, steps, embd, seed=5)
+    assert nmse(l0, lr) < 2e-3 and nmse(l1, lr) < 2e-3, (nmse(l0, lr), nmse(l1, lr))
+    assert nmse(l0, l1) < 1e-4, nmse(l0, l1)
+
+
+@pytest.mark.parametrize("vtype", ["q4_k", "q6_k"])
+def test_grouped_qkv_launch_with_packed_descriptors_and_block_per_lane_consumer_vs_oracle(pkg, be, vtype):
+    """wq / wk / wv of a decode layer as ONE launch behind RMS_NORM + MUL: the k / v workgroups take their matrix from the pre-loaded scalars (32-bit offsets
+    from wq), Q4_K workgroups run the block-per-lane consumer (groups of four rows, also the ragged last group: 4096 / 1024 rows over 256 workgroups by bytes give
+    23 .. 25 rows each), a Q6_K v counts 1.7 x its bytes in the split.  Every row against the oracle's vec_dot on the oracle's Q8_K image (NMSE 1e-9: the same
+    integers, another order of the float sums); one launch for the six nodes."""
+    from oracle import oracle_py as orc
+    from llama_cpp_omni_amd import qwen3
+    from test_gpu_parity import run_graph
+    rng = np.random.default_rng(7)
+    K = 4096
+    rows = [4096, 1024, 1024]
+    types = [pkg.GGML_TYPE_Q4_K, pkg.GGML_TYPE_Q4_K, pkg.GGML_TYPE_Q4_K if vtype == "q4_k" else pkg.GGML_TYPE_Q6_K]
+    x = (rng.standard_normal((1, K)) * 1.5).astype(np.float32)
+    x[0, 512:768] = 0.0                                                 # an all-zero Q8_K block
+    nw = (1.0 + 0.1 * rng.standard_normal(K)).astype(np.float32)
+    wvs = [qwen3.random_blocks(rng, t, m, K, std=0.05) for t, m in zip(types, rows)]
+    c = pkg.Context(be)
+    ws = [c.new_tensor(t, K, m) for t, m in zip(types, rows)]
+    xt = c.new_tensor(pkg.GGML_TYPE_F32, K, 1); nt = c.new_tensor(pkg.GGML_TYPE_F32, K)
+    xn = c.mul(c.rms_norm(xt, 1e-6), nt)
+    ys = [c.mul_mat(w, xn) for w in ws]
+    res = run_graph(be, c, ys, list(zip(ws, wvs)) + [(xt, x), (nt, nw)])
+    assert be.get_stat("kernels_last_graph") == 1
+    xn_ref = (orc.rms_norm(x, 1e-6) * nw).astype(np.float32)
+    for i, (t, m) in enumerate(zip(types, rows)):
+        want = orc.mul_mat(t, wvs[i].view(np.uint8).reshape(m, -1), xn_ref)
+        assert nmse(res[i], want) < 1e-9, (i, nmse(res[i], want))

@@ -84,8 +84,8 @@ int main(int argc, char ** argv) {
     if (getenv("FA1_PTRS")) fprintf(stderr, "qkv %p qw %p kw %p tab %p dst %p kc %p vc %p mask %p idx %p parts %p (%zu B) dst2 %p\n", qkv, qw, kw, tab, dst, kc, vc, mask, idx, parts, fattn_gs_parts_bytes(NH, D), dst2);
     auto gs = [&](int s) {
         fa1_dev a = args(s % NL); a.nsplit = FGS_NSL; a.part = parts;
-        const uint32_t pk = (uint32_t) NKVH | (1u << 8) | (1u << 9) | ((uint32_t) nkv << 16);
-        k_fattn_gs<128><<<dim3(NKVH * FGS_NSL), dim3(64 * FGS_W), 0, st>>>(a.qraw, a.qw, a.tab, a.k, (int) (a.kraw - a.qraw), (int) (a.vraw - a.qraw), (int) ((const char *) a.kw - (const char *) a.qw), (int) ((a.v - a.k) / 16), a.knb1, pk, a);
+        const uint32_t pk = (uint32_t) NKVH | (1u << 8) | (1u << 9) | ((uint32_t) nkv << 10) | ((uint32_t) (int32_t) ((a.vidx - a.kidx) / 8) << 19);
+        k_fattn_gs<128><<<dim3(NKVH * FGS_NSL), dim3(64 * FGS_W), 0, st>>>(a.qraw, a.qw, a.k, (int) (((const char *) a.tab - a.qraw) / 16), (int) ((a.kidx - a.qraw) / 8), (uint32_t) (uint16_t) (int16_t) ((a.kraw - a.qraw) / 16) | ((uint32_t) (uint16_t) (int16_t) ((a.vraw - a.qraw) / 16) << 16), (int) ((a.mask - a.qraw) / 16), (int) ((const char *) a.kw - (const char *) a.qw), (int) ((a.v - a.k) / 16), a.eps, pk, a);
     };
     {   // result check: the group-slice form + merge against the one-workgroup-per-head form, same cache (the new rows are written by both: identical values)
         k_producer<<<256, 256, 0, st>>>(qkv, 5); attn(3); HIP_CHECK(hipStreamSynchronize(st)); fprintf(stderr, "one-per-head form ran\n");
@@ -126,7 +126,7 @@ int main(int argc, char ** argv) {
         std::vector<unsigned long long> hg(nwv * 8);
         HIP_CHECK(hipMemcpy(hg.data(), trace_dev, hg.size() * 8, hipMemcpyDeviceToHost));
         unsigned long long tg = ~0ull; for (size_t w = 0; w < nwv; ++w) if (hg[w * 8]) tg = std::min(tg, hg[w * 8]);
-        static const char * labg[8] = { "start", "K / V DMA + every load requested", "chains done", "past barrier 1 (K / V tiles landed)", "scores done, past barrier 2", "soft-max done, past barrier 3", "P.V done, past barrier 4", "end (partial state stored)" };
+        static const char * labg[8] = { "start", "K / V DMA + every load requested", "chains done", "past barrier 1 (K / V tiles landed)", "K / V DMA issued (slot 4)", "soft-max done, past barrier 3", "P.V done, past barrier 4", "end (partial state stored)" };
         printf("   group-slice form, time line (us after the first wave's start; min / median / max over the %d waves)\n", (int) nwv);
         for (int i = 0; i < 8; ++i) {
             std::vector<double> v; for (size_t w = 0; w < nwv; ++w) if (hg[w * 8 + i]) v.push_back((double) (hg[w * 8 + i] - tg) * 0.01);
