@@ -164,6 +164,20 @@ def _cpu_baseline_worker(pkg, cfg, types, n_kv, th, seconds):
     return {"tok_s": n / dt if n else 1.0 / pilot, "steps": n, "wbytes": wbytes, "build": ref_variant()[0]}
 
 
+def _cgroup_cpu_quota():
+    """CPUs' worth of time the container's cgroup grants this process (cpu.max of cgroup v2, cfs_quota / cfs_period of v1), None when unlimited or unreadable:
+    a team wider than the quota is throttled, whatever sched_getaffinity says."""
+    try:
+        here = "/sys/fs/cgroup"
+        if os.path.exists(here + "/cpu.max"):
+            q, per = open(here + "/cpu.max").read().split()[:2]
+            return None if q == "max" else round(int(q) / int(per), 2)
+        q = int(open(here + "/cpu/cpu.cfs_quota_us").read()); per = int(open(here + "/cpu/cpu.cfs_period_us").read())
+        return None if q <= 0 else round(q / per, 2)
+    except Exception:
+        return None
+
+
 def cpu_baseline(pkg, cfg, types, n_kv, seconds_budget=24.0, tiny=False):
     """Reference CPU backend (oracle/_ref, built from /root/reference sources) on the SAME decode graph, timed on this box's host
     cores for a bounded sample.  Thread counts come from the cores this process may actually run on (sched_getaffinity: a cgroup /
@@ -183,7 +197,11 @@ def cpu_baseline(pkg, cfg, types, n_kv, seconds_budget=24.0, tiny=False):
         n_phys = topo["physical_cores"]
         per_node = max(1, n_phys // max(1, topo["nodes"]))
         pin = os.environ.get("MI355X_CPU_BASELINE_NO_PIN") is None
+        quota = _cgroup_cpu_quota()
         cands = sorted({c for c in (8, 16, 24, 32, 48, 64, per_node, n_phys) if 1 <= c <= n_phys})
+        if quota is not None:                                      # the sweep still runs past the quota once (the line shows the throttled point), not beyond
+            lim = max(1, int(quota))
+            cands = sorted({c for c in cands if c <= lim} | {min(lim, n_phys)} | ({min(c for c in cands if c > lim)} if any(c > lim for c in cands) else set()))
         results, build, wbytes = [], None, None
         t_start = time.perf_counter()
         for th in cands:
@@ -217,7 +235,9 @@ def cpu_baseline(pkg, cfg, types, n_kv, seconds_budget=24.0, tiny=False):
                 v3 = round(json.loads(r.stdout.strip().splitlines()[-1])["tok_s"], 3)
         return {"value": round(best[0], 3), "unit": "tok/s", "cores": best[1], "kind": "reference", "value_x86_64_v3_build": v3,
                 "gb_per_s": round(best[0] * wbytes / 1e9, 1) if wbytes else None,
-                "allowed_cpus": n_aff, "physical_cores_allowed": n_phys,
+                "allowed_cpus": n_aff, "physical_cores_allowed": n_phys, "cgroup_cpu_quota": quota,
+                "cgroup_note": ("no cgroup CPU quota: the thread sweep is limited by the affinity mask only" if quota is None else
+                                f"the cgroup grants {quota} CPUs' worth of time: teams wider than that are throttled (the sweep's falling tail), so this baseline is the container's, not the host's"),
                 "thread_sweep_tok_s": {str(th): round(v, 3) for v, th, _ in results},
                 "build": build, "placement": ("one pinned thread per CPU (OMP_PLACES): one per physical core, home NUMA node first, round-robin over its L3 domains" if pin else "unpinned"), "topology": topo,
                 "sample": f"{best[2]} decode steps of the same Qwen3-8B Q4_K_M graph on the reference ggml CPU backend (oracle/_ref, {build} build, "
