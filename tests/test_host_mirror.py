@@ -104,3 +104,24 @@ def test_bench_replica_logic_world2_gloo(tmp_path):
     dt = float(line[2])
     assert 0.2 <= dt < 0.5                                        # MAX over ranks: the slow rank's 5 x 0.04 s, not rank 0's 5 x 0.02 s
     assert abs(float(line[1]) - 2 * 5 / dt) < 1e-6                # whole-job aggregate = units of all ranks / max time
+
+
+def test_omni_runtime_device_map_uses_the_reference_knobs():
+    """tools/omni_runtime.sh --map ... --print: one module per GPU translated to the reference runtime's own knobs and nothing else -- common_params.main_gpu / split_mode
+    (common/arg.cpp:2906, 2955) for the LLM, MTMD_BACKEND_DEVICE (audition.cpp:241), Omni_BACKEND_DEVICE (vision.cpp:201), omni_init's token2wav_device
+    (omni.cpp:3775); a TTS device that differs from the LLM's is refused with a pointer to the maintainer patch (omni.cpp:3457 loads it with the LLM's params)."""
+    import os, subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sh = os.path.join(root, "tools", "omni_runtime.sh")
+    r = subprocess.run(["bash", sh, "--map", "llm=0,tts=1,t2w=2,apm=3,vpm=4", "--print", "16", "2", "omni"], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0, r.stderr
+    line = r.stdout.strip().splitlines()[-1]
+    assert " -mg 0 -sm none " in line and "--t2w-device gpu:2" in line and "MTMD_BACKEND_DEVICE=MI355X3" in line and "Omni_BACKEND_DEVICE=MI355X4" in line, line
+    assert "--test case/audio_ 2" in line and "--max-tgt 16" in line and line.rstrip().endswith("--omni"), line
+    assert "GGML_BACKEND_PATH=" in line and "libggml-mi355x.so" in line
+    assert "tts=1 ignored" in r.stderr and "omni.cpp:3457" in r.stderr
+    r = subprocess.run(["bash", sh, "--print"], capture_output=True, text=True, timeout=60)                # no map: the one-GPU form, unchanged
+    line = r.stdout.strip().splitlines()[-1]
+    assert "-mg" not in line and "BACKEND_DEVICE" not in line and "--t2w-device gpu:0" in line, line
+    r = subprocess.run(["bash", sh, "--map", "dsp=1", "--print"], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 2 and "unknown module" in r.stderr

@@ -98,3 +98,31 @@ def test_reference_omni_runtime_drives_the_plugin(tmp_path):
         print("omni runtime on the plug-in:", json.dumps(j))
     finally:
         shutil.rmtree(root, ignore_errors=True)
+
+
+def test_pinned_form_one_module_per_gpu_through_the_reference_knobs(tmp_path):
+    """BASELINE C4 / C5's pinned form with the reference runtime as caller: tools/omni_runtime.sh --map puts the LLM (+ TTS: omni.cpp:3457 loads it with the LLM's
+    common_params) on device 0 and the audio encoder, the image encoder and Token2Wav's flow model on device 1, spelled with the reference's own knobs (-mg / -sm none,
+    MTMD_BACKEND_DEVICE, Omni_BACKEND_DEVICE, --t2w-device gpu:1).  Needs two MI355X: skipped on the one-GPU boxes this round's tests ran on (the translation itself is
+    covered without a GPU by tests/test_host_mirror.py::test_omni_runtime_device_map_uses_the_reference_knobs)."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two MI355X")
+    if not os.path.exists(BIN):
+        pytest.skip("oracle/_ref/omni-min not built (make -f oracle/Makefile.ref omnirt)")
+    if shutil.disk_usage(str(tmp_path)).free < 9e9:
+        pytest.skip("needs 7 GB of scratch disk for the synthetic module set")
+    root = str(tmp_path / "set")
+    env = dict(os.environ, OMNI_SET=root)
+    try:
+        r = subprocess.run(["bash", os.path.join(ROOT, "tools", "omni_runtime.sh"), "--map", "llm=0,t2w=1,apm=1,vpm=1", "24", "2", "omni"], env=env, capture_output=True, text=True, timeout=3000)
+        assert r.returncode == 0 and "pass 2 exit 0" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
+        log = open(os.path.join(ROOT, "gpurun_out", "omni_runtime_pass2.log"), errors="replace").read()
+        assert "init_backend device=gpu:1, gpu_idx=1, backend=MI355X1" in log                                # Token2Wav's flow model on the second device
+        m = re.search(r"vision using (\S+) backend", log)
+        assert m and m.group(1).startswith("MI355X1"), m and m.group(0)
+        assert len(re.findall(r"offloaded 37/37 layers to GPU", log)) >= 1 and len(re.findall(r"offloaded 21/21 layers to GPU", log)) >= 1
+        used = {d for d, a, b, c in re.findall(r"\[mi355x\] (MI355X\d): graphs eager=(\d+) captured=(\d+) replayed=(\d+)", log) if int(a) + int(b) + int(c) > 0}
+        assert used == {"MI355X0", "MI355X1"}, used
+    finally:
+        shutil.rmtree(root, ignore_errors=True)

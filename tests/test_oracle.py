@@ -138,3 +138,42 @@ def test_reference_decorrelates_under_a_1e6_perturbation():
     be.close()
     assert nmse(outs[1], outs[0]) < 1e-9            # (1e-7: no rounding happened to flip in this small model)
     assert 1e-5 < nmse(outs[2], outs[0]) < 1e-1     # 1e-6: one flipped, the outputs decorrelate to the rounding-noise floor
+
+
+def test_reference_build_flags_give_the_same_bytes(tmp_path):
+    """oracle/_ref is the reference built with `-std=c11 -ffp-contract=off -march=x86-64-v3` (oracle/Makefile.ref); the reference's OWN default build is GGML_NATIVE +
+    gnu11 (ggml/CMakeLists.txt:265), under which gcc contracts `iscale * x + 12582912.f` inside nearest_int (ggml-quants.c) into one fma.  Both builds (the second:
+    `make -f oracle/Makefile.ref native`, oracle/_ref/native/) run oracle/ref_flags_probe.py in a process of their own:
+      * on the golden signal of tests/golden/quant.npz every byte the parity tests are pinned to -- quantize_row_q8_K / _q8_0 of y and of the tie / zero edge rows, the
+        Q4_K / Q6_K / Q8_0 blocks of x -- and the three vec_dot scalars per type are IDENTICAL under both flag sets (and equal to the fixture);
+      * on 2^20 seeded normal values at block scales 2^-20 .. 2^20 the Q8_0 image is identical, every Q8_K block scale d is identical, and a handful of Q8_K quants
+        (measured: 3 of 1 048 576) differ by one step -- exact ties of the magic-number rounding, which the contracted fma resolves on the unrounded product.
+    "Bit-exact with the reference CPU backend" therefore means: with either build on the fixtures; with the c11 build (the stricter reading of the source) at ties."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    libs = [os.path.join(root, "oracle", "_ref", "libggml-ref.so"), os.path.join(root, "oracle", "_ref", "native", "libggml-ref.so")]
+    if not all(os.path.exists(l) for l in libs):
+        pytest.skip("needs oracle/_ref and oracle/_ref/native (make -f oracle/Makefile.ref all native; the second is tied to the build container's CPU)")
+    outs, arrs = [], []
+    for i, l in enumerate(libs):
+        npz = str(tmp_path / f"b{i}.npz")
+        r = subprocess.run([sys.executable, os.path.join(root, "oracle", "ref_flags_probe.py"), l, npz], capture_output=True, text=True, timeout=300)
+        if r.returncode != 0:
+            pytest.skip(f"{l} does not run on this CPU: {r.stderr[-200:]}")
+        outs.append(json.loads(r.stdout.strip().splitlines()[-1])); arrs.append(np.load(npz))
+    a, b = outs
+    for k in a:
+        if k.endswith("_diff_bytes_vs_golden"):
+            assert a[k] == 0 and b[k] == 0, (k, a[k], b[k])
+        elif k.endswith("_dots_rel_vs_golden"):
+            assert max(a[k]) == 0.0 and max(b[k]) == 0.0, (k, a[k], b[k])
+        elif not k.startswith("rand_"):
+            assert a[k] == b[k], k
+    assert a["rand_q8_0"] == b["rand_q8_0"]
+    qa, qb = arrs[0]["rand_q8_K"].reshape(-1, 292), arrs[1]["rand_q8_K"].reshape(-1, 292)
+    assert (qa[:, :4] == qb[:, :4]).all()                               # block scales d
+    ia, ib = qa[:, 4:260].view(np.int8).astype(np.int32), qb[:, 4:260].view(np.int8).astype(np.int32)
+    n_diff = int((ia != ib).sum())
+    print(f"Q8_K quants differing between the c11 / no-contraction and the gnu11 / native build: {n_diff} of {ia.size}")
+    assert np.abs(ia - ib).max() <= 1 and n_diff <= ia.size // 100000, n_diff
+    assert (arrs[0]["rand"] == arrs[1]["rand"]).all()

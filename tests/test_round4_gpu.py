@@ -322,7 +322,7 @@ def test_soft_max_attention_of_a_batch_is_one_launch_vs_reference_backend(pkg, b
 # flash-attention-off node chain (llama-bench's default), through the GEMM tiles, the grouped q/k/v launch, the SWIGLU epilogue, the norm / rope row kernels, the prefill
 # attention kernel (and its V^T form), the split-K reductions fused into the norms.
 @pytest.mark.parametrize("flash_attn", [True, False])
-def test_8b_width_f16_prefill_512_logits_within_1e3(pkg, be, ref_be, flash_attn):
+def test_8b_width_f16_prefill_512_logits_nmse_1e6_and_within_1e3_on_all_but_1e5_of_the_entries(pkg, be, ref_be, flash_attn):
     import numpy as np
     from llama_cpp_omni_amd import qwen3
     cfg = dict(qwen3.QWEN3_8B, n_layer=2, n_vocab=4096)
@@ -341,15 +341,17 @@ def test_8b_width_f16_prefill_512_logits_within_1e3(pkg, be, ref_be, flash_attn)
     assert np.isfinite(got).all()
     # 2 M logits of magnitude up to ~6.5: both backends round the SAME f32 activations to f16 before every mat-mul, but activations that differ in the 7th digit (another
     # f32 summation order) land on different f16 neighbours now and then -- a 2^-11 step of that activation on one side only.  So the bar is stated on the distribution:
-    # NMSE, the 1e-3 bound (relative to the largest logit) on all but 1e-4 of the entries, and a hard cap of 2e-3 on every entry.
+    # NMSE, the 1e-3 bound (relative to the largest logit) on all but 1e-5 of the entries, and a hard cap of 1.5e-3 on every entry.  Measured (round 6, MI355X): FA on
+    # NMSE 9.7e-7, 2 of 2 097 152 entries above 1e-3, max 1.04e-3; FA off NMSE 3.7e-7, none above, max 6.7e-4 -- DESIGN.md section 4 carries these as the stated deviation
+    # from north_star's "within 1e-3" at 8B width (strict 1e-3 on every entry holds on the tiny model: test_gpu_parity.py::test_f16_model_logits_within_1e3).
     from conftest import nmse
     scale = max(1.0, float(np.abs(want).max()))
     d = np.abs(got - want)
     stats = (nmse(got, want), float((d > 1e-3 * scale).mean()), float(d.max()) / scale)
     print("8B-width F16 prefill: NMSE %.2e, fraction above 1e-3 x max logit %.2e, max |d| / max logit %.2e" % stats)
     assert stats[0] < 1e-6, stats
-    assert stats[1] < 1e-4, stats
-    assert stats[2] < 2e-3, stats
+    assert stats[1] < 1e-5, stats
+    assert stats[2] < 1.5e-3, stats
     assert (got.argmax(1) == want.argmax(1)).mean() > 0.99                     # (near-ties among 4096 random logits may flip)
 
 

@@ -8,7 +8,7 @@
 // common_init(), whose body references the cmake-generated common/build-info.cpp (LLAMA_BUILD_NUMBER / LLAMA_COMMIT / LLAMA_COMPILER /
 // LLAMA_BUILD_TARGET).  No stand-in for that file exists here: the harness never reaches common_init and the link drops its section (--gc-sections).
 //
-//   omni-min -m LLM.gguf [--test PREFIX N] [-c CTX] [-ngl N] [--ref-audio WAV] [--no-tts] [--omni] [--out DIR] [--t2w-device gpu:0|cpu] [--max-tgt N]
+//   omni-min -m LLM.gguf [--test PREFIX N] [-c CTX] [-ngl N] [--ref-audio WAV] [--no-tts] [--omni] [--out DIR] [--t2w-device gpu:N|cpu] [--max-tgt N] [-mg N] [-sm none]
 // The other module paths follow omni-cli's directory convention ({dir}/audio/MiniCPM-o-4_5-audio-F16.gguf, {dir}/tts/..., {dir}/vision/...,
 // {dir}/token2wav-gguf/*).  Prints one JSON line: the devices every module's backend landed on (from the registry), prefill / decode wall times and
 // the timestamps the reference itself writes (TTFT of the first wav chunk from the output directory's mtime).
@@ -33,8 +33,8 @@ static double now_s() { return std::chrono::duration<double>(std::chrono::steady
 
 int main(int argc, char ** argv) {
     std::string llm, prefix, ref_audio, out_dir = "./omni_out", t2w_dev = "gpu:0";
-    int n = 1, n_ctx = 4096, ngl = 99, max_tgt = -1;
-    bool use_tts = true, omni_mode = false;
+    int n = 1, n_ctx = 4096, ngl = 99, max_tgt = -1, main_gpu = -1;
+    bool use_tts = true, omni_mode = false, split_none = false;
     for (int i = 1; i < argc; ++i) {
         const std::string a = argv[i];
         if (a == "-m" && i + 1 < argc) llm = argv[++i];
@@ -45,6 +45,8 @@ int main(int argc, char ** argv) {
         else if (a == "--out" && i + 1 < argc) out_dir = argv[++i];
         else if (a == "--t2w-device" && i + 1 < argc) t2w_dev = argv[++i];
         else if (a == "--max-tgt" && i + 1 < argc) max_tgt = atoi(argv[++i]);
+        else if ((a == "-mg" || a == "--main-gpu") && i + 1 < argc) main_gpu = atoi(argv[++i]);    // common/arg.cpp:2955 (with -sm none: the one device of the LLM -- and of the TTS model, omni.cpp:3457)
+        else if ((a == "-sm" || a == "--split-mode") && i + 1 < argc) split_none = std::string(argv[++i]) == "none";
         else if (a == "--no-tts") use_tts = false;
         else if (a == "--omni") omni_mode = true;
         else { fprintf(stderr, "usage: %s -m LLM.gguf --test PREFIX N [-c CTX] [-ngl N] [--ref-audio WAV] [--no-tts] [--omni] [--out DIR] [--t2w-device D] [--max-tgt N]\n", argv[0]); return 2; }
@@ -60,6 +62,8 @@ int main(int argc, char ** argv) {
     params.tts_model = dir + "/tts/MiniCPM-o-4_5-tts-F16.gguf";
     params.n_ctx = n_ctx;
     params.n_gpu_layers = ngl;
+    if (main_gpu >= 0) params.main_gpu = main_gpu;
+    if (split_none) params.split_mode = LLAMA_SPLIT_MODE_NONE;
     if (max_tgt > 0) params.n_predict = max_tgt;           // stream_decode's max_tgt_len (omni.cpp:9112): a random-weight LLM never emits <|tts_eos|>
     if (use_tts && !file_exists(params.tts_model)) { fprintf(stderr, "TTS model missing: %s\n", params.tts_model.c_str()); return 1; }
     const std::string tts_bin_dir = parent_dir(params.tts_model);
