@@ -23,3 +23,9 @@ for p in range(8, 8 + N):
     t3 = time.perf_counter()
     tu += t1 - t0; tg += t2 - t1; ts += t3 - t2
 print("per token (us): uploads + host prep %.1f | graph_compute call %.1f | read-back + wait %.1f | total %.1f; graph nodes %d" % (tu / N * 1e6, tg / N * 1e6, ts / N * 1e6, (tu + tg + ts) / N * 1e6, dec.graph.g.n_nodes))
+# MI355X_GRAPH_GPU_TIME=1: the event pair the backend puts around every graph -- printed when the backend is freed
+import os
+if os.environ.get("MI355X_GRAPH_GPU_TIME"):
+    be.synchronize()
+    del dec
+    be.close()

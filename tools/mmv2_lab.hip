@@ -76,6 +76,13 @@ static void trace_report(const char * nm, int nwg, int nl, int NW) {
             printf("      WG %3d %2d %2d %2d  %6.2f %6.2f %6.2f  %6.2f\n", g, (int) (L[5] & 15), (int) ((L[6] >> 13) & 7), (int) ((L[6] >> 8) & 15), (double) (L[0] - t0) * 0.01, (double) (L[2] - t0) * 0.01, (double) (L[7] - t0) * 0.01, cend);
         }
     }
+    if (getenv("MV2_WG0")) {                     // every wave of workgroups 0 and 1: the eight stamps (us after the workgroup's first wave)
+        for (int g = 0; g < 2; ++g) {
+            unsigned long long w0 = ~0ull; for (int w = 0; w < NW; ++w) if (h[((size_t) g * NW + w) * 8]) w0 = std::min(w0, h[((size_t) g * NW + w) * 8]);
+            printf("      workgroup %d, per wave (stamps 0 1 2 3 4 5 7; loader = wave 0, row waves = the last four):\n", g);
+            for (int w = 0; w < NW; ++w) { printf("        wave %2d:", w); for (int i = 0; i < 8; ++i) { if (i == 6) continue; const unsigned long long v = h[((size_t) g * NW + w) * 8 + i]; if (v && i != 5) printf(" %6.2f", (double) (v - w0) * 0.01); else if (i == 5 && w > 0 && v) printf(" %6.2f", (double) (v - w0) * 0.01); else printf("      -"); } printf("\n"); }
+        }
+    }
     printf("      time line of %s (us after the first wave's start; min / median / max)\n", nm);
     for (int role = 0; role < 3; ++role) for (int i = 0; i < 8; ++i) {
         const char * const * lab = role == 0 ? labl : role == 1 ? labc : labr;
