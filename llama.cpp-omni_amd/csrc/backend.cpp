@@ -450,6 +450,14 @@ static void * reg_proc(ggml_backend_reg_t, const char * name) {
     return nullptr;
 }
 static const ggml_backend_reg_i k_reg_iface = { reg_name, reg_dev_count, reg_get_dev, reg_proc };
+// A host that calls ggml_backend_load_all() more than once (token2wav-impl.cpp does, after omni_init already did) makes the reference's loader bind and call
+// ggml_backend_init again, and ggml-backend-reg.cpp:226-239 appends whatever devices the returned registry reports: MI355X0 appeared three times in
+// ggml_backend_dev_count() under the omni runtime.  The loader's entry point therefore hands out the device-bearing registry ONCE per process; later calls get this
+// second registry object -- same name, same proc addresses, no devices -- so the global device list stays what the first registration made it.
+static size_t reg_dev_count_none(ggml_backend_reg_t) { return 0; }
+static ggml_backend_dev_t reg_get_dev_none(ggml_backend_reg_t, size_t) { return nullptr; }
+static const ggml_backend_reg_i k_reg_again_iface = { reg_name, reg_dev_count_none, reg_get_dev_none, reg_proc };
+static ggml_backend_reg g_reg_again = { GGML_BACKEND_API_VERSION, k_reg_again_iface, nullptr };
 
 static void init_once() {
     std::lock_guard<std::mutex> lock(g_mutex);
@@ -487,7 +495,12 @@ static void init_once() {
 extern "C" {
 
 ggml_backend_reg_t ggml_backend_mi355x_reg(void) { mi::init_once(); return &mi::g_reg; }
-ggml_backend_reg_t ggml_backend_init(void) { return ggml_backend_mi355x_reg(); }
+ggml_backend_reg_t ggml_backend_init(void) {          // the loader's entry (ggml-backend-reg.cpp:265-285): idempotent towards the registry's device list
+    static std::atomic<int> calls{0};
+    static const bool always_full = getenv("MI355X_INIT_ALWAYS_FULL") != nullptr;
+    ggml_backend_reg_t full = ggml_backend_mi355x_reg();
+    return calls.fetch_add(1) == 0 || always_full ? full : &mi::g_reg_again;
+}
 int ggml_backend_score(void) {
     mi::init_once();
     return mi::g_devices.empty() ? 0 : 100;

@@ -177,6 +177,7 @@ def load_library():
                                "the MI355X backend has no CPU fallback")
         lib = C.CDLL(p, mode=C.RTLD_GLOBAL)
         lib.ggml_backend_init.restype = C.POINTER(reg_t)
+        lib.ggml_backend_mi355x_reg.restype = C.POINTER(reg_t)
         lib.ggml_backend_score.restype = C.c_int
         lib.mi355x_host_buffer_free.argtypes = [_vp]
         lib.mi355x_timed_event_new.restype = _vp
@@ -241,9 +242,9 @@ class Backend:
 
     def __init__(self, device_index=0):
         self.lib = load_library()
-        self.reg = self.lib.ggml_backend_init()
+        self.reg = self.lib.ggml_backend_mi355x_reg()       # (the direct-link entry: ggml_backend_init, the LOADER's entry, reports the devices once per process)
         if not self.reg or self.reg.contents.api_version != 2:
-            raise RuntimeError("ggml_backend_init: bad registry / api_version")
+            raise RuntimeError("ggml_backend_mi355x_reg: bad registry / api_version")
         n = self.reg.contents.iface.get_device_count(self.reg)
         if n == 0:
             raise RuntimeError("libggml-mi355x.so: no gfx950 device visible (ggml_backend_score() == 0)")

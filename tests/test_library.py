@@ -38,7 +38,7 @@ def test_only_weak_host_imports(pkg):
 
 def test_registry_object_without_gpu(pkg):
     lib = pkg.load_library()
-    reg = lib.ggml_backend_init()
+    reg = lib.ggml_backend_mi355x_reg()
     assert reg.contents.api_version == 2
     assert reg.contents.iface.get_name(reg) == b"MI355X"
     n = reg.contents.iface.get_device_count(reg)
@@ -69,3 +69,31 @@ def test_reference_loader_accepts_the_plugin():
     txt = r.stdout + r.stderr
     assert "failed to" not in txt.lower() or "not supported on this system" in txt
     assert ("MI355X" in txt) or ("not supported on this system" in txt), txt[-2000:]
+
+
+def test_loader_entry_reports_its_devices_once_per_process(pkg):
+    """ggml_backend_init is what ggml-backend-reg.cpp binds; a host that calls ggml_backend_load_all() repeatedly (token2wav-impl.cpp after omni_init) calls it again and
+    appends the returned registry's devices each time.  The first call of a process returns the device-bearing registry, later calls a registry of the same name and proc
+    addresses with no devices -- run in a process of its own, because the first call is global state."""
+    import subprocess, sys, textwrap
+    code = textwrap.dedent("""
+        import sys
+        sys.path.insert(0, %r)
+        import conftest
+        lib = conftest.load_pkg().load_library()
+        full = lib.ggml_backend_mi355x_reg()
+        a, b, c = lib.ggml_backend_init(), lib.ggml_backend_init(), lib.ggml_backend_init()
+        import ctypes as C
+        addr = lambda r: C.cast(r, C.c_void_p).value
+        n = full.contents.iface.get_device_count(full)
+        assert addr(a) == addr(full), "first call: the registry itself"
+        assert addr(b) == addr(c) != addr(full)
+        for r in (b, c):
+            assert r.contents.api_version == 2 and r.contents.iface.get_name(r) == b"MI355X"
+            assert r.contents.iface.get_device_count(r) == 0
+            assert r.contents.iface.get_proc_address(r, b"mi355x_set_option")
+        assert full.contents.iface.get_device_count(full) == n
+        print("ok", n)
+    """) % (__import__("os").path.dirname(__import__("os").path.abspath(__file__)),)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.strip().startswith("ok"), (r.stdout, r.stderr[-2000:])

@@ -85,7 +85,7 @@ def test_reference_omni_runtime_drives_the_plugin(tmp_path):
         live = [s for s in stats if s[0] + s[1] + s[2] > 0]
         assert len(live) >= 4 and any(s[3] > 2000 for s in live) and any(s[2] > 500 for s in live), stats        # (Token2Wav's 4 000-launch window graph; the TTS decoder's replays)
         j = summarise(log)
-        assert "MI355X0" in j["registry_devices"]
+        assert j["registry_devices"].count("MI355X0") == 1, j["registry_devices"]      # (round 6: the loader entry reports its devices once, however often the modules call ggml_backend_load_all)
         # ---- completion: the three threads ran to the end and wrote audio
         assert j["first_wav_s"] > 0 and j["n_wav"] >= 2 and j["n_past_after_decode"] > j["n_past_after_prefill"] > 100
         assert j["reference_first_audio_ms"] is not None and j["t2w_token2mel_ms_median"] is not None
