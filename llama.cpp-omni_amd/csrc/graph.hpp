@@ -76,7 +76,7 @@ struct backend_ctx {
 
     // statistics
     long stat_replays = 0, stat_captures = 0, stat_eager = 0, stat_kernels_last = 0, stat_fp_mismatch = 0;
-    long stat_lazy_taken = 0, stat_lazy_materialised = 0;      // lazy CONTs (graph_exec.cpp lazy_try_register): left un-run / made real after all
+    long stat_lazy_taken = 0, stat_lazy_materialised = 0;      // lazy CONTs (graph_exec_t2w.cpp lazy_try_register): left un-run / made real after all
     // host time spent inside the backend's entry points (ns; reported with MI355X_LOG_STATS): graph_compute, set/get_tensor_async, synchronize
     uint64_t host_ns_match = 0, host_ns_launch = 0;      // replay fast path: the record compare, hipGraphLaunch
     uint64_t host_ns_graph = 0, host_ns_set = 0, host_ns_get = 0, host_ns_sync = 0, host_ns_eager_run = 0; long n_eager_kernels = 0; long n_set = 0, n_get = 0, n_sync = 0, n_graph = 0;

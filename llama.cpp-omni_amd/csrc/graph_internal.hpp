@@ -1,5 +1,5 @@
 // graph_internal.hpp -- what the three translation units of the graph executor share: graph_plan.cpp (supports_op, which kernel family a MUL_MAT takes, scratch
-// sizing), graph_exec.cpp (the node executors and their fusion matchers), graph.cpp (fingerprints, capture records, graph_compute / graph_optimize, options).
+// sizing), graph_exec.cpp + graph_exec_llm.cpp + graph_exec_t2w.cpp (the node executors and their fusion matchers), graph.cpp (fingerprints, capture records, graph_compute / graph_optimize, options).
 #pragma once
 #include "graph.hpp"
 #include <chrono>

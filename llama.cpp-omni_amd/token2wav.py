@@ -65,7 +65,7 @@ def causal_conv1d_chunk(c, x_ctb, cache_ctb, w, b, want_cache=True):
     fmCausalConv1d::build_forward_chunk_graph (token2wav-impl.cpp:925-1000), node for node with a cache given: the cache and x transposed
     to [T, C, B] copies, CONCAT on the time axis + CONT, per batch element VIEW -> IM2COL(F32) -> MUL_MAT, CONCAT over the batch,
     PERMUTE + CONT back, ADD of the bias; the new cache is the tail of CONT(CONCAT(cache, x) on dim 1).  The plug-in runs the y branch
-    as one dense concat + one any-shape GEMM over overlapping rows (graph_exec.cpp exec_causal_conv)."""
+    as one dense concat + one any-shape GEMM over overlapping rows (graph_exec_t2w.cpp exec_causal_conv)."""
     K, Cin, Cout = w.ne[0], w.ne[1], w.ne[2]
     dt, B = x_ctb.ne[1], x_ctb.ne[2]
     cache_in = c.cont(cache_ctb)

@@ -224,7 +224,7 @@ def test_dit_block_graph_replay_matches_the_eager_run(pkg, be):
 
 @pytest.mark.parametrize("C,T,B", [(512, 56, 2), (64, 7, 1)])
 def test_lazy_cache_copies_become_real_when_somebody_else_reads_them(pkg, be, ref_be, C, T, B):
-    """graph_exec.cpp lazy_try_register: the causal convolution's two copies of the cached frames (cache_in = CONT(view of the packed cache), cache_tcb =
+    """graph_exec_t2w.cpp lazy_try_register: the causal convolution's two copies of the cached frames (cache_in = CONT(view of the packed cache), cache_tcb =
     CONT(PERMUTE(cache_in)); token2wav-impl.cpp:952-957) are not run when they are met.  This graph has the shape that makes them lazy but NOT the convolution
     behind it, so every reader is an ordinary node: the CONCAT with the transposed x must get the transposed frames (read in place through swapped strides), and a late reader of
     cache_in -- behind a CPY that overwrites those very frames in the cache -- must still see the OLD frames (materialised at the deadline, before the CPY runs).
@@ -256,7 +256,7 @@ def test_lazy_cache_copies_become_real_when_somebody_else_reads_them(pkg, be, re
 
 @pytest.mark.parametrize("Tq,Tk", [(56, 206), (50, 200)])
 def test_attention_chain_reads_its_operands_through_the_permuted_views(pkg, be, ref_be, Tq, Tk):
-    """graph_exec.cpp lazy_try_register, case C: the DiT attention as token2wav-impl.cpp:245-291 / :470-497 spells it -- Q, K, V [D, H, T, B] each flattened by CONT(PERMUTE),
+    """graph_exec_t2w.cpp lazy_try_register, case C: the DiT attention as token2wav-impl.cpp:245-291 / :470-497 spells it -- Q, K, V [D, H, T, B] each flattened by CONT(PERMUTE),
     V transposed by a second CONT(PERMUTE), K.Q -> SCALE -> SOFT_MAX -> V^T.P -> merge.  The four copies are not run: k_attn_f32 reads the permuted 4-D views (two-level
     head-batch strides; V itself, keys a row apart).  206 keys: rows of V^T would be 824 bytes, the odd-length path.  Bar: the fused chain's f32 arithmetic against the reference
     CPU backend's separate nodes, NMSE <= 1e-10; the copies must have been deferred and only the merge's reader-less CONT may be real."""
