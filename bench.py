@@ -302,7 +302,7 @@ def kernel_roofline(pkg, be, model, reps=5):
                 break
     except Exception:
         pass
-    kname = "mi::k_mv2<1,1,true,true> (LDS-DMA engine: " if mv2 else "mi::k_mv1<8,2,2,1,1,true,false,false> ("
+    kname = "mi::k_mv2<1,1,true,true,16> (LDS-DMA engine, 16 waves: " if mv2 else "mi::k_mv1<8,2,2,1,1,true,false,false> ("
     return {"bound": "hbm", "kernel": kname + "RMS norm + Q8_K image prologue, Q4_K ffn_gate+ffn_up mat-vec, SWIGLU epilogue)",
             "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
             "bytes_per_launch": nbytes // launches, "avg_launch_us": round(us / launches, 3), "launches": launches,

@@ -27,25 +27,27 @@ def _decode(pkg, backend, steps, embd, n_kv=256, seed=4):
 
 
 def test_group_slice_attention_with_the_fold_in_wo_vs_reference_and_vs_the_per_head_kernel(pkg, be, ref_be):
-    """70 decode steps from an empty cache (positions 0 .. 69: the new token's row moves through slice 0 into slice 1; slices 2 and 3 of the 256-row view stay
+    """70 decode steps from an empty cache (positions 0 .. 69: the new token's row moves through slice 0 into slice 1; slices 2 and 3 of the 224-row view stay
     empty: M = -inf, S = 0): logits of the group-slice attention + PARTS wo launch against (a) the reference CPU backend on the same graphs and (b) the
     round-5 launches (one workgroup per head, plain wo) on the same backend.  (a) carries the documented deviation of flash-attention on this backend
     (V accumulated in f32, reference f16) through two layers; (b) differs only in the order of float sums."""
     steps = 70
+    NKV = 224           # (a view length no other test decodes at: the launches are counted where they are CAPTURED, and a graph another test left in the backend's capture cache -- same shapes
+                        #  at the same re-used addresses -- would be replayed without counting; 224 rows = 3.5 slices: the last slice is half empty)
     rng = np.random.default_rng(61)
     embd = rng.standard_normal((steps, CFG["n_embd"])).astype(np.float32)
     n0 = be.get_stat("fattn_gs_launches")
     be.set_option("fattn_gs", 1)
     try:
-        lg = _decode(pkg, be, steps, embd)
+        lg = _decode(pkg, be, steps, embd, n_kv=NKV)
         n1 = be.get_stat("fattn_gs_launches")
         assert n1 - n0 >= CFG["n_layer"] * 1, (n0, n1)                   # the path ran (captured launches are counted once, at capture)
         be.set_option("fattn_gs", 0)
-        lo = _decode(pkg, be, steps, embd)
+        lo = _decode(pkg, be, steps, embd, n_kv=NKV)
         assert be.get_stat("fattn_gs_launches") == n1                   # ... and the option switches it off
     finally:
         be.set_option("fattn_gs", -1)
-    lr = _decode(pkg, ref_be, steps, embd)
+    lr = _decode(pkg, ref_be, steps, embd, n_kv=NKV)
     assert np.isfinite(lg).all()
     e_old = nmse(lg, lo)
     e_ref, e_ref_old = nmse(lg, lr), nmse(lo, lr)
@@ -149,3 +151,29 @@ def test_8b_width_512_token_prompt_natural_logits_ids_agree_where_the_reference_
     assert (same | ~bound).all(), np.nonzero(~same & bound)[0][:8]
     assert int(bound.sum()) >= T // 4, int(bound.sum())                     # the rule is not vacuous
     assert int(same.sum()) >= int(0.9 * T), int(same.sum())
+
+
+@pytest.mark.parametrize("D,nq,nkv,H", [(72, 1024, 1024, 3), (72, 200, 1000, 2), (80, 77, 516, 2), (72, 64, 508, 2)])
+def test_f32_attention_chain_key_quarter_form_vs_reference(pkg, be, ref_be, D, nq, nkv, H):
+    """k_attn_f32<D, true, BAL> (attn_f32.hip, round 6): head sizes of five 16-wide slices (SigLip2's 72; 80) at >= 512 keys -- every wave takes all slices over a quarter of
+    the keys, the next 64 keys' V^T quads in flight under the current MFMAs, the four partial outputs added through LDS -- on the graph vision.cpp:670-690 spells
+    (MUL_MAT K.Q -> SOFT_MAX_EXT -> MUL_MAT V^T.P -> PERMUTE + CONT), against the reference CPU backend on the same graph; ragged cases: queries / keys that are no
+    multiple of 16 / 64, and 508 keys (below the form's threshold: the slice-per-wave form).  One launch per chain."""
+    from test_gpu_parity import run_graph
+    rng = np.random.default_rng(D + nkv)
+    F32 = pkg.GGML_TYPE_F32
+    qv = rng.standard_normal((H, nq, D)).astype(np.float32)
+    kv = rng.standard_normal((H, nkv, D)).astype(np.float32)
+    vv = rng.standard_normal((H, D, nkv)).astype(np.float32)
+    outs = []
+    for backend in (be, ref_be):
+        c = pkg.Context(backend)
+        q = c.new_tensor(F32, D, nq, H); k = c.new_tensor(F32, D, nkv, H); v = c.new_tensor(F32, nkv, D, H)
+        kq = c.soft_max_ext(c.mul_mat(k, q), None, 1.0 / np.sqrt(D), 0.0)
+        o = c.cont(c.permute(c.mul_mat(v, kq), 0, 2, 1, 3), D * H, nq)
+        (got,) = run_graph(backend, c, [o], [(q, qv), (k, kv), (v, vv)])
+        outs.append(got.copy())
+        if backend is be:
+            assert be.get_stat("kernels_last_graph") == 1
+    assert np.isfinite(outs[0]).all()
+    assert nmse(outs[0], outs[1]) < 1e-11, nmse(outs[0], outs[1])
