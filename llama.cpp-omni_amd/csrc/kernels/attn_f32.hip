@@ -8,7 +8,6 @@
 //   3. O = P . V on the same MFMA, one 16-wide slice of the head per wave, P from LDS, the rows of V^T from global; written through the CONT's strides
 // f32 products and accumulation throughout, i.e. the separate nodes' arithmetic with another summation order.
 #include "../kernels.hpp"
-#include <type_traits>
 
 namespace mi {
 
@@ -25,7 +24,7 @@ struct attn_f32_dev {
 
 extern __shared__ float af_lds[];
 
-template <int D, bool V4, bool BAL = false>
+template <int D, bool V4>
 __global__ void __launch_bounds__(256) k_attn_f32(const attn_f32_dev a) {
     typedef float acc4 __attribute__((ext_vector_type(4)));
     float * S = af_lds;                                  // [16][ldp]
@@ -45,7 +44,10 @@ __global__ void __launch_bounds__(256) k_attn_f32(const attn_f32_dev a) {
             if (d >= D) qv[j] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
         // four 16-key tiles of this wave at a time, every operand quad requested before the first MFMA (the loads are the latency here, not the arithmetic); head sizes up to
-        // 80 keep TWO such batches in registers: the next batch's quads are requested before the current batch's MFMAs (round 6: the SigLip2 shape, 1024 keys, waited ~1 us per batch)
+        // 80 keep TWO such batches in registers: the next batch's quads are requested before the current batch's MFMAs (round 6: the SigLip2 shape, 1024 keys, waited ~1 us per
+        // batch: 118 -> 110.7 us per launch, same sums in the same order).  Measured and NOT kept: a key-quarter form of step 3 for head sizes of five slices (every wave all
+        // slices over a quarter of the keys, partial outputs added through LDS): 130 us -- the launch is bound by its 8 waves per CU waiting on operand quads straight from
+        // global memory, not by wave 0's second slice; what it needs is K / V tiles staged through LDS for all four waves (tools/attn_f32_bench.py)
         auto load_batch = [&](int kb, float4 (&kv)[4][NJ]) {
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
@@ -116,75 +118,6 @@ __global__ void __launch_bounds__(256) k_attn_f32(const attn_f32_dev a) {
         for (int k = a.nkv + l; k < kpad; k += 16) row[k] = 0.0f;
     }
     __syncthreads();
-    // ---- 3 (BAL). head sizes whose 16-wide slices do not divide over the four waves (72, 80: five slices -- wave 0 ran two of them, the other three waited) at many keys:
-    // wave w takes EVERY slice over its quarter of the keys -- the P fragment of a 16-key step read once for all slices, the V^T quads of the next 64 keys requested before
-    // the current 64 keys' MFMAs --, the four partial outputs are added in a fixed order through the score rows' LDS
-    if constexpr (BAL) {
-        constexpr int NSL = (D + 15) / 16, DL = NSL * 16;
-        const int kq_len = ((a.nkv + 63) / 64) * 16;                       // keys per wave (a multiple of 16)
-        const int kpad = (a.nkv + 15) & ~15;
-        const int kbeg = wave * kq_len, kend = kbeg + kq_len < kpad ? kbeg + kq_len : kpad;
-        const char * vrow[NSL];
-#pragma unroll
-        for (int sl = 0; sl < NSL; ++sl) vrow[sl] = VT + (size_t) (16 * sl + r16 < D ? 16 * sl + r16 : D - 1) * a.v_rs;
-        acc4 acc[NSL];
-#pragma unroll
-        for (int sl = 0; sl < NSL; ++sl) acc[sl] = acc4{ 0.0f, 0.0f, 0.0f, 0.0f };
-        auto load_grp = [&](int kg, float4 (&vq)[4][NSL]) {                // the quads of keys kg .. kg + 63 (four 16-key steps), every slice
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int k = kg + 16 * u + 4 * gq;
-#pragma unroll
-                for (int sl = 0; sl < NSL; ++sl) {
-                    float4 v = *(const float4 *) (vrow[sl] + (size_t) (k < a.nkv ? k : a.nkv - 4) * 4);      // (V4: nkv % 4 == 0, a quad is inside or outside as a whole)
-                    if (k >= a.nkv) v = make_float4(0.f, 0.f, 0.f, 0.f);
-                    vq[u][sl] = v;
-                }
-            }
-        };
-        auto mma_grp = [&](int kg, const float4 (&vq)[4][NSL]) {
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int k0 = kg + 16 * u;
-                if (k0 >= kend) break;
-                const float4 p = *(const float4 *) &S[r16 * a.ldp + k0 + 4 * gq];
-#pragma unroll
-                for (int sl = 0; sl < NSL; ++sl) {
-                    acc[sl] = __builtin_amdgcn_mfma_f32_16x16x4f32(p.x, vq[u][sl].x, acc[sl], 0, 0, 0);
-                    acc[sl] = __builtin_amdgcn_mfma_f32_16x16x4f32(p.y, vq[u][sl].y, acc[sl], 0, 0, 0);
-                    acc[sl] = __builtin_amdgcn_mfma_f32_16x16x4f32(p.z, vq[u][sl].z, acc[sl], 0, 0, 0);
-                    acc[sl] = __builtin_amdgcn_mfma_f32_16x16x4f32(p.w, vq[u][sl].w, acc[sl], 0, 0, 0);
-                }
-            }
-        };
-        {
-            float4 va[4][NSL], vb[4][NSL];
-            int kg = kbeg;
-            if (kg < kend) load_grp(kg, va);
-            for (; kg < kend; kg += 128) {
-                if (kg + 64 < kend) load_grp(kg + 64, vb);
-                mma_grp(kg, va);
-                if (kg + 64 >= kend) break;
-                if (kg + 128 < kend) load_grp(kg + 128, va);
-                mma_grp(kg + 64, vb);
-            }
-        }
-        __syncthreads();                                                 // every wave has read its P: the score rows become the partial outputs [wave][16 queries][DL]
-#pragma unroll
-        for (int sl = 0; sl < NSL; ++sl)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) S[(wave * 16 + 4 * gq + e) * DL + 16 * sl + r16] = acc[sl][e];
-        __syncthreads();
-        const int h = hb % a.H, sidx = hb / a.H;
-        const int qi = t >> 4, q = q0 + qi;
-#pragma unroll
-        for (int sl = 0; sl < NSL; ++sl) {
-            const int d = 16 * sl + (t & 15);
-            const float o = ((S[(0 * 16 + qi) * DL + d] + S[(1 * 16 + qi) * DL + d]) + S[(2 * 16 + qi) * DL + d]) + S[(3 * 16 + qi) * DL + d];
-            if (q < a.nq && d < D) *(float *) (a.dst + (size_t) d * 4 + (size_t) q * a.d_nb_q + (size_t) h * a.d_nb_h + (size_t) sidx * a.d_nb_s) = o;
-        }
-        return;
-    }
     // ---- 3. O = P . V: wave w the head slice d0 = 16 w .. (D = 64: one slice per wave)
     for (int d0 = wave * 16; d0 < D; d0 += 64) {
         acc4 acc = { 0.0f, 0.0f, 0.0f, 0.0f };
@@ -256,30 +189,21 @@ void attn_f32(const attn_f32_args & a, hipStream_t st) {
     const bool v4 = !a.v_ks && a.nkv % 4 == 0 && (((uintptr_t) a.vt | a.v_rs | a.v_bs) & 15) == 0;
     const dim3 grid((unsigned) ((a.nq + 15) / 16), (unsigned) a.HB);
     int dev = 0; HIP_CHECK(hipGetDevice(&dev));
-    auto go = [&](auto k4, auto k1, int slot, auto kbal) {
-        static int attr_lds[16][64] = {};
+    auto go = [&](auto k4, auto k1, int slot) {
+        static int attr_lds[8][64] = {};
         if (lds > 65536 && (dev < 0 || dev >= 64 || attr_lds[slot][dev] < lds)) {
             HIP_CHECK(hipFuncSetAttribute((const void *) k4, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
             HIP_CHECK(hipFuncSetAttribute((const void *) k1, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
             if (dev >= 0 && dev < 64) attr_lds[slot][dev] = lds;
         }
-        if constexpr (!std::is_same<decltype(kbal), std::nullptr_t>::value) {
-            // many keys at a head size of five 16-wide slices: the key-quarter form (needs V^T rows of whole, aligned quads and 4 x 16 x 80 floats of LDS behind the soft-max)
-            static const bool no_bal = getenv("MI355X_ATTN_F32_NO_BAL") != nullptr;
-            if (v4 && !no_bal && a.nkv >= 512) {
-                if (lds > 65536 && (dev < 0 || dev >= 64 || attr_lds[slot + 5][dev] < lds)) { HIP_CHECK(hipFuncSetAttribute((const void *) kbal, hipFuncAttributeMaxDynamicSharedMemorySize, lds)); if (dev >= 0 && dev < 64) attr_lds[slot + 5][dev] = lds; }
-                kbal<<<grid, dim3(256), lds, st>>>(d);
-                return;
-            }
-        }
         if (v4) k4<<<grid, dim3(256), lds, st>>>(d); else k1<<<grid, dim3(256), lds, st>>>(d);
     };
     switch ((int) a.D) {
-        case 64:  go(k_attn_f32<64, true>,  k_attn_f32<64, false>,  0, nullptr); break;
+        case 64:  go(k_attn_f32<64, true>,  k_attn_f32<64, false>,  0); break;
         case 72:  go(k_attn_f32<72, true>,  k_attn_f32<72, false>,  1, k_attn_f32<72, true, true>); break;      // SigLip2: 1152 / 16 heads
-        case 80:  go(k_attn_f32<80, true>,  k_attn_f32<80, false>,  2, k_attn_f32<80, true, true>); break;
-        case 96:  go(k_attn_f32<96, true>,  k_attn_f32<96, false>,  3, nullptr); break;
-        default:  go(k_attn_f32<128, true>, k_attn_f32<128, false>, 4, nullptr); break;
+        case 80:  go(k_attn_f32<80, true>,  k_attn_f32<80, false>,  2); break;
+        case 96:  go(k_attn_f32<96, true>,  k_attn_f32<96, false>,  3); break;
+        default:  go(k_attn_f32<128, true>, k_attn_f32<128, false>, 4); break;
     }
 }
 

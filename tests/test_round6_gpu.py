@@ -154,11 +154,10 @@ def test_8b_width_512_token_prompt_natural_logits_ids_agree_where_the_reference_
 
 
 @pytest.mark.parametrize("D,nq,nkv,H", [(72, 1024, 1024, 3), (72, 200, 1000, 2), (80, 77, 516, 2), (72, 64, 508, 2)])
-def test_f32_attention_chain_key_quarter_form_vs_reference(pkg, be, ref_be, D, nq, nkv, H):
-    """k_attn_f32<D, true, BAL> (attn_f32.hip, round 6): head sizes of five 16-wide slices (SigLip2's 72; 80) at >= 512 keys -- every wave takes all slices over a quarter of
-    the keys, the next 64 keys' V^T quads in flight under the current MFMAs, the four partial outputs added through LDS -- on the graph vision.cpp:670-690 spells
-    (MUL_MAT K.Q -> SOFT_MAX_EXT -> MUL_MAT V^T.P -> PERMUTE + CONT), against the reference CPU backend on the same graph; ragged cases: queries / keys that are no
-    multiple of 16 / 64, and 508 keys (below the form's threshold: the slice-per-wave form).  One launch per chain."""
+def test_f32_attention_chain_at_siglip2_shapes_vs_reference(pkg, be, ref_be, D, nq, nkv, H):
+    """k_attn_f32<D> (attn_f32.hip; round 6: two batches of key quads in registers, the next one requested under the current one's MFMAs) at the head sizes of five
+    16-wide slices (SigLip2's 72; 80) and 500 .. 1024 keys, on the graph vision.cpp:670-690 spells (MUL_MAT K.Q -> SOFT_MAX_EXT -> MUL_MAT V^T.P -> PERMUTE + CONT),
+    against the reference CPU backend on the same graph; ragged cases: queries / keys that are no multiple of 16 / 64 / 256.  One launch per chain."""
     from test_gpu_parity import run_graph
     rng = np.random.default_rng(D + nkv)
     F32 = pkg.GGML_TYPE_F32
