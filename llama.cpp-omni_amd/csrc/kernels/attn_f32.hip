@@ -200,7 +200,7 @@ void attn_f32(const attn_f32_args & a, hipStream_t st) {
     };
     switch ((int) a.D) {
         case 64:  go(k_attn_f32<64, true>,  k_attn_f32<64, false>,  0); break;
-        case 72:  go(k_attn_f32<72, true>,  k_attn_f32<72, false>,  1, k_attn_f32<72, true, true>); break;      // SigLip2: 1152 / 16 heads
+        case 72:  go(k_attn_f32<72, true>,  k_attn_f32<72, false>,  1); break;      // SigLip2: 1152 / 16 heads
         case 80:  go(k_attn_f32<80, true>,  k_attn_f32<80, false>,  2); break;
         case 96:  go(k_attn_f32<96, true>,  k_attn_f32<96, false>,  3); break;
         default:  go(k_attn_f32<128, true>, k_attn_f32<128, false>, 4); break;
