@@ -570,7 +570,19 @@ void compute_node(exec_state & s, int i) {
                 lazy_net(s, i);                                            // everything else this node reads, and the deadlines
             }
             prof_scope ps(s, "concat", 0);
-            concat(sd[0], sd[1], td(n), op_param_i32(n, 0), n->type == GGML_TYPE_F16 ? 2 : 4, s.st); ++s.n_kernels;
+            {
+                const int dim = op_param_i32(n, 0), es = n->type == GGML_TYPE_F16 ? 2 : 4;
+                const tdesc y = td(n);
+                copy_pair cp[2];
+                for (int k = 0; k < 2; ++k) {                               // operand k lands in its slab of y: the same strides, its own extent, b behind a along `dim`
+                    cp[k].src = sd[k]; cp[k].es = es; cp[k].dst = y;
+                    for (int d = 0; d < 4; ++d) cp[k].dst.ne[d] = sd[k].ne[d];
+                    if (k == 1) cp[k].dst.p = (char *) y.p + (size_t) sd[0].ne[dim] * y.nb[dim];
+                }
+                const bool same = (n->type == GGML_TYPE_F32 || n->type == GGML_TYPE_F16 || n->type == GGML_TYPE_I32) && n->src[0]->type == n->type && n->src[1]->type == n->type;
+                if (copy_queue_on(s) && same && dim >= 0 && dim < 4 && copy_batch_ok(cp[0].src, cp[0].dst, es) && copy_batch_ok(cp[1].src, cp[1].dst, es)) copy_queue(s, cp, 2, y, n, dim);
+                else { copy_flush(s); concat(sd[0], sd[1], y, dim, es, s.st); ++s.n_kernels; }
+            }
             break;
         }
         case GGML_OP_REPEAT: {
@@ -710,7 +722,7 @@ void compute_node(exec_state & s, int i) {
             if (dbg_cpy) fprintf(stderr, "[mi355x] cpy node %s: %s [%lld, %lld, %lld, %lld] type %d nb [%zu, %zu, %zu] -> type %d\n", n->name, src->name, (long long) src->ne[0], (long long) src->ne[1],
                                  (long long) src->ne[2], (long long) src->ne[3], (int) src->type, src->nb[1], src->nb[2], src->nb[3], (int) n->type);
             // CPY writes into src[1]'s storage, which `n` is a view of; n->data is the destination in all three ops
-            if ((src->type == GGML_TYPE_F32) != (n->type == GGML_TYPE_F32) && (src->type == GGML_TYPE_I32 || n->type == GGML_TYPE_I32)) cast_f32_i32(td(src), src->type == GGML_TYPE_F32, td(n), s.st);
+            if ((src->type == GGML_TYPE_F32) != (n->type == GGML_TYPE_F32) && (src->type == GGML_TYPE_I32 || n->type == GGML_TYPE_I32)) { copy_flush(s); cast_f32_i32(td(src), src->type == GGML_TYPE_F32, td(n), s.st); }
             else {
                 // CONT(PERMUTE(kqv)) of a prefill ubatch whose only readers are MFMA GEMMs (wo): gather straight into the f16 activation image
                 const ggml_tensor * xg = nullptr;
@@ -720,6 +732,7 @@ void compute_node(exec_state & s, int i) {
                 const int cu = s.c->opt_fusion && !is_out(s, n) ? sole_user(s, n) : -1;
                 if (n->op == GGML_OP_CONT && src->type == GGML_TYPE_F32 && n->type == GGML_TYPE_F32 && n->ne[2] == 1 && n->ne[3] == 1 && n->nb[1] == (size_t) n->ne[0] * 4 &&
                     cu > i && next_real_node(s, i) == cu && n_users(s, n) == 1 && gemm_only_consumers(s, n, n->ne[0], n->ne[1], &xg)) {
+                    copy_flush(s);
                     tdesc d; d.p = s.c->act_scratch; d.ne[0] = n->ne[0]; d.ne[1] = n->ne[1]; d.ne[2] = 1; d.ne[3] = 1;
                     const size_t img = act_image_bytes(ACT_F16, n->ne[0]);
                     d.nb[0] = 2; d.nb[1] = img; d.nb[2] = img * (size_t) n->ne[1]; d.nb[3] = d.nb[2];
@@ -728,6 +741,16 @@ void compute_node(exec_state & s, int i) {
                     seed_act_f16(s, xg);
                     return;                                         // (the f32 copy was not written)
                 }
+                {
+                    const int es = src->type == GGML_TYPE_F16 ? 2 : 4;
+                    const copy_pair cp = { td(src), td(n), es };
+                    if (copy_queue_on(s) && src->type == n->type && (src->type == GGML_TYPE_F32 || src->type == GGML_TYPE_F16 || src->type == GGML_TYPE_I32) && copy_batch_ok(cp.src, cp.dst, es)) {
+                        copy_queue(s, &cp, 1, cp.dst, n);
+                        note_write(s, n);
+                        return;                                         // (counted when the batch leaves)
+                    }
+                }
+                copy_flush(s);
                 cpy_strided(td(src), src->type, td(n), n->type, s.st);
             }
             ++s.n_kernels;
@@ -852,11 +875,150 @@ byte_range range_of(const tdesc & d) {
     return { (const char *) d.p, (const char *) d.p + ext };
 }
 
+// ------------------------------------------------------------------------------------------------ deferred layout copies
+// Token2Wav's window graph spends a third of its launches on CONT / CONCAT / CPY nodes that move a few KB each (tools/launch_ngrams.py: runs of 4 and 7 of them inside every
+// DiT block, a 350-launch cache-packing suffix), most of them independent of their neighbours.  Such a node does not launch: its copy is queued, and the queue leaves as ONE
+// k_copy_batch launch (elementwise.hip) when (a) a node that is not a plain copy is about to run, (b) a new copy reads bytes a pending copy writes, or writes bytes one reads or
+// writes (conservative byte ranges of the strided views; ggml-alloc re-uses addresses inside such runs), or (c) COPY_BATCH_MAX jobs are pending.  Within a batch no job
+// depends on another, so the result is what the in-order launches gave.  Off with fusion off, in profile mode (per-class event timing) and by MI355X_NO_COPY_BATCH=1.
+bool copy_queue_on(exec_state & s) {
+    static const bool off = getenv("MI355X_NO_COPY_BATCH") != nullptr;
+    return !off && s.c->opt_fusion && !s.c->opt_profile;
+}
+static long g_copy_pruned = 0;
+// pending groups nobody will read: dropped (see copy_pending::node).  `keep`: a group that must stay (the one a forwarding in progress reads from)
+static void copy_prune(exec_state & s, int keep = -1) {
+    static const bool off = getenv("MI355X_NO_COPY_PRUNE") != nullptr;
+    if (off || s.cq.empty()) return;
+    int dead[COPY_BATCH_MAX]; int nd = 0;
+    int last = -1;
+    for (const exec_state::copy_pending & P : s.cq) {
+        if (P.group == last || P.group == keep) continue;
+        last = P.group;
+        const ggml_tensor * t = P.node;
+        if (!t || t->view_src || t->op == GGML_OP_CPY || is_out(s, t)) continue;      // (a view / a CPY writes somebody else's storage: a persistent cache)
+        auto us = s.users.find(t);
+        bool live = us == s.users.end() || us->second.empty();                 // (no reader inside the graph at all: a result somebody fetches afterwards)
+        if (us != s.users.end()) for (int u : us->second) if (u >= s.cur_node && !s.done[u]) { live = true; break; }      // (the node being processed may still read it un-forwarded)
+        if (!live) { const byte_range ry = range_of(P.Y); for (auto & kv : s.lazy) if (overlap(range_of(kv.second.src), ry)) { live = true; break; } }
+        if (!live && s.va.cast) { if (overlap(range_of(s.va.v), range_of(P.Y))) live = true; }
+        if (!live && nd < COPY_BATCH_MAX) {
+            dead[nd++] = P.group;
+            static const bool verify = getenv("MI355X_COPY_PRUNE_VERIFY") != nullptr;
+            if (verify) {
+                const byte_range ry = range_of(P.Y); s.cq_dead.push_back({ ry.lo, ry.hi, t, s.cur_node });
+                if (getenv("MI355X_COPY_PRUNE_VERBOSE")) {
+                    fprintf(stderr, "[mi355x] PRUNE: dropping group of node %d (%s) at node %d; users:", s.index.count(t) ? s.index[t] : -1, t->name, s.cur_node);
+                    if (us != s.users.end()) for (int u : us->second) fprintf(stderr, " %d(op%d%s%s)", u, (int) s.g->nodes[u]->op, s.done[u] ? ",done" : "", s.lazy.count(s.g->nodes[u]) ? ",lazy" : "");
+                    fprintf(stderr, "\n");
+                }
+            }
+        }
+    }
+    if (!nd) return;
+    size_t w = 0;
+    for (size_t r = 0; r < s.cq.size(); ++r) {
+        bool d = false;
+        for (int k = 0; k < nd; ++k) if (s.cq[r].group == dead[k]) d = true;
+        if (!d) { if (w != r) s.cq[w] = s.cq[r]; ++w; } else if (!s.capturing) ++g_copy_pruned;
+    }
+    s.cq.resize(w);
+}
+static long g_copy_hist[COPY_BATCH_MAX + 1], g_copy_why[4];              // MI355X_SINK_DEBUG: batch sizes; flushes by hazard kind (RAW, WAR, WAW, full)
+void copy_flush(exec_state & s) {
+    if (s.cq.empty()) return;
+    static const bool dbg = getenv("MI355X_SINK_DEBUG") != nullptr;
+    struct dump { ~dump() { if (dbg) { fprintf(stderr, "[mi355x] copy batches by size:"); for (int k = 1; k <= COPY_BATCH_MAX; ++k) if (g_copy_hist[k]) fprintf(stderr, " %d:%ld", k, g_copy_hist[k]);
+                                       fprintf(stderr, "; hazard checks that hit RAW %ld WAR %ld WAW %ld, nodes forwarded %ld, jobs dropped %ld\n", g_copy_why[0], g_copy_why[1], g_copy_why[2], g_copy_why[3], g_copy_pruned); } } };
+    static dump at_exit;
+    copy_prune(s);
+    if (s.cq.empty()) return;
+    if (dbg && !s.capturing) ++g_copy_hist[s.cq.size()];
+    copy_pair jobs[COPY_BATCH_MAX];
+    const int n = (int) s.cq.size();
+    for (int k = 0; k < n; ++k) jobs[k] = s.cq[k].job;
+    if (n == 1) {                                                           // (one copy: the kernels that know dense rows and 64-bit sizes)
+        const int ty = jobs[0].es == 4 ? GGML_TYPE_F32 : GGML_TYPE_F16;
+        cpy_strided(jobs[0].src, ty, jobs[0].dst, ty, s.st);
+    } else {
+        copy_batch(jobs, n, s.st);
+        s.n_copies_batched += n;
+    }
+    ++s.n_kernels;
+    s.cq.clear(); s.cq_dead.clear();
+}
+static bool same_desc(const tdesc & a, const tdesc & b) {
+    if (a.p != b.p) return false;
+    for (int d = 0; d < 4; ++d) if (a.ne[d] != b.ne[d] || (a.ne[d] > 1 && a.nb[d] != b.nb[d])) return false;
+    return true;
+}
+void copy_queue(exec_state & s, const copy_pair * jobs, int nj, const tdesc & Y, const ggml_tensor * node, int dim1) {
+    if (nj < 1 || nj > 2) { fprintf(stderr, "[mi355x] copy_queue: %d jobs\n", nj); abort(); }
+    typedef exec_state::copy_pending pend;
+    auto mk = [&](const copy_pair & j, const int64_t (&org)[4], int group) {
+        pend e; e.job = j;
+        const byte_range r = range_of(j.src), w = range_of(j.dst);
+        e.rlo = r.lo; e.rhi = r.hi; e.wlo = w.lo; e.whi = w.hi; e.group = group; e.Y = Y; e.node = s.cq_owner ? s.cq_owner : node;
+        e.same = true;
+        for (int d = 0; d < 4; ++d) { e.org[d] = org[d]; if (j.src.ne[d] != j.dst.ne[d]) e.same = false; }
+        return e;
+    };
+    auto hit = [](const char * alo, const char * ahi, const char * blo, const char * bhi) { return alo < bhi && blo < ahi; };
+    auto hazard = [&](const std::vector<pend> & v) {
+        for (const pend & P : s.cq)
+            for (const pend & e : v) {
+                const int why = hit(e.rlo, e.rhi, P.wlo, P.whi) ? 0 : hit(e.wlo, e.whi, P.rlo, P.rhi) ? 1 : hit(e.wlo, e.whi, P.wlo, P.whi) ? 2 : -1;
+                if (why >= 0) { if (!s.capturing) ++g_copy_why[why]; return true; }
+            }
+        return false;
+    };
+    auto undead = [&](const std::vector<pend> & v) {                      // (verify mode) bytes these jobs write are defined again
+        for (const pend & e : v) for (size_t q = 0; q < s.cq_dead.size(); ) { if (e.wlo < s.cq_dead[q].hi && s.cq_dead[q].lo < e.whi) s.cq_dead.erase(s.cq_dead.begin() + q); else ++q; }
+    };
+    const int group = ++s.cq_group;
+    std::vector<pend> orig, fwd;
+    bool any_fwd = false;
+    static const bool no_fwd = getenv("MI355X_NO_COPY_FORWARD") != nullptr;
+    for (int k = 0; k < nj; ++k) {
+        int64_t org[4] = { 0, 0, 0, 0 };
+        if (k == 1 && dim1 >= 0) org[dim1] = jobs[0].dst.ne[dim1];
+        const pend e = mk(jobs[k], org, group);
+        orig.push_back(e);
+        // forwarding: this job reads EXACTLY the output of a pending node whose boxes are same-shape copies -> it reads that node's sources, box by box, instead
+        int g = -1;
+        if (!no_fwd && e.same) for (const pend & P : s.cq) if (same_desc(P.Y, e.job.src)) { g = P.group; break; }
+        bool ok = g >= 0;
+        if (ok) for (const pend & P : s.cq) if (P.group == g && (!P.same || P.job.es != e.job.es)) ok = false;
+        if (!ok) { fwd.push_back(e); continue; }
+        for (const pend & P : s.cq) {
+            if (P.group != g) continue;
+            copy_pair c; c.es = e.job.es; c.src = P.job.src; c.dst = e.job.dst;
+            int64_t o2[4];
+            char * dp = (char *) e.job.dst.p;
+            for (int d = 0; d < 4; ++d) { c.dst.ne[d] = P.job.dst.ne[d]; dp += (size_t) P.org[d] * e.job.dst.nb[d]; o2[d] = org[d] + P.org[d]; }
+            c.dst.p = dp;
+            fwd.push_back(mk(c, o2, group));
+        }
+        any_fwd = true;
+    }
+    if (any_fwd && (s.cq.size() + fwd.size() > (size_t) COPY_BATCH_MAX || hazard(fwd))) copy_prune(s);          // (dead packs in the way: WAW / WAR against bytes nobody reads)
+    if (any_fwd && s.cq.size() + fwd.size() <= (size_t) COPY_BATCH_MAX && !hazard(fwd)) {
+        if (!s.capturing) ++g_copy_why[3];                                  // (counted as "forwarded")
+        for (const pend & e : fwd) s.cq.push_back(e);
+        undead(fwd);
+        return;
+    }
+    if (s.cq.size() + orig.size() > (size_t) COPY_BATCH_MAX || hazard(orig)) { copy_prune(s); if (s.cq.size() + orig.size() > (size_t) COPY_BATCH_MAX || hazard(orig)) copy_flush(s); }
+    for (const pend & e : orig) s.cq.push_back(e);
+    undead(orig);
+}
+
 void run_nodes(exec_state & s, ggml_cgraph * g) {
     static FILE * const launch_log = getenv("MI355X_LAUNCH_LOG") ? fopen(getenv("MI355X_LAUNCH_LOG"), "w") : nullptr;      // one line per node that launched: what a graph's launches are made of (tools/launch_ngrams.py)
     s.g = g;
     s.done.assign(g->n_nodes, 0);
     s.index.clear(); s.users.clear(); s.lazy.clear(); s.lazy_base_deadline.clear(); s.gs = {};
+    s.cq.clear();
     if (s.c->opt_fusion) {
         s.index.reserve(g->n_nodes * 2); s.users.reserve(g->n_nodes * 2);
         for (int i = 0; i < g->n_nodes; ++i) {
@@ -921,7 +1083,29 @@ void run_nodes(exec_state & s, ggml_cgraph * g) {
             for (int k = 0; k < 3 && n->src[k]; ++k) fprintf(launch_log, " s%d:op%d%s[%lld,%lld,%lld,%lld]", k, (int) n->src[k]->op, is_contiguous(n->src[k]) ? "c" : "n", (long long) n->src[k]->ne[0], (long long) n->src[k]->ne[1], (long long) n->src[k]->ne[2], (long long) n->src[k]->ne[3]);
             fprintf(launch_log, "\n");
         } } ll_g{ s, g, i, s.n_kernels, s.n_fused };
-        if (s.gs.n && i != s.gs.consumer && !is_noop(g->nodes[i]) && g->nodes[i] != s.gs.n) gs_materialise(s);       // (somebody else runs before wo folds the attention slices)
+        s.cur_node = i;
+        if (!s.cq_dead.empty() && !is_noop(g->nodes[i])) {                   // (verify mode) does this node read bytes of a dropped copy that nobody has rewritten since?
+            const ggml_tensor * n_ = g->nodes[i];
+            for (int k = 0; k < GGML_MAX_SRC; ++k) {
+                if (!n_->src[k] || !n_->src[k]->data) continue;
+                { bool lz = false; for (const ggml_tensor * t_ = n_->src[k]; t_; t_ = t_->view_src ? t_->view_src : ((t_->op == GGML_OP_RESHAPE || t_->op == GGML_OP_VIEW || t_->op == GGML_OP_PERMUTE || t_->op == GGML_OP_TRANSPOSE) ? t_->src[0] : nullptr)) if (s.lazy.count(t_)) lz = true; if (lz) continue; }
+                const byte_range r = range_of(n_->src[k]);
+                for (const auto & d : s.cq_dead)
+                    if (r.lo < d.hi && d.lo < r.hi)
+                        fprintf(stderr, "[mi355x] PRUNE VERIFY: node %d (%s, op %d) src%d %s [%lld,%lld,%lld,%lld] reads the dropped output of %s (op %d, dropped at node %d); src is node %d, dropped is node %d, src range %p+%zu dead range %p+%zu\n", i, n_->name, (int) n_->op, k, n_->src[k]->name,
+                                (long long) n_->src[k]->ne[0], (long long) n_->src[k]->ne[1], (long long) n_->src[k]->ne[2], (long long) n_->src[k]->ne[3], d.node->name, (int) d.node->op, d.at, s.index.count(n_->src[k]) ? s.index[n_->src[k]] : -1, s.index.count(d.node) ? s.index[d.node] : -1, (const void *) r.lo, (size_t) (r.hi - r.lo), (const void *) d.lo, (size_t) (d.hi - d.lo));
+            }
+        }
+        struct dead_guard { exec_state & s; const ggml_tensor * n; ~dead_guard() {        // whatever this node wrote is defined again
+            if (s.cq_dead.empty() || is_noop(n)) return;
+            const byte_range w = range_of(n);
+            for (size_t q = 0; q < s.cq_dead.size(); ) { if (w.lo < s.cq_dead[q].hi && s.cq_dead[q].lo < w.hi) s.cq_dead.erase(s.cq_dead.begin() + q); else ++q; }
+        } } dead_g{ s, g->nodes[i] };
+        {   // pending copies leave before anything that is not itself a plain copy (the copy-shaped matchers below flush where they launch)
+            const int op_ = g->nodes[i]->op;
+            if (!s.cq.empty() && !is_noop(g->nodes[i]) && op_ != GGML_OP_CONT && op_ != GGML_OP_CONCAT && op_ != GGML_OP_CPY && op_ != GGML_OP_DUP) copy_flush(s);
+        }
+        if (s.gs.n && i != s.gs.consumer && !is_noop(g->nodes[i]) && g->nodes[i] != s.gs.n) { copy_flush(s); gs_materialise(s); }       // (somebody else runs before wo folds the attention slices)
         if (g->nodes[i]->op == GGML_OP_IM2COL && exec_conv1d_tc(s, i)) continue;
         if (g->nodes[i]->op == GGML_OP_CONT && exec_causal_conv(s, i)) continue;
         if ((g->nodes[i]->op == GGML_OP_CONT || g->nodes[i]->op == GGML_OP_CONCAT) && exec_concat_tail(s, i)) continue;
@@ -937,7 +1121,9 @@ void run_nodes(exec_state & s, ggml_cgraph * g) {
         if (sink >= 0) {
             void * own = g->nodes[i]->data;
             g->nodes[i]->data = g->nodes[sink]->data;            // (the launches take the pointer now; the node gets its own back right after)
+            s.cq_owner = g->nodes[sink];
             compute_node(s, i);
+            s.cq_owner = nullptr;
             g->nodes[i]->data = own;
             s.done[sink] = 1; ++s.n_fused;
             note_write(s, g->nodes[sink]);
@@ -953,6 +1139,7 @@ void run_nodes(exec_state & s, ggml_cgraph * g) {
             }
         }
     }
+    copy_flush(s);
     gs_materialise(s);                                       // (the attention node was the graph's last launching node)
     if (launch_log && !s.capturing) { fprintf(launch_log, "== end of a graph of %d nodes\n", g->n_nodes); fflush(launch_log); }
 }

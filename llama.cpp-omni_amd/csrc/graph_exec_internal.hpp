@@ -40,6 +40,10 @@ static inline size_t attn_sm_mask16_off(int64_t nq, int64_t nkv) { return (fattn
 
 static inline tdesc swapped01(tdesc d) { std::swap(d.ne[0], d.ne[1]); std::swap(d.nb[0], d.nb[1]); return d; }
 
+// deferred copies (graph_exec.cpp): queue `nj` jobs of ONE node (they may write interleaved parts of one tensor: not checked against each other) / launch what is pending
+bool copy_queue_on(exec_state & s);
+void copy_queue(exec_state & s, const copy_pair * jobs, int nj, const tdesc & Y, const ggml_tensor * node, int dim1 = -1);      // Y: the node's output; dim1 >= 0: job 1's box starts at jobs[0].dst.ne[dim1] along that dimension
+void copy_flush(exec_state & s);
 void materialise_norm(exec_state & s);
 void lazy_net(exec_state & s, int i);
 void lazy_materialise(exec_state & s, const ggml_tensor * t, int reader_op = -1);

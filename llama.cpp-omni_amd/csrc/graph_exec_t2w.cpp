@@ -186,6 +186,7 @@ bool exec_attn_f32(exec_state & s, int i) {
     if (s.pn.m && (s.pn.m == fq || s.pn.m == fk || s.pn.m == fv)) materialise_norm(s);
     {
         prof_scope ps(s, "attn_f32", 4.0 * (double) D * (double) nq * (double) nkv * (double) HB);
+        copy_flush(s);
         attn_f32(a, s.st); ++s.n_kernels;
     }
     for (int k : { sci, smi, m2, ci }) if (k >= 0) { s.done[k] = 1; ++s.n_fused; }
@@ -362,7 +363,9 @@ void lazy_materialise(exec_state & s, const ggml_tensor * t, int reader_op) {
     ++s.c->stat_lazy_materialised;
     {
         prof_scope ps(s, "cpy", 0);
-        cpy_strided(it->second.src, GGML_TYPE_F32, td(t), GGML_TYPE_F32, s.st); ++s.n_kernels;
+        const copy_pair cp = { it->second.src, td(t), 4 };
+        if (copy_queue_on(s) && copy_batch_ok(cp.src, cp.dst, 4)) copy_queue(s, &cp, 1, cp.dst, t);
+        else { copy_flush(s); cpy_strided(it->second.src, GGML_TYPE_F32, td(t), GGML_TYPE_F32, s.st); ++s.n_kernels; }
     }
     s.lazy.erase(it);
     note_write(s, t);
@@ -382,6 +385,9 @@ void lazy_net(exec_state & s, int i) {
         if (us != s.users.end()) for (int u : us->second) if (u >= i && !s.done[u]) needed = true;
         if (needed) lazy_materialise(s, t); else s.lazy.erase(t);
     }
+    // a copy made real here was QUEUED (copy_queue): node i is about to launch a kernel that reads it -- or that writes over its source (the deadline) -- unless it is itself a
+    // plain copy, whose own job is checked against the queue
+    if (n->op != GGML_OP_CONT && n->op != GGML_OP_CONCAT && n->op != GGML_OP_CPY && n->op != GGML_OP_DUP) copy_flush(s);
 }
 bool lazy_try_register(exec_state & s, int i) {
     static const bool off = getenv("MI355X_NO_LAZY_CACHE_CONT") != nullptr;
@@ -628,6 +634,7 @@ bool exec_causal_conv(exec_state & s, int i) {
     bool created = false;
     float * wrows = (float *) shadow_get_or_create(s.c->device, Wk->data, nbytes(Wk), /*type: conv rows*/ 1000 + (int) KW, 2 * KW * C, Cout, (size_t) KW * 4, s.st, s.capturing, &created);
     if (!wrows) return no(__LINE__);
+    copy_flush(s);                                                      // (copies met but not launched yet: this pattern's kernels read what they write)
     if (s.pr.A) materialise_reduce(s);
     if (s.prm.n) materialise_group(s);
     if (s.pn.m && (s.pn.m == x || s.pn.m == cc)) materialise_norm(s);
@@ -702,6 +709,7 @@ bool exec_concat_tail(exec_state & s, int i) {
     // x->data directly and runs BEFORE lazy_net -- make such a copy real first
     for (const ggml_tensor * t = x; t; t = (t->op == GGML_OP_RESHAPE || t->op == GGML_OP_VIEW || t->op == GGML_OP_PERMUTE || t->op == GGML_OP_TRANSPOSE) ? t->src[0] : nullptr)
         if (s.lazy.count(t)) lazy_materialise(s, t, (int) GGML_OP_CONCAT);
+    if (s.pr.A || s.prm.n || (s.pn.m && s.pn.m == x)) copy_flush(s);
     if (s.pr.A) materialise_reduce(s);
     if (s.prm.n) materialise_group(s);
     if (s.pn.m && s.pn.m == x) materialise_norm(s);
@@ -709,7 +717,9 @@ bool exec_concat_tail(exec_state & s, int i) {
         prof_scope ps(s, "cpy", 0);
         tdesc src = td(x);
         src.p = (char *) x->data + (size_t) (f0 - P) * x->nb[1]; src.ne[1] = keep;
-        cpy_strided(src, GGML_TYPE_F32, td(n3), GGML_TYPE_F32, s.st); ++s.n_kernels;
+        const copy_pair cp = { src, td(n3), 4 };
+        if (copy_queue_on(s) && copy_batch_ok(cp.src, cp.dst, 4)) copy_queue(s, &cp, 1, cp.dst, n3);
+        else { cpy_strided(src, GGML_TYPE_F32, td(n3), GGML_TYPE_F32, s.st); ++s.n_kernels; }
     }
     note_write(s, n3);
     for (int k : { n0 ? j1 : -1, j2, j3 }) if (k >= 0) { s.done[k] = 1; ++s.n_fused; }

@@ -91,6 +91,20 @@ struct exec_state {
     struct lazy_ent { tdesc src; int deadline; };
     std::unordered_map<const ggml_tensor *, lazy_ent> lazy;
     std::unordered_map<const ggml_tensor *, int> lazy_base_deadline;
+    // same-type strided copies (CONT / CONCAT / CPY / a lazy copy made real) that have been MET but not launched: mutually independent by byte ranges, they leave as one
+    // k_copy_batch launch when a node of another kind is about to run, when a new copy touches bytes a pending one writes (or writes bytes one reads), or at COPY_BATCH_MAX
+    // `group` / `Y` / `org`: the node the job belongs to, that node's output, the origin of the job's box in it (a CONCAT is two boxes); `same`: source and destination box have
+    // the same shape.  A later copy that reads exactly a pending node's output is FORWARDED: it reads that node's sources instead (copy_queue), so chains of packs leave together
+    // `node`: the tensor the group writes -- a group whose tensor has no reader left (every reader so far was forwarded, none comes later, nothing lazy looks at it, it is no
+    // output and owns its bytes) is DROPPED instead of launched: the intermediate packs of a CONCAT chain are never written
+    struct copy_pending { copy_pair job; const char * rlo, * rhi, * wlo, * whi; int group; tdesc Y; int64_t org[4]; bool same; const ggml_tensor * node; };
+    int           cur_node = 0;
+    const ggml_tensor * cq_owner = nullptr;          // a node run with its output re-pointed at a CONT sink's buffer (cont_sink): the bytes a queued copy writes belong to the SINK tensor
+    struct dead_range { const char * lo, * hi; const ggml_tensor * node; int at; };
+    std::vector<dead_range> cq_dead;                 // MI355X_COPY_PRUNE_VERIFY=1: outputs of dropped groups; a later read of one is reported
+    int           cq_group = 0;
+    std::vector<copy_pending> cq;
+    long          n_copies_batched = 0;
 };
 
 // ------------------------------------------------------------------------------------------------ profiling

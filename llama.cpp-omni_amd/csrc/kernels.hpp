@@ -179,6 +179,12 @@ void conv_transpose_1d_f32(const tdesc & w, int w_type, const tdesc & x, const t
 void cast_f32_i32(const tdesc & src, bool src_is_f32, const tdesc & dst, hipStream_t st);                          // ops.cpp:555, 558-561
 // CPY / CONT / DUP between f32 / f16 with arbitrary strides (same element count)
 void cpy_strided(const tdesc & src, int src_type, const tdesc & dst, int dst_type, hipStream_t st);
+// up to COPY_BATCH_MAX same-type strided copies (element size 2 or 4 bytes, < 2^31 elements each, shapes of equal element count) as one launch; the CALLER guarantees that
+// no job reads or writes bytes another job of the batch writes (graph_exec.cpp copy_queue)
+#define COPY_BATCH_MAX 32
+struct copy_pair { tdesc src, dst; int es; };
+bool copy_batch_ok(const tdesc & src, const tdesc & dst, int es);
+void copy_batch(const copy_pair * jobs, int n, hipStream_t st);
 // n small copies in one launch: entry i copies ents[i].size bytes from base + ents[i].off to ents[i].dst (base / ents: device-visible pinned memory)
 struct upload_ent { void * dst; uint32_t off, size; };
 void upload_small(const upload_ent * ents, const char * base, int n, hipStream_t st);

@@ -1140,6 +1140,59 @@ void cpy_strided(const tdesc & src, int src_type, const tdesc & dst, int dst_typ
     else { fprintf(stderr, "[mi355x] cpy: unsupported %d -> %d\n", src_type, dst_type); abort(); }
 }
 
+// ---- a batch of same-type strided copies in ONE launch (round 6): runs of layout-only nodes (CONT / CONCAT / CPY of Token2Wav's cache packing, the head-flattening copies in
+// front of an attention chain) are mutually independent more often than not, and each is a ~2.7 us launch that moves a few KB.  The executor queues them (graph_exec.cpp
+// copy_queue: byte-range hazards against everything pending) and hands up to COPY_BATCH_MAX of them over by value: blockIdx.y = the job, blockIdx.x strides over its units.
+// A job is the linear-index copy of k_cpy (source and destination decompose the same element index over their OWN shapes), its element 2, 4 or -- when both innermost
+// dimensions are contiguous, a multiple of 16 bytes and everything is 16-byte aligned -- 16 bytes wide.
+struct copy_job_dev { const char * sp; char * dp; int sne[4]; int dne[4]; long long snb[4]; long long dnb[4]; unsigned total; int es; };
+struct copy_batch_dev { copy_job_dev j[COPY_BATCH_MAX]; };
+template <typename T>
+static __device__ __forceinline__ void copy_job_run(const copy_job_dev & J) {
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < J.total; i += gridDim.x * blockDim.x) {
+        unsigned r = i;
+        const unsigned s0 = r % (unsigned) J.sne[0]; r /= (unsigned) J.sne[0];
+        const unsigned s1 = r % (unsigned) J.sne[1]; r /= (unsigned) J.sne[1];
+        const unsigned s2 = r % (unsigned) J.sne[2]; const unsigned s3 = r / (unsigned) J.sne[2];
+        r = i;
+        const unsigned d0 = r % (unsigned) J.dne[0]; r /= (unsigned) J.dne[0];
+        const unsigned d1 = r % (unsigned) J.dne[1]; r /= (unsigned) J.dne[1];
+        const unsigned d2 = r % (unsigned) J.dne[2]; const unsigned d3 = r / (unsigned) J.dne[2];
+        *(T *) (J.dp + d0 * J.dnb[0] + d1 * J.dnb[1] + d2 * J.dnb[2] + d3 * J.dnb[3]) = *(const T *) (J.sp + s0 * J.snb[0] + s1 * J.snb[1] + s2 * J.snb[2] + s3 * J.snb[3]);
+    }
+}
+__global__ void __launch_bounds__(256) k_copy_batch(const copy_batch_dev b) {
+    const copy_job_dev & J = b.j[blockIdx.y];
+    if (J.es == 16) copy_job_run<uint4>(J); else if (J.es == 4) copy_job_run<uint32_t>(J); else copy_job_run<uint16_t>(J);
+}
+bool copy_batch_ok(const tdesc & src, const tdesc & dst, int es) {
+    if (es != 2 && es != 4) return false;
+    int64_t ts = 1, tdn = 1;
+    for (int i = 0; i < 4; ++i) { if (src.ne[i] < 1 || dst.ne[i] < 1 || src.ne[i] > 0x7fffffff || dst.ne[i] > 0x7fffffff) return false; ts *= src.ne[i]; tdn *= dst.ne[i]; }
+    return ts == tdn && ts < ((int64_t) 1 << 31);
+}
+void copy_batch(const copy_pair * jobs, int n, hipStream_t st) {
+    if (n < 1 || n > COPY_BATCH_MAX) { fprintf(stderr, "[mi355x] copy_batch: %d jobs\n", n); abort(); }
+    copy_batch_dev b;
+    unsigned max_units = 1;
+    for (int k = 0; k < n; ++k) {
+        const tdesc & s = jobs[k].src; const tdesc & d = jobs[k].dst; const int es = jobs[k].es;
+        if (!copy_batch_ok(s, d, es)) { fprintf(stderr, "[mi355x] copy_batch: job %d not a same-type copy of < 2^31 elements\n", k); abort(); }
+        copy_job_dev & J = b.j[k];
+        J.sp = (const char *) s.p; J.dp = (char *) d.p; J.es = es;
+        int64_t total = 1;
+        for (int i = 0; i < 4; ++i) { J.sne[i] = (int) s.ne[i]; J.dne[i] = (int) d.ne[i]; J.snb[i] = (long long) s.nb[i]; J.dnb[i] = (long long) d.nb[i]; total *= s.ne[i]; }
+        const int V = 16 / es;
+        bool wide = s.nb[0] == (size_t) es && d.nb[0] == (size_t) es && s.ne[0] % V == 0 && d.ne[0] % V == 0 && (((uintptr_t) s.p | (uintptr_t) d.p) & 15) == 0;
+        for (int i = 1; i < 4 && wide; ++i) if (((s.ne[i] > 1 ? s.nb[i] : 0) | (d.ne[i] > 1 ? d.nb[i] : 0)) & 15) wide = false;
+        if (wide) { J.sne[0] /= V; J.dne[0] /= V; J.snb[0] = 16; J.dnb[0] = 16; J.es = 16; total /= V; }
+        J.total = (unsigned) total;
+        if (J.total > max_units) max_units = J.total;
+    }
+    unsigned gx = (max_units + 255) / 256; if (gx > 2048) gx = 2048;
+    k_copy_batch<<<dim3(gx, (unsigned) n), dim3(256), 0, st>>>(b);
+}
+
 // ================================================================================================
 // GET_ROWS (ops.cpp:4500-4665): dst[:, i10, i11, i12] = to_float(src0[:, idx[i10,i11,i12], i11, i12])
 // ================================================================================================
