@@ -371,6 +371,7 @@ int mi355x_set_option(struct ggml_backend * backend, const char * key, long valu
     if (!strcmp(key, "kq_staging")) { c->opt_kq_staging = value != 0; mi::drop_graph_execs(c); return 0; }
     if (!strcmp(key, "fattn_gqa")) { mi::fattn_set_gqa(value != 0); mi::drop_graph_execs(c); return 0; }
     if (!strcmp(key, "fattn_one")) { mi::fattn_set_one(value != 0); mi::drop_graph_execs(c); return 0; }
+    if (!strcmp(key, "copy_batch")) { c->opt_copy_batch = (int) value; mi::drop_graph_execs(c); return 0; }
     if (!strcmp(key, "fattn_gs")) { mi::fattn_set_gs((int) value); mi::drop_graph_execs(c); return 0; }       // (process-wide)
     if (!strcmp(key, "fattn_dma")) { mi::fattn_set_dma((int) value); mi::drop_graph_execs(c); return 0; }      // (process-wide)
     if (!strcmp(key, "f16_shadow")) { mi::shadow_set_enabled(value != 0); mi::drop_graph_execs(c); return 0; }
@@ -385,6 +386,9 @@ double mi355x_get_stat(struct ggml_backend * backend, const char * key) {
     if (!strcmp(key, "eager_graphs"))       return (double) c->stat_eager;
     if (!strcmp(key, "kernels_last_graph")) return (double) c->stat_kernels_last;
     if (!strcmp(key, "lazy_conts"))         return (double) c->stat_lazy_taken;
+    if (!strcmp(key, "copies_batched"))     return (double) c->stat_copies_batched;
+    if (!strcmp(key, "copies_forwarded"))   return (double) c->stat_copies_forwarded;
+    if (!strcmp(key, "copies_dropped"))     return (double) c->stat_copies_dropped;
     if (!strcmp(key, "lazy_conts_materialised")) return (double) c->stat_lazy_materialised;
     if (!strncmp(key, "shadow_", 7))        return mi::shadow_stat(key);
     if (!strcmp(key, "gemm256_launches"))   return (double) mi::gemm_variant_launches(0);

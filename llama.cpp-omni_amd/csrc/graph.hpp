@@ -76,6 +76,8 @@ struct backend_ctx {
 
     // statistics
     long stat_replays = 0, stat_captures = 0, stat_eager = 0, stat_kernels_last = 0, stat_fp_mismatch = 0;
+    int  opt_copy_batch = -1;                                  // deferred layout copies (graph_exec.cpp copy_queue): -1 default (on), 0 off, 1 on
+    long stat_copies_batched = 0, stat_copies_forwarded = 0, stat_copies_dropped = 0;   // copies that left in a batch of >= 2 / nodes forwarded to a pending node's sources / jobs never launched
     long stat_lazy_taken = 0, stat_lazy_materialised = 0;      // lazy CONTs (graph_exec_t2w.cpp lazy_try_register): left un-run / made real after all
     // host time spent inside the backend's entry points (ns; reported with MI355X_LOG_STATS): graph_compute, set/get_tensor_async, synchronize
     uint64_t host_ns_match = 0, host_ns_launch = 0;      // replay fast path: the record compare, hipGraphLaunch

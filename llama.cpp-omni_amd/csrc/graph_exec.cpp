@@ -883,7 +883,7 @@ byte_range range_of(const tdesc & d) {
 // depends on another, so the result is what the in-order launches gave.  Off with fusion off, in profile mode (per-class event timing) and by MI355X_NO_COPY_BATCH=1.
 bool copy_queue_on(exec_state & s) {
     static const bool off = getenv("MI355X_NO_COPY_BATCH") != nullptr;
-    return !off && s.c->opt_fusion && !s.c->opt_profile;
+    return !off && s.c->opt_copy_batch != 0 && s.c->opt_fusion && !s.c->opt_profile;
 }
 static long g_copy_pruned = 0;
 // pending groups nobody will read: dropped (see copy_pending::node).  `keep`: a group that must stay (the one a forwarding in progress reads from)
@@ -920,7 +920,7 @@ static void copy_prune(exec_state & s, int keep = -1) {
     for (size_t r = 0; r < s.cq.size(); ++r) {
         bool d = false;
         for (int k = 0; k < nd; ++k) if (s.cq[r].group == dead[k]) d = true;
-        if (!d) { if (w != r) s.cq[w] = s.cq[r]; ++w; } else if (!s.capturing) ++g_copy_pruned;
+        if (!d) { if (w != r) s.cq[w] = s.cq[r]; ++w; } else { ++s.c->stat_copies_dropped; if (!s.capturing) ++g_copy_pruned; }
     }
     s.cq.resize(w);
 }
@@ -942,7 +942,7 @@ void copy_flush(exec_state & s) {
         cpy_strided(jobs[0].src, ty, jobs[0].dst, ty, s.st);
     } else {
         copy_batch(jobs, n, s.st);
-        s.n_copies_batched += n;
+        s.n_copies_batched += n; s.c->stat_copies_batched += n;
     }
     ++s.n_kernels;
     s.cq.clear(); s.cq_dead.clear();
@@ -1004,6 +1004,7 @@ void copy_queue(exec_state & s, const copy_pair * jobs, int nj, const tdesc & Y,
     if (any_fwd && (s.cq.size() + fwd.size() > (size_t) COPY_BATCH_MAX || hazard(fwd))) copy_prune(s);          // (dead packs in the way: WAW / WAR against bytes nobody reads)
     if (any_fwd && s.cq.size() + fwd.size() <= (size_t) COPY_BATCH_MAX && !hazard(fwd)) {
         if (!s.capturing) ++g_copy_why[3];                                  // (counted as "forwarded")
+        ++s.c->stat_copies_forwarded;
         for (const pend & e : fwd) s.cq.push_back(e);
         undead(fwd);
         return;

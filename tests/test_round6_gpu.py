@@ -176,3 +176,61 @@ def test_f32_attention_chain_at_siglip2_shapes_vs_reference(pkg, be, ref_be, D, 
             assert be.get_stat("kernels_last_graph") == 1
     assert np.isfinite(outs[0]).all()
     assert nmse(outs[0], outs[1]) < 1e-11, nmse(outs[0], outs[1])
+
+
+@pytest.mark.parametrize("ty", ["f32", "f16"])
+def test_deferred_layout_copies_forwarding_and_dropping_vs_reference_and_vs_in_order_launches(pkg, be, ref_be, ty):
+    """graph_exec.cpp copy_queue / elementwise.hip k_copy_batch (round 6): CONT / CONCAT / CPY nodes queue their copies; the queue leaves as ONE launch at the next node of another kind
+    or at a byte-range hazard; a copy that reads exactly a pending node's output reads that node's sources instead (forwarding) and pending groups nobody reads any more are dropped.
+    The graph is Token2Wav's cache packing in small (token2wav-impl.cpp:808-845): permuted copies of four tensors, a chain of CONCATs growing a pack along dim 3 and along dim 1, a
+    reshaping CONT of the pack, a CPY of it into a view of a persistent cache, a CONCAT whose operand is rewritten (WAR) afterwards, and element-wise readers in between -- against
+    the reference CPU backend, and bit for bit against the same backend with the option off (one launch per node)."""
+    from test_gpu_parity import run_graph
+    T = pkg.GGML_TYPE_F32 if ty == "f32" else pkg.GGML_TYPE_F16
+    dt = np.float32 if ty == "f32" else np.float16
+    rng = np.random.default_rng(66)
+    xs = [rng.standard_normal((3, 5, 8)).astype(dt) for _ in range(4)]                     # ne = [8, 5, 3]
+    cache0 = rng.standard_normal((6, 3, 5, 8)).astype(dt)                                     # ne = [8, 5, 3, 6]
+
+    def build(backend):
+        c = pkg.Context(backend)
+        x = [c.new_tensor(T, 8, 5, 3) for _ in range(4)]
+        cache = c.new_tensor(T, 8, 5, 3, 6)
+        p = [c.cont(c.permute(t, 0, 2, 1, 3)) for t in x]                                   # [8, 3, 5]: four independent permuting copies
+        pack = c.concat(c.reshape(p[0], 8, 3, 5, 1), c.reshape(p[1], 8, 3, 5, 1), 3)      # [8, 3, 5, 2]
+        pack = c.concat(pack, c.reshape(p[2], 8, 3, 5, 1), 3)                              # chain: reads the pack before it
+        pack = c.concat(pack, c.reshape(p[3], 8, 3, 5, 1), 3)                              # [8, 3, 5, 4]
+        wide = c.concat(p[0], p[1], 1)                                                     # [8, 6, 5]: interleaved slabs (dim 1)
+        wide2 = c.concat(wide, p[2], 1)                                                    # [8, 9, 5]
+        flat = c.cont(c.permute(pack, 0, 2, 1, 3))                                         # [8, 5, 3, 4]: a reader that is not a whole-tensor copy of the pack
+        dst = c.view_4d(cache, 8, 5, 3, 4, cache.t.nb[1], cache.t.nb[2], cache.t.nb[3], 2 * cache.t.nb[3])
+        stored = c.cpy(flat, dst)                                                          # into rows 2..5 of the persistent cache
+        outs = [pack, wide2, stored, cache]
+        if ty == "f32":
+            outs.append(c.scale(wide2, 2.0))                                               # a reader of another kind: the queue must have left before it
+            outs.append(c.add(c.cont(c.permute(wide2, 0, 2, 1, 3)), c.cont(c.permute(wide2, 0, 2, 1, 3))))
+        return c, x, cache, outs
+
+    res = []
+    for backend, opt in ((be, 1), (be, 0), (ref_be, None)):
+        if opt is not None:
+            backend.set_option("copy_batch", opt)
+        try:
+            c, x, cache, outs = build(backend)
+            k0 = be.get_stat("copies_batched") if backend is be else 0
+            got = run_graph(backend, c, outs, [(t, v) for t, v in zip(x, xs)] + [(cache, cache0)])
+            if backend is be and opt == 1:
+                assert be.get_stat("copies_batched") - k0 >= 4 and be.get_stat("copies_forwarded") >= 2, (be.get_stat("copies_batched") - k0, be.get_stat("copies_forwarded"))
+                n_on = be.get_stat("kernels_last_graph")
+            elif backend is be:
+                assert be.get_stat("kernels_last_graph") > n_on, (be.get_stat("kernels_last_graph"), n_on)
+            res.append([g.copy() for g in got])
+        finally:
+            if opt is not None:
+                backend.set_option("copy_batch", -1)
+    for a, b, r in zip(*res):
+        assert a.tobytes() == b.tobytes()                                                   # batched == one launch per node, bit for bit
+        if ty == "f32":
+            assert np.array_equal(a, r)
+        else:
+            assert np.array_equal(a.view(np.uint16), r.view(np.uint16))
