@@ -799,7 +799,7 @@ void compute_node(exec_state & s, int i) {
                 if (u > i && next_real_node(s, i) == u && fattn_gs_ok(f) && s.c->fa_scratch && s.c->fa_scratch_bytes >= fattn_gs_parts_bytes((int) n->ne[1], D) && mmv2_enabled()) {
                     const ggml_tensor * c = g->nodes[u];
                     const ggml_tensor * x = c->op == GGML_OP_MUL_MAT ? c->src[1] : nullptr;
-                    if (x && x->data == n->data && x->ne[0] == n->ne[0] * n->ne[1] && x->ne[1] == 1 && x->ne[2] == 1 && x->ne[3] == 1 && x != s.pn.m && mv1_node_ok(s, c) && !q80_mv1_node(s, c)) {
+                    if (x && x->data == n->data && x->ne[0] == n->ne[0] * n->ne[1] && x->ne[1] == 1 && x->ne[2] == 1 && x->ne[3] == 1 && x != s.pn.m && mv1_node_ok(s, c)) {                 // (K-quant or Q8_0 wo: mmv2_ok decides)
                         mv1_args t; t.nmat = 1; t.K = x->ne[0];
                         t.m[0] = { c->src[0]->data, c->src[0]->nb[1], (float *) c->data, 0, nullptr, 0, c->src[0]->ne[1], (int) c->src[0]->type };
                         t.parts = (const float *) s.c->fa_scratch; t.nslice = fattn_gs_nslice();

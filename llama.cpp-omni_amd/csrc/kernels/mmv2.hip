@@ -46,7 +46,7 @@ __global__ void __launch_bounds__(64 * NW) k_mv2(const char * W0, const float * 
                                                          uint32_t w_rs0, uint32_t qr0, uint32_t qr1, uint32_t qr2, float eps, uint32_t wgt /* MV2_WGT: first workgroups of m[1] / m[2], their types */, const mv2_dev rest) {
     __shared__ mv2_flags F;
     __shared__ double red[16];
-    static_assert(!PARTS || (!PAIR && NIT == 1 && TM != 4), "PARTS: one K-quant matrix of K = 4096 = n_head x 128 on the attention slices' partial states (x = the parts buffer)");
+    static_assert(!PARTS || (!PAIR && NIT == 1), "PARTS: one matrix of K = 4096 = n_head x 128 on the attention slices' partial states (x = the parts buffer)");
     constexpr int PBYTES = MV2_PARTS_NSL * 4096 * 4 + MV2_PARTS_NSL * 32 * 8;                          // the parts buffer (K = 4096)
     constexpr int XS = PARTS ? PBYTES + 512 - 32768 : 0;            // staging: the parts buffer + the fold's coefficient table instead of row + norm weights
     constexpr int RWN = PARTS ? MV2_PARTS_RW : RWK;                   // row waves (RWK: lab sweeps; 4 in the product)
@@ -135,7 +135,7 @@ __global__ void __launch_bounds__(64 * NW) k_mv2(const char * W0, const float * 
         if constexpr (PARTS) { if (c >= C - RWN) mv2_parts_loader((const char *) x, K, c - (C - RWN), resid_p, G0, ntask, mv2_lds_addr(stg), mv2_lds_addr(rstg), &F MV2_TR_ARG); }
         else if (c >= C - RWN) mv2_row_loader<RWN>(src, K, c - (C - RWN), resid_p, G0, ntask, mv2_lds_addr(stg), mv2_lds_addr(rstg), &F MV2_TR_ARG);
         uint32_t img_need = 4 * NIT;
-        if constexpr (PARTS) { if (c < 4) mv2_prologue_parts(K, c, im, stg, (float *) (stg + PBYTES), &F MV2_TR_ARG); }
+        if constexpr (PARTS) { if (c < 4) mv2_prologue_parts<TM == 4>(K, c, im, stg, (float *) (stg + PBYTES), &F MV2_TR_ARG); }
         else if (src.img) { if constexpr (Q80) mv2_image_copy_q80<C>(src.img, K, c, im, &F); else mv2_image_copy<C>(src.img, K, c, im, &F); img_need = C; }
         else if (c < PW) mv2_prologue<NIT, Q80, PW, RWN>(src, K, c, im, stg, red, &F MV2_TR_ARG);
         { uint32_t spins = 0; while (mv2_peek(MV2_FLAG(F.img_cnt)) < img_need) { __builtin_amdgcn_s_sleep(4); if (++spins > MV2_SPIN_MAX) __builtin_trap(); } asm volatile("" ::: "memory"); }
@@ -145,7 +145,7 @@ __global__ void __launch_bounds__(64 * NW) k_mv2(const char * W0, const float * 
         if (resid_p) { mv2_await(MV2_FLAG(F.x_landed), RWN); const int r = c + lane * C; if (r < ntask) resid = *(const float *) (rstg + r * 4); }
         MV2_STAMP(4);
         char * dst = R->m[mi_].dst;                        // (needed when the first results are stored)
-        if constexpr (Q80) mv2_consume_q80<PAIR ? 2 : 1, NIT, C, PAIR>(im, ringp, K, c, ntask, dst, G0 + c, resid, &F);
+        if constexpr (Q80) mv2_consume_q80<PAIR ? 2 : 1, NIT, C, PAIR, XS>(im, ringp, K, c, ntask, dst, G0 + c, resid, &F);
         else if (q4) {
             if constexpr (BL) mv2_consume_q4k_b<NIT, C, PAIR, XS>(im, ringp, K, c, ntask, dst, G0, rstg, resid_p != nullptr, &F);
             else mv2_consume_q4k<PAIR ? 2 : 1, NIT, C, PAIR, XS>(im, ringp, K, c, ntask, dst, G0 + c, resid, &F);
@@ -186,7 +186,7 @@ bool mmv2_ok(const mv1_args & a) {
         if (m.resid && m.nrows > (int64_t) cus * 256) return false;                           // the residual staging area holds 256 rows per workgroup
     }
     if (a.parts)                                                                             // attention slices' partial states: folded in the prologue (k_mv2 PARTS)
-        return a.nslice == MV2_PARTS_NSL && a.K == 4096 && a.nmat == 1 && !q80 && !a.W_up && !a.norm_w && !a.img && !a.x && ((uintptr_t) a.parts & 15) == 0;
+        return a.nslice == MV2_PARTS_NSL && a.K == 4096 && a.nmat == 1 && !a.W_up && !a.norm_w && !a.img && !a.x && ((uintptr_t) a.parts & 15) == 0;
     if (a.img) return ((uintptr_t) a.img & 15) == 0;
     return a.x && ((uintptr_t) a.x & 15) == 0 && ((uintptr_t) a.norm_w & 15) == 0;
 }
@@ -277,10 +277,15 @@ void mmv2(const mv1_args & a, hipStream_t st) {
         }
     }
 #endif
-    if (tm == 4) {                                                                           // Q8_0
+    if (tm == 4) {                                                                           // Q8_0 (the 8B LLM of BASELINE configs[4]): the same rule, its own measurements
+        static const int q80_nw = getenv("MI355X_MV2_Q80_NW") ? atoi(getenv("MI355X_MV2_Q80_NW")) : -1;      // A/B: 16 = the round-5 form everywhere
+        static const int q80_grp = getenv("MI355X_MV2_Q80_NW_GRP") ? atoi(getenv("MI355X_MV2_Q80_NW_GRP")) : -1;
+        // (tools/q80_decode_bench.py, three alternating repeats: one matrix 16 / q-k-v group 10: 552-553 tok/s; 10 / 10: 548-549; 16 / 16: 543-554, bimodal; 10 / 16: 545-547)
+        const int nwq = nw16 ? 16 : small ? (q80_nw > 0 ? q80_nw : 16) : (a.nmat > 1 && a.K == 4096) ? (q80_grp > 0 ? q80_grp : 10) : 16;
         if (pair)              mv2_launch<4, 1, true, true>(d, grid, st);
-        else if (a.K == 4096)  mv2_launch<4, 1, false, true>(d, grid, st);
-        else                   mv2_launch<4, 3, false, true>(d, grid, st);
+        else if (a.parts)      mv2_launch<4, 1, false, true, 10, true>(d, grid, st, a.parts);
+        else if (a.K == 4096)  { if (nwq == 10) mv2_launch<4, 1, false, true, 10>(d, grid, st); else if (nwq == 12) mv2_launch<4, 1, false, true, 12>(d, grid, st); else mv2_launch<4, 1, false, true>(d, grid, st); }
+        else                   { if (nwq == 10) mv2_launch<4, 3, false, true, 10>(d, grid, st); else if (nwq == 12) mv2_launch<4, 3, false, true, 12>(d, grid, st); else mv2_launch<4, 3, false, true>(d, grid, st); }
         return;
     }
     if (pair)               { mv2_launch<1, 1, true, true>(d, grid, st); return; }

@@ -457,6 +457,7 @@ static __device__ __forceinline__ void mv2_parts_loader(const char * parts, int 
     mv2_arrive(MV2_FLAG(F->rows_landed));
 }
 // prologue wave pw of 4 (K = 4096): blocks 4 pw + row; a 256-block is two heads (lane's m = 0, 1: head 2 b; m = 2, 3: head 2 b + 1)
+template <bool Q80 = false>
 static __device__ __forceinline__ void mv2_prologue_parts(int K, int pw, char * im, const char * stg, float * coef /* [16 blocks][8] */, mv2_flags * F MV2_TR_PARAM) {
     const int lane = threadIdx.x & 63, row = lane >> 4, i = lane & 15, nb = K >> 8, nh = K >> 7;
     constexpr int NSL = MV2_PARTS_NSL;
@@ -494,7 +495,7 @@ static __device__ __forceinline__ void mv2_prologue_parts(int K, int pw, char * 
         y[m] = acc;
     }
     MV2_STAMP(3);
-    mv2_q8k_rows(y, lane, b, nb, im);
+    if constexpr (Q80) mv2_q80_rows(y, lane, b, K, im); else mv2_q8k_rows(y, lane, b, nb, im);      // (the Q8_0 image of an all-Q8_0 model's wo: the same register layout)
     mv2_arrive(MV2_FLAG(F->img_cnt));
     MV2_STAMP(5);
 }
@@ -802,9 +803,9 @@ static __device__ __forceinline__ float mv2_q80_dot(const uint32_t (&w)[17], con
     acc = fmaf((float) s1, h2f((uint16_t) (w[8] >> 16)) * A.yd[1], acc);
     return acc;
 }
-template <int R, int NIT, int C, bool PAIR>
+template <int R, int NIT, int C, bool PAIR, int XS = 0>
 static __device__ __forceinline__ void mv2_consume_q80(const char * im, const char * ringp, int K, int c, int ntask, char * dst, int row0, float resid, mv2_flags * F) {
-    typedef mv2_geo<4352, R, NIT> geo;
+    typedef mv2_geo<4352, R, NIT, XS> geo;
     constexpr int SLOTB = geo::SLOTB, NS = geo::NS;
     const int lane = threadIdx.x & 63;
     mv2_q80_act A[NIT];

@@ -12,9 +12,9 @@ pytestmark = pytest.mark.gpu
 CFG = dict(n_embd=4096, n_layer=2, n_head=32, n_head_kv=8, head_dim=128, n_ff=12288, n_vocab=512, rms_eps=1e-6, rope_base=1e6, n_ctx_orig=4096)
 
 
-def _decode(pkg, backend, steps, embd, n_kv=256, seed=4):
+def _decode(pkg, backend, steps, embd, n_kv=256, seed=4, q80=False):
     from llama_cpp_omni_amd import qwen3
-    mdl = qwen3.Model(backend, CFG, qwen3.q4_k_m_types(CFG), n_ctx=n_kv, seed=seed, flash_attn=True)
+    mdl = qwen3.Model(backend, CFG, qwen3.uniform_types(CFG, pkg.GGML_TYPE_Q8_0) if q80 else qwen3.q4_k_m_types(CFG), n_ctx=n_kv, seed=seed, flash_attn=True)
     g1, I1, logits1 = mdl.build(1, n_kv)
     gr = g1.graph()
     ls = []
@@ -234,3 +234,29 @@ def test_deferred_layout_copies_forwarding_and_dropping_vs_reference_and_vs_in_o
             assert np.array_equal(a, r)
         else:
             assert np.array_equal(a.view(np.uint16), r.view(np.uint16))
+
+
+def test_group_slice_attention_folded_by_a_q8_0_wo(pkg, be, ref_be):
+    """The all-Q8_0 model (BASELINE configs[4] ships the 8B LLM as Q8_0): the wo launch of the LDS-DMA engine's Q8_0 form folds the attention slices' partial states and
+    builds the Q8_0 activation image from them (k_mv2<4, 1, false, true, 10, PARTS>).  66 decode steps at a view of 208 rows against the reference CPU backend and against the
+    per-head attention kernel + plain wo on the same backend."""
+    steps, NKV = 66, 208
+    rng = np.random.default_rng(63)
+    embd = rng.standard_normal((steps, CFG["n_embd"])).astype(np.float32)
+    n0 = be.get_stat("fattn_gs_launches")
+    be.set_option("fattn_gs", 1)
+    try:
+        lg = _decode(pkg, be, steps, embd, n_kv=NKV, seed=6, q80=True)
+        n1 = be.get_stat("fattn_gs_launches")
+        assert n1 - n0 >= CFG["n_layer"], (n0, n1)
+        be.set_option("fattn_gs", 0)
+        lo = _decode(pkg, be, steps, embd, n_kv=NKV, seed=6, q80=True)
+        assert be.get_stat("fattn_gs_launches") == n1
+    finally:
+        be.set_option("fattn_gs", -1)
+    lr = _decode(pkg, ref_be, steps, embd, n_kv=NKV, seed=6, q80=True)
+    e_old, e_ref, e_ref_old = nmse(lg, lo), nmse(lg, lr), nmse(lo, lr)
+    print(f"Q8_0 wo, group-slice vs per-head kernel {e_old:.1e}; vs reference {e_ref:.1e} (per-head kernel vs reference {e_ref_old:.1e})")
+    assert np.isfinite(lg).all()
+    assert e_old < 1e-4 and e_ref < 2e-3 and e_ref < 3.0 * e_ref_old + 1e-5, (e_old, e_ref, e_ref_old)
+    assert int((lg.argmax(-1) == lr.argmax(-1)).sum()) >= int(0.9 * steps)
