@@ -401,6 +401,7 @@ double mi355x_get_stat(struct ggml_backend * backend, const char * key) {
     if (!strcmp(key, "gemm_kq_launches"))   return (double) mi::gemm_variant_launches(3);
     if (!strcmp(key, "fattn_dma_launches")) return (double) mi::fattn_dma_launches();
     if (!strcmp(key, "fattn_gs_launches"))  return (double) mi::fattn_gs_launches();
+    if (!strcmp(key, "fattn_gs_far_launches")) return (double) mi::fattn_gs_far_launches();
     if (!strncmp(key, "prof_", 5)) {
         std::string k(key + 5);
         const size_t us = k.rfind("_us"), nn = k.rfind("_n"), by = k.rfind("_bytes");

@@ -247,7 +247,7 @@ bool   fattn_gs_ok(const fattn_args & a);        // ... and the group-slice form
 size_t fattn_gs_parts_bytes(int n_head, int D);
 int    fattn_gs_nslice();
 void   fattn_set_gs(int m);          // option "fattn_gs": the group-slice one-token attention + fold in wo's prologue: -1 default (on), 0 off, 1 on
-long   fattn_gs_launches();
+long   fattn_gs_launches(); long fattn_gs_far_launches();
 void   fattn_gs_merge(const float * parts, float * dst, int n_head, int D, hipStream_t st);
 // (cos, sin) * mscale of every (token, rotation pair): tab[T][D/2][2], what ggml_rope_cache_init / rope_yarn give for these positions
 void   rope_table(const int32_t * pos, const float * ff, const rope_params & rp, int T, int D, float * tab, hipStream_t st);

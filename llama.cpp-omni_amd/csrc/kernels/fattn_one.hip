@@ -393,9 +393,22 @@ __global__ void __launch_bounds__(64 * FGS_W) k_fattn_gs(FGS_LEAD_PARAMS, const 
     __shared__ __attribute__((aligned(16))) uint16_t q16[GQ][D];
     FA1_STAMP_DECL; FA1_STAMP(0);
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    // pk_: [7:0] KV heads, [8] neox, [9] norm, [18:10] rows of the view (<= 256), [31:19] v's row index relative to k's, x 8 B (signed)
+    // pk_: [7:0] KV heads, [8] neox, [9] norm, [18:10] rows of the view (<= 256), [30:19] v's row index relative to k's, x 8 B (signed), [31] FAR
     const int nkvh = (int) (pk_ & 0xffu), neox = (int) ((pk_ >> 8) & 1u), has_norm = (int) ((pk_ >> 9) & 1u), nkv_all = (int) ((pk_ >> 10) & 0x1ffu);
+    // FAR (bit 31, round 6): some operand lies beyond the reach of its pre-loaded offset (the graph's buffers can be tens of GB apart in a 288 GB address space -- after a model
+    // with resident F16 images was loaded between two of them, for one): every such pointer is then taken from the argument block instead, at the price of its ~0.85 us
+    const bool far_ = (pk_ >> 31) != 0u;
+    const fgs_kp kp0 = (fgs_kp) __builtin_amdgcn_kernarg_segment_ptr() + 56;
     const float * tab_ = (const float *) (qraw_ + (int64_t) tab_off16_ * 16);
+    const char * kraw_p = qraw_ + (int) (int16_t) (kv_off16_ & 0xffffu) * 16, * vraw_p = qraw_ + (int) (int16_t) (kv_off16_ >> 16) * 16;
+    const char * vview_p = k_ + (int64_t) v_off16_ * 16, * kw_p = (const char *) qw_ + kw_off_;
+    const char * mask_p = mask_off16_ ? qraw_ + (int64_t) mask_off16_ * 16 : nullptr;
+    const char * kidx_p = qraw_ + (int64_t) kidx_off8_ * 8, * vidx_p = kidx_p + (int64_t) ((int32_t) (pk_ << 1) >> 20) * 8;      // ([30:19]: v's index relative to k's, signed, x 8 B)
+    if (far_) {
+        tab_ = fgs_ld<const float *>(kp0, offsetof(fa1_dev, tab)); kraw_p = fgs_ld<const char *>(kp0, offsetof(fa1_dev, kraw)); vraw_p = fgs_ld<const char *>(kp0, offsetof(fa1_dev, vraw));
+        vview_p = fgs_ld<const char *>(kp0, offsetof(fa1_dev, v)); kw_p = (const char *) fgs_ld<const float *>(kp0, offsetof(fa1_dev, kw)); mask_p = fgs_ld<const char *>(kp0, offsetof(fa1_dev, mask));
+        kidx_p = fgs_ld<const char *>(kp0, offsetof(fa1_dev, kidx)); vidx_p = fgs_ld<const char *>(kp0, offsetof(fa1_dev, vidx));
+    }
     const int knb1_ = nkvh * D * 2;                               // cache rows hold the KV heads back to back (fattn_gs_ok); eps rides in the pre-loaded scalars instead: the
                                                                   // chains then need nothing of the argument block (its scalar loads come back ~0.85 us into the launch)
     const int sp = __builtin_amdgcn_readfirstlane((int) blockIdx.x / nkvh), g = (int) blockIdx.x - sp * nkvh;        // workgroups of one KV head are congruent modulo the KV head count: one XCD's L2 serves the group
@@ -407,7 +420,7 @@ __global__ void __launch_bounds__(64 * FGS_W) k_fattn_gs(FGS_LEAD_PARAMS, const 
         const uint32_t vo = (uint32_t) (lane >> 4) * (uint32_t) knb1_ + (uint32_t) (lane & 15) * 16u;
         const int nb = nkv > 0 ? (nkv - 1) * knb1_ + D * 2 : 0;
         const __amdgpu_buffer_rsrc_t krs = fa1_rsrc_u(k_ + g * (D * 2) + (int64_t) row0 * knb1_, nb);
-        const __amdgpu_buffer_rsrc_t vrs = fa1_rsrc_u(k_ + (int64_t) v_off16_ * 16 + g * (D * 2) + (int64_t) row0 * knb1_, nb);
+        const __amdgpu_buffer_rsrc_t vrs = fa1_rsrc_u(vview_p + g * (D * 2) + (int64_t) row0 * knb1_, nb);
         const uint32_t kl = (uint32_t) (uintptr_t) (__attribute__((address_space(3))) void *) kt, vl = (uint32_t) (uintptr_t) (__attribute__((address_space(3))) void *) vt;
 #pragma unroll
         for (int i = 0; i < RS / 4 / FGS_W; ++i) {                        // instruction j of 16: rows 4 j .. 4 j + 3
@@ -423,24 +436,22 @@ __global__ void __launch_bounds__(64 * FGS_W) k_fattn_gs(FGS_LEAD_PARAMS, const 
     FA1_STAMP(4);
     // waves 0 .. 3: the q chain of head 4 g + wave; wave 4: the k chain; wave 5: the v head (elements lane, lane + 64)
     const int  e0 = neox ? lane : 2 * lane, e1 = neox ? lane + HALF : 2 * lane + 1;
-    const int kraw_off_ = (int) (int16_t) (kv_off16_ & 0xffffu) * 16, vraw_off_ = (int) (int16_t) (kv_off16_ >> 16) * 16;
-    const char * xb = wave < GQ ? qraw_ + (g * GQ + wave) * (D * 4) : (wave == GQ ? qraw_ + kraw_off_ + g * (D * 4) : qraw_ + vraw_off_ + g * (D * 4));
+    const char * xb = wave < GQ ? qraw_ + (g * GQ + wave) * (D * 4) : (wave == GQ ? kraw_p + g * (D * 4) : vraw_p + g * (D * 4));
     const __amdgpu_buffer_rsrc_t xrs = fa1_rsrc(xb, wave <= GQ + 1 ? D * 4 : 0);
     const uint32_t xo0 = wave <= GQ ? e0 * 4 : lane * 4, xo1 = wave <= GQ ? e1 * 4 : (lane + 64) * 4;
     const float x0 = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(xrs, xo0, 0, 0)), x1 = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(xrs, xo1, 0, 0));
-    const __amdgpu_buffer_rsrc_t wrs = fa1_rsrc(wave < GQ ? (const char *) qw_ : (const char *) qw_ + kw_off_, (wave <= GQ && has_norm) ? D * 4 : 0);
+    const __amdgpu_buffer_rsrc_t wrs = fa1_rsrc(wave < GQ ? (const char *) qw_ : kw_p, (wave <= GQ && has_norm) ? D * 4 : 0);
     const __amdgpu_buffer_rsrc_t trs = fa1_rsrc(tab_, wave <= GQ ? D * 4 : 0);
     const float w0 = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(wrs, xo0, 0, 0)), w1 = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(wrs, xo1, 0, 0));
     const u32x2 tcs = __builtin_amdgcn_raw_buffer_load_b64(trs, lane * 8, 0, 0);
     // the mask row (one f16 row shared by the heads: fattn_gs_ok), lane = row of the slice, exact bounds (rows past the view are set to -inf in the soft-max): its address
     // is pre-loaded too -- behind the argument block it would be requested 0.9 us into the launch and the soft-max would wait for it
-    const char * a_mask = mask_off16_ ? qraw_ + (int64_t) mask_off16_ * 16 : nullptr;
+    const char * a_mask = mask_p;
     const __amdgpu_buffer_rsrc_t mrs = fa1_rsrc(a_mask ? a_mask + row0 * 2 : a_mask, (a_mask && wave < GQ) ? nkv * 2 : 0);
     const uint16_t mraw = __builtin_amdgcn_raw_buffer_load_b16(mrs, lane * 2, 0, 0);
     // ... and the new token's row index (k's and v's: scalar loads -- constant address space + a uniform address; the indices were written before the launch)
     typedef const volatile __attribute__((address_space(4))) int * fgs_cint;
-    const char * kidx_p = qraw_ + (int64_t) kidx_off8_ * 8;
-    const int krow_u = *(fgs_cint) (uintptr_t) kidx_p, vrow_u = *(fgs_cint) (uintptr_t) (kidx_p + (int64_t) ((int32_t) pk_ >> 19) * 8);
+    const int krow_u = *(fgs_cint) (uintptr_t) kidx_p, vrow_u = *(fgs_cint) (uintptr_t) vidx_p;
     __builtin_amdgcn_sched_barrier(0);                             // (everything above needs only the pre-loaded arguments)
     // Every field of the argument block the kernel uses is REQUESTED here (volatile scalar loads through the kernarg segment pointer: issued in program order, waited for
     // at the first use) and none is used before barrier 1: the block's loads come back ~0.85 us into the launch, and the chains -- raw rows, norm weights, (cos, sin), eps:
@@ -850,9 +861,10 @@ void flash_attn_one(const fa_dev & f, int D, const float * rope_tab, hipStream_t
 size_t fattn_gs_parts_bytes(int n_head, int D) { return (size_t) FGS_NSL * n_head * D * 4 + (size_t) FGS_NSL * n_head * 2 * 4; }
 int    fattn_gs_nslice() { return FGS_NSL; }
 static int  g_gs_mode = -1;                          // option "fattn_gs": -1 = MI355X_FA_NO_GS decides (default on), 0 off, 1 on
-static long g_gs_launches = 0;
+static long g_gs_launches = 0, g_gs_far_launches = 0;
 void fattn_set_gs(int m) { g_gs_mode = m; }
 long fattn_gs_launches() { return g_gs_launches; }
+long fattn_gs_far_launches() { return g_gs_far_launches; }
 bool fattn_gs_ok(const fattn_args & f) {
     static const bool env_off = getenv("MI355X_FA_NO_GS") != nullptr;
     if (!(g_gs_mode >= 0 ? g_gs_mode != 0 : !env_off) || !fattn_one_ok(f)) return false;
@@ -863,17 +875,17 @@ bool fattn_gs_ok(const fattn_args & f) {
     if (((uintptr_t) P.qraw & 15) != 0 || ((uintptr_t) P.kraw & 15) != 0 || ((uintptr_t) P.vraw & 15) != 0 || ((uintptr_t) f.k.p & 15) != 0 || ((uintptr_t) f.v.p & 15) != 0) return false;
     if (f.mask && ((((uintptr_t) f.mask->p) & 3) != 0 || f.mask->nb[2] % 4 != 0)) return false;
     const int64_t ko = (const char *) P.kraw - (const char *) P.qraw, vo = (const char *) P.vraw - (const char *) P.qraw, vco = ((const char *) f.v.p - (const char *) f.k.p) / 16;
-    if (ko / 16 != (int64_t) (int16_t) (ko / 16) || vo / 16 != (int64_t) (int16_t) (vo / 16) || vco != (int64_t) (int32_t) vco) return false;     // (k / v rows within +-512 KB of q's: ggml-alloc places the three results side by side)
+    (void) ko; (void) vo; (void) vco;                                 // (out of an offset's reach: the launch takes the pointers from the argument block, fattn_gs_far)
     if (f.mask) {                                                    // one mask row for every head, 16-byte aligned, within +-32 GB of the q rows
         const int64_t mo = (const char *) f.mask->p - (const char *) P.qraw;
-        if (f.mask->ne[2] != 1 || (((uintptr_t) f.mask->p) & 15) != 0 || mo == 0 || mo / 16 != (int64_t) (int32_t) (mo / 16)) return false;
+        if (f.mask->ne[2] != 1 || (((uintptr_t) f.mask->p) & 15) != 0 || mo == 0) return false;
     }
-    if (P.qw) { const int64_t wo = (const char *) P.kw - (const char *) P.qw; if (!P.kw || wo != (int64_t) (int32_t) wo) return false; }
+    if (P.qw && !P.kw) return false;
     {   // the (cos, sin) table and the new token's row indices are reached through pre-loaded offsets from the q rows: the table 16-byte units, k's index 8-byte units, v's index
         // within +-32 KB of k's (the two index tensors are graph inputs allocated side by side)
         if (!f.rope_tab || !P.kidx || !P.vidx) return false;
         const int64_t to = (const char *) f.rope_tab - (const char *) P.qraw, io = (const char *) P.kidx - (const char *) P.qraw, vi = (const char *) P.vidx - (const char *) P.kidx;
-        if ((to & 15) != 0 || to / 16 != (int64_t) (int32_t) (to / 16) || (io & 7) != 0 || io / 8 != (int64_t) (int32_t) (io / 8) || (vi & 7) != 0 || vi / 8 < -4096 || vi / 8 > 4095) return false;
+        if ((to & 15) != 0 || (io & 7) != 0 || (vi & 7) != 0) return false;
     }
     return true;
 }
@@ -891,11 +903,19 @@ void flash_attn_gs(const fa_dev & f, int D, const float * rope_tab, float * part
     a.eps = P.eps; a.scale = f.scale; a.max_bias = 0.0f; a.logit_softcap = 0.0f; a.m0 = 1.0f; a.m1 = 1.0f;
     a.n_head = f.nh; a.nkvh_log2 = -1;
     const int nkvh = f.nh / 4;
-    const uint32_t pk = (uint32_t) nkvh | ((uint32_t) a.neox << 8) | ((uint32_t) a.has_norm << 9) | ((uint32_t) f.nkv << 10) | ((uint32_t) (int32_t) ((a.vidx - a.kidx) / 8) << 19);
+    // does every pre-loaded offset reach its operand?  (k / v rows +-512 KB from q's, table / mask +-32 GB, k's index +-16 GB, v's index +-16 KB from k's, k's norm weights +-2 GB
+    // from q's, the V view +-32 GB from the K view)  If not: FAR, the kernel reads the pointers from the argument block
+    auto fits = [](int64_t v, int bits) { return v >= -((int64_t) 1 << (bits - 1)) && v < ((int64_t) 1 << (bits - 1)); };
+    const int64_t ko = (a.kraw - a.qraw) / 16, vo = (a.vraw - a.qraw) / 16, to = ((const char *) a.tab - a.qraw) / 16, io = (a.kidx - a.qraw) / 8, vi = (a.vidx - a.kidx) / 8,
+                  mo = a.mask ? (a.mask - a.qraw) / 16 : 0, wo = a.qw ? (const char *) a.kw - (const char *) a.qw : 0, vco = (a.v - a.k) / 16;
+    static const bool force_far = getenv("MI355X_FA_GS_FAR") != nullptr;          // (test / A-B switch)
+    const bool far = force_far || !(fits(ko, 16) && fits(vo, 16) && fits(to, 32) && fits(io, 32) && fits(vi, 12) && fits(mo, 32) && fits(wo, 32) && fits(vco, 32));
+    if (far) ++g_gs_far_launches;
+    const uint32_t pk = (uint32_t) nkvh | ((uint32_t) a.neox << 8) | ((uint32_t) a.has_norm << 9) | ((uint32_t) f.nkv << 10) | (far ? 0x80000000u : (((uint32_t) (int32_t) vi & 0xfffu) << 19));
     ++g_gs_launches;
-    const uint32_t kv16 = (uint32_t) (uint16_t) (int16_t) ((a.kraw - a.qraw) / 16) | ((uint32_t) (uint16_t) (int16_t) ((a.vraw - a.qraw) / 16) << 16);
-    k_fattn_gs<128><<<dim3((unsigned) (nkvh * FGS_NSL)), dim3(64 * FGS_W), 0, st>>>(a.qraw, a.qw, a.k, (int) (((const char *) a.tab - a.qraw) / 16), (int) ((a.kidx - a.qraw) / 8), kv16, a.mask ? (int) ((a.mask - a.qraw) / 16) : 0, a.qw ? (int) ((const char *) a.kw - (const char *) a.qw) : 0,
-                                                                                      (int) ((a.v - a.k) / 16), a.eps, pk, a);
+    const uint32_t kv16 = far ? 0u : ((uint32_t) (uint16_t) (int16_t) ko | ((uint32_t) (uint16_t) (int16_t) vo << 16));
+    k_fattn_gs<128><<<dim3((unsigned) (nkvh * FGS_NSL)), dim3(64 * FGS_W), 0, st>>>(a.qraw, a.qw, a.k, far ? 0 : (int) to, far ? 0 : (int) io, kv16, far ? 0 : (int) mo, far ? 0 : (int) wo,
+                                                                                      far ? 0 : (int) vco, a.eps, pk, a);
 }
 // the slices' partial states folded into the f32 rows [n_head * D] (what the wo launch does in its prologue; used when that launch cannot take the parts)
 __global__ void k_fattn_gs_merge(const float * parts, float * dst, int n_head, int D) {

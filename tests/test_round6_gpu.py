@@ -42,6 +42,9 @@ def test_group_slice_attention_with_the_fold_in_wo_vs_reference_and_vs_the_per_h
         lg = _decode(pkg, be, steps, embd, n_kv=NKV)
         n1 = be.get_stat("fattn_gs_launches")
         assert n1 - n0 >= CFG["n_layer"] * 1, (n0, n1)                   # the path ran (captured launches are counted once, at capture)
+        import os
+        if os.environ.get("MI355X_FA_GS_FAR"):                          # (the subprocess of test_group_slice_attention_far_operands)
+            assert be.get_stat("fattn_gs_far_launches") >= CFG["n_layer"]
         be.set_option("fattn_gs", 0)
         lo = _decode(pkg, be, steps, embd, n_kv=NKV)
         assert be.get_stat("fattn_gs_launches") == n1                   # ... and the option switches it off
@@ -260,3 +263,16 @@ def test_group_slice_attention_folded_by_a_q8_0_wo(pkg, be, ref_be):
     assert np.isfinite(lg).all()
     assert e_old < 1e-4 and e_ref < 2e-3 and e_ref < 3.0 * e_ref_old + 1e-5, (e_old, e_ref, e_ref_old)
     assert int((lg.argmax(-1) == lr.argmax(-1)).sum()) >= int(0.9 * steps)
+
+
+def test_group_slice_attention_far_operands():
+    """k_fattn_gs reaches the rope table, the mask row, the new token's row indices, the raw k / v rows and k's norm weights through offsets in pre-loaded scalars; an operand out
+    of an offset's reach (buffers tens of GB apart: the full -m gpu run allocates and frees several models before this file, and both counter tests of this file found the
+    path refused there) switches the launch to FAR -- every such pointer from the argument block.  MI355X_FA_GS_FAR=1 forces that form: the two group-slice decode tests of this
+    file again, in a process of their own."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MI355X_FA_GS_FAR="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_round6_gpu.py"), "-q", "-m", "gpu", "-x", "-k",
+                        "group_slice_attention_with_the_fold or folded_by_a_q8_0_wo"], env=env, capture_output=True, text=True, timeout=1500, cwd=root)
+    assert r.returncode == 0 and "2 passed" in r.stdout, (r.stdout[-1500:], r.stderr[-500:])

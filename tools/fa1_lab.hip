@@ -84,7 +84,7 @@ int main(int argc, char ** argv) {
     if (getenv("FA1_PTRS")) fprintf(stderr, "qkv %p qw %p kw %p tab %p dst %p kc %p vc %p mask %p idx %p parts %p (%zu B) dst2 %p\n", qkv, qw, kw, tab, dst, kc, vc, mask, idx, parts, fattn_gs_parts_bytes(NH, D), dst2);
     auto gs = [&](int s) {
         fa1_dev a = args(s % NL); a.nsplit = FGS_NSL; a.part = parts;
-        const uint32_t pk = (uint32_t) NKVH | (1u << 8) | (1u << 9) | ((uint32_t) nkv << 10) | ((uint32_t) (int32_t) ((a.vidx - a.kidx) / 8) << 19);
+        const uint32_t pk = (uint32_t) NKVH | (1u << 8) | (1u << 9) | ((uint32_t) nkv << 10) | (((uint32_t) (int32_t) ((a.vidx - a.kidx) / 8) & 0xfffu) << 19) | (getenv("FA1_LAB_FAR") ? 0x80000000u : 0u);
         k_fattn_gs<128><<<dim3(NKVH * FGS_NSL), dim3(64 * FGS_W), 0, st>>>(a.qraw, a.qw, a.k, (int) (((const char *) a.tab - a.qraw) / 16), (int) ((a.kidx - a.qraw) / 8), (uint32_t) (uint16_t) (int16_t) ((a.kraw - a.qraw) / 16) | ((uint32_t) (uint16_t) (int16_t) ((a.vraw - a.qraw) / 16) << 16), (int) ((a.mask - a.qraw) / 16), (int) ((const char *) a.kw - (const char *) a.qw), (int) ((a.v - a.k) / 16), a.eps, pk, a);
     };
     {   // result check: the group-slice form + merge against the one-workgroup-per-head form, same cache (the new rows are written by both: identical values)
