@@ -304,6 +304,7 @@ void mmv2(const mv1_args & a, hipStream_t st) {
             else              mv2_launch<2, 1, false, true, 10>(d, grid, st);
         } else {
             if (tm == 1)      mv2_launch<1, 1, false, true>(d, grid, st);
+            else if (tm == 2 && a.nmat == 1 && !nw16) mv2_launch<2, 1, false, true, 9>(d, grid, st);      // the Q6_K lm-head (151936 rows): 78.9 us at sixteen waves, 76.4 at nine (tools/mmv2_lab.hip shape 8)
             else if (tm == 2) mv2_launch<2, 1, false, true>(d, grid, st);
             else              mv2_launch<3, 1, false, true>(d, grid, st);
         }

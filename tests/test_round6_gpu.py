@@ -32,8 +32,9 @@ def test_group_slice_attention_with_the_fold_in_wo_vs_reference_and_vs_the_per_h
     round-5 launches (one workgroup per head, plain wo) on the same backend.  (a) carries the documented deviation of flash-attention on this backend
     (V accumulated in f32, reference f16) through two layers; (b) differs only in the order of float sums."""
     steps = 70
-    NKV = 224           # (a view length no other test decodes at: the launches are counted where they are CAPTURED, and a graph another test left in the backend's capture cache -- same shapes
-                        #  at the same re-used addresses -- would be replayed without counting; 224 rows = 3.5 slices: the last slice is half empty)
+    NKV = 224           # (a view length of its own -- launches are counted where they are captured -- and 3.5 slices: the last slice is half empty.  In the first full -m gpu run of
+                        #  round 6 this assertion failed for another reason: the path was REFUSED, its operands out of reach of the kernel's 32-bit offsets after the allocations of
+                        #  the test files before this one; the launch now switches to its FAR form instead: test_group_slice_attention_far_operands)
     rng = np.random.default_rng(61)
     embd = rng.standard_normal((steps, CFG["n_embd"])).astype(np.float32)
     n0 = be.get_stat("fattn_gs_launches")
