@@ -20,6 +20,7 @@ struct attn_f32_dev {
     int nq, nkv, H, ldp;                                // H: heads per batch element of the destination's split of the head-batch index
     float s1, b1, s2;
     int has_scale;
+    int xcd_map;                                        // head-batch count % 8 == 0: heads are dealt to XCDs (see the kernel)
 };
 
 extern __shared__ float af_lds[];
@@ -29,7 +30,15 @@ __global__ void __launch_bounds__(256) k_attn_f32(const attn_f32_dev a) {
     typedef float acc4 __attribute__((ext_vector_type(4)));
     float * S = af_lds;                                  // [16][ldp]
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, r16 = lane & 15, gq = lane >> 4;
-    const int q0 = (int) blockIdx.x * 16, hb = (int) blockIdx.y;
+    // workgroup -> (query tile, head-batch): dispatch order (x fastest) deals consecutive workgroups round-robin over the 8 XCDs, each with an L2 of its own.  With the plain
+    // (blockIdx.x, blockIdx.y) reading every XCD sees EVERY head's K and V^T (SigLip2: 16 heads x 590 KB = 9.4 MB through each 4 MB L2: FETCH_SIZE 80 MB per launch); when the
+    // head-batch count is a multiple of 8 the workgroups an XCD receives (linear id mod 8) are given heads xcd, xcd + 8, ... -- two heads, 1.2 MB per L2
+    int qt = (int) blockIdx.x, hb = (int) blockIdx.y;
+    if (a.xcd_map) {
+        const int L = (int) blockIdx.x + (int) gridDim.x * (int) blockIdx.y, xcd = L & 7, idx = L >> 3;
+        hb = xcd + 8 * (idx / (int) gridDim.x); qt = idx % (int) gridDim.x;
+    }
+    const int q0 = qt * 16;
     const char * Q = a.q + (size_t) (hb % a.q_H) * a.q_bs + (size_t) (hb / a.q_H) * a.q_bs2, * K = a.k + (size_t) (hb % a.k_H) * a.k_bs + (size_t) (hb / a.k_H) * a.k_bs2,
                * VT = a.vt + (size_t) (hb % a.v_H) * a.v_bs + (size_t) (hb / a.v_H) * a.v_bs2;
     // ---- 1. scores
@@ -185,6 +194,8 @@ void attn_f32(const attn_f32_args & a, hipStream_t st) {
     d.v_ks = a.v_ks; d.v_H = a.v_ks ? (int) a.v_H : (int) a.HB; d.v_bs2 = a.v_ks ? a.v_bs2 : 0;
     d.nq = (int) a.nq; d.nkv = (int) a.nkv; d.H = (int) a.H; d.ldp = (int) (((a.nkv + 63) / 64) * 64 + 4);
     d.s1 = a.s1; d.b1 = a.b1; d.s2 = a.s2; d.has_scale = a.has_scale ? 1 : 0;
+    static const bool no_xcd = getenv("MI355X_ATTN_F32_NO_XCD") != nullptr;
+    d.xcd_map = !no_xcd && a.HB % 8 == 0 ? 1 : 0;
     const int lds = 16 * d.ldp * 4;
     const bool v4 = !a.v_ks && a.nkv % 4 == 0 && (((uintptr_t) a.vt | a.v_rs | a.v_bs) & 15) == 0;
     const dim3 grid((unsigned) ((a.nq + 15) / 16), (unsigned) a.HB);
