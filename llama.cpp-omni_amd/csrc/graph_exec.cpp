@@ -945,7 +945,7 @@ void copy_flush(exec_state & s) {
         s.n_copies_batched += n; s.c->stat_copies_batched += n;
     }
     ++s.n_kernels;
-    s.cq.clear(); s.cq_dead.clear();
+    s.cq.clear(); s.cq_dead.clear(); s.vplain.t = nullptr;
 }
 static bool same_desc(const tdesc & a, const tdesc & b) {
     if (a.p != b.p) return false;
@@ -1140,6 +1140,7 @@ void run_nodes(exec_state & s, ggml_cgraph * g) {
             }
         }
     }
+    if (s.vplain.t) { fprintf(stderr, "[mi355x] graph_compute: a V tensor written as rows was never read by its attention launch\n"); abort(); }
     copy_flush(s);
     gs_materialise(s);                                       // (the attention node was the graph's last launching node)
     if (launch_log && !s.capturing) { fprintf(launch_log, "== end of a graph of %d nodes\n", g->n_nodes); fflush(launch_log); }

@@ -201,7 +201,31 @@ bool exec_gemm_group(exec_state & s, int i) {
             else if (S->ne[0] == N && S->ne[1] == M && S->ne[2] == 1 && S->ne[3] == 1 && S->nb[0] == R->nb[1] && S->nb[1] == 4 &&
                      Cp->ne[0] == N && Cp->ne[1] == M && Cp->ne[2] == 1 && Cp->ne[3] == 1 && Cp->nb[0] == 2 && Cp->nb[1] % 2 == 0) { ms = Cp->nb[1]; rs = 2; }   // the transposed view: V rows
             else if (S->ne[0] == N && S->ne[1] > 0 && S->ne[1] * S->ne[2] == M && S->ne[3] == 1 && S->nb[0] == R->nb[1] && S->nb[1] == 4 && S->nb[2] == (size_t) S->ne[1] * 4 &&
-                     is_contiguous(Cp) && Cp->ne[0] == N && Cp->ne[1] == S->ne[1] && Cp->ne[2] == S->ne[2] && Cp->ne[3] == 1) { ms = (size_t) N * 2; rs = 2; }       // [n_tokens, D, H] of PERMUTE(1, 2, 0, 3): V^T per head (an encoder's V CAST)
+                     is_contiguous(Cp) && Cp->ne[0] == N && Cp->ne[1] == S->ne[1] && Cp->ne[2] == S->ne[2] && Cp->ne[3] == 1) {       // [n_tokens, D, H] of PERMUTE(1, 2, 0, 3): V^T per head (an encoder's V CAST)
+                ms = (size_t) N * 2; rs = 2;
+                // ... unless its one reader is the K.Q -> SOFT_MAX -> V^T.P chain this executor runs as ONE flash-attention launch: then the tensor's bytes are written as V rows
+                // ([D, n_tokens, H], the layout K has) and the launch is the plain-V form, whose head-size-64 kernel is the LDS-DMA ring (Whisper 1500 x 1500 x 16: 53.7 -> 39.5 us)
+                static const bool no_vplain = getenv("MI355X_NO_ATTN_VPLAIN") != nullptr;
+                const int64_t Dh = S->ne[1];
+                int u2 = -1;                                               // Cp's one reader besides the CPY node itself (ggml_cast names its result as src[1])
+                if (!no_vplain && Dh == 64 && !s.vplain.t) {
+                    auto us = s.users.find(Cp);
+                    int cnt = 0;
+                    if (us != s.users.end()) for (int u : us->second) if (u != cj) { u2 = u; ++cnt; }
+                    if (cnt != 1 || is_out(s, Cp)) u2 = -1;
+                }
+                if (u2 > cj && !s.done[u2] && g->nodes[u2]->op == GGML_OP_MUL_MAT && g->nodes[u2]->src[0] == Cp && g->nodes[u2]->src[1] && g->nodes[u2]->src[1]->op == GGML_OP_SOFT_MAX) {
+                    const ggml_tensor * SMn = g->nodes[u2]->src[1];
+                    const ggml_tensor * M1n = SMn->src[0];
+                    auto i1 = M1n ? s.index.find(M1n) : s.index.end();
+                    if (i1 != s.index.end() && i1->second > cj && M1n->op == GGML_OP_MUL_MAT && M * 2 % 16 == 0 && ((uintptr_t) Cp->data & 15) == 0 && exec_attn_sm_prefill(s, i1->second, true)) {
+                        ms = 2; rs = (size_t) M * 2;
+                        s.vplain.t = Cp;
+                        s.vplain.v.p = Cp->data; s.vplain.v.ne[0] = Dh; s.vplain.v.ne[1] = N; s.vplain.v.ne[2] = S->ne[2]; s.vplain.v.ne[3] = 1;
+                        s.vplain.v.nb[0] = 2; s.vplain.v.nb[1] = (size_t) M * 2; s.vplain.v.nb[2] = (size_t) Dh * 2; s.vplain.v.nb[3] = (size_t) M * 2 * (size_t) N;
+                    }
+                }
+            }
             else continue;
             if (ms == 2 && (((uintptr_t) Cp->data & 7) != 0 || rs % 8 != 0)) continue;
             int item[8]; int ni = 0;
@@ -1169,12 +1193,14 @@ bool exec_attn_sm_prefill(exec_state & s, int i, bool dry) {       // dry: would
         if (k != smi && k != m2 && !s.done[k] && !is_noop(g->nodes[k])) return false;       // something else runs in between: keep the separate launches
     fattn_args f; tdesc m;
     f.q = td(fq); f.k = td(fk); f.v = s.va.cast == fv ? s.va.v : td(fv); f.v_transposed = true; f.kv_type = GGML_TYPE_F16;
+    const bool vplain = s.vplain.t == fv;                              // (the V^T tensor's bytes hold V rows: exec_gemm_group wrote them that way for this launch)
     f.dst = td(C);
     f.dst.ne[0] = D; f.dst.ne[1] = H; f.dst.ne[2] = nq; f.dst.ne[3] = ns;
     f.dst.nb[0] = 4; f.dst.nb[1] = (size_t) D * 4; f.dst.nb[2] = (size_t) D * H * 4; f.dst.nb[3] = (size_t) D * H * nq * 4;
     f.mask = nullptr; f.sinks = nullptr; f.scale = op_param_f32(SM, 0); f.max_bias = 0.0f; f.logit_softcap = 0.0f;
     f.scratch = nullptr; f.scratch_bytes = 0;
-    if (!fattn_sm_prefill_ok(f)) return false;
+    if (!fattn_sm_prefill_ok(f)) { if (vplain) { fprintf(stderr, "[mi355x] exec_attn_sm_prefill: the chain whose V was written as rows is refused\n"); abort(); } return false; }
+    if (vplain && !dry) { f.v = s.vplain.v; f.v_transposed = false; s.vplain.t = nullptr; }
     if (mk) {
         const size_t map_b0 = attn_sm_mask16_off(nq, nkv), m16_b0 = mk->type == GGML_TYPE_F32 ? (size_t) mk->ne[1] * (size_t) nkv * 2 : 0;
         if (!s.c->fa_scratch || s.c->fa_scratch_bytes < map_b0 + m16_b0) return false;

@@ -83,6 +83,9 @@ struct exec_state {
     // a V^T that a fused soft-max attention will read where it LIES (a transposed V cache) instead of from the CONT + CAST copies the graph makes of it: `cast` = the CAST node the
     // attention's second mat-mul names, `v` = the same elements in the cache (try_alias_vt in graph_exec.cpp)
     struct { const ggml_tensor * cast = nullptr; tdesc v; int cont_i = -1, cast_i = -1; } va;
+    // an encoder's V^T CAST tensor `t` whose bytes were written as V ROWS instead ([D, n_tokens, H] like K: the GEMM epilogue that makes the f16 copy chooses the layout): its one
+    // reader, the flash-attention-off chain exec_attn_sm_prefill fuses, then runs as plain flash attention on the LDS-DMA ring kernel (head size 64); set by exec_gemm_group
+    struct { const ggml_tensor * t = nullptr; tdesc v; } vplain;
     // deferred split-K reduction of a GROUPED launch (wq / wk / wv of a prefill ubatch): the results A[0..n) still lie as `nsplit` slabs in gemm_partial (slab = `slab` floats,
     // matrix q a dense [N][M[q]] block at + off[q]); the q / k norm + rope + store launch behind them sums the slabs itself (k_norm_rope_v4), anybody else gets materialise_group
     struct { int n = 0; const ggml_tensor * A[3] = { nullptr, nullptr, nullptr }; size_t off[3] = { 0, 0, 0 }; int64_t M[3] = { 0, 0, 0 }; int nsplit = 0; size_t slab = 0; int64_t N = 0; } prm;
