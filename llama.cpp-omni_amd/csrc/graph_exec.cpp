@@ -81,7 +81,7 @@ bool mm_takes_gemm_any(const ggml_tensor * n) {
            ((x->type == GGML_TYPE_F32 && x->nb[0] == 4) || (x->type == GGML_TYPE_F16 && x->nb[0] == 2 && w->type == GGML_TYPE_F16)) && w->nb[0] == (w->type == GGML_TYPE_F16 ? 2u : 4u) && n->nb[0] == 4 &&
            x->ne[2] * x->ne[3] <= 65535 && M < (1ll << 31) && N < (1ll << 31) && K < (1ll << 31);
 }
-void op_mul_mat(exec_state & s, const ggml_tensor * dst, const ggml_tensor * out, const float * bias, const mm_sibling * sib, int nsib, bool * sib_taken) {
+void op_mul_mat(exec_state & s, const ggml_tensor * dst, const ggml_tensor * out, const float * bias, const mm_sibling * sib, int nsib, bool * sib_taken, int act) {
     const ggml_tensor * w = dst->src[0];
     const ggml_tensor * x = dst->src[1];
     if (!out) out = dst;
@@ -183,7 +183,7 @@ void op_mul_mat(exec_state & s, const ggml_tensor * dst, const ggml_tensor * out
         } else {
             a.X = (const char *) x->data + k_done * (x->type == GGML_TYPE_F16 ? 2 : 4); a.x_rs = x->nb[1]; a.x_nb2 = x->nb[2]; a.x_nb3 = x->nb[3]; a.x_f16 = x->type == GGML_TYPE_F16;
         }
-        a.dst = (float *) out->data; a.dst_cs = out->nb[1]; a.dst_nb2 = out->nb[2]; a.dst_nb3 = out->nb[3]; a.accumulate = k_done > 0; a.bias = bias;
+        a.dst = (float *) out->data; a.dst_cs = out->nb[1]; a.dst_nb2 = out->nb[2]; a.dst_nb3 = out->nb[3]; a.accumulate = k_done > 0; a.bias = bias; a.act = act;
         a.M = M; a.N = N; a.K = K - k_done; a.nbatch = (int) (ne12 * ne13); a.ne12 = (int) ne12; a.r2 = (int) r2; a.r3 = (int) r3;
         if (s.c->gemm_partial && !s.c->fa_counters && !s.capturing) {      // (first use is an eager submission: captures come from the second on)
             if (hipMalloc((void **) &s.c->fa_counters, 1024 * sizeof(unsigned)) == hipSuccess) HIP_CHECK(hipMemsetAsync(s.c->fa_counters, 0, 1024 * sizeof(unsigned), s.st));

@@ -52,7 +52,7 @@ size_t prepare_act(exec_state & s, const ggml_tensor * x, act_kind kind);
 const char * mmv_class(int type);
 const uint16_t * weight_shadow(exec_state & s, const ggml_tensor * w, const char * wp, int64_t K, int64_t M);
 bool mm_takes_gemm_any(const ggml_tensor * n);
-void op_mul_mat(exec_state & s, const ggml_tensor * dst, const ggml_tensor * out = nullptr, const float * bias = nullptr, const mm_sibling * sib = nullptr, int nsib = 0, bool * sib_taken = nullptr);
+void op_mul_mat(exec_state & s, const ggml_tensor * dst, const ggml_tensor * out = nullptr, const float * bias = nullptr, const mm_sibling * sib = nullptr, int nsib = 0, bool * sib_taken = nullptr, int act = 0);
 bool plain_kq_matvec(const ggml_tensor * n, int max_cols);
 bool kq_mm_ok(const ggml_tensor * n);
 bool q80_mv1_node(exec_state & s, const ggml_tensor * n);

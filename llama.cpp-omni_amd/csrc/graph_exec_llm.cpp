@@ -350,6 +350,22 @@ void exec_mul_mat(exec_state & s, int i) {
                     sib[nsib] = { wc, Aj, (const float *) rj->data }; sib_mm[nsib] = j; sib_add[nsib] = aj; ++nsib;
                 }
                 bool taken = false;
+                // ... and the GELU behind that ADD (a DiT block's FFN: linear -> + bias -> GELU -> linear, token2wav-impl.cpp DiT feed-forward): the ADD's only reader, the next launch,
+                // same shape -- applied to the finished value in the same epilogue, with the element-wise kernel's arithmetic (act_dev.hpp op_gelu); the ADD's rows are never written
+                static const bool no_act = getenv("MI355X_NO_GEMM_ANY_ACT") != nullptr;
+                const int ui = no_act || nsib > 0 || is_out(s, A) ? -1 : sole_user(s, A);
+                if (ui > ai && next_real_node(s, ai) == ui && g->nodes[ui]->op == GGML_OP_UNARY && op_param_i32(g->nodes[ui], 0) == GGML_UNARY_OP_GELU && g->nodes[ui]->src[0] == A) {
+                    const ggml_tensor * U = g->nodes[ui];
+                    bool oku = U->type == GGML_TYPE_F32 && U->data;
+                    for (int d = 0; oku && d < 4; ++d) oku = U->ne[d] == A->ne[d] && U->nb[d] == A->nb[d];
+                    oku = oku && !overlap(range_of(U), range_of(n->src[0])) && !overlap(range_of(U), range_of(n->src[1])) && !overlap(range_of(U), range_of(r));
+                    if (oku) {
+                        op_mul_mat(s, n, U, (const float *) r->data, nullptr, 0, nullptr, 1);
+                        s.done[ai] = 1; s.done[ui] = 1; s.n_fused += 2;
+                        note_write(s, U);
+                        return;
+                    }
+                }
                 op_mul_mat(s, n, A, (const float *) r->data, sib, nsib, &taken);
                 s.done[ai] = 1; ++s.n_fused;
                 note_write(s, A);

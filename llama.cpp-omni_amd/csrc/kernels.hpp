@@ -346,6 +346,7 @@ struct gemm_any_args {
     int64_t M, N, K; int nbatch = 1, ne12 = 1, r2 = 1, r3 = 1;
     bool accumulate = false;                 // dst += W.X (the K tail behind a gemm_f16 launch over the first K - K % 64 columns)
     const float * bias = nullptr;            // dst[n][m] = W.X + bias[m]: the ADD of a [M] row vector that follows the mat-mul (one more f32 rounding, as the separate op)
+    int act = 0;                             // 1: GELU of the finished value (the UNARY node behind the bias ADD: a DiT block's FFN), same arithmetic as the element-wise kernel
     // optional, for small f32 x f32 products with a long K: split K over workgroups too; partial tiles go to `partial`, the last workgroup of a tile to arrive (ticket in
     // `counters`, zero between launches) folds them in split order.  Both belong to the calling backend context (one stream: launches do not overlap).
     float * partial = nullptr; size_t partial_bytes = 0; unsigned * counters = nullptr; int n_counters = 0;

@@ -11,6 +11,7 @@
 // through two padded LDS buffers (one barrier per step, the next step's global loads in flight under the MFMAs): these matrices are small --
 // the point is one launch instead of thousands, and a short per-workgroup latency chain.
 #include "../kernels.hpp"
+#include "act_dev.hpp"
 
 namespace mi {
 
@@ -21,6 +22,7 @@ struct gemm_any_dev {
     const char * X; size_t x_rs, x_nb2, x_nb3;
     char * dst; size_t dst_cs, dst_nb2, dst_nb3;
     const float * bias;
+    int act;                                             // 1: GELU (the reference's f16-table arithmetic, act_dev.hpp op_gelu) on the finished value, behind the bias
     int M, N, K, tiles_m, ne12, r2, r3, round_x, accumulate;      // round_x: 0 none, 1 activations rounded to f16, 2 to bf16 (and the 16-bit weights are bf16)
     float * partial; unsigned * counters; int ksplit;             // k_gemm_f32_sk128: K split over gridDim.z workgroups (1: none)
     const char * W_more[2]; char * dst_more[2]; const float * bias_more[2];     // k_gemm_f32_t16: matrices 1, 2 of a grouped launch (blockIdx.z)
@@ -84,7 +86,7 @@ __global__ void __launch_bounds__(256) k_gemm_any(const gemm_any_dev g) {
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
         const int n = n0 + wn * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh;
-        if (m < g.M && n < g.N) { float * p = (float *) (dst + (size_t) n * g.dst_cs + (size_t) m * 4); float v = g.accumulate ? *p + acc[e] : acc[e]; if (g.bias) v = __fadd_rn(v, g.bias[m]); *p = v; }
+        if (m < g.M && n < g.N) { float * p = (float *) (dst + (size_t) n * g.dst_cs + (size_t) m * 4); float v = g.accumulate ? *p + acc[e] : acc[e]; if (g.bias) v = __fadd_rn(v, g.bias[m]); if (g.act) v = op_gelu(v); *p = v; }
     }
 }
 
@@ -155,7 +157,7 @@ __global__ void __launch_bounds__(256) k_gemm_any_h(const gemm_any_dev g) {
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
         const int n = n0 + wn * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh;
-        if (m < g.M && n < g.N) { float * p = (float *) (dst + (size_t) n * g.dst_cs + (size_t) m * 4); float v = g.accumulate ? *p + acc[e] : acc[e]; if (g.bias) v = __fadd_rn(v, g.bias[m]); *p = v; }
+        if (m < g.M && n < g.N) { float * p = (float *) (dst + (size_t) n * g.dst_cs + (size_t) m * 4); float v = g.accumulate ? *p + acc[e] : acc[e]; if (g.bias) v = __fadd_rn(v, g.bias[m]); if (g.act) v = op_gelu(v); *p = v; }
     }
 }
 
@@ -227,7 +229,7 @@ __global__ void __launch_bounds__(256) k_gemm_any_sk(const gemm_any_dev g) {
         float v = acc[e];
 #pragma unroll
         for (int w = 0; w < 3; ++w) v += red[w][e * 64 + lane];
-        if (m < g.M && n < g.N) { float * p = (float *) (dst + (size_t) n * g.dst_cs + (size_t) m * 4); if (g.accumulate) v = *p + v; if (g.bias) v = __fadd_rn(v, g.bias[m]); *p = v; }
+        if (m < g.M && n < g.N) { float * p = (float *) (dst + (size_t) n * g.dst_cs + (size_t) m * 4); if (g.accumulate) v = *p + v; if (g.bias) v = __fadd_rn(v, g.bias[m]); if (g.act) v = op_gelu(v); *p = v; }
     }
 }
 
@@ -288,7 +290,7 @@ __global__ void __launch_bounds__(NW * 64) k_gemm_f32_rows(const gemm_any_dev g)
         float v = acc[e];
 #pragma unroll
         for (int w = 0; w < NW - 1; ++w) v += red[w][e * 64 + lane];
-        if (m < g.M && n < g.N) { float * p = (float *) (dst + (size_t) n * g.dst_cs + (size_t) m * 4); if (g.accumulate) v = *p + v; if (g.bias) v = __fadd_rn(v, g.bias[m]); *p = v; }
+        if (m < g.M && n < g.N) { float * p = (float *) (dst + (size_t) n * g.dst_cs + (size_t) m * 4); if (g.accumulate) v = *p + v; if (g.bias) v = __fadd_rn(v, g.bias[m]); if (g.act) v = op_gelu(v); *p = v; }
     }
 }
 
@@ -388,7 +390,7 @@ __global__ void __launch_bounds__(256) k_gemm_f32_sk128(const gemm_any_dev g) {
     for (int e = 0; e < 16; ++e) {
         const int n = n0 + (e & 3) + 8 * (e >> 2) + 4 * kh;
         float r = v[e];
-        if (m < g.M && n < g.N) { float * p = (float *) (dst + (size_t) n * g.dst_cs + (size_t) m * 4); if (g.accumulate) r = *p + r; if (g.bias) r = __fadd_rn(r, g.bias[m]); *p = r; }
+        if (m < g.M && n < g.N) { float * p = (float *) (dst + (size_t) n * g.dst_cs + (size_t) m * 4); if (g.accumulate) r = *p + r; if (g.bias) r = __fadd_rn(r, g.bias[m]); if (g.act) r = op_gelu(r); *p = r; }
     }
 }
 
@@ -459,7 +461,7 @@ __global__ void __launch_bounds__(256) k_gemm_f32_t16(const gemm_any_dev g) {
         float v = acc[e];
 #pragma unroll
         for (int w = 0; w < 3; ++w) v += red[w * 256 + e * 64 + lane];
-        if (m < g.M && n < g.N) { float * p = (float *) (dst + (size_t) n * g.dst_cs + (size_t) m * 4); if (g.accumulate) v = *p + v; if (bias) v = __fadd_rn(v, bias[m]); *p = v; }
+        if (m < g.M && n < g.N) { float * p = (float *) (dst + (size_t) n * g.dst_cs + (size_t) m * 4); if (g.accumulate) v = *p + v; if (bias) v = __fadd_rn(v, bias[m]); if (g.act) v = op_gelu(v); *p = v; }
     }
 }
 
@@ -498,7 +500,7 @@ void gemm_any(const gemm_any_args & a, hipStream_t st) {
     g.X = (const char *) a.X; g.x_rs = a.x_rs; g.x_nb2 = a.x_nb2; g.x_nb3 = a.x_nb3;
     g.dst = (char *) a.dst; g.dst_cs = a.dst_cs; g.dst_nb2 = a.dst_nb2; g.dst_nb3 = a.dst_nb3;
     g.partial = nullptr; g.counters = nullptr; g.ksplit = 1;
-    g.M = (int) a.M; g.N = (int) a.N; g.K = (int) a.K; g.tiles_m = (int) ((a.M + 63) / 64); g.ne12 = a.ne12; g.r2 = a.r2; g.r3 = a.r3; g.round_x = a.w_bf16 ? 2 : (a.w_f16 ? 1 : 0); g.accumulate = a.accumulate ? 1 : 0; g.bias = a.bias;
+    g.M = (int) a.M; g.N = (int) a.N; g.K = (int) a.K; g.tiles_m = (int) ((a.M + 63) / 64); g.ne12 = a.ne12; g.r2 = a.r2; g.r3 = a.r3; g.round_x = a.w_bf16 ? 2 : (a.w_f16 ? 1 : 0); g.accumulate = a.accumulate ? 1 : 0; g.bias = a.bias; g.act = a.act;
     static const bool no_sk = getenv("MI355X_GEMM_ANY_NO_SPLIT") != nullptr;
     // (F16 weights have the f16 matrix cores below -- 8x the K per MFMA, paired loads: their chains are short without a split; measured on Whisper's
     //  V^T . P of a streaming chunk, 64 x 50 x 400 x 16 heads: 24 us here, 6 us there)
