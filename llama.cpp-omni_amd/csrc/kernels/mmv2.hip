@@ -54,7 +54,12 @@ __global__ void __launch_bounds__(64 * NW) k_mv2(const char * W0, const float * 
     // Q4_K launches at K = 4096: one super-block per lane (mv2_consume_q4k_b); mixed / Q6_K / Q8_0 launches: the sub-block-pair form.  (K = 12288: a group of 4 rows is 12 of
     // the ring's 29 slots and is released whole -- the loader stalls, ffn_down 7.6 -> 17.9 us; that launch is bound by its stream, not by the consumers' instructions.)
     constexpr bool BL = MV2_BLOCK_LANE && (TM & 1) != 0 && TM != 4 + 1 && NIT == 1;      // (a mixed launch: its Q4_K workgroups)
-    constexpr int GRB = BL ? (PAIR ? 2 : 4) : 1;
+#ifndef MV2_HALF_BLOCK
+#define MV2_HALF_BLOCK 1
+#endif
+    // one matrix of a few thousand rows at K = 4096 (wo: 16 rows per workgroup, ten waves): half a super-block per lane, two rows per wave step (mv2_consume_q4k_h)
+    constexpr bool HBL = MV2_HALF_BLOCK && BL && !PAIR && TM == 1 && (NW == 10 || (MV2_HALF_BLOCK > 1 && NW == 9));
+    constexpr int GRB = BL ? (PAIR || HBL ? 2 : 4) : 1;
     constexpr int C = NW - 1;
     constexpr int PW = 4 * NIT < C ? 4 * NIT : C;   // prologue waves
     typedef mv2_geo<2304, 1, NIT, XS> geo0;            // (IMG and STG do not depend on the weight type)
@@ -147,7 +152,8 @@ __global__ void __launch_bounds__(64 * NW) k_mv2(const char * W0, const float * 
         char * dst = R->m[mi_].dst;                        // (needed when the first results are stored)
         if constexpr (Q80) mv2_consume_q80<PAIR ? 2 : 1, NIT, C, PAIR, XS>(im, ringp, K, c, ntask, dst, G0 + c, resid, &F);
         else if (q4) {
-            if constexpr (BL) mv2_consume_q4k_b<NIT, C, PAIR, XS>(im, ringp, K, c, ntask, dst, G0, rstg, resid_p != nullptr, &F);
+            if constexpr (HBL) mv2_consume_q4k_h<NIT, C, XS>(im, ringp, K, c, ntask, dst, G0, rstg, resid_p != nullptr, &F);
+            else if constexpr (BL) mv2_consume_q4k_b<NIT, C, PAIR, XS>(im, ringp, K, c, ntask, dst, G0, rstg, resid_p != nullptr, &F);
             else mv2_consume_q4k<PAIR ? 2 : 1, NIT, C, PAIR, XS>(im, ringp, K, c, ntask, dst, G0 + c, resid, &F);
         }
         else if constexpr ((TM & 2) != 0 && !PAIR) mv2_consume_q6k<NIT, C, XS>(im, ringp, K, c, ntask, dst, G0 + c, resid, &F);

@@ -689,6 +689,76 @@ static __device__ __forceinline__ void mv2_consume_q4k_b(const char * im, const 
     }
 }
 
+// ================================================================================================= Q4_K consumer, HALF a super-block per lane (round 6)
+// mv2_consume_q4k_b keeps 4 rows x 16 blocks in a wave step: a workgroup's 16 rows of a 4096 x 4096 matrix (wo) are four such steps -- four of the nine consumers work for
+// 1.0 - 1.4 us (~300 dependent-ish instructions at one wave per SIMD) while five have nothing to do.  Here a lane takes (row r of TWO, half h of the block's eight sub-blocks,
+// block): eight wave steps of half the length for the same rows, one per consumer.  Same integers per sub-block; a block's two half sums are added after the 16-lane row sum
+// (v_permlane16_swap), i.e. the float order is (sum over blocks of half 0) + (sum over blocks of half 1).  Groups are TWO rows (the loader's GR).
+template <int NIT, int C, int XS = 0>
+static __device__ __forceinline__ void mv2_consume_q4k_h(const char * im, const char * ringp, int K, int c, int ntask, char * dst, int G0, const char * rstg, bool has_resid, mv2_flags * F) {
+    constexpr int GR = 2;
+    typedef mv2_geo<2304, 1, NIT, XS> geo;
+    constexpr int SLOTB = geo::SLOTB, NS = geo::NS;
+    const int lane = threadIdx.x & 63, nb = K >> 8;
+    const int blk = lane & 15, h = (lane >> 4) & 1, r = lane >> 5;
+    const int ng = (ntask + GR - 1) / GR;
+    uint32_t seen = 0;
+    int k = 0;
+    for (int g = c; g < ng; g += C, ++k) {
+        const int j = g * GR + r;
+        const bool valid = j < ntask;
+        const int jl = (g * GR + GR <= ntask ? g * GR + GR : ntask) - 1;
+        float accv = 0.0f, accm = 0.0f;
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            mv2_wait_step(__builtin_amdgcn_readfirstlane(jl * NIT + it), seen, F);
+            const int t = (valid ? j : jl) * NIT + it;
+            const int b0 = __builtin_amdgcn_readfirstlane((g * GR * NIT + it) % NS);
+            int slot = b0 + (t - (g * GR * NIT + it));
+            if (slot >= NS) slot -= NS;
+            const char * p = ringp + slot * SLOTB + blk * 144;
+            const u32x4 H = *(const u32x4 *) p;
+            u32x4 Q[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) Q[e] = *(const u32x4 *) (p + 16 + 64 * h + 16 * e);
+            const int ib = it * 16 + blk;
+            const char * la = im + ib * 272 + 128 * h;
+            u32x4 a[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) a[e] = *(const u32x4 *) (la + 16 * e);
+            const u32x2 bsv = *(const u32x2 *) (im + mv1_img_bs(nb) + ib * 16 + 8 * h);       // bsums of the half's four sub-blocks (int16)
+            const float yd = *(const float *) (im + mv1_img_d(nb) + ib * 4);
+            if (it == NIT - 1) { MV2_LGKM0(); mv2_poke(MV2_FLAG(F->consumed[c]), (uint32_t) (k + 1)); }
+            // 6-bit scales / mins of this half's four sub-blocks, one byte each (get_scale_min_k4, ggml-quants.c:703-710): half 0 = sub-blocks 0..3, half 1 = 4..7
+            const uint32_t sw = h ? ((H[3] & 0x0f0f0f0fu) | ((H[1] >> 2) & 0x30303030u)) : (H[1] & 0x3f3f3f3fu);
+            const uint32_t mw = h ? (((H[3] >> 4) & 0x0f0f0f0fu) | ((H[2] >> 2) & 0x30303030u)) : (H[2] & 0x3f3f3f3fu);
+            int isum = 0, msum = 0;
+#pragma unroll
+            for (int tj = 0; tj < 2; ++tj) {                  // 64 weights: low nibbles = sub-block 2 jg, high nibbles = sub-block 2 jg + 1 (jg = 2 h + tj)
+                int dl = 0, dh = 0;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    dl = dot4(Q[2 * tj][e] & 0x0f0f0f0fu, a[4 * tj][e], dl);         dh = dot4((Q[2 * tj][e] >> 4) & 0x0f0f0f0fu, a[4 * tj + 2][e], dh);
+                    dl = dot4(Q[2 * tj + 1][e] & 0x0f0f0f0fu, a[4 * tj + 1][e], dl); dh = dot4((Q[2 * tj + 1][e] >> 4) & 0x0f0f0f0fu, a[4 * tj + 3][e], dh);
+                }
+                const int sh = 16 * tj;
+                const int sc0 = (int) ((sw >> sh) & 0xffu), sc1 = (int) ((sw >> (sh + 8)) & 0xffu), mn0 = (int) ((mw >> sh) & 0xffu), mn1 = (int) ((mw >> (sh + 8)) & 0xffu);
+                const uint32_t bw = bsv[tj];
+                isum = mad24(sc0, dl, mad24(sc1, dh, isum));
+                msum = mad24(mn0, (int) (int16_t) (bw & 0xffff), mad24(mn1, (int) (int16_t) (bw >> 16), msum));
+            }
+            const float dx = h2f((uint16_t) (H[0] & 0xffff)), dmin = h2f((uint16_t) (H[0] >> 16));
+            accv = fmaf(dx * yd, (float) isum, accv);
+            accm = fmaf(dmin * yd, (float) msum, accm);
+        }
+        float v = accv - accm;
+        v += __uint_as_float(mv2_dpp_row<0xB1>(__float_as_uint(v))); v += __uint_as_float(mv2_dpp_row<0x4E>(__float_as_uint(v)));
+        v += __uint_as_float(mv2_dpp_row<0x141>(__float_as_uint(v))); v += __uint_as_float(mv2_dpp_row<0x140>(__float_as_uint(v)));       // the 16 blocks of this (row, half)
+        { const auto sw2 = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false); v = __uint_as_float((uint32_t) sw2[0]) + __uint_as_float((uint32_t) sw2[1]); }   // + the other half: DPP rows 0|1, 2|3
+        if (valid && blk == 0 && h == 0) *(float *) (dst + (size_t) (G0 + j) * 4) = v + (has_resid ? *(const float *) (rstg + j * 4) : 0.0f);
+    }
+}
+
 // ================================================================================================= Q6_K consumer
 // 210-B super-block {ql[128], qh[64], int8 scales[16], f16 d} (ggml-common.h:330-335), 2-byte aligned in the ring as in memory (hardware-
 // unaligned ds_read_b128).  FOUR lanes per super-block as in mmv1.hip mv1_q6k: lane (n, hf) owns l in [16hf, 16hf+16) of the 128-half n.
